@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Build recipe for oracle/_ref: the reference's own spectral-core Fortran, compiled in place.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is imported, linked or executed by the
+product (isca_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may touch it, and only as the checker / reported CPU baseline.
+
+What this does (our recipe, not the reference's mkmf/Makefile build system):
+  * scans the reference source tree where it lies (/root/reference/src) for Fortran modules,
+  * takes the dependency closure of the modules our harness (oracle/ref_harness.F90) uses,
+  * compiles exactly those files, unmodified, with AMD flang (-fdefault-real-8: every real is
+    fp64, as the reference's own templates do) in the reference's single-PE "nocomm" mpp mode
+    (no -Duse_libMPI) and without netCDF (no -Duse_netCDF),
+  * links the harness into oracle/_ref/ref_harness.x.
+Outputs go only to oracle/_ref/ (git-ignored; travels to the GPU box with gpurun).
+No reference source is copied into this repository.
+
+Link note: flang has no GNU `STAT` intrinsic, which mpp_io's file-size helper
+(src/shared/mpp/include/mpp_io_connect.inc:870) references as an external `stat_`.  That helper is
+never reached on this path (it is only used for `filesize='file'` opens), so the symbol is left
+unresolved at link time (-Wl,--unresolved-symbols=ignore-all); no stand-in is written.
+"""
+import os, re, subprocess, sys, hashlib, json
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("ISCA_REFERENCE", "/root/reference")
+SRC = os.path.join(REF, "src")
+OUT = os.path.join(HERE, "_ref")
+BLD = os.path.join(OUT, "build")
+FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
+CC = os.environ.get("CC", "gcc")
+
+SCAN_DIRS = ["shared", "atmos_spectral", "atmos_shared", "atmos_param/hs_forcing"]
+INCLUDES = ["shared/include", "shared/mpp/include", "shared/fms", "shared/fft",
+            "shared/drifters", "shared/mpp"]
+CPPDEFS = ["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"]
+FFLAGS = ["-cpp", "-O2", "-fdefault-real-8", "-fdefault-double-8"]
+
+mod_re = re.compile(r"^\s*module\s+(\w+)\s*$", re.I)
+use_re = re.compile(r"^\s*use\s*(?:,\s*\w+\s*::)?\s*(\w+)", re.I)
+prog_re = re.compile(r"^\s*program\s+\w+", re.I)
+
+
+def scan(path):
+    mods, uses, is_prog = set(), set(), False
+    depth_if = []  # crude: skip `#ifdef test_*` blocks that hold print-only test programs
+    with open(path, errors="replace") as f:
+        for line in f:
+            s = line.strip()
+            if s.startswith("#"):
+                m = re.match(r"#\s*ifdef\s+(\w+)", s)
+                if m:
+                    depth_if.append(m.group(1).lower().startswith("test_"))
+                elif re.match(r"#\s*if", s):
+                    depth_if.append(False)
+                elif re.match(r"#\s*endif", s) and depth_if:
+                    depth_if.pop()
+                continue
+            if any(depth_if):
+                continue
+            m = mod_re.match(line)
+            if m and m.group(1).lower() != "procedure":
+                mods.add(m.group(1).lower())
+            m = use_re.match(line)
+            if m:
+                uses.add(m.group(1).lower())
+            if prog_re.match(line):
+                is_prog = True
+    return mods, uses, is_prog
+
+
+def main():
+    if not os.path.isdir(SRC):
+        print("build_ref: reference tree not present (%s); keeping prebuilt oracle/_ref" % SRC)
+        return 0
+    os.makedirs(BLD, exist_ok=True)
+    files = {}
+    for d in SCAN_DIRS:
+        for root, _, names in os.walk(os.path.join(SRC, d)):
+            if "barotropic" in root or "shallow" in root:
+                continue
+            for n in names:
+                if n.endswith((".F90", ".f90")) and not n.startswith("test_"):
+                    p = os.path.join(root, n)
+                    files[p] = scan(p)
+    mod2file = {}
+    for p, (mods, _, is_prog) in files.items():
+        if is_prog and not mods:
+            continue
+        for m in mods:
+            mod2file.setdefault(m, p)
+    harness = os.path.join(HERE, "ref_harness.F90")
+    hm, hu, _ = scan(harness)
+    order, seen = [], set()
+
+    def visit(p, uses):
+        for u in sorted(uses):
+            q = mod2file.get(u)
+            if q and q not in seen:
+                seen.add(q)
+                visit(q, files[q][1])
+                order.append(q)
+
+    visit(harness, hu)
+    inc = sum((["-I", os.path.join(SRC, i)] for i in INCLUDES), []) + ["-I", BLD]
+    stamp_path = os.path.join(BLD, "stamps.json")
+    stamps = json.load(open(stamp_path)) if os.path.exists(stamp_path) else {}
+    objs = []
+    rebuilt_any = False
+    for p in order:
+        o = os.path.join(BLD, os.path.basename(p).rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        h = hashlib.sha1(open(p, "rb").read()).hexdigest()
+        if os.path.exists(o) and stamps.get(p) == h and not rebuilt_any:
+            continue
+        cmd = [FLANG] + FFLAGS + CPPDEFS + inc + ["-module-dir", BLD, "-c", p, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print("FAILED:", " ".join(cmd)); print(r.stderr[-4000:]); return 1
+        stamps[p] = h; rebuilt_any = True
+        json.dump(stamps, open(stamp_path, "w"))
+        print("compiled", os.path.relpath(p, SRC), flush=True)
+    # the reference's few C helpers used by mpp/memutils (compiled in place, unmodified)
+    cobjs = []
+    for c in ["shared/mpp/nsclock.c", "shared/mpp/threadloc.c", "shared/mpp/affinity.c",
+              "shared/memutils/memuse.c"]:
+        p = os.path.join(SRC, c)
+        o = os.path.join(BLD, os.path.basename(c)[:-2] + "_c.o")
+        if not os.path.exists(o):
+            r = subprocess.run([CC, "-O2", "-D__IFC", "-c", p, "-o", o], capture_output=True, text=True)
+            if r.returncode != 0:
+                print("C helper failed (skipped):", c, r.stderr[-500:])
+                continue
+        cobjs.append(o)
+    ho = os.path.join(BLD, "ref_harness.o")
+    cmd = [FLANG] + FFLAGS + CPPDEFS + inc + ["-module-dir", BLD, "-c", harness, "-o", ho]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print("FAILED harness:"); print(r.stderr[-6000:]); return 1
+    exe = os.path.join(OUT, "ref_harness.x")
+    cmd = [FLANG, "-o", exe, ho] + objs + cobjs + ["-Wl,--unresolved-symbols=ignore-all"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print("FAILED link:"); print(r.stderr[-6000:]); return 1
+    print("built", exe, "from", len(order), "reference Fortran files")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

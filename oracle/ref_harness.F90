@@ -1,0 +1,447 @@
+! oracle/ref_harness.F90 -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+!
+! Driver program (ours) that calls ONLY the public module API of the reference's spectral core,
+! compiled in place from /root/reference by oracle/build_ref.py, and dumps raw little-endian fp64
+! arrays (Fortran order) to the current directory.  It follows the call order of the reference's
+! per-step driver (src/atmos_spectral/driver/solo/atmosphere.F90:120-352, Held-Suarez branch) and
+! of its main program's initialisation (src/atmos_solo/atmos_model.F90:148-260); it does not call
+! the *_end routines because those write netCDF restarts (netCDF is absent in this image).
+!
+! Control: ./harness.nml (namelist &harness_nml) in the run directory, next to the reference's own
+! input.nml / field_table / diag_table.
+!   mode = 'run'     : cold start, nsteps steps; dumps ug,vg,tg,psg (+ re-derived spectral state)
+!                      after the steps listed in dump_steps; prints wall time per step.
+!   mode = 'kernels' : after init, reads in_*.bin written by oracle/make_golden.py and applies
+!                      individual public routines (transforms, spectral operators, implicit
+!                      correction, damping, pressure variables, vertical advection, hs_forcing).
+program ref_harness
+
+use constants_mod,         only: constants_init, pi
+use fms_mod,               only: fms_init
+use time_manager_mod,      only: time_type, set_time, set_calendar_type, NO_CALENDAR, operator(+)
+use field_manager_mod,     only: MODEL_ATMOS
+use tracer_manager_mod,    only: register_tracers, get_number_tracers
+use diag_manager_mod,      only: diag_manager_init
+use tracer_type_mod,       only: tracer_type
+use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics, get_num_levels, &
+                                 get_initial_fields, get_surf_geopotential, get_pk_bk, get_axis_id
+use transforms_mod,        only: get_grid_domain, get_spec_domain, get_deg_lon, get_deg_lat, &
+                                 get_grid_boundaries, get_sin_lat, get_wts_lat, &
+                                 trans_grid_to_spherical, trans_spherical_to_grid, &
+                                 vor_div_from_uv_grid, uv_grid_from_vor_div, horizontal_advection, &
+                                 compute_laplacian, compute_gradient_cos, compute_ucos_vcos, &
+                                 compute_vor_div, area_weighted_global_mean, &
+                                 compute_legendre, compute_gaussian, &
+                                 trans_spherical_to_fourier, trans_fourier_to_spherical, &
+                                 trans_grid_to_fourier, trans_fourier_to_grid, &
+                                 get_eigen_laplacian
+use press_and_geopot_mod,  only: compute_pressures_and_heights, pressure_variables, compute_geopotential
+use hs_forcing_mod,        only: hs_forcing_init, hs_forcing
+use implicit_mod,          only: implicit_correction
+use spectral_damping_mod,  only: compute_spectral_damping, compute_spectral_damping_vor, &
+                                 compute_spectral_damping_div
+use vert_advection_mod,    only: vert_advection, SECOND_CENTERED, ADVECTIVE_FORM
+use global_integral_mod,   only: mass_weighted_global_integral
+use leapfrog_mod,          only: leapfrog, leapfrog_2level_A, leapfrog_2level_B
+
+implicit none
+
+character(len=16) :: mode = 'run'
+integer :: nsteps = 1, dt_atmos = 600
+integer, dimension(64) :: dump_steps = -1
+logical :: dump_tables = .true.
+namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, dump_tables
+
+type(time_type) :: Time, Time_step, Time_next
+type(tracer_type), allocatable, dimension(:) :: tracer_attributes
+integer :: ntrace, ntprog, ntdiag, ntfamily, num_tracers, nhum
+logical :: dry_model
+integer :: is, ie, js, je, ms, me, ns, ne, num_levels, nlon, nlat
+integer :: previous, current, future, i, j, k, istep, unit, idump
+real    :: delta_t, dt_real
+integer(kind=8) :: c0, c1, crate
+real(kind=8) :: t_loop
+
+real, allocatable, dimension(:,:,:,:)   :: p_half, p_full, z_half, z_full, ug, vg, tg
+real, allocatable, dimension(:,:,:,:,:) :: grid_tracers
+real, allocatable, dimension(:,:,:)     :: psg, wg_full, dt_ug, dt_vg, dt_tg
+real, allocatable, dimension(:,:,:,:)   :: dt_tracers
+real, allocatable, dimension(:,:)       :: dt_psg, surf_geopotential
+real, allocatable, dimension(:)         :: deg_lon, deg_lat, rad_lonb, rad_latb, pk, bk, sin_lat, wts_lat
+real, allocatable, dimension(:,:)       :: rad_lon_2d, rad_lat_2d, rad_lonb_2d, rad_latb_2d
+
+open(newunit=unit, file='harness.nml', status='old', action='read')
+read(unit, nml=harness_nml)
+close(unit)
+
+! ---- initialisation, order of atmos_model.F90:148-350 -----------------------------------------
+call fms_init()
+call constants_init()
+call register_tracers(MODEL_ATMOS, ntrace, ntprog, ntdiag, ntfamily)
+call set_calendar_type(NO_CALENDAR)
+call diag_manager_init()
+Time      = set_time(0, 0)
+Time_step = set_time(dt_atmos, 0)
+dt_real   = real(dt_atmos)
+
+! ---- atmosphere_init, atmosphere.F90:151-266 ----------------------------------------------------
+call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
+allocate(tracer_attributes(num_tracers))
+call spectral_dynamics_init(Time, Time_step, tracer_attributes, dry_model, nhum)
+call get_grid_domain(is, ie, js, je)
+call get_spec_domain(ms, me, ns, ne)
+call get_num_levels(num_levels)
+nlon = ie-is+1; nlat = je-js+1
+
+allocate(p_half(is:ie,js:je,num_levels+1,2), z_half(is:ie,js:je,num_levels+1,2))
+allocate(p_full(is:ie,js:je,num_levels,2),   z_full(is:ie,js:je,num_levels,2))
+allocate(wg_full(is:ie,js:je,num_levels), psg(is:ie,js:je,2))
+allocate(ug(is:ie,js:je,num_levels,2), vg(is:ie,js:je,num_levels,2), tg(is:ie,js:je,num_levels,2))
+allocate(grid_tracers(is:ie,js:je,num_levels,2,num_tracers))
+allocate(dt_psg(is:ie,js:je), dt_ug(is:ie,js:je,num_levels), dt_vg(is:ie,js:je,num_levels))
+allocate(dt_tg(is:ie,js:je,num_levels), dt_tracers(is:ie,js:je,num_levels,num_tracers))
+allocate(deg_lon(is:ie), deg_lat(js:je), rad_lon_2d(is:ie,js:je), rad_lat_2d(is:ie,js:je))
+allocate(rad_lonb_2d(is:ie+1,js:je+1), rad_latb_2d(is:ie+1,js:je+1), rad_lonb(is:ie+1), rad_latb(js:je+1))
+allocate(surf_geopotential(is:ie,js:je), pk(num_levels+1), bk(num_levels+1), sin_lat(js:je), wts_lat(js:je))
+p_half=0.; z_half=0.; p_full=0.; z_full=0.; wg_full=0.; psg=0.; ug=0.; vg=0.; tg=0.; grid_tracers=0.
+dt_psg=0.; dt_ug=0.; dt_vg=0.; dt_tg=0.; dt_tracers=0.
+
+call get_surf_geopotential(surf_geopotential)
+previous = 1; current = 1
+call get_initial_fields(ug(:,:,:,1), vg(:,:,:,1), tg(:,:,:,1), psg(:,:,1), grid_tracers(:,:,:,1,:))
+if(dry_model) then
+  call compute_pressures_and_heights(tg(:,:,:,current), psg(:,:,current), surf_geopotential, &
+       z_full(:,:,:,current), z_half(:,:,:,current), p_full(:,:,:,current), p_half(:,:,:,current))
+else
+  call compute_pressures_and_heights(tg(:,:,:,current), psg(:,:,current), surf_geopotential, &
+       z_full(:,:,:,current), z_half(:,:,:,current), p_full(:,:,:,current), p_half(:,:,:,current), &
+       grid_tracers(:,:,:,current,nhum))
+endif
+call get_deg_lon(deg_lon)
+do i=is,ie
+  rad_lon_2d(i,:) = deg_lon(i)*pi/180.
+enddo
+call get_deg_lat(deg_lat)
+do j=js,je
+  rad_lat_2d(:,j) = deg_lat(j)*pi/180.
+enddo
+call get_grid_boundaries(rad_lonb, rad_latb)
+do i=is,ie+1
+  rad_lonb_2d(i,:) = rad_lonb(i)
+enddo
+do j=js,je+1
+  rad_latb_2d(:,j) = rad_latb(j)
+enddo
+call hs_forcing_init(get_axis_id(), Time, rad_lonb_2d, rad_latb_2d, rad_lat_2d)
+
+call get_pk_bk(pk, bk)
+call get_sin_lat(sin_lat)
+call get_wts_lat(wts_lat)
+
+if(dump_tables) then
+  call dump1('tab_pk.bin', pk);          call dump1('tab_bk.bin', bk)
+  call dump1('tab_sin_lat.bin', sin_lat); call dump1('tab_wts_lat.bin', wts_lat)
+  call dump1('tab_deg_lat.bin', deg_lat); call dump1('tab_deg_lon.bin', deg_lon)
+  call dump1('tab_rad_latb.bin', rad_latb)
+  call dump_legendre()
+endif
+
+if(trim(mode) == 'run') then
+  call dump_state(0)
+  idump = 1
+  t_loop = 0.
+  call system_clock(count_rate=crate)
+  do istep = 1, nsteps
+    call system_clock(c0)
+    call one_step()
+    call system_clock(c1)
+    t_loop = t_loop + real(c1-c0,8)/real(crate,8)
+    if(any(dump_steps == istep)) call dump_state(istep)
+  enddo
+  write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
+  write(*,'(a,3es24.16)') 'REF_STATE Tmin,Tmax,maxabsU=', minval(tg(:,:,:,current)), maxval(tg(:,:,:,current)), maxval(abs(ug(:,:,:,current)))
+else if(trim(mode) == 'kernels') then
+  call run_kernels()
+else
+  write(*,*) 'unknown mode ', trim(mode)
+  stop 2
+endif
+
+contains
+
+!--------------------------------------------------------------------------------------------------
+subroutine one_step()
+! atmosphere.F90:286-349 (Held-Suarez branch), without spectral_diagnostics
+dt_ug = 0.0; dt_vg = 0.0; dt_tg = 0.0; dt_psg = 0.0; dt_tracers = 0.0
+if(current == previous) then
+  delta_t = dt_real
+else
+  delta_t = 2*dt_real
+endif
+Time_next = Time + Time_step
+call hs_forcing(1, ie-is+1, 1, je-js+1, delta_t, Time_next, rad_lon_2d, rad_lat_2d, &
+                p_half(:,:,:,current ),       p_full(:,:,:,current   ), &
+                    ug(:,:,:,previous),           vg(:,:,:,previous  ), &
+                    tg(:,:,:,previous), grid_tracers(:,:,:,previous,:), &
+                    ug(:,:,:,previous),           vg(:,:,:,previous  ), &
+                    tg(:,:,:,previous), grid_tracers(:,:,:,previous,:), &
+                 dt_ug(:,:,:         ),        dt_vg(:,:,:           ), &
+                 dt_tg(:,:,:         ),   dt_tracers(:,:,:,:), z_full(:,:,:,current))
+if(previous == current) then
+  future = 3 - current
+else
+  future = previous
+endif
+call spectral_dynamics(Time, psg(:,:,future), ug(:,:,:,future), vg(:,:,:,future), &
+                       tg(:,:,:,future), tracer_attributes, grid_tracers(:,:,:,:,:), future, &
+                       dt_psg, dt_ug, dt_vg, dt_tg, dt_tracers, wg_full, &
+                       p_full(:,:,:,current), p_half(:,:,:,current), z_full(:,:,:,current))
+if(dry_model) then
+  call compute_pressures_and_heights(tg(:,:,:,future), psg(:,:,future), surf_geopotential, &
+       z_full(:,:,:,future), z_half(:,:,:,future), p_full(:,:,:,future), p_half(:,:,:,future))
+else
+  call compute_pressures_and_heights(tg(:,:,:,future), psg(:,:,future), surf_geopotential, &
+       z_full(:,:,:,future), z_half(:,:,:,future), p_full(:,:,:,future), p_half(:,:,:,future), &
+       grid_tracers(:,:,:,future,nhum))
+endif
+previous = current
+current  = future
+Time = Time_next
+end subroutine one_step
+
+!--------------------------------------------------------------------------------------------------
+subroutine dump_state(n)
+integer, intent(in) :: n
+character(len=8) :: tag
+complex, allocatable, dimension(:,:,:) :: vors, divs, ts
+complex, allocatable, dimension(:,:)   :: lnps
+real,    allocatable, dimension(:,:)   :: lnpsg
+write(tag,'(i6.6)') n
+call dump3('st_ug_'//trim(tag)//'.bin', ug(:,:,:,current))
+call dump3('st_vg_'//trim(tag)//'.bin', vg(:,:,:,current))
+call dump3('st_tg_'//trim(tag)//'.bin', tg(:,:,:,current))
+call dump2('st_psg_'//trim(tag)//'.bin', psg(:,:,current))
+call dump3('st_wg_full_'//trim(tag)//'.bin', wg_full)
+call dump3('st_p_full_'//trim(tag)//'.bin', p_full(:,:,:,current))
+call dump3('st_z_full_'//trim(tag)//'.bin', z_full(:,:,:,current))
+if(num_tracers > 0) call dump3('st_tr1_'//trim(tag)//'.bin', grid_tracers(:,:,:,current,1))
+! spectral state re-derived through the public API (the module-private arrays have no getter)
+allocate(vors(ms:me,ns:ne,num_levels), divs(ms:me,ns:ne,num_levels), ts(ms:me,ns:ne,num_levels))
+allocate(lnps(ms:me,ns:ne), lnpsg(is:ie,js:je))
+call vor_div_from_uv_grid(ug(:,:,:,current), vg(:,:,:,current), vors, divs)
+call trans_grid_to_spherical(tg(:,:,:,current), ts)
+lnpsg = log(psg(:,:,current))
+call trans_grid_to_spherical(lnpsg, lnps)
+call dumpc3('st_vors_'//trim(tag)//'.bin', vors)
+call dumpc3('st_divs_'//trim(tag)//'.bin', divs)
+call dumpc3('st_ts_'//trim(tag)//'.bin', ts)
+call dumpc2('st_lnps_'//trim(tag)//'.bin', lnps)
+deallocate(vors, divs, ts, lnps, lnpsg)
+end subroutine dump_state
+
+!--------------------------------------------------------------------------------------------------
+subroutine dump_legendre()
+integer :: nhem, nf, nsph
+real, allocatable :: sin_hem(:), wts_hem(:), leg(:,:,:), eig(:,:)
+nhem = nlat/2; nf = me-ms; nsph = ne-ns
+allocate(sin_hem(nhem), wts_hem(nhem), leg(0:nf,0:nsph,nhem), eig(0:nf,0:nsph))
+call compute_gaussian(sin_hem, wts_hem, nhem)
+call compute_legendre(leg, nf, 1, nsph, sin_hem, nhem)
+call get_eigen_laplacian(eig)
+call dump1('tab_sin_hem.bin', sin_hem)
+call dump1('tab_wts_hem.bin', wts_hem)
+call dump3('tab_legendre.bin', leg)
+call dump2('tab_eigen_laplacian.bin', eig)
+end subroutine dump_legendre
+
+!--------------------------------------------------------------------------------------------------
+subroutine run_kernels()
+! Each block reads inputs written by oracle/make_golden.py and applies one public routine.
+complex, allocatable, dimension(:,:,:) :: sa, sb, sc, sd
+complex, allocatable, dimension(:,:)   :: s2a, s2b
+complex, allocatable, dimension(:,:,:,:) :: s4a, s4b
+complex, allocatable, dimension(:,:,:) :: s3lnps
+real,    allocatable, dimension(:,:,:) :: ga, gb, gc, gd, ge, w, dp
+real,    allocatable, dimension(:,:,:,:) :: tr4, trdt
+real,    allocatable, dimension(:,:)   :: g2a
+complex, allocatable, dimension(:,:,:,:) :: fs
+complex, allocatable, dimension(:,:,:)   :: fg
+integer :: kk
+real :: dtk, gm
+
+kk = num_levels
+allocate(sa(ms:me,ns:ne,kk), sb(ms:me,ns:ne,kk), sc(ms:me,ns:ne,kk), sd(ms:me,ns:ne,kk))
+allocate(ga(is:ie,js:je,kk), gb(is:ie,js:je,kk), gc(is:ie,js:je,kk), gd(is:ie,js:je,kk), ge(is:ie,js:je,kk))
+allocate(s2a(ms:me,ns:ne), s2b(ms:me,ns:ne), g2a(is:ie,js:je))
+
+! --- transforms ---
+call readc3('in_spec_a.bin', sa)
+call readc3('in_spec_b.bin', sb)
+call trans_spherical_to_grid(sa, ga)
+call dump3('out_s2g_a.bin', ga)
+call trans_grid_to_spherical(ga, sc)
+call dumpc3('out_g2s_s2g_a.bin', sc)
+call read3('in_grid_a.bin', ga)
+call read3('in_grid_b.bin', gb)
+call trans_grid_to_spherical(ga, sc)
+call dumpc3('out_g2s_a.bin', sc)
+call trans_grid_to_spherical(ga, sc, do_truncation=.false.)
+call dumpc3('out_g2s_a_notrunc.bin', sc)
+! Legendre / Fourier stages separately
+allocate(fs(ms:me, nlat, kk, 1), fg(0:nlon/2, nlat, kk))
+call trans_spherical_to_fourier(sa, fs)
+call dumpc3('out_s2f_a.bin', fs(:,:,:,1))
+fg = trans_grid_to_fourier(ga)
+call dumpc3('out_g2f_a.bin', fg)
+! --- vor/div <-> u,v ---
+call vor_div_from_uv_grid(ga, gb, sc, sd)
+call dumpc3('out_vor_from_uv.bin', sc)
+call dumpc3('out_div_from_uv.bin', sd)
+call uv_grid_from_vor_div(sa, sb, gc, gd)
+call dump3('out_u_from_vd.bin', gc)
+call dump3('out_v_from_vd.bin', gd)
+! --- spectral operators ---
+sc = compute_laplacian(sa)
+call dumpc3('out_laplacian_a.bin', sc)
+call compute_gradient_cos(sa, sc, sd)
+call dumpc3('out_gradcos_dx_a.bin', sc)
+call dumpc3('out_gradcos_dy_a.bin', sd)
+call compute_ucos_vcos(sa, sb, sc, sd)
+call dumpc3('out_ucos.bin', sc)
+call dumpc3('out_vcos.bin', sd)
+call compute_vor_div(sa, sb, sc, sd)
+call dumpc3('out_vor_from_ucos.bin', sc)
+call dumpc3('out_div_from_ucos.bin', sd)
+! --- horizontal advection: tendency(inout) -= u dT/dx + v dT/dy ---
+gc = 0.
+call horizontal_advection(sa, ga, gb, gc)
+call dump3('out_hadv.bin', gc)
+! --- global means ---
+gm = area_weighted_global_mean(ga(:,:,1))
+call dump1('out_gmean.bin', (/gm/))
+call read2('in_ps.bin', g2a)
+gm = mass_weighted_global_integral(ga, g2a)
+call dump1('out_mwgi.bin', (/gm/))
+! --- pressure variables / geopotential (press_and_geopot.F90) ---
+allocate(w(is:ie,js:je,kk+1), dp(is:ie,js:je,kk+1))
+call pressure_variables(w, dp, gc, gd, g2a)     ! p_half, ln_p_half, p_full, ln_p_full
+call dump3('out_p_half.bin', w);   call dump3('out_ln_p_half.bin', dp)
+call dump3('out_p_full.bin', gc);  call dump3('out_ln_p_full.bin', gd)
+call read3('in_temp.bin', ge)
+deallocate(w); allocate(w(is:ie,js:je,kk+1))
+call compute_geopotential(ge, dp, gd, surf_geopotential, gc, w)
+call dump3('out_geopot_full.bin', gc); call dump3('out_geopot_half.bin', w)
+! --- hs_forcing on (u=ga, v=gb, T=ge) with pressures from in_ps ---
+call pressure_variables(w, dp, gc, gd, g2a)
+allocate(tr4(is:ie,js:je,kk,num_tracers), trdt(is:ie,js:je,kk,num_tracers))
+tr4 = 0.; trdt = 0.
+dt_ug = 0.; dt_vg = 0.; dt_tg = 0.
+dtk = 2*dt_real
+call hs_forcing(1, nlon, 1, nlat, dtk, Time, rad_lon_2d, rad_lat_2d, w, gc, ga, gb, ge, tr4, &
+                ga, gb, ge, tr4, dt_ug, dt_vg, dt_tg, trdt, gd)
+call dump3('out_hs_dt_u.bin', dt_ug); call dump3('out_hs_dt_v.bin', dt_vg); call dump3('out_hs_dt_t.bin', dt_tg)
+if(num_tracers > 0) call dump3('out_hs_dt_tr.bin', trdt(:,:,:,1))
+! --- vertical advection, second centred / advective form (vert_advection.F90:185-193,467-470) ---
+call read3('in_wg.bin', w)      ! (lon,lat,kk+1)
+do k=1,kk
+  dp(:,:,k) = (pk(k+1)-pk(k)) + (bk(k+1)-bk(k))*g2a
+enddo
+call vert_advection(dtk, w, dp(:,:,1:kk), ge, gc, scheme=SECOND_CENTERED, form=ADVECTIVE_FORM)
+call dump3('out_vadv.bin', gc)
+! --- implicit correction (implicit.F90:241-286) ---
+allocate(s4a(ms:me,ns:ne,kk,2), s4b(ms:me,ns:ne,kk,2), s3lnps(ms:me,ns:ne,2))
+call readc3('in_spec_a.bin', s4a(:,:,:,1)); call readc3('in_spec_b.bin', s4a(:,:,:,2))
+call readc3('in_spec_c.bin', s4b(:,:,:,1)); call readc3('in_spec_d.bin', s4b(:,:,:,2))
+call readc2('in_spec2_a.bin', s3lnps(:,:,1)); call readc2('in_spec2_b.bin', s3lnps(:,:,2))
+call readc3('in_spec_e.bin', sc); call readc3('in_spec_f.bin', sd); call readc2('in_spec2_c.bin', s2a)
+call implicit_correction(sc, sd, s2a, s4a, s4b, s3lnps, dtk, 1, 2)
+call dumpc3('out_impl_dt_divs.bin', sc); call dumpc3('out_impl_dt_ts.bin', sd); call dumpc2('out_impl_dt_lnps.bin', s2a)
+! --- spectral damping (spectral_damping.F90:172-291) ---
+call readc3('in_spec_e.bin', sc)
+call compute_spectral_damping_vor(sa, sc, dtk); call dumpc3('out_damp_vor.bin', sc)
+call readc3('in_spec_e.bin', sc)
+call compute_spectral_damping_div(sa, sc, dtk); call dumpc3('out_damp_div.bin', sc)
+call readc3('in_spec_e.bin', sc)
+call compute_spectral_damping(sa, sc, dtk);     call dumpc3('out_damp.bin', sc)
+! --- leapfrog + Robert filter (leapfrog.F90:58-105) ---
+call readc3('in_spec_e.bin', sc)
+call leapfrog_2level_A(s4a, sc, 1, 2, 1, dtk, 0.04, 1.0, sd)
+call leapfrog_2level_B(s4a, sd, 2, 1, 0.04, 1.0)
+call dumpc3('out_leap_l1.bin', s4a(:,:,:,1)); call dumpc3('out_leap_l2.bin', s4a(:,:,:,2))
+end subroutine run_kernels
+
+!--------------------------------------------------------------------------------------------------
+subroutine dump1(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump1
+subroutine dump2(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump2
+subroutine dump3(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump3
+subroutine dumpc2(name, a)
+character(len=*), intent(in) :: name
+complex, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dumpc2
+subroutine dumpc3(name, a)
+character(len=*), intent(in) :: name
+complex, intent(in) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dumpc3
+subroutine read2(name, a)
+character(len=*), intent(in) :: name
+real, intent(out) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='old')
+read(u) a
+close(u)
+end subroutine read2
+subroutine read3(name, a)
+character(len=*), intent(in) :: name
+real, intent(out) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='old')
+read(u) a
+close(u)
+end subroutine read3
+subroutine readc2(name, a)
+character(len=*), intent(in) :: name
+complex, intent(out) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='old')
+read(u) a
+close(u)
+end subroutine readc2
+subroutine readc3(name, a)
+character(len=*), intent(in) :: name
+complex, intent(out) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='old')
+read(u) a
+close(u)
+end subroutine readc3
+
+end program ref_harness
