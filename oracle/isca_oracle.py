@@ -1,0 +1,744 @@
+"""CPU restatement (numpy, fp64) of the reference's spectral dynamical-core hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module, and only as the checker.  The product (isca_amd/) never imports it.
+
+Pinned against the reference itself: oracle/make_golden.py runs oracle/_ref/ref_harness.x (the
+reference's own Fortran, compiled in place by oracle/build_ref.py) and commits its outputs as
+tests/golden/*.npz; tests/test_oracle_vs_golden.py checks every function here against them.
+
+Array conventions.  The reference is Fortran column-major: grid (lon, lat, lev), spectral
+(m, n, lev) with n the meridional index (total wavenumber = m + n).  Here arrays are the SAME
+memory viewed by numpy in C order, i.e. grid[lev, lat, lon] and spec[lev, n, m]; 2-D fields drop
+the lev axis.  Latitudes run south to north.  All citations are relative to /root/reference/src.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# constants: shared/constants/constants.F90:83-86,250-254
+RADIUS = 6376.0e3
+OMEGA = 7.2921150e-5
+GRAV = 9.80
+RDGAS = 287.04
+KAPPA = 2.0 / 7.0
+CP_AIR = RDGAS / KAPPA
+PI = 3.14159265358979323846
+
+
+@dataclass
+class Config:
+    """Namelist keys actually used on the path (spectral_dynamics.F90:152-224, hs_forcing.F90:76-122)."""
+    lon_max: int = 64
+    lat_max: int = 32
+    num_fourier: int = 21
+    num_spherical: int = 22
+    num_levels: int = 25
+    dt_atmos: float = 600.0
+    # spectral_dynamics_nml (values of exp/test_cases/held_suarez/held_suarez_test_case.py:45-98)
+    damping_order: int = 4
+    damping_coeff: float = 1.15740741e-4
+    damping_option: str = "resolution_dependent"
+    robert_coeff: float = 0.04
+    raw_filter_coeff: float = 1.0
+    alpha_implicit: float = 0.5
+    reference_sea_level_press: float = 1.0e5
+    scale_heights: float = 6.0
+    exponent: float = 7.5
+    surf_res: float = 0.5
+    vert_coord_option: str = "uneven_sigma"
+    do_mass_correction: bool = True
+    do_energy_correction: bool = True
+    do_water_correction: bool = True
+    water_correction_limit: float = 200.0e2
+    eddy_sponge_coeff: float = 0.0
+    zmu_sponge_coeff: float = 0.0
+    zmv_sponge_coeff: float = 0.0
+    initial_temperature: float = 264.0
+    valid_range_t: tuple = (100.0, 800.0)
+    initial_sphum: float = 0.0
+    num_tracers: int = 1          # the dry field_table carries one grid tracer (sphum)
+    # hs_forcing_nml
+    t_zero: float = 315.0
+    t_strat: float = 200.0
+    delh: float = 60.0
+    delv: float = 10.0
+    eps: float = 0.0
+    sigma_b: float = 0.7
+    ka: float = -40.0
+    ks: float = -4.0
+    kf: float = -1.0
+    do_conserve_energy: bool = True
+    trflux: float = 1.0e-5
+    trsink: float = -4.0
+    P00: float = 1.0e5
+
+    @staticmethod
+    def resolution(name: str, num_levels: int, **kw) -> "Config":
+        # src/extra/python/isca/experiment.py:29-57
+        table = {"T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43),
+                 "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
+        lon, lat, nf, ns = table[name]
+        return Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns,
+                      num_levels=num_levels, **kw)
+
+
+# --------------------------------------------------------------------------------------------
+# tables
+# --------------------------------------------------------------------------------------------
+def compute_gaussian(n_hem: int):
+    """atmos_spectral/tools/gauss_and_legendre.F90:111-183 (Newton iteration, pole-most first)."""
+    converg = 0.1 ** 15            # precision(real*8) = 15
+    n = 2 * n_hem
+    sin_hem = np.zeros(n_hem)
+    wts_hem = np.zeros(n_hem)
+    for i in range(1, n_hem + 1):
+        z = math.cos(PI * (i - 0.25) / (n + 0.5))
+        for _ in range(10):
+            p1, p2 = 1.0, 0.0
+            for j in range(1, n + 1):
+                p3 = p2
+                p2 = p1
+                p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j
+            pp = n * (z * p1 - p2) / (z * z - 1.0)
+            z1 = z
+            z = z1 - p1 / pp
+            if abs(z - z1) < converg:
+                break
+        else:
+            raise RuntimeError("abscissas failed to converge")
+        sin_hem[i - 1] = z
+        wts_hem[i - 1] = 2.0 / ((1.0 - z * z) * pp * pp)
+    return sin_hem, wts_hem
+
+
+def compute_legendre(num_fourier: int, num_spherical: int, sin_hem: np.ndarray):
+    """gauss_and_legendre.F90:47-108, fourier_inc=1.  Returns leg[j, n, m] (Fortran (m,n,j))."""
+    M1, N1 = num_fourier + 1, num_spherical + 1
+    m = np.arange(M1, dtype=np.float64)[None, :]
+    n = np.arange(N1, dtype=np.float64)[:, None]
+    l2 = (m + n) ** 2
+    m2 = m ** 2 + 0 * n
+    with np.errstate(invalid="ignore", divide="ignore"):
+        eps = np.sqrt((l2 - m2) / (4.0 * l2 - 1.0))          # eps[n, m]
+    leg = np.zeros((len(sin_hem), N1, M1))
+    b = np.zeros(M1)
+    for mm in range(1, M1):
+        b[mm] = math.sqrt(0.5 * (2.0 * mm + 1.0) / mm)
+    for j, s in enumerate(sin_hem):
+        c = math.sqrt(1 - s * s)
+        poly = np.zeros((N1, M1))
+        poly[0, 0] = math.sqrt(0.5)
+        for mm in range(1, M1):
+            poly[0, mm] = b[mm] * c * poly[0, mm - 1]
+        poly[1, :] = s * poly[0, :] / eps[1, :]
+        for nn in range(2, N1):
+            poly[nn, :] = (s * poly[nn - 1, :] - eps[nn - 1, :] * poly[nn - 2, :]) / eps[nn, :]
+        leg[j] = poly
+    return leg
+
+
+def compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent):
+    """atmos_spectral/init/vert_coordinate.F90:248-273 (zero_top=.true.); returns (pk, bk)."""
+    b = np.zeros(num_levels + 1)
+    s2 = 1.0 - surf_res
+    for k in range(1, num_levels + 1):
+        zeta = 1.0 - float(k - 1) / float(num_levels)
+        z = surf_res * zeta + s2 * (zeta ** exponent)
+        b[k - 1] = math.exp(-z * scale_heights)
+    b[num_levels] = 1.0
+    b[0] = 0.0
+    return np.zeros(num_levels + 1), b
+
+
+def invert_gauss_jordan(a):
+    """model/matrix_invert.F90:38-130 restated as a plain inverse (fp64, pivoted)."""
+    return np.linalg.inv(a)
+
+
+class SpectralCore:
+    """Tables + operators + the time step of spectral_dynamics_mod / atmosphere_mod (HS branch)."""
+
+    def __init__(self, cfg: Config):
+        self.cfg = c = cfg
+        self.I, self.J, self.L = c.lon_max, c.lat_max, c.num_levels
+        self.M1, self.N1 = c.num_fourier + 1, c.num_spherical + 1
+        I, J, M1, N1 = self.I, self.J, self.M1, self.N1
+        # --- Gaussian grid: spherical_fourier.F90:397-431 ---
+        self.sin_hem, self.wts_hem = compute_gaussian(J // 2)
+        self.sin_lat = np.concatenate([-self.sin_hem, self.sin_hem[::-1]])
+        self.wts_lat = np.concatenate([self.wts_hem, self.wts_hem[::-1]])
+        self.cos_lat = np.sqrt(1 - self.sin_lat * self.sin_lat)
+        self.cosm_lat = 1.0 / self.cos_lat
+        self.deg_lat = np.arcsin(self.sin_lat) * 180.0 / PI
+        self.deg_lon = np.arange(I) * 360.0 / I                       # grid_fourier.F90:109-118
+        self.rad_lat = self.deg_lat * PI / 180.0                      # atmosphere.F90:248-251
+        # --- Legendre: spherical_fourier.F90:376-394 ---
+        self.legendre = compute_legendre(c.num_fourier, c.num_spherical, self.sin_hem)   # [j,n,m]
+        self.legendre_wts = self.legendre * self.wts_hem[:, None, None]
+        # --- spherical.F90:137-216 ---
+        m = np.arange(M1, dtype=np.float64)[None, :] + 0 * np.arange(N1)[:, None]
+        n = np.arange(N1, dtype=np.float64)[:, None] + 0 * m
+        Lw = m + n
+        self.fourier_wave, self.spherical_wave = m, Lw
+        self.triangle_mask = np.where(Lw > c.num_spherical - 1, 0.0, 1.0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            eps = np.sqrt((Lw ** 2 - m ** 2) / (4.0 * Lw ** 2 - 1.0))
+            self.epsilon = eps
+            self.eigen_laplacian = Lw * (Lw + 1.0) / (RADIUS * RADIUS)
+            self.coef_uvm = np.where(Lw > 0, -RADIUS * eps / np.where(Lw > 0, Lw, 1), 0.0)
+            self.coef_uvc = np.where(Lw > 0, -RADIUS * m / np.where(Lw > 0, Lw * (Lw + 1.0), 1), 0.0)
+        z = np.zeros((N1, M1))
+        self.coef_uvp = z.copy(); self.coef_alpp = z.copy(); self.coef_dyp = z.copy()
+        self.coef_uvp[:-1] = -RADIUS * eps[1:] / (Lw[:-1] + 1.0)
+        self.coef_alpm = (Lw + 1.0) * eps / RADIUS
+        self.coef_alpp[:-1] = Lw[:-1] * eps[1:] / RADIUS
+        self.coef_dym = (Lw - 1.0) * eps / RADIUS
+        self.coef_dx = m / RADIUS
+        self.coef_dyp[:-1] = (Lw[:-1] + 2.0) * eps[1:] / RADIUS
+        # --- vertical coordinate + derived (spectral_dynamics.F90:456-462) ---
+        if c.vert_coord_option != "uneven_sigma":
+            raise NotImplementedError(c.vert_coord_option)
+        self.pk, self.bk = compute_uneven_sigma(self.L, c.scale_heights, c.surf_res, c.exponent)
+        self.dpk = self.pk[1:] - self.pk[:-1]
+        self.dbk = self.bk[1:] - self.bk[:-1]
+        self.coriolis = 2 * OMEGA * self.sin_lat                      # spectral_dynamics.F90:445
+        # --- damping: spectral_damping.F90:124-156 ---
+        eig = self.eigen_laplacian
+        if c.damping_option != "resolution_dependent":
+            raise NotImplementedError(c.damping_option)
+        ref = eig[c.num_spherical - 1, 0]
+        self.damping = c.damping_coeff * ((eig / ref) ** c.damping_order)
+        self.damping_vor = self.damping.copy()
+        self.damping_div = self.damping.copy()
+        self.damping_eddy_sponge = c.eddy_sponge_coeff * eig
+        self.damping_zmu_sponge = c.zmu_sponge_coeff * eig[:, 0]
+        self.damping_zmv_sponge = c.zmv_sponge_coeff * eig[:, 0]
+        # --- implicit: implicit.F90:79-217 ---
+        self._implicit_init()
+        self._wave_dt = None
+        # --- HS constants: hs_forcing.F90:391-410 ---
+        self.tka = -1.0 / (86400 * c.ka) if c.ka < 0 else c.ka
+        self.tks = -1.0 / (86400 * c.ks) if c.ks < 0 else c.ks
+        self.vkf = -1.0 / (86400 * c.kf) if c.kf < 0 else c.kf
+        self.trsink = -86400.0 * c.trsink if c.trsink < 0 else c.trsink
+        self.surf_geopotential = np.zeros((J, I))
+        self.step_count = 0
+
+    # ----------------------------------------------------------------------------------------
+    # transforms (tools/transforms.F90:379-533, spherical_fourier.F90:177-339, grid_fourier.F90)
+    # ----------------------------------------------------------------------------------------
+    def spherical_to_fourier(self, s):
+        """spherical_fourier.F90:214-258.  s[...,n,m] -> f[...,j,m] (all J latitudes, S->N)."""
+        P = self.legendre
+        xe = np.einsum("...nm,jnm->...jm", s[..., 0::2, :], P[:, 0::2, :])
+        xo = np.einsum("...nm,jnm->...jm", s[..., 1::2, :], P[:, 1::2, :])
+        south = xe - xo            # row j  (southern hemisphere, pole-most first)
+        north = xe + xo            # row J+1-j
+        return np.concatenate([south, north[..., ::-1, :]], axis=-2)
+
+    def fourier_to_spherical(self, f):
+        """spherical_fourier.F90:300-336.  f[...,j,m] -> s[...,n,m] (full rectangle)."""
+        Jh = self.J // 2
+        fs = f[..., :Jh, :]
+        fn = f[..., ::-1, :][..., :Jh, :]
+        xe = fn + fs
+        xo = fn - fs
+        W = self.legendre_wts
+        s = np.zeros(f.shape[:-2] + (self.N1, self.M1), dtype=np.complex128)
+        s[..., 0::2, :] = np.einsum("...jm,jnm->...nm", xe, W[:, 0::2, :])
+        s[..., 1::2, :] = np.einsum("...jm,jnm->...nm", xo, W[:, 1::2, :])
+        return s
+
+    def grid_to_fourier(self, g):
+        """grid_fourier.F90:129-152 + fft.F90:578-586: c(k) = (1/I) sum_j x(j) exp(-2 pi i jk/I)."""
+        return np.fft.rfft(g, axis=-1) / self.I          # [..., 0:I/2+1]
+
+    def fourier_to_grid(self, f):
+        """grid_fourier.F90:155-179: x(j) = sum_k c(k) exp(+2 pi i jk/I), Hermitian symmetry."""
+        return np.fft.irfft(f, n=self.I, axis=-1) * self.I
+
+    def trans_spherical_to_grid(self, s):
+        f = self.spherical_to_fourier(s)
+        full = np.zeros(f.shape[:-1] + (self.I // 2 + 1,), dtype=np.complex128)
+        full[..., : self.M1] = f                       # transforms.F90:424 zero above trunc_fourier
+        return self.fourier_to_grid(full)
+
+    def trans_grid_to_spherical(self, g, do_truncation=True):
+        f = self.grid_to_fourier(g)[..., : self.M1]
+        s = self.fourier_to_spherical(f)
+        if do_truncation:
+            s = s * self.triangle_mask               # spherical.F90:579-581
+        return s
+
+    # ----------------------------------------------------------------------------------------
+    # spectral operators (tools/spherical.F90:270-600)
+    # ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _i_times(x):
+        return 1j * x         # cmplx(-aimag, real)
+
+    def compute_lon_deriv_cos(self, s):
+        return self.coef_dx * self._i_times(s)
+
+    def compute_lat_deriv_cos(self, s):
+        d = np.zeros_like(s)
+        d[..., 1:, :] = -s[..., :-1, :] * self.coef_dym[1:]
+        d[..., :-1, :] += s[..., 1:, :] * self.coef_dyp[:-1]
+        return d
+
+    def compute_gradient_cos(self, s):
+        return self.compute_lon_deriv_cos(s), self.compute_lat_deriv_cos(s)
+
+    def compute_laplacian(self, s):
+        return s * (-self.eigen_laplacian)
+
+    def compute_ucos_vcos(self, vor, div):
+        u = self.coef_uvc * self._i_times(div)
+        v = self.coef_uvc * self._i_times(vor)
+        u[..., 1:, :] += self.coef_uvm[1:] * vor[..., :-1, :]
+        v[..., 1:, :] -= self.coef_uvm[1:] * div[..., :-1, :]
+        u[..., :-1, :] -= self.coef_uvp[:-1] * vor[..., 1:, :]
+        v[..., :-1, :] += self.coef_uvp[:-1] * div[..., 1:, :]
+        return u, v
+
+    def compute_alpha_operator(self, a, b, isign):
+        al = self.coef_dx * self._i_times(a)
+        al[..., 1:, :] -= isign * self.coef_alpm[1:] * b[..., :-1, :]
+        al[..., :-1, :] += isign * self.coef_alpp[:-1] * b[..., 1:, :]
+        return al
+
+    def compute_vor_div(self, ucos, vcos):
+        return self.compute_alpha_operator(vcos, ucos, -1), self.compute_alpha_operator(ucos, vcos, +1)
+
+    def divide_by_cos(self, g):
+        return g * self.cosm_lat[:, None]
+
+    def uv_grid_from_vor_div(self, vor, div):
+        """transforms.F90:700-719."""
+        us, vs = self.compute_ucos_vcos(vor, div)
+        return (self.divide_by_cos(self.trans_spherical_to_grid(us)),
+                self.divide_by_cos(self.trans_spherical_to_grid(vs)))
+
+    def vor_div_from_uv_grid(self, u, v):
+        """transforms.F90:742-783 (triang=.true.)."""
+        dx = self.trans_grid_to_spherical(self.divide_by_cos(u), do_truncation=False)
+        dy = self.trans_grid_to_spherical(self.divide_by_cos(v), do_truncation=False)
+        vor, div = self.compute_vor_div(dx, dy)
+        return vor * self.triangle_mask, div * self.triangle_mask
+
+    def horizontal_advection(self, field_spec, u, v, tendency):
+        """transforms.F90:808-831."""
+        dx, dy = self.compute_gradient_cos(field_spec)
+        dxg = self.divide_by_cos(self.trans_spherical_to_grid(dx))
+        dyg = self.divide_by_cos(self.trans_spherical_to_grid(dy))
+        return tendency - u * dxg - v * dyg
+
+    def area_weighted_global_mean(self, field2d):
+        """transforms.F90:1059-1077."""
+        return float(np.sum(self.wts_lat[:, None] * field2d) / (np.sum(self.wts_lat) * self.I))
+
+    def mass_weighted_global_integral(self, field, ps):
+        """model/global_integral.F90:49-81."""
+        p_half = self.pk[:, None, None] + self.bk[:, None, None] * ps
+        dp = p_half[1:] - p_half[:-1]
+        return self.area_weighted_global_mean(np.sum(field * dp, axis=0)) / GRAV
+
+    # ----------------------------------------------------------------------------------------
+    # column routines
+    # ----------------------------------------------------------------------------------------
+    def pressure_variables(self, ps):
+        """model/press_and_geopot.F90:152-221 (simmons_and_burridge, pk(1)=bk(1)=0 branch too)."""
+        ps = np.asarray(ps, dtype=np.float64)
+        sh = (self.L + 1,) + ps.shape
+        p_half = self.pk.reshape((-1,) + (1,) * ps.ndim) + self.bk.reshape((-1,) + (1,) * ps.ndim) * ps
+        ln_p_half = np.zeros(sh)
+        ln_p_full = np.zeros((self.L,) + ps.shape)
+        if self.pk[0] == 0.0 and self.bk[0] == 0.0:
+            ln_p_half[1:] = np.log(p_half[1:])
+            for k in range(1, self.L):
+                alpha = 1.0 - p_half[k] * (ln_p_half[k + 1] - ln_p_half[k]) / (p_half[k + 1] - p_half[k])
+                ln_p_full[k] = ln_p_half[k + 1] - alpha
+            ln_p_full[0] = ln_p_half[1] - 1.0
+            ln_p_half[0] = 0.0
+        else:
+            ln_p_half[:] = np.log(p_half)
+            for k in range(self.L):
+                alpha = 1.0 - p_half[k] * (ln_p_half[k + 1] - ln_p_half[k]) / (p_half[k + 1] - p_half[k])
+                ln_p_full[k] = ln_p_half[k + 1] - alpha
+        p_full = np.exp(ln_p_full)
+        return p_half, ln_p_half, p_full, ln_p_full
+
+    def compute_geopotential(self, t, ln_p_half, ln_p_full):
+        """press_and_geopot.F90:314-359 (dry: virtual_t = t)."""
+        L = self.L
+        gh = np.zeros((L + 1,) + t.shape[1:])
+        gh[L] = self.surf_geopotential if t.ndim == 3 else 0.0
+        ktop = 1 if self.pk[0] == 0.0 else 0
+        for k in range(L - 1, ktop - 1, -1):
+            gh[k] = gh[k + 1] + RDGAS * t[k] * (ln_p_half[k + 1] - ln_p_half[k])
+        gf = gh[1:] + RDGAS * t * (ln_p_half[1:] - ln_p_full)
+        return gf, gh
+
+    def compute_pressures_and_heights(self, t, ps):
+        """press_and_geopot.F90:363-387."""
+        p_half, ln_p_half, p_full, ln_p_full = self.pressure_variables(ps)
+        zf, zh = self.compute_geopotential(t, ln_p_half, ln_p_full)
+        return zf / GRAV, zh / GRAV, p_full, p_half
+
+    def four_in_one(self, divg, u, v, t, ps, ln_p_half, ln_p_full, p_full, dx_ps, dy_ps,
+                    dt_ps, dt_t, dt_u, dt_v):
+        """spectral_dynamics.F90:1038-1112 (simmons_and_burridge).  Returns updated tendencies + wg."""
+        L = self.L
+        dmean_tot = np.zeros_like(ps)
+        wg = np.zeros((L + 1,) + ps.shape)
+        wg_full = np.zeros((L,) + ps.shape)
+        dt_t = dt_t.copy(); dt_u = dt_u.copy(); dt_v = dt_v.copy()
+        for k in range(L):
+            dp = self.dpk[k] + self.dbk[k] * ps
+            dp_inv = 1 / dp
+            dlog_1 = ln_p_half[k + 1] - ln_p_full[k]
+            dlog_2 = ln_p_full[k] - ln_p_half[k]
+            dlog_3 = ln_p_half[k + 1] - ln_p_half[k]
+            x1 = (self.bk[k + 1] * dlog_1 + self.bk[k] * dlog_2) * dp_inv
+            x2 = x1 * dx_ps
+            x3 = x1 * dy_ps
+            dt_u[k] = dt_u[k] - RDGAS * t[k] * x2
+            dt_v[k] = dt_v[k] - RDGAS * t[k] * x3
+            dmean = divg[k] * dp + self.dbk[k] * (u[k] * dx_ps + v[k] * dy_ps)
+            x4 = (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
+            x5 = x4 - u[k] * x2 - v[k] * x3
+            dt_t[k] = dt_t[k] - KAPPA * t[k] * x5
+            wg_full[k] = -x5 * p_full[k]
+            dmean_tot = dmean_tot + dmean
+            wg[k + 1] = -dmean_tot
+        dt_ps = dt_ps - dmean_tot
+        for k in range(1, L):
+            wg[k] = wg[k] + dmean_tot * self.bk[k]
+        wg[0] = 0.0
+        wg[L] = 0.0
+        return dt_ps, wg, wg_full, dt_t, dt_u, dt_v
+
+    @staticmethod
+    def vert_advection_second_centered(w, dz, r):
+        """atmos_shared/vert_advection/vert_advection.F90:162-193,467-470 (ADVECTIVE_FORM)."""
+        L = r.shape[0]
+        flux = np.zeros_like(w)
+        flux[0] = w[0] * r[0]
+        flux[L] = w[L] * r[L - 1]
+        flux[1:L] = w[1:L] * (0.5 * (r[1:] + r[:-1]))
+        return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
+
+    # ----------------------------------------------------------------------------------------
+    # Held-Suarez forcing (atmos_param/hs_forcing/hs_forcing.F90:148-272,508-724)
+    # ----------------------------------------------------------------------------------------
+    def hs_forcing(self, dt, p_half, p_full, u, v, t, tr=None, tr_dt=None):
+        c = self.cfg
+        ps = p_half[-1]
+        rps = 1.0 / ps
+        sigma = p_full * rps
+        bl = (sigma <= 1.0) & (sigma > c.sigma_b)
+        # rayleigh_damping :615-679
+        vcoeff = -self.vkf / (1.0 - c.sigma_b)
+        vfactr = np.where(bl, vcoeff * (sigma - c.sigma_b), 0.0)
+        utnd = vfactr * u
+        vtnd = vfactr * v
+        tdt = np.zeros_like(t)
+        if c.do_conserve_energy:                                           # :198-200
+            tdt = tdt + (-((u + 0.5 * utnd * dt) * utnd + (v + 0.5 * vtnd * dt) * vtnd) / CP_AIR)
+        # newtonian_damping :508-611
+        sin_lat = np.sin(self.rad_lat)[:, None]
+        sin_lat_2 = sin_lat * sin_lat
+        cos_lat_2 = 1.0 - sin_lat_2
+        cos_lat_4 = cos_lat_2 * cos_lat_2
+        t_star = c.t_zero - c.delh * sin_lat_2 - c.eps * sin_lat
+        tstr = c.t_strat - c.eps * sin_lat
+        tcoeff = (self.tks - self.tka) / (1.0 - c.sigma_b)
+        p_norm = p_full / c.P00
+        the = t_star - c.delv * cos_lat_2 * np.log(p_norm)
+        teq = np.maximum(the * p_norm ** KAPPA, tstr)
+        tdamp = np.where(bl, self.tka + cos_lat_4 * (tcoeff * (sigma - c.sigma_b)), self.tka)
+        tdt = tdt + (-tdamp * (t - teq))
+        out = [utnd, vtnd, tdt]
+        if tr is not None:                                                   # :240-263, 683-724
+            rst = tr + dt * tr_dt
+            rdamp = 1.0 / self.trsink if self.trsink > 0 else 0.0
+            source = np.zeros_like(tr)
+            source[-1] = c.trflux / (p_half[-1] - p_half[-2])
+            out.append(tr_dt + source - rdamp * rst)
+        return tuple(out)
+
+    # ----------------------------------------------------------------------------------------
+    # semi-implicit (model/implicit.F90)
+    # ----------------------------------------------------------------------------------------
+    def _pressure_variables_1d(self, ps):
+        ph, lph, pf, lpf = self.pressure_variables(np.array(ps))
+        return ph, lph, pf, lpf
+
+    def linear_tp_tendency(self, div):
+        """implicit.F90:414-480.  div[k, ...] complex -> (dt_p_surf[...], dt_t[k, ...])."""
+        L = self.L
+        t_ref = self.ref_temperature_implicit
+        dmean_tot = np.zeros(div.shape[1:], dtype=div.dtype)
+        dt_t = np.zeros_like(div)
+        vert_vel = np.zeros((L + 1,) + div.shape[1:], dtype=div.dtype)
+        for k in range(L):
+            dp = self.dpk[k] + self.dbk[k] * self.ref_surf_p_implicit
+            dp_inv = 1 / dp
+            dlog_1 = self.ref_ln_p_half[k + 1] - self.ref_ln_p_full[k]
+            dlog_3 = self.ref_ln_p_half[k + 1] - self.ref_ln_p_half[k]
+            dmean = div[k] * dp
+            dt_t[k] = -KAPPA * t_ref[k] * (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
+            dmean_tot = dmean_tot + dmean
+            vert_vel[k + 1] = -dmean_tot
+        dt_p_surf = -dmean_tot
+        temp = np.zeros_like(vert_vel)
+        for k in range(1, L):
+            vert_vel[k] = vert_vel[k] + dmean_tot * self.bk[k]
+            temp[k] = -vert_vel[k] * (t_ref[k] - t_ref[k - 1])
+        for k in range(L):
+            dp = self.dpk[k] + self.dbk[k] * self.ref_surf_p_implicit
+            dt_t[k] = dt_t[k] + 0.5 * (1 / dp) * (temp[k + 1] + temp[k])
+        return dt_p_surf, dt_t
+
+    def linear_geopotential(self, del_t, del_ln_p_half, del_ln_p_full):
+        """implicit.F90:329-359."""
+        L = self.L
+        t = self.ref_temperature_implicit
+        lph, lpf = self.ref_ln_p_half, self.ref_ln_p_full
+        gh = np.zeros((L + 1,) + del_t.shape[1:], dtype=del_t.dtype)
+        for k in range(L - 1, 0, -1):
+            gh[k] = gh[k + 1] + RDGAS * (del_t[k] * (lph[k + 1] - lph[k])
+                                         + t[k] * (del_ln_p_half[k + 1] - del_ln_p_half[k]))
+        g = np.zeros_like(del_t)
+        for k in range(L):
+            g[k] = gh[k + 1] + RDGAS * (del_t[k] * (lph[k + 1] - lpf[k])
+                                        + t[k] * (del_ln_p_half[k + 1] - del_ln_p_full[k]))
+        return g
+
+    def _implicit_init(self):
+        c = self.cfg
+        L = self.L
+        self.ref_temperature_implicit = np.full(L, 300.0)          # spectral_dynamics.F90:473
+        self.ref_surf_p_implicit = c.reference_sea_level_press
+        pref = self.ref_surf_p_implicit
+        _, self.ref_ln_p_half, _, self.ref_ln_p_full = self._pressure_variables_1d(pref)
+        del_ln_p_half = np.zeros(L + 1)
+        del_ln_p_half[1:] = self.bk[1:] / (self.pk[1:] + self.bk[1:] * pref)
+        del_ln_p_half[0] = 1.0 / pref if self.pk[0] == 0.0 else self.bk[0] / (self.pk[0] + self.bk[0] * pref)
+        eps = 1.0e-5
+        _, _, _, l1 = self._pressure_variables_1d(pref * (1.0 - 0.5 * eps))
+        _, _, _, l2 = self._pressure_variables_1d(pref * (1.0 + 0.5 * eps))
+        del_ln_p_full = (l2 - l1) / (eps * pref)
+        # build_matrix :171-217
+        ident = np.eye(L)
+        nu = np.zeros(L); tau = np.zeros((L, L)); gamma = np.zeros((L, L))
+        for k in range(L):
+            dt_p, dt_t = self.linear_tp_tendency(ident[:, k].copy())
+            nu[k] = -dt_p
+            tau[:, k] = -dt_t
+            gamma[:, k] = self.linear_geopotential(ident[:, k].copy(), np.zeros(L + 1), np.zeros(L))
+        t = self.ref_temperature_implicit
+        dlog_1 = self.ref_ln_p_half[1:] - self.ref_ln_p_full
+        dlog_2 = self.ref_ln_p_full - self.ref_ln_p_half[:-1]
+        h1 = RDGAS * t * (self.bk[1:] * dlog_1 + self.bk[:-1] * dlog_2) / (self.dpk + self.dbk * pref)
+        h2 = self.linear_geopotential(np.zeros(L), del_ln_p_half, del_ln_p_full)
+        self.h = h1 + h2
+        self.div_mat = np.outer(self.h, nu) + gamma @ tau
+        self.nu_vec, self.tau_mat, self.gamma_mat = nu, tau, gamma
+
+    def build_wave_matrices(self, dt):
+        """implicit.F90:221-237."""
+        self.xi = dt * self.cfg.alpha_implicit
+        ntw = self.cfg.num_spherical - 1
+        L = self.L
+        self.wave_matrix = np.zeros((ntw + 1, L, L))
+        for Lw in range(ntw + 1):
+            factor = self.xi * self.xi * Lw * (Lw + 1) / RADIUS ** 2
+            self.wave_matrix[Lw] = invert_gauss_jordan(np.eye(L) + factor * self.div_mat)
+        self._wave_dt = dt
+
+    def implicit_correction(self, dt_divs, dt_ts, dt_ln_ps, divs, ts, ln_ps, dt, previous, current):
+        """implicit.F90:241-325.  divs/ts: [2][k,n,m]; ln_ps: [2][n,m].  Returns new tendencies."""
+        if self._wave_dt != dt:
+            self.build_wave_matrices(dt)
+        xi, pref = self.xi, self.ref_surf_p_implicit
+        # adjust_dt_divs :289-325
+        dps, dts = self.linear_tp_tendency(divs[previous] - divs[current])
+        dt_ts = dt_ts + dts
+        dt_ln_ps = dt_ln_ps + dps / pref
+        ts_temp = ts[previous] - ts[current] + xi * dt_ts
+        ps_temp = ln_ps[previous] - ln_ps[current] + xi * dt_ln_ps
+        zero_h = np.zeros((self.L + 1,) + ts_temp.shape[1:], dtype=ts_temp.dtype)
+        geopot = self.linear_geopotential(ts_temp, zero_h, np.zeros_like(ts_temp))
+        dt_divs = dt_divs + self.eigen_laplacian * (geopot + self.h[:, None, None] * ps_temp * pref)
+        # per-(m,n) L x L matvec :268-277
+        Lw = self.spherical_wave.astype(int)
+        ntw = self.cfg.num_spherical - 1
+        out = dt_divs.copy()
+        ok = Lw <= ntw
+        Wsel = self.wave_matrix[np.where(ok, Lw, 0)]              # [n,m,L,L]
+        prod = np.einsum("nmab,bnm->anm", Wsel, dt_divs)
+        out = np.where(ok[None], prod, dt_divs)
+        dps, dts = self.linear_tp_tendency(out)
+        dt_ts = dt_ts + xi * dts
+        dt_ln_ps = dt_ln_ps + xi * dps / pref
+        return out, dt_ts, dt_ln_ps
+
+    # ----------------------------------------------------------------------------------------
+    # damping + leapfrog (spectral_damping.F90:172-291, leapfrog.F90:58-105)
+    # ----------------------------------------------------------------------------------------
+    def compute_spectral_damping(self, spec, dt_spec, dt, kind="t"):
+        d = {"t": self.damping, "vor": self.damping_vor, "div": self.damping_div}[kind]
+        coeff = 1.0 / (1.0 + d * dt)
+        out = coeff * (dt_spec - d * spec)
+        if kind in ("vor", "div"):
+            es = self.damping_eddy_sponge
+            zs = self.damping_zmu_sponge if kind == "vor" else self.damping_zmv_sponge
+            top = out[0].copy()
+            top[:, 1:] = (top[:, 1:] - es[:, 1:] * spec[0][:, 1:]) / (1.0 + es[:, 1:] * dt)
+            top[:, 0] = (top[:, 0] - zs * spec[0][:, 0]) / (1.0 + zs * dt)
+            out[0] = top
+        return out
+
+    # ----------------------------------------------------------------------------------------
+    # model state and the step
+    # ----------------------------------------------------------------------------------------
+    def cold_start(self):
+        """init/spectral_initialize_fields.F90:45-135 + spectral_dynamics.F90:580-630."""
+        c = self.cfg
+        L, J, I, N1, M1 = self.L, self.J, self.I, self.N1, self.M1
+        st = {}
+        vors = np.zeros((L, N1, M1), dtype=np.complex128)
+        divs = np.zeros_like(vors)
+        for (m, n) in ((1, 3), (5, 3), (1, 2), (5, 2)):
+            if m < M1 and n < N1:
+                vors[L - 3:L, n, m] = 1.0e-7
+        ug, vg = self.uv_grid_from_vor_div(vors, divs)
+        tg = np.full((L, J, I), c.initial_temperature)
+        ln_psg = math.log(c.reference_sea_level_press) - self.surf_geopotential / (RDGAS * c.initial_temperature)
+        ts = self.trans_grid_to_spherical(tg)
+        tg = self.trans_spherical_to_grid(ts)
+        ln_ps = self.trans_grid_to_spherical(ln_psg)
+        psg = np.exp(self.trans_spherical_to_grid(ln_ps))
+        vors, divs = self.vor_div_from_uv_grid(ug, vg)
+        ug, vg = self.uv_grid_from_vor_div(vors, divs)
+        self.vorg = self.trans_spherical_to_grid(vors)
+        self.divg = self.trans_spherical_to_grid(divs)
+        two = lambda a: [a.copy(), a.copy()]
+        self.vors, self.divs, self.ts, self.ln_ps = two(vors), two(divs), two(ts), two(ln_ps)
+        self.ug, self.vg, self.tg, self.psg = two(ug), two(vg), two(tg), two(psg)
+        tr = np.full((L, J, I), c.initial_sphum)
+        self.tr = two(tr)
+        self.previous = 0
+        self.current = 0
+        self.step_count = 0
+        # atmosphere_init :229-241
+        self.p_full = [None, None]; self.p_half = [None, None]
+        self.z_full = [None, None]; self.z_half = [None, None]
+        self._pressures_and_heights(0)
+        self.p_full[1], self.p_half[1] = self.p_full[0].copy(), self.p_half[0].copy()
+        self.z_full[1], self.z_half[1] = self.z_full[0].copy(), self.z_half[0].copy()
+        self.wg_full = np.zeros((L, J, I))
+
+    def _pressures_and_heights(self, lev):
+        zf, zh, pf, ph = self.compute_pressures_and_heights(self.tg[lev], self.psg[lev])
+        self.z_full[lev], self.z_half[lev], self.p_full[lev], self.p_half[lev] = zf, zh, pf, ph
+
+    def step(self, with_tracer=False):
+        """One call of atmosphere (driver/solo/atmosphere.F90:276-352), HS branch, i.e.
+        hs_forcing -> spectral_dynamics (spectral_dynamics.F90:780-1034) -> pressures/heights."""
+        c = self.cfg
+        prev, cur = self.previous, self.current
+        delta_t = c.dt_atmos if prev == cur else 2 * c.dt_atmos
+        fut = 1 - cur if prev == cur else prev
+        # --- physics: u,v,T at PREVIOUS, p at CURRENT (atmosphere.F90:304-311)
+        dt_u, dt_v, dt_t = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur],
+                                           self.ug[prev], self.vg[prev], self.tg[prev])
+        dt_ps = np.zeros((self.J, self.I))
+        # --- initialize_corrections :1306-1338
+        if c.do_mass_correction:
+            mean_ps_prev = self.area_weighted_global_mean(self.psg[prev])
+        if c.do_energy_correction:
+            energy = 0.5 * ((self.ug[prev] + dt_u * delta_t) ** 2 + (self.vg[prev] + dt_v * delta_t) ** 2) \
+                + CP_AIR * (self.tg[prev] + dt_t * delta_t)
+            mean_energy_prev = self.mass_weighted_global_integral(energy, self.psg[prev])
+        # --- dynamics tendencies :853-904
+        p_half, ln_p_half, p_full, ln_p_full = self.pressure_variables(self.psg[cur])
+        dxs, dys = self.compute_gradient_cos(self.ln_ps[cur])
+        dx_ps = self.divide_by_cos(self.psg[cur] * self.trans_spherical_to_grid(dxs))
+        dy_ps = self.divide_by_cos(self.psg[cur] * self.trans_spherical_to_grid(dys))
+        u, v, t = self.ug[cur], self.vg[cur], self.tg[cur]
+        dt_ps, wg, wg_full, dt_t, dt_u, dt_v = self.four_in_one(
+            self.divg, u, v, t, self.psg[cur], ln_p_half, ln_p_full, p_full, dx_ps, dy_ps,
+            dt_ps, dt_t, dt_u, dt_v)
+        phig_full, _ = self.compute_geopotential(t, ln_p_half, ln_p_full)
+        dt_ln_ps = self.trans_grid_to_spherical(dt_ps / self.psg[cur])
+        dp = p_half[1:] - p_half[:-1]
+        dt_u = dt_u + self.vert_advection_second_centered(wg, dp, u)
+        dt_v = dt_v + self.vert_advection_second_centered(wg, dp, v)
+        dt_t = dt_t + self.vert_advection_second_centered(wg, dp, t)
+        dt_t = self.horizontal_advection(self.ts[cur], u, v, dt_t)
+        dt_ts = self.trans_grid_to_spherical(dt_t)
+        absvor = self.vorg + self.coriolis[None, :, None]
+        dt_u = dt_u + absvor * v
+        dt_v = dt_v - absvor * u
+        dt_vors, dt_divs = self.vor_div_from_uv_grid(dt_u, dt_v)
+        phis_plus_ke = self.trans_grid_to_spherical(phig_full + 0.5 * (u ** 2 + v ** 2))
+        dt_divs = dt_divs - self.compute_laplacian(phis_plus_ke)
+        # --- implicit, damping, leapfrog :906-931
+        dt_divs, dt_ts, dt_ln_ps = self.implicit_correction(
+            dt_divs, dt_ts, dt_ln_ps, self.divs, self.ts, self.ln_ps, delta_t, prev, cur)
+        dt_vors = self.compute_spectral_damping(self.vors[prev], dt_vors, delta_t, "vor")
+        dt_divs = self.compute_spectral_damping(self.divs[prev], dt_divs, delta_t, "div")
+        dt_ts = self.compute_spectral_damping(self.ts[prev], dt_ts, delta_t, "t")
+        rc, raw = c.robert_coeff, c.raw_filter_coeff
+        part = {}
+        for name, dta in (("ln_ps", dt_ln_ps), ("vors", dt_vors), ("divs", dt_divs), ("ts", dt_ts)):
+            a = getattr(self, name)
+            part[name] = a[prev] - 2.0 * a[cur]                    # leapfrog.F90:73
+            newfut = a[prev] + delta_t * dta
+            a[cur] = a[cur] + rc * part[name] * raw
+            if prev == cur:
+                pass                                                 # same storage: :75-77
+            a[fut] = newfut
+        # --- back to grid :933-938
+        self.divg = self.trans_spherical_to_grid(self.divs[fut])
+        self.vorg = self.trans_spherical_to_grid(self.vors[fut])
+        self.ug[fut], self.vg[fut] = self.uv_grid_from_vor_div(self.vors[fut], self.divs[fut])
+        self.tg[fut] = self.trans_spherical_to_grid(self.ts[fut])
+        self.psg[fut] = np.exp(self.trans_spherical_to_grid(self.ln_ps[fut]))
+        tmin, tmax = self.tg[fut].min(), self.tg[fut].max()
+        if tmin < c.valid_range_t[0] or tmax > c.valid_range_t[1]:
+            raise FloatingPointError("temperatures out of valid range")      # :940-972
+        # --- compute_corrections :1213-1302
+        if c.do_mass_correction:
+            mean_ps_tmp = self.area_weighted_global_mean(self.psg[fut])
+            factor = mean_ps_prev / mean_ps_tmp
+            self.psg[fut] = factor * self.psg[fut]
+            self.ln_ps[fut][0, 0] += math.sqrt(2.0) * math.log(factor)
+        if c.do_energy_correction:
+            mean_energy_tmp = self.mass_weighted_global_integral(
+                0.5 * (self.ug[fut] ** 2 + self.vg[fut] ** 2) + CP_AIR * self.tg[fut], self.psg[fut])
+            tcorr = GRAV * (mean_energy_prev - mean_energy_tmp) / (CP_AIR * mean_ps_prev)
+            self.tg[fut] = self.tg[fut] + tcorr
+            self.ts[fut][:, 0, 0] += math.sqrt(2.0) * tcorr
+        self.previous, self.current = cur, fut
+        # --- complete_robert_filter :1456-1490 (leapfrog_2level_B with swapped pointers)
+        for name in ("ln_ps", "vors", "divs", "ts"):
+            a = getattr(self, name)
+            a[cur] = a[cur] + rc * a[fut] * raw
+            a[fut] = a[fut] + rc * (part[name] + a[fut]) * (raw - 1.0)
+        self.wg_full = wg_full
+        self.p_full[cur], self.p_half[cur] = p_full, p_half       # intent(out) of spectral_dynamics
+        self._pressures_and_heights(fut)                          # atmosphere.F90:331-338
+        self.step_count += 1
+
+    # convenience
+    def state(self):
+        cur = self.current
+        return dict(ug=self.ug[cur], vg=self.vg[cur], tg=self.tg[cur], psg=self.psg[cur],
+                    vors=self.vors[cur], divs=self.divs[cur], ts=self.ts[cur], ln_ps=self.ln_ps[cur])

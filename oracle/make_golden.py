@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the reference itself (oracle/_ref/ref_harness.x).
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs oracle/_ref built from /root/reference
+by oracle/build_ref.py).  The committed .npz files are data: inputs + the reference's outputs.
+Usage: python oracle/make_golden.py [--only NAME]
+"""
+import argparse, os, re, shutil, subprocess, sys, tempfile
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+EXE = os.path.join(HERE, "_ref", "ref_harness.x")
+GOLD = os.path.join(REPO, "tests", "golden")
+
+# tracer table of the dry model (one grid tracer), a configuration input of the HS test case
+FIELD_TABLE = '''"TRACER", "atmos_mod", "sphum"
+          "longname",  "specific humidity"
+          "units",     "kg/kg"
+          "numerical_representation", "grid"
+	  "hole_filling",             "off"
+          "advect_vert",              "finite_volume_parabolic"
+          "robert_filter",            "on"
+          "profile_type", "fixed",   "surface_value=0.0" /
+'''
+
+RES = {"T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
+       "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
+
+
+def input_nml(res, num_levels, extra=""):
+    lon, lat, nf, ns = RES[res]
+    # namelist of exp/test_cases/held_suarez/held_suarez_test_case.py:45-98
+    return f""" &atmosphere_nml
+    idealized_moist_model = .false.
+ /
+ &spectral_dynamics_nml
+    damping_order = 4,
+    water_correction_limit = 200.e2,
+    reference_sea_level_press = 1.0e5,
+    valid_range_t = 100., 800.,
+    initial_sphum = 0.0,
+    vert_coord_option = 'uneven_sigma',
+    scale_heights = 6.0,
+    exponent = 7.5,
+    surf_res = 0.5,
+    lon_max = {lon}, lat_max = {lat}, num_fourier = {nf}, num_spherical = {ns}, num_levels = {num_levels}
+    {extra}
+ /
+ &hs_forcing_nml
+    t_zero = 315., t_strat = 200., delh = 60., delv = 10., eps = 0., sigma_b = 0.7,
+    ka = -40., ks = -4., kf = -1., do_conserve_energy = .true.
+ /
+ &diag_manager_nml
+    mix_snapshot_average_fields = .false.
+ /
+ &fms_nml
+    domains_stack_size = 2000000
+ /
+"""
+
+
+def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra=""):
+    os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
+    os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
+    open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra))
+    open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)
+    open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
+    ds = ", ".join(str(s) for s in dump_steps) if dump_steps else "-1"
+    open(os.path.join(d, "harness.nml"), "w").write(
+        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {ds}\n /\n")
+
+
+def run_harness(d, exe=EXE, timeout=3600):
+    r = subprocess.run(f"ulimit -s unlimited; exec {exe}", shell=True, cwd=d, capture_output=True,
+                       text=True, timeout=timeout, executable="/bin/bash")
+    if r.returncode != 0:
+        raise RuntimeError("ref harness failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+    return r.stdout
+
+
+def shapes(res, L):
+    lon, lat, nf, ns = RES[res]
+    return dict(grid=(L, lat, lon), grid2=(lat, lon), spec=(L, ns + 1, nf + 1), spec2=(ns + 1, nf + 1),
+                gridh=(L + 1, lat, lon))
+
+
+def read_outputs(d, res, L):
+    sh = shapes(res, L)
+    lon, lat, nf, ns = RES[res]
+    out = {}
+    for fn in sorted(os.listdir(d)):
+        if not fn.endswith(".bin") or fn.startswith("in_"):
+            continue
+        name = fn[:-4]
+        raw = np.fromfile(os.path.join(d, fn), dtype=np.float64)
+        n = raw.size
+        cands = [("spec", True), ("spec2", True), ("grid", False), ("grid2", False), ("gridh", False)]
+        arr = None
+        if name == "tab_legendre":
+            arr = raw.reshape(lat // 2, ns + 1, nf + 1)
+        elif name == "tab_eigen_laplacian":
+            arr = raw.reshape(ns + 1, nf + 1)
+        elif name == "out_s2f_a":
+            arr = raw.view(np.complex128).reshape(L, lat, nf + 1)
+        elif name == "out_g2f_a":
+            arr = raw.view(np.complex128).reshape(L, lat, lon // 2 + 1)
+        else:
+            is_spec = bool(re.search(r"(vors|divs|_ts_|lnps|g2s|vor_from|div_from|laplacian|gradcos|ucos|vcos|impl|damp|leap)", name))
+            for key, cplx in cands:
+                if cplx != is_spec:
+                    continue
+                cnt = int(np.prod(sh[key])) * (2 if cplx else 1)
+                if cnt == n:
+                    arr = (raw.view(np.complex128) if cplx else raw).reshape(sh[key])
+                    break
+            if arr is None:
+                arr = raw
+        out[name] = arr
+    return out
+
+
+def rand_spec(rng, res, L, two_d=False):
+    """Band-limited random coefficients: N(0,1)+iN(0,1), imag(m=0)=0, /(1+L)^2, truncated."""
+    lon, lat, nf, ns = RES[res]
+    shp = (ns + 1, nf + 1) if two_d else (L, ns + 1, nf + 1)
+    s = rng.standard_normal(shp) + 1j * rng.standard_normal(shp)
+    s[..., 0] = s[..., 0].real
+    m = np.arange(nf + 1)[None, :]; n = np.arange(ns + 1)[:, None]
+    tot = m + n
+    s = s / (1.0 + tot) ** 2
+    s = s * (tot <= ns - 1)
+    return s
+
+
+def golden_kernels(res, L, seed):
+    rng = np.random.default_rng(seed)
+    lon, lat, nf, ns = RES[res]
+    sh = shapes(res, L)
+    inp = {}
+    for nm in "abcdef":
+        inp[f"in_spec_{nm}"] = rand_spec(rng, res, L)
+    for nm in "abc":
+        inp[f"in_spec2_{nm}"] = rand_spec(rng, res, L, two_d=True)
+    inp["in_grid_a"] = 10.0 * rng.standard_normal(sh["grid"])
+    inp["in_grid_b"] = 10.0 * rng.standard_normal(sh["grid"])
+    inp["in_ps"] = 1.0e5 * (1.0 + 0.03 * rng.standard_normal(sh["grid2"]))
+    inp["in_temp"] = 260.0 + 20.0 * rng.standard_normal(sh["grid"])
+    wg = 0.05 * rng.standard_normal(sh["gridh"]); wg[0] = 0; wg[-1] = 0
+    inp["in_wg"] = wg
+    with tempfile.TemporaryDirectory(prefix="refk_") as d:
+        prepare_rundir(d, res, L, "kernels", dt=600)
+        for k, v in inp.items():
+            np.ascontiguousarray(v).tofile(os.path.join(d, k + ".bin"))
+        run_harness(d)
+        out = read_outputs(d, res, L)
+    meta = dict(res=res, num_levels=L, dt_atmos=600.0, seed=seed)
+    return {**{k: v for k, v in inp.items()}, **out, **{"meta_" + k: np.array(v) for k, v in meta.items()}}
+
+
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None):
+    with tempfile.TemporaryDirectory(prefix="refr_") as d:
+        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps)
+        stdout = run_harness(d)
+        out = read_outputs(d, res, L)
+    if keep is not None:
+        out = {k: v for k, v in out.items() if keep(k)}
+    m = re.search(r"REF_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["final_Tmin_Tmax_maxabsU"] = np.array([float(x) for x in m.groups()])
+    meta = dict(res=res, num_levels=L, dt_atmos=float(dt), nsteps=nsteps)
+    out.update({"meta_" + k: np.array(v) for k, v in meta.items()})
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    jobs = {
+        # small config: every public routine + a 50-step trajectory with full state
+        "kernels_T10L8": lambda: golden_kernels("T10", 8, 20260927),
+        "run_T10L8": lambda: golden_run("T10", 8, 50, (1, 2, 3, 10, 50)),
+        # real resolution of configs[0], few levels, kernel level
+        "kernels_T21L6": lambda: golden_kernels("T21", 6, 20260928),
+        # configs[0] itself: T21L25 HS, 1 day (144 steps); keep grid state at steps 2 and 144
+        "run_T21L25": lambda: golden_run(
+            "T21", 25, 144, (2, 144),
+            keep=lambda k: k.startswith("tab_") and k != "tab_legendre"
+            or re.match(r"st_(ug|vg|tg|psg)_(000002|000144)$", k) is not None),
+        # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
+        "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
+    }
+    for name, fn in jobs.items():
+        if a.only and a.only != name:
+            continue
+        out = fn()
+        path = os.path.join(GOLD, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path)/1e6:.2f} MB")
+    if not a.only or a.only == "tables_T85":
+        out = golden_run("T85", 2, 0, (), keep=lambda k: k.startswith("tab_"))
+        leg = out.pop("tab_legendre")
+        out["tab_legendre_j0_j31_j63"] = leg[[0, 31, 63]]
+        path = os.path.join(GOLD, "tables_T85.npz")
+        np.savez_compressed(path, **out)
+        print(f"tables_T85: {os.path.getsize(path)/1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,163 @@
+"""The numpy oracle (oracle/isca_oracle.py) against the reference's own outputs.
+
+tests/golden/*.npz were produced by oracle/make_golden.py running oracle/_ref/ref_harness.x, i.e. the
+reference Fortran compiled in place.  Tolerances: kernel level 1e-12 relative L-inf,
+one step 1e-11, one day 1e-9.  Measured: tables bit-exact, kernels <= 5e-15, 144 steps <= 1e-11.
+"""
+import os
+import numpy as np
+import pytest
+
+from oracle.isca_oracle import Config, SpectralCore
+
+RES = {"T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86)}
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
+
+
+def core(res, L):
+    lon, lat, nf, ns = RES[res]
+    return SpectralCore(Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns, num_levels=L))
+
+
+@pytest.fixture(scope="module", params=[("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6)])
+def kern(request, golden_dir):
+    name, res, L = request.param
+    return np.load(os.path.join(golden_dir, name + ".npz")), core(res, L)
+
+
+def test_tables_bit_exact(kern):
+    g, sc = kern
+    # gauss_and_legendre.F90:47-183, vert_coordinate.F90:248-273, spherical.F90:192
+    assert np.array_equal(sc.sin_hem, g["tab_sin_hem"])
+    assert np.array_equal(sc.wts_hem, g["tab_wts_hem"])
+    assert np.array_equal(sc.legendre, g["tab_legendre"])
+    assert np.array_equal(sc.bk, g["tab_bk"]) and np.array_equal(sc.pk, g["tab_pk"])
+    assert np.array_equal(sc.deg_lat, g["tab_deg_lat"]) and np.array_equal(sc.deg_lon, g["tab_deg_lon"])
+    assert np.array_equal(sc.sin_lat, g["tab_sin_lat"]) and np.array_equal(sc.wts_lat, g["tab_wts_lat"])
+    assert rel(sc.eigen_laplacian, g["tab_eigen_laplacian"]) < 1e-15
+
+
+@pytest.mark.parametrize("res", ["T42", "T85"])
+def test_tables_high_resolution(res, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"tables_{res}.npz"))
+    sc = core(res, 2)
+    assert np.array_equal(sc.sin_hem, g["tab_sin_hem"]) and np.array_equal(sc.wts_hem, g["tab_wts_hem"])
+    if "tab_legendre" in g:
+        assert np.array_equal(sc.legendre, g["tab_legendre"])
+    else:
+        assert np.array_equal(sc.legendre[[0, 31, 63]], g["tab_legendre_j0_j31_j63"])
+    assert abs(sc.wts_lat.sum() - 2.0) < 1e-14
+
+
+def test_survey_known_answers():
+    # SURVEY Appendix C (T21), printed from the reference's routines
+    sc = core("T21", 25)
+    assert sc.sin_hem[0] == 9.9726386184948157e-01 and sc.wts_hem[15] == 9.6540088514727854e-02
+    assert sc.legendre[0, 0, 0] == 7.0710678118654757e-01          # P(m=0,n=0,j=1)
+    assert sc.legendre[7, 3, 5] == 1.1028365286710009e+00          # P(5,3,8)
+    assert sc.legendre[15, 22, 0] == -3.7086750165534227e-01       # P(0,22,16)
+    assert sc.bk[12] == 2.0551410880237991e-01 and sc.bk[24] == 8.8692043662996956e-01
+    lat = np.deg2rad(sc.deg_lat)[:, None]; lon = np.deg2rad(sc.deg_lon)[None, :]
+    gfield = 1 + 2 * np.sin(lat) + np.cos(lon) * np.cos(lat) + 0.5 * np.sin(2 * lon) * np.cos(lat) ** 2
+    s = sc.trans_grid_to_spherical(gfield)
+    assert abs(s[0, 0] - np.sqrt(2.0)) < 1e-14 and abs(s[1, 0] - 1.6329931618554487) < 1e-14
+    assert abs(s[0, 1] - 0.57735026918962551) < 1e-14 and abs(s[0, 2] - (-0.25819888974716104j)) < 1e-14
+    vor, div = sc.vor_div_from_uv_grid(10 * np.cos(lat) + 0 * lon, 0 * lat + 0 * lon)
+    assert abs(vor[1, 0] - 2.5611561509652623e-06) < 1e-19 and np.abs(div).max() < 1e-20
+
+
+def test_transforms(kern):
+    g, sc = kern
+    sa, ga = g["in_spec_a"], g["in_grid_a"]
+    assert rel(sc.spherical_to_fourier(sa), g["out_s2f_a"]) < 1e-13      # spherical_fourier.F90:214-258
+    assert rel(sc.grid_to_fourier(ga), g["out_g2f_a"]) < 1e-13           # fft99 forward, 1/I
+    assert rel(sc.trans_spherical_to_grid(sa), g["out_s2g_a"]) < 1e-13
+    assert rel(sc.trans_grid_to_spherical(ga), g["out_g2s_a"]) < 1e-13
+    assert rel(sc.trans_grid_to_spherical(ga, False), g["out_g2s_a_notrunc"]) < 1e-13
+    assert rel(sc.trans_grid_to_spherical(g["out_s2g_a"]), g["out_g2s_s2g_a"]) < 1e-13
+
+
+def test_spectral_operators(kern):
+    g, sc = kern
+    sa, sb, ga, gb = g["in_spec_a"], g["in_spec_b"], g["in_grid_a"], g["in_grid_b"]
+    assert rel(sc.compute_laplacian(sa), g["out_laplacian_a"]) < 1e-15
+    dx, dy = sc.compute_gradient_cos(sa)
+    assert rel(dx, g["out_gradcos_dx_a"]) < 1e-15 and rel(dy, g["out_gradcos_dy_a"]) < 1e-15
+    uc, vc = sc.compute_ucos_vcos(sa, sb)
+    assert rel(uc, g["out_ucos"]) < 1e-15 and rel(vc, g["out_vcos"]) < 1e-15
+    vo, di = sc.compute_vor_div(sa, sb)
+    assert rel(vo, g["out_vor_from_ucos"]) < 1e-15 and rel(di, g["out_div_from_ucos"]) < 1e-15
+    vor, div = sc.vor_div_from_uv_grid(ga, gb)
+    assert rel(vor, g["out_vor_from_uv"]) < 1e-13 and rel(div, g["out_div_from_uv"]) < 1e-13
+    u, v = sc.uv_grid_from_vor_div(sa, sb)
+    assert rel(u, g["out_u_from_vd"]) < 1e-13 and rel(v, g["out_v_from_vd"]) < 1e-13
+    assert rel(sc.horizontal_advection(sa, ga, gb, np.zeros_like(ga)), g["out_hadv"]) < 1e-13
+    assert abs(sc.area_weighted_global_mean(ga[0]) - g["out_gmean"][0]) < 1e-13
+    assert abs(sc.mass_weighted_global_integral(ga, g["in_ps"]) / g["out_mwgi"][0] - 1) < 1e-12
+
+
+def test_column_routines(kern):
+    g, sc = kern
+    ps, T, ga, gb = g["in_ps"], g["in_temp"], g["in_grid_a"], g["in_grid_b"]
+    ph, lph, pf, lpf = sc.pressure_variables(ps)
+    assert rel(ph, g["out_p_half"]) < 1e-15 and rel(lph, g["out_ln_p_half"]) < 1e-14
+    assert rel(pf, g["out_p_full"]) < 1e-13 and rel(lpf, g["out_ln_p_full"]) < 1e-14
+    gf, gh = sc.compute_geopotential(T, lph, lpf)
+    assert rel(gf, g["out_geopot_full"]) < 1e-13 and rel(gh, g["out_geopot_half"]) < 1e-13
+    ut, vt, tt, trt = sc.hs_forcing(1200.0, ph, pf, ga, gb, T, np.zeros_like(T), np.zeros_like(T))
+    assert rel(ut, g["out_hs_dt_u"]) < 1e-13 and rel(vt, g["out_hs_dt_v"]) < 1e-13
+    assert rel(tt, g["out_hs_dt_t"]) < 1e-13 and rel(trt, g["out_hs_dt_tr"]) < 1e-13
+    assert rel(sc.vert_advection_second_centered(g["in_wg"], ph[1:] - ph[:-1], T), g["out_vadv"]) < 1e-13
+
+
+def test_implicit_damping_leapfrog(kern):
+    g, sc = kern
+    dtk = 1200.0
+    divs = [g["in_spec_a"], g["in_spec_b"]]; ts = [g["in_spec_c"], g["in_spec_d"]]
+    lnps = [g["in_spec2_a"], g["in_spec2_b"]]
+    o1, o2, o3 = sc.implicit_correction(g["in_spec_e"], g["in_spec_f"], g["in_spec2_c"], divs, ts, lnps, dtk, 0, 1)
+    assert rel(o1, g["out_impl_dt_divs"]) < 1e-12 and rel(o2, g["out_impl_dt_ts"]) < 1e-12
+    assert rel(o3, g["out_impl_dt_lnps"]) < 1e-12
+    for kind, key in (("vor", "out_damp_vor"), ("div", "out_damp_div"), ("t", "out_damp")):
+        assert rel(sc.compute_spectral_damping(g["in_spec_a"], g["in_spec_e"], dtk, kind), g[key]) < 1e-15
+    # leapfrog_2level_A (prev=1,cur=2,fut=1) then _B with swapped pointers: leapfrog.F90:58-105
+    a = [g["in_spec_a"].copy(), g["in_spec_b"].copy()]
+    part = a[0] - 2.0 * a[1]
+    a[1] = a[1] + 0.04 * part
+    a[0] = a[0] + dtk * g["in_spec_e"]
+    a[1] = a[1] + 0.04 * a[0]
+    assert rel(a[0], g["out_leap_l1"]) < 1e-15 and rel(a[1], g["out_leap_l2"]) < 1e-15
+
+
+def test_trajectory_T10L8(golden_dir):
+    g = np.load(os.path.join(golden_dir, "run_T10L8.npz"))
+    sc = core("T10", 8); sc.cold_start()
+    for i in range(1, 51):
+        sc.step()
+        if i in (1, 2, 3, 10, 50):
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):      # winds are O(1e-2..1) m/s here: compare absolutely
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+            assert rel(s["ts"], g[f"st_ts_{tag}"]) < 1e-12 and rel(s["ln_ps"], g[f"st_lnps_{tag}"]) < 1e-12
+            assert rel(s["vors"], g[f"st_vors_{tag}"]) < 1e-10
+
+
+def test_trajectory_T21L25_one_day(golden_dir):
+    """configs[0] (T21L25 HS): 144 steps = 1 day against the reference run; SURVEY tolerance 1e-9."""
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    sc = core("T21", 25); sc.cold_start()
+    for i in range(1, 145):
+        sc.step()
+        if i in (2, 144):
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg", "tg", "psg"):
+                assert rel(s[k], g[f"st_{k}_{tag}"]) < 1e-9, (k, tag)
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    assert abs(s["tg"].min() - tmin) < 1e-9 and abs(s["tg"].max() - tmax) < 1e-9
+    assert abs(np.abs(s["ug"]).max() - umax) < 1e-9
+    # SURVEY 8c anchors printed by the survey probe
+    assert abs(tmin - 262.169090) < 1e-6 and abs(tmax - 272.371035) < 1e-6 and abs(umax - 1.148573) < 1e-6
