@@ -1,0 +1,138 @@
+/* isca_dyn.h -- C-ABI of the MI355X-native spectral dynamical core.
+ *
+ * Drop-in boundary for the hot path of ExeClim/Isca's src/atmos_spectral (paths below are relative
+ * to the reference's src/):
+ *   - atmosphere_mod          atmos_spectral/driver/solo/atmosphere.F90:78   (atmosphere_init/atmosphere/atmosphere_end)
+ *   - spectral_dynamics_mod   atmos_spectral/model/spectral_dynamics.F90:95-98
+ *   - transforms_mod          atmos_spectral/tools/transforms.F90:134-184
+ *   - hs_forcing_mod          atmos_param/hs_forcing/hs_forcing.F90:65
+ * The reference has no FFI: the boundary is its Fortran module interface.  A maintainer binds these
+ * entry points with `bind(C)` interface blocks; our own Python host binds them
+ * with ctypes (isca_amd/dyncore.py).
+ *
+ * Conventions
+ *   - every real is fp64 (the reference builds with -r8); complex = interleaved (re,im) fp64 pairs.
+ *   - host arrays use the reference's Fortran layouts: grid (lon, lat, lev), spectral (m, n, lev)
+ *     with m fastest; n = meridional index (total wavenumber m+n), n = 0..num_spherical.
+ *   - latitudes south -> north (spherical_fourier.F90:413-423).
+ *   - all functions return 0 on success, non-zero on error (the reference aborts with FATAL;
+ *     here the message is available from isca_last_error()).  Nothing falls back to the CPU: if no
+ *     HIP device is usable isca_dyn_create fails.
+ *   - a handle owns its device memory and one HIP stream; calls on a handle are serialised.
+ */
+#ifndef ISCA_DYN_H
+#define ISCA_DYN_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct isca_dyn isca_dyn_t;
+
+/* namelist keys used on the path: spectral_dynamics_nml (spectral_dynamics.F90:152-224),
+ * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
+typedef struct isca_dyn_config {
+  int lon_max, lat_max, num_fourier, num_spherical, num_levels;
+  int fourier_inc;              /* must be 1 */
+  int triang_trunc;             /* must be 1 */
+  double dt_atmos;              /* seconds */
+  /* spectral_dynamics_nml */
+  int damping_order;            /* damping_option = 'resolution_dependent' */
+  double damping_coeff;
+  double eddy_sponge_coeff, zmu_sponge_coeff, zmv_sponge_coeff;
+  double robert_coeff;
+  double raw_filter_coeff;      /* must be 1.0 (pure Robert filter, the reference default) */
+  double alpha_implicit;
+  double reference_sea_level_press;
+  double scale_heights, exponent, surf_res;   /* vert_coord_option = 'uneven_sigma' */
+  int do_mass_correction, do_energy_correction, do_water_correction;
+  double water_correction_limit;
+  double initial_temperature;   /* spectral_init_cond_nml, default 264 */
+  double initial_sphum;
+  double valid_range_t[2];
+  int num_tracers;              /* grid tracers carried (dry field_table: 1 = sphum) */
+  /* hs_forcing_nml */
+  double t_zero, t_strat, delh, delv, eps, sigma_b, ka, ks, kf;
+  int do_conserve_energy;
+  double trflux, trsink, P00;
+  /* decomposition: latitude bands in grid space, zonal-wavenumber sets in spectral space
+   * (spec_mpp.F90:61-80).  world_size must divide lat_max/2. */
+  int rank, world_size;
+  int device;                   /* HIP device ordinal */
+  void *stream;                 /* hipStream_t to run on, or NULL for a private stream */
+  int legendre_impl;            /* 0 = MFMA (default), 1 = plain-FMA check kernels */
+} isca_dyn_config;
+
+/* fills the defaults of the reference's namelists + the Held-Suarez test case values */
+int isca_dyn_config_default(isca_dyn_config *cfg);
+
+/* spectral_dynamics_init + atmosphere_init + hs_forcing_init (tables, device state; no fields yet) */
+int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out);
+int isca_dyn_destroy(isca_dyn_t *h);
+const char *isca_last_error(void);
+
+/* read_restart_or_do_coldstart (spectral_dynamics.F90:580-630) + spectral_initialize_fields */
+int isca_dyn_cold_start(isca_dyn_t *h);
+
+/* atmosphere(Time) x nsteps: hs_forcing -> spectral_dynamics -> time-level rotation
+ * (atmosphere.F90:276-352).  Asynchronous on the handle's stream unless sync != 0. */
+int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync);
+int isca_dyn_synchronize(isca_dyn_t *h);
+
+/* --- multi-GPU: one step split at its two lat<->m exchange points (transforms.F90:970-1056).
+ * phase 0: grid tendencies + FFT            -> send buffer "fwd"
+ * phase 1: Legendre analysis, spectral update, Legendre synthesis -> send buffer "inv"
+ * phase 2: inverse FFT, fixer partial sums  -> 8 doubles to all-reduce (isca_dyn_reduce_buffer)
+ * phase 3: fixers applied, time levels rotated.
+ * The host performs the all-to-all / all-reduce between phases (isca_amd/parallel.py). */
+int isca_dyn_step_phase(isca_dyn_t *h, int phase);
+int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv*/, void **send, void **recv,
+                              size_t *bytes_per_peer);
+int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count);
+
+/* state access in the reference's layouts.  name is one of:
+ *  grid 3-D (lon,lat_local,lev):  "ug","vg","tg","vorg","divg","wg_full","p_full","z_full","tr"
+ *  grid 3-D half levels (lev+1):  "p_half","z_half"
+ *  grid 2-D:                      "psg"
+ *  spectral (m,n,lev) complex:    "vors","divs","ts";  (m,n): "ln_ps"     [global m; local m on world_size>1]
+ * time_level: 0 = previous, 1 = current (ignored for single-level fields). */
+int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_level, double *host, size_t count);
+int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_level, const double *host, size_t count);
+/* after set_state of grid fields: rebuild the spectral side like complete_update_of_future
+ * (spectral_dynamics.F90:1416-1454) for the given time level */
+int isca_dyn_complete_update(isca_dyn_t *h, int time_level);
+
+/* tables: "sin_lat","wts_lat","deg_lat","deg_lon","pk","bk","legendre" (m,n,lat_max/2),
+ * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
+int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
+int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","m_local","kernels_per_step" */
+
+/* --- transforms_mod entry points (host buffers, Fortran layouts; nlev = size of 3rd dim) --- */
+int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev);   /* transforms.F90:379 */
+int isca_trans_grid_to_spherical(isca_dyn_t *h, const double *grid, double *spherical, int nlev, int do_truncation); /* :462 */
+int isca_vor_div_from_uv_grid(isca_dyn_t *h, const double *u, const double *v, double *vor, double *div, int nlev);  /* :742 */
+int isca_uv_grid_from_vor_div(isca_dyn_t *h, const double *vor, const double *div, double *u, double *v, int nlev);  /* :700 */
+int isca_horizontal_advection(isca_dyn_t *h, const double *field_spec, const double *u, const double *v, double *tendency, int nlev); /* :808 */
+int isca_trans_spherical_to_fourier(isca_dyn_t *h, const double *spherical, double *fourier, int nlev); /* spherical_fourier.F90:177; fourier (m, lat, lev) */
+int isca_trans_fourier_to_spherical(isca_dyn_t *h, const double *fourier, double *spherical, int nlev); /* spherical_fourier.F90:264 */
+int isca_trans_grid_to_fourier(isca_dyn_t *h, const double *grid, double *fourier, int nlev);           /* grid_fourier.F90:129; fourier (0:num_fourier, lat, lev) */
+int isca_trans_fourier_to_grid(isca_dyn_t *h, const double *fourier, double *grid, int nlev);           /* grid_fourier.F90:155 */
+int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double *mean);                 /* transforms.F90:1059 */
+
+/* hs_forcing(...) on caller-supplied fields (hs_forcing.F90:148): tendencies are accumulated into udt,vdt,tdt */
+int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
+                    const double *v, const double *t, double *udt, double *vdt, double *tdt);
+
+/* --- benchmarking helpers: transform pair with data resident in HBM ------------------------------
+ * Runs `reps` (s2g, g2s) pairs over nfields level-fields on device buffers owned by the handle and
+ * returns the average time of one pair in milliseconds measured with HIP events on the handle's
+ * stream.  kernel_ms[0..3] = {legendre_inv, fft_inv, fft_fwd, legendre_fwd} per-launch averages. */
+int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, double *pair_ms, double *kernel_ms);
+/* per-kernel average milliseconds over the steps run since the last call (HIP events); names are
+ * returned as a ';'-separated list in `names` */
+int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int max, char *names, size_t names_len, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,60 @@
+"""Build the in-tree HIP shared library isca_amd/lib/libisca_dyn.so for gfx950 (hipcc cross-compiles
+without a GPU).  Used by __graft_entry__.build() and importable on its own: python -m isca_amd.build"""
+import os, subprocess, sys, hashlib, json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libisca_dyn.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+UNITS = [  # (source, extra flags)
+    ("tables.cpp", ["-ffp-contract=off"]),      # host tables: reproduce the reference's non-FMA fp64 results
+    ("kernels.hip", []),
+    ("api.hip", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _digest(paths):
+    h = hashlib.sha1()
+    for p in sorted(paths):
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "isca_dyn.h")]
+    stamp = os.path.join(LIBDIR, "build_stamp.json")
+    dig = _digest(srcs)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and json.load(open(stamp)).get("digest") == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src, extra in UNITS:
+        obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    json.dump({"digest": dig}, open(stamp, "w"))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

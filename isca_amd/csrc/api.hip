@@ -1,0 +1,909 @@
+// C-ABI of the MI355X spectral core (see include/isca_dyn.h for the reference interfaces replaced).
+#include "kernels.h"
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <mutex>
+
+using namespace isca;
+
+static thread_local std::string g_last_error;
+extern "C" const char *isca_last_error(void) { return g_last_error.c_str(); }
+
+#define API_BEGIN try {
+#define API_END                                   \
+  }                                               \
+  catch (const std::exception &e) {               \
+    g_last_error = e.what();                      \
+    return 1;                                     \
+  }                                               \
+  catch (...) {                                   \
+    g_last_error = "unknown error";               \
+    return 1;                                     \
+  }                                               \
+  return 0;
+
+static void fail(const std::string &m) { throw std::runtime_error(m); }
+
+// ---------------------------------------------------------------------------------------------------
+// kernel timing (HIP events on the handle's stream)
+// ---------------------------------------------------------------------------------------------------
+struct Timed {
+  isca_dyn *h;
+  int id = -1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  Timed(isca_dyn *h_, const char *name) : h(h_) {
+    if (!h->timer.enabled) return;
+    auto &t = h->timer;
+    for (size_t i = 0; i < t.names.size(); ++i)
+      if (t.names[i] == name) id = (int)i;
+    if (id < 0) { id = (int)t.names.size(); t.names.push_back(name); t.ms.push_back(0); t.calls.push_back(0); }
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, h->stream);
+  }
+  ~Timed() {
+    if (id < 0) return;
+    hipEventRecord(e1, h->stream);
+    h->timer.ev.push_back(e0); h->timer.ev.push_back(e1); h->timer.ev_name.push_back(id);
+  }
+};
+static void timer_collect(isca_dyn *h) {
+  auto &t = h->timer;
+  if (t.ev.empty()) return;
+  hipStreamSynchronize(h->stream);
+  for (size_t i = 0; i < t.ev_name.size(); ++i) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
+    t.ms[t.ev_name[i]] += ms; t.calls[t.ev_name[i]] += 1;
+    hipEventDestroy(t.ev[2 * i]); hipEventDestroy(t.ev[2 * i + 1]);
+  }
+  t.ev.clear(); t.ev_name.clear();
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+static T *dalloc(isca_dyn *h, size_t n, bool zero = true) {
+  T *p = nullptr;
+  HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+  if (zero) HIP_CHECK(hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)));
+  h->allocs.push_back(p);
+  return p;
+}
+template <typename T>
+static T *dupload(isca_dyn *h, const std::vector<T> &v) {
+  T *p = dalloc<T>(h, v.size(), false);
+  if (!v.empty()) HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+
+extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
+  if (!c) return 1;
+  std::memset(c, 0, sizeof(*c));
+  // spectral_dynamics.F90:152-206 defaults overridden by held_suarez_test_case.py:45-98 (T21)
+  c->lon_max = 64; c->lat_max = 32; c->num_fourier = 21; c->num_spherical = 22; c->num_levels = 25;
+  c->fourier_inc = 1; c->triang_trunc = 1; c->dt_atmos = 600.0;
+  c->damping_order = 4; c->damping_coeff = 1.15740741e-4;
+  c->robert_coeff = 0.04; c->raw_filter_coeff = 1.0; c->alpha_implicit = 0.5;
+  c->reference_sea_level_press = 1.0e5; c->scale_heights = 6.0; c->exponent = 7.5; c->surf_res = 0.5;
+  c->do_mass_correction = 1; c->do_energy_correction = 1; c->do_water_correction = 1;
+  c->water_correction_limit = 200.e2; c->initial_temperature = 264.0; c->initial_sphum = 0.0;
+  c->valid_range_t[0] = 100.; c->valid_range_t[1] = 800.; c->num_tracers = 1;
+  c->t_zero = 315.; c->t_strat = 200.; c->delh = 60.; c->delv = 10.; c->eps = 0.; c->sigma_b = 0.7;
+  c->ka = -40.; c->ks = -4.; c->kf = -1.; c->do_conserve_energy = 1; c->trflux = 1.e-5; c->trsink = -4.; c->P00 = 1.e5;
+  c->rank = 0; c->world_size = 1; c->device = 0; c->stream = nullptr; c->legendre_impl = 0;
+  return 0;
+}
+
+static void check_config(const isca_dyn_config &c) {
+  // check_dynamics_nml (spectral_dynamics.F90:666-755) + what this implementation supports
+  if (c.num_fourier <= 0 || c.num_spherical <= 0 || c.num_levels <= 0) fail("invalid resolution");
+  if (c.fourier_inc != 1) fail("fourier_inc must be 1");
+  if (!c.triang_trunc) fail("only triangular truncation is supported");
+  if (c.num_spherical != c.num_fourier + 1) fail("num_spherical must equal num_fourier+1 (triangular truncation)");
+  if (c.lon_max < 3 * c.num_fourier + 1) fail("number of longitude points is too small for number of fourier waves");
+  if (2 * c.lat_max < 3 * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");
+  if (c.lon_max & (c.lon_max - 1)) fail("lon_max must be a power of two (Stockham FFT kernel)");
+  if (c.lat_max % 8) fail("lat_max must be a multiple of 8");
+  if (c.num_levels > 64) fail("num_levels must be <= 64 (one wavefront lane per level in the spectral update)");
+  if (c.raw_filter_coeff != 1.0) fail("raw_filter_coeff must be 1.0");
+  if (c.robert_coeff < 0. || c.robert_coeff > 1.) fail("invalid robert_coeff");
+  if (c.damping_order < 0 || c.damping_coeff < 0.) fail("invalid damping");
+  if ((c.do_energy_correction) && !c.do_mass_correction) fail("energy_correction requires mass_correction");
+  if (c.world_size < 1 || c.rank < 0 || c.rank >= c.world_size) fail("invalid rank/world_size");
+  if (c.lat_max % c.world_size) fail("lat_max must be divisible by world_size (spec_mpp.F90:69-75)");
+  if (((c.lat_max / c.world_size) * c.lon_max) % 64) fail("local columns must be a multiple of 64");
+  if (c.dt_atmos <= 0) fail("dt_atmos has not been specified");
+}
+
+static void build_field_lists(isca_dyn *h) {
+  const int L = h->g.L;
+  Dev &d = h->d;
+  FieldList &f = h->fl_fwd;
+  f.nf = 5;
+  double *fg[5] = {d.g_dtu, d.g_dtv, d.g_dtT, d.g_E, d.g_dtlp};
+  int off = 0;
+  for (int i = 0; i < 5; ++i) { f.g[i] = fg[i]; f.nlev[i] = (i < 4) ? L : 1; f.off[i] = off; f.op[i] = OP_NONE; off += f.nlev[i]; }
+  f.ncol = off;
+  h->Cf = 2 * f.ncol;
+}
+// inverse batch targets depend on the time level that receives the new state
+static FieldList inverse_list(isca_dyn *h, int tl) {
+  const int L = h->g.L;
+  Dev &d = h->d;
+  FieldList f;
+  f.nf = 10;
+  double *ig[10] = {d.divg, d.vorg, d.ug[tl], d.vg[tl], d.tg[tl], d.dxT, d.dyT, d.psg[tl], d.dxlp, d.dylp};
+  const int ops[10] = {OP_NONE, OP_NONE, OP_COSM, OP_COSM, OP_NONE, OP_COSM, OP_COSM, OP_EXP, OP_COSM, OP_COSM};
+  int off = 0;
+  for (int i = 0; i < 10; ++i) { f.g[i] = ig[i]; f.nlev[i] = (i < 7) ? L : 1; f.off[i] = off; f.op[i] = ops[i]; off += f.nlev[i]; }
+  f.ncol = off;
+  return f;
+}
+
+extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
+  if (!h) return 0;
+  timer_collect(h);
+  for (void *p : h->allocs) hipFree(p);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+static void upload_wave_matrices(isca_dyn *h, double delta_t) {
+  if (h->wave_dt == delta_t) return;
+  h->tab.build_wave_matrices(h->cfg, delta_t);     // implicit.F90:260-264: rebuilt when dt changes
+  const int L = h->g.L, nw = h->cfg.num_spherical;
+  std::vector<double> wt((size_t)nw * L * L);
+  for (int w = 0; w < nw; ++w)
+    for (int k = 0; k < L; ++k)
+      for (int k2 = 0; k2 < L; ++k2) wt[((size_t)w * L + k2) * L + k] = h->tab.wave_matrix[((size_t)w * L + k) * L + k2];
+  HIP_CHECK(hipMemcpyAsync(h->d.wave_mat_t, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->wave_dt = delta_t;
+}
+
+extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
+  isca_dyn *h = nullptr;
+  try {
+    if (!cfg || !out) fail("null argument");
+    check_config(*cfg);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      fail("no HIP device available: the MI355X spectral core has no CPU fallback");
+    HIP_CHECK(hipSetDevice(cfg->device));
+    h = new isca_dyn();
+    h->cfg = *cfg;
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else { HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    h->tab.build(*cfg);
+    Tables &T = h->tab;
+    Geom &g = h->g;
+    g.I = T.I; g.J = T.J; g.M1 = T.M1; g.N1 = T.N1; g.L = T.L;
+    g.P = cfg->world_size; g.rank = cfg->rank; g.Jl = g.J / g.P; g.j0 = g.rank * g.Jl; g.Jh = g.J / 2;
+    g.Ml = (g.M1 + g.P - 1) / g.P;
+    g.NHP = (((g.N1 + 1) / 2) + 15) / 16 * 16;
+    g.log2I = 0; while ((1 << g.log2I) < g.I) ++g.log2I;
+    if (g.M1 > g.I / 2) fail("num_fourier too large for lon_max");
+    // ---- wavenumber dealing: boustrophedon over ranks for triangular load balance
+    h->h_m_of_slot.assign((size_t)g.P * g.Ml, -1);
+    h->h_slot_of_m.assign(g.M1, 0);
+    for (int idx = 0; idx < g.P * g.Ml; ++idx) {
+      const int r = idx / g.P, pos = idx % g.P;
+      const int q = (r % 2 == 0) ? pos : g.P - 1 - pos;
+      if (idx < g.M1) { h->h_m_of_slot[(size_t)q * g.Ml + r] = idx; h->h_slot_of_m[idx] = q * g.Ml + r; }
+    }
+    h->h_m_local.assign(g.Ml, -1);
+    for (int ml = 0; ml < g.Ml; ++ml) h->h_m_local[ml] = h->h_m_of_slot[(size_t)g.rank * g.Ml + ml];
+    h->ml_of_m0 = -1;
+    for (int ml = 0; ml < g.Ml; ++ml) if (h->h_m_local[ml] == 0) h->ml_of_m0 = ml;
+    Dev &d = h->d;
+    std::memset(&d, 0, sizeof(d));
+    d.m_of_slot = dupload(h, h->h_m_of_slot);
+    d.slot_of_m = dupload(h, h->h_slot_of_m);
+    d.m_local = dupload(h, h->h_m_local);
+    // ---- latitude tables of the local band
+    auto band = [&](const std::vector<double> &v) { return std::vector<double>(v.begin() + g.j0, v.begin() + g.j0 + g.Jl); };
+    d.cosm_lat_l = dupload(h, band(T.cosm_lat)); d.wts_lat_l = dupload(h, band(T.wts_lat));
+    d.coriolis_l = dupload(h, band(T.coriolis)); d.sin_lat_l = dupload(h, band(T.sin_lat));
+    d.rad_lat_l = dupload(h, band(T.rad_lat)); d.wts_lat_g = dupload(h, T.wts_lat);
+    // ---- Legendre tables for the local wavenumbers, parity-split (spherical_fourier.F90:376-394)
+    {
+      std::vector<double> pw((size_t)g.Ml * 2 * g.Jh * g.NHP, 0.0), pi((size_t)g.Ml * 2 * g.NHP * g.Jh, 0.0);
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_local[ml];
+        if (m < 0) continue;
+        for (int n = 0; n < g.N1; ++n) {
+          const int par = n & 1, nh = n >> 1;
+          for (int jp = 0; jp < g.Jh; ++jp) {
+            const double p = T.legendre[((size_t)jp * g.N1 + n) * g.M1 + m];
+            pw[(((size_t)ml * 2 + par) * g.Jh + jp) * g.NHP + nh] = p * T.wts_hem[jp];
+            pi[(((size_t)ml * 2 + par) * g.NHP + nh) * g.Jh + jp] = p;
+          }
+        }
+      }
+      d.pw_fwd = dupload(h, pw);
+      d.p_inv = dupload(h, pi);
+    }
+    {  // coefficient tables per local m
+      const std::vector<double> *src[11] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
+                                            &T.coef_dym, &T.coef_dx, &T.coef_dyp, &T.tri_mask, &T.damping};
+      std::vector<double> cf((size_t)11 * g.Ml * g.N1, 0.0);
+      for (int id = 0; id < 11; ++id)
+        for (int ml = 0; ml < g.Ml; ++ml) {
+          const int m = h->h_m_local[ml];
+          if (m < 0) continue;
+          for (int n = 0; n < g.N1; ++n) cf[((size_t)id * g.Ml + ml) * g.N1 + n] = (*src[id])[(size_t)n * g.M1 + m];
+        }
+      d.coef = dupload(h, cf);
+    }
+    d.pk = dupload(h, T.pk); d.bk = dupload(h, T.bk); d.dpk = dupload(h, T.dpk); d.dbk = dupload(h, T.dbk);
+    {
+      std::vector<double> iv(5 * 64, 0.0);
+      for (int k = 0; k < g.L; ++k) {
+        iv[0 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_full[k];
+        iv[1 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_half[k];
+        iv[2 * 64 + k] = T.dpk[k] + T.dbk[k] * T.ref_surf_p;
+        iv[3 * 64 + k] = T.h_impl[k];
+        iv[4 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_full[k];
+      }
+      for (int k = g.L; k < 64; ++k) iv[2 * 64 + k] = 1.0;
+      d.impl_vec = dupload(h, iv);
+    }
+    d.wave_mat_t = dalloc<double>(h, (size_t)cfg->num_spherical * g.L * g.L);
+    {
+      std::vector<double> tw((size_t)g.I);
+      for (int k = 0; k < g.I / 2; ++k) { tw[2 * k] = T.tw_re[k]; tw[2 * k + 1] = T.tw_im[k]; }
+      d.tw = dupload(h, tw);
+    }
+    // ---- state
+    const size_t ng3 = (size_t)g.L * g.Jl * g.I, ng2 = (size_t)g.Jl * g.I;
+    const size_t ns3 = (size_t)g.Ml * g.N1 * g.L * 2, ns2 = (size_t)g.Ml * g.N1 * 2;
+    for (int t = 0; t < 2; ++t) {
+      d.ug[t] = dalloc<double>(h, ng3); d.vg[t] = dalloc<double>(h, ng3); d.tg[t] = dalloc<double>(h, ng3);
+      d.psg[t] = dalloc<double>(h, ng2); d.tr[t] = dalloc<double>(h, ng3);
+      d.vors[t] = dalloc<double>(h, ns3); d.divs[t] = dalloc<double>(h, ns3); d.ts[t] = dalloc<double>(h, ns3);
+      d.lnps[t] = dalloc<double>(h, ns2);
+    }
+    d.vorg = dalloc<double>(h, ng3); d.divg = dalloc<double>(h, ng3); d.dxT = dalloc<double>(h, ng3); d.dyT = dalloc<double>(h, ng3);
+    d.dxlp = dalloc<double>(h, ng2); d.dylp = dalloc<double>(h, ng2); d.wg_full = dalloc<double>(h, ng3);
+    d.g_dtu = dalloc<double>(h, ng3); d.g_dtv = dalloc<double>(h, ng3); d.g_dtT = dalloc<double>(h, ng3);
+    d.g_E = dalloc<double>(h, ng3); d.g_dtlp = dalloc<double>(h, ng2);
+    d.s_dtvor = dalloc<double>(h, ns3); d.s_dtdiv = dalloc<double>(h, ns3); d.s_dtT = dalloc<double>(h, ns3); d.s_dtlp = dalloc<double>(h, ns2);
+    // ---- work buffers sized for the largest batch (7L+3 level-fields)
+    h->cap_cols = 7 * g.L + 3;
+    const size_t nF = (size_t)g.P * g.Ml * g.Jl * 2 * h->cap_cols, nS = (size_t)g.Ml * g.N1 * 2 * h->cap_cols;
+    d.Ff_g = dalloc<double>(h, nF); d.Fi_s = dalloc<double>(h, nF);
+    if (g.P == 1) { d.Ff_s = d.Ff_g; d.Fi_g = d.Fi_s; }
+    else { d.Ff_s = dalloc<double>(h, nF); d.Fi_g = dalloc<double>(h, nF); }
+    d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
+    d.partials = dalloc<double>(h, 8 * (ng2 / 64 + 1));
+    d.red = dalloc<double>(h, 16);
+    for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
+    build_field_lists(h);
+    h->Ci = 2 * (7 * g.L + 3);
+    h->kernels_per_step = 13;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipDeviceSynchronize());
+    *out = h;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    if (h) isca_dyn_destroy(h);
+    return 1;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// batched transforms on device buffers (single rank: the two Fourier-side views coincide)
+// ---------------------------------------------------------------------------------------------------
+static void require_single(isca_dyn *h, const char *what) {
+  if (h->g.P != 1) fail(std::string(what) + ": only available with world_size == 1 (use the phase API)");
+}
+static void run_inverse(isca_dyn *h, const FieldList &fl, int full) {    // Si -> grid
+  const int C = 2 * fl.ncol;
+  { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, C, full, h->cfg.legendre_impl, h->stream); }
+  { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
+}
+static void run_forward(isca_dyn *h, const FieldList &fl, int full) {    // grid -> Sf
+  const int C = 2 * fl.ncol;
+  { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, fl, h->d.Ff_g, h->stream); }
+  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, C, full, h->cfg.legendre_impl, h->stream); }
+}
+static FieldList single_list(double *gptr, int nlev, int op) {
+  FieldList f; f.nf = 1; f.ncol = nlev; f.g[0] = gptr; f.nlev[0] = nlev; f.off[0] = 0; f.op[0] = op; return f;
+}
+static FieldList pair_list(double *a, double *b, int nlev, int op) {
+  FieldList f; f.nf = 2; f.ncol = 2 * nlev; f.g[0] = a; f.g[1] = b; f.nlev[0] = f.nlev[1] = nlev; f.off[0] = 0; f.off[1] = nlev; f.op[0] = f.op[1] = op; return f;
+}
+// device spectral state [ml][n][nlev] -> grid (trans_spherical_to_grid)
+static void dev_s2g(isca_dyn *h, const double *spec, double *grid, int nlev, int op) {
+  FieldList fl = single_list(grid, nlev, op);
+  launch_spec_pack(h->g, spec, h->d.Si, 2 * fl.ncol, 0, nlev, h->stream);
+  run_inverse(h, fl, 1);
+}
+static void dev_g2s(isca_dyn *h, double *grid, double *spec, int nlev, int do_trunc, int op) {
+  FieldList fl = single_list(grid, nlev, op);
+  run_forward(h, fl, 1);
+  launch_spec_unpack(h->g, h->d, h->d.Sf, spec, 2 * fl.ncol, 0, nlev, do_trunc, h->stream);
+}
+static void dev_uv_from_vd(isca_dyn *h, const double *vor, const double *div, double *u, double *v, int nlev) {
+  FieldList fl = pair_list(u, v, nlev, OP_COSM);
+  launch_spec_ucos_vcos(h->g, h->d, vor, div, h->d.Si, 2 * fl.ncol, 0, nlev, nlev, h->stream);
+  run_inverse(h, fl, 1);
+}
+static void dev_vd_from_uv(isca_dyn *h, double *u, double *v, double *vor, double *div, int nlev) {
+  FieldList fl = pair_list(u, v, nlev, OP_COSM);
+  run_forward(h, fl, 1);
+  launch_spec_vor_div(h->g, h->d, h->d.Sf, 2 * fl.ncol, 0, nlev, vor, div, nlev, h->stream);
+}
+
+// all grid fields at time level tl (+ vorg, divg, gradients) from the spectral state at tl
+static void synthesize_level(isca_dyn *h, int tl) {
+  FieldList fl = inverse_list(h, tl);
+  { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, tl, h->stream); }
+  run_inverse(h, fl, 0);
+}
+
+// host (m,n,lev) Fortran <-> device [ml][n][lev] complex
+static void spec_host_to_dev(isca_dyn *h, const double *host, double *dev, int nlev) {
+  const Geom &g = h->g;
+  std::vector<double> tmp((size_t)g.Ml * g.N1 * nlev * 2, 0.0);
+  for (int k = 0; k < nlev; ++k)
+    for (int n = 0; n < g.N1; ++n)
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_local[ml];
+        if (m < 0) continue;
+        const size_t src = (((size_t)k * g.N1 + n) * g.M1 + m) * 2, dst = (((size_t)ml * g.N1 + n) * nlev + k) * 2;
+        tmp[dst] = host[src]; tmp[dst + 1] = host[src + 1];
+      }
+  HIP_CHECK(hipMemcpyAsync(dev, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+// fills only the wavenumbers this rank owns; others are left untouched in `host`
+static void spec_dev_to_host(isca_dyn *h, const double *dev, double *host, int nlev) {
+  const Geom &g = h->g;
+  std::vector<double> tmp((size_t)g.Ml * g.N1 * nlev * 2);
+  HIP_CHECK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int k = 0; k < nlev; ++k)
+    for (int n = 0; n < g.N1; ++n)
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_local[ml];
+        if (m < 0) continue;
+        const size_t dst = (((size_t)k * g.N1 + n) * g.M1 + m) * 2, src = (((size_t)ml * g.N1 + n) * nlev + k) * 2;
+        host[dst] = tmp[src]; host[dst + 1] = tmp[src + 1];
+      }
+}
+static void h2d(isca_dyn *h, double *dev, const double *host, size_t n) {
+  HIP_CHECK(hipMemcpyAsync(dev, host, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+static void d2h(isca_dyn *h, double *host, const double *dev, size_t n) {
+  HIP_CHECK(hipMemcpyAsync(host, dev, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+static void dcopy(isca_dyn *h, double *dst, const double *src, size_t n) {
+  HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cold start: spectral_initialize_fields.F90:45-135 + spectral_dynamics.F90:580-630
+// ---------------------------------------------------------------------------------------------------
+static void cold_start_single(isca_dyn *h) {
+  const Geom &g = h->g;
+  Dev &d = h->d;
+  const int L = g.L;
+  const size_t ng3 = (size_t)L * g.Jl * g.I, ng2 = (size_t)g.Jl * g.I;
+  const size_t ns3 = (size_t)g.Ml * g.N1 * L * 2, ns2 = (size_t)g.Ml * g.N1 * 2;
+  std::vector<double> vors0((size_t)L * g.N1 * g.M1 * 2, 0.0);
+  const int pert[4][2] = {{1, 3}, {5, 3}, {1, 2}, {5, 2}};
+  for (auto &mn : pert)
+    if (mn[0] < g.M1 && mn[1] < g.N1)
+      for (int k = L - 3; k < L; ++k)
+        if (k >= 0) vors0[(((size_t)k * g.N1 + mn[1]) * g.M1 + mn[0]) * 2] = 1.e-7;
+  spec_host_to_dev(h, vors0.data(), d.vors[0], L);
+  HIP_CHECK(hipMemsetAsync(d.divs[0], 0, ns3 * sizeof(double), h->stream));
+  dev_uv_from_vd(h, d.vors[0], d.divs[0], d.ug[0], d.vg[0], L);
+  std::vector<double> tg(ng3, h->cfg.initial_temperature), lnp(ng2, std::log(h->cfg.reference_sea_level_press));
+  h2d(h, d.tg[0], tg.data(), ng3);
+  h2d(h, d.psg[0], lnp.data(), ng2);                       // flat topography: ln ps = log(p_ref)
+  dev_g2s(h, d.tg[0], d.ts[0], L, 1, OP_NONE);
+  dev_s2g(h, d.ts[0], d.tg[0], L, OP_NONE);
+  dev_g2s(h, d.psg[0], d.lnps[0], 1, 1, OP_NONE);
+  dev_vd_from_uv(h, d.ug[0], d.vg[0], d.vors[0], d.divs[0], L);
+  // ug, vg, tg, psg = exp(ln ps), vorg, divg and the gradient fields in one synthesis batch
+  synthesize_level(h, 0);
+  for (auto pr : {std::make_pair(d.ug[1], d.ug[0]), std::make_pair(d.vg[1], d.vg[0]), std::make_pair(d.tg[1], d.tg[0])})
+    dcopy(h, pr.first, pr.second, ng3);
+  dcopy(h, d.psg[1], d.psg[0], ng2);
+  dcopy(h, d.vors[1], d.vors[0], ns3); dcopy(h, d.divs[1], d.divs[0], ns3); dcopy(h, d.ts[1], d.ts[0], ns3);
+  dcopy(h, d.lnps[1], d.lnps[0], ns2);
+  std::vector<double> tr(ng3, h->cfg.initial_sphum);
+  h2d(h, d.tr[0], tr.data(), ng3); h2d(h, d.tr[1], tr.data(), ng3);
+  HIP_CHECK(hipMemsetAsync(d.wg_full, 0, ng3 * sizeof(double), h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true;
+}
+
+static const char *GRID3[] = {"ug", "vg", "tg", "tr"};
+static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t &count, int &kind) {
+  // kind: 0 grid (device layout = host layout), 1 spectral 3-D, 2 spectral 2-D
+  const Geom &g = h->g;
+  Dev &d = h->d;
+  const size_t ng3 = (size_t)g.L * g.Jl * g.I, ng2 = (size_t)g.Jl * g.I;
+  const int tl = (tlev == 0) ? h->previous : h->current;
+  kind = 0;
+  if (name == "ug") { count = ng3; return d.ug[tl]; }
+  if (name == "vg") { count = ng3; return d.vg[tl]; }
+  if (name == "tg") { count = ng3; return d.tg[tl]; }
+  if (name == "tr") { count = ng3; return d.tr[tl]; }
+  if (name == "psg") { count = ng2; return d.psg[tl]; }
+  if (name == "vorg") { count = ng3; return d.vorg; }
+  if (name == "divg") { count = ng3; return d.divg; }
+  if (name == "wg_full") { count = ng3; return d.wg_full; }
+  if (name == "dxT") { count = ng3; return d.dxT; }
+  if (name == "dyT") { count = ng3; return d.dyT; }
+  if (name == "dxlp") { count = ng2; return d.dxlp; }
+  if (name == "dylp") { count = ng2; return d.dylp; }
+  if (name == "g_dtu") { count = ng3; return d.g_dtu; }
+  if (name == "g_dtv") { count = ng3; return d.g_dtv; }
+  if (name == "g_dtT") { count = ng3; return d.g_dtT; }
+  if (name == "g_E") { count = ng3; return d.g_E; }
+  if (name == "g_dtlp") { count = ng2; return d.g_dtlp; }
+  kind = 1;
+  count = (size_t)g.L * g.N1 * g.M1 * 2;
+  if (name == "vors") return d.vors[tl];
+  if (name == "divs") return d.divs[tl];
+  if (name == "ts") return d.ts[tl];
+  if (name == "s_dtvor") return d.s_dtvor;
+  if (name == "s_dtdiv") return d.s_dtdiv;
+  if (name == "s_dtT") return d.s_dtT;
+  kind = 2;
+  count = (size_t)g.N1 * g.M1 * 2;
+  if (name == "ln_ps") return d.lnps[tl];
+  if (name == "s_dtlp") return d.s_dtlp;
+  (void)GRID3;
+  return nullptr;
+}
+
+extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_level, double *host, size_t count) {
+  API_BEGIN
+  if (!h || !name || !host) fail("null argument");
+  const Geom &g = h->g;
+  const std::string nm(name);
+  const size_t ng2 = (size_t)g.Jl * g.I;
+  if (nm == "p_full" || nm == "p_half" || nm == "z_full" || nm == "z_half") {
+    // compute_pressures_and_heights of the requested level (atmosphere.F90:229-241, 331-338)
+    const int tl = (time_level == 0) ? h->previous : h->current;
+    double *pf = h->d.scratch_g[0], *ph = h->d.scratch_g[1], *zf = h->d.scratch_g[2], *zh = h->d.scratch_g[3];
+    launch_pressures_heights(*h, h->d.tg[tl], h->d.psg[tl], pf, ph, zf, zh, h->stream);
+    const bool half = (nm == "p_half" || nm == "z_half");
+    const size_t need = ng2 * (g.L + (half ? 1 : 0));
+    if (count != need) fail("get_state: wrong element count for " + nm);
+    d2h(h, host, nm == "p_full" ? pf : nm == "p_half" ? ph : nm == "z_full" ? zf : zh, need);
+    return 0;
+  }
+  size_t cnt; int kind;
+  double *p = state_ptr(h, nm, time_level, cnt, kind);
+  if (!p) fail("get_state: unknown field " + nm);
+  if (cnt != count) fail("get_state: wrong element count for " + nm);
+  if (kind == 0) d2h(h, host, p, cnt);
+  else spec_dev_to_host(h, p, host, kind == 1 ? g.L : 1);
+  API_END
+}
+
+extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_level, const double *host, size_t count) {
+  API_BEGIN
+  if (!h || !name || !host) fail("null argument");
+  size_t cnt; int kind;
+  double *p = state_ptr(h, name, time_level, cnt, kind);
+  if (!p) fail(std::string("set_state: unknown field ") + name);
+  if (cnt != count) fail(std::string("set_state: wrong element count for ") + name);
+  if (kind == 0) h2d(h, p, host, cnt);
+  else spec_host_to_dev(h, host, p, kind == 1 ? h->g.L : 1);
+  h->have_state = true;
+  API_END
+}
+
+// complete_update_of_future (spectral_dynamics.F90:1416-1454): rebuild the spectral side of a level from
+// its grid fields, then every derived grid field of that level
+extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
+  API_BEGIN
+  require_single(h, "complete_update");
+  const int tl = (time_level == 0) ? h->previous : h->current;
+  Dev &d = h->d;
+  const int L = h->g.L;
+  const size_t ng2 = (size_t)h->g.Jl * h->g.I;
+  dev_vd_from_uv(h, d.ug[tl], d.vg[tl], d.vors[tl], d.divs[tl], L);
+  dev_g2s(h, d.tg[tl], d.ts[tl], L, 1, OP_NONE);
+  std::vector<double> ps(ng2);
+  d2h(h, ps.data(), d.psg[tl], ng2);
+  for (auto &x : ps) x = std::log(x);
+  h2d(h, d.scratch_g[0], ps.data(), ng2);
+  dev_g2s(h, d.scratch_g[0], d.lnps[tl], 1, 1, OP_NONE);
+  if (tl == h->current) {
+    // keep the caller's grid values: only the derived fields (vorg, divg, gradients) are regenerated
+    std::vector<double> u((size_t)L * ng2), v((size_t)L * ng2), t((size_t)L * ng2), p(ng2);
+    d2h(h, u.data(), d.ug[tl], u.size()); d2h(h, v.data(), d.vg[tl], v.size()); d2h(h, t.data(), d.tg[tl], t.size()); d2h(h, p.data(), d.psg[tl], ng2);
+    synthesize_level(h, tl);
+    h2d(h, d.ug[tl], u.data(), u.size()); h2d(h, d.vg[tl], v.data(), v.size()); h2d(h, d.tg[tl], t.data(), t.size()); h2d(h, d.psg[tl], p.data(), ng2);
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the time step: atmosphere.F90:276-352 -> spectral_dynamics.F90:780-1034
+// ---------------------------------------------------------------------------------------------------
+static StepScalars step_scalars(isca_dyn *h) {
+  StepScalars sc;
+  sc.prev = h->previous; sc.cur = h->current;
+  sc.delta_t = (sc.prev == sc.cur) ? h->cfg.dt_atmos : 2 * h->cfg.dt_atmos;
+  sc.fut = (sc.prev == sc.cur) ? 1 - sc.cur : sc.prev;
+  sc.xi = sc.delta_t * h->cfg.alpha_implicit;
+  return sc;
+}
+static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
+  { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
+  { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
+}
+static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
+  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, 0, h->cfg.legendre_impl, h->stream); }
+  { Timed t(h, "spec_tendencies"); launch_spec_tendencies(*h, h->stream); }
+  { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
+  { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
+  { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream); }
+}
+static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
+  FieldList fl = inverse_list(h, sc.fut);
+  { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
+  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
+}
+static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
+  { Timed t(h, "fixer_finalize"); launch_fixer_finalize(*h, sc, h->stream); }
+  { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc.fut, h->stream); }
+  h->previous = sc.cur;
+  h->current = sc.fut;
+  h->step_count += 1;
+}
+
+extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  if (!h->have_state) fail("isca_dyn_step: no state (call isca_dyn_cold_start or set_state first)");
+  require_single(h, "isca_dyn_step");
+  for (int i = 0; i < nsteps; ++i) {
+    const StepScalars sc = step_scalars(h);
+    upload_wave_matrices(h, sc.delta_t);
+    phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
+  }
+  if (sync) {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    // valid-range check (spectral_dynamics.F90:940-972) on demand: a NaN/blow-up shows in the fixer scalars
+    double red[16];
+    HIP_CHECK(hipMemcpy(red, h->d.red, sizeof(red), hipMemcpyDeviceToHost));
+    if (!(std::isfinite(red[8]) && std::isfinite(red[9]))) fail("temperatures out of valid range (non-finite state)");
+  }
+  API_END
+}
+extern "C" int isca_dyn_synchronize(isca_dyn_t *h) {
+  API_BEGIN
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  API_END
+}
+
+extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
+  API_BEGIN
+  if (!h || !h->have_state) fail("isca_dyn_step_phase: no state");
+  const StepScalars sc = step_scalars(h);
+  switch (phase) {
+    case 0: upload_wave_matrices(h, sc.delta_t); phase0(h, sc); break;
+    case 1: phase1(h, sc); break;
+    case 2: phase2(h, sc); break;
+    case 3: phase3(h, sc); break;
+    default: fail("invalid phase");
+  }
+  API_END
+}
+extern "C" int isca_dyn_exchange_buffers(isca_dyn_t *h, int which, void **send, void **recv, size_t *bytes_per_peer) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const int C = which == 0 ? h->Cf : h->Ci;
+  if (which == 0) { *send = h->d.Ff_g; *recv = h->d.Ff_s; }
+  else if (which == 1) { *send = h->d.Fi_s; *recv = h->d.Fi_g; }
+  else fail("invalid buffer id");
+  *bytes_per_peer = (size_t)g.Ml * g.Jl * C * sizeof(double);
+  API_END
+}
+extern "C" int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count) {
+  API_BEGIN
+  *buf = h->d.red; *count = 5;
+  API_END
+}
+
+extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  if (h->g.P == 1) { cold_start_single(h); return 0; }
+  // multi-rank: every rank computes the (cheap) global cold start on its own GPU with a single-rank
+  // handle and keeps its latitude band / wavenumber set
+  isca_dyn_config c1 = h->cfg;
+  c1.rank = 0; c1.world_size = 1; c1.stream = nullptr;
+  isca_dyn_t *g1 = nullptr;
+  if (isca_dyn_create(&c1, &g1)) fail(std::string("cold start: ") + isca_last_error());
+  try {
+    cold_start_single(g1);
+    const Geom &g = h->g;
+    const Geom &G = g1->g;
+    const size_t NG3 = (size_t)G.L * G.J * G.I, NG2 = (size_t)G.J * G.I;
+    std::vector<double> big(NG3), loc((size_t)g.L * g.Jl * g.I);
+    auto grid3 = [&](double *src, double *dst, int nlev) {
+      d2h(g1, big.data(), src, (size_t)nlev * NG2);
+      for (int k = 0; k < nlev; ++k)
+        std::memcpy(&loc[(size_t)k * g.Jl * g.I], &big[((size_t)k * G.J + g.j0) * G.I], (size_t)g.Jl * g.I * sizeof(double));
+      h2d(h, dst, loc.data(), (size_t)nlev * g.Jl * g.I);
+    };
+    for (int t = 0; t < 2; ++t) {
+      grid3(g1->d.ug[t], h->d.ug[t], g.L); grid3(g1->d.vg[t], h->d.vg[t], g.L); grid3(g1->d.tg[t], h->d.tg[t], g.L);
+      grid3(g1->d.tr[t], h->d.tr[t], g.L); grid3(g1->d.psg[t], h->d.psg[t], 1);
+    }
+    grid3(g1->d.vorg, h->d.vorg, g.L); grid3(g1->d.divg, h->d.divg, g.L); grid3(g1->d.dxT, h->d.dxT, g.L);
+    grid3(g1->d.dyT, h->d.dyT, g.L); grid3(g1->d.dxlp, h->d.dxlp, 1); grid3(g1->d.dylp, h->d.dylp, 1);
+    std::vector<double> sp((size_t)G.L * G.N1 * G.M1 * 2);
+    auto spec = [&](double *src, double *dst, int nlev) {
+      spec_dev_to_host(g1, src, sp.data(), nlev);
+      spec_host_to_dev(h, sp.data(), dst, nlev);
+    };
+    for (int t = 0; t < 2; ++t) {
+      spec(g1->d.vors[t], h->d.vors[t], g.L); spec(g1->d.divs[t], h->d.divs[t], g.L);
+      spec(g1->d.ts[t], h->d.ts[t], g.L); spec(g1->d.lnps[t], h->d.lnps[t], 1);
+    }
+    h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true;
+  } catch (...) { isca_dyn_destroy(g1); throw; }
+  isca_dyn_destroy(g1);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count) {
+  API_BEGIN
+  const Tables &T = h->tab;
+  const std::string nm(name);
+  const std::vector<double> *v = nullptr;
+  std::vector<double> tmp;
+  if (nm == "sin_lat") v = &T.sin_lat; else if (nm == "wts_lat") v = &T.wts_lat; else if (nm == "deg_lat") v = &T.deg_lat;
+  else if (nm == "deg_lon") v = &T.deg_lon; else if (nm == "pk") v = &T.pk; else if (nm == "bk") v = &T.bk;
+  else if (nm == "legendre") v = &T.legendre; else if (nm == "eigen_laplacian") v = &T.eigen;
+  else if (nm == "sin_hem") v = &T.sin_hem; else if (nm == "wts_hem") v = &T.wts_hem;
+  else if (nm == "wave_matrix") {
+    if (T.wave_dt < 0) fail("wave matrices not built yet (run a step)");
+    const int L = T.L, nw = h->cfg.num_spherical;
+    tmp.resize((size_t)nw * L * L);
+    for (int w = 0; w < nw; ++w) for (int k = 0; k < L; ++k) for (int k2 = 0; k2 < L; ++k2)
+      tmp[((size_t)w * L + k2) * L + k] = T.wave_matrix[((size_t)w * L + k) * L + k2];   // Fortran (k,k2,w)
+    v = &tmp;
+  } else if (nm == "fixer") {
+    tmp.resize(16);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    HIP_CHECK(hipMemcpy(tmp.data(), h->d.red, 16 * sizeof(double), hipMemcpyDeviceToHost));
+    v = &tmp;
+  }
+  if (!v) fail("unknown table " + nm);
+  if (v->size() != count) fail("get_table: wrong element count for " + nm + " (have " + std::to_string(v->size()) + ")");
+  std::memcpy(host, v->data(), count * sizeof(double));
+  API_END
+}
+extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
+  API_BEGIN
+  const std::string nm(name);
+  if (nm == "step") *value = h->step_count; else if (nm == "previous") *value = h->previous;
+  else if (nm == "current") *value = h->current; else if (nm == "lat_local") *value = h->g.Jl;
+  else if (nm == "lat_start") *value = h->g.j0;
+  else if (nm == "m_local") *value = h->g.Ml; else if (nm == "kernels_per_step") *value = h->kernels_per_step;
+  else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
+  else fail("unknown info " + nm);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
+// transforms_mod entry points on host buffers
+// ---------------------------------------------------------------------------------------------------
+static void check_nlev(isca_dyn *h, int nlev) {
+  if (nlev < 1 || nlev > h->g.L + 1) fail("nlev must be between 1 and num_levels+1");
+}
+extern "C" int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_spherical_to_grid"); check_nlev(h, nlev);
+  spec_host_to_dev(h, spherical, h->d.scratch_s[0], nlev);
+  dev_s2g(h, h->d.scratch_s[0], h->d.scratch_g[0], nlev, OP_NONE);
+  d2h(h, grid, h->d.scratch_g[0], (size_t)nlev * h->g.Jl * h->g.I);
+  API_END
+}
+extern "C" int isca_trans_grid_to_spherical(isca_dyn_t *h, const double *grid, double *spherical, int nlev, int do_truncation) {
+  API_BEGIN
+  require_single(h, "trans_grid_to_spherical"); check_nlev(h, nlev);
+  h2d(h, h->d.scratch_g[0], grid, (size_t)nlev * h->g.Jl * h->g.I);
+  dev_g2s(h, h->d.scratch_g[0], h->d.scratch_s[0], nlev, do_truncation, OP_NONE);
+  spec_dev_to_host(h, h->d.scratch_s[0], spherical, nlev);
+  API_END
+}
+extern "C" int isca_vor_div_from_uv_grid(isca_dyn_t *h, const double *u, const double *v, double *vor, double *div, int nlev) {
+  API_BEGIN
+  require_single(h, "vor_div_from_uv_grid"); check_nlev(h, nlev);
+  const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
+  h2d(h, h->d.scratch_g[0], u, n); h2d(h, h->d.scratch_g[1], v, n);
+  dev_vd_from_uv(h, h->d.scratch_g[0], h->d.scratch_g[1], h->d.scratch_s[0], h->d.scratch_s[1], nlev);
+  spec_dev_to_host(h, h->d.scratch_s[0], vor, nlev); spec_dev_to_host(h, h->d.scratch_s[1], div, nlev);
+  API_END
+}
+extern "C" int isca_uv_grid_from_vor_div(isca_dyn_t *h, const double *vor, const double *div, double *u, double *v, int nlev) {
+  API_BEGIN
+  require_single(h, "uv_grid_from_vor_div"); check_nlev(h, nlev);
+  const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
+  spec_host_to_dev(h, vor, h->d.scratch_s[0], nlev); spec_host_to_dev(h, div, h->d.scratch_s[1], nlev);
+  dev_uv_from_vd(h, h->d.scratch_s[0], h->d.scratch_s[1], h->d.scratch_g[0], h->d.scratch_g[1], nlev);
+  d2h(h, u, h->d.scratch_g[0], n); d2h(h, v, h->d.scratch_g[1], n);
+  API_END
+}
+extern "C" int isca_horizontal_advection(isca_dyn_t *h, const double *field_spec, const double *u, const double *v, double *tendency, int nlev) {
+  API_BEGIN
+  require_single(h, "horizontal_advection"); check_nlev(h, nlev);
+  if (nlev > h->g.L) fail("horizontal_advection: nlev must be <= num_levels");
+  const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
+  Dev &d = h->d;
+  spec_host_to_dev(h, field_spec, d.scratch_s[0], nlev);
+  FieldList fl = pair_list(d.scratch_g[0], d.scratch_g[1], nlev, OP_COSM);
+  launch_spec_gradient(h->g, d, d.scratch_s[0], d.Si, 2 * fl.ncol, 0, nlev, nlev, h->stream);
+  run_inverse(h, fl, 1);
+  h2d(h, d.scratch_g[2], u, n); h2d(h, d.scratch_g[3], v, n);
+  // tendency buffer: reuse g_E as scratch only when no step is in flight (host-synchronous API)
+  double *tend = d.g_E;
+  h2d(h, tend, tendency, n);
+  launch_hadv_combine(h->g, d.scratch_g[2], d.scratch_g[3], d.scratch_g[0], d.scratch_g[1], tend, nlev, h->stream);
+  d2h(h, tendency, tend, n);
+  API_END
+}
+// Legendre / Fourier stages exposed separately (spherical_fourier.F90:177,264; grid_fourier.F90:129,155).
+// host fourier layout: (m, lat, lev) complex with m = 0..num_fourier
+static void fourier_host_to_dev(isca_dyn *h, const double *host, double *dev, int nlev) {
+  const Geom &g = h->g;
+  const int C = 2 * nlev;
+  std::vector<double> tmp((size_t)g.Ml * g.Jl * C, 0.0);
+  for (int k = 0; k < nlev; ++k) for (int j = 0; j < g.J; ++j) for (int m = 0; m < g.M1; ++m) {
+    const size_t src = (((size_t)k * g.J + j) * g.M1 + m) * 2, dst = ((size_t)h->h_slot_of_m[m] * g.Jl + j) * C + 2 * k;
+    tmp[dst] = host[src]; tmp[dst + 1] = host[src + 1];
+  }
+  h2d(h, dev, tmp.data(), tmp.size());
+}
+static void fourier_dev_to_host(isca_dyn *h, const double *dev, double *host, int nlev) {
+  const Geom &g = h->g;
+  const int C = 2 * nlev;
+  std::vector<double> tmp((size_t)g.Ml * g.Jl * C);
+  d2h(h, tmp.data(), dev, tmp.size());
+  for (int k = 0; k < nlev; ++k) for (int j = 0; j < g.J; ++j) for (int m = 0; m < g.M1; ++m) {
+    const size_t dst = (((size_t)k * g.J + j) * g.M1 + m) * 2, src = ((size_t)h->h_slot_of_m[m] * g.Jl + j) * C + 2 * k;
+    host[dst] = tmp[src]; host[dst + 1] = tmp[src + 1];
+  }
+}
+extern "C" int isca_trans_spherical_to_fourier(isca_dyn_t *h, const double *spherical, double *fourier, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_spherical_to_fourier"); check_nlev(h, nlev);
+  spec_host_to_dev(h, spherical, h->d.scratch_s[0], nlev);
+  launch_spec_pack(h->g, h->d.scratch_s[0], h->d.Si, 2 * nlev, 0, nlev, h->stream);
+  launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, 2 * nlev, 1, h->cfg.legendre_impl, h->stream);
+  fourier_dev_to_host(h, h->d.Fi_s, fourier, nlev);
+  API_END
+}
+extern "C" int isca_trans_fourier_to_spherical(isca_dyn_t *h, const double *fourier, double *spherical, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_fourier_to_spherical"); check_nlev(h, nlev);
+  fourier_host_to_dev(h, fourier, h->d.Ff_s, nlev);
+  launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, 2 * nlev, 1, h->cfg.legendre_impl, h->stream);
+  launch_spec_unpack(h->g, h->d, h->d.Sf, h->d.scratch_s[0], 2 * nlev, 0, nlev, 0, h->stream);
+  spec_dev_to_host(h, h->d.scratch_s[0], spherical, nlev);
+  API_END
+}
+extern "C" int isca_trans_grid_to_fourier(isca_dyn_t *h, const double *grid, double *fourier, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_grid_to_fourier"); check_nlev(h, nlev);
+  h2d(h, h->d.scratch_g[0], grid, (size_t)nlev * h->g.Jl * h->g.I);
+  FieldList fl = single_list(h->d.scratch_g[0], nlev, OP_NONE);
+  launch_fft_forward(h->g, h->d, fl, h->d.Ff_g, h->stream);
+  fourier_dev_to_host(h, h->d.Ff_g, fourier, nlev);
+  API_END
+}
+extern "C" int isca_trans_fourier_to_grid(isca_dyn_t *h, const double *fourier, double *grid, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_fourier_to_grid"); check_nlev(h, nlev);
+  fourier_host_to_dev(h, fourier, h->d.Fi_g, nlev);
+  FieldList fl = single_list(h->d.scratch_g[0], nlev, OP_NONE);
+  launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream);
+  d2h(h, grid, h->d.scratch_g[0], (size_t)nlev * h->g.Jl * h->g.I);
+  API_END
+}
+extern "C" int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double *mean) {
+  API_BEGIN
+  // transforms.F90:1059-1077 -- a host-side convenience (the step uses the fused device reduction)
+  const Tables &T = h->tab;
+  double s = 0.0, sw = 0.0;
+  for (int j = 0; j < T.J; ++j) { sw += T.wts_lat[j]; for (int i = 0; i < T.I; ++i) s += T.wts_lat[j] * field2d[(size_t)j * T.I + i]; }
+  *mean = s / (sw * T.I);
+  API_END
+}
+extern "C" int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
+                               const double *v, const double *t, double *udt, double *vdt, double *tdt) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n3 = (size_t)g.L * g.Jl * g.I, n3h = (size_t)(g.L + 1) * g.Jl * g.I;
+  std::vector<double *> dv;
+  auto up = [&](const double *src, size_t n) { double *p; HIP_CHECK(hipMalloc((void **)&p, n * sizeof(double))); h2d(h, p, src, n); dv.push_back(p); return p; };
+  double *dph = up(p_half, n3h), *dpf = up(p_full, n3), *du = up(u, n3), *dvv = up(v, n3), *dt_ = up(t, n3);
+  double *dud = up(udt, n3), *dvd = up(vdt, n3), *dtd = up(tdt, n3);
+  launch_hs_forcing(*h, dt, dph, dpf, du, dvv, dt_, dud, dvd, dtd, h->stream);
+  d2h(h, udt, dud, n3); d2h(h, vdt, dvd, n3); d2h(h, tdt, dtd, n3);
+  for (double *p : dv) hipFree(p);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
+// benchmarking helpers
+// ---------------------------------------------------------------------------------------------------
+extern "C" int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, double *pair_ms, double *kernel_ms) {
+  API_BEGIN
+  require_single(h, "bench_transform_pair");
+  const Geom &g = h->g;
+  if (nfields < 1 || nfields > h->cap_cols) fail("nfields out of range");
+  double *grid = nullptr;
+  const size_t ngrid = (size_t)nfields * g.Jl * g.I;
+  HIP_CHECK(hipMalloc((void **)&grid, ngrid * sizeof(double)));
+  // band-limited random coefficients already in Si (deterministic LCG), synthesised once
+  {
+    std::vector<double> s((size_t)g.Ml * g.N1 * 2 * nfields, 0.0);
+    unsigned long long st = 20260927ULL;
+    for (int ml = 0; ml < g.Ml; ++ml) for (int n = 0; n < g.N1 - 1 - h->h_m_local[ml]; ++n) for (int c = 0; c < 2 * nfields; ++c) {
+      st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+      const double r = ((double)(st >> 11) / 9007199254740992.0) - 0.5;
+      const double tot = h->h_m_local[ml] + n;
+      s[((size_t)ml * g.N1 + n) * 2 * nfields + c] = (h->h_m_local[ml] == 0 && (c & 1)) ? 0.0 : r / ((1 + tot) * (1 + tot));
+    }
+    h2d(h, h->d.Si, s.data(), s.size());
+  }
+  FieldList fl = single_list(grid, nfields, OP_NONE);
+  const int C = 2 * nfields;
+  hipEvent_t ev[5][2];
+  for (auto &e : ev) { hipEventCreate(&e[0]); hipEventCreate(&e[1]); }
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int r = -2; r < reps; ++r) {
+    hipEventRecord(ev[4][0], h->stream);
+    hipEventRecord(ev[0][0], h->stream); launch_legendre_inverse(g, h->d, h->d.Si, h->d.Fi_s, C, 0, h->cfg.legendre_impl, h->stream); hipEventRecord(ev[0][1], h->stream);
+    hipEventRecord(ev[1][0], h->stream); launch_fft_inverse(g, h->d, fl, h->d.Fi_g, h->stream); hipEventRecord(ev[1][1], h->stream);
+    hipEventRecord(ev[2][0], h->stream); launch_fft_forward(g, h->d, fl, h->d.Ff_g, h->stream); hipEventRecord(ev[2][1], h->stream);
+    hipEventRecord(ev[3][0], h->stream); launch_legendre_forward(g, h->d, h->d.Ff_s, h->d.Sf, C, 0, h->cfg.legendre_impl, h->stream); hipEventRecord(ev[3][1], h->stream);
+    hipEventRecord(ev[4][1], h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (r >= 0) for (int i = 0; i < 5; ++i) { float ms; hipEventElapsedTime(&ms, ev[i][0], ev[i][1]); acc[i] += ms; }
+  }
+  for (auto &e : ev) { hipEventDestroy(e[0]); hipEventDestroy(e[1]); }
+  *pair_ms = acc[4] / reps;
+  for (int i = 0; i < 4; ++i) kernel_ms[i] = acc[i] / reps;
+  hipFree(grid);
+  API_END
+}
+
+extern "C" int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int max, char *names, size_t names_len, int *n) {
+  API_BEGIN
+  timer_collect(h);
+  auto &t = h->timer;
+  int cnt = 0;
+  std::string nm;
+  for (size_t i = 0; i < t.names.size() && (int)i < max; ++i) {
+    ms[i] = t.calls[i] ? t.ms[i] / t.calls[i] : 0.0;
+    nm += t.names[i]; nm += ';';
+    ++cnt;
+  }
+  if (names && names_len) { std::strncpy(names, nm.c_str(), names_len - 1); names[names_len - 1] = 0; }
+  if (n) *n = cnt;
+  t.names.clear(); t.ms.clear(); t.calls.clear();
+  t.enabled = enable != 0;
+  API_END
+}

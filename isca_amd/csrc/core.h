@@ -1,0 +1,105 @@
+// Device-side state of one isca_dyn handle (one rank = one GPU = one latitude band + one m-set).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "tables.h"
+
+namespace isca {
+
+#define HIP_CHECK(expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                               ":" + std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+constexpr int MAX_FIELDS = 12;
+
+// One batched transform = a list of level-fields.  Grid side: pointers to [nlev][Jl][I] arrays.
+// Column index of (field f, level k, re/im) in the Fourier / spectral work buffers: 2*(off[f]+k)+ri.
+enum GridOp { OP_NONE = 0, OP_COSM = 1, OP_EXP = 2 };
+struct FieldList {
+  int nf;
+  int ncol;                 // real level-fields = sum(nlev)
+  double *g[MAX_FIELDS];    // grid arrays
+  int nlev[MAX_FIELDS];
+  int off[MAX_FIELDS];
+  int op[MAX_FIELDS];       // applied to grid values: inverse: after FFT; forward: before FFT
+};
+
+// geometry shared by all kernels
+struct Geom {
+  int I, J, Jl, j0;         // lon points, global lats, local lats, first local lat (global index)
+  int M1, N1, L;            // num_fourier+1, num_spherical+1, levels
+  int P, rank, Ml;          // ranks, this rank, local m slots (padded)
+  int Jh;                   // J/2
+  int NHP;                  // padded count of n per parity (multiple of 16)
+  int log2I;
+};
+
+struct Dev {
+  // ---- tables
+  double *cosm_lat_l, *wts_lat_l, *coriolis_l, *sin_lat_l, *rad_lat_l;   // [Jl] local latitudes
+  double *wts_lat_g;                                                      // [J]
+  int *m_of_slot;            // [P*Ml]   global m of (rank q, local slot), -1 if padding
+  int *slot_of_m;            // [M1]     q*Ml + ml
+  int *m_local;              // [Ml]     global m of my slots
+  // Legendre tables for my m slots, MFMA-friendly: parity-split, n-half index padded to NHP
+  double *pw_fwd;            // [Ml][2][Jh][NHP]   P(m,n,j')*w(j'), n = 2*nh+par   (analysis A operand)
+  double *p_inv;             // [Ml][2][NHP][Jh]   P(m,n,j')                       (synthesis A operand)
+  double *coef;              // [9][Ml][N1]: eigen,uvm,uvc,uvp,alpm,alpp,dym,dx,dyp ; [9]=mask ; [10]=damping
+  double *pk, *bk, *dpk, *dbk;
+  double *wave_mat_t;        // [num_spherical][L(k')][L(k)]  transposed wave matrices
+  double *tau_t, *gamma_t;   // unused by the scan formulation; kept for checks
+  double *impl_vec;          // [6][L+1]: ref_ln_p_half, ref_ln_p_full, h, dp_ref, ...
+  double *tw;                // [I/2][2] twiddles exp(-2 pi i k/I)
+  // ---- prognostic state
+  double *ug[2], *vg[2], *tg[2], *psg[2], *tr[2];   // grid, two time levels
+  double *vorg, *divg, *dxT, *dyT, *dxlp, *dylp;    // grid, at `current`
+  double *wg_full;
+  double *vors[2], *divs[2], *ts[2], *lnps[2];      // spectral [Ml][N1][L] complex ; lnps [Ml][N1]
+  // ---- work
+  double *g_dtu, *g_dtv, *g_dtT, *g_E, *g_dtlp;     // forward-batch grid inputs
+  double *Ff_g, *Ff_s, *Fi_s, *Fi_g;                // Fourier buffers (grid side / spectral side)
+  double *Sf, *Si;                                  // spectral work [Ml][N1][Cf], [Ml][N1][Ci]
+  double *s_dtvor, *s_dtdiv, *s_dtT, *s_dtlp;       // spectral tendencies [Ml][N1][L]
+  double *partials;                                 // block partial sums
+  double *red;                                      // [16] reduction results / fixer scalars
+  double *scratch_g[4], *scratch_s[4];              // API transforms
+};
+
+struct KernelTimer {
+  bool enabled = false;
+  std::vector<std::string> names;
+  std::vector<double> ms;
+  std::vector<long> calls;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> ev_name;
+};
+
+}  // namespace isca
+
+struct isca_dyn {
+  isca_dyn_config cfg;
+  isca::Tables tab;
+  isca::Geom g;
+  isca::Dev d;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int previous = 0, current = 0;
+  long step_count = 0;
+  bool have_state = false;
+  int Cf, Ci;                       // doubles per (m,j) row in forward / inverse Fourier buffers
+  isca::FieldList fl_fwd, fl_inv;
+  std::vector<void *> allocs;
+  isca::KernelTimer timer;
+  size_t nblocks_col = 0;
+  int kernels_per_step = 0;
+  double wave_dt = -1.0;
+  int ml_of_m0 = -1;
+  std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
+  int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
+};

@@ -1,0 +1,47 @@
+// Launchers for the gfx950 kernels of the spectral core (definitions in kernels.hip).
+#pragma once
+#include "core.h"
+
+namespace isca {
+
+struct StepScalars {      // per-step scalars passed by value to kernels
+  double delta_t;         // dt or 2 dt
+  double xi;              // alpha_implicit * delta_t
+  int prev, cur, fut;
+};
+
+// ---- transforms
+void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s);
+void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s);
+void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s);
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s);
+
+// ---- spectral-space kernels
+// pack a spectral state array [Ml][N1][nlev] (complex) into columns of a work buffer, and back
+void launch_spec_pack(const Geom &g, const double *state, double *S, int C, int coloff, int nlev, hipStream_t s);
+void launch_spec_unpack(const Geom &g, const Dev &d, const double *S, double *state, int C, int coloff, int nlev, int mask, hipStream_t s);
+// (vor,div) state -> (ucos,vcos) columns ; (ucos,vcos) columns -> masked (vor,div) state ; gradient_cos
+void launch_spec_ucos_vcos(const Geom &g, const Dev &d, const double *vor, const double *div, double *S, int C, int col_u, int col_v, int nlev, hipStream_t s);
+void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s);
+void launch_spec_gradient(const Geom &g, const Dev &d, const double *state, double *S, int C, int col_dx, int col_dy, int nlev, hipStream_t s);
+
+// the time step in spectral space
+void launch_spec_tendencies(const isca_dyn &h, hipStream_t s);                       // S1
+void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s);    // S2
+void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s);         // S3
+
+// ---- grid-space kernels
+void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
+void launch_fixer_finalize(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2
+void launch_fixer_apply(const isca_dyn &h, int fut, hipStream_t s);         // R3
+void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const double *p_full, const double *u,
+                       const double *v, const double *t, double *udt, double *vdt, double *tdt, hipStream_t s);
+void launch_pressures_heights(const isca_dyn &h, const double *t, const double *ps, double *p_full, double *p_half,
+                              double *z_full, double *z_half, hipStream_t s);
+void launch_hadv_combine(const Geom &g, const double *u, const double *v, const double *dx, const double *dy, double *tend, int nlev, hipStream_t s);
+void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStream_t s);   // a *= cosm_lat (divide_by_cos)
+
+size_t column_partials_count(const isca_dyn &h);
+
+}  // namespace isca

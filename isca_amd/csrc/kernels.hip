@@ -1,0 +1,1079 @@
+// gfx950 (CDNA4, wave64) kernels of the spectral dynamical core.  Written for MI355X only.
+//
+// Data layouts (device):
+//   grid fields      [lev][lat_local][lon]            (= the reference's Fortran (lon,lat,lev))
+//   Fourier buffers  [slot = q*Ml+ml][lat_local][C]   C doubles per row: 2*(level-field)+re/im; grid
+//                    side indexes slot by owner (q,ml) of wavenumber m, spectral side by source rank
+//                    p = j/Jl of latitude j -- the two coincide on one GPU, and differ by exactly one
+//                    all-to-all otherwise (transforms.F90:970-1056).
+//   spectral work    [ml][n][C]
+//   spectral state   [ml][n][lev] complex
+#include "kernels.h"
+
+namespace isca {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 cscale(double s, double2 a) { return make_double2(s * a.x, s * a.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 ctimes_i(double2 a) { return make_double2(-a.y, a.x); }   // cmplx(-aimag, real)
+
+enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP, C_MASK, C_DAMP, C_COUNT };
+
+// =====================================================================================================
+// Longitude FFT (grid_fourier.F90:129-179, fft99.F90:578-727): real <-> half-complex of length I = 2^p,
+// done as one complex Stockham FFT of length I/2 per row in LDS + the even/odd split.
+// One block = R rows (R consecutive level-fields at one latitude), 256 threads.
+// =====================================================================================================
+template <int R>
+__global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const double *__restrict__ cosm,
+                                                 const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
+                                                 double *__restrict__ Fg, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Nc = g.I >> 1, rs = Nc + 1;
+  double2 *buf0 = (double2 *)smem, *buf1 = buf0 + R * rs;
+  constexpr int TPR = 256 / R;
+  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  const int jl = blockIdx.y;
+  {
+    const int c = blockIdx.x * R + r;
+    const double2 *src = nullptr;
+    double scale = 1.0;
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      const int k = c - fl.off[f];
+      src = (const double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
+      if (fl.op[f] == OP_COSM) scale = cosm[jl];
+    }
+    for (int n = tr; n < Nc; n += TPR) {
+      double2 z = make_double2(0., 0.);
+      if (src) { z = src[n]; z.x *= scale; z.y *= scale; }
+      buf0[r * rs + n] = z;
+    }
+  }
+  __syncthreads();
+  double2 *x = buf0, *y = buf1;
+  for (int n = Nc, s = 1; n > 1; n >>= 1, s <<= 1) {
+    const int m = n >> 1;
+    for (int b = tr; b < (Nc >> 1); b += TPR) {
+      const int p = b / s, q = b - p * s;
+      const double2 a = x[r * rs + q + s * p], bb = x[r * rs + q + s * (p + m)];
+      const double2 w = tw[2 * p * s];
+      y[r * rs + q + s * (2 * p)] = cadd(a, bb);
+      y[r * rs + q + s * (2 * p + 1)] = cmul(csub(a, bb), w);
+    }
+    __syncthreads();
+    double2 *tmp = x; x = y; y = tmp;
+  }
+  // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
+  const int rr = t % R, cc = blockIdx.x * R + rr;
+  const double inv_n = 1.0 / (double)g.I;
+  for (int m = t / R; m < g.M1; m += 256 / R) {
+    const double2 zk = x[rr * rs + m];
+    const double2 zc = cconj(x[rr * rs + ((Nc - m) & (Nc - 1))]);
+    const double2 e = cscale(0.5, cadd(zk, zc));
+    const double2 dd = csub(zk, zc);
+    const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+    double2 X = cadd(e, cmul(tw[m], o));
+    X.x *= inv_n; X.y *= inv_n;
+    if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc) = X;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const double *__restrict__ cosm,
+                                                 const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
+                                                 const double *__restrict__ Fg, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Nc = g.I >> 1, rs = Nc + 1;
+  double2 *buf0 = (double2 *)smem, *buf1 = buf0 + R * rs;
+  constexpr int TPR = 256 / R;
+  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  const int jl = blockIdx.y;
+  {  // load truncated coefficients m = 0..M (transforms.F90:424 zeroes everything above)
+    const int rr = t % R, cc = blockIdx.x * R + rr;
+    for (int m = t / R; m < Nc; m += 256 / R) {
+      double2 X = make_double2(0., 0.);
+      if (m < g.M1 && cc < fl.ncol) {
+        X = *(const double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc);
+        if (m == 0) X.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
+      }
+      buf0[rr * rs + m] = X;
+    }
+  }
+  __syncthreads();
+  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0
+  for (int k = tr; k < Nc; k += TPR) {
+    const double2 xk = buf0[r * rs + k];
+    const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf0[r * rs + Nc - k]);
+    const double2 e = cadd(xk, xc);
+    const double2 o = cmul(cconj(tw[k]), csub(xk, xc));
+    buf1[r * rs + k] = make_double2(e.x - o.y, e.y + o.x);
+  }
+  __syncthreads();
+  double2 *x = buf1, *y = buf0;
+  for (int n = Nc, s = 1; n > 1; n >>= 1, s <<= 1) {
+    const int m = n >> 1;
+    for (int b = tr; b < (Nc >> 1); b += TPR) {
+      const int p = b / s, q = b - p * s;
+      const double2 a = x[r * rs + q + s * p], bb = x[r * rs + q + s * (p + m)];
+      const double2 w = cconj(tw[2 * p * s]);
+      y[r * rs + q + s * (2 * p)] = cadd(a, bb);
+      y[r * rs + q + s * (2 * p + 1)] = cmul(csub(a, bb), w);
+    }
+    __syncthreads();
+    double2 *tmp = x; x = y; y = tmp;
+  }
+  const int c = blockIdx.x * R + r;
+  if (c < fl.ncol) {
+    int f = 0;
+    while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+    const int k = c - fl.off[f];
+    double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
+    const int op = fl.op[f];
+    const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
+    for (int n = tr; n < Nc; n += TPR) {
+      double2 z = x[r * rs + n];
+      if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
+      else { z.x *= scale; z.y *= scale; }
+      dst[n] = z;
+    }
+  }
+}
+
+static inline int fft_rows_per_block(int I) { return I >= 512 ? 8 : 16; }
+
+void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
+  const int C = 2 * fl.ncol;
+  const int R = fft_rows_per_block(g.I);
+  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
+  const size_t lds = (size_t)2 * R * (g.I / 2 + 1) * sizeof(double2);
+  if (R == 16) hipLaunchKernelGGL(k_fft_fwd<16>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+  else         hipLaunchKernelGGL(k_fft_fwd<8>,  grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+}
+void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
+  const int C = 2 * fl.ncol;
+  const int R = fft_rows_per_block(g.I);
+  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
+  const size_t lds = (size_t)2 * R * (g.I / 2 + 1) * sizeof(double2);
+  if (R == 16) hipLaunchKernelGGL(k_fft_inv<16>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+  else         hipLaunchKernelGGL(k_fft_inv<8>,  grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+}
+
+// =====================================================================================================
+// Legendre transforms (spherical_fourier.F90:177-339) as per-m dense contractions on the FP64 matrix
+// cores: v_mfma_f64_16x16x4_f64, one wavefront per (zonal wavenumber m, 16 columns), hemispheric
+// even/odd folding, triangular loop bounds (rows n < N1-m only unless `full`).
+//   A operand: lane l holds A[row = l&15][k = l>>4];  B: B[k = l>>4][col = l&15]
+//   C/D: lane l, reg r  ->  row = (l>>4) + 4 r, col = l&15
+// =====================================================================================================
+__device__ __forceinline__ size_t frow(const Geom &g, int j, int ml, int C) {   // spectral-side row of latitude j
+  const int p = j / g.Jl, jl = j - p * g.Jl;
+  return ((size_t)(p * g.Ml + ml) * g.Jl + jl) * C;
+}
+
+template <int JH4>
+__global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
+                                                      const double *__restrict__ pw, const double *__restrict__ Fs,
+                                                      double *__restrict__ S, int C, int full) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ml = blockIdx.y, m = m_local[ml];
+  if (m < 0) return;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  if (c0 >= C) return;
+  const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
+  const bool cok = c < C;
+  double be[JH4], bo[JH4];
+#pragma unroll
+  for (int ks = 0; ks < JH4; ++ks) {
+    const int jp = ks * 4 + kq;
+    double xs = 0., xn = 0.;
+    if (cok) {
+      xs = Fs[frow(g, jp, ml, C) + c];
+      xn = Fs[frow(g, g.J - 1 - jp, ml, C) + c];
+    }
+    be[ks] = xn + xs;      // x_even = F(north) + F(south)   (:311)
+    bo[ks] = xn - xs;      // x_odd  = F(north) - F(south)   (:312)
+  }
+  const int nlim = full ? g.N1 : g.N1 - m;
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int cnt = (nlim - par + 1) >> 1;
+    const int ntile = (cnt + 15) >> 4;
+    const double *A = pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP;
+    for (int tile = 0; tile < ntile; ++tile) {
+      double4_t acc = {0., 0., 0., 0.};
+#pragma unroll
+      for (int ks = 0; ks < JH4; ++ks) {
+        const double a = A[(size_t)(ks * 4 + kq) * g.NHP + tile * 16 + cl];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, par ? bo[ks] : be[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 2 * (tile * 16 + kq + 4 * r) + par;
+        if (n < g.N1 && cok) S[((size_t)ml * g.N1 + n) * C + c] = acc[r];
+      }
+    }
+  }
+}
+
+template <int JT>
+__device__ __forceinline__ void leg_inv_parity(const Geom &g, const double *__restrict__ A, const double *__restrict__ S,
+                                               int ml, int par, int nlim, int C, int c, bool cok, int cl, int kq,
+                                               double4_t (&acc)[JT]) {
+  const int cnt = (nlim - par + 1) >> 1;
+  const int nks = (cnt + 3) >> 2;
+  for (int ks = 0; ks < nks; ++ks) {
+    const int nh = ks * 4 + kq, n = 2 * nh + par;
+    const double b = (n < nlim && cok) ? S[((size_t)ml * g.N1 + n) * C + c] : 0.0;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+      const double a = A[(size_t)nh * g.Jh + jt * 16 + cl];
+      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+    }
+  }
+}
+
+template <int JT>
+__global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
+                                                      const double *__restrict__ pinv, const double *__restrict__ S,
+                                                      double *__restrict__ Fs, int C, int full) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ml = blockIdx.y, m = m_local[ml];
+  if (m < 0) return;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  if (c0 >= C) return;
+  const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
+  const bool cok = c < C;
+  const int nlim = full ? g.N1 : g.N1 - m;
+  double4_t accE[JT], accO[JT];
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt) { accE[jt] = (double4_t){0., 0., 0., 0.}; accO[jt] = (double4_t){0., 0., 0., 0.}; }
+  leg_inv_parity<JT>(g, pinv + ((size_t)(ml * 2 + 0) * g.NHP) * g.Jh, S, ml, 0, nlim, C, c, cok, cl, kq, accE);
+  leg_inv_parity<JT>(g, pinv + ((size_t)(ml * 2 + 1) * g.NHP) * g.Jh, S, ml, 1, nlim, C, c, cok, cl, kq, accO);
+  if (!cok) return;
+#pragma unroll
+  for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int jp = jt * 16 + kq + 4 * r;
+      const double e = accE[jt][r], o = accO[jt][r];
+      Fs[frow(g, jp, ml, C) + c] = e - o;                 // southern row  (:235)
+      Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;       // northern mirror (:236)
+    }
+}
+
+// plain-FMA check kernels (legendre_impl = 1, and lat_max not a multiple of 32)
+__global__ void k_leg_fwd_simple(Geom g, const int *__restrict__ m_local, const double *__restrict__ pw,
+                                 const double *__restrict__ Fs, double *__restrict__ S, int C, int full) {
+  const int c = blockIdx.x * 64 + threadIdx.x, n = blockIdx.y, ml = blockIdx.z;
+  const int m = m_local[ml];
+  if (m < 0 || c >= C) return;
+  const int nlim = full ? g.N1 : g.N1 - m;
+  if (n >= nlim) return;
+  const int par = n & 1, nh = n >> 1;
+  const double *A = pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP + nh;
+  double acc = 0.0;
+  for (int jp = 0; jp < g.Jh; ++jp) {
+    const double xs = Fs[frow(g, jp, ml, C) + c], xn = Fs[frow(g, g.J - 1 - jp, ml, C) + c];
+    acc += (par ? (xn - xs) : (xn + xs)) * A[(size_t)jp * g.NHP];
+  }
+  S[((size_t)ml * g.N1 + n) * C + c] = acc;
+}
+__global__ void k_leg_inv_simple(Geom g, const int *__restrict__ m_local, const double *__restrict__ pinv,
+                                 const double *__restrict__ S, double *__restrict__ Fs, int C, int full) {
+  const int c = blockIdx.x * 64 + threadIdx.x, jp = blockIdx.y, ml = blockIdx.z;
+  const int m = m_local[ml];
+  if (m < 0 || c >= C) return;
+  const int nlim = full ? g.N1 : g.N1 - m;
+  double e = 0.0, o = 0.0;
+  for (int n = 0; n < nlim; ++n) {
+    const int par = n & 1, nh = n >> 1;
+    const double p = pinv[((size_t)(ml * 2 + par) * g.NHP + nh) * g.Jh + jp];
+    const double sv = S[((size_t)ml * g.N1 + n) * C + c];
+    if (par) o += sv * p; else e += sv * p;
+  }
+  Fs[frow(g, jp, ml, C) + c] = e - o;
+  Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;
+}
+
+static bool mfma_ok(const Geom &g, int impl) { return impl == 0 && (g.J % 32 == 0) && g.Jh / 4 <= 64; }
+
+void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
+  if (mfma_ok(g, impl)) {
+    dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
+#define LF(N) hipLaunchKernelGGL(k_leg_fwd_mfma<N>, grid, dim3(256), 0, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
+    switch (g.Jh / 4) {
+      case 4: LF(4); break;   case 8: LF(8); break;   case 16: LF(16); break;
+      case 32: LF(32); break; case 64: LF(64); break;
+      default: throw std::runtime_error("legendre_forward: unsupported lat_max for the MFMA kernel");
+    }
+#undef LF
+  } else {
+    dim3 grid((C + 63) / 64, g.N1, g.Ml);
+    hipLaunchKernelGGL(k_leg_fwd_simple, grid, dim3(64), 0, s, g, d.m_local, d.pw_fwd, Fs, S, C, full);
+  }
+}
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s) {
+  if (mfma_ok(g, impl) && g.Jh / 16 <= 8) {
+    dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
+#define LI(N) hipLaunchKernelGGL(k_leg_inv_mfma<N>, grid, dim3(256), 0, s, g, d.m_local, d.p_inv, S, Fs, C, full)
+    switch (g.Jh / 16) {
+      case 1: LI(1); break; case 2: LI(2); break; case 4: LI(4); break; case 8: LI(8); break;
+      default: throw std::runtime_error("legendre_inverse: unsupported lat_max for the MFMA kernel");
+    }
+#undef LI
+  } else {
+    dim3 grid((C + 63) / 64, g.Jh, g.Ml);
+    hipLaunchKernelGGL(k_leg_inv_simple, grid, dim3(64), 0, s, g, d.m_local, d.p_inv, S, Fs, C, full);
+  }
+}
+
+// =====================================================================================================
+// Spectral-space operators (tools/spherical.F90:270-600).  State arrays are [ml][n][lev] complex.
+// =====================================================================================================
+#define COEF(id, ml, n) coef[((size_t)(id) * g.Ml + (ml)) * g.N1 + (n)]
+
+__global__ void k_spec_pack(Geom g, const double2 *__restrict__ st, double *__restrict__ S, int C, int coloff, int nlev) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const int k = idx % nlev;
+  const size_t mn = idx / nlev;
+  *(double2 *)(S + mn * C + 2 * (coloff + k)) = st[idx];
+}
+__global__ void k_spec_unpack(Geom g, const double *__restrict__ coef, const double *__restrict__ S,
+                              double2 *__restrict__ st, int C, int coloff, int nlev, int mask) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const int k = idx % nlev;
+  const size_t mn = idx / nlev;
+  double2 v = *(const double2 *)(S + mn * C + 2 * (coloff + k));
+  if (mask) { const double mk = coef[(size_t)C_MASK * g.Ml * g.N1 + mn]; v.x *= mk; v.y *= mk; }
+  st[idx] = v;
+}
+// compute_ucos_vcos (spherical.F90:409-469)
+__global__ void k_spec_ucos_vcos(Geom g, const double *__restrict__ coef, const double2 *__restrict__ vor,
+                                 const double2 *__restrict__ div, double *__restrict__ S, int C, int col_u, int col_v, int nlev) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const int k = idx % nlev;
+  const size_t mn = idx / nlev;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  const double2 vo = vor[idx], dv = div[idx];
+  double2 u = cscale(COEF(C_UVC, ml, n), ctimes_i(dv));
+  double2 v = cscale(COEF(C_UVC, ml, n), ctimes_i(vo));
+  if (n >= 1) {
+    const double cm = COEF(C_UVM, ml, n);
+    u = cadd(u, cscale(cm, vor[idx - nlev]));
+    v = csub(v, cscale(cm, div[idx - nlev]));
+  }
+  if (n + 1 < g.N1) {
+    const double cp = COEF(C_UVP, ml, n);
+    u = csub(u, cscale(cp, vor[idx + nlev]));
+    v = cadd(v, cscale(cp, div[idx + nlev]));
+  }
+  *(double2 *)(S + mn * C + 2 * (col_u + k)) = u;
+  *(double2 *)(S + mn * C + 2 * (col_v + k)) = v;
+}
+// compute_vor_div (spherical.F90:472-561) + triangular truncation (:564-600)
+__device__ __forceinline__ void alpha_pair(const Geom &g, const double *__restrict__ coef, const double *__restrict__ S,
+                                           int C, size_t mn, int ml, int n, int cu, int cv, double2 &vor, double2 &div) {
+  const double2 U = *(const double2 *)(S + mn * C + 2 * cu), V = *(const double2 *)(S + mn * C + 2 * cv);
+  const double dx = COEF(C_DX, ml, n);
+  vor = cscale(dx, ctimes_i(V));
+  div = cscale(dx, ctimes_i(U));
+  if (n >= 1) {
+    const double am = COEF(C_ALPM, ml, n);
+    const double2 Um = *(const double2 *)(S + (mn - 1) * C + 2 * cu), Vm = *(const double2 *)(S + (mn - 1) * C + 2 * cv);
+    vor = cadd(vor, cscale(am, Um));     // alpha(v,u,-1): - (-1) alpm u(n-1)
+    div = csub(div, cscale(am, Vm));     // alpha(u,v,+1): - alpm v(n-1)
+  }
+  if (n + 1 < g.N1) {
+    const double ap = COEF(C_ALPP, ml, n);
+    const double2 Up = *(const double2 *)(S + (mn + 1) * C + 2 * cu), Vp = *(const double2 *)(S + (mn + 1) * C + 2 * cv);
+    vor = csub(vor, cscale(ap, Up));
+    div = cadd(div, cscale(ap, Vp));
+  }
+  const double mk = COEF(C_MASK, ml, n);
+  vor = cscale(mk, vor);
+  div = cscale(mk, div);
+}
+__global__ void k_spec_vor_div(Geom g, const double *__restrict__ coef, const double *__restrict__ S, int C, int col_u,
+                               int col_v, double2 *__restrict__ vor, double2 *__restrict__ div, int nlev) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const int k = idx % nlev;
+  const size_t mn = idx / nlev;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  double2 vo, dv;
+  alpha_pair(g, coef, S, C, mn, ml, n, col_u + k, col_v + k, vo, dv);
+  vor[idx] = vo;
+  div[idx] = dv;
+}
+// compute_gradient_cos (spherical.F90:270-351)
+__global__ void k_spec_gradient(Geom g, const double *__restrict__ coef, const double2 *__restrict__ st,
+                                double *__restrict__ S, int C, int col_dx, int col_dy, int nlev) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const int k = idx % nlev;
+  const size_t mn = idx / nlev;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  const double2 dx = cscale(COEF(C_DX, ml, n), ctimes_i(st[idx]));
+  double2 dy = make_double2(0., 0.);
+  if (n >= 1) dy = cscale(-COEF(C_DYM, ml, n), st[idx - nlev]);
+  if (n + 1 < g.N1) dy = cadd(dy, cscale(COEF(C_DYP, ml, n), st[idx + nlev]));
+  *(double2 *)(S + mn * C + 2 * (col_dx + k)) = dx;
+  *(double2 *)(S + mn * C + 2 * (col_dy + k)) = dy;
+}
+
+static inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+void launch_spec_pack(const Geom &g, const double *state, double *S, int C, int coloff, int nlev, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_pack, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, (const double2 *)state, S, C, coloff, nlev);
+}
+void launch_spec_unpack(const Geom &g, const Dev &d, const double *S, double *state, int C, int coloff, int nlev, int mask, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_unpack, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, S, (double2 *)state, C, coloff, nlev, mask);
+}
+void launch_spec_ucos_vcos(const Geom &g, const Dev &d, const double *vor, const double *div, double *S, int C, int col_u, int col_v, int nlev, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_ucos_vcos, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, (const double2 *)vor, (const double2 *)div, S, C, col_u, col_v, nlev);
+}
+void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_vor_div, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, S, C, col_u, col_v, (double2 *)vor, (double2 *)div, nlev);
+}
+void launch_spec_gradient(const Geom &g, const Dev &d, const double *state, double *S, int C, int col_dx, int col_dy, int nlev, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_gradient, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, (const double2 *)state, S, C, col_dx, col_dy, nlev);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// S1: spectral tendencies from the forward batch (spectral_dynamics.F90:874,891,900-904).
+// Forward-batch columns: [0,L) dt_u/cos, [L,2L) dt_v/cos, [2L,3L) dt_T, [3L,4L) Phi+KE, 4L: dt_ln_ps
+// -----------------------------------------------------------------------------------------------------
+__global__ void k_spec_tendencies(Geom g, const double *__restrict__ coef, const double *__restrict__ Sf, int C,
+                                  double2 *__restrict__ dtvor, double2 *__restrict__ dtdiv, double2 *__restrict__ dtT,
+                                  double2 *__restrict__ dtlp) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = g.L;
+  const size_t tot = (size_t)g.Ml * g.N1 * L;
+  if (idx >= tot) return;
+  const int k = idx % L;
+  const size_t mn = idx / L;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  const double mk = COEF(C_MASK, ml, n);
+  if (mk == 0.0) {
+    dtvor[idx] = dtdiv[idx] = dtT[idx] = make_double2(0., 0.);
+    if (k == 0) dtlp[mn] = make_double2(0., 0.);
+    return;
+  }
+  double2 vo, dv;
+  alpha_pair(g, coef, Sf, C, mn, ml, n, k, L + k, vo, dv);
+  const double2 E = *(const double2 *)(Sf + mn * C + 2 * (3 * L + k));
+  dv = cadd(dv, cscale(COEF(C_EIG, ml, n), E));     // dt_divs - laplacian(E),  laplacian = -eigen*E
+  dtvor[idx] = vo;
+  dtdiv[idx] = dv;
+  dtT[idx] = *(const double2 *)(Sf + mn * C + 2 * (2 * L + k));
+  if (k == 0) dtlp[mn] = *(const double2 *)(Sf + mn * C + 2 * (4 * L));
+}
+
+// wave-wide exclusive prefix sum over lanes 0..63
+__device__ __forceinline__ double wave_incl_scan(double v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// S2: one wavefront per retained (m,n), lane = level.  implicit_correction (implicit.F90:241-325) with
+// the L x L wave matrix applied by lane-broadcast mat-vec, spectral damping (spectral_damping.F90:172-291),
+// leapfrog_2level_A + the Robert filter completion leapfrog_2level_B (leapfrog.F90:58-105) for
+// raw_filter_coeff = 1.  impl_vec rows: 0 dlog_1, 1 dlog_3, 2 dp_ref, 3 h, 4 dlogf = lph(k+1)-lpf(k)
+// -----------------------------------------------------------------------------------------------------
+struct SpecUpdateArgs {
+  double2 *vors[2], *divs[2], *ts[2], *lnps[2];
+  double2 *dtvor, *dtdiv, *dtT, *dtlp;
+  const double *coef, *impl_vec, *wave_t;
+  const int *m_local;
+  double delta_t, xi, ref_p, ref_t, robert, eddy_sponge, zmu_sponge, zmv_sponge;
+  int prev, cur, fut;
+};
+
+__device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, double dlog1, double dlog3, double ref_t,
+                                       double2 &dt_p, double2 &dt_t) {
+  // linear_tp_tendency (implicit.F90:414-480) with a uniform reference temperature
+  const double2 dmean = (lane < L) ? cscale(dp, dv) : make_double2(0., 0.);
+  double2 inc;
+  inc.x = wave_incl_scan(dmean.x, lane);
+  inc.y = wave_incl_scan(dmean.y, lane);
+  const double2 before = csub(inc, dmean);
+  const double f = -KAPPA * ref_t / dp;
+  dt_t = make_double2(f * (before.x * dlog3 + dmean.x * dlog1), f * (before.y * dlog3 + dmean.y * dlog1));
+  dt_p = make_double2(-__shfl(inc.x, 63, 64), -__shfl(inc.y, 63, 64));
+}
+
+__global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t mn = (size_t)blockIdx.x * 4 + wave;
+  if (mn >= (size_t)g.Ml * g.N1) return;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  const double *coef = a.coef;
+  if (COEF(C_MASK, ml, n) == 0.0) return;           // outside the triangle: state stays zero
+  const int L = g.L;
+  const bool act = lane < L;
+  const int kk = act ? lane : 0;
+  const size_t idx = mn * L + kk;
+  const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
+  const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
+  const double eig = COEF(C_EIG, ml, n);
+  const int prev = a.prev, cur = a.cur, fut = a.fut;
+  const double2 zero = make_double2(0., 0.);
+  double2 dprev = act ? a.divs[prev][idx] : zero, dcur = act ? a.divs[cur][idx] : zero;
+  double2 tprev = act ? a.ts[prev][idx] : zero, tcur = act ? a.ts[cur][idx] : zero;
+  double2 vprev = act ? a.vors[prev][idx] : zero, vcur = act ? a.vors[cur][idx] : zero;
+  const double2 lprev = a.lnps[prev][mn], lcur = a.lnps[cur][mn];
+  double2 dt_div = act ? a.dtdiv[idx] : zero, dt_t = act ? a.dtT[idx] : zero, dt_vor = act ? a.dtvor[idx] : zero;
+  double2 dt_lp = a.dtlp[mn];
+  // --- adjust_dt_divs (:289-325)
+  double2 dps, dts;
+  lin_tp(csub(dprev, dcur), lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
+  dt_t = cadd(dt_t, dts);
+  dt_lp = cadd(dt_lp, cscale(1.0 / a.ref_p, dps));
+  const double2 ts_temp = cadd(csub(tprev, tcur), cscale(a.xi, dt_t));
+  const double2 ps_temp = cadd(csub(lprev, lcur), cscale(a.xi, dt_lp));
+  {  // linear_geopotential (:329-359) with del_ln_p = 0: suffix sums of RDGAS*T'*dlog3 below the level
+    const double2 av = (act && lane >= 1) ? cscale(RDGAS * dlog3, ts_temp) : zero;
+    double2 inc;
+    inc.x = wave_incl_scan(av.x, lane);
+    inc.y = wave_incl_scan(av.y, lane);
+    const double2 tot = make_double2(__shfl(inc.x, 63, 64), __shfl(inc.y, 63, 64));
+    const double2 below = csub(tot, inc);                                  // sum over k' > k
+    const double2 geo = cadd(below, cscale(RDGAS * dlogf, ts_temp));
+    const double hp = hk * a.ref_p;
+    dt_div = cadd(dt_div, cscale(eig, make_double2(geo.x + hp * ps_temp.x, geo.y + hp * ps_temp.y)));
+  }
+  // dt_divs <- wave_matrix(L) . dt_divs   (:268-277);  wave_t[Lw][k'][k], lane-broadcast mat-vec
+  {
+    const int Lw = a.m_local[ml] + n;
+    const double *W = a.wave_t + (size_t)Lw * L * L;
+    double2 out = zero;
+    if (!act) dt_div = zero;
+    for (int k2 = 0; k2 < L; ++k2) {
+      const double xr = __shfl(dt_div.x, k2, 64), xi_ = __shfl(dt_div.y, k2, 64);
+      const double w = W[(size_t)k2 * L + kk];
+      out.x += w * xr;
+      out.y += w * xi_;
+    }
+    dt_div = act ? out : zero;
+  }
+  lin_tp(dt_div, lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
+  dt_t = cadd(dt_t, cscale(a.xi, dts));
+  dt_lp = cadd(dt_lp, cscale(a.xi / a.ref_p, dps));
+  // --- damping
+  {
+    const double dmp = COEF(C_DAMP, ml, n);
+    const double cf = 1.0 / (1.0 + dmp * a.delta_t);
+    dt_vor = cscale(cf, csub(dt_vor, cscale(dmp, vprev)));
+    dt_div = cscale(cf, csub(dt_div, cscale(dmp, dprev)));
+    dt_t = cscale(cf, csub(dt_t, cscale(dmp, tprev)));
+    if (lane == 0) {   // sponge on the top level (:236-245, :281-290)
+      const int mglob = a.m_local[ml];
+      const double sv = (mglob != 0) ? a.eddy_sponge * eig : a.zmu_sponge * eig;
+      const double sd = (mglob != 0) ? a.eddy_sponge * eig : a.zmv_sponge * eig;
+      dt_vor = cscale(1.0 / (1.0 + sv * a.delta_t), csub(dt_vor, cscale(sv, vprev)));
+      dt_div = cscale(1.0 / (1.0 + sd * a.delta_t), csub(dt_div, cscale(sd, dprev)));
+    }
+  }
+  // --- leapfrog_2level_A then _B (Robert filter, raw_filter_coeff = 1)
+  const double rc = a.robert, dtt = a.delta_t;
+#define LEAP(PREV, CUR, DT, ARR, IDX, GUARD)                                        \
+  {                                                                                 \
+    const double2 part = make_double2(PREV.x - 2.0 * CUR.x, PREV.y - 2.0 * CUR.y);  \
+    const double2 nf = make_double2(PREV.x + dtt * DT.x, PREV.y + dtt * DT.y);      \
+    double2 nc = make_double2(CUR.x + rc * part.x, CUR.y + rc * part.y);            \
+    nc = make_double2(nc.x + rc * nf.x, nc.y + rc * nf.y);                          \
+    if (GUARD) { ARR[cur][IDX] = nc; ARR[fut][IDX] = nf; }                          \
+  }
+  LEAP(vprev, vcur, dt_vor, a.vors, idx, act)
+  LEAP(dprev, dcur, dt_div, a.divs, idx, act)
+  LEAP(tprev, tcur, dt_t, a.ts, idx, act)
+  LEAP(lprev, lcur, dt_lp, a.lnps, mn, lane == 0)
+#undef LEAP
+}
+
+void launch_spec_tendencies(const isca_dyn &h, hipStream_t s) {
+  const Geom &g = h.g;
+  hipLaunchKernelGGL(k_spec_tendencies, grid1d((size_t)g.Ml * g.N1 * g.L), dim3(256), 0, s, g, h.d.coef, h.d.Sf, h.Cf,
+                     (double2 *)h.d.s_dtvor, (double2 *)h.d.s_dtdiv, (double2 *)h.d.s_dtT, (double2 *)h.d.s_dtlp);
+}
+void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  SpecUpdateArgs a;
+  for (int t = 0; t < 2; ++t) {
+    a.vors[t] = (double2 *)h.d.vors[t]; a.divs[t] = (double2 *)h.d.divs[t];
+    a.ts[t] = (double2 *)h.d.ts[t]; a.lnps[t] = (double2 *)h.d.lnps[t];
+  }
+  a.dtvor = (double2 *)h.d.s_dtvor; a.dtdiv = (double2 *)h.d.s_dtdiv; a.dtT = (double2 *)h.d.s_dtT; a.dtlp = (double2 *)h.d.s_dtlp;
+  a.coef = h.d.coef; a.impl_vec = h.d.impl_vec; a.wave_t = h.d.wave_mat_t; a.m_local = h.d.m_local;
+  a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
+  a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
+  a.prev = sc.prev; a.cur = sc.cur; a.fut = sc.fut;
+  const size_t nmn = (size_t)g.Ml * g.N1;
+  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)((nmn + 3) / 4)), dim3(256), 0, s, g, a);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// S3: inverse-batch inputs from the spectral state at time level tl (spectral_dynamics.F90:933-937 for the
+// new state merged with :855,:890 for the next step's gradients -- SURVEY Appendix B).
+// Inverse-batch columns: [0,L) div, [L,2L) vor, [2L,3L) u cos, [3L,4L) v cos, [4L,5L) T, [5L,6L) dT/dx cos,
+// [6L,7L) dT/dy cos, 7L ln ps, 7L+1 d(ln ps)/dx cos, 7L+2 d(ln ps)/dy cos
+// -----------------------------------------------------------------------------------------------------
+__global__ void k_spec_synth_inputs(Geom g, const double *__restrict__ coef, const double2 *__restrict__ vor,
+                                    const double2 *__restrict__ div, const double2 *__restrict__ ts,
+                                    const double2 *__restrict__ lnps, double *__restrict__ Si, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = g.L;
+  const size_t tot = (size_t)g.Ml * g.N1 * L;
+  if (idx >= tot) return;
+  const int k = idx % L;
+  const size_t mn = idx / L;
+  const int n = mn % g.N1, ml = mn / g.N1;
+  const double2 vo = vor[idx], dv = div[idx], tt = ts[idx];
+  double2 u = cscale(COEF(C_UVC, ml, n), ctimes_i(dv));
+  double2 v = cscale(COEF(C_UVC, ml, n), ctimes_i(vo));
+  const double dxc = COEF(C_DX, ml, n);
+  const double2 tdx = cscale(dxc, ctimes_i(tt));
+  double2 tdy = make_double2(0., 0.);
+  if (n >= 1) {
+    const double cm = COEF(C_UVM, ml, n);
+    u = cadd(u, cscale(cm, vor[idx - L]));
+    v = csub(v, cscale(cm, div[idx - L]));
+    tdy = cscale(-COEF(C_DYM, ml, n), ts[idx - L]);
+  }
+  if (n + 1 < g.N1) {
+    const double cp = COEF(C_UVP, ml, n);
+    u = csub(u, cscale(cp, vor[idx + L]));
+    v = cadd(v, cscale(cp, div[idx + L]));
+    tdy = cadd(tdy, cscale(COEF(C_DYP, ml, n), ts[idx + L]));
+  }
+  double *row = Si + mn * C;
+  *(double2 *)(row + 2 * (0 * L + k)) = dv;
+  *(double2 *)(row + 2 * (1 * L + k)) = vo;
+  *(double2 *)(row + 2 * (2 * L + k)) = u;
+  *(double2 *)(row + 2 * (3 * L + k)) = v;
+  *(double2 *)(row + 2 * (4 * L + k)) = tt;
+  *(double2 *)(row + 2 * (5 * L + k)) = tdx;
+  *(double2 *)(row + 2 * (6 * L + k)) = tdy;
+  if (k == 0) {
+    const double2 lp = lnps[mn];
+    double2 ldy = make_double2(0., 0.);
+    if (n >= 1) ldy = cscale(-COEF(C_DYM, ml, n), lnps[mn - 1]);
+    if (n + 1 < g.N1) ldy = cadd(ldy, cscale(COEF(C_DYP, ml, n), lnps[mn + 1]));
+    *(double2 *)(row + 2 * (7 * L + 0)) = lp;
+    *(double2 *)(row + 2 * (7 * L + 1)) = cscale(dxc, ctimes_i(lp));
+    *(double2 *)(row + 2 * (7 * L + 2)) = ldy;
+  }
+}
+void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s) {
+  const Geom &g = h.g;
+  hipLaunchKernelGGL(k_spec_synth_inputs, grid1d((size_t)g.Ml * g.N1 * g.L), dim3(256), 0, s, g, h.d.coef,
+                     (const double2 *)h.d.vors[tl], (const double2 *)h.d.divs[tl], (const double2 *)h.d.ts[tl],
+                     (const double2 *)h.d.lnps[tl], h.d.Si, h.Ci);
+}
+
+// =====================================================================================================
+// Grid-point column kernel: hs_forcing (hs_forcing.F90:148-272) at the PREVIOUS level with CURRENT
+// pressures (atmosphere.F90:304-311), pressure_variables (press_and_geopot.F90:152-221), four_in_one
+// (spectral_dynamics.F90:1038-1112), vert_advection second-centred/advective (vert_advection.F90:185-193,
+// 467-470), horizontal T advection (transforms.F90:822-828), vorticity/Coriolis terms and Phi+KE
+// (spectral_dynamics.F90:893-902), and the "previous" sums of the fixers (:1306-1338).
+// One thread per column, 64 columns (one wavefront, consecutive longitudes) per block.
+// =====================================================================================================
+struct ColumnArgs {
+  const double *u, *v, *t, *ps;            // current
+  const double *up, *vp, *tp, *psp;        // previous
+  const double *vor, *div, *dxT, *dyT, *dxlp, *dylp;
+  double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials;
+  const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
+  double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
+  int do_conserve_energy;
+};
+
+__device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double ps, double p_full, double up, double vp,
+                                         double tp, double sin_lat, double sin2, double cos2, double cos4,
+                                         double &utnd, double &vtnd, double &ttnd) {
+  // rayleigh_damping (:615-679), dissipative heating (:198-200), newtonian_damping (:508-611)
+  const double sigma = p_full * (1. / ps);
+  const bool bl = (sigma <= 1.0) && (sigma > a.sigma_b);
+  const double vcoeff = -a.vkf / (1.0 - a.sigma_b);
+  const double vfactr = bl ? vcoeff * (sigma - a.sigma_b) : 0.0;
+  utnd = vfactr * up;
+  vtnd = vfactr * vp;
+  ttnd = 0.0;
+  if (a.do_conserve_energy) ttnd = -((up + .5 * utnd * dt) * utnd + (vp + .5 * vtnd * dt) * vtnd) / CP_AIR;
+  const double t_star = a.t_zero - a.delh * sin2 - a.eps * sin_lat;
+  const double tstr = a.t_strat - a.eps * sin_lat;
+  const double tcoeff = (a.tks - a.tka) / (1.0 - a.sigma_b);
+  const double p_norm = p_full / a.P00;
+  const double the = t_star - a.delv * cos2 * log(p_norm);
+  double teq = the * pow(p_norm, KAPPA);
+  teq = fmax(teq, tstr);
+  const double tdamp = bl ? a.tka + cos4 * (tcoeff * (sigma - a.sigma_b)) : a.tka;
+  ttnd = ttnd + (-tdamp * (tp - teq));
+}
+
+__global__ __launch_bounds__(64) void k_column(Geom g, ColumnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = g.L, I = g.I;
+  double *lph = (double *)smem;            // [L+1][64]
+  double *lpf = lph + (L + 1) * 64;        // [L][64]
+  const int tid = threadIdx.x;
+  const int col = blockIdx.x * 64 + tid;   // 64 divides I
+  const int jl = col / I;
+  const size_t c2 = (size_t)col;           // index into [Jl][I]
+  const size_t lev = (size_t)g.Jl * I;     // level stride
+  const double ps = a.ps[c2];
+  const double dx_ps = ps * a.dxlp[c2], dy_ps = ps * a.dylp[c2];
+  const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
+  // ---- pass 0: total mass divergence
+  double dmean_total = 0.0;
+  for (int k = 0; k < L; ++k) {
+    const double dp = a.dpk[k] + a.dbk[k] * ps;
+    dmean_total = dmean_total + (a.div[c2 + k * lev] * dp + a.dbk[k] * (a.u[c2 + k * lev] * dx_ps + a.v[c2 + k * lev] * dy_ps));
+  }
+  // ---- pressure variables of the column -> LDS (ln p at half and full levels)
+  {
+    double ph_k = a.pk[0] + a.bk[0] * ps;
+    double l_k = top0 ? 0.0 : log(ph_k);
+    lph[0 * 64 + tid] = l_k;
+    for (int k = 0; k < L; ++k) {
+      const double ph_n = a.pk[k + 1] + a.bk[k + 1] * ps;
+      const double l_n = log(ph_n);
+      lph[(k + 1) * 64 + tid] = l_n;
+      double lf;
+      if (top0 && k == 0) lf = l_n - 1.0;
+      else { const double alpha = 1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k); lf = l_n - alpha; }
+      lpf[k * 64 + tid] = lf;
+      ph_k = ph_n; l_k = l_n;
+    }
+  }
+  const double sin_lat = sin(a.rad_lat[jl]);
+  const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
+  const double cosm = a.cosm[jl], cor = a.coriolis[jl];
+  const double psp = a.psp[c2];
+  // ---- pass 1: top-down
+  double dmean_tot = 0.0, wg_k = 0.0;       // wg at interface k (top of level k)
+  double um = 0., vm = 0., tm = 0.;         // r(k-1)
+  double uc = a.u[c2], vc = a.v[c2], tc = a.t[c2];
+  double e_prev = 0.0;                      // column integral of the "previous" energy
+  for (int k = 0; k < L; ++k) {
+    const size_t q = c2 + k * lev;
+    const double un = (k + 1 < L) ? a.u[q + lev] : 0.0, vn = (k + 1 < L) ? a.v[q + lev] : 0.0, tn = (k + 1 < L) ? a.t[q + lev] : 0.0;
+    const double l_h0 = lph[k * 64 + tid], l_h1 = lph[(k + 1) * 64 + tid], l_f = lpf[k * 64 + tid];
+    const double p_full = exp(l_f);
+    // physics at the previous level
+    const double upv = a.up[q], vpv = a.vp[q], tpv = a.tp[q];
+    double dt_u, dt_v, dt_t;
+    hs_level(a, a.delta_t, ps, p_full, upv, vpv, tpv, sin_lat, sin2, cos2, cos4, dt_u, dt_v, dt_t);
+    {  // initialize_corrections (:1318-1321): energy of previous + physics increments, dp from psg(previous)
+      const double ue = upv + dt_u * a.delta_t, ve = vpv + dt_v * a.delta_t;
+      const double en = 0.5 * (ue * ue + ve * ve) + CP_AIR * (tpv + dt_t * a.delta_t);
+      e_prev = e_prev + en * (a.dpk[k] + a.dbk[k] * psp);
+    }
+    // four_in_one
+    const double dp = a.dpk[k] + a.dbk[k] * ps, dp_inv = 1 / dp;
+    const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
+    const double x1 = (a.bk[k + 1] * dlog_1 + a.bk[k] * dlog_2) * dp_inv;
+    const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
+    dt_u = dt_u - RDGAS * tc * x2;
+    dt_v = dt_v - RDGAS * tc * x3;
+    const double dmean = a.div[q] * dp + a.dbk[k] * (uc * dx_ps + vc * dy_ps);
+    const double x4 = (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv;
+    const double x5 = x4 - uc * x2 - vc * x3;
+    dt_t = dt_t - KAPPA * tc * x5;
+    a.wg_full[q] = -x5 * p_full;
+    dmean_tot = dmean_tot + dmean;
+    const double wg_n = (k + 1 < L) ? (-dmean_tot + dmean_total * a.bk[k + 1]) : 0.0;   // interface k+1
+    // vert_advection, SECOND_CENTERED + ADVECTIVE_FORM
+    {
+      const double dw = wg_n - wg_k;
+      const double fu0 = (k == 0) ? wg_k * uc : wg_k * (0.5 * (uc + um));
+      const double fv0 = (k == 0) ? wg_k * vc : wg_k * (0.5 * (vc + vm));
+      const double ft0 = (k == 0) ? wg_k * tc : wg_k * (0.5 * (tc + tm));
+      const double fu1 = (k + 1 < L) ? wg_n * (0.5 * (un + uc)) : wg_n * uc;
+      const double fv1 = (k + 1 < L) ? wg_n * (0.5 * (vn + vc)) : wg_n * vc;
+      const double ft1 = (k + 1 < L) ? wg_n * (0.5 * (tn + tc)) : wg_n * tc;
+      dt_u = dt_u + (-(fu1 - fu0 - uc * dw) / dp);
+      dt_v = dt_v + (-(fv1 - fv0 - vc * dw) / dp);
+      dt_t = dt_t + (-(ft1 - ft0 - tc * dw) / dp);
+    }
+    // horizontal advection of T, vorticity/Coriolis terms
+    dt_t = dt_t - uc * a.dxT[q] - vc * a.dyT[q];
+    const double av = a.vor[q] + cor;
+    dt_u = dt_u + av * vc;
+    dt_v = dt_v - av * uc;
+    a.dtu[q] = dt_u * cosm;      // vor_div_from_uv_grid divides by cos before the analysis (transforms.F90:764-770)
+    a.dtv[q] = dt_v * cosm;
+    a.dtT[q] = dt_t;
+    um = uc; vm = vc; tm = tc; uc = un; vc = vn; tc = tn; wg_k = wg_n;
+  }
+  a.dtlp[c2] = (0.0 - dmean_tot) / ps;     // dt_psg - dmean_tot, then /psg (:873)
+  // ---- pass 2: bottom-up hydrostatic integral, Phi + KE
+  {
+    double gh = 0.0;                        // flat topography: surf_geopotential = 0
+    const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
+    for (int k = L - 1; k >= 0; --k) {
+      const size_t q = c2 + k * lev;
+      const double tk = a.t[q], uk = a.u[q], vk = a.v[q];
+      const double l_h0 = lph[k * 64 + tid], l_h1 = lph[(k + 1) * 64 + tid], l_f = lpf[k * 64 + tid];
+      const double gf = gh + RDGAS * tk * (l_h1 - l_f);
+      a.E[q] = gf + .5 * (uk * uk + vk * vk);
+      if (k >= ktop) gh = gh + RDGAS * tk * (l_h1 - l_h0);
+    }
+  }
+  // ---- block partial sums for mean_surf_press_previous and mean_energy_previous
+  double s_ps = a.wts[jl] * psp, s_en = a.wts[jl] * e_prev;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s_ps += __shfl_down(s_ps, off, 64);
+    s_en += __shfl_down(s_en, off, 64);
+  }
+  if (tid == 0) { a.partials[2 * blockIdx.x] = s_ps; a.partials[2 * blockIdx.x + 1] = s_en; }
+}
+
+size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
+
+void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  ColumnArgs a;
+  a.u = d.ug[sc.cur]; a.v = d.vg[sc.cur]; a.t = d.tg[sc.cur]; a.ps = d.psg[sc.cur];
+  a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.psp = d.psg[sc.prev];
+  a.vor = d.vorg; a.div = d.divg; a.dxT = d.dxT; a.dyT = d.dyT; a.dxlp = d.dxlp; a.dylp = d.dylp;
+  a.dtu = d.g_dtu; a.dtv = d.g_dtv; a.dtT = d.g_dtT; a.E = d.g_E; a.dtlp = d.g_dtlp; a.wg_full = d.wg_full;
+  a.partials = d.partials;
+  a.pk = d.pk; a.bk = d.bk; a.dpk = d.dpk; a.dbk = d.dbk; a.cosm = d.cosm_lat_l; a.coriolis = d.coriolis_l;
+  a.rad_lat = d.rad_lat_l; a.wts = d.wts_lat_l;
+  a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
+  a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
+  a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
+  const size_t lds = (size_t)(2 * g.L + 1) * 64 * sizeof(double);
+  hipLaunchKernelGGL(k_column, dim3((unsigned)column_partials_count(h)), dim3(64), lds, s, g, a);
+}
+
+// standalone hs_forcing on caller fields (for the C-ABI entry point / parity tests)
+__global__ void k_hs_forcing(Geom g, ColumnArgs a, double dt, const double *__restrict__ p_half,
+                             const double *__restrict__ p_full, const double *__restrict__ u, const double *__restrict__ v,
+                             const double *__restrict__ t, double *udt, double *vdt, double *tdt) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (idx >= lev * g.L) return;
+  const size_t c2 = idx % lev;
+  const int jl = c2 / g.I;
+  const double sin_lat = sin(a.rad_lat[jl]);
+  const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
+  const double ps = p_half[(size_t)g.L * lev + c2];
+  double ut, vt, tt;
+  hs_level(a, dt, ps, p_full[idx], u[idx], v[idx], t[idx], sin_lat, sin2, cos2, cos4, ut, vt, tt);
+  udt[idx] += ut; vdt[idx] += vt; tdt[idx] += tt;
+}
+void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const double *p_full, const double *u,
+                       const double *v, const double *t, double *udt, double *vdt, double *tdt, hipStream_t s) {
+  ColumnArgs a = {};
+  a.rad_lat = h.d.rad_lat_l;
+  a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
+  a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
+  a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
+  hipLaunchKernelGGL(k_hs_forcing, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, dt, p_half, p_full, u, v, t, udt, vdt, tdt);
+}
+
+// compute_pressures_and_heights (press_and_geopot.F90:363-387), flat topography
+__global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const double *__restrict__ bk,
+                                    const double *__restrict__ t, const double *__restrict__ psg, double *p_full,
+                                    double *p_half, double *z_full, double *z_half) {
+  const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (c2 >= lev) return;
+  const int L = g.L;
+  const double ps = psg[c2];
+  const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
+  // top-down pressures, bottom-up heights recomputing the logs (diagnostic path, not in the step)
+  double ph_k = pk[0] + bk[0] * ps;
+  p_half[c2] = ph_k;
+  for (int k = 0; k < L; ++k) {
+    const double ph_n = pk[k + 1] + bk[k + 1] * ps;
+    p_half[c2 + (k + 1) * lev] = ph_n;
+    const double l_k = (top0 && k == 0) ? 0.0 : log(ph_k), l_n = log(ph_n);
+    double lf;
+    if (top0 && k == 0) lf = l_n - 1.0;
+    else lf = l_n - (1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k));
+    p_full[c2 + k * lev] = exp(lf);
+    ph_k = ph_n;
+  }
+  double gh = 0.0;
+  z_half[c2 + (size_t)L * lev] = 0.0;
+  const int ktop = (pk[0] == 0.0) ? 1 : 0;
+  for (int k = L - 1; k >= 0; --k) {
+    const double ph0 = pk[k] + bk[k] * ps, ph1 = pk[k + 1] + bk[k + 1] * ps;
+    const double l0 = (top0 && k == 0) ? 0.0 : log(ph0), l1 = log(ph1);
+    double lf;
+    if (top0 && k == 0) lf = l1 - 1.0;
+    else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
+    const double tk = t[c2 + k * lev];
+    z_full[c2 + k * lev] = (gh + RDGAS * tk * (l1 - lf)) / GRAV;
+    if (k >= ktop) gh = gh + RDGAS * tk * (l1 - l0);
+    z_half[c2 + k * lev] = (k >= ktop) ? gh / GRAV : 0.0;
+  }
+}
+void launch_pressures_heights(const isca_dyn &h, const double *t, const double *ps, double *p_full, double *p_half,
+                              double *z_full, double *z_half, hipStream_t s) {
+  hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, p_full, p_half, z_full, z_half);
+}
+
+__global__ void k_hadv_combine(size_t n, const double *u, const double *v, const double *dx, const double *dy, double *tend) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tend[i] = tend[i] - u[i] * dx[i] - v[i] * dy[i];
+}
+void launch_hadv_combine(const Geom &g, const double *u, const double *v, const double *dx, const double *dy, double *tend, int nlev, hipStream_t s) {
+  const size_t n = (size_t)g.Jl * g.I * nlev;
+  hipLaunchKernelGGL(k_hadv_combine, grid1d(n), dim3(256), 0, s, n, u, v, dx, dy, tend);
+}
+__global__ void k_scale_rows(Geom g, const double *cosm, double *a, int nlev) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (i < lev * nlev) a[i] *= cosm[(i % lev) / g.I];
+}
+void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_rows, grid1d((size_t)g.Jl * g.I * nlev), dim3(256), 0, s, g, d.cosm_lat_l, a, nlev);
+}
+
+// =====================================================================================================
+// Mass / energy fixers (spectral_dynamics.F90:1213-1302; global_integral.F90:49-81; transforms.F90:1059-1077)
+//   red[0..1]  local sums of the column kernel: w*ps(prev), w*E(prev)
+//   red[2..4]  local sums of the new state:     w*ps(fut), w*sum_k e_k dpk_k, w*sum_k e_k dbk_k ps(fut)
+//   red[8]     mass_correction_factor, red[9] temperature_correction
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                   const double *__restrict__ t, const double *__restrict__ psg,
+                                                   const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                                   const double *__restrict__ wts, double *__restrict__ partials) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int jl = col / g.I;
+  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
+  const double ps = psg[c2];
+  double sa = 0.0, sb = 0.0;
+  for (int k = 0; k < g.L; ++k) {
+    const size_t q = c2 + k * lev;
+    const double uk = u[q], vk = v[q];
+    const double e = 0.5 * (uk * uk + vk * vk) + CP_AIR * t[q];
+    sa += e * dpk[k];
+    sb += e * dbk[k];
+  }
+  const double w = wts[jl];
+  double s0 = w * ps, s1 = w * sa, s2 = w * sb * ps;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (threadIdx.x == 0) { partials[3 * blockIdx.x] = s0; partials[3 * blockIdx.x + 1] = s1; partials[3 * blockIdx.x + 2] = s2; }
+}
+// sum `n` groups of `stride` partials in a fixed order -> out[0..stride)
+__global__ void k_sum_partials(const double *__restrict__ partials, int n, int stride, double *__restrict__ out) {
+  __shared__ double sh[256];
+  for (int c = 0; c < stride; ++c) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[(size_t)i * stride + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sh[0];
+    __syncthreads();
+  }
+}
+struct FixerArgs {
+  double *red;
+  double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
+  int ml0;                 // local slot of m = 0, or -1
+  double sumw_nlon;        // global_sum_of_wts * num_lon
+  double robert;
+  int do_mass, do_energy;
+};
+__global__ void k_fixer_finalize(Geom g, FixerArgs a) {
+  // every thread recomputes the two scalars from the (already globally summed) red[0..4]
+  double *red = a.red;
+  const double mean_ps_prev = red[0] / a.sumw_nlon;
+  const double mean_en_prev = red[1] / a.sumw_nlon / GRAV;
+  double factor = 1.0, tcorr = 0.0;
+  if (a.do_mass) factor = mean_ps_prev / (red[2] / a.sumw_nlon);
+  if (a.do_energy) {
+    const double mean_en_tmp = (red[3] + factor * red[4]) / a.sumw_nlon / GRAV;
+    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+  }
+  const int k = threadIdx.x;
+  if (k == 0) { red[8] = factor; red[9] = tcorr; }
+  if (a.ml0 >= 0) {
+    const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
+    const double s2 = sqrt(2.);
+    if (k == 0 && a.do_mass) {
+      const double dl = s2 * log(factor);
+      a.lnps_fut[mn].x += dl;
+      a.lnps_cur[mn].x += a.robert * dl;        // the Robert filter completion sees the corrected future (:1470)
+    }
+    if (k < g.L && a.do_energy) {
+      const double dtc = s2 * tcorr;
+      a.ts_fut[mn * g.L + k].x += dtc;
+      a.ts_cur[mn * g.L + k].x += a.robert * dtc;
+    }
+  }
+}
+__global__ void k_fixer_apply(Geom g, const double *__restrict__ red, double *psg, double *tg) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  const double factor = red[8], tcorr = red[9];
+  if (i < lev) psg[i] = factor * psg[i];
+  if (i < lev * g.L) tg[i] = tg[i] + tcorr;
+}
+
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  const int nb = (int)column_partials_count(h);
+  // previous-level sums left by the column kernel -> red[0..1]
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, d.partials, nb, 2, d.red);
+  double *p2 = d.partials + 2 * (size_t)nb;
+  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, p2, nb, 3, d.red + 2);
+}
+void launch_fixer_finalize(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  FixerArgs a;
+  a.red = h.d.red;
+  a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
+  a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
+  a.ml0 = h.ml_of_m0;      // local slot of m = 0, or -1 when another rank owns it
+  double sumw = 0.0;
+  for (double w : h.tab.wts_lat) sumw += w;
+  a.sumw_nlon = sumw * h.g.I;
+  a.robert = h.cfg.robert_coeff;
+  a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
+  hipLaunchKernelGGL(k_fixer_finalize, dim3(1), dim3(64), 0, s, h.g, a);
+}
+void launch_fixer_apply(const isca_dyn &h, int fut, hipStream_t s) {
+  const Geom &g = h.g;
+  hipLaunchKernelGGL(k_fixer_apply, grid1d((size_t)g.Jl * g.I * g.L), dim3(256), 0, s, g, h.d.red, h.d.psg[fut], h.d.tg[fut]);
+}
+
+}  // namespace isca

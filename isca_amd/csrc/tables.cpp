@@ -1,0 +1,293 @@
+// Host tables for the MI355X spectral core.  Compiled with -ffp-contract=off so that the Gauss
+// nodes / Legendre recursion reproduce the reference's fp64 results bit for bit (the reference's
+// flang -O2 build emits no FMA on x86-64).
+#include "tables.h"
+#include <cmath>
+#include <stdexcept>
+
+namespace isca {
+
+// atmos_spectral/tools/gauss_and_legendre.F90:111-183 (Newton iteration on P_n, pole-most node first)
+void compute_gaussian(int n_hem, std::vector<double> &sin_hem, std::vector<double> &wts_hem) {
+  double converg = 1.0;
+  for (int i = 0; i < 15; ++i) converg *= 0.1;   // .1**precision(real*8)
+  converg = std::pow(0.1, 15);
+  const int n = 2 * n_hem;
+  sin_hem.assign(n_hem, 0.0);
+  wts_hem.assign(n_hem, 0.0);
+  for (int i = 1; i <= n_hem; ++i) {
+    double z = std::cos(PI * (i - 0.25) / (n + 0.5));
+    double pp = 0.0;
+    bool ok = false;
+    for (int iter = 0; iter < 10; ++iter) {
+      double p1 = 1.0, p2 = 0.0, p3;
+      for (int j = 1; j <= n; ++j) {
+        p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j - 1.0) * z * p2 - (j - 1.0) * p3) / j;
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      double z1 = z;
+      z = z1 - p1 / pp;
+      if (std::fabs(z - z1) < converg) { ok = true; break; }
+    }
+    if (!ok) throw std::runtime_error("compute_gaussian: abscissas failed to converge in itermax iterations");
+    sin_hem[i - 1] = z;
+    wts_hem[i - 1] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+}
+
+// gauss_and_legendre.F90:47-108 (fourier_inc = 1); leg[j][n][m]
+void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg) {
+  const int M1 = num_fourier + 1, N1 = num_spherical + 1, nlat = (int)sin_hem.size();
+  std::vector<double> eps((size_t)N1 * M1), poly((size_t)N1 * M1), b(M1, 0.0);
+  for (int n = 0; n < N1; ++n)
+    for (int m = 0; m < M1; ++m) {
+      double m2 = (double)m * m, l2 = (double)(m + n) * (m + n);
+      eps[(size_t)n * M1 + m] = std::sqrt((l2 - m2) / (4.0 * l2 - 1.0));
+    }
+  for (int m = 1; m < M1; ++m) b[m] = std::sqrt(0.5 * (2.0 * (double)m + 1.0) / (double)m);
+  leg.assign((size_t)nlat * N1 * M1, 0.0);
+  for (int j = 0; j < nlat; ++j) {
+    const double s = sin_hem[j];
+    const double c = std::sqrt(1 - s * s);
+    poly[0] = std::sqrt(0.5);
+    for (int m = 1; m < M1; ++m) poly[m] = b[m] * c * poly[m - 1];
+    for (int m = 0; m < M1; ++m) poly[M1 + m] = s * poly[m] / eps[M1 + m];
+    for (int n = 2; n < N1; ++n)
+      for (int m = 0; m < M1; ++m)
+        poly[(size_t)n * M1 + m] =
+            (s * poly[(size_t)(n - 1) * M1 + m] - eps[(size_t)(n - 1) * M1 + m] * poly[(size_t)(n - 2) * M1 + m]) /
+            eps[(size_t)n * M1 + m];
+    for (size_t q = 0; q < (size_t)N1 * M1; ++q) leg[(size_t)j * N1 * M1 + q] = poly[q];
+  }
+}
+
+// model/matrix_invert.F90:38-130: Gauss-Jordan elimination with pivoting
+bool invert_matrix(std::vector<double> &a, int n) {
+  std::vector<double> inv((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) inv[(size_t)i * n + i] = 1.0;
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    double best = std::fabs(a[(size_t)col * n + col]);
+    for (int r = col + 1; r < n; ++r)
+      if (std::fabs(a[(size_t)r * n + col]) > best) { best = std::fabs(a[(size_t)r * n + col]); piv = r; }
+    if (best == 0.0) return false;
+    if (piv != col)
+      for (int k = 0; k < n; ++k) {
+        std::swap(a[(size_t)piv * n + k], a[(size_t)col * n + k]);
+        std::swap(inv[(size_t)piv * n + k], inv[(size_t)col * n + k]);
+      }
+    const double d = 1.0 / a[(size_t)col * n + col];
+    for (int k = 0; k < n; ++k) { a[(size_t)col * n + k] *= d; inv[(size_t)col * n + k] *= d; }
+    for (int r = 0; r < n; ++r) {
+      if (r == col) continue;
+      const double f = a[(size_t)r * n + col];
+      if (f == 0.0) continue;
+      for (int k = 0; k < n; ++k) {
+        a[(size_t)r * n + k] -= f * a[(size_t)col * n + k];
+        inv[(size_t)r * n + k] -= f * inv[(size_t)col * n + k];
+      }
+    }
+  }
+  a.swap(inv);
+  return true;
+}
+
+namespace {
+
+// model/press_and_geopot.F90:152-221 for a single column (simmons_and_burridge)
+void pressure_variables_1d(const std::vector<double> &pk, const std::vector<double> &bk, double ps,
+                           std::vector<double> &ln_p_half, std::vector<double> &ln_p_full) {
+  const int L = (int)pk.size() - 1;
+  std::vector<double> p_half(L + 1);
+  ln_p_half.assign(L + 1, 0.0);
+  ln_p_full.assign(L, 0.0);
+  for (int k = 0; k <= L; ++k) p_half[k] = pk[k] + bk[k] * ps;
+  if (pk[0] == 0.0 && bk[0] == 0.0) {
+    for (int k = 1; k <= L; ++k) ln_p_half[k] = std::log(p_half[k]);
+    for (int k = 1; k < L; ++k) {
+      double alpha = 1.0 - p_half[k] * (ln_p_half[k + 1] - ln_p_half[k]) / (p_half[k + 1] - p_half[k]);
+      ln_p_full[k] = ln_p_half[k + 1] - alpha;
+    }
+    ln_p_full[0] = ln_p_half[1] - 1.0;
+    ln_p_half[0] = 0.0;
+  } else {
+    for (int k = 0; k <= L; ++k) ln_p_half[k] = std::log(p_half[k]);
+    for (int k = 0; k < L; ++k) {
+      double alpha = 1.0 - p_half[k] * (ln_p_half[k + 1] - ln_p_half[k]) / (p_half[k + 1] - p_half[k]);
+      ln_p_full[k] = ln_p_half[k + 1] - alpha;
+    }
+  }
+}
+
+}  // namespace
+
+void Tables::build(const isca_dyn_config &c) {
+  I = c.lon_max; J = c.lat_max; M1 = c.num_fourier + 1; N1 = c.num_spherical + 1; L = c.num_levels;
+  // --- Gaussian grid: spherical_fourier.F90:397-431
+  compute_gaussian(J / 2, sin_hem, wts_hem);
+  sin_lat.resize(J); wts_lat.resize(J); cos_lat.resize(J); cosm_lat.resize(J); deg_lat.resize(J);
+  rad_lat.resize(J); coriolis.resize(J);
+  for (int j = 0; j < J / 2; ++j) {
+    sin_lat[j] = -sin_hem[j];
+    sin_lat[J - 1 - j] = -sin_lat[j];
+    wts_lat[j] = wts_hem[j];
+    wts_lat[J - 1 - j] = wts_hem[j];
+  }
+  for (int j = 0; j < J; ++j) {
+    cos_lat[j] = std::sqrt(1 - sin_lat[j] * sin_lat[j]);
+    cosm_lat[j] = 1. / cos_lat[j];
+    deg_lat[j] = std::asin(sin_lat[j]) * 180.0 / PI;
+    rad_lat[j] = deg_lat[j] * PI / 180.;               // atmosphere.F90:248-251
+    coriolis[j] = 2 * OMEGA * sin_lat[j];              // spectral_dynamics.F90:445
+  }
+  deg_lon.resize(I);
+  for (int i = 0; i < I; ++i) deg_lon[i] = i * 360.0 / (double)I;   // grid_fourier.F90:109-118
+  compute_legendre(c.num_fourier, c.num_spherical, sin_hem, legendre);
+  // --- spherical.F90:137-216
+  const size_t NM = (size_t)N1 * M1;
+  eigen.assign(NM, 0); coef_uvm.assign(NM, 0); coef_uvc.assign(NM, 0); coef_uvp.assign(NM, 0);
+  coef_alpm.assign(NM, 0); coef_alpp.assign(NM, 0); coef_dym.assign(NM, 0); coef_dx.assign(NM, 0);
+  coef_dyp.assign(NM, 0); tri_mask.assign(NM, 1.0);
+  std::vector<double> eps(NM);
+  for (int n = 0; n < N1; ++n)
+    for (int m = 0; m < M1; ++m) {
+      const size_t q = (size_t)n * M1 + m;
+      const double fw = m, sw = m + n;
+      if (m + n > c.num_spherical - 1) tri_mask[q] = 0.0;
+      eps[q] = std::sqrt((sw * sw - fw * fw) / (4.0 * sw * sw - 1.0));
+      eigen[q] = sw * (sw + 1.0) / (RADIUS * RADIUS);
+      if (m + n > 0) {
+        coef_uvm[q] = -RADIUS * eps[q] / sw;
+        coef_uvc[q] = -RADIUS * fw / (sw * (sw + 1.0));
+      }
+      coef_alpm[q] = (sw + 1.0) * eps[q] / RADIUS;
+      coef_dym[q] = (sw - 1.0) * eps[q] / RADIUS;
+      coef_dx[q] = fw / RADIUS;
+    }
+  for (int n = 0; n < N1 - 1; ++n)
+    for (int m = 0; m < M1; ++m) {
+      const size_t q = (size_t)n * M1 + m, qp = (size_t)(n + 1) * M1 + m;
+      const double sw = m + n;
+      coef_uvp[q] = -RADIUS * eps[qp] / (sw + 1.0);
+      coef_alpp[q] = sw * eps[qp] / RADIUS;
+      coef_dyp[q] = (sw + 2.0) * eps[qp] / RADIUS;
+    }
+  // --- spectral_damping.F90:124-127 ('resolution_dependent')
+  damping.assign(NM, 0);
+  const double eref = eigen[(size_t)(c.num_spherical - 1) * M1 + 0];
+  for (size_t q = 0; q < NM; ++q) damping[q] = c.damping_coeff * std::pow(eigen[q] / eref, c.damping_order);
+  // --- vertical coordinate: init/vert_coordinate.F90:248-273 ('uneven_sigma', zero_top)
+  pk.assign(L + 1, 0.0); bk.assign(L + 1, 0.0);
+  {
+    const double s2 = 1.0 - c.surf_res;
+    for (int k = 1; k <= L; ++k) {
+      const double zeta = 1. - ((double)(k - 1) / (double)L);
+      const double z = c.surf_res * zeta + s2 * std::pow(zeta, c.exponent);
+      bk[k - 1] = std::exp(-z * c.scale_heights);
+    }
+    bk[L] = 1.0;
+    bk[0] = 0.0;
+  }
+  dpk.resize(L); dbk.resize(L);
+  for (int k = 0; k < L; ++k) { dpk[k] = pk[k + 1] - pk[k]; dbk[k] = bk[k + 1] - bk[k]; }
+  // --- implicit_init + build_matrix: model/implicit.F90:79-217 (ref T = 300 K: spectral_dynamics.F90:473)
+  ref_t = 300.0;
+  ref_surf_p = c.reference_sea_level_press;
+  pressure_variables_1d(pk, bk, ref_surf_p, ref_ln_p_half, ref_ln_p_full);
+  std::vector<double> del_ln_p_half(L + 1), del_ln_p_full(L), l1h, l1, l2h, l2;
+  for (int k = 1; k <= L; ++k) del_ln_p_half[k] = bk[k] / (pk[k] + bk[k] * ref_surf_p);
+  del_ln_p_half[0] = (pk[0] == 0.0) ? 1.0 / ref_surf_p : bk[0] / (pk[0] + bk[0] * ref_surf_p);
+  const double epsv = 1.e-5;
+  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 - 0.5 * epsv), l1h, l1);
+  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 + 0.5 * epsv), l2h, l2);
+  for (int k = 0; k < L; ++k) del_ln_p_full[k] = (l2[k] - l1[k]) / (epsv * ref_surf_p);
+  // linear_tp_tendency_1d (implicit.F90:414-480) and linear_geopotential_1d (:329-359) on unit vectors
+  auto tp_tend = [&](const std::vector<double> &div, double &dt_p, std::vector<double> &dt_t) {
+    dt_t.assign(L, 0.0);
+    std::vector<double> vv(L + 1, 0.0), temp(L + 1, 0.0);
+    double dmean_tot = 0.0;
+    for (int k = 0; k < L; ++k) {
+      const double dp = dpk[k] + dbk[k] * ref_surf_p, dp_inv = 1 / dp;
+      const double dlog_1 = ref_ln_p_half[k + 1] - ref_ln_p_full[k];
+      const double dlog_3 = ref_ln_p_half[k + 1] - ref_ln_p_half[k];
+      const double dmean = div[k] * dp;
+      dt_t[k] = -KAPPA * ref_t * (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv;
+      dmean_tot = dmean_tot + dmean;
+      vv[k + 1] = -dmean_tot;
+    }
+    dt_p = -dmean_tot;
+    for (int k = 1; k < L; ++k) { vv[k] += dmean_tot * bk[k]; temp[k] = -vv[k] * (ref_t - ref_t); }
+    for (int k = 0; k < L; ++k) {
+      const double dp = dpk[k] + dbk[k] * ref_surf_p;
+      dt_t[k] += .5 * (1 / dp) * (temp[k + 1] + temp[k]);
+    }
+  };
+  auto lin_geopot = [&](const std::vector<double> &del_t, const std::vector<double> &dlh,
+                        const std::vector<double> &dlf, std::vector<double> &g) {
+    std::vector<double> gh(L + 1, 0.0);
+    g.assign(L, 0.0);
+    for (int k = L - 1; k >= 1; --k)
+      gh[k] = gh[k + 1] + RDGAS * (del_t[k] * (ref_ln_p_half[k + 1] - ref_ln_p_half[k]) + ref_t * (dlh[k + 1] - dlh[k]));
+    for (int k = 0; k < L; ++k)
+      g[k] = gh[k + 1] + RDGAS * (del_t[k] * (ref_ln_p_half[k + 1] - ref_ln_p_full[k]) + ref_t * (dlh[k + 1] - dlf[k]));
+  };
+  tau_mat.assign((size_t)L * L, 0); gamma_mat.assign((size_t)L * L, 0); nu_vec.assign(L, 0);
+  std::vector<double> unit(L), zero(L, 0.0), zero1(L + 1, 0.0), col, g;
+  for (int k = 0; k < L; ++k) {
+    unit.assign(L, 0.0); unit[k] = 1.0;
+    double dtp;
+    tp_tend(unit, dtp, col);
+    nu_vec[k] = -dtp;
+    for (int r = 0; r < L; ++r) tau_mat[(size_t)r * L + k] = -col[r];
+    lin_geopot(unit, zero1, zero, g);
+    for (int r = 0; r < L; ++r) gamma_mat[(size_t)r * L + k] = g[r];
+  }
+  std::vector<double> h2;
+  lin_geopot(zero, del_ln_p_half, del_ln_p_full, h2);
+  h_impl.assign(L, 0.0);
+  for (int k = 0; k < L; ++k) {   // pres_grad_funct :389-411
+    const double dlog_1 = ref_ln_p_half[k + 1] - ref_ln_p_full[k];
+    const double dlog_2 = ref_ln_p_full[k] - ref_ln_p_half[k];
+    const double h1 = RDGAS * ref_t * (bk[k + 1] * dlog_1 + bk[k] * dlog_2) / (dpk[k] + dbk[k] * ref_surf_p);
+    h_impl[k] = h1 + h2[k];
+  }
+  div_mat.assign((size_t)L * L, 0.0);
+  for (int k = 0; k < L; ++k)
+    for (int kk = 0; kk < L; ++kk) {
+      double s = h_impl[k] * nu_vec[kk];
+      for (int q = 0; q < L; ++q) s = s + gamma_mat[(size_t)k * L + q] * tau_mat[(size_t)q * L + kk];
+      div_mat[(size_t)k * L + kk] = s;
+    }
+  // --- hs_forcing_init: hs_forcing.F90:391-410
+  tka = (c.ka < 0.) ? -1. / (86400 * c.ka) : c.ka;
+  tks = (c.ks < 0.) ? -1. / (86400 * c.ks) : c.ks;
+  vkf = (c.kf < 0.) ? -1. / (86400 * c.kf) : c.kf;
+  trsink_s = (c.trsink < 0.) ? -86400. * c.trsink : c.trsink;
+  // --- FFT twiddles
+  tw_re.resize(I / 2); tw_im.resize(I / 2);
+  for (int k = 0; k < I / 2; ++k) {
+    const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)I;
+    tw_re[k] = (double)cosl(a);
+    tw_im[k] = (double)sinl(a);
+  }
+}
+
+// implicit.F90:221-237
+void Tables::build_wave_matrices(const isca_dyn_config &c, double dt) {
+  xi = dt * c.alpha_implicit;
+  const int ntw = c.num_spherical - 1;
+  wave_matrix.assign((size_t)(ntw + 1) * L * L, 0.0);
+  std::vector<double> a((size_t)L * L);
+  for (int Lw = 0; Lw <= ntw; ++Lw) {
+    const double factor = xi * xi * Lw * (Lw + 1) / (RADIUS * RADIUS);
+    for (int k = 0; k < L; ++k)
+      for (int kk = 0; kk < L; ++kk) a[(size_t)k * L + kk] = (k == kk ? 1.0 : 0.0) + factor * div_mat[(size_t)k * L + kk];
+    if (!invert_matrix(a, L)) throw std::runtime_error("build_wave_matrices: singular matrix");
+    for (size_t q = 0; q < (size_t)L * L; ++q) wave_matrix[(size_t)Lw * L * L + q] = a[q];
+  }
+  wave_dt = dt;
+}
+
+}  // namespace isca

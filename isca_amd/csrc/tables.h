@@ -1,0 +1,46 @@
+// Host-side init-time tables of the spectral core (fp64), built once per handle.
+// Restated from the reference's math (citations per function in tables.cpp).
+#pragma once
+#include <vector>
+#include <cstddef>
+#include "../../include/isca_dyn.h"
+
+namespace isca {
+
+constexpr double RADIUS = 6376.0e3;   // shared/constants/constants.F90:254
+constexpr double OMEGA = 7.2921150e-5;
+constexpr double GRAV = 9.80;
+constexpr double RDGAS = 287.04;
+constexpr double KAPPA = 2.0 / 7.0;
+constexpr double CP_AIR = RDGAS / KAPPA;
+constexpr double PI = 3.14159265358979323846;
+
+struct Tables {
+  int I, J, M1, N1, L;
+  std::vector<double> sin_hem, wts_hem;          // [J/2], pole-most first
+  std::vector<double> sin_lat, wts_lat, cos_lat, cosm_lat, deg_lat, rad_lat, deg_lon, coriolis;  // [J] / [I]
+  std::vector<double> legendre;                  // [J/2][N1][M1]  (Fortran (m,n,j))
+  // spherical.F90 coefficient tables, [N1][M1]
+  std::vector<double> eigen, coef_uvm, coef_uvc, coef_uvp, coef_alpm, coef_alpp, coef_dym, coef_dx, coef_dyp, tri_mask;
+  std::vector<double> damping;                   // [N1][M1], same for vor/div/T with default options
+  std::vector<double> pk, bk, dpk, dbk;          // [L+1], [L]
+  // implicit.F90
+  std::vector<double> ref_ln_p_half, ref_ln_p_full, h_impl, div_mat;   // [L+1],[L],[L],[L*L] (row-major k,kk)
+  std::vector<double> tau_mat, gamma_mat, nu_vec;                      // [L*L],[L*L],[L]
+  double ref_surf_p, ref_t;
+  std::vector<double> wave_matrix;               // [num_spherical][L][L] for wave_dt
+  double wave_dt = -1.0, xi = 0.0;
+  // hs
+  double tka, tks, vkf, trsink_s;
+  // FFT twiddles exp(-2 pi i k / I), k < I/2
+  std::vector<double> tw_re, tw_im;
+
+  void build(const isca_dyn_config &c);
+  void build_wave_matrices(const isca_dyn_config &c, double dt);
+};
+
+void compute_gaussian(int n_hem, std::vector<double> &sin_hem, std::vector<double> &wts_hem);
+void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg);
+bool invert_matrix(std::vector<double> &a, int n);   // Gauss-Jordan with pivoting; returns false if singular
+
+}  // namespace isca

@@ -1,0 +1,336 @@
+"""ctypes binding of the C-ABI in include/isca_dyn.h (isca_amd/lib/libisca_dyn.so).
+
+This is the host side of the MI355X spectral core.  It has no CPU fallback: if the shared library
+is missing or no HIP device is usable, construction raises.
+
+Array conventions at this level are the library's (= the reference's Fortran layouts seen from C):
+grid fields are numpy arrays [lev, lat, lon], spectral fields complex [lev, n, m].
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field, fields as dc_fields
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libisca_dyn.so")
+
+
+class IscaError(RuntimeError):
+    """Raised where the reference calls error_mesg(..., FATAL)."""
+
+
+class _CConfig(C.Structure):
+    _fields_ = [
+        ("lon_max", C.c_int), ("lat_max", C.c_int), ("num_fourier", C.c_int), ("num_spherical", C.c_int),
+        ("num_levels", C.c_int), ("fourier_inc", C.c_int), ("triang_trunc", C.c_int), ("dt_atmos", C.c_double),
+        ("damping_order", C.c_int), ("damping_coeff", C.c_double),
+        ("eddy_sponge_coeff", C.c_double), ("zmu_sponge_coeff", C.c_double), ("zmv_sponge_coeff", C.c_double),
+        ("robert_coeff", C.c_double), ("raw_filter_coeff", C.c_double), ("alpha_implicit", C.c_double),
+        ("reference_sea_level_press", C.c_double),
+        ("scale_heights", C.c_double), ("exponent", C.c_double), ("surf_res", C.c_double),
+        ("do_mass_correction", C.c_int), ("do_energy_correction", C.c_int), ("do_water_correction", C.c_int),
+        ("water_correction_limit", C.c_double), ("initial_temperature", C.c_double), ("initial_sphum", C.c_double),
+        ("valid_range_t", C.c_double * 2), ("num_tracers", C.c_int),
+        ("t_zero", C.c_double), ("t_strat", C.c_double), ("delh", C.c_double), ("delv", C.c_double),
+        ("eps", C.c_double), ("sigma_b", C.c_double), ("ka", C.c_double), ("ks", C.c_double), ("kf", C.c_double),
+        ("do_conserve_energy", C.c_int), ("trflux", C.c_double), ("trsink", C.c_double), ("P00", C.c_double),
+        ("rank", C.c_int), ("world_size", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
+        ("legendre_impl", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IscaError(f"{LIB_PATH} not found: build it with `python -m isca_amd.build` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.isca_last_error.restype = C.c_char_p
+    dp = C.POINTER(C.c_double)
+    H = C.c_void_p
+    sig = {
+        "isca_dyn_config_default": [C.POINTER(_CConfig)],
+        "isca_dyn_create": [C.POINTER(_CConfig), C.POINTER(H)],
+        "isca_dyn_destroy": [H],
+        "isca_dyn_cold_start": [H],
+        "isca_dyn_step": [H, C.c_int, C.c_int],
+        "isca_dyn_synchronize": [H],
+        "isca_dyn_step_phase": [H, C.c_int],
+        "isca_dyn_exchange_buffers": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+        "isca_dyn_reduce_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+        "isca_dyn_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+        "isca_dyn_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+        "isca_dyn_complete_update": [H, C.c_int],
+        "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
+        "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+        "isca_trans_spherical_to_grid": [H, dp, dp, C.c_int],
+        "isca_trans_grid_to_spherical": [H, dp, dp, C.c_int, C.c_int],
+        "isca_vor_div_from_uv_grid": [H, dp, dp, dp, dp, C.c_int],
+        "isca_uv_grid_from_vor_div": [H, dp, dp, dp, dp, C.c_int],
+        "isca_horizontal_advection": [H, dp, dp, dp, dp, C.c_int],
+        "isca_trans_spherical_to_fourier": [H, dp, dp, C.c_int],
+        "isca_trans_fourier_to_spherical": [H, dp, dp, C.c_int],
+        "isca_trans_grid_to_fourier": [H, dp, dp, C.c_int],
+        "isca_trans_fourier_to_grid": [H, dp, dp, C.c_int],
+        "isca_area_weighted_global_mean": [H, dp, dp],
+        "isca_hs_forcing": [H, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp],
+        "isca_bench_transform_pair": [H, C.c_int, C.c_int, dp, dp],
+        "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
+    "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_step_phase", "isca_dyn_exchange_buffers",
+    "isca_dyn_reduce_buffer", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
+    "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
+    "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
+    "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
+    "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
+    "isca_bench_transform_pair", "isca_dyn_kernel_times",
+]
+
+# RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
+RESOLUTIONS = {
+    "T21": dict(lon_max=64, lat_max=32, num_fourier=21, num_spherical=22),
+    "T42": dict(lon_max=128, lat_max=64, num_fourier=42, num_spherical=43),
+    "T85": dict(lon_max=256, lat_max=128, num_fourier=85, num_spherical=86),
+    "T170": dict(lon_max=512, lat_max=256, num_fourier=170, num_spherical=171),
+    # small test resolutions (not in the reference's table)
+    "T10": dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11),
+}
+
+
+def default_config(resolution: str | None = None, **overrides) -> _CConfig:
+    lib = load_library()
+    c = _CConfig()
+    lib.isca_dyn_config_default(C.byref(c))
+    if resolution is not None:
+        overrides = {**RESOLUTIONS[resolution], **overrides}
+    for k, v in overrides.items():
+        if k == "valid_range_t":
+            c.valid_range_t[0], c.valid_range_t[1] = v
+        elif not hasattr(c, k):
+            raise IscaError(f"unknown configuration key {k!r}")
+        else:
+            setattr(c, k, v)
+    return c
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class DynCore:
+    """One handle = one GPU = one latitude band and one zonal-wavenumber set."""
+
+    def __init__(self, cfg: _CConfig):
+        self.lib = load_library()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._check(self.lib.isca_dyn_create(C.byref(cfg), C.byref(self._h)))
+        self.I, self.J, self.L = cfg.lon_max, cfg.lat_max, cfg.num_levels
+        self.M1, self.N1 = cfg.num_fourier + 1, cfg.num_spherical + 1
+        self.Jl = self.info("lat_local")
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise IscaError(self.lib.isca_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self.lib.isca_dyn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self, name: str) -> int:
+        v = C.c_long()
+        self._check(self.lib.isca_dyn_get_info(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- shapes
+    def _shape(self, name):
+        L, Jl, I, N1, M1 = self.L, self.Jl, self.I, self.N1, self.M1
+        if name in ("psg", "dxlp", "dylp", "g_dtlp"):
+            return (Jl, I), False
+        if name in ("p_half", "z_half"):
+            return (L + 1, Jl, I), False
+        if name in ("vors", "divs", "ts", "s_dtvor", "s_dtdiv", "s_dtT"):
+            return (L, N1, M1), True
+        if name in ("ln_ps", "s_dtlp"):
+            return (N1, M1), True
+        return (L, Jl, I), False
+
+    def get(self, name: str, time_level: int = 1):
+        shape, cplx = self._shape(name)
+        a = np.zeros(shape, dtype=np.complex128 if cplx else np.float64)
+        v = a.view(np.float64)
+        self._check(self.lib.isca_dyn_get_state(self._h, name.encode(), time_level, _dptr(v), v.size))
+        return a
+
+    def set(self, name: str, value, time_level: int = 1):
+        shape, cplx = self._shape(name)
+        a = np.ascontiguousarray(value, dtype=np.complex128 if cplx else np.float64)
+        if a.shape != shape:
+            raise IscaError(f"set({name}): shape {a.shape} != {shape}")
+        v = a.view(np.float64)
+        self._check(self.lib.isca_dyn_set_state(self._h, name.encode(), time_level, _dptr(v), v.size))
+
+    def table(self, name: str):
+        n = {"sin_lat": self.J, "wts_lat": self.J, "deg_lat": self.J, "deg_lon": self.I, "pk": self.L + 1,
+             "bk": self.L + 1, "legendre": (self.J // 2) * self.N1 * self.M1, "eigen_laplacian": self.N1 * self.M1,
+             "sin_hem": self.J // 2, "wts_hem": self.J // 2, "fixer": 16,
+             "wave_matrix": self.cfg.num_spherical * self.L * self.L}[name]
+        a = np.zeros(n)
+        self._check(self.lib.isca_dyn_get_table(self._h, name.encode(), _dptr(a), a.size))
+        if name == "legendre":
+            a = a.reshape(self.J // 2, self.N1, self.M1)
+        elif name == "eigen_laplacian":
+            a = a.reshape(self.N1, self.M1)
+        elif name == "wave_matrix":
+            a = a.reshape(self.cfg.num_spherical, self.L, self.L)
+        return a
+
+    # -- model
+    def cold_start(self):
+        self._check(self.lib.isca_dyn_cold_start(self._h))
+
+    def step(self, nsteps: int = 1, sync: bool = True):
+        self._check(self.lib.isca_dyn_step(self._h, nsteps, 1 if sync else 0))
+
+    def synchronize(self):
+        self._check(self.lib.isca_dyn_synchronize(self._h))
+
+    def step_phase(self, phase: int):
+        self._check(self.lib.isca_dyn_step_phase(self._h, phase))
+
+    def exchange_buffers(self, which: int):
+        s, r, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        self._check(self.lib.isca_dyn_exchange_buffers(self._h, which, C.byref(s), C.byref(r), C.byref(n)))
+        return s.value, r.value, n.value
+
+    def reduce_buffer(self):
+        b, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.isca_dyn_reduce_buffer(self._h, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def complete_update(self, time_level: int = 1):
+        self._check(self.lib.isca_dyn_complete_update(self._h, time_level))
+
+    def state(self):
+        return {k: self.get(k) for k in ("ug", "vg", "tg", "psg", "vors", "divs", "ts", "ln_ps")}
+
+    # -- transforms_mod
+    def _nlev(self, a, nd):
+        a = np.asarray(a)
+        return (a[None] if a.ndim == nd - 1 else a), a.ndim == nd - 1
+
+    def trans_spherical_to_grid(self, spherical):
+        s, two_d = self._nlev(spherical, 3)
+        s = np.ascontiguousarray(s, dtype=np.complex128)
+        g = np.zeros((s.shape[0], self.Jl, self.I))
+        self._check(self.lib.isca_trans_spherical_to_grid(self._h, _dptr(s.view(np.float64)), _dptr(g), s.shape[0]))
+        return g[0] if two_d else g
+
+    def trans_grid_to_spherical(self, grid, do_truncation=True):
+        g, two_d = self._nlev(grid, 3)
+        g = np.ascontiguousarray(g, dtype=np.float64)
+        s = np.zeros((g.shape[0], self.N1, self.M1), dtype=np.complex128)
+        self._check(self.lib.isca_trans_grid_to_spherical(self._h, _dptr(g), _dptr(s.view(np.float64)), g.shape[0],
+                                                          1 if do_truncation else 0))
+        return s[0] if two_d else s
+
+    def vor_div_from_uv_grid(self, u, v):
+        u, two_d = self._nlev(u, 3); v, _ = self._nlev(v, 3)
+        u = np.ascontiguousarray(u, dtype=np.float64); v = np.ascontiguousarray(v, dtype=np.float64)
+        vor = np.zeros((u.shape[0], self.N1, self.M1), dtype=np.complex128); div = np.zeros_like(vor)
+        self._check(self.lib.isca_vor_div_from_uv_grid(self._h, _dptr(u), _dptr(v), _dptr(vor.view(np.float64)),
+                                                       _dptr(div.view(np.float64)), u.shape[0]))
+        return (vor[0], div[0]) if two_d else (vor, div)
+
+    def uv_grid_from_vor_div(self, vor, div):
+        vor, two_d = self._nlev(vor, 3); div, _ = self._nlev(div, 3)
+        vor = np.ascontiguousarray(vor, dtype=np.complex128); div = np.ascontiguousarray(div, dtype=np.complex128)
+        u = np.zeros((vor.shape[0], self.Jl, self.I)); v = np.zeros_like(u)
+        self._check(self.lib.isca_uv_grid_from_vor_div(self._h, _dptr(vor.view(np.float64)), _dptr(div.view(np.float64)),
+                                                       _dptr(u), _dptr(v), vor.shape[0]))
+        return (u[0], v[0]) if two_d else (u, v)
+
+    def horizontal_advection(self, field_spec, u, v, tendency):
+        s = np.ascontiguousarray(field_spec, dtype=np.complex128)
+        u = np.ascontiguousarray(u, dtype=np.float64); v = np.ascontiguousarray(v, dtype=np.float64)
+        t = np.array(tendency, dtype=np.float64, order="C", copy=True)
+        self._check(self.lib.isca_horizontal_advection(self._h, _dptr(s.view(np.float64)), _dptr(u), _dptr(v), _dptr(t), s.shape[0]))
+        return t
+
+    def trans_spherical_to_fourier(self, spherical):
+        s = np.ascontiguousarray(spherical, dtype=np.complex128)
+        f = np.zeros((s.shape[0], self.J, self.M1), dtype=np.complex128)
+        self._check(self.lib.isca_trans_spherical_to_fourier(self._h, _dptr(s.view(np.float64)), _dptr(f.view(np.float64)), s.shape[0]))
+        return f
+
+    def trans_fourier_to_spherical(self, fourier):
+        f = np.ascontiguousarray(fourier, dtype=np.complex128)
+        s = np.zeros((f.shape[0], self.N1, self.M1), dtype=np.complex128)
+        self._check(self.lib.isca_trans_fourier_to_spherical(self._h, _dptr(f.view(np.float64)), _dptr(s.view(np.float64)), f.shape[0]))
+        return s
+
+    def trans_grid_to_fourier(self, grid):
+        g = np.ascontiguousarray(grid, dtype=np.float64)
+        f = np.zeros((g.shape[0], self.J, self.M1), dtype=np.complex128)
+        self._check(self.lib.isca_trans_grid_to_fourier(self._h, _dptr(g), _dptr(f.view(np.float64)), g.shape[0]))
+        return f
+
+    def trans_fourier_to_grid(self, fourier):
+        f = np.ascontiguousarray(fourier, dtype=np.complex128)
+        g = np.zeros((f.shape[0], self.J, self.I))
+        self._check(self.lib.isca_trans_fourier_to_grid(self._h, _dptr(f.view(np.float64)), _dptr(g), f.shape[0]))
+        return g
+
+    def area_weighted_global_mean(self, field2d):
+        a = np.ascontiguousarray(field2d, dtype=np.float64)
+        out = C.c_double()
+        self._check(self.lib.isca_area_weighted_global_mean(self._h, _dptr(a), C.cast(C.byref(out), C.POINTER(C.c_double))))
+        return out.value
+
+    def hs_forcing(self, dt, p_half, p_full, u, v, t, udt=None, vdt=None, tdt=None):
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (p_half, p_full, u, v, t)]
+        outs = [np.zeros_like(arrs[2]) if x is None else np.array(x, dtype=np.float64, copy=True) for x in (udt, vdt, tdt)]
+        self._check(self.lib.isca_hs_forcing(self._h, float(dt), *[_dptr(a) for a in arrs], *[_dptr(o) for o in outs]))
+        return tuple(outs)
+
+    # -- measurement
+    def bench_transform_pair(self, nfields: int, reps: int = 20):
+        pair = C.c_double()
+        k = np.zeros(4)
+        self._check(self.lib.isca_bench_transform_pair(self._h, nfields, reps, C.cast(C.byref(pair), C.POINTER(C.c_double)), _dptr(k)))
+        return pair.value, dict(zip(("legendre_inv", "fft_inv", "fft_fwd", "legendre_fwd"), k.tolist()))
+
+    def kernel_times(self, enable=True):
+        ms = np.zeros(64)
+        names = C.create_string_buffer(4096)
+        n = C.c_int()
+        self._check(self.lib.isca_dyn_kernel_times(self._h, 1 if enable else 0, _dptr(ms), 64, names, 4096, C.byref(n)))
+        nm = [x for x in names.value.decode().split(";") if x]
+        return dict(zip(nm, ms[: n.value].tolist()))

@@ -689,6 +689,10 @@ class SpectralCore:
         dt_vors, dt_divs = self.vor_div_from_uv_grid(dt_u, dt_v)
         phis_plus_ke = self.trans_grid_to_spherical(phig_full + 0.5 * (u ** 2 + v ** 2))
         dt_divs = dt_divs - self.compute_laplacian(phis_plus_ke)
+        # intermediates for stage-by-stage parity tests of the device pipeline
+        self.dbg = dict(g_dtu=self.divide_by_cos(dt_u), g_dtv=self.divide_by_cos(dt_v), g_dtT=dt_t,
+                        g_E=phig_full + 0.5 * (u ** 2 + v ** 2), g_dtlp=dt_ps / self.psg[cur], wg_full=wg_full,
+                        s_dtvor=dt_vors, s_dtdiv=dt_divs, s_dtT=dt_ts, s_dtlp=dt_ln_ps)
         # --- implicit, damping, leapfrog :906-931
         dt_divs, dt_ts, dt_ln_ps = self.implicit_correction(
             dt_divs, dt_ts, dt_ln_ps, self.divs, self.ts, self.ln_ps, delta_t, prev, cur)
