@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Headline benchmark: simulated years per wall-clock day of the T85L40 Held-Suarez dry dynamical core
+(BASELINE.json metric) on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one call of atmosphere (hs_forcing -> spectral_dynamics, atmosphere.F90:276-352) on the
+cold-started model, state resident in HBM.  Prints ONE JSON line (rank 0).
+"""
+import argparse, json, os, sys, time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+WORKLOADS = {  # name: (resolution, levels, dt_atmos)
+    "T85L40": ("T85", 40, 300.0), "T42L25": ("T42", 25, 600.0), "T21L25": ("T21", 25, 600.0),
+    "T170L60": ("T170", 60, 150.0),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TF = 78.6       # v_mfma_f64_16x16x4: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+
+
+def sim_years_per_day(sec_per_step, dt):
+    return 86400.0 / (sec_per_step * 360.0 * 86400.0 / dt)     # 360-day calendar (held_suarez_test_case.py:47-50)
+
+
+def cpu_baseline(workload, budget_steps):
+    """The reference's own Fortran (oracle/_ref, built in place by oracle/build_ref.py) on one host core,
+    bounded sample; falls back to the numpy oracle ("port") when the reference binary did not travel."""
+    res, L, dt = WORKLOADS[workload]
+    import tempfile
+    exe = os.path.join(REPO, "oracle", "_ref", "ref_harness.x")
+    if os.path.exists(exe):
+        from oracle import make_golden as mg
+        with tempfile.TemporaryDirectory(prefix="refbench_") as d:
+            mg.prepare_rundir(d, res, L, "run", nsteps=budget_steps, dt=dt, dump_steps=())
+            open(os.path.join(d, "harness.nml"), "w").write(
+                f" &harness_nml\n   mode = 'run', nsteps = {budget_steps}, dt_atmos = {int(dt)}, dump_steps = -1, dump_tables = .false.\n /\n")
+            out = mg.run_harness(d, exe=exe)
+        import re
+        m = re.search(r"REF_TIMING steps=\s*(\d+)\s+seconds=\s*(\S+)\s+ms_per_step=\s*(\S+)", out)
+        sec = float(m.group(2)) / int(m.group(1))
+        return {"value": sim_years_per_day(sec, dt), "unit": "sim_years/day", "cores": 1, "kind": "reference",
+                "ms_per_step": 1e3 * sec,
+                "sample": f"{budget_steps} steps of {workload} HS from cold start, reference Fortran (flang -O2, nocomm) on 1 host core"}
+    from oracle.isca_oracle import Config, SpectralCore
+    from isca_amd import dyncore
+    sc = SpectralCore(Config(num_levels=L, dt_atmos=dt, **dyncore.RESOLUTIONS[res]))
+    sc.cold_start()
+    n = max(2, budget_steps // 4)
+    t0 = time.time()
+    for _ in range(n):
+        sc.step()
+    sec = (time.time() - t0) / n
+    return {"value": sim_years_per_day(sec, dt), "unit": "sim_years/day", "cores": os.cpu_count(), "kind": "port",
+            "ms_per_step": 1e3 * sec, "sample": f"{n} steps of {workload} HS, numpy oracle (BLAS threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="T85L40", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-steps", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
+    a = ap.parse_args()
+    res, L, dt = WORKLOADS[a.workload]
+
+    import torch
+    from isca_amd import dyncore
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from isca_amd.parallel import ShardedDynCore
+        core = ShardedDynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, rank=rank, world_size=world, device=local_rank))
+        barrier = dist.barrier
+    else:
+        core = dyncore.DynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, device=local_rank))
+        barrier = lambda: None
+    core.cold_start()
+    core.step(a.warmup, sync=True)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    core.step(a.steps, sync=True)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    sec_per_step = elapsed / a.steps
+
+    # per-kernel durations: HIP events on the stream the kernels run on, same number of steps, right after
+    core.kernel_times(True)
+    core.step(min(a.steps, 200), sync=True)
+    kt = core.kernel_times(False)
+    if rank != 0:
+        return
+    I, J, M1, N = core.I, core.J, core.M1, core.cfg.num_fourier
+    field_bytes = 8.0 * I * J * L
+    # algorithmic bytes/flops per launch (DESIGN.md "Kernels")
+    col_bytes = 14.0 * field_bytes                                   # column kernel: ~14 L-level field passes
+    leg_flops_lf = J * (N + 1) * (N + 4)                             # per level-field
+    kern = {}
+    if "column" in kt:
+        kern["column"] = {"bound": "hbm", "ms": kt["column"], "achieved_GBs": col_bytes / (kt["column"] * 1e-3) / 1e9}
+    for nm, nlf in (("legendre_fwd", 4 * L + 1), ("legendre_inv", 7 * L + 3)):
+        if nm in kt:
+            kern[nm] = {"bound": "mfma", "ms": kt[nm], "achieved_TFs": nlf * leg_flops_lf / (kt[nm] * 1e-3) / 1e12}
+    for nm, nlf in (("fft_fwd", 4 * L + 1), ("fft_inv", 7 * L + 3)):
+        if nm in kt:
+            b = nlf * (8.0 * I * J + 16.0 * M1 * J)                  # one grid pass + one truncated Fourier pass
+            kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": b / (kt[nm] * 1e-3) / 1e9}
+    dom = max(kt, key=kt.get) if kt else None
+    roof = None
+    if dom == "column" or dom not in kern:
+        c = kern.get("column")
+        if c:
+            roof = {"kernel": "k_column", "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": col_bytes,
+                    "avg_launch_ms": c["ms"]}
+    else:
+        c = kern[dom]
+        if c["bound"] == "mfma":
+            roof = {"kernel": dom, "bound": "mfma", "achieved": c["achieved_TFs"], "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": c["achieved_TFs"] / FP64_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": c["ms"]}
+        else:
+            roof = {"kernel": dom, "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": c["ms"]}
+    out = {
+        "metric": "simulated-years/day at T85L40 Held-Suarez" if a.workload == "T85L40" else f"simulated-years/day at {a.workload} Held-Suarez",
+        "value": sim_years_per_day(sec_per_step, dt), "unit": "sim_years/day", "n_gpus": a.gpus, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * sec_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic (reference cold start: T=264 K at rest + 1e-7 vorticity seed)",
+        "config": {"workload": f"{a.workload} Held-Suarez dry core, dt_atmos={dt:g}s, 360-day calendar",
+                   "parallelism": f"lat-band x{a.gpus}" if a.gpus > 1 else "single GPU",
+                   "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": 2 if a.gpus > 1 else 0,
+                   "grid_tracer": "not advected yet (SURVEY 8f rank 2)"},
+        "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
+    }
+    if a.gpus == 1 and a.cpu_steps > 0:
+        out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,191 @@
+"""Parity of the HIP path (through the C-ABI, isca_amd/lib/libisca_dyn.so) with
+  (a) the committed reference outputs in tests/golden (produced by the reference Fortran itself), and
+  (b) the numpy oracle on seeded inputs at sizes it finishes in seconds,
+plus size-independent properties at BASELINE.json's full sizes (T85L40, T170).
+Tolerances: kernel level 1e-12 relative L-inf, one step 1e-11, one day 1e-9.
+"""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from isca_amd import dyncore                       # noqa: E402
+from oracle.isca_oracle import Config, SpectralCore   # noqa: E402  (checker only)
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def make(res, L, **kw):
+    return dyncore.DynCore(dyncore.default_config(res, num_levels=L, **kw))
+
+
+def oracle(res, L, **kw):
+    return SpectralCore(Config(num_levels=L, **dyncore.RESOLUTIONS[res], **kw))
+
+
+def rand_spec(rng, sc, L):
+    s = rng.standard_normal((L, sc.N1, sc.M1)) + 1j * rng.standard_normal((L, sc.N1, sc.M1))
+    s[..., 0] = s[..., 0].real
+    return s / (1.0 + sc.spherical_wave) ** 2 * sc.triangle_mask
+
+
+# ------------------------------------------------------------------ (a) against the reference's own outputs
+@pytest.mark.parametrize("name,res,L,impl", [("kernels_T10L8", "T10", 8, 1), ("kernels_T21L6", "T21", 6, 0),
+                                             ("kernels_T21L6", "T21", 6, 1)])
+def test_golden_kernels(golden_dir, name, res, L, impl):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dc = make(res, L, legendre_impl=impl)
+    assert np.array_equal(dc.table("sin_lat"), g["tab_sin_lat"]) and np.array_equal(dc.table("wts_lat"), g["tab_wts_lat"])
+    assert np.array_equal(dc.table("legendre"), g["tab_legendre"]) and np.array_equal(dc.table("bk"), g["tab_bk"])
+    assert np.array_equal(dc.table("deg_lat"), g["tab_deg_lat"]) and np.array_equal(dc.table("deg_lon"), g["tab_deg_lon"])
+    sa, sb, ga, gb = g["in_spec_a"], g["in_spec_b"], g["in_grid_a"], g["in_grid_b"]
+    assert rel(dc.trans_spherical_to_grid(sa), g["out_s2g_a"]) < 1e-12          # transforms.F90:379
+    assert rel(dc.trans_grid_to_spherical(ga), g["out_g2s_a"]) < 1e-12          # transforms.F90:462
+    assert rel(dc.trans_grid_to_spherical(ga, False), g["out_g2s_a_notrunc"]) < 1e-12
+    assert rel(dc.trans_spherical_to_fourier(sa), g["out_s2f_a"]) < 1e-12       # spherical_fourier.F90:177
+    assert rel(dc.trans_grid_to_fourier(ga), g["out_g2f_a"][..., : dc.M1]) < 1e-12   # grid_fourier.F90:129
+    vor, div = dc.vor_div_from_uv_grid(ga, gb)
+    assert rel(vor, g["out_vor_from_uv"]) < 1e-12 and rel(div, g["out_div_from_uv"]) < 1e-12
+    u, v = dc.uv_grid_from_vor_div(sa, sb)
+    assert rel(u, g["out_u_from_vd"]) < 1e-12 and rel(v, g["out_v_from_vd"]) < 1e-12
+    assert rel(dc.horizontal_advection(sa, ga, gb, np.zeros_like(ga)), g["out_hadv"]) < 1e-12
+    assert abs(dc.area_weighted_global_mean(ga[0]) - g["out_gmean"][0]) < 1e-13
+    ut, vt, tt = dc.hs_forcing(1200.0, g["out_p_half"], g["out_p_full"], ga, gb, g["in_temp"])
+    assert rel(ut, g["out_hs_dt_u"]) < 1e-12 and rel(vt, g["out_hs_dt_v"]) < 1e-12 and rel(tt, g["out_hs_dt_t"]) < 1e-12
+    dc.close()
+
+
+def test_golden_trajectory_T10L8(golden_dir):
+    g = np.load(os.path.join(golden_dir, "run_T10L8.npz"))
+    dc = make("T10", 8); dc.cold_start()
+    done = 0
+    for i in (1, 2, 3, 10, 50):
+        dc.step(i - done); done = i
+        s, tag = dc.state(), f"{i:06d}"
+        for k in ("ug", "vg"):
+            assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11
+        assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+        assert rel(s["ts"], g[f"st_ts_{tag}"]) < 1e-12 and rel(s["ln_ps"], g[f"st_lnps_{tag}"]) < 1e-12
+        assert rel(s["vors"], g[f"st_vors_{tag}"]) < 1e-10
+        assert rel(dc.get("wg_full"), g[f"st_wg_full_{tag}"]) < (1e-9 if i > 1 else 1.0)
+        assert rel(dc.get("p_full"), g[f"st_p_full_{tag}"]) < 1e-12 and rel(dc.get("z_full"), g[f"st_z_full_{tag}"]) < 1e-12
+    dc.close()
+
+
+def test_golden_T21L25_one_day(golden_dir):
+    """configs[0]: T21L25 Held-Suarez, 144 steps = 1 day, against the reference CPU run itself."""
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    dc = make("T21", 25); dc.cold_start()
+    dc.step(2)
+    for k in ("ug", "vg", "tg", "psg"):
+        assert rel(dc.get(k), g[f"st_{k}_000002"]) < 1e-10, k
+    dc.step(142)
+    for k in ("ug", "vg", "tg", "psg"):
+        assert rel(dc.get(k), g[f"st_{k}_000144"]) < 1e-9, k      # stated 1-day tolerance
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    dc.close()
+
+
+# ------------------------------------------------------------------ (b) against the oracle on seeded inputs
+@pytest.mark.parametrize("res,L,impl", [("T21", 25, 0), ("T42", 25, 0), ("T42", 25, 1)])
+def test_transform_stages_vs_oracle(res, L, impl):
+    dc, sc = make(res, L, legendre_impl=impl), oracle(res, L)
+    rng = np.random.default_rng(20260927)
+    sa, ga = rand_spec(rng, sc, L), 10 * rng.standard_normal((L, sc.J, sc.I))
+    f = sc.spherical_to_fourier(sa)
+    assert rel(dc.trans_spherical_to_fourier(sa), f) < 1e-13
+    full = np.zeros(f.shape[:-1] + (sc.I // 2 + 1,), dtype=complex); full[..., : sc.M1] = f
+    assert rel(dc.trans_fourier_to_grid(f), sc.fourier_to_grid(full)) < 1e-13
+    fr = sc.grid_to_fourier(ga)[..., : sc.M1]
+    assert rel(dc.trans_grid_to_fourier(ga), fr) < 1e-13
+    assert rel(dc.trans_fourier_to_spherical(fr), sc.fourier_to_spherical(fr)) < 1e-13
+    # ragged / edge shapes: a single 2-D field and num_levels+1 levels
+    assert rel(dc.trans_spherical_to_grid(sa[0]), sc.trans_spherical_to_grid(sa[0])) < 1e-13
+    s1 = np.concatenate([sa, sa[:1]]); assert rel(dc.trans_spherical_to_grid(s1), sc.trans_spherical_to_grid(s1)) < 1e-13
+    # empty input: zero coefficients give an exactly zero grid
+    assert np.all(dc.trans_spherical_to_grid(np.zeros_like(sa)) == 0.0)
+    dc.close()
+
+
+def test_T42L25_steps_vs_oracle():
+    """configs[1]: T42L25 HS on one MI355X, tolerance-checked against the CPU path (36 steps)."""
+    dc, sc = make("T42", 25), oracle("T42", 25)
+    dc.cold_start(); sc.cold_start()
+    for i in range(36):
+        sc.step()
+    dc.step(36)
+    st, so = dc.state(), sc.state()
+    for k in ("ug", "vg"):
+        assert np.max(np.abs(st[k] - so[k])) < 1e-10
+    for k in ("tg", "psg", "ts", "ln_ps"):
+        assert rel(st[k], so[k]) < 1e-11, k
+    assert rel(st["vors"], so["vors"]) < 1e-9
+    # developed-state intermediates of step 37 (phase API): grid tendencies and spectral tendencies
+    sc.step()
+    dc.step_phase(0); dc.step_phase(1)
+    for k in ("g_dtu", "g_dtv", "g_dtT", "g_E", "wg_full", "s_dtvor", "s_dtT"):
+        assert rel(dc.get(k), sc.dbg[k]) < 1e-8, k
+    dc.step_phase(2); dc.step_phase(3)
+    assert rel(dc.get("tg"), sc.state()["tg"]) < 1e-11
+    dc.close()
+
+
+def test_error_behaviour():
+    """FATAL conditions of check_dynamics_nml (spectral_dynamics.F90:666-755) surface as errors."""
+    with pytest.raises(dyncore.IscaError, match="longitude"):
+        make("T21", 25, lon_max=32)
+    with pytest.raises(dyncore.IscaError, match="latitude"):
+        make("T21", 25, lat_max=24)
+    dc = make("T21", 25)
+    with pytest.raises(dyncore.IscaError, match="no state"):
+        dc.step(1)
+    with pytest.raises(dyncore.IscaError):
+        dc.set("ug", np.zeros((3, 3, 3)))
+    dc.close()
+
+
+# ------------------------------------------------------------------ (c) full BASELINE sizes: properties
+@pytest.mark.parametrize("res,L", [("T85", 40), ("T170", 60)])
+def test_full_size_properties(res, L):
+    dc = make(res, L, dt_atmos=300.0 if res == "T85" else 150.0)
+    rng = np.random.default_rng(1)
+    M1, N1 = dc.M1, dc.N1
+    m = np.arange(M1)[None, :]; n = np.arange(N1)[:, None]
+    mask = (m + n <= dc.cfg.num_fourier)
+    def rs(nl):
+        s = rng.standard_normal((nl, N1, M1)) + 1j * rng.standard_normal((nl, N1, M1))
+        s[..., 0] = s[..., 0].real
+        return s / (1.0 + m + n) ** 2 * mask
+    a, b = rs(4), rs(4)
+    ga, gb = dc.trans_spherical_to_grid(a), dc.trans_spherical_to_grid(b)
+    # spectral -> grid -> spectral round trip is the identity on the truncated space
+    assert rel(dc.trans_grid_to_spherical(ga), a) < 1e-12
+    # linearity
+    assert rel(dc.trans_spherical_to_grid(2.0 * a - 3.0 * b), 2.0 * ga - 3.0 * gb) < 1e-12
+    # Parseval-type check: Gaussian quadrature of g^2 equals the spectral sum (normalisation int P^2 dmu = 1)
+    w = dc.table("wts_lat")[:, None]
+    quad = np.sum(w * ga[0] ** 2) / dc.I
+    spec = np.sum(np.abs(a[0][:, 0]) ** 2) + 2 * np.sum(np.abs(a[0][:, 1:]) ** 2)
+    assert abs(quad / spec - 1) < 1e-12
+    # (vor,div) -> (u,v) -> (vor,div) round trip
+    u, v = dc.uv_grid_from_vor_div(a, b)
+    vor, div = dc.vor_div_from_uv_grid(u, v)
+    assert rel(vor, a) < 1e-11 and rel(div, b) < 1e-11
+    # MFMA and plain-FMA Legendre kernels agree
+    dc1 = make(res, L, legendre_impl=1, dt_atmos=dc.cfg.dt_atmos)
+    assert rel(dc1.trans_spherical_to_grid(a), ga) < 1e-13
+    dc1.close()
+    # the model itself: mass is conserved by the fixer, state stays finite, mean T stays near 264 K
+    dc.cold_start()
+    ps0 = dc.area_weighted_global_mean(dc.get("psg"))
+    dc.step(20)
+    ps1 = dc.area_weighted_global_mean(dc.get("psg"))
+    assert abs(ps1 / ps0 - 1) < 1e-13
+    t = dc.get("tg")
+    assert np.isfinite(t).all() and 200 < t.min() and t.max() < 300
+    dc.close()

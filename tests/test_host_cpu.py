@@ -1,0 +1,65 @@
+"""CPU-side checks of the product's host layer: the C-ABI library loads and exports every symbol that
+include/isca_dyn.h declares, configuration errors follow the reference's FATAL conditions, and the
+product never imports the oracle.  No compute calls (no GPU here)."""
+import os, re, subprocess, sys
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from isca_amd import build, dyncore
+    build.build(verbose=False)
+    return dyncore.load_library()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "isca_dyn.h")).read()
+    declared = set(re.findall(r"\b(isca_[a-z_0-9]+)\s*\(", hdr))
+    declared.discard("isca_dyn_config")
+    assert len(declared) >= 25
+    from isca_amd import dyncore
+    assert declared == set(dyncore.EXPORTED_SYMBOLS), declared ^ set(dyncore.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_config_struct_matches_header(lib):
+    from isca_amd import dyncore
+    hdr = open(os.path.join(REPO, "include", "isca_dyn.h")).read()
+    start = hdr.index("typedef struct isca_dyn_config {") + len("typedef struct isca_dyn_config {")
+    body = hdr[start:hdr.index("} isca_dyn_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        m = re.match(r"(?:int|double|void \*)\s*(.*)", decl, flags=re.S)
+        if m:
+            names += [re.sub(r"\[.*\]|\*", "", x).strip() for x in m.group(1).split(",")]
+    assert names == [f[0] for f in dyncore._CConfig._fields_]
+    c = dyncore.default_config("T85", num_levels=40, dt_atmos=300.0)
+    assert (c.lon_max, c.lat_max, c.num_fourier, c.num_spherical) == (256, 128, 85, 86)
+    assert c.damping_order == 4 and c.robert_coeff == 0.04 and c.reference_sea_level_press == 1.0e5
+
+
+def test_no_device_fails_loudly(lib):
+    """No CPU fallback: without a HIP device creation must fail with a message (skipped on a GPU box)."""
+    import ctypes as C
+    from isca_amd import dyncore
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(dyncore.IscaError, match="no HIP device|no CPU fallback|hip"):
+        dyncore.DynCore(dyncore.default_config("T21"))
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "isca_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(root, f), errors="replace").read()
+                assert "oracle" not in txt.replace("the oracle", "").lower() or f == "build.py", f
