@@ -90,6 +90,13 @@ int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv*/, void **
                               size_t *bytes_per_peer);
 int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count);
 
+/* Pure host function (no GPU needed): the dealing of zonal wavenumbers m = 0..num_fourier to `world_size`
+ * ranks used by the lat<->m exchange (replaces the contiguous m-blocks of spec_mpp.F90:78-80 /
+ * mpp_domains_define.inc:164-250 by a boustrophedon deal that balances the triangle).
+ * m_of_slot[q*m_local + ml] = global m owned by rank q in local slot ml, or -1 for padding;
+ * *m_local = slots per rank.  m_of_slot must hold world_size*ceil((num_fourier+1)/world_size) ints. */
+int isca_wavenumber_dealing(int num_fourier, int world_size, int *m_of_slot, int *m_local);
+
 /* state access in the reference's layouts.  name is one of:
  *  grid 3-D (lon,lat_local,lev):  "ug","vg","tg","vorg","divg","wg_full","p_full","z_full","tr"
  *  grid 3-D half levels (lev+1):  "p_half","z_half"

@@ -94,6 +94,26 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   return 0;
 }
 
+static void deal_wavenumbers(int M1, int P, std::vector<int> &m_of_slot, int &Ml) {
+  // boustrophedon over ranks: round r deals m = r*P .. r*P+P-1 left-to-right (r even) or right-to-left
+  Ml = (M1 + P - 1) / P;
+  m_of_slot.assign((size_t)P * Ml, -1);
+  for (int idx = 0; idx < P * Ml; ++idx) {
+    const int r = idx / P, pos = idx % P;
+    const int q = (r % 2 == 0) ? pos : P - 1 - pos;
+    if (idx < M1) m_of_slot[(size_t)q * Ml + r] = idx;
+  }
+}
+extern "C" int isca_wavenumber_dealing(int num_fourier, int world_size, int *m_of_slot, int *m_local) {
+  API_BEGIN
+  if (num_fourier < 0 || world_size < 1 || !m_of_slot || !m_local) fail("invalid argument");
+  std::vector<int> v; int Ml;
+  deal_wavenumbers(num_fourier + 1, world_size, v, Ml);
+  std::memcpy(m_of_slot, v.data(), v.size() * sizeof(int));
+  *m_local = Ml;
+  API_END
+}
+
 static void check_config(const isca_dyn_config &c) {
   // check_dynamics_nml (spectral_dynamics.F90:666-755) + what this implementation supports
   if (c.num_fourier <= 0 || c.num_spherical <= 0 || c.num_levels <= 0) fail("invalid resolution");
@@ -185,13 +205,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     g.log2I = 0; while ((1 << g.log2I) < g.I) ++g.log2I;
     if (g.M1 > g.I / 2) fail("num_fourier too large for lon_max");
     // ---- wavenumber dealing: boustrophedon over ranks for triangular load balance
-    h->h_m_of_slot.assign((size_t)g.P * g.Ml, -1);
+    { int Ml; deal_wavenumbers(g.M1, g.P, h->h_m_of_slot, Ml); }
     h->h_slot_of_m.assign(g.M1, 0);
-    for (int idx = 0; idx < g.P * g.Ml; ++idx) {
-      const int r = idx / g.P, pos = idx % g.P;
-      const int q = (r % 2 == 0) ? pos : g.P - 1 - pos;
-      if (idx < g.M1) { h->h_m_of_slot[(size_t)q * g.Ml + r] = idx; h->h_slot_of_m[idx] = q * g.Ml + r; }
-    }
+    for (int sl = 0; sl < g.P * g.Ml; ++sl)
+      if (h->h_m_of_slot[sl] >= 0) h->h_slot_of_m[h->h_m_of_slot[sl]] = sl;
     h->h_m_local.assign(g.Ml, -1);
     for (int ml = 0; ml < g.Ml; ++ml) h->h_m_local[ml] = h->h_m_of_slot[(size_t)g.rank * g.Ml + ml];
     h->ml_of_m0 = -1;

@@ -67,6 +67,7 @@ def load_library():
         "isca_dyn_step_phase": [H, C.c_int],
         "isca_dyn_exchange_buffers": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "isca_dyn_reduce_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+        "isca_wavenumber_dealing": [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "isca_dyn_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
         "isca_dyn_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
         "isca_dyn_complete_update": [H, C.c_int],
@@ -97,7 +98,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
     "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_step_phase", "isca_dyn_exchange_buffers",
-    "isca_dyn_reduce_buffer", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
+    "isca_dyn_reduce_buffer", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
@@ -130,6 +131,17 @@ def default_config(resolution: str | None = None, **overrides) -> _CConfig:
         else:
             setattr(c, k, v)
     return c
+
+
+def wavenumber_dealing(num_fourier: int, world_size: int):
+    """m_of_slot[q, ml] (global m or -1) of the boustrophedon deal used by the lat<->m exchange."""
+    lib = load_library()
+    ml = (num_fourier + 1 + world_size - 1) // world_size
+    out = (C.c_int * (world_size * ml))()
+    n = C.c_int()
+    if lib.isca_wavenumber_dealing(num_fourier, world_size, out, C.byref(n)) != 0:
+        raise IscaError(lib.isca_last_error().decode())
+    return np.array(out[:], dtype=np.int64).reshape(world_size, n.value)
 
 
 def _dptr(a):

@@ -1,0 +1,101 @@
+"""Latitude-band sharding over the GPUs of one node: host side of the lat<->m exchange.
+
+The reference's "transpose method" (tools/spec_mpp.F90:61-80, transforms.F90:970-1056): grid space is
+split into latitude bands, spectral space into zonal-wavenumber sets, with ONE all-to-all between the
+FFT and the Legendre stage of every (batched) transform, plus the all-reduce of the fixer sums
+(transforms.F90:1059-1077 gathers instead).  Here each rank drives its own GPU through the phase API of
+the C-ABI and the exchanges go through torch.distributed ("nccl" = RCCL over xGMI on the GPU box;
+"gloo" with host staging for CPU-side tests).  Per step: 2 all-to-alls + 1 all-reduce of 5 doubles.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import dyncore
+
+
+class _DevPtr:
+    """__cuda_array_interface__ view of a device buffer owned by the C library."""
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+
+def exchange(send, recv, group=None):
+    """all_to_all_single of equal blocks [P][block]; stages through the host on non-NCCL backends."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(recv, send, group=group)
+        return
+    P = dist.get_world_size(group)
+    s = send.detach().cpu().reshape(P, -1)
+    outs = [torch.empty_like(s[0]) for _ in range(P)]
+    _gloo_all_to_all(outs, s, group)
+    recv.copy_(torch.stack(outs).reshape(recv.shape).to(recv.device))
+
+
+def _gloo_all_to_all(outs, s, group):
+    """gloo has no all_to_all: P rounds of scatter (root q scatters its P blocks)."""
+    import torch.distributed as dist
+    P = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    for root in range(P):
+        dist.scatter(outs[root], [s[q].contiguous() for q in range(P)] if me == root else None, src=root, group=group)
+
+
+def allreduce_sum(t, group=None):
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, group=group)
+        return
+    c = t.detach().cpu()
+    dist.all_reduce(c, group=group)
+    t.copy_(c.to(t.device))
+
+
+class ShardedDynCore(dyncore.DynCore):
+    """DynCore for world_size > 1: same interface, step() interleaves the device phases with the exchanges."""
+
+    def __init__(self, cfg, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        assert cfg.world_size == dist.get_world_size(group) and cfg.rank == dist.get_rank(group)
+        self._torch = torch
+        # one explicit stream shared by our kernels and (through stream-ordered waits) torch's collectives
+        self._stream = torch.cuda.Stream(device=cfg.device)
+        cfg.stream = self._stream.cuda_stream
+        super().__init__(cfg)
+        self._bufs = []
+        for which in (0, 1):
+            s, r, nbytes = self.exchange_buffers(which)
+            tot = nbytes * cfg.world_size
+            self._bufs.append((torch.as_tensor(_DevPtr(s, tot), device="cuda"), torch.as_tensor(_DevPtr(r, tot), device="cuda")))
+        b, n = self.reduce_buffer()
+        self._red = torch.as_tensor(_DevPtr(b, 8 * n), device="cuda")
+
+    def step(self, nsteps: int = 1, sync: bool = True):
+        with self._torch.cuda.stream(self._stream):
+            for _ in range(nsteps):
+                self.step_phase(0)                                          # grid tendencies + FFT
+                exchange(self._bufs[0][0], self._bufs[0][1], self.group)    # lat -> m   (transpose_fourier)
+                self.step_phase(1)                                          # Legendre, spectral update, Legendre
+                exchange(self._bufs[1][0], self._bufs[1][1], self.group)    # m -> lat   (reverse_transpose_fourier)
+                self.step_phase(2)                                          # inverse FFT + local fixer sums
+                allreduce_sum(self._red, self.group)                        # global means
+                self.step_phase(3)                                          # fixers, time-level rotation
+        if sync:
+            self._stream.synchronize()
+
+    def gather_grid(self, name, time_level=1):
+        """all-gather a grid field to every rank (tests/diagnostics): [lev, lat_global, lon]"""
+        import torch.distributed as dist
+        loc = self._torch.from_numpy(np.ascontiguousarray(self.get(name, time_level)))
+        parts = [self._torch.empty_like(loc) for _ in range(self.cfg.world_size)]
+        if dist.get_backend(self.group) == "nccl":
+            parts = [p.cuda() for p in parts]
+            dist.all_gather(parts, loc.cuda(), group=self.group)
+            parts = [p.cpu() for p in parts]
+        else:
+            dist.all_gather(parts, loc, group=self.group)
+        return np.concatenate([p.numpy() for p in parts], axis=-2)

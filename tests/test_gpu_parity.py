@@ -190,3 +190,18 @@ def test_full_size_properties(res, L):
     assert np.isfinite(t).all() and 200 < t.min() and t.max() < 300, (t.min(), t.max())
     assert abs(ps1 / ps0 - 1) < 1e-12, (ps0, ps1)
     dc.close()
+
+
+# ------------------------------------------------------------------ (d) latitude-band sharding on the device path
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_device_path_matches_single(world):
+    """N ranks drive the real HIP kernels in sharded mode on ONE GPU (gloo, host-staged exchange) and must
+    reproduce the single-rank model; on an 8-GPU node the same code runs with backend nccl (RCCL)."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
+           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "6"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
