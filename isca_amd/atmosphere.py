@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's module procedures for the hot path.
+
+Same names, argument meaning and error behaviour as
+  atmosphere_mod          (src/atmos_spectral/driver/solo/atmosphere.F90:78,120-390)
+  spectral_dynamics_mod   (src/atmos_spectral/model/spectral_dynamics.F90:95-98)
+  transforms_mod          (src/atmos_spectral/tools/transforms.F90:134-184)
+Like the Fortran modules this keeps ONE module-level instance ("module_is_initialized"); errors that are
+FATAL in the reference raise IscaError.  Arrays are numpy views of the reference's Fortran layouts:
+grid (lon,lat,lev) <-> [lev,lat,lon], spectral (m,n,lev) <-> [lev,n,m].
+"""
+from __future__ import annotations
+
+import re
+import numpy as np
+
+from . import dyncore
+from .dyncore import IscaError, RESOLUTIONS
+
+_core: dyncore.DynCore | None = None
+_NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
+
+
+def parse_namelist(text: str) -> dict:
+    """Minimal reader of the reference's input.nml format (&group key = value, ... /)."""
+    out: dict = {}
+    for grp, body in re.findall(r"&(\w+)(.*?)^\s*/", text, flags=re.S | re.M):
+        d = out.setdefault(grp.lower(), {})
+        body = re.sub(r"!.*", "", body)
+        for key, val in re.findall(r"(\w+)\s*=\s*(.*?)(?=,?\s*\w+\s*=|\s*$)", body, flags=re.S):
+            vals = [v.strip() for v in val.replace("\n", " ").split(",") if v.strip()]
+            conv = []
+            for v in vals:
+                lv = v.lower()
+                if lv in (".true.", "t", ".t."):
+                    conv.append(True)
+                elif lv in (".false.", "f", ".f."):
+                    conv.append(False)
+                elif v[0] in "'\"":
+                    conv.append(v.strip("'\""))
+                else:
+                    try:
+                        conv.append(int(v))
+                    except ValueError:
+                        conv.append(float(lv.replace("d", "e")))
+            d[key.lower()] = conv[0] if len(conv) == 1 else conv
+    return out
+
+
+def config_from_namelist(namelist: dict | str | None, resolution: str | None = None, **overrides):
+    """Build the C config from namelist groups (dict as in held_suarez_test_case.py:45-98, or input.nml text)."""
+    if isinstance(namelist, str):
+        namelist = parse_namelist(namelist)
+    kw: dict = {}
+    unsupported = {"vert_coord_option": "uneven_sigma", "damping_option": "resolution_dependent",
+                   "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
+                   "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
+                   "equilibrium_t_option": "Held_Suarez"}
+    for grp in _NML_GROUPS:
+        for k, v in (namelist or {}).get(grp, {}).items():
+            k = k.lower()
+            if k in unsupported:
+                if str(v).lower() != unsupported[k].lower():
+                    raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
+                continue
+            if k in ("days", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
+                     "graceful_shutdown", "ocean_topog_smoothing", "use_virtual_temperature", "use_implicit"):
+                continue
+            if isinstance(v, bool):
+                v = int(v)
+            kw[k] = tuple(v) if isinstance(v, list) else v
+    kw.update(overrides)
+    return dyncore.default_config(resolution, **kw)
+
+
+# ---------------------------------------------------------------- atmosphere_mod
+def atmosphere_init(namelist=None, resolution: str | None = None, **overrides):
+    """atmosphere.F90:120-272: spectral_dynamics_init + cold start (no restart present) + hs_forcing_init."""
+    global _core
+    if _core is not None:
+        return _core                                   # `if(module_is_initialized) return`
+    _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
+    _core.cold_start()
+    return _core
+
+
+def atmosphere(nsteps: int = 1):
+    """atmosphere.F90:276-352: one call advances the model by dt_atmos."""
+    if _core is None:
+        raise IscaError("atmosphere: atmosphere module is not initialized")
+    _core.step(nsteps)
+
+
+def atmosphere_end():
+    global _core
+    if _core is not None:
+        _core.close()
+        _core = None
+
+
+def _need():
+    if _core is None:
+        raise IscaError("spectral_dynamics has not been initialized")
+    return _core
+
+
+# ---------------------------------------------------------------- spectral_dynamics_mod getters
+def spectral_dynamics_init(namelist=None, resolution=None, **overrides):
+    return atmosphere_init(namelist, resolution, **overrides)
+
+
+def get_num_levels():
+    return _need().L
+
+
+def get_pk_bk():
+    c = _need()
+    return c.table("pk"), c.table("bk")
+
+
+def get_field(name: str, time_level: str = "current"):
+    return _need().get(name, 1 if time_level == "current" else 0)
+
+
+def get_initial_fields():
+    c = _need()
+    if c.info("step") != 0:
+        raise IscaError("get_initial_fields: This routine may be called only to get the initial values after a cold_start")
+    return c.get("ug"), c.get("vg"), c.get("tg"), c.get("psg")
+
+
+# ---------------------------------------------------------------- transforms_mod
+def trans_spherical_to_grid(spherical):
+    return _need().trans_spherical_to_grid(spherical)
+
+
+def trans_grid_to_spherical(grid, do_truncation=True):
+    return _need().trans_grid_to_spherical(grid, do_truncation)
+
+
+def vor_div_from_uv_grid(u_grid, v_grid):
+    return _need().vor_div_from_uv_grid(u_grid, v_grid)
+
+
+def uv_grid_from_vor_div(vor_spec, div_spec):
+    return _need().uv_grid_from_vor_div(vor_spec, div_spec)
+
+
+def horizontal_advection(field_spec, u_grid, v_grid, tendency):
+    return _need().horizontal_advection(field_spec, u_grid, v_grid, tendency)
+
+
+def area_weighted_global_mean(field):
+    return _need().area_weighted_global_mean(field)
+
+
+def get_deg_lat():
+    return _need().table("deg_lat")
+
+
+def get_deg_lon():
+    return _need().table("deg_lon")
+
+
+def get_sin_lat():
+    return _need().table("sin_lat")
+
+
+def get_wts_lat():
+    return _need().table("wts_lat")

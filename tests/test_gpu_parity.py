@@ -205,3 +205,21 @@ def test_sharded_device_path_matches_single(world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_atmosphere_module_mirror(golden_dir):
+    """The module-level mirror of atmosphere_mod / transforms_mod drives the same C-ABI."""
+    from isca_amd import atmosphere as atm
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    nml = {"main_nml": {"dt_atmos": 600}, "spectral_dynamics_nml": {"damping_order": 4, "num_levels": 25,
+           "vert_coord_option": "uneven_sigma", "scale_heights": 6.0, "exponent": 7.5, "surf_res": 0.5,
+           "reference_sea_level_press": 1.0e5, "valid_range_t": [100., 800.]}}
+    atm.atmosphere_init(nml, resolution="T21")
+    u0, v0, t0, p0 = atm.get_initial_fields()
+    assert rel(t0, np.full_like(t0, 264.0)) < 1e-12
+    atm.atmosphere(2)
+    assert rel(atm.get_field("tg"), g["st_tg_000002"]) < 1e-11
+    with pytest.raises(dyncore.IscaError):
+        atm.get_initial_fields()
+    assert np.array_equal(atm.get_deg_lat(), g["tab_deg_lat"])
+    atm.atmosphere_end()

@@ -63,3 +63,28 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert "oracle" not in txt.replace("the oracle", "").lower() or f == "build.py", f
+
+
+def test_namelist_to_config(lib):
+    """The reference's input.nml keys (held_suarez_test_case.py:45-98) map onto the C config; unsupported option
+    values are FATAL like in the reference's own checks."""
+    from isca_amd import atmosphere as atm, dyncore
+    nml_text = '''
+ &spectral_dynamics_nml
+    damping_order = 4,  water_correction_limit = 200.e2, reference_sea_level_press = 1.0e5,
+    valid_range_t = 100., 800., vert_coord_option = 'uneven_sigma', scale_heights = 6.0, exponent = 7.5,
+    surf_res = 0.5, lon_max = 128, lat_max = 64, num_fourier = 42, num_spherical = 43, num_levels = 25 /
+ &hs_forcing_nml
+    t_zero = 315., ka = -40., ks = -4., kf = -1., do_conserve_energy = .true. /
+ &main_nml
+    dt_atmos = 600, days = 30, calendar = 'thirty_day' /
+'''
+    c = atm.config_from_namelist(nml_text)
+    assert (c.lon_max, c.lat_max, c.num_fourier, c.num_levels) == (128, 64, 42, 25)
+    assert c.dt_atmos == 600.0 and c.water_correction_limit == 200.e2 and list(c.valid_range_t) == [100.0, 800.0]
+    assert c.do_conserve_energy == 1 and c.ka == -40.0
+    d = {"spectral_dynamics_nml": {"damping_order": 4, "vert_coord_option": "hybrid"}}
+    with pytest.raises(dyncore.IscaError, match="vert_coord_option"):
+        atm.config_from_namelist(d, "T21")
+    with pytest.raises(dyncore.IscaError, match="not initialized"):
+        atm.atmosphere()
