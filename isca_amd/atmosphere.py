@@ -23,10 +23,30 @@ _NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
 def parse_namelist(text: str) -> dict:
     """Minimal reader of the reference's input.nml format (&group key = value, ... /)."""
     out: dict = {}
-    for grp, body in re.findall(r"&(\w+)(.*?)^\s*/", text, flags=re.S | re.M):
-        d = out.setdefault(grp.lower(), {})
-        body = re.sub(r"!.*", "", body)
-        for key, val in re.findall(r"(\w+)\s*=\s*(.*?)(?=,?\s*\w+\s*=|\s*$)", body, flags=re.S):
+    text = re.sub(r"!.*", "", text)
+    pos = 0
+    while True:
+        m = re.search(r"&(\w+)", text[pos:])
+        if not m:
+            break
+        grp = m.group(1).lower()
+        i = pos + m.end()
+        j, quote = i, None
+        while j < len(text):                       # the terminating '/' outside quotes
+            ch = text[j]
+            if quote:
+                quote = None if ch == quote else quote
+            elif ch in "'\"":
+                quote = ch
+            elif ch == "/":
+                break
+            j += 1
+        body = text[i:j]
+        pos = j + 1
+        d = out.setdefault(grp, {})
+        keys = list(re.finditer(r"(\w+)\s*=", body))
+        for n, km in enumerate(keys):
+            val = body[km.end(): keys[n + 1].start() if n + 1 < len(keys) else len(body)]
             vals = [v.strip() for v in val.replace("\n", " ").split(",") if v.strip()]
             conv = []
             for v in vals:
@@ -42,7 +62,8 @@ def parse_namelist(text: str) -> dict:
                         conv.append(int(v))
                     except ValueError:
                         conv.append(float(lv.replace("d", "e")))
-            d[key.lower()] = conv[0] if len(conv) == 1 else conv
+            if conv:
+                d[km.group(1).lower()] = conv[0] if len(conv) == 1 else conv
     return out
 
 
