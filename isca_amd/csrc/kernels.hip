@@ -731,123 +731,176 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
   ttnd = ttnd + (-tdamp * (tp - teq));
 }
 
-__global__ __launch_bounds__(64) void k_column(Geom g, ColumnArgs a) {
+// Block = 64 consecutive columns x NW wavefronts; wavefront w owns the contiguous levels [w*CH, w*CH+CH).
+// The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
+// everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
+// together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
+template <int CH>
+__global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
-  double *lph = (double *)smem;            // [L+1][64]
-  double *lpf = lph + (L + 1) * 64;        // [L][64]
-  const int tid = threadIdx.x;
-  const int col = blockIdx.x * 64 + tid;   // 64 divides I
+  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  double *lds_dm = (double *)smem;          // [NW][64] chunk sums of dmean
+  double *lds_a = lds_dm + NW * 64;         // [NW][64] chunk sums of RDGAS*T*dlog3
+  double *lds_e = lds_a + NW * 64;          // [NW] energy partials
+  const int col = blockIdx.x * 64 + tid;
   const int jl = col / I;
-  const size_t c2 = (size_t)col;           // index into [Jl][I]
-  const size_t lev = (size_t)g.Jl * I;     // level stride
-  const double ps = a.ps[c2];
+  const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
+  const int k0 = w * CH, nk = min(CH, L - k0);          // nk >= 1 by construction of NW
+  const double ps = a.ps[c2], psp = a.psp[c2];
   const double dx_ps = ps * a.dxlp[c2], dy_ps = ps * a.dylp[c2];
   const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
-  // ---- pass 0: total mass divergence
-  double dmean_total = 0.0;
-  for (int k = 0; k < L; ++k) {
+  const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
+  double u[CH], v[CH], t[CH], dm[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int k = k0 + (i < nk ? i : 0);
+    const size_t q = c2 + (size_t)k * lev;
+    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
     const double dp = a.dpk[k] + a.dbk[k] * ps;
-    dmean_total = dmean_total + (a.div[c2 + k * lev] * dp + a.dbk[k] * (a.u[c2 + k * lev] * dx_ps + a.v[c2 + k * lev] * dy_ps));
+    dm[i] = (i < nk) ? a.div[q] * dp + a.dbk[k] * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
   }
-  // ---- pressure variables of the column -> LDS (ln p at half and full levels)
+  // neighbours across the chunk boundary for the centred vertical fluxes
+  double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
+  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
+  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
+  // ln p at my half levels k0..k0+nk and full levels (press_and_geopot.F90:165-194)
+  double lph[CH + 1], lpf[CH];
   {
-    double ph_k = a.pk[0] + a.bk[0] * ps;
-    double l_k = top0 ? 0.0 : log(ph_k);
-    lph[0 * 64 + tid] = l_k;
-    for (int k = 0; k < L; ++k) {
+    const double ph0 = a.pk[k0] + a.bk[k0] * ps;
+    lph[0] = (top0 && k0 == 0) ? 0.0 : log(ph0);
+    double ph_k = ph0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int k = k0 + (i < nk ? i : 0);
       const double ph_n = a.pk[k + 1] + a.bk[k + 1] * ps;
       const double l_n = log(ph_n);
-      lph[(k + 1) * 64 + tid] = l_n;
-      double lf;
-      if (top0 && k == 0) lf = l_n - 1.0;
-      else { const double alpha = 1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k); lf = l_n - alpha; }
-      lpf[k * 64 + tid] = lf;
-      ph_k = ph_n; l_k = l_n;
+      lph[i + 1] = l_n;
+      if (top0 && k == 0) lpf[i] = l_n - 1.0;
+      else lpf[i] = l_n - (1.0 - ph_k * (l_n - lph[i]) / (ph_n - ph_k));
+      ph_k = ph_n;
     }
+  }
+  double csum = 0.0, asum = 0.0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int k = k0 + (i < nk ? i : 0);
+    csum += dm[i];
+    asum += (i < nk && k >= ktop) ? RDGAS * t[i] * (lph[i + 1] - lph[i]) : 0.0;
+  }
+  lds_dm[w * 64 + tid] = csum;
+  lds_a[w * 64 + tid] = asum;
+  __syncthreads();
+  double base = 0.0, total = 0.0, below = 0.0;
+  for (int ww = 0; ww < NW; ++ww) {
+    const double x = lds_dm[ww * 64 + tid];
+    total += x;
+    if (ww < w) base += x;
+    if (ww > w) below += lds_a[ww * 64 + tid];
   }
   const double sin_lat = sin(a.rad_lat[jl]);
   const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
   const double cosm = a.cosm[jl], cor = a.coriolis[jl];
-  const double psp = a.psp[c2];
-  // ---- pass 1: top-down
-  double dmean_tot = 0.0, wg_k = 0.0;       // wg at interface k (top of level k)
-  double um = 0., vm = 0., tm = 0.;         // r(k-1)
-  double uc = a.u[c2], vc = a.v[c2], tc = a.t[c2];
-  double e_prev = 0.0;                      // column integral of the "previous" energy
-  for (int k = 0; k < L; ++k) {
-    const size_t q = c2 + k * lev;
-    const double un = (k + 1 < L) ? a.u[q + lev] : 0.0, vn = (k + 1 < L) ? a.v[q + lev] : 0.0, tn = (k + 1 < L) ? a.t[q + lev] : 0.0;
-    const double l_h0 = lph[k * 64 + tid], l_h1 = lph[(k + 1) * 64 + tid], l_f = lpf[k * 64 + tid];
-    const double p_full = exp(l_f);
-    // physics at the previous level
-    const double upv = a.up[q], vpv = a.vp[q], tpv = a.tp[q];
-    double dt_u, dt_v, dt_t;
-    hs_level(a, a.delta_t, ps, p_full, upv, vpv, tpv, sin_lat, sin2, cos2, cos4, dt_u, dt_v, dt_t);
-    {  // initialize_corrections (:1318-1321): energy of previous + physics increments, dp from psg(previous)
-      const double ue = upv + dt_u * a.delta_t, ve = vpv + dt_v * a.delta_t;
-      const double en = 0.5 * (ue * ue + ve * ve) + CP_AIR * (tpv + dt_t * a.delta_t);
-      e_prev = e_prev + en * (a.dpk[k] + a.dbk[k] * psp);
+  const double lnP00 = log(a.P00);
+  const double vcoeff = -a.vkf / (1.0 - a.sigma_b), tcoeff = (a.tks - a.tka) / (1.0 - a.sigma_b);
+  const double t_star = a.t_zero - a.delh * sin2 - a.eps * sin_lat, tstr = a.t_strat - a.eps * sin_lat;
+  const double rps = 1. / ps;
+  double dmean_tot = base;
+  double wg_k = (k0 == 0) ? 0.0 : (-base + total * a.bk[k0]);
+  double e_prev = 0.0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (i < nk) {
+      const int k = k0 + i;
+      const size_t q = c2 + (size_t)k * lev;
+      const double l_h0 = lph[i], l_h1 = lph[i + 1], l_f = lpf[i];
+      const double upi = a.up[q], vpi = a.vp[q], tpi = a.tp[q], voi = a.vor[q], dxti = a.dxT[q], dyti = a.dyT[q];
+      const double p_full = exp(l_f);
+      // ---- hs_forcing at the previous level (rayleigh :615-679, dissipative heating :198-200, newtonian :508-611)
+      const double sigma = p_full * rps;
+      const bool bl = (sigma <= 1.0) && (sigma > a.sigma_b);
+      const double vfactr = bl ? vcoeff * (sigma - a.sigma_b) : 0.0;
+      double dt_u = vfactr * upi, dt_v = vfactr * vpi, dt_t = 0.0;
+      if (a.do_conserve_energy) dt_t = -((upi + .5 * dt_u * a.delta_t) * dt_u + (vpi + .5 * dt_v * a.delta_t) * dt_v) / CP_AIR;
+      {
+        const double lpn = l_f - lnP00;                       // log(p_full/P00)
+        const double the = t_star - a.delv * cos2 * lpn;
+        const double teq = fmax(the * exp(KAPPA * lpn), tstr);   // (p/P00)**kappa
+        const double tdamp = bl ? a.tka + cos4 * (tcoeff * (sigma - a.sigma_b)) : a.tka;
+        dt_t = dt_t + (-tdamp * (tpi - teq));
+      }
+      {  // initialize_corrections (:1318-1321)
+        const double ue = upi + dt_u * a.delta_t, ve = vpi + dt_v * a.delta_t;
+        e_prev += (0.5 * (ue * ue + ve * ve) + CP_AIR * (tpi + dt_t * a.delta_t)) * (a.dpk[k] + a.dbk[k] * psp);
+      }
+      // ---- four_in_one (:1064-1083)
+      const double dp = a.dpk[k] + a.dbk[k] * ps, dp_inv = 1 / dp;
+      const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
+      const double x1 = (a.bk[k + 1] * dlog_1 + a.bk[k] * dlog_2) * dp_inv;
+      const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
+      const double uc = u[i], vc = v[i], tc = t[i];
+      dt_u = dt_u - RDGAS * tc * x2;
+      dt_v = dt_v - RDGAS * tc * x3;
+      const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
+      const double x5 = x4 - uc * x2 - vc * x3;
+      dt_t = dt_t - KAPPA * tc * x5;
+      a.wg_full[q] = -x5 * p_full;
+      dmean_tot = dmean_tot + dm[i];
+      const double wg_n = (k + 1 < L) ? (-dmean_tot + total * a.bk[k + 1]) : 0.0;
+      // ---- vert_advection SECOND_CENTERED / ADVECTIVE_FORM (vert_advection.F90:185-193, 467-470)
+      const double ukm = (i == 0) ? um : u[i > 0 ? i - 1 : 0], vkm = (i == 0) ? vm : v[i > 0 ? i - 1 : 0], tkm = (i == 0) ? tm : t[i > 0 ? i - 1 : 0];
+      const double ukp = (i == nk - 1) ? un : u[i + 1 < CH ? i + 1 : i], vkp = (i == nk - 1) ? vn : v[i + 1 < CH ? i + 1 : i], tkp = (i == nk - 1) ? tn : t[i + 1 < CH ? i + 1 : i];
+      {
+        const double dw = wg_n - wg_k;
+        const double fu0 = (k == 0) ? wg_k * uc : wg_k * (0.5 * (uc + ukm));
+        const double fv0 = (k == 0) ? wg_k * vc : wg_k * (0.5 * (vc + vkm));
+        const double ft0 = (k == 0) ? wg_k * tc : wg_k * (0.5 * (tc + tkm));
+        const double fu1 = (k + 1 < L) ? wg_n * (0.5 * (ukp + uc)) : wg_n * uc;
+        const double fv1 = (k + 1 < L) ? wg_n * (0.5 * (vkp + vc)) : wg_n * vc;
+        const double ft1 = (k + 1 < L) ? wg_n * (0.5 * (tkp + tc)) : wg_n * tc;
+        dt_u = dt_u + (-(fu1 - fu0 - uc * dw) / dp);
+        dt_v = dt_v + (-(fv1 - fv0 - vc * dw) / dp);
+        dt_t = dt_t + (-(ft1 - ft0 - tc * dw) / dp);
+      }
+      // ---- horizontal T advection (transforms.F90:828), vorticity/Coriolis terms (:895-896)
+      dt_t = dt_t - uc * dxti - vc * dyti;
+      const double av = voi + cor;
+      dt_u = dt_u + av * vc;
+      dt_v = dt_v - av * uc;
+      a.dtu[q] = dt_u * cosm;
+      a.dtv[q] = dt_v * cosm;
+      a.dtT[q] = dt_t;
+      wg_k = wg_n;
     }
-    // four_in_one
-    const double dp = a.dpk[k] + a.dbk[k] * ps, dp_inv = 1 / dp;
-    const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
-    const double x1 = (a.bk[k + 1] * dlog_1 + a.bk[k] * dlog_2) * dp_inv;
-    const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
-    dt_u = dt_u - RDGAS * tc * x2;
-    dt_v = dt_v - RDGAS * tc * x3;
-    const double dmean = a.div[q] * dp + a.dbk[k] * (uc * dx_ps + vc * dy_ps);
-    const double x4 = (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv;
-    const double x5 = x4 - uc * x2 - vc * x3;
-    dt_t = dt_t - KAPPA * tc * x5;
-    a.wg_full[q] = -x5 * p_full;
-    dmean_tot = dmean_tot + dmean;
-    const double wg_n = (k + 1 < L) ? (-dmean_tot + dmean_total * a.bk[k + 1]) : 0.0;   // interface k+1
-    // vert_advection, SECOND_CENTERED + ADVECTIVE_FORM
-    {
-      const double dw = wg_n - wg_k;
-      const double fu0 = (k == 0) ? wg_k * uc : wg_k * (0.5 * (uc + um));
-      const double fv0 = (k == 0) ? wg_k * vc : wg_k * (0.5 * (vc + vm));
-      const double ft0 = (k == 0) ? wg_k * tc : wg_k * (0.5 * (tc + tm));
-      const double fu1 = (k + 1 < L) ? wg_n * (0.5 * (un + uc)) : wg_n * uc;
-      const double fv1 = (k + 1 < L) ? wg_n * (0.5 * (vn + vc)) : wg_n * vc;
-      const double ft1 = (k + 1 < L) ? wg_n * (0.5 * (tn + tc)) : wg_n * tc;
-      dt_u = dt_u + (-(fu1 - fu0 - uc * dw) / dp);
-      dt_v = dt_v + (-(fv1 - fv0 - vc * dw) / dp);
-      dt_t = dt_t + (-(ft1 - ft0 - tc * dw) / dp);
-    }
-    // horizontal advection of T, vorticity/Coriolis terms
-    dt_t = dt_t - uc * a.dxT[q] - vc * a.dyT[q];
-    const double av = a.vor[q] + cor;
-    dt_u = dt_u + av * vc;
-    dt_v = dt_v - av * uc;
-    a.dtu[q] = dt_u * cosm;      // vor_div_from_uv_grid divides by cos before the analysis (transforms.F90:764-770)
-    a.dtv[q] = dt_v * cosm;
-    a.dtT[q] = dt_t;
-    um = uc; vm = vc; tm = tc; uc = un; vc = vn; tc = tn; wg_k = wg_n;
   }
-  a.dtlp[c2] = (0.0 - dmean_tot) / ps;     // dt_psg - dmean_tot, then /psg (:873)
-  // ---- pass 2: bottom-up hydrostatic integral, Phi + KE
+  if (w == NW - 1) a.dtlp[c2] = (0.0 - total) / ps;     // (dt_psg - dmean_tot)/psg (:873, :1102)
+  // ---- hydrostatic integral bottom-up within the chunk, Phi + KE (:350-356, :902)
   {
-    double gh = 0.0;                        // flat topography: surf_geopotential = 0
-    const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
-    for (int k = L - 1; k >= 0; --k) {
-      const size_t q = c2 + k * lev;
-      const double tk = a.t[q], uk = a.u[q], vk = a.v[q];
-      const double l_h0 = lph[k * 64 + tid], l_h1 = lph[(k + 1) * 64 + tid], l_f = lpf[k * 64 + tid];
-      const double gf = gh + RDGAS * tk * (l_h1 - l_f);
-      a.E[q] = gf + .5 * (uk * uk + vk * vk);
-      if (k >= ktop) gh = gh + RDGAS * tk * (l_h1 - l_h0);
+    double gh = below;
+#pragma unroll
+    for (int i = CH - 1; i >= 0; --i) {
+      if (i < nk) {
+        const size_t q = c2 + (size_t)(k0 + i) * lev;
+        a.E[q] = gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]);
+        if (k0 + i >= ktop) gh = gh + RDGAS * t[i] * (lph[i + 1] - lph[i]);
+      }
     }
   }
-  // ---- block partial sums for mean_surf_press_previous and mean_energy_previous
-  double s_ps = a.wts[jl] * psp, s_en = a.wts[jl] * e_prev;
+  // ---- block partial sums: mean_surf_press_previous, mean_energy_previous
+  double s_en = a.wts[jl] * e_prev, s_ps = (w == 0) ? a.wts[jl] * psp : 0.0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     s_ps += __shfl_down(s_ps, off, 64);
     s_en += __shfl_down(s_en, off, 64);
   }
-  if (tid == 0) { a.partials[2 * blockIdx.x] = s_ps; a.partials[2 * blockIdx.x + 1] = s_en; }
+  if (tid == 0) lds_e[w] = s_en;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double e = 0.0;
+    for (int ww = 0; ww < NW; ++ww) e += lds_e[ww];
+    a.partials[2 * blockIdx.x] = s_ps;
+    a.partials[2 * blockIdx.x + 1] = e;
+  }
 }
 
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
@@ -866,8 +919,16 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
-  const size_t lds = (size_t)(2 * g.L + 1) * 64 * sizeof(double);
-  hipLaunchKernelGGL(k_column, dim3((unsigned)column_partials_count(h)), dim3(64), lds, s, g, a);
+  const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
+  const int NW = (g.L + CH - 1) / CH;
+  const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double);
+  const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
+#define LC(N) hipLaunchKernelGGL(k_column<N>, grid, block, lds, s, g, a)
+  switch (CH) {
+    case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
+    case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
+  }
+#undef LC
 }
 
 // standalone hs_forcing on caller fields (for the C-ABI entry point / parity tests)
