@@ -268,8 +268,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     d.wave_mat_t = dalloc<double>(h, (size_t)cfg->num_spherical * g.L * g.L);
     {
-      std::vector<double> tw((size_t)g.I);
-      for (int k = 0; k < g.I / 2; ++k) { tw[2 * k] = T.tw_re[k]; tw[2 * k + 1] = T.tw_im[k]; }
+      std::vector<double> tw((size_t)2 * g.I);
+      for (int k = 0; k < g.I; ++k) { tw[2 * k] = T.tw_re[k]; tw[2 * k + 1] = T.tw_im[k]; }
       d.tw = dupload(h, tw);
     }
     // ---- state

@@ -28,16 +28,91 @@ enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP
 // done as one complex Stockham FFT of length I/2 per row in LDS + the even/odd split.
 // One block = R rows (R consecutive level-fields at one latitude), 256 threads.
 // =====================================================================================================
-template <int R>
+// ---- in-register radix-2/4/8 butterflies (INV: conjugate transform)
+template <bool INV> __device__ __forceinline__ double2 mul_mi(double2 a) {   // * (-i) forward, * (+i) inverse
+  return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
+}
+template <bool INV> __device__ __forceinline__ void dft4(double2 &a0, double2 &a1, double2 &a2, double2 &a3) {
+  const double2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mi<INV>(csub(a1, a3));
+  a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+}
+template <bool INV, int R> __device__ __forceinline__ void dftR(double2 (&v)[R]) {
+  if constexpr (R == 2) {
+    const double2 a = v[0], b = v[1];
+    v[0] = cadd(a, b); v[1] = csub(a, b);
+  } else if constexpr (R == 4) {
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+  } else {
+    dft4<INV>(v[0], v[2], v[4], v[6]);      // E0..E3 -> v0,v2,v4,v6
+    dft4<INV>(v[1], v[3], v[5], v[7]);      // O0..O3 -> v1,v3,v5,v7
+    const double h = 0.70710678118654752440;
+    const double2 o1 = v[3], o3 = v[7];
+    const double2 w1 = INV ? make_double2(h * (o1.x - o1.y), h * (o1.x + o1.y)) : make_double2(h * (o1.x + o1.y), h * (o1.y - o1.x));
+    const double2 w2 = mul_mi<INV>(v[5]);
+    const double2 w3 = INV ? make_double2(-h * (o3.x + o3.y), h * (o3.x - o3.y)) : make_double2(h * (o3.y - o3.x), -h * (o3.x + o3.y));
+    const double2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], w0 = v[1];
+    v[0] = cadd(e0, w0); v[4] = csub(e0, w0);
+    v[1] = cadd(e1, w1); v[5] = csub(e1, w1);
+    v[2] = cadd(e2, w2); v[6] = csub(e2, w2);
+    v[3] = cadd(e3, w3); v[7] = csub(e3, w3);
+  }
+}
+__device__ __forceinline__ int fpad(int i) { return i + (i >> 3); }     // LDS padding: 1 slot per 8
+
+// One Stockham pass of radix R at stride S over a row of NC complex points held in LDS (in place: all reads,
+// barrier, all writes, barrier).  16 threads per row.  twl = LDS copy of exp(-2 pi i k / (2 NC)), k < 2 NC.
+template <int NC, int R, int S, bool INV>
+__device__ __forceinline__ void fft_pass(double2 *row, const double2 *twl, int tr) {
+  constexpr int NB = NC / R, M = NB / S, PER = (NB + 15) / 16;
+  double2 v[PER][R];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int b = tr + 16 * i;
+    if (b < NB) {
+      const int p = b / S, q = b - p * S;
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[i][j] = row[fpad(q + S * (p + j * M))];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int b = tr + 16 * i;
+    if (b < NB) {
+      const int p = b / S, q = b - p * S;
+      dftR<INV, R>(v[i]);
+      row[fpad(q + S * (R * p))] = v[i][0];
+#pragma unroll
+      for (int j = 1; j < R; ++j) {
+        double2 w = twl[2 * S * j * p];
+        if (INV) w.y = -w.y;
+        row[fpad(q + S * (R * p + j))] = cmul(v[i][j], w);
+      }
+    }
+  }
+  __syncthreads();
+}
+template <int NC, bool INV> __device__ __forceinline__ void fft_row(double2 *row, const double2 *twl, int tr) {
+  if constexpr (NC == 8) { fft_pass<8, 8, 1, INV>(row, twl, tr); }
+  else if constexpr (NC == 16) { fft_pass<16, 4, 1, INV>(row, twl, tr); fft_pass<16, 4, 4, INV>(row, twl, tr); }
+  else if constexpr (NC == 32) { fft_pass<32, 8, 1, INV>(row, twl, tr); fft_pass<32, 4, 8, INV>(row, twl, tr); }
+  else if constexpr (NC == 64) { fft_pass<64, 8, 1, INV>(row, twl, tr); fft_pass<64, 8, 8, INV>(row, twl, tr); }
+  else if constexpr (NC == 128) { fft_pass<128, 8, 1, INV>(row, twl, tr); fft_pass<128, 4, 8, INV>(row, twl, tr); fft_pass<128, 4, 32, INV>(row, twl, tr); }
+  else { fft_pass<256, 8, 1, INV>(row, twl, tr); fft_pass<256, 8, 8, INV>(row, twl, tr); fft_pass<256, 4, 64, INV>(row, twl, tr); }
+}
+
+constexpr int FFT_R = 16;      // rows (level-fields) per block; 16 threads per row
+
+template <int NC>
 __global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  double *__restrict__ Fg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int Nc = g.I >> 1, rs = Nc + 1;
-  double2 *buf0 = (double2 *)smem, *buf1 = buf0 + R * rs;
-  constexpr int TPR = 256 / R;
-  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  constexpr int R = FFT_R, rs = NC + NC / 8 + 1;
+  double2 *buf = (double2 *)smem, *twl = buf + R * rs;
+  const int t = threadIdx.x, r = t >> 4, tr = t & 15;
   const int jl = blockIdx.y;
+  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
   {
     const int c = blockIdx.x * R + r;
     const double2 *src = nullptr;
@@ -49,85 +124,76 @@ __global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const dou
       src = (const double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
       if (fl.op[f] == OP_COSM) scale = cosm[jl];
     }
-    for (int n = tr; n < Nc; n += TPR) {
+#pragma unroll
+    for (int n = tr; n < NC; n += 16) {
       double2 z = make_double2(0., 0.);
       if (src) { z = src[n]; z.x *= scale; z.y *= scale; }
-      buf0[r * rs + n] = z;
+      buf[r * rs + fpad(n)] = z;
     }
   }
   __syncthreads();
-  double2 *x = buf0, *y = buf1;
-  for (int n = Nc, s = 1; n > 1; n >>= 1, s <<= 1) {
-    const int m = n >> 1;
-    for (int b = tr; b < (Nc >> 1); b += TPR) {
-      const int p = b / s, q = b - p * s;
-      const double2 a = x[r * rs + q + s * p], bb = x[r * rs + q + s * (p + m)];
-      const double2 w = tw[2 * p * s];
-      y[r * rs + q + s * (2 * p)] = cadd(a, bb);
-      y[r * rs + q + s * (2 * p + 1)] = cmul(csub(a, bb), w);
-    }
-    __syncthreads();
-    double2 *tmp = x; x = y; y = tmp;
-  }
+  fft_row<NC, false>(buf + r * rs, twl, tr);
   // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
-  const int rr = t % R, cc = blockIdx.x * R + rr;
+  const int rr = t & 15, cc = blockIdx.x * R + rr;
   const double inv_n = 1.0 / (double)g.I;
-  for (int m = t / R; m < g.M1; m += 256 / R) {
-    const double2 zk = x[rr * rs + m];
-    const double2 zc = cconj(x[rr * rs + ((Nc - m) & (Nc - 1))]);
+  for (int m = t >> 4; m < g.M1; m += 16) {
+    const double2 zk = buf[rr * rs + fpad(m)];
+    const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
     const double2 e = cscale(0.5, cadd(zk, zc));
     const double2 dd = csub(zk, zc);
     const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
-    double2 X = cadd(e, cmul(tw[m], o));
+    double2 X = cadd(e, cmul(twl[m], o));
     X.x *= inv_n; X.y *= inv_n;
     if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc) = X;
   }
 }
 
-template <int R>
+template <int NC>
 __global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  const double *__restrict__ Fg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int Nc = g.I >> 1, rs = Nc + 1;
-  double2 *buf0 = (double2 *)smem, *buf1 = buf0 + R * rs;
-  constexpr int TPR = 256 / R;
-  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  constexpr int R = FFT_R, rs = NC + NC / 8 + 1;
+  double2 *buf = (double2 *)smem, *twl = buf + R * rs;
+  const int t = threadIdx.x, r = t >> 4, tr = t & 15;
   const int jl = blockIdx.y;
+  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
   {  // load truncated coefficients m = 0..M (transforms.F90:424 zeroes everything above)
-    const int rr = t % R, cc = blockIdx.x * R + rr;
-    for (int m = t / R; m < Nc; m += 256 / R) {
+    const int rr = t & 15, cc = blockIdx.x * R + rr;
+#pragma unroll 4
+    for (int m = t >> 4; m < NC; m += 16) {
       double2 X = make_double2(0., 0.);
       if (m < g.M1 && cc < fl.ncol) {
         X = *(const double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc);
         if (m == 0) X.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
       }
-      buf0[rr * rs + m] = X;
+      buf[rr * rs + fpad(m)] = X;
     }
   }
   __syncthreads();
-  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0
-  for (int k = tr; k < Nc; k += TPR) {
-    const double2 xk = buf0[r * rs + k];
-    const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf0[r * rs + Nc - k]);
-    const double2 e = cadd(xk, xc);
-    const double2 o = cmul(cconj(tw[k]), csub(xk, xc));
-    buf1[r * rs + k] = make_double2(e.x - o.y, e.y + o.x);
-  }
-  __syncthreads();
-  double2 *x = buf1, *y = buf0;
-  for (int n = Nc, s = 1; n > 1; n >>= 1, s <<= 1) {
-    const int m = n >> 1;
-    for (int b = tr; b < (Nc >> 1); b += TPR) {
-      const int p = b / s, q = b - p * s;
-      const double2 a = x[r * rs + q + s * p], bb = x[r * rs + q + s * (p + m)];
-      const double2 w = cconj(tw[2 * p * s]);
-      y[r * rs + q + s * (2 * p)] = cadd(a, bb);
-      y[r * rs + q + s * (2 * p + 1)] = cmul(csub(a, bb), w);
+  {  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0 ; in place via registers
+    constexpr int PER = (NC + 15) / 16;
+    double2 zz[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int k = tr + 16 * i;
+      if (k < NC) {
+        const double2 xk = buf[r * rs + fpad(k)];
+        const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf[r * rs + fpad(NC - k)]);
+        const double2 e = cadd(xk, xc);
+        const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
+        zz[i] = make_double2(e.x - o.y, e.y + o.x);
+      }
     }
     __syncthreads();
-    double2 *tmp = x; x = y; y = tmp;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int k = tr + 16 * i;
+      if (k < NC) buf[r * rs + fpad(k)] = zz[i];
+    }
+    __syncthreads();
   }
+  fft_row<NC, true>(buf + r * rs, twl, tr);
   const int c = blockIdx.x * R + r;
   if (c < fl.ncol) {
     int f = 0;
@@ -136,8 +202,9 @@ __global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const dou
     double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
     const int op = fl.op[f];
     const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
-    for (int n = tr; n < Nc; n += TPR) {
-      double2 z = x[r * rs + n];
+#pragma unroll
+    for (int n = tr; n < NC; n += 16) {
+      double2 z = buf[r * rs + fpad(n)];
       if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
       else { z.x *= scale; z.y *= scale; }
       dst[n] = z;
@@ -145,23 +212,31 @@ __global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const dou
   }
 }
 
-static inline int fft_rows_per_block(int I) { return I >= 512 ? 8 : 16; }
+static size_t fft_lds_bytes(int NC) { return (size_t)(FFT_R * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
-  const int C = 2 * fl.ncol;
-  const int R = fft_rows_per_block(g.I);
-  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
-  const size_t lds = (size_t)2 * R * (g.I / 2 + 1) * sizeof(double2);
-  if (R == 16) hipLaunchKernelGGL(k_fft_fwd<16>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
-  else         hipLaunchKernelGGL(k_fft_fwd<8>,  grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+  const int C = 2 * fl.ncol, NC = g.I / 2;
+  dim3 grid((fl.ncol + FFT_R - 1) / FFT_R, g.Jl);
+  const size_t lds = fft_lds_bytes(NC);
+#define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+  switch (NC) {
+    case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
+    case 128: LF(128); break; case 256: LF(256); break;
+    default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
+  }
+#undef LF
 }
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
-  const int C = 2 * fl.ncol;
-  const int R = fft_rows_per_block(g.I);
-  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
-  const size_t lds = (size_t)2 * R * (g.I / 2 + 1) * sizeof(double2);
-  if (R == 16) hipLaunchKernelGGL(k_fft_inv<16>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
-  else         hipLaunchKernelGGL(k_fft_inv<8>,  grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C);
+  const int C = 2 * fl.ncol, NC = g.I / 2;
+  dim3 grid((fl.ncol + FFT_R - 1) / FFT_R, g.Jl);
+  const size_t lds = fft_lds_bytes(NC);
+#define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+  switch (NC) {
+    case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
+    case 128: LI(128); break; case 256: LI(256); break;
+    default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
+  }
+#undef LI
 }
 
 // =====================================================================================================

@@ -266,8 +266,8 @@ void Tables::build(const isca_dyn_config &c) {
   vkf = (c.kf < 0.) ? -1. / (86400 * c.kf) : c.kf;
   trsink_s = (c.trsink < 0.) ? -86400. * c.trsink : c.trsink;
   // --- FFT twiddles
-  tw_re.resize(I / 2); tw_im.resize(I / 2);
-  for (int k = 0; k < I / 2; ++k) {
+  tw_re.resize(I); tw_im.resize(I);
+  for (int k = 0; k < I; ++k) {
     const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)k / (long double)I;
     tw_re[k] = (double)cosl(a);
     tw_im[k] = (double)sinl(a);
