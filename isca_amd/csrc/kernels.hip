@@ -577,8 +577,9 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 struct SpecUpdateArgs {
   double2 *vors[2], *divs[2], *ts[2], *lnps[2];
   double2 *dtvor, *dtdiv, *dtT, *dtlp;
-  const double *coef, *impl_vec, *wave_t;
+  const double *coef, *impl_vec, *wave_t, *Sf;
   const int *m_local;
+  int C;
   double delta_t, xi, ref_p, ref_t, robert, eddy_sponge, zmu_sponge, zmv_sponge;
   int prev, cur, fut;
 };
@@ -597,6 +598,7 @@ __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, d
 }
 
 __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
+  __shared__ double2 xs[4][64];                      // per-wavefront vector for the wave-matrix product
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t mn = (size_t)blockIdx.x * 4 + wave;
   if (mn >= (size_t)g.Ml * g.N1) return;
@@ -616,8 +618,17 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   double2 tprev = act ? a.ts[prev][idx] : zero, tcur = act ? a.ts[cur][idx] : zero;
   double2 vprev = act ? a.vors[prev][idx] : zero, vcur = act ? a.vors[cur][idx] : zero;
   const double2 lprev = a.lnps[prev][mn], lcur = a.lnps[cur][mn];
-  double2 dt_div = act ? a.dtdiv[idx] : zero, dt_t = act ? a.dtT[idx] : zero, dt_vor = act ? a.dtvor[idx] : zero;
-  double2 dt_lp = a.dtlp[mn];
+  // --- spectral tendencies of the forward batch (spectral_dynamics.F90:874,891,900-904)
+  double2 dt_vor, dt_div, dt_t = zero;
+  alpha_pair(g, coef, a.Sf, a.C, mn, ml, n, kk, L + kk, dt_vor, dt_div);
+  if (act) {
+    const double2 E = *(const double2 *)(a.Sf + mn * a.C + 2 * (3 * L + kk));
+    dt_div = cadd(dt_div, cscale(eig, E));            // dt_divs - laplacian(Phi+KE), laplacian = -eigen
+    dt_t = *(const double2 *)(a.Sf + mn * a.C + 2 * (2 * L + kk));
+    a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t;      // kept for diagnostics/tests
+  } else { dt_vor = zero; dt_div = zero; }
+  double2 dt_lp = *(const double2 *)(a.Sf + mn * a.C + 2 * (4 * L));
+  if (lane == 0) a.dtlp[mn] = dt_lp;
   // --- adjust_dt_divs (:289-325)
   double2 dps, dts;
   lin_tp(csub(dprev, dcur), lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
@@ -636,17 +647,20 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     const double hp = hk * a.ref_p;
     dt_div = cadd(dt_div, cscale(eig, make_double2(geo.x + hp * ps_temp.x, geo.y + hp * ps_temp.y)));
   }
-  // dt_divs <- wave_matrix(L) . dt_divs   (:268-277);  wave_t[Lw][k'][k], lane-broadcast mat-vec
-  {
+  {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); wave_t[Lw][k'][k]; x broadcast from LDS
     const int Lw = a.m_local[ml] + n;
     const double *W = a.wave_t + (size_t)Lw * L * L;
+    xs[wave][lane] = act ? dt_div : zero;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double2 out = zero;
-    if (!act) dt_div = zero;
+#pragma unroll 8
     for (int k2 = 0; k2 < L; ++k2) {
-      const double xr = __shfl(dt_div.x, k2, 64), xi_ = __shfl(dt_div.y, k2, 64);
+      const double2 x = xs[wave][k2];
       const double w = W[(size_t)k2 * L + kk];
-      out.x += w * xr;
-      out.y += w * xi_;
+      out.x += w * x.x;
+      out.y += w * x.y;
     }
     dt_div = act ? out : zero;
   }
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     dt_vor = cscale(cf, csub(dt_vor, cscale(dmp, vprev)));
     dt_div = cscale(cf, csub(dt_div, cscale(dmp, dprev)));
     dt_t = cscale(cf, csub(dt_t, cscale(dmp, tprev)));
-    if (lane == 0) {   // sponge on the top level (:236-245, :281-290)
+    if (lane == 0 && (a.eddy_sponge != 0.0 || a.zmu_sponge != 0.0 || a.zmv_sponge != 0.0)) {   // sponge on the top level (:236-245, :281-290)
       const int mglob = a.m_local[ml];
       const double sv = (mglob != 0) ? a.eddy_sponge * eig : a.zmu_sponge * eig;
       const double sd = (mglob != 0) ? a.eddy_sponge * eig : a.zmv_sponge * eig;
@@ -699,6 +713,7 @@ void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   }
   a.dtvor = (double2 *)h.d.s_dtvor; a.dtdiv = (double2 *)h.d.s_dtdiv; a.dtT = (double2 *)h.d.s_dtT; a.dtlp = (double2 *)h.d.s_dtlp;
   a.coef = h.d.coef; a.impl_vec = h.d.impl_vec; a.wave_t = h.d.wave_mat_t; a.m_local = h.d.m_local;
+  a.Sf = h.d.Sf; a.C = h.Cf;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
   a.prev = sc.prev; a.cur = sc.cur; a.fut = sc.fut;
@@ -1098,47 +1113,58 @@ void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStre
 //   red[2..4]  local sums of the new state:     w*ps(fut), w*sum_k e_k dpk_k, w*sum_k e_k dbk_k ps(fut)
 //   red[8]     mass_correction_factor, red[9] temperature_correction
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
-                                                   const double *__restrict__ t, const double *__restrict__ psg,
-                                                   const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                                   const double *__restrict__ wts, double *__restrict__ partials) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
+// block = 64 columns x NW wavefronts (level chunks), like the column kernel
+__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ t, const double *__restrict__ psg,
+                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH) {
+  __shared__ double red[2][8];
+  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int col = blockIdx.x * 64 + tid;
   const int jl = col / g.I;
   const size_t c2 = col, lev = (size_t)g.Jl * g.I;
-  const double ps = psg[c2];
   double sa = 0.0, sb = 0.0;
-  for (int k = 0; k < g.L; ++k) {
+  const int k0 = w * CH, k1 = min(g.L, k0 + CH);
+  for (int k = k0; k < k1; ++k) {
     const size_t q = c2 + k * lev;
     const double uk = u[q], vk = v[q];
     const double e = 0.5 * (uk * uk + vk * vk) + CP_AIR * t[q];
     sa += e * dpk[k];
     sb += e * dbk[k];
   }
-  const double w = wts[jl];
-  double s0 = w * ps, s1 = w * sa, s2 = w * sb * ps;
+  const double wgt = wts[jl], ps = psg[c2];
+  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     s0 += __shfl_down(s0, off, 64);
     s1 += __shfl_down(s1, off, 64);
     s2 += __shfl_down(s2, off, 64);
   }
-  if (threadIdx.x == 0) { partials[3 * blockIdx.x] = s0; partials[3 * blockIdx.x + 1] = s1; partials[3 * blockIdx.x + 2] = s2; }
+  if (tid == 0) { red[0][w] = s1; red[1][w] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int ww = 0; ww < NW; ++ww) { a1 += red[0][ww]; a2 += red[1][ww]; }
+    partials[3 * blockIdx.x] = s0; partials[3 * blockIdx.x + 1] = a1; partials[3 * blockIdx.x + 2] = a2;
+  }
 }
-// sum `n` groups of `stride` partials in a fixed order -> out[0..stride)
-__global__ void k_sum_partials(const double *__restrict__ partials, int n, int stride, double *__restrict__ out) {
-  __shared__ double sh[256];
-  for (int c = 0; c < stride; ++c) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[(size_t)i * stride + c];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] = sh[0];
+// red[0..1] <- sums of the column kernel's partials (2 per block), red[2..4] <- sums of k_fixer_sums' (3 per block)
+__global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                      double *__restrict__ red) {
+  __shared__ double sh[5][256];
+  double acc[5] = {0., 0., 0., 0., 0.};
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    acc[0] += pprev[2 * i]; acc[1] += pprev[2 * i + 1];
+    acc[2] += pfut[3 * i]; acc[3] += pfut[3 * i + 1]; acc[4] += pfut[3 * i + 2];
+  }
+  for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] = acc[c];
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off)
+      for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
     __syncthreads();
   }
+  if (threadIdx.x < 5) red[threadIdx.x] = sh[threadIdx.x][0];
 }
 struct FixerArgs {
   double *red;
@@ -1177,22 +1203,21 @@ __global__ void k_fixer_finalize(Geom g, FixerArgs a) {
   }
 }
 __global__ void k_fixer_apply(Geom g, const double *__restrict__ red, double *psg, double *tg) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;     // two doubles per thread
   const size_t lev = (size_t)g.Jl * g.I;
   const double factor = red[8], tcorr = red[9];
-  if (i < lev) psg[i] = factor * psg[i];
-  if (i < lev * g.L) tg[i] = tg[i] + tcorr;
+  if (i < lev) { double2 p = *(double2 *)(psg + i); p.x *= factor; p.y *= factor; *(double2 *)(psg + i) = p; }
+  if (i < lev * g.L) { double2 t = *(double2 *)(tg + i); t.x += tcorr; t.y += tcorr; *(double2 *)(tg + i) = t; }
 }
 
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
   const int nb = (int)column_partials_count(h);
-  // previous-level sums left by the column kernel -> red[0..1]
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, d.partials, nb, 2, d.red);
   double *p2 = d.partials + 2 * (size_t)nb;
-  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2);
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, s, p2, nb, 3, d.red + 2);
+  const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
+  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH);
+  hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
 void launch_fixer_finalize(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   FixerArgs a;
@@ -1209,7 +1234,7 @@ void launch_fixer_finalize(const isca_dyn &h, const StepScalars &sc, hipStream_t
 }
 void launch_fixer_apply(const isca_dyn &h, int fut, hipStream_t s) {
   const Geom &g = h.g;
-  hipLaunchKernelGGL(k_fixer_apply, grid1d((size_t)g.Jl * g.I * g.L), dim3(256), 0, s, g, h.d.red, h.d.psg[fut], h.d.tg[fut]);
+  hipLaunchKernelGGL(k_fixer_apply, grid1d((size_t)g.Jl * g.I * g.L / 2), dim3(256), 0, s, g, h.d.red, h.d.psg[fut], h.d.tg[fut]);
 }
 
 }  // namespace isca
