@@ -251,15 +251,26 @@ __device__ __forceinline__ size_t frow(const Geom &g, int j, int ml, int C) {   
   return ((size_t)(p * g.Ml + ml) * g.Jl + jl) * C;
 }
 
+// cooperative copy of a contiguous table slab into LDS, 16 bytes per lane per step (256 threads)
+__device__ __forceinline__ void lds_fill(double *dst, const double *__restrict__ src, int ndoubles) {
+  const double2 *s2 = (const double2 *)src;
+  double2 *d2 = (double2 *)dst;
+  for (int i = threadIdx.x; i < (ndoubles >> 1); i += 256) d2[i] = s2[i];
+}
+
+// Analysis (Fourier -> spectral).  Block = 4 wavefronts = 4 column tiles of one wavenumber m; the A operand
+// (P*w of this m, both parities, only the rows the triangle needs) is staged once per block in LDS, the folded
+// B operand lives in registers, so the MFMA loop touches no global memory.
 template <int JH4>
 __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pw, const double *__restrict__ Fs,
                                                       double *__restrict__ S, int C, int full) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *As = (double *)smem;                      // [Jh][NHP], one parity at a time
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ml = blockIdx.y, m = m_local[ml];
   if (m < 0) return;
   const int c0 = (blockIdx.x * 4 + wave) * 16;
-  if (c0 >= C) return;
   const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
   const bool cok = c < C;
   double be[JH4], bo[JH4];
@@ -277,14 +288,17 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
   const int nlim = full ? g.N1 : g.N1 - m;
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
+    if (par) __syncthreads();                       // everyone done with the even-parity table
+    lds_fill(As, pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP, g.Jh * g.NHP);
+    __syncthreads();
     const int cnt = (nlim - par + 1) >> 1;
-    const int ntile = (cnt + 15) >> 4;
-    const double *A = pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP;
+    const int ntile = (c0 < C) ? (cnt + 15) >> 4 : 0;
+    const double *A = As;
     for (int tile = 0; tile < ntile; ++tile) {
       double4_t acc = {0., 0., 0., 0.};
 #pragma unroll
       for (int ks = 0; ks < JH4; ++ks) {
-        const double a = A[(size_t)(ks * 4 + kq) * g.NHP + tile * 16 + cl];
+        const double a = A[(ks * 4 + kq) * g.NHP + tile * 16 + cl];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, par ? bo[ks] : be[ks], acc, 0, 0, 0);
       }
 #pragma unroll
@@ -296,40 +310,58 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
   }
 }
 
-template <int JT>
-__device__ __forceinline__ void leg_inv_parity(const Geom &g, const double *__restrict__ A, const double *__restrict__ S,
-                                               int ml, int par, int nlim, int C, int c, bool cok, int cl, int kq,
-                                               double4_t (&acc)[JT]) {
-  const int cnt = (nlim - par + 1) >> 1;
-  const int nks = (cnt + 3) >> 2;
-  for (int ks = 0; ks < nks; ++ks) {
-    const int nh = ks * 4 + kq, n = 2 * nh + par;
-    const double b = (n < nlim && cok) ? S[((size_t)ml * g.N1 + n) * C + c] : 0.0;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-      const double a = A[(size_t)nh * g.Jh + jt * 16 + cl];
-      acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
-    }
-  }
-}
-
-template <int JT>
+// Synthesis (spectral -> Fourier).  Same blocking; A = P of this m from LDS, B rows preloaded in registers.
+template <int JT, int NKS>
 __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pinv, const double *__restrict__ S,
                                                       double *__restrict__ Fs, int C, int full) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *As = (double *)smem;                      // [NHP][Jh], one parity at a time
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ml = blockIdx.y, m = m_local[ml];
   if (m < 0) return;
   const int c0 = (blockIdx.x * 4 + wave) * 16;
-  if (c0 >= C) return;
   const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
   const bool cok = c < C;
   const int nlim = full ? g.N1 : g.N1 - m;
+  const int cnt0 = (nlim + 1) >> 1, cnt1 = nlim >> 1;
+  const int nks0 = (cnt0 + 3) >> 2, nks1 = (cnt1 + 3) >> 2;
+  double b0[NKS], b1[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int nh = ks * 4 + kq;
+    const int n0 = 2 * nh, n1 = 2 * nh + 1;
+    b0[ks] = (ks < nks0 && n0 < nlim && cok) ? S[((size_t)ml * g.N1 + n0) * C + c] : 0.0;
+    b1[ks] = (ks < nks1 && n1 < nlim && cok) ? S[((size_t)ml * g.N1 + n1) * C + c] : 0.0;
+  }
   double4_t accE[JT], accO[JT];
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) { accE[jt] = (double4_t){0., 0., 0., 0.}; accO[jt] = (double4_t){0., 0., 0., 0.}; }
-  leg_inv_parity<JT>(g, pinv + ((size_t)(ml * 2 + 0) * g.NHP) * g.Jh, S, ml, 0, nlim, C, c, cok, cl, kq, accE);
-  leg_inv_parity<JT>(g, pinv + ((size_t)(ml * 2 + 1) * g.NHP) * g.Jh, S, ml, 1, nlim, C, c, cok, cl, kq, accO);
+  const bool wave_on = c0 < C;
+  // even parity: only the rows nh < 4*nks are needed
+  lds_fill(As, pinv + ((size_t)(ml * 2 + 0) * g.NHP) * g.Jh, 4 * nks0 * g.Jh);
+  __syncthreads();
+  if (wave_on) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      if (ks < nks0) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+          accE[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(ks * 4 + kq) * g.Jh + jt * 16 + cl], b0[ks], accE[jt], 0, 0, 0);
+      }
+  }
+  __syncthreads();
+  lds_fill(As, pinv + ((size_t)(ml * 2 + 1) * g.NHP) * g.Jh, 4 * nks1 * g.Jh);
+  __syncthreads();
+  if (wave_on) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      if (ks < nks1) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(ks * 4 + kq) * g.Jh + jt * 16 + cl], b1[ks], accO[jt], 0, 0, 0);
+      }
+  }
   if (!cok) return;
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt)
@@ -376,15 +408,18 @@ __global__ void k_leg_inv_simple(Geom g, const int *__restrict__ m_local, const 
   Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;
 }
 
-static bool mfma_ok(const Geom &g, int impl) { return impl == 0 && (g.J % 32 == 0) && g.Jh / 4 <= 64; }
+static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42/T85/T170 (J = 32/64/128/256)
+  return impl == 0 && ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
+}
 
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (mfma_ok(g, impl)) {
     dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
-#define LF(N) hipLaunchKernelGGL(k_leg_fwd_mfma<N>, grid, dim3(256), 0, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
+    const size_t lds = (size_t)g.Jh * g.NHP * sizeof(double);
+#define LF(N) hipLaunchKernelGGL(k_leg_fwd_mfma<N>, grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
     switch (g.Jh / 4) {
       case 4: LF(4); break;   case 8: LF(8); break;   case 16: LF(16); break;
-      case 32: LF(32); break; case 64: LF(64); break;
+      case 32: LF(32); break;
       default: throw std::runtime_error("legendre_forward: unsupported lat_max for the MFMA kernel");
     }
 #undef LF
@@ -394,13 +429,16 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
   }
 }
 void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s) {
-  if (mfma_ok(g, impl) && g.Jh / 16 <= 8) {
+  if (mfma_ok(g, impl)) {
     dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
-#define LI(N) hipLaunchKernelGGL(k_leg_inv_mfma<N>, grid, dim3(256), 0, s, g, d.m_local, d.p_inv, S, Fs, C, full)
-    switch (g.Jh / 16) {
-      case 1: LI(1); break; case 2: LI(2); break; case 4: LI(4); break; case 8: LI(8); break;
-      default: throw std::runtime_error("legendre_inverse: unsupported lat_max for the MFMA kernel");
-    }
+    const size_t lds = (size_t)g.NHP * g.Jh * sizeof(double);
+    // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
+#define LI(JT, NKS) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full)
+    if (g.Jh == 16 && g.NHP == 16) LI(1, 4);
+    else if (g.Jh == 32 && g.NHP == 32) LI(2, 8);
+    else if (g.Jh == 64 && g.NHP == 48) LI(4, 12);
+    else if (g.Jh == 128 && g.NHP == 96) LI(8, 24);
+    else throw std::runtime_error("legendre_inverse: unsupported resolution for the MFMA kernel");
 #undef LI
   } else {
     dim3 grid((C + 63) / 64, g.Jh, g.Ml);
