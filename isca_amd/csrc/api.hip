@@ -203,6 +203,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     g.Ml = (g.M1 + g.P - 1) / g.P;
     g.NHP = (((g.N1 + 1) / 2) + 15) / 16 * 16;
     g.log2I = 0; while ((1 << g.log2I) < g.I) ++g.log2I;
+    g.log2Jl = -1;
+    if ((g.Jl & (g.Jl - 1)) == 0) { g.log2Jl = 0; while ((1 << g.log2Jl) < g.Jl) ++g.log2Jl; }
     if (g.M1 > g.I / 2) fail("num_fourier too large for lon_max");
     // ---- wavenumber dealing: boustrophedon over ranks for triangular load balance
     { int Ml; deal_wavenumbers(g.M1, g.P, h->h_m_of_slot, Ml); }
@@ -253,6 +255,16 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         }
       d.coef = dupload(h, cf);
     }
+    {
+      std::vector<int> act;
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_local[ml];
+        if (m < 0) continue;
+        for (int n = 0; n < g.N1; ++n) if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) act.push_back(ml * g.N1 + n);
+      }
+      h->n_active = (int)act.size();
+      d.mn_active = dupload(h, act);
+    }
     d.pk = dupload(h, T.pk); d.bk = dupload(h, T.bk); d.dpk = dupload(h, T.dpk); d.dbk = dupload(h, T.dbk);
     {
       std::vector<double> iv(5 * 64, 0.0);
@@ -298,7 +310,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
-    h->kernels_per_step = 11;
+    h->kernels_per_step = 9;
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -576,8 +588,7 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
   { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
-  { Timed t(h, "fixer_finalize"); launch_fixer_finalize(*h, sc, h->stream); }
-  { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc.fut, h->stream); }
+  { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
   h->previous = sc.cur;
   h->current = sc.fut;
   h->step_count += 1;

@@ -38,6 +38,7 @@ struct Geom {
   int Jh;                   // J/2
   int NHP;                  // padded count of n per parity (multiple of 16)
   int log2I;
+  int log2Jl;               // log2(Jl) when Jl is a power of two, else -1
 };
 
 struct Dev {
@@ -54,6 +55,7 @@ struct Dev {
   double *pk, *bk, *dpk, *dbk;
   double *wave_mat_t;        // [num_spherical][L(k')][L(k)]  transposed wave matrices
   double *tau_t, *gamma_t;   // unused by the scan formulation; kept for checks
+  int *mn_active;            // [n_active] indices ml*N1+n of the retained (m,n) of my wavenumbers
   double *impl_vec;          // [6][L+1]: ref_ln_p_half, ref_ln_p_full, h, dp_ref, ...
   double *tw;                // [I/2][2] twiddles exp(-2 pi i k/I)
   // ---- prognostic state
@@ -101,5 +103,6 @@ struct isca_dyn {
   double wave_dt = -1.0;
   int ml_of_m0 = -1;
   std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
+  int n_active = 0;
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
 };

@@ -257,10 +257,15 @@ __device__ __forceinline__ void lds_fill(double *dst, const double *__restrict__
   double2 *d2 = (double2 *)dst;
   for (int i = threadIdx.x; i < (ndoubles >> 1); i += 256) d2[i] = s2[i];
 }
+// spectral-side row offset (in doubles, fits 31 bits) of latitude j for local wavenumber slot ml; Jl = 2^lg
+__device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
+  return ((((j >> lg) * Ml + ml) << lg) | (j & ((1 << lg) - 1))) * C;
+}
 
 // Analysis (Fourier -> spectral).  Block = 4 wavefronts = 4 column tiles of one wavenumber m; the A operand
-// (P*w of this m, both parities, only the rows the triangle needs) is staged once per block in LDS, the folded
-// B operand lives in registers, so the MFMA loop touches no global memory.
+// (P*w of this m, one parity at a time, only the rows the triangle needs) is staged in LDS, the folded
+// B operand lives in registers, so the MFMA loop touches no global memory.  32-bit index arithmetic throughout:
+// these kernels have ~50 MFMAs per wavefront, so address VALU work must stay well below that.
 template <int JH4>
 __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pw, const double *__restrict__ Fs,
@@ -273,39 +278,38 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
   const int c0 = (blockIdx.x * 4 + wave) * 16;
   const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
   const bool cok = c < C;
+  const int lg = g.log2Jl, NHP = g.NHP;
   double be[JH4], bo[JH4];
 #pragma unroll
   for (int ks = 0; ks < JH4; ++ks) {
     const int jp = ks * 4 + kq;
     double xs = 0., xn = 0.;
     if (cok) {
-      xs = Fs[frow(g, jp, ml, C) + c];
-      xn = Fs[frow(g, g.J - 1 - jp, ml, C) + c];
+      xs = Fs[frow32(jp, ml, C, lg, g.Ml) + c];
+      xn = Fs[frow32(g.J - 1 - jp, ml, C, lg, g.Ml) + c];
     }
     be[ks] = xn + xs;      // x_even = F(north) + F(south)   (:311)
     bo[ks] = xn - xs;      // x_odd  = F(north) - F(south)   (:312)
   }
   const int nlim = full ? g.N1 : g.N1 - m;
+  const int srow = ml * g.N1 * C + c;               // S offset of (ml, n=0, c)
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
     if (par) __syncthreads();                       // everyone done with the even-parity table
-    lds_fill(As, pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP, g.Jh * g.NHP);
+    lds_fill(As, pw + (size_t)(ml * 2 + par) * g.Jh * NHP, g.Jh * NHP);
     __syncthreads();
     const int cnt = (nlim - par + 1) >> 1;
     const int ntile = (c0 < C) ? (cnt + 15) >> 4 : 0;
-    const double *A = As;
+    const double *A = As + kq * NHP + cl;
     for (int tile = 0; tile < ntile; ++tile) {
       double4_t acc = {0., 0., 0., 0.};
 #pragma unroll
-      for (int ks = 0; ks < JH4; ++ks) {
-        const double a = A[(ks * 4 + kq) * g.NHP + tile * 16 + cl];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, par ? bo[ks] : be[ks], acc, 0, 0, 0);
-      }
+      for (int ks = 0; ks < JH4; ++ks)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * NHP + tile * 16], par ? bo[ks] : be[ks], acc, 0, 0, 0);
+      const int n0 = 2 * (tile * 16 + kq) + par;    // rows n0 + 8 r
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = 2 * (tile * 16 + kq + 4 * r) + par;
-        if (n < g.N1 && cok) S[((size_t)ml * g.N1 + n) * C + c] = acc[r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (n0 + 8 * r < g.N1 && cok) S[srow + (n0 + 8 * r) * C] = acc[r];
     }
   }
 }
@@ -326,20 +330,24 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
   const int nlim = full ? g.N1 : g.N1 - m;
   const int cnt0 = (nlim + 1) >> 1, cnt1 = nlim >> 1;
   const int nks0 = (cnt0 + 3) >> 2, nks1 = (cnt1 + 3) >> 2;
+  const int Jh = g.Jh;
   double b0[NKS], b1[NKS];
+  {
+    const int sbase = (ml * g.N1 + 2 * kq) * C + c;    // row n = 2*(ks*4+kq) (+1)
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int nh = ks * 4 + kq;
-    const int n0 = 2 * nh, n1 = 2 * nh + 1;
-    b0[ks] = (ks < nks0 && n0 < nlim && cok) ? S[((size_t)ml * g.N1 + n0) * C + c] : 0.0;
-    b1[ks] = (ks < nks1 && n1 < nlim && cok) ? S[((size_t)ml * g.N1 + n1) * C + c] : 0.0;
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int n0 = 8 * ks + 2 * kq;
+      b0[ks] = (ks < nks0 && n0 < nlim && cok) ? S[sbase + 8 * ks * C] : 0.0;
+      b1[ks] = (ks < nks1 && n0 + 1 < nlim && cok) ? S[sbase + (8 * ks + 1) * C] : 0.0;
+    }
   }
   double4_t accE[JT], accO[JT];
 #pragma unroll
   for (int jt = 0; jt < JT; ++jt) { accE[jt] = (double4_t){0., 0., 0., 0.}; accO[jt] = (double4_t){0., 0., 0., 0.}; }
   const bool wave_on = c0 < C;
+  const double *A = As + kq * Jh + cl;
   // even parity: only the rows nh < 4*nks are needed
-  lds_fill(As, pinv + ((size_t)(ml * 2 + 0) * g.NHP) * g.Jh, 4 * nks0 * g.Jh);
+  lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * Jh, 4 * nks0 * Jh);
   __syncthreads();
   if (wave_on) {
 #pragma unroll
@@ -347,11 +355,11 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
       if (ks < nks0) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt)
-          accE[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(ks * 4 + kq) * g.Jh + jt * 16 + cl], b0[ks], accE[jt], 0, 0, 0);
+          accE[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * Jh + jt * 16], b0[ks], accE[jt], 0, 0, 0);
       }
   }
   __syncthreads();
-  lds_fill(As, pinv + ((size_t)(ml * 2 + 1) * g.NHP) * g.Jh, 4 * nks1 * g.Jh);
+  lds_fill(As, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
   __syncthreads();
   if (wave_on) {
 #pragma unroll
@@ -359,19 +367,22 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
       if (ks < nks1) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt)
-          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(ks * 4 + kq) * g.Jh + jt * 16 + cl], b1[ks], accO[jt], 0, 0, 0);
+          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * Jh + jt * 16], b1[ks], accO[jt], 0, 0, 0);
       }
   }
   if (!cok) return;
+  // rows jp = jt*16 + kq + 4r and their mirrors J-1-jp stay inside one 16-aligned latitude group (Jl % 16 == 0)
 #pragma unroll
-  for (int jt = 0; jt < JT; ++jt)
+  for (int jt = 0; jt < JT; ++jt) {
+    const int south = frow32(jt * 16 + kq, ml, C, g.log2Jl, g.Ml) + c;
+    const int north = frow32(g.J - 1 - jt * 16 - kq, ml, C, g.log2Jl, g.Ml) + c;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int jp = jt * 16 + kq + 4 * r;
       const double e = accE[jt][r], o = accO[jt][r];
-      Fs[frow(g, jp, ml, C) + c] = e - o;                 // southern row  (:235)
-      Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;       // northern mirror (:236)
+      Fs[south + 4 * r * C] = e - o;                 // southern row  (:235)
+      Fs[north - 4 * r * C] = e + o;                 // northern mirror (:236)
     }
+  }
 }
 
 // plain-FMA check kernels (legendre_impl = 1, and lat_max not a multiple of 32)
@@ -409,6 +420,7 @@ __global__ void k_leg_inv_simple(Geom g, const int *__restrict__ m_local, const 
 }
 
 static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42/T85/T170 (J = 32/64/128/256)
+  if (g.Jl % 16 || (g.Jl & (g.Jl - 1))) return false;   // 32-bit shift/mask row addressing
   return impl == 0 && ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
 }
 
@@ -596,14 +608,25 @@ __global__ void k_spec_tendencies(Geom g, const double *__restrict__ coef, const
   if (k == 0) dtlp[mn] = *(const double2 *)(Sf + mn * C + 2 * (4 * L));
 }
 
-// wave-wide exclusive prefix sum over lanes 0..63
+// wave-wide inclusive prefix sum over lanes 0..63 with DPP row shifts / row broadcasts (no LDS crossbar traffic)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const double t = __shfl_up(v, off, 64);
-    if (lane >= off) v += t;
-  }
+  (void)lane;
+  v = dpp_add<0x111, 0xf>(v);     // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);     // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);     // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);     // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 -> rows 2,3
   return v;
+}
+__device__ __forceinline__ double wave_last(double v) {   // value held by lane 63
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -613,13 +636,13 @@ __device__ __forceinline__ double wave_incl_scan(double v, int lane) {
 // raw_filter_coeff = 1.  impl_vec rows: 0 dlog_1, 1 dlog_3, 2 dp_ref, 3 h, 4 dlogf = lph(k+1)-lpf(k)
 // -----------------------------------------------------------------------------------------------------
 struct SpecUpdateArgs {
-  double2 *vors[2], *divs[2], *ts[2], *lnps[2];
+  double2 *vors_p, *vors_c, *vors_f, *divs_p, *divs_c, *divs_f, *ts_p, *ts_c, *ts_f, *lnps_p, *lnps_c, *lnps_f;
+  const int *active; int nactive;
   double2 *dtvor, *dtdiv, *dtT, *dtlp;
   const double *coef, *impl_vec, *wave_t, *Sf;
   const int *m_local;
   int C;
   double delta_t, xi, ref_p, ref_t, robert, eddy_sponge, zmu_sponge, zmv_sponge;
-  int prev, cur, fut;
 };
 
 __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, double dlog1, double dlog3, double ref_t,
@@ -632,17 +655,17 @@ __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, d
   const double2 before = csub(inc, dmean);
   const double f = -KAPPA * ref_t / dp;
   dt_t = make_double2(f * (before.x * dlog3 + dmean.x * dlog1), f * (before.y * dlog3 + dmean.y * dlog1));
-  dt_p = make_double2(-__shfl(inc.x, 63, 64), -__shfl(inc.y, 63, 64));
+  dt_p = make_double2(-wave_last(inc.x), -wave_last(inc.y));
 }
 
 __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   __shared__ double2 xs[4][64];                      // per-wavefront vector for the wave-matrix product
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const size_t mn = (size_t)blockIdx.x * 4 + wave;
-  if (mn >= (size_t)g.Ml * g.N1) return;
+  const int ia = blockIdx.x * 4 + wave;
+  if (ia >= a.nactive) return;
+  const int mn = a.active[ia];                       // retained (m,n) only: outside the triangle the state stays zero
   const int n = mn % g.N1, ml = mn / g.N1;
   const double *coef = a.coef;
-  if (COEF(C_MASK, ml, n) == 0.0) return;           // outside the triangle: state stays zero
   const int L = g.L;
   const bool act = lane < L;
   const int kk = act ? lane : 0;
@@ -650,12 +673,11 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
   const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
   const double eig = COEF(C_EIG, ml, n);
-  const int prev = a.prev, cur = a.cur, fut = a.fut;
   const double2 zero = make_double2(0., 0.);
-  double2 dprev = act ? a.divs[prev][idx] : zero, dcur = act ? a.divs[cur][idx] : zero;
-  double2 tprev = act ? a.ts[prev][idx] : zero, tcur = act ? a.ts[cur][idx] : zero;
-  double2 vprev = act ? a.vors[prev][idx] : zero, vcur = act ? a.vors[cur][idx] : zero;
-  const double2 lprev = a.lnps[prev][mn], lcur = a.lnps[cur][mn];
+  double2 dprev = act ? a.divs_p[idx] : zero, dcur = act ? a.divs_c[idx] : zero;
+  double2 tprev = act ? a.ts_p[idx] : zero, tcur = act ? a.ts_c[idx] : zero;
+  double2 vprev = act ? a.vors_p[idx] : zero, vcur = act ? a.vors_c[idx] : zero;
+  const double2 lprev = a.lnps_p[mn], lcur = a.lnps_c[mn];
   // --- spectral tendencies of the forward batch (spectral_dynamics.F90:874,891,900-904)
   double2 dt_vor, dt_div, dt_t = zero;
   alpha_pair(g, coef, a.Sf, a.C, mn, ml, n, kk, L + kk, dt_vor, dt_div);
@@ -679,7 +701,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     double2 inc;
     inc.x = wave_incl_scan(av.x, lane);
     inc.y = wave_incl_scan(av.y, lane);
-    const double2 tot = make_double2(__shfl(inc.x, 63, 64), __shfl(inc.y, 63, 64));
+    const double2 tot = make_double2(wave_last(inc.x), wave_last(inc.y));
     const double2 below = csub(tot, inc);                                  // sum over k' > k
     const double2 geo = cadd(below, cscale(RDGAS * dlogf, ts_temp));
     const double hp = hk * a.ref_p;
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     const double2 nf = make_double2(PREV.x + dtt * DT.x, PREV.y + dtt * DT.y);      \
     double2 nc = make_double2(CUR.x + rc * part.x, CUR.y + rc * part.y);            \
     nc = make_double2(nc.x + rc * nf.x, nc.y + rc * nf.y);                          \
-    if (GUARD) { ARR[cur][IDX] = nc; ARR[fut][IDX] = nf; }                          \
+    if (GUARD) { ARR##_c[IDX] = nc; ARR##_f[IDX] = nf; }                            \
   }
   LEAP(vprev, vcur, dt_vor, a.vors, idx, act)
   LEAP(dprev, dcur, dt_div, a.divs, idx, act)
@@ -745,18 +767,17 @@ void launch_spec_tendencies(const isca_dyn &h, hipStream_t s) {
 void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   SpecUpdateArgs a;
-  for (int t = 0; t < 2; ++t) {
-    a.vors[t] = (double2 *)h.d.vors[t]; a.divs[t] = (double2 *)h.d.divs[t];
-    a.ts[t] = (double2 *)h.d.ts[t]; a.lnps[t] = (double2 *)h.d.lnps[t];
-  }
+  a.vors_p = (double2 *)h.d.vors[sc.prev]; a.vors_c = (double2 *)h.d.vors[sc.cur]; a.vors_f = (double2 *)h.d.vors[sc.fut];
+  a.divs_p = (double2 *)h.d.divs[sc.prev]; a.divs_c = (double2 *)h.d.divs[sc.cur]; a.divs_f = (double2 *)h.d.divs[sc.fut];
+  a.ts_p = (double2 *)h.d.ts[sc.prev]; a.ts_c = (double2 *)h.d.ts[sc.cur]; a.ts_f = (double2 *)h.d.ts[sc.fut];
+  a.lnps_p = (double2 *)h.d.lnps[sc.prev]; a.lnps_c = (double2 *)h.d.lnps[sc.cur]; a.lnps_f = (double2 *)h.d.lnps[sc.fut];
+  a.active = h.d.mn_active; a.nactive = h.n_active;
   a.dtvor = (double2 *)h.d.s_dtvor; a.dtdiv = (double2 *)h.d.s_dtdiv; a.dtT = (double2 *)h.d.s_dtT; a.dtlp = (double2 *)h.d.s_dtlp;
   a.coef = h.d.coef; a.impl_vec = h.d.impl_vec; a.wave_t = h.d.wave_mat_t; a.m_local = h.d.m_local;
   a.Sf = h.d.Sf; a.C = h.Cf;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
-  a.prev = sc.prev; a.cur = sc.cur; a.fut = sc.fut;
-  const size_t nmn = (size_t)g.Ml * g.N1;
-  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)((nmn + 3) / 4)), dim3(256), 0, s, g, a);
+  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)((h.n_active + 3) / 4)), dim3(256), 0, s, g, a);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1206,32 +1227,66 @@ __global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__
 }
 struct FixerArgs {
   double *red;
+  const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 3 per block (k_fixer_sums)
+  int nb;
   double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
+  double *psg, *tg;
   int ml0;                 // local slot of m = 0, or -1
   double sumw_nlon;        // global_sum_of_wts * num_lon
   double robert;
-  int do_mass, do_energy;
+  int do_mass, do_energy, reduce_here;
 };
-__global__ void k_fixer_finalize(Geom g, FixerArgs a) {
-  // every thread recomputes the two scalars from the (already globally summed) red[0..4]
-  double *red = a.red;
-  const double mean_ps_prev = red[0] / a.sumw_nlon;
-  const double mean_en_prev = red[1] / a.sumw_nlon / GRAV;
-  double factor = 1.0, tcorr = 0.0;
-  if (a.do_mass) factor = mean_ps_prev / (red[2] / a.sumw_nlon);
-  if (a.do_energy) {
-    const double mean_en_tmp = (red[3] + factor * red[4]) / a.sumw_nlon / GRAV;
-    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+// Every block reduces the block partials itself in the same fixed order (deterministic, identical in all blocks),
+// derives the two fixer scalars and applies them to its slice of psg / tg; block 0 also patches the (0,0)
+// spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
+// With several ranks the host all-reduces red[0..4] first (reduce_here = 0).
+__global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
+  __shared__ double sh[5][256];
+  __shared__ double sc[2];
+  if (a.reduce_here) {
+    double acc[5] = {0., 0., 0., 0., 0.};
+    for (int i = threadIdx.x; i < a.nb; i += 256) {
+      acc[0] += a.pprev[2 * i]; acc[1] += a.pprev[2 * i + 1];
+      acc[2] += a.pfut[3 * i]; acc[3] += a.pfut[3 * i + 1]; acc[4] += a.pfut[3 * i + 2];
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off)
+#pragma unroll
+        for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
+      __syncthreads();
+    }
+  } else {
+    if (threadIdx.x < 5) sh[threadIdx.x][0] = a.red[threadIdx.x];
+    __syncthreads();
   }
-  const int k = threadIdx.x;
-  if (k == 0) { red[8] = factor; red[9] = tcorr; }
-  if (a.ml0 >= 0) {
+  if (threadIdx.x == 0) {
+    const double mean_ps_prev = sh[0][0] / a.sumw_nlon;
+    const double mean_en_prev = sh[1][0] / a.sumw_nlon / GRAV;
+    double factor = 1.0, tcorr = 0.0;
+    if (a.do_mass) factor = mean_ps_prev / (sh[2][0] / a.sumw_nlon);
+    if (a.do_energy) {
+      const double mean_en_tmp = (sh[3][0] + factor * sh[4][0]) / a.sumw_nlon / GRAV;
+      tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+    }
+    sc[0] = factor; sc[1] = tcorr;
+    if (blockIdx.x == 0) {
+      for (int c = 0; c < 5; ++c) a.red[c] = sh[c][0];
+      a.red[8] = factor; a.red[9] = tcorr;
+    }
+  }
+  __syncthreads();
+  const double factor = sc[0], tcorr = sc[1];
+  if (blockIdx.x == 0 && a.ml0 >= 0) {
     const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
     const double s2 = sqrt(2.);
+    const int k = threadIdx.x;
     if (k == 0 && a.do_mass) {
       const double dl = s2 * log(factor);
       a.lnps_fut[mn].x += dl;
-      a.lnps_cur[mn].x += a.robert * dl;        // the Robert filter completion sees the corrected future (:1470)
+      a.lnps_cur[mn].x += a.robert * dl;
     }
     if (k < g.L && a.do_energy) {
       const double dtc = s2 * tcorr;
@@ -1239,13 +1294,11 @@ __global__ void k_fixer_finalize(Geom g, FixerArgs a) {
       a.ts_cur[mn * g.L + k].x += a.robert * dtc;
     }
   }
-}
-__global__ void k_fixer_apply(Geom g, const double *__restrict__ red, double *psg, double *tg) {
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;     // two doubles per thread
-  const size_t lev = (size_t)g.Jl * g.I;
-  const double factor = red[8], tcorr = red[9];
-  if (i < lev) { double2 p = *(double2 *)(psg + i); p.x *= factor; p.y *= factor; *(double2 *)(psg + i) = p; }
-  if (i < lev * g.L) { double2 t = *(double2 *)(tg + i); t.x += tcorr; t.y += tcorr; *(double2 *)(tg + i) = t; }
+  const size_t lev = (size_t)g.Jl * g.I, n3 = lev * g.L;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n3; i += (size_t)gridDim.x * 512) {
+    if (i < lev) { double2 p = *(double2 *)(a.psg + i); p.x *= factor; p.y *= factor; *(double2 *)(a.psg + i) = p; }
+    double2 t = *(double2 *)(a.tg + i); t.x += tcorr; t.y += tcorr; *(double2 *)(a.tg + i) = t;
+  }
 }
 
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
@@ -1255,24 +1308,27 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
   hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH);
-  hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
+  if (g.P > 1)   // the host all-reduces red[0..4] between the phases
+    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
-void launch_fixer_finalize(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
   FixerArgs a;
-  a.red = h.d.red;
+  const int nb = (int)column_partials_count(h);
+  a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
-  a.ml0 = h.ml_of_m0;      // local slot of m = 0, or -1 when another rank owns it
+  a.psg = h.d.psg[sc.fut]; a.tg = h.d.tg[sc.fut];
+  a.ml0 = h.ml_of_m0;
   double sumw = 0.0;
   for (double w : h.tab.wts_lat) sumw += w;
-  a.sumw_nlon = sumw * h.g.I;
+  a.sumw_nlon = sumw * g.I;
   a.robert = h.cfg.robert_coeff;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
-  hipLaunchKernelGGL(k_fixer_finalize, dim3(1), dim3(64), 0, s, h.g, a);
-}
-void launch_fixer_apply(const isca_dyn &h, int fut, hipStream_t s) {
-  const Geom &g = h.g;
-  hipLaunchKernelGGL(k_fixer_apply, grid1d((size_t)g.Jl * g.I * g.L / 2), dim3(256), 0, s, g, h.d.red, h.d.psg[fut], h.d.tg[fut]);
+  a.reduce_here = (g.P == 1);
+  const size_t n3 = (size_t)g.Jl * g.I * g.L;
+  const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
+  hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
 
 }  // namespace isca
