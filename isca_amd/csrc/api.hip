@@ -256,11 +256,15 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       d.coef = dupload(h, cf);
     }
     {
+      // retained (m,n) of my wavenumbers grouped by total wavenumber m+n, each group padded to a multiple of 4
       std::vector<int> act;
-      for (int ml = 0; ml < g.Ml; ++ml) {
-        const int m = h->h_m_local[ml];
-        if (m < 0) continue;
-        for (int n = 0; n < g.N1; ++n) if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) act.push_back(ml * g.N1 + n);
+      for (int Lw = 0; Lw < cfg->num_spherical; ++Lw) {
+        for (int ml = 0; ml < g.Ml; ++ml) {
+          const int m = h->h_m_local[ml], n = Lw - m;
+          if (m < 0 || n < 0 || n >= g.N1) continue;
+          if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) act.push_back(ml * g.N1 + n);
+        }
+        while (act.size() % 4) act.push_back(-1);
       }
       h->n_active = (int)act.size();
       d.mn_active = dupload(h, act);

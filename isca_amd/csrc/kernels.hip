@@ -659,17 +659,26 @@ __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, d
 }
 
 __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
-  __shared__ double2 xs[4][64];                      // per-wavefront vector for the wave-matrix product
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2 *xsb = (double2 *)smem;                    // [4][64] per-wavefront vector for the wave-matrix product
+  double *ws = (double *)(xsb + 4 * 64);             // [L][L] transposed wave matrix of this block's total wavenumber
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ia = blockIdx.x * 4 + wave;
-  if (ia >= a.nactive) return;
-  const int mn = a.active[ia];                       // retained (m,n) only: outside the triangle the state stays zero
+  const int L = g.L;
+  // the list is grouped by total wavenumber (padded with -1), so the 4 wavefronts of a block share one matrix
+  const int mn0 = a.active[blockIdx.x * 4];
+  {
+    const int Lw = a.m_local[mn0 / g.N1] + mn0 % g.N1;
+    const double *W = a.wave_t + (size_t)Lw * L * L;     // L*L may be odd: plain 8-byte copies
+    for (int i = threadIdx.x; i < L * L; i += 256) ws[i] = W[i];
+  }
+  const int mn_raw = a.active[blockIdx.x * 4 + wave];   // retained (m,n) only: outside the triangle the state stays zero
+  const bool idle = mn_raw < 0;                          // padding entry: helps with the copy, computes on (0,0), stores nothing
+  const int mn = idle ? 0 : mn_raw;
   const int n = mn % g.N1, ml = mn / g.N1;
   const double *coef = a.coef;
-  const int L = g.L;
-  const bool act = lane < L;
-  const int kk = act ? lane : 0;
-  const size_t idx = mn * L + kk;
+  const bool act = lane < L && !idle;
+  const int kk = (lane < L) ? lane : 0;
+  const size_t idx = (size_t)mn * L + kk;
   const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
   const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
   const double eig = COEF(C_EIG, ml, n);
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t;      // kept for diagnostics/tests
   } else { dt_vor = zero; dt_div = zero; }
   double2 dt_lp = *(const double2 *)(a.Sf + mn * a.C + 2 * (4 * L));
-  if (lane == 0) a.dtlp[mn] = dt_lp;
+  if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
   // --- adjust_dt_divs (:289-325)
   double2 dps, dts;
   lin_tp(csub(dprev, dcur), lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
@@ -707,23 +716,21 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     const double hp = hk * a.ref_p;
     dt_div = cadd(dt_div, cscale(eig, make_double2(geo.x + hp * ps_temp.x, geo.y + hp * ps_temp.y)));
   }
-  {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); wave_t[Lw][k'][k]; x broadcast from LDS
-    const int Lw = a.m_local[ml] + n;
-    const double *W = a.wave_t + (size_t)Lw * L * L;
-    xs[wave][lane] = act ? dt_div : zero;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); ws[k'][k] in LDS, x broadcast from LDS
+    double2 *xs = xsb + wave * 64;
+    xs[lane] = act ? dt_div : zero;
+    __syncthreads();                                  // matrix copy + x vectors visible
     double2 out = zero;
 #pragma unroll 8
     for (int k2 = 0; k2 < L; ++k2) {
-      const double2 x = xs[wave][k2];
-      const double w = W[(size_t)k2 * L + kk];
+      const double2 x = xs[k2];
+      const double w = ws[k2 * L + kk];
       out.x += w * x.x;
       out.y += w * x.y;
     }
     dt_div = act ? out : zero;
   }
+  if (idle) return;
   lin_tp(dt_div, lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
   dt_t = cadd(dt_t, cscale(a.xi, dts));
   dt_lp = cadd(dt_lp, cscale(a.xi / a.ref_p, dps));
@@ -777,7 +784,8 @@ void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.Sf = h.d.Sf; a.C = h.Cf;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
-  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)((h.n_active + 3) / 4)), dim3(256), 0, s, g, a);
+  const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
+  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, a);
 }
 
 // -----------------------------------------------------------------------------------------------------
