@@ -4,6 +4,7 @@
 #include <cmath>
 #include <algorithm>
 #include <mutex>
+#include <cstdlib>
 
 using namespace isca;
 
@@ -314,7 +315,11 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
-    h->kernels_per_step = 9;
+    // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
+    h->fuse_synth = (cfg->legendre_impl == 0) && (g.Jl % 16 == 0) && ((g.Jl & (g.Jl - 1)) == 0) &&
+                    ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
+    if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
+    h->kernels_per_step = h->fuse_synth ? 8 : 9;
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -583,8 +588,12 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
   { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, 0, h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
-  { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
-  { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream); }
+  if (h->fuse_synth) {
+    Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut);
+  } else {
+    { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream); }
+  }
 }
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
   FieldList fl = inverse_list(h, sc.fut);

@@ -104,5 +104,6 @@ struct isca_dyn {
   int ml_of_m0 = -1;
   std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
   int n_active = 0;
+  bool fuse_synth = false;
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
 };

@@ -14,7 +14,8 @@ struct StepScalars {      // per-step scalars passed by value to kernels
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s);
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s);
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s);
-void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s);
+// fused_tl >= 0: build the inverse-batch columns on the fly from the spectral state at that time level (S unused)
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl = -1);
 
 // ---- spectral-space kernels
 // pack a spectral state array [Ml][N1][nlev] (complex) into columns of a work buffer, and back

@@ -101,18 +101,19 @@ template <int NC, bool INV> __device__ __forceinline__ void fft_row(double2 *row
   else { fft_pass<256, 8, 1, INV>(row, twl, tr); fft_pass<256, 8, 8, INV>(row, twl, tr); fft_pass<256, 4, 64, INV>(row, twl, tr); }
 }
 
-constexpr int FFT_R = 16;      // rows (level-fields) per block; 16 threads per row
+// rows (level-fields) per block: 16 (256 threads) up to lon_max = 256, 8 (128 threads) at lon_max = 512; 16 threads per row
+template <int NC> struct FftCfg { static constexpr int R = (NC >= 256) ? 8 : 16; };
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const double *__restrict__ cosm,
+__global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  double *__restrict__ Fg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FFT_R, rs = NC + NC / 8 + 1;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
   const int jl = blockIdx.y;
-  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
+  for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
   {
     const int c = blockIdx.x * R + r;
     const double2 *src = nullptr;
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const dou
   __syncthreads();
   fft_row<NC, false>(buf + r * rs, twl, tr);
   // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
-  const int rr = t & 15, cc = blockIdx.x * R + rr;
+  const int rr = t % R, cc = blockIdx.x * R + rr;
   const double inv_n = 1.0 / (double)g.I;
-  for (int m = t >> 4; m < g.M1; m += 16) {
+  for (int m = t / R; m < g.M1; m += 16) {
     const double2 zk = buf[rr * rs + fpad(m)];
     const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
     const double2 e = cscale(0.5, cadd(zk, zc));
@@ -149,19 +150,19 @@ __global__ __launch_bounds__(256) void k_fft_fwd(Geom g, FieldList fl, const dou
 }
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const double *__restrict__ cosm,
+__global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  const double *__restrict__ Fg, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FFT_R, rs = NC + NC / 8 + 1;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
   const int jl = blockIdx.y;
-  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
+  for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
   {  // load truncated coefficients m = 0..M (transforms.F90:424 zeroes everything above)
-    const int rr = t & 15, cc = blockIdx.x * R + rr;
+    const int rr = t % R, cc = blockIdx.x * R + rr;
 #pragma unroll 4
-    for (int m = t >> 4; m < NC; m += 16) {
+    for (int m = t / R; m < NC; m += 16) {
       double2 X = make_double2(0., 0.);
       if (m < g.M1 && cc < fl.ncol) {
         X = *(const double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc);
@@ -212,13 +213,15 @@ __global__ __launch_bounds__(256) void k_fft_inv(Geom g, FieldList fl, const dou
   }
 }
 
-static size_t fft_lds_bytes(int NC) { return (size_t)(FFT_R * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
+static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
+static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
-  dim3 grid((fl.ncol + FFT_R - 1) / FFT_R, g.Jl);
+  const int R = fft_rows(NC);
+  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
   const size_t lds = fft_lds_bytes(NC);
-#define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+#define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
   switch (NC) {
     case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
     case 128: LF(128); break; case 256: LF(256); break;
@@ -228,9 +231,10 @@ void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double
 }
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
-  dim3 grid((fl.ncol + FFT_R - 1) / FFT_R, g.Jl);
+  const int R = fft_rows(NC);
+  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
   const size_t lds = fft_lds_bytes(NC);
-#define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(256), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+#define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
   switch (NC) {
     case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
     case 128: LI(128); break; case 256: LI(256); break;
@@ -266,7 +270,7 @@ __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
 // (P*w of this m, one parity at a time, only the rows the triangle needs) is staged in LDS, the folded
 // B operand lives in registers, so the MFMA loop touches no global memory.  32-bit index arithmetic throughout:
 // these kernels have ~50 MFMAs per wavefront, so address VALU work must stay well below that.
-template <int JH4>
+template <int JH4, bool BOTH>
 __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pw, const double *__restrict__ Fs,
                                                       double *__restrict__ S, int C, int full) {
@@ -293,14 +297,20 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
   }
   const int nlim = full ? g.N1 : g.N1 - m;
   const int srow = ml * g.N1 * C + c;               // S offset of (ml, n=0, c)
+  if (BOTH) {                                       // both parity tables fit in LDS: one fill, one barrier
+    lds_fill(As, pw + (size_t)(ml * 2) * g.Jh * NHP, 2 * g.Jh * NHP);
+    __syncthreads();
+  }
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
-    if (par) __syncthreads();                       // everyone done with the even-parity table
-    lds_fill(As, pw + (size_t)(ml * 2 + par) * g.Jh * NHP, g.Jh * NHP);
-    __syncthreads();
+    if (!BOTH) {
+      if (par) __syncthreads();                     // everyone done with the even-parity table
+      lds_fill(As, pw + (size_t)(ml * 2 + par) * g.Jh * NHP, g.Jh * NHP);
+      __syncthreads();
+    }
     const int cnt = (nlim - par + 1) >> 1;
     const int ntile = (c0 < C) ? (cnt + 15) >> 4 : 0;
-    const double *A = As + kq * NHP + cl;
+    const double *A = As + (BOTH ? par * g.Jh * NHP : 0) + kq * NHP + cl;
     for (int tile = 0; tile < ntile; ++tile) {
       double4_t acc = {0., 0., 0., 0.};
 #pragma unroll
@@ -315,12 +325,19 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
 }
 
 // Synthesis (spectral -> Fourier).  Same blocking; A = P of this m from LDS, B rows preloaded in registers.
-template <int JT, int NKS>
+// FUSED: the B operand (inverse-batch columns div, vor, u cos, v cos, T, dT/dx cos, dT/dy cos, ln ps and its two
+// gradients) is generated on the fly from the spectral state (compute_ucos_vcos spherical.F90:409-469,
+// compute_gradient_cos :270-351) instead of being read from a staged work buffer.
+struct SynthSrc { const double *vor, *div, *ts, *lnps, *coef; };
+enum { LC_UVC = 0, LC_UVM, LC_UVP, LC_DX, LC_DYM, LC_DYP, LC_ONE, LC_ZERO, LC_ROWS };
+
+template <int JT, int NKS, bool BOTH, bool FUSED>
 __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pinv, const double *__restrict__ S,
-                                                      double *__restrict__ Fs, int C, int full) {
+                                                      double *__restrict__ Fs, int C, int full, SynthSrc src) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *As = (double *)smem;                      // [NHP][Jh], one parity at a time
+  double *As = (double *)smem;                      // [NHP][Jh] per parity
+  double *lc = As + (BOTH ? 2 : 1) * g.NHP * g.Jh;  // FUSED: [LC_ROWS][N1] operator coefficients of this m
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ml = blockIdx.y, m = m_local[ml];
   if (m < 0) return;
@@ -332,13 +349,61 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
   const int nks0 = (cnt0 + 3) >> 2, nks1 = (cnt1 + 3) >> 2;
   const int Jh = g.Jh;
   double b0[NKS], b1[NKS];
-  {
+  if (!FUSED) {
     const int sbase = (ml * g.N1 + 2 * kq) * C + c;    // row n = 2*(ks*4+kq) (+1)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int n0 = 8 * ks + 2 * kq;
       b0[ks] = (ks < nks0 && n0 < nlim && cok) ? S[sbase + 8 * ks * C] : 0.0;
       b1[ks] = (ks < nks1 && n0 + 1 < nlim && cok) ? S[sbase + (8 * ks + 1) * C] : 0.0;
+    }
+  } else {
+    const int N1 = g.N1, L = g.L;
+    {  // coefficient rows of this wavenumber -> LDS
+      const int ids[6] = {C_UVC, C_UVM, C_UVP, C_DX, C_DYM, C_DYP};
+      for (int i = threadIdx.x; i < LC_ROWS * N1; i += 256) {
+        const int row = i / N1, n = i - row * N1;
+        lc[i] = (row < 6) ? src.coef[((size_t)ids[row] * g.Ml + ml) * N1 + n] : (row == LC_ONE ? 1.0 : 0.0);
+      }
+    }
+    // what this lane's column is made of: w_a(n) A[n] + w_m(n) M[n-1] + w_p(n) P[n+1]
+    const int lf = c >> 1, ri = c & 1;
+    int f = 7 + (lf - 7 * L), k = 0;
+    if (lf < 7 * L) { f = lf / L; k = lf - f * L; }
+    const int stride = (f < 7) ? 2 * L : 2;                               // doubles per n in the source array
+    const size_t e0 = (f < 7) ? ((size_t)ml * N1 * L + k) * 2 : (size_t)ml * N1 * 2;
+    const double *tsrc = (f < 7) ? src.ts : src.lnps;
+    const double *pa = nullptr, *pm = nullptr;                             // centre array, neighbour array (n-1 and n+1)
+    int ra = LC_ZERO, rm = LC_ZERO, rp = LC_ZERO;
+    double sa = 1.0, sm = 1.0, sp = 1.0;
+    int ca = ri;                                                           // component read from the centre array
+    const double si = ri ? 1.0 : -1.0;                                     // (i z).re = -z.im, (i z).im = z.re
+    switch (f) {
+      case 0: pa = src.div; ra = LC_ONE; break;
+      case 1: pa = src.vor; ra = LC_ONE; break;
+      case 2: pa = src.div; ra = LC_UVC; sa = si; ca = 1 - ri; pm = src.vor; rm = LC_UVM; sm = 1.0; rp = LC_UVP; sp = -1.0; break;
+      case 3: pa = src.vor; ra = LC_UVC; sa = si; ca = 1 - ri; pm = src.div; rm = LC_UVM; sm = -1.0; rp = LC_UVP; sp = 1.0; break;
+      case 4: case 7: pa = tsrc; ra = LC_ONE; break;
+      case 5: case 8: pa = tsrc; ra = LC_DX; sa = si; ca = 1 - ri; break;
+      default: pm = tsrc; rm = LC_DYM; sm = -1.0; rp = LC_DYP; sp = 1.0; break;     // 6, 9
+    }
+    if (!cok) { pa = nullptr; pm = nullptr; }
+    __syncthreads();                                                       // lc ready
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int n = 8 * ks + 2 * kq + par;
+        double v = 0.0;
+        if (ks < (par ? nks1 : nks0) && n < nlim) {
+          if (pa) v = sa * lc[ra * N1 + n] * pa[e0 + (size_t)n * stride + ca];
+          if (pm) {
+            if (n >= 1) v += sm * lc[rm * N1 + n] * pm[e0 + (size_t)(n - 1) * stride + ri];
+            if (n + 1 < N1) v += sp * lc[rp * N1 + n] * pm[e0 + (size_t)(n + 1) * stride + ri];
+          }
+        }
+        if (par) b1[ks] = v; else b0[ks] = v;
+      }
     }
   }
   double4_t accE[JT], accO[JT];
@@ -348,6 +413,7 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
   const double *A = As + kq * Jh + cl;
   // even parity: only the rows nh < 4*nks are needed
   lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * Jh, 4 * nks0 * Jh);
+  if (BOTH) lds_fill(As + g.NHP * Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
   __syncthreads();
   if (wave_on) {
 #pragma unroll
@@ -358,16 +424,19 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
           accE[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * Jh + jt * 16], b0[ks], accE[jt], 0, 0, 0);
       }
   }
-  __syncthreads();
-  lds_fill(As, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
-  __syncthreads();
+  if (!BOTH) {
+    __syncthreads();
+    lds_fill(As, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
+    __syncthreads();
+  }
   if (wave_on) {
+    const double *A1 = A + (BOTH ? g.NHP * Jh : 0);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
       if (ks < nks1) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt)
-          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * Jh + jt * 16], b1[ks], accO[jt], 0, 0, 0);
+          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[ks * 4 * Jh + jt * 16], b1[ks], accO[jt], 0, 0, 0);
       }
   }
   if (!cok) return;
@@ -427,11 +496,12 @@ static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (mfma_ok(g, impl)) {
     dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
-    const size_t lds = (size_t)g.Jh * g.NHP * sizeof(double);
-#define LF(N) hipLaunchKernelGGL(k_leg_fwd_mfma<N>, grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
+    const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
+    const size_t lds = (size_t)(both ? 2 : 1) * g.Jh * g.NHP * sizeof(double);
+#define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
     switch (g.Jh / 4) {
-      case 4: LF(4); break;   case 8: LF(8); break;   case 16: LF(16); break;
-      case 32: LF(32); break;
+      case 4: LF(4, true); break;   case 8: LF(8, true); break;   case 16: LF(16, true); break;
+      case 32: LF(32, false); break;
       default: throw std::runtime_error("legendre_forward: unsupported lat_max for the MFMA kernel");
     }
 #undef LF
@@ -440,16 +510,24 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     hipLaunchKernelGGL(k_leg_fwd_simple, grid, dim3(64), 0, s, g, d.m_local, d.pw_fwd, Fs, S, C, full);
   }
 }
-void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s) {
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl) {
+  if (fused_tl >= 0 && !mfma_ok(g, impl)) throw std::runtime_error("fused synthesis needs the MFMA Legendre kernel");
   if (mfma_ok(g, impl)) {
+    SynthSrc src = {nullptr, nullptr, nullptr, nullptr, d.coef};
+    if (fused_tl >= 0) { src.vor = d.vors[fused_tl]; src.div = d.divs[fused_tl]; src.ts = d.ts[fused_tl]; src.lnps = d.lnps[fused_tl]; }
     dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
-    const size_t lds = (size_t)g.NHP * g.Jh * sizeof(double);
+    const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
+    const size_t lds = (size_t)(both ? 2 : 1) * g.NHP * g.Jh * sizeof(double) + (size_t)LC_ROWS * g.N1 * sizeof(double);
     // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
-#define LI(JT, NKS) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full)
-    if (g.Jh == 16 && g.NHP == 16) LI(1, 4);
-    else if (g.Jh == 32 && g.NHP == 32) LI(2, 8);
-    else if (g.Jh == 64 && g.NHP == 48) LI(4, 12);
-    else if (g.Jh == 128 && g.NHP == 96) LI(8, 24);
+#define LI(JT, NKS, B)                                                                                                            \
+  do {                                                                                                                            \
+    if (fused_tl >= 0) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, true>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src);  \
+    else hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, false>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src);               \
+  } while (0)
+    if (g.Jh == 16 && g.NHP == 16) LI(1, 4, true);
+    else if (g.Jh == 32 && g.NHP == 32) LI(2, 8, true);
+    else if (g.Jh == 64 && g.NHP == 48) LI(4, 12, true);
+    else if (g.Jh == 128 && g.NHP == 96) LI(8, 24, false);
     else throw std::runtime_error("legendre_inverse: unsupported resolution for the MFMA kernel");
 #undef LI
   } else {
