@@ -633,6 +633,7 @@ class SpectralCore:
         self.ug, self.vg, self.tg, self.psg = two(ug), two(vg), two(tg), two(psg)
         tr = np.full((L, J, I), c.initial_sphum)
         self.tr = two(tr)
+        self.tr_atm = two(tr)
         self.previous = 0
         self.current = 0
         self.step_count = 0
@@ -648,7 +649,7 @@ class SpectralCore:
         zf, zh, pf, ph = self.compute_pressures_and_heights(self.tg[lev], self.psg[lev])
         self.z_full[lev], self.z_half[lev], self.p_full[lev], self.p_half[lev] = zf, zh, pf, ph
 
-    def step(self, with_tracer=False):
+    def step(self, with_tracer=True):
         """One call of atmosphere (driver/solo/atmosphere.F90:276-352), HS branch, i.e.
         hs_forcing -> spectral_dynamics (spectral_dynamics.F90:780-1034) -> pressures/heights."""
         c = self.cfg
@@ -656,8 +657,14 @@ class SpectralCore:
         delta_t = c.dt_atmos if prev == cur else 2 * c.dt_atmos
         fut = 1 - cur if prev == cur else prev
         # --- physics: u,v,T at PREVIOUS, p at CURRENT (atmosphere.F90:304-311)
-        dt_u, dt_v, dt_t = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur],
-                                           self.ug[prev], self.vg[prev], self.tg[prev])
+        if with_tracer:
+            # atmosphere_mod keeps its OWN grid_tracers copy (atmosphere.F90:95,326), which only ever receives
+            # the new level (spectral_dynamics.F90:1028): physics sees the un-Robert-filtered tracer
+            dt_u, dt_v, dt_t, dt_tr = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur], self.ug[prev],
+                                                      self.vg[prev], self.tg[prev], self.tr_atm[prev], np.zeros_like(self.tr[prev]))
+        else:
+            dt_u, dt_v, dt_t = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur],
+                                               self.ug[prev], self.vg[prev], self.tg[prev])
         dt_ps = np.zeros((self.J, self.I))
         # --- initialize_corrections :1306-1338
         if c.do_mass_correction:
@@ -666,6 +673,8 @@ class SpectralCore:
             energy = 0.5 * ((self.ug[prev] + dt_u * delta_t) ** 2 + (self.vg[prev] + dt_v * delta_t) ** 2) \
                 + CP_AIR * (self.tg[prev] + dt_t * delta_t)
             mean_energy_prev = self.mass_weighted_global_integral(energy, self.psg[prev])
+        if with_tracer and c.do_water_correction:
+            mean_water_prev = self.mass_weighted_global_integral(self.tr[prev] + delta_t * dt_tr, self.psg[prev])
         # --- dynamics tendencies :853-904
         p_half, ln_p_half, p_full, ln_p_full = self.pressure_variables(self.psg[cur])
         dxs, dys = self.compute_gradient_cos(self.ln_ps[cur])
@@ -718,6 +727,13 @@ class SpectralCore:
         tmin, tmax = self.tg[fut].min(), self.tg[fut].max()
         if tmin < c.valid_range_t[0] or tmax > c.valid_range_t[1]:
             raise FloatingPointError("temperatures out of valid range")      # :940-972
+        if with_tracer:                                                      # update_tracers :1007
+            tr_cur_new, tr_future, part_tr = self.update_grid_tracer(self.tr[prev], self.tr[cur], dt_tr, u, v, wg, p_half, delta_t)
+            if prev == cur:
+                self.tr[cur] = tr_cur_new
+            else:
+                self.tr[cur] = tr_cur_new
+            self.tr[fut] = tr_future
         # --- compute_corrections :1213-1302
         if c.do_mass_correction:
             mean_ps_tmp = self.area_weighted_global_mean(self.psg[fut])
@@ -730,16 +746,270 @@ class SpectralCore:
             tcorr = GRAV * (mean_energy_prev - mean_energy_tmp) / (CP_AIR * mean_ps_prev)
             self.tg[fut] = self.tg[fut] + tcorr
             self.ts[fut][:, 0, 0] += math.sqrt(2.0) * tcorr
+        if with_tracer and c.do_water_correction:                              # :1245-1283
+            q = self.tr[fut]
+            mean_water_tmp = self.mass_weighted_global_integral(q, self.psg[fut])
+            mask = (p_full >= c.water_correction_limit)
+            corr = self.mass_weighted_global_integral(q * mask, self.psg[fut])
+            notc = self.mass_weighted_global_integral(q * (~mask), self.psg[fut])
+            if mean_water_tmp > 0.0:
+                f = mean_water_prev / mean_water_tmp
+                f = f * (1. + notc / corr) - notc / corr
+                self.tr[fut] = np.where(mask, f * q, q)
+        if with_tracer:
+            self.tr_atm[fut] = self.tr[fut].copy()
         self.previous, self.current = cur, fut
         # --- complete_robert_filter :1456-1490 (leapfrog_2level_B with swapped pointers)
         for name in ("ln_ps", "vors", "divs", "ts"):
             a = getattr(self, name)
             a[cur] = a[cur] + rc * a[fut] * raw
             a[fut] = a[fut] + rc * (part[name] + a[fut]) * (raw - 1.0)
+        if with_tracer:                                                      # leapfrog_2level_B on the grid tracer :1484
+            self.tr[cur] = self.tr[cur] + rc * self.tr[fut] * raw
+            self.tr[fut] = self.tr[fut] + rc * (part_tr + self.tr[fut]) * (raw - 1.0)
         self.wg_full = wg_full
         self.p_full[cur], self.p_half[cur] = p_full, p_half       # intent(out) of spectral_dynamics
         self._pressures_and_heights(fut)                          # atmosphere.F90:331-338
         self.step_count += 1
+
+    # ----------------------------------------------------------------------------------------
+    # grid-tracer transport: model/fv_advection.F90 (van Leer on the sphere) and
+    # atmos_shared/vert_advection/vert_advection.F90:301-438 (PPM), update_tracers spectral_dynamics.F90:1155-1180
+    # ----------------------------------------------------------------------------------------
+    def _fv_init(self):
+        """fv_advection_init (fv_advection.F90:58-120) with the boundaries of transforms.F90:313-321."""
+        if hasattr(self, "_fv"):
+            return self._fv
+        J, I = self.J, self.I
+        yy = np.zeros(J + 1)
+        yy[0] = -0.5 * PI
+        sum_wts = 0.0
+        for j in range(J - 1):
+            sum_wts = sum_wts + self.wts_lat[j]
+            yy[j + 1] = math.asin(sum_wts - 1.0)
+        yy[J] = 0.5 * PI
+        y = 0.5 * (yy[1:] + yy[:-1])
+        fv = dict(c=np.cos(y), cc=np.cos(yy))
+        dy = np.zeros(J + 4)                       # index offset 2: dy[-1..J+2] -> dy[j+1]
+        dy[2:J + 2] = yy[1:] - yy[:-1]
+        dy[0] = dy[3]; dy[1] = dy[2]; dy[J + 2] = dy[J + 1]; dy[J + 3] = dy[J]
+        dyy = np.zeros(J + 1)                      # dyy(1:ny+1) -> dyy[j-1]
+        dyy[1:J] = y[1:] - y[:-1]
+        dyy[0] = 2 * (y[0] - yy[0]); dyy[J] = 2 * (yy[J] - y[J - 1])
+        # dy_plus(0:ny+1), dy_minus(0:ny+1): index j -> [j]
+        dyF = lambda j: dy[j + 1]                  # Fortran dy(j)
+        fv["dy_plus"] = np.array([dyF(j) / (dyF(j) + dyF(j + 1)) for j in range(0, J + 2)])
+        fv["dy_minus"] = np.array([dyF(j) / (dyF(j - 1) + dyF(j)) for j in range(0, J + 2)])
+        fv["dy"] = dy * RADIUS                     # Fortran dy(j) = fv['dy'][j+1]
+        fv["dyy"] = dyy * RADIUS                   # Fortran dyy(j) = fv['dyy'][j-1]
+        fv["dx"] = 2.0 * PI * RADIUS / float(I)
+        self._fv = fv
+        return fv
+
+    @staticmethod
+    def _find_cell_x(b):
+        I = b.shape[-1]
+        ii = np.arange(I)[None, None, :] - np.floor(b).astype(np.int64)      # 1-based: (i-1) - floor(b)
+        ii = np.where(ii > I, ii - I, ii)
+        ii = np.where(ii < 1, ii + I, ii)
+        return ii                                                            # 1-based cell index
+
+    def _semi_x(self, ua, q, dt):
+        fv = self._fv_init()
+        I = self.I
+        b = ua * dt / (fv["dx"] * fv["c"][None, :, None])
+        ii = self._find_cell_x(b)
+        i_left = ii
+        i_right = np.where(ii + 1 > I, 1, ii + 1)
+        bb = b - np.floor(b)
+        ql = np.take_along_axis(q, i_left - 1, axis=2)
+        qr = np.take_along_axis(q, i_right - 1, axis=2)
+        return bb * ql + (1.0 - bb) * qr - q
+
+    @staticmethod
+    def _slope_x(q):
+        grad = q - np.roll(q, 1, axis=2)
+        slope = (np.roll(grad, -1, axis=2) + grad) / 2
+        qm, qp = np.roll(q, 1, axis=2), np.roll(q, -1, axis=2)
+        q_min = np.minimum(np.minimum(qm, q), qp); q_max = np.maximum(np.maximum(qm, q), qp)
+        return np.where(slope >= 0, 1.0, -1.0) * np.minimum(np.minimum(np.abs(slope), 2.0 * (q - q_min)), 2.0 * (q_max - q))
+
+    def _vanleer_x(self, dq_dt, uc, q, dt):
+        fv = self._fv_init()
+        I = self.I
+        b = uc * dt / (fv["dx"] * fv["c"][None, :, None])
+        bb = b - np.trunc(b)                                   # b - int(b)
+        flux = np.zeros_like(q)
+        big = np.abs(b).max(axis=2) > 1.0                      # rows with |CFL| > 1: integer_flux_x (:494-527)
+        for k, j in zip(*np.nonzero(big)):
+            c_, q_ = b[k, j], q[k, j]
+            iic = np.trunc(c_).astype(int)
+            for i in range(1, I + 1):
+                n_ = iic[i - 1]
+                if n_ >= 1:
+                    if i - n_ >= 1:
+                        flux[k, j, i - 1] = np.sum(q_[i - n_ - 1:i - 1])
+                    else:
+                        flux[k, j, i - 1] = np.sum(q_[0:i - 1]) + np.sum(q_[i - n_ + I - 1:I])
+                elif n_ <= -1:
+                    if i - 1 - n_ <= I:
+                        flux[k, j, i - 1] = -np.sum(q_[i - 1:i - 1 - n_])
+                    else:
+                        flux[k, j, i - 1] = -np.sum(q_[i - 1:I]) - np.sum(q_[0:i - 1 - n_ - I])
+        s = self._slope_x(q)
+        ii = self._find_cell_x(b)
+        qq = np.take_along_axis(q, ii - 1, axis=2)
+        ss = np.take_along_axis(s, ii - 1, axis=2)
+        flux = flux + bb * (qq + 0.5 * ss * (np.where(bb >= 0, 1.0, -1.0) - bb))
+        return dq_dt - (np.roll(flux, -1, axis=2) - flux) / dt
+
+    def _slope_sphere(self, q):
+        """q rows -2..J+1 (J+4 rows) -> slope rows -1..J (J+2 rows); dy_plus/minus index j = row+... (:546-565)"""
+        fv = self._fv_init()
+        J = self.J
+        mid, up, dn = q[:, 1:J + 3], q[:, 2:J + 4], q[:, 0:J + 2]       # rows j=0..J+1 (Fortran), j+1, j-1
+        slope = (up - mid) * fv["dy_plus"][None, :, None] + (mid - dn) * fv["dy_minus"][None, :, None]
+        q_min = np.minimum(np.minimum(dn, mid), up); q_max = np.maximum(np.maximum(dn, mid), up)
+        return np.where(slope >= 0, 1.0, -1.0) * np.minimum(np.minimum(np.abs(slope), 2.0 * (mid - q_min)), 2.0 * (q_max - mid))
+
+    def _vanleer_sphere(self, dq_dt, vc, q, dt):
+        """vc rows 1..J+1 (J+1 rows); q rows -1..J+2 (J+4 rows) (:268-304)"""
+        fv = self._fv_init()
+        J = self.J
+        s = self._slope_sphere(q)                                       # rows 0..J+1
+        dyF = fv["dy"]                                                  # Fortran dy(j) = dyF[j+1]
+        flux = np.zeros((q.shape[0], J + 1, q.shape[2]))
+        for jj in range(1, J + 2):                                      # Fortran j = 1..J+1
+            v = vc[:, jj - 1]
+            qm, sm = q[:, jj - 1 + 1], s[:, jj - 1]                     # q(j-1): row index j-1 -> array (j-1)+2-... see below
+            # arrays: q index a = j + 1 (rows -1..J+2 -> 0..J+3), s index a = j (rows 0..J+1 -> 0..J+1)
+            qm, sm = q[:, (jj - 1) + 1], s[:, (jj - 1)]
+            q0, s0 = q[:, jj + 1], s[:, jj]
+            dtdy_m = dt / dyF[(jj - 1) + 1]; dtdy_0 = dt / dyF[jj + 1]
+            flux[:, jj - 1] = np.where(v >= 0.0, v * fv["cc"][jj - 1] * (qm + 0.5 * sm * (1.0 - dtdy_m * v)),
+                                       v * fv["cc"][jj - 1] * (q0 - 0.5 * s0 * (1.0 + dtdy_0 * v)))
+        flux[:, 0] = 0.0; flux[:, J] = 0.0
+        dyc = 1.0 / (dyF[2:J + 2] * fv["c"])
+        return dq_dt - dyc[None, :, None] * (flux[:, 1:] - flux[:, :-1])
+
+    def a_grid_horiz_advection(self, ua, va, q, dt, dq_dt):
+        """fv_advection.F90:126-207 + advection_sphere_3d :238-264 (single PE: polar mirror rows only)."""
+        fv = self._fv_init()
+        J, I = self.J, self.I
+        sh = I // 2
+        def with_halo(a, sign):                                          # rows -1..J+2
+            out = np.zeros((a.shape[0], J + 4, I))
+            out[:, 2:J + 2] = a
+            out[:, 1] = sign * np.roll(a[:, 0], -sh, axis=1)             # row 0  <- ii(i)=i+nx/2 of row 1
+            out[:, 0] = sign * np.roll(a[:, 1], -sh, axis=1)             # row -1 <- row 2
+            out[:, J + 2] = sign * np.roll(a[:, J - 1], -sh, axis=1)
+            out[:, J + 3] = sign * np.roll(a[:, J - 2], -sh, axis=1)
+            return out
+        vx = with_halo(va, -1.0); vx[:, 0] = 0.0; vx[:, J + 3] = 0.0     # vx(-1), vx(ny+2) stay zero in the reference
+        qx = with_halo(q, 1.0)
+        uc = 0.5 * (np.roll(ua, 1, axis=2) + ua)
+        vc = 0.5 * (vx[:, 1:J + 2] + vx[:, 2:J + 3])                     # Fortran j=1..J+1: vx(j-1)+vx(j)
+        cF, ccF, dyF = fv["c"], fv["cc"], fv["dy"]
+        div = (vc[:, 1:] * ccF[None, 1:, None] - vc[:, :-1] * ccF[None, :-1, None]) / (cF * dyF[2:J + 2])[None, :, None]
+        div = div + (np.roll(uc, -1, axis=2) - uc) / (cF[None, :, None] * fv["dx"])
+        dq_dt = dq_dt + q * div
+        # advection_sphere
+        q1 = q + self._semi_x(ua, q, 0.5 * dt)
+        qxm, qxp = qx[:, 1:J + 1], qx[:, 3:J + 3]                         # rows j-1, j+1 for j=1..J
+        dyyF = fv["dyy"]                                                  # Fortran dyy(j) = dyyF[j-1]
+        semi_y = np.where(va >= 0.0, va * dt * 0.5 * (qxm - q) / dyyF[None, 0:J, None],
+                          va * dt * 0.5 * (q - qxp) / dyyF[None, 1:J + 1, None])
+        q2 = q + semi_y
+        q1h = with_halo(q1, 1.0)
+        dq_dt = self._vanleer_x(dq_dt, uc, q2, dt)
+        return self._vanleer_sphere(dq_dt, vc, q1h, dt)
+
+    @staticmethod
+    def _compute_weights(dz):
+        L = dz.shape[0]
+        zwt = np.zeros((4, L) + dz.shape[1:])
+        for k in range(2, L - 1):                                         # Fortran k = 3..n-1
+            d1 = 1.0 / (dz[k - 1] + dz[k]); d2 = 1.0 / (dz[k - 2] + dz[k - 1] + dz[k] + dz[k + 1])
+            d3 = 1.0 / (2 * dz[k - 1] + dz[k]); d4 = 1.0 / (dz[k - 1] + 2 * dz[k])
+            n3 = dz[k - 2] + dz[k - 1]; n4 = dz[k] + dz[k + 1]
+            x = n3 * d3 - n4 * d4; y = 2.0 * dz[k - 1] * dz[k]
+            zwt[0, k] = dz[k - 1] * d1
+            zwt[1, k] = zwt[0, k] + x * y * d1 * d2
+            zwt[2, k] = dz[k - 1] * n3 * d3 * d2
+            zwt[3, k] = dz[k] * n4 * d4 * d2
+        return zwt
+
+    @staticmethod
+    def _slope_z(r, dz):
+        """slope_z(limit=.true., linear=.false.) vert_advection.F90:505-568"""
+        L = r.shape[0]
+        grad = np.zeros_like(r)
+        grad[1:] = (r[1:] - r[:-1]) / (dz[1:] + dz[:-1])
+        slope = np.zeros_like(r)
+        slope[1:-1] = (grad[2:] * (2. * dz[:-2] + dz[1:-1]) + grad[1:-1] * (2. * dz[2:] + dz[1:-1])) \
+            * dz[1:-1] / (dz[:-2] + dz[1:-1] + dz[2:])
+        rmin = np.minimum(np.minimum(r[:-2], r[1:-1]), r[2:]); rmax = np.maximum(np.maximum(r[:-2], r[1:-1]), r[2:])
+        slope[1:-1] = np.where(slope[1:-1] >= 0, 1.0, -1.0) * np.minimum(np.minimum(np.abs(slope[1:-1]), 2. * (r[1:-1] - rmin)), 2. * (rmax - r[1:-1]))
+        slope[0] = 0.0; slope[-1] = 0.0
+        return slope
+
+    def vert_advection_ppm(self, dt, w, dz, r):
+        """vert_advection_3d, scheme=FINITE_VOLUME_PARABOLIC, form=ADVECTIVE_FORM (:301-438, :467-470)."""
+        L = r.shape[0]
+        zwt = self._compute_weights(dz)
+        slp = self._slope_z(r, dz)
+        r_left = np.zeros_like(r); r_right = np.zeros_like(r)
+        for k in range(2, L - 1):
+            r_left[k] = r[k - 1] + zwt[1, k] * (r[k] - r[k - 1]) - zwt[2, k] * slp[k] + zwt[3, k] * slp[k - 1]
+            r_right[k - 1] = r_left[k]
+        r_left[1] = r[1] - 0.5 * slp[1]; r_right[L - 2] = r[L - 2] + 0.5 * slp[L - 2]
+        r_left[0] = r[0] - 0.5 * slp[0]; r_right[0] = r[0] + 0.5 * slp[0]
+        r_left[L - 1] = r[L - 1] - 0.5 * slp[L - 1]; r_right[L - 1] = r[L - 1] + 0.5 * slp[L - 1]
+        for k in range(L):                                                 # Colella-Woodward limiter (:354-370)
+            t1 = (r_right[k] - r[k]) * (r[k] - r_left[k]) <= 0.0
+            r_left[k] = np.where(t1, r[k], r_left[k]); r_right[k] = np.where(t1, r[k], r_right[k])
+            if k == 0 or k == L - 1:
+                continue
+            rm = r_right[k] - r_left[k]
+            a = rm * (r[k] - 0.5 * (r_right[k] + r_left[k])); b = rm * rm / 6.
+            new_left = np.where(a > b, 3.0 * r[k] - 2.0 * r_right[k], r_left[k])
+            rm2 = r_right[k] - new_left
+            new_right = np.where(a < -b, 3.0 * r[k] - 2.0 * new_left, r_right[k])
+            r_left[k], r_right[k] = new_left, new_right
+        flux = np.zeros_like(w)
+        flux[0] = w[0] * r[0]; flux[L] = w[L] * r[L - 1]
+        tt = 2. / 3.
+        for k in range(1, L):
+            wk = w[k]
+            cn_p = dt * wk / dz[k - 1]; cn_m = -dt * wk / dz[k]
+            if np.any((wk >= 0) & (cn_p > 1.0)) or np.any((wk < 0) & (cn_m > 1.0)):
+                raise NotImplementedError("vertical Courant number > 1 (vert_advection.F90:385-396) not needed by the oracle cases")
+            kk = k - 1
+            rm = r_right[kk] - r_left[kk]
+            r6 = 6.0 * (r[kk] - 0.5 * (r_right[kk] + r_left[kk]))
+            if kk == 0:
+                r6 = 0.0 * r6
+            rst_p = r_right[kk] - 0.5 * cn_p * (rm - (1.0 - tt * cn_p) * r6)
+            kk = k
+            rm = r_right[kk] - r_left[kk]
+            r6 = 6.0 * (r[kk] - 0.5 * (r_right[kk] + r_left[kk]))
+            if kk == L - 1:
+                r6 = 0.0 * r6
+            rst_m = r_left[kk] + 0.5 * cn_m * (rm + (1.0 - tt * cn_m) * r6)
+            flux[k] = wk * np.where(wk >= 0., rst_p, rst_m)
+        return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
+
+    def update_grid_tracer(self, tr_prev, tr_cur, dt_tr, u, v, wg, p_half, delta_t):
+        """update_tracers, 'grid' branch (spectral_dynamics.F90:1155-1180); returns (tr_cur filtered part A, tr_future)."""
+        tr_future = tr_prev + delta_t * dt_tr
+        dq = self.a_grid_horiz_advection(u, v, tr_future, delta_t, np.zeros_like(tr_future))
+        tr_future = tr_future + delta_t * dq
+        dp = p_half[1:] - p_half[:-1]
+        tr_future = tr_future + delta_t * self.vert_advection_ppm(delta_t, wg, dp, tr_future)
+        rc, raw = self.cfg.robert_coeff, self.cfg.raw_filter_coeff
+        part = tr_prev - 2.0 * tr_cur
+        tr_cur_new = tr_cur + rc * part * raw
+        return tr_cur_new, tr_future, part
 
     # convenience
     def state(self):

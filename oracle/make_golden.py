@@ -148,6 +148,7 @@ def golden_kernels(res, L, seed):
     inp["in_temp"] = 260.0 + 20.0 * rng.standard_normal(sh["grid"])
     wg = 0.05 * rng.standard_normal(sh["gridh"]); wg[0] = 0; wg[-1] = 0
     inp["in_wg"] = wg
+    inp["in_q"] = np.abs(1.0e-3 * (1.0 + rng.standard_normal(sh["grid"])))          # tracer-like positive field
     with tempfile.TemporaryDirectory(prefix="refk_") as d:
         prepare_rundir(d, res, L, "kernels", dt=600)
         for k, v in inp.items():
@@ -187,7 +188,7 @@ def main():
         "run_T21L25": lambda: golden_run(
             "T21", 25, 144, (2, 144),
             keep=lambda k: k.startswith("tab_") and k != "tab_legendre"
-            or re.match(r"st_(ug|vg|tg|psg)_(000002|000144)$", k) is not None),
+            or re.match(r"st_(ug|vg|tg|psg)_(000002|000144)$", k) is not None or k == "st_tr1_000144"),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }

@@ -40,7 +40,8 @@ use hs_forcing_mod,        only: hs_forcing_init, hs_forcing
 use implicit_mod,          only: implicit_correction
 use spectral_damping_mod,  only: compute_spectral_damping, compute_spectral_damping_vor, &
                                  compute_spectral_damping_div
-use vert_advection_mod,    only: vert_advection, SECOND_CENTERED, ADVECTIVE_FORM
+use vert_advection_mod,    only: vert_advection, SECOND_CENTERED, ADVECTIVE_FORM, FINITE_VOLUME_PARABOLIC
+use fv_advection_mod,      only: a_grid_horiz_advection
 use global_integral_mod,   only: mass_weighted_global_integral
 use leapfrog_mod,          only: leapfrog, leapfrog_2level_A, leapfrog_2level_B
 
@@ -348,6 +349,19 @@ do k=1,kk
 enddo
 call vert_advection(dtk, w, dp(:,:,1:kk), ge, gc, scheme=SECOND_CENTERED, form=ADVECTIVE_FORM)
 call dump3('out_vadv.bin', gc)
+! --- PPM vertical advection of a tracer-like field (vert_advection.F90:301-438) ---
+call read3('in_q.bin', ga)
+call vert_advection(dtk, w, dp(:,:,1:kk), ga, gc, scheme=FINITE_VOLUME_PARABOLIC, form=ADVECTIVE_FORM)
+call dump3('out_vadv_ppm.bin', gc)
+! --- van Leer horizontal advection on the sphere (fv_advection.F90:126-207), moderate and >1 Courant numbers ---
+call read3('in_grid_a.bin', gd); call read3('in_grid_b.bin', gb)
+gc = 0.
+call a_grid_horiz_advection(gd, gb, ga, dtk, gc)
+call dump3('out_hadv_fv.bin', gc)
+gc = 0.
+call a_grid_horiz_advection(gd, gb, ga, 40.*dtk, gc)
+call dump3('out_hadv_fv_bigcfl.bin', gc)
+call read3('in_grid_a.bin', ga)
 ! --- implicit correction (implicit.F90:241-286) ---
 allocate(s4a(ms:me,ns:ne,kk,2), s4b(ms:me,ns:ne,kk,2), s3lnps(ms:me,ns:ne,2))
 call readc3('in_spec_a.bin', s4a(:,:,:,1)); call readc3('in_spec_b.bin', s4a(:,:,:,2))

@@ -161,3 +161,29 @@ def test_trajectory_T21L25_one_day(golden_dir):
     assert abs(np.abs(s["ug"]).max() - umax) < 1e-9
     # SURVEY 8c anchors printed by the survey probe
     assert abs(tmin - 262.169090) < 1e-6 and abs(tmax - 272.371035) < 1e-6 and abs(umax - 1.148573) < 1e-6
+
+
+def test_tracer_kernels(kern):
+    """van Leer horizontal advection (fv_advection.F90:126-560, incl. Courant numbers > 1) and PPM vertical
+    advection (vert_advection.F90:301-438) of the grid tracer."""
+    g, sc = kern
+    ph, _, _, _ = sc.pressure_variables(g["in_ps"])
+    q = g["in_q"]
+    assert rel(sc.vert_advection_ppm(1200.0, g["in_wg"], ph[1:] - ph[:-1], q), g["out_vadv_ppm"]) < 1e-13
+    z = np.zeros_like(q)
+    assert rel(sc.a_grid_horiz_advection(g["in_grid_a"], g["in_grid_b"], q, 1200.0, z), g["out_hadv_fv"]) < 1e-13
+    assert rel(sc.a_grid_horiz_advection(g["in_grid_a"], g["in_grid_b"], q, 48000.0, z), g["out_hadv_fv_bigcfl"]) < 1e-13
+
+
+def test_tracer_trajectories(golden_dir):
+    g = np.load(os.path.join(golden_dir, "run_T10L8.npz"))
+    sc = core("T10", 8); sc.cold_start()
+    for i in range(1, 51):
+        sc.step()
+        if i in (1, 2, 3, 10, 50):
+            assert rel(sc.tr[sc.current], g[f"st_tr1_{i:06d}"]) < 1e-12
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    sc = core("T21", 25); sc.cold_start()
+    for i in range(144):
+        sc.step()
+    assert rel(sc.tr[sc.current], g["st_tr1_000144"]) < 1e-10
