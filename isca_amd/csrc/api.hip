@@ -310,8 +310,14 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (g.P == 1) { d.Ff_s = d.Ff_g; d.Fi_g = d.Fi_s; }
     else { d.Ff_s = dalloc<double>(h, nF); d.Fi_g = dalloc<double>(h, nF); }
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
-    d.partials = dalloc<double>(h, 8 * (ng2 / 64 + 1));
-    d.red = dalloc<double>(h, 16);
+    d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
+    d.red = dalloc<double>(h, 32);
+    d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
+    d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
+    d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2);
+    d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
+    d.fv_dyy = dupload(h, T.fv_dyy); d.fv_dyp = dupload(h, T.fv_dyp); d.fv_dym = dupload(h, T.fv_dym);
+    h->tracer_on = (cfg->num_tracers > 0) && (g.P == 1) && (g.L >= 4) && (16 * g.L <= 1024) && !getenv("ISCA_NO_TRACER");
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
@@ -319,7 +325,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     h->fuse_synth = (cfg->legendre_impl == 0) && (g.Jl % 16 == 0) && ((g.Jl & (g.Jl - 1)) == 0) &&
                     ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
-    h->kernels_per_step = h->fuse_synth ? 8 : 9;
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -458,6 +464,7 @@ static void cold_start_single(isca_dyn *h) {
   dcopy(h, d.lnps[1], d.lnps[0], ns2);
   std::vector<double> tr(ng3, h->cfg.initial_sphum);
   h2d(h, d.tr[0], tr.data(), ng3); h2d(h, d.tr[1], tr.data(), ng3);
+  h2d(h, d.tr_atm[0], tr.data(), ng3); h2d(h, d.tr_atm[1], tr.data(), ng3);
   HIP_CHECK(hipMemsetAsync(d.wg_full, 0, ng3 * sizeof(double), h->stream));
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true;
@@ -475,6 +482,8 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
   if (name == "vg") { count = ng3; return d.vg[tl]; }
   if (name == "tg") { count = ng3; return d.tg[tl]; }
   if (name == "tr") { count = ng3; return d.tr[tl]; }
+  if (name == "tr_atm") { count = ng3; return d.tr_atm[tl]; }
+  if (name == "trh") { count = ng3; return d.trh; }
   if (name == "psg") { count = ng2; return d.psg[tl]; }
   if (name == "vorg") { count = ng3; return d.vorg; }
   if (name == "divg") { count = ng3; return d.divg; }
@@ -583,6 +592,7 @@ static StepScalars step_scalars(isca_dyn *h) {
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
+  if (h->tracer_on) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); }
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
@@ -620,9 +630,9 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     // valid-range check (spectral_dynamics.F90:940-972) on demand: a NaN/blow-up shows in the fixer scalars
-    double red[16];
+    double red[32];
     HIP_CHECK(hipMemcpy(red, h->d.red, sizeof(red), hipMemcpyDeviceToHost));
-    if (!(std::isfinite(red[8]) && std::isfinite(red[9]))) fail("temperatures out of valid range (non-finite state)");
+    if (!(std::isfinite(red[16]) && std::isfinite(red[17]))) fail("temperatures out of valid range (non-finite state)");
   }
   API_END
 }
@@ -657,7 +667,7 @@ extern "C" int isca_dyn_exchange_buffers(isca_dyn_t *h, int which, void **send, 
 }
 extern "C" int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count) {
   API_BEGIN
-  *buf = h->d.red; *count = 5;
+  *buf = h->d.red; *count = 10;
   API_END
 }
 
@@ -723,9 +733,9 @@ extern "C" int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host,
       tmp[((size_t)w * L + k2) * L + k] = T.wave_matrix[((size_t)w * L + k) * L + k2];   // Fortran (k,k2,w)
     v = &tmp;
   } else if (nm == "fixer") {
-    tmp.resize(16);
+    tmp.resize(32);
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    HIP_CHECK(hipMemcpy(tmp.data(), h->d.red, 16 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(tmp.data(), h->d.red, 32 * sizeof(double), hipMemcpyDeviceToHost));
     v = &tmp;
   }
   if (!v) fail("unknown table " + nm);

@@ -62,6 +62,12 @@ struct Dev {
   double *ug[2], *vg[2], *tg[2], *psg[2], *tr[2];   // grid, two time levels
   double *vorg, *divg, *dxT, *dyT, *dxlp, *dylp;    // grid, at `current`
   double *wg_full;
+  double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
+  double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
+  double *trh;               // tracer after the horizontal van Leer step
+  int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit
+  double *wcol;              // [5][Jl][I] column sums for the water fixer
+  double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
   double *vors[2], *divs[2], *ts[2], *lnps[2];      // spectral [Ml][N1][L] complex ; lnps [Ml][N1]
   // ---- work
   double *g_dtu, *g_dtv, *g_dtT, *g_E, *g_dtlp;     // forward-batch grid inputs
@@ -105,5 +111,6 @@ struct isca_dyn {
   std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
   int n_active = 0;
   bool fuse_synth = false;
+  bool tracer_on = false;           // advect the grid tracer (single rank)
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
 };

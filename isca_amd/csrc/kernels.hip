@@ -937,7 +937,8 @@ struct ColumnArgs {
   const double *u, *v, *t, *ps;            // current
   const double *up, *vp, *tp, *psp;        // previous
   const double *vor, *div, *dxT, *dyT, *dxlp, *dylp;
-  double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials;
+  double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg;
+  int *kmask; double water_limit;
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -978,6 +979,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   double *lds_dm = (double *)smem;          // [NW][64] chunk sums of dmean
   double *lds_a = lds_dm + NW * 64;         // [NW][64] chunk sums of RDGAS*T*dlog3
   double *lds_e = lds_a + NW * 64;          // [NW] energy partials
+  int *lds_cnt = (int *)(lds_e + NW);       // [NW][64] levels with p_full < water_correction_limit
   const int col = blockIdx.x * 64 + tid;
   const int jl = col / I;
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
@@ -1043,6 +1045,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   double dmean_tot = base;
   double wg_k = (k0 == 0) ? 0.0 : (-base + total * a.bk[k0]);
   double e_prev = 0.0;
+  int nbelow = 0;
+  if (a.wg && w == 0) a.wg[c2] = 0.0;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     if (i < nk) {
@@ -1080,8 +1084,10 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double x5 = x4 - uc * x2 - vc * x3;
       dt_t = dt_t - KAPPA * tc * x5;
       a.wg_full[q] = -x5 * p_full;
+      nbelow += (p_full < a.water_limit) ? 1 : 0;
       dmean_tot = dmean_tot + dm[i];
       const double wg_n = (k + 1 < L) ? (-dmean_tot + total * a.bk[k + 1]) : 0.0;
+      if (a.wg) a.wg[q + lev] = wg_n;
       // ---- vert_advection SECOND_CENTERED / ADVECTIVE_FORM (vert_advection.F90:185-193, 467-470)
       const double ukm = (i == 0) ? um : u[i > 0 ? i - 1 : 0], vkm = (i == 0) ? vm : v[i > 0 ? i - 1 : 0], tkm = (i == 0) ? tm : t[i > 0 ? i - 1 : 0];
       const double ukp = (i == nk - 1) ? un : u[i + 1 < CH ? i + 1 : i], vkp = (i == nk - 1) ? vn : v[i + 1 < CH ? i + 1 : i], tkp = (i == nk - 1) ? tn : t[i + 1 < CH ? i + 1 : i];
@@ -1129,7 +1135,13 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     s_en += __shfl_down(s_en, off, 64);
   }
   if (tid == 0) lds_e[w] = s_en;
+  lds_cnt[w * 64 + tid] = nbelow;
   __syncthreads();
+  if (a.kmask && w == 0) {
+    int cnt = 0;
+    for (int ww = 0; ww < NW; ++ww) cnt += lds_cnt[ww * 64 + tid];
+    a.kmask[c2] = cnt;
+  }
   if (threadIdx.x == 0) {
     double e = 0.0;
     for (int ww = 0; ww < NW; ++ww) e += lds_e[ww];
@@ -1154,9 +1166,11 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
+  a.wg = h.cfg.num_tracers > 0 ? d.wg : nullptr; a.kmask = h.cfg.num_tracers > 0 ? d.kmask : nullptr;
+  a.water_limit = h.cfg.water_correction_limit;
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
-  const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double);
+  const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
 #define LC(N) hipLaunchKernelGGL(k_column<N>, grid, block, lds, s, g, a)
   switch (CH) {
@@ -1253,16 +1267,291 @@ void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStre
 }
 
 // =====================================================================================================
+// Grid tracer (sphum): update_tracers 'grid' branch (spectral_dynamics.F90:1155-1180)
+//   q0 = tr(prev) + dt * tracer_source_sink          (hs_forcing.F90:240-263, 683-724; sink on atmosphere_mod's copy)
+//   horizontal: a_grid_horiz_advection (fv_advection.F90:126-207): van Leer on the sphere with the
+//               semi-Lagrangian half-step predictors, polar mirror rows and integer Courant shifts in x
+//   vertical:   vert_advection PPM / advective form (vert_advection.F90:301-438, 467-470)
+// =====================================================================================================
+struct TracerArgs {
+  const double *ua, *va, *trp, *tratm_p, *ps_cur, *ps_prev, *wg;
+  double *trh, *tr_fut, *tr_cur;
+  const double *c, *cc, *dy, *dyy, *dyp, *dym, *dpk, *dbk, *wts;
+  const int *kmask;
+  double *wcol;
+  double dx, dt, flux, rdamp, robert;
+};
+
+__device__ __forceinline__ double tr_q0(const TracerArgs &a, const Geom &g, int k, size_t q, size_t c2) {
+  const double src = (k == g.L - 1) ? a.flux / (a.dpk[k] + a.dbk[k] * a.ps_cur[c2]) : 0.0;
+  return a.trp[q] + a.dt * (src - a.rdamp * a.tratm_p[q]);
+}
+__device__ __forceinline__ double vl_limit(double slope, double qm, double q0, double qp) {
+  const double q_min = fmin(fmin(qm, q0), qp), q_max = fmax(fmax(qm, q0), qp);
+  return copysign(1.0, slope) * fmin(fmin(fabs(slope), 2.0 * (q0 - q_min)), 2.0 * (q_max - q0));
+}
+
+// one block = one latitude row of one level, one thread per longitude (single rank: all rows are local)
+__global__ void k_tracer_horiz(Geom g, TracerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int I = g.I, J = g.J;
+  double *qs = (double *)smem;        // [5][I] q0 of the source rows of virtual rows j-2..j+2 (unshifted)
+  double *us = qs + 5 * I;            // [5][I] u of those rows
+  double *q1 = us + 5 * I;            // [5][I] q + semi_x(q) of those rows
+  double *vs = q1 + 5 * I;            // [3][I] v of rows j-1..j+1 (sign-flipped when mirrored)
+  double *q2 = vs + 3 * I;            // [I]
+  double *sx = q2 + I;                // [I]
+  double *fl = sx + I;                // [I]
+  __shared__ int any_big;
+  const int i = threadIdx.x, jg = blockIdx.x, k = blockIdx.y;
+  const size_t lev = (size_t)g.Jl * I;
+  int jsrc[5], sh[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int jv = jg + r - 2;
+    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I / 2; }
+    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I / 2; }
+    else { jsrc[r] = jv; sh[r] = 0; }
+    const size_t c2 = (size_t)jsrc[r] * I + i, q = (size_t)k * lev + c2;
+    qs[r * I + i] = tr_q0(a, g, k, q, c2);
+    us[r * I + i] = a.ua[q];
+    if (r >= 1 && r <= 3) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * a.va[q];
+  }
+  if (i == 0) any_big = 0;
+  __syncthreads();
+  const double hdt = 0.5 * a.dt;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {       // semi_x (:376-411) on each source row
+    const double b = us[r * I + i] * hdt / (a.dx * a.c[jsrc[r]]);
+    const double fb = floor(b);
+    int il = i - 1 - (int)fb;
+    if (il > I - 1) il -= I;
+    if (il < 0) il += I;
+    int ir = il + 1;
+    if (ir > I - 1) ir = 0;
+    const double bb = b - fb, qc = qs[r * I + i];
+    q1[r * I + i] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
+  }
+  const double q0c = qs[2 * I + i], va_c = vs[I + i];
+  const int im = (i == 0) ? I - 1 : i - 1, ip = (i == I - 1) ? 0 : i + 1;
+  // semi_y (:415-433)
+  {
+    const double qxm = qs[1 * I + ((i + sh[1]) % I)], qxp = qs[3 * I + ((i + sh[3]) % I)];
+    const double dq = (va_c >= 0.0) ? va_c * hdt * (qxm - q0c) / a.dyy[jg] : va_c * hdt * (q0c - qxp) / a.dyy[jg + 1];
+    q2[i] = q0c + dq;
+  }
+  const double vm = vs[0 * I + ((i + sh[1]) % I)], vp = vs[2 * I + ((i + sh[3]) % I)];
+  const double vc_lo = 0.5 * (vm + va_c), vc_hi = 0.5 * (va_c + vp);
+  const double uc_i = 0.5 * (us[2 * I + im] + us[2 * I + i]), uc_p = 0.5 * (us[2 * I + i] + us[2 * I + ip]);
+  const double cj = a.c[jg], dyj = a.dy[jg + 2];
+  double dq = q0c * ((vc_hi * a.cc[jg + 1] - vc_lo * a.cc[jg]) / (cj * dyj) + (uc_p - uc_i) / (cj * a.dx));
+  const double b = uc_i * a.dt / (a.dx * cj);
+  if (fabs(b) > 1.0) any_big = 1;
+  __syncthreads();
+  // vanleer_x (:308-347): slope_x, integer part of the Courant number, fractional van Leer flux
+  {
+    const double g0 = q2[i] - q2[im], g1 = q2[ip] - q2[i];
+    sx[i] = vl_limit((g1 + g0) / 2, q2[im], q2[i], q2[ip]);
+  }
+  double fx = 0.0;
+  if (any_big) {                     // integer_flux_x (:494-527), modular form
+    const int n_ = (int)b;
+    if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fx += q2[((i - t) % I + I) % I]; }
+    else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fx -= q2[(i + t) % I]; }
+  }
+  __syncthreads();
+  {
+    const double fb = floor(b), bb = b - trunc(b);
+    int ii = i - 1 - (int)fb;
+    if (ii > I - 1) ii -= I;
+    if (ii < 0) ii += I;
+    fl[i] = fx + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
+  }
+  __syncthreads();
+  dq = dq - (fl[ip] - fl[i]) / a.dt;
+  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
+  {
+    double Q[5], sl[3];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) Q[r] = q1[r * I + ((i + sh[r]) % I)];
+#pragma unroll
+    for (int r = 1; r <= 3; ++r) {
+      const int jf = jg + r - 1;     // Fortran row index j' = 0..J+1 of the virtual row
+      sl[r - 1] = vl_limit((Q[r + 1] - Q[r]) * a.dyp[jf] + (Q[r] - Q[r - 1]) * a.dym[jf], Q[r - 1], Q[r], Q[r + 1]);
+    }
+    double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (Q[1] + 0.5 * sl[0] * (1.0 - a.dt / a.dy[jg + 1] * vc_lo))
+                                 : vc_lo * a.cc[jg] * (Q[2] - 0.5 * sl[1] * (1.0 + a.dt / a.dy[jg + 2] * vc_lo));
+    double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (Q[2] + 0.5 * sl[1] * (1.0 - a.dt / a.dy[jg + 2] * vc_hi))
+                                 : vc_hi * a.cc[jg + 1] * (Q[3] - 0.5 * sl[2] * (1.0 + a.dt / a.dy[jg + 3] * vc_hi));
+    if (jg == 0) f_lo = 0.0;
+    if (jg == J - 1) f_hi = 0.0;
+    dq = dq - (1.0 / (dyj * cj)) * (f_hi - f_lo);
+  }
+  a.trh[(size_t)k * lev + (size_t)jg * I + i] = q0c + a.dt * dq;
+}
+
+// block = 16 columns x L levels (thread = one cell); PPM edge values, Colella-Woodward limiter, fluxes, the
+// advective-form tendency, then the Robert filter part A on the tracer and the column sums of the water fixer
+__global__ __launch_bounds__(1024) void k_tracer_vert(Geom g, TracerArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = g.L;
+  double *r_ = (double *)smem;            // [L][16]
+  double *dz = r_ + L * 16, *slp = dz + L * 16, *rl = slp + L * 16, *rr = rl + L * 16;
+  double *w_ = rr + L * 16;               // [L+1][16]
+  double *fx = w_ + (L + 1) * 16;         // [L+1][16]
+  double *acc = fx + (L + 1) * 16;        // [5][L][16]
+  const int cl = threadIdx.x & 15, k = threadIdx.x >> 4;
+  const size_t lev = (size_t)g.Jl * g.I;
+  const size_t c2 = (size_t)blockIdx.x * 16 + cl, q = (size_t)k * lev + c2;
+#define AT(arr, kk) arr[(kk) * 16 + cl]
+  const double ps = a.ps_cur[c2];
+  const double rk = a.trh[q];
+  AT(r_, k) = rk;
+  AT(dz, k) = a.dpk[k] + a.dbk[k] * ps;
+  AT(w_, k) = a.wg[q];
+  if (k == 0) AT(w_, L) = a.wg[(size_t)L * lev + c2];
+  __syncthreads();
+  {  // slope_z, limit=.true., linear=.false. (:505-568)
+    double s_ = 0.0;
+    if (k >= 1 && k <= L - 2) {
+      const double gk = (AT(r_, k) - AT(r_, k - 1)) / (AT(dz, k) + AT(dz, k - 1));
+      const double gp = (AT(r_, k + 1) - AT(r_, k)) / (AT(dz, k + 1) + AT(dz, k));
+      s_ = (gp * (2. * AT(dz, k - 1) + AT(dz, k)) + gk * (2. * AT(dz, k + 1) + AT(dz, k))) * AT(dz, k) /
+           (AT(dz, k - 1) + AT(dz, k) + AT(dz, k + 1));
+      const double rmin = fmin(fmin(AT(r_, k - 1), rk), AT(r_, k + 1)), rmax = fmax(fmax(AT(r_, k - 1), rk), AT(r_, k + 1));
+      s_ = copysign(1.0, s_) * fmin(fmin(fabs(s_), 2. * (rk - rmin)), 2. * (rmax - rk));
+    }
+    AT(slp, k) = s_;
+  }
+  __syncthreads();
+  {  // edge values (:304-336): interface value between k-1 and k for k = 2..L-2, linear near the boundaries
+    if (k >= 2 && k <= L - 2) {
+      const double d1 = 1.0 / (AT(dz, k - 1) + AT(dz, k));
+      const double d2 = 1.0 / (AT(dz, k - 2) + AT(dz, k - 1) + AT(dz, k) + AT(dz, k + 1));
+      const double d3 = 1.0 / (2 * AT(dz, k - 1) + AT(dz, k)), d4 = 1.0 / (AT(dz, k - 1) + 2 * AT(dz, k));
+      const double n3 = AT(dz, k - 2) + AT(dz, k - 1), n4 = AT(dz, k) + AT(dz, k + 1);
+      const double x = n3 * d3 - n4 * d4, y = 2.0 * AT(dz, k - 1) * AT(dz, k);
+      const double z0 = AT(dz, k - 1) * d1;
+      const double z1 = z0 + x * y * d1 * d2, z2 = AT(dz, k - 1) * n3 * d3 * d2, z3 = AT(dz, k) * n4 * d4 * d2;
+      const double e = AT(r_, k - 1) + z1 * (rk - AT(r_, k - 1)) - z2 * AT(slp, k) + z3 * AT(slp, k - 1);
+      AT(rl, k) = e;
+      AT(rr, k - 1) = e;
+    }
+    if (k == 1) AT(rl, 1) = rk - 0.5 * AT(slp, 1);
+    if (k == L - 2) AT(rr, L - 2) = rk + 0.5 * AT(slp, L - 2);
+    if (k == 0) { AT(rl, 0) = rk - 0.5 * AT(slp, 0); AT(rr, 0) = rk + 0.5 * AT(slp, 0); }
+    if (k == L - 1) { AT(rl, L - 1) = rk - 0.5 * AT(slp, L - 1); AT(rr, L - 1) = rk + 0.5 * AT(slp, L - 1); }
+  }
+  __syncthreads();
+  {  // Colella & Woodward (1984) limiter (:354-370)
+    double left = AT(rl, k), right = AT(rr, k);
+    if ((right - rk) * (rk - left) <= 0.0) { left = rk; right = rk; }
+    if (k != 0 && k != L - 1) {
+      const double rm = right - left;
+      const double aa = rm * (rk - 0.5 * (right + left)), bb = rm * rm / 6.;
+      if (aa > bb) left = 3.0 * rk - 2.0 * right;
+      if (aa < -bb) right = 3.0 * rk - 2.0 * left;
+    }
+    __syncthreads();
+    AT(rl, k) = left; AT(rr, k) = right;
+  }
+  __syncthreads();
+  {  // fluxes at the interfaces (:373-432), with the extension for Courant numbers > 1
+    const double tt = 2. / 3.;
+    double f = 0.0;
+    const double wk = AT(w_, k);
+    if (k == 0) { f = wk * rk; AT(fx, L) = AT(w_, L) * AT(r_, L - 1); }
+    else {
+      if (wk >= 0.) {
+        const double cn = a.dt * wk / AT(dz, k - 1);
+        int kk = k - 1;
+        double xx = cn, rsum = 0.;
+        if (cn > 1.) {
+          double dzsum = 0.;
+          const double dtw = a.dt * wk;
+          while (dzsum + AT(dz, kk) < dtw) { if (kk == 0) break; dzsum += AT(dz, kk); rsum += AT(r_, kk); kk -= 1; }
+          xx = (dtw - dzsum) / AT(dz, kk);
+        }
+        const double rm = AT(rr, kk) - AT(rl, kk);
+        double r6 = 6.0 * (AT(r_, kk) - 0.5 * (AT(rr, kk) + AT(rl, kk)));
+        if (kk == 0) r6 = 0.;
+        double rst = AT(rr, kk) - 0.5 * xx * (rm - (1.0 - tt * xx) * r6);
+        if (cn > 1.) rst = (xx * rst + rsum) / cn;
+        f = wk * rst;
+      } else {
+        const double cn = -a.dt * wk / AT(dz, k);
+        int kk = k;
+        double xx = cn, rsum = 0.;
+        if (cn > 1.) {
+          double dzsum = 0.;
+          const double dtw = -a.dt * wk;
+          while (dzsum + AT(dz, kk) < dtw) { if (kk == 0) break; dzsum += AT(dz, kk); rsum += AT(r_, kk); kk += 1; }
+          xx = (dtw - dzsum) / AT(dz, kk);
+        }
+        const double rm = AT(rr, kk) - AT(rl, kk);
+        double r6 = 6.0 * (AT(r_, kk) - 0.5 * (AT(rr, kk) + AT(rl, kk)));
+        if (kk == L - 1) r6 = 0.;
+        double rst = AT(rl, kk) + 0.5 * xx * (rm + (1.0 - tt * xx) * r6);
+        if (cn > 1.) rst = (xx * rst + rsum) / cn;
+        f = wk * rst;
+      }
+    }
+    AT(fx, k) = f;
+  }
+  __syncthreads();
+  const double rdt = -(AT(fx, k + 1) - AT(fx, k) - rk * (AT(w_, k + 1) - AT(w_, k))) / AT(dz, k);
+  const double trf = rk + a.dt * rdt;
+  // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): read everything before writing
+  const double q0 = tr_q0(a, g, k, q, c2);
+  const double tp = a.trp[q], tc = a.tr_cur[q];
+  a.tr_cur[q] = tc + a.robert * (tp - 2.0 * tc);      // leapfrog part A on the grid tracer (:1164-1167)
+  a.tr_fut[q] = trf;
+  // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
+  const int km = a.kmask[c2];
+  const double msk = (k >= km) ? 1.0 : 0.0;
+  acc[(0 * L + k) * 16 + cl] = q0 * (a.dpk[k] + a.dbk[k] * a.ps_prev[c2]);
+  acc[(1 * L + k) * 16 + cl] = trf * a.dpk[k];
+  acc[(2 * L + k) * 16 + cl] = trf * a.dbk[k];
+  acc[(3 * L + k) * 16 + cl] = msk * trf * a.dpk[k];
+  acc[(4 * L + k) * 16 + cl] = msk * trf * a.dbk[k];
+  __syncthreads();
+  if (k < 5) {
+    double s_ = 0.0;
+    for (int kk = 0; kk < L; ++kk) s_ += acc[(k * L + kk) * 16 + cl];
+    a.wcol[(size_t)k * lev + c2] = s_;
+  }
+#undef AT
+}
+
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  TracerArgs a;
+  a.ua = d.ug[sc.cur]; a.va = d.vg[sc.cur]; a.trp = d.tr[sc.prev]; a.tratm_p = d.tr_atm[sc.prev];
+  a.ps_cur = d.psg[sc.cur]; a.ps_prev = d.psg[sc.prev]; a.wg = d.wg;
+  a.trh = d.trh; a.tr_fut = d.tr[sc.fut]; a.tr_cur = d.tr[sc.cur];
+  a.c = d.fv_c; a.cc = d.fv_cc; a.dy = d.fv_dy; a.dyy = d.fv_dyy; a.dyp = d.fv_dyp; a.dym = d.fv_dym;
+  a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.wcol = d.wcol;
+  a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
+  a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
+  a.robert = h.cfg.robert_coeff;
+  hipLaunchKernelGGL(k_tracer_horiz, dim3(g.Jl, g.L), dim3(g.I), (size_t)21 * g.I * sizeof(double), s, g, a);
+  const size_t lds = (size_t)((5 + 2 + 5) * g.L + 2) * 16 * sizeof(double);
+  hipLaunchKernelGGL(k_tracer_vert, dim3((unsigned)((size_t)g.Jl * g.I / 16)), dim3(16 * g.L), lds, s, g, a);
+}
+
+// =====================================================================================================
 // Mass / energy fixers (spectral_dynamics.F90:1213-1302; global_integral.F90:49-81; transforms.F90:1059-1077)
 //   red[0..1]  local sums of the column kernel: w*ps(prev), w*E(prev)
 //   red[2..4]  local sums of the new state:     w*ps(fut), w*sum_k e_k dpk_k, w*sum_k e_k dbk_k ps(fut)
-//   red[8]     mass_correction_factor, red[9] temperature_correction
+//   red[16] mass_correction_factor, red[17] temperature_correction, red[18] water_correction_factor
 // =====================================================================================================
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH) {
+                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH,
+                                                    const double *__restrict__ wcol) {
   __shared__ double red[2][8];
   const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int col = blockIdx.x * 64 + tid;
@@ -1287,84 +1576,109 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   }
   if (tid == 0) { red[0][w] = s1; red[1][w] = s2; }
   __syncthreads();
+  // water fixer column sums left by the tracer kernel (wave 0 only): before, after (dpk part, dbk*ps part), masked
+  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+  if (wcol && w == 0) {
+    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
+  }
+  if (w == 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
+    }
+  }
   if (threadIdx.x == 0) {
     double a1 = 0.0, a2 = 0.0;
     for (int ww = 0; ww < NW; ++ww) { a1 += red[0][ww]; a2 += red[1][ww]; }
-    partials[3 * blockIdx.x] = s0; partials[3 * blockIdx.x + 1] = a1; partials[3 * blockIdx.x + 2] = a2;
+    double *p = partials + 8 * (size_t)blockIdx.x;
+    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4;
   }
 }
-// red[0..1] <- sums of the column kernel's partials (2 per block), red[2..4] <- sums of k_fixer_sums' (3 per block)
-__global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                                      double *__restrict__ red) {
-  __shared__ double sh[5][256];
-  double acc[5] = {0., 0., 0., 0., 0.};
+constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
+__device__ __forceinline__ void fixer_block_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                   double (*sh)[256]) {
+  double acc[NRED];
+#pragma unroll
+  for (int c = 0; c < NRED; ++c) acc[c] = 0.;
   for (int i = threadIdx.x; i < nb; i += 256) {
     acc[0] += pprev[2 * i]; acc[1] += pprev[2 * i + 1];
-    acc[2] += pfut[3 * i]; acc[3] += pfut[3 * i + 1]; acc[4] += pfut[3 * i + 2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[2 + c] += pfut[8 * i + c];
   }
-  for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] = acc[c];
+#pragma unroll
+  for (int c = 0; c < NRED; ++c) sh[c][threadIdx.x] = acc[c];
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
     if ((int)threadIdx.x < off)
-      for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
+#pragma unroll
+      for (int c = 0; c < NRED; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x < 5) red[threadIdx.x] = sh[threadIdx.x][0];
+}
+// red[0..1] <- sums of the column kernel's partials (2 per block), red[2..9] <- sums of k_fixer_sums' (8 per block)
+__global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                      double *__restrict__ red) {
+  __shared__ double sh[NRED][256];
+  fixer_block_reduce(pprev, pfut, nb, sh);
+  if (threadIdx.x < NRED) red[threadIdx.x] = sh[threadIdx.x][0];
 }
 struct FixerArgs {
   double *red;
-  const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 3 per block (k_fixer_sums)
+  const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
   int nb;
   double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
   double *psg, *tg;
+  double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
+  const int *kmask;
   int ml0;                 // local slot of m = 0, or -1
   double sumw_nlon;        // global_sum_of_wts * num_lon
   double robert;
-  int do_mass, do_energy, reduce_here;
+  int do_mass, do_energy, do_water, reduce_here;
 };
 // Every block reduces the block partials itself in the same fixed order (deterministic, identical in all blocks),
-// derives the two fixer scalars and applies them to its slice of psg / tg; block 0 also patches the (0,0)
+// derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0)
 // spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
-// With several ranks the host all-reduces red[0..4] first (reduce_here = 0).
+// With several ranks the host all-reduces red[0..9] first (reduce_here = 0).
+// Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
 __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
-  __shared__ double sh[5][256];
-  __shared__ double sc[2];
+  __shared__ double sh[NRED][256];
+  __shared__ double sc[3];
   if (a.reduce_here) {
-    double acc[5] = {0., 0., 0., 0., 0.};
-    for (int i = threadIdx.x; i < a.nb; i += 256) {
-      acc[0] += a.pprev[2 * i]; acc[1] += a.pprev[2 * i + 1];
-      acc[2] += a.pfut[3 * i]; acc[3] += a.pfut[3 * i + 1]; acc[4] += a.pfut[3 * i + 2];
-    }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] = acc[c];
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-      if ((int)threadIdx.x < off)
-#pragma unroll
-        for (int c = 0; c < 5; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
-      __syncthreads();
-    }
+    fixer_block_reduce(a.pprev, a.pfut, a.nb, sh);
   } else {
-    if (threadIdx.x < 5) sh[threadIdx.x][0] = a.red[threadIdx.x];
+    if (threadIdx.x < NRED) sh[threadIdx.x][0] = a.red[threadIdx.x];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     const double mean_ps_prev = sh[0][0] / a.sumw_nlon;
     const double mean_en_prev = sh[1][0] / a.sumw_nlon / GRAV;
-    double factor = 1.0, tcorr = 0.0;
+    double factor = 1.0, tcorr = 0.0, wfac = 1.0;
     if (a.do_mass) factor = mean_ps_prev / (sh[2][0] / a.sumw_nlon);
     if (a.do_energy) {
       const double mean_en_tmp = (sh[3][0] + factor * sh[4][0]) / a.sumw_nlon / GRAV;
       tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
     }
-    sc[0] = factor; sc[1] = tcorr;
+    if (a.do_water && a.tr_fut) {       // compute_corrections :1245-1283 (with mj's correction limit)
+      const double nrm = 1.0 / a.sumw_nlon / GRAV;
+      const double water_prev = sh[5][0] * nrm;
+      const double water_tmp = (sh[6][0] + factor * sh[7][0]) * nrm;
+      const double corr = (sh[8][0] + factor * sh[9][0]) * nrm;
+      const double notc = water_tmp - corr;
+      if (water_tmp > 0.) {
+        wfac = water_prev / water_tmp;
+        wfac = wfac * (1. + notc / corr) - notc / corr;
+      }
+    }
+    sc[0] = factor; sc[1] = tcorr; sc[2] = wfac;
     if (blockIdx.x == 0) {
-      for (int c = 0; c < 5; ++c) a.red[c] = sh[c][0];
-      a.red[8] = factor; a.red[9] = tcorr;
+      for (int c = 0; c < NRED; ++c) a.red[c] = sh[c][0];
+      a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
     }
   }
   __syncthreads();
-  const double factor = sc[0], tcorr = sc[1];
+  const double factor = sc[0], tcorr = sc[1], wfac = sc[2];
   if (blockIdx.x == 0 && a.ml0 >= 0) {
     const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
     const double s2 = sqrt(2.);
@@ -1384,6 +1698,15 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n3; i += (size_t)gridDim.x * 512) {
     if (i < lev) { double2 p = *(double2 *)(a.psg + i); p.x *= factor; p.y *= factor; *(double2 *)(a.psg + i) = p; }
     double2 t = *(double2 *)(a.tg + i); t.x += tcorr; t.y += tcorr; *(double2 *)(a.tg + i) = t;
+    if (a.tr_fut) {   // water factor where p_full >= limit, then leapfrog part B (:1484) and atmosphere_mod's copy (:1028)
+      const int k = (int)(i / lev);
+      const size_t c2 = i - (size_t)k * lev;
+      double2 f = *(double2 *)(a.tr_fut + i), c = *(double2 *)(a.tr_cur + i);
+      if (k >= a.kmask[c2]) f.x *= wfac;
+      if (k >= a.kmask[c2 + 1]) f.y *= wfac;
+      c.x += a.robert * f.x; c.y += a.robert * f.y;
+      *(double2 *)(a.tr_fut + i) = f; *(double2 *)(a.tr_cur + i) = c; *(double2 *)(a.tratm_fut + i) = f;
+    }
   }
 }
 
@@ -1393,7 +1716,8 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const int nb = (int)column_partials_count(h);
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH);
+  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
+                     h.tracer_on ? d.wcol : (const double *)nullptr);
   if (g.P > 1)   // the host all-reduces red[0..4] between the phases
     hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
@@ -1405,6 +1729,8 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
   a.psg = h.d.psg[sc.fut]; a.tg = h.d.tg[sc.fut];
+  a.tr_fut = h.tracer_on ? h.d.tr[sc.fut] : nullptr; a.tr_cur = h.d.tr[sc.cur]; a.tratm_fut = h.d.tr_atm[sc.fut];
+  a.kmask = h.d.kmask; a.do_water = h.cfg.do_water_correction;
   a.ml0 = h.ml_of_m0;
   double sumw = 0.0;
   for (double w : h.tab.wts_lat) sumw += w;

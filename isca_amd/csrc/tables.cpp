@@ -265,6 +265,28 @@ void Tables::build(const isca_dyn_config &c) {
   tks = (c.ks < 0.) ? -1. / (86400 * c.ks) : c.ks;
   vkf = (c.kf < 0.) ? -1. / (86400 * c.kf) : c.kf;
   trsink_s = (c.trsink < 0.) ? -86400. * c.trsink : c.trsink;
+  // --- fv_advection_init (fv_advection.F90:58-120) with the cell boundaries of transforms.F90:313-321
+  {
+    std::vector<double> yy(J + 1), y(J);
+    yy[0] = -.5 * PI;
+    double sum_wts = 0.;
+    for (int j = 0; j < J - 1; ++j) { sum_wts = sum_wts + wts_lat[j]; yy[j + 1] = std::asin(sum_wts - 1.); }
+    yy[J] = .5 * PI;
+    fv_c.resize(J); fv_cc.resize(J + 1); fv_dy.assign(J + 4, 0.0); fv_dyy.assign(J + 1, 0.0);
+    fv_dyp.resize(J + 2); fv_dym.resize(J + 2);
+    for (int j = 0; j < J; ++j) { y[j] = 0.5 * (yy[j + 1] + yy[j]); fv_c[j] = std::cos(y[j]); }
+    for (int j = 0; j <= J; ++j) fv_cc[j] = std::cos(yy[j]);
+    auto dyF = [&](int j) -> double & { return fv_dy[j + 1]; };      // Fortran index j = -1..J+2
+    for (int j = 1; j <= J; ++j) dyF(j) = yy[j] - yy[j - 1];
+    dyF(-1) = dyF(2); dyF(0) = dyF(1); dyF(J + 1) = dyF(J); dyF(J + 2) = dyF(J - 1);
+    for (int j = 2; j <= J; ++j) fv_dyy[j - 1] = y[j - 1] - y[j - 2];
+    fv_dyy[0] = 2 * (y[0] - yy[0]);
+    fv_dyy[J] = 2 * (yy[J] - y[J - 1]);
+    for (int j = 0; j <= J + 1; ++j) { fv_dyp[j] = dyF(j) / (dyF(j) + dyF(j + 1)); fv_dym[j] = dyF(j) / (dyF(j - 1) + dyF(j)); }
+    for (auto &v : fv_dy) v = v * RADIUS;
+    for (auto &v : fv_dyy) v = v * RADIUS;
+    fv_dx = 2.0 * PI * RADIUS / (double)I;
+  }
   // --- FFT twiddles
   tw_re.resize(I); tw_im.resize(I);
   for (int k = 0; k < I; ++k) {

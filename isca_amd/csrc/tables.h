@@ -32,6 +32,10 @@ struct Tables {
   double wave_dt = -1.0, xi = 0.0;
   // hs
   double tka, tks, vkf, trsink_s;
+  // fv_advection_init (model/fv_advection.F90:58-120): c[J], cc[J+1], dy[J+4] (Fortran dy(j) = dy[j+1]),
+  // dyy[J+1] (dyy(j) = dyy[j-1]), dy_plus/minus[J+2] (index j = 0..J+1), dx
+  std::vector<double> fv_c, fv_cc, fv_dy, fv_dyy, fv_dyp, fv_dym;
+  double fv_dx;
   // FFT twiddles exp(-2 pi i k / I), k < I/2
   std::vector<double> tw_re, tw_im;
 

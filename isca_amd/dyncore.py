@@ -212,7 +212,7 @@ class DynCore:
     def table(self, name: str):
         n = {"sin_lat": self.J, "wts_lat": self.J, "deg_lat": self.J, "deg_lon": self.I, "pk": self.L + 1,
              "bk": self.L + 1, "legendre": (self.J // 2) * self.N1 * self.M1, "eigen_laplacian": self.N1 * self.M1,
-             "sin_hem": self.J // 2, "wts_hem": self.J // 2, "fixer": 16,
+             "sin_hem": self.J // 2, "wts_hem": self.J // 2, "fixer": 32,
              "wave_matrix": self.cfg.num_spherical * self.L * self.L}[name]
         a = np.zeros(n)
         self._check(self.lib.isca_dyn_get_table(self._h, name.encode(), _dptr(a), a.size))

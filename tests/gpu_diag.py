@@ -102,7 +102,7 @@ def run(res, L, impl, nsteps=12):
             check(f"step{i} vors", st["vors"], so["vors"], 1e-9)
             check(f"step{i} divs(abs)", st["divs"], so["divs"], 1e-16, True)
             fx = dc.table("fixer")
-            print(f"     fixer factor-1={fx[8]-1:.3e} tcorr={fx[9]:.3e}")
+            print(f"     fixer factor-1={fx[16]-1:.3e} tcorr={fx[17]:.3e} water={fx[18]-1:.3e}")
     t0 = time.time(); dc.step(50, True); t1 = time.time()
     print(f"  timing: {1e3*(t1-t0)/50:.3f} ms/step (eager, host-inclusive)")
     dc.kernel_times(True); dc.step(20, True)

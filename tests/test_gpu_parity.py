@@ -72,6 +72,7 @@ def test_golden_trajectory_T10L8(golden_dir):
         assert rel(s["vors"], g[f"st_vors_{tag}"]) < 1e-10
         assert rel(dc.get("wg_full"), g[f"st_wg_full_{tag}"]) < (1e-9 if i > 1 else 1.0)
         assert rel(dc.get("p_full"), g[f"st_p_full_{tag}"]) < 1e-12 and rel(dc.get("z_full"), g[f"st_z_full_{tag}"]) < 1e-12
+        assert rel(dc.get("tr"), g[f"st_tr1_{tag}"]) < 1e-11          # grid tracer: van Leer + PPM + water fixer
     dc.close()
 
 
@@ -85,6 +86,7 @@ def test_golden_T21L25_one_day(golden_dir):
     dc.step(142)
     for k in ("ug", "vg", "tg", "psg"):
         assert rel(dc.get(k), g[f"st_{k}_000144"]) < 1e-9, k      # stated 1-day tolerance
+    assert rel(dc.get("tr"), g["st_tr1_000144"]) < 1e-9
     tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
     t, u = dc.get("tg"), dc.get("ug")
     assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
@@ -125,6 +127,7 @@ def test_T42L25_steps_vs_oracle():
     for k in ("tg", "psg", "ts", "ln_ps"):
         assert rel(st[k], so[k]) < 1e-11, k
     assert rel(st["vors"], so["vors"]) < 1e-9
+    assert rel(dc.get("tr"), sc.tr[sc.current]) < 1e-10 and rel(dc.get("tr", 0), sc.tr[sc.previous]) < 1e-10
     # developed-state intermediates of step 37 (phase API): grid tendencies and spectral tendencies
     sc.step()
     dc.step_phase(0); dc.step_phase(1)
