@@ -33,18 +33,19 @@ struct Timed {
   isca_dyn *h;
   int id = -1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  Timed(isca_dyn *h_, const char *name) : h(h_) {
+  hipStream_t st;
+  Timed(isca_dyn *h_, const char *name, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream) {
     if (!h->timer.enabled) return;
     auto &t = h->timer;
     for (size_t i = 0; i < t.names.size(); ++i)
       if (t.names[i] == name) id = (int)i;
     if (id < 0) { id = (int)t.names.size(); t.names.push_back(name); t.ms.push_back(0); t.calls.push_back(0); }
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, h->stream);
+    hipEventRecord(e0, st);
   }
   ~Timed() {
     if (id < 0) return;
-    hipEventRecord(e1, h->stream);
+    hipEventRecord(e1, st);
     h->timer.ev.push_back(e0); h->timer.ev.push_back(e1); h->timer.ev_name.push_back(id);
   }
 };
@@ -52,6 +53,7 @@ static void timer_collect(isca_dyn *h) {
   auto &t = h->timer;
   if (t.ev.empty()) return;
   hipStreamSynchronize(h->stream);
+  if (h->stream2) hipStreamSynchronize(h->stream2);
   for (size_t i = 0; i < t.ev_name.size(); ++i) {
     float ms = 0;
     hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]);
@@ -165,6 +167,9 @@ extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   if (!h) return 0;
   timer_collect(h);
   for (void *p : h->allocs) hipFree(p);
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -314,7 +319,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.red = dalloc<double>(h, 32);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
-    d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2);
+    d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
     d.fv_dyy = dupload(h, T.fv_dyy); d.fv_dyp = dupload(h, T.fv_dyp); d.fv_dym = dupload(h, T.fv_dym);
     h->tracer_on = (cfg->num_tracers > 0) && (g.P == 1) && (g.L >= 4) && (16 * g.L <= 1024) && !getenv("ISCA_NO_TRACER");
@@ -592,7 +600,12 @@ static StepScalars step_scalars(isca_dyn *h) {
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
-  if (h->tracer_on) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); }
+  if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
+    HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
+    HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
+    HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
+  }
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
@@ -608,6 +621,7 @@ static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, s
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
+  if (h->tracer_on) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation

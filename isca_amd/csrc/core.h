@@ -65,6 +65,7 @@ struct Dev {
   double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
   double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
   double *trh;               // tracer after the horizontal van Leer step
+  double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit
   double *wcol;              // [5][Jl][I] column sums for the water fixer
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
@@ -97,6 +98,8 @@ struct isca_dyn {
   isca::Dev d;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t stream2 = nullptr;    // grid-tracer transport runs here, concurrently with the spectral pipeline
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int previous = 0, current = 0;
   long step_count = 0;
   bool have_state = false;

@@ -937,7 +937,7 @@ struct ColumnArgs {
   const double *u, *v, *t, *ps;            // current
   const double *up, *vp, *tp, *psp;        // previous
   const double *vor, *div, *dxT, *dyT, *dxlp, *dylp;
-  double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg;
+  double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg, *psp_copy;
   int *kmask; double water_limit;
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   double wg_k = (k0 == 0) ? 0.0 : (-base + total * a.bk[k0]);
   double e_prev = 0.0;
   int nbelow = 0;
-  if (a.wg && w == 0) a.wg[c2] = 0.0;
+  if (a.wg && w == 0) { a.wg[c2] = 0.0; a.psp_copy[c2] = psp; }
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     if (i < nk) {
@@ -1166,7 +1166,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
-  a.wg = h.cfg.num_tracers > 0 ? d.wg : nullptr; a.kmask = h.cfg.num_tracers > 0 ? d.kmask : nullptr;
+  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
@@ -1528,7 +1528,7 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
   TracerArgs a;
   a.ua = d.ug[sc.cur]; a.va = d.vg[sc.cur]; a.trp = d.tr[sc.prev]; a.tratm_p = d.tr_atm[sc.prev];
-  a.ps_cur = d.psg[sc.cur]; a.ps_prev = d.psg[sc.prev]; a.wg = d.wg;
+  a.ps_cur = d.psg[sc.cur]; a.ps_prev = d.psp_copy; a.wg = d.wg;   // psg(prev) storage is rewritten by the synthesis running concurrently
   a.trh = d.trh; a.tr_fut = d.tr[sc.fut]; a.tr_cur = d.tr[sc.cur];
   a.c = d.fv_c; a.cc = d.fv_cc; a.dy = d.fv_dy; a.dyy = d.fv_dyy; a.dyp = d.fv_dyp; a.dym = d.fv_dym;
   a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.wcol = d.wcol;
