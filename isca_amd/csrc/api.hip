@@ -325,7 +325,35 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
     d.fv_dyy = dupload(h, T.fv_dyy); d.fv_dyp = dupload(h, T.fv_dyp); d.fv_dym = dupload(h, T.fv_dym);
-    h->tracer_on = (cfg->num_tracers > 0) && (g.P == 1) && (g.L >= 4) && (16 * g.L <= 1024) && !getenv("ISCA_NO_TRACER");
+    {
+      const int J = g.J;
+      std::vector<double> rcdx(J), rdyy(J + 1), rcdy(J), rdy(J + 4), ppm((size_t)6 * g.L, 0.0);
+      for (int j = 0; j < J; ++j) { rcdx[j] = 1.0 / (T.fv_dx * T.fv_c[j]); rcdy[j] = 1.0 / (T.fv_dy[j + 2] * T.fv_c[j]); }
+      for (int j = 0; j <= J; ++j) rdyy[j] = 1.0 / T.fv_dyy[j];
+      for (int j = 0; j < J + 4; ++j) rdy[j] = 1.0 / T.fv_dy[j];
+      // slope_z (vert_advection.F90:525-531) and compute_weights (:604-619) with dz = dbk (pk = 0: ps cancels)
+      const std::vector<double> &dz = T.dbk;
+      const int L = g.L;
+      for (int k = 1; k <= L - 2; ++k) {
+        const double f = dz[k] / (dz[k - 1] + dz[k] + dz[k + 1]);
+        ppm[0 * L + k] = (2. * dz[k - 1] + dz[k]) / (dz[k + 1] + dz[k]) * f;
+        ppm[1 * L + k] = (2. * dz[k + 1] + dz[k]) / (dz[k] + dz[k - 1]) * f;
+      }
+      for (int k = 2; k <= L - 2; ++k) {
+        const double d1 = 1.0 / (dz[k - 1] + dz[k]), d2 = 1.0 / (dz[k - 2] + dz[k - 1] + dz[k] + dz[k + 1]);
+        const double d3 = 1.0 / (2 * dz[k - 1] + dz[k]), d4 = 1.0 / (dz[k - 1] + 2 * dz[k]);
+        const double n3 = dz[k - 2] + dz[k - 1], n4 = dz[k] + dz[k + 1];
+        const double x = n3 * d3 - n4 * d4, y = 2.0 * dz[k - 1] * dz[k];
+        const double z0 = dz[k - 1] * d1;
+        ppm[2 * L + k] = z0 + x * y * d1 * d2; ppm[3 * L + k] = dz[k - 1] * n3 * d3 * d2; ppm[4 * L + k] = dz[k] * n4 * d4 * d2;
+      }
+      d.fv_rcdx = dupload(h, rcdx); d.fv_rdyy = dupload(h, rdyy); d.fv_rcdy = dupload(h, rcdy); d.fv_rdy = dupload(h, rdy);
+      d.ppm_tab = dupload(h, ppm);
+    }
+    h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr;
+    bool pure_sigma = true;
+    for (double v : T.pk) if (v != 0.0) pure_sigma = false;
+    h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.P == 1) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
@@ -601,10 +629,14 @@ static StepScalars step_scalars(isca_dyn *h) {
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
-    HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
-    HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-    { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
-    HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
+    if (h->tracer_serial) {
+      Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream);
+    } else {
+      HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
+      HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+      { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
+      HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
+    }
   }
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
@@ -621,7 +653,7 @@ static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, s
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
-  if (h->tracer_on) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation

@@ -69,6 +69,8 @@ struct Dev {
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit
   double *wcol;              // [5][Jl][I] column sums for the water fixer
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
+  double *fv_rcdx, *fv_rdyy, *fv_rcdy, *fv_rdy;              // reciprocals used by the kernels
+  double *ppm_tab;           // [6][L] pure-sigma PPM slope / edge weights
   double *vors[2], *divs[2], *ts[2], *lnps[2];      // spectral [Ml][N1][L] complex ; lnps [Ml][N1]
   // ---- work
   double *g_dtu, *g_dtv, *g_dtT, *g_E, *g_dtlp;     // forward-batch grid inputs
@@ -114,6 +116,7 @@ struct isca_dyn {
   std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
   int n_active = 0;
   bool fuse_synth = false;
+  bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_on = false;           // advect the grid tracer (single rank)
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
 };

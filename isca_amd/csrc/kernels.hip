@@ -1277,6 +1277,8 @@ struct TracerArgs {
   const double *ua, *va, *trp, *tratm_p, *ps_cur, *ps_prev, *wg;
   double *trh, *tr_fut, *tr_cur;
   const double *c, *cc, *dy, *dyy, *dyp, *dym, *dpk, *dbk, *wts;
+  const double *rcdx, *rdyy, *rcdy, *rdy;   // 1/(dx c(j)), 1/dyy, 1/(c(j) dy(j)), 1/dy  (same index conventions)
+  const double *ppm;                         // [6][L] pure-sigma PPM weights: slope A,B ; edge z1,z2,z3 ; (unused)
   const int *kmask;
   double *wcol;
   double dx, dt, flux, rdamp, robert;
@@ -1291,236 +1293,292 @@ __device__ __forceinline__ double vl_limit(double slope, double qm, double q0, d
   return copysign(1.0, slope) * fmin(fmin(fabs(slope), 2.0 * (q0 - q_min)), 2.0 * (q_max - q0));
 }
 
-// one block = one latitude row of one level, one thread per longitude (single rank: all rows are local)
+// one block = RB consecutive latitude rows of one level, one thread per longitude (lon_max = 2^p; single rank:
+// all rows are local).  RB+4 source rows are staged once (q0, u, q + semi_x(q)), RB+2 rows of v.
+constexpr int TR_RB = 4;
 __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int I = g.I, J = g.J;
-  double *qs = (double *)smem;        // [5][I] q0 of the source rows of virtual rows j-2..j+2 (unshifted)
-  double *us = qs + 5 * I;            // [5][I] u of those rows
-  double *q1 = us + 5 * I;            // [5][I] q + semi_x(q) of those rows
-  double *vs = q1 + 5 * I;            // [3][I] v of rows j-1..j+1 (sign-flipped when mirrored)
-  double *q2 = vs + 3 * I;            // [I]
+  constexpr int RB = TR_RB, NR = RB + 4;
+  const int I = g.I, J = g.J, IM = I - 1;
+  double *qs = (double *)smem;        // [NR][I] q0 of the source rows of virtual rows j0-2..j0+RB+1 (unshifted)
+  double *us = qs + NR * I;           // [NR][I] u of those rows
+  double *q1 = us + NR * I;           // [NR][I] q + semi_x(q) of those rows
+  double *vs = q1 + NR * I;           // [RB+2][I] v of rows j0-1..j0+RB (sign-flipped when mirrored)
+  double *q2 = vs + (RB + 2) * I;     // [I]
   double *sx = q2 + I;                // [I]
   double *fl = sx + I;                // [I]
-  __shared__ int any_big;
-  const int i = threadIdx.x, jg = blockIdx.x, k = blockIdx.y;
+  __shared__ int any_big[RB];
+  const int i = threadIdx.x, j0 = blockIdx.x * RB, k = blockIdx.y;
   const size_t lev = (size_t)g.Jl * I;
-  int jsrc[5], sh[5];
+  int jsrc[NR], sh[NR];
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const int jv = jg + r - 2;
-    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I / 2; }
-    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I / 2; }
+  for (int r = 0; r < NR; ++r) {
+    const int jv = j0 + r - 2;
+    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I >> 1; }
+    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I >> 1; }
     else { jsrc[r] = jv; sh[r] = 0; }
     const size_t c2 = (size_t)jsrc[r] * I + i, q = (size_t)k * lev + c2;
     qs[r * I + i] = tr_q0(a, g, k, q, c2);
     us[r * I + i] = a.ua[q];
-    if (r >= 1 && r <= 3) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * a.va[q];
+    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * a.va[q];
   }
-  if (i == 0) any_big = 0;
+  if (i < RB) any_big[i] = 0;
   __syncthreads();
   const double hdt = 0.5 * a.dt;
 #pragma unroll
-  for (int r = 0; r < 5; ++r) {       // semi_x (:376-411) on each source row
-    const double b = us[r * I + i] * hdt / (a.dx * a.c[jsrc[r]]);
+  for (int r = 0; r < NR; ++r) {      // semi_x (:376-411) on each source row
+    const double b = us[r * I + i] * hdt * a.rcdx[jsrc[r]];
     const double fb = floor(b);
-    int il = i - 1 - (int)fb;
-    if (il > I - 1) il -= I;
-    if (il < 0) il += I;
-    int ir = il + 1;
-    if (ir > I - 1) ir = 0;
+    const int il = (i - 1 - (int)fb) & IM, ir = (il + 1) & IM;
     const double bb = b - fb, qc = qs[r * I + i];
     q1[r * I + i] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
   }
-  const double q0c = qs[2 * I + i], va_c = vs[I + i];
-  const int im = (i == 0) ? I - 1 : i - 1, ip = (i == I - 1) ? 0 : i + 1;
-  // semi_y (:415-433)
-  {
-    const double qxm = qs[1 * I + ((i + sh[1]) % I)], qxp = qs[3 * I + ((i + sh[3]) % I)];
-    const double dq = (va_c >= 0.0) ? va_c * hdt * (qxm - q0c) / a.dyy[jg] : va_c * hdt * (q0c - qxp) / a.dyy[jg + 1];
-    q2[i] = q0c + dq;
-  }
-  const double vm = vs[0 * I + ((i + sh[1]) % I)], vp = vs[2 * I + ((i + sh[3]) % I)];
-  const double vc_lo = 0.5 * (vm + va_c), vc_hi = 0.5 * (va_c + vp);
-  const double uc_i = 0.5 * (us[2 * I + im] + us[2 * I + i]), uc_p = 0.5 * (us[2 * I + i] + us[2 * I + ip]);
-  const double cj = a.c[jg], dyj = a.dy[jg + 2];
-  double dq = q0c * ((vc_hi * a.cc[jg + 1] - vc_lo * a.cc[jg]) / (cj * dyj) + (uc_p - uc_i) / (cj * a.dx));
-  const double b = uc_i * a.dt / (a.dx * cj);
-  if (fabs(b) > 1.0) any_big = 1;
-  __syncthreads();
-  // vanleer_x (:308-347): slope_x, integer part of the Courant number, fractional van Leer flux
-  {
-    const double g0 = q2[i] - q2[im], g1 = q2[ip] - q2[i];
-    sx[i] = vl_limit((g1 + g0) / 2, q2[im], q2[i], q2[ip]);
-  }
-  double fx = 0.0;
-  if (any_big) {                     // integer_flux_x (:494-527), modular form
-    const int n_ = (int)b;
-    if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fx += q2[((i - t) % I + I) % I]; }
-    else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fx -= q2[(i + t) % I]; }
-  }
-  __syncthreads();
-  {
-    const double fb = floor(b), bb = b - trunc(b);
-    int ii = i - 1 - (int)fb;
-    if (ii > I - 1) ii -= I;
-    if (ii < 0) ii += I;
-    fl[i] = fx + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
-  }
-  __syncthreads();
-  dq = dq - (fl[ip] - fl[i]) / a.dt;
-  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
-  {
-    double Q[5], sl[3];
+  const int im = (i - 1) & IM, ip = (i + 1) & IM;
+  double bx[RB];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) Q[r] = q1[r * I + ((i + sh[r]) % I)];
-#pragma unroll
-    for (int r = 1; r <= 3; ++r) {
-      const int jf = jg + r - 1;     // Fortran row index j' = 0..J+1 of the virtual row
-      sl[r - 1] = vl_limit((Q[r + 1] - Q[r]) * a.dyp[jf] + (Q[r] - Q[r - 1]) * a.dym[jf], Q[r - 1], Q[r], Q[r + 1]);
-    }
-    double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (Q[1] + 0.5 * sl[0] * (1.0 - a.dt / a.dy[jg + 1] * vc_lo))
-                                 : vc_lo * a.cc[jg] * (Q[2] - 0.5 * sl[1] * (1.0 + a.dt / a.dy[jg + 2] * vc_lo));
-    double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (Q[2] + 0.5 * sl[1] * (1.0 - a.dt / a.dy[jg + 2] * vc_hi))
-                                 : vc_hi * a.cc[jg + 1] * (Q[3] - 0.5 * sl[2] * (1.0 + a.dt / a.dy[jg + 3] * vc_hi));
-    if (jg == 0) f_lo = 0.0;
-    if (jg == J - 1) f_hi = 0.0;
-    dq = dq - (1.0 / (dyj * cj)) * (f_hi - f_lo);
-  }
-  a.trh[(size_t)k * lev + (size_t)jg * I + i] = q0c + a.dt * dq;
-}
-
-// block = 16 columns x L levels (thread = one cell); PPM edge values, Colella-Woodward limiter, fluxes, the
-// advective-form tendency, then the Robert filter part A on the tracer and the column sums of the water fixer
-__global__ __launch_bounds__(1024) void k_tracer_vert(Geom g, TracerArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int L = g.L;
-  double *r_ = (double *)smem;            // [L][16]
-  double *dz = r_ + L * 16, *slp = dz + L * 16, *rl = slp + L * 16, *rr = rl + L * 16;
-  double *w_ = rr + L * 16;               // [L+1][16]
-  double *fx = w_ + (L + 1) * 16;         // [L+1][16]
-  double *acc = fx + (L + 1) * 16;        // [5][L][16]
-  const int cl = threadIdx.x & 15, k = threadIdx.x >> 4;
-  const size_t lev = (size_t)g.Jl * g.I;
-  const size_t c2 = (size_t)blockIdx.x * 16 + cl, q = (size_t)k * lev + c2;
-#define AT(arr, kk) arr[(kk) * 16 + cl]
-  const double ps = a.ps_cur[c2];
-  const double rk = a.trh[q];
-  AT(r_, k) = rk;
-  AT(dz, k) = a.dpk[k] + a.dbk[k] * ps;
-  AT(w_, k) = a.wg[q];
-  if (k == 0) AT(w_, L) = a.wg[(size_t)L * lev + c2];
-  __syncthreads();
-  {  // slope_z, limit=.true., linear=.false. (:505-568)
-    double s_ = 0.0;
-    if (k >= 1 && k <= L - 2) {
-      const double gk = (AT(r_, k) - AT(r_, k - 1)) / (AT(dz, k) + AT(dz, k - 1));
-      const double gp = (AT(r_, k + 1) - AT(r_, k)) / (AT(dz, k + 1) + AT(dz, k));
-      s_ = (gp * (2. * AT(dz, k - 1) + AT(dz, k)) + gk * (2. * AT(dz, k + 1) + AT(dz, k))) * AT(dz, k) /
-           (AT(dz, k - 1) + AT(dz, k) + AT(dz, k + 1));
-      const double rmin = fmin(fmin(AT(r_, k - 1), rk), AT(r_, k + 1)), rmax = fmax(fmax(AT(r_, k - 1), rk), AT(r_, k + 1));
-      s_ = copysign(1.0, s_) * fmin(fmin(fabs(s_), 2. * (rk - rmin)), 2. * (rmax - rk));
-    }
-    AT(slp, k) = s_;
+  for (int rr = 0; rr < RB; ++rr) {   // Courant numbers of the x fluxes, block-wide flag for the integer part
+    const int r = rr + 2;
+    bx[rr] = 0.5 * (us[r * I + im] + us[r * I + i]) * a.dt * a.rcdx[j0 + rr];
+    if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
   }
   __syncthreads();
-  {  // edge values (:304-336): interface value between k-1 and k for k = 2..L-2, linear near the boundaries
-    if (k >= 2 && k <= L - 2) {
-      const double d1 = 1.0 / (AT(dz, k - 1) + AT(dz, k));
-      const double d2 = 1.0 / (AT(dz, k - 2) + AT(dz, k - 1) + AT(dz, k) + AT(dz, k + 1));
-      const double d3 = 1.0 / (2 * AT(dz, k - 1) + AT(dz, k)), d4 = 1.0 / (AT(dz, k - 1) + 2 * AT(dz, k));
-      const double n3 = AT(dz, k - 2) + AT(dz, k - 1), n4 = AT(dz, k) + AT(dz, k + 1);
-      const double x = n3 * d3 - n4 * d4, y = 2.0 * AT(dz, k - 1) * AT(dz, k);
-      const double z0 = AT(dz, k - 1) * d1;
-      const double z1 = z0 + x * y * d1 * d2, z2 = AT(dz, k - 1) * n3 * d3 * d2, z3 = AT(dz, k) * n4 * d4 * d2;
-      const double e = AT(r_, k - 1) + z1 * (rk - AT(r_, k - 1)) - z2 * AT(slp, k) + z3 * AT(slp, k - 1);
-      AT(rl, k) = e;
-      AT(rr, k - 1) = e;
+  for (int rr = 0; rr < RB; ++rr) {
+    const int r = rr + 2, jg = j0 + rr;
+    if (jg >= J) break;
+    const double q0c = qs[r * I + i], va_c = vs[(rr + 1) * I + i];
+    {  // semi_y (:415-433)
+      const double qxm = qs[(r - 1) * I + ((i + sh[r - 1]) & IM)], qxp = qs[(r + 1) * I + ((i + sh[r + 1]) & IM)];
+      q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (qxm - q0c) * a.rdyy[jg] : va_c * hdt * (q0c - qxp) * a.rdyy[jg + 1]);
     }
-    if (k == 1) AT(rl, 1) = rk - 0.5 * AT(slp, 1);
-    if (k == L - 2) AT(rr, L - 2) = rk + 0.5 * AT(slp, L - 2);
-    if (k == 0) { AT(rl, 0) = rk - 0.5 * AT(slp, 0); AT(rr, 0) = rk + 0.5 * AT(slp, 0); }
-    if (k == L - 1) { AT(rl, L - 1) = rk - 0.5 * AT(slp, L - 1); AT(rr, L - 1) = rk + 0.5 * AT(slp, L - 1); }
-  }
-  __syncthreads();
-  {  // Colella & Woodward (1984) limiter (:354-370)
-    double left = AT(rl, k), right = AT(rr, k);
-    if ((right - rk) * (rk - left) <= 0.0) { left = rk; right = rk; }
-    if (k != 0 && k != L - 1) {
-      const double rm = right - left;
-      const double aa = rm * (rk - 0.5 * (right + left)), bb = rm * rm / 6.;
-      if (aa > bb) left = 3.0 * rk - 2.0 * right;
-      if (aa < -bb) right = 3.0 * rk - 2.0 * left;
+    const double vm = vs[rr * I + ((i + sh[r - 1]) & IM)], vp = vs[(rr + 2) * I + ((i + sh[r + 1]) & IM)];
+    const double vc_lo = 0.5 * (vm + va_c), vc_hi = 0.5 * (va_c + vp);
+    const double uc_i = 0.5 * (us[r * I + im] + us[r * I + i]), uc_p = 0.5 * (us[r * I + i] + us[r * I + ip]);
+    const double rcdy = a.rcdy[jg];
+    double dq = q0c * ((vc_hi * a.cc[jg + 1] - vc_lo * a.cc[jg]) * rcdy + (uc_p - uc_i) * a.rcdx[jg]);
+    const double b = bx[rr];
+    __syncthreads();
+    // vanleer_x (:308-347): slope_x, integer part of the Courant number, fractional van Leer flux
+    sx[i] = vl_limit(((q2[ip] - q2[i]) + (q2[i] - q2[im])) / 2, q2[im], q2[i], q2[ip]);
+    double fxi = 0.0;
+    if (any_big[rr]) {               // integer_flux_x (:494-527), modular form
+      const int n_ = (int)b;
+      if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fxi += q2[(i - t) & IM]; }
+      else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fxi -= q2[(i + t) & IM]; }
     }
     __syncthreads();
-    AT(rl, k) = left; AT(rr, k) = right;
+    {
+      const double bb = b - trunc(b);
+      const int ii = (i - 1 - (int)floor(b)) & IM;
+      fl[i] = fxi + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
+    }
+    __syncthreads();
+    dq = dq - (fl[ip] - fl[i]) * (1.0 / a.dt);
+    {  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
+      double Q[5], sl[3];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) Q[t] = q1[(rr + t) * I + ((i + sh[rr + t]) & IM)];
+#pragma unroll
+      for (int t = 1; t <= 3; ++t) {
+        const int jf = jg + t - 1;     // Fortran row index j' = 0..J+1 of the virtual row
+        sl[t - 1] = vl_limit((Q[t + 1] - Q[t]) * a.dyp[jf] + (Q[t] - Q[t - 1]) * a.dym[jf], Q[t - 1], Q[t], Q[t + 1]);
+      }
+      double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (Q[1] + 0.5 * sl[0] * (1.0 - a.dt * a.rdy[jg + 1] * vc_lo))
+                                   : vc_lo * a.cc[jg] * (Q[2] - 0.5 * sl[1] * (1.0 + a.dt * a.rdy[jg + 2] * vc_lo));
+      double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (Q[2] + 0.5 * sl[1] * (1.0 - a.dt * a.rdy[jg + 2] * vc_hi))
+                                   : vc_hi * a.cc[jg + 1] * (Q[3] - 0.5 * sl[2] * (1.0 + a.dt * a.rdy[jg + 3] * vc_hi));
+      if (jg == 0) f_lo = 0.0;
+      if (jg == J - 1) f_hi = 0.0;
+      dq = dq - rcdy * (f_hi - f_lo);
+    }
+    a.trh[(size_t)k * lev + (size_t)jg * I + i] = q0c + a.dt * dq;
   }
-  __syncthreads();
-  {  // fluxes at the interfaces (:373-432), with the extension for Courant numbers > 1
-    const double tt = 2. / 3.;
-    double f = 0.0;
-    const double wk = AT(w_, k);
-    if (k == 0) { f = wk * rk; AT(fx, L) = AT(w_, L) * AT(r_, L - 1); }
-    else {
-      if (wk >= 0.) {
-        const double cn = a.dt * wk / AT(dz, k - 1);
-        int kk = k - 1;
-        double xx = cn, rsum = 0.;
-        if (cn > 1.) {
-          double dzsum = 0.;
-          const double dtw = a.dt * wk;
-          while (dzsum + AT(dz, kk) < dtw) { if (kk == 0) break; dzsum += AT(dz, kk); rsum += AT(r_, kk); kk -= 1; }
-          xx = (dtw - dzsum) / AT(dz, kk);
-        }
-        const double rm = AT(rr, kk) - AT(rl, kk);
-        double r6 = 6.0 * (AT(r_, kk) - 0.5 * (AT(rr, kk) + AT(rl, kk)));
-        if (kk == 0) r6 = 0.;
-        double rst = AT(rr, kk) - 0.5 * xx * (rm - (1.0 - tt * xx) * r6);
-        if (cn > 1.) rst = (xx * rst + rsum) / cn;
-        f = wk * rst;
-      } else {
-        const double cn = -a.dt * wk / AT(dz, k);
-        int kk = k;
-        double xx = cn, rsum = 0.;
-        if (cn > 1.) {
-          double dzsum = 0.;
-          const double dtw = -a.dt * wk;
-          while (dzsum + AT(dz, kk) < dtw) { if (kk == 0) break; dzsum += AT(dz, kk); rsum += AT(r_, kk); kk += 1; }
-          xx = (dtw - dzsum) / AT(dz, kk);
-        }
-        const double rm = AT(rr, kk) - AT(rl, kk);
-        double r6 = 6.0 * (AT(r_, kk) - 0.5 * (AT(rr, kk) + AT(rl, kk)));
-        if (kk == L - 1) r6 = 0.;
-        double rst = AT(rl, kk) + 0.5 * xx * (rm + (1.0 - tt * xx) * r6);
-        if (cn > 1.) rst = (xx * rst + rsum) / cn;
-        f = wk * rst;
+}
+
+// PPM reconstruction of one cell from the column values around it (slope_z :505-568 with limiters, non-linear
+// weights; edge values :304-336; Colella-Woodward limiter :354-370).  rv[0..6] = r(k-3..k+3), dv likewise.
+__device__ __forceinline__ double ppm_slope(const double *rv, const double *dv, int k, int L) {   // rv/dv centred at index 0 -> cell k
+  if (k < 1 || k > L - 2) return 0.0;
+  const double gk = (rv[0] - rv[-1]) / (dv[0] + dv[-1]), gp = (rv[1] - rv[0]) / (dv[1] + dv[0]);
+  double s_ = (gp * (2. * dv[-1] + dv[0]) + gk * (2. * dv[1] + dv[0])) * dv[0] / (dv[-1] + dv[0] + dv[1]);
+  const double rmin = fmin(fmin(rv[-1], rv[0]), rv[1]), rmax = fmax(fmax(rv[-1], rv[0]), rv[1]);
+  return copysign(1.0, s_) * fmin(fmin(fabs(s_), 2. * (rv[0] - rmin)), 2. * (rmax - rv[0]));
+}
+__device__ __forceinline__ double ppm_edge(const double *rv, const double *dv, double slp_k, double slp_km1) {
+  // interface between cells k-1 and k (valid for 2 <= k <= L-2); rv/dv centred at cell k
+  const double d1 = 1.0 / (dv[-1] + dv[0]), d2 = 1.0 / (dv[-2] + dv[-1] + dv[0] + dv[1]);
+  const double d3 = 1.0 / (2 * dv[-1] + dv[0]), d4 = 1.0 / (dv[-1] + 2 * dv[0]);
+  const double n3 = dv[-2] + dv[-1], n4 = dv[0] + dv[1];
+  const double x = n3 * d3 - n4 * d4, y = 2.0 * dv[-1] * dv[0];
+  const double z0 = dv[-1] * d1, z1 = z0 + x * y * d1 * d2, z2 = dv[-1] * n3 * d3 * d2, z3 = dv[0] * n4 * d4 * d2;
+  return rv[-1] + z1 * (rv[0] - rv[-1]) - z2 * slp_k + z3 * slp_km1;
+}
+// limited (r_left, r_right) of cell k; rv/dv centred at cell k, valid offsets -3..+3 where inside the column
+__device__ __forceinline__ void ppm_cell(const double *rv, const double *dv, int k, int L, double &left, double &right) {
+  const double sk = ppm_slope(rv, dv, k, L);
+  const double rk = rv[0];
+  // left edge = interface (k-1,k), right edge = interface (k,k+1)
+  if (k >= 2 && k <= L - 2) left = ppm_edge(rv, dv, sk, ppm_slope(rv - 1, dv - 1, k - 1, L));
+  else left = rk - 0.5 * sk;                       // k = 0, 1, L-1 : linear (slope is 0 at the two ends)
+  if (k + 1 >= 2 && k + 1 <= L - 2) right = ppm_edge(rv + 1, dv + 1, ppm_slope(rv + 1, dv + 1, k + 1, L), sk);
+  else right = rk + 0.5 * sk;                      // k = 0, L-2, L-1
+  if ((right - rk) * (rk - left) <= 0.0) { left = rk; right = rk; }
+  if (k != 0 && k != L - 1) {
+    const double rm = right - left;
+    const double aa = rm * (rk - 0.5 * (right + left)), bb = rm * rm / 6.;
+    if (aa > bb) left = 3.0 * rk - 2.0 * right;
+    if (aa < -bb) right = 3.0 * rk - 2.0 * left;
+  }
+}
+// same for an arbitrary cell, reading the column from global memory (only for vertical Courant numbers > 1)
+__device__ void ppm_cell_global(const TracerArgs &a, const Geom &g, size_t c2, double ps, int kk, double &rc, double &left, double &right) {
+  const size_t lev = (size_t)g.Jl * g.I;
+  double rv[7], dv[7];
+  for (int t = -3; t <= 3; ++t) {
+    const int kc = min(max(kk + t, 0), g.L - 1);
+    rv[t + 3] = a.trh[(size_t)kc * lev + c2];
+    dv[t + 3] = a.dpk[kc] + a.dbk[kc] * ps;
+  }
+  rc = rv[3];
+  ppm_cell(rv + 3, dv + 3, kk, g.L, left, right);
+}
+
+// Block = 64 columns x NW wavefronts, wavefront w owns levels [w*CH, w*CH+CH) like the column kernel; every thread
+// reconstructs its CH+2 cells from CH+8 column values held in registers (no LDS, no barriers in the main part).
+// Pure sigma coordinates (pk = 0, the only vertical coordinate supported): dz = dbk*ps, so the slope and edge
+// weights of slope_z / compute_weights are independent of the column and come from the host table a.ppm.
+template <int CH>
+__global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
+  __shared__ double red[5][8][64];
+  const int L = g.L;
+  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const size_t lev = (size_t)g.Jl * g.I;
+  const size_t c2 = (size_t)blockIdx.x * 64 + tid;
+  const int k0 = w * CH, nk = min(CH, L - k0);
+  const double ps = a.ps_cur[c2];
+  constexpr int NV = CH + 8;                     // cells k0-4 .. k0+CH+3
+  double rv[NV], dv[NV];
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int kc = min(max(k0 - 4 + t, 0), L - 1);
+    rv[t] = a.trh[(size_t)kc * lev + c2];
+    dv[t] = a.dpk[kc] + a.dbk[kc] * ps;
+  }
+  double wv[CH + 1];
+#pragma unroll
+  for (int t = 0; t <= CH; ++t) wv[t] = a.wg[(size_t)min(k0 + t, L) * lev + c2];
+  // limited slopes of cells k0-2 .. k0+CH+1 (rv index t+2), once each
+  double sl[CH + 4];
+#pragma unroll
+  for (int t = 0; t < CH + 4; ++t) {
+    const int kc = k0 - 2 + t;
+    double s_ = 0.0;
+    if (kc >= 1 && kc <= L - 2) {
+      const double rm1 = rv[t + 1], r0 = rv[t + 2], rp1 = rv[t + 3];
+      s_ = a.ppm[0 * L + kc] * (rp1 - r0) + a.ppm[1 * L + kc] * (r0 - rm1);
+      const double rmin = fmin(fmin(rm1, r0), rp1), rmax = fmax(fmax(rm1, r0), rp1);
+      s_ = copysign(1.0, s_) * fmin(fmin(fabs(s_), 2. * (r0 - rmin)), 2. * (rmax - r0));
+    }
+    sl[t] = s_;
+  }
+  // edge values at interfaces k0-1 .. k0+CH+1 (interface kc lies between cells kc-1 and kc), once each
+  double ed[CH + 3];
+#pragma unroll
+  for (int t = 0; t < CH + 3; ++t) {
+    const int kc = k0 - 1 + t;                    // cell kc = rv index t+3, slope index t+1
+    double e = 0.0;
+    if (kc >= 2 && kc <= L - 2)
+      e = rv[t + 2] + a.ppm[2 * L + kc] * (rv[t + 3] - rv[t + 2]) - a.ppm[3 * L + kc] * sl[t + 1] + a.ppm[4 * L + kc] * sl[t];
+    ed[t] = e;
+  }
+  // limited parabolas of cells k0-1 .. k0+CH
+  double rl[CH + 2], rr[CH + 2];
+#pragma unroll
+  for (int t = 0; t < CH + 2; ++t) {
+    const int kc = k0 - 1 + t;
+    double left = 0., right = 0.;
+    if (kc >= 0 && kc < L) {
+      const double rk = rv[t + 3], sk = sl[t + 1];
+      left = (kc >= 2 && kc <= L - 2) ? ed[t] : rk - 0.5 * sk;
+      right = (kc + 1 >= 2 && kc + 1 <= L - 2) ? ed[t + 1] : rk + 0.5 * sk;
+      if ((right - rk) * (rk - left) <= 0.0) { left = rk; right = rk; }
+      if (kc != 0 && kc != L - 1) {
+        const double rm = right - left;
+        const double aa = rm * (rk - 0.5 * (right + left)), bb = rm * rm / 6.;
+        if (aa > bb) left = 3.0 * rk - 2.0 * right;
+        if (aa < -bb) right = 3.0 * rk - 2.0 * left;
       }
     }
-    AT(fx, k) = f;
+    rl[t] = left; rr[t] = right;
   }
-  __syncthreads();
-  const double rdt = -(AT(fx, k + 1) - AT(fx, k) - rk * (AT(w_, k + 1) - AT(w_, k))) / AT(dz, k);
-  const double trf = rk + a.dt * rdt;
-  // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): read everything before writing
-  const double q0 = tr_q0(a, g, k, q, c2);
-  const double tp = a.trp[q], tc = a.tr_cur[q];
-  a.tr_cur[q] = tc + a.robert * (tp - 2.0 * tc);      // leapfrog part A on the grid tracer (:1164-1167)
-  a.tr_fut[q] = trf;
-  // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
+  // fluxes at interfaces k0 .. k0+CH (:373-432)
+  double fx[CH + 1];
+  const double tt = 2. / 3.;
+#pragma unroll
+  for (int t = 0; t <= CH; ++t) {
+    const int k = k0 + t;
+    const double wk = wv[t];
+    double f = 0.0;
+    if (k <= 0) f = wk * rv[4];                               // flux(ks) = w(ks) r(ks)
+    else if (k >= L) f = wk * rv[4 + (L - 1 - k0)];           // flux(ke+1) = w(ke+1) r(ke)
+    else if (t <= nk) {
+      const bool up = wk >= 0.;
+      const int kk = up ? k - 1 : k;                          // donor cell; local index kk-(k0-1) = t or t+1
+      const int lt = up ? t : t + 1;
+      const double cn = (up ? a.dt * wk : -a.dt * wk) / dv[3 + lt];
+      double rc = rv[3 + lt], left = rl[lt], right = rr[lt], xx = cn, rsum = 0.;
+      int kd = kk;
+      if (cn > 1.) {                                          // extension for Courant numbers > 1 (:385-396, :410-421)
+        double dzsum = 0.;
+        const double dtw = up ? a.dt * wk : -a.dt * wk;
+        double dzk = dv[3 + lt];
+        while (dzsum + dzk < dtw) {
+          if (kd == 0) break;                                 // the reference stops at kk == 1 (up) / ks (down)
+          dzsum += dzk; rsum += a.trh[(size_t)kd * lev + c2];
+          kd += up ? -1 : 1;
+          dzk = a.dpk[kd] + a.dbk[kd] * ps;
+        }
+        xx = (dtw - dzsum) / dzk;
+        if (kd != kk) ppm_cell_global(a, g, c2, ps, kd, rc, left, right);
+      }
+      const double rm = right - left;
+      double r6 = 6.0 * (rc - 0.5 * (right + left));
+      if (up ? (kd == 0) : (kd == L - 1)) r6 = 0.;
+      double rst = up ? right - 0.5 * xx * (rm - (1.0 - tt * xx) * r6) : left + 0.5 * xx * (rm + (1.0 - tt * xx) * r6);
+      if (cn > 1.) rst = (xx * rst + rsum) / cn;
+      f = wk * rst;
+    }
+    fx[t] = f;
+  }
   const int km = a.kmask[c2];
-  const double msk = (k >= km) ? 1.0 : 0.0;
-  acc[(0 * L + k) * 16 + cl] = q0 * (a.dpk[k] + a.dbk[k] * a.ps_prev[c2]);
-  acc[(1 * L + k) * 16 + cl] = trf * a.dpk[k];
-  acc[(2 * L + k) * 16 + cl] = trf * a.dbk[k];
-  acc[(3 * L + k) * 16 + cl] = msk * trf * a.dpk[k];
-  acc[(4 * L + k) * 16 + cl] = msk * trf * a.dbk[k];
-  __syncthreads();
-  if (k < 5) {
-    double s_ = 0.0;
-    for (int kk = 0; kk < L; ++kk) s_ += acc[(k * L + kk) * 16 + cl];
-    a.wcol[(size_t)k * lev + c2] = s_;
+  const double psp = a.ps_prev[c2];
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    if (t < nk) {
+      const int k = k0 + t;
+      const size_t q = (size_t)k * lev + c2;
+      const double rk = rv[4 + t];
+      const double rdt = -(fx[t + 1] - fx[t] - rk * (wv[t + 1] - wv[t])) / dv[4 + t];
+      const double trf = rk + a.dt * rdt;
+      // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): read everything before writing
+      const double q0 = tr_q0(a, g, k, q, c2);
+      const double tp = a.trp[q], tc = a.tr_cur[q];
+      a.tr_cur[q] = tc + a.robert * (tp - 2.0 * tc);      // leapfrog part A on the grid tracer (:1164-1167)
+      a.tr_fut[q] = trf;
+      // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
+      const double msk = (k >= km) ? 1.0 : 0.0;
+      s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
+      s1 += trf * a.dpk[k]; s2 += trf * a.dbk[k];
+      s3 += msk * trf * a.dpk[k]; s4 += msk * trf * a.dbk[k];
+    }
   }
-#undef AT
+  red[0][w][tid] = s0; red[1][w][tid] = s1; red[2][w][tid] = s2; red[3][w][tid] = s3; red[4][w][tid] = s4;
+  __syncthreads();
+  if (w < 5) {
+    double s_ = 0.0;
+    for (int ww = 0; ww < NW; ++ww) s_ += red[w][ww][tid];
+    a.wcol[(size_t)w * lev + c2] = s_;
+  }
 }
 
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -1532,12 +1590,20 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.trh = d.trh; a.tr_fut = d.tr[sc.fut]; a.tr_cur = d.tr[sc.cur];
   a.c = d.fv_c; a.cc = d.fv_cc; a.dy = d.fv_dy; a.dyy = d.fv_dyy; a.dyp = d.fv_dyp; a.dym = d.fv_dym;
   a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.wcol = d.wcol;
+  a.rcdx = d.fv_rcdx; a.rdyy = d.fv_rdyy; a.rcdy = d.fv_rcdy; a.rdy = d.fv_rdy; a.ppm = d.ppm_tab;
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
   a.robert = h.cfg.robert_coeff;
-  hipLaunchKernelGGL(k_tracer_horiz, dim3(g.Jl, g.L), dim3(g.I), (size_t)21 * g.I * sizeof(double), s, g, a);
-  const size_t lds = (size_t)((5 + 2 + 5) * g.L + 2) * 16 * sizeof(double);
-  hipLaunchKernelGGL(k_tracer_vert, dim3((unsigned)((size_t)g.Jl * g.I / 16)), dim3(16 * g.L), lds, s, g, a);
+  const size_t ldsh = (size_t)(3 * (TR_RB + 4) + (TR_RB + 2) + 3) * g.I * sizeof(double);
+  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+  const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums
+  const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64)), block(64 * NW);
+#define LT(N) hipLaunchKernelGGL(k_tracer_vert<N>, grid, block, 0, s, g, a)
+  switch (CH) {
+    case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
+    case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
+  }
+#undef LT
 }
 
 // =====================================================================================================
