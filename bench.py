@@ -105,7 +105,13 @@ def main():
     I, J, M1, N = core.I, core.J, core.M1, core.cfg.num_fourier
     field_bytes = 8.0 * I * J * L
     # algorithmic bytes/flops per launch (DESIGN.md "Kernels")
-    col_bytes = 14.0 * field_bytes                                   # column kernel: ~14 L-level field passes
+    col_bytes = 14.0 * field_bytes                                   # column kernel: ~14 L-level field passes (SURVEY 8d)
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 per the
+    # gfx950 correction, calibrated on this kernel's known byte count, + WRITE_SIZE); see profiles/README.md
+    traffic = {}
+    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and a.workload == "T85L40":
+        traffic = json.load(open(tpath)).get("bytes_per_launch", {})
     leg_flops_lf = J * (N + 1) * (N + 4)                             # per level-field
     kern = {}
     if "column" in kt:
@@ -117,22 +123,23 @@ def main():
         if nm in kt:
             b = nlf * (8.0 * I * J + 16.0 * M1 * J)                  # one grid pass + one truncated Fourier pass
             kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": b / (kt[nm] * 1e-3) / 1e9}
-    dom = max(kt, key=kt.get) if kt else None
+    kt_main = {k: v for k, v in kt.items() if k != "tracer"}        # "tracer" spans two kernels on the side stream
+    dom = max(kt_main, key=kt_main.get) if kt_main else None
     roof = None
     if dom == "column" or dom not in kern:
         c = kern.get("column")
         if c:
             roof = {"kernel": "k_column", "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": col_bytes,
-                    "avg_launch_ms": c["ms"]}
+                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic.get("k_column"),
+                    "algorithmic_bytes_per_launch": col_bytes, "avg_launch_ms": c["ms"]}
     else:
         c = kern[dom]
         if c["bound"] == "mfma":
             roof = {"kernel": dom, "bound": "mfma", "achieved": c["achieved_TFs"], "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": c["achieved_TFs"] / FP64_MFMA_PEAK_TF, "traffic": None, "avg_launch_ms": c["ms"]}
+                    "frac": c["achieved_TFs"] / FP64_MFMA_PEAK_TF, "traffic": traffic.get(dom), "avg_launch_ms": c["ms"]}
         else:
             roof = {"kernel": dom, "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": c["ms"]}
+                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic.get(dom), "avg_launch_ms": c["ms"]}
     out = {
         "metric": "simulated-years/day at T85L40 Held-Suarez" if a.workload == "T85L40" else f"simulated-years/day at {a.workload} Held-Suarez",
         "value": sim_years_per_day(sec_per_step, dt), "unit": "sim_years/day", "n_gpus": a.gpus, "steps": a.steps,
@@ -141,7 +148,8 @@ def main():
         "config": {"workload": f"{a.workload} Held-Suarez dry core, dt_atmos={dt:g}s, 360-day calendar",
                    "parallelism": f"lat-band x{a.gpus}" if a.gpus > 1 else "single GPU",
                    "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": 2 if a.gpus > 1 else 0,
-                   "grid_tracer": "not advected yet (SURVEY 8f rank 2)"},
+                   "grid_tracer": ("sphum advected (van Leer + PPM) on a concurrent stream" if a.gpus == 1
+                                   else "carried, not advected when sharded (halo exchange not built yet)")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
     }
     if a.gpus == 1 and a.cpu_steps > 0:
