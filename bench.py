@@ -147,9 +147,9 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (reference cold start: T=264 K at rest + 1e-7 vorticity seed)",
         "config": {"workload": f"{a.workload} Held-Suarez dry core, dt_atmos={dt:g}s, 360-day calendar",
                    "parallelism": f"lat-band x{a.gpus}" if a.gpus > 1 else "single GPU",
-                   "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": 2 if a.gpus > 1 else 0,
+                   "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": "2 all-to-all + 1 halo + 1 all-reduce" if a.gpus > 1 else 0,
                    "grid_tracer": ("sphum advected (van Leer + PPM) on a concurrent stream" if a.gpus == 1
-                                   else "carried, not advected when sharded (halo exchange not built yet)")},
+                                   else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
     }
     if a.gpus == 1 and a.cpu_steps > 0:

@@ -80,7 +80,7 @@ int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync);
 int isca_dyn_synchronize(isca_dyn_t *h);
 
 /* --- multi-GPU: one step split at its two lat<->m exchange points (transforms.F90:970-1056).
- * phase 0: grid tendencies + FFT            -> send buffer "fwd"
+ * phase 0: grid tendencies + FFT            -> send buffer "fwd" (+ tracer halo rows)
  * phase 1: Legendre analysis, spectral update, Legendre synthesis -> send buffer "inv"
  * phase 2: inverse FFT, fixer partial sums  -> 8 doubles to all-reduce (isca_dyn_reduce_buffer)
  * phase 3: fixers applied, time levels rotated.
@@ -89,6 +89,9 @@ int isca_dyn_step_phase(isca_dyn_t *h, int phase);
 int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv*/, void **send, void **recv,
                               size_t *bytes_per_peer);
 int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count);
+/* grid-tracer halo rows (the mpp_update_domains of fv_advection.F90:161-162,259): after phase 0 the host sends
+ * send_lo to rank-1 (which receives it as recv_hi) and send_hi to rank+1 (as recv_lo); *bytes = 0 if no tracer. */
+int isca_dyn_halo_buffers(isca_dyn_t *h, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi, size_t *bytes);
 
 /* Pure host function (no GPU needed): the dealing of zonal wavenumbers m = 0..num_fourier to `world_size`
  * ranks used by the lat<->m exchange (replaces the contiguous m-blocks of spec_mpp.F90:78-80 /

@@ -319,6 +319,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.red = dalloc<double>(h, 32);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
+    d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
     d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -353,7 +354,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr;
     bool pure_sigma = true;
     for (double v : T.pk) if (v != 0.0) pure_sigma = false;
-    h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.P == 1) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
+    h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.Jl >= 4) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
+    if (g.P > 1) h->tracer_serial = true;     // sharded: the halo exchange sits between the column kernel and the tracer
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
@@ -629,7 +631,9 @@ static StepScalars step_scalars(isca_dyn *h) {
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
-    if (h->tracer_serial) {
+    if (h->g.P > 1) {
+      Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // tracer itself runs in phase 1
+    } else if (h->tracer_serial) {
       Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream);
     } else {
       HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
@@ -641,6 +645,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
+  if (h->tracer_on && h->g.P > 1) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); }   // halos have arrived
   { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, 0, h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
@@ -709,6 +714,13 @@ extern "C" int isca_dyn_exchange_buffers(isca_dyn_t *h, int which, void **send, 
   else if (which == 1) { *send = h->d.Fi_s; *recv = h->d.Fi_g; }
   else fail("invalid buffer id");
   *bytes_per_peer = (size_t)g.Ml * g.Jl * C * sizeof(double);
+  API_END
+}
+extern "C" int isca_dyn_halo_buffers(isca_dyn_t *h, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi, size_t *bytes) {
+  API_BEGIN
+  const size_t n = (size_t)3 * h->g.L * 2 * h->g.I;
+  *send_lo = h->d.halo_send; *send_hi = h->d.halo_send + n; *recv_lo = h->d.halo_recv; *recv_hi = h->d.halo_recv + n;
+  *bytes = h->tracer_on ? n * sizeof(double) : 0;
   API_END
 }
 extern "C" int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count) {

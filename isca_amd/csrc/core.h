@@ -65,6 +65,7 @@ struct Dev {
   double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
   double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
   double *trh;               // tracer after the horizontal van Leer step
+  double *halo_send, *halo_recv;   // [2 sides][3][L][2][I] tracer halo rows (lo, hi)
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit
   double *wcol;              // [5][Jl][I] column sums for the water fixer

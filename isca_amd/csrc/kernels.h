@@ -33,7 +33,8 @@ void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s);    
 
 // ---- grid-space kernels
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
-void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // grid tracer: van Leer + PPM + filter part A
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
 void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const double *p_full, const double *u,

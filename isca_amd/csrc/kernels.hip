@@ -1279,6 +1279,8 @@ struct TracerArgs {
   const double *c, *cc, *dy, *dyy, *dyp, *dym, *dpk, *dbk, *wts;
   const double *rcdx, *rdyy, *rcdy, *rdy;   // 1/(dx c(j)), 1/dyy, 1/(c(j) dy(j)), 1/dy  (same index conventions)
   const double *ppm;                         // [6][L] pure-sigma PPM weights: slope A,B ; edge z1,z2,z3 ; (unused)
+  const double *halo_lo, *halo_hi;           // [3 (q0,u,v)][L][2][I] rows j0-2,j0-1 / j0+Jl,j0+Jl+1 received from the neighbour bands
+  double *send_lo, *send_hi;                 // same layout: my rows 0,1 / Jl-2,Jl-1
   const int *kmask;
   double *wcol;
   double dx, dt, flux, rdamp, robert;
@@ -1308,19 +1310,29 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
   double *sx = q2 + I;                // [I]
   double *fl = sx + I;                // [I]
   __shared__ int any_big[RB];
-  const int i = threadIdx.x, j0 = blockIdx.x * RB, k = blockIdx.y;
+  const int i = threadIdx.x, j0 = g.j0 + blockIdx.x * RB, k = blockIdx.y;      // j0: global index of the block's first row
   const size_t lev = (size_t)g.Jl * I;
-  int jsrc[NR], sh[NR];
+  int jsrc[NR], sh[NR];                                                         // global source row, longitude shift
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int jv = j0 + r - 2;
-    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I >> 1; }
-    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I >> 1; }
+    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I >> 1; }                          // across the south pole (:150-156)
+    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I >> 1; }             // across the north pole (:158-164)
     else { jsrc[r] = jv; sh[r] = 0; }
-    const size_t c2 = (size_t)jsrc[r] * I + i, q = (size_t)k * lev + c2;
-    qs[r * I + i] = tr_q0(a, g, k, q, c2);
-    us[r * I + i] = a.ua[q];
-    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * a.va[q];
+    const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
+    double q0v, uv, vv;
+    if (jl >= 0 && jl < g.Jl) {
+      const size_t c2 = (size_t)jl * I + i, q = (size_t)k * lev + c2;
+      q0v = tr_q0(a, g, k, q, c2); uv = a.ua[q]; vv = a.va[q];
+    } else {
+      const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
+      const int hr = (jl < 0) ? jl + 2 : jl - g.Jl;
+      const size_t o = (((size_t)0 * g.L + k) * 2 + hr) * I + i, fs = (size_t)g.L * 2 * I;
+      q0v = hb[o]; uv = hb[o + fs]; vv = hb[o + 2 * fs];
+    }
+    qs[r * I + i] = q0v;
+    us[r * I + i] = uv;
+    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * vv;
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
@@ -1344,7 +1356,7 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
   __syncthreads();
   for (int rr = 0; rr < RB; ++rr) {
     const int r = rr + 2, jg = j0 + rr;
-    if (jg >= J) break;
+    if (jg >= g.j0 + g.Jl) break;
     const double q0c = qs[r * I + i], va_c = vs[(rr + 1) * I + i];
     {  // semi_y (:415-433)
       const double qxm = qs[(r - 1) * I + ((i + sh[r - 1]) & IM)], qxp = qs[(r + 1) * I + ((i + sh[r + 1]) & IM)];
@@ -1390,8 +1402,18 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
       if (jg == J - 1) f_hi = 0.0;
       dq = dq - rcdy * (f_hi - f_lo);
     }
-    a.trh[(size_t)k * lev + (size_t)jg * I + i] = q0c + a.dt * dq;
+    a.trh[(size_t)k * lev + (size_t)(jg - g.j0) * I + i] = q0c + a.dt * dq;
   }
+}
+
+// rows 0,1 and Jl-2,Jl-1 of (q0, u, v) for the neighbouring latitude bands (mpp_update_domains, fv_advection.F90:161-162,259)
+__global__ void k_tracer_pack_halo(Geom g, TracerArgs a) {
+  const int i = threadIdx.x, k = blockIdx.x, hr = blockIdx.y & 1, side = blockIdx.y >> 1;
+  const int jl = side ? g.Jl - 2 + hr : hr;
+  const size_t lev = (size_t)g.Jl * g.I, c2 = (size_t)jl * g.I + i, q = (size_t)k * lev + c2;
+  double *dst = side ? a.send_hi : a.send_lo;
+  const size_t o = ((size_t)k * 2 + hr) * g.I + i, fs = (size_t)g.L * 2 * g.I;
+  dst[o] = tr_q0(a, g, k, q, c2); dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q];
 }
 
 // PPM reconstruction of one cell from the column values around it (slope_z :505-568 with limiters, non-linear
@@ -1581,8 +1603,7 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
   }
 }
 
-void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  const Geom &g = h.g;
+static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   const Dev &d = h.d;
   TracerArgs a;
   a.ua = d.ug[sc.cur]; a.va = d.vg[sc.cur]; a.trp = d.tr[sc.prev]; a.tratm_p = d.tr_atm[sc.prev];
@@ -1594,6 +1615,18 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
   a.robert = h.cfg.robert_coeff;
+  a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + (size_t)3 * h.g.L * 2 * h.g.I;
+  a.send_lo = d.halo_send; a.send_hi = d.halo_send + (size_t)3 * h.g.L * 2 * h.g.I;
+  return a;
+}
+void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  TracerArgs a = tracer_args(h, sc);
+  hipLaunchKernelGGL(k_tracer_pack_halo, dim3(g.L, 4), dim3(g.I), 0, s, g, a);
+}
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  TracerArgs a = tracer_args(h, sc);
   const size_t ldsh = (size_t)(3 * (TR_RB + 4) + (TR_RB + 2) + 3) * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
   const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums

@@ -67,6 +67,7 @@ def load_library():
         "isca_dyn_step_phase": [H, C.c_int],
         "isca_dyn_exchange_buffers": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "isca_dyn_reduce_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+        "isca_dyn_halo_buffers": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "isca_wavenumber_dealing": [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "isca_dyn_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
         "isca_dyn_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
@@ -98,7 +99,7 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
     "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_step_phase", "isca_dyn_exchange_buffers",
-    "isca_dyn_reduce_buffer", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
+    "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
@@ -241,6 +242,12 @@ class DynCore:
         s, r, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
         self._check(self.lib.isca_dyn_exchange_buffers(self._h, which, C.byref(s), C.byref(r), C.byref(n)))
         return s.value, r.value, n.value
+
+    def halo_buffers(self):
+        p = [C.c_void_p() for _ in range(4)]
+        n = C.c_size_t()
+        self._check(self.lib.isca_dyn_halo_buffers(self._h, *[C.byref(x) for x in p], C.byref(n)))
+        return [x.value for x in p], n.value
 
     def reduce_buffer(self):
         b, n = C.c_void_p(), C.c_size_t()

@@ -43,6 +43,29 @@ def _gloo_all_to_all(outs, s, group):
         dist.scatter(outs[root], [s[q].contiguous() for q in range(P)] if me == root else None, src=root, group=group)
 
 
+def halo_exchange(send_lo, send_hi, recv_lo, recv_hi, group=None):
+    """Nearest-neighbour exchange of the tracer halo rows: send_lo -> rank-1 (its recv_hi), send_hi -> rank+1 (its recv_lo)."""
+    import torch
+    import torch.distributed as dist
+    P, me = dist.get_world_size(group), dist.get_rank(group)
+    nccl = dist.get_backend(group) == "nccl"
+    sl, sh = (send_lo, send_hi) if nccl else (send_lo.detach().cpu(), send_hi.detach().cpu())
+    rl, rh = (recv_lo, recv_hi) if nccl else (torch.empty_like(sl), torch.empty_like(sh))
+    ops = []
+    if me > 0:
+        ops += [dist.P2POp(dist.isend, sl, me - 1, group), dist.P2POp(dist.irecv, rl, me - 1, group)]
+    if me < P - 1:
+        ops += [dist.P2POp(dist.isend, sh, me + 1, group), dist.P2POp(dist.irecv, rh, me + 1, group)]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if not nccl:
+        if me > 0:
+            recv_lo.copy_(rl.to(recv_lo.device))
+        if me < P - 1:
+            recv_hi.copy_(rh.to(recv_hi.device))
+
+
 def allreduce_sum(t, group=None):
     import torch.distributed as dist
     if dist.get_backend(group) == "nccl":
@@ -73,11 +96,15 @@ class ShardedDynCore(dyncore.DynCore):
             self._bufs.append((torch.as_tensor(_DevPtr(s, tot), device="cuda"), torch.as_tensor(_DevPtr(r, tot), device="cuda")))
         b, n = self.reduce_buffer()
         self._red = torch.as_tensor(_DevPtr(b, 8 * n), device="cuda")
+        ptrs, hbytes = self.halo_buffers()
+        self._halo = [torch.as_tensor(_DevPtr(p, hbytes), device="cuda") for p in ptrs] if hbytes else None
 
     def step(self, nsteps: int = 1, sync: bool = True):
         with self._torch.cuda.stream(self._stream):
             for _ in range(nsteps):
-                self.step_phase(0)                                          # grid tendencies + FFT
+                self.step_phase(0)                                          # grid tendencies + FFT (+ tracer halo rows)
+                if self._halo is not None:
+                    halo_exchange(*self._halo, group=self.group)            # fv_advection's mpp_update_domains
                 exchange(self._bufs[0][0], self._bufs[0][1], self.group)    # lat -> m   (transpose_fourier)
                 self.step_phase(1)                                          # Legendre, spectral update, Legendre
                 exchange(self._bufs[1][0], self._bufs[1][1], self.group)    # m -> lat   (reverse_transpose_fourier)

@@ -11,7 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--res", default="T21"); ap.add_argument("--levels", type=int, default=25)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=8)
     a = ap.parse_args()
     import torch, torch.distributed as dist
     from isca_amd import dyncore
@@ -23,7 +23,7 @@ def main():
     sh = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev))
     sh.cold_start()
     sh.step(a.steps)
-    got = {k: sh.gather_grid(k) for k in ("ug", "vg", "tg")}
+    got = {k: sh.gather_grid(k) for k in ("ug", "vg", "tg", "tr")}
     got["psg"] = sh.gather_grid("psg")
     spec_local = {k: sh.get(k) for k in ("ts", "vors", "ln_ps")}
     ok = True
@@ -32,7 +32,7 @@ def main():
         ref.cold_start(); ref.step(a.steps)
         for k, v in got.items():
             r = ref.get(k)
-            err = np.max(np.abs(v - r)) / max(np.max(np.abs(r)), 1e-300) if k in ("tg", "psg") else np.max(np.abs(v - r))
+            err = np.max(np.abs(v - r)) / max(np.max(np.abs(r)), 1e-300) if k in ("tg", "psg", "tr") else np.max(np.abs(v - r))
             print(f"sharded x{world} vs single after {a.steps} steps: {k:4s} err={err:.3e}")
             ok &= bool(err < 1e-10)
         owned = dyncore.wavenumber_dealing(ref.cfg.num_fourier, world)[0]

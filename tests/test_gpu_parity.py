@@ -204,7 +204,7 @@ def test_sharded_device_path_matches_single(world):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
-           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "6"]
+           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
