@@ -111,11 +111,18 @@ int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_level, const do
 /* after set_state of grid fields: rebuild the spectral side like complete_update_of_future
  * (spectral_dynamics.F90:1416-1454) for the given time level */
 int isca_dyn_complete_update(isca_dyn_t *h, int time_level);
+/* Restart (replaces read_restart_or_do_coldstart's restart branch, spectral_dynamics.F90:509-575, and the
+ * time_pointers of atmosphere.F90:207-211): set the leapfrog pointers first (0-based storage slots of
+ * `previous` and `current`), then set_state every array of both levels, then refresh_derived, which rebuilds
+ * from the spectral state of `current` the grid fields the step keeps between calls (vorg, divg, grad T,
+ * grad ln ps) without touching the grid u, v, T, ps just set (world_size == 1). */
+int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int current, long step_count);
+int isca_dyn_refresh_derived(isca_dyn_t *h);
 
 /* tables: "sin_lat","wts_lat","deg_lat","deg_lon","pk","bk","legendre" (m,n,lat_max/2),
  * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
 int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
-int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","m_local","kernels_per_step" */
+int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer" */
 
 /* --- transforms_mod entry points (host buffers, Fortran layouts; nlev = size of 3rd dim) --- */
 int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev);   /* transforms.F90:379 */

@@ -10,13 +10,15 @@ grid (lon,lat,lev) <-> [lev,lat,lon], spectral (m,n,lev) <-> [lev,n,m].
 """
 from __future__ import annotations
 
+import os
 import re
 import numpy as np
 
-from . import dyncore
+from . import dyncore, restart
 from .dyncore import IscaError, RESOLUTIONS
 
 _core: dyncore.DynCore | None = None
+_run_dir: str | None = None
 _NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
 
 
@@ -94,13 +96,27 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
 
 
 # ---------------------------------------------------------------- atmosphere_mod
-def atmosphere_init(namelist=None, resolution: str | None = None, **overrides):
-    """atmosphere.F90:120-272: spectral_dynamics_init + cold start (no restart present) + hs_forcing_init."""
-    global _core
+def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str | None = None, **overrides):
+    """atmosphere.F90:120-272: spectral_dynamics_init + (restart | cold start) + hs_forcing_init.
+
+    With `run_dir` the reference's file protocol applies: `run_dir/INPUT/spectral_dynamics.res.nc` (+
+    `atmosphere.res.nc`) is read when present (atmosphere.F90:197-223, spectral_dynamics.F90:509-575),
+    otherwise the model cold-starts; atmosphere_end() then writes `run_dir/RESTART/`."""
+    global _core, _run_dir
     if _core is not None:
         return _core                                   # `if(module_is_initialized) return`
     _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
-    _core.cold_start()
+    _run_dir = run_dir
+    inp = None if run_dir is None else os.path.join(run_dir, "INPUT")
+    try:
+        if inp is not None and restart.restart_exists(inp):
+            restart.read_restart(_core, inp)
+        else:
+            _core.cold_start()
+    except Exception:
+        _core.close()
+        _core = None
+        raise
     return _core
 
 
@@ -112,10 +128,16 @@ def atmosphere(nsteps: int = 1):
 
 
 def atmosphere_end():
-    global _core
+    """atmosphere.F90:358-392: write RESTART/atmosphere.res.nc and RESTART/spectral_dynamics.res.nc, free."""
+    global _core, _run_dir
     if _core is not None:
-        _core.close()
-        _core = None
+        try:
+            if _run_dir is not None:
+                restart.write_restart(_core, os.path.join(_run_dir, "RESTART"))
+        finally:
+            _core.close()
+            _core = None
+            _run_dir = None
 
 
 def _need():

@@ -590,6 +590,19 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
   API_END
 }
 
+// vorg, divg and the gradient fields of the `current` level from its spectral state; the caller's grid
+// u, v, T, ps of that level are kept bit for bit (the synthesis would reproduce them only to roundoff)
+static void refresh_derived(isca_dyn *h) {
+  Dev &d = h->d;
+  const int tl = h->current;
+  const size_t ng2 = (size_t)h->g.Jl * h->g.I, ng3 = ng2 * h->g.L;
+  dcopy(h, d.scratch_g[0], d.ug[tl], ng3); dcopy(h, d.scratch_g[1], d.vg[tl], ng3);
+  dcopy(h, d.scratch_g[2], d.tg[tl], ng3); dcopy(h, d.scratch_g[3], d.psg[tl], ng2);
+  synthesize_level(h, tl);
+  dcopy(h, d.ug[tl], d.scratch_g[0], ng3); dcopy(h, d.vg[tl], d.scratch_g[1], ng3);
+  dcopy(h, d.tg[tl], d.scratch_g[2], ng3); dcopy(h, d.psg[tl], d.scratch_g[3], ng2);
+}
+
 // complete_update_of_future (spectral_dynamics.F90:1416-1454): rebuild the spectral side of a level from
 // its grid fields, then every derived grid field of that level
 extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
@@ -606,13 +619,28 @@ extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
   for (auto &x : ps) x = std::log(x);
   h2d(h, d.scratch_g[0], ps.data(), ng2);
   dev_g2s(h, d.scratch_g[0], d.lnps[tl], 1, 1, OP_NONE);
-  if (tl == h->current) {
-    // keep the caller's grid values: only the derived fields (vorg, divg, gradients) are regenerated
-    std::vector<double> u((size_t)L * ng2), v((size_t)L * ng2), t((size_t)L * ng2), p(ng2);
-    d2h(h, u.data(), d.ug[tl], u.size()); d2h(h, v.data(), d.vg[tl], v.size()); d2h(h, t.data(), d.tg[tl], t.size()); d2h(h, p.data(), d.psg[tl], ng2);
-    synthesize_level(h, tl);
-    h2d(h, d.ug[tl], u.data(), u.size()); h2d(h, d.vg[tl], v.data(), v.size()); h2d(h, d.tg[tl], t.data(), t.size()); h2d(h, d.psg[tl], p.data(), ng2);
-  }
+  if (tl == h->current) refresh_derived(h);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  API_END
+}
+
+// Restart support (spectral_dynamics.F90:509-575 read_restart, :1502-1531 write; atmosphere.F90:197-223).
+// After the state arrays of both time levels have been set: restore the leapfrog time pointers
+// ('previous'/'current' of the restart file, 0-based here) and the step counter ...
+extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int current, long step_count) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  if (previous < 0 || previous > 1 || current < 0 || current > 1) fail("set_time_pointers: time levels are 0 or 1");
+  if (step_count < 0) fail("set_time_pointers: negative step count");
+  h->previous = previous; h->current = current; h->step_count = step_count;
+  API_END
+}
+// ... then rebuild what the step keeps between calls but the restart file does not hold.
+extern "C" int isca_dyn_refresh_derived(isca_dyn_t *h) {
+  API_BEGIN
+  if (!h || !h->have_state) fail("refresh_derived: no state");
+  require_single(h, "refresh_derived");
+  refresh_derived(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   API_END
 }
@@ -808,6 +836,7 @@ extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
   else if (nm == "current") *value = h->current; else if (nm == "lat_local") *value = h->g.Jl;
   else if (nm == "lat_start") *value = h->g.j0;
   else if (nm == "m_local") *value = h->g.Ml; else if (nm == "kernels_per_step") *value = h->kernels_per_step;
+  else if (nm == "tracer") *value = h->tracer_on ? 1 : 0;
   else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
   else fail("unknown info " + nm);
   API_END

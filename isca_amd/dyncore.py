@@ -72,6 +72,8 @@ def load_library():
         "isca_dyn_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
         "isca_dyn_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
         "isca_dyn_complete_update": [H, C.c_int],
+        "isca_dyn_set_time_pointers": [H, C.c_int, C.c_int, C.c_long],
+        "isca_dyn_refresh_derived": [H],
         "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
         "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
         "isca_trans_spherical_to_grid": [H, dp, dp, C.c_int],
@@ -100,6 +102,7 @@ EXPORTED_SYMBOLS = [
     "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
     "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_step_phase", "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
+    "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
     "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
@@ -256,6 +259,12 @@ class DynCore:
 
     def complete_update(self, time_level: int = 1):
         self._check(self.lib.isca_dyn_complete_update(self._h, time_level))
+
+    def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
+        self._check(self.lib.isca_dyn_set_time_pointers(self._h, previous, current, step_count))
+
+    def refresh_derived(self):
+        self._check(self.lib.isca_dyn_refresh_derived(self._h))
 
     def state(self):
         return {k: self.get(k) for k in ("ug", "vg", "tg", "psg", "vors", "divs", "ts", "ln_ps")}

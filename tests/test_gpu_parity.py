@@ -226,3 +226,92 @@ def test_atmosphere_module_mirror(golden_dir):
         atm.get_initial_fields()
     assert np.array_equal(atm.get_deg_lat(), g["tab_deg_lat"])
     atm.atmosphere_end()
+
+
+# ------------------------------------------------------------------ restart files
+ALL_STATE = ("vors", "divs", "ts", "ln_ps", "ug", "vg", "tg", "psg", "tr", "tr_atm", "vorg", "divg", "wg_full")
+
+
+@pytest.mark.parametrize("first", [1, 9])
+def test_restart_is_bit_exact(tmp_path, first):
+    """run(N) == run(n1) + atmosphere_end + atmosphere_init(restart) + run(N - n1), bit for bit, through the
+    reference's file protocol (RESTART/ -> INPUT/, spectral_dynamics.F90:509-575,1502-1531; atmosphere.F90:197-223,362-375).
+    first = 1 restarts right after the forward (dt) step, when the two time levels still alias."""
+    from isca_amd import atmosphere as atm, restart
+    total = 20
+    nml = {"main_nml": {"dt_atmos": 600}, "spectral_dynamics_nml": {"num_levels": 12}}
+    ref = make("T21", 12)
+    ref.cold_start()
+    ref.step(total)
+    want = {k: (ref.get(k, 0), ref.get(k, 1)) for k in ALL_STATE}
+    ref.close()
+
+    run1, run2 = str(tmp_path / "run1"), str(tmp_path / "run2")
+    atm.atmosphere_init(nml, resolution="T21", run_dir=run1)
+    atm.atmosphere(first)
+    atm.atmosphere_end()
+    for fn in ("spectral_dynamics.res.nc", "atmosphere.res.nc"):
+        assert os.path.exists(os.path.join(run1, "RESTART", fn))
+    os.makedirs(run2)
+    os.rename(os.path.join(run1, "RESTART"), os.path.join(run2, "INPUT"))     # what experiment.py:300-330 does
+    core = atm.atmosphere_init(nml, resolution="T21", run_dir=run2)
+    assert core.info("previous") != core.info("current")
+    atm.atmosphere(total - first)
+    for k in ALL_STATE:
+        for tl in (0, 1):
+            assert np.array_equal(core.get(k, tl), want[k][tl]), (k, tl)
+    # the variable set of the reference's files
+    from scipy.io import netcdf_file
+    atm.atmosphere_end()
+    f = netcdf_file(os.path.join(run2, "RESTART", "spectral_dynamics.res.nc"), "r", mmap=False)
+    for v in ("previous", "current", "pk", "bk", "vors_real", "vors_imag", "divs_real", "divs_imag", "ts_real", "ts_imag",
+              "ln_ps_real", "ln_ps_imag", "ug", "vg", "tg", "psg", "sphum", "vorg", "divg", "surf_geopotential"):
+        assert v in f.variables, v
+    assert f.variables["vors_real"].shape == (2, 12, 23, 22) and f.variables["psg"].shape == (2, 1, 32, 64)
+    f.close()
+    # resolution mismatch is FATAL like the reference's check (:512-531)
+    c2 = make("T21", 10)
+    with pytest.raises(dyncore.IscaError, match="Resolution of restart data"):
+        restart.read_restart(c2, os.path.join(run2, "RESTART"))
+    c2.close()
+
+
+def test_restart_read_by_the_oracle(tmp_path):
+    """The file written on the GPU carries the reference's meaning of every variable: the CPU oracle
+    (restating spectral_dynamics.F90:535-575 / atmosphere.F90:207-223 as a reader) continues from it and
+    stays on the GPU trajectory."""
+    from isca_amd import restart
+    from scipy.io import netcdf_file
+    L = 8
+    dc = make("T21", L)
+    dc.cold_start()
+    dc.step(6)
+    restart.write_restart(dc, str(tmp_path))
+    sc = oracle("T21", L)
+    sc.cold_start()
+    f = netcdf_file(str(tmp_path / "spectral_dynamics.res.nc"), "r", mmap=False)
+    fa = netcdf_file(str(tmp_path / "atmosphere.res.nc"), "r", mmap=False)
+    V = lambda ff, n: np.array(ff.variables[n][:])
+    sc.previous, sc.current = int(V(f, "previous").ravel()[0]) - 1, int(V(f, "current").ravel()[0]) - 1
+    assert [int(x) - 1 for x in V(fa, "time_pointers")[0].ravel()] == [sc.previous, sc.current]
+    for nt in (0, 1):                                                # record nt <-> time level nt+1 of the Fortran arrays
+        for nm in ("vors", "divs", "ts"):
+            getattr(sc, nm)[nt] = V(f, nm + "_real")[nt] + 1j * V(f, nm + "_imag")[nt]
+        sc.ln_ps[nt] = V(f, "ln_ps_real")[nt, 0] + 1j * V(f, "ln_ps_imag")[nt, 0]
+        for nm in ("ug", "vg", "tg"):
+            getattr(sc, nm)[nt] = V(fa, nm)[nt]
+        sc.psg[nt] = V(fa, "psg")[nt, 0]
+        sc.tr[nt] = V(f, "sphum")[nt]
+        sc.tr_atm[nt] = V(fa, "sphum")[nt]
+        sc._pressures_and_heights(nt)
+    sc.vorg, sc.divg = V(f, "vorg")[0], V(f, "divg")[0]
+    sc.step_count = 6
+    f.close(); fa.close()
+    for _ in range(4):
+        sc.step()
+    dc.step(4)
+    for nm, tol in (("ug", 1e-11), ("vg", 1e-11), ("tg", 1e-12), ("psg", 1e-13), ("vors", 1e-11), ("ts", 1e-12), ("tr", 1e-10)):
+        for tl in (0, 1):
+            want = getattr(sc, nm)[sc.current if tl else sc.previous]
+            assert rel(dc.get(nm, tl), want) < tol, (nm, tl)
+    dc.close()

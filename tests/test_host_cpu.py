@@ -88,3 +88,61 @@ def test_namelist_to_config(lib):
         atm.config_from_namelist(d, "T21")
     with pytest.raises(dyncore.IscaError, match="not initialized"):
         atm.atmosphere()
+
+
+def test_restart_file_round_trip_on_host(tmp_path):
+    """restart.py against a host stand-in for the device handle: variable set, record <-> time-level mapping,
+    1-based pointers (spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375) and the FATAL resolution check."""
+    import types
+    import numpy as np
+    from isca_amd import restart
+    from isca_amd.dyncore import IscaError
+    from scipy.io import netcdf_file
+
+    class Host:
+        L, J, Jl, I, N1, M1 = 3, 8, 8, 16, 7, 6
+        cfg = types.SimpleNamespace(world_size=1)
+
+        def __init__(self, seed=None):
+            self.ptr = {"previous": 1, "current": 0, "tracer": 1, "step": 5}
+            self.store, self.refreshed = {}, False
+            if seed is not None:
+                rng = np.random.default_rng(seed)
+                for tl in (0, 1):
+                    for nm in ("vors", "divs", "ts"):
+                        self.store[nm, tl] = rng.standard_normal((3, 7, 6)) + 1j * rng.standard_normal((3, 7, 6))
+                    self.store["ln_ps", tl] = rng.standard_normal((7, 6)) + 1j * rng.standard_normal((7, 6))
+                    for nm in ("ug", "vg", "tg", "tr", "tr_atm", "vorg", "divg", "wg_full"):
+                        self.store[nm, tl] = rng.standard_normal((3, 8, 16))
+                    self.store["psg", tl] = 1e5 + rng.standard_normal((8, 16))
+                for nm in ("vorg", "divg", "wg_full"):
+                    self.store[nm, 0] = self.store[nm, 1]
+
+        def info(self, k): return self.ptr[k]
+        def table(self, k): return np.linspace(0, 1, 4) if k == "bk" else np.zeros(4)
+        def get(self, nm, tl=1): return self.store[nm, tl]
+        def set(self, nm, v, tl=1): self.store[nm, tl] = np.array(v)
+        def set_time_pointers(self, p, c, s): self.ptr.update(previous=p, current=c, step=s)
+        def refresh_derived(self): self.refreshed = True
+
+    a = Host(seed=3)
+    restart.write_restart(a, str(tmp_path))
+    f = netcdf_file(str(tmp_path / "spectral_dynamics.res.nc"), "r", mmap=False)
+    assert float(f.variables["previous"][0].ravel()[0]) == 2.0 and float(f.variables["current"][0].ravel()[0]) == 1.0
+    # record 0 is Fortran time level 1 = storage slot 0 = `current` here
+    assert np.array_equal(f.variables["ug"][0], a.store["ug", 1]) and np.array_equal(f.variables["ug"][1], a.store["ug", 0])
+    dims = f.variables["vors_real"].dimensions
+    assert dims[0] == "Time" and [d[:5] for d in dims[1:]] == ["zaxis", "yaxis", "xaxis"]
+    assert f.variables["vors_real"].shape == (2, 3, 7, 6) and f.variables["psg"].shape == (2, 1, 8, 16)
+    f.close()
+    b = Host()
+    restart.read_restart(b, str(tmp_path))
+    assert b.refreshed and (b.ptr["previous"], b.ptr["current"]) == (1, 0)
+    for key, val in a.store.items():
+        if key[0] in ("vorg", "divg"):
+            continue                                   # rebuilt by refresh_derived on the device
+        assert np.array_equal(b.store[key], val), key
+    c = Host()
+    c.L = 4
+    with pytest.raises(IscaError, match="num_levels=   3|num_levels=3"):
+        restart.read_restart(c, str(tmp_path))
