@@ -85,7 +85,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 if str(v).lower() != unsupported[k].lower():
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
                 continue
-            if k in ("days", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
+            if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
                      "graceful_shutdown", "ocean_topog_smoothing", "use_virtual_temperature", "use_implicit"):
                 continue
             if isinstance(v, bool):

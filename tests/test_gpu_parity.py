@@ -315,3 +315,30 @@ def test_restart_read_by_the_oracle(tmp_path):
             want = getattr(sc, nm)[sc.current if tl else sc.previous]
             assert rel(dc.get(nm, tl), want) < tol, (nm, tl)
     dc.close()
+
+
+def test_experiment_restart_chaining(tmp_path):
+    """Two chained segments (res0001.tar.gz -> INPUT/) equal one segment of twice the length, bit for bit."""
+    from isca_amd.experiment import Experiment
+    from isca_amd import restart
+    nml = {"main_nml": {"days": 0, "hours": 2, "dt_atmos": 600}, "spectral_dynamics_nml": {"damping_order": 4}}
+    a = Experiment("chained", str(tmp_path))
+    a.set_resolution("T21", 10)
+    a.update_namelist(nml)
+    assert a.run(1) and a.run(2)
+    assert a.run(2) is False                                   # existing output, overwrite_data False
+    b = a.derive("single")
+    b.update_namelist({"main_nml": {"hours": 4}})
+    assert b.run(1, use_restart=False)
+    cores = []
+    for e, i in ((a, 2), (b, 1)):
+        d = str(tmp_path / ("x_" + e.name))
+        e.extract_restart_archive(e.get_restart_file(i), d)
+        c = make("T21", 10)
+        restart.read_restart(c, d)
+        cores.append(c)
+    for k in ALL_STATE:
+        for tl in (0, 1):
+            assert np.array_equal(cores[0].get(k, tl), cores[1].get(k, tl)), (k, tl)
+    for c in cores:
+        c.close()

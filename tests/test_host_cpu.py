@@ -146,3 +146,28 @@ def test_restart_file_round_trip_on_host(tmp_path):
     c.L = 4
     with pytest.raises(IscaError, match="num_levels=   3|num_levels=3"):
         restart.read_restart(c, str(tmp_path))
+
+
+def test_experiment_host_logic(tmp_path):
+    """Run segmentation mirror (experiment.py:198-346): segment length, namelist file, restart chaining errors."""
+    from isca_amd.experiment import Experiment
+    from isca_amd.atmosphere import parse_namelist
+    from isca_amd.dyncore import IscaError
+    exp = Experiment("hs", str(tmp_path))
+    exp.set_resolution("T42", 25)
+    exp.update_namelist({"main_nml": {"days": 30, "hours": 0, "dt_atmos": 600, "calendar": "thirty_day"},
+                         "spectral_dynamics_nml": {"valid_range_t": [100., 800.], "vert_coord_option": "uneven_sigma"},
+                         "atmosphere_nml": {"idealized_moist_model": False}})
+    assert exp.steps_per_run() == 30 * 144
+    assert exp.namelist["spectral_dynamics_nml"]["lon_max"] == 128 and exp.namelist["spectral_dynamics_nml"]["num_levels"] == 25
+    os.makedirs(exp.rundir)
+    exp.write_namelist(exp.rundir)
+    back = parse_namelist(open(os.path.join(exp.rundir, "input.nml")).read())
+    assert back["main_nml"]["calendar"] == "thirty_day" and back["spectral_dynamics_nml"]["valid_range_t"] == [100.0, 800.0]
+    assert back["atmosphere_nml"]["idealized_moist_model"] is False
+    assert exp.get_restart_file(3).endswith(os.path.join("hs", "restarts", "res0003.tar.gz"))
+    with pytest.raises(IOError, match="Restart file not found"):
+        exp.run(2)                                    # no res0001.tar.gz
+    exp.update_namelist({"main_nml": {"days": 0, "seconds": 700}})
+    with pytest.raises(IscaError):
+        exp.steps_per_run()
