@@ -126,3 +126,76 @@ class ShardedDynCore(dyncore.DynCore):
         else:
             dist.all_gather(parts, loc, group=self.group)
         return np.concatenate([p.numpy() for p in parts], axis=-2)
+
+    # ---- restart files on a sharded run (the reference writes per-PE fragments and combines them with
+    #      mppnccombine, experiment.py:318-323; here rank 0 writes the combined files directly)
+    def gather_spectral(self, name, time_level=1):
+        """global (lev, n, m) array on every rank: each rank contributes the wavenumbers it owns"""
+        import torch.distributed as dist
+        loc = self.get(name, time_level)                       # zeros where m is not ours
+        t = self._torch.from_numpy(np.ascontiguousarray(loc).view(np.float64))
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+            dist.all_reduce(t, group=self.group)
+            t = t.cpu()
+        else:
+            dist.all_reduce(t, group=self.group)               # x + 0 is exact
+        return t.numpy().view(np.complex128).reshape(loc.shape)
+
+    def write_restart(self, directory: str):
+        from . import restart
+        view = _GatheredView(self)
+        if self.cfg.rank == 0:
+            restart.write_restart(view, directory)
+
+    def read_restart(self, directory: str):
+        """Every rank reads the combined files through a single-rank handle on its own GPU (which also rebuilds
+        the derived grid fields) and keeps its latitude band / wavenumber set."""
+        from . import restart
+        c1 = dyncore.default_config()
+        for f, _ in self.cfg._fields_:
+            setattr(c1, f, getattr(self.cfg, f))
+        c1.rank, c1.world_size, c1.stream = 0, 1, None
+        one = dyncore.DynCore(c1)
+        try:
+            restart.read_restart(one, directory)
+            self.set_time_pointers(one.info("previous"), one.info("current"), one.info("step"))
+            j0, jl = self.info("lat_start"), self.Jl
+            levels = (0, 1) if one.info("previous") != one.info("current") else (1,)
+            for tl in levels:
+                for nm in ("vors", "divs", "ts", "ln_ps"):
+                    self.set(nm, one.get(nm, tl), tl)
+                names = ("ug", "vg", "tg", "psg") + (("tr", "tr_atm") if self.info("tracer") else ())
+                for nm in names:
+                    self.set(nm, one.get(nm, tl)[..., j0:j0 + jl, :], tl)
+            for nm in ("vorg", "divg", "dxT", "dyT", "dxlp", "dylp", "wg_full"):
+                self.set(nm, one.get(nm)[..., j0:j0 + jl, :])
+        finally:
+            one.close()
+
+
+class _GatheredView:
+    """What restart.write_restart needs from a handle, answered with globally gathered arrays."""
+
+    def __init__(self, sh: ShardedDynCore):
+        import types
+        self._sh = sh
+        self.cfg = types.SimpleNamespace(world_size=1)
+        self.L, self.J, self.Jl, self.I, self.N1, self.M1 = sh.L, sh.J, sh.J, sh.I, sh.N1, sh.M1
+        self._cache = {}
+        for nm in ("vors", "divs", "ts", "ln_ps"):
+            for tl in (0, 1):
+                self._cache[nm, tl] = sh.gather_spectral(nm, tl)
+        grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full"] + (["tr", "tr_atm"] if sh.info("tracer") else [])
+        for nm in grids:
+            for tl in (0, 1):
+                self._cache[nm, tl] = sh.gather_grid(nm, tl)
+
+    def info(self, k):
+        return self._sh.info(k)
+
+    def table(self, k):
+        return self._sh.table(k)
+
+    def get(self, name, time_level=1):
+        return self._cache[name, time_level]
