@@ -140,6 +140,23 @@ int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double 
 int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
                     const double *v, const double *t, double *udt, double *vdt, double *tdt);
 
+/* --- components of the step on caller fields (world_size == 1) -------------------------------------
+ * Each entry replaces one public routine the reference's callers use on its own, and runs the kernel or
+ * device function the step itself uses.  Spectral arrays (m,n,lev) complex, grid arrays (lon,lat,lev). */
+int isca_compute_laplacian(isca_dyn_t *h, const double *spherical, double *laplacian, int nlev, int power);   /* spherical.F90:354-406; power = 1 is the default */
+int isca_compute_gradient_cos(isca_dyn_t *h, const double *spherical, double *deriv_lon, double *deriv_lat, int nlev);   /* spherical.F90:270-351; also compute_lon/lat_deriv_cos (NULL skips an output) */
+int isca_compute_ucos_vcos(isca_dyn_t *h, const double *vorticity, const double *divergence, double *u_cos, double *v_cos, int nlev);     /* spherical.F90:409-469 */
+int isca_compute_vor_div(isca_dyn_t *h, const double *u_div_cos, const double *v_div_cos, double *vorticity, double *divergence, int nlev);   /* spherical.F90:472-561 */
+int isca_triangular_truncation(isca_dyn_t *h, double *spherical, int nlev);                             /* spherical.F90:564-600, in place */
+int isca_divide_by_cos(isca_dyn_t *h, double *grid, int nlev, int power);                               /* transforms.F90:599-648 divide_by_cos (1) / divide_by_cos2 (2), in place */
+int isca_mass_weighted_global_integral(isca_dyn_t *h, const double *field, const double *surf_press, double *integral);   /* global_integral.F90:49-81 */
+int isca_pressure_variables(isca_dyn_t *h, const double *surf_p, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full);   /* press_and_geopot.F90:152-221 */
+int isca_compute_geopotential(isca_dyn_t *h, const double *t, const double *ln_p_half, const double *ln_p_full,
+                              double *geopot_full, double *geopot_half);                              /* press_and_geopot.F90:327-359, dry, flat surface */
+int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v, const double *q, double dt, double *tendency);   /* fv_advection.F90:126-207; tendency is accumulated */
+int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt);   /* vert_advection.F90:70-478, FINITE_VOLUME_PARABOLIC / ADVECTIVE_FORM, dz = dpk + dbk*surf_p */
+int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, const double *r, double *rdt);      /* hs_forcing.F90:683-724; rdt is accumulated */
+
 /* --- benchmarking helpers: transform pair with data resident in HBM ------------------------------
  * Runs `reps` (s2g, g2s) pairs over nfields level-fields on device buffers owned by the handle and
  * returns the average time of one pair in milliseconds measured with HIP events on the handle's

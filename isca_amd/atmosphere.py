@@ -210,3 +210,62 @@ def get_sin_lat():
 
 def get_wts_lat():
     return _need().table("wts_lat")
+
+
+# ---------------------------------------------------------------- spherical_mod operators re-exported by transforms_mod
+def compute_laplacian(spherical, power=1):
+    return _need().compute_laplacian(spherical, power)
+
+
+def compute_gradient_cos(spherical):
+    return _need().compute_gradient_cos(spherical)
+
+
+def compute_lon_deriv_cos(spherical):
+    return _need().compute_lon_deriv_cos(spherical)
+
+
+def compute_lat_deriv_cos(spherical):
+    return _need().compute_lat_deriv_cos(spherical)
+
+
+def compute_ucos_vcos(vorticity, divergence):
+    return _need().compute_ucos_vcos(vorticity, divergence)
+
+
+def compute_vor_div(u_div_cos, v_div_cos):
+    return _need().compute_vor_div(u_div_cos, v_div_cos)
+
+
+def triangular_truncation(spherical):
+    return _need().triangular_truncation(spherical)
+
+
+def divide_by_cos(grid):
+    return _need().divide_by_cos(grid, 1)
+
+
+def divide_by_cos2(grid):
+    return _need().divide_by_cos(grid, 2)
+
+
+# ---------------------------------------------------------------- press_and_geopot_mod / global_integral_mod / advection
+def pressure_variables(surf_p):
+    """-> p_half, ln_p_half, p_full, ln_p_full (press_and_geopot.F90:152)"""
+    return _need().pressure_variables(surf_p)
+
+
+def compute_geopotential(t, ln_p_half, ln_p_full):
+    return _need().compute_geopotential(t, ln_p_half, ln_p_full)
+
+
+def mass_weighted_global_integral(field, surf_press):
+    return _need().mass_weighted_global_integral(field, surf_press)
+
+
+def a_grid_horiz_advection(u, v, q, dt, tendency=None):
+    return _need().a_grid_horiz_advection(u, v, q, dt, tendency)
+
+
+def vert_advection_ppm(dt, w, surf_p, r):
+    return _need().vert_advection_ppm(dt, w, surf_p, r)

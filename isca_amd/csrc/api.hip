@@ -983,6 +983,179 @@ extern "C" int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, c
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Components of the step on caller fields.  These run the kernels (or the device functions) the step
+// itself uses, so the reference's per-routine outputs can be compared directly.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevTmp {      // short-lived device buffers of one host-synchronous call
+  isca_dyn *h; std::vector<double *> v;
+  explicit DevTmp(isca_dyn *h_) : h(h_) {}
+  double *alloc(size_t n, bool zero = false) {
+    double *p; HIP_CHECK(hipMalloc((void **)&p, n * sizeof(double)));
+    v.push_back(p);
+    if (zero) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(double), h->stream));
+    return p;
+  }
+  double *up(const double *src, size_t n) { double *p = alloc(n); h2d(h, p, src, n); return p; }
+  ~DevTmp() { hipStreamSynchronize(h->stream); for (double *p : v) hipFree(p); }
+};
+}  // namespace
+
+// spherical.F90:354-406 compute_laplacian(spherical [, power])
+extern "C" int isca_compute_laplacian(isca_dyn_t *h, const double *spherical, double *laplacian, int nlev, int power) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  spec_host_to_dev(h, spherical, h->d.scratch_s[0], nlev);
+  launch_spec_laplacian(h->g, h->d, h->d.scratch_s[0], h->d.scratch_s[1], nlev, power, h->stream);
+  spec_dev_to_host(h, h->d.scratch_s[1], laplacian, nlev);
+  API_END
+}
+// spherical.F90:270-351 compute_gradient_cos / compute_lon_deriv_cos / compute_lat_deriv_cos (either output may be NULL)
+extern "C" int isca_compute_gradient_cos(isca_dyn_t *h, const double *spherical, double *deriv_lon, double *deriv_lat, int nlev) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  Dev &d = h->d;
+  spec_host_to_dev(h, spherical, d.scratch_s[0], nlev);
+  launch_spec_gradient(h->g, d, d.scratch_s[0], d.Si, 4 * nlev, 0, nlev, nlev, h->stream);
+  launch_spec_unpack(h->g, d, d.Si, d.scratch_s[1], 4 * nlev, 0, nlev, 0, h->stream);
+  launch_spec_unpack(h->g, d, d.Si, d.scratch_s[2], 4 * nlev, nlev, nlev, 0, h->stream);
+  if (deriv_lon) spec_dev_to_host(h, d.scratch_s[1], deriv_lon, nlev);
+  if (deriv_lat) spec_dev_to_host(h, d.scratch_s[2], deriv_lat, nlev);
+  API_END
+}
+// spherical.F90:409-469 compute_ucos_vcos
+extern "C" int isca_compute_ucos_vcos(isca_dyn_t *h, const double *vorticity, const double *divergence, double *u_cos, double *v_cos, int nlev) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  Dev &d = h->d;
+  spec_host_to_dev(h, vorticity, d.scratch_s[0], nlev); spec_host_to_dev(h, divergence, d.scratch_s[1], nlev);
+  launch_spec_ucos_vcos(h->g, d, d.scratch_s[0], d.scratch_s[1], d.Si, 4 * nlev, 0, nlev, nlev, h->stream);
+  launch_spec_unpack(h->g, d, d.Si, d.scratch_s[2], 4 * nlev, 0, nlev, 0, h->stream);
+  launch_spec_unpack(h->g, d, d.Si, d.scratch_s[3], 4 * nlev, nlev, nlev, 0, h->stream);
+  spec_dev_to_host(h, d.scratch_s[2], u_cos, nlev); spec_dev_to_host(h, d.scratch_s[3], v_cos, nlev);
+  API_END
+}
+// spherical.F90:472-561 compute_vor_div (no truncation, unlike vor_div_from_uv_grid)
+extern "C" int isca_compute_vor_div(isca_dyn_t *h, const double *u_div_cos, const double *v_div_cos, double *vorticity, double *divergence, int nlev) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  Dev &d = h->d;
+  spec_host_to_dev(h, u_div_cos, d.scratch_s[0], nlev); spec_host_to_dev(h, v_div_cos, d.scratch_s[1], nlev);
+  launch_spec_pack(h->g, d.scratch_s[0], d.Si, 4 * nlev, 0, nlev, h->stream);
+  launch_spec_pack(h->g, d.scratch_s[1], d.Si, 4 * nlev, nlev, nlev, h->stream);
+  launch_spec_vor_div(h->g, d, d.Si, 4 * nlev, 0, nlev, d.scratch_s[2], d.scratch_s[3], nlev, h->stream, 0);
+  spec_dev_to_host(h, d.scratch_s[2], vorticity, nlev); spec_dev_to_host(h, d.scratch_s[3], divergence, nlev);
+  API_END
+}
+// spherical.F90:564-600 triangular_truncation (default mask), in place
+extern "C" int isca_triangular_truncation(isca_dyn_t *h, double *spherical, int nlev) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  Dev &d = h->d;
+  spec_host_to_dev(h, spherical, d.scratch_s[0], nlev);
+  launch_spec_pack(h->g, d.scratch_s[0], d.Si, 2 * nlev, 0, nlev, h->stream);
+  launch_spec_unpack(h->g, d, d.Si, d.scratch_s[1], 2 * nlev, 0, nlev, 1, h->stream);
+  spec_dev_to_host(h, d.scratch_s[1], spherical, nlev);
+  API_END
+}
+// transforms.F90:599-648 divide_by_cos / divide_by_cos2, in place (power = 1 or 2)
+extern "C" int isca_divide_by_cos(isca_dyn_t *h, double *grid, int nlev, int power) {
+  API_BEGIN
+  check_nlev(h, nlev);
+  if (power != 1 && power != 2) fail("divide_by_cos: power must be 1 or 2");
+  const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
+  h2d(h, h->d.scratch_g[0], grid, n);
+  for (int p = 0; p < power; ++p) launch_scale_rows(h->g, h->d, h->d.scratch_g[0], nlev, h->stream);
+  d2h(h, grid, h->d.scratch_g[0], n);
+  API_END
+}
+// global_integral.F90:49-81 mass_weighted_global_integral(field, surf_press)
+extern "C" int isca_mass_weighted_global_integral(isca_dyn_t *h, const double *field, const double *surf_press, double *integral) {
+  API_BEGIN
+  require_single(h, "mass_weighted_global_integral");
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I;
+  DevTmp t(h);
+  double *f = t.up(field, n2 * g.L), *ps = t.up(surf_press, n2), *rows = t.alloc(g.Jl);
+  launch_mass_weighted_rows(*h, f, ps, rows, h->stream);
+  std::vector<double> r(g.Jl);
+  d2h(h, r.data(), rows, g.Jl);
+  double s_ = 0.0, sw = 0.0;
+  for (int j = 0; j < g.Jl; ++j) { s_ += r[j]; sw += h->tab.wts_lat[j]; }
+  *integral = s_ / (sw * g.I) / GRAV;
+  API_END
+}
+// press_and_geopot.F90:152-221 pressure_variables(p_half, ln_p_half, p_full, ln_p_full, surf_p)
+extern "C" int isca_pressure_variables(isca_dyn_t *h, const double *surf_p, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I;
+  DevTmp t(h);
+  double *ps = t.up(surf_p, n2), *ph = t.alloc(n2 * (g.L + 1)), *lph = t.alloc(n2 * (g.L + 1)), *pf = t.alloc(n2 * g.L), *lpf = t.alloc(n2 * g.L);
+  launch_pressure_variables(*h, ps, ph, lph, pf, lpf, h->stream);
+  d2h(h, p_half, ph, n2 * (g.L + 1)); d2h(h, ln_p_half, lph, n2 * (g.L + 1)); d2h(h, p_full, pf, n2 * g.L); d2h(h, ln_p_full, lpf, n2 * g.L);
+  API_END
+}
+// press_and_geopot.F90:327-359 compute_geopotential(t, ln_p_half, ln_p_full, surf_geopotential = 0, geopot_full, geopot_half)
+extern "C" int isca_compute_geopotential(isca_dyn_t *h, const double *t, const double *ln_p_half, const double *ln_p_full, double *geopot_full, double *geopot_half) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I;
+  DevTmp tmp(h);
+  double *dt_ = tmp.up(t, n2 * g.L), *lph = tmp.up(ln_p_half, n2 * (g.L + 1)), *lpf = tmp.up(ln_p_full, n2 * g.L);
+  double *gf = tmp.alloc(n2 * g.L), *gh = tmp.alloc(n2 * (g.L + 1), true);
+  launch_geopotential(*h, dt_, lph, lpf, gf, gh, h->stream);
+  d2h(h, geopot_full, gf, n2 * g.L); d2h(h, geopot_half, gh, n2 * (g.L + 1));
+  API_END
+}
+// fv_advection.F90:126-207 a_grid_horiz_advection(u, v, q, dt, tendency): tendency += van Leer advective tendency.
+// Runs the step's own tracer kernel without source/sink.
+extern "C" int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v, const double *q, double dt, double *tendency) {
+  API_BEGIN
+  require_single(h, "a_grid_horiz_advection");
+  const Geom &g = h->g;
+  if (g.Jl < 4) fail("a_grid_horiz_advection: needs at least 4 latitude rows");
+  const size_t n3 = (size_t)g.L * g.Jl * g.I;
+  DevTmp t(h);
+  double *du = t.up(u, n3), *dv = t.up(v, n3), *dq = t.up(q, n3), *qn = t.alloc(n3);
+  const std::vector<double> ones((size_t)g.Jl * g.I, h->cfg.reference_sea_level_press);
+  double *ps = t.up(ones.data(), ones.size());
+  launch_fv_horiz_on(*h, du, dv, dq, ps, dt, qn, h->stream);
+  std::vector<double> out(n3);
+  d2h(h, out.data(), qn, n3);
+  for (size_t i = 0; i < n3; ++i) tendency[i] += (out[i] - q[i]) / dt;
+  API_END
+}
+// vert_advection.F90:70-478 vert_advection(dt, w, dz, r, rdt, scheme = FINITE_VOLUME_PARABOLIC, form = ADVECTIVE_FORM)
+// with dz = dpk + dbk * surf_p (pure sigma levels).  Runs the step's own tracer kernel.
+extern "C" int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt) {
+  API_BEGIN
+  const Geom &g = h->g;
+  if (!h->d.ppm_tab) fail("vert_advection_ppm: not available");
+  for (double v : h->tab.pk) if (v != 0.0) fail("vert_advection_ppm: pure sigma levels only");
+  const size_t n2 = (size_t)g.Jl * g.I, n3 = n2 * g.L;
+  DevTmp t(h);
+  double *dw = t.up(w, n2 * (g.L + 1)), *ps = t.up(surf_p, n2), *dr = t.up(r, n3), *rn = t.alloc(n3);
+  double *da = t.alloc(n3, true), *db = t.alloc(n3, true);
+  launch_ppm_vert_on(*h, dt, dw, ps, dr, rn, da, db, h->stream);
+  std::vector<double> out(n3);
+  d2h(h, out.data(), rn, n3);
+  for (size_t i = 0; i < n3; ++i) rdt[i] = (out[i] - r[i]) / dt;
+  API_END
+}
+// hs_forcing.F90:683-724 tracer_source_sink(flux, sink, p_half, r, rdt): rdt += source - sink
+extern "C" int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, const double *r, double *rdt) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I, n3 = n2 * g.L;
+  DevTmp t(h);
+  double *ps = t.up(surf_p, n2), *dr = t.up(r, n3), *dd = t.up(rdt, n3);
+  launch_tracer_source_sink(*h, ps, dr, dd, h->stream);
+  d2h(h, rdt, dd, n3);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
 // benchmarking helpers
 // ---------------------------------------------------------------------------------------------------
 extern "C" int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, double *pair_ms, double *kernel_ms) {

@@ -23,7 +23,8 @@ void launch_spec_pack(const Geom &g, const double *state, double *S, int C, int 
 void launch_spec_unpack(const Geom &g, const Dev &d, const double *S, double *state, int C, int coloff, int nlev, int mask, hipStream_t s);
 // (vor,div) state -> (ucos,vcos) columns ; (ucos,vcos) columns -> masked (vor,div) state ; gradient_cos
 void launch_spec_ucos_vcos(const Geom &g, const Dev &d, const double *vor, const double *div, double *S, int C, int col_u, int col_v, int nlev, hipStream_t s);
-void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s);
+void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s, int mask = 1);
+void launch_spec_laplacian(const Geom &g, const Dev &d, const double *in, double *out, int nlev, int power, hipStream_t s);
 void launch_spec_gradient(const Geom &g, const Dev &d, const double *state, double *S, int C, int col_dx, int col_dy, int nlev, hipStream_t s);
 
 // the time step in spectral space
@@ -43,6 +44,15 @@ void launch_pressures_heights(const isca_dyn &h, const double *t, const double *
                               double *z_full, double *z_half, hipStream_t s);
 void launch_hadv_combine(const Geom &g, const double *u, const double *v, const double *dx, const double *dy, double *tend, int nlev, hipStream_t s);
 void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStream_t s);   // a *= cosm_lat (divide_by_cos)
+
+// component entry points on caller fields
+void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full, hipStream_t s);
+void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s);
+void launch_mass_weighted_rows(const isca_dyn &h, const double *f, const double *ps, double *rows, hipStream_t s);
+void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, const double *q, const double *ps, double dt, double *q_new, hipStream_t s);
+void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
+                        double *dummy_a, double *dummy_b, hipStream_t s);
+void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s);
 
 size_t column_partials_count(const isca_dyn &h);
 

@@ -587,7 +587,8 @@ __global__ void k_spec_ucos_vcos(Geom g, const double *__restrict__ coef, const 
 }
 // compute_vor_div (spherical.F90:472-561) + triangular truncation (:564-600)
 __device__ __forceinline__ void alpha_pair(const Geom &g, const double *__restrict__ coef, const double *__restrict__ S,
-                                           int C, size_t mn, int ml, int n, int cu, int cv, double2 &vor, double2 &div) {
+                                           int C, size_t mn, int ml, int n, int cu, int cv, double2 &vor, double2 &div,
+                                           bool mask = true) {
   const double2 U = *(const double2 *)(S + mn * C + 2 * cu), V = *(const double2 *)(S + mn * C + 2 * cv);
   const double dx = COEF(C_DX, ml, n);
   vor = cscale(dx, ctimes_i(V));
@@ -604,12 +605,14 @@ __device__ __forceinline__ void alpha_pair(const Geom &g, const double *__restri
     vor = csub(vor, cscale(ap, Up));
     div = cadd(div, cscale(ap, Vp));
   }
-  const double mk = COEF(C_MASK, ml, n);
-  vor = cscale(mk, vor);
-  div = cscale(mk, div);
+  if (mask) {
+    const double mk = COEF(C_MASK, ml, n);
+    vor = cscale(mk, vor);
+    div = cscale(mk, div);
+  }
 }
 __global__ void k_spec_vor_div(Geom g, const double *__restrict__ coef, const double *__restrict__ S, int C, int col_u,
-                               int col_v, double2 *__restrict__ vor, double2 *__restrict__ div, int nlev) {
+                               int col_v, double2 *__restrict__ vor, double2 *__restrict__ div, int nlev, int mask) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t tot = (size_t)g.Ml * g.N1 * nlev;
   if (idx >= tot) return;
@@ -617,7 +620,7 @@ __global__ void k_spec_vor_div(Geom g, const double *__restrict__ coef, const do
   const size_t mn = idx / nlev;
   const int n = mn % g.N1, ml = mn / g.N1;
   double2 vo, dv;
-  alpha_pair(g, coef, S, C, mn, ml, n, col_u + k, col_v + k, vo, dv);
+  alpha_pair(g, coef, S, C, mn, ml, n, col_u + k, col_v + k, vo, dv, mask != 0);
   vor[idx] = vo;
   div[idx] = dv;
 }
@@ -649,8 +652,24 @@ void launch_spec_unpack(const Geom &g, const Dev &d, const double *S, double *st
 void launch_spec_ucos_vcos(const Geom &g, const Dev &d, const double *vor, const double *div, double *S, int C, int col_u, int col_v, int nlev, hipStream_t s) {
   hipLaunchKernelGGL(k_spec_ucos_vcos, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, (const double2 *)vor, (const double2 *)div, S, C, col_u, col_v, nlev);
 }
-void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s) {
-  hipLaunchKernelGGL(k_spec_vor_div, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, S, C, col_u, col_v, (double2 *)vor, (double2 *)div, nlev);
+void launch_spec_vor_div(const Geom &g, const Dev &d, const double *S, int C, int col_u, int col_v, double *vor, double *div, int nlev, hipStream_t s, int mask) {
+  hipLaunchKernelGGL(k_spec_vor_div, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, S, C, col_u, col_v, (double2 *)vor, (double2 *)div, nlev, mask);
+}
+// compute_laplacian (spherical.F90:354-406): (-eigen_laplacian)**power, 0 where the eigenvalue is 0 for power < 0
+__global__ void k_spec_laplacian(Geom g, const double *__restrict__ coef, const double2 *__restrict__ in,
+                                 double2 *__restrict__ out, int nlev, int power) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)g.Ml * g.N1 * nlev;
+  if (idx >= tot) return;
+  const size_t mn = idx / nlev;
+  const double e = -coef[(size_t)C_EIG * g.Ml * g.N1 + mn];
+  double f = 1.0, b = e;
+  for (int p = power < 0 ? -power : power; p > 0; p >>= 1) { if (p & 1) f *= b; b *= b; }   // integer power by squaring
+  if (power < 0) f = (e != 0.0) ? 1.0 / f : 0.0;
+  out[idx] = cscale(f, in[idx]);
+}
+void launch_spec_laplacian(const Geom &g, const Dev &d, const double *in, double *out, int nlev, int power, hipStream_t s) {
+  hipLaunchKernelGGL(k_spec_laplacian, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, (const double2 *)in, (double2 *)out, nlev, power);
 }
 void launch_spec_gradient(const Geom &g, const Dev &d, const double *state, double *S, int C, int col_dx, int col_dy, int nlev, hipStream_t s) {
   hipLaunchKernelGGL(k_spec_gradient, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, d.coef, (const double2 *)state, S, C, col_dx, col_dy, nlev);
@@ -1249,6 +1268,75 @@ void launch_pressures_heights(const isca_dyn &h, const double *t, const double *
   hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, p_full, p_half, z_full, z_half);
 }
 
+// pressure_variables (press_and_geopot.F90:152-221, simmons_and_burridge): p_half, ln_p_half, p_full, ln_p_full
+__global__ void k_pressure_variables(Geom g, const double *__restrict__ pk, const double *__restrict__ bk,
+                                     const double *__restrict__ psg, double *p_half, double *ln_p_half, double *p_full,
+                                     double *ln_p_full) {
+  const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (c2 >= lev) return;
+  const double ps = psg[c2];
+  const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
+  double ph_k = pk[0] + bk[0] * ps, l_k = top0 ? 0.0 : log(ph_k);
+  p_half[c2] = ph_k; ln_p_half[c2] = l_k;
+  for (int k = 0; k < g.L; ++k) {
+    const double ph_n = pk[k + 1] + bk[k + 1] * ps, l_n = log(ph_n);
+    p_half[c2 + (k + 1) * lev] = ph_n; ln_p_half[c2 + (k + 1) * lev] = l_n;
+    const double lf = (top0 && k == 0) ? l_n - 1.0 : l_n - (1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k));
+    ln_p_full[c2 + k * lev] = lf; p_full[c2 + k * lev] = exp(lf);
+    ph_k = ph_n; l_k = l_n;
+  }
+}
+// compute_geopotential (press_and_geopot.F90:327-359), dry, flat surface
+__global__ void k_geopotential(Geom g, const double *__restrict__ pk, const double *__restrict__ t,
+                               const double *__restrict__ ln_p_half, const double *__restrict__ ln_p_full,
+                               double *geopot_full, double *geopot_half) {
+  const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (c2 >= lev) return;
+  const int L = g.L, ktop = (pk[0] == 0.0) ? 1 : 0;
+  double gh = 0.0;
+  geopot_half[c2 + (size_t)L * lev] = 0.0;
+  if (ktop == 1) geopot_half[c2] = 0.0;
+  for (int k = L - 1; k >= 0; --k) {
+    const double tk = t[c2 + k * lev], l1 = ln_p_half[c2 + (k + 1) * lev];
+    geopot_full[c2 + k * lev] = gh + RDGAS * tk * (l1 - ln_p_full[c2 + k * lev]);
+    if (k >= ktop) { gh = gh + RDGAS * tk * (l1 - ln_p_half[c2 + k * lev]); geopot_half[c2 + k * lev] = gh; }
+  }
+}
+void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full, hipStream_t s) {
+  hipLaunchKernelGGL(k_pressure_variables, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, ps, p_half, ln_p_half, p_full, ln_p_full);
+}
+void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s) {
+  hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, t, ln_p_half, ln_p_full, gf, gh);
+}
+// mass_weighted_global_integral (global_integral.F90:49-81): per-latitude sums of wts * sum_k field*dp, one block per row
+__global__ void k_mass_weighted_rows(Geom g, const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                     const double *__restrict__ wts, const double *__restrict__ f,
+                                     const double *__restrict__ psg, double *__restrict__ rows) {
+  __shared__ double sh[1024];
+  const int jl = blockIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < g.I; i += blockDim.x) {
+    const size_t c2 = (size_t)jl * g.I + i;
+    const double ps = psg[c2];
+    double col = 0.0;
+    for (int k = 0; k < g.L; ++k) col += f[c2 + k * lev] * (dpk[k] + dbk[k] * ps);
+    acc += col;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = blockDim.x >> 1; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rows[jl] = wts[jl] * sh[0];
+}
+void launch_mass_weighted_rows(const isca_dyn &h, const double *f, const double *ps, double *rows, hipStream_t s) {
+  hipLaunchKernelGGL(k_mass_weighted_rows, dim3(h.g.Jl), dim3(256), 0, s, h.g, h.d.dpk, h.d.dbk, h.d.wts_lat_l, f, ps, rows);
+}
+
 __global__ void k_hadv_combine(size_t n, const double *u, const double *v, const double *dx, const double *dy, double *tend) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) tend[i] = tend[i] - u[i] * dx[i] - v[i] * dy[i];
@@ -1286,9 +1374,13 @@ struct TracerArgs {
   double dx, dt, flux, rdamp, robert;
 };
 
-__device__ __forceinline__ double tr_q0(const TracerArgs &a, const Geom &g, int k, size_t q, size_t c2) {
+// tracer_source_sink (hs_forcing.F90:683-724): surface flux into the lowest level, linear sink
+__device__ __forceinline__ double tr_source_sink(const TracerArgs &a, const Geom &g, int k, size_t c2, double tr_atm) {
   const double src = (k == g.L - 1) ? a.flux / (a.dpk[k] + a.dbk[k] * a.ps_cur[c2]) : 0.0;
-  return a.trp[q] + a.dt * (src - a.rdamp * a.tratm_p[q]);
+  return src - a.rdamp * tr_atm;
+}
+__device__ __forceinline__ double tr_q0(const TracerArgs &a, const Geom &g, int k, size_t q, size_t c2) {
+  return a.trp[q] + a.dt * tr_source_sink(a, g, k, c2, a.tratm_p[q]);
 }
 __device__ __forceinline__ double vl_limit(double slope, double qm, double q0, double qp) {
   const double q_min = fmin(fmin(qm, q0), qp), q_max = fmax(fmax(qm, q0), qp);
@@ -1637,6 +1729,49 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
   }
 #undef LT
+}
+
+// The same two kernels on caller fields (C-ABI entry points isca_a_grid_horiz_advection / isca_vert_advection_ppm):
+// no source/sink, so the kernels return q + dt * tendency of the pure advection operator.
+void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, const double *q, const double *ps, double dt, double *q_new, hipStream_t s) {
+  const Geom &g = h.g;
+  StepScalars sc{}; sc.delta_t = dt;
+  TracerArgs a = tracer_args(h, sc);
+  a.ua = u; a.va = v; a.trp = q; a.tratm_p = q; a.trh = q_new; a.ps_cur = ps;   // ps only enters the (zero) surface flux
+  a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
+  const size_t ldsh = (size_t)(3 * (TR_RB + 4) + (TR_RB + 2) + 3) * g.I * sizeof(double);
+  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+}
+void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
+                        double *dummy_a, double *dummy_b, hipStream_t s) {
+  const Geom &g = h.g;
+  StepScalars sc{}; sc.delta_t = dt;
+  TracerArgs a = tracer_args(h, sc);
+  a.trh = const_cast<double *>(r); a.wg = w; a.ps_cur = ps; a.ps_prev = ps; a.trp = dummy_a; a.tratm_p = dummy_a;
+  a.tr_cur = dummy_b; a.tr_fut = r_new; a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
+  const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;
+  const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64)), block(64 * NW);
+#define LT(N) hipLaunchKernelGGL(k_tracer_vert<N>, grid, block, 0, s, g, a)
+  switch (CH) {
+    case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
+    case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
+  }
+#undef LT
+}
+// tracer_source_sink (hs_forcing.F90:683-724) on caller fields: rst += flux/dp at the lowest level - tr/sink
+__global__ void k_tracer_source_sink(Geom g, TracerArgs a, const double *__restrict__ tr, double *__restrict__ rdt) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (idx >= lev * g.L) return;
+  const int k = idx / lev;
+  const size_t c2 = idx % lev;
+  rdt[idx] += tr_source_sink(a, g, k, c2, tr[idx]);
+}
+void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s) {
+  StepScalars sc{};
+  TracerArgs a = tracer_args(h, sc);
+  a.ps_cur = ps;
+  hipLaunchKernelGGL(k_tracer_source_sink, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, tr, rdt);
 }
 
 // =====================================================================================================

@@ -88,6 +88,18 @@ def load_library():
         "isca_area_weighted_global_mean": [H, dp, dp],
         "isca_hs_forcing": [H, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp],
         "isca_bench_transform_pair": [H, C.c_int, C.c_int, dp, dp],
+        "isca_compute_laplacian": [H, dp, dp, C.c_int, C.c_int],
+        "isca_compute_gradient_cos": [H, dp, dp, dp, C.c_int],
+        "isca_compute_ucos_vcos": [H, dp, dp, dp, dp, C.c_int],
+        "isca_compute_vor_div": [H, dp, dp, dp, dp, C.c_int],
+        "isca_triangular_truncation": [H, dp, C.c_int],
+        "isca_divide_by_cos": [H, dp, C.c_int, C.c_int],
+        "isca_mass_weighted_global_integral": [H, dp, dp, dp],
+        "isca_pressure_variables": [H, dp, dp, dp, dp, dp],
+        "isca_compute_geopotential": [H, dp, dp, dp, dp, dp],
+        "isca_a_grid_horiz_advection": [H, dp, dp, dp, C.c_double, dp],
+        "isca_vert_advection_ppm": [H, C.c_double, dp, dp, dp, dp],
+        "isca_hs_tracer_source_sink": [H, dp, dp, dp],
         "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     }
     for name, argtypes in sig.items():
@@ -108,6 +120,9 @@ EXPORTED_SYMBOLS = [
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
     "isca_bench_transform_pair", "isca_dyn_kernel_times",
+    "isca_compute_laplacian", "isca_compute_gradient_cos", "isca_compute_ucos_vcos", "isca_compute_vor_div",
+    "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
+    "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -347,6 +362,104 @@ class DynCore:
         outs = [np.zeros_like(arrs[2]) if x is None else np.array(x, dtype=np.float64, copy=True) for x in (udt, vdt, tdt)]
         self._check(self.lib.isca_hs_forcing(self._h, float(dt), *[_dptr(a) for a in arrs], *[_dptr(o) for o in outs]))
         return tuple(outs)
+
+    # -- components of the step on caller fields (spherical_mod / press_and_geopot_mod / fv_advection_mod / ...)
+    def _spec(self, a):
+        a, two_d = self._nlev(a, 3)
+        return np.ascontiguousarray(a, dtype=np.complex128), two_d
+
+    def _spec_call(self, fn, ins, nout, *extra):
+        arrs, two_d = zip(*[self._spec(a) for a in ins])
+        outs = [np.zeros_like(arrs[0]) for _ in range(nout)]
+        self._check(fn(self._h, *[_dptr(a.view(np.float64)) for a in arrs], *[_dptr(o.view(np.float64)) for o in outs],
+                       arrs[0].shape[0], *extra))
+        outs = [o[0] if two_d[0] else o for o in outs]
+        return outs[0] if nout == 1 else tuple(outs)
+
+    def compute_laplacian(self, spherical, power: int = 1):
+        return self._spec_call(self.lib.isca_compute_laplacian, [spherical], 1, int(power))
+
+    def compute_gradient_cos(self, spherical):
+        return self._spec_call(self.lib.isca_compute_gradient_cos, [spherical], 2)
+
+    def compute_lon_deriv_cos(self, spherical):
+        return self.compute_gradient_cos(spherical)[0]
+
+    def compute_lat_deriv_cos(self, spherical):
+        return self.compute_gradient_cos(spherical)[1]
+
+    def compute_ucos_vcos(self, vorticity, divergence):
+        return self._spec_call(self.lib.isca_compute_ucos_vcos, [vorticity, divergence], 2)
+
+    def compute_vor_div(self, u_div_cos, v_div_cos):
+        return self._spec_call(self.lib.isca_compute_vor_div, [u_div_cos, v_div_cos], 2)
+
+    def triangular_truncation(self, spherical):
+        a, two_d = self._spec(spherical)
+        a = a.copy()
+        self._check(self.lib.isca_triangular_truncation(self._h, _dptr(a.view(np.float64)), a.shape[0]))
+        return a[0] if two_d else a
+
+    def divide_by_cos(self, grid, power: int = 1):
+        g, two_d = self._nlev(grid, 3)
+        g = np.array(g, dtype=np.float64, copy=True, order="C")
+        self._check(self.lib.isca_divide_by_cos(self._h, _dptr(g), g.shape[0], power))
+        return g[0] if two_d else g
+
+    def divide_by_cos2(self, grid):
+        return self.divide_by_cos(grid, 2)
+
+    def mass_weighted_global_integral(self, field, surf_press):
+        f = np.ascontiguousarray(field, dtype=np.float64); ps = np.ascontiguousarray(surf_press, dtype=np.float64)
+        if f.shape != (self.L, self.Jl, self.I) or ps.shape != (self.Jl, self.I):
+            raise IscaError("mass_weighted_global_integral: field (lev,lat,lon) and surf_press (lat,lon) expected")
+        out = C.c_double()
+        self._check(self.lib.isca_mass_weighted_global_integral(self._h, _dptr(f), _dptr(ps), C.cast(C.byref(out), C.POINTER(C.c_double))))
+        return out.value
+
+    def pressure_variables(self, surf_p):
+        ps = np.ascontiguousarray(surf_p, dtype=np.float64)
+        if ps.shape != (self.Jl, self.I):
+            raise IscaError("pressure_variables: surf_p (lat,lon) expected")
+        ph = np.zeros((self.L + 1, self.Jl, self.I)); lph = np.zeros_like(ph)
+        pf = np.zeros((self.L, self.Jl, self.I)); lpf = np.zeros_like(pf)
+        self._check(self.lib.isca_pressure_variables(self._h, _dptr(ps), _dptr(ph), _dptr(lph), _dptr(pf), _dptr(lpf)))
+        return ph, lph, pf, lpf
+
+    def compute_geopotential(self, t, ln_p_half, ln_p_full):
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (t, ln_p_half, ln_p_full)]
+        gf = np.zeros((self.L, self.Jl, self.I)); gh = np.zeros((self.L + 1, self.Jl, self.I))
+        self._check(self.lib.isca_compute_geopotential(self._h, *[_dptr(x) for x in a], _dptr(gf), _dptr(gh)))
+        return gf, gh
+
+    def _grid3(self, *arrs):
+        out = [np.ascontiguousarray(x, dtype=np.float64) for x in arrs]
+        for x in out:
+            if x.shape != (self.L, self.Jl, self.I):
+                raise IscaError(f"grid field of shape {(self.L, self.Jl, self.I)} expected, got {x.shape}")
+        return out
+
+    def a_grid_horiz_advection(self, u, v, q, dt, tendency=None):
+        u, v, q = self._grid3(u, v, q)
+        tend = np.zeros_like(q) if tendency is None else np.array(tendency, dtype=np.float64, copy=True, order="C")
+        self._check(self.lib.isca_a_grid_horiz_advection(self._h, _dptr(u), _dptr(v), _dptr(q), float(dt), _dptr(tend)))
+        return tend
+
+    def vert_advection_ppm(self, dt, w, surf_p, r):
+        (r,) = self._grid3(r)
+        w = np.ascontiguousarray(w, dtype=np.float64); ps = np.ascontiguousarray(surf_p, dtype=np.float64)
+        if w.shape != (self.L + 1, self.Jl, self.I) or ps.shape != (self.Jl, self.I):
+            raise IscaError("vert_advection_ppm: w (lev+1,lat,lon) and surf_p (lat,lon) expected")
+        rdt = np.zeros_like(r)
+        self._check(self.lib.isca_vert_advection_ppm(self._h, float(dt), _dptr(w), _dptr(ps), _dptr(r), _dptr(rdt)))
+        return rdt
+
+    def hs_tracer_source_sink(self, surf_p, r, rdt=None):
+        (r,) = self._grid3(r)
+        ps = np.ascontiguousarray(surf_p, dtype=np.float64)
+        out = np.zeros_like(r) if rdt is None else np.array(rdt, dtype=np.float64, copy=True, order="C")
+        self._check(self.lib.isca_hs_tracer_source_sink(self._h, _dptr(ps), _dptr(r), _dptr(out)))
+        return out
 
     # -- measurement
     def bench_transform_pair(self, nfields: int, reps: int = 20):

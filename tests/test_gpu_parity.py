@@ -342,3 +342,41 @@ def test_experiment_restart_chaining(tmp_path):
             assert np.array_equal(cores[0].get(k, tl), cores[1].get(k, tl)), (k, tl)
     for c in cores:
         c.close()
+
+
+# ------------------------------------------------------------------ every public routine on the path, one by one
+@pytest.mark.parametrize("name,res,L", [("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6)])
+def test_golden_components(golden_dir, name, res, L):
+    """The reference's own outputs of the routines its callers use one at a time (spherical_mod operators,
+    press_and_geopot_mod, global_integral_mod, fv_advection_mod, vert_advection_mod PPM, tracer_source_sink),
+    against the C-ABI entry points that run the step's kernels on caller fields."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    dc = make(res, L)
+    sa, sb, ga, gb, ps, T = g["in_spec_a"], g["in_spec_b"], g["in_grid_a"], g["in_grid_b"], g["in_ps"], g["in_temp"]
+    assert rel(dc.compute_laplacian(sa), g["out_laplacian_a"]) < 1e-14                       # spherical.F90:354
+    dx, dy = dc.compute_gradient_cos(sa)                                                     # spherical.F90:270
+    assert rel(dx, g["out_gradcos_dx_a"]) < 1e-14 and rel(dy, g["out_gradcos_dy_a"]) < 1e-14
+    assert np.array_equal(dc.compute_lon_deriv_cos(sa), dx) and np.array_equal(dc.compute_lat_deriv_cos(sa[0]), dy[0])
+    uc, vc = dc.compute_ucos_vcos(sa, sb)                                                    # spherical.F90:409
+    assert rel(uc, g["out_ucos"]) < 1e-14 and rel(vc, g["out_vcos"]) < 1e-14
+    vo, di = dc.compute_vor_div(sa, sb)                                                      # spherical.F90:472
+    assert rel(vo, g["out_vor_from_ucos"]) < 1e-14 and rel(di, g["out_div_from_ucos"]) < 1e-14
+    m, n = np.meshgrid(np.arange(dc.M1), np.arange(dc.N1))
+    tri = (m + n <= dc.cfg.num_spherical - 1)
+    full = np.ones((2, dc.N1, dc.M1), dtype=np.complex128) * (1 + 2j)
+    assert np.array_equal(dc.triangular_truncation(full), full * tri)                        # spherical.F90:564
+    cosm = 1.0 / np.sqrt(1.0 - dc.table("sin_lat") ** 2)
+    assert rel(dc.divide_by_cos(ga), ga * cosm[None, :, None]) < 1e-15                       # transforms.F90:599
+    assert rel(dc.divide_by_cos2(ga[0]), ga[0] * cosm[:, None] ** 2) < 1e-15
+    assert abs(dc.mass_weighted_global_integral(ga, ps) / g["out_mwgi"][0] - 1) < 1e-12      # global_integral.F90:49
+    ph, lph, pf, lpf = dc.pressure_variables(ps)                                             # press_and_geopot.F90:152
+    assert rel(ph, g["out_p_half"]) < 1e-15 and rel(lph, g["out_ln_p_half"]) < 1e-14
+    assert rel(pf, g["out_p_full"]) < 1e-13 and rel(lpf, g["out_ln_p_full"]) < 1e-14
+    gf, gh = dc.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"])              # press_and_geopot.F90:327
+    assert rel(gf, g["out_geopot_full"]) < 1e-13 and rel(gh, g["out_geopot_half"]) < 1e-13
+    assert rel(dc.hs_tracer_source_sink(ps, np.zeros_like(T)), g["out_hs_dt_tr"]) < 1e-13    # hs_forcing.F90:683
+    q = g["in_q"]
+    assert rel(dc.vert_advection_ppm(1200.0, g["in_wg"], ps, q), g["out_vadv_ppm"]) < 1e-12  # vert_advection.F90:301
+    assert rel(dc.a_grid_horiz_advection(ga, gb, q, 1200.0), g["out_hadv_fv"]) < 1e-12       # fv_advection.F90:126
+    assert rel(dc.a_grid_horiz_advection(ga, gb, q, 48000.0), g["out_hadv_fv_bigcfl"]) < 1e-12
+    dc.close()
