@@ -157,6 +157,13 @@ int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v,
 int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt);   /* vert_advection.F90:70-478, FINITE_VOLUME_PARABOLIC / ADVECTIVE_FORM, dz = dpk + dbk*surf_p */
 int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, const double *r, double *rdt);      /* hs_forcing.F90:683-724; rdt is accumulated */
 
+/* the three stages of the spectral update, run by the step's own kernel on caller data (num_levels 3-D arrays) */
+int isca_implicit_correction(isca_dyn_t *h, double *dt_divs, double *dt_ts, double *dt_ln_ps, const double *divs_previous,
+                             const double *divs_current, const double *ts_previous, const double *ts_current,
+                             const double *ln_ps_previous, const double *ln_ps_current, double delta_t);   /* implicit.F90:241-286 */
+int isca_compute_spectral_damping(isca_dyn_t *h, int which, const double *field_previous, double *dt_field, double delta_t);   /* spectral_damping.F90:172-291; which 0 generic, 1 vor, 2 div */
+int isca_leapfrog(isca_dyn_t *h, double *previous, double *current, const double *dt_field, double delta_t, double robert_coeff);   /* leapfrog.F90:58-105, A then B, future = previous */
+
 /* --- benchmarking helpers: transform pair with data resident in HBM ------------------------------
  * Runs `reps` (s2g, g2s) pairs over nfields level-fields on device buffers owned by the handle and
  * returns the average time of one pair in milliseconds measured with HIP events on the handle's

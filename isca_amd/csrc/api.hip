@@ -1155,6 +1155,66 @@ extern "C" int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, c
   API_END
 }
 
+// The three stages of the spectral update on caller data, run by the step's own kernel (k_spec_update).
+static void spec_stage(isca_dyn *h, int stage, double delta_t, double robert, const double *const host_st[4][3],
+                       double *const host_dt[4], bool want_state) {
+  require_single(h, "spectral stage");
+  const Geom &g = h->g;
+  if (g.L > 64) fail("spectral stages: num_levels <= 64");
+  const size_t n3 = (size_t)g.Ml * g.N1 * g.L * 2, n2 = (size_t)g.Ml * g.N1 * 2;
+  DevTmp t(h);
+  double *st[4][3], *dt[4];
+  for (int v = 0; v < 4; ++v) {
+    const int nlev = (v == 3) ? 1 : g.L;
+    for (int tl = 0; tl < 3; ++tl) {
+      st[v][tl] = (tl == 2) ? st[v][0] : t.alloc(v == 3 ? n2 : n3, true);     // future shares the previous slot (leapfrog.F90:58)
+      if (tl < 2 && host_st[v][tl]) spec_host_to_dev(h, host_st[v][tl], st[v][tl], nlev);
+    }
+    dt[v] = t.alloc(v == 3 ? n2 : n3, true);
+    if (host_dt[v]) spec_host_to_dev(h, host_dt[v], dt[v], nlev);
+  }
+  if (stage == 0) upload_wave_matrices(h, delta_t);
+  launch_spec_update_stage(*h, stage, delta_t, robert, st, dt, h->stream);
+  for (int v = 0; v < 4; ++v) {
+    const int nlev = (v == 3) ? 1 : g.L;
+    if (!want_state && host_dt[v]) spec_dev_to_host(h, dt[v], host_dt[v], nlev);
+    if (want_state) for (int tl = 0; tl < 2; ++tl)
+      if (host_st[v][tl]) spec_dev_to_host(h, st[v][tl], const_cast<double *>(host_st[v][tl]), nlev);
+  }
+}
+// implicit.F90:241-286 implicit_correction(dt_divs, dt_ts, dt_ln_ps, divs, ts, ln_ps, delta_t, previous, current)
+extern "C" int isca_implicit_correction(isca_dyn_t *h, double *dt_divs, double *dt_ts, double *dt_ln_ps, const double *divs_previous,
+                                        const double *divs_current, const double *ts_previous, const double *ts_current,
+                                        const double *ln_ps_previous, const double *ln_ps_current, double delta_t) {
+  API_BEGIN
+  const double *const st[4][3] = {{nullptr, nullptr, nullptr}, {divs_previous, divs_current, nullptr},
+                                  {ts_previous, ts_current, nullptr}, {ln_ps_previous, ln_ps_current, nullptr}};
+  double *const dt[4] = {nullptr, dt_divs, dt_ts, dt_ln_ps};
+  spec_stage(h, 0, delta_t, h->cfg.robert_coeff, st, dt, false);
+  API_END
+}
+// spectral_damping.F90:172-291 compute_spectral_damping (which = 0), _vor (1), _div (2): dt <- (dt - c*field)/(1 + c*delta_t)
+extern "C" int isca_compute_spectral_damping(isca_dyn_t *h, int which, const double *field_previous, double *dt_field, double delta_t) {
+  API_BEGIN
+  if (which < 0 || which > 2) fail("compute_spectral_damping: which = 0 (temperature/tracer), 1 (vorticity), 2 (divergence)");
+  const int v = (which == 0) ? 2 : which - 1;
+  const double *st[4][3] = {};
+  double *dt[4] = {};
+  st[v][0] = field_previous; dt[v] = dt_field;
+  spec_stage(h, 1, delta_t, h->cfg.robert_coeff, st, dt, false);
+  API_END
+}
+// leapfrog.F90:58-105 leapfrog_2level_A + leapfrog_2level_B with future = previous (raw_filter_coeff = 1):
+// on return `previous` holds the new time level and `current` the Robert-filtered one
+extern "C" int isca_leapfrog(isca_dyn_t *h, double *previous, double *current, const double *dt_field, double delta_t, double robert_coeff) {
+  API_BEGIN
+  const double *st[4][3] = {};
+  double *dt[4] = {};
+  st[2][0] = previous; st[2][1] = current; dt[2] = const_cast<double *>(dt_field);
+  spec_stage(h, 2, delta_t, robert_coeff, st, dt, true);
+  API_END
+}
+
 // ---------------------------------------------------------------------------------------------------
 // benchmarking helpers
 // ---------------------------------------------------------------------------------------------------

@@ -755,6 +755,10 @@ __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, d
   dt_p = make_double2(-wave_last(inc.x), -wave_last(inc.y));
 }
 
+// MODE 0 is the step.  The other modes run parts of the same code on caller data for the C-ABI entry points
+// isca_implicit_correction / isca_compute_spectral_damping / isca_leapfrog (tendencies given in dtvor..dtlp):
+enum { SU_GIVEN = 1, SU_NO_IMPLICIT = 2, SU_NO_DAMPING = 4, SU_STOP_IMPLICIT = 8, SU_STOP_DAMPING = 16 };
+template <int MODE>
 __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2 *xsb = (double2 *)smem;                    // [4][64] per-wavefront vector for the wave-matrix product
@@ -785,54 +789,67 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   double2 vprev = act ? a.vors_p[idx] : zero, vcur = act ? a.vors_c[idx] : zero;
   const double2 lprev = a.lnps_p[mn], lcur = a.lnps_c[mn];
   // --- spectral tendencies of the forward batch (spectral_dynamics.F90:874,891,900-904)
-  double2 dt_vor, dt_div, dt_t = zero;
-  alpha_pair(g, coef, a.Sf, a.C, mn, ml, n, kk, L + kk, dt_vor, dt_div);
-  if (act) {
-    const double2 E = *(const double2 *)(a.Sf + mn * a.C + 2 * (3 * L + kk));
-    dt_div = cadd(dt_div, cscale(eig, E));            // dt_divs - laplacian(Phi+KE), laplacian = -eigen
-    dt_t = *(const double2 *)(a.Sf + mn * a.C + 2 * (2 * L + kk));
-    a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t;      // kept for diagnostics/tests
-  } else { dt_vor = zero; dt_div = zero; }
-  double2 dt_lp = *(const double2 *)(a.Sf + mn * a.C + 2 * (4 * L));
-  if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
-  // --- adjust_dt_divs (:289-325)
-  double2 dps, dts;
-  lin_tp(csub(dprev, dcur), lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
-  dt_t = cadd(dt_t, dts);
-  dt_lp = cadd(dt_lp, cscale(1.0 / a.ref_p, dps));
-  const double2 ts_temp = cadd(csub(tprev, tcur), cscale(a.xi, dt_t));
-  const double2 ps_temp = cadd(csub(lprev, lcur), cscale(a.xi, dt_lp));
-  {  // linear_geopotential (:329-359) with del_ln_p = 0: suffix sums of RDGAS*T'*dlog3 below the level
-    const double2 av = (act && lane >= 1) ? cscale(RDGAS * dlog3, ts_temp) : zero;
-    double2 inc;
-    inc.x = wave_incl_scan(av.x, lane);
-    inc.y = wave_incl_scan(av.y, lane);
-    const double2 tot = make_double2(wave_last(inc.x), wave_last(inc.y));
-    const double2 below = csub(tot, inc);                                  // sum over k' > k
-    const double2 geo = cadd(below, cscale(RDGAS * dlogf, ts_temp));
-    const double hp = hk * a.ref_p;
-    dt_div = cadd(dt_div, cscale(eig, make_double2(geo.x + hp * ps_temp.x, geo.y + hp * ps_temp.y)));
+  double2 dt_vor, dt_div, dt_t = zero, dt_lp;
+  if (MODE & SU_GIVEN) {
+    dt_vor = act ? a.dtvor[idx] : zero; dt_div = act ? a.dtdiv[idx] : zero; dt_t = act ? a.dtT[idx] : zero;
+    dt_lp = a.dtlp[mn];
+  } else {
+    alpha_pair(g, coef, a.Sf, a.C, mn, ml, n, kk, L + kk, dt_vor, dt_div);
+    if (act) {
+      const double2 E = *(const double2 *)(a.Sf + mn * a.C + 2 * (3 * L + kk));
+      dt_div = cadd(dt_div, cscale(eig, E));            // dt_divs - laplacian(Phi+KE), laplacian = -eigen
+      dt_t = *(const double2 *)(a.Sf + mn * a.C + 2 * (2 * L + kk));
+      a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t;      // kept for diagnostics/tests
+    } else { dt_vor = zero; dt_div = zero; }
+    dt_lp = *(const double2 *)(a.Sf + mn * a.C + 2 * (4 * L));
+    if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
   }
-  {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); ws[k'][k] in LDS, x broadcast from LDS
-    double2 *xs = xsb + wave * 64;
-    xs[lane] = act ? dt_div : zero;
-    __syncthreads();                                  // matrix copy + x vectors visible
-    double2 out = zero;
-#pragma unroll 8
-    for (int k2 = 0; k2 < L; ++k2) {
-      const double2 x = xs[k2];
-      const double w = ws[k2 * L + kk];
-      out.x += w * x.x;
-      out.y += w * x.y;
+  double2 dps, dts;
+  if (!(MODE & SU_NO_IMPLICIT)) {
+    // --- adjust_dt_divs (:289-325)
+    lin_tp(csub(dprev, dcur), lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
+    dt_t = cadd(dt_t, dts);
+    dt_lp = cadd(dt_lp, cscale(1.0 / a.ref_p, dps));
+    const double2 ts_temp = cadd(csub(tprev, tcur), cscale(a.xi, dt_t));
+    const double2 ps_temp = cadd(csub(lprev, lcur), cscale(a.xi, dt_lp));
+    {  // linear_geopotential (:329-359) with del_ln_p = 0: suffix sums of RDGAS*T'*dlog3 below the level
+      const double2 av = (act && lane >= 1) ? cscale(RDGAS * dlog3, ts_temp) : zero;
+      double2 inc;
+      inc.x = wave_incl_scan(av.x, lane);
+      inc.y = wave_incl_scan(av.y, lane);
+      const double2 tot = make_double2(wave_last(inc.x), wave_last(inc.y));
+      const double2 below = csub(tot, inc);                                  // sum over k' > k
+      const double2 geo = cadd(below, cscale(RDGAS * dlogf, ts_temp));
+      const double hp = hk * a.ref_p;
+      dt_div = cadd(dt_div, cscale(eig, make_double2(geo.x + hp * ps_temp.x, geo.y + hp * ps_temp.y)));
     }
-    dt_div = act ? out : zero;
+    {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); ws[k'][k] in LDS, x broadcast from LDS
+      double2 *xs = xsb + wave * 64;
+      xs[lane] = act ? dt_div : zero;
+      __syncthreads();                                  // matrix copy + x vectors visible
+      double2 out = zero;
+  #pragma unroll 8
+      for (int k2 = 0; k2 < L; ++k2) {
+        const double2 x = xs[k2];
+        const double w = ws[k2 * L + kk];
+        out.x += w * x.x;
+        out.y += w * x.y;
+      }
+      dt_div = act ? out : zero;
+    }
+    if (idle) return;
+    lin_tp(dt_div, lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
+    dt_t = cadd(dt_t, cscale(a.xi, dts));
+    dt_lp = cadd(dt_lp, cscale(a.xi / a.ref_p, dps));
   }
   if (idle) return;
-  lin_tp(dt_div, lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
-  dt_t = cadd(dt_t, cscale(a.xi, dts));
-  dt_lp = cadd(dt_lp, cscale(a.xi / a.ref_p, dps));
+  if (MODE & SU_STOP_IMPLICIT) {
+    if (act) { a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }
+    if (lane == 0) a.dtlp[mn] = dt_lp;
+    return;
+  }
   // --- damping
-  {
+  if (!(MODE & SU_NO_DAMPING)) {
     const double dmp = COEF(C_DAMP, ml, n);
     const double cf = 1.0 / (1.0 + dmp * a.delta_t);
     dt_vor = cscale(cf, csub(dt_vor, cscale(dmp, vprev)));
@@ -845,6 +862,10 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
       dt_vor = cscale(1.0 / (1.0 + sv * a.delta_t), csub(dt_vor, cscale(sv, vprev)));
       dt_div = cscale(1.0 / (1.0 + sd * a.delta_t), csub(dt_div, cscale(sd, dprev)));
     }
+  }
+  if (MODE & SU_STOP_DAMPING) {
+    if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }
+    return;
   }
   // --- leapfrog_2level_A then _B (Robert filter, raw_filter_coeff = 1)
   const double rc = a.robert, dtt = a.delta_t;
@@ -868,8 +889,7 @@ void launch_spec_tendencies(const isca_dyn &h, hipStream_t s) {
   hipLaunchKernelGGL(k_spec_tendencies, grid1d((size_t)g.Ml * g.N1 * g.L), dim3(256), 0, s, g, h.d.coef, h.d.Sf, h.Cf,
                      (double2 *)h.d.s_dtvor, (double2 *)h.d.s_dtdiv, (double2 *)h.d.s_dtT, (double2 *)h.d.s_dtlp);
 }
-void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  const Geom &g = h.g;
+static SpecUpdateArgs spec_update_args(const isca_dyn &h, const StepScalars &sc) {
   SpecUpdateArgs a;
   a.vors_p = (double2 *)h.d.vors[sc.prev]; a.vors_c = (double2 *)h.d.vors[sc.cur]; a.vors_f = (double2 *)h.d.vors[sc.fut];
   a.divs_p = (double2 *)h.d.divs[sc.prev]; a.divs_c = (double2 *)h.d.divs[sc.cur]; a.divs_f = (double2 *)h.d.divs[sc.fut];
@@ -881,8 +901,32 @@ void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.Sf = h.d.Sf; a.C = h.Cf;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
+  return a;
+}
+void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  const SpecUpdateArgs a = spec_update_args(h, sc);
   const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
-  hipLaunchKernelGGL(k_spec_update, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, a);
+  hipLaunchKernelGGL(k_spec_update<0>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, a);
+}
+// parts of the same kernel on caller data: stage 0 implicit_correction, 1 spectral damping, 2 leapfrog A+B.
+// st[v][t]: v = vors, divs, ts, ln_ps; t = previous, current, future.  dtend: dt_vors, dt_divs, dt_ts, dt_ln_ps.
+void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, double robert, double *const st[4][3],
+                              double *const dtend[4], hipStream_t s) {
+  const Geom &g = h.g;
+  StepScalars sc{}; sc.delta_t = delta_t; sc.xi = delta_t * h.cfg.alpha_implicit;
+  SpecUpdateArgs a = spec_update_args(h, sc);
+  a.vors_p = (double2 *)st[0][0]; a.vors_c = (double2 *)st[0][1]; a.vors_f = (double2 *)st[0][2];
+  a.divs_p = (double2 *)st[1][0]; a.divs_c = (double2 *)st[1][1]; a.divs_f = (double2 *)st[1][2];
+  a.ts_p = (double2 *)st[2][0]; a.ts_c = (double2 *)st[2][1]; a.ts_f = (double2 *)st[2][2];
+  a.lnps_p = (double2 *)st[3][0]; a.lnps_c = (double2 *)st[3][1]; a.lnps_f = (double2 *)st[3][2];
+  a.dtvor = (double2 *)dtend[0]; a.dtdiv = (double2 *)dtend[1]; a.dtT = (double2 *)dtend[2]; a.dtlp = (double2 *)dtend[3];
+  a.robert = robert;
+  const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
+  const dim3 grid((unsigned)(h.n_active / 4)), block(256);
+  if (stage == 0) hipLaunchKernelGGL(k_spec_update<SU_GIVEN | SU_STOP_IMPLICIT>, grid, block, lds, s, g, a);
+  else if (stage == 1) hipLaunchKernelGGL(k_spec_update<SU_GIVEN | SU_NO_IMPLICIT | SU_STOP_DAMPING>, grid, block, lds, s, g, a);
+  else hipLaunchKernelGGL(k_spec_update<SU_GIVEN | SU_NO_IMPLICIT | SU_NO_DAMPING>, grid, block, lds, s, g, a);
 }
 
 // -----------------------------------------------------------------------------------------------------

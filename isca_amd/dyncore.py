@@ -100,6 +100,9 @@ def load_library():
         "isca_a_grid_horiz_advection": [H, dp, dp, dp, C.c_double, dp],
         "isca_vert_advection_ppm": [H, C.c_double, dp, dp, dp, dp],
         "isca_hs_tracer_source_sink": [H, dp, dp, dp],
+        "isca_implicit_correction": [H, dp, dp, dp, dp, dp, dp, dp, dp, dp, C.c_double],
+        "isca_compute_spectral_damping": [H, C.c_int, dp, dp, C.c_double],
+        "isca_leapfrog": [H, dp, dp, dp, C.c_double, C.c_double],
         "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     }
     for name, argtypes in sig.items():
@@ -123,6 +126,7 @@ EXPORTED_SYMBOLS = [
     "isca_compute_laplacian", "isca_compute_gradient_cos", "isca_compute_ucos_vcos", "isca_compute_vor_div",
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
+    "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -460,6 +464,33 @@ class DynCore:
         out = np.zeros_like(r) if rdt is None else np.array(rdt, dtype=np.float64, copy=True, order="C")
         self._check(self.lib.isca_hs_tracer_source_sink(self._h, _dptr(ps), _dptr(r), _dptr(out)))
         return out
+
+    def _spec3(self, a, two_d=False):
+        a = np.array(a, dtype=np.complex128, copy=True, order="C")
+        want = (self.N1, self.M1) if two_d else (self.L, self.N1, self.M1)
+        if a.shape != want:
+            raise IscaError(f"spectral array of shape {want} expected, got {a.shape}")
+        return a
+
+    def implicit_correction(self, dt_divs, dt_ts, dt_ln_ps, divs, ts, ln_ps, delta_t):
+        """divs, ts, ln_ps: (previous, current) pairs.  Returns the corrected (dt_divs, dt_ts, dt_ln_ps)."""
+        o = [self._spec3(dt_divs), self._spec3(dt_ts), self._spec3(dt_ln_ps, True)]
+        i = [self._spec3(divs[0]), self._spec3(divs[1]), self._spec3(ts[0]), self._spec3(ts[1]),
+             self._spec3(ln_ps[0], True), self._spec3(ln_ps[1], True)]
+        self._check(self.lib.isca_implicit_correction(self._h, *[_dptr(x.view(np.float64)) for x in o + i], float(delta_t)))
+        return tuple(o)
+
+    def compute_spectral_damping(self, field_previous, dt_field, delta_t, kind="t"):
+        f, d = self._spec3(field_previous), self._spec3(dt_field)
+        which = {"t": 0, "vor": 1, "div": 2}[kind]
+        self._check(self.lib.isca_compute_spectral_damping(self._h, which, _dptr(f.view(np.float64)), _dptr(d.view(np.float64)), float(delta_t)))
+        return d
+
+    def leapfrog(self, previous, current, dt_field, delta_t, robert_coeff=0.04):
+        """-> (new level, Robert-filtered current)"""
+        p, c, d = self._spec3(previous), self._spec3(current), self._spec3(dt_field)
+        self._check(self.lib.isca_leapfrog(self._h, *[_dptr(x.view(np.float64)) for x in (p, c, d)], float(delta_t), float(robert_coeff)))
+        return p, c
 
     # -- measurement
     def bench_transform_pair(self, nfields: int, reps: int = 20):

@@ -379,4 +379,13 @@ def test_golden_components(golden_dir, name, res, L):
     assert rel(dc.vert_advection_ppm(1200.0, g["in_wg"], ps, q), g["out_vadv_ppm"]) < 1e-12  # vert_advection.F90:301
     assert rel(dc.a_grid_horiz_advection(ga, gb, q, 1200.0), g["out_hadv_fv"]) < 1e-12       # fv_advection.F90:126
     assert rel(dc.a_grid_horiz_advection(ga, gb, q, 48000.0), g["out_hadv_fv_bigcfl"]) < 1e-12
+    # the three stages of the spectral update, run by the step's own kernel on the harness inputs
+    dtk = 1200.0
+    o1, o2, o3 = dc.implicit_correction(g["in_spec_e"], g["in_spec_f"], g["in_spec2_c"], (sa, sb), (g["in_spec_c"], g["in_spec_d"]),
+                                        (g["in_spec2_a"], g["in_spec2_b"]), dtk)                 # implicit.F90:241
+    assert rel(o1, g["out_impl_dt_divs"]) < 1e-12 and rel(o2, g["out_impl_dt_ts"]) < 1e-12 and rel(o3, g["out_impl_dt_lnps"]) < 1e-12
+    for kind, key in (("vor", "out_damp_vor"), ("div", "out_damp_div"), ("t", "out_damp")):       # spectral_damping.F90:172
+        assert rel(dc.compute_spectral_damping(sa, g["in_spec_e"], dtk, kind), g[key]) < 1e-14
+    new, filt = dc.leapfrog(sa, sb, g["in_spec_e"], dtk, 0.04)                                   # leapfrog.F90:58-105
+    assert rel(new, g["out_leap_l1"]) < 1e-15 and rel(filt, g["out_leap_l2"]) < 1e-15
     dc.close()
