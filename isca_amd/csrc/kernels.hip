@@ -266,6 +266,18 @@ __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
   return ((((j >> lg) * Ml + ml) << lg) | (j & ((1 << lg) - 1))) * C;
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All column tiles of one
+// wavenumber share that wavenumber's Legendre table, so they are mapped onto the same XCD: the table then comes
+// from HBM once per XCD instead of once per tile.  T = column tiles (of 4 wavefronts) per wavenumber.
+__device__ __forceinline__ bool leg_block(int Ml, int T, int &ml, int &tile) {
+  const int lin = blockIdx.x, xcd = lin & 7, q = lin >> 3;
+  const int grp = q / T;
+  ml = xcd + 8 * grp;
+  tile = q - grp * T;
+  return ml < Ml;
+}
+static unsigned leg_grid(int Ml, int T) { return (unsigned)(8 * ((Ml + 7) / 8) * T); }
+
 // Analysis (Fourier -> spectral).  Block = 4 wavefronts = 4 column tiles of one wavenumber m; the A operand
 // (P*w of this m, one parity at a time, only the rows the triangle needs) is staged in LDS, the folded
 // B operand lives in registers, so the MFMA loop touches no global memory.  32-bit index arithmetic throughout:
@@ -273,13 +285,15 @@ __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
 template <int JH4, bool BOTH>
 __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pw, const double *__restrict__ Fs,
-                                                      double *__restrict__ S, int C, int full) {
+                                                      double *__restrict__ S, int C, int full, int T) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *As = (double *)smem;                      // [Jh][NHP], one parity at a time
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ml = blockIdx.y, m = m_local[ml];
+  int ml, tile_x;
+  if (!leg_block(g.Ml, T, ml, tile_x)) return;
+  const int m = m_local[ml];
   if (m < 0) return;
-  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  const int c0 = (tile_x * 4 + wave) * 16;
   const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
   const bool cok = c < C;
   const int lg = g.log2Jl, NHP = g.NHP;
@@ -334,14 +348,16 @@ enum { LC_UVC = 0, LC_UVM, LC_UVP, LC_DX, LC_DYM, LC_DYP, LC_ONE, LC_ZERO, LC_RO
 template <int JT, int NKS, bool BOTH, bool FUSED>
 __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
                                                       const double *__restrict__ pinv, const double *__restrict__ S,
-                                                      double *__restrict__ Fs, int C, int full, SynthSrc src) {
+                                                      double *__restrict__ Fs, int C, int full, SynthSrc src, int T) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *As = (double *)smem;                      // [NHP][Jh] per parity
   double *lc = As + (BOTH ? 2 : 1) * g.NHP * g.Jh;  // FUSED: [LC_ROWS][N1] operator coefficients of this m
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ml = blockIdx.y, m = m_local[ml];
+  int ml, tile_x;
+  if (!leg_block(g.Ml, T, ml, tile_x)) return;
+  const int m = m_local[ml];
   if (m < 0) return;
-  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  const int c0 = (tile_x * 4 + wave) * 16;
   const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
   const bool cok = c < C;
   const int nlim = full ? g.N1 : g.N1 - m;
@@ -495,10 +511,11 @@ static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42
 
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (mfma_ok(g, impl)) {
-    dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
+    const int T = ((C + 15) / 16 + 3) / 4;
+    dim3 grid(leg_grid(g.Ml, T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.Jh * g.NHP * sizeof(double);
-#define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full)
+#define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full, T)
     switch (g.Jh / 4) {
       case 4: LF(4, true); break;   case 8: LF(8, true); break;   case 16: LF(16, true); break;
       case 32: LF(32, false); break;
@@ -515,14 +532,15 @@ void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, doubl
   if (mfma_ok(g, impl)) {
     SynthSrc src = {nullptr, nullptr, nullptr, nullptr, d.coef};
     if (fused_tl >= 0) { src.vor = d.vors[fused_tl]; src.div = d.divs[fused_tl]; src.ts = d.ts[fused_tl]; src.lnps = d.lnps[fused_tl]; }
-    dim3 grid(((C + 15) / 16 + 3) / 4, g.Ml);
+    const int T = ((C + 15) / 16 + 3) / 4;
+    dim3 grid(leg_grid(g.Ml, T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.NHP * g.Jh * sizeof(double) + (size_t)LC_ROWS * g.N1 * sizeof(double);
     // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
 #define LI(JT, NKS, B)                                                                                                            \
   do {                                                                                                                            \
-    if (fused_tl >= 0) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, true>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src);  \
-    else hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, false>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src);               \
+    if (fused_tl >= 0) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, true>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src, T);  \
+    else hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, false>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src, T);            \
   } while (0)
     if (g.Jh == 16 && g.NHP == 16) LI(1, 4, true);
     else if (g.Jh == 32 && g.NHP == 32) LI(2, 8, true);
