@@ -9,6 +9,7 @@
 //   spectral work    [ml][n][C]
 //   spectral state   [ml][n][lev] complex
 #include "kernels.h"
+#include <cstdlib>
 
 namespace isca {
 
@@ -270,6 +271,7 @@ __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
 // wavenumber share that wavenumber's Legendre table, so they are mapped onto the same XCD: the table then comes
 // from HBM once per XCD instead of once per tile.  T = column tiles (of 4 wavefronts) per wavenumber.
 __device__ __forceinline__ bool leg_block(int Ml, int T, int &ml, int &tile) {
+  if (T < 0) { ml = blockIdx.x / (-T); tile = blockIdx.x - ml * (-T); return ml < Ml; }   // plain order (experiments)
   const int lin = blockIdx.x, xcd = lin & 7, q = lin >> 3;
   const int grp = q / T;
   ml = xcd + 8 * grp;
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
                                                       double *__restrict__ S, int C, int full, int T) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *As = (double *)smem;                      // [Jh][NHP], one parity at a time
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int ml, tile_x;
   if (!leg_block(g.Ml, T, ml, tile_x)) return;
   const int m = m_local[ml];
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *As = (double *)smem;                      // [NHP][Jh] per parity
   double *lc = As + (BOTH ? 2 : 1) * g.NHP * g.Jh;  // FUSED: [LC_ROWS][N1] operator coefficients of this m
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   int ml, tile_x;
   if (!leg_block(g.Ml, T, ml, tile_x)) return;
   const int m = m_local[ml];
@@ -511,8 +513,9 @@ static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42
 
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (mfma_ok(g, impl)) {
-    const int T = ((C + 15) / 16 + 3) / 4;
-    dim3 grid(leg_grid(g.Ml, T));
+    static const bool plain = getenv("ISCA_LEG_PLAIN") != nullptr;
+    const int T = (plain ? -1 : 1) * (((C + 15) / 16 + 3) / 4);
+    dim3 grid(leg_grid(g.Ml, plain ? -T : T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.Jh * g.NHP * sizeof(double);
 #define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full, T)
@@ -532,8 +535,9 @@ void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, doubl
   if (mfma_ok(g, impl)) {
     SynthSrc src = {nullptr, nullptr, nullptr, nullptr, d.coef};
     if (fused_tl >= 0) { src.vor = d.vors[fused_tl]; src.div = d.divs[fused_tl]; src.ts = d.ts[fused_tl]; src.lnps = d.lnps[fused_tl]; }
-    const int T = ((C + 15) / 16 + 3) / 4;
-    dim3 grid(leg_grid(g.Ml, T));
+    static const bool plain = getenv("ISCA_LEG_PLAIN") != nullptr;
+    const int T = (plain ? -1 : 1) * (((C + 15) / 16 + 3) / 4);
+    dim3 grid(leg_grid(g.Ml, plain ? -T : T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.NHP * g.Jh * sizeof(double) + (size_t)LC_ROWS * g.N1 * sizeof(double);
     // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double2 *xsb = (double2 *)smem;                    // [4][64] per-wavefront vector for the wave-matrix product
   double *ws = (double *)(xsb + 4 * 64);             // [L][L] transposed wave matrix of this block's total wavenumber
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int L = g.L;
   // the list is grouped by total wavenumber (padded with -1), so the 4 wavefronts of a block share one matrix
   const int mn0 = a.active[blockIdx.x * 4];
@@ -1052,11 +1056,20 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
 // everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
+#if defined(EXP_COL_NOSTORE)
+#define CST(dst, val) do { const double v__ = (val); if (v__ == 1.234e300) dst = v__; } while (0)
+#else
+#define CST(dst, val) dst = (val)
+#endif
+#if defined(EXP_COL_NOMATH)
+#define log(x) ((x) * 0.5)
+#define exp(x) ((x) * 0.5)
+#endif
 template <int CH>
 __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
-  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
   double *lds_dm = (double *)smem;          // [NW][64] chunk sums of dmean
   double *lds_a = lds_dm + NW * 64;         // [NW][64] chunk sums of RDGAS*T*dlog3
   double *lds_e = lds_a + NW * 64;          // [NW] energy partials
@@ -1069,29 +1082,48 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   const double dx_ps = ps * a.dxlp[c2], dy_ps = ps * a.dylp[c2];
   const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
   const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
+  // per-level constants of my chunk, read before the first store: afterwards the compiler could not keep them on the
+  // scalar path (possible aliasing with the outputs) and every level would wait on vector loads and on its stores
+  double dpk_r[CH], dbk_r[CH], pk_r[CH + 1], bk_r[CH + 1];
+#pragma unroll
+  for (int i = 0; i <= CH; ++i) {
+    const int k = min(k0 + i, L);
+    pk_r[i] = a.pk[k]; bk_r[i] = a.bk[k];
+    if (i < CH) { const int kk = min(k0 + i, L - 1); dpk_r[i] = a.dpk[kk]; dbk_r[i] = a.dbk[kk]; }
+  }
+  const double wts_j = a.wts[jl], cosm = a.cosm[jl], cor = a.coriolis[jl], rad_lat = a.rad_lat[jl];
   double u[CH], v[CH], t[CH], dm[CH];
+  // every global load of the block is issued here, before the barrier of the vertical scans: one memory
+  // round trip per block instead of two (the loads below the barrier could not start before it)
+  double upv[CH], vpv[CH], tpv[CH], vov[CH], dxv[CH], dyv[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int k = k0 + (i < nk ? i : 0);
     const size_t q = c2 + (size_t)k * lev;
     u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
-    const double dp = a.dpk[k] + a.dbk[k] * ps;
-    dm[i] = (i < nk) ? a.div[q] * dp + a.dbk[k] * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
+    upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q]; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q];
+    dm[i] = a.div[q];
   }
   // neighbours across the chunk boundary for the centred vertical fluxes
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
   if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
   if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {          // mass divergence of the layer (four_in_one :1064-1067)
+    const int k = k0 + (i < nk ? i : 0);
+    const double dp = dpk_r[i] + dbk_r[i] * ps;
+    dm[i] = (i < nk) ? dm[i] * dp + dbk_r[i] * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
+  }
   // ln p at my half levels k0..k0+nk and full levels (press_and_geopot.F90:165-194)
   double lph[CH + 1], lpf[CH];
   {
-    const double ph0 = a.pk[k0] + a.bk[k0] * ps;
+    const double ph0 = pk_r[0] + bk_r[0] * ps;
     lph[0] = (top0 && k0 == 0) ? 0.0 : log(ph0);
     double ph_k = ph0;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int k = k0 + (i < nk ? i : 0);
-      const double ph_n = a.pk[k + 1] + a.bk[k + 1] * ps;
+      const double ph_n = pk_r[i + 1] + bk_r[i + 1] * ps;      // (levels past the chunk end are computed but never used)
       const double l_n = log(ph_n);
       lph[i + 1] = l_n;
       if (top0 && k == 0) lpf[i] = l_n - 1.0;
@@ -1116,15 +1148,14 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     if (ww < w) base += x;
     if (ww > w) below += lds_a[ww * 64 + tid];
   }
-  const double sin_lat = sin(a.rad_lat[jl]);
+  const double sin_lat = sin(rad_lat);
   const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
-  const double cosm = a.cosm[jl], cor = a.coriolis[jl];
   const double lnP00 = log(a.P00);
   const double vcoeff = -a.vkf / (1.0 - a.sigma_b), tcoeff = (a.tks - a.tka) / (1.0 - a.sigma_b);
   const double t_star = a.t_zero - a.delh * sin2 - a.eps * sin_lat, tstr = a.t_strat - a.eps * sin_lat;
   const double rps = 1. / ps;
   double dmean_tot = base;
-  double wg_k = (k0 == 0) ? 0.0 : (-base + total * a.bk[k0]);
+  double wg_k = (k0 == 0) ? 0.0 : (-base + total * bk_r[0]);
   double e_prev = 0.0;
   int nbelow = 0;
   if (a.wg && w == 0) { a.wg[c2] = 0.0; a.psp_copy[c2] = psp; }
@@ -1134,7 +1165,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const int k = k0 + i;
       const size_t q = c2 + (size_t)k * lev;
       const double l_h0 = lph[i], l_h1 = lph[i + 1], l_f = lpf[i];
-      const double upi = a.up[q], vpi = a.vp[q], tpi = a.tp[q], voi = a.vor[q], dxti = a.dxT[q], dyti = a.dyT[q];
+      const double upi = upv[i], vpi = vpv[i], tpi = tpv[i], voi = vov[i], dxti = dxv[i], dyti = dyv[i];
       const double p_full = exp(l_f);
       // ---- hs_forcing at the previous level (rayleigh :615-679, dissipative heating :198-200, newtonian :508-611)
       const double sigma = p_full * rps;
@@ -1151,12 +1182,12 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       }
       {  // initialize_corrections (:1318-1321)
         const double ue = upi + dt_u * a.delta_t, ve = vpi + dt_v * a.delta_t;
-        e_prev += (0.5 * (ue * ue + ve * ve) + CP_AIR * (tpi + dt_t * a.delta_t)) * (a.dpk[k] + a.dbk[k] * psp);
+        e_prev += (0.5 * (ue * ue + ve * ve) + CP_AIR * (tpi + dt_t * a.delta_t)) * (dpk_r[i] + dbk_r[i] * psp);
       }
       // ---- four_in_one (:1064-1083)
-      const double dp = a.dpk[k] + a.dbk[k] * ps, dp_inv = 1 / dp;
+      const double dp = dpk_r[i] + dbk_r[i] * ps, dp_inv = 1 / dp;
       const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
-      const double x1 = (a.bk[k + 1] * dlog_1 + a.bk[k] * dlog_2) * dp_inv;
+      const double x1 = (bk_r[i + 1] * dlog_1 + bk_r[i] * dlog_2) * dp_inv;
       const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
       const double uc = u[i], vc = v[i], tc = t[i];
       dt_u = dt_u - RDGAS * tc * x2;
@@ -1164,11 +1195,11 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
       const double x5 = x4 - uc * x2 - vc * x3;
       dt_t = dt_t - KAPPA * tc * x5;
-      a.wg_full[q] = -x5 * p_full;
+      CST(a.wg_full[q], -x5 * p_full);
       nbelow += (p_full < a.water_limit) ? 1 : 0;
       dmean_tot = dmean_tot + dm[i];
-      const double wg_n = (k + 1 < L) ? (-dmean_tot + total * a.bk[k + 1]) : 0.0;
-      if (a.wg) a.wg[q + lev] = wg_n;
+      const double wg_n = (k + 1 < L) ? (-dmean_tot + total * bk_r[i + 1]) : 0.0;
+      if (a.wg) CST(a.wg[q + lev], wg_n);
       // ---- vert_advection SECOND_CENTERED / ADVECTIVE_FORM (vert_advection.F90:185-193, 467-470)
       const double ukm = (i == 0) ? um : u[i > 0 ? i - 1 : 0], vkm = (i == 0) ? vm : v[i > 0 ? i - 1 : 0], tkm = (i == 0) ? tm : t[i > 0 ? i - 1 : 0];
       const double ukp = (i == nk - 1) ? un : u[i + 1 < CH ? i + 1 : i], vkp = (i == nk - 1) ? vn : v[i + 1 < CH ? i + 1 : i], tkp = (i == nk - 1) ? tn : t[i + 1 < CH ? i + 1 : i];
@@ -1189,9 +1220,9 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double av = voi + cor;
       dt_u = dt_u + av * vc;
       dt_v = dt_v - av * uc;
-      a.dtu[q] = dt_u * cosm;
-      a.dtv[q] = dt_v * cosm;
-      a.dtT[q] = dt_t;
+      CST(a.dtu[q], dt_u * cosm);
+      CST(a.dtv[q], dt_v * cosm);
+      CST(a.dtT[q], dt_t);
       wg_k = wg_n;
     }
   }
@@ -1203,13 +1234,13 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     for (int i = CH - 1; i >= 0; --i) {
       if (i < nk) {
         const size_t q = c2 + (size_t)(k0 + i) * lev;
-        a.E[q] = gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]);
+        CST(a.E[q], gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]));
         if (k0 + i >= ktop) gh = gh + RDGAS * t[i] * (lph[i + 1] - lph[i]);
       }
     }
   }
   // ---- block partial sums: mean_surf_press_previous, mean_energy_previous
-  double s_en = a.wts[jl] * e_prev, s_ps = (w == 0) ? a.wts[jl] * psp : 0.0;
+  double s_en = wts_j * e_prev, s_ps = (w == 0) ? wts_j * psp : 0.0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     s_ps += __shfl_down(s_ps, off, 64);
@@ -1231,6 +1262,10 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   }
 }
 
+#if defined(EXP_COL_NOMATH)
+#undef log
+#undef exp
+#endif
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
 
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -1626,7 +1661,7 @@ template <int CH>
 __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
   __shared__ double red[5][8][64];
   const int L = g.L;
-  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
   const size_t lev = (size_t)g.Jl * g.I;
   const size_t c2 = (size_t)blockIdx.x * 64 + tid;
   const int k0 = w * CH, nk = min(CH, L - k0);
@@ -1849,7 +1884,7 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
                                                     const double *__restrict__ wts, double *__restrict__ partials, int CH,
                                                     const double *__restrict__ wcol) {
   __shared__ double red[2][8];
-  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
   const int col = blockIdx.x * 64 + tid;
   const int jl = col / g.I;
   const size_t c2 = col, lev = (size_t)g.Jl * g.I;

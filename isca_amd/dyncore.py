@@ -15,7 +15,7 @@ from dataclasses import dataclass, field, fields as dc_fields
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libisca_dyn.so")
+LIB_PATH = os.environ.get("ISCA_DYN_LIB") or os.path.join(_HERE, "lib", "libisca_dyn.so")   # override: kernel experiments
 
 
 class IscaError(RuntimeError):
