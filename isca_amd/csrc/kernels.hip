@@ -126,11 +126,18 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldLis
       src = (const double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
       if (fl.op[f] == OP_COSM) scale = cosm[jl];
     }
+    // all loads of the row first (independent of the row being real: a padding row re-reads row 0 and is zeroed),
+    // then the LDS writes: the loads are in flight together instead of one round trip each
+    constexpr int PER = (NC + 15) / 16;
+    const double2 *srcv = src ? src : (const double2 *)(fl.g[0] + (size_t)jl * g.I);
+    double2 zz[PER];
 #pragma unroll
-    for (int n = tr; n < NC; n += 16) {
-      double2 z = make_double2(0., 0.);
-      if (src) { z = src[n]; z.x *= scale; z.y *= scale; }
-      buf[r * rs + fpad(n)] = z;
+    for (int i = 0; i < PER; ++i) { const int n = tr + 16 * i; if (n < NC) zz[i] = srcv[n]; }
+    if (!src) scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int n = tr + 16 * i;
+      if (n < NC) buf[r * rs + fpad(n)] = src ? make_double2(zz[i].x * scale, zz[i].y * scale) : make_double2(0., 0.);
     }
   }
   __syncthreads();
@@ -138,15 +145,23 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldLis
   // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
   const int rr = t % R, cc = blockIdx.x * R + rr;
   const double inv_n = 1.0 / (double)g.I;
-  for (int m = t / R; m < g.M1; m += 16) {
-    const double2 zk = buf[rr * rs + fpad(m)];
-    const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
-    const double2 e = cscale(0.5, cadd(zk, zc));
-    const double2 dd = csub(zk, zc);
-    const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
-    double2 X = cadd(e, cmul(twl[m], o));
-    X.x *= inv_n; X.y *= inv_n;
-    if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc) = X;
+  constexpr int PERM = (NC + 15) / 16;          // num_fourier + 1 <= NC
+  int slot[PERM];
+#pragma unroll
+  for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
+#pragma unroll
+  for (int i = 0; i < PERM; ++i) {
+    const int m = t / R + 16 * i;
+    if (m < g.M1) {
+      const double2 zk = buf[rr * rs + fpad(m)];
+      const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
+      const double2 e = cscale(0.5, cadd(zk, zc));
+      const double2 dd = csub(zk, zc);
+      const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+      double2 X = cadd(e, cmul(twl[m], o));
+      X.x *= inv_n; X.y *= inv_n;
+      if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * cc) = X;
+    }
   }
 }
 
@@ -162,14 +177,23 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
   for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
   {  // load truncated coefficients m = 0..M (transforms.F90:424 zeroes everything above)
     const int rr = t % R, cc = blockIdx.x * R + rr;
-#pragma unroll 4
-    for (int m = t / R; m < NC; m += 16) {
-      double2 X = make_double2(0., 0.);
-      if (m < g.M1 && cc < fl.ncol) {
-        X = *(const double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc);
-        if (m == 0) X.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
+    constexpr int PERM = (NC + 15) / 16;
+    const int ccl = min(cc, fl.ncol - 1);
+    int slot[PERM];
+#pragma unroll
+    for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
+    double2 X[PERM];
+#pragma unroll
+    for (int i = 0; i < PERM; ++i)       // wavenumbers above the truncation re-read m = 0 (cached) and are zeroed below
+      X[i] = *(const double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * ccl);
+#pragma unroll
+    for (int i = 0; i < PERM; ++i) {
+      const int m = t / R + 16 * i;
+      if (m < NC) {
+        double2 x = (m < g.M1 && cc < fl.ncol) ? X[i] : make_double2(0., 0.);
+        if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
+        buf[rr * rs + fpad(m)] = x;
       }
-      buf[rr * rs + fpad(m)] = X;
     }
   }
   __syncthreads();
@@ -260,7 +284,13 @@ __device__ __forceinline__ size_t frow(const Geom &g, int j, int ml, int C) {   
 __device__ __forceinline__ void lds_fill(double *dst, const double *__restrict__ src, int ndoubles) {
   const double2 *s2 = (const double2 *)src;
   double2 *d2 = (double2 *)dst;
-  for (int i = threadIdx.x; i < (ndoubles >> 1); i += 256) d2[i] = s2[i];
+  const int n2 = ndoubles >> 1;
+  int i = threadIdx.x;
+  for (; i + 768 < n2; i += 1024) {        // four loads in flight per lane, then the four LDS writes
+    const double2 a = s2[i], b = s2[i + 256], c = s2[i + 512], d = s2[i + 768];
+    d2[i] = a; d2[i + 256] = b; d2[i + 512] = c; d2[i + 768] = d;
+  }
+  for (; i < n2; i += 256) d2[i] = s2[i];
 }
 // spectral-side row offset (in doubles, fits 31 bits) of latitude j for local wavenumber slot ml; Jl = 2^lg
 __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
@@ -384,6 +414,10 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
         lc[i] = (row < 6) ? src.coef[((size_t)ids[row] * g.Ml + ml) * N1 + n] : (row == LC_ONE ? 1.0 : 0.0);
       }
     }
+    if (BOTH) {   // the Legendre table of this wavenumber goes to LDS while the B operand is being gathered
+      lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * g.Jh, 4 * nks0 * g.Jh);
+      lds_fill(As + g.NHP * g.Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * g.Jh, 4 * nks1 * g.Jh);
+    }
     // what this lane's column is made of: w_a(n) A[n] + w_m(n) M[n-1] + w_p(n) P[n+1]
     const int lf = c >> 1, ri = c & 1;
     int f = 7 + (lf - 7 * L), k = 0;
@@ -406,21 +440,57 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
       default: pm = tsrc; rm = LC_DYM; sm = -1.0; rp = LC_DYP; sp = 1.0; break;     // 6, 9
     }
     if (!cok) { pa = nullptr; pm = nullptr; }
+    // Loads first, arithmetic second, in groups of 4 k-steps: every lane reads a valid (clamped) element of a valid
+    // array and the selects below drop what it does not use, so the loads of a group carry no branches and are in
+    // flight together.  Groups wholly beyond the triangle of this wavenumber are skipped (wave-uniform test).
+    const double *pa_ = pa ? pa : src.vor, *pm_ = pm ? pm : src.vor;
+    const size_t e0c = cok ? e0 : 0;
+    const bool any_m = __any(pm != nullptr);
     __syncthreads();                                                       // lc ready
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int g4 = 0; g4 < NKS; g4 += 4) {
+      if (g4 < nks0) {                                                     // nks1 <= nks0
+        double ta[4][2], tm[4][2], tp[4][2];
 #pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int n = 8 * ks + 2 * kq + par;
-        double v = 0.0;
-        if (ks < (par ? nks1 : nks0) && n < nlim) {
-          if (pa) v = sa * lc[ra * N1 + n] * pa[e0 + (size_t)n * stride + ca];
-          if (pm) {
-            if (n >= 1) v += sm * lc[rm * N1 + n] * pm[e0 + (size_t)(n - 1) * stride + ri];
-            if (n + 1 < N1) v += sp * lc[rp * N1 + n] * pm[e0 + (size_t)(n + 1) * stride + ri];
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            const int nn = min(8 * (g4 + q) + 2 * kq + par, N1 - 1);
+            ta[q][par] = pa_[e0c + (size_t)nn * stride + ca];
           }
+        if (any_m) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+              const int nn = min(8 * (g4 + q) + 2 * kq + par, N1 - 1);
+              tm[q][par] = pm_[e0c + (size_t)max(nn - 1, 0) * stride + ri];
+              tp[q][par] = pm_[e0c + (size_t)min(nn + 1, N1 - 1) * stride + ri];
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { tm[q][0] = tm[q][1] = tp[q][0] = tp[q][1] = 0.0; }
         }
-        if (par) b1[ks] = v; else b0[ks] = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            const int ks = g4 + q;
+            if (ks < NKS) {
+              const int n = 8 * ks + 2 * kq + par, nn = min(n, N1 - 1);
+              double v = 0.0;
+              if (pa) v = sa * lc[ra * N1 + nn] * ta[q][par];
+              if (pm) {
+                if (n >= 1) v += sm * lc[rm * N1 + nn] * tm[q][par];
+                if (n + 1 < N1) v += sp * lc[rp * N1 + nn] * tp[q][par];
+              }
+              if (!(ks < (par ? nks1 : nks0) && n < nlim)) v = 0.0;
+              if (par) b1[ks] = v; else b0[ks] = v;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (g4 + q < NKS) { b0[g4 + q] = 0.0; b1[g4 + q] = 0.0; }
       }
     }
   }
@@ -429,9 +499,11 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
   for (int jt = 0; jt < JT; ++jt) { accE[jt] = (double4_t){0., 0., 0., 0.}; accO[jt] = (double4_t){0., 0., 0., 0.}; }
   const bool wave_on = c0 < C;
   const double *A = As + kq * Jh + cl;
-  // even parity: only the rows nh < 4*nks are needed
-  lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * Jh, 4 * nks0 * Jh);
-  if (BOTH) lds_fill(As + g.NHP * Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
+  if (!(FUSED && BOTH)) {
+    // even parity: only the rows nh < 4*nks are needed
+    lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * Jh, 4 * nks0 * Jh);
+    if (BOTH) lds_fill(As + g.NHP * Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
+  }
   __syncthreads();
   if (wave_on) {
 #pragma unroll
