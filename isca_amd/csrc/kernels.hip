@@ -799,6 +799,8 @@ __global__ void k_spec_tendencies(Geom g, const double *__restrict__ coef, const
   if (k == 0) dtlp[mn] = *(const double2 *)(Sf + mn * C + 2 * (4 * L));
 }
 
+__device__ __forceinline__ double2 sel2(bool c, double2 v) { return make_double2(c ? v.x : 0.0, c ? v.y : 0.0); }   // by value: stays in registers
+
 // wave-wide inclusive prefix sum over lanes 0..63 with DPP row shifts / row broadcasts (no LDS crossbar traffic)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
@@ -876,26 +878,43 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const size_t idx = (size_t)mn * L + kk;
   const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
   const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
-  const double eig = COEF(C_EIG, ml, n);
+  const double eig = COEF(C_EIG, ml, n), dmp = COEF(C_DAMP, ml, n);   // read before the first store (scalar path)
+  const int mglob = a.m_local[ml];
   const double2 zero = make_double2(0., 0.);
-  double2 dprev = act ? a.divs_p[idx] : zero, dcur = act ? a.divs_c[idx] : zero;
-  double2 tprev = act ? a.ts_p[idx] : zero, tcur = act ? a.ts_c[idx] : zero;
-  double2 vprev = act ? a.vors_p[idx] : zero, vcur = act ? a.vors_c[idx] : zero;
+  // unconditional loads (idx is valid for every lane) masked afterwards: `c ? lvalue : lvalue` on a double2 selects
+  // an address and would push both operands into scratch memory
+  const double2 dprev = sel2(act, a.divs_p[idx]), dcur = sel2(act, a.divs_c[idx]);
+  const double2 tprev = sel2(act, a.ts_p[idx]), tcur = sel2(act, a.ts_c[idx]);
+  const double2 vprev = sel2(act, a.vors_p[idx]), vcur = sel2(act, a.vors_c[idx]);
   const double2 lprev = a.lnps_p[mn], lcur = a.lnps_c[mn];
   // --- spectral tendencies of the forward batch (spectral_dynamics.F90:874,891,900-904)
   double2 dt_vor, dt_div, dt_t = zero, dt_lp;
   if (MODE & SU_GIVEN) {
-    dt_vor = act ? a.dtvor[idx] : zero; dt_div = act ? a.dtdiv[idx] : zero; dt_t = act ? a.dtT[idx] : zero;
+    dt_vor = sel2(act, a.dtvor[idx]); dt_div = sel2(act, a.dtdiv[idx]); dt_t = sel2(act, a.dtT[idx]);
     dt_lp = a.dtlp[mn];
   } else {
-    alpha_pair(g, coef, a.Sf, a.C, mn, ml, n, kk, L + kk, dt_vor, dt_div);
-    if (act) {
-      const double2 E = *(const double2 *)(a.Sf + mn * a.C + 2 * (3 * L + kk));
-      dt_div = cadd(dt_div, cscale(eig, E));            // dt_divs - laplacian(Phi+KE), laplacian = -eigen
-      dt_t = *(const double2 *)(a.Sf + mn * a.C + 2 * (2 * L + kk));
-      a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t;      // kept for diagnostics/tests
-    } else { dt_vor = zero; dt_div = zero; }
-    dt_lp = *(const double2 *)(a.Sf + mn * a.C + 2 * (4 * L));
+    // compute_vor_div of (dt_u, dt_v)/cos (alpha_pair above, spherical.F90:472-561) with every load of the forward
+    // batch issued together: rows n-1 / n+1 are clamped and their coefficients zeroed at the ends of the column
+    const double *row = a.Sf + (size_t)mn * a.C;
+    const int dm_ = (n >= 1) ? a.C : 0, dp_ = (n + 1 < g.N1) ? a.C : 0;
+    const double2 U = *(const double2 *)(row + 2 * kk), V = *(const double2 *)(row + 2 * (L + kk));
+    const double2 Um = *(const double2 *)(row - dm_ + 2 * kk), Vm = *(const double2 *)(row - dm_ + 2 * (L + kk));
+    const double2 Up = *(const double2 *)(row + dp_ + 2 * kk), Vp = *(const double2 *)(row + dp_ + 2 * (L + kk));
+    const double2 E = *(const double2 *)(row + 2 * (3 * L + kk));
+    const double2 Tt = *(const double2 *)(row + 2 * (2 * L + kk));
+    dt_lp = *(const double2 *)(row + 2 * (4 * L));
+    const double dx = COEF(C_DX, ml, n), mk = COEF(C_MASK, ml, n);
+    const double am = (n >= 1) ? COEF(C_ALPM, ml, n) : 0.0, ap = (n + 1 < g.N1) ? COEF(C_ALPP, ml, n) : 0.0;
+    dt_vor = cscale(dx, ctimes_i(V));
+    dt_div = cscale(dx, ctimes_i(U));
+    dt_vor = cadd(dt_vor, cscale(am, Um));            // alpha(v,u,-1)
+    dt_div = csub(dt_div, cscale(am, Vm));            // alpha(u,v,+1)
+    dt_vor = csub(dt_vor, cscale(ap, Up));
+    dt_div = cadd(dt_div, cscale(ap, Vp));
+    dt_vor = sel2(act, cscale(mk, dt_vor));
+    dt_div = sel2(act, cadd(cscale(mk, dt_div), cscale(eig, E)));   // dt_divs - laplacian(Phi+KE), laplacian = -eigen
+    dt_t = sel2(act, Tt);
+    if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }      // kept for diagnostics/tests
     if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
   }
   double2 dps, dts;
@@ -907,7 +926,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     const double2 ts_temp = cadd(csub(tprev, tcur), cscale(a.xi, dt_t));
     const double2 ps_temp = cadd(csub(lprev, lcur), cscale(a.xi, dt_lp));
     {  // linear_geopotential (:329-359) with del_ln_p = 0: suffix sums of RDGAS*T'*dlog3 below the level
-      const double2 av = (act && lane >= 1) ? cscale(RDGAS * dlog3, ts_temp) : zero;
+      const double2 av = sel2(act && lane >= 1, cscale(RDGAS * dlog3, ts_temp));
       double2 inc;
       inc.x = wave_incl_scan(av.x, lane);
       inc.y = wave_incl_scan(av.y, lane);
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     }
     {  // dt_divs <- wave_matrix(L) . dt_divs (:268-277); ws[k'][k] in LDS, x broadcast from LDS
       double2 *xs = xsb + wave * 64;
-      xs[lane] = act ? dt_div : zero;
+      xs[lane] = sel2(act, dt_div);
       __syncthreads();                                  // matrix copy + x vectors visible
       double2 out = zero;
   #pragma unroll 8
@@ -929,7 +948,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
         out.x += w * x.x;
         out.y += w * x.y;
       }
-      dt_div = act ? out : zero;
+      dt_div = sel2(act, out);
     }
     if (idle) return;
     lin_tp(dt_div, lane, L, dp, dlog1, dlog3, a.ref_t, dps, dts);
@@ -944,13 +963,11 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   }
   // --- damping
   if (!(MODE & SU_NO_DAMPING)) {
-    const double dmp = COEF(C_DAMP, ml, n);
     const double cf = 1.0 / (1.0 + dmp * a.delta_t);
     dt_vor = cscale(cf, csub(dt_vor, cscale(dmp, vprev)));
     dt_div = cscale(cf, csub(dt_div, cscale(dmp, dprev)));
     dt_t = cscale(cf, csub(dt_t, cscale(dmp, tprev)));
     if (lane == 0 && (a.eddy_sponge != 0.0 || a.zmu_sponge != 0.0 || a.zmv_sponge != 0.0)) {   // sponge on the top level (:236-245, :281-290)
-      const int mglob = a.m_local[ml];
       const double sv = (mglob != 0) ? a.eddy_sponge * eig : a.zmu_sponge * eig;
       const double sd = (mglob != 0) ? a.eddy_sponge * eig : a.zmv_sponge * eig;
       dt_vor = cscale(1.0 / (1.0 + sv * a.delta_t), csub(dt_vor, cscale(sv, vprev)));
