@@ -79,7 +79,7 @@ struct Dev {
   double *Sf, *Si;                                  // spectral work [Ml][N1][Cf], [Ml][N1][Ci]
   double *s_dtvor, *s_dtdiv, *s_dtT, *s_dtlp;       // spectral tendencies [Ml][N1][L]
   double *partials;                                 // block partial sums
-  double *red;                                      // [16] reduction results / fixer scalars
+  double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18]
   double *scratch_g[4], *scratch_s[4];              // API transforms
 };
 

@@ -1199,7 +1199,6 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
 #pragma unroll
   for (int i = 0; i < CH; ++i) {          // mass divergence of the layer (four_in_one :1064-1067)
-    const int k = k0 + (i < nk ? i : 0);
     const double dp = dpk_r[i] + dbk_r[i] * ps;
     dm[i] = (i < nk) ? dm[i] * dp + dbk_r[i] * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
   }
@@ -1568,6 +1567,11 @@ __device__ __forceinline__ double tr_source_sink(const TracerArgs &a, const Geom
 __device__ __forceinline__ double tr_q0(const TracerArgs &a, const Geom &g, int k, size_t q, size_t c2) {
   return a.trp[q] + a.dt * tr_source_sink(a, g, k, c2, a.tratm_p[q]);
 }
+// the same from values already in registers (ps is only used at the lowest level)
+__device__ __forceinline__ double tr_q0_of(const TracerArgs &a, const Geom &g, int k, double tr_prev, double tr_atm, double ps) {
+  const double src = (k == g.L - 1) ? a.flux / (a.dpk[k] + a.dbk[k] * ps) : 0.0;
+  return tr_prev + a.dt * (src - a.rdamp * tr_atm);
+}
 __device__ __forceinline__ double vl_limit(double slope, double qm, double q0, double qp) {
   const double q_min = fmin(fmin(qm, q0), qp), q_max = fmax(fmax(qm, q0), qp);
   return copysign(1.0, slope) * fmin(fmin(fabs(slope), 2.0 * (q0 - q_min)), 2.0 * (q_max - q0));
@@ -1591,6 +1595,11 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
   const int i = threadIdx.x, j0 = g.j0 + blockIdx.x * RB, k = blockIdx.y;      // j0: global index of the block's first row
   const size_t lev = (size_t)g.Jl * I;
   int jsrc[NR], sh[NR];                                                         // global source row, longitude shift
+  // every global load of the block first (branch-free: a row outside my band comes from the halo buffer, which
+  // already holds q0), then the LDS writes
+  double tq[NR], ta[NR], tu[NR], tv[NR];
+  bool loc[NR];
+  const size_t fs = (size_t)g.L * 2 * I;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int jv = j0 + r - 2;
@@ -1598,19 +1607,22 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
     else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I >> 1; }             // across the north pole (:158-164)
     else { jsrc[r] = jv; sh[r] = 0; }
     const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
-    double q0v, uv, vv;
-    if (jl >= 0 && jl < g.Jl) {
-      const size_t c2 = (size_t)jl * I + i, q = (size_t)k * lev + c2;
-      q0v = tr_q0(a, g, k, q, c2); uv = a.ua[q]; vv = a.va[q];
-    } else {
-      const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
-      const int hr = (jl < 0) ? jl + 2 : jl - g.Jl;
-      const size_t o = (((size_t)0 * g.L + k) * 2 + hr) * I + i, fs = (size_t)g.L * 2 * I;
-      q0v = hb[o]; uv = hb[o + fs]; vv = hb[o + 2 * fs];
-    }
-    qs[r * I + i] = q0v;
-    us[r * I + i] = uv;
-    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * vv;
+    loc[r] = jl >= 0 && jl < g.Jl;
+    const size_t q = (size_t)k * lev + (size_t)(loc[r] ? jl : 0) * I + i;
+    const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + i;
+    const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
+    const double *pq = loc[r] ? a.trp + q : hb + o, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
+    tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
+  }
+  double psr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)                                                   // surface flux only enters the lowest level
+    psr[r] = (k == g.L - 1 && loc[r]) ? a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + i] : 1.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    qs[r * I + i] = loc[r] ? tr_q0_of(a, g, k, tq[r], ta[r], psr[r]) : tq[r];
+    us[r * I + i] = tu[r];
+    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * tv[r];
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
@@ -1632,9 +1644,12 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
     if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
   }
   __syncthreads();
+  double res[RB];                      // stored after the loop: with a store inside, the per-row tables would leave the scalar path
+#pragma unroll
   for (int rr = 0; rr < RB; ++rr) {
     const int r = rr + 2, jg = j0 + rr;
-    if (jg >= g.j0 + g.Jl) break;
+    res[rr] = 0.0;
+    if (jg >= g.j0 + g.Jl) continue;
     const double q0c = qs[r * I + i], va_c = vs[(rr + 1) * I + i];
     {  // semi_y (:415-433)
       const double qxm = qs[(r - 1) * I + ((i + sh[r - 1]) & IM)], qxp = qs[(r + 1) * I + ((i + sh[r + 1]) & IM)];
@@ -1680,8 +1695,11 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
       if (jg == J - 1) f_hi = 0.0;
       dq = dq - rcdy * (f_hi - f_lo);
     }
-    a.trh[(size_t)k * lev + (size_t)(jg - g.j0) * I + i] = q0c + a.dt * dq;
+    res[rr] = q0c + a.dt * dq;
   }
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr)
+    if (j0 + rr < g.j0 + g.Jl) a.trh[(size_t)k * lev + (size_t)(j0 + rr - g.j0) * I + i] = res[rr];
 }
 
 // rows 0,1 and Jl-2,Jl-1 of (q0, u, v) for the neighbouring latitude bands (mpp_update_domains, fv_advection.F90:161-162,259)
@@ -1733,6 +1751,7 @@ __device__ __forceinline__ void ppm_cell(const double *rv, const double *dv, int
 __device__ void ppm_cell_global(const TracerArgs &a, const Geom &g, size_t c2, double ps, int kk, double &rc, double &left, double &right) {
   const size_t lev = (size_t)g.Jl * g.I;
   double rv[7], dv[7];
+#pragma unroll
   for (int t = -3; t <= 3; ++t) {
     const int kc = min(max(kk + t, 0), g.L - 1);
     rv[t + 3] = a.trh[(size_t)kc * lev + c2];
@@ -1766,6 +1785,15 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
   double wv[CH + 1];
 #pragma unroll
   for (int t = 0; t <= CH; ++t) wv[t] = a.wg[(size_t)min(k0 + t, L) * lev + c2];
+  // what the update at the end needs, requested now with everything else
+  double tpv[CH], tav[CH], tcv[CH];
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {
+    const size_t q = (size_t)min(k0 + t, L - 1) * lev + c2;
+    tpv[t] = a.trp[q]; tav[t] = a.tratm_p[q]; tcv[t] = a.tr_cur[q];
+  }
+  const int km = a.kmask[c2];
+  const double psp = a.ps_prev[c2];
   // limited slopes of cells k0-2 .. k0+CH+1 (rv index t+2), once each
   double sl[CH + 4];
 #pragma unroll
@@ -1811,6 +1839,9 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
     rl[t] = left; rr[t] = right;
   }
   // fluxes at interfaces k0 .. k0+CH (:373-432)
+  double r_last = 0.0;                                        // r(ke) when my chunk holds the lowest level (static indices only:
+#pragma unroll                                                // a run-time index would move rv[] to scratch memory)
+  for (int t = 0; t < CH; ++t) if (k0 + t == L - 1) r_last = rv[4 + t];
   double fx[CH + 1];
   const double tt = 2. / 3.;
 #pragma unroll
@@ -1819,18 +1850,20 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
     const double wk = wv[t];
     double f = 0.0;
     if (k <= 0) f = wk * rv[4];                               // flux(ks) = w(ks) r(ks)
-    else if (k >= L) f = wk * rv[4 + (L - 1 - k0)];           // flux(ke+1) = w(ke+1) r(ke)
+    else if (k >= L) f = wk * r_last;                         // flux(ke+1) = w(ke+1) r(ke)
     else if (t <= nk) {
       const bool up = wk >= 0.;
       const int kk = up ? k - 1 : k;                          // donor cell; local index kk-(k0-1) = t or t+1
-      const int lt = up ? t : t + 1;
-      const double cn = (up ? a.dt * wk : -a.dt * wk) / dv[3 + lt];
-      double rc = rv[3 + lt], left = rl[lt], right = rr[lt], xx = cn, rsum = 0.;
+      // donor-cell values picked with selects between two fixed registers (an index computed at run time would
+      // make the compiler keep a copy of rv/dv in scratch memory)
+      const double dvd = up ? dv[3 + t] : dv[4 + t];
+      const double cn = (up ? a.dt * wk : -a.dt * wk) / dvd;
+      double rc = up ? rv[3 + t] : rv[4 + t], left = up ? rl[t] : rl[t + 1], right = up ? rr[t] : rr[t + 1], xx = cn, rsum = 0.;
       int kd = kk;
       if (cn > 1.) {                                          // extension for Courant numbers > 1 (:385-396, :410-421)
         double dzsum = 0.;
         const double dtw = up ? a.dt * wk : -a.dt * wk;
-        double dzk = dv[3 + lt];
+        double dzk = dvd;
         while (dzsum + dzk < dtw) {
           if (kd == 0) break;                                 // the reference stops at kk == 1 (up) / ks (down)
           dzsum += dzk; rsum += a.trh[(size_t)kd * lev + c2];
@@ -1849,22 +1882,20 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
     }
     fx[t] = f;
   }
-  const int km = a.kmask[c2];
-  const double psp = a.ps_prev[c2];
   double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  double newc[CH], newf[CH];
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
+    newc[t] = newf[t] = 0.0;
     if (t < nk) {
       const int k = k0 + t;
-      const size_t q = (size_t)k * lev + c2;
       const double rk = rv[4 + t];
       const double rdt = -(fx[t + 1] - fx[t] - rk * (wv[t + 1] - wv[t])) / dv[4 + t];
       const double trf = rk + a.dt * rdt;
-      // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): read everything before writing
-      const double q0 = tr_q0(a, g, k, q, c2);
-      const double tp = a.trp[q], tc = a.tr_cur[q];
-      a.tr_cur[q] = tc + a.robert * (tp - 2.0 * tc);      // leapfrog part A on the grid tracer (:1164-1167)
-      a.tr_fut[q] = trf;
+      // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): everything was read at the top
+      const double q0 = tr_q0_of(a, g, k, tpv[t], tav[t], ps);
+      newc[t] = tcv[t] + a.robert * (tpv[t] - 2.0 * tcv[t]);      // leapfrog part A on the grid tracer (:1164-1167)
+      newf[t] = trf;
       // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
       const double msk = (k >= km) ? 1.0 : 0.0;
       s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
@@ -1872,6 +1903,9 @@ __global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
       s3 += msk * trf * a.dpk[k]; s4 += msk * trf * a.dbk[k];
     }
   }
+#pragma unroll
+  for (int t = 0; t < CH; ++t)
+    if (t < nk) { const size_t q = (size_t)(k0 + t) * lev + c2; a.tr_cur[q] = newc[t]; a.tr_fut[q] = newf[t]; }
   red[0][w][tid] = s0; red[1][w][tid] = s1; red[2][w][tid] = s2; red[3][w][tid] = s3; red[4][w][tid] = s4;
   __syncthreads();
   if (w < 5) {
@@ -1967,26 +2001,39 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 //   red[16] mass_correction_factor, red[17] temperature_correction, red[18] water_correction_factor
 // =====================================================================================================
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
+constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
                                                     const double *__restrict__ wts, double *__restrict__ partials, int CH,
                                                     const double *__restrict__ wcol) {
-  __shared__ double red[2][8];
-  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
+  __shared__ double sred[2][8];
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
   const int col = blockIdx.x * 64 + tid;
   const int jl = col / g.I;
   const size_t c2 = col, lev = (size_t)g.Jl * g.I;
-  double sa = 0.0, sb = 0.0;
-  const int k0 = w * CH, k1 = min(g.L, k0 + CH);
-  for (int k = k0; k < k1; ++k) {
-    const size_t q = c2 + k * lev;
-    const double uk = u[q], vk = v[q];
-    const double e = 0.5 * (uk * uk + vk * vk) + CP_AIR * t[q];
-    sa += e * dpk[k];
-    sb += e * dbk[k];
+  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
+  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
+    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
   }
   const double wgt = wts[jl], ps = psg[c2];
+  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
+    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
+  }
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nk) {
+      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
+      sa += e * dpk[k0 + i];
+      sb += e * dbk[k0 + i];
+    }
+  }
   double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1994,14 +2041,8 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     s1 += __shfl_down(s1, off, 64);
     s2 += __shfl_down(s2, off, 64);
   }
-  if (tid == 0) { red[0][w] = s1; red[1][w] = s2; }
+  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
   __syncthreads();
-  // water fixer column sums left by the tracer kernel (wave 0 only): before, after (dpk part, dbk*ps part), masked
-  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-  if (wcol && w == 0) {
-    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
-    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
-  }
   if (w == 0) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -2011,14 +2052,16 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   }
   if (threadIdx.x == 0) {
     double a1 = 0.0, a2 = 0.0;
-    for (int ww = 0; ww < NW; ++ww) { a1 += red[0][ww]; a2 += red[1][ww]; }
+    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; }
     double *p = partials + 8 * (size_t)blockIdx.x;
     p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4;
   }
 }
-constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
-__device__ __forceinline__ void fixer_block_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                                   double (*sh)[256]) {
+// Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
+// strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
+// the totals.  Deterministic and identical in every block that calls it.
+__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                             double (*sh)[NRED], double *tot) {
   double acc[NRED];
 #pragma unroll
   for (int c = 0; c < NRED; ++c) acc[c] = 0.;
@@ -2028,26 +2071,31 @@ __device__ __forceinline__ void fixer_block_reduce(const double *__restrict__ pp
     for (int c = 0; c < 8; ++c) acc[2 + c] += pfut[8 * i + c];
   }
 #pragma unroll
-  for (int c = 0; c < NRED; ++c) sh[c][threadIdx.x] = acc[c];
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off)
+  for (int c = 0; c < NRED; ++c) {
 #pragma unroll
-      for (int c = 0; c < NRED; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + off];
-    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
   }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NRED; ++c) tot[c] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
 }
-// red[0..1] <- sums of the column kernel's partials (2 per block), red[2..9] <- sums of k_fixer_sums' (8 per block)
+// red[0..9] <- totals, for the host all-reduce between the phases when world_size > 1
 __global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
                                                       double *__restrict__ red) {
-  __shared__ double sh[NRED][256];
-  fixer_block_reduce(pprev, pfut, nb, sh);
-  if (threadIdx.x < NRED) red[threadIdx.x] = sh[threadIdx.x][0];
+  __shared__ double sh[4][NRED];
+  double tot[NRED];
+  fixer_totals(pprev, pfut, nb, sh, tot);
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) red[c] = tot[c];
 }
 struct FixerArgs {
-  double *red;
+  double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
   const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
-  int nb;
+  int nb, reduce_here;
   double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
   double *psg, *tg;
   double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
@@ -2055,77 +2103,95 @@ struct FixerArgs {
   int ml0;                 // local slot of m = 0, or -1
   double sumw_nlon;        // global_sum_of_wts * num_lon
   double robert;
-  int do_mass, do_energy, do_water, reduce_here;
+  int do_mass, do_energy, do_water;
 };
-// Every block reduces the block partials itself in the same fixed order (deterministic, identical in all blocks),
-// derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0)
-// spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
-// With several ranks the host all-reduces red[0..9] first (reduce_here = 0).
+// Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
+// red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
 // Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
 __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
-  __shared__ double sh[NRED][256];
-  __shared__ double sc[3];
-  if (a.reduce_here) {
-    fixer_block_reduce(a.pprev, a.pfut, a.nb, sh);
-  } else {
-    if (threadIdx.x < NRED) sh[threadIdx.x][0] = a.red[threadIdx.x];
-    __syncthreads();
+  __shared__ double sh[4][NRED];
+  double r_[NRED];
+  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_);
+  else {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
   }
-  if (threadIdx.x == 0) {
-    const double mean_ps_prev = sh[0][0] / a.sumw_nlon;
-    const double mean_en_prev = sh[1][0] / a.sumw_nlon / GRAV;
-    double factor = 1.0, tcorr = 0.0, wfac = 1.0;
-    if (a.do_mass) factor = mean_ps_prev / (sh[2][0] / a.sumw_nlon);
+  double factor = 1.0, tcorr = 0.0, wfac = 1.0;
+  {
+    const double mean_ps_prev = r_[0] / a.sumw_nlon;
+    const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
+    if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
     if (a.do_energy) {
-      const double mean_en_tmp = (sh[3][0] + factor * sh[4][0]) / a.sumw_nlon / GRAV;
+      const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
       tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
     }
     if (a.do_water && a.tr_fut) {       // compute_corrections :1245-1283 (with mj's correction limit)
       const double nrm = 1.0 / a.sumw_nlon / GRAV;
-      const double water_prev = sh[5][0] * nrm;
-      const double water_tmp = (sh[6][0] + factor * sh[7][0]) * nrm;
-      const double corr = (sh[8][0] + factor * sh[9][0]) * nrm;
+      const double water_prev = r_[5] * nrm;
+      const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
+      const double corr = (r_[8] + factor * r_[9]) * nrm;
       const double notc = water_tmp - corr;
       if (water_tmp > 0.) {
         wfac = water_prev / water_tmp;
         wfac = wfac * (1. + notc / corr) - notc / corr;
       }
     }
-    sc[0] = factor; sc[1] = tcorr; sc[2] = wfac;
-    if (blockIdx.x == 0) {
-      for (int c = 0; c < NRED; ++c) a.red[c] = sh[c][0];
+  }
+  // 32-bit element indices (a 3-D field has < 2^31 elements): the 64-bit i / lev would expand into a branchy routine
+  const unsigned lev = (unsigned)(g.Jl * g.I), n3 = lev * (unsigned)g.L;
+  const unsigned first = (blockIdx.x * 256u + threadIdx.x) * 2u, stride = gridDim.x * 512u;
+  constexpr int UN = 4;                                   // independent 16-byte loads in flight per array and lane
+  for (unsigned i0 = first; i0 < n3; i0 += UN * stride) {
+    double2 tv[UN], fv[UN], cv[UN];
+    int km0[UN], km1[UN], kk[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned i = min(i0 + u * stride, n3 - 2u);
+      tv[u] = *(const double2 *)(a.tg + i);
+      if (a.tr_fut) {
+        kk[u] = (int)(i / lev);
+        const unsigned c2 = i - (unsigned)kk[u] * lev;
+        fv[u] = *(const double2 *)(a.tr_fut + i); cv[u] = *(const double2 *)(a.tr_cur + i);
+        km0[u] = a.kmask[c2]; km1[u] = a.kmask[c2 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const unsigned i = i0 + u * stride;
+      if (i < n3) {
+        *(double2 *)(a.tg + i) = make_double2(tv[u].x + tcorr, tv[u].y + tcorr);
+        if (a.tr_fut) {   // water factor where p_full >= limit, then leapfrog part B (:1484) and atmosphere_mod's copy (:1028)
+          double2 f = fv[u], c = cv[u];
+          if (kk[u] >= km0[u]) f.x *= wfac;
+          if (kk[u] >= km1[u]) f.y *= wfac;
+          c.x += a.robert * f.x; c.y += a.robert * f.y;
+          *(double2 *)(a.tr_fut + i) = f; *(double2 *)(a.tr_cur + i) = c; *(double2 *)(a.tratm_fut + i) = f;
+        }
+      }
+    }
+  }
+  for (unsigned i = first; i < lev; i += stride) {
+    double2 p = *(double2 *)(a.psg + i); p.x *= factor; p.y *= factor; *(double2 *)(a.psg + i) = p;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
       a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
     }
-  }
-  __syncthreads();
-  const double factor = sc[0], tcorr = sc[1], wfac = sc[2];
-  if (blockIdx.x == 0 && a.ml0 >= 0) {
-    const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
-    const double s2 = sqrt(2.);
-    const int k = threadIdx.x;
-    if (k == 0 && a.do_mass) {
-      const double dl = s2 * log(factor);
-      a.lnps_fut[mn].x += dl;
-      a.lnps_cur[mn].x += a.robert * dl;
-    }
-    if (k < g.L && a.do_energy) {
-      const double dtc = s2 * tcorr;
-      a.ts_fut[mn * g.L + k].x += dtc;
-      a.ts_cur[mn * g.L + k].x += a.robert * dtc;
-    }
-  }
-  const size_t lev = (size_t)g.Jl * g.I, n3 = lev * g.L;
-  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n3; i += (size_t)gridDim.x * 512) {
-    if (i < lev) { double2 p = *(double2 *)(a.psg + i); p.x *= factor; p.y *= factor; *(double2 *)(a.psg + i) = p; }
-    double2 t = *(double2 *)(a.tg + i); t.x += tcorr; t.y += tcorr; *(double2 *)(a.tg + i) = t;
-    if (a.tr_fut) {   // water factor where p_full >= limit, then leapfrog part B (:1484) and atmosphere_mod's copy (:1028)
-      const int k = (int)(i / lev);
-      const size_t c2 = i - (size_t)k * lev;
-      double2 f = *(double2 *)(a.tr_fut + i), c = *(double2 *)(a.tr_cur + i);
-      if (k >= a.kmask[c2]) f.x *= wfac;
-      if (k >= a.kmask[c2 + 1]) f.y *= wfac;
-      c.x += a.robert * f.x; c.y += a.robert * f.y;
-      *(double2 *)(a.tr_fut + i) = f; *(double2 *)(a.tr_cur + i) = c; *(double2 *)(a.tratm_fut + i) = f;
+    if (a.ml0 >= 0) {
+      const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
+      const double s2 = sqrt(2.);
+      const int k = threadIdx.x;
+      if (k == 0 && a.do_mass) {
+        const double dl = s2 * log(factor);
+        a.lnps_fut[mn].x += dl;
+        a.lnps_cur[mn].x += a.robert * dl;
+      }
+      if (k < g.L && a.do_energy) {
+        const double dtc = s2 * tcorr;
+        a.ts_fut[mn * g.L + k].x += dtc;
+        a.ts_cur[mn * g.L + k].x += a.robert * dtc;
+      }
     }
   }
 }
@@ -2138,7 +2204,7 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
   hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
                      h.tracer_on ? d.wcol : (const double *)nullptr);
-  if (g.P > 1)   // the host all-reduces red[0..4] between the phases
+  if (g.P > 1)   // the host all-reduces red[0..9] between the phases
     hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -2146,6 +2212,7 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
   a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
+  a.reduce_here = (g.P == 1);
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
   a.psg = h.d.psg[sc.fut]; a.tg = h.d.tg[sc.fut];
@@ -2157,7 +2224,6 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.sumw_nlon = sumw * g.I;
   a.robert = h.cfg.robert_coeff;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
-  a.reduce_here = (g.P == 1);
   const size_t n3 = (size_t)g.Jl * g.I * g.L;
   const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
