@@ -375,7 +375,8 @@ __global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restr
 // gradients) is generated on the fly from the spectral state (compute_ucos_vcos spherical.F90:409-469,
 // compute_gradient_cos :270-351) instead of being read from a staged work buffer.
 struct SynthSrc { const double *vor, *div, *ts, *lnps, *coef; };
-enum { LC_UVC = 0, LC_UVM, LC_UVP, LC_DX, LC_DYM, LC_DYP, LC_ONE, LC_ZERO, LC_ROWS };
+enum { LC_UVC = 0, LC_UVM, LC_UVP, LC_DX, LC_DYM, LC_DYP, LC_ROWS, LC_ONE = LC_ROWS };   // LC_ONE: coefficient 1, no table row
+// (6 rows, not 8: with the T85 tables the block then needs 53.3 KB of LDS and three blocks fit a CU instead of two)
 
 template <int JT, int NKS, bool BOTH, bool FUSED>
 __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
       const int ids[6] = {C_UVC, C_UVM, C_UVP, C_DX, C_DYM, C_DYP};
       for (int i = threadIdx.x; i < LC_ROWS * N1; i += 256) {
         const int row = i / N1, n = i - row * N1;
-        lc[i] = (row < 6) ? src.coef[((size_t)ids[row] * g.Ml + ml) * N1 + n] : (row == LC_ONE ? 1.0 : 0.0);
+        lc[i] = src.coef[((size_t)ids[row] * g.Ml + ml) * N1 + n];
       }
     }
     if (BOTH) {   // the Legendre table of this wavenumber goes to LDS while the B operand is being gathered
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
     const size_t e0 = (f < 7) ? ((size_t)ml * N1 * L + k) * 2 : (size_t)ml * N1 * 2;
     const double *tsrc = (f < 7) ? src.ts : src.lnps;
     const double *pa = nullptr, *pm = nullptr;                             // centre array, neighbour array (n-1 and n+1)
-    int ra = LC_ZERO, rm = LC_ZERO, rp = LC_ZERO;
+    int ra = LC_UVC, rm = LC_UVM, rp = LC_UVP;                              // (unused rows point at a valid one)
     double sa = 1.0, sm = 1.0, sp = 1.0;
     int ca = ri;                                                           // component read from the centre array
     const double si = ri ? 1.0 : -1.0;                                     // (i z).re = -z.im, (i z).im = z.re
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restr
             if (ks < NKS) {
               const int n = 8 * ks + 2 * kq + par, nn = min(n, N1 - 1);
               double v = 0.0;
-              if (pa) v = sa * lc[ra * N1 + nn] * ta[q][par];
+              if (pa) v = sa * (ra == LC_ONE ? 1.0 : lc[(ra == LC_ONE ? 0 : ra) * N1 + nn]) * ta[q][par];
               if (pm) {
                 if (n >= 1) v += sm * lc[rm * N1 + nn] * tm[q][par];
                 if (n + 1 < N1) v += sp * lc[rp * N1 + nn] * tp[q][par];
