@@ -1185,13 +1185,15 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   double u[CH], v[CH], t[CH], dm[CH];
   // every global load of the block is issued here, before the barrier of the vertical scans: one memory
   // round trip per block instead of two (the loads below the barrier could not start before it)
-  double upv[CH], vpv[CH], tpv[CH], vov[CH], dxv[CH], dyv[CH];
+  // (chunks of more than 5 levels would not fit the register file that way: they read these six below the barrier)
+  constexpr bool EARLY = CH <= 5;
+  double upv[EARLY ? CH : 1], vpv[EARLY ? CH : 1], tpv[EARLY ? CH : 1], vov[EARLY ? CH : 1], dxv[EARLY ? CH : 1], dyv[EARLY ? CH : 1];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int k = k0 + (i < nk ? i : 0);
     const size_t q = c2 + (size_t)k * lev;
     u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
-    upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q]; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q];
+    if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q]; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
   // neighbours across the chunk boundary for the centred vertical fluxes
@@ -1254,7 +1256,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const int k = k0 + i;
       const size_t q = c2 + (size_t)k * lev;
       const double l_h0 = lph[i], l_h1 = lph[i + 1], l_f = lpf[i];
-      const double upi = upv[i], vpi = vpv[i], tpi = tpv[i], voi = vov[i], dxti = dxv[i], dyti = dyv[i];
+      const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q];
+      const double voi = EARLY ? vov[EARLY ? i : 0] : a.vor[q], dxti = EARLY ? dxv[EARLY ? i : 0] : a.dxT[q], dyti = EARLY ? dyv[EARLY ? i : 0] : a.dyT[q];
       const double p_full = exp(l_f);
       // ---- hs_forcing at the previous level (rayleigh :615-679, dissipative heating :198-200, newtonian :508-611)
       const double sigma = p_full * rps;
