@@ -1584,67 +1584,74 @@ __device__ __forceinline__ double vl_limit(double slope, double qm, double q0, d
 // one block = RB consecutive latitude rows of one level, one thread per longitude (lon_max = 2^p; single rank:
 // all rows are local).  RB+4 source rows are staged once (q0, u, q + semi_x(q)), RB+2 rows of v.
 constexpr int TR_RB = 4;
-__global__ void k_tracer_horiz(Geom g, TracerArgs a) {
+__global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TR_RB, NR = RB + 4;
   const int I = g.I, J = g.J, IM = I - 1;
-  double *qs = (double *)smem;        // [NR][I] q0 of the source rows of virtual rows j0-2..j0+RB+1 (unshifted)
+  double *qs = (double *)smem;        // [NR][I] q0 of virtual rows j0-2..j0+RB+1 (rows across a pole already rotated by I/2)
   double *us = qs + NR * I;           // [NR][I] u of those rows
-  double *q1 = us + NR * I;           // [NR][I] q + semi_x(q) of those rows
-  double *vs = q1 + NR * I;           // [RB+2][I] v of rows j0-1..j0+RB (sign-flipped when mirrored)
-  double *q2 = vs + (RB + 2) * I;     // [I]
+  double *q2 = us + NR * I;           // [I]
   double *sx = q2 + I;                // [I]
   double *fl = sx + I;                // [I]
   __shared__ int any_big[RB];
   const int i = threadIdx.x, j0 = g.j0 + blockIdx.x * RB, k = blockIdx.y;      // j0: global index of the block's first row
   const size_t lev = (size_t)g.Jl * I;
-  int jsrc[NR], sh[NR];                                                         // global source row, longitude shift
-  // every global load of the block first (branch-free: a row outside my band comes from the halo buffer, which
-  // already holds q0), then the LDS writes
+  int jsrc[NR];                                                                 // global source row of each virtual row
+  bool mir[NR], loc[NR];
+  // Every global load of the block first (branch-free: a row outside my band comes from the halo buffer, which
+  // already holds q0), then the LDS writes.  A virtual row across a pole is the mirror row seen half-way round the
+  // globe (fv_advection.F90:150-164): it is read rotated by I/2, so every later access is at the thread's own i and
+  // only q0 and u (gathered at other longitudes) have to live in LDS.
   double tq[NR], ta[NR], tu[NR], tv[NR];
-  bool loc[NR];
   const size_t fs = (size_t)g.L * 2 * I;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int jv = j0 + r - 2;
-    if (jv < 0) { jsrc[r] = -jv - 1; sh[r] = I >> 1; }                          // across the south pole (:150-156)
-    else if (jv >= J) { jsrc[r] = 2 * J - 1 - jv; sh[r] = I >> 1; }             // across the north pole (:158-164)
-    else { jsrc[r] = jv; sh[r] = 0; }
+    mir[r] = jv < 0 || jv >= J;
+    jsrc[r] = jv < 0 ? -jv - 1 : (jv >= J ? 2 * J - 1 - jv : jv);
+    const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
     const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
     loc[r] = jl >= 0 && jl < g.Jl;
-    const size_t q = (size_t)k * lev + (size_t)(loc[r] ? jl : 0) * I + i;
-    const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + i;
+    const size_t q = (size_t)k * lev + (size_t)(loc[r] ? jl : 0) * I + is;
+    const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + is;
     const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
     const double *pq = loc[r] ? a.trp + q : hb + o, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
     tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
   }
   double psr[NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r)                                                   // surface flux only enters the lowest level
-    psr[r] = (k == g.L - 1 && loc[r]) ? a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + i] : 1.0;
+  for (int r = 0; r < NR; ++r) {                                                // surface flux only enters the lowest level
+    const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
+    psr[r] = (k == g.L - 1 && loc[r]) ? a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + is] : 1.0;
+  }
+  double q0r[NR], vr[NR];                                                       // own-longitude values stay in registers
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    qs[r * I + i] = loc[r] ? tr_q0_of(a, g, k, tq[r], ta[r], psr[r]) : tq[r];
+    q0r[r] = loc[r] ? tr_q0_of(a, g, k, tq[r], ta[r], psr[r]) : tq[r];
+    vr[r] = mir[r] ? -tv[r] : tv[r];
+    qs[r * I + i] = q0r[r];
     us[r * I + i] = tu[r];
-    if (r >= 1 && r <= RB + 2) vs[(r - 1) * I + i] = (sh[r] ? -1.0 : 1.0) * tv[r];
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
   const double hdt = 0.5 * a.dt;
+  double q1r[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {      // semi_x (:376-411) on each source row
-    const double b = us[r * I + i] * hdt * a.rcdx[jsrc[r]];
+    const double b = tu[r] * hdt * a.rcdx[jsrc[r]];
     const double fb = floor(b);
     const int il = (i - 1 - (int)fb) & IM, ir = (il + 1) & IM;
-    const double bb = b - fb, qc = qs[r * I + i];
-    q1[r * I + i] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
+    const double bb = b - fb, qc = q0r[r];
+    q1r[r] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
   }
   const int im = (i - 1) & IM, ip = (i + 1) & IM;
-  double bx[RB];
+  double bx[RB], ucl[RB], ucr[RB];
 #pragma unroll
-  for (int rr = 0; rr < RB; ++rr) {   // Courant numbers of the x fluxes, block-wide flag for the integer part
+  for (int rr = 0; rr < RB; ++rr) {   // u at the cell faces, Courant numbers of the x fluxes, block-wide flag for the integer part
     const int r = rr + 2;
-    bx[rr] = 0.5 * (us[r * I + im] + us[r * I + i]) * a.dt * a.rcdx[j0 + rr];
+    ucl[rr] = 0.5 * (us[r * I + im] + tu[r]);
+    ucr[rr] = 0.5 * (tu[r] + us[r * I + ip]);
+    bx[rr] = ucl[rr] * a.dt * a.rcdx[j0 + rr];
     if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
   }
   __syncthreads();
@@ -1654,14 +1661,11 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
     const int r = rr + 2, jg = j0 + rr;
     res[rr] = 0.0;
     if (jg >= g.j0 + g.Jl) continue;
-    const double q0c = qs[r * I + i], va_c = vs[(rr + 1) * I + i];
-    {  // semi_y (:415-433)
-      const double qxm = qs[(r - 1) * I + ((i + sh[r - 1]) & IM)], qxp = qs[(r + 1) * I + ((i + sh[r + 1]) & IM)];
-      q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (qxm - q0c) * a.rdyy[jg] : va_c * hdt * (q0c - qxp) * a.rdyy[jg + 1]);
-    }
-    const double vm = vs[rr * I + ((i + sh[r - 1]) & IM)], vp = vs[(rr + 2) * I + ((i + sh[r + 1]) & IM)];
-    const double vc_lo = 0.5 * (vm + va_c), vc_hi = 0.5 * (va_c + vp);
-    const double uc_i = 0.5 * (us[r * I + im] + us[r * I + i]), uc_p = 0.5 * (us[r * I + i] + us[r * I + ip]);
+    const double q0c = q0r[r], va_c = vr[r];
+    // semi_y (:415-433)
+    q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (q0r[r - 1] - q0c) * a.rdyy[jg] : va_c * hdt * (q0c - q0r[r + 1]) * a.rdyy[jg + 1]);
+    const double vc_lo = 0.5 * (vr[r - 1] + va_c), vc_hi = 0.5 * (va_c + vr[r + 1]);
+    const double uc_i = ucl[rr], uc_p = ucr[rr];
     const double rcdy = a.rcdy[jg];
     double dq = q0c * ((vc_hi * a.cc[jg + 1] - vc_lo * a.cc[jg]) * rcdy + (uc_p - uc_i) * a.rcdx[jg]);
     const double b = bx[rr];
@@ -1683,18 +1687,17 @@ __global__ void k_tracer_horiz(Geom g, TracerArgs a) {
     __syncthreads();
     dq = dq - (fl[ip] - fl[i]) * (1.0 / a.dt);
     {  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
-      double Q[5], sl[3];
-#pragma unroll
-      for (int t = 0; t < 5; ++t) Q[t] = q1[(rr + t) * I + ((i + sh[rr + t]) & IM)];
+      double sl[3];
 #pragma unroll
       for (int t = 1; t <= 3; ++t) {
         const int jf = jg + t - 1;     // Fortran row index j' = 0..J+1 of the virtual row
-        sl[t - 1] = vl_limit((Q[t + 1] - Q[t]) * a.dyp[jf] + (Q[t] - Q[t - 1]) * a.dym[jf], Q[t - 1], Q[t], Q[t + 1]);
+        sl[t - 1] = vl_limit((q1r[rr + t + 1] - q1r[rr + t]) * a.dyp[jf] + (q1r[rr + t] - q1r[rr + t - 1]) * a.dym[jf],
+                             q1r[rr + t - 1], q1r[rr + t], q1r[rr + t + 1]);
       }
-      double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (Q[1] + 0.5 * sl[0] * (1.0 - a.dt * a.rdy[jg + 1] * vc_lo))
-                                   : vc_lo * a.cc[jg] * (Q[2] - 0.5 * sl[1] * (1.0 + a.dt * a.rdy[jg + 2] * vc_lo));
-      double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (Q[2] + 0.5 * sl[1] * (1.0 - a.dt * a.rdy[jg + 2] * vc_hi))
-                                   : vc_hi * a.cc[jg + 1] * (Q[3] - 0.5 * sl[2] * (1.0 + a.dt * a.rdy[jg + 3] * vc_hi));
+      double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (q1r[rr + 1] + 0.5 * sl[0] * (1.0 - a.dt * a.rdy[jg + 1] * vc_lo))
+                                   : vc_lo * a.cc[jg] * (q1r[rr + 2] - 0.5 * sl[1] * (1.0 + a.dt * a.rdy[jg + 2] * vc_lo));
+      double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (q1r[rr + 2] + 0.5 * sl[1] * (1.0 - a.dt * a.rdy[jg + 2] * vc_hi))
+                                   : vc_hi * a.cc[jg + 1] * (q1r[rr + 3] - 0.5 * sl[2] * (1.0 + a.dt * a.rdy[jg + 3] * vc_hi));
       if (jg == 0) f_lo = 0.0;
       if (jg == J - 1) f_hi = 0.0;
       dq = dq - rcdy * (f_hi - f_lo);
@@ -1943,7 +1946,7 @@ void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   TracerArgs a = tracer_args(h, sc);
-  const size_t ldsh = (size_t)(3 * (TR_RB + 4) + (TR_RB + 2) + 3) * g.I * sizeof(double);
+  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
   const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums
   const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64)), block(64 * NW);
@@ -1963,7 +1966,7 @@ void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, con
   TracerArgs a = tracer_args(h, sc);
   a.ua = u; a.va = v; a.trp = q; a.tratm_p = q; a.trh = q_new; a.ps_cur = ps;   // ps only enters the (zero) surface flux
   a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
-  const size_t ldsh = (size_t)(3 * (TR_RB + 4) + (TR_RB + 2) + 3) * g.I * sizeof(double);
+  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
 }
 void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
