@@ -105,148 +105,171 @@ template <int NC, bool INV> __device__ __forceinline__ void fft_row(double2 *row
 // rows (level-fields) per block: 16 (256 threads) up to lon_max = 256, 8 (128 threads) at lon_max = 512; 16 threads per row
 template <int NC> struct FftCfg { static constexpr int R = (NC >= 256) ? 8 : 16; };
 
+// Both kernels are persistent: a block walks over (row group, latitude) work items gx + GX * jl with stride gridDim.x and
+// requests the rows of its next item before it transforms the current one, so only the first load of a block is exposed.
 template <int NC>
 __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
-                                                 double *__restrict__ Fg, int C) {
+                                                 double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
+  constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;          // num_fourier + 1 <= NC
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
-  const int jl = blockIdx.y;
   for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
-  {
-    const int c = blockIdx.x * R + r;
-    const double2 *src = nullptr;
-    double scale = 1.0;
+  const int rr = t % R;
+  const double inv_n = 1.0 / (double)g.I;
+  int slot[PERM];
+#pragma unroll
+  for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
+  const int NG = GX * g.Jl;
+  double2 zn[PER];
+  double scale_n = 0.0;
+  // rows of work item `item` into registers (a padding row re-reads a valid row and gets scale 0)
+  auto request = [&](int item, double2 (&z)[PER], double &scale) {
+    const int gx = item % GX, jl = item / GX;
+    const int c = gx * R + r;
+    const double2 *src = (const double2 *)(fl.g[0] + (size_t)jl * g.I);
+    scale = 0.0;
     if (c < fl.ncol) {
       int f = 0;
       while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
       const int k = c - fl.off[f];
       src = (const double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
-      if (fl.op[f] == OP_COSM) scale = cosm[jl];
+      scale = (fl.op[f] == OP_COSM) ? cosm[jl] : 1.0;
     }
-    // all loads of the row first (independent of the row being real: a padding row re-reads row 0 and is zeroed),
-    // then the LDS writes: the loads are in flight together instead of one round trip each
-    constexpr int PER = (NC + 15) / 16;
-    const double2 *srcv = src ? src : (const double2 *)(fl.g[0] + (size_t)jl * g.I);
-    double2 zz[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { const int n = tr + 16 * i; if (n < NC) zz[i] = srcv[n]; }
-    if (!src) scale = 0.0;
+    for (int i = 0; i < PER; ++i) { const int n = tr + 16 * i; if (n < NC) z[i] = src[n]; }
+  };
+  int item = blockIdx.x;
+  if (item < NG) request(item, zn, scale_n);
+  for (; item < NG; item += gridDim.x) {
+    const int gx = item % GX, jl = item / GX;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int n = tr + 16 * i;
-      if (n < NC) buf[r * rs + fpad(n)] = src ? make_double2(zz[i].x * scale, zz[i].y * scale) : make_double2(0., 0.);
+      if (n < NC) buf[r * rs + fpad(n)] = make_double2(zn[i].x * scale_n, zn[i].y * scale_n);
     }
-  }
-  __syncthreads();
-  fft_row<NC, false>(buf + r * rs, twl, tr);
-  // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
-  const int rr = t % R, cc = blockIdx.x * R + rr;
-  const double inv_n = 1.0 / (double)g.I;
-  constexpr int PERM = (NC + 15) / 16;          // num_fourier + 1 <= NC
-  int slot[PERM];
+    if (item + (int)gridDim.x < NG) request(item + gridDim.x, zn, scale_n);       // in flight during the transform
+    __syncthreads();
+    fft_row<NC, false>(buf + r * rs, twl, tr);
+    // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
+    const int cc = gx * R + rr;
 #pragma unroll
-  for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
-#pragma unroll
-  for (int i = 0; i < PERM; ++i) {
-    const int m = t / R + 16 * i;
-    if (m < g.M1) {
-      const double2 zk = buf[rr * rs + fpad(m)];
-      const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
-      const double2 e = cscale(0.5, cadd(zk, zc));
-      const double2 dd = csub(zk, zc);
-      const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
-      double2 X = cadd(e, cmul(twl[m], o));
-      X.x *= inv_n; X.y *= inv_n;
-      if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * cc) = X;
+    for (int i = 0; i < PERM; ++i) {
+      const int m = t / R + 16 * i;
+      if (m < g.M1) {
+        const double2 zk = buf[rr * rs + fpad(m)];
+        const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
+        const double2 e = cscale(0.5, cadd(zk, zc));
+        const double2 dd = csub(zk, zc);
+        const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+        double2 X = cadd(e, cmul(twl[m], o));
+        X.x *= inv_n; X.y *= inv_n;
+        if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * cc) = X;
+      }
     }
+    __syncthreads();                                   // buf is rewritten by the next item
   }
 }
 
 template <int NC>
 __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldList fl, const double *__restrict__ cosm,
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
-                                                 const double *__restrict__ Fg, int C) {
+                                                 const double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
+  constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
-  const int jl = blockIdx.y;
   for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
-  {  // load truncated coefficients m = 0..M (transforms.F90:424 zeroes everything above)
-    const int rr = t % R, cc = blockIdx.x * R + rr;
-    constexpr int PERM = (NC + 15) / 16;
-    const int ccl = min(cc, fl.ncol - 1);
-    int slot[PERM];
+  const int rr = t % R;
+  int slot[PERM];
 #pragma unroll
-    for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
-    double2 X[PERM];
+  for (int i = 0; i < PERM; ++i) { const int m = t / R + 16 * i; slot[i] = slot_of_m[m < g.M1 ? m : 0]; }
+  const int NG = GX * g.Jl;
+  double2 Xn[PERM];
+  // truncated coefficients m = 0..M of work item `item` (wavenumbers above the truncation re-read m = 0 and are zeroed)
+  auto request = [&](int item, double2 (&X)[PERM]) {
+    const int gx = item % GX, jl = item / GX;
+    const int ccl = min(gx * R + rr, fl.ncol - 1);
 #pragma unroll
-    for (int i = 0; i < PERM; ++i)       // wavenumbers above the truncation re-read m = 0 (cached) and are zeroed below
-      X[i] = *(const double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * ccl);
+    for (int i = 0; i < PERM; ++i) X[i] = *(const double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * ccl);
+  };
+  int item = blockIdx.x;
+  if (item < NG) request(item, Xn);
+  for (; item < NG; item += gridDim.x) {
+    const int gx = item % GX, jl = item / GX;
+    {  // transforms.F90:424 zeroes everything above the truncation
+      const int cc = gx * R + rr;
 #pragma unroll
-    for (int i = 0; i < PERM; ++i) {
-      const int m = t / R + 16 * i;
-      if (m < NC) {
-        double2 x = (m < g.M1 && cc < fl.ncol) ? X[i] : make_double2(0., 0.);
-        if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
-        buf[rr * rs + fpad(m)] = x;
+      for (int i = 0; i < PERM; ++i) {
+        const int m = t / R + 16 * i;
+        if (m < NC) {
+          double2 x = (m < g.M1 && cc < fl.ncol) ? Xn[i] : make_double2(0., 0.);
+          if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
+          buf[rr * rs + fpad(m)] = x;
+        }
       }
     }
-  }
-  __syncthreads();
-  {  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0 ; in place via registers
-    constexpr int PER = (NC + 15) / 16;
-    double2 zz[PER];
+    if (item + (int)gridDim.x < NG) request(item + gridDim.x, Xn);               // in flight during the transform
+    __syncthreads();
+    {  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0 ; in place via registers
+      double2 zz[PER];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int k = tr + 16 * i;
-      if (k < NC) {
-        const double2 xk = buf[r * rs + fpad(k)];
-        const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf[r * rs + fpad(NC - k)]);
-        const double2 e = cadd(xk, xc);
-        const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
-        zz[i] = make_double2(e.x - o.y, e.y + o.x);
+      for (int i = 0; i < PER; ++i) {
+        const int k = tr + 16 * i;
+        if (k < NC) {
+          const double2 xk = buf[r * rs + fpad(k)];
+          const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf[r * rs + fpad(NC - k)]);
+          const double2 e = cadd(xk, xc);
+          const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
+          zz[i] = make_double2(e.x - o.y, e.y + o.x);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int k = tr + 16 * i;
+        if (k < NC) buf[r * rs + fpad(k)] = zz[i];
+      }
+      __syncthreads();
+    }
+    fft_row<NC, true>(buf + r * rs, twl, tr);
+    const int c = gx * R + r;
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      const int k = c - fl.off[f];
+      double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
+      const int op = fl.op[f];
+      const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
+#pragma unroll
+      for (int n = tr; n < NC; n += 16) {
+        double2 z = buf[r * rs + fpad(n)];
+        if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
+        else { z.x *= scale; z.y *= scale; }
+        dst[n] = z;
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int k = tr + 16 * i;
-      if (k < NC) buf[r * rs + fpad(k)] = zz[i];
-    }
-    __syncthreads();
-  }
-  fft_row<NC, true>(buf + r * rs, twl, tr);
-  const int c = blockIdx.x * R + r;
-  if (c < fl.ncol) {
-    int f = 0;
-    while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
-    const int k = c - fl.off[f];
-    double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
-    const int op = fl.op[f];
-    const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
-#pragma unroll
-    for (int n = tr; n < NC; n += 16) {
-      double2 z = buf[r * rs + fpad(n)];
-      if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
-      else { z.x *= scale; z.y *= scale; }
-      dst[n] = z;
-    }
+    __syncthreads();                                   // buf is rewritten by the next item
   }
 }
 
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
+static unsigned fft_grid(int items) {                  // persistent blocks: 3 per CU of the 256 (LDS-limited residency)
+  static const int cap = getenv("ISCA_FFT_BLOCKS") ? atoi(getenv("ISCA_FFT_BLOCKS")) : 768;
+  return (unsigned)std::min(items, cap);
+}
 static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
   const int R = fft_rows(NC);
-  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
+  const int GX = (fl.ncol + R - 1) / R;
+  dim3 grid(fft_grid(GX * g.Jl));
   const size_t lds = fft_lds_bytes(NC);
-#define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+#define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
     case 128: LF(128); break; case 256: LF(256); break;
@@ -257,9 +280,10 @@ void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
   const int R = fft_rows(NC);
-  dim3 grid((fl.ncol + R - 1) / R, g.Jl);
+  const int GX = (fl.ncol + R - 1) / R;
+  dim3 grid(fft_grid(GX * g.Jl));
   const size_t lds = fft_lds_bytes(NC);
-#define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C)
+#define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
     case 128: LI(128); break; case 256: LI(256); break;
