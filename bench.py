@@ -100,6 +100,23 @@ def main():
     core.kernel_times(True)
     core.step(min(a.steps, 200), sync=True)
     kt = core.kernel_times(False)
+    replicas = None
+    if world > 1:
+        # For reference next to the sharded number: N independent replicas (ensemble members), no communication.
+        # NOT `value`: the path shards, so `value` is the sharded job; at T85L40 a step is ~0.2 ms and the
+        # 4 exchanges per step are latency-bound, which this second figure makes visible.
+        one = dyncore.DynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, device=local_rank))
+        one.cold_start()
+        one.step(a.warmup, sync=True)
+        barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one.step(a.steps, sync=True)
+        torch.cuda.synchronize(); barrier()
+        e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e1, op=dist.ReduceOp.MAX)
+        one.close()
+        replicas = {"value": world * sim_years_per_day(float(e1.item()) / a.steps, dt), "unit": "sim_years/day (sum over members)",
+                    "ms_per_step": 1e3 * float(e1.item()) / a.steps, "scaling": "weak", "note": "independent ensemble members, one per GPU"}
     if rank != 0:
         return
     I, J, M1, N = core.I, core.J, core.M1, core.cfg.num_fourier
@@ -152,6 +169,8 @@ def main():
                                    else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
     }
+    if replicas is not None:
+        out["replicas"] = replicas
     if a.gpus == 1 and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps)
     print(json.dumps(out))

@@ -58,7 +58,13 @@ template <bool INV, int R> __device__ __forceinline__ void dftR(double2 (&v)[R])
     v[3] = cadd(e3, w3); v[7] = csub(e3, w3);
   }
 }
-__device__ __forceinline__ int fpad(int i) { return i + (i >> 3); }     // LDS padding: 1 slot per 8
+#ifndef FPAD_SHIFT
+#define FPAD_SHIFT 3
+#endif
+#ifndef FPAD_ROW_EXTRA
+#define FPAD_ROW_EXTRA 1
+#endif
+__device__ __forceinline__ int fpad(int i) { return i + (i >> FPAD_SHIFT); }     // LDS padding: 1 slot per 8
 
 // One Stockham pass of radix R at stride S over a row of NC complex points held in LDS (in place: all reads,
 // barrier, all writes, barrier).  16 threads per row.  twl = LDS copy of exp(-2 pi i k / (2 NC)), k < 2 NC.
@@ -94,6 +100,9 @@ __device__ __forceinline__ void fft_pass(double2 *row, const double2 *twl, int t
   __syncthreads();
 }
 template <int NC, bool INV> __device__ __forceinline__ void fft_row(double2 *row, const double2 *twl, int tr) {
+#if defined(EXP_FFT_NOPASS)
+  return;
+#endif
   if constexpr (NC == 8) { fft_pass<8, 8, 1, INV>(row, twl, tr); }
   else if constexpr (NC == 16) { fft_pass<16, 4, 1, INV>(row, twl, tr); fft_pass<16, 4, 4, INV>(row, twl, tr); }
   else if constexpr (NC == 32) { fft_pass<32, 8, 1, INV>(row, twl, tr); fft_pass<32, 4, 8, INV>(row, twl, tr); }
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldLis
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA;
   constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;          // num_fourier + 1 <= NC
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  const double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA;
   constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
@@ -261,7 +270,7 @@ static unsigned fft_grid(int items) {                  // persistent blocks: 3 p
   static const int cap = getenv("ISCA_FFT_BLOCKS") ? atoi(getenv("ISCA_FFT_BLOCKS")) : 768;
   return (unsigned)std::min(items, cap);
 }
-static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
+static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
