@@ -70,13 +70,19 @@ def main():
     from isca_amd import dyncore
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("ISCA_BENCH_BACKEND", "nccl")        # "gloo" + ISCA_BENCH_SHARE_GPU=1: all ranks on GPU 0 (tests on a 1-GPU box)
+    if os.environ.get("ISCA_BENCH_SHARE_GPU"):
+        local_rank = 0
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from isca_amd.parallel import ShardedDynCore
         core = ShardedDynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, rank=rank, world_size=world, device=local_rank))
         barrier = dist.barrier
@@ -91,7 +97,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     sec_per_step = elapsed / a.steps
@@ -112,7 +118,7 @@ def main():
         t1 = time.perf_counter()
         one.step(a.steps, sync=True)
         torch.cuda.synchronize(); barrier()
-        e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        e1 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(e1, op=dist.ReduceOp.MAX)
         one.close()
         replicas = {"value": world * sim_years_per_day(float(e1.item()) / a.steps, dt), "unit": "sim_years/day (sum over members)",

@@ -389,3 +389,23 @@ def test_golden_components(golden_dir, name, res, L):
     new, filt = dc.leapfrog(sa, sb, g["in_spec_e"], dtk, 0.04)                                   # leapfrog.F90:58-105
     assert rel(new, g["out_leap_l1"]) < 1e-15 and rel(filt, g["out_leap_l2"]) < 1e-15
     dc.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 flow end to end (launch line of the driver, gloo with host staging so that two ranks can
+    share this box's GPU): one JSON line from rank 0 with the contract's keys, sharded value plus the replica figure."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--workload", "T21L25"]
+    env = dict(os.environ, ISCA_BENCH_BACKEND="gloo", ISCA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["dtype"] == "f64" and d["scaling"] == "strong" and d["value"] > 0
+    assert d["replicas"]["value"] > 0 and "workload" in d["config"]
