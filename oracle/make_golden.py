@@ -189,6 +189,10 @@ def main():
             "T21", 25, 144, (2, 144),
             keep=lambda k: k.startswith("tab_") and k != "tab_legendre"
             or re.match(r"st_(ug|vg|tg|psg)_(000002|000144)$", k) is not None or k == "st_tr1_000144"),
+        # configs[0] for 10 days (1440 steps): the long-run tolerance of SURVEY 8d (1e-7 relative; 1-ulp noise ~2e-10)
+        "run_T21L25_10day": lambda: golden_run(
+            "T21", 25, 1440, (1440,),
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_001440$", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }

@@ -93,6 +93,22 @@ def test_golden_T21L25_one_day(golden_dir):
     dc.close()
 
 
+def test_golden_T21L25_ten_days(golden_dir):
+    """configs[0] for 10 days (1440 steps) against the reference run: SURVEY 8d's long-run bound is 1e-7 relative
+    (the reference's own response to a 1-ulp perturbation of the initial temperature is 2e-10 m/s after 10 days)."""
+    g = np.load(os.path.join(golden_dir, "run_T21L25_10day.npz"))
+    dc = make("T21", 25); dc.cold_start()
+    dc.step(1440)
+    errs = {k: rel(dc.get(k), g[f"st_{k}_001440"]) for k in ("ug", "vg", "tg", "psg")}
+    errs["tr"] = rel(dc.get("tr"), g["st_tr1_001440"])
+    print("10-day relative L-inf vs the reference:", errs)
+    assert all(e < 1e-7 for e in errs.values()), errs
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-7 and abs(t.max() - tmax) < 1e-7 and abs(np.abs(u).max() - umax) < 1e-7
+    dc.close()
+
+
 # ------------------------------------------------------------------ (b) against the oracle on seeded inputs
 @pytest.mark.parametrize("res,L,impl", [("T21", 25, 0), ("T42", 25, 0), ("T42", 25, 1)])
 def test_transform_stages_vs_oracle(res, L, impl):
