@@ -203,6 +203,15 @@ def main():
         path = os.path.join(GOLD, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {len(out)} arrays, {os.path.getsize(path)/1e6:.2f} MB")
+    if not a.only or a.only == "run_T42L25":
+        # configs[1]: T42L25 HS, 1 day; 3-D fields kept as the [::2, ::2, ::2] sample (every 2nd level, latitude, longitude)
+        out = golden_run("T42", 25, 144, (144,), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000144$", k) is not None)
+        for k in list(out):
+            if k.startswith("st_") and out[k].ndim == 3:
+                out[k + "_s222"] = np.ascontiguousarray(out.pop(k)[::2, ::2, ::2])
+        path = os.path.join(GOLD, "run_T42L25.npz")
+        np.savez_compressed(path, **out)
+        print(f"run_T42L25: {os.path.getsize(path)/1e6:.2f} MB")
     if not a.only or a.only == "tables_T85":
         out = golden_run("T85", 2, 0, (), keep=lambda k: k.startswith("tab_"))
         leg = out.pop("tab_legendre")

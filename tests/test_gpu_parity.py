@@ -93,6 +93,23 @@ def test_golden_T21L25_one_day(golden_dir):
     dc.close()
 
 
+def test_golden_T42L25_one_day(golden_dir):
+    """configs[1]: T42L25 Held-Suarez on one GPU, 1 day from the identical initial state, against the reference CPU run
+    (3-D fields compared on the committed [::2, ::2, ::2] sample of the reference output)."""
+    g = np.load(os.path.join(golden_dir, "run_T42L25.npz"))
+    dc = make("T42", 25); dc.cold_start()
+    dc.step(144)
+    for k, gk in (("ug", "st_ug_000144_s222"), ("vg", "st_vg_000144_s222"), ("tg", "st_tg_000144_s222"), ("tr", "st_tr1_000144_s222")):
+        assert rel(dc.get(k)[::2, ::2, ::2], g[gk]) < 1e-9, k          # stated 1-day tolerance
+    assert rel(dc.get("psg"), g["st_psg_000144"]) < 1e-9
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    # SURVEY 8c anchors of this run
+    assert abs(tmin - 262.166978) < 1e-6 and abs(tmax - 272.410821) < 1e-6 and abs(umax - 1.157461) < 1e-6
+    dc.close()
+
+
 def test_golden_T21L25_ten_days(golden_dir):
     """configs[0] for 10 days (1440 steps) against the reference run: SURVEY 8d's long-run bound is 1e-7 relative
     (the reference's own response to a 1-ulp perturbation of the initial temperature is 2e-10 m/s after 10 days)."""
