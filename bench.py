@@ -171,6 +171,8 @@ def main():
         "config": {"workload": f"{a.workload} Held-Suarez dry core, dt_atmos={dt:g}s, 360-day calendar",
                    "parallelism": f"lat-band x{a.gpus}" if a.gpus > 1 else "single GPU",
                    "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": "2 all-to-all + 1 halo + 1 all-reduce" if a.gpus > 1 else 0,
+                   "exchange_driver": (("RCCL calls issued by the library on the step's stream" if getattr(core, "native", False)
+                                        else f"torch.distributed ({backend}) between the device phases") if a.gpus > 1 else None),
                    "grid_tracer": ("sphum advected (van Leer + PPM) on a concurrent stream" if a.gpus == 1
                                    else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,

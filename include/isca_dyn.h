@@ -140,6 +140,16 @@ int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double 
 int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
                     const double *v, const double *t, double *udt, double *vdt, double *tdt);
 
+/* --- RCCL communicator of the sharded step (world_size > 1) ----------------------------------------
+ * With a communicator, isca_dyn_step runs the whole sharded step on the handle's stream: the lat<->m all-to-alls
+ * (replacing mpp_transmit in transpose_fourier / reverse_transpose_fourier, transforms.F90:990-1054), the tracer halo
+ * rows (mpp_update_domains, fv_advection.F90:161-162,259) and the all-reduce of the fixer sums (transforms.F90:1059-1077)
+ * as RCCL calls between the kernels, nothing returning to the host.  Rank 0 calls isca_comm_get_unique_id and
+ * distributes the 128 bytes; every rank calls isca_dyn_comm_init (collective).  RCCL is loaded with dlopen. */
+int isca_comm_get_unique_id(void *id128);
+int isca_dyn_comm_init(isca_dyn_t *h, const void *id128);
+int isca_comm_selftest(int device, double *max_err);     /* one-rank communicator: load RCCL, run every collective once */
+
 /* --- components of the step on caller fields (world_size == 1) -------------------------------------
  * Each entry replaces one public routine the reference's callers use on its own, and runs the kernel or
  * device function the step itself uses.  Spectral arrays (m,n,lev) complex, grid arrays (lon,lat,lev). */

@@ -11,6 +11,7 @@ ARCH = "gfx950"
 
 UNITS = [  # (source, extra flags)
     ("tables.cpp", ["-ffp-contract=off"]),      # host tables: reproduce the reference's non-FMA fp64 results
+    ("comm.cpp", []),                           # RCCL bound with dlopen (no link-time dependency)
     ("kernels.hip", []),
     ("api.hip", []),
 ]
@@ -46,7 +47,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

@@ -166,6 +166,7 @@ static FieldList inverse_list(isca_dyn *h, int tl) {
 extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   if (!h) return 0;
   timer_collect(h);
+  if (h->comm) { hipStreamSynchronize(h->stream); delete h->comm; h->comm = nullptr; }
   for (void *p : h->allocs) hipFree(p);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -696,12 +697,36 @@ static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, poi
   h->step_count += 1;
 }
 
+// One step of the latitude-band sharded model with the exchanges issued on the same stream through RCCL:
+// lat -> m all-to-all (transpose_fourier), m -> lat all-to-all (reverse_transpose_fourier), the tracer's 2-row halo
+// exchange (mpp_update_domains in fv_advection) and the all-reduce of the 10 fixer sums.  Nothing returns to the host.
+static void sharded_step(isca_dyn *h) {
+  const StepScalars sc = step_scalars(h);
+  const Geom &g = h->g;
+  isca::Comm &c = *h->comm;
+  upload_wave_matrices(h, sc.delta_t);
+  phase0(h, sc);
+  if (h->tracer_on) {
+    const size_t n = (size_t)3 * g.L * 2 * g.I;
+    Timed t(h, "halo_exchange");
+    c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream);
+  }
+  { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
+  phase1(h, sc);
+  { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
+  phase2(h, sc);
+  { Timed t(h, "all_reduce"); c.all_reduce_sum(h->d.red, 10, h->stream); }
+  phase3(h, sc);
+}
+
 extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   API_BEGIN
   if (!h) fail("null handle");
   if (!h->have_state) fail("isca_dyn_step: no state (call isca_dyn_cold_start or set_state first)");
-  require_single(h, "isca_dyn_step");
+  if (h->g.P > 1 && !h->comm)
+    fail("isca_dyn_step: world_size > 1 needs isca_dyn_comm_init first (or drive isca_dyn_step_phase and the exchanges from the host)");
   for (int i = 0; i < nsteps; ++i) {
+    if (h->g.P > 1) { sharded_step(h); continue; }
     const StepScalars sc = step_scalars(h);
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
@@ -713,6 +738,56 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     HIP_CHECK(hipMemcpy(red, h->d.red, sizeof(red), hipMemcpyDeviceToHost));
     if (!(std::isfinite(red[16]) && std::isfinite(red[17]))) fail("temperatures out of valid range (non-finite state)");
   }
+  API_END
+}
+// RCCL communicator for the sharded step.  Rank 0 obtains the 128-byte id and hands it to the other ranks by any
+// means (the Python driver broadcasts it with torch.distributed); every rank then calls isca_dyn_comm_init.
+extern "C" int isca_comm_get_unique_id(void *id128) {
+  API_BEGIN
+  if (!id128) fail("null argument");
+  isca::Comm::unique_id(id128);
+  API_END
+}
+extern "C" int isca_dyn_comm_init(isca_dyn_t *h, const void *id128) {
+  API_BEGIN
+  if (!h || !id128) fail("null argument");
+  if (h->comm) fail("comm_init: communicator already initialised");
+  HIP_CHECK(hipSetDevice(h->cfg.device));
+  h->comm = new isca::Comm(id128, h->cfg.rank, h->cfg.world_size);
+  API_END
+}
+// Exercises every collective of the sharded step on a communicator of this process alone (world_size 1):
+// checks that RCCL can be loaded and that send/recv, grouped exchange and all-reduce run on the given device.
+extern "C" int isca_comm_selftest(int device, double *max_err) {
+  API_BEGIN
+  HIP_CHECK(hipSetDevice(device));
+  char id[isca::Comm::UNIQUE_ID_BYTES];
+  isca::Comm::unique_id(id);
+  isca::Comm c(id, 0, 1);
+  const size_t n = 4096;
+  std::vector<double> a(n), b(n, 0.0), r(16);
+  for (size_t i = 0; i < n; ++i) a[i] = 0.25 * (double)i - 7.0;
+  for (int i = 0; i < 16; ++i) r[i] = 1.0 + i;
+  double *da, *db, *dr;
+  hipStream_t s;
+  HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  HIP_CHECK(hipMalloc((void **)&da, n * sizeof(double))); HIP_CHECK(hipMalloc((void **)&db, n * sizeof(double)));
+  HIP_CHECK(hipMalloc((void **)&dr, 16 * sizeof(double)));
+  HIP_CHECK(hipMemcpyAsync(da, a.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemsetAsync(db, 0, n * sizeof(double), s));
+  HIP_CHECK(hipMemcpyAsync(dr, r.data(), 16 * sizeof(double), hipMemcpyHostToDevice, s));
+  c.all_to_all(da, db, n, s);
+  c.all_reduce_sum(dr, 10, s);
+  c.halo(da, da, db, db, 16, s);              // no neighbours: must be a no-op
+  HIP_CHECK(hipMemcpyAsync(b.data(), db, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  std::vector<double> r2(16);
+  HIP_CHECK(hipMemcpyAsync(r2.data(), dr, 16 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  double e = 0.0;
+  for (size_t i = 0; i < n; ++i) e = std::max(e, std::fabs(a[i] - b[i]));
+  for (int i = 0; i < 16; ++i) e = std::max(e, std::fabs(r[i] - r2[i]));
+  if (max_err) *max_err = e;
+  hipFree(da); hipFree(db); hipFree(dr); hipStreamDestroy(s);
   API_END
 }
 extern "C" int isca_dyn_synchronize(isca_dyn_t *h) {

@@ -5,6 +5,7 @@
 #include <vector>
 #include <stdexcept>
 #include "tables.h"
+#include "comm.h"
 
 namespace isca {
 
@@ -120,4 +121,5 @@ struct isca_dyn {
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_on = false;           // advect the grid tracer (single rank)
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
+  isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
 };

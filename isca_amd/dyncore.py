@@ -103,6 +103,9 @@ def load_library():
         "isca_implicit_correction": [H, dp, dp, dp, dp, dp, dp, dp, dp, dp, C.c_double],
         "isca_compute_spectral_damping": [H, C.c_int, dp, dp, C.c_double],
         "isca_leapfrog": [H, dp, dp, dp, C.c_double, C.c_double],
+        "isca_comm_get_unique_id": [C.c_char_p],
+        "isca_dyn_comm_init": [H, C.c_char_p],
+        "isca_comm_selftest": [C.c_int, dp],
         "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     }
     for name, argtypes in sig.items():
@@ -127,6 +130,7 @@ EXPORTED_SYMBOLS = [
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
+    "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -491,6 +495,15 @@ class DynCore:
         p, c, d = self._spec3(previous), self._spec3(current), self._spec3(dt_field)
         self._check(self.lib.isca_leapfrog(self._h, *[_dptr(x.view(np.float64)) for x in (p, c, d)], float(delta_t), float(robert_coeff)))
         return p, c
+
+    @staticmethod
+    def comm_selftest(device: int = 0) -> float:
+        """Load RCCL and run each collective of the sharded step once on a one-rank communicator; returns the max error."""
+        lib = load_library()
+        e = C.c_double(-1.0)
+        if lib.isca_comm_selftest(device, C.cast(C.byref(e), C.POINTER(C.c_double))) != 0:
+            raise IscaError(lib.isca_last_error().decode())
+        return e.value
 
     # -- measurement
     def bench_transform_pair(self, nfields: int, reps: int = 20):

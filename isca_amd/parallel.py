@@ -9,6 +9,9 @@ the C-ABI and the exchanges go through torch.distributed ("nccl" = RCCL over xGM
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+
 import numpy as np
 
 from . import dyncore
@@ -98,8 +101,35 @@ class ShardedDynCore(dyncore.DynCore):
         self._red = torch.as_tensor(_DevPtr(b, 8 * n), device="cuda")
         ptrs, hbytes = self.halo_buffers()
         self._halo = [torch.as_tensor(_DevPtr(p, hbytes), device="cuda") for p in ptrs] if hbytes else None
+        # Native mode: the library issues the exchanges itself through RCCL on our stream and a whole run of steps is one
+        # call (no Python, no torch between the kernels).  Default with the nccl backend; ISCA_COMM=torch|native overrides.
+        self.native = False
+        mode = os.environ.get("ISCA_COMM", "native" if dist.get_backend(group) == "nccl" else "torch")
+        if mode == "native":
+            box = [None]
+            if cfg.rank == 0:
+                buf = C.create_string_buffer(128)
+                if self.lib.isca_comm_get_unique_id(buf) == 0:
+                    box[0] = buf.raw
+                else:
+                    box[0] = "ERR:" + self.lib.isca_last_error().decode()
+            dist.broadcast_object_list(box, src=0, group=group)
+            why = box[0] if not isinstance(box[0], bytes) else None
+            if why is None:
+                ok = self.lib.isca_dyn_comm_init(self._h, box[0]) == 0
+                flags = [None] * cfg.world_size
+                dist.all_gather_object(flags, ok if ok else self.lib.isca_last_error().decode(), group=group)
+                bad = [f for f in flags if f is not True]
+                if bad:
+                    why = str(bad[0])
+                else:
+                    self.native = True
+            if why is not None and cfg.rank == 0:
+                print(f"isca_amd: native RCCL exchange not available ({why}); exchanges go through torch.distributed", flush=True)
 
     def step(self, nsteps: int = 1, sync: bool = True):
+        if self.native:
+            return super().step(nsteps, sync)
         with self._torch.cuda.stream(self._stream):
             for _ in range(nsteps):
                 self.step_phase(0)                                          # grid tendencies + FFT (+ tracer halo rows)

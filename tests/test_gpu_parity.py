@@ -442,3 +442,9 @@ def test_bench_two_ranks_on_one_gpu():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["dtype"] == "f64" and d["scaling"] == "strong" and d["value"] > 0
     assert d["replicas"]["value"] > 0 and "workload" in d["config"]
+
+
+def test_rccl_layer_selftest():
+    """The native exchange layer (RCCL through dlopen): library loads, communicator of one rank is created on this GPU,
+    grouped send/recv all-to-all, all-reduce and the (empty) halo exchange run on a stream and return the data unchanged."""
+    assert dyncore.DynCore.comm_selftest(0) == 0.0
