@@ -140,6 +140,13 @@ int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double 
 int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
                     const double *v, const double *t, double *udt, double *vdt, double *tdt);
 
+/* --- diagnostics: what spectral_diagnostics sends to diag_manager every step (spectral_dynamics.F90:1705-1867),
+ * accumulated on the device for the time means of the diag_table.  Field names as registered by the reference:
+ * ps, ucomp, vcomp, temp, vor, div, omega, sphum, ucomp_sq, vcomp_sq, ucomp_vcomp, temp_sq, ucomp_temp, vcomp_temp,
+ * omega_sq, omega_temp, ucomp_omega, vcomp_omega, vcomp_vor, wspd. */
+int isca_dyn_diag_select(isca_dyn_t *h, const char *comma_separated_names);     /* "" switches the accumulation off */
+int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host, size_t count, long *nsteps, int reset);   /* mean over the steps since the last reset; host may be NULL */
+
 /* --- RCCL communicator of the sharded step (world_size > 1) ----------------------------------------
  * With a communicator, isca_dyn_step runs the whole sharded step on the handle's stream: the lat<->m all-to-alls
  * (replacing mpp_transmit in transpose_fourier / reverse_transpose_fourier, transforms.F90:990-1054), the tracer halo

@@ -692,6 +692,10 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+  if (h->diag_mask) {   // spectral_diagnostics(Time_next, psg(future), ug(future), ...) at the end of atmosphere (atmosphere.F90:344)
+    Timed t(h, "diagnostics"); launch_diag_accumulate(*h, sc.fut, h->stream);
+    h->diag_count += 1;
+  }
   h->previous = sc.cur;
   h->current = sc.fut;
   h->step_count += 1;
@@ -1287,6 +1291,66 @@ extern "C" int isca_leapfrog(isca_dyn_t *h, double *previous, double *current, c
   double *dt[4] = {};
   st[2][0] = previous; st[2][1] = current; dt[2] = const_cast<double *>(dt_field);
   spec_stage(h, 2, delta_t, robert_coeff, st, dt, true);
+  API_END
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Diagnostics (spectral_diagnostics + diag_manager's time averaging, spectral_dynamics.F90:1554-1867)
+// ---------------------------------------------------------------------------------------------------
+static int diag_index(const std::string &nm) {
+  for (int i = 0; i < NDIAG; ++i) if (nm == DIAG_NAMES[i]) return i;
+  return -1;
+}
+// select the fields to accumulate: comma-separated reference names ("ps,ucomp,vcomp,temp,vor,div"), "" switches off
+extern "C" int isca_dyn_diag_select(isca_dyn_t *h, const char *names) {
+  API_BEGIN
+  if (!h || !names) fail("null argument");
+  unsigned mask = 0;
+  std::string all(names), tok;
+  for (size_t i = 0; i <= all.size(); ++i) {
+    if (i == all.size() || all[i] == ',') {
+      while (!tok.empty() && tok.back() == ' ') tok.pop_back();
+      while (!tok.empty() && tok.front() == ' ') tok.erase(tok.begin());
+      if (!tok.empty()) {
+        const int k = diag_index(tok);
+        if (k < 0) fail("diag_select: unknown field '" + tok + "'");
+        if (k == 7 && !h->tracer_on) fail("diag_select: no grid tracer in this configuration");
+        mask |= 1u << k;
+      }
+      tok.clear();
+    } else tok.push_back(all[i]);
+  }
+  const Geom &g = h->g;
+  const size_t ng2 = (size_t)g.Jl * g.I, ng3 = ng2 * g.L;
+  for (int k = 0; k < NDIAG; ++k)
+    if ((mask >> k & 1u) && !h->d.diag_acc[k]) h->d.diag_acc[k] = dalloc<double>(h, k == 0 ? ng2 : ng3);
+  h->diag_mask = mask;
+  for (int k = 0; k < NDIAG; ++k)
+    if (mask >> k & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[k], 0, (k == 0 ? ng2 : ng3) * sizeof(double), h->stream));
+  h->diag_count = 0;
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  API_END
+}
+// time mean of a selected field since the last reset (sum / number of steps) and that number; reset != 0 starts a new interval
+extern "C" int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host, size_t count, long *nsteps, int reset) {
+  API_BEGIN
+  if (!h || !name) fail("null argument");
+  const int k = diag_index(name);
+  if (k < 0 || !(h->diag_mask >> k & 1u)) fail(std::string("diag_read: field not selected: ") + name);
+  const Geom &g = h->g;
+  const size_t n = (size_t)g.Jl * g.I * (k == 0 ? 1 : g.L);
+  if (nsteps) *nsteps = h->diag_count;
+  if (host) {
+    if (count != n) fail(std::string("diag_read: wrong element count for ") + name);
+    d2h(h, host, h->d.diag_acc[k], n);
+    if (h->diag_count > 0) for (size_t i = 0; i < n; ++i) host[i] = host[i] / (double)h->diag_count;
+  }
+  if (reset) {
+    for (int q = 0; q < NDIAG; ++q)
+      if (h->diag_mask >> q & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[q], 0, (size_t)g.Jl * g.I * (q == 0 ? 1 : g.L) * sizeof(double), h->stream));
+    h->diag_count = 0;
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
   API_END
 }
 

@@ -62,6 +62,7 @@ struct Dev {
   // ---- prognostic state
   double *ug[2], *vg[2], *tg[2], *psg[2], *tr[2];   // grid, two time levels
   double *vorg, *divg, *dxT, *dyT, *dxlp, *dylp;    // grid, at `current`
+  double *diag_acc[32] = {};                        // diagnostics: running sums of the selected fields
   double *wg_full;
   double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
   double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
@@ -121,5 +122,7 @@ struct isca_dyn {
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_on = false;           // advect the grid tracer (single rank)
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
+  unsigned diag_mask = 0;           // spectral_diagnostics fields being accumulated (bit = index in DIAG_NAMES)
+  long diag_count = 0;              // send_data calls since the last reset
   isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
 };

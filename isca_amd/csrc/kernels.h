@@ -56,6 +56,11 @@ void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const dou
                         double *dummy_a, double *dummy_b, hipStream_t s);
 void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s);
 
+// spectral_diagnostics (spectral_dynamics.F90:1705-1867): add this step's fields to the running sums
+constexpr int NDIAG = 20;
+extern const char *const DIAG_NAMES[NDIAG];     // reference field names, index = bit in the mask; [0] is 2-D
+void launch_diag_accumulate(const isca_dyn &h, int fut, hipStream_t s);
+
 size_t column_partials_count(const isca_dyn &h);
 
 }  // namespace isca

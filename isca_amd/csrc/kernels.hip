@@ -2269,4 +2269,54 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
 
+// =====================================================================================================
+// Diagnostics: what spectral_diagnostics hands to diag_manager's send_data every step
+// (spectral_dynamics.F90:1728-1790), accumulated on the device for the time means of the diag_table.
+// u, v, T, ps, tracer: the new time level; omega = wg_full; vor, div: vorg/divg, already those of the new level
+// (:933-934).
+// =====================================================================================================
+const char *const DIAG_NAMES[NDIAG] = {"ps", "ucomp", "vcomp", "temp", "vor", "div", "omega", "sphum", "ucomp_sq", "vcomp_sq",
+                                       "ucomp_vcomp", "temp_sq", "ucomp_temp", "vcomp_temp", "omega_sq", "omega_temp",
+                                       "ucomp_omega", "vcomp_omega", "vcomp_vor", "wspd"};
+struct DiagArgs {
+  const double *u, *v, *t, *ps, *vor, *div, *w, *tr;
+  double *acc[NDIAG];
+  unsigned mask;
+  unsigned n3, n2;
+};
+__global__ __launch_bounds__(256) void k_diag_accumulate(DiagArgs a) {
+  const unsigned i = (blockIdx.x * 256u + threadIdx.x) * 2u;
+  if (i >= a.n3) return;
+  const unsigned m = a.mask;
+  double2 u = {0, 0}, v = {0, 0}, t = {0, 0}, vo = {0, 0}, dv = {0, 0}, w = {0, 0}, q = {0, 0};
+  // inputs first (only those some selected field needs), then the read-modify-writes of the sums
+  if (m & 0x91502u) u = *(const double2 *)(a.u + i);          // ucomp, ucomp_sq, ucomp_vcomp, ucomp_temp, ucomp_omega, wspd
+  if (m & 0xE2604u) v = *(const double2 *)(a.v + i);          // vcomp, vcomp_sq, ucomp_vcomp, vcomp_temp, vcomp_omega, vcomp_vor, wspd
+  if (m & 0x0B808u) t = *(const double2 *)(a.t + i);          // temp, temp_sq, ucomp_temp, vcomp_temp, omega_temp
+  if (m & 0x40010u) vo = *(const double2 *)(a.vor + i);       // vor, vcomp_vor
+  if (m & 0x00020u) dv = *(const double2 *)(a.div + i);
+  if (m & 0x3C040u) w = *(const double2 *)(a.w + i);          // omega, omega_sq, omega_temp, ucomp_omega, vcomp_omega
+  if ((m & 0x00080u) && a.tr) q = *(const double2 *)(a.tr + i);
+#define ACC(bit, ex, ey)                                                                   \
+  if (m & (1u << (bit))) { double2 s = *(double2 *)(a.acc[bit] + i); s.x += (ex); s.y += (ey); *(double2 *)(a.acc[bit] + i) = s; }
+  ACC(1, u.x, u.y) ACC(2, v.x, v.y) ACC(3, t.x, t.y) ACC(4, vo.x, vo.y) ACC(5, dv.x, dv.y) ACC(6, w.x, w.y) ACC(7, q.x, q.y)
+  ACC(8, u.x * u.x, u.y * u.y) ACC(9, v.x * v.x, v.y * v.y) ACC(10, u.x * v.x, u.y * v.y) ACC(11, t.x * t.x, t.y * t.y)
+  ACC(12, u.x * t.x, u.y * t.y) ACC(13, v.x * t.x, v.y * t.y) ACC(14, w.x * w.x, w.y * w.y) ACC(15, w.x * t.x, w.y * t.y)
+  ACC(16, u.x * w.x, u.y * w.y) ACC(17, w.x * v.x, w.y * v.y) ACC(18, v.x * vo.x, v.y * vo.y)
+  ACC(19, sqrt(u.x * u.x + v.x * v.x), sqrt(u.y * u.y + v.y * v.y))
+#undef ACC
+  if ((m & 1u) && i < a.n2) { double2 s = *(double2 *)(a.acc[0] + i); const double2 p = *(const double2 *)(a.ps + i); s.x += p.x; s.y += p.y; *(double2 *)(a.acc[0] + i) = s; }
+}
+void launch_diag_accumulate(const isca_dyn &h, int fut, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  DiagArgs a;
+  a.u = d.ug[fut]; a.v = d.vg[fut]; a.t = d.tg[fut]; a.ps = d.psg[fut]; a.vor = d.vorg; a.div = d.divg; a.w = d.wg_full;
+  a.tr = h.tracer_on ? d.tr[fut] : nullptr;
+  for (int i = 0; i < NDIAG; ++i) a.acc[i] = d.diag_acc[i];
+  a.mask = h.diag_mask;
+  a.n2 = (unsigned)(g.Jl * g.I); a.n3 = a.n2 * (unsigned)g.L;
+  hipLaunchKernelGGL(k_diag_accumulate, dim3((a.n3 / 2 + 255) / 256), dim3(256), 0, s, a);
+}
+
 }  // namespace isca

@@ -1,0 +1,138 @@
+"""diag_table and history files for the dynamics diagnostics.
+
+Counterpart, for the fields of the hot path, of the harness's DiagTable (src/extra/python/isca/diagtable.py) and of what
+diag_manager does with the send_data calls of spectral_diagnostics (atmos_spectral/model/spectral_dynamics.F90:1554-1867):
+time means over the output interval, one record per interval, written as netCDF-3 with the reference's dimension and
+variable names (lon, lat, pfull, phalf, time; ps, ucomp, vcomp, temp, vor, div, ...; static pk, bk).
+The sums are accumulated on the device every step (isca_dyn_diag_select / isca_dyn_diag_read).
+"""
+from __future__ import annotations
+
+import os
+import numpy as np
+from scipy.io import netcdf_file
+
+from .dyncore import IscaError
+
+# name -> (long name, units) as registered by the reference (spectral_dynamics.F90:1604-1690)
+FIELDS = {
+    "ps": ("surface pressure", "pascals"), "ucomp": ("zonal wind component", "m/sec"),
+    "vcomp": ("meridional wind component", "m/sec"), "temp": ("temperature", "deg_k"), "vor": ("vorticity", "sec**-1"),
+    "div": ("divergence", "sec**-1"), "omega": ("dp/dt vertical velocity", "Pa/sec"), "sphum": ("specific humidity", "kg/kg"),
+    "ucomp_sq": ("zonal wind squared", "(m/sec)**2"), "vcomp_sq": ("meridional wind squared", "(m/sec)**2"),
+    "ucomp_vcomp": ("zonal wind * meridional wind", "(m/sec)**2"), "temp_sq": ("temperature squared", "deg_k**2"),
+    "ucomp_temp": ("zonal wind * temperature", "m*K/sec"), "vcomp_temp": ("meridional wind * temperature", "m*K/sec"),
+    "omega_sq": ("omega squared", "(Pa/sec)**2"), "omega_temp": ("dp/dt * temperature", "Pa*K/sec"),
+    "ucomp_omega": ("vertical * zonal wind", "m*Pa/sec**2"), "vcomp_omega": ("vertical * meridional wind", "m*Pa/sec**2"),
+    "vcomp_vor": ("meridional wind * vorticity", "m/sec**2"), "wspd": ("wind speed", "m/sec"),
+}
+STATIC = {"pk": ("vertical coordinate pressure values", "pascals"), "bk": ("vertical coordinate sigma values", "none")}
+_SECONDS = {"seconds": 1, "minutes": 60, "hours": 3600, "days": 86400}
+
+
+class DiagTable:
+    """add_file / add_field as in diagtable.py:60-120 (one output file is supported per table entry)."""
+
+    def __init__(self):
+        self.files: dict = {}
+
+    def add_file(self, name, freq, units="hours", time_units=None):
+        if units not in _SECONDS:
+            raise IscaError(f"diag_table: unsupported frequency units {units!r}")
+        self.files[name] = {"name": name, "freq": freq, "units": units, "time_units": time_units or units, "fields": []}
+
+    def add_field(self, module, name, time_avg=False, files=None):
+        if module != "dynamics":
+            raise IscaError(f"diag_table: module {module!r} is outside the dynamical core (only 'dynamics')")
+        if name not in FIELDS and name not in STATIC:
+            raise IscaError(f"diag_table: unknown dynamics field {name!r}")
+        for f in (files or list(self.files)):
+            self.files[f]["fields"].append({"name": name, "time_avg": bool(time_avg)})
+
+    def is_valid(self):
+        return len(self.files) > 0
+
+    def copy(self):
+        import copy
+        d = DiagTable()
+        d.files = copy.deepcopy(self.files)
+        return d
+
+
+class History:
+    """One history file of a run: device-side sums every step, one record per output interval."""
+
+    def __init__(self, core, table_file: dict, dt_atmos: float, path: str, start_seconds: float = 0.0):
+        self.core, self.spec, self.dt, self.path = core, table_file, float(dt_atmos), path
+        self.interval = table_file["freq"] * _SECONDS[table_file["units"]]
+        if self.interval % dt_atmos:
+            raise IscaError("diag_table: output interval must be a multiple of dt_atmos")
+        self.every = int(self.interval // dt_atmos)
+        self.names = [f["name"] for f in table_file["fields"] if f["name"] in FIELDS]
+        self.avg = {f["name"]: f["time_avg"] for f in table_file["fields"]}
+        self.static = [f["name"] for f in table_file["fields"] if f["name"] in STATIC]
+        self.t0 = float(start_seconds)
+        self.elapsed_steps = 0
+        self.records = []                       # (t1, t2, {name: array})
+        if self.names:
+            core.diag_select(self.names)
+
+    def after_steps(self, nsteps: int):
+        """Call after every `nsteps` steps of the model (a multiple of steps per interval boundary is not required)."""
+        self.elapsed_steps += nsteps
+        if self.elapsed_steps % self.every == 0:
+            self._flush()
+
+    def _flush(self):
+        rec = {}
+        for i, nm in enumerate(self.names):
+            mean, n = self.core.diag_mean(nm)
+            if not self.avg[nm]:                # instantaneous sample at the end of the interval
+                mean = self.core.get({"ucomp": "ug", "vcomp": "vg", "temp": "tg", "ps": "psg", "vor": "vorg", "div": "divg",
+                                      "omega": "wg_full", "sphum": "tr"}.get(nm, nm)) if nm in (
+                    "ucomp", "vcomp", "temp", "ps", "vor", "div", "omega", "sphum") else mean
+            rec[nm] = mean
+        if self.names:
+            self.core.diag_reset(self.names[0])
+        t2 = self.t0 + self.elapsed_steps * self.dt
+        self.records.append((t2 - self.interval, t2, rec))
+
+    def close(self):
+        c, tu = self.core, self.spec["time_units"]
+        scale = _SECONDS[tu]
+        f = netcdf_file(self.path, "w", version=2)
+        f.createDimension("time", None)
+        for nm, n, vals, units, axis in (("lon", c.I, c.table("deg_lon"), "degrees_E", "X"), ("lat", c.J, c.table("deg_lat"), "degrees_N", "Y")):
+            f.createDimension(nm, n)
+            v = f.createVariable(nm, "d", (nm,)); v[:] = vals; v.units = units; v.cartesian_axis = axis
+        pk, bk = c.table("pk"), c.table("bk")
+        p_half = (pk + bk * c.cfg.reference_sea_level_press) / 100.0            # approx. pressure levels, hPa (:1583-1589)
+        lnp = np.log(np.where(p_half > 0, p_half, 1.0))
+        p_full = np.empty(c.L)
+        for k in range(c.L):                                                     # Simmons-Burridge full levels of the reference surface pressure
+            if p_half[k] == 0.0:
+                p_full[k] = np.exp(lnp[k + 1] - 1.0)
+            else:
+                p_full[k] = np.exp(lnp[k + 1] - (1.0 - p_half[k] * (lnp[k + 1] - lnp[k]) / (p_half[k + 1] - p_half[k])))
+        for nm, n, vals in (("phalf", c.L + 1, p_half), ("pfull", c.L, p_full)):
+            f.createDimension(nm, n)
+            v = f.createVariable(nm, "d", (nm,)); v[:] = vals; v.units = "hPa"; v.cartesian_axis = "Z"; v.positive = "down"
+        tv = f.createVariable("time", "d", ("time",)); tv.units = f"{tu} since 0001-01-01 00:00:00"; tv.cartesian_axis = "T"
+        t1v = f.createVariable("average_T1", "d", ("time",)); t2v = f.createVariable("average_T2", "d", ("time",))
+        dtv = f.createVariable("average_DT", "d", ("time",))
+        for nm in self.static:
+            v = f.createVariable(nm, "d", ("phalf",)); v[:] = c.table(nm); v.long_name, v.units = STATIC[nm]
+        out = {}
+        for nm in self.names:
+            dims = ("time", "lat", "lon") if nm == "ps" else ("time", "pfull", "lat", "lon")
+            v = f.createVariable(nm, "d", dims); v.long_name, v.units = FIELDS[nm]
+            if self.avg[nm]:
+                v.cell_methods = "time: mean"; v.time_avg_info = "average_T1,average_T2,average_DT"
+            out[nm] = v
+        for r, (t1, t2, rec) in enumerate(self.records):
+            tv[r] = 0.5 * (t1 + t2) / scale; t1v[r] = t1 / scale; t2v[r] = t2 / scale; dtv[r] = (t2 - t1) / scale
+            for nm in self.names:
+                out[nm][r] = rec[nm]
+        f.close()
+        if self.names:
+            self.core.diag_select("")

@@ -106,6 +106,8 @@ def load_library():
         "isca_comm_get_unique_id": [C.c_char_p],
         "isca_dyn_comm_init": [H, C.c_char_p],
         "isca_comm_selftest": [C.c_int, dp],
+        "isca_dyn_diag_select": [H, C.c_char_p],
+        "isca_dyn_diag_read": [H, C.c_char_p, dp, C.c_size_t, C.POINTER(C.c_long), C.c_int],
         "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
     }
     for name, argtypes in sig.items():
@@ -131,6 +133,7 @@ EXPORTED_SYMBOLS = [
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest",
+    "isca_dyn_diag_select", "isca_dyn_diag_read",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -504,6 +507,24 @@ class DynCore:
         if lib.isca_comm_selftest(device, C.cast(C.byref(e), C.POINTER(C.c_double))) != 0:
             raise IscaError(lib.isca_last_error().decode())
         return e.value
+
+    # -- diagnostics (spectral_diagnostics + time averaging)
+    def diag_select(self, names):
+        """names: iterable of the reference's diagnostic field names (or a comma-separated string); () switches off."""
+        txt = names if isinstance(names, str) else ",".join(names)
+        self._check(self.lib.isca_dyn_diag_select(self._h, txt.encode()))
+
+    def diag_mean(self, name: str, reset: bool = False):
+        """-> (time mean since the last reset, number of steps in it)"""
+        a = np.zeros((self.Jl, self.I) if name == "ps" else (self.L, self.Jl, self.I))
+        n = C.c_long()
+        self._check(self.lib.isca_dyn_diag_read(self._h, name.encode(), _dptr(a), a.size, C.byref(n), 1 if reset else 0))
+        return a, n.value
+
+    def diag_reset(self, name_of_any_selected_field: str):
+        n = C.c_long()
+        self._check(self.lib.isca_dyn_diag_read(self._h, name_of_any_selected_field.encode(), None, 0, C.byref(n), 1))
+        return n.value
 
     # -- measurement
     def bench_transform_pair(self, nfields: int, reps: int = 20):

@@ -7,17 +7,20 @@ archives (`restarts/res0001.tar.gz`, ...).  `run(i)` is one segment of `main_nml
 restart archive i-1 (or cold, for i == 1), advances the GPU core, and archives the new restart.  Where the
 reference renders run.sh and launches the Fortran executable under mpirun, this drives
 atmosphere_init / atmosphere / atmosphere_end of `isca_amd.atmosphere` directly.
-Diagnostics (`diag_table`, netCDF history files) are outside the hot path.
+The `diag_table` of the dynamics fields (time means accumulated on the device) is written as netCDF history files
+into the run's data folder (`isca_amd/diag.py`).
 """
 from __future__ import annotations
 
 import copy
 import logging
+import math
 import os
 import shutil
 import tarfile
 
 from . import atmosphere as atm
+from .diag import DiagTable, History
 from .dyncore import RESOLUTIONS, IscaError
 
 
@@ -37,6 +40,7 @@ class Experiment:
         self.datadir = os.path.join(database if database else os.path.join(workbase, "data"), name)
         self.restartdir = os.path.join(self.datadir, "restarts")
         self.namelist: dict = {}
+        self.diag_table = DiagTable()                 # experiment.py:79; history files land in the run's data folder
         self.resolution: str | None = None
         self.log = logging.getLogger("isca_amd.experiment")
 
@@ -111,15 +115,32 @@ class Experiment:
                 raise IOError("Restart file not found, expecting file %r" % restart_file)
             self.extract_restart_archive(restart_file, indir)
         nsteps = self.steps_per_run()
+        dt = self.namelist["main_nml"]["dt_atmos"]
         try:
-            atm.atmosphere_init(copy.deepcopy(self.namelist), run_dir=self.rundir)
-            atm.atmosphere(nsteps)
+            core = atm.atmosphere_init(copy.deepcopy(self.namelist), run_dir=self.rundir)
+            hist = [History(core, spec, dt, os.path.join(self.rundir, name + ".nc"), start_seconds=(i - 1) * nsteps * dt)
+                    for name, spec in self.diag_table.files.items() if spec["fields"]]
+            if len({tuple(h.names) for h in hist}) > 1:
+                raise IscaError("diag_table: all files of one run must list the same dynamics fields")
+            chunk = nsteps
+            for h in hist:
+                chunk = math.gcd(chunk, h.every)
+            for _ in range(nsteps // chunk):
+                atm.atmosphere(chunk)
+                for h in hist:
+                    h.after_steps(chunk)
+            for h in hist:
+                h.close()
             atm.atmosphere_end()
         except IscaError as e:
             atm.atmosphere_end()
             self.log.error("Run %d failed: %s", i, e)
             raise FailedRunError(str(e))
         os.makedirs(outdir)
+        for name, spec in self.diag_table.files.items():          # experiment.py:325-330: history files into the data folder
+            src = os.path.join(self.rundir, name + ".nc")
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(outdir, name + ".nc"))
         self.make_restart_archive(self.get_restart_file(i), resdir)
         shutil.rmtree(resdir)
         self.write_namelist(outdir)
@@ -144,4 +165,5 @@ class Experiment:
         e.datadir = os.path.join(os.path.dirname(self.datadir), new_experiment_name)
         e.restartdir = os.path.join(e.datadir, "restarts")
         e.namelist = copy.deepcopy(self.namelist)
+        e.diag_table = self.diag_table.copy()
         return e

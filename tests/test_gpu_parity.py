@@ -358,7 +358,14 @@ def test_experiment_restart_chaining(tmp_path):
     a = Experiment("chained", str(tmp_path))
     a.set_resolution("T21", 10)
     a.update_namelist(nml)
+    a.diag_table.add_file("atmos_hourly", 1, "hours", time_units="days")
+    for nm in ("ps", "ucomp", "temp"):
+        a.diag_table.add_field("dynamics", nm, time_avg=True)
     assert a.run(1) and a.run(2)
+    from scipy.io import netcdf_file
+    f = netcdf_file(os.path.join(a.get_outputdir(2), "atmos_hourly.nc"), "r", mmap=False)
+    assert f.variables["temp"].shape == (2, 10, 32, 64) and np.allclose(f.variables["average_T1"][:] * 24, [2.0, 3.0])
+    f.close()
     assert a.run(2) is False                                   # existing output, overwrite_data False
     b = a.derive("single")
     b.update_namelist({"main_nml": {"hours": 4}})
@@ -448,3 +455,59 @@ def test_rccl_layer_selftest():
     """The native exchange layer (RCCL through dlopen): library loads, communicator of one rank is created on this GPU,
     grouped send/recv all-to-all, all-reduce and the (empty) halo exchange run on a stream and return the data unchanged."""
     assert dyncore.DynCore.comm_selftest(0) == 0.0
+
+
+# ------------------------------------------------------------------ diagnostics (SURVEY 8f rank 3)
+def test_diagnostics_time_means(tmp_path):
+    """Device-side time means of what spectral_diagnostics sends every step (spectral_dynamics.F90:1728-1790): u, v, T, ps,
+    vor, div of the new level, omega.  Against per-step snapshots of a second handle
+    (same summation order: identical) and against the oracle trajectory; then the history file of the HS diag_table."""
+    from isca_amd.diag import DiagTable, History
+    from scipy.io import netcdf_file
+    L, n = 8, 12
+    names = ["ps", "ucomp", "vcomp", "temp", "vor", "div", "omega", "sphum", "ucomp_sq", "vcomp_temp", "vcomp_vor", "wspd"]
+    a = make("T21", L); a.cold_start(); a.step(5)
+    b = make("T21", L); b.cold_start(); b.step(5)
+    sc = oracle("T21", L); sc.cold_start()
+    for _ in range(5):
+        sc.step()
+    a.diag_select(names)
+    a.step(n)
+    acc = {k: 0.0 for k in names}
+    oacc = {k: 0.0 for k in ("ps", "ucomp", "temp", "vor", "div")}
+    for _ in range(n):
+        b.step(1)
+        u, v, t, w = b.get("ug"), b.get("vg"), b.get("tg"), b.get("wg_full")
+        vor0, div0 = b.get("vorg"), b.get("divg")
+        for k, val in (("ps", b.get("psg")), ("ucomp", u), ("vcomp", v), ("temp", t), ("vor", vor0), ("div", div0), ("omega", w),
+                       ("sphum", b.get("tr")), ("ucomp_sq", u * u), ("vcomp_temp", v * t), ("vcomp_vor", v * vor0),
+                       ("wspd", np.sqrt(u * u + v * v))):
+            acc[k] = acc[k] + val
+        sc.step()
+        c = sc.current
+        for k, val in (("ps", sc.psg[c]), ("ucomp", sc.ug[c]), ("temp", sc.tg[c]), ("vor", sc.vorg), ("div", sc.divg)):
+            oacc[k] = oacc[k] + val
+    for k in names:
+        mean, cnt = a.diag_mean(k)
+        assert cnt == n
+        assert rel(mean, acc[k] / n) < 1e-15, k
+    for k, tol in (("ps", 1e-13), ("ucomp", 1e-11), ("temp", 1e-12), ("vor", 1e-10), ("div", 1e-9)):
+        assert rel(a.diag_mean(k)[0], oacc[k] / n) < tol, k
+    with pytest.raises(dyncore.IscaError):
+        a.diag_mean("temp_sq")                              # not selected
+    a.close(); b.close()
+    # the HS test case's diag_table (held_suarez_test_case.py:27-38) on 2-hourly means
+    diag = DiagTable()
+    diag.add_file("atmos_2hourly", 2, "hours", time_units="days")
+    for nm, avg in (("ps", True), ("bk", False), ("pk", False), ("ucomp", True), ("vcomp", True), ("temp", True), ("vor", True), ("div", True)):
+        diag.add_field("dynamics", nm, time_avg=avg)
+    c = make("T21", L); c.cold_start()
+    hist = History(c, diag.files["atmos_2hourly"], 600.0, str(tmp_path / "atmos_2hourly.nc"))
+    for _ in range(3):
+        c.step(12); hist.after_steps(12)
+    hist.close()
+    f = netcdf_file(str(tmp_path / "atmos_2hourly.nc"), "r", mmap=False)
+    assert f.variables["ucomp"].shape == (3, L, 32, 64) and f.variables["ps"].shape == (3, 32, 64) and f.variables["bk"].shape == (L + 1,)
+    assert np.allclose(f.variables["average_DT"][:], 2.0 / 24.0) and np.allclose(f.variables["time"][:], [1 / 24, 3 / 24, 5 / 24])
+    assert f.variables["temp"].units == b"deg_k" and abs(float(f.variables["temp"][:].mean()) - 264.0) < 1.0
+    f.close(); c.close()

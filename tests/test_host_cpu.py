@@ -171,3 +171,18 @@ def test_experiment_host_logic(tmp_path):
     exp.update_namelist({"main_nml": {"days": 0, "seconds": 700}})
     with pytest.raises(IscaError):
         exp.steps_per_run()
+
+
+def test_diag_table_host_logic():
+    from isca_amd.diag import DiagTable, FIELDS
+    from isca_amd.dyncore import IscaError
+    d = DiagTable()
+    d.add_file("atmos_monthly", 30, "days", time_units="days")
+    for nm in ("ps", "bk", "pk", "ucomp", "vcomp", "temp", "vor", "div"):          # held_suarez_test_case.py:30-38
+        d.add_field("dynamics", nm, time_avg=nm not in ("bk", "pk"))
+    assert [f["name"] for f in d.files["atmos_monthly"]["fields"]][:3] == ["ps", "bk", "pk"] and d.is_valid()
+    with pytest.raises(IscaError):
+        d.add_field("two_stream", "olr")                     # outside the dynamical core
+    with pytest.raises(IscaError):
+        d.add_field("dynamics", "no_such_field")
+    assert {"ucomp_vcomp", "omega", "wspd", "vcomp_vor"} <= set(FIELDS)
