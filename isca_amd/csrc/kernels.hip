@@ -58,13 +58,8 @@ template <bool INV, int R> __device__ __forceinline__ void dftR(double2 (&v)[R])
     v[3] = cadd(e3, w3); v[7] = csub(e3, w3);
   }
 }
-#ifndef FPAD_SHIFT
-#define FPAD_SHIFT 3
-#endif
-#ifndef FPAD_ROW_EXTRA
-#define FPAD_ROW_EXTRA 1
-#endif
-__device__ __forceinline__ int fpad(int i) { return i + (i >> FPAD_SHIFT); }     // LDS padding: 1 slot per 8
+// LDS padding: 1 slot per 8 and one more per row (measured against no padding and 1 per 4/16/32: best of those)
+__device__ __forceinline__ int fpad(int i) { return i + (i >> 3); }
 
 // One Stockham pass of radix R at stride S over a row of NC complex points held in LDS (in place: all reads,
 // barrier, all writes, barrier).  16 threads per row.  twl = LDS copy of exp(-2 pi i k / (2 NC)), k < 2 NC.
@@ -100,9 +95,6 @@ __device__ __forceinline__ void fft_pass(double2 *row, const double2 *twl, int t
   __syncthreads();
 }
 template <int NC, bool INV> __device__ __forceinline__ void fft_row(double2 *row, const double2 *twl, int tr) {
-#if defined(EXP_FFT_NOPASS)
-  return;
-#endif
   if constexpr (NC == 8) { fft_pass<8, 8, 1, INV>(row, twl, tr); }
   else if constexpr (NC == 16) { fft_pass<16, 4, 1, INV>(row, twl, tr); fft_pass<16, 4, 4, INV>(row, twl, tr); }
   else if constexpr (NC == 32) { fft_pass<32, 8, 1, INV>(row, twl, tr); fft_pass<32, 4, 8, INV>(row, twl, tr); }
@@ -121,7 +113,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldLis
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
   constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;          // num_fourier + 1 <= NC
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
@@ -187,7 +179,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
                                                  const int *__restrict__ slot_of_m, const double2 *__restrict__ tw,
                                                  const double *__restrict__ Fg, int C, int GX) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA;
+  constexpr int R = FftCfg<NC>::R, NT = R * 16, rs = NC + NC / 8 + 1;
   constexpr int PER = (NC + 15) / 16, PERM = (NC + 15) / 16;
   double2 *buf = (double2 *)smem, *twl = buf + R * rs;
   const int t = threadIdx.x, r = t >> 4, tr = t & 15;
@@ -254,11 +246,14 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
       const int op = fl.op[f];
       const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
 #pragma unroll
-      for (int n = tr; n < NC; n += 16) {
-        double2 z = buf[r * rs + fpad(n)];
-        if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
-        else { z.x *= scale; z.y *= scale; }
-        dst[n] = z;
+      for (int i = 0; i < PER; ++i) {
+        const int n = tr + 16 * i;
+        if (n < NC) {
+          double2 z = buf[r * rs + fpad(n)];
+          if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
+          else { z.x *= scale; z.y *= scale; }
+          dst[n] = z;
+        }
       }
     }
     __syncthreads();                                   // buf is rewritten by the next item
@@ -267,10 +262,9 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
 
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
 static unsigned fft_grid(int items) {                  // persistent blocks: 3 per CU of the 256 (LDS-limited residency)
-  static const int cap = getenv("ISCA_FFT_BLOCKS") ? atoi(getenv("ISCA_FFT_BLOCKS")) : 768;
-  return (unsigned)std::min(items, cap);
+  return (unsigned)std::min(items, 768);             // measured against 512 / 1024 / 1536
 }
-static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + (NC >> FPAD_SHIFT) + FPAD_ROW_EXTRA) + 2 * NC) * sizeof(double2); }
+static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
   const int C = 2 * fl.ncol, NC = g.I / 2;
@@ -334,7 +328,6 @@ __device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
 // wavenumber share that wavenumber's Legendre table, so they are mapped onto the same XCD: the table then comes
 // from HBM once per XCD instead of once per tile.  T = column tiles (of 4 wavefronts) per wavenumber.
 __device__ __forceinline__ bool leg_block(int Ml, int T, int &ml, int &tile) {
-  if (T < 0) { ml = blockIdx.x / (-T); tile = blockIdx.x - ml * (-T); return ml < Ml; }   // plain order (experiments)
   const int lin = blockIdx.x, xcd = lin & 7, q = lin >> 3;
   const int grp = q / T;
   ml = xcd + 8 * grp;
@@ -619,9 +612,8 @@ static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42
 
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (mfma_ok(g, impl)) {
-    static const bool plain = getenv("ISCA_LEG_PLAIN") != nullptr;
-    const int T = (plain ? -1 : 1) * (((C + 15) / 16 + 3) / 4);
-    dim3 grid(leg_grid(g.Ml, plain ? -T : T));
+    const int T = ((C + 15) / 16 + 3) / 4;
+    dim3 grid(leg_grid(g.Ml, T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.Jh * g.NHP * sizeof(double);
 #define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full, T)
@@ -641,9 +633,8 @@ void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, doubl
   if (mfma_ok(g, impl)) {
     SynthSrc src = {nullptr, nullptr, nullptr, nullptr, d.coef};
     if (fused_tl >= 0) { src.vor = d.vors[fused_tl]; src.div = d.divs[fused_tl]; src.ts = d.ts[fused_tl]; src.lnps = d.lnps[fused_tl]; }
-    static const bool plain = getenv("ISCA_LEG_PLAIN") != nullptr;
-    const int T = (plain ? -1 : 1) * (((C + 15) / 16 + 3) / 4);
-    dim3 grid(leg_grid(g.Ml, plain ? -T : T));
+    const int T = ((C + 15) / 16 + 3) / 4;
+    dim3 grid(leg_grid(g.Ml, T));
     const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
     const size_t lds = (size_t)(both ? 2 : 1) * g.NHP * g.Jh * sizeof(double) + (size_t)LC_ROWS * g.N1 * sizeof(double);
     // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
@@ -1179,15 +1170,6 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
 // everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
-#if defined(EXP_COL_NOSTORE)
-#define CST(dst, val) do { const double v__ = (val); if (v__ == 1.234e300) dst = v__; } while (0)
-#else
-#define CST(dst, val) dst = (val)
-#endif
-#if defined(EXP_COL_NOMATH)
-#define log(x) ((x) * 0.5)
-#define exp(x) ((x) * 0.5)
-#endif
 template <int CH>
 __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1320,11 +1302,11 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
       const double x5 = x4 - uc * x2 - vc * x3;
       dt_t = dt_t - KAPPA * tc * x5;
-      CST(a.wg_full[q], -x5 * p_full);
+      a.wg_full[q] = -x5 * p_full;
       nbelow += (p_full < a.water_limit) ? 1 : 0;
       dmean_tot = dmean_tot + dm[i];
       const double wg_n = (k + 1 < L) ? (-dmean_tot + total * bk_r[i + 1]) : 0.0;
-      if (a.wg) CST(a.wg[q + lev], wg_n);
+      if (a.wg) a.wg[q + lev] = wg_n;
       // ---- vert_advection SECOND_CENTERED / ADVECTIVE_FORM (vert_advection.F90:185-193, 467-470)
       const double ukm = (i == 0) ? um : u[i > 0 ? i - 1 : 0], vkm = (i == 0) ? vm : v[i > 0 ? i - 1 : 0], tkm = (i == 0) ? tm : t[i > 0 ? i - 1 : 0];
       const double ukp = (i == nk - 1) ? un : u[i + 1 < CH ? i + 1 : i], vkp = (i == nk - 1) ? vn : v[i + 1 < CH ? i + 1 : i], tkp = (i == nk - 1) ? tn : t[i + 1 < CH ? i + 1 : i];
@@ -1345,9 +1327,9 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double av = voi + cor;
       dt_u = dt_u + av * vc;
       dt_v = dt_v - av * uc;
-      CST(a.dtu[q], dt_u * cosm);
-      CST(a.dtv[q], dt_v * cosm);
-      CST(a.dtT[q], dt_t);
+      a.dtu[q] = dt_u * cosm;
+      a.dtv[q] = dt_v * cosm;
+      a.dtT[q] = dt_t;
       wg_k = wg_n;
     }
   }
@@ -1359,7 +1341,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     for (int i = CH - 1; i >= 0; --i) {
       if (i < nk) {
         const size_t q = c2 + (size_t)(k0 + i) * lev;
-        CST(a.E[q], gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]));
+        a.E[q] = gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]);
         if (k0 + i >= ktop) gh = gh + RDGAS * t[i] * (lph[i + 1] - lph[i]);
       }
     }
@@ -1387,10 +1369,6 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   }
 }
 
-#if defined(EXP_COL_NOMATH)
-#undef log
-#undef exp
-#endif
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
 
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
