@@ -183,6 +183,34 @@ def test_error_behaviour():
     with pytest.raises(dyncore.IscaError):
         dc.set("ug", np.zeros((3, 3, 3)))
     dc.close()
+    with pytest.raises(dyncore.IscaError, match="num_levels"):
+        make("T21", 65)
+    for bad, msg in ((dict(raw_filter_coeff=0.5), "raw_filter_coeff"),
+                     (dict(fourier_inc=2), "fourier_inc"), (dict(world_size=3), "world_size"), (dict(dt_atmos=0.0), "dt_atmos"),
+                     (dict(triang_trunc=0), "triangular"), (dict(do_mass_correction=0), "mass_correction")):
+        with pytest.raises(dyncore.IscaError, match=msg):
+            make("T21", 25, **bad)
+
+
+@pytest.mark.parametrize("res,L,steps", [("T5", 1, 12), ("T5", 5, 12), ("T10", 64, 6), ("T21", 3, 12)])
+def test_edge_sizes_vs_oracle(res, L, steps):
+    """Smallest truncation, a single level (no tracer transport below 5 levels), the largest level count (64 = one
+    lane per level in the spectral update), level counts that leave wavefronts partly empty."""
+    dyncore.RESOLUTIONS.setdefault("T5", dict(lon_max=16, lat_max=8, num_fourier=5, num_spherical=6))
+    dyncore.RESOLUTIONS.setdefault("T10", dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11))
+    dc = make(res, L); dc.cold_start()
+    sc = oracle(res, L); sc.cold_start()
+    dc.step(steps)
+    tracer = bool(dc.info("tracer"))
+    for _ in range(steps):
+        sc.step(with_tracer=tracer)
+    c = sc.current
+    for k, want, tol in (("ug", sc.ug[c], 1e-11), ("tg", sc.tg[c], 1e-12), ("psg", sc.psg[c], 1e-13), ("vors", sc.vors[c], 1e-10),
+                         ("ts", sc.ts[c], 1e-12)):
+        assert rel(dc.get(k), want) < tol, (k, rel(dc.get(k), want))
+    if tracer:
+        assert rel(dc.get("tr"), sc.tr[c]) < 1e-10
+    dc.close()
 
 
 # ------------------------------------------------------------------ (c) full BASELINE sizes: properties
