@@ -189,6 +189,26 @@ static void upload_wave_matrices(isca_dyn *h, double delta_t) {
   h->wave_dt = delta_t;
 }
 
+// valid_range_t (spectral_dynamics.F90:940-972, FATAL 'temperatures out of valid range'): the fixer kernels keep the
+// running extremes of every new temperature field since the last check; looked at whenever the host synchronises.
+static void reset_valid_range(isca_dyn *h) {
+  const double init[2] = {INFINITY, -INFINITY};
+  HIP_CHECK(hipMemcpy(h->d.red + 20, init, sizeof(init), hipMemcpyHostToDevice));
+}
+static void check_valid_range(isca_dyn *h) {
+  double red[22];
+  HIP_CHECK(hipMemcpy(red, h->d.red, sizeof(red), hipMemcpyDeviceToHost));
+  reset_valid_range(h);
+  const double tmin = red[20], tmax = red[21];
+  if (tmin > tmax) return;                                   // no step since the last check
+  if (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17])) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "temperatures out of valid range (min %.3f, max %.3f, valid %.1f..%.1f)", tmin, tmax,
+             h->cfg.valid_range_t[0], h->cfg.valid_range_t[1]);
+    fail(msg);
+  }
+}
+
 extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
   isca_dyn *h = nullptr;
   try {
@@ -318,6 +338,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
     d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
+    reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
     d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
@@ -737,10 +758,7 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   }
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    // valid-range check (spectral_dynamics.F90:940-972) on demand: a NaN/blow-up shows in the fixer scalars
-    double red[32];
-    HIP_CHECK(hipMemcpy(red, h->d.red, sizeof(red), hipMemcpyDeviceToHost));
-    if (!(std::isfinite(red[16]) && std::isfinite(red[17]))) fail("temperatures out of valid range (non-finite state)");
+    check_valid_range(h);
   }
   API_END
 }
@@ -797,6 +815,7 @@ extern "C" int isca_comm_selftest(int device, double *max_err) {
 extern "C" int isca_dyn_synchronize(isca_dyn_t *h) {
   API_BEGIN
   HIP_CHECK(hipStreamSynchronize(h->stream));
+  check_valid_range(h);
   API_END
 }
 

@@ -2020,12 +2020,13 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 // =====================================================================================================
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
+constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
                                                     const double *__restrict__ wts, double *__restrict__ partials, int CH,
                                                     const double *__restrict__ wcol) {
-  __shared__ double sred[2][8];
+  __shared__ double sred[4][8];
   const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
   const int col = blockIdx.x * 64 + tid;
   const int jl = col / g.I;
@@ -2044,14 +2045,25 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
   }
   double sa = 0.0, sb = 0.0;
+  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
+  bool nan = false;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (i < nk) {
       const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
       sa += e * dpk[k0 + i];
       sb += e * dbk[k0 + i];
+      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
+      nan = nan || !(tt[i] == tt[i]);
     }
   }
+  if (nan) tmx = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
+    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
+  }
+  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
   double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -2069,46 +2081,55 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     }
   }
   if (threadIdx.x == 0) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; }
-    double *p = partials + 8 * (size_t)blockIdx.x;
-    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4;
+    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
+    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
+    double *p = partials + NPART * (size_t)blockIdx.x;
+    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
   }
 }
 // Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
 // strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
 // the totals.  Deterministic and identical in every block that calls it.
 __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                             double (*sh)[NRED], double *tot) {
+                                             double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
   double acc[NRED];
 #pragma unroll
   for (int c = 0; c < NRED; ++c) acc[c] = 0.;
+  double mn = INFINITY, mx = -INFINITY;
   for (int i = threadIdx.x; i < nb; i += 256) {
     acc[0] += pprev[2 * i]; acc[1] += pprev[2 * i + 1];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[2 + c] += pfut[8 * i + c];
+    for (int c = 0; c < 8; ++c) acc[2 + c] += pfut[NPART * i + c];
+    mn = fmin(mn, pfut[NPART * i + 8]); mx = fmax(mx, pfut[NPART * i + 9]);
   }
 #pragma unroll
-  for (int c = 0; c < NRED; ++c) {
+  for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+    for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+    mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
   }
-  if ((threadIdx.x & 63) == 0)
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
+    sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
+  }
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < NRED; ++c) tot[c] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
+  tmin = fmin(fmin(sh[0][NRED], sh[1][NRED]), fmin(sh[2][NRED], sh[3][NRED]));
+  tmax = fmax(fmax(sh[0][NRED + 1], sh[1][NRED + 1]), fmax(sh[2][NRED + 1], sh[3][NRED + 1]));
 }
 // red[0..9] <- totals, for the host all-reduce between the phases when world_size > 1
 __global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
                                                       double *__restrict__ red) {
-  __shared__ double sh[4][NRED];
-  double tot[NRED];
-  fixer_totals(pprev, pfut, nb, sh, tot);
-  if (threadIdx.x == 0)
+  __shared__ double sh[4][NRED + 2];
+  double tot[NRED], tmn, tmx;
+  fixer_totals(pprev, pfut, nb, sh, tot, tmn, tmx);
+  if (threadIdx.x == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) red[c] = tot[c];
+    red[20] = fmin(red[20], tmn); red[21] = fmax(red[21], tmx);      // running extremes of this rank's band
+  }
 }
 struct FixerArgs {
   double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
@@ -2127,9 +2148,9 @@ struct FixerArgs {
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
 // Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
 __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
-  __shared__ double sh[4][NRED];
-  double r_[NRED];
-  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_);
+  __shared__ double sh[4][NRED + 2];
+  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
+  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
   else {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
@@ -2195,6 +2216,8 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
     if (threadIdx.x == 0) {
       for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
       a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
+      // valid_range_t (spectral_dynamics.F90:940): running extremes of the new temperatures since the host last looked
+      if (a.reduce_here) { a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx); }
     }
     if (a.ml0 >= 0) {
       const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)

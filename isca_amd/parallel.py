@@ -143,6 +143,7 @@ class ShardedDynCore(dyncore.DynCore):
                 self.step_phase(3)                                          # fixers, time-level rotation
         if sync:
             self._stream.synchronize()
+            self.synchronize()                 # valid-range check of the temperatures, like isca_dyn_step(sync)
 
     def gather_grid(self, name, time_level=1):
         """all-gather a grid field to every rank (tests/diagnostics): [lev, lat_global, lon]"""

@@ -185,6 +185,12 @@ def test_error_behaviour():
     dc.close()
     with pytest.raises(dyncore.IscaError, match="num_levels"):
         make("T21", 65)
+    dc = make("T21", 10, valid_range_t=(265.0, 800.0))        # the 264 K cold start is below this range
+    dc.cold_start()
+    with pytest.raises(dyncore.IscaError, match="temperatures out of valid range"):   # spectral_dynamics.F90:940-972
+        dc.step(3)
+    dc.close()
+    dc = make("T21", 10); dc.cold_start(); dc.step(3); dc.close()                     # default range: fine
     for bad, msg in ((dict(raw_filter_coeff=0.5), "raw_filter_coeff"),
                      (dict(fourier_inc=2), "fourier_inc"), (dict(world_size=3), "world_size"), (dict(dt_atmos=0.0), "dt_atmos"),
                      (dict(triang_trunc=0), "triangular"), (dict(do_mass_correction=0), "mass_correction")):
