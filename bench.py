@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="T85L40", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-steps", type=int, default=12, help="bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="bounded CPU-baseline sample (0 = skip)")
     a = ap.parse_args()
     res, L, dt = WORKLOADS[a.workload]
 

@@ -262,6 +262,25 @@ def test_full_size_properties(res, L):
     dc.close()
 
 
+def test_T85L40_long_run_stays_physical():
+    """The headline configuration for 6000 steps (~21 model days at dt = 300 s): the spin-up of the Held-Suarez circulation
+    from rest must leave mass conserved to roundoff, the tracer non-negative within its sink/flux balance, winds and
+    temperatures in a physical range (the valid_range_t check runs inside), and a jet must have formed."""
+    dc = make("T85", 40, dt_atmos=300.0)
+    dc.cold_start()
+    ps0 = dc.area_weighted_global_mean(dc.get("psg"))
+    dc.step(6000)
+    ps1 = dc.area_weighted_global_mean(dc.get("psg"))
+    t, u, q = dc.get("tg"), dc.get("ug"), dc.get("tr")
+    assert abs(ps1 / ps0 - 1) < 1e-11, (ps0, ps1)
+    assert np.isfinite(u).all() and 170 < t.min() and t.max() < 320, (t.min(), t.max())
+    assert 5.0 < np.abs(u).max() < 150.0, np.abs(u).max()                       # a zonal jet is spinning up
+    zonal = u.mean(axis=2)
+    assert abs(zonal[:, : zonal.shape[1] // 2].max() - zonal[:, zonal.shape[1] // 2:].max()) < 0.5 * zonal.max()   # two hemispheres
+    assert q.min() > -1e-6 and q.max() < 1.0, (q.min(), q.max())
+    dc.close()
+
+
 # ------------------------------------------------------------------ (d) latitude-band sharding on the device path
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_device_path_matches_single(world):
