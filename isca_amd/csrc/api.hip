@@ -731,12 +731,12 @@ static void sharded_step(isca_dyn *h) {
   isca::Comm &c = *h->comm;
   upload_wave_matrices(h, sc.delta_t);
   phase0(h, sc);
-  if (h->tracer_on) {
-    const size_t n = (size_t)3 * g.L * 2 * g.I;
-    Timed t(h, "halo_exchange");
-    c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream);
+  {   // lat -> m all-to-all and the tracer's halo rows in one RCCL group (two messages to the same neighbour are fine)
+    const size_t n = h->tracer_on ? (size_t)3 * g.L * 2 * g.I : 0;
+    Timed t(h, "all_to_all_fwd");
+    c.all_to_all_with_halo(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->d.halo_send, h->d.halo_send + n,
+                           h->d.halo_recv, h->d.halo_recv + n, n, h->stream);
   }
-  { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
   phase1(h, sc);
   { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
   phase2(h, sc);
@@ -801,6 +801,7 @@ extern "C" int isca_comm_selftest(int device, double *max_err) {
   c.all_to_all(da, db, n, s);
   c.all_reduce_sum(dr, 10, s);
   c.halo(da, da, db, db, 16, s);              // no neighbours: must be a no-op
+  c.all_to_all_with_halo(da, db, n, da, da, db, db, 16, s);
   HIP_CHECK(hipMemcpyAsync(b.data(), db, n * sizeof(double), hipMemcpyDeviceToHost, s));
   std::vector<double> r2(16);
   HIP_CHECK(hipMemcpyAsync(r2.data(), dr, 16 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -97,6 +97,25 @@ void Comm::halo(const double *send_lo, const double *send_hi, double *recv_lo, d
   ck(a.GroupEnd(), "ncclGroupEnd");
 }
 
+void Comm::all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
+                                double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s) {
+  Api &a = api();
+  ck(a.GroupStart(), "ncclGroupStart");
+  for (int p = 0; p < world_; ++p) {
+    ck(a.Send(send + (size_t)p * count, count, kDouble, p, comm_, s), "ncclSend");
+    ck(a.Recv(recv + (size_t)p * count, count, kDouble, p, comm_, s), "ncclRecv");
+  }
+  if (halo_count > 0 && rank_ > 0) {
+    ck(a.Send(send_lo, halo_count, kDouble, rank_ - 1, comm_, s), "ncclSend");
+    ck(a.Recv(recv_lo, halo_count, kDouble, rank_ - 1, comm_, s), "ncclRecv");
+  }
+  if (halo_count > 0 && rank_ < world_ - 1) {
+    ck(a.Send(send_hi, halo_count, kDouble, rank_ + 1, comm_, s), "ncclSend");
+    ck(a.Recv(recv_hi, halo_count, kDouble, rank_ + 1, comm_, s), "ncclRecv");
+  }
+  ck(a.GroupEnd(), "ncclGroupEnd");
+}
+
 void Comm::all_reduce_sum(double *buf, size_t count, hipStream_t s) {
   ck(api().AllReduce(buf, buf, count, kDouble, kSum, comm_, s), "ncclAllReduce");
 }

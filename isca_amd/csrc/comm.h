@@ -24,6 +24,9 @@ class Comm {
   void all_to_all(const double *send, double *recv, size_t count, hipStream_t s);
   // rows for the neighbouring latitude bands: lo <-> rank-1, hi <-> rank+1 (no wrap-around)
   void halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s);
+  // both of the above in one RCCL group (one fused send/recv kernel instead of two)
+  void all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
+                            double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s);
   void all_reduce_sum(double *buf, size_t count, hipStream_t s);         // in place
 
  private:
