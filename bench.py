@@ -38,11 +38,40 @@ def cpu_baseline(workload, budget_steps):
                 f" &harness_nml\n   mode = 'run', nsteps = {budget_steps}, dt_atmos = {int(dt)}, dump_steps = -1, dump_tables = .false.\n /\n")
             out = mg.run_harness(d, exe=exe)
         import re
-        m = re.search(r"REF_TIMING steps=\s*(\d+)\s+seconds=\s*(\S+)\s+ms_per_step=\s*(\S+)", out)
+        pat = r"REF_TIMING steps=\s*(\d+)\s+seconds=\s*(\S+)\s+ms_per_step=\s*(\S+)"
+        m = re.search(pat, out)
         sec = float(m.group(2)) / int(m.group(1))
-        return {"value": sim_years_per_day(sec, dt), "unit": "sim_years/day", "cores": 1, "kind": "reference",
+        res_ = {"value": sim_years_per_day(sec, dt), "unit": "sim_years/day", "cores": 1, "kind": "reference",
                 "ms_per_step": 1e3 * sec,
                 "sample": f"{budget_steps} steps of {workload} HS from cold start, reference Fortran (flang -O2, nocomm) on 1 host core"}
+        # More cores: the build has no MPI here, so 8 cores are loaded with independent copies of the same run (what an
+        # ensemble would get, memory-bandwidth contention between the copies included).  Not more than 8: the GPU boxes
+        # report 256 CPUs but schedule this container on about a dozen (64 copies ran 8x slower each).
+        import subprocess
+        ncopy = max(1, min(os.cpu_count() or 1, 8))
+        nst = max(4, budget_steps // 2)
+        if ncopy > 1:
+            with tempfile.TemporaryDirectory(prefix="refbench_all_") as top:
+                procs = []
+                for c in range(ncopy):
+                    d = os.path.join(top, f"c{c:03d}")
+                    mg.prepare_rundir(d, res, L, "run", nsteps=nst, dt=dt, dump_steps=())
+                    open(os.path.join(d, "harness.nml"), "w").write(
+                        f" &harness_nml\n   mode = 'run', nsteps = {nst}, dt_atmos = {int(dt)}, dump_steps = -1, dump_tables = .false.\n /\n")
+                    procs.append(subprocess.Popen(f"ulimit -s unlimited; exec {exe}", shell=True, cwd=d, stdout=subprocess.PIPE,
+                                                  stderr=subprocess.DEVNULL, text=True, executable="/bin/bash"))
+                secs = []
+                for pr in procs:
+                    o, _ = pr.communicate(timeout=1800)
+                    mm = re.search(pat, o)
+                    if pr.returncode == 0 and mm:
+                        secs.append(float(mm.group(2)) / int(mm.group(1)))
+            if len(secs) == ncopy:
+                slow = max(secs)
+                res_["multi_core"] = {"value": ncopy * sim_years_per_day(slow, dt), "unit": "sim_years/day (sum over copies)", "cores": ncopy,
+                                     "kind": "reference", "ms_per_step_slowest_copy": 1e3 * slow,
+                                     "sample": f"{ncopy} concurrent single-core copies of the same run, {nst} steps each"}
+        return res_
     from oracle.isca_oracle import Config, SpectralCore
     from isca_amd import dyncore
     sc = SpectralCore(Config(num_levels=L, dt_atmos=dt, **dyncore.RESOLUTIONS[res]))
