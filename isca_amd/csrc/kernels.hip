@@ -1783,9 +1783,9 @@ __device__ void ppm_cell_global(const TracerArgs &a, const Geom &g, size_t c2, d
 // reconstructs its CH+2 cells from CH+8 column values held in registers (no LDS, no barriers in the main part).
 // Pure sigma coordinates (pk = 0, the only vertical coordinate supported): dz = dbk*ps, so the slope and edge
 // weights of slope_z / compute_weights are independent of the column and come from the host table a.ppm.
-template <int CH>
-__global__ __launch_bounds__(512) void k_tracer_vert(Geom g, TracerArgs a) {
-  __shared__ double red[5][8][64];
+template <int CH, int MAXW>      // MAXW = wavefronts per block: 8, or 12 (chunks of 5 levels) for 41..60 levels
+__global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a) {
+  __shared__ double red[5][MAXW][64];
   const int L = g.L;
   const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
   const size_t lev = (size_t)g.Jl * g.I;
@@ -1954,19 +1954,28 @@ void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream
   TracerArgs a = tracer_args(h, sc);
   hipLaunchKernelGGL(k_tracer_pack_halo, dim3(g.L, 4), dim3(g.I), 0, s, g, a);
 }
-void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  const Geom &g = h.g;
-  TracerArgs a = tracer_args(h, sc);
-  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
-  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStream_t s) {
+  const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64));
+  if (g.L > 40 && g.L <= 60) {                  // 12 wavefronts of 5 levels (164 VGPRs, 3 wavefronts per SIMD) instead of 8 of 8 (207)
+    const int NW = (g.L + 4) / 5;
+    hipLaunchKernelGGL((k_tracer_vert<5, 12>), grid, dim3(64 * NW), 0, s, g, a);
+    return;
+  }
   const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums
-  const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64)), block(64 * NW);
-#define LT(N) hipLaunchKernelGGL(k_tracer_vert<N>, grid, block, 0, s, g, a)
+  const dim3 block(64 * NW);
+#define LT(N) hipLaunchKernelGGL((k_tracer_vert<N, 8>), grid, block, 0, s, g, a)
   switch (CH) {
     case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
     case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
   }
 #undef LT
+}
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  TracerArgs a = tracer_args(h, sc);
+  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
+  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+  launch_tracer_vert_kernel(g, a, s);
 }
 
 // The same two kernels on caller fields (C-ABI entry points isca_a_grid_horiz_advection / isca_vert_advection_ppm):
@@ -1987,14 +1996,7 @@ void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const dou
   TracerArgs a = tracer_args(h, sc);
   a.trh = const_cast<double *>(r); a.wg = w; a.ps_cur = ps; a.ps_prev = ps; a.trp = dummy_a; a.tratm_p = dummy_a;
   a.tr_cur = dummy_b; a.tr_fut = r_new; a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
-  const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;
-  const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64)), block(64 * NW);
-#define LT(N) hipLaunchKernelGGL(k_tracer_vert<N>, grid, block, 0, s, g, a)
-  switch (CH) {
-    case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
-    case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
-  }
-#undef LT
+  launch_tracer_vert_kernel(g, a, s);
 }
 // tracer_source_sink (hs_forcing.F90:683-724) on caller fields: rst += flux/dp at the lowest level - tr/sink
 __global__ void k_tracer_source_sink(Geom g, TracerArgs a, const double *__restrict__ tr, double *__restrict__ rdt) {
