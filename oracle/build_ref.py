@@ -8,10 +8,11 @@ may touch it, and only as the checker / reported CPU baseline.
 What this does (our recipe, not the reference's mkmf/Makefile build system):
   * scans the reference source tree where it lies (/root/reference/src) for Fortran modules,
   * takes the dependency closure of the modules our harness (oracle/ref_harness.F90) uses,
-  * compiles exactly those files, unmodified, with AMD flang (-fdefault-real-8: every real is
-    fp64, as the reference's own templates do) in the reference's single-PE "nocomm" mpp mode
-    (no -Duse_libMPI) and without netCDF (no -Duse_netCDF),
-  * links the harness into oracle/_ref/ref_harness.x.
+  * compiles exactly those files with AMD flang (-fdefault-real-8: every real is fp64, as the
+    reference's own templates do) in the reference's single-PE "nocomm" mpp mode (no -Duse_libMPI)
+    and without netCDF (no -Duse_netCDF) -- unmodified and where they lie, with ONE exception for the
+    moist target that is spelled out at COMPAT_EDITS below (a build-time copy with an explicit int()),
+  * links the harnesses into oracle/_ref/ref_harness.x and oracle/_ref/ref_moist_harness.x.
 Outputs go only to oracle/_ref/ (git-ignored; travels to the GPU box with gpurun).
 No reference source is copied into this repository.
 
@@ -31,11 +32,37 @@ BLD = os.path.join(OUT, "build")
 FLANG = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
 CC = os.environ.get("CC", "gcc")
 
-SCAN_DIRS = ["shared", "atmos_spectral", "atmos_shared", "atmos_param/hs_forcing"]
 INCLUDES = ["shared/include", "shared/mpp/include", "shared/fms", "shared/fft",
             "shared/drifters", "shared/mpp"]
-CPPDEFS = ["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"]
 FFLAGS = ["-cpp", "-O2", "-fdefault-real-8", "-fdefault-double-8"]
+
+# Two targets, same recipe:
+#   dry   : oracle/ref_harness.F90        -> oracle/_ref/ref_harness.x        (spectral core + Held-Suarez, configs 0-2 and 4)
+#   moist : oracle/ref_moist_harness.F90  -> oracle/_ref/ref_moist_harness.x  (+ the Frierson column chain of config 3:
+#           idealized_moist_phys and the atmos_param / coupler modules it calls; RRTM and SOCRATES switched off with the
+#           reference's own -DRRTM_NO_COMPILE / -DSOC_NO_COMPILE)
+TARGETS = {
+    "dry": dict(harness="ref_harness.F90", exe="ref_harness.x", build="build",
+                scan=["shared", "atmos_spectral", "atmos_shared", "atmos_param/hs_forcing"],
+                cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"]),
+    "moist": dict(harness="ref_moist_harness.F90", exe="ref_moist_harness.x", build="build_moist",
+                  scan=["shared", "atmos_spectral", "atmos_shared", "atmos_param", "coupler"],
+                  cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8", "-DRRTM_NO_COMPILE", "-DSOC_NO_COMPILE"],
+                  # external (non-module) procedures the `use` graph cannot see: the Monin-Obukhov kernels called by monin_obukhov_mod
+                  extra=["atmos_param/monin_obukhov/monin_obukhov_kernel.F90"]),
+}
+# One compiler-compatibility edit, applied to a BUILD-TIME COPY under oracle/_ref/<build>/compat/ (git-ignored, never in
+# this repository): qe_moist_convection.F90 indexes lcl_temp_table with a variable declared `real` (get_lcl_temp, :1060,
+# :1080).  gfortran/ifort convert such a subscript to integer silently; flang rejects it.  The copy spells out the same
+# conversion, int(iv_floor) -- iv_floor holds floor(...)+1, so the value is unchanged.  Every other file is compiled
+# where it lies, unmodified.
+COMPAT_EDITS = {
+    "atmos_param/qe_moist_convection/qe_moist_convection.F90": [
+        ("lcl_temp_table(iv_floor+1)*w_ceil - lcl_temp_table(iv_floor)*(w_ceil-1)",
+         "lcl_temp_table(int(iv_floor)+1)*w_ceil - lcl_temp_table(int(iv_floor))*(w_ceil-1)"),
+    ],
+}
+SKIP_DIR_WORDS = ("atmos_spectral_barotropic", "atmos_spectral_shallow", "socrates", "rrtm_radiation", "atmos_column")
 
 mod_re = re.compile(r"^\s*module\s+(\w+)\s*$", re.I)
 use_re = re.compile(r"^\s*use\s*(?:,\s*\w+\s*::)?\s*(\w+)", re.I)
@@ -70,15 +97,14 @@ def scan(path):
     return mods, uses, is_prog
 
 
-def main():
-    if not os.path.isdir(SRC):
-        print("build_ref: reference tree not present (%s); keeping prebuilt oracle/_ref" % SRC)
-        return 0
+def build_target(name):
+    t = TARGETS[name]
+    BLD = os.path.join(OUT, t["build"])
     os.makedirs(BLD, exist_ok=True)
     files = {}
-    for d in SCAN_DIRS:
+    for d in t["scan"]:
         for root, _, names in os.walk(os.path.join(SRC, d)):
-            if "barotropic" in root or "shallow" in root:
+            if any(w in root.lower() for w in SKIP_DIR_WORDS):
                 continue
             for n in names:
                 if n.endswith((".F90", ".f90")) and not n.startswith("test_"):
@@ -90,7 +116,7 @@ def main():
             continue
         for m in mods:
             mod2file.setdefault(m, p)
-    harness = os.path.join(HERE, "ref_harness.F90")
+    harness = os.path.join(HERE, t["harness"])
     hm, hu, _ = scan(harness)
     order, seen = [], set()
 
@@ -103,6 +129,12 @@ def main():
                 order.append(q)
 
     visit(harness, hu)
+    for rel in t.get("extra", []):
+        q = os.path.join(SRC, rel)
+        if q not in seen:
+            seen.add(q)
+            visit(q, files[q][1])
+            order.append(q)
     inc = sum((["-I", os.path.join(SRC, i)] for i in INCLUDES), []) + ["-I", BLD]
     stamp_path = os.path.join(BLD, "stamps.json")
     stamps = json.load(open(stamp_path)) if os.path.exists(stamp_path) else {}
@@ -114,13 +146,25 @@ def main():
         h = hashlib.sha1(open(p, "rb").read()).hexdigest()
         if os.path.exists(o) and stamps.get(p) == h and not rebuilt_any:
             continue
-        cmd = [FLANG] + FFLAGS + CPPDEFS + inc + ["-module-dir", BLD, "-c", p, "-o", o]
+        src = p
+        rel = os.path.relpath(p, SRC)
+        if rel in COMPAT_EDITS:
+            text = open(p, errors="replace").read()
+            for old, new in COMPAT_EDITS[rel]:
+                if text.count(old) != 1:
+                    print("compat edit does not apply to", rel); return 1
+                text = text.replace(old, new)
+            os.makedirs(os.path.join(BLD, "compat"), exist_ok=True)
+            src = os.path.join(BLD, "compat", os.path.basename(p))
+            open(src, "w").write(text)
+            print("compat copy:", rel, "->", os.path.relpath(src, HERE))
+        cmd = [FLANG] + FFLAGS + t["cppdefs"] + inc + ["-I", os.path.dirname(p), "-module-dir", BLD, "-c", src, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             print("FAILED:", " ".join(cmd)); print(r.stderr[-4000:]); return 1
         stamps[p] = h; rebuilt_any = True
         json.dump(stamps, open(stamp_path, "w"))
-        print("compiled", os.path.relpath(p, SRC), flush=True)
+        print("compiled", rel, flush=True)
     # the reference's few C helpers used by mpp/memutils (compiled in place, unmodified)
     cobjs = []
     for c in ["shared/mpp/nsclock.c", "shared/mpp/threadloc.c", "shared/mpp/affinity.c",
@@ -133,17 +177,29 @@ def main():
                 print("C helper failed (skipped):", c, r.stderr[-500:])
                 continue
         cobjs.append(o)
-    ho = os.path.join(BLD, "ref_harness.o")
-    cmd = [FLANG] + FFLAGS + CPPDEFS + inc + ["-module-dir", BLD, "-c", harness, "-o", ho]
+    ho = os.path.join(BLD, t["harness"][:-4] + ".o")
+    cmd = [FLANG] + FFLAGS + t["cppdefs"] + inc + ["-module-dir", BLD, "-c", harness, "-o", ho]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         print("FAILED harness:"); print(r.stderr[-6000:]); return 1
-    exe = os.path.join(OUT, "ref_harness.x")
+    exe = os.path.join(OUT, t["exe"])
     cmd = [FLANG, "-o", exe, ho] + objs + cobjs + ["-Wl,--unresolved-symbols=ignore-all"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         print("FAILED link:"); print(r.stderr[-6000:]); return 1
     print("built", exe, "from", len(order), "reference Fortran files")
+    return 0
+
+
+def main():
+    if not os.path.isdir(SRC):
+        print("build_ref: reference tree not present (%s); keeping prebuilt oracle/_ref" % SRC)
+        return 0
+    want = [a for a in sys.argv[1:] if a in TARGETS] or ["dry"] + (["moist"] if os.path.exists(os.path.join(HERE, TARGETS["moist"]["harness"])) else [])
+    for name in want:
+        rc = build_target(name)
+        if rc:
+            return rc
     return 0
 
 

@@ -60,6 +60,85 @@ def input_nml(res, num_levels, extra=""):
 """
 
 
+FRIERSON_BK = [0.000000, 0.0117665, 0.0196679, 0.0315244, 0.0485411, 0.0719344, 0.1027829, 0.1418581, 0.1894648, 0.2453219,
+               0.3085103, 0.3775033, 0.4502789, 0.5244989, 0.5977253, 0.6676441, 0.7322627, 0.7900587, 0.8400683, 0.8819111,
+               0.9157609, 0.9422770, 0.9625127, 0.9778177, 0.9897489, 1.0000000]
+MOIST_EXE = os.path.join(HERE, "_ref", "ref_moist_harness.x")
+
+
+def moist_input_nml(res):
+    """namelist of exp/test_cases/frierson/frierson_test_case.py:49-170 (config 3 of BASELINE.json), 25 levels"""
+    lon, lat, nf, ns = RES[res]
+    bk = ", ".join(f"{b:.7f}" for b in FRIERSON_BK)
+    pk = ", ".join("0.0" for _ in FRIERSON_BK)
+    return f""" &atmosphere_nml
+    idealized_moist_model = .true.
+ /
+ &idealized_moist_phys_nml
+    do_damping = .true., turb = .true., mixed_layer_bc = .true., do_virtual = .false., do_simple = .true.,
+    roughness_mom = 3.21e-05, roughness_heat = 3.21e-05, roughness_moist = 3.21e-05,
+    two_stream_gray = .true., convection_scheme = 'SIMPLE_BETTS_MILLER'
+ /
+ &vert_turb_driver_nml
+    do_mellor_yamada = .false., do_diffusivity = .true., do_simple = .true., constant_gust = 0.0, use_tau = .false.
+ /
+ &diffusivity_nml
+    do_entrain = .false., do_simple = .true.
+ /
+ &surface_flux_nml
+    use_virtual_temp = .false., do_simple = .true., old_dtaudv = .true.
+ /
+ &mixed_layer_nml
+    tconst = 285., prescribe_initial_dist = .true., evaporation = .true., depth = 2.5, albedo_value = 0.31
+ /
+ &qe_moist_convection_nml
+    rhbm = 0.7, Tmin = 160., Tmax = 350.
+ /
+ &betts_miller_nml
+    rhbm = .7, do_simp = .false., do_shallower = .true.
+ /
+ &lscale_cond_nml
+    do_simple = .true., do_evap = .true.
+ /
+ &sat_vapor_pres_nml
+    do_simple = .true.
+ /
+ &damping_driver_nml
+    do_rayleigh = .true., trayfric = -0.25, sponge_pbottom = 5000., do_conserve_energy = .true.
+ /
+ &two_stream_gray_rad_nml
+    rad_scheme = 'frierson', do_seasonal = .false., atm_abs = 0.2
+ /
+ &diag_manager_nml
+    mix_snapshot_average_fields = .false.
+ /
+ &fms_nml
+    domains_stack_size = 2000000
+ /
+ &spectral_dynamics_nml
+    damping_order = 4, water_correction_limit = 200.e2, reference_sea_level_press = 1.0e5, num_levels = 25,
+    valid_range_t = 100., 800., initial_sphum = 2.e-6, vert_coord_option = 'input', surf_res = 0.5,
+    scale_heights = 11.0, exponent = 7.0, robert_coeff = 0.03,
+    lon_max = {lon}, lat_max = {lat}, num_fourier = {nf}, num_spherical = {ns}
+ /
+ &vert_coordinate_nml
+    bk = {bk},
+    pk = {pk}
+ /
+"""
+
+
+def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=()):
+    os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
+    os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
+    open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res))
+    open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)       # src/extra/model/isca/field_table: the same sphum entry
+    open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
+    fmt = lambda t: ", ".join(str(s) for s in t) if t else "-1"
+    open(os.path.join(d, "harness.nml"), "w").write(
+        f" &harness_nml\n   mode = 'run', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
+
+
 def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)

@@ -1,0 +1,223 @@
+! oracle/ref_moist_harness.F90 -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+!
+! Driver program (ours) for the reference's moist configuration (config 3 of BASELINE.json: Frierson grey-radiation
+! aquaplanet).  It calls only public module procedures, in the order of the reference's per-step driver with
+! idealized_moist_model = .true. (src/atmos_spectral/driver/solo/atmosphere.F90:120-352):
+!   idealized_moist_phys (driver/solo/idealized_moist_phys.F90:819-1395) -> spectral_dynamics -> pressures/heights,
+! and dumps raw little-endian fp64 arrays (Fortran order).  Compiled in place from /root/reference by oracle/build_ref.py.
+!
+! Control: ./harness.nml (&harness_nml) next to the reference's own input.nml / field_table / diag_table.
+!   mode = 'run'  : cold start, nsteps steps; after the steps in dump_steps dumps ug, vg, tg, psg, sphum of the new level
+!                   (st_*), and for the steps in phys_steps the inputs and outputs of that step's idealized_moist_phys call:
+!                   ph_in_* = u, v, T, q at `previous` and `current`, p_half/p_full/z_half/z_full at both levels,
+!                   ph_dt_* = the physics tendencies dt_ug, dt_vg, dt_tg, dt_tracers it returned.
+program ref_moist_harness
+
+use constants_mod,         only: constants_init, pi
+use fms_mod,               only: fms_init
+use time_manager_mod,      only: time_type, set_time, set_calendar_type, NO_CALENDAR, operator(+)
+use field_manager_mod,     only: MODEL_ATMOS
+use tracer_manager_mod,    only: register_tracers, get_number_tracers
+use diag_manager_mod,      only: diag_manager_init
+use tracer_type_mod,       only: tracer_type
+use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics, get_num_levels, &
+                                 get_initial_fields, get_surf_geopotential, get_pk_bk, get_axis_id
+use transforms_mod,        only: get_grid_domain, get_spec_domain, get_deg_lon, get_deg_lat, get_grid_boundaries
+use press_and_geopot_mod,  only: compute_pressures_and_heights
+use idealized_moist_phys_mod, only: idealized_moist_phys_init, idealized_moist_phys
+
+implicit none
+
+character(len=16) :: mode = 'run'
+integer :: nsteps = 1, dt_atmos = 720
+integer, dimension(64) :: dump_steps = -1, phys_steps = -1
+namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, phys_steps
+
+type(time_type) :: Time, Time_step, Time_next
+type(tracer_type), allocatable, dimension(:) :: tracer_attributes
+integer :: ntrace, ntprog, ntdiag, ntfamily, num_tracers, nhum
+logical :: dry_model
+integer :: is, ie, js, je, ms, me, ns, ne, num_levels, nlon, nlat
+integer :: previous, current, future, i, j, istep, unit
+real    :: delta_t, dt_real
+integer(kind=8) :: c0, c1, crate
+real(kind=8) :: t_loop
+
+real, allocatable, dimension(:,:,:,:)   :: p_half, p_full, z_half, z_full, ug, vg, tg
+real, allocatable, dimension(:,:,:,:,:) :: grid_tracers
+real, allocatable, dimension(:,:,:)     :: psg, wg_full, dt_ug, dt_vg, dt_tg
+real, allocatable, dimension(:,:,:,:)   :: dt_tracers
+real, allocatable, dimension(:,:)       :: dt_psg, surf_geopotential
+real, allocatable, dimension(:)         :: deg_lon, deg_lat, rad_lonb, rad_latb, pk, bk
+real, allocatable, dimension(:,:)       :: rad_lon_2d, rad_lat_2d, rad_lonb_2d, rad_latb_2d
+
+open(newunit=unit, file='harness.nml', status='old', action='read')
+read(unit, nml=harness_nml)
+close(unit)
+
+! ---- initialisation, order of atmos_model.F90:148-350 and atmosphere.F90:151-266 ------------------
+call fms_init()
+call constants_init()
+call register_tracers(MODEL_ATMOS, ntrace, ntprog, ntdiag, ntfamily)
+call set_calendar_type(NO_CALENDAR)
+call diag_manager_init()
+Time      = set_time(0, 0)
+Time_step = set_time(dt_atmos, 0)
+dt_real   = real(dt_atmos)
+
+call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
+allocate(tracer_attributes(num_tracers))
+call spectral_dynamics_init(Time, Time_step, tracer_attributes, dry_model, nhum)
+call get_grid_domain(is, ie, js, je)
+call get_spec_domain(ms, me, ns, ne)
+call get_num_levels(num_levels)
+nlon = ie-is+1; nlat = je-js+1
+
+allocate(p_half(is:ie,js:je,num_levels+1,2), z_half(is:ie,js:je,num_levels+1,2))
+allocate(p_full(is:ie,js:je,num_levels,2),   z_full(is:ie,js:je,num_levels,2))
+allocate(wg_full(is:ie,js:je,num_levels), psg(is:ie,js:je,2))
+allocate(ug(is:ie,js:je,num_levels,2), vg(is:ie,js:je,num_levels,2), tg(is:ie,js:je,num_levels,2))
+allocate(grid_tracers(is:ie,js:je,num_levels,2,num_tracers))
+allocate(dt_psg(is:ie,js:je), dt_ug(is:ie,js:je,num_levels), dt_vg(is:ie,js:je,num_levels))
+allocate(dt_tg(is:ie,js:je,num_levels), dt_tracers(is:ie,js:je,num_levels,num_tracers))
+allocate(deg_lon(is:ie), deg_lat(js:je), rad_lon_2d(is:ie,js:je), rad_lat_2d(is:ie,js:je))
+allocate(rad_lonb_2d(is:ie+1,js:je+1), rad_latb_2d(is:ie+1,js:je+1), rad_lonb(is:ie+1), rad_latb(js:je+1))
+allocate(surf_geopotential(is:ie,js:je), pk(num_levels+1), bk(num_levels+1))
+p_half=0.; z_half=0.; p_full=0.; z_full=0.; wg_full=0.; psg=0.; ug=0.; vg=0.; tg=0.; grid_tracers=0.
+dt_psg=0.; dt_ug=0.; dt_vg=0.; dt_tg=0.; dt_tracers=0.
+
+call get_surf_geopotential(surf_geopotential)
+previous = 1; current = 1
+call get_initial_fields(ug(:,:,:,1), vg(:,:,:,1), tg(:,:,:,1), psg(:,:,1), grid_tracers(:,:,:,1,:))
+call compute_pressures_and_heights(tg(:,:,:,current), psg(:,:,current), surf_geopotential, &
+     z_full(:,:,:,current), z_half(:,:,:,current), p_full(:,:,:,current), p_half(:,:,:,current), &
+     grid_tracers(:,:,:,current,nhum))
+call compute_pressures_and_heights(tg(:,:,:,previous), psg(:,:,previous), surf_geopotential, &
+     z_full(:,:,:,previous), z_half(:,:,:,previous), p_full(:,:,:,previous), p_half(:,:,:,previous), &
+     grid_tracers(:,:,:,previous,nhum))
+call get_deg_lon(deg_lon)
+do i=is,ie
+  rad_lon_2d(i,:) = deg_lon(i)*pi/180.
+enddo
+call get_deg_lat(deg_lat)
+do j=js,je
+  rad_lat_2d(:,j) = deg_lat(j)*pi/180.
+enddo
+call get_grid_boundaries(rad_lonb, rad_latb)
+do i=is,ie+1
+  rad_lonb_2d(i,:) = rad_lonb(i)
+enddo
+do j=js,je+1
+  rad_latb_2d(:,j) = rad_latb(j)
+enddo
+call idealized_moist_phys_init(Time, Time_step, nhum, rad_lon_2d, rad_lat_2d, rad_lonb_2d, rad_latb_2d, tg(:,:,num_levels,current))
+call get_pk_bk(pk, bk)
+call dump1('tab_pk.bin', pk); call dump1('tab_bk.bin', bk); call dump1('tab_deg_lat.bin', deg_lat)
+
+if(trim(mode) == 'run') then
+  call dump_state(0)
+  t_loop = 0.
+  call system_clock(count_rate=crate)
+  do istep = 1, nsteps
+    call system_clock(c0)
+    call one_step(any(phys_steps == istep))
+    call system_clock(c1)
+    t_loop = t_loop + real(c1-c0,8)/real(crate,8)
+    if(any(dump_steps == istep)) call dump_state(istep)
+  enddo
+  write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
+  write(*,'(a,4es24.16)') 'REF_STATE Tmin,Tmax,maxabsU,qmax=', minval(tg(:,:,:,current)), maxval(tg(:,:,:,current)), &
+        maxval(abs(ug(:,:,:,current))), maxval(grid_tracers(:,:,:,current,nhum))
+else
+  write(*,*) 'unknown mode ', trim(mode)
+  stop 2
+endif
+
+contains
+
+!--------------------------------------------------------------------------------------------------
+subroutine one_step(dump_phys)
+! atmosphere.F90:286-349, idealized_moist_model branch, without spectral_diagnostics
+logical, intent(in) :: dump_phys
+character(len=8) :: tag
+dt_ug = 0.0; dt_vg = 0.0; dt_tg = 0.0; dt_psg = 0.0; dt_tracers = 0.0
+if(current == previous) then
+  delta_t = dt_real
+else
+  delta_t = 2*dt_real
+endif
+Time_next = Time + Time_step
+if(dump_phys) then
+  write(tag,'(i6.6)') istep
+  call dump3('ph_in_u_prev_'//trim(tag)//'.bin', ug(:,:,:,previous)); call dump3('ph_in_u_cur_'//trim(tag)//'.bin', ug(:,:,:,current))
+  call dump3('ph_in_v_prev_'//trim(tag)//'.bin', vg(:,:,:,previous)); call dump3('ph_in_v_cur_'//trim(tag)//'.bin', vg(:,:,:,current))
+  call dump3('ph_in_t_prev_'//trim(tag)//'.bin', tg(:,:,:,previous)); call dump3('ph_in_t_cur_'//trim(tag)//'.bin', tg(:,:,:,current))
+  call dump3('ph_in_q_prev_'//trim(tag)//'.bin', grid_tracers(:,:,:,previous,nhum))
+  call dump3('ph_in_q_cur_'//trim(tag)//'.bin', grid_tracers(:,:,:,current,nhum))
+  call dump2('ph_in_ps_prev_'//trim(tag)//'.bin', psg(:,:,previous)); call dump2('ph_in_ps_cur_'//trim(tag)//'.bin', psg(:,:,current))
+  call dump3('ph_in_p_half_prev_'//trim(tag)//'.bin', p_half(:,:,:,previous)); call dump3('ph_in_p_half_cur_'//trim(tag)//'.bin', p_half(:,:,:,current))
+  call dump3('ph_in_p_full_prev_'//trim(tag)//'.bin', p_full(:,:,:,previous)); call dump3('ph_in_p_full_cur_'//trim(tag)//'.bin', p_full(:,:,:,current))
+  call dump3('ph_in_z_half_prev_'//trim(tag)//'.bin', z_half(:,:,:,previous)); call dump3('ph_in_z_half_cur_'//trim(tag)//'.bin', z_half(:,:,:,current))
+  call dump3('ph_in_z_full_prev_'//trim(tag)//'.bin', z_full(:,:,:,previous)); call dump3('ph_in_z_full_cur_'//trim(tag)//'.bin', z_full(:,:,:,current))
+endif
+call idealized_moist_phys(Time, p_half, p_full, z_half, z_full, ug, vg, psg, wg_full, tg, grid_tracers, &
+                          previous, current, dt_ug, dt_vg, dt_tg, dt_tracers)
+if(dump_phys) then
+  call dump3('ph_dt_u_'//trim(tag)//'.bin', dt_ug); call dump3('ph_dt_v_'//trim(tag)//'.bin', dt_vg)
+  call dump3('ph_dt_t_'//trim(tag)//'.bin', dt_tg); call dump3('ph_dt_q_'//trim(tag)//'.bin', dt_tracers(:,:,:,nhum))
+endif
+if(previous == current) then
+  future = 3 - current
+else
+  future = previous
+endif
+call spectral_dynamics(Time, psg(:,:,future), ug(:,:,:,future), vg(:,:,:,future), &
+                       tg(:,:,:,future), tracer_attributes, grid_tracers(:,:,:,:,:), future, &
+                       dt_psg, dt_ug, dt_vg, dt_tg, dt_tracers, wg_full, &
+                       p_full(:,:,:,current), p_half(:,:,:,current), z_full(:,:,:,current))
+call compute_pressures_and_heights(tg(:,:,:,future), psg(:,:,future), surf_geopotential, &
+     z_full(:,:,:,future), z_half(:,:,:,future), p_full(:,:,:,future), p_half(:,:,:,future), &
+     grid_tracers(:,:,:,future,nhum))
+previous = current
+current  = future
+Time = Time_next
+end subroutine one_step
+
+!--------------------------------------------------------------------------------------------------
+subroutine dump_state(n)
+integer, intent(in) :: n
+character(len=8) :: tag
+write(tag,'(i6.6)') n
+call dump3('st_ug_'//trim(tag)//'.bin', ug(:,:,:,current))
+call dump3('st_vg_'//trim(tag)//'.bin', vg(:,:,:,current))
+call dump3('st_tg_'//trim(tag)//'.bin', tg(:,:,:,current))
+call dump2('st_psg_'//trim(tag)//'.bin', psg(:,:,current))
+call dump3('st_q_'//trim(tag)//'.bin', grid_tracers(:,:,:,current,nhum))
+end subroutine dump_state
+
+subroutine dump1(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump1
+subroutine dump2(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump2
+subroutine dump3(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dump3
+
+end program ref_moist_harness
