@@ -7,6 +7,10 @@
 ! and dumps raw little-endian fp64 arrays (Fortran order).  Compiled in place from /root/reference by oracle/build_ref.py.
 !
 ! Control: ./harness.nml (&harness_nml) next to the reference's own input.nml / field_table / diag_table.
+!   mode = 'kernels': nsteps steps as in 'run', then the routines of the column chain are called one by one, in the order
+!                   and with the arguments of idealized_moist_phys (:862-1340), on the state reached; inputs (k_in_*) and
+!                   every output (k_*) are dumped.  The surface temperature, private to the reference's driver, is replaced
+!                   by one this harness chooses (k_in_t_surf) -- the routines take it as an argument.
 !   mode = 'run'  : cold start, nsteps steps; after the steps in dump_steps dumps ug, vg, tg, psg, sphum of the new level
 !                   (st_*), and for the steps in phys_steps the inputs and outputs of that step's idealized_moist_phys call:
 !                   ph_in_* = u, v, T, q at `previous` and `current`, p_half/p_full/z_half/z_full at both levels,
@@ -25,6 +29,10 @@ use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics, get_
 use transforms_mod,        only: get_grid_domain, get_spec_domain, get_deg_lon, get_deg_lat, get_grid_boundaries
 use press_and_geopot_mod,  only: compute_pressures_and_heights
 use idealized_moist_phys_mod, only: idealized_moist_phys_init, idealized_moist_phys
+use sat_vapor_pres_mod,    only: lookup_es, lookup_des
+use qe_moist_convection_mod, only: qe_moist_convection
+use lscale_cond_mod,       only: lscale_cond
+use two_stream_gray_rad_mod, only: two_stream_gray_rad_down, two_stream_gray_rad_up
 
 implicit none
 
@@ -128,12 +136,65 @@ if(trim(mode) == 'run') then
   write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
   write(*,'(a,4es24.16)') 'REF_STATE Tmin,Tmax,maxabsU,qmax=', minval(tg(:,:,:,current)), maxval(tg(:,:,:,current)), &
         maxval(abs(ug(:,:,:,current))), maxval(grid_tracers(:,:,:,current,nhum))
+else if(trim(mode) == 'kernels') then
+  do istep = 1, nsteps
+    call one_step(.false.)
+  enddo
+  call run_kernels()
 else
   write(*,*) 'unknown mode ', trim(mode)
   stop 2
 endif
 
 contains
+
+!--------------------------------------------------------------------------------------------------
+subroutine run_kernels()
+real, dimension(is:ie,js:je,num_levels) :: tin, qin, es, des, conv_dt, conv_dq, qref, tref, tg_tmp, qg_tmp, cond_dt, cond_dq, rad_dt
+real, dimension(is:ie,js:je) :: rain, snow, cape, cin, invtau_q, invtau_t, net_sw, lw_down, albedo, t_surf
+integer, dimension(is:ie,js:je) :: convflag, klzbs, klcls
+logical, dimension(is:ie,js:je) :: coldT
+if(current == previous) then
+  delta_t = dt_real
+else
+  delta_t = 2*dt_real
+endif
+coldT = .false.
+tin = tg(:,:,:,previous); qin = grid_tracers(:,:,:,previous,nhum)
+call dump3('k_in_t_prev.bin', tin); call dump3('k_in_q_prev.bin', qin)
+call dump3('k_in_u_prev.bin', ug(:,:,:,previous)); call dump3('k_in_v_prev.bin', vg(:,:,:,previous))
+call dump3('k_in_t_cur.bin', tg(:,:,:,current)); call dump3('k_in_q_cur.bin', grid_tracers(:,:,:,current,nhum))
+call dump3('k_in_u_cur.bin', ug(:,:,:,current)); call dump3('k_in_v_cur.bin', vg(:,:,:,current))
+call dump3('k_in_p_full_prev.bin', p_full(:,:,:,previous)); call dump3('k_in_p_half_prev.bin', p_half(:,:,:,previous))
+call dump3('k_in_p_full_cur.bin', p_full(:,:,:,current)); call dump3('k_in_p_half_cur.bin', p_half(:,:,:,current))
+call dump3('k_in_z_full_cur.bin', z_full(:,:,:,current)); call dump3('k_in_z_half_cur.bin', z_half(:,:,:,current))
+call dump1('k_in_delta_t.bin', (/delta_t/))
+! --- sat_vapor_pres (shared/sat_vapor_pres/sat_vapor_pres.F90: lookup_es, lookup_des)
+call lookup_es(tin, es); call lookup_des(tin, des)
+call dump3('k_es.bin', es); call dump3('k_des.bin', des)
+! --- convection (:862-880)
+call qe_moist_convection(delta_t, tin, qin, p_full(:,:,:,previous), p_half(:,:,:,previous), coldT, rain, snow, conv_dt, conv_dq, &
+                         qref, convflag, klzbs, cape, cin, invtau_q, invtau_t, tref, klcls)
+call dump2('k_conv_rain.bin', rain); call dump3('k_conv_dt.bin', conv_dt); call dump3('k_conv_dq.bin', conv_dq)
+call dump3('k_conv_qref.bin', qref); call dump3('k_conv_tref.bin', tref); call dump2('k_conv_cape.bin', cape); call dump2('k_conv_cin.bin', cin)
+call dump2('k_conv_flag.bin', real(convflag)); call dump2('k_conv_klzb.bin', real(klzbs)); call dump2('k_conv_klcl.bin', real(klcls))
+call dump2('k_conv_invtau_q.bin', invtau_q); call dump2('k_conv_invtau_t.bin', invtau_t)
+tg_tmp = conv_dt + tin
+qg_tmp = conv_dq + qin
+! --- large-scale condensation (:983-987)
+rain = 0.; snow = 0.
+call lscale_cond(tg_tmp, qg_tmp, p_full(:,:,:,previous), p_half(:,:,:,previous), coldT, rain, snow, cond_dt, cond_dq)
+call dump2('k_cond_rain.bin', rain); call dump3('k_cond_dt.bin', cond_dt); call dump3('k_cond_dq.bin', cond_dq)
+! --- grey radiation, downward then upward (:1054-1061, :1156-1162)
+albedo = 0.31
+call two_stream_gray_rad_down(is, js, Time, rad_lat_2d, rad_lon_2d, p_half(:,:,:,current), tin, net_sw, lw_down, albedo, qin)
+call dump2('k_rad_net_sw_down.bin', net_sw); call dump2('k_rad_lw_down.bin', lw_down)
+t_surf = tin(:,:,num_levels) + 1.5 + 0.5*cos(rad_lon_2d)
+call dump2('k_in_t_surf.bin', t_surf)
+rad_dt = 0.
+call two_stream_gray_rad_up(is, js, Time, rad_lat_2d, p_half(:,:,:,current), t_surf, tin, rad_dt, albedo)
+call dump3('k_rad_dt.bin', rad_dt)
+end subroutine run_kernels
 
 !--------------------------------------------------------------------------------------------------
 subroutine one_step(dump_phys)
