@@ -89,6 +89,7 @@ MP_HD void lscale_cond(const SatTable &st, int L, const double *tin, const doubl
 // with do_seasonal = .false.: annual-mean insolation 0.25 S0 (1 + del_sol P2(lat) + del_sw sin lat), SW absorbed with
 // optical depth sw_tau_0 (p/p0)^solar_exponent, grey LW with lw_tau_0(lat) (linear_tau p/p0 + (1-linear_tau)(p/p0)^wv_exponent).
 // ------------------------------------------------------------------------------------------------
+MP_HD double pow4(double x) { return x * x * x * x; }     // x**4 as the reference build expands it, ((x x) x) x
 struct GrayRadParams {
   double solar_constant = 1360.0, del_sol = 1.4, del_sw = 0.0, ir_tau_eq = 6.0, ir_tau_pole = 1.5, atm_abs = 0.0, odp = 1.0,
          sw_diff = 0.0, linear_tau = 0.1, wv_exponent = 4.0, solar_exponent = 4.0, diabatic_acce = 1.0;
@@ -97,11 +98,11 @@ struct GrayRadParams {
 MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, const double *p_half, int s,
                          double *lw_down, double *lw_dtrans, double &insolation, double &sw_tau_0, double &net_surf_sw_down,
                          double &surf_lw_down) {
-  const double sl = sin(lat);
-  const double p2 = (1. - 3. * sl * sl) / 4.;
+  const double sl = sin(lat), sl2 = sl * sl;
+  const double p2 = (1. - 3. * sl2) / 4.;
   insolation = 0.25 * p.solar_constant * (1.0 + p.del_sol * p2 + p.del_sw * sl);
-  sw_tau_0 = (1.0 - p.sw_diff * sl * sl) * p.atm_abs;
-  double lw_tau_0 = p.ir_tau_eq + (p.ir_tau_pole - p.ir_tau_eq) * sl * sl;
+  sw_tau_0 = (1.0 - p.sw_diff * sl2) * p.atm_abs;
+  double lw_tau_0 = p.ir_tau_eq + (p.ir_tau_pole - p.ir_tau_eq) * sl2;
   lw_tau_0 = lw_tau_0 * p.odp;
   double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pow(p_half[0] / PSTD_MKS, p.wv_exponent));
   lw_down[0] = 0.;
@@ -110,7 +111,7 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
     const double tau_n = lw_tau_0 * (p.linear_tau * ph / PSTD_MKS + (1.0 - p.linear_tau) * pow(ph / PSTD_MKS, p.wv_exponent));
     lw_dtrans[k] = exp(-(tau_n - tau_k));
     const double tk = t[k * s];
-    const double b = STEFAN * (tk * tk * tk * tk);
+    const double b = STEFAN * pow4(tk);
     lw_down[k + 1] = lw_down[k] * lw_dtrans[k] + b * (1. - lw_dtrans[k]);
     tau_k = tau_n;
   }
@@ -121,13 +122,13 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
 // Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, const double *p_half, int s,
                        const double *lw_down, const double *lw_dtrans, double insolation, double sw_tau_0, double *tdt, int st) {
-  const double b_surf = STEFAN * (t_surf * t_surf * t_surf * t_surf);
+  const double b_surf = STEFAN * pow4(t_surf);
   const double sw_up = albedo * (insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
   double flux_n = (lw_up_n - lw_down[L]) + (sw_up - insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
   for (int k = L - 1; k >= 0; --k) {
     const double tk = t[k * s];
-    const double b = STEFAN * (tk * tk * tk * tk);
+    const double b = STEFAN * pow4(tk);
     const double lw_up_k = lw_up_n * lw_dtrans[k] + b * (1.0 - lw_dtrans[k]);
     const double sw_down_k = insolation * exp(-sw_tau_0 * pow(p_half[k * s] / PSTD_MKS, p.solar_exponent));
     const double flux_k = (lw_up_k - lw_down[k]) + (sw_up - sw_down_k);
@@ -362,6 +363,366 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     if (Tref_out) Tref_out[(k - 1) * so] = c.Tref[k];
     if (qref_out) qref_out[(k - 1) * so] = c.qref[k];
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Monin-Obukhov surface layer (atmos_param/monin_obukhov/monin_obukhov_kernel.F90:122-420, :423-520, :648-810) with the
+// module defaults rich_crit = 2, drag_min = 1e-5, stable_option = 1, neutral = .false.  The reference iterates a row of
+// points together but freezes each point once it has converged, which is this per-point loop.
+// ------------------------------------------------------------------------------------------------
+struct MoParams { double rich_crit = 2.0, drag_min = 1.e-05, zeta_trans = 0.5; };
+MP_HD double mo_phi_t(const MoParams &p, double zeta) {
+  if (zeta < 0.0) return pow(1 - 16.0 * zeta, -0.5);
+  const double b_stab = 1.0 / p.rich_crit;
+  return 1.0 + zeta * (5.0 + b_stab * zeta) / (1.0 + zeta);
+}
+MP_HD double mo_phi_m(const MoParams &p, double zeta) {
+  if (zeta < 0.0) { const double x = pow(1 - 16.0 * zeta, -0.5); return sqrt(x); }
+  const double b_stab = 1.0 / p.rich_crit;
+  return 1.0 + zeta * (5.0 + b_stab * zeta) / (1.0 + zeta);
+}
+MP_HD double mo_psi_m(const MoParams &p, double zeta, double zeta_0, double ln_z_z0) {
+  const double b_stab = 1.0 / p.rich_crit;
+  if (zeta < 0.0) {
+    double x = sqrt(1 - 16.0 * zeta), x_0 = sqrt(1 - 16.0 * zeta_0);
+    x = sqrt(x); x_0 = sqrt(x_0);
+    const double x1 = 1.0 + x, x1_0 = 1.0 + x_0;
+    const double num = x1 * x1 * (1.0 + x * x), denom = x1_0 * x1_0 * (1.0 + x_0 * x_0);
+    const double y = atan(x) - atan(x_0);
+    return ln_z_z0 - log(num / denom) + 2 * y;
+  }
+  return ln_z_z0 + (5.0 - b_stab) * log((1.0 + zeta) / (1.0 + zeta_0)) + b_stab * (zeta - zeta_0);
+}
+MP_HD double mo_psi_t(const MoParams &p, double zeta, double zeta_t, double ln_z_zt) {
+  const double b_stab = 1.0 / p.rich_crit;
+  if (zeta < 0.0) {
+    const double x = sqrt(1 - 16.0 * zeta), x_t = sqrt(1 - 16.0 * zeta_t);
+    return ln_z_zt - 2.0 * log((1.0 + x) / (1.0 + x_t));
+  }
+  return ln_z_zt + (5.0 - b_stab) * log((1.0 + zeta) / (1.0 + zeta_t)) + b_stab * (zeta - zeta_t);
+}
+// monin_obukhov_solve_zeta (:245-420) for one point
+MP_HD void mo_solve_zeta(const MoParams &p, double rich, double z, double z0, double zt, double zq, double &f_m, double &f_t, double &f_q) {
+  const double error = 1.e-04, zeta_min = 1.e-06;
+  const int max_iter = 20;
+  const double z_z0 = z / z0, z_zt = z / zt, z_zq = z / zq;
+  const double ln_z_z0 = log(z_z0), ln_z_zt = log(z_zt), ln_z_zq = log(z_zq);
+  double zeta = rich * ln_z_z0 * ln_z_z0 / ln_z_zt;
+  if (rich >= 0.0) zeta = zeta / (1.0 - rich / p.rich_crit);
+  f_m = f_t = f_q = 0.0;
+  for (int iter = 1; iter <= max_iter; ++iter) {
+    if (fabs(zeta) < zeta_min) { f_m = ln_z_z0; f_t = ln_z_zt; f_q = ln_z_zq; return; }
+    const double rzeta = 1.0 / zeta, zeta_0 = zeta / z_z0, zeta_t = zeta / z_zt, zeta_q = zeta / z_zq;
+    const double phi_m = mo_phi_m(p, zeta), phi_m_0 = mo_phi_m(p, zeta_0), phi_t = mo_phi_t(p, zeta), phi_t_0 = mo_phi_t(p, zeta_t);
+    f_m = mo_psi_m(p, zeta, zeta_0, ln_z_z0);
+    f_t = mo_psi_t(p, zeta, zeta_t, ln_z_zt);
+    f_q = mo_psi_t(p, zeta, zeta_q, ln_z_zq);
+    const double df_m = (phi_m - phi_m_0) * rzeta, df_t = (phi_t - phi_t_0) * rzeta;
+    const double rich_1 = zeta * f_t / (f_m * f_m);
+    const double d_rich = rich_1 * (rzeta + df_t / f_t - 2.0 * df_m / f_m);
+    const double correction = (rich - rich_1) / d_rich;
+    const double corr = fmin(fabs(correction), fabs(correction / zeta));
+    if (corr > error) zeta = zeta + correction; else return;
+  }
+}
+// monin_obukhov_drag_1d (:122-241)
+MP_HD void mo_drag(const MoParams &p, double pt, double pt0, double z, double z0, double zt, double zq, double speed, double &drag_m,
+                   double &drag_t, double &drag_q, double &u_star, double &b_star) {
+  const double small = 1.e-04;
+  const double r_crit = 0.95 * p.rich_crit;
+  const double sqrt_drag_min = (p.drag_min != 0.0) ? sqrt(p.drag_min) : 0.0;
+  const double delta_b = GRAV * (pt0 - pt) / pt0;
+  const double rich = -z * delta_b / (speed * speed + small);
+  const double zz = fmax(fmax(z, z0), fmax(zt, zq));
+  if (rich >= r_crit) {
+    drag_m = drag_t = drag_q = p.drag_min;
+    u_star = sqrt_drag_min * speed; b_star = sqrt_drag_min * delta_b;
+    return;
+  }
+  double fm, ft, fq;
+  mo_solve_zeta(p, rich, zz, z0, zt, zq, fm, ft, fq);
+  const double us = fmax(VONKARM / fm, sqrt_drag_min), bs = fmax(VONKARM / ft, sqrt_drag_min), qs = fmax(VONKARM / fq, sqrt_drag_min);
+  drag_m = us * us; drag_t = us * bs; drag_q = us * qs;
+  u_star = us * speed; b_star = bs * delta_b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// surface_flux (coupler/surface_flux.F90:290-700) over an ocean point with do_simple = .true., use_virtual_temp = .false.,
+// old_dtaudv = .true., no bucket, gust_min = 0, surface at rest.
+// ------------------------------------------------------------------------------------------------
+struct SurfFlux {
+  double flux_t, flux_q, flux_r, flux_u, flux_v, dhdt_surf, dedt_surf, dedq_surf, drdt_surf, dhdt_atm, dedq_atm, dtaudu_atm, dtaudv_atm,
+         w_atm, u_star, b_star, q_star, cd_m, cd_t, cd_q, q_surf;
+};
+MP_HD void surface_flux(const SatTable &st, const MoParams &mo, double t_atm, double q_atm, double u_atm, double v_atm, double p_atm,
+                        double z_atm, double p_surf, double t_surf, double rough_mom, double rough_heat, double rough_moist,
+                        double rough_scale, double gust, SurfFlux &o) {
+  const double del_temp = 0.1, del_temp_inv = 1.0 / del_temp;
+  const double d622 = RDGAS / RVGAS, kappa = RDGAS / CP_AIR, d608 = 0.0;   // use_virtual_temp = .false.
+  const double t_surf0 = t_surf, t_surf1 = t_surf0 + del_temp;
+  const double e_sat = lookup_es(st, t_surf0), e_sat1 = lookup_es(st, t_surf1);
+  const double q_sat = d622 * e_sat / p_surf, q_sat1 = d622 * e_sat1 / p_surf;     // do_simple
+  const double q_surf0 = q_sat;
+  const double p_ratio = pow(p_surf / p_atm, kappa);
+  const double tv_atm = t_atm * (1.0 + d608 * q_atm);
+  const double th_atm = t_atm * p_ratio, thv_atm = tv_atm * p_ratio, thv_surf = t_surf0 * (1.0 + d608 * q_surf0);
+  const double u_dif = 0.0 - u_atm, v_dif = 0.0 - v_atm;
+  const double w_gust = gust;
+  const double w_atm = sqrt(u_dif * u_dif + v_dif * v_dif + w_gust * w_gust);
+  double cd_m, cd_t, cd_q, u_star, b_star;
+  mo_drag(mo, thv_atm, thv_surf, z_atm, rough_mom, rough_heat, rough_moist, w_atm, cd_m, cd_t, cd_q, u_star, b_star);
+  const double lr = log(z_atm / rough_mom + 1) / log(z_atm / rough_scale + 1);
+  cd_m = cd_m * (lr * lr);
+  const double drag_t = cd_t * w_atm, drag_q = cd_q * w_atm, drag_m = cd_m * w_atm;
+  const double rho = p_atm / (RDGAS * tv_atm);
+  double rho_drag = CP_AIR * drag_t * rho;
+  o.flux_t = rho_drag * (t_surf0 - th_atm);
+  o.dhdt_surf = rho_drag;
+  o.dhdt_atm = -rho_drag * p_ratio;
+  rho_drag = drag_q * rho;
+  o.flux_q = rho_drag * (q_surf0 - q_atm);
+  o.dedq_surf = 0;
+  o.dedt_surf = rho_drag * (q_sat1 - q_sat) * del_temp_inv;
+  o.dedq_atm = -rho_drag;
+  o.q_star = o.flux_q / (u_star * rho);
+  o.q_surf = q_atm + o.flux_q / (rho * cd_q * w_atm);
+  o.flux_r = STEFAN * pow4(t_surf);
+  o.drdt_surf = 4 * STEFAN * (t_surf * t_surf * t_surf);
+  rho_drag = drag_m * rho;
+  o.flux_u = rho_drag * u_dif;
+  o.flux_v = rho_drag * v_dif;
+  o.dtaudv_atm = -rho_drag;            // old_dtaudv
+  o.dtaudu_atm = -rho_drag;
+  o.w_atm = w_atm; o.u_star = u_star; o.b_star = b_star; o.cd_m = cd_m; o.cd_t = cd_t; o.cd_q = cd_q;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Rayleigh sponge of damping_driver (atmos_param/damping_driver/damping_driver.f90:164-171, :594-637): levels
+// 1..nlev_rayfric above sponge_pbottom are damped towards rest with rate rfactr ((p_b - p)/p_b)^2, the kinetic energy
+// removed goes into heat (do_conserve_energy).  nlev_rayfric and rfactr are set up by the host (:411-420).
+// ------------------------------------------------------------------------------------------------
+struct RayleighParams { int nlev_rayfric = 0; double rfactr = 0.0, sponge_pbottom = 50.0; bool conserve_energy = true; };
+MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pfull, const double *u, const double *v, int s, double *udt,
+                            double *vdt, double *tdt, int st) {
+  for (int k = 0; k < p.nlev_rayfric; ++k) {
+    double ut = 0.0, vt = 0.0;
+    if (pfull[k * s] < p.sponge_pbottom) {
+      const double d = p.sponge_pbottom - pfull[k * s];
+      const double fact = p.rfactr * (d * d) / (p.sponge_pbottom * p.sponge_pbottom);
+      ut = -u[k * s] * fact; vt = -v[k * s] * fact;
+    }
+    udt[k * st] = udt[k * st] + ut;
+    vdt[k * st] = vdt[k * st] + vt;
+    if (p.conserve_energy) tdt[k * st] = tdt[k * st] + (-((u[k * s] + .5 * dt * ut) * ut + (v[k * s] + .5 * dt * vt) * vt) / CP_AIR);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Boundary-layer diffusivities: vert_turb_driver with do_diffusivity (atmos_param/vert_turb_driver/vert_turb_driver.F90:204-273)
+// -> diffusivity with do_simple = .true., do_entrain = .false. (atmos_param/diffusivity/diffusivity.F90:283-360): boundary
+// layer depth from the bulk Richardson number of the dry static energy profile (pbl_depth :364-444), Monin-Obukhov
+// diffusivities in the inner layer, the Troen-Mahrt shape above (diffusivity_pbl :448-510; mo_diff =
+// monin_obukhov_kernel.F90:42-120).  Inputs are the provisional fields x_prev + dt * dx/dt (use_tau = .false.);
+// k_m[k], k_t[k] sit on the interface above full level k (k = 0 stays zero).
+// ------------------------------------------------------------------------------------------------
+struct DiffusivityParams { double frac_inner = 0.1, rich_crit_pbl = 1.0, small = 1.e-04, ustar_min = 1.e-10; };
+MP_HD void mo_diff(const MoParams &mo, const DiffusivityParams &dp, double z, double u_star, double b_star, double &k_m, double &k_h) {
+  const double uss = fmax(u_star, dp.ustar_min);
+  const double zeta = -(VONKARM * b_star * z / (uss * uss));
+  k_m = VONKARM * uss * z / mo_phi_m(mo, zeta);
+  k_h = VONKARM * uss * z / mo_phi_t(mo, zeta);
+}
+template <int LMAX>
+MP_HD void pbl_diffusivity(const MoParams &mo, const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um,
+                           const double *vm, int s, const double *tdt, const double *udt, const double *vdt, int st, const double *z_full,
+                           const double *z_half, int sz, double u_star, double b_star, double &h, double *k_m, double *k_t, int so) {
+  const double gcp = GRAV / CP_AIR;
+  const double z_surf = z_half[L * sz];
+  double rich[LMAX], zf[LMAX];
+  const double tbot = (tm[(L - 1) * s] + dt * tdt[(L - 1) * st]) + gcp * (z_full[(L - 1) * sz] - z_surf);
+  for (int k = 0; k < L; ++k) {
+    zf[k] = z_full[k * sz] - z_surf;
+    const double svcp = (tm[k * s] + dt * tdt[k * st]) + gcp * zf[k];
+    const double uu = um[k * s] + dt * udt[k * st], vv = vm[k * s] + dt * vdt[k * st];
+    rich[k] = zf[k] * GRAV * (svcp - tbot) / tbot / (uu * uu + vv * vv + dp.small);
+  }
+  double h1 = zf[L - 1], rich1 = rich[L - 1];
+  h = h1;
+  for (int k = L - 2; k >= 0; --k) {
+    const double rich2 = rich[k], h2 = zf[k];
+    if (rich2 > dp.rich_crit_pbl) { h = h2 + (h1 - h2) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1); break; }
+    rich1 = rich2; h1 = h2;
+  }
+  const double h_inner = dp.frac_inner * h;
+  double k_m_ref, k_t_ref;
+  mo_diff(mo, dp, h_inner, u_star, b_star, k_m_ref, k_t_ref);
+  k_m[0] = 0.0; k_t[0] = 0.0;
+  for (int k = 1; k < L; ++k) {
+    const double zm = z_half[k * sz] - z_surf;
+    double km = 0.0, kt = 0.0;
+    if (zm < h_inner) mo_diff(mo, dp, zm, u_star, b_star, km, kt);
+    else if (zm < h) {
+      const double r = 1.0 - (zm - h_inner) / (h - h_inner);
+      const double factor = (zm / h_inner) * (r * r);
+      km = k_m_ref * factor; kt = k_t_ref * factor;
+    }
+    k_m[k * so] = km; k_t[k * so] = kt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Implicit vertical diffusion (atmos_param/vert_diff/vert_diff.F90): downward sweep of the tridiagonal elimination for
+// momentum (closed at the surface with the stress and its derivative, kinetic energy dissipated into heat) and for
+// dry static energy / humidity (left open: Tri_surf hands the lowest-level increments to the surface model),
+// gcm_vert_diff_down :270-406; the mixed-layer ocean closes the system (mixed_layer.F90:568-720) and
+// gcm_vert_diff_up :410-467 back-substitutes.
+// ------------------------------------------------------------------------------------------------
+struct VdiffSurf { double dtmass, dflux_t, delta_t, dflux_q, delta_q, delta_u, delta_v; };
+template <int LMAX>
+struct VdiffWork { double e[LMAX], f_t[LMAX], f_q[LMAX]; };
+
+namespace vd {
+// compute_e (:951-980): a, b, c of the tridiagonal system, e and g of the elimination.  0-based; g valid for 1..L-2.
+template <int LMAX>
+MP_HD void compute_e(int L, double delt, const double *mu, const double *nu, double *e, double *b, double *c, double *g) {
+  double a_prev = 0.0;
+  for (int k = 0; k < L; ++k) {
+    const double a = (k < L - 1) ? -(mu[k] * nu[k + 1] * delt) : 0.0;
+    c[k] = (k > 0) ? -(mu[k] * nu[k] * delt) : 0.0;
+    b[k] = 1.0 - a - c[k];
+    if (k == 0) e[0] = -a / b[0];
+    else if (k < L - 1) { g[k] = 1.0 / (b[k] + c[k] * e[k - 1]); e[k] = -a * g[k]; }
+    (void)a_prev;
+  }
+}
+// explicit_tend (:1005-1029)
+MP_HD void explicit_tend(int L, const double *mu, const double *nu, const double *xi, double *dt_xi) {
+  double fl_k = 0.0;                                         // flux through the top of level k
+  for (int k = 0; k < L - 1; ++k) {
+    const double fl_n = nu[k + 1] * (xi[k + 1] - xi[k]);
+    dt_xi[k] = dt_xi[k] + mu[k] * (fl_n - fl_k);
+    fl_k = fl_n;
+  }
+  dt_xi[L - 1] = dt_xi[L - 1] - mu[L - 1] * fl_k;
+}
+// compute_f (:984-1001)
+MP_HD void compute_f(int L, const double *dt_xi, const double *b, const double *c, const double *g, double *f) {
+  f[0] = dt_xi[0] / b[0];
+  for (int k = 1; k < L - 1; ++k) f[k] = (dt_xi[k] - c[k] * f[k - 1]) * g[k];
+}
+// diff_surface (:882-910)
+MP_HD void diff_surface(double mu_delt, double nu, double e_n1, double f_delt_n1, double dflux_datmos, double &flux, double factor,
+                        double &delta_xi) {
+  const double fff = 1.0 / factor;
+  const double dflux = -nu * (1.0 - e_n1);
+  delta_xi = delta_xi + mu_delt * nu * f_delt_n1;
+  delta_xi = (delta_xi + mu_delt * flux * fff) / (1.0 - mu_delt * (dflux + dflux_datmos * fff));
+  flux = flux + dflux_datmos * delta_xi;
+}
+// vert_diff_up (:914-947)
+MP_HD void diff_up(int L, double delt, const double *e, const double *f, double delta_xi_n, double *dt_xi, int st) {
+  double x = delta_xi_n / delt;
+  dt_xi[(L - 1) * st] = x;
+  for (int k = L - 2; k >= 0; --k) { x = e[k] * x + f[k]; dt_xi[k * st] = x; }
+}
+}  // namespace vd
+
+// gcm_vert_diff_down for one column.  u, v, t, q: previous time level; p_half, p_full, z_full: current; dt_*: accumulated
+// tendencies (dt_u, dt_v are final on return, dt_t has the dissipative heating added).  Leaves e, f_t, f_q in w.
+template <int LMAX>
+MP_HD void vert_diff_down(int L, double delt, const double *u, const double *v, const double *t, const double *q, int s, const double *diff_m,
+                          const double *diff_t, int sd, const double *p_half, const double *p_full, const double *z_full, int sp,
+                          double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u, double *dt_v, double *dt_t,
+                          const double *dt_q, int st, double *diss_heat, int sh, VdiffWork<LMAX> &w, VdiffSurf &S) {
+  const double gcp = GRAV / CP_AIR;
+  double mu[LMAX], nu[LMAX], b[LMAX], c[LMAX], g[LMAX], x1[LMAX], x2[LMAX], d1[LMAX], d2[LMAX], f1[LMAX], f2[LMAX], e[LMAX];
+  for (int k = 0; k < L; ++k) mu[k] = GRAV / (p_half[(k + 1) * sp] - p_half[k * sp]);                      // compute_mu :1033
+  auto compute_nu = [&](const double *diff) {                                                              // compute_nu :1053
+    nu[0] = 0.0;
+    for (int k = 1; k < L; ++k) {
+      const double rho_half = 2.0 * p_half[k * sp] / (RDGAS * (t[k * s] + t[(k - 1) * s]));
+      nu[k] = rho_half * diff[k * sd] / (z_full[(k - 1) * sp] - z_full[k * sp]);
+    }
+  };
+  // ---- momentum (uv_vert_diff :560-623)
+  compute_nu(diff_m);
+  for (int k = 0; k < L; ++k) { x1[k] = u[k * s]; x2[k] = v[k * s]; d1[k] = dt_u[k * st]; d2[k] = dt_v[k * st]; }
+  vd::explicit_tend(L, mu, nu, x1, d1);
+  vd::explicit_tend(L, mu, nu, x2, d2);
+  vd::compute_e<LMAX>(L, delt, mu, nu, e, b, c, g);
+  vd::compute_f(L, d1, b, c, g, f1);
+  vd::compute_f(L, d2, b, c, g, f2);
+  {
+    const double mu_delt_n = mu[L - 1] * delt, nu_n = nu[L - 1], e_n1 = e[L - 2];
+    double delta_u_n = d1[L - 1] * delt, delta_v_n = d2[L - 1] * delt;
+    vd::diff_surface(mu_delt_n, nu_n, e_n1, f1[L - 2] * delt, dtau_du, tau_u, 1.0, delta_u_n);
+    vd::diff_surface(mu_delt_n, nu_n, e_n1, f2[L - 2] * delt, dtau_dv, tau_v, 1.0, delta_v_n);
+    S.delta_u = delta_u_n; S.delta_v = delta_v_n;
+    double xu = delta_u_n / delt, xv = delta_v_n / delt;
+    const double half_delt = 0.5 * delt, cp_inv = 1.0 / CP_AIR;
+    for (int k = L - 1; k >= 0; --k) {
+      if (k < L - 1) { xu = e[k] * xu + f1[k]; xv = e[k] * xv + f2[k]; }
+      const double du = xu - dt_u[k * st], dv = xv - dt_v[k * st];
+      const double dh = -cp_inv * ((u[k * s] + half_delt * du) * du + (v[k * s] + half_delt * dv) * dv);
+      dt_u[k * st] = xu; dt_v[k * st] = xv;
+      dt_t[k * st] = dt_t[k * st] + dh;
+      if (diss_heat) diss_heat[k * sh] = dh;
+    }
+  }
+  // ---- dry static energy and humidity (vert_diff_down_2 :814-878)
+  compute_nu(diff_t);
+  for (int k = 0; k < L; ++k) { x1[k] = t[k * s] + z_full[k * sp] * gcp; x2[k] = q[k * s]; d1[k] = dt_t[k * st]; d2[k] = dt_q[k * st]; }
+  vd::explicit_tend(L, mu, nu, x1, d1);
+  vd::explicit_tend(L, mu, nu, x2, d2);
+  vd::compute_e<LMAX>(L, delt, mu, nu, w.e, b, c, g);
+  vd::compute_f(L, d1, b, c, g, w.f_t);
+  vd::compute_f(L, d2, b, c, g, w.f_q);
+  const double mu_delt_n = mu[L - 1] * delt, nu_n = nu[L - 1], e_n1 = w.e[L - 2];
+  S.delta_t = d1[L - 1] * delt + mu_delt_n * nu_n * (w.f_t[L - 2] * delt);
+  S.dflux_t = -nu_n * (1.0 - e_n1);
+  S.delta_q = d2[L - 1] * delt + mu_delt_n * nu_n * (w.f_q[L - 2] * delt);
+  S.dflux_q = -nu_n * (1.0 - e_n1);
+  S.dtmass = mu_delt_n;
+}
+
+// mixed_layer (atmos_spectral/driver/solo/mixed_layer.F90:568-720): slab ocean of uniform heat capacity closing the implicit
+// system; updates t_surf and the lowest-level increments.  dt is dt_atmos (not the leapfrog 2 dt).
+struct MixedLayerParams { double heat_capacity = 2.5 * 1.035e3 * 3989.24495292815; bool evaporation = true; double ocean_qflux = 0.0; };
+MP_HD void mixed_layer(const MixedLayerParams &p, double dt, double &t_surf, double flux_t, double flux_q, double flux_r, double net_sw,
+                       double lw_down, VdiffSurf &S, double dhdt_surf, double dedt_surf, double drdt_surf, double dhdt_atm,
+                       double dedq_atm) {
+  const double inv_cp_air = 1.0 / CP_AIR;
+  const double gamma_t = 1.0 / (1.0 - S.dtmass * (S.dflux_t + dhdt_atm * inv_cp_air));
+  const double gamma_q = 1.0 / (1.0 - S.dtmass * (S.dflux_q + dedq_atm));
+  const double fn_t = gamma_t * (S.delta_t + S.dtmass * flux_t * inv_cp_air);
+  const double fn_q = gamma_q * (S.delta_q + S.dtmass * flux_q);
+  const double en_t = gamma_t * S.dtmass * dhdt_surf * inv_cp_air;
+  const double en_q = gamma_q * S.dtmass * dedt_surf;
+  const double alpha_t = flux_t * inv_cp_air + dhdt_atm * inv_cp_air * fn_t;
+  const double alpha_q = flux_q + dedq_atm * fn_q;
+  const double alpha_lw = flux_r;
+  const double beta_t = dhdt_surf * inv_cp_air + dhdt_atm * inv_cp_air * en_t;
+  const double beta_q = dedt_surf + dedq_atm * en_q;
+  const double beta_lw = drdt_surf;
+  double corrected_flux = -net_sw - lw_down + alpha_t * CP_AIR + alpha_lw - p.ocean_qflux;
+  double t_surf_dependence = beta_t * CP_AIR + beta_lw;
+  if (p.evaporation) {
+    corrected_flux = corrected_flux + alpha_q * HLV;
+    t_surf_dependence = t_surf_dependence + beta_q * HLV;
+  }
+  const double eff_heat_capacity = p.heat_capacity + t_surf_dependence * dt;
+  const double delta_t_surf = -corrected_flux * dt / eff_heat_capacity;
+  t_surf = t_surf + delta_t_surf;
+  S.delta_t = fn_t + en_t * delta_t_surf;
+  if (p.evaporation) S.delta_q = fn_q + en_q * delta_t_surf;
+}
+
+// gcm_vert_diff_up: final dt_t, dt_q
+template <int LMAX>
+MP_HD void vert_diff_up(int L, double delt, const VdiffWork<LMAX> &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st) {
+  vd::diff_up(L, delt, w.e, w.f_t, S.delta_t, dt_t, st);
+  vd::diff_up(L, delt, w.e, w.f_q, S.delta_q, dt_q, st);
 }
 
 }  // namespace moist

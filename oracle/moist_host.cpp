@@ -46,4 +46,53 @@ void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const doubl
     gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), ins, tau0, tdt + c, ncol);
   }
 }
+// out: 21 doubles per column in the order of struct SurfFlux
+void mh_surface_flux(int ncol, const double *t_atm, const double *q_atm, const double *u_atm, const double *v_atm, const double *p_atm,
+                     const double *z_atm, const double *p_surf, const double *t_surf, double rough, double gust, double *out) {
+  const SatTable st = sat();
+  MoParams mo;
+  for (int c = 0; c < ncol; ++c) {
+    SurfFlux o;
+    surface_flux(st, mo, t_atm[c], q_atm[c], u_atm[c], v_atm[c], p_atm[c], z_atm[c], p_surf[c], t_surf[c], rough, rough, rough, rough, gust, o);
+    const double v[21] = {o.flux_t, o.flux_q, o.flux_r, o.flux_u, o.flux_v, o.dhdt_surf, o.dedt_surf, o.dedq_surf, o.drdt_surf, o.dhdt_atm,
+                          o.dedq_atm, o.dtaudu_atm, o.dtaudv_atm, o.w_atm, o.u_star, o.b_star, o.q_star, o.cd_m, o.cd_t, o.cd_q, o.q_surf};
+    for (int i = 0; i < 21; ++i) out[c * 21 + i] = v[i];
+  }
+}
+void mh_rayleigh(int L, int ncol, int nlev_rayfric, double rfactr, double sponge_pbottom, double dt, const double *pfull, const double *u,
+                 const double *v, double *udt, double *vdt, double *tdt) {
+  RayleighParams p; p.nlev_rayfric = nlev_rayfric; p.rfactr = rfactr; p.sponge_pbottom = sponge_pbottom;
+  for (int c = 0; c < ncol; ++c) rayleigh_damping(p, dt, pfull + c, u + c, v + c, ncol, udt + c, vdt + c, tdt + c, ncol);
+}
+void mh_diffusivity(int L, int ncol, double dt, const double *tm, const double *um, const double *vm, const double *tdt, const double *udt,
+                    const double *vdt, const double *z_full, const double *z_half, const double *u_star, const double *b_star, double *h,
+                    double *k_m, double *k_t) {
+  MoParams mo; DiffusivityParams dp;
+  for (int c = 0; c < ncol; ++c)
+    pbl_diffusivity<64>(mo, dp, L, dt, tm + c, um + c, vm + c, ncol, tdt + c, udt + c, vdt + c, ncol, z_full + c, z_half + c, ncol, u_star[c],
+                        b_star[c], h[c], k_m + c, k_t + c, ncol);
+}
+// surf: 7 doubles per column (VdiffSurf) after the downward sweep; surf_ml: the same after mixed_layer
+void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u, const double *v, const double *t, const double *q,
+                  const double *diff_m, const double *diff_t, const double *p_half, const double *p_full, const double *z_full,
+                  const double *flux_u, const double *flux_v, const double *dtau_du, const double *dtau_dv, double *dt_u, double *dt_v,
+                  double *dt_t, double *dt_q, double *diss_heat, double *surf, double *t_surf, const double *flux_t, const double *flux_q,
+                  const double *flux_r, const double *net_sw, const double *lw_down, const double *dhdt_surf, const double *dedt_surf,
+                  const double *drdt_surf, const double *dhdt_atm, const double *dedq_atm, double *surf_ml, double *dt_t_down) {
+  MixedLayerParams ml;
+  for (int c = 0; c < ncol; ++c) {
+    VdiffWork<64> w; VdiffSurf S;
+    double tu = flux_u[c], tv = flux_v[c];
+    vert_diff_down<64>(L, delt, u + c, v + c, t + c, q + c, ncol, diff_m + c, diff_t + c, ncol, p_half + c, p_full + c, z_full + c, ncol, tu,
+                       tv, dtau_du[c], dtau_dv[c], dt_u + c, dt_v + c, dt_t + c, dt_q + c, ncol, diss_heat + c, ncol, w, S);
+    const double a[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
+    for (int i = 0; i < 7; ++i) surf[c * 7 + i] = a[i];
+    for (int k = 0; k < L; ++k) dt_t_down[k * ncol + c] = dt_t[k * ncol + c];
+    mixed_layer(ml, dt_atmos, t_surf[c], flux_t[c], flux_q[c], flux_r[c], net_sw[c], lw_down[c], S, dhdt_surf[c], dedt_surf[c],
+                drdt_surf[c], dhdt_atm[c], dedq_atm[c]);
+    const double b[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
+    for (int i = 0; i < 7; ++i) surf_ml[c * 7 + i] = b[i];
+    vert_diff_up<64>(L, delt, w, S, dt_t + c, dt_q + c, ncol);
+  }
+}
 }

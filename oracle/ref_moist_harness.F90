@@ -33,6 +33,11 @@ use sat_vapor_pres_mod,    only: lookup_es, lookup_des
 use qe_moist_convection_mod, only: qe_moist_convection
 use lscale_cond_mod,       only: lscale_cond
 use two_stream_gray_rad_mod, only: two_stream_gray_rad_down, two_stream_gray_rad_up
+use surface_flux_mod,      only: surface_flux
+use damping_driver_mod,    only: damping_driver
+use vert_turb_driver_mod,  only: vert_turb_driver
+use vert_diff_mod,         only: gcm_vert_diff_down, gcm_vert_diff_up, surf_diff_type
+use mixed_layer_mod,       only: mixed_layer
 
 implicit none
 
@@ -194,7 +199,82 @@ call dump2('k_in_t_surf.bin', t_surf)
 rad_dt = 0.
 call two_stream_gray_rad_up(is, js, Time, rad_lat_2d, p_half(:,:,:,current), t_surf, tin, rad_dt, albedo)
 call dump3('k_rad_dt.bin', rad_dt)
+! --- large-scale condensation once more on a moistened profile, so that the adjustment and the re-evaporation act
+qg_tmp = 1.6*qg_tmp
+call dump3('k_in_cond2_q.bin', qg_tmp)
+call lscale_cond(tg_tmp, qg_tmp, p_full(:,:,:,previous), p_half(:,:,:,previous), coldT, rain, snow, cond_dt, cond_dq)
+call dump2('k_cond2_rain.bin', rain); call dump3('k_cond2_dt.bin', cond_dt); call dump3('k_cond2_dq.bin', cond_dq)
+call run_kernels_surface(conv_dt, conv_dq, rad_dt, t_surf, albedo, net_sw, lw_down, klcls)
 end subroutine run_kernels
+
+!--------------------------------------------------------------------------------------------------
+subroutine run_kernels_surface(conv_dt, conv_dq, rad_dt, t_surf_in, albedo_in, net_sw, lw_down, klcls)
+! surface fluxes, Rayleigh sponge, boundary-layer diffusivities, implicit vertical diffusion with the mixed-layer surface
+! (idealized_moist_phys.F90:1077-1340), continuing with the tendencies accumulated so far
+real, dimension(is:ie,js:je,num_levels), intent(in) :: conv_dt, conv_dq, rad_dt
+real, dimension(is:ie,js:je), intent(in) :: t_surf_in, albedo_in, net_sw, lw_down
+integer, dimension(is:ie,js:je), intent(in) :: klcls
+real, dimension(is:ie,js:je) :: t_surf, q_surf, u_surf, v_surf, rough, gust, flux_t, flux_q, flux_r, flux_u, flux_v, drag_m, drag_t, &
+     drag_q, w_atm, ustar, bstar, qstar, dhdt_surf, dedt_surf, dedq_surf, drdt_surf, dhdt_atm, dedq_atm, dtaudu_atm, dtaudv_atm, &
+     ex_del_m, ex_del_h, ex_del_q, temp_2m, u_10m, v_10m, q_2m, rh_2m, bucket_depth, depth_change_lh, depth_change_conv, &
+     depth_change_cond, z_pbl, fracland, albedo
+logical, dimension(is:ie,js:je) :: land, avail, convect
+real, dimension(is:ie,js:je,num_levels) :: tdtlw, diff_t, diff_m, diss_heat
+type(surf_diff_type) :: Tri_surf
+integer :: n
+n = num_levels
+dt_ug = 0.; dt_vg = 0.; dt_tracers = 0.
+dt_tg = conv_dt/delta_t + rad_dt
+dt_tracers(:,:,:,nhum) = conv_dq/delta_t
+t_surf = t_surf_in; albedo = albedo_in
+q_surf = 0.; u_surf = 0.; v_surf = 0.; rough = 3.21e-05; gust = 1.0
+land = .false.; avail = .true.; bucket_depth = 0.; depth_change_lh = 0.; depth_change_conv = 0.; depth_change_cond = 0.
+call surface_flux(tg(:,:,n,previous), grid_tracers(:,:,n,previous,nhum), ug(:,:,n,previous), vg(:,:,n,previous), &
+     p_full(:,:,n,current), z_full(:,:,n,current), p_half(:,:,n+1,current), t_surf, t_surf, q_surf, .false., bucket_depth, 0.15, &
+     depth_change_lh, depth_change_conv, depth_change_cond, u_surf, v_surf, rough, rough, rough, rough, gust, &
+     flux_t, flux_q, flux_r, flux_u, flux_v, drag_m, drag_t, drag_q, w_atm, ustar, bstar, qstar, dhdt_surf, dedt_surf, dedq_surf, &
+     drdt_surf, dhdt_atm, dedq_atm, dtaudu_atm, dtaudv_atm, ex_del_m, ex_del_h, ex_del_q, temp_2m, u_10m, v_10m, q_2m, rh_2m, &
+     delta_t, land, .not.land, avail)
+call dump2('k_sf_flux_t.bin', flux_t); call dump2('k_sf_flux_q.bin', flux_q); call dump2('k_sf_flux_r.bin', flux_r)
+call dump2('k_sf_flux_u.bin', flux_u); call dump2('k_sf_flux_v.bin', flux_v)
+call dump2('k_sf_drag_m.bin', drag_m); call dump2('k_sf_drag_t.bin', drag_t); call dump2('k_sf_drag_q.bin', drag_q)
+call dump2('k_sf_w_atm.bin', w_atm); call dump2('k_sf_ustar.bin', ustar); call dump2('k_sf_bstar.bin', bstar); call dump2('k_sf_qstar.bin', qstar)
+call dump2('k_sf_dhdt_surf.bin', dhdt_surf); call dump2('k_sf_dedt_surf.bin', dedt_surf); call dump2('k_sf_dedq_surf.bin', dedq_surf)
+call dump2('k_sf_drdt_surf.bin', drdt_surf); call dump2('k_sf_dhdt_atm.bin', dhdt_atm); call dump2('k_sf_dedq_atm.bin', dedq_atm)
+call dump2('k_sf_dtaudu_atm.bin', dtaudu_atm); call dump2('k_sf_dtaudv_atm.bin', dtaudv_atm); call dump2('k_sf_q_surf.bin', q_surf)
+! --- Rayleigh sponge (damping_driver :1228-1237)
+z_pbl = 0.
+call damping_driver(is, js, rad_lat_2d, Time+Time_step, delta_t, p_full(:,:,:,current), p_half(:,:,:,current), &
+     z_full(:,:,:,current), z_half(:,:,:,current), ug(:,:,:,previous), vg(:,:,:,previous), tg(:,:,:,previous), &
+     grid_tracers(:,:,:,previous,nhum), grid_tracers(:,:,:,previous,:), dt_ug, dt_vg, dt_tg, dt_tracers(:,:,:,nhum), dt_tracers, z_pbl)
+call dump3('k_damp_dt_u.bin', dt_ug); call dump3('k_damp_dt_v.bin', dt_vg); call dump3('k_damp_dt_t.bin', dt_tg)
+! --- boundary-layer diffusivities (vert_turb_driver :1242-1262)
+tdtlw = 0.; fracland = 0.; convect = .false.
+call vert_turb_driver(1, 1, Time, Time+Time_step, delta_t, tdtlw, fracland, p_half(:,:,:,current), p_full(:,:,:,current), &
+     z_half(:,:,:,current), z_full(:,:,:,current), ustar, bstar, qstar, rough, rad_lat_2d, convect, &
+     ug(:,:,:,current), vg(:,:,:,current), tg(:,:,:,current), grid_tracers(:,:,:,current,nhum), grid_tracers(:,:,:,current,:), &
+     ug(:,:,:,previous), vg(:,:,:,previous), tg(:,:,:,previous), grid_tracers(:,:,:,previous,nhum), grid_tracers(:,:,:,previous,:), &
+     dt_ug, dt_vg, dt_tg, dt_tracers(:,:,:,nhum), dt_tracers, klcls, .false., diff_t, diff_m, gust, z_pbl)
+call dump3('k_turb_diff_t.bin', diff_t); call dump3('k_turb_diff_m.bin', diff_m); call dump2('k_turb_gust.bin', gust); call dump2('k_turb_z_pbl.bin', z_pbl)
+! --- implicit vertical diffusion, downward sweep / mixed layer / upward sweep (:1292-1330)
+allocate(Tri_surf%dtmass(is:ie,js:je), Tri_surf%dflux_t(is:ie,js:je), Tri_surf%delta_t(is:ie,js:je), Tri_surf%delta_u(is:ie,js:je), &
+         Tri_surf%delta_v(is:ie,js:je), Tri_surf%sst_miz(is:ie,js:je), Tri_surf%dflux_tr(is:ie,js:je,num_tracers), &
+         Tri_surf%delta_tr(is:ie,js:je,num_tracers))
+Tri_surf%dtmass = 0.; Tri_surf%dflux_t = 0.; Tri_surf%delta_t = 0.; Tri_surf%delta_u = 0.; Tri_surf%delta_v = 0.
+Tri_surf%sst_miz = 0.; Tri_surf%dflux_tr = 0.; Tri_surf%delta_tr = 0.
+call gcm_vert_diff_down(1, 1, delta_t, ug(:,:,:,previous), vg(:,:,:,previous), tg(:,:,:,previous), grid_tracers(:,:,:,previous,nhum), &
+     grid_tracers(:,:,:,previous,:), diff_m, diff_t, p_half(:,:,:,current), p_full(:,:,:,current), z_full(:,:,:,current), &
+     flux_u, flux_v, dtaudu_atm, dtaudv_atm, dt_ug, dt_vg, dt_tg, dt_tracers(:,:,:,nhum), dt_tracers, diss_heat, Tri_surf)
+call dump2('k_vd_dtmass.bin', Tri_surf%dtmass); call dump2('k_vd_dflux_t.bin', Tri_surf%dflux_t); call dump2('k_vd_delta_t.bin', Tri_surf%delta_t)
+call dump2('k_vd_delta_q.bin', Tri_surf%delta_tr(:,:,nhum)); call dump2('k_vd_dflux_q.bin', Tri_surf%dflux_tr(:,:,nhum))
+call dump3('k_vd_down_dt_u.bin', dt_ug); call dump3('k_vd_down_dt_t.bin', dt_tg); call dump3('k_vd_diss_heat.bin', diss_heat)
+call mixed_layer(Time, Time+Time_step, js, je, t_surf, flux_t, flux_q, flux_r, dt_real, net_sw, lw_down, Tri_surf, &
+     dhdt_surf, dedt_surf, dedq_surf, drdt_surf, dhdt_atm, dedq_atm, albedo)
+call dump2('k_ml_t_surf.bin', t_surf); call dump2('k_ml_delta_t.bin', Tri_surf%delta_t); call dump2('k_ml_delta_q.bin', Tri_surf%delta_tr(:,:,nhum))
+call gcm_vert_diff_up(1, 1, delta_t, Tri_surf, dt_tg, dt_tracers(:,:,:,nhum), dt_tracers)
+call dump3('k_fin_dt_u.bin', dt_ug); call dump3('k_fin_dt_v.bin', dt_vg); call dump3('k_fin_dt_t.bin', dt_tg)
+call dump3('k_fin_dt_q.bin', dt_tracers(:,:,:,nhum))
+end subroutine run_kernels_surface
 
 !--------------------------------------------------------------------------------------------------
 subroutine one_step(dump_phys)
