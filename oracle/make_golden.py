@@ -128,7 +128,7 @@ def moist_input_nml(res):
 """
 
 
-def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=()):
+def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run"):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
     open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res))
@@ -136,7 +136,7 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=()):
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     fmt = lambda t: ", ".join(str(s) for s in t) if t else "-1"
     open(os.path.join(d, "harness.nml"), "w").write(
-        f" &harness_nml\n   mode = 'run', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
+        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
 
 
 def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra=""):
@@ -238,6 +238,41 @@ def golden_kernels(res, L, seed):
     return {**{k: v for k, v in inp.items()}, **out, **{"meta_" + k: np.array(v) for k, v in meta.items()}}
 
 
+def golden_moist_kernels(res="T21", L=25, nsteps=2400, dt=720, stride=13):
+    """Column routines of the Frierson physics chain on a spun-up moist state (harness mode 'kernels' after `nsteps` steps
+    of the reference moist model): inputs and outputs of every routine, kept for every `stride`-th column as [lev][col].
+    MOIST_KERNELS_DIR=<dir> reuses an existing harness run directory instead of running the reference again (~2 min)."""
+    lon, lat, nf, ns = RES[res]
+    nc = lon * lat
+    reuse = os.environ.get("MOIST_KERNELS_DIR")
+    tmp = None
+    if reuse:
+        d = reuse
+    else:
+        tmp = tempfile.TemporaryDirectory(prefix="refmk_")
+        d = tmp.name
+        prepare_moist_rundir(d, res, nsteps, dt=dt, mode="kernels")
+        run_harness(d, exe=MOIST_EXE)
+    cols = np.arange(0, nc, stride)
+    shallow = np.flatnonzero(np.fromfile(os.path.join(d, "k_conv_flag.bin")) == 1.0)[:24]       # + some shallow-convection columns
+    cols = np.union1d(cols, shallow)
+    out = {"cols": cols, "meta_res": np.array(res), "meta_num_levels": np.array(L), "meta_dt_atmos": np.array(float(dt)),
+           "meta_nsteps": np.array(nsteps)}
+    for fn in sorted(os.listdir(d)):
+        if not fn.endswith(".bin"):
+            continue
+        raw = np.fromfile(os.path.join(d, fn), dtype=np.float64)
+        name = fn[:-4]
+        if name.startswith("tab_") or raw.size % nc:
+            out[name] = raw
+        else:
+            out[name] = np.ascontiguousarray(raw.reshape(-1, nc)[:, cols]) if raw.size > nc else raw[cols].copy()
+    out["lat_of_col"] = (out["tab_deg_lat"] * np.pi / 180.0)[cols // lon]          # rad_lat as the harness builds it
+    if tmp:
+        tmp.cleanup()
+    return out
+
+
 def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None):
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
         prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps)
@@ -273,6 +308,8 @@ def main():
             "T21", 25, 1440, (1440,),
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_001440$", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
+        # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
+        "moist_kernels_T21L25": golden_moist_kernels,
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

@@ -159,12 +159,19 @@ real, dimension(is:ie,js:je,num_levels) :: tin, qin, es, des, conv_dt, conv_dq, 
 real, dimension(is:ie,js:je) :: rain, snow, cape, cin, invtau_q, invtau_t, net_sw, lw_down, albedo, t_surf
 integer, dimension(is:ie,js:je) :: convflag, klzbs, klcls
 logical, dimension(is:ie,js:je) :: coldT
+integer :: ii
 if(current == previous) then
   delta_t = dt_real
 else
   delta_t = 2*dt_real
 endif
 coldT = .false.
+! the spun-up state convects everywhere: dry out every fourth longitude so that the sample also holds columns without CAPE
+! and shallow ones (the routines are column-local, so this is just another set of columns)
+do ii = is, ie
+  if(mod(ii,4) == 0) grid_tracers(ii,:,:,previous,nhum) = 0.15*grid_tracers(ii,:,:,previous,nhum)
+  if(mod(ii,4) == 2) grid_tracers(ii,:,:,previous,nhum) = 0.55*grid_tracers(ii,:,:,previous,nhum)
+enddo
 tin = tg(:,:,:,previous); qin = grid_tracers(:,:,:,previous,nhum)
 call dump3('k_in_t_prev.bin', tin); call dump3('k_in_q_prev.bin', qin)
 call dump3('k_in_u_prev.bin', ug(:,:,:,previous)); call dump3('k_in_v_prev.bin', vg(:,:,:,previous))
@@ -194,7 +201,7 @@ call dump2('k_cond_rain.bin', rain); call dump3('k_cond_dt.bin', cond_dt); call 
 albedo = 0.31
 call two_stream_gray_rad_down(is, js, Time, rad_lat_2d, rad_lon_2d, p_half(:,:,:,current), tin, net_sw, lw_down, albedo, qin)
 call dump2('k_rad_net_sw_down.bin', net_sw); call dump2('k_rad_lw_down.bin', lw_down)
-t_surf = tin(:,:,num_levels) + 1.5 + 0.5*cos(rad_lon_2d)
+t_surf = tin(:,:,num_levels) + 1.5 + 6.0*cos(rad_lon_2d)      ! warmer and colder than the air: unstable and stable surface layers
 call dump2('k_in_t_surf.bin', t_surf)
 rad_dt = 0.
 call two_stream_gray_rad_up(is, js, Time, rad_lat_2d, p_half(:,:,:,current), t_surf, tin, rad_dt, albedo)
