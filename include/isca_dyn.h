@@ -31,6 +31,29 @@ typedef struct isca_dyn isca_dyn_t;
 
 /* namelist keys used on the path: spectral_dynamics_nml (spectral_dynamics.F90:152-224),
  * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
+#define ISCA_MAX_LEVELS 128
+
+/* Parameters of the moist physics package, physics = 1: idealized_moist_phys with the options of the Frierson grey-radiation
+ * aquaplanet (exp/test_cases/frierson/frierson_test_case.py:49-170): SIMPLE_BETTS_MILLER convection, lscale_cond,
+ * two_stream_gray_rad 'frierson' without seasonal cycle, surface_flux over a mixed-layer ocean, Rayleigh sponge,
+ * diffusivity boundary layer, implicit vertical diffusion; do_simple everywhere, no virtual temperature, no land.
+ * Field names are the reference's namelist variables; defaults (isca_dyn_config_default) are the module defaults
+ * overridden by the test case's values. */
+typedef struct isca_moist_config {
+  double roughness_mom, roughness_heat, roughness_moist;          /* idealized_moist_phys_nml */
+  double solar_constant, del_sol, del_sw, ir_tau_eq, ir_tau_pole, atm_abs, odp, sw_diff, linear_tau, wv_exponent,
+         solar_exponent;                                          /* two_stream_gray_rad_nml */
+  double depth, tconst, delta_T, albedo_value;                    /* mixed_layer_nml (prescribe_initial_dist) */
+  int evaporation;
+  double tau_bm, rhbm, Tmin, Tmax, val_inc;                       /* qe_moist_convection_nml */
+  int do_rayleigh;                                                /* damping_driver_nml */
+  double trayfric, sponge_pbottom;
+  int damping_conserve_energy;
+  double constant_gust;                                           /* vert_turb_driver_nml */
+  double frac_inner, rich_crit_pbl;                               /* diffusivity_nml */
+  double rich_crit, drag_min;                                     /* monin_obukhov_nml */
+} isca_moist_config;
+
 typedef struct isca_dyn_config {
   int lon_max, lat_max, num_fourier, num_spherical, num_levels;
   int fourier_inc;              /* must be 1 */
@@ -61,6 +84,13 @@ typedef struct isca_dyn_config {
   int device;                   /* HIP device ordinal */
   void *stream;                 /* hipStream_t to run on, or NULL for a private stream */
   int legendre_impl;            /* 0 = MFMA (default), 1 = plain-FMA check kernels */
+  /* physics package called by atmosphere (atmosphere.F90:304-331): 0 = hs_forcing, 1 = idealized_moist_phys (Frierson);
+   * with 1 the grid tracer is specific humidity: it feeds the physics and receives its tendency. */
+  int physics;
+  /* vert_coord_option = 'input' (vert_coordinate_nml): != 0 -> pk_input/bk_input hold num_levels+1 values, top first */
+  int vert_coord_input;
+  double pk_input[ISCA_MAX_LEVELS + 1], bk_input[ISCA_MAX_LEVELS + 1];
+  isca_moist_config moist;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */
@@ -103,7 +133,7 @@ int isca_wavenumber_dealing(int num_fourier, int world_size, int *m_of_slot, int
 /* state access in the reference's layouts.  name is one of:
  *  grid 3-D (lon,lat_local,lev):  "ug","vg","tg","vorg","divg","wg_full","p_full","z_full","tr"
  *  grid 3-D half levels (lev+1):  "p_half","z_half"
- *  grid 2-D:                      "psg"
+ *  grid 2-D:                      "psg"; moist physics: "t_surf" (mixed-layer temperature), "precip" (last step, kg/m2/s)
  *  spectral (m,n,lev) complex:    "vors","divs","ts";  (m,n): "ln_ps"     [global m; local m on world_size>1]
  * time_level: 0 = previous, 1 = current (ignored for single-level fields). */
 int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_level, double *host, size_t count);
@@ -139,6 +169,17 @@ int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double 
 /* hs_forcing(...) on caller-supplied fields (hs_forcing.F90:148): tendencies are accumulated into udt,vdt,tdt */
 int isca_hs_forcing(isca_dyn_t *h, double dt, const double *p_half, const double *p_full, const double *u,
                     const double *v, const double *t, double *udt, double *vdt, double *tdt);
+
+/* idealized_moist_phys(...) on caller-supplied columns (idealized_moist_phys.F90:819-1340, Frierson options; handle created with
+ * physics = 1): ncol independent columns, arrays (col, lev) / (col, lev+1) with col fastest; fields of the previous time level,
+ * pressures of both levels, heights of the current one, as the reference passes them.  t_surf is updated in place (mixed_layer);
+ * gust is the value left by the previous call of vert_turb_driver (1.0 on the first call, then constant_gust).
+ * Returns the tendencies and the rain rate (kg/m2/s; precip may be NULL). */
+int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u_prev,
+                              const double *v_prev, const double *t_prev, const double *q_prev, const double *p_half_prev,
+                              const double *p_full_prev, const double *p_half_cur, const double *p_full_cur, const double *z_half_cur,
+                              const double *z_full_cur, double *t_surf, double *dt_u, double *dt_v, double *dt_t, double *dt_q,
+                              double *precip);
 
 /* --- diagnostics: what spectral_diagnostics sends to diag_manager every step (spectral_dynamics.F90:1705-1867),
  * accumulated on the device for the time means of the diag_table.  Field names as registered by the reference:

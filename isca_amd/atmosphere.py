@@ -21,6 +21,60 @@ _core: dyncore.DynCore | None = None
 _run_dir: str | None = None
 _NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
 
+# ---- moist physics package (atmosphere_nml: idealized_moist_model = .true.; exp/test_cases/frierson/frierson_test_case.py:49-170)
+# namelist variables handed to the C config (group -> {variable: isca_moist_config member})
+_MOIST_KEYS = {
+    "idealized_moist_phys_nml": {"roughness_mom": "roughness_mom", "roughness_heat": "roughness_heat", "roughness_moist": "roughness_moist"},
+    "two_stream_gray_rad_nml": {k: k for k in ("solar_constant", "del_sol", "del_sw", "ir_tau_eq", "ir_tau_pole", "atm_abs", "odp", "sw_diff",
+                                                "linear_tau", "wv_exponent", "solar_exponent")},
+    "mixed_layer_nml": {"depth": "depth", "tconst": "tconst", "delta_t": "delta_T", "albedo_value": "albedo_value", "evaporation": "evaporation"},
+    "qe_moist_convection_nml": {"tau_bm": "tau_bm", "rhbm": "rhbm", "tmin": "Tmin", "tmax": "Tmax", "val_inc": "val_inc"},
+    "damping_driver_nml": {"do_rayleigh": "do_rayleigh", "trayfric": "trayfric", "sponge_pbottom": "sponge_pbottom",
+                           "do_conserve_energy": "damping_conserve_energy"},
+    "vert_turb_driver_nml": {"constant_gust": "constant_gust"},
+    "diffusivity_nml": {"frac_inner": "frac_inner", "rich_crit_pbl": "rich_crit_pbl"},
+    "monin_obukhov_nml": {"rich_crit": "rich_crit", "drag_min": "drag_min"},
+}
+# options the device package implements in exactly one way: any other value is refused, as an unsupported option
+_MOIST_FIXED = {
+    "idealized_moist_phys_nml": {"two_stream_gray": True, "convection_scheme": "SIMPLE_BETTS_MILLER", "do_damping": True, "turb": True,
+                                 "mixed_layer_bc": True, "do_virtual": False, "do_simple": True, "do_rrtm_radiation": False,
+                                 "do_socrates_radiation": False, "do_cloud_simple": False, "bucket": False, "gp_surface": False,
+                                 "do_lcl_diffusivity_depth": False, "land_option": "none"},
+    "two_stream_gray_rad_nml": {"rad_scheme": "frierson", "do_seasonal": False},
+    "mixed_layer_nml": {"prescribe_initial_dist": True, "do_qflux": False, "do_sc_sst": False, "do_ape_sst": False,
+                        "update_albedo_from_ice": False},
+    "vert_turb_driver_nml": {"do_mellor_yamada": False, "do_diffusivity": True, "do_simple": True, "use_tau": False, "gust_scheme": "constant",
+                             "do_shallow_conv": False, "do_molecular_diffusion": False},
+    "diffusivity_nml": {"do_entrain": False, "do_simple": True, "fixed_depth": False, "free_atm_diff": False, "pbl_mcm": False},
+    "surface_flux_nml": {"use_virtual_temp": False, "do_simple": True, "old_dtaudv": True},
+    "lscale_cond_nml": {"do_simple": True, "do_evap": True},
+    "sat_vapor_pres_nml": {"do_simple": True},
+    "monin_obukhov_nml": {"neutral": False, "stable_option": 1},
+    "damping_driver_nml": {"do_cg_drag": False, "do_mg_drag": False, "do_topo_drag": False},
+}
+
+
+def _moist_config(namelist: dict) -> dict:
+    """idealized_moist_phys_init and friends: collect the namelist variables of the moist package, refuse what is not implemented."""
+    mo: dict = {}
+    for grp, fixed in _MOIST_FIXED.items():
+        for k, v in (namelist.get(grp) or {}).items():
+            k = k.lower()
+            if k in fixed:
+                want = fixed[k]
+                same = str(v).lower() == str(want).lower() if isinstance(want, str) else (bool(v) == want if isinstance(want, bool) else v == want)
+                if not same:
+                    raise IscaError(f'{grp}: "{v}" is not a supported value for {k} (only "{want}")')
+    for grp, keys in _MOIST_KEYS.items():
+        for k, v in (namelist.get(grp) or {}).items():
+            k = k.lower()
+            if k in keys:
+                mo[keys[k]] = int(v) if isinstance(v, bool) else v
+            elif k not in _MOIST_FIXED.get(grp, {}) and grp != "idealized_moist_phys_nml":
+                raise IscaError(f"{grp}: {k} is not supported by the device physics package")
+    return mo
+
 
 def parse_namelist(text: str) -> dict:
     """Minimal reader of the reference's input.nml format (&group key = value, ... /)."""
@@ -74,7 +128,25 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     if isinstance(namelist, str):
         namelist = parse_namelist(namelist)
     kw: dict = {}
-    unsupported = {"vert_coord_option": "uneven_sigma", "damping_option": "resolution_dependent",
+    namelist = {g.lower(): v for g, v in (namelist or {}).items()}
+    moist = bool(namelist.get("atmosphere_nml", {}).get("idealized_moist_model", False))
+    vc = namelist.get("vert_coordinate_nml")
+    vco = str(namelist.get("spectral_dynamics_nml", {}).get("vert_coord_option", "uneven_sigma")).lower()
+    if vco == "input":
+        if not vc or "bk" not in vc:
+            raise IscaError("vert_coord_option = 'input' needs vert_coordinate_nml with bk (and pk)")
+        bk = list(vc["bk"])
+        kw["bk_input"] = bk
+        kw["pk_input"] = list(vc.get("pk", [0.0] * len(bk)))
+        if len(kw["pk_input"]) != len(bk):
+            raise IscaError("vert_coordinate_nml: pk and bk must have the same length")
+        nl = namelist.get("spectral_dynamics_nml", {}).get("num_levels", len(bk) - 1)
+        if len(bk) != nl + 1:
+            raise IscaError("vert_coordinate_nml: bk must hold num_levels+1 values")
+    if moist:
+        kw["physics"] = 1
+        kw["moist"] = _moist_config(namelist)
+    unsupported = {"vert_coord_option": vco if vco == "input" else "uneven_sigma", "damping_option": "resolution_dependent",
                    "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
                    "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}

@@ -1,5 +1,6 @@
 // C-ABI of the MI355X spectral core (see include/isca_dyn.h for the reference interfaces replaced).
 #include "kernels.h"
+#include "moist.h"
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -94,6 +95,16 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->t_zero = 315.; c->t_strat = 200.; c->delh = 60.; c->delv = 10.; c->eps = 0.; c->sigma_b = 0.7;
   c->ka = -40.; c->ks = -4.; c->kf = -1.; c->do_conserve_energy = 1; c->trflux = 1.e-5; c->trsink = -4.; c->P00 = 1.e5;
   c->rank = 0; c->world_size = 1; c->device = 0; c->stream = nullptr; c->legendre_impl = 0;
+  // moist package (physics = 1): module defaults overridden by frierson_test_case.py:49-170
+  c->physics = 0; c->vert_coord_input = 0;
+  isca_moist_config &m = c->moist;
+  m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
+  m.solar_constant = 1360.0; m.del_sol = 1.4; m.del_sw = 0.0; m.ir_tau_eq = 6.0; m.ir_tau_pole = 1.5; m.atm_abs = 0.2; m.odp = 1.0;
+  m.sw_diff = 0.0; m.linear_tau = 0.1; m.wv_exponent = 4.0; m.solar_exponent = 4.0;
+  m.depth = 2.5; m.tconst = 285.; m.delta_T = 40.; m.albedo_value = 0.31; m.evaporation = 1;
+  m.tau_bm = 7200.; m.rhbm = 0.7; m.Tmin = 160.; m.Tmax = 350.; m.val_inc = 0.01;
+  m.do_rayleigh = 1; m.trayfric = -0.25; m.sponge_pbottom = 5000.; m.damping_conserve_energy = 1;
+  m.constant_gust = 0.0; m.frac_inner = 0.1; m.rich_crit_pbl = 1.0; m.rich_crit = 2.0; m.drag_min = 1.e-05;
   return 0;
 }
 
@@ -136,6 +147,25 @@ static void check_config(const isca_dyn_config &c) {
   if (c.lat_max % c.world_size) fail("lat_max must be divisible by world_size (spec_mpp.F90:69-75)");
   if (((c.lat_max / c.world_size) * c.lon_max) % 64) fail("local columns must be a multiple of 64");
   if (c.dt_atmos <= 0) fail("dt_atmos has not been specified");
+  if (c.num_levels > ISCA_MAX_LEVELS) fail("num_levels exceeds ISCA_MAX_LEVELS");
+  if (c.vert_coord_input) {
+    for (int k = 0; k < c.num_levels; ++k)
+      if (!(c.pk_input[k + 1] + c.bk_input[k + 1] * c.reference_sea_level_press > c.pk_input[k] + c.bk_input[k] * c.reference_sea_level_press))
+        fail("vert_coordinate_nml: pk/bk must give increasing half-level pressures");
+    for (int k = 0; k <= c.num_levels; ++k)
+      if (c.pk_input[k] != 0.0) fail("vert_coord_option = 'input': only pure sigma levels (pk = 0) are supported");
+  }
+  if (c.physics != 0 && c.physics != 1) fail("physics must be 0 (hs_forcing) or 1 (idealized_moist_phys)");
+  if (c.physics == 1) {
+    if (c.num_tracers < 1) fail("idealized_moist_phys needs the sphum tracer (num_tracers >= 1)");
+    if (c.num_levels < 3 || c.num_levels > 62) fail("idealized_moist_phys: num_levels must be in 3..62");
+    const isca_moist_config &m = c.moist;
+    if (m.frac_inner <= 0. || m.frac_inner >= 1.) fail("diffusivity_init: frac_inner must be between 0 and 1");
+    if (m.rich_crit_pbl < 0.) fail("diffusivity_init: rich_crit_pbl must be greater than or equal to zero");
+    if (m.rich_crit <= 0.25) fail("monin_obukhov_init: rich_crit must be greater than 0.25");
+    if (m.drag_min < 0.0) fail("monin_obukhov_init: drag_min must be >= 0.0");
+    if (m.depth <= 0. || m.Tmin >= m.Tmax || m.val_inc <= 0.) fail("invalid moist physics parameters");
+  }
 }
 
 static void build_field_lists(isca_dyn *h) {
@@ -168,6 +198,7 @@ extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   timer_collect(h);
   if (h->comm) { hipStreamSynchronize(h->stream); delete h->comm; h->comm = nullptr; }
   for (void *p : h->allocs) hipFree(p);
+  moist_destroy(h->moist);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -378,6 +409,14 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     for (double v : T.pk) if (v != 0.0) pure_sigma = false;
     h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.Jl >= 4) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
     if (g.P > 1) h->tracer_serial = true;     // sharded: the halo exchange sits between the column kernel and the tracer
+    if (cfg->physics == 1) {                  // idealized_moist_phys_init: tables, surface state, tendency arrays
+      if (!h->tracer_on) fail("idealized_moist_phys: the specific-humidity grid tracer is not available in this configuration");
+      h->moist = moist_create(h->cfg, T);
+      d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3); d.ph_dtq = dalloc<double>(h, ng3);
+      d.t_surf = dalloc<double>(h, ng2); d.precip = dalloc<double>(h, ng2);
+      d.moist_work = dalloc<double>(h, moist_work_doubles(g));
+      HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
+    }
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
@@ -526,8 +565,9 @@ static void cold_start_single(isca_dyn *h) {
   h2d(h, d.tr[0], tr.data(), ng3); h2d(h, d.tr[1], tr.data(), ng3);
   h2d(h, d.tr_atm[0], tr.data(), ng3); h2d(h, d.tr_atm[1], tr.data(), ng3);
   HIP_CHECK(hipMemsetAsync(d.wg_full, 0, ng3 * sizeof(double), h->stream));
+  if (h->cfg.physics == 1) launch_t_surf_init(*h, h->stream);       // mixed_layer_init, prescribe_initial_dist
   HIP_CHECK(hipStreamSynchronize(h->stream));
-  h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true;
+  h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true; h->phys_calls = 0;
 }
 
 static const char *GRID3[] = {"ug", "vg", "tg", "tr"};
@@ -548,6 +588,14 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
   if (name == "vorg") { count = ng3; return d.vorg; }
   if (name == "divg") { count = ng3; return d.divg; }
   if (name == "wg_full") { count = ng3; return d.wg_full; }
+  if (name == "t_surf" || name == "precip") {
+    if (h->cfg.physics != 1) fail("get/set_state: " + name + " exists only with the moist physics package");
+    count = ng2; return name == "t_surf" ? d.t_surf : d.precip;
+  }
+  if (name == "dt_ug" || name == "dt_vg" || name == "dt_tg" || name == "dt_sphum") {     // physics tendencies of the last step
+    if (h->cfg.physics != 1) fail("get/set_state: " + name + " exists only with the moist physics package");
+    count = ng3; return name == "dt_ug" ? d.ph_dtu : name == "dt_vg" ? d.ph_dtv : name == "dt_tg" ? d.ph_dtT : d.ph_dtq;
+  }
   if (name == "dxT") { count = ng3; return d.dxT; }
   if (name == "dyT") { count = ng3; return d.dyT; }
   if (name == "dxlp") { count = ng2; return d.dxlp; }
@@ -655,6 +703,7 @@ extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int curre
   if (previous < 0 || previous > 1 || current < 0 || current > 1) fail("set_time_pointers: time levels are 0 or 1");
   if (step_count < 0) fail("set_time_pointers: negative step count");
   h->previous = previous; h->current = current; h->step_count = step_count;
+  h->phys_calls = 0;         // idealized_moist_phys_init sets gust = 1 again after a restart
   API_END
 }
 // ... then rebuild what the step keeps between calls but the restart file does not hold.
@@ -679,6 +728,10 @@ static StepScalars step_scalars(isca_dyn *h) {
   return sc;
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
+  if (h->cfg.physics == 1) {
+    Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream);
+    h->phys_calls++;
+  }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
     if (h->g.P > 1) {
@@ -1099,6 +1152,29 @@ struct DevTmp {      // short-lived device buffers of one host-synchronous call
   ~DevTmp() { hipStreamSynchronize(h->stream); for (double *p : v) hipFree(p); }
 };
 }  // namespace
+
+// idealized_moist_phys on caller columns: host arrays [lev][ncol] (Fortran (col, lev)), half levels [lev+1][ncol]
+extern "C" int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u_prev,
+                                         const double *v_prev, const double *t_prev, const double *q_prev, const double *p_half_prev,
+                                         const double *p_full_prev, const double *p_half_cur, const double *p_full_cur,
+                                         const double *z_half_cur, const double *z_full_cur, double *t_surf, double *dt_u, double *dt_v,
+                                         double *dt_t, double *dt_q, double *precip) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  if (h->cfg.physics != 1) fail("idealized_moist_phys: the handle was not created with physics = 1");
+  if (ncol <= 0) fail("idealized_moist_phys: ncol must be positive");
+  const int L = h->g.L;
+  const size_t nf = (size_t)ncol * L, nh = (size_t)ncol * (L + 1);
+  DevTmp tmp(h);
+  const double *u = tmp.up(u_prev, nf), *v = tmp.up(v_prev, nf), *t = tmp.up(t_prev, nf), *q = tmp.up(q_prev, nf), *php = tmp.up(p_half_prev, nh),
+               *pfp = tmp.up(p_full_prev, nf), *phc = tmp.up(p_half_cur, nh), *pfc = tmp.up(p_full_cur, nf), *zhc = tmp.up(z_half_cur, nh),
+               *zfc = tmp.up(z_full_cur, nf), *lat = tmp.up(rad_lat, ncol);
+  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol);
+  launch_moist_physics_on(*h, ncol, delta_t, gust, lat, u, v, t, q, php, pfp, phc, pfc, zhc, zfc, ts, du, dv, dt, dq, pr, h->stream);
+  d2h(h, t_surf, ts, ncol); d2h(h, dt_u, du, nf); d2h(h, dt_v, dv, nf); d2h(h, dt_t, dt, nf); d2h(h, dt_q, dq, nf);
+  if (precip) d2h(h, precip, pr, ncol);
+  API_END
+}
 
 // spherical.F90:354-406 compute_laplacian(spherical [, power])
 extern "C" int isca_compute_laplacian(isca_dyn_t *h, const double *spherical, double *laplacian, int nlev, int power) {

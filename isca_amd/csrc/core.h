@@ -8,6 +8,7 @@
 #include "comm.h"
 
 namespace isca {
+struct MoistState;
 
 #define HIP_CHECK(expr)                                                                              \
   do {                                                                                               \
@@ -83,6 +84,10 @@ struct Dev {
   double *partials;                                 // block partial sums
   double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18]
   double *scratch_g[4], *scratch_s[4];              // API transforms
+  // ---- moist physics package (physics = 1)
+  double *ph_dtu = nullptr, *ph_dtv = nullptr, *ph_dtT = nullptr, *ph_dtq = nullptr;   // tendencies returned by idealized_moist_phys
+  double *t_surf = nullptr, *precip = nullptr;      // [Jl][I] mixed-layer temperature; rain rate of the last step
+  double *moist_work = nullptr;                     // p_full/p_half/z_full/z_half of both time levels
 };
 
 struct KernelTimer {
@@ -124,5 +129,7 @@ struct isca_dyn {
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
   unsigned diag_mask = 0;           // spectral_diagnostics fields being accumulated (bit = index in DIAG_NAMES)
   long diag_count = 0;              // send_data calls since the last reset
+  isca::MoistState *moist = nullptr;   // tables of the moist physics package (physics = 1)
+  long phys_calls = 0;              // calls of the physics since create / restart (gust is 1 m/s on the first)
   isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
 };

@@ -1138,6 +1138,7 @@ struct ColumnArgs {
   const double *vor, *div, *dxT, *dyT, *dxlp, *dylp;
   double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg, *psp_copy;
   int *kmask; double water_limit;
+  const double *phu, *phv, *pht;           // tendencies of the physics package when it is not hs_forcing (k_column<CH, true>)
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1170,7 +1171,7 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
 // everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
-template <int CH>
+template <int CH, bool EXT>
 __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
@@ -1274,11 +1275,15 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q];
       const double voi = EARLY ? vov[EARLY ? i : 0] : a.vor[q], dxti = EARLY ? dxv[EARLY ? i : 0] : a.dxT[q], dyti = EARLY ? dyv[EARLY ? i : 0] : a.dyT[q];
       const double p_full = exp(l_f);
+      double dt_u, dt_v, dt_t;
+      if (EXT) {   // physics tendencies computed beforehand (idealized_moist_phys, atmosphere.F90:304-317)
+        dt_u = a.phu[q]; dt_v = a.phv[q]; dt_t = a.pht[q];
+      } else {
       // ---- hs_forcing at the previous level (rayleigh :615-679, dissipative heating :198-200, newtonian :508-611)
       const double sigma = p_full * rps;
       const bool bl = (sigma <= 1.0) && (sigma > a.sigma_b);
       const double vfactr = bl ? vcoeff * (sigma - a.sigma_b) : 0.0;
-      double dt_u = vfactr * upi, dt_v = vfactr * vpi, dt_t = 0.0;
+      dt_u = vfactr * upi; dt_v = vfactr * vpi; dt_t = 0.0;
       if (a.do_conserve_energy) dt_t = -((upi + .5 * dt_u * a.delta_t) * dt_u + (vpi + .5 * dt_v * a.delta_t) * dt_v) / CP_AIR;
       {
         const double lpn = l_f - lnP00;                       // log(p_full/P00)
@@ -1286,6 +1291,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
         const double teq = fmax(the * exp(KAPPA * lpn), tstr);   // (p/P00)**kappa
         const double tdamp = bl ? a.tka + cos4 * (tcoeff * (sigma - a.sigma_b)) : a.tka;
         dt_t = dt_t + (-tdamp * (tpi - teq));
+      }
       }
       {  // initialize_corrections (:1318-1321)
         const double ue = upi + dt_u * a.delta_t, ve = vpi + dt_v * a.delta_t;
@@ -1387,11 +1393,12 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
   a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
+  a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT;
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
-#define LC(N) hipLaunchKernelGGL(k_column<N>, grid, block, lds, s, g, a)
+#define LC(N) do { if (h.cfg.physics == 1) hipLaunchKernelGGL((k_column<N, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false>), grid, block, lds, s, g, a); } while (0)
   switch (CH) {
     case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
@@ -1945,6 +1952,9 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
   a.robert = h.cfg.robert_coeff;
+  if (h.cfg.physics == 1) {     // sphum: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
+    a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0;
+  }
   a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + (size_t)3 * h.g.L * 2 * h.g.I;
   a.send_lo = d.halo_send; a.send_hi = d.halo_send + (size_t)3 * h.g.L * 2 * h.g.I;
   return a;

@@ -1,0 +1,219 @@
+// Moist physics package on the device: idealized_moist_phys (atmos_spectral/driver/solo/idealized_moist_phys.F90:819-1340)
+// with the Frierson grey-radiation aquaplanet options, one thread per column, levels strided by the column count
+// (consecutive lanes = consecutive longitudes: every level access of a wavefront is one coalesced row segment).
+// The column routines themselves are in moist_physics.h (shared with the host build the CPU tests check against the
+// reference); this file holds the driver kernel in the reference's call order, the table upload and the launchers.
+#include "core.h"
+#include "kernels.h"
+#include "moist.h"
+#include "moist_tables.h"
+
+namespace isca {
+
+struct MoistArgs {
+  int ncol, L, I;                       // columns, levels, columns per latitude row (for rad_lat_row)
+  const double *up, *vp, *tp, *qp;      // previous time level [L][ncol]
+  const double *pf_p, *ph_p;            // pressures of the previous level (convection, condensation)
+  const double *pf_c, *ph_c, *zf_c, *zh_c;   // pressures and heights of the current level (everything else)
+  const double *rad_lat_row, *rad_lat_col;   // latitude by row (grid) or by column (caller fields)
+  double *t_surf;                       // mixed-layer temperature, updated
+  double *dtu, *dtv, *dtT, *dtq;        // tendencies out
+  double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
+  double delta_t, dt_atmos, gust, albedo;
+  double rough_mom, rough_heat, rough_moist;
+  moist::SatTable sat;
+  moist::QeParams qe;
+  moist::GrayRadParams rad;
+  moist::MoParams mo;
+  moist::RayleighParams ray;
+  moist::DiffusivityParams dif;
+  moist::MixedLayerParams ml;
+  int do_damping;
+};
+
+template <int LMAX>
+__global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= a.ncol) return;
+  const int L = a.L, s = a.ncol;
+  const size_t c = (size_t)col;
+  const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
+  double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
+  const double delta_t = a.delta_t;
+  // ---- convection (:862-880): deltas over the step, then rates
+  double rain, cape, cin;
+  int flag, klzb, klcl;
+  moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
+                                   nullptr, nullptr, s);
+  double precip = rain / delta_t;
+  // ---- large-scale condensation on the convectively adjusted profile (:975-997)
+  {
+    double tt[LMAX], qq[LMAX], td[LMAX], qd[LMAX];
+    for (int k = 0; k < L; ++k) { tt[k] = dtT[k * s] + tp[k * s]; qq[k] = dtq[k * s] + qp[k * s]; }
+    double rain_ls;
+    moist::lscale_cond<LMAX>(a.sat, L, tt, qq, 1, a.pf_p + c, a.ph_p + c, s, td, qd, 1, rain_ls);
+    for (int k = 0; k < L; ++k) {
+      dtT[k * s] = dtT[k * s] / delta_t + td[k] / delta_t;       // dt_tg = (0 + conv_dt_tg) + cond_dt_tg
+      dtq[k * s] = dtq[k * s] / delta_t + qd[k] / delta_t;
+      dtu[k * s] = 0.0; dtv[k * s] = 0.0;
+    }
+    precip = precip + rain_ls / delta_t;
+  }
+  if (a.precip) a.precip[c] = precip;
+  // ---- grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162)
+  const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
+  double t_surf = a.t_surf[c];
+  double net_sw, lw_down_surf;
+  moist::SurfFlux sf;
+  {
+    double lw_down[LMAX + 1], lw_dtrans[LMAX];
+    double insolation, sw_tau_0;
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, lw_down, lw_dtrans, insolation, sw_tau_0, net_sw, lw_down_surf);
+    const size_t low = (size_t)(L - 1) * s;
+    moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
+                        a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, lw_down, lw_dtrans, insolation, sw_tau_0, dtT, s);
+  }
+  // ---- Rayleigh sponge (:1228-1237)
+  if (a.do_damping) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, dtT, s);
+  // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
+  {
+    double k_m[LMAX], k_t[LMAX], h;
+    moist::pbl_diffusivity<LMAX>(a.mo, a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s, sf.u_star, sf.b_star, h,
+                                 k_m, k_t, 1);
+    moist::VdiffWork<LMAX> w;
+    moist::VdiffSurf S;
+    double tau_u = sf.flux_u, tau_v = sf.flux_v;
+    moist::vert_diff_down<LMAX>(L, delta_t, up, vp, tp, qp, s, k_m, k_t, 1, a.ph_c + c, a.pf_c + c, a.zf_c + c, s, tau_u, tau_v, sf.dtaudu_atm,
+                                sf.dtaudv_atm, dtu, dtv, dtT, dtq, s, nullptr, 0, w, S);
+    moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
+                       sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
+    moist::vert_diff_up<LMAX>(L, delta_t, w, S, dtT, dtq, s);
+  }
+  a.t_surf[c] = t_surf;
+}
+
+// mixed_layer_init with prescribe_initial_dist (mixed_layer.F90:455-460): t_surf = tconst - delta_T (3 sin^2 lat - 1)/3
+__global__ void k_t_surf_init(int ncol, int I, const double *__restrict__ rad_lat_row, double tconst, double delta_T, double *t_surf) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  const double sl = sin(rad_lat_row[col / I]);
+  t_surf[col] = tconst - delta_T * ((3. * (sl * sl)) - 1.) / 3.;
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+struct MoistState {
+  moist::SatTableHost sat;
+  moist::QeTablesHost qe;
+  double *d_sat[3] = {nullptr, nullptr, nullptr}, *d_lcl = nullptr;
+  moist::SatTable sat_dev;
+  moist::QeParams qe_dev;
+  moist::RayleighParams ray;
+};
+
+static void *dev_upload(const std::vector<double> &v) {
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, v.size() * sizeof(double)));
+  HIP_CHECK(hipMemcpy(p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+  return p;
+}
+
+MoistState *moist_create(const isca_dyn_config &cfg, const Tables &tab) {
+  MoistState *m = new MoistState();
+  const isca_moist_config &mc = cfg.moist;
+  m->sat.build();                                          // sat_vapor_pres_init, do_simple
+  m->qe.build(m->sat.view(), mc.rhbm, mc.Tmin, mc.Tmax, mc.tau_bm, mc.val_inc);
+  m->d_sat[0] = (double *)dev_upload(m->sat.tab); m->d_sat[1] = (double *)dev_upload(m->sat.dtab); m->d_sat[2] = (double *)dev_upload(m->sat.d2tab);
+  m->d_lcl = (double *)dev_upload(m->qe.lcl);
+  m->sat_dev = m->sat.view();
+  m->sat_dev.tab = m->d_sat[0]; m->sat_dev.dtab = m->d_sat[1]; m->sat_dev.d2tab = m->d_sat[2];
+  m->qe_dev = m->qe.params;
+  m->qe_dev.lcl_temp_table = m->d_lcl;
+  // damping_driver_init (damping_driver.f90:411-420) with the reference pressures of idealized_moist_phys_init (:620-629)
+  const int L = cfg.num_levels;
+  std::vector<double> lph, lpf;
+  pressure_variables_1d(tab.pk, tab.bk, moist::PSTD_MKS, lph, lpf);
+  int best = 0;
+  double bestv = INFINITY;
+  for (int k = 0; k <= L; ++k) {
+    const double pref = (k < L) ? std::exp(lpf[k]) : moist::PSTD_MKS;
+    const double v = std::fabs(pref - 2 * mc.sponge_pbottom);
+    if (v < bestv) { bestv = v; best = k; }
+  }
+  m->ray.nlev_rayfric = std::min(best + 1, L);
+  m->ray.rfactr = (mc.trayfric > 0.0) ? (1. / mc.trayfric) : (1. / std::fabs(mc.trayfric)) * (1. / 86400.);
+  m->ray.sponge_pbottom = mc.sponge_pbottom;
+  m->ray.conserve_energy = mc.damping_conserve_energy != 0;
+  return m;
+}
+void moist_destroy(MoistState *m) {
+  if (!m) return;
+  for (double *p : m->d_sat) if (p) (void)hipFree(p);
+  if (m->d_lcl) (void)hipFree(m->d_lcl);
+  delete m;
+}
+
+static MoistArgs moist_args(const isca_dyn &h) {
+  const isca_moist_config &mc = h.cfg.moist;
+  const MoistState &m = *h.moist;
+  MoistArgs a{};
+  a.L = h.g.L;
+  a.albedo = mc.albedo_value;
+  a.rough_mom = mc.roughness_mom; a.rough_heat = mc.roughness_heat; a.rough_moist = mc.roughness_moist;
+  a.sat = m.sat_dev; a.qe = m.qe_dev;
+  a.rad.solar_constant = mc.solar_constant; a.rad.del_sol = mc.del_sol; a.rad.del_sw = mc.del_sw; a.rad.ir_tau_eq = mc.ir_tau_eq;
+  a.rad.ir_tau_pole = mc.ir_tau_pole; a.rad.atm_abs = mc.atm_abs; a.rad.odp = mc.odp; a.rad.sw_diff = mc.sw_diff;
+  a.rad.linear_tau = mc.linear_tau; a.rad.wv_exponent = mc.wv_exponent; a.rad.solar_exponent = mc.solar_exponent; a.rad.diabatic_acce = 1.0;
+  a.mo.rich_crit = mc.rich_crit; a.mo.drag_min = mc.drag_min;
+  a.ray = m.ray; a.do_damping = mc.do_rayleigh;
+  a.dif.frac_inner = mc.frac_inner; a.dif.rich_crit_pbl = mc.rich_crit_pbl;
+  a.ml.heat_capacity = mc.depth * (1.035e3 * 3989.24495292815);       // depth*RHO_CP (mixed_layer.F90:514)
+  a.ml.evaporation = mc.evaporation != 0; a.ml.ocean_qflux = 0.0;
+  a.dt_atmos = h.cfg.dt_atmos;
+  return a;
+}
+static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
+  const dim3 grid((a.ncol + 63) / 64), block(64);
+  if (a.L <= 30) hipLaunchKernelGGL(k_moist_physics<32>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_moist_physics<64>, grid, block, 0, s, a);
+}
+
+// physics of one step on the model state: previous-level fields, pressures of both levels, heights of the current one
+void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Dev &d = h.d;
+  const size_t lev = (size_t)h.g.Jl * h.g.I;
+  double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
+  double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L, *zf_p = zh_c + lev * (h.g.L + 1), *zh_p = zf_p + lev * h.g.L;
+  launch_pressures_heights(h, d.tg[sc.prev], d.psg[sc.prev], pf_p, ph_p, zf_p, zh_p, s);
+  launch_pressures_heights(h, d.tg[sc.cur], d.psg[sc.cur], pf_c, ph_c, zf_c, zh_c, s);
+  MoistArgs a = moist_args(h);
+  a.ncol = (int)lev; a.I = h.g.I;
+  a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
+  a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
+  a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
+  a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
+  a.delta_t = sc.delta_t;
+  a.gust = h.phys_calls == 0 ? 1.0 : h.cfg.moist.constant_gust;    // gust = 1 until vert_turb_driver has run once (:592, :1262)
+  launch_moist_kernel(a, s);
+}
+// the same on caller columns (device pointers, [lev][ncol])
+void launch_moist_physics_on(const isca_dyn &h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u, const double *v,
+                             const double *t, const double *q, const double *ph_p, const double *pf_p, const double *ph_c, const double *pf_c,
+                             const double *zh_c, const double *zf_c, double *t_surf, double *dtu, double *dtv, double *dtT, double *dtq,
+                             double *precip, hipStream_t s) {
+  MoistArgs a = moist_args(h);
+  a.ncol = ncol; a.I = 1;
+  a.up = u; a.vp = v; a.tp = t; a.qp = q; a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
+  a.rad_lat_row = nullptr; a.rad_lat_col = rad_lat;
+  a.t_surf = t_surf; a.dtu = dtu; a.dtv = dtv; a.dtT = dtT; a.dtq = dtq; a.precip = precip;
+  a.delta_t = delta_t; a.gust = gust;
+  launch_moist_kernel(a, s);
+}
+void launch_t_surf_init(const isca_dyn &h, hipStream_t s) {
+  const int ncol = h.g.Jl * h.g.I;
+  hipLaunchKernelGGL(k_t_surf_init, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, h.g.I, h.d.rad_lat_l, h.cfg.moist.tconst,
+                     h.cfg.moist.delta_T, h.d.t_surf);
+}
+size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 4 * (g.L + 1)); }
+
+}  // namespace isca

@@ -6,6 +6,9 @@
 // temperature, grey radiation 'frierson', SIMPLE_BETTS_MILLER convection, diffusivity PBL, mixed-layer surface).
 #pragma once
 #include <cmath>
+#if defined(__clang__)
+#pragma clang fp contract(off)      // the reference is built without FMA contraction; the convective regime tests are knife-edge
+#endif
 #if defined(__HIPCC__)
 #define MP_HD __host__ __device__ __forceinline__
 #else
@@ -56,29 +59,29 @@ MP_HD void compute_qs(const SatTable &t, double temp, double press, double &qs, 
 // (precip_evap :215-252); returns the deltas (not rates) and the rain in kg/m2.
 // ------------------------------------------------------------------------------------------------
 template <int LMAX>
-MP_HD void lscale_cond(const SatTable &st, int L, const double *tin, const double *qin, const double *pfull, const double *phalf,
-                       int s, double *tdel, double *qdel, double &rain) {
+MP_HD void lscale_cond(const SatTable &st, int L, const double *tin, const double *qin, int si, const double *pfull, const double *phalf,
+                       int s, double *tdel, double *qdel, int so, double &rain) {
   const double hlcp = HLV / CP_AIR;
   double exq = 0.0, precip = 0.0;
   for (int k = 0; k < L; ++k) {
     double qsat, dqsat;
-    compute_qs(st, tin[k * s], pfull[k * s], qsat, dqsat);
+    compute_qs(st, tin[k * si], pfull[k * s], qsat, dqsat);
     double qd = 0.0, td = 0.0;
-    if ((qin[k * s] - qsat) * qsat > 0.0) {
-      qd = (qsat - qin[k * s]) / (1.0 + hlcp * dqsat);
+    if ((qin[k * si] - qsat) * qsat > 0.0) {
+      qd = (qsat - qin[k * si]) / (1.0 + hlcp * dqsat);
       td = -hlcp * qd;
     }
     const double pmass = (phalf[(k + 1) * s] - phalf[k * s]) / GRAV;
     if (qd < 0.0) exq = exq - qd * pmass;
     if (qd >= 0.0 && exq > 0.0) {                 // evaporate precip where needed
       exq = exq / pmass;
-      double def = (qsat - qin[k * s]) / (1. + hlcp * dqsat);
+      double def = (qsat - qin[k * si]) / (1. + hlcp * dqsat);
       def = fmin(fmax(def, 0.0), exq);
       qd = qd + def;
       td = td - def * hlcp;
       exq = (exq - def) * pmass;
     }
-    qdel[k * s] = qd; tdel[k * s] = td;
+    qdel[k * so] = qd; tdel[k * so] = td;
     precip = precip - pmass * qd;
   }
   rain = fmax(precip, 0.0);

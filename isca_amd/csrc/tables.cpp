@@ -94,7 +94,6 @@ bool invert_matrix(std::vector<double> &a, int n) {
   return true;
 }
 
-namespace {
 
 // model/press_and_geopot.F90:152-221 for a single column (simmons_and_burridge)
 void pressure_variables_1d(const std::vector<double> &pk, const std::vector<double> &bk, double ps,
@@ -121,7 +120,6 @@ void pressure_variables_1d(const std::vector<double> &pk, const std::vector<doub
   }
 }
 
-}  // namespace
 
 void Tables::build(const isca_dyn_config &c) {
   I = c.lon_max; J = c.lat_max; M1 = c.num_fourier + 1; N1 = c.num_spherical + 1; L = c.num_levels;
@@ -180,7 +178,9 @@ void Tables::build(const isca_dyn_config &c) {
   for (size_t q = 0; q < NM; ++q) damping[q] = c.damping_coeff * std::pow(eigen[q] / eref, c.damping_order);
   // --- vertical coordinate: init/vert_coordinate.F90:248-273 ('uneven_sigma', zero_top)
   pk.assign(L + 1, 0.0); bk.assign(L + 1, 0.0);
-  {
+  if (c.vert_coord_input) {                    // 'input': vert_coordinate_nml's pk, bk as given (vert_coordinate.F90:150-160)
+    for (int k = 0; k <= L; ++k) { pk[k] = c.pk_input[k]; bk[k] = c.bk_input[k]; }
+  } else {
     const double s2 = 1.0 - c.surf_res;
     for (int k = 1; k <= L; ++k) {
       const double zeta = 1. - ((double)(k - 1) / (double)L);

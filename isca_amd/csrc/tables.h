@@ -43,6 +43,9 @@ struct Tables {
   void build_wave_matrices(const isca_dyn_config &c, double dt);
 };
 
+// pressure_variables for one column (press_and_geopot.F90:152-221): ln p at half and full levels
+void pressure_variables_1d(const std::vector<double> &pk, const std::vector<double> &bk, double ps, std::vector<double> &ln_p_half,
+                           std::vector<double> &ln_p_full);
 void compute_gaussian(int n_hem, std::vector<double> &sin_hem, std::vector<double> &wts_hem);
 void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg);
 bool invert_matrix(std::vector<double> &a, int n);   // Gauss-Jordan with pivoting; returns false if singular

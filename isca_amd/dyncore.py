@@ -22,6 +22,23 @@ class IscaError(RuntimeError):
     """Raised where the reference calls error_mesg(..., FATAL)."""
 
 
+MAX_LEVELS = 128          # ISCA_MAX_LEVELS
+
+
+class _CMoistConfig(C.Structure):
+    _fields_ = [
+        ("roughness_mom", C.c_double), ("roughness_heat", C.c_double), ("roughness_moist", C.c_double),
+        ("solar_constant", C.c_double), ("del_sol", C.c_double), ("del_sw", C.c_double), ("ir_tau_eq", C.c_double),
+        ("ir_tau_pole", C.c_double), ("atm_abs", C.c_double), ("odp", C.c_double), ("sw_diff", C.c_double), ("linear_tau", C.c_double),
+        ("wv_exponent", C.c_double), ("solar_exponent", C.c_double),
+        ("depth", C.c_double), ("tconst", C.c_double), ("delta_T", C.c_double), ("albedo_value", C.c_double), ("evaporation", C.c_int),
+        ("tau_bm", C.c_double), ("rhbm", C.c_double), ("Tmin", C.c_double), ("Tmax", C.c_double), ("val_inc", C.c_double),
+        ("do_rayleigh", C.c_int), ("trayfric", C.c_double), ("sponge_pbottom", C.c_double), ("damping_conserve_energy", C.c_int),
+        ("constant_gust", C.c_double), ("frac_inner", C.c_double), ("rich_crit_pbl", C.c_double), ("rich_crit", C.c_double),
+        ("drag_min", C.c_double),
+    ]
+
+
 class _CConfig(C.Structure):
     _fields_ = [
         ("lon_max", C.c_int), ("lat_max", C.c_int), ("num_fourier", C.c_int), ("num_spherical", C.c_int),
@@ -39,6 +56,9 @@ class _CConfig(C.Structure):
         ("do_conserve_energy", C.c_int), ("trflux", C.c_double), ("trsink", C.c_double), ("P00", C.c_double),
         ("rank", C.c_int), ("world_size", C.c_int), ("device", C.c_int), ("stream", C.c_void_p),
         ("legendre_impl", C.c_int),
+        ("physics", C.c_int), ("vert_coord_input", C.c_int),
+        ("pk_input", C.c_double * (MAX_LEVELS + 1)), ("bk_input", C.c_double * (MAX_LEVELS + 1)),
+        ("moist", _CMoistConfig),
     ]
 
 
@@ -87,6 +107,7 @@ def load_library():
         "isca_trans_fourier_to_grid": [H, dp, dp, C.c_int],
         "isca_area_weighted_global_mean": [H, dp, dp],
         "isca_hs_forcing": [H, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp],
+        "isca_idealized_moist_phys": [H, C.c_int, C.c_double, C.c_double] + [dp] * 17,
         "isca_bench_transform_pair": [H, C.c_int, C.c_int, dp, dp],
         "isca_compute_laplacian": [H, dp, dp, C.c_int, C.c_int],
         "isca_compute_gradient_cos": [H, dp, dp, dp, C.c_int],
@@ -133,7 +154,7 @@ EXPORTED_SYMBOLS = [
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest",
-    "isca_dyn_diag_select", "isca_dyn_diag_read",
+    "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -156,6 +177,18 @@ def default_config(resolution: str | None = None, **overrides) -> _CConfig:
     for k, v in overrides.items():
         if k == "valid_range_t":
             c.valid_range_t[0], c.valid_range_t[1] = v
+        elif k in ("pk_input", "bk_input"):               # vert_coordinate_nml with vert_coord_option = 'input'
+            if len(v) > MAX_LEVELS + 1:
+                raise IscaError(f"{k}: more than {MAX_LEVELS + 1} half levels")
+            arr = getattr(c, k)
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+            c.vert_coord_input = 1
+        elif k == "moist":
+            for mk, mv in v.items():
+                if not hasattr(c.moist, mk):
+                    raise IscaError(f"unknown moist physics key {mk!r}")
+                setattr(c.moist, mk, mv)
         elif not hasattr(c, k):
             raise IscaError(f"unknown configuration key {k!r}")
         else:
@@ -214,7 +247,7 @@ class DynCore:
     # -- shapes
     def _shape(self, name):
         L, Jl, I, N1, M1 = self.L, self.Jl, self.I, self.N1, self.M1
-        if name in ("psg", "dxlp", "dylp", "g_dtlp"):
+        if name in ("psg", "dxlp", "dylp", "g_dtlp", "t_surf", "precip"):
             return (Jl, I), False
         if name in ("p_half", "z_half"):
             return (L + 1, Jl, I), False
@@ -373,6 +406,22 @@ class DynCore:
         outs = [np.zeros_like(arrs[2]) if x is None else np.array(x, dtype=np.float64, copy=True) for x in (udt, vdt, tdt)]
         self._check(self.lib.isca_hs_forcing(self._h, float(dt), *[_dptr(a) for a in arrs], *[_dptr(o) for o in outs]))
         return tuple(outs)
+
+    def idealized_moist_phys(self, delta_t, gust, rad_lat, u_prev, v_prev, t_prev, q_prev, p_half_prev, p_full_prev, p_half_cur, p_full_cur,
+                             z_half_cur, z_full_cur, t_surf):
+        """idealized_moist_phys on independent columns: arrays [lev(+1), ncol]; returns dt_u, dt_v, dt_t, dt_q, t_surf_new, precip."""
+        ins = [np.ascontiguousarray(x, dtype=np.float64) for x in (rad_lat, u_prev, v_prev, t_prev, q_prev, p_half_prev, p_full_prev,
+                                                                      p_half_cur, p_full_cur, z_half_cur, z_full_cur)]
+        L, ncol = ins[1].shape
+        if L != self.L or any(a.shape != (L, ncol) for a in (ins[2], ins[3], ins[4], ins[6], ins[8], ins[10])) or \
+                any(a.shape != (L + 1, ncol) for a in (ins[5], ins[7], ins[9])) or ins[0].shape != (ncol,):
+            raise IscaError("idealized_moist_phys: inconsistent array shapes")
+        ts = np.array(t_surf, dtype=np.float64, copy=True)
+        outs = [np.zeros((L, ncol)) for _ in range(4)]
+        precip = np.zeros(ncol)
+        self._check(self.lib.isca_idealized_moist_phys(self._h, ncol, float(delta_t), float(gust), *[_dptr(a) for a in ins], _dptr(ts),
+                                                       *[_dptr(o) for o in outs], _dptr(precip)))
+        return (*outs, ts, precip)
 
     # -- components of the step on caller fields (spherical_mod / press_and_geopot_mod / fv_advection_mod / ...)
     def _spec(self, a):

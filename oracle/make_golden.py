@@ -273,6 +273,25 @@ def golden_moist_kernels(res="T21", L=25, nsteps=2400, dt=720, stride=13):
     return out
 
 
+def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt=720, keep=None):
+    """The reference moist model (Frierson physics) from its cold start: grid state u, v, T, q, ps at `dump_steps`."""
+    lon, lat, nf, ns = RES[res]
+    with tempfile.TemporaryDirectory(prefix="refmr_") as d:
+        prepare_moist_rundir(d, res, nsteps, dt=dt, dump_steps=dump_steps)
+        stdout = run_harness(d, exe=MOIST_EXE)
+        out = {}
+        for fn in sorted(os.listdir(d)):
+            if fn.startswith("st_") and fn.endswith(".bin") and (keep is None or keep(fn[:-4])):
+                raw = np.fromfile(os.path.join(d, fn))
+                out[fn[:-4]] = raw.reshape((L, lat, lon) if raw.size == L * lat * lon else (lat, lon))
+            elif fn.startswith("tab_") and fn.endswith(".bin"):
+                out[fn[:-4]] = np.fromfile(os.path.join(d, fn))
+    m = re.search(r"REF_STATE Tmin,Tmax,maxabsU,qmax=\s*(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["final_Tmin_Tmax_maxabsU_qmax"] = np.array([float(x) for x in m.groups()])
+    out.update({"meta_res": np.array(res), "meta_num_levels": np.array(L), "meta_dt_atmos": np.array(float(dt)), "meta_nsteps": np.array(nsteps)})
+    return out
+
+
 def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None):
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
         prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps)
@@ -310,6 +329,10 @@ def main():
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,
+        # configs[3]'s model at T21L25 from the cold start: 1.2 days with early steps, and 12 days (final state only)
+        "moist_run_T21L25": lambda: golden_moist_run(
+            keep=lambda k: re.match(r"st_(ug|tg|q|psg)_(000001|000002|000010)$", k) is not None or k.endswith("_000144")),
+        "moist_run_T21L25_12day": lambda: golden_moist_run(nsteps=1440, dump_steps=(1440,), keep=lambda k: k.endswith("_001440")),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

@@ -34,7 +34,7 @@ void mh_lookup_es_des(int n, const double *t, double *es, double *des) {
 void mh_lscale_cond(int L, int ncol, const double *tin, const double *qin, const double *pfull, const double *phalf, double *tdel,
                     double *qdel, double *rain) {
   const SatTable st = sat();
-  for (int c = 0; c < ncol; ++c) lscale_cond<64>(st, L, tin + c, qin + c, pfull + c, phalf + c, ncol, tdel + c, qdel + c, rain[c]);
+  for (int c = 0; c < ncol; ++c) lscale_cond<64>(st, L, tin + c, qin + c, ncol, pfull + c, phalf + c, ncol, tdel + c, qdel + c, ncol, rain[c]);
 }
 void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const double *albedo, const double *t_surf, const double *t,
                  const double *p_half, double *net_sw, double *lw_down_surf, double *tdt) {
