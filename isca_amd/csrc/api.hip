@@ -416,6 +416,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       d.t_surf = dalloc<double>(h, ng2); d.precip = dalloc<double>(h, ng2);
       d.moist_work = dalloc<double>(h, moist_work_doubles(g));
       HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
+      launch_t_surf_init(*h, h->stream);      // mixed_layer_init without restart file: the prescribed distribution
     }
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
@@ -933,8 +934,9 @@ extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
     };
     for (int t = 0; t < 2; ++t) {
       grid3(g1->d.ug[t], h->d.ug[t], g.L); grid3(g1->d.vg[t], h->d.vg[t], g.L); grid3(g1->d.tg[t], h->d.tg[t], g.L);
-      grid3(g1->d.tr[t], h->d.tr[t], g.L); grid3(g1->d.psg[t], h->d.psg[t], 1);
+      grid3(g1->d.tr[t], h->d.tr[t], g.L); grid3(g1->d.tr_atm[t], h->d.tr_atm[t], g.L); grid3(g1->d.psg[t], h->d.psg[t], 1);
     }
+    if (h->cfg.physics == 1) grid3(g1->d.t_surf, h->d.t_surf, 1);
     grid3(g1->d.vorg, h->d.vorg, g.L); grid3(g1->d.divg, h->d.divg, g.L); grid3(g1->d.dxT, h->d.dxT, g.L);
     grid3(g1->d.dyT, h->d.dyT, g.L); grid3(g1->d.dxlp, h->d.dxlp, 1); grid3(g1->d.dylp, h->d.dylp, 1);
     std::vector<double> sp((size_t)G.L * G.N1 * G.M1 * 2);
@@ -946,7 +948,7 @@ extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
       spec(g1->d.vors[t], h->d.vors[t], g.L); spec(g1->d.divs[t], h->d.divs[t], g.L);
       spec(g1->d.ts[t], h->d.ts[t], g.L); spec(g1->d.lnps[t], h->d.lnps[t], 1);
     }
-    h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true;
+    h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true; h->phys_calls = 0;
   } catch (...) { isca_dyn_destroy(g1); throw; }
   isca_dyn_destroy(g1);
   API_END

@@ -43,8 +43,12 @@ __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
   // ---- convection (:862-880): deltas over the step, then rates
   double rain, cape, cin;
   int flag, klzb, klcl;
+#ifdef MOIST_EXP_NOCONV
+  rain = 0; for (int k = 0; k < L; ++k) { dtT[k * s] = 0; dtq[k * s] = 0; }
+#else
   moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
                                    nullptr, nullptr, s);
+#endif
   double precip = rain / delta_t;
   // ---- large-scale condensation on the convectively adjusted profile (:975-997)
   {
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
   // ---- Rayleigh sponge (:1228-1237)
   if (a.do_damping) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, dtT, s);
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
+#ifndef MOIST_EXP_NOVD
   {
     double k_m[LMAX], k_t[LMAX], h;
     moist::pbl_diffusivity<LMAX>(a.mo, a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s, sf.u_star, sf.b_star, h,
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
     moist::vert_diff_up<LMAX>(L, delta_t, w, S, dtT, dtq, s);
   }
+#endif
   a.t_surf[c] = t_surf;
 }
 
@@ -175,6 +181,7 @@ static MoistArgs moist_args(const isca_dyn &h) {
 static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
   const dim3 grid((a.ncol + 63) / 64), block(64);
   if (a.L <= 30) hipLaunchKernelGGL(k_moist_physics<32>, grid, block, 0, s, a);
+  else if (a.L <= 46) hipLaunchKernelGGL(k_moist_physics<48>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(k_moist_physics<64>, grid, block, 0, s, a);
 }
 

@@ -1,6 +1,6 @@
 // Column physics of the moist configuration (config 3: Frierson grey-radiation aquaplanet), restated from the reference's
-// atmos_param / coupler modules as functions of ONE column, usable on the device (k_moist_* kernels) and on the host
-// (oracle/moist_host.cpp, the checker built for the CPU tests).  A column field is addressed as x[k * s] (s = level
+// atmos_param / coupler modules as functions of ONE column, usable on the device (moist.hip) and on the host (the CPU
+// tests compile this header with g++ and compare every routine with the reference's outputs).  A column field is addressed as x[k * s] (s = level
 // stride: lat*lon on the device grid layout [lev][lat][lon]); k = 0 is the model top.
 // Options: those of exp/test_cases/frierson/frierson_test_case.py:49-170 (do_simple everywhere, no snow, no virtual
 // temperature, grey radiation 'frierson', SIMPLE_BETTS_MILLER convection, diffusivity PBL, mixed-layer surface).

@@ -199,7 +199,7 @@ class ShardedDynCore(dyncore.DynCore):
                 names = ("ug", "vg", "tg", "psg") + (("tr", "tr_atm") if self.info("tracer") else ())
                 for nm in names:
                     self.set(nm, one.get(nm, tl)[..., j0:j0 + jl, :], tl)
-            for nm in ("vorg", "divg", "dxT", "dyT", "dxlp", "dylp", "wg_full"):
+            for nm in ("vorg", "divg", "dxT", "dyT", "dxlp", "dylp", "wg_full") + (("t_surf",) if self.cfg.physics == 1 else ()):
                 self.set(nm, one.get(nm)[..., j0:j0 + jl, :])
         finally:
             one.close()
@@ -211,13 +211,14 @@ class _GatheredView:
     def __init__(self, sh: ShardedDynCore):
         import types
         self._sh = sh
-        self.cfg = types.SimpleNamespace(world_size=1)
+        self.cfg = types.SimpleNamespace(world_size=1, physics=sh.cfg.physics)
         self.L, self.J, self.Jl, self.I, self.N1, self.M1 = sh.L, sh.J, sh.J, sh.I, sh.N1, sh.M1
         self._cache = {}
         for nm in ("vors", "divs", "ts", "ln_ps"):
             for tl in (0, 1):
                 self._cache[nm, tl] = sh.gather_spectral(nm, tl)
-        grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full"] + (["tr", "tr_atm"] if sh.info("tracer") else [])
+        grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full"] + (["tr", "tr_atm"] if sh.info("tracer") else []) + \
+                (["t_surf"] if sh.cfg.physics == 1 else [])
         for nm in grids:
             for tl in (0, 1):
                 self._cache[nm, tl] = sh.gather_grid(nm, tl)

@@ -4,6 +4,8 @@ Replaces, for the hot path, the restart branches of
   read_restart_or_do_coldstart   (src/atmos_spectral/model/spectral_dynamics.F90:509-575)
   spectral_dynamics_end          (spectral_dynamics.F90:1502-1531)
   atmosphere_init / _end         (src/atmos_spectral/driver/solo/atmosphere.F90:197-223, 362-375)
+  mixed_layer_init / _end        (src/atmos_spectral/driver/solo/mixed_layer.F90:324-327, :813) -- moist package only: t_surf in
+                                 <dir>/mixed_layer.res.nc
 Files: <dir>/spectral_dynamics.res.nc and <dir>/atmosphere.res.nc with the reference's variable names
 (`vors_real`, `vors_imag`, ..., `ug`, `psg`, `<tracer>`, `vorg`, `divg`, `surf_geopotential`, `previous`,
 `current`, `pk`, `bk`; `time_pointers`, `wg_full`), two records along `Time` (one per leapfrog time level,
@@ -108,6 +110,11 @@ def write_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
     w.put("wg_full", [core.get("wg_full")])
     w.close()
 
+    if core.cfg.physics == 1:                                    # mixed_layer_end
+        w = _Writer(os.path.join(directory, "mixed_layer.res.nc"))
+        w.put("t_surf", [core.get("t_surf")])
+        w.close()
+
 
 def _read_all(path):
     f = netcdf_file(path, "r", mmap=False)
@@ -174,4 +181,11 @@ def read_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
                 core.set("tr_atm", (at if at is not None else sd)[tracer_name][nt], tl)
     if at is not None:
         core.set("wg_full", at["wg_full"][0])
+    if core.cfg.physics == 1:                                    # mixed_layer_init: restart file, else the prescribed distribution
+        ml_path = os.path.join(directory, "mixed_layer.res.nc")
+        if os.path.exists(ml_path):
+            ts = _read_all(ml_path)["t_surf"]
+            if ts.shape[-2:] != (J, I):
+                raise IscaError("mixed_layer_init: resolution of mixed_layer.res does not match the namelist")
+            core.set("t_surf", ts.reshape(-1, J, I)[0])
     core.refresh_derived()

@@ -31,13 +31,17 @@ def test_config_struct_matches_header(lib):
     start = hdr.index("typedef struct isca_dyn_config {") + len("typedef struct isca_dyn_config {")
     body = hdr[start:hdr.index("} isca_dyn_config;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    names = []
-    for decl in body.split(";"):
-        decl = decl.strip()
-        m = re.match(r"(?:int|double|void \*)\s*(.*)", decl, flags=re.S)
-        if m:
-            names += [re.sub(r"\[.*\]|\*", "", x).strip() for x in m.group(1).split(",")]
-    assert names == [f[0] for f in dyncore._CConfig._fields_]
+    def members(text):
+        names = []
+        for decl in text.split(";"):
+            m = re.match(r"(?:int|double|void \*|isca_moist_config)\s*(.*)", decl.strip(), flags=re.S)
+            if m:
+                names += [re.sub(r"\[.*\]|\*", "", x).strip() for x in m.group(1).split(",")]
+        return names
+    assert members(body) == [f[0] for f in dyncore._CConfig._fields_]
+    mstart = hdr.index("typedef struct isca_moist_config {") + len("typedef struct isca_moist_config {")
+    mbody = re.sub(r"/\*.*?\*/", "", hdr[mstart:hdr.index("} isca_moist_config;")], flags=re.S)
+    assert members(mbody) == [f[0] for f in dyncore._CMoistConfig._fields_]
     c = dyncore.default_config("T85", num_levels=40, dt_atmos=300.0)
     assert (c.lon_max, c.lat_max, c.num_fourier, c.num_spherical) == (256, 128, 85, 86)
     assert c.damping_order == 4 and c.robert_coeff == 0.04 and c.reference_sea_level_press == 1.0e5
@@ -101,7 +105,7 @@ def test_restart_file_round_trip_on_host(tmp_path):
 
     class Host:
         L, J, Jl, I, N1, M1 = 3, 8, 8, 16, 7, 6
-        cfg = types.SimpleNamespace(world_size=1)
+        cfg = types.SimpleNamespace(world_size=1, physics=0)
 
         def __init__(self, seed=None):
             self.ptr = {"previous": 1, "current": 0, "tracer": 1, "step": 5}
@@ -186,3 +190,34 @@ def test_diag_table_host_logic():
     with pytest.raises(IscaError):
         d.add_field("dynamics", "no_such_field")
     assert {"ucomp_vcomp", "omega", "wspd", "vcomp_vor"} <= set(FIELDS)
+
+
+def test_moist_namelist_mapping():
+    """idealized_moist_model = .true.: the Frierson test case's namelists become the C config; options the device package does not
+    implement are refused like unsupported namelist values (no GPU needed: only the config is built)."""
+    from isca_amd import atmosphere as atm, dyncore
+    bk = [0.0, 0.2, 0.5, 0.8, 1.0]
+    nml = {"atmosphere_nml": {"idealized_moist_model": True}, "main_nml": {"dt_atmos": 720},
+           "spectral_dynamics_nml": {"num_levels": 4, "vert_coord_option": "input", "robert_coeff": 0.03, "initial_sphum": 2e-6},
+           "vert_coordinate_nml": {"bk": bk, "pk": [0.0] * 5},
+           "two_stream_gray_rad_nml": {"rad_scheme": "frierson", "atm_abs": 0.2, "do_seasonal": False},
+           "mixed_layer_nml": {"depth": 10.0, "albedo_value": 0.25, "delta_T": 30.0, "evaporation": True},
+           "qe_moist_convection_nml": {"rhbm": 0.8, "Tmin": 150.0},
+           "damping_driver_nml": {"do_rayleigh": True, "trayfric": -0.5, "do_conserve_energy": False}}
+    c = atm.config_from_namelist(nml, resolution="T21")
+    assert c.physics == 1 and c.vert_coord_input == 1 and [c.bk_input[i] for i in range(5)] == bk and c.num_levels == 4
+    m = c.moist
+    assert (m.atm_abs, m.depth, m.albedo_value, m.delta_T, m.evaporation) == (0.2, 10.0, 0.25, 30.0, 1)
+    assert (m.rhbm, m.Tmin, m.Tmax, m.trayfric, m.damping_conserve_energy) == (0.8, 150.0, 350.0, -0.5, 0)
+    assert m.roughness_mom == 3.21e-05 and m.rich_crit == 2.0               # defaults of the test case / modules
+    text = "&atmosphere_nml idealized_moist_model = .true. /\n&two_stream_gray_rad_nml rad_scheme = 'byrne' /\n"
+    with pytest.raises(dyncore.IscaError, match="not a supported value for rad_scheme"):
+        atm.config_from_namelist(text)
+    with pytest.raises(dyncore.IscaError, match="vert_coordinate_nml"):
+        atm.config_from_namelist({"spectral_dynamics_nml": {"vert_coord_option": "input"}})
+    with pytest.raises(dyncore.IscaError, match="num_levels\\+1"):
+        atm.config_from_namelist({"spectral_dynamics_nml": {"vert_coord_option": "input", "num_levels": 7}, "vert_coordinate_nml": {"bk": bk}})
+    with pytest.raises(dyncore.IscaError, match="not supported by the device physics"):
+        atm.config_from_namelist({"atmosphere_nml": {"idealized_moist_model": True}, "mixed_layer_nml": {"land_depth": 2.0}})
+    dry = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 25}})
+    assert dry.physics == 0 and dry.vert_coord_input == 0
