@@ -12,6 +12,6 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
 void launch_moist_physics_on(const isca_dyn &h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u, const double *v,
                              const double *t, const double *q, const double *ph_p, const double *pf_p, const double *ph_c, const double *pf_c,
                              const double *zh_c, const double *zf_c, double *t_surf, double *dtu, double *dtv, double *dtT, double *dtq,
-                             double *precip, hipStream_t s);
+                             double *precip, double *work, hipStream_t s);
 void launch_t_surf_init(const isca_dyn &h, hipStream_t s);
 }  // namespace isca

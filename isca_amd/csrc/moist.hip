@@ -19,6 +19,7 @@ struct MoistArgs {
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
+  double *work;                         // [3][L+1][ncol] work arrays when they do not fit LDS
   double delta_t, dt_atmos, gust, albedo;
   double rough_mom, rough_heat, rough_moist;
   moist::SatTable sat;
@@ -31,12 +32,18 @@ struct MoistArgs {
   int do_damping;
 };
 
-template <int LMAX>
+// Three work arrays of L+1 levels per column (radiation: lw_down, lw_dtrans; diffusion: e, f_1, f_2) live in LDS when the block's
+// 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the grid layout.
+// LMAX only sizes the private arrays of the convection scheme.
+template <int LMAX, bool LDSW>
 __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= a.ncol) return;
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  const int col = min(blockIdx.x * 64 + (int)threadIdx.x, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
   const int L = a.L, s = a.ncol;
   const size_t c = (size_t)col;
+  const int sw = LDSW ? 64 : a.ncol;
+  double *w0 = LDSW ? lds_work + threadIdx.x : a.work + c;
+  double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
@@ -50,17 +57,17 @@ __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
                                    nullptr, nullptr, s);
 #endif
   double precip = rain / delta_t;
-  // ---- large-scale condensation on the convectively adjusted profile (:975-997)
+  // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
   {
-    double tt[LMAX], qq[LMAX], td[LMAX], qd[LMAX];
-    for (int k = 0; k < L; ++k) { tt[k] = dtT[k * s] + tp[k * s]; qq[k] = dtq[k * s] + qp[k * s]; }
     double rain_ls;
-    moist::lscale_cond<LMAX>(a.sat, L, tt, qq, 1, a.pf_p + c, a.ph_p + c, s, td, qd, 1, rain_ls);
-    for (int k = 0; k < L; ++k) {
-      dtT[k * s] = dtT[k * s] / delta_t + td[k] / delta_t;       // dt_tg = (0 + conv_dt_tg) + cond_dt_tg
-      dtq[k * s] = dtq[k * s] / delta_t + qd[k] / delta_t;
-      dtu[k * s] = 0.0; dtv[k * s] = 0.0;
-    }
+    moist::lscale_cond(a.sat, L, [&](int k) { return dtT[k * s] + tp[k * s]; }, [&](int k) { return dtq[k * s] + qp[k * s]; }, a.pf_p + c,
+                       a.ph_p + c, s,
+                       [&](int k, double td, double qd) {
+                         dtT[k * s] = dtT[k * s] / delta_t + td / delta_t;
+                         dtq[k * s] = dtq[k * s] / delta_t + qd / delta_t;
+                         dtu[k * s] = 0.0; dtv[k * s] = 0.0;
+                       },
+                       rain_ls);
     precip = precip + rain_ls / delta_t;
   }
   if (a.precip) a.precip[c] = precip;
@@ -70,30 +77,30 @@ __global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
   double net_sw, lw_down_surf;
   moist::SurfFlux sf;
   {
-    double lw_down[LMAX + 1], lw_dtrans[LMAX];
     double insolation, sw_tau_0;
-    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, lw_down, lw_dtrans, insolation, sw_tau_0, net_sw, lw_down_surf);
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, net_sw, lw_down_surf);
     const size_t low = (size_t)(L - 1) * s;
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, lw_down, lw_dtrans, insolation, sw_tau_0, dtT, s);
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, dtT, s);
   }
   // ---- Rayleigh sponge (:1228-1237)
   if (a.do_damping) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, dtT, s);
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
 #ifndef MOIST_EXP_NOVD
   {
-    double k_m[LMAX], k_t[LMAX], h;
-    moist::pbl_diffusivity<LMAX>(a.mo, a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s, sf.u_star, sf.b_star, h,
-                                 k_m, k_t, 1);
-    moist::VdiffWork<LMAX> w;
+    const double h = moist::pbl_depth(a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s);
+    moist::PblProfile pbl;
+    pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
+    const moist::VdiffWork w{w0, w1, w2, sw};
     moist::VdiffSurf S;
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
-    moist::vert_diff_down<LMAX>(L, delta_t, up, vp, tp, qp, s, k_m, k_t, 1, a.ph_c + c, a.pf_c + c, a.zf_c + c, s, tau_u, tau_v, sf.dtaudu_atm,
-                                sf.dtaudv_atm, dtu, dtv, dtT, dtq, s, nullptr, 0, w, S);
+    moist::vert_diff_momentum(L, delta_t, up, vp, tp, s, [&](int k) { return pbl.k_m(k); }, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
+                              sf.dtaudu_atm, sf.dtaudv_atm, dtu, dtv, dtT, s, nullptr, 0, w, S);
+    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, [&](int k) { return pbl.k_t(k); }, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
     moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
-    moist::vert_diff_up<LMAX>(L, delta_t, w, S, dtT, dtq, s);
+    moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s);
   }
 #endif
   a.t_surf[c] = t_surf;
@@ -180,9 +187,15 @@ static MoistArgs moist_args(const isca_dyn &h) {
 }
 static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
   const dim3 grid((a.ncol + 63) / 64), block(64);
-  if (a.L <= 30) hipLaunchKernelGGL(k_moist_physics<32>, grid, block, 0, s, a);
-  else if (a.L <= 46) hipLaunchKernelGGL(k_moist_physics<48>, grid, block, 0, s, a);
-  else hipLaunchKernelGGL(k_moist_physics<64>, grid, block, 0, s, a);
+  const size_t lds = (size_t)3 * 64 * (a.L + 1) * sizeof(double);
+  const bool in_lds = lds <= 65536 && !getenv("ISCA_MOIST_GLOBAL_WORK");
+#define LM(N)                                                                                          \
+  do {                                                                                                 \
+    if (in_lds) hipLaunchKernelGGL((k_moist_physics<N, true>), grid, block, lds, s, a);                \
+    else hipLaunchKernelGGL((k_moist_physics<N, false>), grid, block, 0, s, a);                        \
+  } while (0)
+  if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
+#undef LM
 }
 
 // physics of one step on the model state: previous-level fields, pressures of both levels, heights of the current one
@@ -199,6 +212,7 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
   a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
   a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
+  a.work = zh_p + lev * (h.g.L + 1);
   a.delta_t = sc.delta_t;
   a.gust = h.phys_calls == 0 ? 1.0 : h.cfg.moist.constant_gust;    // gust = 1 until vert_turb_driver has run once (:592, :1262)
   launch_moist_kernel(a, s);
@@ -207,8 +221,9 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
 void launch_moist_physics_on(const isca_dyn &h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u, const double *v,
                              const double *t, const double *q, const double *ph_p, const double *pf_p, const double *ph_c, const double *pf_c,
                              const double *zh_c, const double *zf_c, double *t_surf, double *dtu, double *dtv, double *dtT, double *dtq,
-                             double *precip, hipStream_t s) {
+                             double *precip, double *work, hipStream_t s) {
   MoistArgs a = moist_args(h);
+  a.work = work;
   a.ncol = ncol; a.I = 1;
   a.up = u; a.vp = v; a.tp = t; a.qp = q; a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
   a.rad_lat_row = nullptr; a.rad_lat_col = rad_lat;
@@ -221,6 +236,6 @@ void launch_t_surf_init(const isca_dyn &h, hipStream_t s) {
   hipLaunchKernelGGL(k_t_surf_init, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, h.g.I, h.d.rad_lat_l, h.cfg.moist.tconst,
                      h.cfg.moist.delta_T, h.d.t_surf);
 }
-size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 4 * (g.L + 1)); }
+size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 7 * (g.L + 1)); }
 
 }  // namespace isca

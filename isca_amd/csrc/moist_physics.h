@@ -58,30 +58,30 @@ MP_HD void compute_qs(const SatTable &t, double temp, double press, double &qs, 
 // saturation adjustment where q > qsat, re-evaporation of the falling precipitation in the layers below
 // (precip_evap :215-252); returns the deltas (not rates) and the rain in kg/m2.
 // ------------------------------------------------------------------------------------------------
-template <int LMAX>
-MP_HD void lscale_cond(const SatTable &st, int L, const double *tin, const double *qin, int si, const double *pfull, const double *phalf,
-                       int s, double *tdel, double *qdel, int so, double &rain) {
+template <class TIN, class QIN, class OUT>
+MP_HD void lscale_cond(const SatTable &st, int L, TIN tin, QIN qin, const double *pfull, const double *phalf, int s, OUT out, double &rain) {
   const double hlcp = HLV / CP_AIR;
   double exq = 0.0, precip = 0.0;
   for (int k = 0; k < L; ++k) {
     double qsat, dqsat;
-    compute_qs(st, tin[k * si], pfull[k * s], qsat, dqsat);
+    const double tk = tin(k), qk = qin(k);
+    compute_qs(st, tk, pfull[k * s], qsat, dqsat);
     double qd = 0.0, td = 0.0;
-    if ((qin[k * si] - qsat) * qsat > 0.0) {
-      qd = (qsat - qin[k * si]) / (1.0 + hlcp * dqsat);
+    if ((qk - qsat) * qsat > 0.0) {
+      qd = (qsat - qk) / (1.0 + hlcp * dqsat);
       td = -hlcp * qd;
     }
     const double pmass = (phalf[(k + 1) * s] - phalf[k * s]) / GRAV;
     if (qd < 0.0) exq = exq - qd * pmass;
     if (qd >= 0.0 && exq > 0.0) {                 // evaporate precip where needed
       exq = exq / pmass;
-      double def = (qsat - qin[k * si]) / (1. + hlcp * dqsat);
+      double def = (qsat - qk) / (1. + hlcp * dqsat);
       def = fmin(fmax(def, 0.0), exq);
       qd = qd + def;
       td = td - def * hlcp;
       exq = (exq - def) * pmass;
     }
-    qdel[k * so] = qd; tdel[k * so] = td;
+    out(k, td, qd);
     precip = precip - pmass * qd;
   }
   rain = fmax(precip, 0.0);
@@ -99,7 +99,7 @@ struct GrayRadParams {
 };
 // Downward pass: fills lw_down[0..L] (caller storage, unit stride) and lw_dtrans[0..L-1], returns the surface fluxes.
 MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, const double *p_half, int s,
-                         double *lw_down, double *lw_dtrans, double &insolation, double &sw_tau_0, double &net_surf_sw_down,
+                         double *lw_down, double *lw_dtrans, int sw, double &insolation, double &sw_tau_0, double &net_surf_sw_down,
                          double &surf_lw_down) {
   const double sl = sin(lat), sl2 = sl * sl;
   const double p2 = (1. - 3. * sl2) / 4.;
@@ -109,32 +109,36 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   lw_tau_0 = lw_tau_0 * p.odp;
   double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pow(p_half[0] / PSTD_MKS, p.wv_exponent));
   lw_down[0] = 0.;
+  double lwd = 0.;
   for (int k = 0; k < L; ++k) {
     const double ph = p_half[(k + 1) * s];
     const double tau_n = lw_tau_0 * (p.linear_tau * ph / PSTD_MKS + (1.0 - p.linear_tau) * pow(ph / PSTD_MKS, p.wv_exponent));
-    lw_dtrans[k] = exp(-(tau_n - tau_k));
+    const double dtr = exp(-(tau_n - tau_k));
+    lw_dtrans[k * sw] = dtr;
     const double tk = t[k * s];
     const double b = STEFAN * pow4(tk);
-    lw_down[k + 1] = lw_down[k] * lw_dtrans[k] + b * (1. - lw_dtrans[k]);
+    lwd = lwd * dtr + b * (1. - dtr);
+    lw_down[(k + 1) * sw] = lwd;
     tau_k = tau_n;
   }
-  surf_lw_down = lw_down[L];
+  surf_lw_down = lwd;
   const double sw_surf = insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent));
   net_surf_sw_down = sw_surf * (1. - albedo);
 }
 // Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, const double *p_half, int s,
-                       const double *lw_down, const double *lw_dtrans, double insolation, double sw_tau_0, double *tdt, int st) {
+                       const double *lw_down, const double *lw_dtrans, int sw, double insolation, double sw_tau_0, double *tdt, int st) {
   const double b_surf = STEFAN * pow4(t_surf);
   const double sw_up = albedo * (insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
-  double flux_n = (lw_up_n - lw_down[L]) + (sw_up - insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
+  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
   for (int k = L - 1; k >= 0; --k) {
     const double tk = t[k * s];
     const double b = STEFAN * pow4(tk);
-    const double lw_up_k = lw_up_n * lw_dtrans[k] + b * (1.0 - lw_dtrans[k]);
+    const double dtr = lw_dtrans[k * sw];
+    const double lw_up_k = lw_up_n * dtr + b * (1.0 - dtr);
     const double sw_down_k = insolation * exp(-sw_tau_0 * pow(p_half[k * s] / PSTD_MKS, p.solar_exponent));
-    const double flux_k = (lw_up_k - lw_down[k]) + (sw_up - sw_down_k);
+    const double flux_k = (lw_up_k - lw_down[k * sw]) + (sw_up - sw_down_k);
     const double tdt_rad = p.diabatic_acce * (flux_n - flux_k) * GRAV / (CP_AIR * (p_half[(k + 1) * s] - p_half[k * s]));
     tdt[k * st] = tdt[k * st] + tdt_rad;
     lw_up_n = lw_up_k; flux_n = flux_k;
@@ -530,49 +534,71 @@ MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pf
 // k_m[k], k_t[k] sit on the interface above full level k (k = 0 stays zero).
 // ------------------------------------------------------------------------------------------------
 struct DiffusivityParams { double frac_inner = 0.1, rich_crit_pbl = 1.0, small = 1.e-04, ustar_min = 1.e-10; };
-MP_HD void mo_diff(const MoParams &mo, const DiffusivityParams &dp, double z, double u_star, double b_star, double &k_m, double &k_h) {
+MP_HD double mo_diff_m(const MoParams &mo, const DiffusivityParams &dp, double z, double u_star, double b_star) {
   const double uss = fmax(u_star, dp.ustar_min);
   const double zeta = -(VONKARM * b_star * z / (uss * uss));
-  k_m = VONKARM * uss * z / mo_phi_m(mo, zeta);
-  k_h = VONKARM * uss * z / mo_phi_t(mo, zeta);
+  return VONKARM * uss * z / mo_phi_m(mo, zeta);
 }
-template <int LMAX>
-MP_HD void pbl_diffusivity(const MoParams &mo, const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um,
-                           const double *vm, int s, const double *tdt, const double *udt, const double *vdt, int st, const double *z_full,
-                           const double *z_half, int sz, double u_star, double b_star, double &h, double *k_m, double *k_t, int so) {
+MP_HD double mo_diff_t(const MoParams &mo, const DiffusivityParams &dp, double z, double u_star, double b_star) {
+  const double uss = fmax(u_star, dp.ustar_min);
+  const double zeta = -(VONKARM * b_star * z / (uss * uss));
+  return VONKARM * uss * z / mo_phi_t(mo, zeta);
+}
+// pbl_depth (:364-444), do_simple: the height where the bulk Richardson number of the provisional profile first exceeds
+// rich_crit_pbl, searched upward from the lowest level.  Nothing is stored: each level is visited once.
+MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
+                       const double *tdt, const double *udt, const double *vdt, int st, const double *z_full, const double *z_half, int sz) {
   const double gcp = GRAV / CP_AIR;
   const double z_surf = z_half[L * sz];
-  double rich[LMAX], zf[LMAX];
-  const double tbot = (tm[(L - 1) * s] + dt * tdt[(L - 1) * st]) + gcp * (z_full[(L - 1) * sz] - z_surf);
-  for (int k = 0; k < L; ++k) {
-    zf[k] = z_full[k * sz] - z_surf;
-    const double svcp = (tm[k * s] + dt * tdt[k * st]) + gcp * zf[k];
+  auto rich_at = [&](int k, double tbot, double &zf) {
+    zf = z_full[k * sz] - z_surf;
+    const double svcp = (tm[k * s] + dt * tdt[k * st]) + gcp * zf;
     const double uu = um[k * s] + dt * udt[k * st], vv = vm[k * s] + dt * vdt[k * st];
-    rich[k] = zf[k] * GRAV * (svcp - tbot) / tbot / (uu * uu + vv * vv + dp.small);
-  }
-  double h1 = zf[L - 1], rich1 = rich[L - 1];
-  h = h1;
+    return zf * GRAV * (svcp - tbot) / tbot / (uu * uu + vv * vv + dp.small);
+  };
+  const double tbot = (tm[(L - 1) * s] + dt * tdt[(L - 1) * st]) + gcp * (z_full[(L - 1) * sz] - z_surf);
+  double h1, rich1 = rich_at(L - 1, tbot, h1);
+  double h = h1;
   for (int k = L - 2; k >= 0; --k) {
-    const double rich2 = rich[k], h2 = zf[k];
+    double h2;
+    const double rich2 = rich_at(k, tbot, h2);
     if (rich2 > dp.rich_crit_pbl) { h = h2 + (h1 - h2) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1); break; }
     rich1 = rich2; h1 = h2;
   }
-  const double h_inner = dp.frac_inner * h;
-  double k_m_ref, k_t_ref;
-  mo_diff(mo, dp, h_inner, u_star, b_star, k_m_ref, k_t_ref);
-  k_m[0] = 0.0; k_t[0] = 0.0;
-  for (int k = 1; k < L; ++k) {
-    const double zm = z_half[k * sz] - z_surf;
-    double km = 0.0, kt = 0.0;
-    if (zm < h_inner) mo_diff(mo, dp, zm, u_star, b_star, km, kt);
-    else if (zm < h) {
-      const double r = 1.0 - (zm - h_inner) / (h - h_inner);
-      const double factor = (zm / h_inner) * (r * r);
-      km = k_m_ref * factor; kt = k_t_ref * factor;
-    }
-    k_m[k * so] = km; k_t[k * so] = kt;
-  }
+  return h;
 }
+// diffusivity_pbl (:448-510) as a function of the interface: k_m, k_t on the interface above full level k (k >= 1; 0 at k = 0)
+struct PblProfile {
+  MoParams mo; DiffusivityParams dp;
+  double h, h_inner, k_m_ref, k_t_ref, u_star, b_star, z_surf;
+  const double *z_half; int sz;
+  MP_HD void init(const MoParams &mo_, const DiffusivityParams &dp_, double h_, double u_star_, double b_star_, const double *z_half_, int sz_,
+                  int L) {
+    mo = mo_; dp = dp_; h = h_; u_star = u_star_; b_star = b_star_; z_half = z_half_; sz = sz_;
+    z_surf = z_half[L * sz];
+    h_inner = dp.frac_inner * h;
+    k_m_ref = mo_diff_m(mo, dp, h_inner, u_star, b_star);
+    k_t_ref = mo_diff_t(mo, dp, h_inner, u_star, b_star);
+  }
+  MP_HD double shape(double zm) const {
+    const double r = 1.0 - (zm - h_inner) / (h - h_inner);
+    return (zm / h_inner) * (r * r);
+  }
+  MP_HD double k_m(int k) const {
+    if (k == 0) return 0.0;
+    const double zm = z_half[k * sz] - z_surf;
+    if (zm < h_inner) return mo_diff_m(mo, dp, zm, u_star, b_star);
+    if (zm < h) return k_m_ref * shape(zm);
+    return 0.0;
+  }
+  MP_HD double k_t(int k) const {
+    if (k == 0) return 0.0;
+    const double zm = z_half[k * sz] - z_surf;
+    if (zm < h_inner) return mo_diff_t(mo, dp, zm, u_star, b_star);
+    if (zm < h) return k_t_ref * shape(zm);
+    return 0.0;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Implicit vertical diffusion (atmos_param/vert_diff/vert_diff.F90): downward sweep of the tridiagonal elimination for
@@ -580,40 +606,15 @@ MP_HD void pbl_diffusivity(const MoParams &mo, const DiffusivityParams &dp, int 
 // dry static energy / humidity (left open: Tri_surf hands the lowest-level increments to the surface model),
 // gcm_vert_diff_down :270-406; the mixed-layer ocean closes the system (mixed_layer.F90:568-720) and
 // gcm_vert_diff_up :410-467 back-substitutes.
+// The reference builds mu, nu, the explicit tendencies, a/b/c, e/g and f in separate array passes (compute_mu :1033,
+// compute_nu :1053, explicit_tend :1005, compute_e :951, compute_f :984, vert_diff_down_2 :814); here one downward loop per
+// pair of fields evaluates the same expressions level by level with the neighbours carried in registers, and only e, f_1,
+// f_2 (needed again by the upward sweep) are stored, in caller storage (w[k * sw]: LDS on the device).
 // ------------------------------------------------------------------------------------------------
 struct VdiffSurf { double dtmass, dflux_t, delta_t, dflux_q, delta_q, delta_u, delta_v; };
-template <int LMAX>
-struct VdiffWork { double e[LMAX], f_t[LMAX], f_q[LMAX]; };
+struct VdiffWork { double *e, *f1, *f2; int sw; };
 
 namespace vd {
-// compute_e (:951-980): a, b, c of the tridiagonal system, e and g of the elimination.  0-based; g valid for 1..L-2.
-template <int LMAX>
-MP_HD void compute_e(int L, double delt, const double *mu, const double *nu, double *e, double *b, double *c, double *g) {
-  double a_prev = 0.0;
-  for (int k = 0; k < L; ++k) {
-    const double a = (k < L - 1) ? -(mu[k] * nu[k + 1] * delt) : 0.0;
-    c[k] = (k > 0) ? -(mu[k] * nu[k] * delt) : 0.0;
-    b[k] = 1.0 - a - c[k];
-    if (k == 0) e[0] = -a / b[0];
-    else if (k < L - 1) { g[k] = 1.0 / (b[k] + c[k] * e[k - 1]); e[k] = -a * g[k]; }
-    (void)a_prev;
-  }
-}
-// explicit_tend (:1005-1029)
-MP_HD void explicit_tend(int L, const double *mu, const double *nu, const double *xi, double *dt_xi) {
-  double fl_k = 0.0;                                         // flux through the top of level k
-  for (int k = 0; k < L - 1; ++k) {
-    const double fl_n = nu[k + 1] * (xi[k + 1] - xi[k]);
-    dt_xi[k] = dt_xi[k] + mu[k] * (fl_n - fl_k);
-    fl_k = fl_n;
-  }
-  dt_xi[L - 1] = dt_xi[L - 1] - mu[L - 1] * fl_k;
-}
-// compute_f (:984-1001)
-MP_HD void compute_f(int L, const double *dt_xi, const double *b, const double *c, const double *g, double *f) {
-  f[0] = dt_xi[0] / b[0];
-  for (int k = 1; k < L - 1; ++k) f[k] = (dt_xi[k] - c[k] * f[k - 1]) * g[k];
-}
 // diff_surface (:882-910)
 MP_HD void diff_surface(double mu_delt, double nu, double e_n1, double f_delt_n1, double dflux_datmos, double &flux, double factor,
                         double &delta_xi) {
@@ -623,70 +624,92 @@ MP_HD void diff_surface(double mu_delt, double nu, double e_n1, double f_delt_n1
   delta_xi = (delta_xi + mu_delt * flux * fff) / (1.0 - mu_delt * (dflux + dflux_datmos * fff));
   flux = flux + dflux_datmos * delta_xi;
 }
-// vert_diff_up (:914-947)
-MP_HD void diff_up(int L, double delt, const double *e, const double *f, double delta_xi_n, double *dt_xi, int st) {
-  double x = delta_xi_n / delt;
-  dt_xi[(L - 1) * st] = x;
-  for (int k = L - 2; k >= 0; --k) { x = e[k] * x + f[k]; dt_xi[k * st] = x; }
+struct DownResult { double mu_delt_n, nu_n, e_n1, f1_delt_n1, f2_delt_n1, delta_1_n, delta_2_n; };
+// vert_diff_down_2 for the pair (x1, x2) with tendencies (d1, d2), diffusivity diff(k) on the interface above level k.
+template <class X1, class X2, class D1, class D2, class DIFF>
+MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF diff, const double *t, int s, const double *p_half,
+                           const double *z_full, int sp, const VdiffWork &w) {
+  DownResult r;
+  double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
+  double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = p_half[0];
+  for (int k = 0; k < L; ++k) {
+    const double ph_n = p_half[(k + 1) * sp];
+    const double mu = GRAV / (ph_n - ph_k);                                         // compute_mu
+    double nu_n = 0.0, e1, e2, x1_n = 0.0, x2_n = 0.0, t_n = 0.0, z_n = 0.0, fl1_n = 0.0, fl2_n = 0.0;
+    if (k < L - 1) {
+      t_n = t[(k + 1) * s]; z_n = z_full[(k + 1) * sp];
+      const double rho_half = 2.0 * ph_n / (RDGAS * (t_n + t_k));                     // compute_nu, no virtual temperature
+      nu_n = rho_half * diff(k + 1) / (z_k - z_n);
+      x1_n = x1(k + 1); x2_n = x2(k + 1);
+      fl1_n = nu_n * (x1_n - x1_k); fl2_n = nu_n * (x2_n - x2_k);                    // explicit_tend
+      e1 = d1(k) + mu * (fl1_n - fl1_k); e2 = d2(k) + mu * (fl2_n - fl2_k);
+    } else {
+      e1 = d1(k) - mu * fl1_k; e2 = d2(k) - mu * fl2_k;
+    }
+    const double a = (k < L - 1) ? -(mu * nu_n * delt) : 0.0;                        // compute_e
+    const double c = (k > 0) ? -(mu * nu_k * delt) : 0.0;
+    const double b = 1.0 - a - c;
+    if (k == 0) {
+      e_prev = -a / b; f1_prev = e1 / b; f2_prev = e2 / b;                           // compute_f
+      w.e[0] = e_prev; w.f1[0] = f1_prev; w.f2[0] = f2_prev;
+    } else if (k < L - 1) {
+      const double g = 1.0 / (b + c * e_prev);
+      e_prev = -a * g; f1_prev = (e1 - c * f1_prev) * g; f2_prev = (e2 - c * f2_prev) * g;
+      w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
+    } else {
+      r.mu_delt_n = mu * delt; r.nu_n = nu_k; r.e_n1 = e_prev; r.f1_delt_n1 = f1_prev * delt; r.f2_delt_n1 = f2_prev * delt;
+      r.delta_1_n = e1 * delt; r.delta_2_n = e2 * delt;
+    }
+    fl1_k = fl1_n; fl2_k = fl2_n; nu_k = nu_n; x1_k = x1_n; x2_k = x2_n; t_k = t_n; z_k = z_n; ph_k = ph_n;
+  }
+  return r;
 }
 }  // namespace vd
 
-// gcm_vert_diff_down for one column.  u, v, t, q: previous time level; p_half, p_full, z_full: current; dt_*: accumulated
-// tendencies (dt_u, dt_v are final on return, dt_t has the dissipative heating added).  Leaves e, f_t, f_q in w.
-template <int LMAX>
-MP_HD void vert_diff_down(int L, double delt, const double *u, const double *v, const double *t, const double *q, int s, const double *diff_m,
-                          const double *diff_t, int sd, const double *p_half, const double *p_full, const double *z_full, int sp,
-                          double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u, double *dt_v, double *dt_t,
-                          const double *dt_q, int st, double *diss_heat, int sh, VdiffWork<LMAX> &w, VdiffSurf &S) {
-  const double gcp = GRAV / CP_AIR;
-  double mu[LMAX], nu[LMAX], b[LMAX], c[LMAX], g[LMAX], x1[LMAX], x2[LMAX], d1[LMAX], d2[LMAX], f1[LMAX], f2[LMAX], e[LMAX];
-  for (int k = 0; k < L; ++k) mu[k] = GRAV / (p_half[(k + 1) * sp] - p_half[k * sp]);                      // compute_mu :1033
-  auto compute_nu = [&](const double *diff) {                                                              // compute_nu :1053
-    nu[0] = 0.0;
-    for (int k = 1; k < L; ++k) {
-      const double rho_half = 2.0 * p_half[k * sp] / (RDGAS * (t[k * s] + t[(k - 1) * s]));
-      nu[k] = rho_half * diff[k * sd] / (z_full[(k - 1) * sp] - z_full[k * sp]);
-    }
-  };
-  // ---- momentum (uv_vert_diff :560-623)
-  compute_nu(diff_m);
-  for (int k = 0; k < L; ++k) { x1[k] = u[k * s]; x2[k] = v[k * s]; d1[k] = dt_u[k * st]; d2[k] = dt_v[k * st]; }
-  vd::explicit_tend(L, mu, nu, x1, d1);
-  vd::explicit_tend(L, mu, nu, x2, d2);
-  vd::compute_e<LMAX>(L, delt, mu, nu, e, b, c, g);
-  vd::compute_f(L, d1, b, c, g, f1);
-  vd::compute_f(L, d2, b, c, g, f2);
-  {
-    const double mu_delt_n = mu[L - 1] * delt, nu_n = nu[L - 1], e_n1 = e[L - 2];
-    double delta_u_n = d1[L - 1] * delt, delta_v_n = d2[L - 1] * delt;
-    vd::diff_surface(mu_delt_n, nu_n, e_n1, f1[L - 2] * delt, dtau_du, tau_u, 1.0, delta_u_n);
-    vd::diff_surface(mu_delt_n, nu_n, e_n1, f2[L - 2] * delt, dtau_dv, tau_v, 1.0, delta_v_n);
-    S.delta_u = delta_u_n; S.delta_v = delta_v_n;
-    double xu = delta_u_n / delt, xv = delta_v_n / delt;
-    const double half_delt = 0.5 * delt, cp_inv = 1.0 / CP_AIR;
-    for (int k = L - 1; k >= 0; --k) {
-      if (k < L - 1) { xu = e[k] * xu + f1[k]; xv = e[k] * xv + f2[k]; }
-      const double du = xu - dt_u[k * st], dv = xv - dt_v[k * st];
-      const double dh = -cp_inv * ((u[k * s] + half_delt * du) * du + (v[k * s] + half_delt * dv) * dv);
-      dt_u[k * st] = xu; dt_v[k * st] = xv;
-      dt_t[k * st] = dt_t[k * st] + dh;
-      if (diss_heat) diss_heat[k * sh] = dh;
-    }
+// uv_vert_diff (:560-623): dt_u, dt_v become the final tendencies, the dissipated kinetic energy is added to dt_t.
+template <class DIFFM>
+MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
+                              const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u,
+                              double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
+  const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return u[k * s]; }, [&](int k) { return v[k * s]; },
+                                         [&](int k) { return dt_u[k * st]; }, [&](int k) { return dt_v[k * st]; }, diff_m, t, s, p_half, z_full, sp, w);
+  double delta_u_n = r.delta_1_n, delta_v_n = r.delta_2_n;
+  vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f1_delt_n1, dtau_du, tau_u, 1.0, delta_u_n);
+  vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f2_delt_n1, dtau_dv, tau_v, 1.0, delta_v_n);
+  S.delta_u = delta_u_n; S.delta_v = delta_v_n;
+  double xu = delta_u_n / delt, xv = delta_v_n / delt;                              // vert_diff_up (:914-947)
+  const double half_delt = 0.5 * delt, cp_inv = 1.0 / CP_AIR;
+  for (int k = L - 1; k >= 0; --k) {
+    if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw]; }
+    const double du = xu - dt_u[k * st], dv = xv - dt_v[k * st];
+    const double dh = -cp_inv * ((u[k * s] + half_delt * du) * du + (v[k * s] + half_delt * dv) * dv);
+    dt_u[k * st] = xu; dt_v[k * st] = xv;
+    dt_t[k * st] = dt_t[k * st] + dh;
+    if (diss_heat) diss_heat[k * sh] = dh;
   }
-  // ---- dry static energy and humidity (vert_diff_down_2 :814-878)
-  compute_nu(diff_t);
-  for (int k = 0; k < L; ++k) { x1[k] = t[k * s] + z_full[k * sp] * gcp; x2[k] = q[k * s]; d1[k] = dt_t[k * st]; d2[k] = dt_q[k * st]; }
-  vd::explicit_tend(L, mu, nu, x1, d1);
-  vd::explicit_tend(L, mu, nu, x2, d2);
-  vd::compute_e<LMAX>(L, delt, mu, nu, w.e, b, c, g);
-  vd::compute_f(L, d1, b, c, g, w.f_t);
-  vd::compute_f(L, d2, b, c, g, w.f_q);
-  const double mu_delt_n = mu[L - 1] * delt, nu_n = nu[L - 1], e_n1 = w.e[L - 2];
-  S.delta_t = d1[L - 1] * delt + mu_delt_n * nu_n * (w.f_t[L - 2] * delt);
-  S.dflux_t = -nu_n * (1.0 - e_n1);
-  S.delta_q = d2[L - 1] * delt + mu_delt_n * nu_n * (w.f_q[L - 2] * delt);
-  S.dflux_q = -nu_n * (1.0 - e_n1);
-  S.dtmass = mu_delt_n;
+}
+// vert_diff_down_2 for dry static energy and humidity + the Tri_surf hand-over (gcm_vert_diff_down :372-404)
+template <class DIFFT>
+MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double *q, int s, DIFFT diff_t, const double *p_half,
+                               const double *z_full, int sp, const double *dt_t, const double *dt_q, int st, const VdiffWork &w, VdiffSurf &S) {
+  const double gcp = GRAV / CP_AIR;
+  const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return t[k * s] + z_full[k * sp] * gcp; }, [&](int k) { return q[k * s]; },
+                                         [&](int k) { return dt_t[k * st]; }, [&](int k) { return dt_q[k * st]; }, diff_t, t, s, p_half, z_full, sp, w);
+  S.delta_t = r.delta_1_n + r.mu_delt_n * r.nu_n * r.f1_delt_n1;
+  S.dflux_t = -r.nu_n * (1.0 - r.e_n1);
+  S.delta_q = r.delta_2_n + r.mu_delt_n * r.nu_n * r.f2_delt_n1;
+  S.dflux_q = -r.nu_n * (1.0 - r.e_n1);
+  S.dtmass = r.mu_delt_n;
+}
+// gcm_vert_diff_up: final dt_t, dt_q
+MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st) {
+  double xt = S.delta_t / delt, xq = S.delta_q / delt;
+  dt_t[(L - 1) * st] = xt; dt_q[(L - 1) * st] = xq;
+  for (int k = L - 2; k >= 0; --k) {
+    const double e = w.e[k * w.sw];
+    xt = e * xt + w.f1[k * w.sw]; xq = e * xq + w.f2[k * w.sw];
+    dt_t[k * st] = xt; dt_q[k * st] = xq;
+  }
 }
 
 // mixed_layer (atmos_spectral/driver/solo/mixed_layer.F90:568-720): slab ocean of uniform heat capacity closing the implicit
@@ -719,13 +742,6 @@ MP_HD void mixed_layer(const MixedLayerParams &p, double dt, double &t_surf, dou
   t_surf = t_surf + delta_t_surf;
   S.delta_t = fn_t + en_t * delta_t_surf;
   if (p.evaporation) S.delta_q = fn_q + en_q * delta_t_surf;
-}
-
-// gcm_vert_diff_up: final dt_t, dt_q
-template <int LMAX>
-MP_HD void vert_diff_up(int L, double delt, const VdiffWork<LMAX> &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st) {
-  vd::diff_up(L, delt, w.e, w.f_t, S.delta_t, dt_t, st);
-  vd::diff_up(L, delt, w.e, w.f_q, S.delta_q, dt_q, st);
 }
 
 }  // namespace moist

@@ -34,7 +34,8 @@ void mh_lookup_es_des(int n, const double *t, double *es, double *des) {
 void mh_lscale_cond(int L, int ncol, const double *tin, const double *qin, const double *pfull, const double *phalf, double *tdel,
                     double *qdel, double *rain) {
   const SatTable st = sat();
-  for (int c = 0; c < ncol; ++c) lscale_cond<64>(st, L, tin + c, qin + c, ncol, pfull + c, phalf + c, ncol, tdel + c, qdel + c, ncol, rain[c]);
+  for (int c = 0; c < ncol; ++c) lscale_cond(st, L, [&](int k) { return tin[k * ncol + c]; }, [&](int k) { return qin[k * ncol + c]; }, pfull + c, phalf + c, ncol,
+                                             [&](int k, double td, double qd) { tdel[k * ncol + c] = td; qdel[k * ncol + c] = qd; }, rain[c]);
 }
 void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const double *albedo, const double *t_surf, const double *t,
                  const double *p_half, double *net_sw, double *lw_down_surf, double *tdt) {
@@ -42,8 +43,8 @@ void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const doubl
   std::vector<double> lwd(L + 1), ltr(L);
   for (int c = 0; c < ncol; ++c) {
     double ins, tau0;
-    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), ins, tau0, net_sw[c], lw_down_surf[c]);
-    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), ins, tau0, tdt + c, ncol);
+    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, ins, tau0, net_sw[c], lw_down_surf[c]);
+    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, ins, tau0, tdt + c, ncol);
   }
 }
 // out: 21 doubles per column in the order of struct SurfFlux
@@ -68,9 +69,12 @@ void mh_diffusivity(int L, int ncol, double dt, const double *tm, const double *
                     const double *vdt, const double *z_full, const double *z_half, const double *u_star, const double *b_star, double *h,
                     double *k_m, double *k_t) {
   MoParams mo; DiffusivityParams dp;
-  for (int c = 0; c < ncol; ++c)
-    pbl_diffusivity<64>(mo, dp, L, dt, tm + c, um + c, vm + c, ncol, tdt + c, udt + c, vdt + c, ncol, z_full + c, z_half + c, ncol, u_star[c],
-                        b_star[c], h[c], k_m + c, k_t + c, ncol);
+  for (int c = 0; c < ncol; ++c) {
+    h[c] = pbl_depth(dp, L, dt, tm + c, um + c, vm + c, ncol, tdt + c, udt + c, vdt + c, ncol, z_full + c, z_half + c, ncol);
+    PblProfile pr;
+    pr.init(mo, dp, h[c], u_star[c], b_star[c], z_half + c, ncol, L);
+    for (int k = 0; k < L; ++k) { k_m[k * ncol + c] = pr.k_m(k); k_t[k * ncol + c] = pr.k_t(k); }
+  }
 }
 // surf: 7 doubles per column (VdiffSurf) after the downward sweep; surf_ml: the same after mixed_layer
 void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u, const double *v, const double *t, const double *q,
@@ -80,11 +84,16 @@ void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u
                   const double *flux_r, const double *net_sw, const double *lw_down, const double *dhdt_surf, const double *dedt_surf,
                   const double *drdt_surf, const double *dhdt_atm, const double *dedq_atm, double *surf_ml, double *dt_t_down) {
   MixedLayerParams ml;
+  std::vector<double> we(L), wf1(L), wf2(L);
+  (void)p_full;
   for (int c = 0; c < ncol; ++c) {
-    VdiffWork<64> w; VdiffSurf S;
+    VdiffWork w{we.data(), wf1.data(), wf2.data(), 1};
+    VdiffSurf S;
     double tu = flux_u[c], tv = flux_v[c];
-    vert_diff_down<64>(L, delt, u + c, v + c, t + c, q + c, ncol, diff_m + c, diff_t + c, ncol, p_half + c, p_full + c, z_full + c, ncol, tu,
-                       tv, dtau_du[c], dtau_dv[c], dt_u + c, dt_v + c, dt_t + c, dt_q + c, ncol, diss_heat + c, ncol, w, S);
+    vert_diff_momentum(L, delt, u + c, v + c, t + c, ncol, [&](int k) { return diff_m[k * ncol + c]; }, p_half + c, z_full + c, ncol, tu, tv,
+                       dtau_du[c], dtau_dv[c], dt_u + c, dt_v + c, dt_t + c, ncol, diss_heat + c, ncol, w, S);
+    vert_diff_heat_down(L, delt, t + c, q + c, ncol, [&](int k) { return diff_t[k * ncol + c]; }, p_half + c, z_full + c, ncol, dt_t + c,
+                        dt_q + c, ncol, w, S);
     const double a[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
     for (int i = 0; i < 7; ++i) surf[c * 7 + i] = a[i];
     for (int k = 0; k < L; ++k) dt_t_down[k * ncol + c] = dt_t[k * ncol + c];
@@ -92,7 +101,7 @@ void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u
                 drdt_surf[c], dhdt_atm[c], dedq_atm[c]);
     const double b[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
     for (int i = 0; i < 7; ++i) surf_ml[c * 7 + i] = b[i];
-    vert_diff_up<64>(L, delt, w, S, dt_t + c, dt_q + c, ncol);
+    vert_diff_up(L, delt, w, S, dt_t + c, dt_q + c, ncol);
   }
 }
 }
