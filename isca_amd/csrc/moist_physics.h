@@ -11,8 +11,20 @@
 #endif
 #if defined(__HIPCC__)
 #define MP_HD __host__ __device__ __forceinline__
+#define MP_UNROLL _Pragma("unroll 4")
 #else
 #define MP_HD inline
+#define MP_UNROLL
+#endif
+#define MP_R __restrict__
+// Level loops run in chunks of MP_U levels: all global loads of a chunk are issued first (one memory round trip per chunk
+// instead of one per level: a column is a chain of dependent recurrences, and a GPU thread walking it level by level waits a
+// full memory latency per level), then the recurrence is advanced, then the chunk's results are stored.
+#define MP_U 8
+#if defined(__HIPCC__)
+#define MP_UNROLL_ALL _Pragma("unroll")
+#else
+#define MP_UNROLL_ALL
 #endif
 
 namespace moist {
@@ -62,27 +74,42 @@ template <class TIN, class QIN, class OUT>
 MP_HD void lscale_cond(const SatTable &st, int L, TIN tin, QIN qin, const double *pfull, const double *phalf, int s, OUT out, double &rain) {
   const double hlcp = HLV / CP_AIR;
   double exq = 0.0, precip = 0.0;
-  for (int k = 0; k < L; ++k) {
-    double qsat, dqsat;
-    const double tk = tin(k), qk = qin(k);
-    compute_qs(st, tk, pfull[k * s], qsat, dqsat);
-    double qd = 0.0, td = 0.0;
-    if ((qk - qsat) * qsat > 0.0) {
-      qd = (qsat - qk) / (1.0 + hlcp * dqsat);
-      td = -hlcp * qd;
+  double ph_k = phalf[0];
+  for (int k0 = 0; k0 < L; k0 += MP_U) {
+    double tk[MP_U], qk[MP_U], pf[MP_U], phn[MP_U], qsat[MP_U], dqsat[MP_U], tdo[MP_U], qdo[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 + i < L) ? k0 + i : L - 1;
+      tk[i] = tin(k); qk[i] = qin(k); pf[i] = pfull[k * s]; phn[i] = phalf[(k + 1) * s];
     }
-    const double pmass = (phalf[(k + 1) * s] - phalf[k * s]) / GRAV;
-    if (qd < 0.0) exq = exq - qd * pmass;
-    if (qd >= 0.0 && exq > 0.0) {                 // evaporate precip where needed
-      exq = exq / pmass;
-      double def = (qsat - qk) / (1. + hlcp * dqsat);
-      def = fmin(fmax(def, 0.0), exq);
-      qd = qd + def;
-      td = td - def * hlcp;
-      exq = (exq - def) * pmass;
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) compute_qs(st, tk[i], pf[i], qsat[i], dqsat[i]);
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      double qd = 0.0, td = 0.0;
+      if (k0 + i < L) {
+        if ((qk[i] - qsat[i]) * qsat[i] > 0.0) {
+          qd = (qsat[i] - qk[i]) / (1.0 + hlcp * dqsat[i]);
+          td = -hlcp * qd;
+        }
+        const double pmass = (phn[i] - ph_k) / GRAV;
+        if (qd < 0.0) exq = exq - qd * pmass;
+        if (qd >= 0.0 && exq > 0.0) {                 // evaporate precip where needed
+          exq = exq / pmass;
+          double def = (qsat[i] - qk[i]) / (1. + hlcp * dqsat[i]);
+          def = fmin(fmax(def, 0.0), exq);
+          qd = qd + def;
+          td = td - def * hlcp;
+          exq = (exq - def) * pmass;
+        }
+        precip = precip - pmass * qd;
+        ph_k = phn[i];
+      }
+      tdo[i] = td; qdo[i] = qd;
     }
-    out(k, td, qd);
-    precip = precip - pmass * qd;
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      if (k0 + i < L) out(k0 + i, tdo[i], qdo[i]);
   }
   rain = fmax(precip, 0.0);
 }
@@ -110,16 +137,27 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pow(p_half[0] / PSTD_MKS, p.wv_exponent));
   lw_down[0] = 0.;
   double lwd = 0.;
-  for (int k = 0; k < L; ++k) {
-    const double ph = p_half[(k + 1) * s];
-    const double tau_n = lw_tau_0 * (p.linear_tau * ph / PSTD_MKS + (1.0 - p.linear_tau) * pow(ph / PSTD_MKS, p.wv_exponent));
-    const double dtr = exp(-(tau_n - tau_k));
-    lw_dtrans[k * sw] = dtr;
-    const double tk = t[k * s];
-    const double b = STEFAN * pow4(tk);
-    lwd = lwd * dtr + b * (1. - dtr);
-    lw_down[(k + 1) * sw] = lwd;
-    tau_k = tau_n;
+  for (int k0 = 0; k0 < L; k0 += MP_U) {
+    double ph[MP_U], tk[MP_U], tau_n[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 + i < L) ? k0 + i : L - 1;
+      ph[i] = p_half[(k + 1) * s]; tk[i] = t[k * s];
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      tau_n[i] = lw_tau_0 * (p.linear_tau * ph[i] / PSTD_MKS + (1.0 - p.linear_tau) * pow(ph[i] / PSTD_MKS, p.wv_exponent));
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      if (k0 + i < L) {
+        const double dtr = exp(-(tau_n[i] - tau_k));
+        lw_dtrans[(k0 + i) * sw] = dtr;
+        const double b = STEFAN * pow4(tk[i]);
+        lwd = lwd * dtr + b * (1. - dtr);
+        lw_down[(k0 + i + 1) * sw] = lwd;
+        tau_k = tau_n[i];
+      }
+    }
   }
   surf_lw_down = lwd;
   const double sw_surf = insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent));
@@ -129,19 +167,36 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, const double *p_half, int s,
                        const double *lw_down, const double *lw_dtrans, int sw, double insolation, double sw_tau_0, double *tdt, int st) {
   const double b_surf = STEFAN * pow4(t_surf);
-  const double sw_up = albedo * (insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
+  const double ph_surf = p_half[L * s];
+  const double sw_up = albedo * (insolation * exp(-sw_tau_0 * pow(ph_surf / PSTD_MKS, p.solar_exponent)));
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
-  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent)));
-  for (int k = L - 1; k >= 0; --k) {
-    const double tk = t[k * s];
-    const double b = STEFAN * pow4(tk);
-    const double dtr = lw_dtrans[k * sw];
-    const double lw_up_k = lw_up_n * dtr + b * (1.0 - dtr);
-    const double sw_down_k = insolation * exp(-sw_tau_0 * pow(p_half[k * s] / PSTD_MKS, p.solar_exponent));
-    const double flux_k = (lw_up_k - lw_down[k * sw]) + (sw_up - sw_down_k);
-    const double tdt_rad = p.diabatic_acce * (flux_n - flux_k) * GRAV / (CP_AIR * (p_half[(k + 1) * s] - p_half[k * s]));
-    tdt[k * st] = tdt[k * st] + tdt_rad;
-    lw_up_n = lw_up_k; flux_n = flux_k;
+  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - insolation * exp(-sw_tau_0 * pow(ph_surf / PSTD_MKS, p.solar_exponent)));
+  double ph_n = ph_surf;
+  for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
+    double tk[MP_U], ph[MP_U], td[MP_U], swd[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      tk[i] = t[k * s]; ph[i] = p_half[k * s]; td[i] = tdt[k * st];
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) swd[i] = insolation * exp(-sw_tau_0 * pow(ph[i] / PSTD_MKS, p.solar_exponent));
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 - i;
+      if (k >= 0) {
+        const double b = STEFAN * pow4(tk[i]);
+        const double dtr = lw_dtrans[k * sw];
+        const double lw_up_k = lw_up_n * dtr + b * (1.0 - dtr);
+        const double flux_k = (lw_up_k - lw_down[k * sw]) + (sw_up - swd[i]);
+        const double tdt_rad = p.diabatic_acce * (flux_n - flux_k) * GRAV / (CP_AIR * (ph_n - ph[i]));
+        td[i] = td[i] + tdt_rad;
+        lw_up_n = lw_up_k; flux_n = flux_k; ph_n = ph[i];
+      }
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      if (k0 - i >= 0) tdt[(k0 - i) * st] = td[i];
   }
 }
 
@@ -512,16 +567,28 @@ MP_HD void surface_flux(const SatTable &st, const MoParams &mo, double t_atm, do
 struct RayleighParams { int nlev_rayfric = 0; double rfactr = 0.0, sponge_pbottom = 50.0; bool conserve_energy = true; };
 MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pfull, const double *u, const double *v, int s, double *udt,
                             double *vdt, double *tdt, int st) {
-  for (int k = 0; k < p.nlev_rayfric; ++k) {
-    double ut = 0.0, vt = 0.0;
-    if (pfull[k * s] < p.sponge_pbottom) {
-      const double d = p.sponge_pbottom - pfull[k * s];
-      const double fact = p.rfactr * (d * d) / (p.sponge_pbottom * p.sponge_pbottom);
-      ut = -u[k * s] * fact; vt = -v[k * s] * fact;
+  for (int k0 = 0; k0 < p.nlev_rayfric; k0 += MP_U) {
+    double pf[MP_U], uk[MP_U], vk[MP_U], ud[MP_U], vd[MP_U], td[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 + i < p.nlev_rayfric) ? k0 + i : p.nlev_rayfric - 1;
+      pf[i] = pfull[k * s]; uk[i] = u[k * s]; vk[i] = v[k * s]; ud[i] = udt[k * st]; vd[i] = vdt[k * st]; td[i] = tdt[k * st];
     }
-    udt[k * st] = udt[k * st] + ut;
-    vdt[k * st] = vdt[k * st] + vt;
-    if (p.conserve_energy) tdt[k * st] = tdt[k * st] + (-((u[k * s] + .5 * dt * ut) * ut + (v[k * s] + .5 * dt * vt) * vt) / CP_AIR);
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 + i;
+      if (k < p.nlev_rayfric) {
+        double ut = 0.0, vt = 0.0;
+        if (pf[i] < p.sponge_pbottom) {
+          const double d = p.sponge_pbottom - pf[i];
+          const double fact = p.rfactr * (d * d) / (p.sponge_pbottom * p.sponge_pbottom);
+          ut = -uk[i] * fact; vt = -vk[i] * fact;
+        }
+        udt[k * st] = ud[i] + ut;
+        vdt[k * st] = vd[i] + vt;
+        if (p.conserve_energy) tdt[k * st] = td[i] + (-((uk[i] + .5 * dt * ut) * ut + (vk[i] + .5 * dt * vt) * vt) / CP_AIR);
+      }
+    }
   }
 }
 
@@ -550,20 +617,28 @@ MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const doub
                        const double *tdt, const double *udt, const double *vdt, int st, const double *z_full, const double *z_half, int sz) {
   const double gcp = GRAV / CP_AIR;
   const double z_surf = z_half[L * sz];
-  auto rich_at = [&](int k, double tbot, double &zf) {
-    zf = z_full[k * sz] - z_surf;
-    const double svcp = (tm[k * s] + dt * tdt[k * st]) + gcp * zf;
-    const double uu = um[k * s] + dt * udt[k * st], vv = vm[k * s] + dt * vdt[k * st];
-    return zf * GRAV * (svcp - tbot) / tbot / (uu * uu + vv * vv + dp.small);
-  };
-  const double tbot = (tm[(L - 1) * s] + dt * tdt[(L - 1) * st]) + gcp * (z_full[(L - 1) * sz] - z_surf);
-  double h1, rich1 = rich_at(L - 1, tbot, h1);
-  double h = h1;
-  for (int k = L - 2; k >= 0; --k) {
-    double h2;
-    const double rich2 = rich_at(k, tbot, h2);
-    if (rich2 > dp.rich_crit_pbl) { h = h2 + (h1 - h2) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1); break; }
-    rich1 = rich2; h1 = h2;
+  double tbot = 0.0, h1 = 0.0, rich1 = 0.0, h = 0.0;
+  for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
+    double zf[MP_U], tt[MP_U], uu[MP_U], vv[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      zf[i] = z_full[k * sz]; tt[i] = tm[k * s]; uu[i] = um[k * s]; vv[i] = vm[k * s];
+      const double a = tdt[k * st], b = udt[k * st], c = vdt[k * st];
+      tt[i] = tt[i] + dt * a; uu[i] = uu[i] + dt * b; vv[i] = vv[i] + dt * c;
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 - i;
+      if (k < 0) break;
+      const double zfa = zf[i] - z_surf;
+      const double svcp = tt[i] + gcp * zfa;
+      if (k == L - 1) tbot = svcp;
+      const double rich2 = zfa * GRAV * (svcp - tbot) / tbot / (uu[i] * uu[i] + vv[i] * vv[i] + dp.small);
+      if (k == L - 1) { h1 = zfa; h = h1; rich1 = rich2; continue; }
+      if (rich2 > dp.rich_crit_pbl) return zfa + (h1 - zfa) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1);
+      rich1 = rich2; h1 = zfa;
+    }
   }
   return h;
 }
@@ -632,35 +707,46 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
   DownResult r;
   double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
   double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = p_half[0];
-  for (int k = 0; k < L; ++k) {
-    const double ph_n = p_half[(k + 1) * sp];
-    const double mu = GRAV / (ph_n - ph_k);                                         // compute_mu
-    double nu_n = 0.0, e1, e2, x1_n = 0.0, x2_n = 0.0, t_n = 0.0, z_n = 0.0, fl1_n = 0.0, fl2_n = 0.0;
-    if (k < L - 1) {
-      t_n = t[(k + 1) * s]; z_n = z_full[(k + 1) * sp];
-      const double rho_half = 2.0 * ph_n / (RDGAS * (t_n + t_k));                     // compute_nu, no virtual temperature
-      nu_n = rho_half * diff(k + 1) / (z_k - z_n);
-      x1_n = x1(k + 1); x2_n = x2(k + 1);
-      fl1_n = nu_n * (x1_n - x1_k); fl2_n = nu_n * (x2_n - x2_k);                    // explicit_tend
-      e1 = d1(k) + mu * (fl1_n - fl1_k); e2 = d2(k) + mu * (fl2_n - fl2_k);
-    } else {
-      e1 = d1(k) - mu * fl1_k; e2 = d2(k) - mu * fl2_k;
+  for (int k0 = 0; k0 < L; k0 += MP_U) {
+    double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {       // everything level k0+i needs from memory: its own tendencies, the fields of the level below
+      const int k = (k0 + i < L) ? k0 + i : L - 1, kn = (k + 1 < L) ? k + 1 : L - 1;
+      phn[i] = p_half[(k + 1) * sp]; tn[i] = t[kn * s]; zn[i] = z_full[kn * sp]; x1n[i] = x1(kn); x2n[i] = x2(kn);
+      dd1[i] = d1(k); dd2[i] = d2(k); df[i] = diff(kn);
     }
-    const double a = (k < L - 1) ? -(mu * nu_n * delt) : 0.0;                        // compute_e
-    const double c = (k > 0) ? -(mu * nu_k * delt) : 0.0;
-    const double b = 1.0 - a - c;
-    if (k == 0) {
-      e_prev = -a / b; f1_prev = e1 / b; f2_prev = e2 / b;                           // compute_f
-      w.e[0] = e_prev; w.f1[0] = f1_prev; w.f2[0] = f2_prev;
-    } else if (k < L - 1) {
-      const double g = 1.0 / (b + c * e_prev);
-      e_prev = -a * g; f1_prev = (e1 - c * f1_prev) * g; f2_prev = (e2 - c * f2_prev) * g;
-      w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
-    } else {
-      r.mu_delt_n = mu * delt; r.nu_n = nu_k; r.e_n1 = e_prev; r.f1_delt_n1 = f1_prev * delt; r.f2_delt_n1 = f2_prev * delt;
-      r.delta_1_n = e1 * delt; r.delta_2_n = e2 * delt;
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 + i;
+      if (k < L) {
+        const double ph_n = phn[i];
+        const double mu = GRAV / (ph_n - ph_k);                                       // compute_mu
+        double nu_n = 0.0, e1, e2, fl1_n = 0.0, fl2_n = 0.0;
+        if (k < L - 1) {
+          const double rho_half = 2.0 * ph_n / (RDGAS * (tn[i] + t_k));               // compute_nu, no virtual temperature
+          nu_n = rho_half * df[i] / (z_k - zn[i]);
+          fl1_n = nu_n * (x1n[i] - x1_k); fl2_n = nu_n * (x2n[i] - x2_k);             // explicit_tend
+          e1 = dd1[i] + mu * (fl1_n - fl1_k); e2 = dd2[i] + mu * (fl2_n - fl2_k);
+        } else {
+          e1 = dd1[i] - mu * fl1_k; e2 = dd2[i] - mu * fl2_k;
+        }
+        const double a = (k < L - 1) ? -(mu * nu_n * delt) : 0.0;                      // compute_e
+        const double c = (k > 0) ? -(mu * nu_k * delt) : 0.0;
+        const double b = 1.0 - a - c;
+        if (k == 0) {
+          e_prev = -a / b; f1_prev = e1 / b; f2_prev = e2 / b;                         // compute_f
+          w.e[0] = e_prev; w.f1[0] = f1_prev; w.f2[0] = f2_prev;
+        } else if (k < L - 1) {
+          const double g = 1.0 / (b + c * e_prev);
+          e_prev = -a * g; f1_prev = (e1 - c * f1_prev) * g; f2_prev = (e2 - c * f2_prev) * g;
+          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
+        } else {
+          r.mu_delt_n = mu * delt; r.nu_n = nu_k; r.e_n1 = e_prev; r.f1_delt_n1 = f1_prev * delt; r.f2_delt_n1 = f2_prev * delt;
+          r.delta_1_n = e1 * delt; r.delta_2_n = e2 * delt;
+        }
+        fl1_k = fl1_n; fl2_k = fl2_n; nu_k = nu_n; x1_k = x1n[i]; x2_k = x2n[i]; t_k = tn[i]; z_k = zn[i]; ph_k = ph_n;
+      }
     }
-    fl1_k = fl1_n; fl2_k = fl2_n; nu_k = nu_n; x1_k = x1_n; x2_k = x2_n; t_k = t_n; z_k = z_n; ph_k = ph_n;
   }
   return r;
 }
@@ -679,13 +765,32 @@ MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double 
   S.delta_u = delta_u_n; S.delta_v = delta_v_n;
   double xu = delta_u_n / delt, xv = delta_v_n / delt;                              // vert_diff_up (:914-947)
   const double half_delt = 0.5 * delt, cp_inv = 1.0 / CP_AIR;
-  for (int k = L - 1; k >= 0; --k) {
-    if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw]; }
-    const double du = xu - dt_u[k * st], dv = xv - dt_v[k * st];
-    const double dh = -cp_inv * ((u[k * s] + half_delt * du) * du + (v[k * s] + half_delt * dv) * dv);
-    dt_u[k * st] = xu; dt_v[k * st] = xv;
-    dt_t[k * st] = dt_t[k * st] + dh;
-    if (diss_heat) diss_heat[k * sh] = dh;
+  for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
+    double uk[MP_U], vk[MP_U], du0[MP_U], dv0[MP_U], dt0[MP_U], dh[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      uk[i] = u[k * s]; vk[i] = v[k * s]; du0[i] = dt_u[k * st]; dv0[i] = dt_v[k * st]; dt0[i] = dt_t[k * st];
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 - i;
+      if (k >= 0) {
+        if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw]; }
+        const double du = xu - du0[i], dv = xv - dv0[i];
+        dh[i] = -cp_inv * ((uk[i] + half_delt * du) * du + (vk[i] + half_delt * dv) * dv);
+        du0[i] = xu; dv0[i] = xv;
+        dt0[i] = dt0[i] + dh[i];
+      }
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 - i;
+      if (k >= 0) {
+        dt_u[k * st] = du0[i]; dt_v[k * st] = dv0[i]; dt_t[k * st] = dt0[i];
+        if (diss_heat) diss_heat[k * sh] = dh[i];
+      }
+    }
   }
 }
 // vert_diff_down_2 for dry static energy and humidity + the Tri_surf hand-over (gcm_vert_diff_down :372-404)
@@ -705,6 +810,7 @@ MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double
 MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st) {
   double xt = S.delta_t / delt, xq = S.delta_q / delt;
   dt_t[(L - 1) * st] = xt; dt_q[(L - 1) * st] = xq;
+  MP_UNROLL
   for (int k = L - 2; k >= 0; --k) {
     const double e = w.e[k * w.sw];
     xt = e * xt + w.f1[k * w.sw]; xq = e * xq + w.f2[k * w.sw];
