@@ -730,7 +730,8 @@ static StepScalars step_scalars(isca_dyn *h) {
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   if (h->cfg.physics == 1) {
-    Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream);
+    { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream); }
+    { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream); }
     h->phys_calls++;
   }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }

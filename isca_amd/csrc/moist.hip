@@ -199,13 +199,75 @@ static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
 }
 
 // physics of one step on the model state: previous-level fields, pressures of both levels, heights of the current one
+// compute_pressures_and_heights (press_and_geopot.F90:363-387, flat surface, no virtual temperature) of both time levels
+// (atmosphere.F90:296-303) in one launch: blockIdx.y = 0 -> previous level (pressures only: nothing reads its heights),
+// 1 -> current level (pressures and heights).  One bottom-up pass per column; the temperatures of 8 levels are loaded together.
+struct PressArgs {
+  const double *pk, *bk;
+  const double *t[2], *ps[2];
+  double *p_full[2], *p_half[2], *z_full, *z_half;
+  int ncol, L;
+};
+__global__ __launch_bounds__(64) void k_moist_pressures(PressArgs a) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= a.ncol) return;
+  const int tl = blockIdx.y, L = a.L;
+  const size_t c = (size_t)col, s = (size_t)a.ncol;
+  const bool heights = tl == 1;
+  const double ps = a.ps[tl][c];
+  const double *pk = a.pk, *bk = a.bk;
+  const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
+  const int ktop = (pk[0] == 0.0) ? 1 : 0;
+  double *p_full = a.p_full[tl] + c, *p_half = a.p_half[tl] + c;
+  const double *t = a.t[tl] + c;
+  double gh = 0.0;
+  double ph1 = pk[L] + bk[L] * ps, l1 = log(ph1);
+  p_half[(size_t)L * s] = ph1;
+  if (heights) a.z_half[c + (size_t)L * s] = 0.0;
+  for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
+    double tk[8], ph0[8], l0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      tk[i] = heights ? t[(size_t)k * s] : 0.0;
+      ph0[i] = pk[k] + bk[k] * ps;
+      l0[i] = (top0 && k == 0) ? 0.0 : log(ph0[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 - i;
+      if (k >= 0) {
+        double lf;
+        if (top0 && k == 0) lf = l1 - 1.0;
+        else lf = l1 - (1.0 - ph0[i] * (l1 - l0[i]) / (ph1 - ph0[i]));
+        p_full[(size_t)k * s] = exp(lf);
+        p_half[(size_t)k * s] = ph0[i];
+        if (heights) {
+          a.z_full[c + (size_t)k * s] = (gh + RDGAS * tk[i] * (l1 - lf)) / GRAV;
+          if (k >= ktop) gh = gh + RDGAS * tk[i] * (l1 - l0[i]);
+          a.z_half[c + (size_t)k * s] = (k >= ktop) ? gh / GRAV : 0.0;
+        }
+        ph1 = ph0[i]; l1 = l0[i];
+      }
+    }
+  }
+}
+void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Dev &d = h.d;
+  const size_t lev = (size_t)h.g.Jl * h.g.I;
+  double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
+  double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L;
+  PressArgs a;
+  a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L;
+  a.t[0] = d.tg[sc.prev]; a.ps[0] = d.psg[sc.prev]; a.t[1] = d.tg[sc.cur]; a.ps[1] = d.psg[sc.cur];
+  a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
+  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 63) / 64), 2), dim3(64), 0, s, a);
+}
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
   const size_t lev = (size_t)h.g.Jl * h.g.I;
   double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
   double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L, *zf_p = zh_c + lev * (h.g.L + 1), *zh_p = zf_p + lev * h.g.L;
-  launch_pressures_heights(h, d.tg[sc.prev], d.psg[sc.prev], pf_p, ph_p, zf_p, zh_p, s);
-  launch_pressures_heights(h, d.tg[sc.cur], d.psg[sc.cur], pf_c, ph_c, zf_c, zh_c, s);
   MoistArgs a = moist_args(h);
   a.ncol = (int)lev; a.I = h.g.I;
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
