@@ -1515,3 +1515,4 @@ extern "C" int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int 
   t.enabled = enable != 0;
   API_END
 }
+#include "shallow.inc"

@@ -10,6 +10,26 @@ struct StepScalars {      // per-step scalars passed by value to kernels
   int prev, cur, fut;
 };
 
+// ---- shallow-water sibling core (kernels.hip, "Shallow-water sibling core")
+struct SwGridArgs {
+  const double *u, *v, *vor, *div, *h, *up, *vp, *hp, *dxh, *dyh, *coriolis, *h_eq, *deep;
+  double kappa_m, kappa_t;
+  double *tend_u, *tend_v, *tend_h, *bg, *pv;
+  int n, I;
+};
+struct SwSpecArgs {
+  const double *coef;
+  const double2 *vor_p, *div_p, *h_p;
+  double2 *vor_c, *div_c, *h_c, *vor_f, *div_f, *h_f;
+  const double2 *dt_vor, *dt_div, *dt_h, *bs;
+  double delta_t, robert, h_0;
+  int first, mode;
+};
+void launch_sw_grid_tend(const SwGridArgs &a, hipStream_t s);
+void launch_sw_spec_update(const Geom &g, const SwSpecArgs &a, hipStream_t s);
+void launch_sw_grid_tracer_filter(int n, double robert, const double *prev, double *cur, const double *adv, double *fut, hipStream_t s);
+void launch_sw_tracer_tend(int n, const double *u, const double *v, const double *dx, const double *dy, double *tend, hipStream_t s);
+
 // ---- transforms
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s);
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s);

@@ -2283,6 +2283,97 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
 }
 
 // =====================================================================================================
+// Shallow-water sibling core (src/atmos_spectral_shallow): the grid-point and spectral parts of one step; the transforms
+// are the 3-D core's own kernels run with one level.
+// =====================================================================================================
+// shallow_physics (shallow_physics.F90:179-194: linear drag, relaxation of h to h_eq, both at the PREVIOUS level) +
+// grid part of shallow_dynamics (shallow_dynamics.F90:421-437): vorticity flux terms, h tendency, Bernoulli function; pv (:469)
+__global__ void k_sw_grid_tend(SwGridArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int j = i / a.I;
+  const double u = a.u[i], v = a.v[i], h = a.h[i];
+  const double vorg = a.vor[i] + a.coriolis[j];
+  a.tend_u[i] = (0.0 - a.kappa_m * a.up[i]) + vorg * v;
+  a.tend_v[i] = (0.0 - a.kappa_m * a.vp[i]) - vorg * u;
+  a.tend_h[i] = ((0.0 - a.kappa_t * (a.hp[i] - a.h_eq[i])) - u * a.dxh[i] - v * a.dyh[i]) - h * a.div[i];
+  a.bg[i] = (h + a.deep[i]) + 0.5 * (u * u + v * v);
+  a.pv[i] = vorg / h;
+}
+void launch_sw_grid_tend(const SwGridArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_sw_grid_tend, grid1d((size_t)a.n), dim3(256), 0, s, a); }
+
+__device__ __forceinline__ void sw_leapfrog(bool first, double delta_t, double robert, double2 prev, double2 cur, double2 dt, double2 &fut,
+                                            double2 &cur_new) {   // leapfrog_3d_complex with raw_filter_coeff = 1 (leapfrog.F90:217-247)
+  const double2 pc = make_double2(prev.x - 2.0 * cur.x, prev.y - 2.0 * cur.y);
+  if (first) {
+    fut = make_double2(prev.x + delta_t * dt.x, prev.y + delta_t * dt.y);
+    cur_new = make_double2(cur.x + robert * (pc.x + fut.x), cur.y + robert * (pc.y + fut.y));
+  } else {
+    const double2 c1 = make_double2(cur.x + robert * pc.x, cur.y + robert * pc.y);
+    fut = make_double2(prev.x + delta_t * dt.x, prev.y + delta_t * dt.y);
+    cur_new = make_double2(c1.x + robert * fut.x, c1.y + robert * fut.y);
+  }
+}
+// spectral part of shallow_dynamics (:438-455): Laplacian of the Bernoulli function, implicit_correction (:476-495), spectral
+// damping of the three tendencies (spectral_damping.F90:172-199), leapfrog with Robert filter.  mode 1: a spectral tracer instead
+// (update_spec_tracer :505-511: damping + leapfrog of one field).
+__global__ void k_sw_spec_update(Geom g, SwSpecArgs a) {
+  const int mn = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mn >= g.Ml * g.N1) return;
+  const double eig = a.coef[(size_t)C_EIG * g.Ml * g.N1 + mn], dmp = a.coef[(size_t)C_DAMP * g.Ml * g.N1 + mn];
+  const double coeff = 1.0 / (1.0 + dmp * a.delta_t);
+  if (a.mode == 1) {
+    const double2 p = a.vor_p[mn], c = a.vor_c[mn];
+    double2 dt = a.dt_vor[mn];
+    dt = make_double2(coeff * (dt.x - dmp * p.x), coeff * (dt.y - dmp * p.y));
+    double2 f, cn;
+    sw_leapfrog(a.first, a.delta_t, a.robert, p, c, dt, f, cn);
+    a.vor_c[mn] = cn; a.vor_f[mn] = f;
+    return;
+  }
+  const double2 vp = a.vor_p[mn], vc = a.vor_c[mn], dp = a.div_p[mn], dc = a.div_c[mn], hp = a.h_p[mn], hc = a.h_c[mn];
+  double2 dtv = a.dt_vor[mn], dtd = a.dt_div[mn], dth = a.dt_h[mn];
+  const double2 bs = a.bs[mn];
+  const double mu = 0.5 * a.delta_t, mu2 = mu * mu;
+  dtd = make_double2(dtd.x - (-(eig * bs.x)), dtd.y - (-(eig * bs.y)));              // dt_divs - compute_laplacian(bs)
+  dth = make_double2(dth.x + a.h_0 * (dc.x - dp.x), dth.y + a.h_0 * (dc.y - dp.y));
+  dtd = make_double2(dtd.x - eig * (hc.x - hp.x), dtd.y - eig * (hc.y - hp.y));
+  const double den = 1.0 + mu2 * eig * a.h_0;
+  dtd = make_double2((dtd.x + mu * eig * dth.x) / den, (dtd.y + mu * eig * dth.y) / den);
+  dth = make_double2(dth.x - mu * a.h_0 * dtd.x, dth.y - mu * a.h_0 * dtd.y);
+  dtv = make_double2(coeff * (dtv.x - dmp * vp.x), coeff * (dtv.y - dmp * vp.y));
+  dtd = make_double2(coeff * (dtd.x - dmp * dp.x), coeff * (dtd.y - dmp * dp.y));
+  dth = make_double2(coeff * (dth.x - dmp * hp.x), coeff * (dth.y - dmp * hp.y));
+  double2 f, cn;
+  sw_leapfrog(a.first, a.delta_t, a.robert, vp, vc, dtv, f, cn); a.vor_c[mn] = cn; a.vor_f[mn] = f;
+  sw_leapfrog(a.first, a.delta_t, a.robert, dp, dc, dtd, f, cn); a.div_c[mn] = cn; a.div_f[mn] = f;
+  sw_leapfrog(a.first, a.delta_t, a.robert, hp, hc, dth, f, cn); a.h_c[mn] = cn; a.h_f[mn] = f;
+}
+void launch_sw_spec_update(const Geom &g, const SwSpecArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sw_spec_update, grid1d((size_t)g.Ml * g.N1), dim3(256), 0, s, g, a);
+}
+// update_grid_tracer (:521-530) after the van Leer step: Robert filter of the current level, new level stored
+__global__ void k_sw_grid_tracer_filter(int n, double robert, const double *__restrict__ prev, double *cur, const double *__restrict__ adv,
+                                        double *fut) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p = prev[i], c = cur[i], f = adv[i];
+  const double cn = c + robert * (p + f - 2.0 * c);
+  cur[i] = cn; fut[i] = f;
+}
+void launch_sw_grid_tracer_filter(int n, double robert, const double *prev, double *cur, const double *adv, double *fut, hipStream_t s) {
+  hipLaunchKernelGGL(k_sw_grid_tracer_filter, grid1d((size_t)n), dim3(256), 0, s, n, robert, prev, cur, adv, fut);
+}
+// tend = tend_in - u dx - v dy for the spectral tracer (update_spec_tracer: horizontal_advection with a zero tendency)
+__global__ void k_sw_tracer_tend(int n, const double *u, const double *v, const double *dx, const double *dy, double *tend) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tend[i] = 0.0 - u[i] * dx[i] - v[i] * dy[i];
+}
+void launch_sw_tracer_tend(int n, const double *u, const double *v, const double *dx, const double *dy, double *tend, hipStream_t s) {
+  hipLaunchKernelGGL(k_sw_tracer_tend, grid1d((size_t)n), dim3(256), 0, s, n, u, v, dx, dy, tend);
+}
+
+// =====================================================================================================
 // Diagnostics: what spectral_diagnostics hands to diag_manager's send_data every step
 // (spectral_dynamics.F90:1728-1790), accumulated on the device for the time means of the diag_table.
 // u, v, T, ps, tracer: the new time level; omega = wg_full; vor, div: vorg/divg, already those of the new level

@@ -1,0 +1,173 @@
+"""Shallow-water sibling core: ctypes binding of include/isca_shallow.h and a host mirror of the reference's
+`atmosphere_mod` for src/atmos_spectral_shallow (atmosphere.F90:117-250): namelist groups `shallow_dynamics_nml`,
+`shallow_physics_nml`, `main_nml` as in exp/test_cases/shallow_water/*.py.  No CPU fallback: the library and a HIP device
+are required.  Arrays: grid [lat, lon], spectral complex [n, m] (views of the reference's Fortran (lon,lat) / (m,n))."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .dyncore import IscaError, RESOLUTIONS, load_library
+
+
+class _CShallowConfig(C.Structure):
+    _fields_ = [
+        ("num_lon", C.c_int), ("num_lat", C.c_int), ("num_fourier", C.c_int), ("num_spherical", C.c_int), ("dt_atmos", C.c_double),
+        ("damping_order", C.c_int), ("damping_coeff", C.c_double), ("robert_coeff", C.c_double), ("robert_coeff_tracer", C.c_double),
+        ("h_0", C.c_double), ("u_deep_mag", C.c_double), ("n_merid_deep_flow", C.c_double), ("u_upper_mag_init", C.c_double),
+        ("spec_tracer", C.c_int), ("grid_tracer", C.c_int),
+        ("lon_centre_init_cyc", C.c_double), ("lat_centre_init_cyc", C.c_double), ("lon_centre_init_acyc", C.c_double),
+        ("lat_centre_init_acyc", C.c_double), ("init_vortex_radius_deg", C.c_double), ("init_vortex_vor_f", C.c_double),
+        ("init_vortex_h_h_0", C.c_double), ("add_initial_vortex_pair", C.c_int), ("add_initial_vortex_as_height", C.c_int),
+        ("valid_range_v", C.c_double * 2),
+        ("fric_damp_time", C.c_double), ("therm_damp_time", C.c_double), ("phys_h_0", C.c_double), ("h_amp", C.c_double),
+        ("h_lon", C.c_double), ("h_lat", C.c_double), ("h_width", C.c_double), ("h_itcz", C.c_double), ("itcz_width", C.c_double),
+        ("device", C.c_int),
+    ]
+
+
+EXPORTED_SYMBOLS = ["isca_shallow_config_default", "isca_shallow_create", "isca_shallow_destroy", "isca_shallow_cold_start",
+                    "isca_shallow_step", "isca_shallow_get_state", "isca_shallow_set_state", "isca_shallow_get_info",
+                    "isca_shallow_set_time_pointers"]
+_UNSUPPORTED = {"fourier_inc": 1, "triang_trunc": True, "south_to_north": True, "damping_option": "resolution_dependent",
+                "raw_filter_coeff": 1.0, "initial_condition_from_input_file": False, "longitude_origin": 0.0}
+_PHYS_RENAME = {"h_0": "phys_h_0"}
+
+
+def _lib():
+    lib = load_library()
+    if not getattr(lib, "_shallow_bound", False):
+        H, dp = C.c_void_p, C.POINTER(C.c_double)
+        sig = {"isca_shallow_config_default": [C.POINTER(_CShallowConfig)], "isca_shallow_create": [C.POINTER(_CShallowConfig), C.POINTER(H)],
+               "isca_shallow_destroy": [H], "isca_shallow_cold_start": [H], "isca_shallow_step": [H, C.c_int],
+               "isca_shallow_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+               "isca_shallow_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+               "isca_shallow_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+               "isca_shallow_set_time_pointers": [H, C.c_int, C.c_int, C.c_long]}
+        for name, args in sig.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, C.c_int
+        lib._shallow_bound = True
+    return lib
+
+
+def config_from_namelist(namelist: dict | None = None, resolution: str | None = None, **overrides) -> _CShallowConfig:
+    """shallow_dynamics_nml + shallow_physics_nml + main_nml(dt_atmos) -> C config; option values the device core does not
+    implement are refused (stirring must stay off: stirring_nml amplitude = 0)."""
+    c = _CShallowConfig()
+    _lib().isca_shallow_config_default(C.byref(c))
+    kw: dict = {}
+    if resolution is not None:
+        r = RESOLUTIONS[resolution]
+        kw.update(num_lon=r["lon_max"], num_lat=r["lat_max"], num_fourier=r["num_fourier"], num_spherical=r["num_spherical"])
+    nml = {g.lower(): v for g, v in (namelist or {}).items()}
+    if float(nml.get("stirring_nml", {}).get("amplitude", 0.0)) != 0.0:
+        raise IscaError("stirring_nml: amplitude must be 0 (stirring is not part of the device core)")
+    for k, v in nml.get("shallow_dynamics_nml", {}).items():
+        k = k.lower()
+        if k in _UNSUPPORTED:
+            if (str(v).lower() != str(_UNSUPPORTED[k]).lower()) and v != _UNSUPPORTED[k]:
+                raise IscaError(f'"{v}" is not a supported value for {k} (only "{_UNSUPPORTED[k]}")')
+            continue
+        if k in ("check_fourier_imag", "cutoff_wn", "init_cond_file", "input_file_div_name", "input_file_height_name", "input_file_vor_name"):
+            continue
+        kw[k] = v
+    for k, v in nml.get("shallow_physics_nml", {}).items():
+        k = k.lower()
+        if k == "del_h":
+            continue
+        kw[_PHYS_RENAME.get(k, k)] = v
+    if "dt_atmos" in nml.get("main_nml", {}):
+        kw["dt_atmos"] = nml["main_nml"]["dt_atmos"]
+    kw.update(overrides)
+    for k, v in kw.items():
+        if k == "valid_range_v":
+            c.valid_range_v[0], c.valid_range_v[1] = v
+        elif not hasattr(c, k):
+            raise IscaError(f"unknown shallow-water configuration key {k!r}")
+        else:
+            setattr(c, k, int(v) if isinstance(v, bool) else v)
+    return c
+
+
+class ShallowWater:
+    GRID = ("u", "v", "vor", "div", "h", "tr", "trs", "stream", "pv", "h_eq", "deep_geopot")
+    SPEC = ("vors", "divs", "hs", "trss")
+
+    def __init__(self, cfg: _CShallowConfig):
+        self.lib = _lib()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._check(self.lib.isca_shallow_create(C.byref(cfg), C.byref(self._h)))
+        self.I, self.J, self.M1, self.N1 = cfg.num_lon, cfg.num_lat, cfg.num_fourier + 1, cfg.num_spherical + 1
+
+    def _check(self, rc):
+        if rc != 0:
+            raise IscaError(self.lib.isca_last_error().decode())
+
+    def close(self):
+        if self._h:
+            self.lib.isca_shallow_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cold_start(self):
+        self._check(self.lib.isca_shallow_cold_start(self._h))
+
+    def step(self, nsteps: int = 1):
+        self._check(self.lib.isca_shallow_step(self._h, int(nsteps)))
+
+    def info(self, name: str) -> int:
+        v = C.c_long()
+        self._check(self.lib.isca_shallow_get_info(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def get(self, name: str, time_level: int = 1):
+        spec = name in self.SPEC
+        a = np.zeros((self.N1, self.M1), dtype=np.complex128) if spec else np.zeros((self.J, self.I))
+        v = a.view(np.float64)
+        self._check(self.lib.isca_shallow_get_state(self._h, name.encode(), time_level, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+        return a
+
+    def set(self, name: str, value, time_level: int = 1):
+        spec = name in self.SPEC
+        a = np.ascontiguousarray(value, dtype=np.complex128 if spec else np.float64)
+        if a.shape != ((self.N1, self.M1) if spec else (self.J, self.I)):
+            raise IscaError(f"set({name}): wrong shape {a.shape}")
+        v = a.view(np.float64)
+        self._check(self.lib.isca_shallow_set_state(self._h, name.encode(), time_level, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+
+    def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
+        self._check(self.lib.isca_shallow_set_time_pointers(self._h, previous, current, step_count))
+
+
+# ---- module-level mirror of atmosphere_mod (shallow): one instance, like the Fortran module
+_model: ShallowWater | None = None
+
+
+def atmosphere_init(namelist=None, resolution=None, **overrides):
+    global _model
+    if _model is None:
+        _model = ShallowWater(config_from_namelist(namelist, resolution, **overrides))
+        _model.cold_start()
+    return _model
+
+
+def atmosphere(nsteps: int = 1):
+    if _model is None:
+        raise IscaError("atmosphere: atmosphere_init has not been called")
+    _model.step(nsteps)
+
+
+def atmosphere_end():
+    global _model
+    if _model is None:
+        raise IscaError("atmosphere_end: atmosphere_init has not been called.")
+    _model.close()
+    _model = None

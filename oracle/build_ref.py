@@ -12,7 +12,7 @@ What this does (our recipe, not the reference's mkmf/Makefile build system):
     reference's own templates do) in the reference's single-PE "nocomm" mpp mode (no -Duse_libMPI)
     and without netCDF (no -Duse_netCDF) -- unmodified and where they lie, with ONE exception for the
     moist target that is spelled out at COMPAT_EDITS below (a build-time copy with an explicit int()),
-  * links the harnesses into oracle/_ref/ref_harness.x and oracle/_ref/ref_moist_harness.x.
+  * links the harnesses into oracle/_ref/ref_harness.x, ref_moist_harness.x and ref_shallow_harness.x.
 Outputs go only to oracle/_ref/ (git-ignored; travels to the GPU box with gpurun).
 No reference source is copied into this repository.
 
@@ -50,6 +50,11 @@ TARGETS = {
                   cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8", "-DRRTM_NO_COMPILE", "-DSOC_NO_COMPILE"],
                   # external (non-module) procedures the `use` graph cannot see: the Monin-Obukhov kernels called by monin_obukhov_mod
                   extra=["atmos_param/monin_obukhov/monin_obukhov_kernel.F90"]),
+    # sibling core: src/atmos_spectral_shallow + the stirring module it shares with the barotropic core
+    "shallow": dict(harness="ref_shallow_harness.F90", exe="ref_shallow_harness.x", build="build_shallow",
+                    scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_shallow",
+                          "atmos_spectral_barotropic"],
+                    cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"], skip=("socrates", "rrtm_radiation", "atmos_column")),
 }
 # One compiler-compatibility edit, applied to a BUILD-TIME COPY under oracle/_ref/<build>/compat/ (git-ignored, never in
 # this repository): qe_moist_convection.F90 indexes lcl_temp_table with a variable declared `real` (get_lcl_temp, :1060,
@@ -104,7 +109,7 @@ def build_target(name):
     files = {}
     for d in t["scan"]:
         for root, _, names in os.walk(os.path.join(SRC, d)):
-            if any(w in root.lower() for w in SKIP_DIR_WORDS):
+            if any(w in root.lower() for w in t.get("skip", SKIP_DIR_WORDS)):
                 continue
             for n in names:
                 if n.endswith((".F90", ".f90")) and not n.startswith("test_"):

@@ -292,6 +292,52 @@ def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt
     return out
 
 
+SHALLOW_EXE = os.path.join(HERE, "_ref", "ref_shallow_harness.x")
+SHALLOW_NML = """ &shallow_dynamics_nml
+    num_lon = {lon}, num_lat = {lat}, num_fourier = {nf}, num_spherical = {ns},
+    add_initial_vortex_pair = .true., u_upper_mag_init = 10.0, u_deep_mag = 5.0
+ /
+ &shallow_physics_nml
+ /
+ &fms_nml
+    domains_stack_size = 600000
+ /
+ &diag_manager_nml
+    mix_snapshot_average_fields = .false.
+ /
+"""
+
+
+def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=1200, keep=None):
+    """The reference shallow-water core (src/atmos_spectral_shallow) from its cold start with a vortex pair on a zonal flow over
+    the default forcing: grid u, v, vor, div, h, both tracers, stream, pv and the spectral vor, h after `dump_steps`."""
+    lon, lat, nf, ns = RES[res]
+    with tempfile.TemporaryDirectory(prefix="refsw_") as d:
+        os.makedirs(os.path.join(d, "INPUT")); os.makedirs(os.path.join(d, "RESTART"))
+        open(os.path.join(d, "input.nml"), "w").write(SHALLOW_NML.format(lon=lon, lat=lat, nf=nf, ns=ns))
+        open(os.path.join(d, "field_table"), "w").write("")
+        open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
+        open(os.path.join(d, "harness.nml"), "w").write(
+            f" &harness_nml\n   nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {', '.join(str(s) for s in dump_steps)}\n /\n")
+        stdout = run_harness(d, exe=SHALLOW_EXE)
+        out = {}
+        for fn in sorted(os.listdir(d)):
+            if not fn.endswith(".bin") or (keep is not None and not keep(fn[:-4])):
+                continue
+            raw = np.fromfile(os.path.join(d, fn))
+            name = fn[:-4]
+            if raw.size == lon * lat:
+                out[name] = raw.reshape(lat, lon)
+            elif raw.size == 2 * (nf + 1) * (ns + 1):
+                out[name] = raw.view(np.complex128).reshape(ns + 1, nf + 1)
+            else:
+                out[name] = raw
+    m = re.search(r"REF_STATE hmin,hmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["final_hmin_hmax_maxabsU"] = np.array([float(x) for x in m.groups()])
+    out.update({"meta_res": np.array(res), "meta_dt_atmos": np.array(float(dt)), "meta_nsteps": np.array(nsteps)})
+    return out
+
+
 def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None):
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
         prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps)
@@ -333,6 +379,10 @@ def main():
         "moist_run_T21L25": lambda: golden_moist_run(
             keep=lambda k: re.match(r"st_(ug|tg|q|psg)_(000001|000002|000010)$", k) is not None or k.endswith("_000144")),
         "moist_run_T21L25_12day": lambda: golden_moist_run(nsteps=1440, dump_steps=(1440,), keep=lambda k: k.endswith("_001440")),
+        # sibling core: shallow water at T21 (early steps + 200) and T42 (final state of 300 steps)
+        "shallow_run_T21": golden_shallow_run,
+        "shallow_run_T42": lambda: golden_shallow_run("T42", 300, (300,), keep=lambda k: not k.startswith("st_") or re.match(
+            r"st_(u|v|h|vor|tr|trs)_000300$", k) is not None),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

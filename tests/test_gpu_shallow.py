@@ -1,0 +1,95 @@
+"""Shallow-water sibling core on the GPU, through include/isca_shallow.h, against the reference's own
+src/atmos_spectral_shallow (fixtures tests/golden/shallow_run_*.npz written by oracle/ref_shallow_harness.F90): a vortex pair on a
+zonal flow over the default mass forcing, both tracers on.  fp64; bounds are fractions of each field's maximum."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from isca_amd import shallow             # noqa: E402
+from isca_amd.dyncore import IscaError   # noqa: E402
+
+NML = {"shallow_dynamics_nml": {"add_initial_vortex_pair": True, "u_upper_mag_init": 10.0, "u_deep_mag": 5.0}, "main_nml": {"dt_atmos": 1200}}
+PAIRS = (("u", "u"), ("v", "v"), ("vor", "vor"), ("div", "div"), ("h", "h"), ("tr", "tr"), ("trs", "trs"), ("vors", "vors"), ("hs", "hs"),
+         ("stream", "stream"), ("pv", "pv"))
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_shallow_trajectory_T21(golden_dir):
+    g = np.load(os.path.join(golden_dir, "shallow_run_T21.npz"))
+    sw = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    assert rel(sw.get("deep_geopot"), g["tab_deep_geopot"]) < 1e-13
+    sw.cold_start()
+    for mine, ref in PAIRS[:9]:
+        assert rel(sw.get(mine), g["st_%s_000000" % ref]) < 1e-13, mine       # initial condition
+    done = 0
+    tol = {1: 1e-12, 2: 1e-12, 10: 1e-11, 200: 1e-9}
+    for n in (1, 2, 10, 200):
+        sw.step(n - done)
+        done = n
+        err = {ref: rel(sw.get(mine), g["st_%s_%06d" % (ref, n)]) for mine, ref in PAIRS}
+        err["div"] = float(np.abs(sw.get("div") - g["st_div_%06d" % n]).max() / np.abs(g["st_vor_%06d" % n]).max())   # div << vor: scale by vor
+        print("shallow T21 step", n, {k: "%.1e" % v for k, v in err.items()})
+        assert max(err.values()) < tol[n], (n, err)
+    assert sw.info("step") == 200
+    sw.close()
+
+
+def test_shallow_T42_300_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "shallow_run_T42.npz"))
+    sw = shallow.ShallowWater(shallow.config_from_namelist(NML, "T42"))
+    sw.cold_start()
+    sw.step(300)
+    err = {k: rel(sw.get(k), g["st_%s_000300" % k]) for k in ("u", "v", "h", "vor", "tr", "trs")}
+    print("shallow T42 step 300", err)
+    assert max(err.values()) < 1e-9, err
+    h = sw.get("h")
+    assert abs(h.min() - g["final_hmin_hmax_maxabsU"][0]) < 1e-6 and abs(h.max() - g["final_hmin_hmax_maxabsU"][1]) < 1e-6
+    sw.close()
+
+
+def test_shallow_restart_and_module_mirror():
+    """set_state + set_time_pointers continue a run bit for bit; the module-level mirror drives the same handle type."""
+    a = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    a.cold_start()
+    a.step(7)
+    b = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    p, c = a.info("previous"), a.info("current")
+    for tl, slot in ((0, p), (1, c)):
+        b.set_time_pointers(slot, slot, 0)          # address storage slot `slot` as "current" to fill it
+        for k in ("u", "v", "vor", "div", "h", "tr", "trs", "vors", "divs", "hs", "trss"):
+            b.set(k, a.get(k, tl), 1)
+    b.set_time_pointers(p, c, 7)
+    a.step(5)
+    b.step(5)
+    for k in ("u", "v", "h", "vor", "tr", "trs", "vors", "hs"):
+        assert np.array_equal(a.get(k), b.get(k)), k
+    a.close(); b.close()
+    m = shallow.atmosphere_init(NML, "T21")
+    shallow.atmosphere(3)
+    assert m.info("step") == 3 and np.isfinite(m.get("h")).all()
+    shallow.atmosphere_end()
+    with pytest.raises(IscaError, match="atmosphere_init has not been called"):
+        shallow.atmosphere()
+
+
+def test_shallow_errors():
+    with pytest.raises(IscaError, match="not a supported value for fourier_inc"):
+        shallow.config_from_namelist({"shallow_dynamics_nml": {"fourier_inc": 2}})
+    with pytest.raises(IscaError, match="stirring"):
+        shallow.config_from_namelist({"stirring_nml": {"amplitude": 3.e-13}})
+    sw = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    with pytest.raises(IscaError, match="has not been initialized"):
+        sw.step(1)
+    sw.cold_start()
+    with pytest.raises(IscaError, match="unknown field"):
+        sw.get("nonsense")
+    bad = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21", valid_range_v=(-1e-3, 1e-3)))
+    bad.cold_start()
+    with pytest.raises(IscaError, match="meridional wind out of valid range"):
+        bad.step(20)
+    sw.close(); bad.close()
