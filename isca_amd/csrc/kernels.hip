@@ -2300,6 +2300,20 @@ __global__ void k_sw_grid_tend(SwGridArgs a) {
   a.bg[i] = (h + a.deep[i]) + 0.5 * (u * u + v * v);
   a.pv[i] = vorg / h;
 }
+// barotropic_dynamics (barotropic_dynamics.F90:300-306): absolute vorticity and the vorticity-flux tendencies (physics is empty)
+__global__ void k_bt_grid_tend(int n, int I, const double *u, const double *v, const double *vor, const double *coriolis, double *tend_u,
+                               double *tend_v, double *pv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double q = vor[i] + coriolis[i / I];
+  pv[i] = q;
+  tend_u[i] = 0.0 + q * v[i];
+  tend_v[i] = 0.0 - q * u[i];
+}
+void launch_bt_grid_tend(int n, int I, const double *u, const double *v, const double *vor, const double *coriolis, double *tend_u, double *tend_v,
+                         double *pv, hipStream_t s) {
+  hipLaunchKernelGGL(k_bt_grid_tend, grid1d((size_t)n), dim3(256), 0, s, n, I, u, v, vor, coriolis, tend_u, tend_v, pv);
+}
 void launch_sw_grid_tend(const SwGridArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_sw_grid_tend, grid1d((size_t)a.n), dim3(256), 0, s, a); }
 
 __device__ __forceinline__ void sw_leapfrog(bool first, double delta_t, double robert, double2 prev, double2 cur, double2 dt, double2 &fut,
@@ -2320,7 +2334,7 @@ __device__ __forceinline__ void sw_leapfrog(bool first, double delta_t, double r
 __global__ void k_sw_spec_update(Geom g, SwSpecArgs a) {
   const int mn = blockIdx.x * blockDim.x + threadIdx.x;
   if (mn >= g.Ml * g.N1) return;
-  const double eig = a.coef[(size_t)C_EIG * g.Ml * g.N1 + mn], dmp = a.coef[(size_t)C_DAMP * g.Ml * g.N1 + mn];
+  const double eig = a.coef[(size_t)C_EIG * g.Ml * g.N1 + mn], dmp = a.coef[(size_t)C_DAMP * g.Ml * g.N1 + mn] + a.damping_r;
   const double coeff = 1.0 / (1.0 + dmp * a.delta_t);
   if (a.mode == 1) {
     const double2 p = a.vor_p[mn], c = a.vor_c[mn];

@@ -171,3 +171,122 @@ def atmosphere_end():
         raise IscaError("atmosphere_end: atmosphere_init has not been called.")
     _model.close()
     _model = None
+
+
+# =====================================================================================================
+# Barotropic-vorticity sibling core (include/isca_barotropic.h; reference src/atmos_spectral_barotropic)
+# =====================================================================================================
+class _CBarotropicConfig(C.Structure):
+    _fields_ = [
+        ("num_lon", C.c_int), ("num_lat", C.c_int), ("num_fourier", C.c_int), ("num_spherical", C.c_int), ("dt_atmos", C.c_double),
+        ("damping_order", C.c_int), ("damping_coeff", C.c_double), ("damping_coeff_r", C.c_double), ("robert_coeff", C.c_double),
+        ("zeta_0", C.c_double), ("m_0", C.c_int), ("eddy_width", C.c_double), ("eddy_lat", C.c_double),
+        ("spec_tracer", C.c_int), ("grid_tracer", C.c_int), ("valid_range_v", C.c_double * 2), ("initial_zonal_wind", C.c_int),
+        ("device", C.c_int),
+    ]
+
+
+BAROTROPIC_SYMBOLS = ["isca_barotropic_config_default", "isca_barotropic_create", "isca_barotropic_destroy", "isca_barotropic_cold_start",
+                      "isca_barotropic_step", "isca_barotropic_get_state", "isca_barotropic_set_state", "isca_barotropic_get_info",
+                      "isca_barotropic_set_time_pointers"]
+
+
+def _blib():
+    lib = load_library()
+    if not getattr(lib, "_barotropic_bound", False):
+        H, dp = C.c_void_p, C.POINTER(C.c_double)
+        sig = {"isca_barotropic_config_default": [C.POINTER(_CBarotropicConfig)],
+               "isca_barotropic_create": [C.POINTER(_CBarotropicConfig), C.POINTER(H)], "isca_barotropic_destroy": [H],
+               "isca_barotropic_cold_start": [H], "isca_barotropic_step": [H, C.c_int],
+               "isca_barotropic_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+               "isca_barotropic_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
+               "isca_barotropic_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+               "isca_barotropic_set_time_pointers": [H, C.c_int, C.c_int, C.c_long]}
+        for name, args in sig.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, C.c_int
+        lib._barotropic_bound = True
+    return lib
+
+
+def barotropic_config_from_namelist(namelist: dict | None = None, resolution: str | None = None, **overrides) -> _CBarotropicConfig:
+    """barotropic_dynamics_nml + main_nml(dt_atmos) (exp/test_cases/barotropic_vorticity_equation) -> C config."""
+    c = _CBarotropicConfig()
+    _blib().isca_barotropic_config_default(C.byref(c))
+    kw: dict = {}
+    if resolution is not None:
+        r = RESOLUTIONS[resolution]
+        kw.update(num_lon=r["lon_max"], num_lat=r["lat_max"], num_fourier=r["num_fourier"], num_spherical=r["num_spherical"])
+    nml = {g.lower(): v for g, v in (namelist or {}).items()}
+    if float(nml.get("stirring_nml", {}).get("amplitude", 0.0)) != 0.0:
+        raise IscaError("stirring_nml: amplitude must be 0 (stirring is not part of the device core)")
+    for k, v in nml.get("barotropic_dynamics_nml", {}).items():
+        k = k.lower()
+        if k in _UNSUPPORTED:
+            if (str(v).lower() != str(_UNSUPPORTED[k]).lower()) and v != _UNSUPPORTED[k]:
+                raise IscaError(f'"{v}" is not a supported value for {k} (only "{_UNSUPPORTED[k]}")')
+            continue
+        if k in ("check_fourier_imag", "cutoff_wn"):
+            continue
+        if k == "initial_zonal_wind":
+            if str(v) not in ("zero", "two_jets"):
+                raise IscaError(f"barotropic_dynamics_init: {v} is not a valid value of initial_zonal_wind ")
+            v = 1 if str(v) == "two_jets" else 0
+        kw[k] = v
+    if "dt_atmos" in nml.get("main_nml", {}):
+        kw["dt_atmos"] = nml["main_nml"]["dt_atmos"]
+    kw.update(overrides)
+    for k, v in kw.items():
+        if k == "valid_range_v":
+            c.valid_range_v[0], c.valid_range_v[1] = v
+        elif not hasattr(c, k):
+            raise IscaError(f"unknown barotropic configuration key {k!r}")
+        else:
+            setattr(c, k, int(v) if isinstance(v, bool) else v)
+    return c
+
+
+class Barotropic(ShallowWater):
+    GRID = ("u", "v", "vor", "tr", "trs", "stream", "pv")
+    SPEC = ("vors", "trss")
+
+    def __init__(self, cfg: _CBarotropicConfig):
+        self.lib = _blib()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        self._check(self.lib.isca_barotropic_create(C.byref(cfg), C.byref(self._h)))
+        self.I, self.J, self.M1, self.N1 = cfg.num_lon, cfg.num_lat, cfg.num_fourier + 1, cfg.num_spherical + 1
+
+    def close(self):
+        if self._h:
+            self.lib.isca_barotropic_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def cold_start(self):
+        self._check(self.lib.isca_barotropic_cold_start(self._h))
+
+    def step(self, nsteps: int = 1):
+        self._check(self.lib.isca_barotropic_step(self._h, int(nsteps)))
+
+    def info(self, name: str) -> int:
+        v = C.c_long()
+        self._check(self.lib.isca_barotropic_get_info(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def get(self, name: str, time_level: int = 1):
+        if name == "zonal_u_init":
+            a = np.zeros(self.J)
+        else:
+            a = np.zeros((self.N1, self.M1), dtype=np.complex128) if name in self.SPEC else np.zeros((self.J, self.I))
+        v = a.view(np.float64)
+        self._check(self.lib.isca_barotropic_get_state(self._h, name.encode(), time_level, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+        return a
+
+    def set(self, name: str, value, time_level: int = 1):
+        spec = name in self.SPEC
+        a = np.ascontiguousarray(value, dtype=np.complex128 if spec else np.float64)
+        v = a.view(np.float64)
+        self._check(self.lib.isca_barotropic_set_state(self._h, name.encode(), time_level, v.ctypes.data_as(C.POINTER(C.c_double)), v.size))
+
+    def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
+        self._check(self.lib.isca_barotropic_set_time_pointers(self._h, previous, current, step_count))

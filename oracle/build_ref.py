@@ -55,6 +55,9 @@ TARGETS = {
                     scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_shallow",
                           "atmos_spectral_barotropic"],
                     cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"], skip=("socrates", "rrtm_radiation", "atmos_column")),
+    "barotropic": dict(harness="ref_barotropic_harness.F90", exe="ref_barotropic_harness.x", build="build_barotropic",
+                       scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_barotropic"],
+                       cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"], skip=("socrates", "rrtm_radiation", "atmos_column")),
 }
 # One compiler-compatibility edit, applied to a BUILD-TIME COPY under oracle/_ref/<build>/compat/ (git-ignored, never in
 # this repository): qe_moist_convection.F90 indexes lcl_temp_table with a variable declared `real` (get_lcl_temp, :1060,

@@ -308,18 +308,31 @@ SHALLOW_NML = """ &shallow_dynamics_nml
 """
 
 
-def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=1200, keep=None):
+BAROTROPIC_EXE = os.path.join(HERE, "_ref", "ref_barotropic_harness.x")
+BAROTROPIC_NML = """ &barotropic_dynamics_nml
+    num_lon = {lon}, num_lat = {lat}, num_fourier = {nf}, num_spherical = {ns}
+ /
+ &fms_nml
+    domains_stack_size = 600000
+ /
+ &diag_manager_nml
+    mix_snapshot_average_fields = .false.
+ /
+"""
+
+
+def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=1200, keep=None, nml=None, exe=None, state_re=None):
     """The reference shallow-water core (src/atmos_spectral_shallow) from its cold start with a vortex pair on a zonal flow over
     the default forcing: grid u, v, vor, div, h, both tracers, stream, pv and the spectral vor, h after `dump_steps`."""
     lon, lat, nf, ns = RES[res]
     with tempfile.TemporaryDirectory(prefix="refsw_") as d:
         os.makedirs(os.path.join(d, "INPUT")); os.makedirs(os.path.join(d, "RESTART"))
-        open(os.path.join(d, "input.nml"), "w").write(SHALLOW_NML.format(lon=lon, lat=lat, nf=nf, ns=ns))
+        open(os.path.join(d, "input.nml"), "w").write((nml or SHALLOW_NML).format(lon=lon, lat=lat, nf=nf, ns=ns))
         open(os.path.join(d, "field_table"), "w").write("")
         open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
         open(os.path.join(d, "harness.nml"), "w").write(
             f" &harness_nml\n   nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {', '.join(str(s) for s in dump_steps)}\n /\n")
-        stdout = run_harness(d, exe=SHALLOW_EXE)
+        stdout = run_harness(d, exe=exe or SHALLOW_EXE)
         out = {}
         for fn in sorted(os.listdir(d)):
             if not fn.endswith(".bin") or (keep is not None and not keep(fn[:-4])):
@@ -332,8 +345,8 @@ def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=120
                 out[name] = raw.view(np.complex128).reshape(ns + 1, nf + 1)
             else:
                 out[name] = raw
-    m = re.search(r"REF_STATE hmin,hmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
-    out["final_hmin_hmax_maxabsU"] = np.array([float(x) for x in m.groups()])
+    m = re.search(state_re or r"REF_STATE hmin,hmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["final_hmin_hmax_maxabsU" if state_re is None else "final_vormin_vormax_maxabsU"] = np.array([float(x) for x in m.groups()])
     out.update({"meta_res": np.array(res), "meta_dt_atmos": np.array(float(dt)), "meta_nsteps": np.array(nsteps)})
     return out
 
@@ -383,6 +396,12 @@ def main():
         "shallow_run_T21": golden_shallow_run,
         "shallow_run_T42": lambda: golden_shallow_run("T42", 300, (300,), keep=lambda k: not k.startswith("st_") or re.match(
             r"st_(u|v|h|vor|tr|trs)_000300$", k) is not None),
+        # sibling core: barotropic vorticity equation (two jets + wavenumber-4 eddy), T21 early steps + 200, T42 final state
+        "barotropic_run_T21": lambda: golden_shallow_run(nml=BAROTROPIC_NML, exe=BAROTROPIC_EXE,
+                                                         state_re=r"REF_STATE vormin,vormax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)"),
+        "barotropic_run_T42": lambda: golden_shallow_run("T42", 300, (300,), nml=BAROTROPIC_NML, exe=BAROTROPIC_EXE,
+                                                         state_re=r"REF_STATE vormin,vormax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)",
+                                                         keep=lambda k: not k.startswith("st_") or k.endswith("_000300")),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

@@ -1,0 +1,115 @@
+! oracle/ref_barotropic_harness.F90 -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+!
+! Driver program (ours) for the reference's barotropic sibling core (src/atmos_spectral_barotropic), compiled in place by
+! oracle/build_ref.py barotropic.  It calls only public module procedures -- barotropic_dynamics_init, barotropic_physics_init,
+! stirring_init, then per step barotropic_physics and barotropic_dynamics with the time-level bookkeeping of
+! src/atmos_spectral_barotropic/atmosphere.F90:110-185 (whose own state is private, hence this driver) -- and dumps raw
+! little-endian fp64 arrays (Fortran order) after the steps listed in harness.nml.
+program ref_barotropic_harness
+
+use constants_mod,        only: constants_init
+use fms_mod,              only: fms_init
+use time_manager_mod,     only: time_type, set_time, set_calendar_type, NO_CALENDAR, operator(+)
+use diag_manager_mod,     only: diag_manager_init
+use transforms_mod,       only: get_grid_domain, get_spec_domain, get_deg_lat
+use barotropic_dynamics_mod, only: barotropic_dynamics_init, barotropic_dynamics, dynamics_type
+use barotropic_physics_mod,  only: barotropic_physics_init, barotropic_physics, phys_type
+use stirring_mod,         only: stirring_init
+
+implicit none
+
+integer :: nsteps = 1, dt_atmos = 1200
+integer, dimension(64) :: dump_steps = -1
+namelist /harness_nml/ nsteps, dt_atmos, dump_steps
+
+type(time_type)     :: Time, Time_init, Time_step
+type(dynamics_type) :: Dyn
+type(phys_type)     :: Phys
+integer :: is, ie, js, je, ms, me, ns, ne, previous, current, future, istep, unit
+real    :: dt_real, delta_t
+integer(kind=8) :: c0, c1, crate
+real, allocatable :: deg_lat(:)
+
+open(newunit=unit, file='harness.nml', status='old', action='read')
+read(unit, nml=harness_nml)
+close(unit)
+
+call fms_init()
+call constants_init()
+call set_calendar_type(NO_CALENDAR)
+call diag_manager_init()
+Time_init = set_time(0, 0)
+Time      = Time_init
+Time_step = set_time(dt_atmos, 0)
+dt_real   = real(dt_atmos)
+
+call barotropic_dynamics_init(Dyn, Time, Time_init, dt_real)
+call get_grid_domain(is, ie, js, je)
+call get_spec_domain(ms, me, ns, ne)
+call barotropic_physics_init(Phys)
+call stirring_init(dt_real, Time, 0, 0, 0, 0)
+previous = 1; current = 1
+allocate(deg_lat(js:je)); call get_deg_lat(deg_lat)
+call dump1('tab_deg_lat.bin', deg_lat)
+call dump1('tab_zonal_u_init.bin', Dyn%Grid%zonal_u_init)
+call dump_state(0)
+
+call system_clock(c0, crate)
+do istep = 1, nsteps
+  Dyn%Tend%u = 0.0; Dyn%Tend%v = 0.0
+  if(Dyn%grid_tracer) Dyn%Tend%tr  = 0.0
+  if(Dyn%spec_tracer) Dyn%Tend%trs = 0.0
+  if(istep == 1) then
+    delta_t = dt_real; future = 2
+  else
+    delta_t = 2.0*dt_real; future = previous
+  endif
+  call barotropic_physics(Time, Dyn%Tend%u, Dyn%Tend%v, Dyn%Grid%u, Dyn%Grid%v, delta_t, previous, current, Phys)
+  call barotropic_dynamics(Time, Time_init, Dyn, previous, current, future, delta_t)
+  previous = current
+  current  = future
+  Time = Time + Time_step
+  if(any(dump_steps == istep)) call dump_state(istep)
+enddo
+call system_clock(c1)
+write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', real(c1-c0,8)/real(crate,8), &
+      ' ms_per_step=', 1.d3*real(c1-c0,8)/real(crate,8)/max(nsteps,1)
+write(*,'(a,3es24.16)') 'REF_STATE vormin,vormax,maxabsU=', minval(Dyn%Grid%vor(:,:,current)), maxval(Dyn%Grid%vor(:,:,current)), &
+      maxval(abs(Dyn%Grid%u(:,:,current)))
+
+contains
+
+subroutine dump_state(n)
+integer, intent(in) :: n
+character(len=6) :: tag
+write(tag,'(i6.6)') n
+call dump2('st_u_'//tag//'.bin', Dyn%Grid%u(:,:,current));     call dump2('st_v_'//tag//'.bin', Dyn%Grid%v(:,:,current))
+call dump2('st_vor_'//tag//'.bin', Dyn%Grid%vor(:,:,current))
+if(Dyn%grid_tracer) call dump2('st_tr_'//tag//'.bin', Dyn%Grid%tr(:,:,current))
+if(Dyn%spec_tracer) call dump2('st_trs_'//tag//'.bin', Dyn%Grid%trs(:,:,current))
+call dumpc('st_vors_'//tag//'.bin', Dyn%Spec%vor(:,:,current))
+if(n > 0) then
+  call dump2('st_stream_'//tag//'.bin', Dyn%Grid%stream); call dump2('st_pv_'//tag//'.bin', Dyn%Grid%pv)
+endif
+end subroutine dump_state
+
+subroutine dump1(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace'); write(u) a; close(u)
+end subroutine dump1
+subroutine dump2(name, a)
+character(len=*), intent(in) :: name
+real, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace'); write(u) a; close(u)
+end subroutine dump2
+subroutine dumpc(name, a)
+character(len=*), intent(in) :: name
+complex, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace'); write(u) a; close(u)
+end subroutine dumpc
+
+end program ref_barotropic_harness

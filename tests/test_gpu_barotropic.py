@@ -1,0 +1,67 @@
+"""Barotropic-vorticity sibling core on the GPU, through include/isca_barotropic.h, against the reference's
+src/atmos_spectral_barotropic (fixtures tests/golden/barotropic_run_*.npz written by oracle/ref_barotropic_harness.F90): two jets
+with a wavenumber-4 eddy perturbation, both tracers on."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from isca_amd import shallow             # noqa: E402
+from isca_amd.dyncore import IscaError   # noqa: E402
+
+NML = {"main_nml": {"dt_atmos": 1200}}
+FIELDS = ("u", "v", "vor", "tr", "trs", "vors", "stream", "pv")
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_barotropic_trajectory_T21(golden_dir):
+    g = np.load(os.path.join(golden_dir, "barotropic_run_T21.npz"))
+    bt = shallow.Barotropic(shallow.barotropic_config_from_namelist(NML, "T21"))
+    assert rel(bt.get("zonal_u_init"), g["tab_zonal_u_init"]) < 1e-15
+    bt.cold_start()
+    for k in FIELDS[:6]:
+        scale = 50.0 if k == "v" else None                 # v starts ~0: compare in units of the jet speed
+        e = np.abs(bt.get(k) - g["st_%s_000000" % k]).max() / (scale or np.abs(g["st_%s_000000" % k]).max())
+        assert e < 1e-13, (k, e)
+    done = 0
+    for n, tol in ((1, 1e-12), (2, 1e-12), (10, 1e-11), (200, 1e-9)):
+        bt.step(n - done)
+        done = n
+        err = {k: rel(bt.get(k), g["st_%s_%06d" % (k, n)]) for k in FIELDS}
+        print("barotropic T21 step", n, {k: "%.1e" % v for k, v in err.items()})
+        assert max(err.values()) < tol, (n, err)
+    bt.close()
+
+
+def test_barotropic_T42_300_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "barotropic_run_T42.npz"))
+    bt = shallow.Barotropic(shallow.barotropic_config_from_namelist(NML, "T42"))
+    bt.cold_start()
+    bt.step(300)
+    err = {k: rel(bt.get(k), g["st_%s_000300" % k]) for k in FIELDS}
+    print("barotropic T42 step 300", err)
+    assert max(err.values()) < 1e-9, err
+    bt.close()
+
+
+def test_barotropic_linear_drag_and_errors():
+    """damping_coeff_r adds a linear drag to the spectral damping (spectral_damping.F90:157-158): the flow decays faster."""
+    a = shallow.Barotropic(shallow.barotropic_config_from_namelist(NML, "T21"))
+    b = shallow.Barotropic(shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"damping_coeff_r": 1.e-5}, **NML}, "T21"))
+    for m in (a, b):
+        m.cold_start()
+        m.step(50)
+    assert np.abs(b.get("u")).max() < 0.7 * np.abs(a.get("u")).max()
+    with pytest.raises(IscaError, match="no field"):
+        a.get("h")
+    with pytest.raises(IscaError, match="not a valid value of initial_zonal_wind"):
+        shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"initial_zonal_wind": "three_jets"}})
+    z = shallow.Barotropic(shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"initial_zonal_wind": "zero", "zeta_0": 0.0}, **NML}, "T21"))
+    z.cold_start()
+    z.step(10)
+    assert np.abs(z.get("u")).max() < 1e-12          # rest stays at rest
+    a.close(); b.close(); z.close()

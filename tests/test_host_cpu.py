@@ -23,6 +23,25 @@ def test_header_symbols_exported(lib):
     assert declared == set(dyncore.EXPORTED_SYMBOLS), declared ^ set(dyncore.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
+    # the sibling cores' headers
+    from isca_amd import shallow
+    for header, names in (("isca_shallow.h", shallow.EXPORTED_SYMBOLS), ("isca_barotropic.h", shallow.BAROTROPIC_SYMBOLS)):
+        h = open(os.path.join(REPO, "include", header)).read()
+        decl = set(re.findall(r"\b(isca_[a-z_0-9]+)\s*\(", h)) - {"isca_last_error"}      # mentioned in the header comment
+        assert decl == set(names), decl ^ set(names)
+        for name in decl:
+            assert hasattr(lib, name), name
+    import ctypes
+    for cls, header, tname in ((shallow._CShallowConfig, "isca_shallow.h", "isca_shallow_config"),
+                               (shallow._CBarotropicConfig, "isca_barotropic.h", "isca_barotropic_config")):
+        h = open(os.path.join(REPO, "include", header)).read()
+        body = re.sub(r"/\*.*?\*/", "", h[h.index("typedef struct %s {" % tname) + len("typedef struct %s {" % tname):h.index("} %s;" % tname)], flags=re.S)
+        members = []
+        for decl in body.split(";"):
+            m = re.match(r"(?:int|double)\s*(.*)", decl.strip(), flags=re.S)
+            if m:
+                members += [re.sub(r"\[.*\]", "", x).strip() for x in m.group(1).split(",")]
+        assert members == [f[0] for f in cls._fields_], (tname, members)
 
 
 def test_config_struct_matches_header(lib):
@@ -221,3 +240,21 @@ def test_moist_namelist_mapping():
         atm.config_from_namelist({"atmosphere_nml": {"idealized_moist_model": True}, "mixed_layer_nml": {"land_depth": 2.0}})
     dry = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 25}})
     assert dry.physics == 0 and dry.vert_coord_input == 0
+
+
+def test_sibling_core_namelists():
+    """shallow_dynamics_nml / shallow_physics_nml / barotropic_dynamics_nml -> C configs (no GPU needed)."""
+    from isca_amd import shallow
+    from isca_amd.dyncore import IscaError
+    c = shallow.config_from_namelist({"shallow_dynamics_nml": {"num_lon": 128, "num_lat": 64, "num_fourier": 42, "num_spherical": 43, "h_0": 2.e4,
+                                                                 "robert_coeff": 0.03, "grid_tracer": False, "valid_range_v": [-500., 500.]},
+                                      "shallow_physics_nml": {"h_0": 2.5e4, "therm_damp_time": -5.0, "del_h": 1.}, "main_nml": {"dt_atmos": 600}})
+    assert (c.num_lon, c.num_fourier, c.h_0, c.phys_h_0, c.therm_damp_time, c.robert_coeff, c.grid_tracer, c.dt_atmos) == \
+        (128, 42, 2.e4, 2.5e4, -5.0, 0.03, 0, 600.0)
+    assert c.valid_range_v[1] == 500.0 and c.fric_damp_time == -20.0 and c.spec_tracer == 1
+    b = shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"initial_zonal_wind": "zero", "m_0": 6, "damping_coeff_r": 1e-6}}, "T42")
+    assert (b.initial_zonal_wind, b.m_0, b.damping_coeff_r, b.num_lat, b.zeta_0) == (0, 6, 1e-6, 64, 8.e-05)
+    with pytest.raises(IscaError, match="unknown shallow-water configuration key"):
+        shallow.config_from_namelist({"shallow_dynamics_nml": {"no_such_key": 1}})
+    with pytest.raises(IscaError, match="not a supported value for triang_trunc"):
+        shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"triang_trunc": False}})
