@@ -32,60 +32,91 @@ struct MoistArgs {
   int do_damping;
 };
 
-// Three work arrays of L+1 levels per column (radiation: lw_down, lw_dtrans; diffusion: e, f_1, f_2) live in LDS when the block's
-// 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the grid layout.
-// LMAX only sizes the private arrays of the convection scheme.
+// Three work arrays of L+1 levels per column (radiation: lw_down, lw_dtrans, its heating; diffusion: e, f_1, f_2) live in LDS when
+// the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the
+// grid layout.  LMAX only sizes the private arrays of the convection scheme.
+// A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
+// on its 64 columns where the chain allows it: wavefront 0 does convection + condensation while wavefront 1 does radiation,
+// surface fluxes and the sponge; they meet at one barrier, wavefront 0 adds wavefront 1's heating in the reference's order
+// (dt_tg = ((conv + cond) + rad) + sponge) and goes on with the boundary layer and the implicit diffusion.  With blockDim = 64
+// the same code runs the three parts one after the other.
+constexpr int MOIST_NX = 20;       // scalars handed from wavefront 1 to wavefront 0 through work array 0 (needs L + 1 >= MOIST_NX)
 template <int LMAX, bool LDSW>
-__global__ __launch_bounds__(64) void k_moist_physics(MoistArgs a) {
+__global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
-  const int col = min(blockIdx.x * 64 + (int)threadIdx.x, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
+  const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nroles = blockDim.x >> 6;
+  const int col = min(blockIdx.x * 64 + lane, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
   const int L = a.L, s = a.ncol;
   const size_t c = (size_t)col;
   const int sw = LDSW ? 64 : a.ncol;
-  double *w0 = LDSW ? lds_work + threadIdx.x : a.work + c;
+  double *w0 = LDSW ? lds_work + lane : a.work + c;
   double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
-  // ---- convection (:862-880): deltas over the step, then rates
-  double rain, cape, cin;
-  int flag, klzb, klcl;
+  const int nray = a.do_damping ? a.ray.nlev_rayfric : 0;
+  double t_surf = 0.0, net_sw = 0.0, lw_down_surf = 0.0;
+  moist::SurfFlux sf;
+  if (role == 0) {
+    // ---- convection (:862-880): deltas over the step, then rates
+    double rain, cape, cin;
+    int flag, klzb, klcl;
 #ifdef MOIST_EXP_NOCONV
-  rain = 0; for (int k = 0; k < L; ++k) { dtT[k * s] = 0; dtq[k * s] = 0; }
+    rain = 0; for (int k = 0; k < L; ++k) { dtT[k * s] = 0; dtq[k * s] = 0; }
 #else
-  moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
-                                   nullptr, nullptr, s);
+    moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
+                                     nullptr, nullptr, s);
 #endif
-  double precip = rain / delta_t;
-  // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
-  {
+    double precip = rain / delta_t;
+    // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
     double rain_ls;
     moist::lscale_cond(a.sat, L, [&](int k) { return dtT[k * s] + tp[k * s]; }, [&](int k) { return dtq[k * s] + qp[k * s]; }, a.pf_p + c,
                        a.ph_p + c, s,
                        [&](int k, double td, double qd) {
                          dtT[k * s] = dtT[k * s] / delta_t + td / delta_t;
                          dtq[k * s] = dtq[k * s] / delta_t + qd / delta_t;
-                         dtu[k * s] = 0.0; dtv[k * s] = 0.0;
                        },
                        rain_ls);
     precip = precip + rain_ls / delta_t;
+    if (a.precip) a.precip[c] = precip;
   }
-  if (a.precip) a.precip[c] = precip;
-  // ---- grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162)
-  const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
-  double t_surf = a.t_surf[c];
-  double net_sw, lw_down_surf;
-  moist::SurfFlux sf;
-  {
+  if (role == nroles - 1) {
+    // ---- grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
+    const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
+    t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
     moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, net_sw, lw_down_surf);
     const size_t low = (size_t)(L - 1) * s;
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, dtT, s);
+    for (int k = 0; k < L; ++k) { w2[k * sw] = 0.0; dtu[k * s] = 0.0; dtv[k * s] = 0.0; }
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, w2, sw);
+    // ---- Rayleigh sponge (:1228-1237): momentum tendencies in place, its heating into work array 1 (radiation is done with it)
+    for (int k = 0; k < nray; ++k) w1[k * sw] = 0.0;
+    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, w1, sw);
+    if (nroles == 2) {
+      const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
+                                  sf.dedq_atm, sf.dtaudu_atm, sf.dtaudv_atm, sf.u_star, sf.b_star, t_surf, net_sw, lw_down_surf, 0., 0., 0.};
+#pragma unroll
+      for (int i = 0; i < MOIST_NX; ++i) w0[i * sw] = x[i];
+    }
   }
-  // ---- Rayleigh sponge (:1228-1237)
-  if (a.do_damping) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, dtT, s);
+  if (nroles == 2) {
+    __syncthreads();
+    if (role != 0) return;
+    double x[MOIST_NX];
+#pragma unroll
+    for (int i = 0; i < MOIST_NX; ++i) x[i] = w0[i * sw];
+    sf.flux_t = x[0]; sf.flux_q = x[1]; sf.flux_r = x[2]; sf.flux_u = x[3]; sf.flux_v = x[4]; sf.dhdt_surf = x[5]; sf.dedt_surf = x[6];
+    sf.drdt_surf = x[7]; sf.dhdt_atm = x[8]; sf.dedq_atm = x[9]; sf.dtaudu_atm = x[10]; sf.dtaudv_atm = x[11]; sf.u_star = x[12];
+    sf.b_star = x[13]; t_surf = x[14]; net_sw = x[15]; lw_down_surf = x[16];
+  }
+  // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order
+  for (int k = 0; k < L; ++k) {
+    double t = dtT[k * s] + w2[k * sw];
+    if (k < nray) t = t + w1[k * sw];
+    dtT[k * s] = t;
+  }
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
 #ifndef MOIST_EXP_NOVD
   {
@@ -186,7 +217,8 @@ static MoistArgs moist_args(const isca_dyn &h) {
   return a;
 }
 static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
-  const dim3 grid((a.ncol + 63) / 64), block(64);
+  const bool two = a.L + 1 >= MOIST_NX && !getenv("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
+  const dim3 grid((a.ncol + 63) / 64), block(two ? 128 : 64);
   const size_t lds = (size_t)3 * 64 * (a.L + 1) * sizeof(double);
   const bool in_lds = lds <= 65536 && !getenv("ISCA_MOIST_GLOBAL_WORK");
 #define LM(N)                                                                                          \

@@ -566,13 +566,13 @@ MP_HD void surface_flux(const SatTable &st, const MoParams &mo, double t_atm, do
 // ------------------------------------------------------------------------------------------------
 struct RayleighParams { int nlev_rayfric = 0; double rfactr = 0.0, sponge_pbottom = 50.0; bool conserve_energy = true; };
 MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pfull, const double *u, const double *v, int s, double *udt,
-                            double *vdt, double *tdt, int st) {
+                            double *vdt, int st, double *tdt, int stt) {
   for (int k0 = 0; k0 < p.nlev_rayfric; k0 += MP_U) {
     double pf[MP_U], uk[MP_U], vk[MP_U], ud[MP_U], vd[MP_U], td[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < p.nlev_rayfric) ? k0 + i : p.nlev_rayfric - 1;
-      pf[i] = pfull[k * s]; uk[i] = u[k * s]; vk[i] = v[k * s]; ud[i] = udt[k * st]; vd[i] = vdt[k * st]; td[i] = tdt[k * st];
+      pf[i] = pfull[k * s]; uk[i] = u[k * s]; vk[i] = v[k * s]; ud[i] = udt[k * st]; vd[i] = vdt[k * st]; td[i] = tdt[k * stt];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -586,7 +586,7 @@ MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pf
         }
         udt[k * st] = ud[i] + ut;
         vdt[k * st] = vd[i] + vt;
-        if (p.conserve_energy) tdt[k * st] = td[i] + (-((uk[i] + .5 * dt * ut) * ut + (vk[i] + .5 * dt * vt) * vt) / CP_AIR);
+        if (p.conserve_energy) tdt[k * stt] = td[i] + (-((uk[i] + .5 * dt * ut) * ut + (vk[i] + .5 * dt * vt) * vt) / CP_AIR);
       }
     }
   }

@@ -63,7 +63,7 @@ void mh_surface_flux(int ncol, const double *t_atm, const double *q_atm, const d
 void mh_rayleigh(int L, int ncol, int nlev_rayfric, double rfactr, double sponge_pbottom, double dt, const double *pfull, const double *u,
                  const double *v, double *udt, double *vdt, double *tdt) {
   RayleighParams p; p.nlev_rayfric = nlev_rayfric; p.rfactr = rfactr; p.sponge_pbottom = sponge_pbottom;
-  for (int c = 0; c < ncol; ++c) rayleigh_damping(p, dt, pfull + c, u + c, v + c, ncol, udt + c, vdt + c, tdt + c, ncol);
+  for (int c = 0; c < ncol; ++c) rayleigh_damping(p, dt, pfull + c, u + c, v + c, ncol, udt + c, vdt + c, ncol, tdt + c, ncol);
 }
 void mh_diffusivity(int L, int ncol, double dt, const double *tm, const double *um, const double *vm, const double *tdt, const double *udt,
                     const double *vdt, const double *z_full, const double *z_half, const double *u_star, const double *b_star, double *h,
