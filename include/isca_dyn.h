@@ -164,6 +164,7 @@ int isca_trans_spherical_to_fourier(isca_dyn_t *h, const double *spherical, doub
 int isca_trans_fourier_to_spherical(isca_dyn_t *h, const double *fourier, double *spherical, int nlev); /* spherical_fourier.F90:264 */
 int isca_trans_grid_to_fourier(isca_dyn_t *h, const double *grid, double *fourier, int nlev);           /* grid_fourier.F90:129; fourier (0:num_fourier, lat, lev) */
 int isca_trans_fourier_to_grid(isca_dyn_t *h, const double *fourier, double *grid, int nlev);           /* grid_fourier.F90:155 */
+int isca_trans_filter(isca_dyn_t *h, double *grid, const double *filter /* (m,n) real or NULL */, int nlev);             /* transforms.F90:555 trans_filter */
 int isca_area_weighted_global_mean(isca_dyn_t *h, const double *field2d, double *mean);                 /* transforms.F90:1059 */
 
 /* hs_forcing(...) on caller-supplied fields (hs_forcing.F90:148): tendencies are accumulated into udt,vdt,tdt */
@@ -184,7 +185,8 @@ int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t, double gu
 /* --- diagnostics: what spectral_diagnostics sends to diag_manager every step (spectral_dynamics.F90:1705-1867),
  * accumulated on the device for the time means of the diag_table.  Field names as registered by the reference:
  * ps, ucomp, vcomp, temp, vor, div, omega, sphum, ucomp_sq, vcomp_sq, ucomp_vcomp, temp_sq, ucomp_temp, vcomp_temp,
- * omega_sq, omega_temp, ucomp_omega, vcomp_omega, vcomp_vor, wspd. */
+ * omega_sq, omega_temp, ucomp_omega, vcomp_omega, vcomp_vor, wspd; with the moist package also the 2-D fields precipitation
+ * (module atmosphere, idealized_moist_phys.F90:672) and t_surf (module mixed_layer, mixed_layer.F90:359). */
 int isca_dyn_diag_select(isca_dyn_t *h, const char *comma_separated_names);     /* "" switches the accumulation off */
 int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host, size_t count, long *nsteps, int reset);   /* mean over the steps since the last reset; host may be NULL */
 

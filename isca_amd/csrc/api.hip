@@ -1019,6 +1019,28 @@ extern "C" int isca_trans_grid_to_spherical(isca_dyn_t *h, const double *grid, d
   spec_dev_to_host(h, h->d.scratch_s[0], spherical, nlev);
   API_END
 }
+// transforms.F90:555-596 trans_filter(grid [, filter]): grid -> spherical (truncated) -> optional real (m,n) factor -> grid
+extern "C" int isca_trans_filter(isca_dyn_t *h, double *grid, const double *filter, int nlev) {
+  API_BEGIN
+  require_single(h, "trans_filter"); check_nlev(h, nlev);
+  const Geom &g = h->g;
+  const size_t n = (size_t)nlev * g.Jl * g.I;
+  h2d(h, h->d.scratch_g[0], grid, n);
+  dev_g2s(h, h->d.scratch_g[0], h->d.scratch_s[0], nlev, 1, OP_NONE);
+  if (filter) {
+    std::vector<double> sp((size_t)nlev * g.N1 * g.M1 * 2);
+    spec_dev_to_host(h, h->d.scratch_s[0], sp.data(), nlev);
+    for (int k = 0; k < nlev; ++k)
+      for (size_t q = 0; q < (size_t)g.N1 * g.M1; ++q) {
+        sp[((size_t)k * g.N1 * g.M1 + q) * 2] *= filter[q];
+        sp[((size_t)k * g.N1 * g.M1 + q) * 2 + 1] *= filter[q];
+      }
+    spec_host_to_dev(h, sp.data(), h->d.scratch_s[0], nlev);
+  }
+  dev_s2g(h, h->d.scratch_s[0], h->d.scratch_g[0], nlev, OP_NONE);
+  d2h(h, grid, h->d.scratch_g[0], n);
+  API_END
+}
 extern "C" int isca_vor_div_from_uv_grid(isca_dyn_t *h, const double *u, const double *v, double *vor, double *div, int nlev) {
   API_BEGIN
   require_single(h, "vor_div_from_uv_grid"); check_nlev(h, nlev);
@@ -1414,6 +1436,7 @@ extern "C" int isca_dyn_diag_select(isca_dyn_t *h, const char *names) {
         const int k = diag_index(tok);
         if (k < 0) fail("diag_select: unknown field '" + tok + "'");
         if (k == 7 && !h->tracer_on) fail("diag_select: no grid tracer in this configuration");
+        if (k >= 20 && h->cfg.physics != 1) fail("diag_select: '" + tok + "' exists only with the moist physics package");
         mask |= 1u << k;
       }
       tok.clear();
@@ -1422,10 +1445,10 @@ extern "C" int isca_dyn_diag_select(isca_dyn_t *h, const char *names) {
   const Geom &g = h->g;
   const size_t ng2 = (size_t)g.Jl * g.I, ng3 = ng2 * g.L;
   for (int k = 0; k < NDIAG; ++k)
-    if ((mask >> k & 1u) && !h->d.diag_acc[k]) h->d.diag_acc[k] = dalloc<double>(h, k == 0 ? ng2 : ng3);
+    if ((mask >> k & 1u) && !h->d.diag_acc[k]) h->d.diag_acc[k] = dalloc<double>(h, diag_is_2d(k) ? ng2 : ng3);
   h->diag_mask = mask;
   for (int k = 0; k < NDIAG; ++k)
-    if (mask >> k & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[k], 0, (k == 0 ? ng2 : ng3) * sizeof(double), h->stream));
+    if (mask >> k & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[k], 0, (diag_is_2d(k) ? ng2 : ng3) * sizeof(double), h->stream));
   h->diag_count = 0;
   HIP_CHECK(hipStreamSynchronize(h->stream));
   API_END
@@ -1437,7 +1460,7 @@ extern "C" int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host,
   const int k = diag_index(name);
   if (k < 0 || !(h->diag_mask >> k & 1u)) fail(std::string("diag_read: field not selected: ") + name);
   const Geom &g = h->g;
-  const size_t n = (size_t)g.Jl * g.I * (k == 0 ? 1 : g.L);
+  const size_t n = (size_t)g.Jl * g.I * (diag_is_2d(k) ? 1 : g.L);
   if (nsteps) *nsteps = h->diag_count;
   if (host) {
     if (count != n) fail(std::string("diag_read: wrong element count for ") + name);
@@ -1446,7 +1469,7 @@ extern "C" int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host,
   }
   if (reset) {
     for (int q = 0; q < NDIAG; ++q)
-      if (h->diag_mask >> q & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[q], 0, (size_t)g.Jl * g.I * (q == 0 ? 1 : g.L) * sizeof(double), h->stream));
+      if (h->diag_mask >> q & 1u) HIP_CHECK(hipMemsetAsync(h->d.diag_acc[q], 0, (size_t)g.Jl * g.I * (diag_is_2d(q) ? 1 : g.L) * sizeof(double), h->stream));
     h->diag_count = 0;
     HIP_CHECK(hipStreamSynchronize(h->stream));
   }

@@ -79,8 +79,9 @@ void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const dou
 void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s);
 
 // spectral_diagnostics (spectral_dynamics.F90:1705-1867): add this step's fields to the running sums
-constexpr int NDIAG = 20;
-extern const char *const DIAG_NAMES[NDIAG];     // reference field names, index = bit in the mask; [0] is 2-D
+constexpr int NDIAG = 22;
+inline bool diag_is_2d(int k) { return k == 0 || k >= 20; }     // ps; moist package: precipitation, t_surf
+extern const char *const DIAG_NAMES[NDIAG];     // reference field names, index = bit in the mask; diag_is_2d(k): (lat, lon) fields
 void launch_diag_accumulate(const isca_dyn &h, int fut, hipStream_t s);
 
 size_t column_partials_count(const isca_dyn &h);

@@ -2395,9 +2395,10 @@ void launch_sw_tracer_tend(int n, const double *u, const double *v, const double
 // =====================================================================================================
 const char *const DIAG_NAMES[NDIAG] = {"ps", "ucomp", "vcomp", "temp", "vor", "div", "omega", "sphum", "ucomp_sq", "vcomp_sq",
                                        "ucomp_vcomp", "temp_sq", "ucomp_temp", "vcomp_temp", "omega_sq", "omega_temp",
-                                       "ucomp_omega", "vcomp_omega", "vcomp_vor", "wspd"};
+                                       "ucomp_omega", "vcomp_omega", "vcomp_vor", "wspd",
+                                       "precipitation", "t_surf"};     // idealized_moist_phys.F90:672, mixed_layer.F90:359
 struct DiagArgs {
-  const double *u, *v, *t, *ps, *vor, *div, *w, *tr;
+  const double *u, *v, *t, *ps, *vor, *div, *w, *tr, *precip, *t_surf;
   double *acc[NDIAG];
   unsigned mask;
   unsigned n3, n2;
@@ -2424,6 +2425,8 @@ __global__ __launch_bounds__(256) void k_diag_accumulate(DiagArgs a) {
   ACC(19, sqrt(u.x * u.x + v.x * v.x), sqrt(u.y * u.y + v.y * v.y))
 #undef ACC
   if ((m & 1u) && i < a.n2) { double2 s = *(double2 *)(a.acc[0] + i); const double2 p = *(const double2 *)(a.ps + i); s.x += p.x; s.y += p.y; *(double2 *)(a.acc[0] + i) = s; }
+  if ((m & (1u << 20)) && i < a.n2) { double2 s = *(double2 *)(a.acc[20] + i); const double2 p = *(const double2 *)(a.precip + i); s.x += p.x; s.y += p.y; *(double2 *)(a.acc[20] + i) = s; }
+  if ((m & (1u << 21)) && i < a.n2) { double2 s = *(double2 *)(a.acc[21] + i); const double2 p = *(const double2 *)(a.t_surf + i); s.x += p.x; s.y += p.y; *(double2 *)(a.acc[21] + i) = s; }
 }
 void launch_diag_accumulate(const isca_dyn &h, int fut, hipStream_t s) {
   const Geom &g = h.g;
@@ -2431,6 +2434,7 @@ void launch_diag_accumulate(const isca_dyn &h, int fut, hipStream_t s) {
   DiagArgs a;
   a.u = d.ug[fut]; a.v = d.vg[fut]; a.t = d.tg[fut]; a.ps = d.psg[fut]; a.vor = d.vorg; a.div = d.divg; a.w = d.wg_full;
   a.tr = h.tracer_on ? d.tr[fut] : nullptr;
+  a.precip = d.precip; a.t_surf = d.t_surf;
   for (int i = 0; i < NDIAG; ++i) a.acc[i] = d.diag_acc[i];
   a.mask = h.diag_mask;
   a.n2 = (unsigned)(g.Jl * g.I); a.n3 = a.n2 * (unsigned)g.L;

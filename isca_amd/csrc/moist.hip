@@ -61,12 +61,8 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     // ---- convection (:862-880): deltas over the step, then rates
     double rain, cape, cin;
     int flag, klzb, klcl;
-#ifdef MOIST_EXP_NOCONV
-    rain = 0; for (int k = 0; k < L; ++k) { dtT[k * s] = 0; dtq[k * s] = 0; }
-#else
     moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
                                      nullptr, nullptr, s);
-#endif
     double precip = rain / delta_t;
     // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
     double rain_ls;
@@ -118,7 +114,6 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     dtT[k * s] = t;
   }
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
-#ifndef MOIST_EXP_NOVD
   {
     const double h = moist::pbl_depth(a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s);
     moist::PblProfile pbl;
@@ -133,7 +128,6 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
     moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s);
   }
-#endif
   a.t_surf[c] = t_surf;
 }
 

@@ -26,6 +26,11 @@ FIELDS = {
     "ucomp_omega": ("vertical * zonal wind", "m*Pa/sec**2"), "vcomp_omega": ("vertical * meridional wind", "m*Pa/sec**2"),
     "vcomp_vor": ("meridional wind * vorticity", "m/sec**2"), "wspd": ("wind speed", "m/sec"),
 }
+# 2-D fields of the moist physics package and the module that registers them (idealized_moist_phys.F90:672, mixed_layer.F90:359)
+MOIST_FIELDS = {"precipitation": ("atmosphere", "precipitation from resolved, parameterised and snow", "kg/m/m/s"),
+                "t_surf": ("mixed_layer", "surface temperature", "K")}
+FIELDS.update({k: v[1:] for k, v in MOIST_FIELDS.items()})
+TWO_D = ("ps",) + tuple(MOIST_FIELDS)
 STATIC = {"pk": ("vertical coordinate pressure values", "pascals"), "bk": ("vertical coordinate sigma values", "none")}
 _SECONDS = {"seconds": 1, "minutes": 60, "hours": 3600, "days": 86400}
 
@@ -42,8 +47,12 @@ class DiagTable:
         self.files[name] = {"name": name, "freq": freq, "units": units, "time_units": time_units or units, "fields": []}
 
     def add_field(self, module, name, time_avg=False, files=None):
-        if module != "dynamics":
-            raise IscaError(f"diag_table: module {module!r} is outside the dynamical core (only 'dynamics')")
+        if name in MOIST_FIELDS:
+            if module != MOIST_FIELDS[name][0]:
+                raise IscaError(f"diag_table: field {name!r} belongs to module {MOIST_FIELDS[name][0]!r}")
+        elif module != "dynamics":
+            raise IscaError(f"diag_table: module {module!r} is outside the dynamical core (only 'dynamics', and precipitation / t_surf "
+                            "of the moist package)")
         if name not in FIELDS and name not in STATIC:
             raise IscaError(f"diag_table: unknown dynamics field {name!r}")
         for f in (files or list(self.files)):
@@ -89,8 +98,8 @@ class History:
             mean, n = self.core.diag_mean(nm)
             if not self.avg[nm]:                # instantaneous sample at the end of the interval
                 mean = self.core.get({"ucomp": "ug", "vcomp": "vg", "temp": "tg", "ps": "psg", "vor": "vorg", "div": "divg",
-                                      "omega": "wg_full", "sphum": "tr"}.get(nm, nm)) if nm in (
-                    "ucomp", "vcomp", "temp", "ps", "vor", "div", "omega", "sphum") else mean
+                                      "omega": "wg_full", "sphum": "tr", "precipitation": "precip"}.get(nm, nm)) if nm in (
+                    "ucomp", "vcomp", "temp", "ps", "vor", "div", "omega", "sphum", "precipitation", "t_surf") else mean
             rec[nm] = mean
         if self.names:
             self.core.diag_reset(self.names[0])
@@ -124,7 +133,7 @@ class History:
             v = f.createVariable(nm, "d", ("phalf",)); v[:] = c.table(nm); v.long_name, v.units = STATIC[nm]
         out = {}
         for nm in self.names:
-            dims = ("time", "lat", "lon") if nm == "ps" else ("time", "pfull", "lat", "lon")
+            dims = ("time", "lat", "lon") if nm in TWO_D else ("time", "pfull", "lat", "lon")
             v = f.createVariable(nm, "d", dims); v.long_name, v.units = FIELDS[nm]
             if self.avg[nm]:
                 v.cell_methods = "time: mean"; v.time_avg_info = "average_T1,average_T2,average_DT"

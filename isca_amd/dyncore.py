@@ -107,6 +107,7 @@ def load_library():
         "isca_trans_fourier_to_grid": [H, dp, dp, C.c_int],
         "isca_area_weighted_global_mean": [H, dp, dp],
         "isca_hs_forcing": [H, C.c_double, dp, dp, dp, dp, dp, dp, dp, dp],
+        "isca_trans_filter": [H, dp, dp, C.c_int],
         "isca_idealized_moist_phys": [H, C.c_int, C.c_double, C.c_double] + [dp] * 17,
         "isca_bench_transform_pair": [H, C.c_int, C.c_int, dp, dp],
         "isca_compute_laplacian": [H, dp, dp, C.c_int, C.c_int],
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = [
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest",
-    "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys",
+    "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
@@ -347,6 +348,16 @@ class DynCore:
         self._check(self.lib.isca_trans_grid_to_spherical(self._h, _dptr(g), _dptr(s.view(np.float64)), g.shape[0],
                                                           1 if do_truncation else 0))
         return s[0] if two_d else s
+
+    def trans_filter(self, grid, filter=None):
+        """trans_filter: spectral truncation of a grid field, optionally times a real (n, m) factor per coefficient."""
+        g, two_d = self._nlev(grid, 3)
+        g = np.array(g, dtype=np.float64, copy=True)
+        f = None if filter is None else np.ascontiguousarray(filter, dtype=np.float64)
+        if f is not None and f.shape != (self.N1, self.M1):
+            raise IscaError("trans_filter: filter must have the spectral shape (n, m)")
+        self._check(self.lib.isca_trans_filter(self._h, _dptr(g), None if f is None else _dptr(f), g.shape[0]))
+        return g[0] if two_d else g
 
     def vor_div_from_uv_grid(self, u, v):
         u, two_d = self._nlev(u, 3); v, _ = self._nlev(v, 3)
@@ -565,7 +576,7 @@ class DynCore:
 
     def diag_mean(self, name: str, reset: bool = False):
         """-> (time mean since the last reset, number of steps in it)"""
-        a = np.zeros((self.Jl, self.I) if name == "ps" else (self.L, self.Jl, self.I))
+        a = np.zeros((self.Jl, self.I) if name in ("ps", "precipitation", "t_surf") else (self.L, self.Jl, self.I))
         n = C.c_long()
         self._check(self.lib.isca_dyn_diag_read(self._h, name.encode(), _dptr(a), a.size, C.byref(n), 1 if reset else 0))
         return a, n.value

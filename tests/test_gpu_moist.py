@@ -180,3 +180,42 @@ def test_moist_sharded_matches_single():
            "--moist"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=repo)
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_moist_diagnostics_and_history(tmp_path):
+    """precipitation (module atmosphere) and t_surf (module mixed_layer) as device-side time means next to the dynamics fields,
+    and in the history file the diag_table asks for."""
+    from isca_amd.diag import DiagTable, History
+    from scipy.io import netcdf_file
+    dc = moist_core()
+    dc.cold_start()
+    dc.step(600)                                   # 5 days: the boundary layer has moistened and it rains
+    dc.diag_select(["precipitation", "t_surf", "temp"])
+    acc_p, acc_t = np.zeros((dc.Jl, dc.I)), np.zeros((dc.Jl, dc.I))
+    for _ in range(6):
+        dc.step(1)
+        acc_p += dc.get("precip"); acc_t += dc.get("t_surf")
+    mp, n = dc.diag_mean("precipitation")
+    mt, _ = dc.diag_mean("t_surf")
+    assert n == 6 and rel(mp, acc_p / 6) < 1e-14 and rel(mt, acc_t / 6) < 1e-15 and mp.max() > 0
+    dc.diag_select("")
+    tab = DiagTable()
+    tab.add_file("atmos_6h", 2, "hours")
+    tab.add_field("dynamics", "ps", time_avg=True)
+    tab.add_field("atmosphere", "precipitation", time_avg=True)
+    tab.add_field("mixed_layer", "t_surf", time_avg=True)
+    with pytest.raises(dyncore.IscaError, match="belongs to module"):
+        tab.add_field("dynamics", "t_surf")
+    hist = History(dc, tab.files["atmos_6h"], 720.0, str(tmp_path / "atmos_6h.nc"))
+    for _ in range(2):
+        dc.step(10)
+        hist.after_steps(10)
+    hist.close()
+    f = netcdf_file(str(tmp_path / "atmos_6h.nc"), "r", mmap=False)
+    assert f.variables["precipitation"].shape == (2, dc.J, dc.I) and f.variables["t_surf"][:].min() > 200.0
+    f.close()
+    dc.close()
+    hs = dyncore.DynCore(dyncore.default_config("T21"))
+    with pytest.raises(dyncore.IscaError, match="moist physics package"):
+        hs.diag_select(["t_surf"])
+    hs.close()

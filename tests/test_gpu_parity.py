@@ -298,6 +298,22 @@ def test_sharded_device_path_matches_single(world, res, levels):
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_trans_filter(golden_dir):
+    """trans_filter = analysis, optional factor, synthesis (transforms.F90:555-580): equals the two transforms composed, and is a
+    projection (filtering twice changes nothing beyond roundoff)."""
+    g = np.load(os.path.join(golden_dir, "kernels_T21L6.npz"))
+    dc = make("T21", 6)
+    ga = g["in_grid_a"]
+    f1 = dc.trans_filter(ga)
+    assert rel(f1, dc.trans_spherical_to_grid(dc.trans_grid_to_spherical(ga))) < 1e-14
+    assert rel(dc.trans_filter(f1), f1) < 1e-13
+    n = np.arange(dc.N1)[:, None] + np.arange(dc.M1)[None, :]
+    filt = np.exp(-(n / 15.0) ** 2)
+    assert rel(dc.trans_filter(ga, filt), dc.trans_spherical_to_grid(dc.trans_grid_to_spherical(ga) * filt)) < 1e-14
+    assert rel(dc.trans_filter(ga[0]), f1[0]) < 1e-15
+    dc.close()
+
+
 def test_atmosphere_module_mirror(golden_dir):
     """The module-level mirror of atmosphere_mod / transforms_mod drives the same C-ABI."""
     from isca_amd import atmosphere as atm
