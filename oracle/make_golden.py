@@ -420,6 +420,17 @@ def main():
         path = os.path.join(GOLD, "run_T42L25.npz")
         np.savez_compressed(path, **out)
         print(f"run_T42L25: {os.path.getsize(path)/1e6:.2f} MB")
+    if not a.only or a.only == "run_T85L40":
+        # the benchmark configuration itself (T85L40, dt = 300 s), 20 steps from the cold start; 3-D fields kept as the
+        # [::4, ::8, ::8] sample (every 4th level, 8th latitude and longitude), ps as [::4, ::4]
+        out = golden_run("T85", 40, 20, (20,), dt=300, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000020$", k) is not None)
+        for k in list(out):
+            if k.startswith("st_"):
+                a3 = out.pop(k)
+                out[k + ("_s488" if a3.ndim == 3 else "_s44")] = np.ascontiguousarray(a3[::4, ::8, ::8] if a3.ndim == 3 else a3[::4, ::4])
+        path = os.path.join(GOLD, "run_T85L40.npz")
+        np.savez_compressed(path, **out)
+        print(f"run_T85L40: {os.path.getsize(path)/1e6:.2f} MB")
     if not a.only or a.only == "tables_T85":
         out = golden_run("T85", 2, 0, (), keep=lambda k: k.startswith("tab_"))
         leg = out.pop("tab_legendre")

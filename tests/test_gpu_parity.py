@@ -110,6 +110,25 @@ def test_golden_T42L25_one_day(golden_dir):
     dc.close()
 
 
+def test_golden_T85L40_benchmark_config(golden_dir):
+    """The benchmark configuration itself (T85L40, dt = 300 s): 20 steps from the cold start against the reference run, on the
+    committed [::4, ::8, ::8] sample (ps: [::4, ::4]); winds as a fraction of max(|u|, 1 m/s) since the state is close to rest."""
+    g = np.load(os.path.join(golden_dir, "run_T85L40.npz"))
+    dc = make("T85", 40, dt_atmos=300.0); dc.cold_start()
+    dc.step(20)
+    err = {}
+    for k, gk in (("ug", "st_ug_000020_s488"), ("vg", "st_vg_000020_s488"), ("tg", "st_tg_000020_s488"), ("tr", "st_tr1_000020_s488")):
+        ref = g[gk]
+        err[k] = float(np.abs(dc.get(k)[::4, ::8, ::8] - ref).max() / max(np.abs(ref).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+    err["psg"] = rel(dc.get("psg")[::4, ::4], g["st_psg_000020_s44"])
+    print("T85L40, 20 steps vs the reference:", err)
+    assert max(err.values()) < 1e-9, err            # measured: u, v 9e-12, T 5e-14, ps 2e-14, tracer 1e-10
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    dc.close()
+
+
 def test_golden_T21L25_ten_days(golden_dir):
     """configs[0] for 10 days (1440 steps) against the reference run: SURVEY 8d's long-run bound is 1e-7 relative
     (the reference's own response to a 1-ulp perturbation of the initial temperature is 2e-10 m/s after 10 days)."""
