@@ -26,9 +26,9 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def moist_core(res="T21", dt=720.0, **kw):
+def moist_namelist(res="T21", dt=720.0):
     """The namelist of the reference run behind the fixtures (oracle/make_golden.py moist_input_nml)."""
-    nml = {
+    return {
         "atmosphere_nml": {"idealized_moist_model": True},
         "main_nml": {"dt_atmos": dt},
         "spectral_dynamics_nml": dict(damping_order=4, water_correction_limit=200.e2, reference_sea_level_press=1.0e5, num_levels=25,
@@ -48,7 +48,10 @@ def moist_core(res="T21", dt=720.0, **kw):
         "damping_driver_nml": dict(do_rayleigh=True, trayfric=-0.25, sponge_pbottom=5000., do_conserve_energy=True),
         "two_stream_gray_rad_nml": dict(rad_scheme="frierson", do_seasonal=False, atm_abs=0.2),
     }
-    return dyncore.DynCore(atm.config_from_namelist(nml, **kw))
+
+
+def moist_core(res="T21", dt=720.0, **kw):
+    return dyncore.DynCore(atm.config_from_namelist(moist_namelist(res, dt), **kw))
 
 
 def test_moist_physics_columns(golden_dir):
@@ -219,3 +222,27 @@ def test_moist_diagnostics_and_history(tmp_path):
     with pytest.raises(dyncore.IscaError, match="moist physics package"):
         hs.diag_select(["t_surf"])
     hs.close()
+
+
+def test_moist_experiment_segments(tmp_path):
+    """Run segmentation with the moist namelist: the restart archive carries mixed_layer.res.nc, the second segment continues from it,
+    the history file holds precipitation and t_surf."""
+    import tarfile
+    from isca_amd.experiment import Experiment
+    from scipy.io import netcdf_file
+    e = Experiment("frierson_mini", str(tmp_path))
+    nml = moist_namelist()
+    nml["main_nml"].update({"days": 0, "hours": 4, "dt_atmos": 720})
+    e.update_namelist(nml)
+    e.diag_table.add_file("atmos_2h", 2, "hours")
+    e.diag_table.add_field("dynamics", "temp", time_avg=True)
+    e.diag_table.add_field("atmosphere", "precipitation", time_avg=True)
+    e.diag_table.add_field("mixed_layer", "t_surf", time_avg=True)
+    assert e.run(1) and e.run(2)
+    with tarfile.open(e.get_restart_file(2)) as tar:
+        names = {os.path.basename(n) for n in tar.getnames()}
+    assert {"spectral_dynamics.res.nc", "atmosphere.res.nc", "mixed_layer.res.nc"} <= names
+    f = netcdf_file(os.path.join(e.get_outputdir(2), "atmos_2h.nc"), "r", mmap=False)
+    assert f.variables["t_surf"].shape == (2, 32, 64) and f.variables["precipitation"].shape == (2, 32, 64)
+    assert np.allclose(f.variables["average_T1"][:], [4.0, 6.0])
+    f.close()
