@@ -187,3 +187,44 @@ def test_tracer_trajectories(golden_dir):
     for i in range(144):
         sc.step()
     assert rel(sc.tr[sc.current], g["st_tr1_000144"]) < 1e-10
+
+
+# ------------------------------------------------------------------ sibling cores (oracle/sibling_oracle.py)
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_shallow_oracle_vs_reference(golden_dir):
+    """numpy restatement of src/atmos_spectral_shallow against the reference's own run (vortex pair on a zonal flow, both tracers)."""
+    from oracle.sibling_oracle import ShallowOracle
+    g = np.load(os.path.join(golden_dir, "shallow_run_T21.npz"))
+    o = ShallowOracle("T21", add_initial_vortex_pair=True, u_upper_mag_init=10.0, u_deep_mag=5.0)
+    assert _rel(o.deep, g["tab_deep_geopot"]) < 1e-13
+    for mine, ref in ((o.u[0], "u"), (o.h[0], "h"), (o.vor[0], "vor"), (o.tr[0], "tr"), (o.vors[0], "vors"), (o.hs[0], "hs")):
+        assert _rel(mine, g["st_%s_000000" % ref]) < 1e-13, ref
+    done = 0
+    for n, tol in ((1, 1e-12), (2, 1e-12), (10, 1e-11), (200, 1e-9)):
+        for _ in range(n - done):
+            o.step()
+        done = n
+        c = o.current
+        err = {k: _rel(v, g["st_%s_%06d" % (k, n)]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("h", o.h[c]), ("tr", o.tr[c]),
+                                                               ("trs", o.trs[c]), ("vors", o.vors[c]), ("hs", o.hs[c]), ("pv", o.pv),
+                                                               ("stream", o.stream()))}
+        assert max(err.values()) < tol, (n, err)
+
+
+def test_barotropic_oracle_vs_reference(golden_dir):
+    from oracle.sibling_oracle import BarotropicOracle
+    g = np.load(os.path.join(golden_dir, "barotropic_run_T21.npz"))
+    o = BarotropicOracle("T21")
+    assert _rel(o.zonal_u_init, g["tab_zonal_u_init"]) < 1e-15
+    done = 0
+    for n, tol in ((1, 1e-12), (10, 1e-11), (200, 1e-9)):
+        for _ in range(n - done):
+            o.step()
+        done = n
+        c = o.current
+        err = {k: _rel(v, g["st_%s_%06d" % (k, n)]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("tr", o.tr[c]),
+                                                               ("trs", o.trs[c]), ("vors", o.vors[c]), ("pv", o.pv), ("stream", o.stream()))}
+        assert max(err.values()) < tol, (n, err)
