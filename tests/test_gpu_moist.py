@@ -144,6 +144,12 @@ def test_moist_surface_state_and_errors():
     assert np.abs(dc.get("t_surf") - ts).max() > 1e-4 and dc.get("precip").min() >= 0.0
     assert np.isfinite(dc.get("dt_tg")).all()
     dc.close()
+    # more levels than the LDS work arrays hold (global-memory work arrays, the 64-level instance of the convection arrays)
+    big = dyncore.DynCore(dyncore.default_config("T21", num_levels=50, physics=1, dt_atmos=600.0, initial_sphum=2e-6, scale_heights=8.0))
+    big.cold_start()
+    big.step(30)
+    assert np.isfinite(big.get("tg")).all() and np.isfinite(big.get("tr")).all() and big.get("tr").max() > 2e-6
+    big.close()
     hs = dyncore.DynCore(dyncore.default_config("T21"))
     with pytest.raises(dyncore.IscaError, match="moist physics"):
         hs.get("t_surf")
