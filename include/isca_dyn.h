@@ -198,6 +198,9 @@ int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host, size_t cou
  * distributes the 128 bytes; every rank calls isca_dyn_comm_init (collective).  RCCL is loaded with dlopen. */
 int isca_comm_get_unique_id(void *id128);
 int isca_dyn_comm_init(isca_dyn_t *h, const void *id128);
+/* collective over all ranks after isca_dyn_comm_init: rank-tagged patterns through every exchange of the sharded step; non-zero if
+ * this rank received wrong data (the host driver then keeps the exchanges in torch.distributed) */
+int isca_dyn_comm_check(isca_dyn_t *h);
 int isca_comm_selftest(int device, double *max_err);     /* one-rank communicator: load RCCL, run every collective once */
 
 /* --- components of the step on caller fields (world_size == 1) -------------------------------------

@@ -833,6 +833,56 @@ extern "C" int isca_dyn_comm_init(isca_dyn_t *h, const void *id128) {
   h->comm = new isca::Comm(id128, h->cfg.rank, h->cfg.world_size);
   API_END
 }
+// Cross-rank check of the communicator before the step trusts it: every collective of the sharded step moves rank-tagged
+// patterns through the step's own buffers (all-to-all + halo in one group, plain all-to-all, all-reduce) and each rank verifies
+// what it received.  Collective over all ranks; non-zero = this rank saw wrong data (the caller then falls back).
+extern "C" int isca_dyn_comm_check(isca_dyn_t *h) {
+  API_BEGIN
+  if (!h || !h->comm) fail("comm_check: no communicator");
+  const Geom &g = h->g;
+  isca::Comm &c = *h->comm;
+  const int P = g.P, me = g.rank;
+  const size_t blk = (size_t)g.Ml * g.Jl * h->Cf;                   // doubles per peer of the forward exchange
+  const size_t nh = h->tracer_on ? (size_t)3 * g.L * 2 * g.I : 0;
+  std::vector<double> send(blk * P), recv(blk * P, -1.0);
+  for (int q = 0; q < P; ++q)
+    for (size_t i = 0; i < blk; ++i) send[q * blk + i] = 1000.0 * me + q + 1e-3 * (double)(i % 997);
+  h2d(h, h->d.Ff_g, send.data(), send.size());
+  std::vector<double> hs(2 * nh), hr(2 * nh, -1.0);
+  for (size_t i = 0; i < nh; ++i) { hs[i] = 10.0 * me + 1 + 1e-3 * (double)(i % 991); hs[nh + i] = 10.0 * me + 2 + 1e-3 * (double)(i % 991); }
+  if (nh) { h2d(h, h->d.halo_send, hs.data(), hs.size()); h2d(h, h->d.halo_recv, hr.data(), hr.size()); }
+  // all collectives first (every rank takes part in each of them), verification afterwards
+  c.all_to_all_with_halo(h->d.Ff_g, h->d.Ff_s, blk, h->d.halo_send, h->d.halo_send + nh, h->d.halo_recv, h->d.halo_recv + nh, nh, h->stream);
+  d2h(h, recv.data(), h->d.Ff_s, recv.size());
+  if (nh) d2h(h, hr.data(), h->d.halo_recv, hr.size());
+  const size_t blk_i = (size_t)g.Ml * g.Jl * h->Ci;
+  std::vector<double> s2(blk_i * P), r2(blk_i * P, -1.0);
+  for (int q = 0; q < P; ++q)
+    for (size_t i = 0; i < blk_i; ++i) s2[q * blk_i + i] = 7.0 * me + 0.5 * q + 1e-3 * (double)(i % 983);
+  h2d(h, h->d.Fi_s, s2.data(), s2.size());
+  c.all_to_all(h->d.Fi_s, h->d.Fi_g, blk_i, h->stream);
+  d2h(h, r2.data(), h->d.Fi_g, r2.size());
+  std::vector<double> red(10), keep(32);
+  d2h(h, keep.data(), h->d.red, 32);
+  for (int i = 0; i < 10; ++i) red[i] = (double)(me + 1) * (i + 1);
+  h2d(h, h->d.red, red.data(), 10);
+  c.all_reduce_sum(h->d.red, 10, h->stream);
+  d2h(h, red.data(), h->d.red, 10);
+  h2d(h, h->d.red, keep.data(), 32);
+  for (int q = 0; q < P; ++q)
+    for (size_t i = 0; i < blk; ++i)
+      if (recv[q * blk + i] != 1000.0 * q + me + 1e-3 * (double)(i % 997)) fail("comm_check: all-to-all delivered wrong data");
+  for (size_t i = 0; i < nh; ++i) {     // recv_lo came from rank-1's send_hi, recv_hi from rank+1's send_lo
+    if (me > 0 && hr[i] != 10.0 * (me - 1) + 2 + 1e-3 * (double)(i % 991)) fail("comm_check: halo (lower neighbour) delivered wrong data");
+    if (me < P - 1 && hr[nh + i] != 10.0 * (me + 1) + 1 + 1e-3 * (double)(i % 991)) fail("comm_check: halo (upper neighbour) delivered wrong data");
+  }
+  for (int q = 0; q < P; ++q)
+    for (size_t i = 0; i < blk_i; ++i)
+      if (r2[q * blk_i + i] != 7.0 * q + 0.5 * me + 1e-3 * (double)(i % 983)) fail("comm_check: inverse all-to-all delivered wrong data");
+  for (int i = 0; i < 10; ++i)
+    if (red[i] != 0.5 * P * (P + 1) * (i + 1)) fail("comm_check: all-reduce gave a wrong sum");
+  API_END
+}
 // Exercises every collective of the sharded step on a communicator of this process alone (world_size 1):
 // checks that RCCL can be loaded and that send/recv, grouped exchange and all-reduce run on the given device.
 extern "C" int isca_comm_selftest(int device, double *max_err) {

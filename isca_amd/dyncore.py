@@ -154,7 +154,7 @@ EXPORTED_SYMBOLS = [
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
-    "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest",
+    "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check",
     "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter",
 ]
 

@@ -120,6 +120,11 @@ class ShardedDynCore(dyncore.DynCore):
                 flags = [None] * cfg.world_size
                 dist.all_gather_object(flags, ok if ok else self.lib.isca_last_error().decode(), group=group)
                 bad = [f for f in flags if f is not True]
+                if not bad:           # every rank has a communicator: move rank-tagged patterns through every exchange of the step
+                    self.lib.isca_dyn_comm_check.argtypes, self.lib.isca_dyn_comm_check.restype = [C.c_void_p], C.c_int
+                    ok = self.lib.isca_dyn_comm_check(self._h) == 0
+                    dist.all_gather_object(flags, ok if ok else self.lib.isca_last_error().decode(), group=group)
+                    bad = [f for f in flags if f is not True]
                 if bad:
                     why = str(bad[0])
                 else:

@@ -541,6 +541,21 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["replicas"]["value"] > 0 and "workload" in d["config"]
 
 
+def test_rccl_comm_check_single_rank():
+    """isca_dyn_comm_check (rank-tagged patterns through the step's exchange buffers) on a one-rank communicator: the path every
+    rank runs before the native exchange driver is trusted."""
+    import ctypes as C
+    dc = make("T21", 6)
+    buf = C.create_string_buffer(128)
+    assert dc.lib.isca_comm_get_unique_id(buf) == 0
+    assert dc.lib.isca_dyn_comm_init(dc._h, buf.raw) == 0, dc.lib.isca_last_error()
+    dc.lib.isca_dyn_comm_check.argtypes, dc.lib.isca_dyn_comm_check.restype = [C.c_void_p], C.c_int
+    assert dc.lib.isca_dyn_comm_check(dc._h) == 0, dc.lib.isca_last_error()
+    dc.cold_start(); dc.step(2)                       # the buffers it used are scratch of the step: the model still runs
+    assert np.isfinite(dc.get("tg")).all()
+    dc.close()
+
+
 def test_rccl_layer_selftest():
     """The native exchange layer (RCCL through dlopen): library loads, communicator of one rank is created on this GPU,
     grouped send/recv all-to-all, all-reduce and the (empty) halo exchange run on a stream and return the data unchanged."""
