@@ -261,8 +261,10 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
 }
 
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
-static unsigned fft_grid(int items) {                  // persistent blocks: 3 per CU of the 256 (LDS-limited residency)
-  return (unsigned)std::min(items, 768);             // measured against 512 / 1024 / 1536
+static unsigned fft_grid(int items) {                  // persistent blocks: at most 3 per CU of the 256 (LDS-limited residency; measured
+  const int cap = 768;                                 // against 512 / 1024 / 1536), and the same number of items for every block
+  const int rounds = (items + cap - 1) / cap;
+  return (unsigned)((items + rounds - 1) / rounds);
 }
 static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
