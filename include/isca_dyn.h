@@ -29,8 +29,6 @@ extern "C" {
 
 typedef struct isca_dyn isca_dyn_t;
 
-/* namelist keys used on the path: spectral_dynamics_nml (spectral_dynamics.F90:152-224),
- * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
 #define ISCA_MAX_LEVELS 128
 
 /* Parameters of the moist physics package, physics = 1: idealized_moist_phys with the options of the Frierson grey-radiation
@@ -54,6 +52,8 @@ typedef struct isca_moist_config {
   double rich_crit, drag_min;                                     /* monin_obukhov_nml */
 } isca_moist_config;
 
+/* namelist keys used on the path: spectral_dynamics_nml (spectral_dynamics.F90:152-224),
+ * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
 typedef struct isca_dyn_config {
   int lon_max, lat_max, num_fourier, num_spherical, num_levels;
   int fourier_inc;              /* must be 1 */
