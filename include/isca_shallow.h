@@ -10,6 +10,7 @@
 #ifndef ISCA_SHALLOW_H
 #define ISCA_SHALLOW_H
 #include <stddef.h>
+#include "isca_stirring.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -17,7 +18,7 @@ extern "C" {
 typedef struct isca_shallow isca_shallow_t;
 
 /* shallow_dynamics_nml (shallow_dynamics.F90:117-194), shallow_physics_nml (shallow_physics.F90:88-103), main_nml dt_atmos.
- * Not carried: initial_condition_from_input_file (netCDF), stirring (stirring_nml amplitude must stay 0), fourier_inc /= 1,
+ * Not carried: initial_condition_from_input_file (netCDF), fourier_inc /= 1,
  * rhomboidal truncation, the exponential damping option. */
 typedef struct isca_shallow_config {
   int num_lon, num_lat, num_fourier, num_spherical;
@@ -33,6 +34,7 @@ typedef struct isca_shallow_config {
   /* shallow_physics_nml; phys_h_0 is that namelist's own h_0 */
   double fric_damp_time, therm_damp_time, phys_h_0, h_amp, h_lon, h_lat, h_width, h_itcz, itcz_width;
   int device;
+  isca_stirring_config stirring;
 } isca_shallow_config;
 
 int isca_shallow_config_default(isca_shallow_config *cfg);
@@ -45,12 +47,15 @@ int isca_shallow_cold_start(isca_shallow_t *h);
  * checks valid_range_v on return ("meridional wind out of valid range") */
 int isca_shallow_step(isca_shallow_t *h, int nsteps);
 /* state: grid "u","v","vor","div","h","tr","trs" (time_level 0 = previous, 1 = current), "stream","pv","h_eq","deep_geopot";
- * spectral "vors","divs","hs","trss" as (m, n) complex */
+ * spectral "vors","divs","hs","trss","stirs" as (m, n) complex */
 int isca_shallow_get_state(isca_shallow_t *h, const char *name, int time_level, double *host, size_t count);
 int isca_shallow_set_state(isca_shallow_t *h, const char *name, int time_level, const double *host, size_t count);
 /* "previous", "current" (0/1 storage slots), "step" */
 int isca_shallow_get_info(isca_shallow_t *h, const char *name, long *value);
 /* restart branch: restore the time pointers after both levels of the spectral and grid state have been set */
+/* the (0:num_fourier, 0:num_spherical, 2) uniform random numbers in [0,1) the NEXT step's stirring uses instead of drawing its own
+ * (stirring.F90:205-210 calls random_number); consumed by that step.  The AR(1) state is the spectral field "stirs" of get/set_state. */
+int isca_shallow_set_stirring_noise(isca_shallow_t *h, const double *ran, size_t count);
 int isca_shallow_set_time_pointers(isca_shallow_t *h, int previous, int current, long step_count);
 
 #ifdef __cplusplus

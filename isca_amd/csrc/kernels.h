@@ -22,6 +22,7 @@ struct SwSpecArgs {
   const double2 *vor_p, *div_p, *h_p;
   double2 *vor_c, *div_c, *h_c, *vor_f, *div_f, *h_f;
   const double2 *dt_vor, *dt_div, *dt_h, *bs;
+  const double2 *stir;                        // stirring added to the vorticity tendency after the damping (null: none)
   double delta_t, robert, h_0, damping_r;     // damping_r: spectral_damping_init's damping_coeff_r (linear drag), 0 for shallow water
   int first, mode;
 };
@@ -30,6 +31,8 @@ void launch_bt_grid_tend(int n, int I, const double *u, const double *v, const d
                          double *pv, hipStream_t s);
 void launch_sw_spec_update(const Geom &g, const SwSpecArgs &a, hipStream_t s);
 void launch_sw_grid_tracer_filter(int n, double robert, const double *prev, double *cur, const double *adv, double *fut, hipStream_t s);
+void launch_sw_stir_update(const Geom &g, double bstir, int mn00, const double *fresh, double *s_stir, hipStream_t s);
+void launch_sw_scale_grid(int n, const double *factor, double *field, hipStream_t s);
 void launch_sw_tracer_tend(int n, const double *u, const double *v, const double *dx, const double *dy, double *tend, hipStream_t s);
 
 // ---- transforms

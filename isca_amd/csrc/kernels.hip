@@ -2342,6 +2342,7 @@ __global__ void k_sw_spec_update(Geom g, SwSpecArgs a) {
     const double2 p = a.vor_p[mn], c = a.vor_c[mn];
     double2 dt = a.dt_vor[mn];
     dt = make_double2(coeff * (dt.x - dmp * p.x), coeff * (dt.y - dmp * p.y));
+    if (a.stir) { const double2 st = a.stir[mn]; dt = make_double2(dt.x + st.x, dt.y + st.y); }
     double2 f, cn;
     sw_leapfrog(a.first, a.delta_t, a.robert, p, c, dt, f, cn);
     a.vor_c[mn] = cn; a.vor_f[mn] = f;
@@ -2358,6 +2359,7 @@ __global__ void k_sw_spec_update(Geom g, SwSpecArgs a) {
   dtd = make_double2((dtd.x + mu * eig * dth.x) / den, (dtd.y + mu * eig * dth.y) / den);
   dth = make_double2(dth.x - mu * a.h_0 * dtd.x, dth.y - mu * a.h_0 * dtd.y);
   dtv = make_double2(coeff * (dtv.x - dmp * vp.x), coeff * (dtv.y - dmp * vp.y));
+  if (a.stir) { const double2 st = a.stir[mn]; dtv = make_double2(dtv.x + st.x, dtv.y + st.y); }
   dtd = make_double2(coeff * (dtd.x - dmp * dp.x), coeff * (dtd.y - dmp * dp.y));
   dth = make_double2(coeff * (dth.x - dmp * hp.x), coeff * (dth.y - dmp * hp.y));
   double2 f, cn;
@@ -2367,6 +2369,26 @@ __global__ void k_sw_spec_update(Geom g, SwSpecArgs a) {
 }
 void launch_sw_spec_update(const Geom &g, const SwSpecArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_sw_spec_update, grid1d((size_t)g.Ml * g.N1), dim3(256), 0, s, g, a);
+}
+// stirring (stirring.F90:216-224): the freshly localised forcing loses its (0,0) coefficient and enters the AR(1) state
+__global__ void k_sw_stir_update(int n, double bstir, int mn00, const double2 *__restrict__ fresh, double2 *s_stir) {
+  const int mn = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mn >= n) return;
+  double2 f = fresh[mn];
+  if (mn == mn00) f = make_double2(0.0, 0.0);
+  const double2 s = s_stir[mn];
+  s_stir[mn] = make_double2(bstir * s.x + f.x, bstir * s.y + f.y);
+}
+void launch_sw_stir_update(const Geom &g, double bstir, int mn00, const double *fresh, double *s_stir, hipStream_t s) {
+  const int n = g.Ml * g.N1;
+  hipLaunchKernelGGL(k_sw_stir_update, grid1d((size_t)n), dim3(256), 0, s, n, bstir, mn00, (const double2 *)fresh, (double2 *)s_stir);
+}
+__global__ void k_sw_scale_grid(int n, const double *__restrict__ factor, double *field) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) field[i] = factor[i] * field[i];
+}
+void launch_sw_scale_grid(int n, const double *factor, double *field, hipStream_t s) {
+  hipLaunchKernelGGL(k_sw_scale_grid, grid1d((size_t)n), dim3(256), 0, s, n, factor, field);
 }
 // update_grid_tracer (:521-530) after the van Leer step: Robert filter of the current level, new level stored
 __global__ void k_sw_grid_tracer_filter(int n, double robert, const double *__restrict__ prev, double *cur, const double *__restrict__ adv,

@@ -11,6 +11,21 @@ import numpy as np
 from .dyncore import IscaError, RESOLUTIONS, load_library
 
 
+class _CStirringConfig(C.Structure):
+    _fields_ = [("decay_time", C.c_double), ("amplitude", C.c_double), ("lat0", C.c_double), ("lon0", C.c_double), ("widthy", C.c_double),
+                ("widthx", C.c_double), ("B", C.c_double), ("do_localize", C.c_int), ("n_total_forcing_max", C.c_int),
+                ("n_total_forcing_min", C.c_int), ("zonal_forcing_min", C.c_int), ("seed", C.c_ulonglong)]
+
+
+def _apply_stirring(c, nml):
+    """stirring_nml -> cfg.stirring (names unchanged; `seed` is ours)."""
+    for k, v in (nml.get("stirring_nml") or {}).items():
+        k = {"b": "B"}.get(k.lower(), k.lower())
+        if not hasattr(c.stirring, k):
+            raise IscaError(f"stirring_nml: unknown variable {k!r}")
+        setattr(c.stirring, k, int(v) if isinstance(v, bool) else v)
+
+
 class _CShallowConfig(C.Structure):
     _fields_ = [
         ("num_lon", C.c_int), ("num_lat", C.c_int), ("num_fourier", C.c_int), ("num_spherical", C.c_int), ("dt_atmos", C.c_double),
@@ -23,13 +38,13 @@ class _CShallowConfig(C.Structure):
         ("valid_range_v", C.c_double * 2),
         ("fric_damp_time", C.c_double), ("therm_damp_time", C.c_double), ("phys_h_0", C.c_double), ("h_amp", C.c_double),
         ("h_lon", C.c_double), ("h_lat", C.c_double), ("h_width", C.c_double), ("h_itcz", C.c_double), ("itcz_width", C.c_double),
-        ("device", C.c_int),
+        ("device", C.c_int), ("stirring", _CStirringConfig),
     ]
 
 
 EXPORTED_SYMBOLS = ["isca_shallow_config_default", "isca_shallow_create", "isca_shallow_destroy", "isca_shallow_cold_start",
                     "isca_shallow_step", "isca_shallow_get_state", "isca_shallow_set_state", "isca_shallow_get_info",
-                    "isca_shallow_set_time_pointers"]
+                    "isca_shallow_set_time_pointers", "isca_shallow_set_stirring_noise"]
 _UNSUPPORTED = {"fourier_inc": 1, "triang_trunc": True, "south_to_north": True, "damping_option": "resolution_dependent",
                 "raw_filter_coeff": 1.0, "initial_condition_from_input_file": False, "longitude_origin": 0.0}
 _PHYS_RENAME = {"h_0": "phys_h_0"}
@@ -44,7 +59,8 @@ def _lib():
                "isca_shallow_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
                "isca_shallow_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
                "isca_shallow_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
-               "isca_shallow_set_time_pointers": [H, C.c_int, C.c_int, C.c_long]}
+               "isca_shallow_set_time_pointers": [H, C.c_int, C.c_int, C.c_long],
+               "isca_shallow_set_stirring_noise": [H, dp, C.c_size_t]}
         for name, args in sig.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, C.c_int
@@ -54,7 +70,7 @@ def _lib():
 
 def config_from_namelist(namelist: dict | None = None, resolution: str | None = None, **overrides) -> _CShallowConfig:
     """shallow_dynamics_nml + shallow_physics_nml + main_nml(dt_atmos) -> C config; option values the device core does not
-    implement are refused (stirring must stay off: stirring_nml amplitude = 0)."""
+    implement are refused; stirring_nml switches the stochastic vorticity forcing on."""
     c = _CShallowConfig()
     _lib().isca_shallow_config_default(C.byref(c))
     kw: dict = {}
@@ -62,8 +78,7 @@ def config_from_namelist(namelist: dict | None = None, resolution: str | None = 
         r = RESOLUTIONS[resolution]
         kw.update(num_lon=r["lon_max"], num_lat=r["lat_max"], num_fourier=r["num_fourier"], num_spherical=r["num_spherical"])
     nml = {g.lower(): v for g, v in (namelist or {}).items()}
-    if float(nml.get("stirring_nml", {}).get("amplitude", 0.0)) != 0.0:
-        raise IscaError("stirring_nml: amplitude must be 0 (stirring is not part of the device core)")
+    _apply_stirring(c, nml)
     for k, v in nml.get("shallow_dynamics_nml", {}).items():
         k = k.lower()
         if k in _UNSUPPORTED:
@@ -93,7 +108,8 @@ def config_from_namelist(namelist: dict | None = None, resolution: str | None = 
 
 class ShallowWater:
     GRID = ("u", "v", "vor", "div", "h", "tr", "trs", "stream", "pv", "h_eq", "deep_geopot")
-    SPEC = ("vors", "divs", "hs", "trss")
+    SPEC = ("vors", "divs", "hs", "trss", "stirs")
+    _noise_fn = "isca_shallow_set_stirring_noise"
 
     def __init__(self, cfg: _CShallowConfig):
         self.lib = _lib()
@@ -146,6 +162,13 @@ class ShallowWater:
     def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
         self._check(self.lib.isca_shallow_set_time_pointers(self._h, previous, current, step_count))
 
+    def set_stirring_noise(self, ran):
+        """Uniform [0,1) numbers of shape (2, n, m) (Fortran ran_nmbrs(0:num_fourier, 0:num_spherical, 2)) for the next step's stirring."""
+        a = np.ascontiguousarray(ran, dtype=np.float64)
+        if a.shape != (2, self.N1, self.M1):
+            raise IscaError("set_stirring_noise: shape must be (2, num_spherical+1, num_fourier+1)")
+        self._check(getattr(self.lib, self._noise_fn)(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+
 
 # ---- module-level mirror of atmosphere_mod (shallow): one instance, like the Fortran module
 _model: ShallowWater | None = None
@@ -182,13 +205,13 @@ class _CBarotropicConfig(C.Structure):
         ("damping_order", C.c_int), ("damping_coeff", C.c_double), ("damping_coeff_r", C.c_double), ("robert_coeff", C.c_double),
         ("zeta_0", C.c_double), ("m_0", C.c_int), ("eddy_width", C.c_double), ("eddy_lat", C.c_double),
         ("spec_tracer", C.c_int), ("grid_tracer", C.c_int), ("valid_range_v", C.c_double * 2), ("initial_zonal_wind", C.c_int),
-        ("device", C.c_int),
+        ("device", C.c_int), ("stirring", _CStirringConfig),
     ]
 
 
 BAROTROPIC_SYMBOLS = ["isca_barotropic_config_default", "isca_barotropic_create", "isca_barotropic_destroy", "isca_barotropic_cold_start",
                       "isca_barotropic_step", "isca_barotropic_get_state", "isca_barotropic_set_state", "isca_barotropic_get_info",
-                      "isca_barotropic_set_time_pointers"]
+                      "isca_barotropic_set_time_pointers", "isca_barotropic_set_stirring_noise"]
 
 
 def _blib():
@@ -201,7 +224,8 @@ def _blib():
                "isca_barotropic_get_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
                "isca_barotropic_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
                "isca_barotropic_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
-               "isca_barotropic_set_time_pointers": [H, C.c_int, C.c_int, C.c_long]}
+               "isca_barotropic_set_time_pointers": [H, C.c_int, C.c_int, C.c_long],
+               "isca_barotropic_set_stirring_noise": [H, dp, C.c_size_t]}
         for name, args in sig.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, C.c_int
@@ -218,8 +242,7 @@ def barotropic_config_from_namelist(namelist: dict | None = None, resolution: st
         r = RESOLUTIONS[resolution]
         kw.update(num_lon=r["lon_max"], num_lat=r["lat_max"], num_fourier=r["num_fourier"], num_spherical=r["num_spherical"])
     nml = {g.lower(): v for g, v in (namelist or {}).items()}
-    if float(nml.get("stirring_nml", {}).get("amplitude", 0.0)) != 0.0:
-        raise IscaError("stirring_nml: amplitude must be 0 (stirring is not part of the device core)")
+    _apply_stirring(c, nml)
     for k, v in nml.get("barotropic_dynamics_nml", {}).items():
         k = k.lower()
         if k in _UNSUPPORTED:
@@ -248,7 +271,8 @@ def barotropic_config_from_namelist(namelist: dict | None = None, resolution: st
 
 class Barotropic(ShallowWater):
     GRID = ("u", "v", "vor", "tr", "trs", "stream", "pv")
-    SPEC = ("vors", "trss")
+    SPEC = ("vors", "trss", "stirs")
+    _noise_fn = "isca_barotropic_set_stirring_noise"
 
     def __init__(self, cfg: _CBarotropicConfig):
         self.lib = _blib()

@@ -321,7 +321,14 @@ BAROTROPIC_NML = """ &barotropic_dynamics_nml
 """
 
 
-def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=1200, keep=None, nml=None, exe=None, state_re=None):
+STIRRING_NML = """ &stirring_nml
+    decay_time = 172800, amplitude = {amp}, lat0 = 45., lon0 = 180., widthy = 12., widthx = 45., B = 1.0
+ /
+"""
+
+
+def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=1200, keep=None, nml=None, exe=None, state_re=None,
+                       dump_random=False):
     """The reference shallow-water core (src/atmos_spectral_shallow) from its cold start with a vortex pair on a zonal flow over
     the default forcing: grid u, v, vor, div, h, both tracers, stream, pv and the spectral vor, h after `dump_steps`."""
     lon, lat, nf, ns = RES[res]
@@ -331,7 +338,8 @@ def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=120
         open(os.path.join(d, "field_table"), "w").write("")
         open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
         open(os.path.join(d, "harness.nml"), "w").write(
-            f" &harness_nml\n   nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {', '.join(str(s) for s in dump_steps)}\n /\n")
+            f" &harness_nml\n   nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {', '.join(str(s) for s in dump_steps)}"
+            f"{', dump_random = .true.' if dump_random else ''}\n /\n")
         stdout = run_harness(d, exe=exe or SHALLOW_EXE)
         out = {}
         for fn in sorted(os.listdir(d)):
@@ -341,6 +349,8 @@ def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=120
             name = fn[:-4]
             if raw.size == lon * lat:
                 out[name] = raw.reshape(lat, lon)
+            elif name == "in_stir_ran":                                   # (m, n, 2) per step -> [step, 2, n, m]
+                out[name] = raw.reshape(nsteps, 2, ns + 1, nf + 1)
             elif raw.size == 2 * (nf + 1) * (ns + 1):
                 out[name] = raw.view(np.complex128).reshape(ns + 1, nf + 1)
             else:
@@ -402,6 +412,15 @@ def main():
         "barotropic_run_T42": lambda: golden_shallow_run("T42", 300, (300,), nml=BAROTROPIC_NML, exe=BAROTROPIC_EXE,
                                                          state_re=r"REF_STATE vormin,vormax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)",
                                                          keep=lambda k: not k.startswith("st_") or k.endswith("_000300")),
+        # the stirring variants of both sibling test cases: 60 steps from rest / from the default state, with the random numbers the
+        # reference's stirring() drew (the Fortran runtime's generator is compiler specific, so they are part of the fixture)
+        "barotropic_stirring_T21": lambda: golden_shallow_run(
+            "T21", 60, (1, 2, 60), exe=BAROTROPIC_EXE, dump_random=True, state_re=r"REF_STATE vormin,vormax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)",
+            nml=BAROTROPIC_NML.replace("num_spherical = {ns}", "num_spherical = {ns}, initial_zonal_wind = 'zero', zeta_0 = 0.0")
+            + STIRRING_NML.format(amp="3.e-11"), keep=lambda k: k == "in_stir_ran" or re.match(r"st_(u|v|vor|vors)_0000(01|02|60)$", k)),
+        "shallow_stirring_T21": lambda: golden_shallow_run(
+            "T21", 40, (1, 40), dump_random=True, nml=SHALLOW_NML + STIRRING_NML.format(amp="3.e-12"),
+            keep=lambda k: k == "in_stir_ran" or re.match(r"st_(u|v|vor|h|vors)_0000(01|40)$", k)),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

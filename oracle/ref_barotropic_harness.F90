@@ -11,7 +11,7 @@ use constants_mod,        only: constants_init
 use fms_mod,              only: fms_init
 use time_manager_mod,     only: time_type, set_time, set_calendar_type, NO_CALENDAR, operator(+)
 use diag_manager_mod,     only: diag_manager_init
-use transforms_mod,       only: get_grid_domain, get_spec_domain, get_deg_lat
+use transforms_mod,       only: get_grid_domain, get_spec_domain, get_deg_lat, get_num_fourier, get_num_spherical
 use barotropic_dynamics_mod, only: barotropic_dynamics_init, barotropic_dynamics, dynamics_type
 use barotropic_physics_mod,  only: barotropic_physics_init, barotropic_physics, phys_type
 use stirring_mod,         only: stirring_init
@@ -20,7 +20,8 @@ implicit none
 
 integer :: nsteps = 1, dt_atmos = 1200
 integer, dimension(64) :: dump_steps = -1
-namelist /harness_nml/ nsteps, dt_atmos, dump_steps
+logical :: dump_random = .false.      ! stirring on: write the random numbers each step's stirring call will draw (in_stir_ran.bin)
+namelist /harness_nml/ nsteps, dt_atmos, dump_steps, dump_random
 
 type(time_type)     :: Time, Time_init, Time_step
 type(dynamics_type) :: Dyn
@@ -28,7 +29,9 @@ type(phys_type)     :: Phys
 integer :: is, ie, js, je, ms, me, ns, ne, previous, current, future, istep, unit
 real    :: dt_real, delta_t
 integer(kind=8) :: c0, c1, crate
-real, allocatable :: deg_lat(:)
+real, allocatable :: deg_lat(:), ran(:,:,:)
+integer, allocatable :: seed(:)
+integer :: nseed, nf, nsph, uran
 
 open(newunit=unit, file='harness.nml', status='old', action='read')
 read(unit, nml=harness_nml)
@@ -53,12 +56,21 @@ allocate(deg_lat(js:je)); call get_deg_lat(deg_lat)
 call dump1('tab_deg_lat.bin', deg_lat)
 call dump1('tab_zonal_u_init.bin', Dyn%Grid%zonal_u_init)
 call dump_state(0)
+if(dump_random) then
+  call get_num_fourier(nf); call get_num_spherical(nsph)
+  allocate(ran(0:nf,0:nsph,2))
+  call random_seed(size=nseed); allocate(seed(nseed))
+  open(newunit=uran, file='in_stir_ran.bin', access='stream', form='unformatted', status='replace')
+endif
 
 call system_clock(c0, crate)
 do istep = 1, nsteps
   Dyn%Tend%u = 0.0; Dyn%Tend%v = 0.0
   if(Dyn%grid_tracer) Dyn%Tend%tr  = 0.0
   if(Dyn%spec_tracer) Dyn%Tend%trs = 0.0
+  if(dump_random) then        ! the numbers stirring() is about to draw: draw them, write them, rewind the generator
+    call random_seed(get=seed); call random_number(ran); write(uran) ran; call random_seed(put=seed)
+  endif
   if(istep == 1) then
     delta_t = dt_real; future = 2
   else

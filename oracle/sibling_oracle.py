@@ -38,6 +38,32 @@ class _Sibling:
         self.coriolis = (2 * OMEGA * self.sc.sin_lat)[:, None]
         self.previous = self.current = 0
         self.damping_r = 0.0
+        self.stir_amp = 0.0
+
+    def stirring_init(self, amplitude, decay_time=172800.0, lat0=45.0, lon0=180.0, widthy=12.0, widthx=45.0, B=0.0, n_max=15, n_min=9,
+                      zonal_min=3):
+        """stirring_init (atmos_spectral_barotropic/stirring.F90:75-170)."""
+        sc = self.sc
+        self.stir_amp = amplitude
+        self.astir = math.sqrt(1.0 - math.exp(-2 * self.dt / decay_time))
+        self.bstir = math.exp(-self.dt / decay_time)
+        self.wave_mask = np.zeros((sc.N1, sc.M1), dtype=bool)
+        for m in range(zonal_min + 1, n_max):
+            for n in range(n_min + 1 - m, n_max - m):
+                if 0 <= n < sc.N1 and 0 <= m < sc.M1:
+                    self.wave_mask[n, m] = True
+        xx = sc.deg_lon - lon0
+        xx = xx - 360.0 * np.rint(xx / 360.0)
+        self.localize = np.exp(-.5 * ((sc.deg_lat - lat0) / widthy) ** 2)[:, None] * (1 + B * np.exp(-.5 * (xx / widthx) ** 2))[None, :]
+        self.s_stir = np.zeros((sc.N1, sc.M1), dtype=np.complex128)
+
+    def stirring(self, dt_vors, ran):
+        """stirring (:190-224) with the uniform numbers `ran` [2, n, m] the reference drew."""
+        new = np.where(self.wave_mask, self.stir_amp * self.astir * ((2 * ran[0] - 1) + 1j * (2 * ran[1] - 1)), 0.0)
+        new = self.g2s(self.localize * self.s2g(new))
+        new[0, 0] = 0.0
+        self.s_stir = self.bstir * self.s_stir + new
+        return dt_vors + self.s_stir
 
     # 2-D wrappers of the (level, lat, lon) routines
     def g2s(self, g):
@@ -125,7 +151,7 @@ class ShallowOracle(_Sibling):
         tr = self.tracer_bands()
         self.tr, self.trs, self.trss = two(tr), two(tr), two(self.g2s(tr))
 
-    def step(self):
+    def step(self, ran=None):
         p, c, f, delta_t = self._levels()
         u, v = self.u[c], self.v[c]
         vorg = self.vor[c] + self.coriolis
@@ -145,6 +171,8 @@ class ShallowOracle(_Sibling):
         dt_vors = self.damp(self.vors[p], dt_vors, delta_t)
         dt_divs = self.damp(self.divs[p], dt_divs, delta_t)
         dt_hs = self.damp(self.hs[p], dt_hs, delta_t)
+        if self.stir_amp != 0.0:
+            dt_vors = self.stirring(dt_vors, ran)
         self.pv = vorg / self.h[c]
         for a, d in ((self.vors, dt_vors), (self.divs, dt_divs), (self.hs, dt_hs)):
             _leapfrog(a, d, p, c, f, delta_t, self.robert)
@@ -156,12 +184,13 @@ class ShallowOracle(_Sibling):
 
 
 class BarotropicOracle(_Sibling):
-    def __init__(self, res="T21", dt_atmos=1200.0, zeta_0=8.e-5, m_0=4, eddy_width=15.0, eddy_lat=45.0, damping_coeff_r=0.0, **kw):
+    def __init__(self, res="T21", dt_atmos=1200.0, zeta_0=8.e-5, m_0=4, eddy_width=15.0, eddy_lat=45.0, damping_coeff_r=0.0,
+                 initial_zonal_wind="two_jets", **kw):
         super().__init__(res, dt_atmos, **kw)
         self.damping_r = damping_coeff_r
         sc = self.sc
         cl, sl = sc.cos_lat, sc.sin_lat
-        self.zonal_u_init = 25.0 * cl - 30.0 * cl ** 3 + 300.0 * sl ** 2 * cl ** 6
+        self.zonal_u_init = (25.0 * cl - 30.0 * cl ** 3 + 300.0 * sl ** 2 * cl ** 6) if initial_zonal_wind == "two_jets" else 0.0 * cl
         u = np.repeat(self.zonal_u_init[:, None], self.I, axis=1)
         vors, _ = self.vd_from_uv(u, np.zeros_like(u))
         vor = self.s2g(vors)
@@ -176,12 +205,14 @@ class BarotropicOracle(_Sibling):
         tr = self.tracer_bands()
         self.tr, self.trs, self.trss = two(tr), two(tr), two(self.g2s(tr))
 
-    def step(self):
+    def step(self, ran=None):
         p, c, f, delta_t = self._levels()
         self.pv = self.vor[c] + self.coriolis
         tu, tv = 0.0 + self.pv * self.v[c], 0.0 - self.pv * self.u[c]
         dt_vors, _ = self.vd_from_uv(tu, tv)
         dt_vors = self.damp(self.vors[p], dt_vors, delta_t)
+        if self.stir_amp != 0.0:
+            dt_vors = self.stirring(dt_vors, ran)
         _leapfrog(self.vors, dt_vors, p, c, f, delta_t, self.robert)
         self.vor[f] = self.s2g(self.vors[f])
         self._tracers(p, c, f, delta_t, self.robert)

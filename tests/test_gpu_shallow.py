@@ -80,8 +80,6 @@ def test_shallow_restart_and_module_mirror():
 def test_shallow_errors():
     with pytest.raises(IscaError, match="not a supported value for fourier_inc"):
         shallow.config_from_namelist({"shallow_dynamics_nml": {"fourier_inc": 2}})
-    with pytest.raises(IscaError, match="stirring"):
-        shallow.config_from_namelist({"stirring_nml": {"amplitude": 3.e-13}})
     sw = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
     with pytest.raises(IscaError, match="has not been initialized"):
         sw.step(1)
@@ -93,3 +91,19 @@ def test_shallow_errors():
     with pytest.raises(IscaError, match="meridional wind out of valid range"):
         bad.step(20)
     sw.close(); bad.close()
+
+
+def test_shallow_stirring_vs_reference(golden_dir):
+    """shallow_water_stirring_test: stirring added to the vorticity tendency of the shallow-water core, with the reference's own draws."""
+    g = np.load(os.path.join(golden_dir, "shallow_stirring_T21.npz"))
+    nml = {**NML, "stirring_nml": {"decay_time": 172800, "amplitude": 3.e-12, "lat0": 45., "lon0": 180., "widthy": 12., "widthx": 45., "B": 1.0}}
+    sw = shallow.ShallowWater(shallow.config_from_namelist(nml, "T21"))
+    sw.cold_start()
+    for n in range(1, 41):
+        sw.set_stirring_noise(g["in_stir_ran"][n - 1])
+        sw.step(1)
+        if n in (1, 40):
+            err = {k: rel(sw.get(k), g["st_%s_%06d" % (k, n)]) for k in ("u", "v", "vor", "h", "vors")}
+            print("shallow stirring step", n, {k: "%.1e" % v for k, v in err.items()})
+            assert max(err.values()) < 1e-11, (n, err)
+    sw.close()

@@ -38,7 +38,7 @@ def test_header_symbols_exported(lib):
         body = re.sub(r"/\*.*?\*/", "", h[h.index("typedef struct %s {" % tname) + len("typedef struct %s {" % tname):h.index("} %s;" % tname)], flags=re.S)
         members = []
         for decl in body.split(";"):
-            m = re.match(r"(?:int|double)\s*(.*)", decl.strip(), flags=re.S)
+            m = re.match(r"(?:int|double|isca_stirring_config)\s*(.*)", decl.strip(), flags=re.S)
             if m:
                 members += [re.sub(r"\[.*\]", "", x).strip() for x in m.group(1).split(",")]
         assert members == [f[0] for f in cls._fields_], (tname, members)
@@ -254,6 +254,10 @@ def test_sibling_core_namelists():
     assert c.valid_range_v[1] == 500.0 and c.fric_damp_time == -20.0 and c.spec_tracer == 1
     b = shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"initial_zonal_wind": "zero", "m_0": 6, "damping_coeff_r": 1e-6}}, "T42")
     assert (b.initial_zonal_wind, b.m_0, b.damping_coeff_r, b.num_lat, b.zeta_0) == (0, 6, 1e-6, 64, 8.e-05)
+    st = shallow.barotropic_config_from_namelist({"stirring_nml": {"amplitude": 3.e-11, "decay_time": 172800, "B": 1.0, "widthx": 45.}}).stirring
+    assert (st.amplitude, st.decay_time, st.B, st.lat0, st.n_total_forcing_max, st.do_localize) == (3.e-11, 172800.0, 1.0, 45.0, 15, 1)
+    with pytest.raises(IscaError, match="stirring_nml: unknown variable"):
+        shallow.config_from_namelist({"stirring_nml": {"colour": "red"}})
     with pytest.raises(IscaError, match="unknown shallow-water configuration key"):
         shallow.config_from_namelist({"shallow_dynamics_nml": {"no_such_key": 1}})
     with pytest.raises(IscaError, match="not a supported value for triang_trunc"):

@@ -228,3 +228,24 @@ def test_barotropic_oracle_vs_reference(golden_dir):
         err = {k: _rel(v, g["st_%s_%06d" % (k, n)]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("tr", o.tr[c]),
                                                                ("trs", o.trs[c]), ("vors", o.vors[c]), ("pv", o.pv), ("stream", o.stream()))}
         assert max(err.values()) < tol, (n, err)
+
+
+def test_sibling_oracles_with_stirring(golden_dir):
+    """The stirring variants of both test cases, fed with the uniform numbers the reference drew."""
+    from oracle.sibling_oracle import BarotropicOracle, ShallowOracle
+    st = dict(decay_time=172800.0, lat0=45.0, lon0=180.0, widthy=12.0, widthx=45.0, B=1.0)
+    g = np.load(os.path.join(golden_dir, "barotropic_stirring_T21.npz"))
+    o = BarotropicOracle("T21", zeta_0=0.0, initial_zonal_wind="zero")
+    o.stirring_init(3.e-11, **st)
+    for n in range(1, 61):
+        o.step(g["in_stir_ran"][n - 1])
+    c = o.current
+    scale = lambda k: np.abs(g["st_%s_000060" % k]).max()
+    assert max(np.abs(v - g["st_%s_000060" % k]).max() / scale(k) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("vors", o.vors[c]))) < 1e-11
+    g = np.load(os.path.join(golden_dir, "shallow_stirring_T21.npz"))
+    o = ShallowOracle("T21", add_initial_vortex_pair=True, u_upper_mag_init=10.0, u_deep_mag=5.0)
+    o.stirring_init(3.e-12, **st)
+    for n in range(1, 41):
+        o.step(g["in_stir_ran"][n - 1])
+    c = o.current
+    assert max(_rel(v, g["st_%s_000040" % k]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("h", o.h[c]), ("vors", o.vors[c]))) < 1e-11
