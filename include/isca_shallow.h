@@ -18,7 +18,7 @@ extern "C" {
 typedef struct isca_shallow isca_shallow_t;
 
 /* shallow_dynamics_nml (shallow_dynamics.F90:117-194), shallow_physics_nml (shallow_physics.F90:88-103), main_nml dt_atmos.
- * Not carried: initial_condition_from_input_file (netCDF), fourier_inc /= 1,
+ * Not carried: reading init_cond_file itself (netCDF; the host passes its fields to isca_shallow_init_from_grid), fourier_inc /= 1,
  * rhomboidal truncation, the exponential damping option. */
 typedef struct isca_shallow_config {
   int num_lon, num_lat, num_fourier, num_spherical;
@@ -43,6 +43,9 @@ int isca_shallow_create(const isca_shallow_config *cfg, isca_shallow_t **out);
 int isca_shallow_destroy(isca_shallow_t *h);
 /* the Time == Time_init branch of shallow_dynamics_init (:330-408): initial h, vor, div, tracers */
 int isca_shallow_cold_start(isca_shallow_t *h);
+/* the initial_condition_from_input_file branch (:332-337): vorticity, divergence and height ANOMALY (h_0 is added) on the model grid,
+ * as the reference's interpolator delivers them from init_cond_file; tracers start as in the cold start */
+int isca_shallow_init_from_grid(isca_shallow_t *h, const double *vor, const double *div, const double *height);
 /* atmosphere(Time) x nsteps (atmosphere.F90:164-200): shallow_physics -> shallow_dynamics -> time-level rotation;
  * checks valid_range_v on return ("meridional wind out of valid range") */
 int isca_shallow_step(isca_shallow_t *h, int nsteps);

@@ -44,9 +44,9 @@ class _CShallowConfig(C.Structure):
 
 EXPORTED_SYMBOLS = ["isca_shallow_config_default", "isca_shallow_create", "isca_shallow_destroy", "isca_shallow_cold_start",
                     "isca_shallow_step", "isca_shallow_get_state", "isca_shallow_set_state", "isca_shallow_get_info",
-                    "isca_shallow_set_time_pointers", "isca_shallow_set_stirring_noise"]
+                    "isca_shallow_set_time_pointers", "isca_shallow_set_stirring_noise", "isca_shallow_init_from_grid"]
 _UNSUPPORTED = {"fourier_inc": 1, "triang_trunc": True, "south_to_north": True, "damping_option": "resolution_dependent",
-                "raw_filter_coeff": 1.0, "initial_condition_from_input_file": False, "longitude_origin": 0.0}
+                "raw_filter_coeff": 1.0, "longitude_origin": 0.0}
 _PHYS_RENAME = {"h_0": "phys_h_0"}
 
 
@@ -60,7 +60,7 @@ def _lib():
                "isca_shallow_set_state": [H, C.c_char_p, C.c_int, dp, C.c_size_t],
                "isca_shallow_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
                "isca_shallow_set_time_pointers": [H, C.c_int, C.c_int, C.c_long],
-               "isca_shallow_set_stirring_noise": [H, dp, C.c_size_t]}
+               "isca_shallow_set_stirring_noise": [H, dp, C.c_size_t], "isca_shallow_init_from_grid": [H, dp, dp, dp]}
         for name, args in sig.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, C.c_int
@@ -85,7 +85,8 @@ def config_from_namelist(namelist: dict | None = None, resolution: str | None = 
             if (str(v).lower() != str(_UNSUPPORTED[k]).lower()) and v != _UNSUPPORTED[k]:
                 raise IscaError(f'"{v}" is not a supported value for {k} (only "{_UNSUPPORTED[k]}")')
             continue
-        if k in ("check_fourier_imag", "cutoff_wn", "init_cond_file", "input_file_div_name", "input_file_height_name", "input_file_vor_name"):
+        if k in ("check_fourier_imag", "cutoff_wn", "init_cond_file", "input_file_div_name", "input_file_height_name", "input_file_vor_name",
+                 "initial_condition_from_input_file"):       # the host reads the file and calls init_from_grid
             continue
         kw[k] = v
     for k, v in nml.get("shallow_physics_nml", {}).items():
@@ -135,6 +136,14 @@ class ShallowWater:
 
     def cold_start(self):
         self._check(self.lib.isca_shallow_cold_start(self._h))
+
+    def init_from_grid(self, vor, div, height):
+        """initial_condition_from_input_file: grid vorticity, divergence and height anomaly (h_0 is added), e.g. the variables of
+        init_cond_file read with scipy.io.netcdf_file on the model grid."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (vor, div, height)]
+        if any(x.shape != (self.J, self.I) for x in a):
+            raise IscaError("init_from_grid: fields must have the grid shape (lat, lon)")
+        self._check(self.lib.isca_shallow_init_from_grid(self._h, *[x.ctypes.data_as(C.POINTER(C.c_double)) for x in a]))
 
     def step(self, nsteps: int = 1):
         self._check(self.lib.isca_shallow_step(self._h, int(nsteps)))

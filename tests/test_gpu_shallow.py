@@ -107,3 +107,25 @@ def test_shallow_stirring_vs_reference(golden_dir):
             print("shallow stirring step", n, {k: "%.1e" % v for k, v in err.items()})
             assert max(err.values()) < 1e-11, (n, err)
     sw.close()
+
+
+def test_shallow_init_from_grid():
+    """initial_condition_from_input_file (prescribed_ics_test): handing the cold start's own vorticity, divergence and height anomaly
+    back through init_from_grid reproduces the cold start (same transforms), and a perturbed height changes the run."""
+    a = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    a.cold_start()
+    b = shallow.ShallowWater(shallow.config_from_namelist({**NML, "shallow_dynamics_nml": {**NML["shallow_dynamics_nml"],
+                                                                                             "initial_condition_from_input_file": True}}, "T21"))
+    vor, div, h = a.get("vor"), a.get("div"), a.get("h")
+    b.init_from_grid(vor, div, h - a.cfg.h_0)
+    for k in ("u", "v", "vor", "div", "vors", "tr", "trs"):
+        assert np.array_equal(a.get(k), b.get(k)), k
+    assert rel(b.get("h"), h) < 1e-15 and rel(b.get("hs"), a.get("hs")) < 1e-15          # (h - h_0) + h_0 is not bit-exact
+    a.step(20); b.step(20)
+    assert rel(b.get("h"), a.get("h")) < 1e-12
+    c = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    c.init_from_grid(vor, div, h - a.cfg.h_0 + 50.0 * np.cos(np.deg2rad(np.arange(32) * 5.0))[:, None])
+    c.step(20)
+    assert rel(c.get("h"), a.get("h")) > 1e-6
+    for m in (a, b, c):
+        m.close()
