@@ -28,6 +28,7 @@ typedef struct isca_barotropic_config {
   int initial_zonal_wind;       /* 0 = 'zero', 1 = 'two_jets' */
   int device;
   isca_stirring_config stirring;
+  double radius, omega;         /* constants_nml (the shallow-water test cases run a giant planet: 55000e3 m, 1.6e-4 1/s) */
 } isca_barotropic_config;
 
 int isca_barotropic_config_default(isca_barotropic_config *cfg);

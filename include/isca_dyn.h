@@ -91,6 +91,7 @@ typedef struct isca_dyn_config {
   int vert_coord_input;
   double pk_input[ISCA_MAX_LEVELS + 1], bk_input[ISCA_MAX_LEVELS + 1];
   isca_moist_config moist;
+  double radius, omega;         /* constants_nml: planetary radius (m) and rotation rate (1/s); defaults 6376.0e3, 7.2921150e-5 */
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -35,6 +35,7 @@ typedef struct isca_shallow_config {
   double fric_damp_time, therm_damp_time, phys_h_0, h_amp, h_lon, h_lat, h_width, h_itcz, itcz_width;
   int device;
   isca_stirring_config stirring;
+  double radius, omega;         /* constants_nml (the shallow-water test cases run a giant planet: 55000e3 m, 1.6e-4 1/s) */
 } isca_shallow_config;
 
 int isca_shallow_config_default(isca_shallow_config *cfg);

@@ -143,6 +143,10 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
         nl = namelist.get("spectral_dynamics_nml", {}).get("num_levels", len(bk) - 1)
         if len(bk) != nl + 1:
             raise IscaError("vert_coordinate_nml: bk must hold num_levels+1 values")
+    for k, v in namelist.get("constants_nml", {}).items():
+        if k.lower() not in ("radius", "omega"):
+            raise IscaError(f"constants_nml: {k} cannot be changed (only radius and omega)")
+        kw[k.lower()] = v
     if moist:
         kw["physics"] = 1
         kw["moist"] = _moist_config(namelist)

@@ -105,6 +105,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   m.tau_bm = 7200.; m.rhbm = 0.7; m.Tmin = 160.; m.Tmax = 350.; m.val_inc = 0.01;
   m.do_rayleigh = 1; m.trayfric = -0.25; m.sponge_pbottom = 5000.; m.damping_conserve_energy = 1;
   m.constant_gust = 0.0; m.frac_inner = 0.1; m.rich_crit_pbl = 1.0; m.rich_crit = 2.0; m.drag_min = 1.e-05;
+  c->radius = RADIUS_EARTH; c->omega = OMEGA_EARTH;
   return 0;
 }
 
@@ -155,6 +156,7 @@ static void check_config(const isca_dyn_config &c) {
     for (int k = 0; k <= c.num_levels; ++k)
       if (c.pk_input[k] != 0.0) fail("vert_coord_option = 'input': only pure sigma levels (pk = 0) are supported");
   }
+  if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics != 0 && c.physics != 1) fail("physics must be 0 (hs_forcing) or 1 (idealized_moist_phys)");
   if (c.physics == 1) {
     if (c.num_tracers < 1) fail("idealized_moist_phys needs the sphum tracer (num_tracers >= 1)");

@@ -122,6 +122,7 @@ void pressure_variables_1d(const std::vector<double> &pk, const std::vector<doub
 
 
 void Tables::build(const isca_dyn_config &c) {
+  radius = c.radius; omega = c.omega;
   I = c.lon_max; J = c.lat_max; M1 = c.num_fourier + 1; N1 = c.num_spherical + 1; L = c.num_levels;
   // --- Gaussian grid: spherical_fourier.F90:397-431
   compute_gaussian(J / 2, sin_hem, wts_hem);
@@ -138,7 +139,7 @@ void Tables::build(const isca_dyn_config &c) {
     cosm_lat[j] = 1. / cos_lat[j];
     deg_lat[j] = std::asin(sin_lat[j]) * 180.0 / PI;
     rad_lat[j] = deg_lat[j] * PI / 180.;               // atmosphere.F90:248-251
-    coriolis[j] = 2 * OMEGA * sin_lat[j];              // spectral_dynamics.F90:445
+    coriolis[j] = 2 * omega * sin_lat[j];              // spectral_dynamics.F90:445
   }
   deg_lon.resize(I);
   for (int i = 0; i < I; ++i) deg_lon[i] = i * 360.0 / (double)I;   // grid_fourier.F90:109-118
@@ -155,22 +156,22 @@ void Tables::build(const isca_dyn_config &c) {
       const double fw = m, sw = m + n;
       if (m + n > c.num_spherical - 1) tri_mask[q] = 0.0;
       eps[q] = std::sqrt((sw * sw - fw * fw) / (4.0 * sw * sw - 1.0));
-      eigen[q] = sw * (sw + 1.0) / (RADIUS * RADIUS);
+      eigen[q] = sw * (sw + 1.0) / (radius * radius);
       if (m + n > 0) {
-        coef_uvm[q] = -RADIUS * eps[q] / sw;
-        coef_uvc[q] = -RADIUS * fw / (sw * (sw + 1.0));
+        coef_uvm[q] = -radius * eps[q] / sw;
+        coef_uvc[q] = -radius * fw / (sw * (sw + 1.0));
       }
-      coef_alpm[q] = (sw + 1.0) * eps[q] / RADIUS;
-      coef_dym[q] = (sw - 1.0) * eps[q] / RADIUS;
-      coef_dx[q] = fw / RADIUS;
+      coef_alpm[q] = (sw + 1.0) * eps[q] / radius;
+      coef_dym[q] = (sw - 1.0) * eps[q] / radius;
+      coef_dx[q] = fw / radius;
     }
   for (int n = 0; n < N1 - 1; ++n)
     for (int m = 0; m < M1; ++m) {
       const size_t q = (size_t)n * M1 + m, qp = (size_t)(n + 1) * M1 + m;
       const double sw = m + n;
-      coef_uvp[q] = -RADIUS * eps[qp] / (sw + 1.0);
-      coef_alpp[q] = sw * eps[qp] / RADIUS;
-      coef_dyp[q] = (sw + 2.0) * eps[qp] / RADIUS;
+      coef_uvp[q] = -radius * eps[qp] / (sw + 1.0);
+      coef_alpp[q] = sw * eps[qp] / radius;
+      coef_dyp[q] = (sw + 2.0) * eps[qp] / radius;
     }
   // --- spectral_damping.F90:124-127 ('resolution_dependent')
   damping.assign(NM, 0);
@@ -283,9 +284,9 @@ void Tables::build(const isca_dyn_config &c) {
     fv_dyy[0] = 2 * (y[0] - yy[0]);
     fv_dyy[J] = 2 * (yy[J] - y[J - 1]);
     for (int j = 0; j <= J + 1; ++j) { fv_dyp[j] = dyF(j) / (dyF(j) + dyF(j + 1)); fv_dym[j] = dyF(j) / (dyF(j - 1) + dyF(j)); }
-    for (auto &v : fv_dy) v = v * RADIUS;
-    for (auto &v : fv_dyy) v = v * RADIUS;
-    fv_dx = 2.0 * PI * RADIUS / (double)I;
+    for (auto &v : fv_dy) v = v * radius;
+    for (auto &v : fv_dyy) v = v * radius;
+    fv_dx = 2.0 * PI * radius / (double)I;
   }
   // --- FFT twiddles
   tw_re.resize(I); tw_im.resize(I);
@@ -303,7 +304,7 @@ void Tables::build_wave_matrices(const isca_dyn_config &c, double dt) {
   wave_matrix.assign((size_t)(ntw + 1) * L * L, 0.0);
   std::vector<double> a((size_t)L * L);
   for (int Lw = 0; Lw <= ntw; ++Lw) {
-    const double factor = xi * xi * Lw * (Lw + 1) / (RADIUS * RADIUS);
+    const double factor = xi * xi * Lw * (Lw + 1) / (radius * radius);
     for (int k = 0; k < L; ++k)
       for (int kk = 0; kk < L; ++kk) a[(size_t)k * L + kk] = (k == kk ? 1.0 : 0.0) + factor * div_mat[(size_t)k * L + kk];
     if (!invert_matrix(a, L)) throw std::runtime_error("build_wave_matrices: singular matrix");

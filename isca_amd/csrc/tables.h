@@ -7,8 +7,8 @@
 
 namespace isca {
 
-constexpr double RADIUS = 6376.0e3;   // shared/constants/constants.F90:254
-constexpr double OMEGA = 7.2921150e-5;
+constexpr double RADIUS_EARTH = 6376.0e3;   // shared/constants/constants.F90:254 (defaults of constants_nml)
+constexpr double OMEGA_EARTH = 7.2921150e-5;
 constexpr double GRAV = 9.80;
 constexpr double RDGAS = 287.04;
 constexpr double KAPPA = 2.0 / 7.0;
@@ -28,6 +28,7 @@ struct Tables {
   std::vector<double> ref_ln_p_half, ref_ln_p_full, h_impl, div_mat;   // [L+1],[L],[L],[L*L] (row-major k,kk)
   std::vector<double> tau_mat, gamma_mat, nu_vec;                      // [L*L],[L*L],[L]
   double ref_surf_p, ref_t;
+  double radius = RADIUS_EARTH, omega = OMEGA_EARTH;   // constants_nml
   std::vector<double> wave_matrix;               // [num_spherical][L][L] for wave_dt
   double wave_dt = -1.0, xi = 0.0;
   // hs

@@ -58,7 +58,7 @@ class _CConfig(C.Structure):
         ("legendre_impl", C.c_int),
         ("physics", C.c_int), ("vert_coord_input", C.c_int),
         ("pk_input", C.c_double * (MAX_LEVELS + 1)), ("bk_input", C.c_double * (MAX_LEVELS + 1)),
-        ("moist", _CMoistConfig),
+        ("moist", _CMoistConfig), ("radius", C.c_double), ("omega", C.c_double),
     ]
 
 

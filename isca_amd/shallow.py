@@ -18,7 +18,11 @@ class _CStirringConfig(C.Structure):
 
 
 def _apply_stirring(c, nml):
-    """stirring_nml -> cfg.stirring (names unchanged; `seed` is ours)."""
+    """stirring_nml -> cfg.stirring (names unchanged; `seed` is ours); constants_nml radius / omega."""
+    for k, v in (nml.get("constants_nml") or {}).items():
+        if k.lower() not in ("radius", "omega"):
+            raise IscaError(f"constants_nml: {k} cannot be changed (only radius and omega)")
+        setattr(c, k.lower(), v)
     for k, v in (nml.get("stirring_nml") or {}).items():
         k = {"b": "B"}.get(k.lower(), k.lower())
         if not hasattr(c.stirring, k):
@@ -38,7 +42,7 @@ class _CShallowConfig(C.Structure):
         ("valid_range_v", C.c_double * 2),
         ("fric_damp_time", C.c_double), ("therm_damp_time", C.c_double), ("phys_h_0", C.c_double), ("h_amp", C.c_double),
         ("h_lon", C.c_double), ("h_lat", C.c_double), ("h_width", C.c_double), ("h_itcz", C.c_double), ("itcz_width", C.c_double),
-        ("device", C.c_int), ("stirring", _CStirringConfig),
+        ("device", C.c_int), ("stirring", _CStirringConfig), ("radius", C.c_double), ("omega", C.c_double),
     ]
 
 
@@ -214,7 +218,7 @@ class _CBarotropicConfig(C.Structure):
         ("damping_order", C.c_int), ("damping_coeff", C.c_double), ("damping_coeff_r", C.c_double), ("robert_coeff", C.c_double),
         ("zeta_0", C.c_double), ("m_0", C.c_int), ("eddy_width", C.c_double), ("eddy_lat", C.c_double),
         ("spec_tracer", C.c_int), ("grid_tracer", C.c_int), ("valid_range_v", C.c_double * 2), ("initial_zonal_wind", C.c_int),
-        ("device", C.c_int), ("stirring", _CStirringConfig),
+        ("device", C.c_int), ("stirring", _CStirringConfig), ("radius", C.c_double), ("omega", C.c_double),
     ]
 
 

@@ -60,6 +60,8 @@ class Config:
     initial_temperature: float = 264.0
     valid_range_t: tuple = (100.0, 800.0)
     initial_sphum: float = 0.0
+    radius: float = 6376.0e3      # constants_nml
+    omega: float = 7.2921150e-5
     num_tracers: int = 1          # the dry field_table carries one grid tracer (sphum)
     # hs_forcing_nml
     t_zero: float = 315.0
@@ -188,24 +190,24 @@ class SpectralCore:
         with np.errstate(invalid="ignore", divide="ignore"):
             eps = np.sqrt((Lw ** 2 - m ** 2) / (4.0 * Lw ** 2 - 1.0))
             self.epsilon = eps
-            self.eigen_laplacian = Lw * (Lw + 1.0) / (RADIUS * RADIUS)
-            self.coef_uvm = np.where(Lw > 0, -RADIUS * eps / np.where(Lw > 0, Lw, 1), 0.0)
-            self.coef_uvc = np.where(Lw > 0, -RADIUS * m / np.where(Lw > 0, Lw * (Lw + 1.0), 1), 0.0)
+            self.eigen_laplacian = Lw * (Lw + 1.0) / (self.cfg.radius * self.cfg.radius)
+            self.coef_uvm = np.where(Lw > 0, -self.cfg.radius * eps / np.where(Lw > 0, Lw, 1), 0.0)
+            self.coef_uvc = np.where(Lw > 0, -self.cfg.radius * m / np.where(Lw > 0, Lw * (Lw + 1.0), 1), 0.0)
         z = np.zeros((N1, M1))
         self.coef_uvp = z.copy(); self.coef_alpp = z.copy(); self.coef_dyp = z.copy()
-        self.coef_uvp[:-1] = -RADIUS * eps[1:] / (Lw[:-1] + 1.0)
-        self.coef_alpm = (Lw + 1.0) * eps / RADIUS
-        self.coef_alpp[:-1] = Lw[:-1] * eps[1:] / RADIUS
-        self.coef_dym = (Lw - 1.0) * eps / RADIUS
-        self.coef_dx = m / RADIUS
-        self.coef_dyp[:-1] = (Lw[:-1] + 2.0) * eps[1:] / RADIUS
+        self.coef_uvp[:-1] = -self.cfg.radius * eps[1:] / (Lw[:-1] + 1.0)
+        self.coef_alpm = (Lw + 1.0) * eps / self.cfg.radius
+        self.coef_alpp[:-1] = Lw[:-1] * eps[1:] / self.cfg.radius
+        self.coef_dym = (Lw - 1.0) * eps / self.cfg.radius
+        self.coef_dx = m / self.cfg.radius
+        self.coef_dyp[:-1] = (Lw[:-1] + 2.0) * eps[1:] / self.cfg.radius
         # --- vertical coordinate + derived (spectral_dynamics.F90:456-462) ---
         if c.vert_coord_option != "uneven_sigma":
             raise NotImplementedError(c.vert_coord_option)
         self.pk, self.bk = compute_uneven_sigma(self.L, c.scale_heights, c.surf_res, c.exponent)
         self.dpk = self.pk[1:] - self.pk[:-1]
         self.dbk = self.bk[1:] - self.bk[:-1]
-        self.coriolis = 2 * OMEGA * self.sin_lat                      # spectral_dynamics.F90:445
+        self.coriolis = 2 * self.cfg.omega * self.sin_lat                      # spectral_dynamics.F90:445
         # --- damping: spectral_damping.F90:124-156 ---
         eig = self.eigen_laplacian
         if c.damping_option != "resolution_dependent":
@@ -557,7 +559,7 @@ class SpectralCore:
         L = self.L
         self.wave_matrix = np.zeros((ntw + 1, L, L))
         for Lw in range(ntw + 1):
-            factor = self.xi * self.xi * Lw * (Lw + 1) / RADIUS ** 2
+            factor = self.xi * self.xi * Lw * (Lw + 1) / self.cfg.radius ** 2
             self.wave_matrix[Lw] = invert_gauss_jordan(np.eye(L) + factor * self.div_mat)
         self._wave_dt = dt
 
@@ -800,9 +802,9 @@ class SpectralCore:
         dyF = lambda j: dy[j + 1]                  # Fortran dy(j)
         fv["dy_plus"] = np.array([dyF(j) / (dyF(j) + dyF(j + 1)) for j in range(0, J + 2)])
         fv["dy_minus"] = np.array([dyF(j) / (dyF(j - 1) + dyF(j)) for j in range(0, J + 2)])
-        fv["dy"] = dy * RADIUS                     # Fortran dy(j) = fv['dy'][j+1]
-        fv["dyy"] = dyy * RADIUS                   # Fortran dyy(j) = fv['dyy'][j-1]
-        fv["dx"] = 2.0 * PI * RADIUS / float(I)
+        fv["dy"] = dy * self.cfg.radius                     # Fortran dy(j) = fv['dy'][j+1]
+        fv["dyy"] = dyy * self.cfg.radius                   # Fortran dyy(j) = fv['dyy'][j-1]
+        fv["dx"] = 2.0 * PI * self.cfg.radius / float(I)
         self._fv = fv
         return fv
 

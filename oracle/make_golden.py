@@ -421,6 +421,10 @@ def main():
         "shallow_stirring_T21": lambda: golden_shallow_run(
             "T21", 40, (1, 40), dump_random=True, nml=SHALLOW_NML + STIRRING_NML.format(amp="3.e-12"),
             keep=lambda k: k == "in_stir_ran" or re.match(r"st_(u|v|vor|h|vors)_0000(01|40)$", k)),
+        # the shallow-water test case's planet (constants_nml of exp/test_cases/shallow_water/shallow_water_test.py: a giant planet)
+        "shallow_run_giant_T21": lambda: golden_shallow_run(
+            "T21", 100, (1, 100), nml=SHALLOW_NML + " &constants_nml\n    radius = 55000.e3, omega = 1.6e-4\n /\n",
+            keep=lambda k: k.startswith("tab_") or re.match(r"st_(u|v|vor|div|h|tr|trs|vors|hs)_000(001|100)$", k)),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
     }
     for name, fn in jobs.items():

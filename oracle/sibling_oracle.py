@@ -12,7 +12,6 @@ import numpy as np
 
 from .isca_oracle import Config, SpectralCore
 
-RADIUS, OMEGA = 6376.0e3, 7.2921150e-5
 
 
 def _leapfrog(a, dt_a, prev, cur, fut, delta_t, robert):
@@ -28,14 +27,16 @@ def _leapfrog(a, dt_a, prev, cur, fut, delta_t, robert):
 
 
 class _Sibling:
-    def __init__(self, res, dt_atmos, damping_coeff=1.e-4, damping_order=4, robert_coeff=0.04):
+    def __init__(self, res, dt_atmos, damping_coeff=1.e-4, damping_order=4, robert_coeff=0.04, radius=6376.0e3, omega=7.2921150e-5):
         table = {"T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43)}
         lon, lat, nf, ns = table[res]
         self.sc = SpectralCore(Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns, num_levels=1, dt_atmos=dt_atmos,
-                                      damping_coeff=damping_coeff, damping_order=damping_order, robert_coeff=robert_coeff))
+                                      damping_coeff=damping_coeff, damping_order=damping_order, robert_coeff=robert_coeff, radius=radius,
+                                      omega=omega))
+        self.radius, self.omega = radius, omega
         self.dt, self.robert = float(dt_atmos), robert_coeff
         self.J, self.I = lat, lon
-        self.coriolis = (2 * OMEGA * self.sc.sin_lat)[:, None]
+        self.coriolis = (2 * omega * self.sc.sin_lat)[:, None]
         self.previous = self.current = 0
         self.damping_r = 0.0
         self.stir_amp = 0.0
@@ -132,13 +133,13 @@ class ShallowOracle(_Sibling):
         self.h_eq = phys_h_0 + h_amp * np.maximum(1.e-10, np.exp(-(xx * xx + yy * yy))) + h_itcz * np.exp(-(lat / itcz_width) ** 2)
         d2r, nm = math.pi / 180.0, n_merid_deep_flow
         la = d2r * lat
-        deep = -2. * OMEGA * u_deep_mag * RADIUS * (1. / (1. - nm ** 2)) * (
+        deep = -2. * self.omega * u_deep_mag * self.radius * (1. / (1. - nm ** 2)) * (
             -np.cos(nm * la) * np.cos(la) - nm * (np.sin(nm * la) * np.sin(la) - math.sin(nm * (2. * math.atan(1.)))))
         deep = np.repeat(deep, self.I, axis=1)
         self.deep = deep - sc.area_weighted_global_mean(deep)
         # initial state (:330-408), vortex pair as a height anomaly
         h = h_0 - self.deep
-        vor = np.repeat(-((u_upper_mag_init * nm) / RADIUS) * np.sin(la), self.I, axis=1)
+        vor = np.repeat(-((u_upper_mag_init * nm) / self.radius) * np.sin(la), self.I, axis=1)
         if add_initial_vortex_pair:
             def rad(lon0, lat0):
                 return np.sqrt(np.minimum((lon - lon0) ** 2, (lon - lon0 - 360.) ** 2) + (lat - lat0) ** 2) / 5.0

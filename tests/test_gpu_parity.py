@@ -317,6 +317,24 @@ def test_sharded_device_path_matches_single(world, res, levels):
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_constants_nml_radius_omega():
+    """constants_nml radius / omega: the transforms do not depend on the radius, the derivative operators scale with 1/a, the Laplacian
+    with 1/a^2, the Coriolis parameter with omega (the 3-D core's tables are the ones the sibling cores use)."""
+    rng = np.random.default_rng(5)
+    e, m = make("T21", 3), make("T21", 3, radius=3389.5e3, omega=7.088e-5)        # Earth, Mars
+    g = rng.standard_normal((3, e.J, e.I))
+    s = e.trans_grid_to_spherical(g)
+    assert np.array_equal(s, m.trans_grid_to_spherical(g))
+    k = 6376.0e3 / 3389.5e3
+    assert rel(m.compute_laplacian(s), k * k * e.compute_laplacian(s)) < 1e-14
+    dxe, dye = e.compute_gradient_cos(s)
+    dxm, dym = m.compute_gradient_cos(s)
+    assert rel(dxm, k * dxe) < 1e-14 and rel(dym, k * dye) < 1e-14
+    e.cold_start(); m.cold_start(); e.step(3); m.step(3)
+    assert np.isfinite(m.get("tg")).all() and rel(m.get("ug"), e.get("ug")) > 1e-3
+    e.close(); m.close()
+
+
 def test_trans_filter(golden_dir):
     """trans_filter = analysis, optional factor, synthesis (transforms.F90:555-580): equals the two transforms composed, and is a
     projection (filtering twice changes nothing beyond roundoff)."""

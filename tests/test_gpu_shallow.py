@@ -129,3 +129,20 @@ def test_shallow_init_from_grid():
     assert rel(c.get("h"), a.get("h")) > 1e-6
     for m in (a, b, c):
         m.close()
+
+
+def test_shallow_giant_planet(golden_dir):
+    """constants_nml (radius 55000 km, omega 1.6e-4: the planet of shallow_water_test.py) reaches the tables, the Coriolis parameter, the
+    van Leer metric terms and the initial condition."""
+    g = np.load(os.path.join(golden_dir, "shallow_run_giant_T21.npz"))
+    nml = {**NML, "constants_nml": {"radius": 55000.e3, "omega": 1.6e-4}}
+    sw = shallow.ShallowWater(shallow.config_from_namelist(nml, "T21"))
+    assert rel(sw.get("deep_geopot"), g["tab_deep_geopot"]) < 1e-13
+    sw.cold_start()
+    sw.step(1)
+    assert max(rel(sw.get(k), g["st_%s_000001" % k]) for k in ("u", "vor", "h", "tr", "trs", "hs")) < 1e-12
+    sw.step(99)
+    err = {k: rel(sw.get(k), g["st_%s_000100" % k]) for k in ("u", "v", "vor", "h", "tr", "trs", "vors", "hs")}
+    print("shallow water on the giant planet, 100 steps:", err)
+    assert max(err.values()) < 1e-10, err
+    sw.close()

@@ -249,3 +249,16 @@ def test_sibling_oracles_with_stirring(golden_dir):
         o.step(g["in_stir_ran"][n - 1])
     c = o.current
     assert max(_rel(v, g["st_%s_000040" % k]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("h", o.h[c]), ("vors", o.vors[c]))) < 1e-11
+
+
+def test_shallow_oracle_on_the_test_case_planet(golden_dir):
+    """constants_nml of exp/test_cases/shallow_water/shallow_water_test.py: radius 55000 km, omega 1.6e-4 (tables, Coriolis, deep flow)."""
+    from oracle.sibling_oracle import ShallowOracle
+    g = np.load(os.path.join(golden_dir, "shallow_run_giant_T21.npz"))
+    o = ShallowOracle("T21", add_initial_vortex_pair=True, u_upper_mag_init=10.0, u_deep_mag=5.0, radius=55000.e3, omega=1.6e-4)
+    assert _rel(o.deep, g["tab_deep_geopot"]) < 1e-13
+    for _ in range(100):
+        o.step()
+    c = o.current
+    assert max(_rel(v, g["st_%s_000100" % k]) for k, v in (("u", o.u[c]), ("v", o.v[c]), ("vor", o.vor[c]), ("h", o.h[c]), ("tr", o.tr[c]),
+                                                           ("trs", o.trs[c]), ("hs", o.hs[c]))) < 1e-10
