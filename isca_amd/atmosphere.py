@@ -132,6 +132,10 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     moist = bool(namelist.get("atmosphere_nml", {}).get("idealized_moist_model", False))
     vc = namelist.get("vert_coordinate_nml")
     vco = str(namelist.get("spectral_dynamics_nml", {}).get("vert_coord_option", "uneven_sigma")).lower()
+    if vco == "even_sigma":               # compute_even_sigma (init/vert_coordinate.F90:230-244): bk = (k-1)/num_levels, pk = 0
+        nl = namelist.get("spectral_dynamics_nml", {}).get("num_levels", overrides.get("num_levels", 25))
+        kw["bk_input"] = [float(k) / float(nl) for k in range(nl)] + [1.0]
+        kw["pk_input"] = [0.0] * (nl + 1)
     if vco == "input":
         if not vc or "bk" not in vc:
             raise IscaError("vert_coord_option = 'input' needs vert_coordinate_nml with bk (and pk)")
@@ -150,7 +154,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     if moist:
         kw["physics"] = 1
         kw["moist"] = _moist_config(namelist)
-    unsupported = {"vert_coord_option": vco if vco == "input" else "uneven_sigma", "damping_option": "resolution_dependent",
+    unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma") else "uneven_sigma", "damping_option": "resolution_dependent",
                    "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
                    "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}

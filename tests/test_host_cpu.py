@@ -238,6 +238,12 @@ def test_moist_namelist_mapping():
         atm.config_from_namelist({"spectral_dynamics_nml": {"vert_coord_option": "input", "num_levels": 7}, "vert_coordinate_nml": {"bk": bk}})
     with pytest.raises(dyncore.IscaError, match="not supported by the device physics"):
         atm.config_from_namelist({"atmosphere_nml": {"idealized_moist_model": True}, "mixed_layer_nml": {"land_depth": 2.0}})
+    ev = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 4, "vert_coord_option": "even_sigma"}})
+    assert ev.vert_coord_input == 1 and [ev.bk_input[i] for i in range(5)] == [0.0, 0.25, 0.5, 0.75, 1.0]
+    mars = atm.config_from_namelist({"constants_nml": {"radius": 3389.5e3, "omega": 7.088e-5}})
+    assert (mars.radius, mars.omega) == (3389.5e3, 7.088e-5)
+    with pytest.raises(dyncore.IscaError, match="only radius and omega"):
+        atm.config_from_namelist({"constants_nml": {"grav": 3.71}})
     dry = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 25}})
     assert dry.physics == 0 and dry.vert_coord_input == 0
 
