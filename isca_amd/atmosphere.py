@@ -170,6 +170,8 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 continue
             if isinstance(v, bool):
                 v = int(v)
+            if isinstance(v, (list, tuple)) and len(v) == 1:       # e.g. initial_sphum = [2.e-6] (one value per tracer)
+                v = v[0]
             kw[k] = tuple(v) if isinstance(v, list) else v
     kw.update(overrides)
     return dyncore.default_config(resolution, **kw)

@@ -27,27 +27,13 @@ def rel(a, b):
 
 
 def moist_namelist(res="T21", dt=720.0):
-    """The namelist of the reference run behind the fixtures (oracle/make_golden.py moist_input_nml)."""
-    return {
-        "atmosphere_nml": {"idealized_moist_model": True},
-        "main_nml": {"dt_atmos": dt},
-        "spectral_dynamics_nml": dict(damping_order=4, water_correction_limit=200.e2, reference_sea_level_press=1.0e5, num_levels=25,
-                                      valid_range_t=[100., 800.], initial_sphum=2.e-6, vert_coord_option="input", surf_res=0.5,
-                                      scale_heights=11.0, exponent=7.0, robert_coeff=0.03, **dyncore.RESOLUTIONS[res]),
-        "vert_coordinate_nml": {"bk": FRIERSON_BK, "pk": [0.0] * 26},
-        "idealized_moist_phys_nml": dict(do_damping=True, turb=True, mixed_layer_bc=True, do_virtual=False, do_simple=True,
-                                         roughness_mom=3.21e-05, roughness_heat=3.21e-05, roughness_moist=3.21e-05, two_stream_gray=True,
-                                         convection_scheme="SIMPLE_BETTS_MILLER"),
-        "vert_turb_driver_nml": dict(do_mellor_yamada=False, do_diffusivity=True, do_simple=True, constant_gust=0.0, use_tau=False),
-        "diffusivity_nml": dict(do_entrain=False, do_simple=True),
-        "surface_flux_nml": dict(use_virtual_temp=False, do_simple=True, old_dtaudv=True),
-        "mixed_layer_nml": dict(tconst=285., prescribe_initial_dist=True, evaporation=True, depth=2.5, albedo_value=0.31),
-        "qe_moist_convection_nml": dict(rhbm=0.7, Tmin=160., Tmax=350.),
-        "lscale_cond_nml": dict(do_simple=True, do_evap=True),
-        "sat_vapor_pres_nml": dict(do_simple=True),
-        "damping_driver_nml": dict(do_rayleigh=True, trayfric=-0.25, sponge_pbottom=5000., do_conserve_energy=True),
-        "two_stream_gray_rad_nml": dict(rad_scheme="frierson", do_seasonal=False, atm_abs=0.2),
-    }
+    """The Frierson test case's namelist (isca_amd/configs.py = frierson_test_case.py:49-170) at resolution `res`: the namelist of the
+    reference run behind the fixtures (oracle/make_golden.py moist_input_nml)."""
+    from isca_amd import configs
+    nml = configs.frierson()
+    nml["main_nml"]["dt_atmos"] = dt
+    nml["spectral_dynamics_nml"].update(dyncore.RESOLUTIONS[res])
+    return nml
 
 
 def moist_core(res="T21", dt=720.0, **kw):

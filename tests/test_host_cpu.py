@@ -268,3 +268,14 @@ def test_sibling_core_namelists():
         shallow.config_from_namelist({"shallow_dynamics_nml": {"no_such_key": 1}})
     with pytest.raises(IscaError, match="not a supported value for triang_trunc"):
         shallow.barotropic_config_from_namelist({"barotropic_dynamics_nml": {"triang_trunc": False}})
+
+
+def test_test_case_config_files(lib):
+    """isca_amd/configs.py holds the namelists of the two reference test cases key for key; both map onto the C config."""
+    from isca_amd import atmosphere as atm, configs
+    hs = atm.config_from_namelist(configs.held_suarez(), resolution="T42")
+    assert (hs.physics, hs.num_levels, hs.dt_atmos, hs.lat_max, hs.scale_heights, hs.ka, hs.initial_sphum) == (0, 25, 600.0, 64, 6.0, -40.0, 0.0)
+    fr = atm.config_from_namelist(configs.frierson(), resolution="T42")
+    assert (fr.physics, fr.num_levels, fr.dt_atmos, fr.initial_sphum, fr.robert_coeff, fr.vert_coord_input) == (1, 25, 720.0, 2.e-6, 0.03, 1)
+    assert fr.bk_input[1] == 0.0117665 and fr.moist.atm_abs == 0.2 and fr.moist.depth == 2.5 and fr.moist.trayfric == -0.25
+    assert fr.moist.rhbm == 0.7 and fr.moist.Tmin == 160.0 and fr.moist.constant_gust == 0.0
