@@ -96,6 +96,8 @@ typedef struct isca_dyn_config {
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */
 int isca_dyn_config_default(isca_dyn_config *cfg);
+/* ABI guard for bindings: sizeof(isca_dyn_config), sizeof(isca_moist_config), sizeof(isca_shallow_config), sizeof(isca_barotropic_config) */
+int isca_config_sizes(size_t *sizes, int n);
 
 /* spectral_dynamics_init + atmosphere_init + hs_forcing_init (tables, device state; no fields yet) */
 int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out);

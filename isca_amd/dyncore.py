@@ -75,6 +75,10 @@ def load_library():
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
     lib.isca_last_error.restype = C.c_char_p
+    sizes = (C.c_size_t * 4)()
+    lib.isca_config_sizes.argtypes, lib.isca_config_sizes.restype = [C.POINTER(C.c_size_t), C.c_int], C.c_int
+    if lib.isca_config_sizes(sizes, 4) != 0 or (sizes[0], sizes[1]) != (C.sizeof(_CConfig), C.sizeof(_CMoistConfig)):
+        raise IscaError(f"{LIB_PATH}: configuration structs of the library and of this binding differ (rebuild: python -m isca_amd.build)")
     dp = C.POINTER(C.c_double)
     H = C.c_void_p
     sig = {
@@ -155,7 +159,7 @@ EXPORTED_SYMBOLS = [
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check",
-    "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter",
+    "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter", "isca_config_sizes",
 ]
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)

@@ -32,6 +32,10 @@ def test_header_symbols_exported(lib):
         for name in decl:
             assert hasattr(lib, name), name
     import ctypes
+    sizes = (ctypes.c_size_t * 4)()
+    assert lib.isca_config_sizes(sizes, 4) == 0
+    assert list(sizes) == [ctypes.sizeof(dyncore._CConfig), ctypes.sizeof(dyncore._CMoistConfig), ctypes.sizeof(shallow._CShallowConfig),
+                           ctypes.sizeof(shallow._CBarotropicConfig)]
     for cls, header, tname in ((shallow._CShallowConfig, "isca_shallow.h", "isca_shallow_config"),
                                (shallow._CBarotropicConfig, "isca_barotropic.h", "isca_barotropic_config")):
         h = open(os.path.join(REPO, "include", header)).read()
