@@ -244,12 +244,23 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   const int ks = L;                                                       // k_surface
   auto set_nocape = [&](double &pLZB, int &kLZB, int &kLFC, double &CIN) {  // set_values_if_nocape (:1014-1030)
     pLZB = pf(1); kLZB = 0; kLFC = 0; CIN = 0.;
+    MP_UNROLL
     for (int k = 1; k <= L; ++k) { c.Tp[k] = Tin(k); c.rp[k] = rin(k); }
   };
   auto to_model = [&](int k1, int k2) {                                   // set_profiles_to_full_model_values (:1034-1047)
+    MP_UNROLL
     for (int k = k1; k <= k2; ++k) { c.Tref[k] = Tin(k); c.qref[k] = qin(k); c.dT[k] = 0.; c.dq[k] = 0.; }
   };
-  for (int k = 1; k <= L; ++k) { c.dT[k] = 0.; c.dq[k] = 0.; c.Tp[k] = Tin(k); c.rp[k] = rin(k); c.Tv[k] = qe_virtual_temp(Tin(k), rin(k)); }
+  for (int k0 = 1; k0 <= L; k0 += MP_U) {               // chunks: the loads of MP_U levels are in flight together
+    double tt[MP_U], qq[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) { const int k = (k0 + i <= L) ? k0 + i : L; tt[i] = Tin(k); qq[i] = qin(k); }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 + i;
+      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); c.dT[k] = 0.; c.dq[k] = 0.; c.Tp[k] = tt[i]; c.rp[k] = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }
+    }
+  }
   // ---- CAPE_calculation (:383-446)
   bool nocape = true, saturated = false, skip = false;
   double CAPE = 0., CIN = 0., pLZB = 0., pLCL = 0.;
@@ -353,38 +364,57 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   if (CAPE > 0) {
     convflag = 1;
     // ---- set_reference_profiles (:768-796)
-    for (int k = 1; k <= L; ++k) c.Tref[k] = c.Tp[k];
-    for (int k = (kLZB < 1 ? 1 : kLZB); k <= ks; ++k) {
-      if (k < kLZB) continue;
-      const double eref = P.rhbm * pf(k) * c.rp[k] / (c.rp[k] + (RDGAS / RVGAS));
-      c.rp[k] = qe_mixing_ratio(eref, pf(k));
-      c.qref[k] = c.rp[k] / (1 + c.rp[k]);
-    }
-    { const int kk = (kLZB - 1 > 1) ? kLZB - 1 : 1; to_model(1, kk); }
-    // ---- Pq_calculation (:710-733), Pt_calculation (:737-764)
     double Pt = 0.;
-    for (int k = kLZB; k <= ks; ++k) {
-      if (k < 1) continue;
-      c.dq[k] = -(qin(k) - c.qref[k]) * dt / P.tau_bm;
-      Pq = Pq + c.dq[k] * (ph(k) - ph(k + 1));
+    const int kb = (kLZB < 1) ? 1 : kLZB, kmodel = (kLZB - 1 > 1) ? kLZB - 1 : 1;
+    // set_reference_profiles (:768-796), set_profiles_to_full_model_values above the LZB, Pq_calculation (:710-733) and
+    // Pt_calculation (:737-764) act on each level independently: one pass in chunks, the four steps of a level in the
+    // reference's order, the two sums in theirs
+    for (int k0 = 1; k0 <= L; k0 += MP_U) {
+      double tp[MP_U], rp[MP_U], pfv[MP_U], qi[MP_U], ti[MP_U], ph0[MP_U], ph1[MP_U];
+      MP_UNROLL_ALL
+      for (int i = 0; i < MP_U; ++i) {
+        const int k = (k0 + i <= L) ? k0 + i : L;
+        tp[i] = c.Tp[k]; rp[i] = c.rp[k]; pfv[i] = pf(k); qi[i] = qin(k); ti[i] = Tin(k); ph0[i] = ph(k); ph1[i] = ph(k + 1);
+      }
+      MP_UNROLL_ALL
+      for (int i = 0; i < MP_U; ++i) {
+        const int k = k0 + i;
+        if (k <= L) {
+          double tref = tp[i], qref = 0.0;
+          c.Tref[k] = tref;
+          if (k >= kb) {
+            const double eref = P.rhbm * pfv[i] * rp[i] / (rp[i] + (RDGAS / RVGAS));
+            const double r = qe_mixing_ratio(eref, pfv[i]);
+            qref = r / (1 + r);
+            c.rp[k] = r; c.qref[k] = qref;
+          }
+          if (k <= kmodel) { tref = ti[i]; qref = qi[i]; c.Tref[k] = tref; c.qref[k] = qref; c.dT[k] = 0.; c.dq[k] = 0.; }
+          if (k >= kb) {
+            const double dq = -(qi[i] - qref) * dt / P.tau_bm;
+            c.dq[k] = dq;
+            Pq = Pq + dq * (ph0[i] - ph1[i]);
+            const double dT = -(ti[i] - tref) * dt / P.tau_bm;
+            c.dT[k] = dT;
+            Pt = Pt + (CP_AIR / (HLV + QE_SMALL)) * dT * (ph1[i] - ph0[i]);
+          }
+        }
+      }
     }
     Pq = Pq / GRAV;
-    for (int k = kLZB; k <= ks; ++k) {
-      if (k < 1) continue;
-      c.dT[k] = -(Tin(k) - c.Tref[k]) * dt / P.tau_bm;
-      Pt = Pt + (CP_AIR / (HLV + QE_SMALL)) * c.dT[k] * (ph(k + 1) - ph(k));
-    }
     Pt = Pt / GRAV;
     if ((Pq > 0) && (Pt > 0)) {
       convflag = 2;
       if (Pq > Pt) {                                  // do_change_time_scale_deepconv (:992-1008)
         const double invtau_q = Pt / Pq / P.tau_bm;
+        MP_UNROLL
         for (int k = kLZB; k <= ks; ++k) c.dq[k] = P.tau_bm * invtau_q * c.dq[k];
         Pq = Pt;
       } else {                                        // do_change_Tref_deepconv (:957-988)
         double deltak = 0.;
+        MP_UNROLL
         for (int k = kLZB; k <= ks; ++k) deltak = deltak - (c.dT[k] + (HLV / CP_AIR) * c.dq[k]) * (ph(k + 1) - ph(k));
         deltak = deltak / (ph(ks + 1) - ph(kLZB));
+        MP_UNROLL
         for (int k = kLZB; k <= ks; ++k) { c.Tref[k] = c.Tref[k] + deltak * P.tau_bm / dt; c.dT[k] = c.dT[k] + deltak; }
       }
     } else if (Pt > 0) {
@@ -403,6 +433,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         c.dq[k_top] = c.dq[k_top] * cc;
         c.dT[k_top] = c.dT[k_top] * cc;
         double deltak = 0.;
+        MP_UNROLL
         for (int kk = k_top; kk <= ks; ++kk) deltak = deltak + c.dT[kk] * (ph(kk) - ph(kk + 1));
         deltak = deltak / (ph(ks + 1) - ph(k_top));
         if (k_top != ks)
@@ -420,6 +451,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     to_model(1, ks);
   }
   rain = Pq;
+  MP_UNROLL
   for (int k = 1; k <= L; ++k) {
     deltaT[(k - 1) * so] = c.dT[k]; deltaq[(k - 1) * so] = c.dq[k];
     if (Tref_out) Tref_out[(k - 1) * so] = c.Tref[k];
