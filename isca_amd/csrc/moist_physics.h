@@ -290,11 +290,18 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       }
       int k = ks;
       CIN = 0.;
-      while (k >= 1 && pf(k) > pLCL) {
-        c.Tp[k] = theta0 * pow(pf(k) / QE_PREF, KAPPA);
-        c.rp[k] = qe_mixing_ratio(lookup_es(st, c.Tp[k]), pf(k));
-        CIN = CIN + RDGAS * (c.Tv[k] - qe_virtual_temp(c.Tp[k], r0)) * log(ph(k + 1) / ph(k));
-        k = k - 1;
+      {
+        double pfk = pf(ks), ph1 = ph(ks + 1), phk = ph(ks), tvk = c.Tv[ks];        // next level requested one iteration ahead
+        while (k >= 1 && pfk > pLCL) {
+          const int kn = (k > 1) ? k - 1 : 1;
+          const double pfn = pf(kn), phn = ph(kn), tvn = c.Tv[kn];
+          const double Tpk = theta0 * pow(pfk / QE_PREF, KAPPA);
+          c.Tp[k] = Tpk;
+          c.rp[k] = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
+          CIN = CIN + RDGAS * (tvk - qe_virtual_temp(Tpk, r0)) * log(ph1 / phk);
+          k = k - 1;
+          pfk = pfn; ph1 = phk; phk = phn; tvk = tvn;
+        }
       }
       kLCL = k;
       if (kLCL >= 1) {
@@ -332,28 +339,40 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   if (skip) {
     if (nocape) set_nocape(pLZB, kLZB, kLFC, CIN);
   } else {
-    for (int k = kLCL - 1; k >= 1; --k) {
-      double a = KAPPA * c.Tp[k + 1] + (HLV / CP_AIR) * c.rp[k + 1];
-      double b = (HLV * HLV) * c.rp[k + 1] / (CP_AIR * RVGAS * (c.Tp[k + 1] * c.Tp[k + 1]));
-      double dtdlnp = a / (1.0 + b);
-      c.Tp[k] = c.Tp[k + 1] + dtdlnp * log(pf(k) / pf(k + 1)) / 2;
-      if ((c.Tp[k] < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
-      c.rp[k] = qe_mixing_ratio(lookup_es(st, c.Tp[k]), (pf(k) + pf(k + 1)) / 2);
-      a = KAPPA * c.Tp[k] + (HLV / CP_AIR) * c.rp[k];
-      b = (HLV * HLV) * c.rp[k] / (CP_AIR * RVGAS * (c.Tp[k] * c.Tp[k]));
-      dtdlnp = a / (1.0 + b);
-      c.Tp[k] = c.Tp[k + 1] + dtdlnp * log(pf(k) / pf(k + 1));
-      if ((c.Tp[k] < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
-      c.rp[k] = qe_mixing_ratio(lookup_es(st, c.Tp[k]), pf(k));
-      const double tvp = qe_virtual_temp(c.Tp[k], c.rp[k]);
-      if ((tvp < c.Tv[k]) && nocape) {
-        CIN = CIN + RDGAS * (c.Tv[k] - tvp) * log(ph(k + 1) / ph(k));
-      } else if ((tvp < c.Tv[k]) && !nocape) {
-        kLZB = k + 1;
-        break;
-      } else {
-        CAPE = CAPE + RDGAS * (tvp - c.Tv[k]) * log(ph(k + 1) / ph(k));
-        if (nocape) { nocape = false; kLFC = k; }
+    if (kLCL - 1 >= 1) {
+      // the parcel's previous level stays in registers; pressures and Tv of the next level are requested one iteration ahead, so their
+      // latency hides behind this level's log / table-lookup chain
+      double Tp1 = c.Tp[kLCL], rp1 = c.rp[kLCL];
+      double pf1 = pf(kLCL), pfk = pf(kLCL - 1), ph1 = ph(kLCL), phk = ph(kLCL - 1), tvk = c.Tv[kLCL - 1];
+      for (int k = kLCL - 1; k >= 1; --k) {
+        const int kn = (k > 1) ? k - 1 : 1;
+        const double pfn = pf(kn), phn = ph(kn), tvn = c.Tv[kn];
+        double a = KAPPA * Tp1 + (HLV / CP_AIR) * rp1;
+        double b = (HLV * HLV) * rp1 / (CP_AIR * RVGAS * (Tp1 * Tp1));
+        double dtdlnp = a / (1.0 + b);
+        double Tpk = Tp1 + dtdlnp * log(pfk / pf1) / 2;
+        c.Tp[k] = Tpk;
+        if ((Tpk < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
+        double rpk = qe_mixing_ratio(lookup_es(st, Tpk), (pfk + pf1) / 2);
+        a = KAPPA * Tpk + (HLV / CP_AIR) * rpk;
+        b = (HLV * HLV) * rpk / (CP_AIR * RVGAS * (Tpk * Tpk));
+        dtdlnp = a / (1.0 + b);
+        Tpk = Tp1 + dtdlnp * log(pfk / pf1);
+        c.Tp[k] = Tpk;
+        if ((Tpk < P.Tmin) && nocape) { c.rp[k] = rpk; set_nocape(pLZB, kLZB, kLFC, CIN); break; }
+        rpk = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
+        c.rp[k] = rpk;
+        const double tvp = qe_virtual_temp(Tpk, rpk);
+        if ((tvp < tvk) && nocape) {
+          CIN = CIN + RDGAS * (tvk - tvp) * log(ph1 / phk);
+        } else if ((tvp < tvk) && !nocape) {
+          kLZB = k + 1;
+          break;
+        } else {
+          CAPE = CAPE + RDGAS * (tvp - tvk) * log(ph1 / phk);
+          if (nocape) { nocape = false; kLFC = k; }
+        }
+        Tp1 = Tpk; rp1 = rpk; pf1 = pfk; pfk = pfn; ph1 = phk; phk = phn; tvk = tvn;
       }
     }
   }
