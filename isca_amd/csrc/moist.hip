@@ -226,54 +226,61 @@ static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
 
 // physics of one step on the model state: previous-level fields, pressures of both levels, heights of the current one
 // compute_pressures_and_heights (press_and_geopot.F90:363-387, flat surface, no virtual temperature) of both time levels
-// (atmosphere.F90:296-303) in one launch: blockIdx.y = 0 -> previous level (pressures only: nothing reads its heights),
-// 1 -> current level (pressures and heights).  One bottom-up pass per column; the temperatures of 8 levels are loaded together.
+// (atmosphere.F90:296-303): the previous level needs pressures only (nothing reads its heights), the current one both.
 struct PressArgs {
   const double *pk, *bk;
   const double *t[2], *ps[2];
   double *p_full[2], *p_half[2], *z_full, *z_half;
   int ncol, L;
 };
-__global__ __launch_bounds__(64) void k_moist_pressures(PressArgs a) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
+// (1) level-parallel part: one thread per (column, level, time level): p_half, p_full, and for the current level the two hydrostatic
+//     increments of that layer, left in z_full / z_half for the scan
+__global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.ncol) return;
-  const int tl = blockIdx.y, L = a.L;
+  const int k = blockIdx.y, tl = blockIdx.z, L = a.L;
   const size_t c = (size_t)col, s = (size_t)a.ncol;
-  const bool heights = tl == 1;
   const double ps = a.ps[tl][c];
   const double *pk = a.pk, *bk = a.bk;
   const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
   const int ktop = (pk[0] == 0.0) ? 1 : 0;
-  double *p_full = a.p_full[tl] + c, *p_half = a.p_half[tl] + c;
-  const double *t = a.t[tl] + c;
+  const double ph0 = pk[k] + bk[k] * ps, ph1 = pk[k + 1] + bk[k + 1] * ps;
+  const double l0 = (top0 && k == 0) ? 0.0 : log(ph0), l1 = log(ph1);
+  double lf;
+  if (top0 && k == 0) lf = l1 - 1.0;
+  else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
+  a.p_full[tl][c + (size_t)k * s] = exp(lf);
+  a.p_half[tl][c + (size_t)k * s] = ph0;
+  if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
+  if (tl == 1) {
+    const double tk = a.t[1][c + (size_t)k * s];
+    a.z_full[c + (size_t)k * s] = RDGAS * tk * (l1 - lf);
+    a.z_half[c + (size_t)k * s] = (k >= ktop) ? RDGAS * tk * (l1 - l0) : 0.0;
+  }
+}
+// (2) the hydrostatic sum, bottom-up, one thread per column, 8 levels of increments requested together
+__global__ __launch_bounds__(64) void k_moist_heights(PressArgs a) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= a.ncol) return;
+  const int L = a.L;
+  const size_t c = (size_t)col, s = (size_t)a.ncol;
+  const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
   double gh = 0.0;
-  double ph1 = pk[L] + bk[L] * ps, l1 = log(ph1);
-  p_half[(size_t)L * s] = ph1;
-  if (heights) a.z_half[c + (size_t)L * s] = 0.0;
+  a.z_half[c + (size_t)L * s] = 0.0;
   for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
-    double tk[8], ph0[8], l0[8];
+    double zf[8], dz[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      tk[i] = heights ? t[(size_t)k * s] : 0.0;
-      ph0[i] = pk[k] + bk[k] * ps;
-      l0[i] = (top0 && k == 0) ? 0.0 : log(ph0[i]);
+      zf[i] = a.z_full[c + (size_t)k * s]; dz[i] = a.z_half[c + (size_t)k * s];
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = k0 - i;
       if (k >= 0) {
-        double lf;
-        if (top0 && k == 0) lf = l1 - 1.0;
-        else lf = l1 - (1.0 - ph0[i] * (l1 - l0[i]) / (ph1 - ph0[i]));
-        p_full[(size_t)k * s] = exp(lf);
-        p_half[(size_t)k * s] = ph0[i];
-        if (heights) {
-          a.z_full[c + (size_t)k * s] = (gh + RDGAS * tk[i] * (l1 - lf)) / GRAV;
-          if (k >= ktop) gh = gh + RDGAS * tk[i] * (l1 - l0[i]);
-          a.z_half[c + (size_t)k * s] = (k >= ktop) ? gh / GRAV : 0.0;
-        }
-        ph1 = ph0[i]; l1 = l0[i];
+        a.z_full[c + (size_t)k * s] = (gh + zf[i]) / GRAV;
+        if (k >= ktop) gh = gh + dz[i];
+        a.z_half[c + (size_t)k * s] = (k >= ktop) ? gh / GRAV : 0.0;
       }
     }
   }
@@ -287,7 +294,8 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L;
   a.t[0] = d.tg[sc.prev]; a.ps[0] = d.psg[sc.prev]; a.t[1] = d.tg[sc.cur]; a.ps[1] = d.psg[sc.cur];
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
-  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 63) / 64), 2), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_moist_heights, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, a);
 }
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
