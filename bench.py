@@ -85,6 +85,33 @@ def cpu_baseline(workload, budget_steps):
             "ms_per_step": 1e3 * sec, "sample": f"{n} steps of {workload} HS, numpy oracle (BLAS threads)"}
 
 
+def other_workloads(device):
+    """Informational, outside the timed region and never part of `value`: the other configurations of the same build on this GPU
+    (BASELINE configs[3] moist physics at the benchmark resolution; the sibling cores).  A failure here is reported, not raised."""
+    res = {}
+    try:
+        from isca_amd import dyncore
+        core = dyncore.DynCore(dyncore.default_config("T85", num_levels=40, physics=1, dt_atmos=300.0, initial_sphum=2e-6, robert_coeff=0.03,
+                                                      scale_heights=11.0, exponent=7.0, device=device))
+        core.cold_start(); core.step(150)
+        t0 = time.time(); core.step(300); dt = (time.time() - t0) / 300
+        res["T85L40 Frierson moist physics, dt_atmos=300s"] = {"ms_per_step": round(1e3 * dt, 4), "sim_years/day": round(sim_years_per_day(dt, 300.0), 1)}
+        core.close()
+    except Exception as e:                                               # noqa: BLE001
+        res["T85L40 Frierson moist physics"] = {"error": str(e)[:200]}
+    try:
+        from isca_amd import shallow
+        for name, mk in (("T85 shallow water, dt_atmos=1200s", lambda: shallow.ShallowWater(shallow.config_from_namelist(None, "T85", device=device))),
+                         ("T85 barotropic vorticity, dt_atmos=1200s", lambda: shallow.Barotropic(shallow.barotropic_config_from_namelist(None, "T85", device=device)))):
+            m = mk(); m.cold_start(); m.step(50)
+            t0 = time.time(); m.step(200); dt = (time.time() - t0) / 200
+            res[name] = {"ms_per_step": round(1e3 * dt, 4)}
+            m.close()
+    except Exception as e:                                               # noqa: BLE001
+        res["sibling cores"] = {"error": str(e)[:200]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +237,8 @@ def main():
         out["replicas"] = replicas
     if a.gpus == 1 and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps)
+    if a.gpus == 1 and a.workload == "T85L40" and not os.environ.get("ISCA_BENCH_NO_EXTRA"):
+        out["other_workloads"] = other_workloads(local_rank)
     print(json.dumps(out))
 
 
