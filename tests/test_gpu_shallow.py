@@ -146,3 +146,23 @@ def test_shallow_giant_planet(golden_dir):
     print("shallow water on the giant planet, 100 steps:", err)
     assert max(err.values()) < 1e-10, err
     sw.close()
+
+
+def test_tracers_are_passive():
+    """spec_tracer / grid_tracer off: the batches shrink, the dynamics do not change (bit for bit), for both cores."""
+    on = shallow.ShallowWater(shallow.config_from_namelist(NML, "T21"))
+    off = shallow.ShallowWater(shallow.config_from_namelist({**NML, "shallow_dynamics_nml": {**NML["shallow_dynamics_nml"], "spec_tracer": False,
+                                                                                                  "grid_tracer": False}}, "T21"))
+    for m in (on, off):
+        m.cold_start(); m.step(25)
+    for k in ("u", "v", "h", "vor", "div", "vors", "hs"):
+        assert np.array_equal(on.get(k), off.get(k)), k
+    on.close(); off.close()
+    bon = shallow.Barotropic(shallow.barotropic_config_from_namelist({"main_nml": {"dt_atmos": 1200}}, "T21"))
+    boff = shallow.Barotropic(shallow.barotropic_config_from_namelist({"main_nml": {"dt_atmos": 1200},
+                                                                       "barotropic_dynamics_nml": {"spec_tracer": False, "grid_tracer": False}}, "T21"))
+    for m in (bon, boff):
+        m.cold_start(); m.step(25)
+    for k in ("u", "v", "vor", "vors"):
+        assert np.array_equal(bon.get(k), boff.get(k)), k
+    bon.close(); boff.close()
