@@ -1,0 +1,135 @@
+! isca_dyn_c -- bind(C) view of include/isca_dyn.h for the reference's own language: what a maintainer adds to the reference to put the
+! GPU core behind atmosphere_mod / spectral_dynamics_mod / transforms_mod (INTEGRATION.md).  The derived types mirror the C structs member
+! for member; isca_config_sizes lets the caller verify that (check_abi below).  Compiled and run by tests/test_gpu_fortran_binding.py.
+module isca_dyn_c
+use iso_c_binding
+implicit none
+public
+
+integer, parameter :: ISCA_MAX_LEVELS = 128
+
+type, bind(C) :: isca_moist_config
+  real(c_double) :: roughness_mom, roughness_heat, roughness_moist
+  real(c_double) :: solar_constant, del_sol, del_sw, ir_tau_eq, ir_tau_pole, atm_abs, odp, sw_diff, linear_tau, wv_exponent, solar_exponent
+  real(c_double) :: depth, tconst, delta_T, albedo_value
+  integer(c_int) :: evaporation
+  real(c_double) :: tau_bm, rhbm, Tmin, Tmax, val_inc
+  integer(c_int) :: do_rayleigh
+  real(c_double) :: trayfric, sponge_pbottom
+  integer(c_int) :: damping_conserve_energy
+  real(c_double) :: constant_gust
+  real(c_double) :: frac_inner, rich_crit_pbl
+  real(c_double) :: rich_crit, drag_min
+end type
+
+type, bind(C) :: isca_dyn_config
+  integer(c_int) :: lon_max, lat_max, num_fourier, num_spherical, num_levels
+  integer(c_int) :: fourier_inc
+  integer(c_int) :: triang_trunc
+  real(c_double) :: dt_atmos
+  integer(c_int) :: damping_order
+  real(c_double) :: damping_coeff
+  real(c_double) :: eddy_sponge_coeff, zmu_sponge_coeff, zmv_sponge_coeff
+  real(c_double) :: robert_coeff
+  real(c_double) :: raw_filter_coeff
+  real(c_double) :: alpha_implicit
+  real(c_double) :: reference_sea_level_press
+  real(c_double) :: scale_heights, exponent, surf_res
+  integer(c_int) :: do_mass_correction, do_energy_correction, do_water_correction
+  real(c_double) :: water_correction_limit
+  real(c_double) :: initial_temperature
+  real(c_double) :: initial_sphum
+  real(c_double) :: valid_range_t(2)
+  integer(c_int) :: num_tracers
+  real(c_double) :: t_zero, t_strat, delh, delv, eps, sigma_b, ka, ks, kf
+  integer(c_int) :: do_conserve_energy
+  real(c_double) :: trflux, trsink, P00
+  integer(c_int) :: rank, world_size
+  integer(c_int) :: device
+  type(c_ptr)    :: stream
+  integer(c_int) :: legendre_impl
+  integer(c_int) :: physics
+  integer(c_int) :: vert_coord_input
+  real(c_double) :: pk_input(ISCA_MAX_LEVELS + 1), bk_input(ISCA_MAX_LEVELS + 1)
+  type(isca_moist_config) :: moist
+  real(c_double) :: radius, omega
+end type
+
+interface
+  integer(c_int) function isca_dyn_config_default(cfg) bind(C)
+    import; type(isca_dyn_config), intent(out) :: cfg
+  end function
+  integer(c_int) function isca_config_sizes(sizes, n) bind(C)
+    import; integer(c_size_t), intent(out) :: sizes(*); integer(c_int), value :: n
+  end function
+  integer(c_int) function isca_dyn_create(cfg, h) bind(C)
+    import; type(isca_dyn_config), intent(in) :: cfg; type(c_ptr), intent(out) :: h
+  end function
+  integer(c_int) function isca_dyn_destroy(h) bind(C)
+    import; type(c_ptr), value :: h
+  end function
+  integer(c_int) function isca_dyn_cold_start(h) bind(C)
+    import; type(c_ptr), value :: h
+  end function
+  integer(c_int) function isca_dyn_step(h, nsteps, sync) bind(C)
+    import; type(c_ptr), value :: h; integer(c_int), value :: nsteps, sync
+  end function
+  integer(c_int) function isca_dyn_get_state(h, name, time_level, host, count) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), value :: time_level; real(c_double), intent(out) :: host(*); integer(c_size_t), value :: count
+  end function
+  integer(c_int) function isca_dyn_set_state(h, name, time_level, host, count) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*)
+    integer(c_int), value :: time_level; real(c_double), intent(in) :: host(*); integer(c_size_t), value :: count
+  end function
+  integer(c_int) function isca_dyn_get_table(h, name, host, count) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*)
+    real(c_double), intent(out) :: host(*); integer(c_size_t), value :: count
+  end function
+  integer(c_int) function isca_trans_spherical_to_grid(h, spherical, grid, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: spherical(*)
+    real(c_double), intent(out) :: grid(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_grid_to_spherical(h, grid, spherical, nlev, do_truncation) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: grid(*)
+    complex(c_double_complex), intent(out) :: spherical(*); integer(c_int), value :: nlev, do_truncation
+  end function
+  integer(c_int) function isca_area_weighted_global_mean(h, field2d, mean) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: field2d(*); real(c_double), intent(out) :: mean
+  end function
+  function isca_last_error() bind(C) result(msg)
+    import; type(c_ptr) :: msg
+  end function
+end interface
+
+contains
+
+! the FATAL message of the library as a Fortran string (for error_mesg(routine, message, FATAL))
+function isca_message() result(text)
+  character(len=:), allocatable :: text
+  character(kind=c_char), pointer :: p(:)
+  type(c_ptr) :: cp
+  integer :: n
+  cp = isca_last_error()
+  text = ''
+  if(.not. c_associated(cp)) return
+  call c_f_pointer(cp, p, (/4096/))
+  n = 0
+  do while(n < 4096)
+    if(p(n+1) == c_null_char) exit
+    n = n + 1
+  enddo
+  allocate(character(len=n) :: text)
+  text = transfer(p(1:n), text)
+end function
+
+! .true. when this module's derived types have the size of the library's structs
+logical function check_abi()
+  integer(c_size_t) :: sizes(4)
+  type(isca_dyn_config) :: cfg
+  check_abi = .false.
+  if(isca_config_sizes(sizes, 4_c_int) /= 0) return
+  check_abi = (sizes(1) == c_sizeof(cfg)) .and. (sizes(2) == c_sizeof(cfg%moist))
+end function
+
+end module isca_dyn_c

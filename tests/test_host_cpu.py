@@ -283,3 +283,21 @@ def test_test_case_config_files(lib):
     assert (fr.physics, fr.num_levels, fr.dt_atmos, fr.initial_sphum, fr.robert_coeff, fr.vert_coord_input) == (1, 25, 720.0, 2.e-6, 0.03, 1)
     assert fr.bk_input[1] == 0.0117665 and fr.moist.atm_abs == 0.2 and fr.moist.depth == 2.5 and fr.moist.trayfric == -0.25
     assert fr.moist.rhbm == 0.7 and fr.moist.Tmin == 160.0 and fr.moist.constant_gust == 0.0
+
+
+def test_fortran_binding_abi(lib, tmp_path):
+    """bindings/fortran/isca_dyn_c.F90 (the bind(C) module for the reference's language) compiles with the image's flang and its
+    derived types have the library's struct sizes; defaults read back through them (no GPU needed)."""
+    flang = os.environ.get("FLANG", "/opt/rocm/lib/llvm/bin/flang")
+    if not os.path.exists(flang):
+        pytest.skip("no flang in this image")
+    src, libdir = os.path.join(REPO, "bindings", "fortran"), os.path.join(REPO, "isca_amd", "lib")
+    mod_o, exe = str(tmp_path / "isca_dyn_c.o"), str(tmp_path / "check_abi.x")
+    subprocess.run([flang, "-c", os.path.join(src, "isca_dyn_c.F90"), "-o", mod_o, "-module-dir", str(tmp_path)], check=True, capture_output=True)
+    subprocess.run([flang, os.path.join(src, "check_abi.F90"), mod_o, "-I", str(tmp_path), "-L", libdir, "-lisca_dyn", "-Wl,-rpath," + libdir,
+                    "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ABI_OK" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.split("ABI_OK")[1].split()[:5] == ["64", "32", "21", "22", "25"]
+    vals = [float(x) for x in r.stdout.split("DEFAULTS")[1].split()[:4]]
+    assert vals == [0.04, 0.2, 6376.0e3, 800.0]
