@@ -293,11 +293,15 @@ def test_fortran_binding_abi(lib, tmp_path):
         pytest.skip("no flang in this image")
     src, libdir = os.path.join(REPO, "bindings", "fortran"), os.path.join(REPO, "isca_amd", "lib")
     mod_o, exe = str(tmp_path / "isca_dyn_c.o"), str(tmp_path / "check_abi.x")
+    sib_o = str(tmp_path / "isca_siblings_c.o")
     subprocess.run([flang, "-c", os.path.join(src, "isca_dyn_c.F90"), "-o", mod_o, "-module-dir", str(tmp_path)], check=True, capture_output=True)
-    subprocess.run([flang, os.path.join(src, "check_abi.F90"), mod_o, "-I", str(tmp_path), "-L", libdir, "-lisca_dyn", "-Wl,-rpath," + libdir,
+    subprocess.run([flang, "-c", os.path.join(src, "isca_siblings_c.F90"), "-o", sib_o, "-module-dir", str(tmp_path)], check=True, capture_output=True)
+    subprocess.run([flang, os.path.join(src, "check_abi.F90"), mod_o, sib_o, "-I", str(tmp_path), "-L", libdir, "-lisca_dyn", "-Wl,-rpath," + libdir,
                     "-o", exe], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "ABI_OK" in r.stdout, r.stdout + r.stderr
     assert r.stdout.split("ABI_OK")[1].split()[:5] == ["64", "32", "21", "22", "25"]
     vals = [float(x) for x in r.stdout.split("DEFAULTS")[1].split()[:4]]
     assert vals == [0.04, 0.2, 6376.0e3, 800.0]
+    sib = r.stdout.split("SIBLINGS")[1].split()[:4]
+    assert [float(x) for x in sib[:3]] == [3.e4, 172800.0, 8.e-5] and int(sib[3]) == 4
