@@ -63,6 +63,37 @@ __global__ __launch_bounds__(512) void probe_blocked(const double *__restrict__ 
   }
 }
 
+// fewer, fatter streams: the NA input fields interleaved component-wise in NG arrays of NA/NG components ([lev][col][comp]), same for the
+// outputs -- a wavefront access is then a contiguous run of 64 * comps * 8 bytes
+template <int NA, int NO, int NG, int CH>
+__global__ __launch_bounds__(512) void probe_interleaved(const double *__restrict__ in, double *__restrict__ out, size_t ls, size_t as, int L) {
+  constexpr int CI = NA / NG, CO = NO / NG;
+  const int tid = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t c2 = (size_t)blockIdx.x * 64 + tid;
+  double acc[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int k = w * CH + i;
+    acc[i] = 0;
+    if (k < L) {
+#pragma unroll
+      for (int gph = 0; gph < NG; ++gph)
+#pragma unroll
+        for (int cmp = 0; cmp < CI; ++cmp) acc[i] += in[(size_t)gph * as * CI + ((size_t)k * ls + c2) * CI + cmp];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int k = w * CH + i;
+    if (k < L) {
+#pragma unroll
+      for (int gph = 0; gph < NG; ++gph)
+#pragma unroll
+        for (int cmp = 0; cmp < CO; ++cmp) out[(size_t)gph * as * CO + ((size_t)k * ls + c2) * CO + cmp] = acc[i];
+    }
+  }
+}
+
 template <int V>
 int run(const char *name) {
   const int L = 40, ncol = 256 * 128, NA = 10, NO = 6, NSET = 6;
@@ -78,8 +109,9 @@ int run(const char *name) {
     hipEventRecord(e0);
     for (int r = 0; r < reps; ++r) {
       const int set = r % NSET;
-      if (V == 0) hipLaunchKernelGGL((probe_blocked<NA, NO, 5>), dim3(ncol / 64), dim3(512), 0, 0, in + set * as * NA, out + set * as * NO, as, L);
-      else hipLaunchKernelGGL((probe<(V ? V : 1), NA, NO, 5>), dim3(ncol / 64 / (V ? V : 1)), dim3(512), 0, 0, in + set * as * NA, out + set * as * NO, ls, as, L);
+      if (V == 5) hipLaunchKernelGGL((probe_interleaved<NA, NO, 2, 5>), dim3(ncol / 64), dim3(512), 0, 0, in + set * as * NA, out + set * as * NO, ls, as, L);
+      else if (V == 0) hipLaunchKernelGGL((probe_blocked<NA, NO, 5>), dim3(ncol / 64), dim3(512), 0, 0, in + set * as * NA, out + set * as * NO, as, L);
+      else hipLaunchKernelGGL((probe<((V == 0 || V == 5) ? 1 : V), NA, NO, 5>), dim3(ncol / 64 / ((V == 0 || V == 5) ? 1 : V)), dim3(512), 0, 0, in + set * as * NA, out + set * as * NO, ls, as, L);
     }
     hipEventRecord(e1); hipEventSynchronize(e1);
   }
@@ -94,5 +126,6 @@ int main() {
   if (run<2>("2 columns / lane (1 KB runs)")) return 1;
   if (run<4>("4 columns / lane (2 KB runs)")) return 1;
   if (run<0>("blocked: 20 KB per block/array")) return 1;
+  if (run<5>("interleaved: 2x(5 in), 2x(3 out)")) return 1;
   return 0;
 }
