@@ -44,3 +44,24 @@ def test_fortran_driver_matches_reference_run(tmp_path, golden_dir):
     ts = sc.trans_grid_to_spherical(tg)
     assert abs(re_ - ts[24, 0, 0].real) < 1e-9 and abs(im_) < 1e-12
     assert "FORTRAN_ERROR" in out and "unknown field" in out          # the FATAL convention: non-zero return + message
+
+
+def test_fortran_moist_driver(tmp_path, golden_dir):
+    """The Frierson configuration set from Fortran through the nested bind(C) types (isca_moist_config, bk array): 144 steps on the GPU land
+    on the reference's moist run."""
+    if not os.path.exists(FLANG):
+        pytest.skip("no flang in this image")
+    src = os.path.join(REPO, "bindings", "fortran")
+    lib = os.path.join(REPO, "isca_amd", "lib")
+    mod_o, exe = str(tmp_path / "isca_dyn_c.o"), str(tmp_path / "drive_frierson.x")
+    subprocess.run([FLANG, "-c", os.path.join(src, "isca_dyn_c.F90"), "-o", mod_o, "-module-dir", str(tmp_path)], check=True, capture_output=True)
+    subprocess.run([FLANG, os.path.join(src, "drive_frierson.F90"), mod_o, "-I", str(tmp_path), "-L", lib, "-lisca_dyn", "-Wl,-rpath," + lib,
+                    "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    g = np.load(os.path.join(golden_dir, "moist_run_T21L25.npz"))
+    tg, q = g["st_tg_000144"], g["st_q_000144"]
+    tmin, tmax, qmax, qpt = [float(x) for x in re.search(r"FORTRAN_MOIST Tmin,Tmax,qmax,q\(10,16,25\)=\s*(.*)", r.stdout).group(1).split()]
+    assert abs(tmin - tg.min()) < 1e-7 and abs(tmax - tg.max()) < 1e-7 and abs(qmax - q.max()) < 1e-10 and abs(qpt - q[24, 15, 9]) < 1e-10
+    smin, smax = [float(x) for x in re.search(r"FORTRAN_TSURF min,max=\s*(.*)", r.stdout).group(1).split()]
+    assert 230.0 < smin < smax < 310.0
