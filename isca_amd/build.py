@@ -28,7 +28,8 @@ def _digest(paths):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "isca_dyn.h")]
+    inc = os.path.join(HERE, "..", "include")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     stamp = os.path.join(LIBDIR, "build_stamp.json")
     dig = _digest(srcs)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and json.load(open(stamp)).get("digest") == dig:
