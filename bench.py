@@ -145,6 +145,18 @@ def main():
     else:
         core = dyncore.DynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, device=local_rank))
         barrier = lambda: None
+    watchdog = None
+    if world > 1:       # a collective that never completes would otherwise hold the whole job until the caller's own limit
+        import threading
+        def _stuck():
+            if rank == 0:
+                print(json.dumps({"metric": "simulated-years/day at T85L40 Held-Suarez", "value": None, "unit": "sim_years/day", "n_gpus": a.gpus,
+                                  "steps": a.steps, "warmup": a.warmup, "error": "sharded step did not complete within the watchdog limit "
+                                  f"(exchange driver: {'native RCCL' if getattr(core, 'native', False) else 'torch.distributed'})"}), flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(float(os.environ.get("ISCA_BENCH_WATCHDOG_S", "900")), _stuck)
+        watchdog.daemon = True
+        watchdog.start()
     core.cold_start()
     core.step(a.warmup, sync=True)
     barrier(); torch.cuda.synchronize()
@@ -157,6 +169,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     sec_per_step = elapsed / a.steps
+    if watchdog is not None:
+        watchdog.cancel()
 
     # per-kernel durations: HIP events on the stream the kernels run on, same number of steps, right after
     core.kernel_times(True)
