@@ -4,6 +4,7 @@
 #   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE; SQ wave/wait/VALU/MFMA counters) with --kernel-trace only
 # Outputs land in gpurun_out/prof_final/ ; tools/summarize_profiles.py turns them into profiles/r01_*.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export ISCA_BENCH_NO_EXTRA=1     # only the headline workload in the profiled command
 OUT=gpurun_out/prof_final
 mkdir -p $OUT
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 500 --warmup 50 --cpu-steps 0 > $OUT/bench_stats.log 2>&1
