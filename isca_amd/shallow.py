@@ -327,3 +327,62 @@ class Barotropic(ShallowWater):
 
     def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
         self._check(self.lib.isca_barotropic_set_time_pointers(self._h, previous, current, step_count))
+
+
+# =====================================================================================================
+# Restart files of the sibling cores, with the reference's variable set (shallow_dynamics.F90:650-678, barotropic_dynamics.F90
+# write_restart; stirring.F90:236-239): two records along Time, record 1 = `previous`, record 2 = `current`
+# =====================================================================================================
+def _restart_layout(model):
+    if isinstance(model, Barotropic):
+        return "barotropic_dynamics.res.nc", ("vors",), ("u", "v", "vor")
+    return "shallow_dynamics.res.nc", ("vors", "divs", "hs"), ("u", "v", "vor", "div", "h")
+
+
+def write_restart(model, directory: str):
+    """shallow_dynamics_end / barotropic_dynamics_end (+ stirring_end): RESTART/<core>_dynamics.res.nc, RESTART/stirring.res.nc."""
+    import os
+    from .restart import _Writer
+    os.makedirs(directory, exist_ok=True)
+    fname, spec, grid = _restart_layout(model)
+    w = _Writer(os.path.join(directory, fname))
+    for nm in spec + (("trss",) if model.cfg.spec_tracer else ()):
+        lv = [model.get(nm, 0), model.get(nm, 1)]
+        out = "trs" if nm == "trss" else nm
+        w.put(out + "_real", [np.ascontiguousarray(a.real) for a in lv])
+        w.put(out + "_imag", [np.ascontiguousarray(a.imag) for a in lv])
+    for nm in grid + (("trs",) if model.cfg.spec_tracer else ()) + (("tr",) if model.cfg.grid_tracer else ()):
+        w.put(nm, [model.get(nm, 0), model.get(nm, 1)])
+    w.close()
+    if model.cfg.stirring.amplitude != 0.0:
+        s = model.get("stirs")
+        w = _Writer(os.path.join(directory, "stirring.res.nc"))
+        w.put("stir_real", [np.ascontiguousarray(s.real)])
+        w.put("stir_imag", [np.ascontiguousarray(s.imag)])
+        w.close()
+
+
+def read_restart(model, directory: str):
+    """The Time /= Time_init branch of *_dynamics_init + atmosphere_init (previous = 1, current = 2) + stirring_init's restart."""
+    import os
+    from .restart import _read_all
+    fname, spec, grid = _restart_layout(model)
+    path = os.path.join(directory, fname)
+    if not os.path.exists(path):
+        raise IscaError("read_restart: restart does not exist")
+    d = _read_all(path)
+    J, I, N1, M1 = model.J, model.I, model.N1, model.M1
+    if d["u"].shape[-2:] != (J, I) or d["vors_real"].shape[-2:] != (N1, M1):
+        raise IscaError("read_restart: resolution of the restart file does not match the namelist")
+    for rec, slot in ((0, 0), (1, 1)):
+        model.set_time_pointers(slot, slot, 0)                      # address storage slot `slot` as "current" to fill it
+        for nm in spec + (("trss",) if model.cfg.spec_tracer else ()):
+            key = "trs" if nm == "trss" else nm
+            model.set(nm, d[key + "_real"][rec].reshape(N1, M1) + 1j * d[key + "_imag"][rec].reshape(N1, M1), 1)
+        for nm in grid + (("trs",) if model.cfg.spec_tracer else ()) + (("tr",) if model.cfg.grid_tracer else ()):
+            model.set(nm, d[nm][rec].reshape(J, I), 1)
+    model.set_time_pointers(0, 1, 1)
+    spath = os.path.join(directory, "stirring.res.nc")
+    if model.cfg.stirring.amplitude != 0.0 and os.path.exists(spath):
+        s = _read_all(spath)
+        model.set("stirs", s["stir_real"].reshape(N1, M1) + 1j * s["stir_imag"].reshape(N1, M1))

@@ -166,3 +166,36 @@ def test_tracers_are_passive():
     for k in ("u", "v", "vor", "vors"):
         assert np.array_equal(bon.get(k), boff.get(k)), k
     bon.close(); boff.close()
+
+
+def test_sibling_restart_files(tmp_path):
+    """<core>_dynamics.res.nc with the reference's variable set (two records: previous, current) and stirring.res.nc: a run continued
+    from the files equals the uninterrupted run bit for bit (with supplied stirring noise, so both draw the same numbers)."""
+    from scipy.io import netcdf_file
+    rng = np.random.default_rng(3)
+    for kind in ("shallow", "barotropic"):
+        nml = {"main_nml": {"dt_atmos": 1200}, "stirring_nml": {"amplitude": 3.e-12, "B": 1.0}}
+        if kind == "shallow":
+            nml["shallow_dynamics_nml"] = NML["shallow_dynamics_nml"]
+            mk = lambda: shallow.ShallowWater(shallow.config_from_namelist(nml, "T21"))
+        else:
+            mk = lambda: shallow.Barotropic(shallow.barotropic_config_from_namelist(nml, "T21"))
+        a = mk(); a.cold_start()
+        noise = rng.random((12, 2, a.N1, a.M1))
+        for n in range(6):
+            a.set_stirring_noise(noise[n]); a.step(1)
+        d = str(tmp_path / kind)
+        shallow.write_restart(a, d)
+        f = netcdf_file(os.path.join(d, kind + "_dynamics.res.nc"), "r", mmap=False)
+        assert f.variables["vors_real"].shape[0] == 2 and f.variables["u"].shape[-2:] == (32, 64) and "tr" in f.variables and "trs_imag" in f.variables
+        f.close()
+        assert os.path.exists(os.path.join(d, "stirring.res.nc"))
+        b = mk(); shallow.read_restart(b, d)
+        for n in range(6, 12):
+            for m in (a, b):
+                m.set_stirring_noise(noise[n]); m.step(1)
+        for k in ("u", "v", "vor", "tr", "trs", "vors", "stirs") + (("h", "hs") if kind == "shallow" else ()):
+            assert np.array_equal(a.get(k), b.get(k)), (kind, k)
+        a.close(); b.close()
+    with pytest.raises(IscaError, match="restart does not exist"):
+        shallow.read_restart(mk(), str(tmp_path / "nowhere"))
