@@ -1614,7 +1614,17 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
   double *sx = q2 + I;                // [I]
   double *fl = sx + I;                // [I]
   __shared__ int any_big[RB];
-  const int i = threadIdx.x, j0 = g.j0 + blockIdx.x * RB, k = blockIdx.y;      // j0: global index of the block's first row
+  // Workgroups go round-robin over the 8 XCDs; neighbouring row blocks share 4 of their 8 source rows, so the tile index is
+  // permuted to give each XCD (= each L2) a contiguous run of row blocks (whole levels) instead of every eighth one.
+  int tbx = blockIdx.x, tby = blockIdx.y;
+  {
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0) {
+      const int lin = blockIdx.x + gridDim.x * blockIdx.y, tile = (lin & 7) * (total >> 3) + (lin >> 3);
+      tby = tile / (int)gridDim.x; tbx = tile - tby * gridDim.x;
+    }
+  }
+  const int i = threadIdx.x, j0 = g.j0 + tbx * RB, k = tby;      // j0: global index of the block's first row
   const size_t lev = (size_t)g.Jl * I;
   int jsrc[NR];                                                                 // global source row of each virtual row
   bool mir[NR], loc[NR];
