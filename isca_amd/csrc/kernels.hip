@@ -30,6 +30,13 @@ enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP
 // One block = R rows (R consecutive level-fields at one latitude), 256 threads.
 // =====================================================================================================
 // ---- in-register radix-2/4/8 butterflies (INV: conjugate transform)
+// First work item of a persistent FFT block.  Workgroups go round-robin over the 8 XCDs and neighbouring items (column groups gx,
+// gx+1 of one latitude) touch the same 128-byte lines of the Fourier buffer (its 256-byte pieces are not line-aligned), so each
+// XCD takes a contiguous run of items: the shared lines are then fetched once per L2 instead of once per block.
+__device__ __forceinline__ int fft_first_item() {
+  const int G = gridDim.x, b = blockIdx.x;
+  return (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+}
 template <bool INV> __device__ __forceinline__ double2 mul_mi(double2 a) {   // * (-i) forward, * (+i) inverse
   return INV ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
 }
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_fwd(Geom g, FieldLis
 #pragma unroll
     for (int i = 0; i < PER; ++i) { const int n = tr + 16 * i; if (n < NC) z[i] = src[n]; }
   };
-  int item = blockIdx.x;
+  int item = fft_first_item();
   if (item < NG) request(item, zn, scale_n);
   for (; item < NG; item += gridDim.x) {
     const int gx = item % GX, jl = item / GX;
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
 #pragma unroll
     for (int i = 0; i < PERM; ++i) X[i] = *(const double2 *)(Fg + ((size_t)slot[i] * g.Jl + jl) * C + 2 * ccl);
   };
-  int item = blockIdx.x;
+  int item = fft_first_item();
   if (item < NG) request(item, Xn);
   for (; item < NG; item += gridDim.x) {
     const int gx = item % GX, jl = item / GX;
