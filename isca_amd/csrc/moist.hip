@@ -41,6 +41,18 @@ struct MoistArgs {
 // (dt_tg = ((conv + cond) + rad) + sponge) and goes on with the boundary layer and the implicit diffusion.  With blockDim = 64
 // the same code runs the three parts one after the other.
 constexpr int MOIST_NX = 20;       // scalars handed from wavefront 1 to wavefront 0 through work array 0 (needs L + 1 >= MOIST_NX)
+// Phase timing for kernel experiments (tools/dev/moist_phase_times.py): built with -DMOIST_TIMING=p the kernel stamps wall_clock64 (10 ns
+// ticks) at the marks of phase p (1: convection + condensation, 2: radiation + surface flux + sponge, 3: after the barrier) and stores,
+// in lane i of every wavefront, the time between marks i and i+1 in place of the precipitation.
+#ifdef MOIST_TIMING
+#define MT_DECL long long mt_[9]; for (int i_ = 0; i_ < 9; ++i_) mt_[i_] = wall_clock64();
+#define MT(p, i) if (MOIST_TIMING == p) { const long long t_ = wall_clock64(); for (int i_ = i; i_ < 9; ++i_) mt_[i_] = t_; }
+#define MT_STORE(p) if (MOIST_TIMING == p) { long long d_ = 0; for (int i_ = 0; i_ < 8; ++i_) if ((lane & 7) == i_) d_ = mt_[i_ + 1] - mt_[i_]; a.precip[c] = (double)d_; }
+#else
+#define MT_DECL
+#define MT(p, i)
+#define MT_STORE(p)
+#endif
 template <int LMAX, bool LDSW>
 __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
@@ -57,12 +69,14 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   const int nray = a.do_damping ? a.ray.nlev_rayfric : 0;
   double t_surf = 0.0, net_sw = 0.0, lw_down_surf = 0.0;
   moist::SurfFlux sf;
+  MT_DECL
   if (role == 0) {
     // ---- convection (:862-880): deltas over the step, then rates
     double rain, cape, cin;
     int flag, klzb, klcl;
     moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
                                      nullptr, nullptr, s);
+    MT(1, 1)
     double precip = rain / delta_t;
     // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
     double rain_ls;
@@ -75,6 +89,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
                        rain_ls);
     precip = precip + rain_ls / delta_t;
     if (a.precip) a.precip[c] = precip;
+    MT(1, 2) MT_STORE(1)
   }
   if (role == nroles - 1) {
     // ---- grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
@@ -82,11 +97,14 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
     moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, net_sw, lw_down_surf);
+    MT(2, 1)
     const size_t low = (size_t)(L - 1) * s;
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
+    MT(2, 2)
     for (int k = 0; k < L; ++k) { w2[k * sw] = 0.0; dtu[k * s] = 0.0; dtv[k * s] = 0.0; }
     moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, w2, sw);
+    MT(2, 3)
     // ---- Rayleigh sponge (:1228-1237): momentum tendencies in place, its heating into work array 1 (radiation is done with it)
     for (int k = 0; k < nray; ++k) w1[k * sw] = 0.0;
     if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, w1, sw);
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
       for (int i = 0; i < MOIST_NX; ++i) w0[i * sw] = x[i];
     }
   }
+  if (role == nroles - 1) { MT(2, 4) MT_STORE(2) }
   if (nroles == 2) {
     __syncthreads();
     if (role != 0) return;
@@ -107,28 +126,44 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     sf.drdt_surf = x[7]; sf.dhdt_atm = x[8]; sf.dedq_atm = x[9]; sf.dtaudu_atm = x[10]; sf.dtaudv_atm = x[11]; sf.u_star = x[12];
     sf.b_star = x[13]; t_surf = x[14]; net_sw = x[15]; lw_down_surf = x[16];
   }
+  MT(3, 0)
   // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order
-  for (int k = 0; k < L; ++k) {
-    double t = dtT[k * s] + w2[k * sw];
-    if (k < nray) t = t + w1[k * sw];
-    dtT[k * s] = t;
+  for (int k0 = 0; k0 < L; k0 += MP_U) {         // loads of a chunk first: a store to dtT may alias the next level's load for all the compiler knows
+    double t[MP_U];
+#pragma unroll
+    for (int i = 0; i < MP_U; ++i) t[i] = dtT[(size_t)min(k0 + i, L - 1) * s];
+#pragma unroll
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = k0 + i;
+      if (k < L) {
+        double x = t[i] + w2[k * sw];
+        if (k < nray) x = x + w1[k * sw];
+        dtT[(size_t)k * s] = x;
+      }
+    }
   }
+  MT(3, 1)
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
   {
     const double h = moist::pbl_depth(a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s);
+    MT(3, 2)
     moist::PblProfile pbl;
     pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
     const moist::VdiffWork w{w0, w1, w2, sw};
     moist::VdiffSurf S;
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
-    moist::vert_diff_momentum(L, delta_t, up, vp, tp, s, [&](int k) { return pbl.k_m(k); }, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
+    moist::vert_diff_momentum(L, delta_t, up, vp, tp, s, moist::PblProfile::Km{pbl}, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
                               sf.dtaudu_atm, sf.dtaudv_atm, dtu, dtv, dtT, s, nullptr, 0, w, S);
-    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, [&](int k) { return pbl.k_t(k); }, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
+    MT(3, 3)
+    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
+    MT(3, 4)
     moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
+    MT(3, 5)
     moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s);
   }
   a.t_surf[c] = t_surf;
+  MT(3, 6) MT_STORE(3)
 }
 
 // mixed_layer_init with prescribe_initial_dist (mixed_layer.F90:455-460): t_surf = tconst - delta_T (3 sin^2 lat - 1)/3

@@ -20,7 +20,9 @@
 // Level loops run in chunks of MP_U levels: all global loads of a chunk are issued first (one memory round trip per chunk
 // instead of one per level: a column is a chain of dependent recurrences, and a GPU thread walking it level by level waits a
 // full memory latency per level), then the recurrence is advanced, then the chunk's results are stored.
+#ifndef MP_U
 #define MP_U 8
+#endif
 #if defined(__HIPCC__)
 #define MP_UNROLL_ALL _Pragma("unroll")
 #else
@@ -710,20 +712,24 @@ struct PblProfile {
     const double r = 1.0 - (zm - h_inner) / (h - h_inner);
     return (zm / h_inner) * (r * r);
   }
-  MP_HD double k_m(int k) const {
+  MP_HD double k_m_at(int k, double z_half_k) const {
     if (k == 0) return 0.0;
-    const double zm = z_half[k * sz] - z_surf;
+    const double zm = z_half_k - z_surf;
     if (zm < h_inner) return mo_diff_m(mo, dp, zm, u_star, b_star);
     if (zm < h) return k_m_ref * shape(zm);
     return 0.0;
   }
-  MP_HD double k_t(int k) const {
+  MP_HD double k_t_at(int k, double z_half_k) const {
     if (k == 0) return 0.0;
-    const double zm = z_half[k * sz] - z_surf;
+    const double zm = z_half_k - z_surf;
     if (zm < h_inner) return mo_diff_t(mo, dp, zm, u_star, b_star);
     if (zm < h) return k_t_ref * shape(zm);
     return 0.0;
   }
+  MP_HD double k_m(int k) const { return k_m_at(k, z_half[k * sz]); }
+  MP_HD double k_t(int k) const { return k_t_at(k, z_half[k * sz]); }
+  struct Km { const PblProfile &p; MP_HD double raw(int k) const { return p.z_half[k * p.sz]; } MP_HD double eval(int k, double z) const { return p.k_m_at(k, z); } };
+  struct Kt { const PblProfile &p; MP_HD double raw(int k) const { return p.z_half[k * p.sz]; } MP_HD double eval(int k, double z) const { return p.k_t_at(k, z); } };
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -741,6 +747,13 @@ struct VdiffSurf { double dtmass, dflux_t, delta_t, dflux_q, delta_q, delta_u, d
 struct VdiffWork { double *e, *f1, *f2; int sw; };
 
 namespace vd {
+// A diffusivity profile is handed to the sweeps in two steps, raw(k) = whatever has to come from memory for interface k and
+// eval(k, raw) = the diffusivity from it, so that a chunk's loads are issued together and the (branchy) evaluation follows.
+struct TableDiff {            // diffusivities already tabulated, tab[k * s]
+  const double *tab; int s;
+  MP_HD double raw(int k) const { return tab[k * s]; }
+  MP_HD double eval(int, double v) const { return v; }
+};
 // diff_surface (:882-910)
 MP_HD void diff_surface(double mu_delt, double nu, double e_n1, double f_delt_n1, double dflux_datmos, double &flux, double factor,
                         double &delta_xi) {
@@ -759,22 +772,27 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
   double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
   double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = p_half[0];
   for (int k0 = 0; k0 < L; k0 += MP_U) {
-    double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U];
+    double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U], zr[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // everything level k0+i needs from memory: its own tendencies, the fields of the level below
       const int k = (k0 + i < L) ? k0 + i : L - 1, kn = (k + 1 < L) ? k + 1 : L - 1;
       phn[i] = p_half[(k + 1) * sp]; tn[i] = t[kn * s]; zn[i] = z_full[kn * sp]; x1n[i] = x1(kn); x2n[i] = x2(kn);
-      dd1[i] = d1(k); dd2[i] = d2(k); df[i] = diff(kn);
+      dd1[i] = d1(k); dd2[i] = d2(k); zr[i] = diff.raw(kn);
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {       // the diffusivities from what was loaded (branches, but no memory access behind them)
+      const int k = (k0 + i < L) ? k0 + i : L - 1, kn = (k + 1 < L) ? k + 1 : L - 1;
+      df[i] = diff.eval(kn, zr[i]);
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 + i;
       if (k < L) {
         const double ph_n = phn[i];
-        const double mu = GRAV / (ph_n - ph_k);                                       // compute_mu
+        const double mu = GRAV / (ph_n - ph_k);                       // compute_mu
         double nu_n = 0.0, e1, e2, fl1_n = 0.0, fl2_n = 0.0;
         if (k < L - 1) {
-          const double rho_half = 2.0 * ph_n / (RDGAS * (tn[i] + t_k));               // compute_nu, no virtual temperature
+          const double rho_half = 2.0 * ph_n / (RDGAS * (tn[i] + t_k));   // compute_nu, no virtual temperature
           nu_n = rho_half * df[i] / (z_k - zn[i]);
           fl1_n = nu_n * (x1n[i] - x1_k); fl2_n = nu_n * (x2n[i] - x2_k);             // explicit_tend
           e1 = dd1[i] + mu * (fl1_n - fl1_k); e2 = dd2[i] + mu * (fl2_n - fl2_k);

@@ -90,9 +90,9 @@ void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u
     VdiffWork w{we.data(), wf1.data(), wf2.data(), 1};
     VdiffSurf S;
     double tu = flux_u[c], tv = flux_v[c];
-    vert_diff_momentum(L, delt, u + c, v + c, t + c, ncol, [&](int k) { return diff_m[k * ncol + c]; }, p_half + c, z_full + c, ncol, tu, tv,
+    vert_diff_momentum(L, delt, u + c, v + c, t + c, ncol, vd::TableDiff{diff_m + c, ncol}, p_half + c, z_full + c, ncol, tu, tv,
                        dtau_du[c], dtau_dv[c], dt_u + c, dt_v + c, dt_t + c, ncol, diss_heat + c, ncol, w, S);
-    vert_diff_heat_down(L, delt, t + c, q + c, ncol, [&](int k) { return diff_t[k * ncol + c]; }, p_half + c, z_full + c, ncol, dt_t + c,
+    vert_diff_heat_down(L, delt, t + c, q + c, ncol, vd::TableDiff{diff_t + c, ncol}, p_half + c, z_full + c, ncol, dt_t + c,
                         dt_q + c, ncol, w, S);
     const double a[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
     for (int i = 0; i < 7; ++i) surf[c * 7 + i] = a[i];

@@ -1,0 +1,25 @@
+"""Phase times of k_moist_physics from the MOIST_TIMING builds (tools/build_variant.sh mtP "-DMOIST_TIMING=P" moist, P = 1, 2, 3): lane i of
+every wavefront stores the wall_clock64 ticks (10 ns) between marks i and i+1 of phase P in the precipitation field (moist.hip, MT macros)."""
+import os, sys, subprocess
+sys.path.insert(0, '/root/repo')
+MARKS = {1: ["qe_moist_convection", "lscale_cond"],
+         2: ["gray_rad_down", "surface_flux", "zero + gray_rad_up", "rayleigh sponge"],
+         3: ["dt_tg sum", "pbl_depth", "pbl profile + vert_diff_momentum", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
+if len(sys.argv) > 1:
+    import numpy as np
+    from isca_amd import dyncore
+    ph = int(sys.argv[1])
+    cfg = dyncore.default_config("T85", num_levels=40, physics=1, dt_atmos=300.0, initial_sphum=2e-6, robert_coeff=0.03, scale_heights=11.0, exponent=7.0)
+    dc = dyncore.DynCore(cfg); dc.cold_start(); dc.step(400)
+    p = dc.get("precip").reshape(-1, 8) * 0.01        # us; column c holds mark interval c % 8
+    tot = 0.0
+    for i, nm in enumerate(MARKS[ph]):
+        print(f"  phase {ph}  {nm:36s} mean {p[:, i].mean():7.1f} us   max {p[:, i].max():7.1f}")
+        tot += p[:, i].mean()
+    print(f"  phase {ph}  total {tot:.1f} us")
+else:
+    only = os.environ.get('MOIST_PHASES')
+    for v in (1, 2, 3):
+        if only and str(v) not in only.split(','): continue
+        env = dict(os.environ, ISCA_DYN_LIB=f"/root/repo/isca_amd/lib/libisca_dyn_mt{v}.so")
+        subprocess.run([sys.executable, __file__, str(v)], env=env)
