@@ -80,11 +80,15 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     double precip = rain / delta_t;
     // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
     double rain_ls;
-    moist::lscale_cond(a.sat, L, [&](int k) { return dtT[k * s] + tp[k * s]; }, [&](int k) { return dtq[k * s] + qp[k * s]; }, a.pf_p + c,
-                       a.ph_p + c, s,
-                       [&](int k, double td, double qd) {
-                         dtT[k * s] = dtT[k * s] / delta_t + td / delta_t;
-                         dtq[k * s] = dtq[k * s] / delta_t + qd / delta_t;
+    moist::lscale_cond(a.sat, L,
+                       [&](int k, double &t, double &q, double &ct, double &cq) {      // the convection's deltas are read once, here
+                         ct = dtT[k * s]; cq = dtq[k * s];
+                         t = ct + tp[k * s]; q = cq + qp[k * s];
+                       },
+                       a.pf_p + c, a.ph_p + c, s,
+                       [&](int k, double td, double qd, double ct, double cq) {
+                         dtT[k * s] = ct / delta_t + td / delta_t;
+                         dtq[k * s] = cq / delta_t + qd / delta_t;
                        },
                        rain_ls);
     precip = precip + rain_ls / delta_t;

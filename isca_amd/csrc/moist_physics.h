@@ -48,14 +48,36 @@ struct SatTable {
 };
 MP_HD void lookup_es_des(const SatTable &t, double temp, double &es, double &des) {
   const double tmp = temp - t.tmin;
-  int ind = (int)(t.dtinv * (tmp + t.teps));
-  if (ind < 0 || ind >= t.n) {                   // 'table overflow' is FATAL in the reference; NaN marks it here
-    es = des = NAN;
-    return;
-  }
+  const int ind = (int)(t.dtinv * (tmp + t.teps));
+  // 'table overflow' is FATAL in the reference; NaN marks it here.  No branch in front of the table reads (clamped index, select
+  // afterwards): behind one, the reads of several lookups in an unrolled loop could not be issued together.
+  const bool overflow = ind < 0 || ind >= t.n;
+  const int ic = overflow ? 0 : ind;
+  const double t0 = t.tab[ic], t1 = t.dtab[ic], t2 = t.d2tab[ic];
   const double del = tmp - t.dtres * (double)ind;
-  es = t.tab[ind] + del * (t.dtab[ind] + del * t.d2tab[ind]);
-  des = t.dtab[ind] + 2. * del * t.d2tab[ind];
+  es = overflow ? NAN : t0 + del * (t1 + del * t2);
+  des = overflow ? NAN : t1 + 2. * del * t2;
+}
+// the same for N temperatures at once, in three passes (indices, table reads, interpolation): written per value the compiler keeps each
+// lookup's reads behind the previous lookup's wait, and a chunk of N levels costs N memory round trips instead of one
+template <int N>
+MP_HD void lookup_es_des_n(const SatTable &t, const double (&temp)[N], double (&es)[N], double (&des)[N]) {
+  int ic[N]; double del[N], t0[N], t1[N], t2[N]; bool overflow[N];
+  MP_UNROLL_ALL
+  for (int i = 0; i < N; ++i) {
+    const double tmp = temp[i] - t.tmin;
+    const int ind = (int)(t.dtinv * (tmp + t.teps));
+    overflow[i] = ind < 0 || ind >= t.n;
+    ic[i] = overflow[i] ? 0 : ind;
+    del[i] = tmp - t.dtres * (double)ind;
+  }
+  MP_UNROLL_ALL
+  for (int i = 0; i < N; ++i) { t0[i] = t.tab[ic[i]]; t1[i] = t.dtab[ic[i]]; t2[i] = t.d2tab[ic[i]]; }
+  MP_UNROLL_ALL
+  for (int i = 0; i < N; ++i) {
+    es[i] = overflow[i] ? NAN : t0[i] + del[i] * (t1[i] + del[i] * t2[i]);
+    des[i] = overflow[i] ? NAN : t1[i] + 2. * del[i] * t2[i];
+  }
 }
 MP_HD double lookup_es(const SatTable &t, double temp) { double e, d; lookup_es_des(t, temp, e, d); return e; }
 // compute_qs (sat_vapor_pres_k.F90:457-540) without q: qs = eps es / (p - (1-eps) es), dqs/dT = eps p des / denom^2
@@ -66,26 +88,38 @@ MP_HD void compute_qs(const SatTable &t, double temp, double press, double &qs, 
   qs = (denom > 0.0) ? EPSILO * es / denom : EPSILO;
   dqsdT = EPSILO * press * des / (denom * denom);
 }
+template <int N>
+MP_HD void compute_qs_n(const SatTable &t, const double (&temp)[N], const double (&press)[N], double (&qs)[N], double (&dqsdT)[N]) {
+  double es[N], des[N];
+  lookup_es_des_n<N>(t, temp, es, des);
+  MP_UNROLL_ALL
+  for (int i = 0; i < N; ++i) {
+    const double denom = press[i] - (1.0 - EPSILO) * es[i];
+    qs[i] = (denom > 0.0) ? EPSILO * es[i] / denom : EPSILO;
+    dqsdT[i] = EPSILO * press[i] * des[i] / (denom * denom);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // lscale_cond (atmos_param/lscale_cond/lscale_cond.F90:79-212) with do_simple, do_evap, hc = 1:
 // saturation adjustment where q > qsat, re-evaporation of the falling precipitation in the layers below
 // (precip_evap :215-252); returns the deltas (not rates) and the rain in kg/m2.
 // ------------------------------------------------------------------------------------------------
-template <class TIN, class QIN, class OUT>
-MP_HD void lscale_cond(const SatTable &st, int L, TIN tin, QIN qin, const double *pfull, const double *phalf, int s, OUT out, double &rain) {
+// load(k, t, q, x, y): temperature and humidity of level k plus two values of the caller's that come from memory and are handed on
+// to out(k, t_delta, q_delta, x, y) - so that everything a chunk of levels reads is requested before anything is stored.
+template <class LOAD, class OUT>
+MP_HD void lscale_cond(const SatTable &st, int L, LOAD load, const double *pfull, const double *phalf, int s, OUT out, double &rain) {
   const double hlcp = HLV / CP_AIR;
   double exq = 0.0, precip = 0.0;
   double ph_k = phalf[0];
   for (int k0 = 0; k0 < L; k0 += MP_U) {
-    double tk[MP_U], qk[MP_U], pf[MP_U], phn[MP_U], qsat[MP_U], dqsat[MP_U], tdo[MP_U], qdo[MP_U];
+    double tk[MP_U], qk[MP_U], pf[MP_U], phn[MP_U], qsat[MP_U], dqsat[MP_U], tdo[MP_U], qdo[MP_U], ax[MP_U], ay[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < L) ? k0 + i : L - 1;
-      tk[i] = tin(k); qk[i] = qin(k); pf[i] = pfull[k * s]; phn[i] = phalf[(k + 1) * s];
+      load(k, tk[i], qk[i], ax[i], ay[i]); pf[i] = pfull[k * s]; phn[i] = phalf[(k + 1) * s];
     }
-    MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) compute_qs(st, tk[i], pf[i], qsat[i], dqsat[i]);
+    compute_qs_n<MP_U>(st, tk, pf, qsat, dqsat);
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       double qd = 0.0, td = 0.0;
@@ -111,7 +145,7 @@ MP_HD void lscale_cond(const SatTable &st, int L, TIN tin, QIN qin, const double
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i)
-      if (k0 + i < L) out(k0 + i, tdo[i], qdo[i]);
+      if (k0 + i < L) out(k0 + i, tdo[i], qdo[i], ax[i], ay[i]);
   }
   rain = fmax(precip, 0.0);
 }
@@ -472,8 +506,9 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     to_model(1, ks);
   }
   rain = Pq;
-  MP_UNROLL
-  for (int k = 1; k <= L; ++k) {
+  MP_UNROLL_ALL
+  for (int k = 1; k <= LMAX; ++k) {          // fixed trip count: the reads of the work arrays are issued together
+    if (k > L) break;
     deltaT[(k - 1) * so] = c.dT[k]; deltaq[(k - 1) * so] = c.dq[k];
     if (Tref_out) Tref_out[(k - 1) * so] = c.Tref[k];
     if (qref_out) qref_out[(k - 1) * so] = c.qref[k];

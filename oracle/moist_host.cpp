@@ -34,8 +34,8 @@ void mh_lookup_es_des(int n, const double *t, double *es, double *des) {
 void mh_lscale_cond(int L, int ncol, const double *tin, const double *qin, const double *pfull, const double *phalf, double *tdel,
                     double *qdel, double *rain) {
   const SatTable st = sat();
-  for (int c = 0; c < ncol; ++c) lscale_cond(st, L, [&](int k) { return tin[k * ncol + c]; }, [&](int k) { return qin[k * ncol + c]; }, pfull + c, phalf + c, ncol,
-                                             [&](int k, double td, double qd) { tdel[k * ncol + c] = td; qdel[k * ncol + c] = qd; }, rain[c]);
+  for (int c = 0; c < ncol; ++c) lscale_cond(st, L, [&](int k, double &t, double &q, double &, double &) { t = tin[k * ncol + c]; q = qin[k * ncol + c]; }, pfull + c, phalf + c, ncol,
+                                             [&](int k, double td, double qd, double, double) { tdel[k * ncol + c] = td; qdel[k * ncol + c] = qd; }, rain[c]);
 }
 void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const double *albedo, const double *t_surf, const double *t,
                  const double *p_half, double *net_sw, double *lw_down_surf, double *tdt) {

@@ -5,9 +5,10 @@ s_waitcnt vmcnt / barriers between them, plus register counts.  Used to spot ser
 usage: python tools/isa_summary.py [substring-of-kernel-name ...]"""
 import re, subprocess, sys, os, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
-src = os.path.join(HERE, "..", "isca_amd", "csrc", "kernels.hip")
-out = os.path.join(tempfile.gettempdir(), "isca_kernels.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", out],
+unit = os.environ.get("ISA_UNIT", "kernels")                    # ISA_UNIT=moist: moist.hip (built like the library: -ffp-contract=off)
+src = os.path.join(HERE, "..", "isca_amd", "csrc", unit + ".hip")
+out = os.path.join(tempfile.gettempdir(), f"isca_{unit}.s")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"] + (["-ffp-contract=off"] if unit == "moist" else []) + [src, "-o", out],
                check=True, stderr=subprocess.DEVNULL)
 text = open(out).read()
 meta = {m.group(1): (m.group(2), m.group(3)) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size: (\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", text)}
