@@ -63,6 +63,9 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   const int sw = LDSW ? 64 : a.ncol;
   double *w0 = LDSW ? lds_work + lane : a.work + c;
   double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
+  // the radiation / sponge wavefront keeps its two level arrays and the scalars it hands over in the global work area, so that LDS
+  // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
+  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
@@ -74,8 +77,10 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     // ---- convection (:862-880): deltas over the step, then rates
     double rain, cape, cin;
     int flag, klzb, klcl;
+    double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
+    const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
     moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
-                                     nullptr, nullptr, s);
+                                     nullptr, nullptr, s, pc);
     MT(1, 1)
     double precip = rain / delta_t;
     // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
@@ -100,23 +105,23 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
     t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
-    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, net_sw, lw_down_surf);
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, r0, r1, s, insolation, sw_tau_0, net_sw, lw_down_surf);
     MT(2, 1)
     const size_t low = (size_t)(L - 1) * s;
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
     MT(2, 2)
     for (int k = 0; k < L; ++k) { w2[k * sw] = 0.0; dtu[k * s] = 0.0; dtv[k * s] = 0.0; }
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, w0, w1, sw, insolation, sw_tau_0, w2, sw);
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, s, insolation, sw_tau_0, w2, sw);
     MT(2, 3)
     // ---- Rayleigh sponge (:1228-1237): momentum tendencies in place, its heating into work array 1 (radiation is done with it)
-    for (int k = 0; k < nray; ++k) w1[k * sw] = 0.0;
-    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, w1, sw);
+    for (int k = 0; k < nray; ++k) r1[(size_t)k * s] = 0.0;
+    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r1, s);
     if (nroles == 2) {
       const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
                                   sf.dedq_atm, sf.dtaudu_atm, sf.dtaudv_atm, sf.u_star, sf.b_star, t_surf, net_sw, lw_down_surf, 0., 0., 0.};
 #pragma unroll
-      for (int i = 0; i < MOIST_NX; ++i) w0[i * sw] = x[i];
+      for (int i = 0; i < MOIST_NX; ++i) r0[(size_t)i * s] = x[i];
     }
   }
   if (role == nroles - 1) { MT(2, 4) MT_STORE(2) }
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     if (role != 0) return;
     double x[MOIST_NX];
 #pragma unroll
-    for (int i = 0; i < MOIST_NX; ++i) x[i] = w0[i * sw];
+    for (int i = 0; i < MOIST_NX; ++i) x[i] = r0[(size_t)i * s];
     sf.flux_t = x[0]; sf.flux_q = x[1]; sf.flux_r = x[2]; sf.flux_u = x[3]; sf.flux_v = x[4]; sf.dhdt_surf = x[5]; sf.dedt_surf = x[6];
     sf.drdt_surf = x[7]; sf.dhdt_atm = x[8]; sf.dedq_atm = x[9]; sf.dtaudu_atm = x[10]; sf.dtaudv_atm = x[11]; sf.u_star = x[12];
     sf.b_star = x[13]; t_surf = x[14]; net_sw = x[15]; lw_down_surf = x[16];
@@ -133,15 +138,18 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   MT(3, 0)
   // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order
   for (int k0 = 0; k0 < L; k0 += MP_U) {         // loads of a chunk first: a store to dtT may alias the next level's load for all the compiler knows
-    double t[MP_U];
+    double t[MP_U], sp[MP_U];
 #pragma unroll
-    for (int i = 0; i < MP_U; ++i) t[i] = dtT[(size_t)min(k0 + i, L - 1) * s];
+    for (int i = 0; i < MP_U; ++i) {
+      t[i] = dtT[(size_t)min(k0 + i, L - 1) * s];
+      sp[i] = r1[(size_t)min(k0 + i, max(nray - 1, 0)) * s];
+    }
 #pragma unroll
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 + i;
       if (k < L) {
         double x = t[i] + w2[k * sw];
-        if (k < nray) x = x + w1[k * sw];
+        if (k < nray) x = x + sp[i];
         dtT[(size_t)k * s] = x;
       }
     }

@@ -262,15 +262,23 @@ MP_HD double qe_get_lcl_temp(const QeParams &p, double value) {
 }
 
 template <int LMAX>
-struct QeColumn {            // work arrays of one column, 1-based
-  double Tp[LMAX + 2], rp[LMAX + 2], Tv[LMAX + 2], Tref[LMAX + 2], qref[LMAX + 2], dT[LMAX + 2], dq[LMAX + 2];
+struct QeColumn {            // work arrays of one column, 1-based (the parcel's Tp, rp: see QeParcel)
+  double Tv[LMAX + 2], Tref[LMAX + 2], qref[LMAX + 2], dT[LMAX + 2], dq[LMAX + 2];
+};
+// The parcel's temperature and mixing ratio, written level by level in the ascent and read back by the reference profiles, live in
+// caller storage: wTp[(k-1)*sw], wrp[(k-1)*sw] for level k = 1..L (LDS on the device; in thread-private arrays every store of the
+// ascent is a memory operation that the loads of the next level then queue behind).
+struct QeParcel {
+  double *wTp, *wrp; int sw;
+  MP_HD double &Tp(int k) const { return wTp[(k - 1) * sw]; }
+  MP_HD double &rp(int k) const { return wrp[(k - 1) * sw]; }
 };
 
 template <int LMAX>
 MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, double dt, const double *Tin_, const double *qin_,
                                const double *p_full_, const double *p_half_, int s, double *deltaT, double *deltaq, double &rain,
                                double &cape_out, double &cin_out, int &convflag, int &kLZB_out, int &kLCL_out, double *Tref_out,
-                               double *qref_out, int so) {
+                               double *qref_out, int so, const QeParcel &pc) {
   QeColumn<LMAX> c;
   auto Tin = [&](int k) { return Tin_[(k - 1) * s]; };
   auto qin = [&](int k) { return qin_[(k - 1) * s]; };
@@ -281,7 +289,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   auto set_nocape = [&](double &pLZB, int &kLZB, int &kLFC, double &CIN) {  // set_values_if_nocape (:1014-1030)
     pLZB = pf(1); kLZB = 0; kLFC = 0; CIN = 0.;
     MP_UNROLL
-    for (int k = 1; k <= L; ++k) { c.Tp[k] = Tin(k); c.rp[k] = rin(k); }
+    for (int k = 1; k <= L; ++k) { pc.Tp(k) = Tin(k); pc.rp(k) = rin(k); }
   };
   auto to_model = [&](int k1, int k2) {                                   // set_profiles_to_full_model_values (:1034-1047)
     MP_UNROLL
@@ -294,7 +302,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 + i;
-      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); c.dT[k] = 0.; c.dq[k] = 0.; c.Tp[k] = tt[i]; c.rp[k] = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }
+      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); c.dT[k] = 0.; c.dq[k] = 0.; pc.Tp(k) = tt[i]; pc.rp(k) = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }
     }
   }
   // ---- CAPE_calculation (:383-446)
@@ -307,8 +315,8 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   // ---- CAPE_below_LCL (:450-583)
   if (saturated) {
     pLCL = pf(ks); kLCL = ks;
-    c.Tp[ks] = T0 + (r0 - rs) / ((CP_AIR / (HLV + QE_SMALL)) + (HLV * rs) / RVGAS / (T0 * T0));
-    c.rp[ks] = qe_mixing_ratio(lookup_es(st, c.Tp[ks]), pf(ks));
+    pc.Tp(ks) = T0 + (r0 - rs) / ((CP_AIR / (HLV + QE_SMALL)) + (HLV * rs) / RVGAS / (T0 * T0));
+    pc.rp(ks) = qe_mixing_ratio(lookup_es(st, pc.Tp(ks)), pf(ks));
   } else {
     const double theta0 = Tin(ks) * pow(QE_PREF / pf(ks), KAPPA);
     double TLCL;
@@ -332,8 +340,8 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
           const int kn = (k > 1) ? k - 1 : 1;
           const double pfn = pf(kn), phn = ph(kn), tvn = c.Tv[kn];
           const double Tpk = theta0 * pow(pfk / QE_PREF, KAPPA);
-          c.Tp[k] = Tpk;
-          c.rp[k] = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
+          pc.Tp(k) = Tpk;
+          pc.rp(k) = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
           CIN = CIN + RDGAS * (tvk - qe_virtual_temp(Tpk, r0)) * log(ph1 / phk);
           k = k - 1;
           pfk = pfn; ph1 = phk; phk = phn; tvk = tvn;
@@ -344,22 +352,22 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         double a = KAPPA * TLCL + (HLV / CP_AIR) * r0;
         double b = (HLV * HLV) * r0 / (CP_AIR * RVGAS * (TLCL * TLCL));
         double dtdlnp = a / (1.0 + b);
-        c.Tp[kLCL] = TLCL + dtdlnp * log(pf(kLCL) / pLCL) / 2;
-        if ((c.Tp[kLCL] < P.Tmin) && nocape) {
+        pc.Tp(kLCL) = TLCL + dtdlnp * log(pf(kLCL) / pLCL) / 2;
+        if ((pc.Tp(kLCL) < P.Tmin) && nocape) {
           skip = true;
           set_nocape(pLZB, kLZB, kLFC, CIN);
         } else {
-          c.rp[kLCL] = qe_mixing_ratio(lookup_es(st, c.Tp[kLCL]), (pf(kLCL) + pLCL) / 2);
-          a = KAPPA * c.Tp[kLCL] + (HLV / CP_AIR) * c.rp[kLCL];
-          b = (HLV * HLV) * c.rp[kLCL] / (CP_AIR * RVGAS * (c.Tp[kLCL] * c.Tp[kLCL]));
+          pc.rp(kLCL) = qe_mixing_ratio(lookup_es(st, pc.Tp(kLCL)), (pf(kLCL) + pLCL) / 2);
+          a = KAPPA * pc.Tp(kLCL) + (HLV / CP_AIR) * pc.rp(kLCL);
+          b = (HLV * HLV) * pc.rp(kLCL) / (CP_AIR * RVGAS * (pc.Tp(kLCL) * pc.Tp(kLCL)));
           dtdlnp = a / (1.0 + b);
-          c.Tp[kLCL] = TLCL + dtdlnp * log(pf(kLCL) / pLCL);
-          if ((c.Tp[kLCL] < P.Tmin) && nocape) {
+          pc.Tp(kLCL) = TLCL + dtdlnp * log(pf(kLCL) / pLCL);
+          if ((pc.Tp(kLCL) < P.Tmin) && nocape) {
             skip = true;
             set_nocape(pLZB, kLZB, kLFC, CIN);
           } else {
-            c.rp[kLCL] = qe_mixing_ratio(lookup_es(st, c.Tp[kLCL]), pf(kLCL));
-            const double tvp = qe_virtual_temp(c.Tp[kLCL], c.rp[kLCL]);
+            pc.rp(kLCL) = qe_mixing_ratio(lookup_es(st, pc.Tp(kLCL)), pf(kLCL));
+            const double tvp = qe_virtual_temp(pc.Tp(kLCL), pc.rp(kLCL));
             if ((tvp < c.Tv[kLCL]) && nocape) {
               CIN = CIN + RDGAS * (c.Tv[kLCL] - tvp) * log(ph(kLCL + 1) / ph(kLCL));
             } else {
@@ -378,7 +386,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     if (kLCL - 1 >= 1) {
       // the parcel's previous level stays in registers; pressures and Tv of the next level are requested one iteration ahead, so their
       // latency hides behind this level's log / table-lookup chain
-      double Tp1 = c.Tp[kLCL], rp1 = c.rp[kLCL];
+      double Tp1 = pc.Tp(kLCL), rp1 = pc.rp(kLCL);
       double pf1 = pf(kLCL), pfk = pf(kLCL - 1), ph1 = ph(kLCL), phk = ph(kLCL - 1), tvk = c.Tv[kLCL - 1];
       for (int k = kLCL - 1; k >= 1; --k) {
         const int kn = (k > 1) ? k - 1 : 1;
@@ -387,17 +395,17 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         double b = (HLV * HLV) * rp1 / (CP_AIR * RVGAS * (Tp1 * Tp1));
         double dtdlnp = a / (1.0 + b);
         double Tpk = Tp1 + dtdlnp * log(pfk / pf1) / 2;
-        c.Tp[k] = Tpk;
+        pc.Tp(k) = Tpk;
         if ((Tpk < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
         double rpk = qe_mixing_ratio(lookup_es(st, Tpk), (pfk + pf1) / 2);
         a = KAPPA * Tpk + (HLV / CP_AIR) * rpk;
         b = (HLV * HLV) * rpk / (CP_AIR * RVGAS * (Tpk * Tpk));
         dtdlnp = a / (1.0 + b);
         Tpk = Tp1 + dtdlnp * log(pfk / pf1);
-        c.Tp[k] = Tpk;
-        if ((Tpk < P.Tmin) && nocape) { c.rp[k] = rpk; set_nocape(pLZB, kLZB, kLFC, CIN); break; }
+        pc.Tp(k) = Tpk;
+        if ((Tpk < P.Tmin) && nocape) { pc.rp(k) = rpk; set_nocape(pLZB, kLZB, kLFC, CIN); break; }
         rpk = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
-        c.rp[k] = rpk;
+        pc.rp(k) = rpk;
         const double tvp = qe_virtual_temp(Tpk, rpk);
         if ((tvp < tvk) && nocape) {
           CIN = CIN + RDGAS * (tvk - tvp) * log(ph1 / phk);
@@ -429,7 +437,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       MP_UNROLL_ALL
       for (int i = 0; i < MP_U; ++i) {
         const int k = (k0 + i <= L) ? k0 + i : L;
-        tp[i] = c.Tp[k]; rp[i] = c.rp[k]; pfv[i] = pf(k); qi[i] = qin(k); ti[i] = Tin(k); ph0[i] = ph(k); ph1[i] = ph(k + 1);
+        tp[i] = pc.Tp(k); rp[i] = pc.rp(k); pfv[i] = pf(k); qi[i] = qin(k); ti[i] = Tin(k); ph0[i] = ph(k); ph1[i] = ph(k + 1);
       }
       MP_UNROLL_ALL
       for (int i = 0; i < MP_U; ++i) {
@@ -441,7 +449,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
             const double eref = P.rhbm * pfv[i] * rp[i] / (rp[i] + (RDGAS / RVGAS));
             const double r = qe_mixing_ratio(eref, pfv[i]);
             qref = r / (1 + r);
-            c.rp[k] = r; c.qref[k] = qref;
+            pc.rp(k) = r; c.qref[k] = qref;
           }
           if (k <= kmodel) { tref = ti[i]; qref = qi[i]; c.Tref[k] = tref; c.qref[k] = qref; c.dT[k] = 0.; c.dq[k] = 0.; }
           if (k >= kb) {

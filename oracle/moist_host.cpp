@@ -19,10 +19,11 @@ void mh_qe_moist_convection(int L, int ncol, double dt, const double *tin, const
                             double *tref, double *qref) {
   const SatTable st = sat();
   const QeParams P = qe();
+  std::vector<double> wtp(L), wrp(L);
   for (int c = 0; c < ncol; ++c) {
     int f, kz, kl;
     qe_moist_convection<64>(st, P, L, dt, tin + c, qin + c, pfull + c, phalf + c, ncol, dT + c, dq + c, rain[c], cape[c], cin[c], f, kz, kl,
-                            tref + c, qref + c, ncol);
+                            tref + c, qref + c, ncol, QeParcel{wtp.data(), wrp.data(), 1});
     flag[c] = f; klzb[c] = kz; klcl[c] = kl;
   }
 }
