@@ -80,14 +80,7 @@ MP_HD void lookup_es_des_n(const SatTable &t, const double (&temp)[N], double (&
   }
 }
 MP_HD double lookup_es(const SatTable &t, double temp) { double e, d; lookup_es_des(t, temp, e, d); return e; }
-// compute_qs (sat_vapor_pres_k.F90:457-540) without q: qs = eps es / (p - (1-eps) es), dqs/dT = eps p des / denom^2
-MP_HD void compute_qs(const SatTable &t, double temp, double press, double &qs, double &dqsdT) {
-  double es, des;
-  lookup_es_des(t, temp, es, des);
-  const double denom = press - (1.0 - EPSILO) * es;
-  qs = (denom > 0.0) ? EPSILO * es / denom : EPSILO;
-  dqsdT = EPSILO * press * des / (denom * denom);
-}
+// compute_qs (sat_vapor_pres_k.F90:457-540) without q: qs = eps es / (p - (1-eps) es), dqs/dT = eps p des / denom^2; N values at once
 template <int N>
 MP_HD void compute_qs_n(const SatTable &t, const double (&temp)[N], const double (&press)[N], double (&qs)[N], double (&dqsdT)[N]) {
   double es[N], des[N];
