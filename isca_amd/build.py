@@ -13,6 +13,7 @@ UNITS = [  # (source, extra flags)
     ("tables.cpp", ["-ffp-contract=off"]),      # host tables: reproduce the reference's non-FMA fp64 results
     ("comm.cpp", []),                           # RCCL bound with dlopen (no link-time dependency)
     ("kernels.hip", []),
+    ("legendre.hip", []),
     ("moist.hip", ["-ffp-contract=off"]),       # moist column physics: no contraction, like the reference build (regime tests)
     ("api.hip", []),
 ]

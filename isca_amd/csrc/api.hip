@@ -302,6 +302,11 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       }
       d.pw_fwd = dupload(h, pw);
       d.p_inv = dupload(h, pi);
+      if (legendre_mfma_ok(g, cfg->legendre_impl)) {
+        std::vector<double> ff, fi, sc;
+        build_legendre_fragments(g, T, h->h_m_local, ff, fi, sc);
+        d.leg_fwd_frag = dupload(h, ff); d.leg_inv_frag = dupload(h, fi); d.leg_scoef = dupload(h, sc);
+      }
     }
     {  // coefficient tables per local m
       const std::vector<double> *src[11] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
@@ -424,8 +429,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     build_field_lists(h);
     h->Ci = 2 * (7 * g.L + 3);
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
-    h->fuse_synth = (cfg->legendre_impl == 0) && (g.Jl % 16 == 0) && ((g.Jl & (g.Jl - 1)) == 0) &&
-                    ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
+    h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl);
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -486,6 +490,11 @@ static void dev_vd_from_uv(isca_dyn *h, double *u, double *v, double *vor, doubl
 // all grid fields at time level tl (+ vorg, divg, gradients) from the spectral state at tl
 static void synthesize_level(isca_dyn *h, int tl) {
   FieldList fl = inverse_list(h, tl);
+  if (h->fuse_synth) {     // the step's own synthesis kernel: a restarted run then continues bit for bit
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, 2 * fl.ncol, 0, h->cfg.legendre_impl, h->stream, tl); }
+    { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
+    return;
+  }
   { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, tl, h->stream); }
   run_inverse(h, fl, 0);
 }

@@ -50,9 +50,13 @@ struct Dev {
   int *m_of_slot;            // [P*Ml]   global m of (rank q, local slot), -1 if padding
   int *slot_of_m;            // [M1]     q*Ml + ml
   int *m_local;              // [Ml]     global m of my slots
-  // Legendre tables for my m slots, MFMA-friendly: parity-split, n-half index padded to NHP
+  // Legendre tables for my m slots, parity-split, n-half index padded to NHP (plain-FMA check kernels)
   double *pw_fwd;            // [Ml][2][Jh][NHP]   P(m,n,j')*w(j'), n = 2*nh+par   (analysis A operand)
   double *p_inv;             // [Ml][2][NHP][Jh]   P(m,n,j')                       (synthesis A operand)
+  // the same tables in MFMA fragment order (legendre.hip) and the coefficient table of the fused synthesis
+  double *leg_fwd_frag;      // [Ml][Jh/4][2][NHP/16][64]
+  double *leg_inv_frag;      // [Ml][2][NHP/4][Jh/16][64]
+  double *leg_scoef;         // [Ml][N1+16][5][4]
   double *coef;              // [9][Ml][N1]: eigen,uvm,uvc,uvp,alpm,alpp,dym,dx,dyp ; [9]=mask ; [10]=damping
   double *pk, *bk, *dpk, *dbk;
   double *wave_mat_t;        // [num_spherical][L(k')][L(k)]  transposed wave matrices

@@ -38,6 +38,10 @@ void launch_sw_tracer_tend(int n, const double *u, const double *v, const double
 // ---- transforms
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s);
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s);
+// legendre.hip: true when the MFMA kernels cover this geometry; fragment-ordered tables built at create
+bool legendre_mfma_ok(const Geom &g, int impl);
+void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<int> &m_local, std::vector<double> &fwd,
+                              std::vector<double> &inv, std::vector<double> &scoef);
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s);
 // fused_tl >= 0: build the inverse-batch columns on the fly from the spectral state at that time level (S unused)
 void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl = -1);

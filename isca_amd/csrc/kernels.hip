@@ -305,366 +305,6 @@ void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const 
 }
 
 // =====================================================================================================
-// Legendre transforms (spherical_fourier.F90:177-339) as per-m dense contractions on the FP64 matrix
-// cores: v_mfma_f64_16x16x4_f64, one wavefront per (zonal wavenumber m, 16 columns), hemispheric
-// even/odd folding, triangular loop bounds (rows n < N1-m only unless `full`).
-//   A operand: lane l holds A[row = l&15][k = l>>4];  B: B[k = l>>4][col = l&15]
-//   C/D: lane l, reg r  ->  row = (l>>4) + 4 r, col = l&15
-// =====================================================================================================
-__device__ __forceinline__ size_t frow(const Geom &g, int j, int ml, int C) {   // spectral-side row of latitude j
-  const int p = j / g.Jl, jl = j - p * g.Jl;
-  return ((size_t)(p * g.Ml + ml) * g.Jl + jl) * C;
-}
-
-// cooperative copy of a contiguous table slab into LDS, 16 bytes per lane per step (256 threads)
-__device__ __forceinline__ void lds_fill(double *dst, const double *__restrict__ src, int ndoubles) {
-  const double2 *s2 = (const double2 *)src;
-  double2 *d2 = (double2 *)dst;
-  const int n2 = ndoubles >> 1;
-  int i = threadIdx.x;
-  for (; i + 768 < n2; i += 1024) {        // four loads in flight per lane, then the four LDS writes
-    const double2 a = s2[i], b = s2[i + 256], c = s2[i + 512], d = s2[i + 768];
-    d2[i] = a; d2[i + 256] = b; d2[i + 512] = c; d2[i + 768] = d;
-  }
-  for (; i < n2; i += 256) d2[i] = s2[i];
-}
-// spectral-side row offset (in doubles, fits 31 bits) of latitude j for local wavenumber slot ml; Jl = 2^lg
-__device__ __forceinline__ int frow32(int j, int ml, int C, int lg, int Ml) {
-  return ((((j >> lg) * Ml + ml) << lg) | (j & ((1 << lg) - 1))) * C;
-}
-
-// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with its own L2.  All column tiles of one
-// wavenumber share that wavenumber's Legendre table, so they are mapped onto the same XCD: the table then comes
-// from HBM once per XCD instead of once per tile.  T = column tiles (of 4 wavefronts) per wavenumber.
-__device__ __forceinline__ bool leg_block(int Ml, int T, int &ml, int &tile) {
-  const int lin = blockIdx.x, xcd = lin & 7, q = lin >> 3;
-  const int grp = q / T;
-  ml = xcd + 8 * grp;
-  tile = q - grp * T;
-  return ml < Ml;
-}
-static unsigned leg_grid(int Ml, int T) { return (unsigned)(8 * ((Ml + 7) / 8) * T); }
-
-// Analysis (Fourier -> spectral).  Block = 4 wavefronts = 4 column tiles of one wavenumber m; the A operand
-// (P*w of this m, one parity at a time, only the rows the triangle needs) is staged in LDS, the folded
-// B operand lives in registers, so the MFMA loop touches no global memory.  32-bit index arithmetic throughout:
-// these kernels have ~50 MFMAs per wavefront, so address VALU work must stay well below that.
-template <int JH4, bool BOTH>
-__global__ __launch_bounds__(256) void k_leg_fwd_mfma(Geom g, const int *__restrict__ m_local,
-                                                      const double *__restrict__ pw, const double *__restrict__ Fs,
-                                                      double *__restrict__ S, int C, int full, int T) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *As = (double *)smem;                      // [Jh][NHP], one parity at a time
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  int ml, tile_x;
-  if (!leg_block(g.Ml, T, ml, tile_x)) return;
-  const int m = m_local[ml];
-  if (m < 0) return;
-  const int c0 = (tile_x * 4 + wave) * 16;
-  const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
-  const bool cok = c < C;
-  const int lg = g.log2Jl, NHP = g.NHP;
-  double be[JH4], bo[JH4];
-#pragma unroll
-  for (int ks = 0; ks < JH4; ++ks) {
-    const int jp = ks * 4 + kq;
-    double xs = 0., xn = 0.;
-    if (cok) {
-      xs = Fs[frow32(jp, ml, C, lg, g.Ml) + c];
-      xn = Fs[frow32(g.J - 1 - jp, ml, C, lg, g.Ml) + c];
-    }
-    be[ks] = xn + xs;      // x_even = F(north) + F(south)   (:311)
-    bo[ks] = xn - xs;      // x_odd  = F(north) - F(south)   (:312)
-  }
-  const int nlim = full ? g.N1 : g.N1 - m;
-  const int srow = ml * g.N1 * C + c;               // S offset of (ml, n=0, c)
-  if (BOTH) {                                       // both parity tables fit in LDS: one fill, one barrier
-    lds_fill(As, pw + (size_t)(ml * 2) * g.Jh * NHP, 2 * g.Jh * NHP);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    if (!BOTH) {
-      if (par) __syncthreads();                     // everyone done with the even-parity table
-      lds_fill(As, pw + (size_t)(ml * 2 + par) * g.Jh * NHP, g.Jh * NHP);
-      __syncthreads();
-    }
-    const int cnt = (nlim - par + 1) >> 1;
-    const int ntile = (c0 < C) ? (cnt + 15) >> 4 : 0;
-    const double *A = As + (BOTH ? par * g.Jh * NHP : 0) + kq * NHP + cl;
-    for (int tile = 0; tile < ntile; ++tile) {
-      double4_t acc = {0., 0., 0., 0.};
-#pragma unroll
-      for (int ks = 0; ks < JH4; ++ks)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * NHP + tile * 16], par ? bo[ks] : be[ks], acc, 0, 0, 0);
-      const int n0 = 2 * (tile * 16 + kq) + par;    // rows n0 + 8 r
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n0 + 8 * r < g.N1 && cok) S[srow + (n0 + 8 * r) * C] = acc[r];
-    }
-  }
-}
-
-// Synthesis (spectral -> Fourier).  Same blocking; A = P of this m from LDS, B rows preloaded in registers.
-// FUSED: the B operand (inverse-batch columns div, vor, u cos, v cos, T, dT/dx cos, dT/dy cos, ln ps and its two
-// gradients) is generated on the fly from the spectral state (compute_ucos_vcos spherical.F90:409-469,
-// compute_gradient_cos :270-351) instead of being read from a staged work buffer.
-struct SynthSrc { const double *vor, *div, *ts, *lnps, *coef; };
-enum { LC_UVC = 0, LC_UVM, LC_UVP, LC_DX, LC_DYM, LC_DYP, LC_ROWS, LC_ONE = LC_ROWS };   // LC_ONE: coefficient 1, no table row
-// (6 rows, not 8: with the T85 tables the block then needs 53.3 KB of LDS and three blocks fit a CU instead of two)
-
-template <int JT, int NKS, bool BOTH, bool FUSED>
-__global__ __launch_bounds__(256) void k_leg_inv_mfma(Geom g, const int *__restrict__ m_local,
-                                                      const double *__restrict__ pinv, const double *__restrict__ S,
-                                                      double *__restrict__ Fs, int C, int full, SynthSrc src, int T) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double *As = (double *)smem;                      // [NHP][Jh] per parity
-  double *lc = As + (BOTH ? 2 : 1) * g.NHP * g.Jh;  // FUSED: [LC_ROWS][N1] operator coefficients of this m
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  int ml, tile_x;
-  if (!leg_block(g.Ml, T, ml, tile_x)) return;
-  const int m = m_local[ml];
-  if (m < 0) return;
-  const int c0 = (tile_x * 4 + wave) * 16;
-  const int cl = lane & 15, kq = lane >> 4, c = c0 + cl;
-  const bool cok = c < C;
-  const int nlim = full ? g.N1 : g.N1 - m;
-  const int cnt0 = (nlim + 1) >> 1, cnt1 = nlim >> 1;
-  const int nks0 = (cnt0 + 3) >> 2, nks1 = (cnt1 + 3) >> 2;
-  const int Jh = g.Jh;
-  double b0[NKS], b1[NKS];
-  if (!FUSED) {
-    const int sbase = (ml * g.N1 + 2 * kq) * C + c;    // row n = 2*(ks*4+kq) (+1)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int n0 = 8 * ks + 2 * kq;
-      b0[ks] = (ks < nks0 && n0 < nlim && cok) ? S[sbase + 8 * ks * C] : 0.0;
-      b1[ks] = (ks < nks1 && n0 + 1 < nlim && cok) ? S[sbase + (8 * ks + 1) * C] : 0.0;
-    }
-  } else {
-    const int N1 = g.N1, L = g.L;
-    {  // coefficient rows of this wavenumber -> LDS
-      const int ids[6] = {C_UVC, C_UVM, C_UVP, C_DX, C_DYM, C_DYP};
-      for (int i = threadIdx.x; i < LC_ROWS * N1; i += 256) {
-        const int row = i / N1, n = i - row * N1;
-        lc[i] = src.coef[((size_t)ids[row] * g.Ml + ml) * N1 + n];
-      }
-    }
-    if (BOTH) {   // the Legendre table of this wavenumber goes to LDS while the B operand is being gathered
-      lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * g.Jh, 4 * nks0 * g.Jh);
-      lds_fill(As + g.NHP * g.Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * g.Jh, 4 * nks1 * g.Jh);
-    }
-    // what this lane's column is made of: w_a(n) A[n] + w_m(n) M[n-1] + w_p(n) P[n+1]
-    const int lf = c >> 1, ri = c & 1;
-    int f = 7 + (lf - 7 * L), k = 0;
-    if (lf < 7 * L) { f = lf / L; k = lf - f * L; }
-    const int stride = (f < 7) ? 2 * L : 2;                               // doubles per n in the source array
-    const size_t e0 = (f < 7) ? ((size_t)ml * N1 * L + k) * 2 : (size_t)ml * N1 * 2;
-    const double *tsrc = (f < 7) ? src.ts : src.lnps;
-    const double *pa = nullptr, *pm = nullptr;                             // centre array, neighbour array (n-1 and n+1)
-    int ra = LC_UVC, rm = LC_UVM, rp = LC_UVP;                              // (unused rows point at a valid one)
-    double sa = 1.0, sm = 1.0, sp = 1.0;
-    int ca = ri;                                                           // component read from the centre array
-    const double si = ri ? 1.0 : -1.0;                                     // (i z).re = -z.im, (i z).im = z.re
-    switch (f) {
-      case 0: pa = src.div; ra = LC_ONE; break;
-      case 1: pa = src.vor; ra = LC_ONE; break;
-      case 2: pa = src.div; ra = LC_UVC; sa = si; ca = 1 - ri; pm = src.vor; rm = LC_UVM; sm = 1.0; rp = LC_UVP; sp = -1.0; break;
-      case 3: pa = src.vor; ra = LC_UVC; sa = si; ca = 1 - ri; pm = src.div; rm = LC_UVM; sm = -1.0; rp = LC_UVP; sp = 1.0; break;
-      case 4: case 7: pa = tsrc; ra = LC_ONE; break;
-      case 5: case 8: pa = tsrc; ra = LC_DX; sa = si; ca = 1 - ri; break;
-      default: pm = tsrc; rm = LC_DYM; sm = -1.0; rp = LC_DYP; sp = 1.0; break;     // 6, 9
-    }
-    if (!cok) { pa = nullptr; pm = nullptr; }
-    // Loads first, arithmetic second, in groups of 4 k-steps: every lane reads a valid (clamped) element of a valid
-    // array and the selects below drop what it does not use, so the loads of a group carry no branches and are in
-    // flight together.  Groups wholly beyond the triangle of this wavenumber are skipped (wave-uniform test).
-    const double *pa_ = pa ? pa : src.vor, *pm_ = pm ? pm : src.vor;
-    const size_t e0c = cok ? e0 : 0;
-    const bool any_m = __any(pm != nullptr);
-    __syncthreads();                                                       // lc ready
-#pragma unroll
-    for (int g4 = 0; g4 < NKS; g4 += 4) {
-      if (g4 < nks0) {                                                     // nks1 <= nks0
-        double ta[4][2], tm[4][2], tp[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int par = 0; par < 2; ++par) {
-            const int nn = min(8 * (g4 + q) + 2 * kq + par, N1 - 1);
-            ta[q][par] = pa_[e0c + (size_t)nn * stride + ca];
-          }
-        if (any_m) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-              const int nn = min(8 * (g4 + q) + 2 * kq + par, N1 - 1);
-              tm[q][par] = pm_[e0c + (size_t)max(nn - 1, 0) * stride + ri];
-              tp[q][par] = pm_[e0c + (size_t)min(nn + 1, N1 - 1) * stride + ri];
-            }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { tm[q][0] = tm[q][1] = tp[q][0] = tp[q][1] = 0.0; }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int par = 0; par < 2; ++par) {
-            const int ks = g4 + q;
-            if (ks < NKS) {
-              const int n = 8 * ks + 2 * kq + par, nn = min(n, N1 - 1);
-              double v = 0.0;
-              if (pa) v = sa * (ra == LC_ONE ? 1.0 : lc[(ra == LC_ONE ? 0 : ra) * N1 + nn]) * ta[q][par];
-              if (pm) {
-                if (n >= 1) v += sm * lc[rm * N1 + nn] * tm[q][par];
-                if (n + 1 < N1) v += sp * lc[rp * N1 + nn] * tp[q][par];
-              }
-              if (!(ks < (par ? nks1 : nks0) && n < nlim)) v = 0.0;
-              if (par) b1[ks] = v; else b0[ks] = v;
-            }
-          }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if (g4 + q < NKS) { b0[g4 + q] = 0.0; b1[g4 + q] = 0.0; }
-      }
-    }
-  }
-  double4_t accE[JT], accO[JT];
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt) { accE[jt] = (double4_t){0., 0., 0., 0.}; accO[jt] = (double4_t){0., 0., 0., 0.}; }
-  const bool wave_on = c0 < C;
-  const double *A = As + kq * Jh + cl;
-  if (!(FUSED && BOTH)) {
-    // even parity: only the rows nh < 4*nks are needed
-    lds_fill(As, pinv + (size_t)(ml * 2 + 0) * g.NHP * Jh, 4 * nks0 * Jh);
-    if (BOTH) lds_fill(As + g.NHP * Jh, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
-  }
-  __syncthreads();
-  if (wave_on) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      if (ks < nks0) {
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-          accE[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ks * 4 * Jh + jt * 16], b0[ks], accE[jt], 0, 0, 0);
-      }
-  }
-  if (!BOTH) {
-    __syncthreads();
-    lds_fill(As, pinv + (size_t)(ml * 2 + 1) * g.NHP * Jh, 4 * nks1 * Jh);
-    __syncthreads();
-  }
-  if (wave_on) {
-    const double *A1 = A + (BOTH ? g.NHP * Jh : 0);
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-      if (ks < nks1) {
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-          accO[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[ks * 4 * Jh + jt * 16], b1[ks], accO[jt], 0, 0, 0);
-      }
-  }
-  if (!cok) return;
-  // rows jp = jt*16 + kq + 4r and their mirrors J-1-jp stay inside one 16-aligned latitude group (Jl % 16 == 0)
-#pragma unroll
-  for (int jt = 0; jt < JT; ++jt) {
-    const int south = frow32(jt * 16 + kq, ml, C, g.log2Jl, g.Ml) + c;
-    const int north = frow32(g.J - 1 - jt * 16 - kq, ml, C, g.log2Jl, g.Ml) + c;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double e = accE[jt][r], o = accO[jt][r];
-      Fs[south + 4 * r * C] = e - o;                 // southern row  (:235)
-      Fs[north - 4 * r * C] = e + o;                 // northern mirror (:236)
-    }
-  }
-}
-
-// plain-FMA check kernels (legendre_impl = 1, and lat_max not a multiple of 32)
-__global__ void k_leg_fwd_simple(Geom g, const int *__restrict__ m_local, const double *__restrict__ pw,
-                                 const double *__restrict__ Fs, double *__restrict__ S, int C, int full) {
-  const int c = blockIdx.x * 64 + threadIdx.x, n = blockIdx.y, ml = blockIdx.z;
-  const int m = m_local[ml];
-  if (m < 0 || c >= C) return;
-  const int nlim = full ? g.N1 : g.N1 - m;
-  if (n >= nlim) return;
-  const int par = n & 1, nh = n >> 1;
-  const double *A = pw + ((size_t)(ml * 2 + par) * g.Jh) * g.NHP + nh;
-  double acc = 0.0;
-  for (int jp = 0; jp < g.Jh; ++jp) {
-    const double xs = Fs[frow(g, jp, ml, C) + c], xn = Fs[frow(g, g.J - 1 - jp, ml, C) + c];
-    acc += (par ? (xn - xs) : (xn + xs)) * A[(size_t)jp * g.NHP];
-  }
-  S[((size_t)ml * g.N1 + n) * C + c] = acc;
-}
-__global__ void k_leg_inv_simple(Geom g, const int *__restrict__ m_local, const double *__restrict__ pinv,
-                                 const double *__restrict__ S, double *__restrict__ Fs, int C, int full) {
-  const int c = blockIdx.x * 64 + threadIdx.x, jp = blockIdx.y, ml = blockIdx.z;
-  const int m = m_local[ml];
-  if (m < 0 || c >= C) return;
-  const int nlim = full ? g.N1 : g.N1 - m;
-  double e = 0.0, o = 0.0;
-  for (int n = 0; n < nlim; ++n) {
-    const int par = n & 1, nh = n >> 1;
-    const double p = pinv[((size_t)(ml * 2 + par) * g.NHP + nh) * g.Jh + jp];
-    const double sv = S[((size_t)ml * g.N1 + n) * C + c];
-    if (par) o += sv * p; else e += sv * p;
-  }
-  Fs[frow(g, jp, ml, C) + c] = e - o;
-  Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;
-}
-
-static bool mfma_ok(const Geom &g, int impl) {   // standard resolutions T21/T42/T85/T170 (J = 32/64/128/256)
-  if (g.Jl % 16 || (g.Jl & (g.Jl - 1))) return false;   // 32-bit shift/mask row addressing
-  return impl == 0 && ((g.Jh == 16 && g.NHP == 16) || (g.Jh == 32 && g.NHP == 32) || (g.Jh == 64 && g.NHP == 48) || (g.Jh == 128 && g.NHP == 96));
-}
-
-void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
-  if (mfma_ok(g, impl)) {
-    const int T = ((C + 15) / 16 + 3) / 4;
-    dim3 grid(leg_grid(g.Ml, T));
-    const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
-    const size_t lds = (size_t)(both ? 2 : 1) * g.Jh * g.NHP * sizeof(double);
-#define LF(N, B) hipLaunchKernelGGL((k_leg_fwd_mfma<N, B>), grid, dim3(256), lds, s, g, d.m_local, d.pw_fwd, Fs, S, C, full, T)
-    switch (g.Jh / 4) {
-      case 4: LF(4, true); break;   case 8: LF(8, true); break;   case 16: LF(16, true); break;
-      case 32: LF(32, false); break;
-      default: throw std::runtime_error("legendre_forward: unsupported lat_max for the MFMA kernel");
-    }
-#undef LF
-  } else {
-    dim3 grid((C + 63) / 64, g.N1, g.Ml);
-    hipLaunchKernelGGL(k_leg_fwd_simple, grid, dim3(64), 0, s, g, d.m_local, d.pw_fwd, Fs, S, C, full);
-  }
-}
-void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl) {
-  if (fused_tl >= 0 && !mfma_ok(g, impl)) throw std::runtime_error("fused synthesis needs the MFMA Legendre kernel");
-  if (mfma_ok(g, impl)) {
-    SynthSrc src = {nullptr, nullptr, nullptr, nullptr, d.coef};
-    if (fused_tl >= 0) { src.vor = d.vors[fused_tl]; src.div = d.divs[fused_tl]; src.ts = d.ts[fused_tl]; src.lnps = d.lnps[fused_tl]; }
-    const int T = ((C + 15) / 16 + 3) / 4;
-    dim3 grid(leg_grid(g.Ml, T));
-    const bool both = (size_t)2 * g.Jh * g.NHP * sizeof(double) <= 50 * 1024;
-    const size_t lds = (size_t)(both ? 2 : 1) * g.NHP * g.Jh * sizeof(double) + (size_t)LC_ROWS * g.N1 * sizeof(double);
-    // JT = Jh/16 row tiles, NKS = NHP/4 k-steps per parity (compile-time upper bound of the triangle)
-#define LI(JT, NKS, B)                                                                                                            \
-  do {                                                                                                                            \
-    if (fused_tl >= 0) hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, true>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src, T);  \
-    else hipLaunchKernelGGL((k_leg_inv_mfma<JT, NKS, B, false>), grid, dim3(256), lds, s, g, d.m_local, d.p_inv, S, Fs, C, full, src, T);            \
-  } while (0)
-    if (g.Jh == 16 && g.NHP == 16) LI(1, 4, true);
-    else if (g.Jh == 32 && g.NHP == 32) LI(2, 8, true);
-    else if (g.Jh == 64 && g.NHP == 48) LI(4, 12, true);
-    else if (g.Jh == 128 && g.NHP == 96) LI(8, 24, false);
-    else throw std::runtime_error("legendre_inverse: unsupported resolution for the MFMA kernel");
-#undef LI
-  } else {
-    dim3 grid((C + 63) / 64, g.Jh, g.Ml);
-    hipLaunchKernelGGL(k_leg_inv_simple, grid, dim3(64), 0, s, g, d.m_local, d.p_inv, S, Fs, C, full);
-  }
-}
-
-// =====================================================================================================
 // Spectral-space operators (tools/spherical.F90:270-600).  State arrays are [ml][n][lev] complex.
 // =====================================================================================================
 #define COEF(id, ml, n) coef[((size_t)(id) * g.Ml + (ml)) * g.N1 + (n)]

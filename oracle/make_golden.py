@@ -66,11 +66,14 @@ FRIERSON_BK = [0.000000, 0.0117665, 0.0196679, 0.0315244, 0.0485411, 0.0719344, 
 MOIST_EXE = os.path.join(HERE, "_ref", "ref_moist_harness.x")
 
 
-def moist_input_nml(res):
-    """namelist of exp/test_cases/frierson/frierson_test_case.py:49-170 (config 3 of BASELINE.json), 25 levels"""
+def moist_input_nml(res, num_levels=25):
+    """namelist of exp/test_cases/frierson/frierson_test_case.py:49-170 (config 3 of BASELINE.json): its 25 levels from
+    vert_coordinate_nml, or (num_levels != 25: the T85L40 size of BASELINE configs[3]) `uneven_sigma` levels with the test case's
+    scale_heights / exponent / surf_res"""
     lon, lat, nf, ns = RES[res]
     bk = ", ".join(f"{b:.7f}" for b in FRIERSON_BK)
     pk = ", ".join("0.0" for _ in FRIERSON_BK)
+    vco = "input" if num_levels == 25 else "uneven_sigma"
     return f""" &atmosphere_nml
     idealized_moist_model = .true.
  /
@@ -116,8 +119,8 @@ def moist_input_nml(res):
     domains_stack_size = 2000000
  /
  &spectral_dynamics_nml
-    damping_order = 4, water_correction_limit = 200.e2, reference_sea_level_press = 1.0e5, num_levels = 25,
-    valid_range_t = 100., 800., initial_sphum = 2.e-6, vert_coord_option = 'input', surf_res = 0.5,
+    damping_order = 4, water_correction_limit = 200.e2, reference_sea_level_press = 1.0e5, num_levels = {num_levels},
+    valid_range_t = 100., 800., initial_sphum = 2.e-6, vert_coord_option = '{vco}', surf_res = 0.5,
     scale_heights = 11.0, exponent = 7.0, robert_coeff = 0.03,
     lon_max = {lon}, lat_max = {lat}, num_fourier = {nf}, num_spherical = {ns}
  /
@@ -128,10 +131,10 @@ def moist_input_nml(res):
 """
 
 
-def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run"):
+def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run", num_levels=25):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
-    open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res))
+    open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res, num_levels))
     open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)       # src/extra/model/isca/field_table: the same sphum entry
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     fmt = lambda t: ", ".join(str(s) for s in t) if t else "-1"
@@ -277,7 +280,7 @@ def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt
     """The reference moist model (Frierson physics) from its cold start: grid state u, v, T, q, ps at `dump_steps`."""
     lon, lat, nf, ns = RES[res]
     with tempfile.TemporaryDirectory(prefix="refmr_") as d:
-        prepare_moist_rundir(d, res, nsteps, dt=dt, dump_steps=dump_steps)
+        prepare_moist_rundir(d, res, nsteps, dt=dt, dump_steps=dump_steps, num_levels=L)
         stdout = run_harness(d, exe=MOIST_EXE)
         out = {}
         for fn in sorted(os.listdir(d)):
@@ -454,6 +457,30 @@ def main():
         path = os.path.join(GOLD, "run_T85L40.npz")
         np.savez_compressed(path, **out)
         print(f"run_T85L40: {os.path.getsize(path)/1e6:.2f} MB")
+    if a.only == "moist_run_T85L40":
+        # BASELINE configs[3] at its full size: the Frierson model at T85L40 (uneven_sigma levels, dt = 300 s) from the cold start,
+        # steps 1, 12 and 144 (12 hours); 3-D fields kept as the [3::4, ::8, ::8] sample (every 4th level up to the lowest one),
+        # 2-D fields as [::4, ::4]   (~4 min of reference time)
+        out = golden_moist_run("T85", 40, 144, (1, 12, 144), dt=300, keep=lambda k: re.match(r"st_(ug|vg|tg|q|psg)_000(001|012|144)$", k) is not None)
+        for k in list(out):
+            if k.startswith("st_"):
+                a3 = out.pop(k)
+                out[k + ("_s488" if a3.ndim == 3 else "_s44")] = np.ascontiguousarray(a3[3::4, ::8, ::8] if a3.ndim == 3 else a3[::4, ::4])
+        out = {k: v for k, v in out.items() if not k.startswith("tab_") or v.size < 4096}
+        path = os.path.join(GOLD, "moist_run_T85L40.npz")
+        np.savez_compressed(path, **out)
+        print(f"moist_run_T85L40: {os.path.getsize(path)/1e6:.2f} MB")
+    if a.only == "run_T170L60":
+        # BASELINE configs[4] at its full size: T170L60 Held-Suarez, dt = 150 s, steps 1 and 8 from the cold start;
+        # 3-D fields kept as the [5::6, ::16, ::16] sample (every 6th level up to the lowest one), ps as [::8, ::8]
+        out = golden_run("T170", 60, 8, (1, 8), dt=150, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_00000(1|8)$", k) is not None)
+        for k in list(out):
+            if k.startswith("st_"):
+                a3 = out.pop(k)
+                out[k + ("_s6gg" if a3.ndim == 3 else "_s88")] = np.ascontiguousarray(a3[5::6, ::16, ::16] if a3.ndim == 3 else a3[::8, ::8])
+        path = os.path.join(GOLD, "run_T170L60.npz")
+        np.savez_compressed(path, **out)
+        print(f"run_T170L60: {os.path.getsize(path)/1e6:.2f} MB")
     if not a.only or a.only == "tables_T85":
         out = golden_run("T85", 2, 0, (), keep=lambda k: k.startswith("tab_"))
         leg = out.pop("tab_legendre")

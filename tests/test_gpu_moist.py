@@ -75,6 +75,36 @@ def test_moist_work_arrays_in_global_memory(golden_dir):
     dc.close()
 
 
+def test_moist_trajectory_T85L40(golden_dir):
+    """BASELINE configs[3] at its full size: the Frierson model at T85L40 (uneven_sigma levels of the test case's scale_heights / exponent,
+    dt = 300 s) from the cold start against the reference run after 1, 12 and 144 steps (12 hours), on the committed
+    [3::4, ::8, ::8] sample (ps: [::4, ::4]).  Same error measure as the T21L25 trajectory."""
+    g = np.load(os.path.join(golden_dir, "moist_run_T85L40.npz"))
+    nml = moist_namelist("T85", float(g["meta_dt_atmos"]))
+    nml["spectral_dynamics_nml"].update(num_levels=40, vert_coord_option="uneven_sigma")
+    nml.pop("vert_coordinate_nml", None)
+    dc = dyncore.DynCore(atm.config_from_namelist(nml))
+    assert np.allclose(dc.table("bk"), g["tab_bk"], rtol=0, atol=1e-15)
+    dc.cold_start()
+    done = 0
+    tol = {1: 1e-11, 12: 1e-9, 144: 1e-8}
+    for n in (1, 12, 144):
+        dc.step(n - done)
+        done = n
+        err = {}
+        for mine, ref in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "q")):
+            r3 = g["st_%s_%06d_s488" % (ref, n)]
+            scale = max(float(np.abs(r3).max()), 1.0 if ref in ("ug", "vg") else 0.0)
+            err[ref] = float(np.abs(dc.get(mine)[3::4, ::8, ::8] - r3).max()) / scale
+        err["psg"] = rel(dc.get("psg")[::4, ::4], g["st_psg_%06d_s44" % n])
+        print("moist T85L40 step", n, err)
+        assert max(err.values()) < tol[n], (n, err)
+    tmin, tmax, umax, qmax = g["final_Tmin_Tmax_maxabsU_qmax"]
+    t = dc.get("tg")
+    assert abs(t.min() - tmin) < 1e-6 and abs(t.max() - tmax) < 1e-6 and abs(dc.get("tr").max() - qmax) < 1e-8 * qmax + 1e-12
+    dc.close()
+
+
 def test_moist_trajectory_T21L25(golden_dir):
     """From the cold start, pointwise, while the comparison is meaningful (1.2 days): fraction of the field maximum (winds, which
     start from rest: of max(|u|, 1 m/s)).  Measured: step 1 1e-14, step 144 1e-10 (u), 2e-12 (T), 1.3e-9 (q) - the same size as the

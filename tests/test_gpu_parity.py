@@ -129,6 +129,27 @@ def test_golden_T85L40_benchmark_config(golden_dir):
     dc.close()
 
 
+def test_golden_T170L60_stress_config(golden_dir):
+    """BASELINE configs[4] at its full size (T170L60 Held-Suarez, dt = 150 s): steps 1 and 8 from the cold start against the reference
+    run, on the committed [5::6, ::16, ::16] sample (ps: [::8, ::8]); winds as a fraction of max(|u|, 1 m/s)."""
+    g = np.load(os.path.join(golden_dir, "run_T170L60.npz"))
+    dc = make("T170", 60, dt_atmos=150.0); dc.cold_start()
+    done = 0
+    for n in (1, 8):
+        dc.step(n - done); done = n
+        err = {}
+        for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1")):
+            ref = g["st_%s_%06d_s6gg" % (gk, n)]
+            err[k] = float(np.abs(dc.get(k)[5::6, ::16, ::16] - ref).max() / max(np.abs(ref).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+        err["psg"] = rel(dc.get("psg")[::8, ::8], g["st_psg_%06d_s88" % n])
+        print("T170L60 step", n, "vs the reference:", err)
+        assert max(err.values()) < 1e-9, (n, err)
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    dc.close()
+
+
 def test_golden_T21L25_ten_days(golden_dir):
     """configs[0] for 10 days (1440 steps) against the reference run: SURVEY 8d's long-run bound is 1e-7 relative
     (the reference's own response to a 1-ulp perturbation of the initial temperature is 2e-10 m/s after 10 days)."""
