@@ -517,25 +517,10 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     a.frag = d.leg_fwd_frag; a.Fs = Fs; a.S = S; a.m_local = d.m_local; a.C = C; a.full = full;
     a.KS = g.Jh / 4; a.NTP = g.NHP / 16;
     a.CB = ((C + 31) / 32 + 3) / 4;
-    static const int variant = env_int("ISCA_LEG_FWD", 0);      // measurement switch: FD * 10 + NTG
-    int fd = variant ? variant / 10 : 4, ntg = variant ? variant % 10 : 3;
-    if (a.KS % fd) { fd = 4; ntg = 3; }
-    a.RG = (a.NTP + ntg - 1) / ntg;
+    constexpr int FD = 4, NTG = 3;                   // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): DESIGN.md
+    a.RG = (a.NTP + NTG - 1) / NTG;
     const dim3 grid(leg_grid(g.Ml, a.CB * a.RG));
-#define LF(FD, NTG, WPS) hipLaunchKernelGGL((k_leg_fwd<FD, NTG, WPS>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x)); break
-    switch (fd * 10 + ntg) {
-      case 43: LF(4, 3, 2);
-      case 41: LF(4, 1, 2);
-      case 42: LF(4, 2, 2);
-      case 81: LF(8, 1, 2);
-      case 82: LF(8, 2, 2);
-      case 161: LF(16, 1, 2);
-      case 162: LF(16, 2, 1);
-      case 83: LF(8, 3, 1);
-      case 46: LF(4, 6, 1);
-      default: throw std::runtime_error("legendre_forward: unsupported variant");
-    }
-#undef LF
+    hipLaunchKernelGGL((k_leg_fwd<FD, NTG, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     TRACE_DUMP(trace_fwd)
   } else {
     dim3 grid((C + 63) / 64, g.N1, g.Ml);
