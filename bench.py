@@ -85,20 +85,77 @@ def cpu_baseline(workload, budget_steps):
             "ms_per_step": 1e3 * sec, "sample": f"{n} steps of {workload} HS, numpy oracle (BLAS threads)"}
 
 
+def kernel_rooflines(kt, I, J, M1, N, L):
+    """Per-kernel achieved rates from the HIP-event durations `kt` (ms) and the ALGORITHMIC work per launch."""
+    field_bytes = 8.0 * I * J * L
+    leg_flops_lf = J * (N + 1) * (N + 4)                             # per level-field
+    kern = {}
+    if "column" in kt:
+        kern["column"] = {"bound": "hbm", "ms": kt["column"], "achieved_GBs": 14.0 * field_bytes / (kt["column"] * 1e-3) / 1e9}   # ~14 L-level field passes
+    for nm, nlf in (("legendre_fwd", 4 * L + 1), ("legendre_inv", 7 * L + 3)):
+        if nm in kt:
+            kern[nm] = {"bound": "mfma", "ms": kt[nm], "achieved_TFs": nlf * leg_flops_lf / (kt[nm] * 1e-3) / 1e12}
+    for nm, nlf in (("fft_fwd", 4 * L + 1), ("fft_inv", 7 * L + 3)):
+        if nm in kt:
+            b = nlf * (8.0 * I * J + 16.0 * M1 * J)                  # one grid pass + one truncated Fourier pass
+            kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": b / (kt[nm] * 1e-3) / 1e9}
+    if "moist_physics" in kt:                                        # 4 fields + 2 x 2 pressures + 2 heights in, 4 tendencies out
+        kern["moist_physics"] = {"bound": "hbm (latency-bound in practice: a dependent fp64 chain per column, DESIGN.md 9)", "ms": kt["moist_physics"],
+                                 "achieved_GBs": 14.0 * field_bytes / (kt["moist_physics"] * 1e-3) / 1e9}
+    return kern
+
+
+def dominant_roofline(kt, kern, traffic, traffic_source):
+    kt_main = {k: v for k, v in kt.items() if k != "tracer"}        # "tracer" spans two kernels on the side stream
+    dom = max(kt_main, key=kt_main.get) if kt_main else None
+    if dom not in kern:
+        dom = "column" if "column" in kern else None
+    if dom is None:
+        return None
+    c = kern[dom]
+    name = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop", "fft_fwd": "k_fft_fwd", "fft_inv": "k_fft_inv",
+            "moist_physics": "k_moist_physics"}[dom]
+    mfma = c["bound"] == "mfma"
+    ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)
+    return {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
+            "frac": ach / peak, "traffic": traffic.get(name), "traffic_source": traffic_source if traffic.get(name) is not None else None,
+            "avg_launch_ms": c["ms"]}
+
+
+def load_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE per the gfx950 correction,
+    calibrated on k_column's known byte count, + WRITE_SIZE; profiles/README.md).  A number measured earlier, NOT in this run: the
+    line says which file it came from."""
+    for tag in ("r02", "r01"):
+        rel = os.path.join("profiles", f"{tag}_pmc_traffic.json" if workload == "T85L40" else f"{tag}_{workload}_pmc_traffic.json")
+        if os.path.exists(os.path.join(REPO, rel)):
+            return json.load(open(os.path.join(REPO, rel))).get("bytes_per_launch", {}), rel
+    return {}, None
+
+
 def other_workloads(device):
     """Informational, outside the timed region and never part of `value`: the other configurations of the same build on this GPU
-    (BASELINE configs[3] moist physics at the benchmark resolution; the sibling cores).  A failure here is reported, not raised."""
+    (BASELINE configs[3] moist physics at the benchmark resolution, configs[4] T170L60, the sibling cores), each with the roofline of its
+    dominant kernel.  A failure here is reported, not raised."""
     res = {}
-    try:
-        from isca_amd import dyncore
-        core = dyncore.DynCore(dyncore.default_config("T85", num_levels=40, physics=1, dt_atmos=300.0, initial_sphum=2e-6, robert_coeff=0.03,
-                                                      scale_heights=11.0, exponent=7.0, device=device))
-        core.cold_start(); core.step(150)
-        t0 = time.time(); core.step(300); dt = (time.time() - t0) / 300
-        res["T85L40 Frierson moist physics, dt_atmos=300s"] = {"ms_per_step": round(1e3 * dt, 4), "sim_years/day": round(sim_years_per_day(dt, 300.0), 1)}
-        core.close()
-    except Exception as e:                                               # noqa: BLE001
-        res["T85L40 Frierson moist physics"] = {"error": str(e)[:200]}
+    from isca_amd import dyncore
+    for name, key, kw, nwarm, nstep in (
+            ("T85L40 Frierson moist physics, dt_atmos=300s", "T85", dict(num_levels=40, physics=1, dt_atmos=300.0, initial_sphum=2e-6, robert_coeff=0.03,
+                                                                     scale_heights=11.0, exponent=7.0), 150, 300),
+            ("T170L60 Held-Suarez, dt_atmos=150s", "T170", dict(num_levels=60, dt_atmos=150.0), 20, 100)):
+        try:
+            core = dyncore.DynCore(dyncore.default_config(key, device=device, **kw))
+            core.cold_start(); core.step(nwarm)
+            t0 = time.time(); core.step(nstep); sec = (time.time() - t0) / nstep
+            core.kernel_times(True); core.step(min(nstep, 100)); kt = core.kernel_times(False)
+            kern = kernel_rooflines(kt, core.I, core.J, core.M1, core.cfg.num_fourier, core.L)
+            traffic, src = load_traffic(name.split()[0] + ("_moist" if "Frierson" in name else ""))
+            res[name] = {"ms_per_step": round(1e3 * sec, 4), "sim_years/day": round(sim_years_per_day(sec, kw["dt_atmos"]), 1),
+                         "roofline": dominant_roofline(kt, kern, traffic, src), "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+                         "kernel_roofline": kern}
+            core.close()
+        except Exception as e:                                           # noqa: BLE001
+            res[name] = {"error": str(e)[:200]}
     try:
         from isca_amd import shallow
         for name, mk in (("T85 shallow water, dt_atmos=1200s", lambda: shallow.ShallowWater(shallow.config_from_namelist(None, "T85", device=device))),
@@ -193,46 +250,21 @@ def main():
         one.close()
         replicas = {"value": world * sim_years_per_day(float(e1.item()) / a.steps, dt), "unit": "sim_years/day (sum over members)",
                     "ms_per_step": 1e3 * float(e1.item()) / a.steps, "scaling": "weak", "note": "independent ensemble members, one per GPU"}
+    exchange_ms = None
+    if world > 1:       # what each rank spent in the exchanges of a step (HIP events around the RCCL calls the library issues)
+        mine = {k: round(v, 5) for k, v in kt.items() if k in ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce")}
+        mine["driver"] = "native RCCL" if getattr(core, "native", False) else f"torch.distributed ({backend})"
+        exchange_ms = [None] * world
+        dist.all_gather_object(exchange_ms, mine)
     if rank != 0:
         return
     I, J, M1, N = core.I, core.J, core.M1, core.cfg.num_fourier
-    field_bytes = 8.0 * I * J * L
-    # algorithmic bytes/flops per launch (DESIGN.md "Kernels")
-    col_bytes = 14.0 * field_bytes                                   # column kernel: ~14 L-level field passes
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 per the
-    # gfx950 correction, calibrated on this kernel's known byte count, + WRITE_SIZE); see profiles/README.md
-    traffic = {}
-    tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and a.workload == "T85L40":
-        traffic = json.load(open(tpath)).get("bytes_per_launch", {})
-    leg_flops_lf = J * (N + 1) * (N + 4)                             # per level-field
-    kern = {}
-    if "column" in kt:
-        kern["column"] = {"bound": "hbm", "ms": kt["column"], "achieved_GBs": col_bytes / (kt["column"] * 1e-3) / 1e9}
-    for nm, nlf in (("legendre_fwd", 4 * L + 1), ("legendre_inv", 7 * L + 3)):
-        if nm in kt:
-            kern[nm] = {"bound": "mfma", "ms": kt[nm], "achieved_TFs": nlf * leg_flops_lf / (kt[nm] * 1e-3) / 1e12}
-    for nm, nlf in (("fft_fwd", 4 * L + 1), ("fft_inv", 7 * L + 3)):
-        if nm in kt:
-            b = nlf * (8.0 * I * J + 16.0 * M1 * J)                  # one grid pass + one truncated Fourier pass
-            kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": b / (kt[nm] * 1e-3) / 1e9}
-    kt_main = {k: v for k, v in kt.items() if k != "tracer"}        # "tracer" spans two kernels on the side stream
-    dom = max(kt_main, key=kt_main.get) if kt_main else None
-    roof = None
-    if dom == "column" or dom not in kern:
-        c = kern.get("column")
-        if c:
-            roof = {"kernel": "k_column", "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic.get("k_column"),
-                    "algorithmic_bytes_per_launch": col_bytes, "avg_launch_ms": c["ms"]}
-    else:
-        c = kern[dom]
-        if c["bound"] == "mfma":
-            roof = {"kernel": dom, "bound": "mfma", "achieved": c["achieved_TFs"], "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": c["achieved_TFs"] / FP64_MFMA_PEAK_TF, "traffic": traffic.get(dom), "avg_launch_ms": c["ms"]}
-        else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": c["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": c["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic.get(dom), "avg_launch_ms": c["ms"]}
+    # algorithmic bytes/flops per launch (DESIGN.md "Kernels") over the HIP-event durations of this run
+    traffic, traffic_source = load_traffic(a.workload)
+    kern = kernel_rooflines(kt, I, J, M1, N, L)
+    roof = dominant_roofline(kt, kern, traffic, traffic_source)
+    if roof is not None and roof["kernel"] == "k_column":
+        roof["algorithmic_bytes_per_launch"] = 14.0 * 8.0 * I * J * L
     out = {
         "metric": "simulated-years/day at T85L40 Held-Suarez" if a.workload == "T85L40" else f"simulated-years/day at {a.workload} Held-Suarez",
         "value": sim_years_per_day(sec_per_step, dt), "unit": "sim_years/day", "n_gpus": a.gpus, "steps": a.steps,
@@ -240,7 +272,7 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic (reference cold start: T=264 K at rest + 1e-7 vorticity seed)",
         "config": {"workload": f"{a.workload} Held-Suarez dry core, dt_atmos={dt:g}s, 360-day calendar",
                    "parallelism": f"lat-band x{a.gpus}" if a.gpus > 1 else "single GPU",
-                   "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": "2 all-to-all + 1 halo + 1 all-reduce" if a.gpus > 1 else 0,
+                   "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": "1 halo + 2 all-to-all + 1 all-reduce (tracer transport under the first all-to-all)" if a.gpus > 1 else 0,
                    "exchange_driver": (("RCCL calls issued by the library on the step's stream" if getattr(core, "native", False)
                                         else f"torch.distributed ({backend}) between the device phases") if a.gpus > 1 else None),
                    "grid_tracer": ("sphum advected (van Leer + PPM) on a concurrent stream" if a.gpus == 1
@@ -249,6 +281,8 @@ def main():
     }
     if replicas is not None:
         out["replicas"] = replicas
+    if exchange_ms is not None:
+        out["exchange_ms"] = exchange_ms          # per rank; kernel_ms holds rank 0's kernels
     if a.gpus == 1 and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps)
     if a.gpus == 1 and a.workload == "T85L40" and not os.environ.get("ISCA_BENCH_NO_EXTRA"):

@@ -74,6 +74,22 @@ interface
   integer(c_int) function isca_dyn_step(h, nsteps, sync) bind(C)
     import; type(c_ptr), value :: h; integer(c_int), value :: nsteps, sync
   end function
+  ! spectral_dynamics(..., dt_ug, dt_vg, dt_tg, dt_tracers, ...) after a physics package of the caller's own (physics = 2):
+  ! (lon, lat, lev) tendency arrays; hs_forcing / tracer_source_sink of hs_forcing_mod on caller fields
+  integer(c_int) function isca_dyn_dynamics(h, dt_ug, dt_vg, dt_tg, dt_tracers, on_device, sync) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: dt_ug(*), dt_vg(*), dt_tg(*), dt_tracers(*)
+    integer(c_int), value :: on_device, sync
+  end function
+  integer(c_int) function isca_dyn_delta_t(h, delta_t) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(out) :: delta_t
+  end function
+  integer(c_int) function isca_hs_forcing(h, dt, p_half, p_full, u, v, t, udt, vdt, tdt) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), value :: dt
+    real(c_double), intent(in) :: p_half(*), p_full(*), u(*), v(*), t(*); real(c_double), intent(inout) :: udt(*), vdt(*), tdt(*)
+  end function
+  integer(c_int) function isca_hs_tracer_source_sink(h, surf_p, r, rdt) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: surf_p(*), r(*); real(c_double), intent(inout) :: rdt(*)
+  end function
   integer(c_int) function isca_dyn_get_state(h, name, time_level, host, count) bind(C)
     import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*)
     integer(c_int), value :: time_level; real(c_double), intent(out) :: host(*); integer(c_size_t), value :: count

@@ -85,7 +85,8 @@ typedef struct isca_dyn_config {
   void *stream;                 /* hipStream_t to run on, or NULL for a private stream */
   int legendre_impl;            /* 0 = MFMA (default), 1 = plain-FMA check kernels */
   /* physics package called by atmosphere (atmosphere.F90:304-331): 0 = hs_forcing, 1 = idealized_moist_phys (Frierson);
-   * with 1 the grid tracer is specific humidity: it feeds the physics and receives its tendency. */
+   * with 1 the grid tracer is specific humidity: it feeds the physics and receives its tendency.
+   * 2 = the caller's own physics: the library is spectral_dynamics_mod only and takes the tendencies (isca_dyn_dynamics). */
   int physics;
   /* vert_coord_option = 'input' (vert_coordinate_nml): != 0 -> pk_input/bk_input hold num_levels+1 values, top first */
   int vert_coord_input;
@@ -112,11 +113,29 @@ int isca_dyn_cold_start(isca_dyn_t *h);
 int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync);
 int isca_dyn_synchronize(isca_dyn_t *h);
 
+/* The physics / dynamics seam of atmosphere.F90:300-329 for a host that keeps a physics package of its own (physics = 2):
+ *   spectral_dynamics(Time, psg_final, ug_final, vg_final, tg_final, tracer_attributes, grid_tracers_final, time_level_out,
+ *                     dt_psg, dt_ug, dt_vg, dt_tg, dt_tracers, wg_full, p_full, p_half, z_full)   (spectral_dynamics.F90:780-795)
+ * One call = one step: the tendencies the host's physics accumulated ((lon, lat_local, lev) arrays, null = zero; host memory, or
+ * device memory with on_device != 0) go through the implicit step; results come back through isca_dyn_get_state (u, v, T, ps, tracer of
+ * the new level, "wg_full", "p_full", "p_half", "z_full").  The physics reads the PREVIOUS level's u, v, T, tracer ("tr_atm": the
+ * never-filtered copy atmosphere_mod keeps, atmosphere.F90:95) and the CURRENT level's pressures, as atmosphere.F90:304-317 passes them,
+ * and isca_dyn_delta_t gives its time step (dt_atmos on the first step, else 2 dt_atmos).  dt_psg: the physics packages of this path
+ * leave it zero (atmosphere.F90:298); not carried.  isca_dyn_set_tendencies hands the arrays over without stepping, for a sharded run
+ * driven phase by phase (isca_dyn_step_phase). */
+int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers,
+                      int on_device, int sync);
+int isca_dyn_set_tendencies(isca_dyn_t *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers,
+                            int on_device);
+int isca_dyn_delta_t(isca_dyn_t *h, double *delta_t);
+
 /* --- multi-GPU: one step split at its two lat<->m exchange points (transforms.F90:970-1056).
  * phase 0: grid tendencies + FFT            -> send buffer "fwd" (+ tracer halo rows)
  * phase 1: Legendre analysis, spectral update, Legendre synthesis -> send buffer "inv"
  * phase 2: inverse FFT, fixer partial sums  -> 8 doubles to all-reduce (isca_dyn_reduce_buffer)
  * phase 3: fixers applied, time levels rotated.
+ * phase 4 (between 0 and 1, after the halo rows of the grid tracer have been exchanged and before the "fwd" all-to-all): the tracer's
+ *          transport, on the handle's side stream, so that it runs under the exchange; a no-op without the tracer.
  * The host performs the all-to-all / all-reduce between phases (isca_amd/parallel.py). */
 int isca_dyn_step_phase(isca_dyn_t *h, int phase);
 int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv*/, void **send, void **recv,

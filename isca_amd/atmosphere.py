@@ -55,9 +55,41 @@ _MOIST_FIXED = {
 }
 
 
+# Module defaults of the reference's namelist variables (what applies when an input.nml leaves a variable out), as C config members:
+# spectral_dynamics.F90:152-206, hs_forcing.F90:76-84; main_nml's dt_atmos defaults to 0 = "dt_atmos has not been specified"
+# (atmos_model.F90:111, FATAL).  isca_dyn_config_default holds the Held-Suarez TEST CASE instead (resolution-less use, benchmarks).
+_REF_DEFAULTS = dict(
+    do_mass_correction=1, do_water_correction=1, do_energy_correction=1, triang_trunc=1, damping_order=2,
+    lon_max=128, lat_max=64, num_fourier=42, num_spherical=43, fourier_inc=1, num_levels=18, damping_coeff=1.15740741e-4,
+    eddy_sponge_coeff=0., zmu_sponge_coeff=0., zmv_sponge_coeff=0., robert_coeff=.04, alpha_implicit=.5, scale_heights=4., surf_res=.1,
+    exponent=2.5, initial_sphum=0.0, reference_sea_level_press=101325., water_correction_limit=0.0, raw_filter_coeff=1.0,
+    valid_range_t=(100., 500.), dt_atmos=0.0,
+    t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=1, trflux=1.e-5,
+    trsink=-4., P00=1.e5)
+_REF_VERT_COORD_OPTION = "even_sigma"            # spectral_dynamics.F90:175
+# moist package, isca_moist_config members: idealized_moist_phys.F90:136-138, two_stream_gray_rad.F90:72-82, mixed_layer.F90:84-95,
+# qe_moist_convection.F90:66-70, damping_driver.f90:42-56, vert_turb_driver.F90:116, diffusivity.F90:127-128, monin_obukhov.F90:88-89
+_MOIST_REF_DEFAULTS = dict(
+    roughness_mom=0.05, roughness_heat=0.05, roughness_moist=0.05, solar_constant=1360.0, del_sol=1.4, del_sw=0.0, ir_tau_eq=6.0,
+    ir_tau_pole=1.5, atm_abs=0.0, odp=1.0, sw_diff=0.0, linear_tau=0.1, wv_exponent=4.0, solar_exponent=4.0, depth=40.0, tconst=305.0,
+    delta_T=40.0, albedo_value=0.06, evaporation=1, tau_bm=7200., rhbm=.8, Tmin=173., Tmax=335., val_inc=0.01, do_rayleigh=0, trayfric=0.,
+    sponge_pbottom=50., damping_conserve_energy=0, constant_gust=1.0, frac_inner=0.1, rich_crit_pbl=1.0, rich_crit=2.0, drag_min=1.e-05)
+# reference defaults of the options in _MOIST_FIXED that differ from the one value implemented here: an input.nml that leaves them out
+# asks the reference for something this package does not do, so they must be given
+_MOIST_MUST_SET = {
+    "idealized_moist_phys_nml": {"convection_scheme": "unset", "do_damping": False, "turb": False, "mixed_layer_bc": False, "do_simple": False},
+    "mixed_layer_nml": {"prescribe_initial_dist": False},
+    "vert_turb_driver_nml": {"do_mellor_yamada": True, "do_diffusivity": False, "do_simple": False, "use_tau": True},
+    "diffusivity_nml": {"do_entrain": True, "do_simple": False},
+    "surface_flux_nml": {"use_virtual_temp": True, "do_simple": False, "old_dtaudv": False},
+    "lscale_cond_nml": {"do_simple": False, "do_evap": False},
+    "sat_vapor_pres_nml": {"do_simple": False},
+}
+
+
 def _moist_config(namelist: dict) -> dict:
     """idealized_moist_phys_init and friends: collect the namelist variables of the moist package, refuse what is not implemented."""
-    mo: dict = {}
+    mo: dict = dict(_MOIST_REF_DEFAULTS)
     for grp, fixed in _MOIST_FIXED.items():
         for k, v in (namelist.get(grp) or {}).items():
             k = k.lower()
@@ -73,6 +105,12 @@ def _moist_config(namelist: dict) -> dict:
                 mo[keys[k]] = int(v) if isinstance(v, bool) else v
             elif k not in _MOIST_FIXED.get(grp, {}) and grp != "idealized_moist_phys_nml":
                 raise IscaError(f"{grp}: {k} is not supported by the device physics package")
+    for grp, must in _MOIST_MUST_SET.items():
+        given = {k.lower() for k in (namelist.get(grp) or {})}
+        for k, ref_default in must.items():
+            if k not in given:
+                raise IscaError(f'{grp}: {k} is not set and defaults to "{ref_default}" in the reference; only '
+                                f'"{_MOIST_FIXED[grp][k]}" is supported, so it has to be given')
     return mo
 
 
@@ -124,16 +162,21 @@ def parse_namelist(text: str) -> dict:
 
 
 def config_from_namelist(namelist: dict | str | None, resolution: str | None = None, **overrides):
-    """Build the C config from namelist groups (dict as in held_suarez_test_case.py:45-98, or input.nml text)."""
+    """Build the C config from namelist groups (dict as in held_suarez_test_case.py:45-98, or input.nml text).  Variables a given
+    namelist leaves out take the reference's MODULE defaults (_REF_DEFAULTS), as they do when the reference reads that input.nml;
+    namelist = None keeps the library's Held-Suarez test-case preset (isca_dyn_config_default)."""
     if isinstance(namelist, str):
         namelist = parse_namelist(namelist)
-    kw: dict = {}
+    kw: dict = {} if namelist is None else dict(_REF_DEFAULTS)
+    have_nml = namelist is not None
+    if have_nml and resolution is not None:          # Experiment.set_resolution: over the module defaults, under what the namelist sets itself
+        kw.update(dyncore.RESOLUTIONS[resolution])
     namelist = {g.lower(): v for g, v in (namelist or {}).items()}
     moist = bool(namelist.get("atmosphere_nml", {}).get("idealized_moist_model", False))
     vc = namelist.get("vert_coordinate_nml")
-    vco = str(namelist.get("spectral_dynamics_nml", {}).get("vert_coord_option", "uneven_sigma")).lower()
+    vco = str(namelist.get("spectral_dynamics_nml", {}).get("vert_coord_option", _REF_VERT_COORD_OPTION if have_nml else "uneven_sigma")).lower()
     if vco == "even_sigma":               # compute_even_sigma (init/vert_coordinate.F90:230-244): bk = (k-1)/num_levels, pk = 0
-        nl = namelist.get("spectral_dynamics_nml", {}).get("num_levels", overrides.get("num_levels", 25))
+        nl = overrides.get("num_levels", namelist.get("spectral_dynamics_nml", {}).get("num_levels", kw.get("num_levels", 25)))
         kw["bk_input"] = [float(k) / float(nl) for k in range(nl)] + [1.0]
         kw["pk_input"] = [0.0] * (nl + 1)
     if vco == "input":
@@ -165,9 +208,16 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 if str(v).lower() != unsupported[k].lower():
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
                 continue
-            if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
-                     "graceful_shutdown", "ocean_topog_smoothing", "use_virtual_temperature", "use_implicit"):
+            if k in ("use_virtual_temperature", "use_implicit", "make_symmetric"):      # one value implemented each
+                want = k == "use_implicit"
+                if bool(v) != want:
+                    raise IscaError(f'"{v}" is not a supported value for {k} (only "{want}")')
                 continue
+            if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
+                     "graceful_shutdown", "ocean_topog_smoothing"):
+                continue
+            if k == "p00":
+                k = "P00"
             if isinstance(v, bool):
                 v = int(v)
             if isinstance(v, (list, tuple)) and len(v) == 1:       # e.g. initial_sphum = [2.e-6] (one value per tracer)

@@ -157,7 +157,7 @@ static void check_config(const isca_dyn_config &c) {
       if (c.pk_input[k] != 0.0) fail("vert_coord_option = 'input': only pure sigma levels (pk = 0) are supported");
   }
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
-  if (c.physics != 0 && c.physics != 1) fail("physics must be 0 (hs_forcing) or 1 (idealized_moist_phys)");
+  if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.physics == 1) {
     if (c.num_tracers < 1) fail("idealized_moist_phys needs the sphum tracer (num_tracers >= 1)");
     if (c.num_levels < 3 || c.num_levels > 62) fail("idealized_moist_phys: num_levels must be in 3..62");
@@ -415,7 +415,6 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     bool pure_sigma = true;
     for (double v : T.pk) if (v != 0.0) pure_sigma = false;
     h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.Jl >= 4) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
-    if (g.P > 1) h->tracer_serial = true;     // sharded: the halo exchange sits between the column kernel and the tracer
     if (cfg->physics == 1) {                  // idealized_moist_phys_init: tables, surface state, tendency arrays
       if (!h->tracer_on) fail("idealized_moist_phys: the specific-humidity grid tracer is not available in this configuration");
       h->moist = moist_create(h->cfg, T);
@@ -424,6 +423,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       d.moist_work = dalloc<double>(h, moist_work_doubles(g));
       HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
       launch_t_surf_init(*h, h->stream);      // mixed_layer_init without restart file: the prescribed distribution
+    }
+    if (cfg->physics == 2) {                  // the caller's physics: only the arrays its tendencies are handed over in (zero until then)
+      d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3); d.ph_dtq = dalloc<double>(h, ng3);
+      for (double *p : {d.ph_dtu, d.ph_dtv, d.ph_dtT, d.ph_dtq}) HIP_CHECK(hipMemsetAsync(p, 0, ng3 * sizeof(double), h->stream));
     }
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
@@ -605,7 +608,7 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
     count = ng2; return name == "t_surf" ? d.t_surf : d.precip;
   }
   if (name == "dt_ug" || name == "dt_vg" || name == "dt_tg" || name == "dt_sphum") {     // physics tendencies of the last step
-    if (h->cfg.physics != 1) fail("get/set_state: " + name + " exists only with the moist physics package");
+    if (h->cfg.physics == 0) fail("get/set_state: " + name + " exists only with physics = 1 (moist package) or 2 (caller's physics)");
     count = ng3; return name == "dt_ug" ? d.ph_dtu : name == "dt_vg" ? d.ph_dtv : name == "dt_tg" ? d.ph_dtT : d.ph_dtq;
   }
   if (name == "dxT") { count = ng3; return d.dxT; }
@@ -748,7 +751,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
     if (h->g.P > 1) {
-      Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // tracer itself runs in phase 1
+      Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // the tracer itself runs once the halo rows are in
     } else if (h->tracer_serial) {
       Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream);
     } else {
@@ -760,8 +763,17 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   }
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
+// Sharded runs: the grid tracer's transport, issued when the neighbours' halo rows have arrived (fv_advection's mpp_update_domains) and
+// BEFORE the lat -> m all-to-all, on the side stream: it then runs under that exchange and the spectral pipeline, like on one GPU.
+static void phase_tracer(isca_dyn *h, const StepScalars &sc) {
+  if (!h->tracer_on || h->g.P == 1) return;
+  if (h->tracer_serial) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); return; }
+  HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
+  HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
+  HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
+}
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
-  if (h->tracer_on && h->g.P > 1) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); }   // halos have arrived
   { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, 0, h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
@@ -797,12 +809,12 @@ static void sharded_step(isca_dyn *h) {
   isca::Comm &c = *h->comm;
   upload_wave_matrices(h, sc.delta_t);
   phase0(h, sc);
-  {   // lat -> m all-to-all and the tracer's halo rows in one RCCL group (two messages to the same neighbour are fine)
-    const size_t n = h->tracer_on ? (size_t)3 * g.L * 2 * g.I : 0;
-    Timed t(h, "all_to_all_fwd");
-    c.all_to_all_with_halo(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->d.halo_send, h->d.halo_send + n,
-                           h->d.halo_recv, h->d.halo_recv + n, n, h->stream);
+  if (h->tracer_on) {   // the tracer's halo rows first (small), so that its transport runs under the all-to-all
+    const size_t n = (size_t)3 * g.L * 2 * g.I;
+    { Timed t(h, "halo"); c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream); }
+    phase_tracer(h, sc);
   }
+  { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
   phase1(h, sc);
   { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
   phase2(h, sc);
@@ -816,6 +828,8 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   if (!h->have_state) fail("isca_dyn_step: no state (call isca_dyn_cold_start or set_state first)");
   if (h->g.P > 1 && !h->comm)
     fail("isca_dyn_step: world_size > 1 needs isca_dyn_comm_init first (or drive isca_dyn_step_phase and the exchanges from the host)");
+  if (h->cfg.physics == 2 && nsteps != 0)
+    fail("isca_dyn_step: physics = 2 has no physics of its own: hand the tendencies to isca_dyn_dynamics, one call per step");
   for (int i = 0; i < nsteps; ++i) {
     if (h->g.P > 1) { sharded_step(h); continue; }
     const StepScalars sc = step_scalars(h);
@@ -826,6 +840,57 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_valid_range(h);
   }
+  API_END
+}
+// spectral_dynamics(Time, psg_final, ug_final, vg_final, tg_final, tracer_attributes, grid_tracers_final, time_level_out, dt_psg, dt_ug,
+// dt_vg, dt_tg, dt_tracers, wg_full, p_full, p_half, z_full) (spectral_dynamics.F90:780-795) as atmosphere calls it (atmosphere.F90:325)
+// after a physics package of the host's own: physics = 2.  The tendencies are the arrays the reference's physics fills between
+// atmosphere.F90:300 and :321 -- (lon, lat_local, lev), accumulated by the caller, null = zero -- on the host or (on_device) in device
+// memory.  set_tendencies only hands them over (for the phase-by-phase sharded driver); dynamics also runs the step.
+static void stage_tendencies(isca_dyn *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers, int on_device) {
+  if (h->cfg.physics != 2) fail("tendencies of a caller's physics need a handle created with physics = 2");
+  const size_t ng3 = (size_t)h->g.L * h->g.Jl * h->g.I;
+  const double *src[4] = {dt_ug, dt_vg, dt_tg, dt_tracers};
+  double *dst[4] = {h->d.ph_dtu, h->d.ph_dtv, h->d.ph_dtT, h->d.ph_dtq};
+  for (int i = 0; i < 4; ++i) {
+    if (!src[i]) HIP_CHECK(hipMemsetAsync(dst[i], 0, ng3 * sizeof(double), h->stream));
+    else HIP_CHECK(hipMemcpyAsync(dst[i], src[i], ng3 * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  }
+  if (!on_device) HIP_CHECK(hipStreamSynchronize(h->stream));      // the caller may reuse its arrays
+}
+extern "C" int isca_dyn_set_tendencies(isca_dyn_t *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers,
+                                       int on_device) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  stage_tendencies(h, dt_ug, dt_vg, dt_tg, dt_tracers, on_device);
+  API_END
+}
+extern "C" int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers,
+                                 int on_device, int sync) {
+  API_BEGIN
+  if (!h) fail("null handle");
+  if (!h->have_state) fail("isca_dyn_dynamics: no state (call isca_dyn_cold_start or set_state first)");
+  if (h->g.P > 1 && !h->comm)
+    fail("isca_dyn_dynamics: world_size > 1 needs isca_dyn_comm_init first (or isca_dyn_set_tendencies + isca_dyn_step_phase driven by the host)");
+  stage_tendencies(h, dt_ug, dt_vg, dt_tg, dt_tracers, on_device);
+  if (h->g.P > 1) sharded_step(h);
+  else {
+    const StepScalars sc = step_scalars(h);
+    upload_wave_matrices(h, sc.delta_t);
+    phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
+  }
+  if (sync) {
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    check_valid_range(h);
+  }
+  API_END
+}
+// delta_t of the step about to be taken (dt_atmos on a first step or after a restart with previous == current, else 2 dt_atmos:
+// atmosphere.F90:286-290): what the caller's physics receives as its time step
+extern "C" int isca_dyn_delta_t(isca_dyn_t *h, double *delta_t) {
+  API_BEGIN
+  if (!h || !delta_t) fail("null argument");
+  *delta_t = step_scalars(h).delta_t;
   API_END
 }
 // RCCL communicator for the sharded step.  Rank 0 obtains the 128-byte id and hands it to the other ranks by any
@@ -945,6 +1010,7 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
     case 1: phase1(h, sc); break;
     case 2: phase2(h, sc); break;
     case 3: phase3(h, sc); break;
+    case 4: phase_tracer(h, sc); break;
     default: fail("invalid phase");
   }
   API_END

@@ -1047,7 +1047,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
-#define LC(N) do { if (h.cfg.physics == 1) hipLaunchKernelGGL((k_column<N, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false>), grid, block, lds, s, g, a); } while (0)
+#define LC(N) do { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false>), grid, block, lds, s, g, a); } while (0)
   switch (CH) {
     case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
@@ -1611,7 +1611,7 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
   a.robert = h.cfg.robert_coeff;
-  if (h.cfg.physics == 1) {     // sphum: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
+  if (h.cfg.physics != 0) {     // sphum / the caller's tracer: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
     a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0;
   }
   a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + (size_t)3 * h.g.L * 2 * h.g.I;
@@ -1680,6 +1680,7 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
   StepScalars sc{};
   TracerArgs a = tracer_args(h, sc);
   a.ps_cur = ps;
+  a.flux = h.cfg.trflux; a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;   // hs_forcing's own, whatever physics the handle steps with
   hipLaunchKernelGGL(k_tracer_source_sink, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, tr, rdt);
 }
 

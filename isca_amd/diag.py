@@ -68,8 +68,43 @@ class DiagTable:
         return d
 
 
+class DiagCollector:
+    """The device keeps ONE set of running sums per handle.  With several history files (different intervals, different field lists)
+    every file needs its own means, so the sums are taken off the device once per chunk of steps -- the union of the fields of all
+    files, read and reset in one go -- and each History adds the chunk to its own host-side sums (diag_manager keeps one buffer per
+    output field and file for the same reason)."""
+
+    def __init__(self, core, histories):
+        self.core, self.histories = core, list(histories)
+        self.names = sorted({nm for h in self.histories for nm in h.names})
+        for h in self.histories:
+            h.collector = self
+        if self.names:
+            core.diag_select(self.names)
+
+    def after_steps(self, nsteps: int):
+        """Call after every `nsteps` steps; nsteps must divide every file's steps per interval."""
+        sums, cnt = {}, nsteps
+        for nm in self.names:
+            mean, cnt = self.core.diag_mean(nm)
+            sums[nm] = mean * cnt
+        if self.names:
+            if cnt != nsteps:
+                raise IscaError(f"diagnostics: the device accumulated {cnt} steps, {nsteps} expected")
+            self.core.diag_reset(self.names[0])
+        for h in self.histories:
+            h.add_chunk(nsteps, sums)
+
+    def close(self):
+        for h in self.histories:
+            h.close()
+        if self.names:
+            self.core.diag_select("")
+
+
 class History:
-    """One history file of a run: device-side sums every step, one record per output interval."""
+    """One history file of a run: sums every step (on the device, handed over chunk by chunk), one record per output interval.
+    A History on its own (no DiagCollector) owns the device sums: only one such file per handle."""
 
     def __init__(self, core, table_file: dict, dt_atmos: float, path: str, start_seconds: float = 0.0):
         self.core, self.spec, self.dt, self.path = core, table_file, float(dt_atmos), path
@@ -83,26 +118,44 @@ class History:
         self.t0 = float(start_seconds)
         self.elapsed_steps = 0
         self.records = []                       # (t1, t2, {name: array})
-        if self.names:
-            core.diag_select(self.names)
+        self.collector = None
+        self._sums, self._nsum = {}, 0
+        self._own = None
+        self.standalone()                       # owns the device sums until a DiagCollector takes the file over
 
     def after_steps(self, nsteps: int):
-        """Call after every `nsteps` steps of the model (a multiple of steps per interval boundary is not required)."""
+        """Stand-alone use: call after every `nsteps` steps of the model."""
+        if self.collector is not self._own:
+            raise IscaError("History.after_steps: this file belongs to a DiagCollector; call the collector's after_steps")
+        self._own.after_steps(nsteps)
+
+    def standalone(self):
+        """A single file owning the device sums (what a one-file diag_table amounts to)."""
+        self._own = DiagCollector(self.core, [self])
+        return self
+
+    def add_chunk(self, nsteps: int, sums: dict):
+        for nm in self.names:
+            if self.avg[nm]:
+                self._sums[nm] = sums[nm] if nm not in self._sums else self._sums[nm] + sums[nm]
+        self._nsum += nsteps
         self.elapsed_steps += nsteps
         if self.elapsed_steps % self.every == 0:
             self._flush()
 
+    _STATE = {"ucomp": "ug", "vcomp": "vg", "temp": "tg", "ps": "psg", "vor": "vorg", "div": "divg", "omega": "wg_full", "sphum": "tr",
+              "precipitation": "precip", "t_surf": "t_surf"}
+
     def _flush(self):
         rec = {}
-        for i, nm in enumerate(self.names):
-            mean, n = self.core.diag_mean(nm)
-            if not self.avg[nm]:                # instantaneous sample at the end of the interval
-                mean = self.core.get({"ucomp": "ug", "vcomp": "vg", "temp": "tg", "ps": "psg", "vor": "vorg", "div": "divg",
-                                      "omega": "wg_full", "sphum": "tr", "precipitation": "precip"}.get(nm, nm)) if nm in (
-                    "ucomp", "vcomp", "temp", "ps", "vor", "div", "omega", "sphum", "precipitation", "t_surf") else mean
-            rec[nm] = mean
-        if self.names:
-            self.core.diag_reset(self.names[0])
+        for nm in self.names:
+            if self.avg[nm]:
+                rec[nm] = self._sums[nm] / self._nsum
+            elif nm in self._STATE:             # instantaneous sample at the end of the interval
+                rec[nm] = self.core.get(self._STATE[nm])
+            else:
+                raise IscaError(f"diag_table: {nm} is only available as a time average")
+        self._sums, self._nsum = {}, 0
         t2 = self.t0 + self.elapsed_steps * self.dt
         self.records.append((t2 - self.interval, t2, rec))
 
@@ -143,5 +196,5 @@ class History:
             for nm in self.names:
                 out[nm][r] = rec[nm]
         f.close()
-        if self.names:
+        if self.collector is self._own and self.names:
             self.core.diag_select("")

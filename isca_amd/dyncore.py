@@ -88,6 +88,9 @@ def load_library():
         "isca_dyn_cold_start": [H],
         "isca_dyn_step": [H, C.c_int, C.c_int],
         "isca_dyn_synchronize": [H],
+        "isca_dyn_dynamics": [H, dp, dp, dp, dp, C.c_int, C.c_int],
+        "isca_dyn_set_tendencies": [H, dp, dp, dp, dp, C.c_int],
+        "isca_dyn_delta_t": [H, dp],
         "isca_dyn_step_phase": [H, C.c_int],
         "isca_dyn_exchange_buffers": [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
         "isca_dyn_reduce_buffer": [H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
@@ -146,7 +149,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
-    "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_step_phase", "isca_dyn_exchange_buffers",
+    "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_dynamics", "isca_dyn_set_tendencies", "isca_dyn_delta_t", "isca_dyn_step_phase",
+    "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
     "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
@@ -415,6 +419,34 @@ class DynCore:
         out = C.c_double()
         self._check(self.lib.isca_area_weighted_global_mean(self._h, _dptr(a), C.cast(C.byref(out), C.POINTER(C.c_double))))
         return out.value
+
+    # ---- physics = 2: the host keeps its own physics package and hands its tendencies to the dynamics (atmosphere.F90:300-329)
+    def delta_t(self):
+        """Time step the physics of the coming step receives (dt_atmos on a first step, else 2 dt_atmos: atmosphere.F90:286-290)."""
+        v = C.c_double()
+        self._check(self.lib.isca_dyn_delta_t(self._h, C.byref(v)))
+        return v.value
+
+    def _tend_ptrs(self, arrs):
+        keep, ptrs = [], []
+        for a in arrs:
+            if a is None:
+                ptrs.append(None)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                if a.shape != (self.L, self.Jl, self.I):
+                    raise IscaError("physics tendencies must be (lev, lat_local, lon) arrays")
+                keep.append(a); ptrs.append(_dptr(a))
+        return keep, ptrs
+
+    def set_tendencies(self, dt_ug=None, dt_vg=None, dt_tg=None, dt_tracers=None):
+        keep, ptrs = self._tend_ptrs((dt_ug, dt_vg, dt_tg, dt_tracers))
+        self._check(self.lib.isca_dyn_set_tendencies(self._h, *ptrs, 0))
+
+    def dynamics(self, dt_ug=None, dt_vg=None, dt_tg=None, dt_tracers=None, sync=True):
+        """spectral_dynamics (spectral_dynamics.F90:780-795) with the caller's physics tendencies: one step."""
+        keep, ptrs = self._tend_ptrs((dt_ug, dt_vg, dt_tg, dt_tracers))
+        self._check(self.lib.isca_dyn_dynamics(self._h, *ptrs, 0, 1 if sync else 0))
 
     def hs_forcing(self, dt, p_half, p_full, u, v, t, udt=None, vdt=None, tdt=None):
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (p_half, p_full, u, v, t)]

@@ -20,7 +20,7 @@ import shutil
 import tarfile
 
 from . import atmosphere as atm
-from .diag import DiagTable, History
+from .diag import DiagCollector, DiagTable, History
 from .dyncore import RESOLUTIONS, IscaError
 
 
@@ -120,17 +120,14 @@ class Experiment:
             core = atm.atmosphere_init(copy.deepcopy(self.namelist), run_dir=self.rundir)
             hist = [History(core, spec, dt, os.path.join(self.rundir, name + ".nc"), start_seconds=(i - 1) * nsteps * dt)
                     for name, spec in self.diag_table.files.items() if spec["fields"]]
-            if len({tuple(h.names) for h in hist}) > 1:
-                raise IscaError("diag_table: all files of one run must list the same dynamics fields")
+            collector = DiagCollector(core, hist)         # one set of device sums, shared by all files of the table
             chunk = nsteps
             for h in hist:
                 chunk = math.gcd(chunk, h.every)
             for _ in range(nsteps // chunk):
                 atm.atmosphere(chunk)
-                for h in hist:
-                    h.after_steps(chunk)
-            for h in hist:
-                h.close()
+                collector.after_steps(chunk)
+            collector.close()
             atm.atmosphere_end()
         except IscaError as e:
             atm.atmosphere_end()

@@ -129,26 +129,65 @@ class ShardedDynCore(dyncore.DynCore):
                     why = str(bad[0])
                 else:
                     self.native = True
-            if why is not None and cfg.rank == 0:
-                print(f"isca_amd: native RCCL exchange not available ({why}); exchanges go through torch.distributed", flush=True)
+            if why is not None:
+                # a silent fall-back would be a silent order-of-magnitude slowdown: torch.distributed between the phases has to be asked for
+                raise dyncore.IscaError(f"native RCCL exchange not available ({why}); set ISCA_COMM=torch to drive the exchanges through "
+                                        "torch.distributed between the device phases")
+
+    def _torch_step(self):
+        self.step_phase(0)                                          # grid tendencies + FFT (+ tracer halo rows)
+        if self._halo is not None:
+            halo_exchange(*self._halo, group=self.group)            # fv_advection's mpp_update_domains
+            self.step_phase(4)                                      # tracer transport on the side stream: runs under the exchange
+        exchange(self._bufs[0][0], self._bufs[0][1], self.group)    # lat -> m   (transpose_fourier)
+        self.step_phase(1)                                          # Legendre, spectral update, Legendre
+        exchange(self._bufs[1][0], self._bufs[1][1], self.group)    # m -> lat   (reverse_transpose_fourier)
+        self.step_phase(2)                                          # inverse FFT + local fixer sums
+        allreduce_sum(self._red, self.group)                        # global means
+        self.step_phase(3)                                          # fixers, time-level rotation
+
+    def _agree(self, err):
+        """error_mesg(..., FATAL) stops every PE: a rank whose band left valid_range_t must not leave the others in the next collective"""
+        import torch.distributed as dist
+        flags = [None] * self.cfg.world_size
+        dist.all_gather_object(flags, err, group=self.group)
+        bad = [(r, f) for r, f in enumerate(flags) if f is not None]
+        if bad:
+            raise dyncore.IscaError(f"rank {bad[0][0]}: {bad[0][1]}")
+
+    def _run(self, native_call, torch_call, sync):
+        err = None
+        if self.native:
+            try:
+                native_call()
+            except dyncore.IscaError as e:
+                if not sync:
+                    raise
+                err = str(e)
+        else:
+            with self._torch.cuda.stream(self._stream):
+                torch_call()
+            if sync:
+                self._stream.synchronize()
+                try:
+                    self.synchronize()             # valid-range check of the temperatures, like isca_dyn_step(sync)
+                except dyncore.IscaError as e:
+                    err = str(e)
+        if sync:
+            self._agree(err)
 
     def step(self, nsteps: int = 1, sync: bool = True):
-        if self.native:
-            return super().step(nsteps, sync)
-        with self._torch.cuda.stream(self._stream):
+        def torch_steps():
             for _ in range(nsteps):
-                self.step_phase(0)                                          # grid tendencies + FFT (+ tracer halo rows)
-                if self._halo is not None:
-                    halo_exchange(*self._halo, group=self.group)            # fv_advection's mpp_update_domains
-                exchange(self._bufs[0][0], self._bufs[0][1], self.group)    # lat -> m   (transpose_fourier)
-                self.step_phase(1)                                          # Legendre, spectral update, Legendre
-                exchange(self._bufs[1][0], self._bufs[1][1], self.group)    # m -> lat   (reverse_transpose_fourier)
-                self.step_phase(2)                                          # inverse FFT + local fixer sums
-                allreduce_sum(self._red, self.group)                        # global means
-                self.step_phase(3)                                          # fixers, time-level rotation
-        if sync:
-            self._stream.synchronize()
-            self.synchronize()                 # valid-range check of the temperatures, like isca_dyn_step(sync)
+                self._torch_step()
+        self._run(lambda: dyncore.DynCore.step(self, nsteps, sync), torch_steps, sync)
+
+    def dynamics(self, dt_ug=None, dt_vg=None, dt_tg=None, dt_tracers=None, sync=True):
+        """physics = 2 on a sharded run: this rank's band of the tendencies, then one step"""
+        def torch_step():
+            self.set_tendencies(dt_ug, dt_vg, dt_tg, dt_tracers)
+            self._torch_step()
+        self._run(lambda: dyncore.DynCore.dynamics(self, dt_ug, dt_vg, dt_tg, dt_tracers, sync), torch_step, sync)
 
     def gather_grid(self, name, time_level=1):
         """all-gather a grid field to every rank (tests/diagnostics): [lev, lat_global, lon]"""

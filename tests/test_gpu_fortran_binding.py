@@ -46,6 +46,30 @@ def test_fortran_driver_matches_reference_run(tmp_path, golden_dir):
     assert "FORTRAN_ERROR" in out and "unknown field" in out          # the FATAL convention: non-zero return + message
 
 
+def test_fortran_external_physics_driver(tmp_path, golden_dir):
+    """The physics / dynamics seam of atmosphere.F90:300-329 from Fortran (physics = 2): the driver evaluates hs_forcing itself (through
+    isca_hs_forcing / isca_hs_tracer_source_sink on the fields the library hands out) and feeds the tendencies to isca_dyn_dynamics
+    (= spectral_dynamics, spectral_dynamics.F90:780-795); 144 steps land on the reference run."""
+    if not os.path.exists(FLANG):
+        pytest.skip("no flang in this image")
+    src = os.path.join(REPO, "bindings", "fortran")
+    lib = os.path.join(REPO, "isca_amd", "lib")
+    mod_o, exe = str(tmp_path / "isca_dyn_c.o"), str(tmp_path / "drive_external_physics.x")
+    subprocess.run([FLANG, "-c", os.path.join(src, "isca_dyn_c.F90"), "-o", mod_o, "-module-dir", str(tmp_path)], check=True, capture_output=True)
+    subprocess.run([FLANG, os.path.join(src, "drive_external_physics.F90"), mod_o, "-I", str(tmp_path), "-L", lib, "-lisca_dyn",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nums = lambda tag: [float(x) for x in re.search(tag + r"\s*(.*)", r.stdout).group(1).split()]
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    tg, ug, tr = g["st_tg_000144"], g["st_ug_000144"], g["st_tr1_000144"]
+    tmin, tmax, umax = nums("FORTRAN_STATE Tmin,Tmax,maxabsU=")
+    assert abs(tmin - tg.min()) < 1e-9 and abs(tmax - tg.max()) < 1e-9 and abs(umax - np.abs(ug).max()) < 1e-9
+    t_pt, u_pt, r_pt = nums(r"FORTRAN_POINT tg\(5,7,20\),ug\(33,12,3\),tr\(9,30,25\)=")
+    assert abs(t_pt - tg[19, 6, 4]) < 1e-9 and abs(u_pt - ug[2, 11, 32]) < 1e-9 and abs(r_pt - tr[24, 29, 8]) < 1e-9 * np.abs(tr).max()
+    assert "FORTRAN_ERROR" in r.stdout and "physics = 2" in r.stdout
+
+
 def test_fortran_moist_driver(tmp_path, golden_dir):
     """The Frierson configuration set from Fortran through the nested bind(C) types (isca_moist_config, bk array): 144 steps on the GPU land
     on the reference's moist run."""

@@ -129,6 +129,30 @@ def test_golden_T85L40_benchmark_config(golden_dir):
     dc.close()
 
 
+def test_external_physics_seam(golden_dir):
+    """physics = 2 (the spectral_dynamics seam of atmosphere.F90:300-329): the host evaluates hs_forcing on the fields the library hands
+    out and gives the tendencies to isca_dyn_dynamics.  One day at T21L25: against the reference run (1e-9) and against the library's own
+    atmosphere() with the forcing fused into its column kernel (same arithmetic in two kernels: 1e-11)."""
+    g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
+    dc = make("T21", 25, physics=2); dc.cold_start()
+    ref = make("T21", 25); ref.cold_start()
+    with pytest.raises(dyncore.IscaError, match="physics = 2"):
+        dc.step(1)
+    for _ in range(144):
+        dt = dc.delta_t()
+        u, v, t, q = dc.get("ug", 0), dc.get("vg", 0), dc.get("tg", 0), dc.get("tr_atm", 0)
+        ph, pf = dc.get("p_half", 1), dc.get("p_full", 1)
+        du, dv, dT = dc.hs_forcing(dt, ph, pf, u, v, t)
+        dc.dynamics(du, dv, dT, dc.hs_tracer_source_sink(ph[-1], q))
+    ref.step(144)
+    for k, gk in (("ug", "st_ug_000144"), ("vg", "st_vg_000144"), ("tg", "st_tg_000144"), ("psg", "st_psg_000144"), ("tr", "st_tr1_000144")):
+        scale = max(np.abs(g[gk]).max(), 1.0 if k in ("ug", "vg") else 1e-300)
+        e_ref, e_own = np.abs(dc.get(k) - g[gk]).max() / scale, np.abs(dc.get(k) - ref.get(k)).max() / scale
+        print("external physics, 144 steps:", k, "vs reference %.2e" % e_ref, "vs fused forcing %.2e" % e_own)
+        assert e_ref < 1e-9 and e_own < 1e-11, (k, e_ref, e_own)
+    dc.close(); ref.close()
+
+
 def test_golden_T170L60_stress_config(golden_dir):
     """BASELINE configs[4] at its full size (T170L60 Held-Suarez, dt = 150 s): steps 1 and 8 from the cold start against the reference
     run, on the committed [5::6, ::16, ::16] sample (ps: [::8, ::8]); winds as a fraction of max(|u|, 1 m/s)."""
@@ -376,9 +400,9 @@ def test_atmosphere_module_mirror(golden_dir):
     """The module-level mirror of atmosphere_mod / transforms_mod drives the same C-ABI."""
     from isca_amd import atmosphere as atm
     g = np.load(os.path.join(golden_dir, "run_T21L25.npz"))
-    nml = {"main_nml": {"dt_atmos": 600}, "spectral_dynamics_nml": {"damping_order": 4, "num_levels": 25,
-           "vert_coord_option": "uneven_sigma", "scale_heights": 6.0, "exponent": 7.5, "surf_res": 0.5,
-           "reference_sea_level_press": 1.0e5, "valid_range_t": [100., 800.]}}
+    from isca_amd import configs
+    nml = configs.held_suarez()                     # the test case's namelist; what it leaves out takes the reference's module defaults
+    nml["spectral_dynamics_nml"]["num_levels"] = 25
     atm.atmosphere_init(nml, resolution="T21")
     u0, v0, t0, p0 = atm.get_initial_fields()
     assert rel(t0, np.full_like(t0, 264.0)) < 1e-12
@@ -401,7 +425,9 @@ def test_restart_is_bit_exact(tmp_path, first):
     first = 1 restarts right after the forward (dt) step, when the two time levels still alias."""
     from isca_amd import atmosphere as atm, restart
     total = 20
-    nml = {"main_nml": {"dt_atmos": 600}, "spectral_dynamics_nml": {"num_levels": 12}}
+    from isca_amd import configs
+    nml = configs.held_suarez()                      # = the library's preset that make() uses
+    nml["spectral_dynamics_nml"]["num_levels"] = 12
     ref = make("T21", 12)
     ref.cold_start()
     ref.step(total)
@@ -483,10 +509,11 @@ def test_experiment_restart_chaining(tmp_path):
     """Two chained segments (res0001.tar.gz -> INPUT/) equal one segment of twice the length, bit for bit."""
     from isca_amd.experiment import Experiment
     from isca_amd import restart
-    nml = {"main_nml": {"days": 0, "hours": 2, "dt_atmos": 600}, "spectral_dynamics_nml": {"damping_order": 4}}
+    from isca_amd import configs
     a = Experiment("chained", str(tmp_path))
+    a.update_namelist(configs.held_suarez())                  # the test case's namelist = the preset of make() below
+    a.update_namelist({"main_nml": {"days": 0, "hours": 2, "dt_atmos": 600}})
     a.set_resolution("T21", 10)
-    a.update_namelist(nml)
     a.diag_table.add_file("atmos_hourly", 1, "hours", time_units="days")
     for nm in ("ps", "ucomp", "temp"):
         a.diag_table.add_field("dynamics", nm, time_avg=True)
@@ -655,3 +682,42 @@ def test_diagnostics_time_means(tmp_path):
     assert np.allclose(f.variables["average_DT"][:], 2.0 / 24.0) and np.allclose(f.variables["time"][:], [1 / 24, 3 / 24, 5 / 24])
     assert f.variables["temp"].units == b"deg_k" and abs(float(f.variables["temp"][:].mean()) - 264.0) < 1.0
     f.close(); c.close()
+
+
+def test_diagnostics_two_history_files(tmp_path):
+    """Two files of one diag_table with different intervals and different field lists: each gets the means of its own intervals (the
+    device holds one set of sums per handle; DiagCollector takes them off chunk by chunk and every file keeps its own)."""
+    from isca_amd.diag import DiagCollector, DiagTable, History
+    from scipy.io import netcdf_file
+    L = 6
+    diag = DiagTable()
+    diag.add_file("atmos_1h", 1, "hours")
+    diag.add_file("atmos_3h", 3, "hours")
+    diag.add_field("dynamics", "temp", time_avg=True)                          # both files
+    diag.add_field("dynamics", "ucomp", time_avg=True, files=["atmos_1h"])
+    diag.add_field("dynamics", "ps", time_avg=True, files=["atmos_3h"])
+    diag.add_field("dynamics", "vcomp", time_avg=False, files=["atmos_3h"])    # instantaneous
+    a = make("T21", L); a.cold_start(); a.step(4)
+    b = make("T21", L); b.cold_start(); b.step(4)
+    hist = [History(a, diag.files[nm], 600.0, str(tmp_path / (nm + ".nc"))) for nm in ("atmos_1h", "atmos_3h")]
+    col = DiagCollector(a, hist)
+    snaps = []
+    for _ in range(6):                                                         # 6 hours in 1-hour chunks (gcd of the intervals)
+        a.step(6); col.after_steps(6)
+        for _ in range(6):
+            b.step(1); snaps.append((b.get("tg"), b.get("ug"), b.get("psg")))
+    v_end = a.get("vg")
+    col.close()
+    f1 = netcdf_file(str(tmp_path / "atmos_1h.nc"), "r", mmap=False)
+    f3 = netcdf_file(str(tmp_path / "atmos_3h.nc"), "r", mmap=False)
+    assert f1.variables["temp"].shape[0] == 6 and f3.variables["temp"].shape[0] == 2
+    assert "ucomp" in f1.variables and "ps" not in f1.variables and "ps" in f3.variables and "ucomp" not in f3.variables
+    for r in range(6):
+        assert rel(f1.variables["temp"][r], sum(s[0] for s in snaps[6 * r:6 * r + 6]) / 6) < 1e-14
+        assert rel(f1.variables["ucomp"][r], sum(s[1] for s in snaps[6 * r:6 * r + 6]) / 6) < 1e-13
+    for r in range(2):
+        assert rel(f3.variables["temp"][r], sum(s[0] for s in snaps[18 * r:18 * r + 18]) / 18) < 1e-14
+        assert rel(f3.variables["ps"][r], sum(s[2] for s in snaps[18 * r:18 * r + 18]) / 18) < 1e-14
+    assert np.array_equal(f3.variables["vcomp"][1], v_end)
+    assert np.allclose(f3.variables["average_DT"][:], 3.0) and np.allclose(f1.variables["average_DT"][:], 1.0)
+    f1.close(); f3.close(); a.close(); b.close()

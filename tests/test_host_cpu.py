@@ -110,6 +110,20 @@ def test_namelist_to_config(lib):
     assert (c.lon_max, c.lat_max, c.num_fourier, c.num_levels) == (128, 64, 42, 25)
     assert c.dt_atmos == 600.0 and c.water_correction_limit == 200.e2 and list(c.valid_range_t) == [100.0, 800.0]
     assert c.do_conserve_energy == 1 and c.ka == -40.0
+    # what an input.nml leaves out takes the reference's module defaults (spectral_dynamics.F90:152-206), not the test-case preset
+    m = atm.config_from_namelist({"main_nml": {"dt_atmos": 900}, "spectral_dynamics_nml": {"num_levels": 10}})
+    assert (m.lon_max, m.num_fourier, m.damping_order, m.vert_coord_input) == (128, 42, 2, 1) and m.reference_sea_level_press == 101325.0
+    assert (m.scale_heights, m.exponent, m.surf_res, m.water_correction_limit) == (4.0, 2.5, 0.1, 0.0) and list(m.valid_range_t) == [100.0, 500.0]
+    assert [m.bk_input[k] for k in (0, 5, 10)] == [0.0, 0.5, 1.0]                        # vert_coord_option defaults to 'even_sigma'
+    assert atm.config_from_namelist(None, "T21").scale_heights == 6.0                    # no namelist: the Held-Suarez test case
+    for key, bad in (("use_virtual_temperature", True), ("use_implicit", False)):
+        with pytest.raises(dyncore.IscaError, match=key):
+            atm.config_from_namelist({"spectral_dynamics_nml": {key: bad}})
+    with pytest.raises(dyncore.IscaError, match="convection_scheme is not set"):          # moist options whose reference default is not implemented
+        atm.config_from_namelist({"atmosphere_nml": {"idealized_moist_model": True}})
+    from isca_amd import configs
+    fr = atm.config_from_namelist(configs.frierson())
+    assert fr.physics == 1 and fr.moist.depth == 2.5 and fr.moist.ir_tau_eq == 6.0 and fr.moist.tau_bm == 7200.0   # set / module default
     d = {"spectral_dynamics_nml": {"damping_order": 4, "vert_coord_option": "hybrid"}}
     with pytest.raises(dyncore.IscaError, match="vert_coord_option"):
         atm.config_from_namelist(d, "T21")
@@ -220,19 +234,21 @@ def test_moist_namelist_mapping():
     implement are refused like unsupported namelist values (no GPU needed: only the config is built)."""
     from isca_amd import atmosphere as atm, dyncore
     bk = [0.0, 0.2, 0.5, 0.8, 1.0]
-    nml = {"atmosphere_nml": {"idealized_moist_model": True}, "main_nml": {"dt_atmos": 720},
-           "spectral_dynamics_nml": {"num_levels": 4, "vert_coord_option": "input", "robert_coeff": 0.03, "initial_sphum": 2e-6},
-           "vert_coordinate_nml": {"bk": bk, "pk": [0.0] * 5},
-           "two_stream_gray_rad_nml": {"rad_scheme": "frierson", "atm_abs": 0.2, "do_seasonal": False},
-           "mixed_layer_nml": {"depth": 10.0, "albedo_value": 0.25, "delta_T": 30.0, "evaporation": True},
-           "qe_moist_convection_nml": {"rhbm": 0.8, "Tmin": 150.0},
-           "damping_driver_nml": {"do_rayleigh": True, "trayfric": -0.5, "do_conserve_energy": False}}
+    from isca_amd import configs
+    nml = configs.frierson()                       # the test case's option switches; some values changed, some left to the module defaults
+    nml.update({"atmosphere_nml": {"idealized_moist_model": True}, "main_nml": {"dt_atmos": 720},
+                "spectral_dynamics_nml": {"num_levels": 4, "vert_coord_option": "input", "robert_coeff": 0.03, "initial_sphum": 2e-6},
+                "vert_coordinate_nml": {"bk": bk, "pk": [0.0] * 5},
+                "two_stream_gray_rad_nml": {"rad_scheme": "frierson", "atm_abs": 0.2, "do_seasonal": False},
+                "mixed_layer_nml": {"depth": 10.0, "albedo_value": 0.25, "delta_T": 30.0, "evaporation": True, "prescribe_initial_dist": True},
+                "qe_moist_convection_nml": {"rhbm": 0.8, "Tmin": 150.0},
+                "damping_driver_nml": {"do_rayleigh": True, "trayfric": -0.5, "do_conserve_energy": False}})
     c = atm.config_from_namelist(nml, resolution="T21")
     assert c.physics == 1 and c.vert_coord_input == 1 and [c.bk_input[i] for i in range(5)] == bk and c.num_levels == 4
     m = c.moist
     assert (m.atm_abs, m.depth, m.albedo_value, m.delta_T, m.evaporation) == (0.2, 10.0, 0.25, 30.0, 1)
-    assert (m.rhbm, m.Tmin, m.Tmax, m.trayfric, m.damping_conserve_energy) == (0.8, 150.0, 350.0, -0.5, 0)
-    assert m.roughness_mom == 3.21e-05 and m.rich_crit == 2.0               # defaults of the test case / modules
+    assert (m.rhbm, m.Tmin, m.Tmax, m.trayfric, m.damping_conserve_energy) == (0.8, 150.0, 335.0, -0.5, 0)
+    assert m.roughness_mom == 3.21e-05 and m.rich_crit == 2.0 and m.tconst == 305.0      # test case value / module defaults
     text = "&atmosphere_nml idealized_moist_model = .true. /\n&two_stream_gray_rad_nml rad_scheme = 'byrne' /\n"
     with pytest.raises(dyncore.IscaError, match="not a supported value for rad_scheme"):
         atm.config_from_namelist(text)
@@ -248,7 +264,7 @@ def test_moist_namelist_mapping():
     assert (mars.radius, mars.omega) == (3389.5e3, 7.088e-5)
     with pytest.raises(dyncore.IscaError, match="only radius and omega"):
         atm.config_from_namelist({"constants_nml": {"grav": 3.71}})
-    dry = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 25}})
+    dry = atm.config_from_namelist({"spectral_dynamics_nml": {"num_levels": 25, "vert_coord_option": "uneven_sigma"}})
     assert dry.physics == 0 and dry.vert_coord_input == 0
 
 
@@ -277,8 +293,9 @@ def test_sibling_core_namelists():
 def test_test_case_config_files(lib):
     """isca_amd/configs.py holds the namelists of the two reference test cases key for key; both map onto the C config."""
     from isca_amd import atmosphere as atm, configs
-    hs = atm.config_from_namelist(configs.held_suarez(), resolution="T42")
+    hs = atm.config_from_namelist(configs.held_suarez(), resolution="T42", num_levels=25)     # exp.set_resolution('T42', 25) of the test case
     assert (hs.physics, hs.num_levels, hs.dt_atmos, hs.lat_max, hs.scale_heights, hs.ka, hs.initial_sphum) == (0, 25, 600.0, 64, 6.0, -40.0, 0.0)
+    assert atm.config_from_namelist(configs.held_suarez(), resolution="T42").num_levels == 18    # spectral_dynamics_nml's own default
     fr = atm.config_from_namelist(configs.frierson(), resolution="T42")
     assert (fr.physics, fr.num_levels, fr.dt_atmos, fr.initial_sphum, fr.robert_coeff, fr.vert_coord_input) == (1, 25, 720.0, 2.e-6, 0.03, 1)
     assert fr.bk_input[1] == 0.0117665 and fr.moist.atm_abs == 0.2 and fr.moist.depth == 2.5 and fr.moist.trayfric == -0.25

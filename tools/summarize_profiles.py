@@ -21,7 +21,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
         for c, v in cs.items():
             tot[k][c] = sum(v) / len(v)
 def short(name):
-    n = name.split("(")[0]
+    n = name.replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("void ", "").replace("isca::", "")
     return n.split("<")[0]
 bytes_per_launch = {}
