@@ -53,6 +53,9 @@ type, bind(C) :: isca_dyn_config
   real(c_double) :: pk_input(ISCA_MAX_LEVELS + 1), bk_input(ISCA_MAX_LEVELS + 1)
   type(isca_moist_config) :: moist
   real(c_double) :: radius, omega
+  integer(c_int) :: damping_option, cutoff_wn
+  real(c_double) :: damping_coeff_vor, damping_coeff_div
+  integer(c_int) :: damping_order_vor, damping_order_div
 end type
 
 interface

@@ -60,7 +60,7 @@ typedef struct isca_dyn_config {
   int triang_trunc;             /* must be 1 */
   double dt_atmos;              /* seconds */
   /* spectral_dynamics_nml */
-  int damping_order;            /* damping_option = 'resolution_dependent' */
+  int damping_order;            /* see damping_option at the end of the struct */
   double damping_coeff;
   double eddy_sponge_coeff, zmu_sponge_coeff, zmv_sponge_coeff;
   double robert_coeff;
@@ -79,7 +79,7 @@ typedef struct isca_dyn_config {
   int do_conserve_energy;
   double trflux, trsink, P00;
   /* decomposition: latitude bands in grid space, zonal-wavenumber sets in spectral space
-   * (spec_mpp.F90:61-80).  world_size must divide lat_max/2. */
+   * (spec_mpp.F90:61-80).  world_size must divide lat_max. */
   int rank, world_size;
   int device;                   /* HIP device ordinal */
   void *stream;                 /* hipStream_t to run on, or NULL for a private stream */
@@ -93,6 +93,12 @@ typedef struct isca_dyn_config {
   double pk_input[ISCA_MAX_LEVELS + 1], bk_input[ISCA_MAX_LEVELS + 1];
   isca_moist_config moist;
   double radius, omega;         /* constants_nml: planetary radius (m) and rotation rate (1/s); defaults 6376.0e3, 7.2921150e-5 */
+  /* spectral_damping_init (spectral_damping.F90:56-168): damping_option 0 = 'resolution_dependent', 1 = 'exponential_cutoff' (with
+   * cutoff_wn; the effective coefficient then depends on the step's delta_t, :186-190), 2 = 'resolution_independent'; separate
+   * coefficient / order for vorticity and divergence, negative = those of damping_coeff / damping_order (spectral_dynamics.F90:447-452) */
+  int damping_option, cutoff_wn;
+  double damping_coeff_vor, damping_coeff_div;
+  int damping_order_vor, damping_order_div;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -11,6 +11,7 @@ grid (lon,lat,lev) <-> [lev,lat,lon], spectral (m,n,lev) <-> [lev,n,m].
 from __future__ import annotations
 
 import os
+import sys
 import re
 import numpy as np
 
@@ -63,10 +64,12 @@ _REF_DEFAULTS = dict(
     lon_max=128, lat_max=64, num_fourier=42, num_spherical=43, fourier_inc=1, num_levels=18, damping_coeff=1.15740741e-4,
     eddy_sponge_coeff=0., zmu_sponge_coeff=0., zmv_sponge_coeff=0., robert_coeff=.04, alpha_implicit=.5, scale_heights=4., surf_res=.1,
     exponent=2.5, initial_sphum=0.0, reference_sea_level_press=101325., water_correction_limit=0.0, raw_filter_coeff=1.0,
-    valid_range_t=(100., 500.), dt_atmos=0.0,
+    valid_range_t=(100., 500.), dt_atmos=0.0, cutoff_wn=15, damping_coeff_vor=-1., damping_coeff_div=-1., damping_order_vor=-1,
+    damping_order_div=-1,
     t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=1, trflux=1.e-5,
     trsink=-4., P00=1.e5)
 _REF_VERT_COORD_OPTION = "even_sigma"            # spectral_dynamics.F90:175
+_DAMPING_OPTIONS = {"resolution_dependent": 0, "exponential_cutoff": 1, "resolution_independent": 2}     # spectral_damping.F90:124-153
 # moist package, isca_moist_config members: idealized_moist_phys.F90:136-138, two_stream_gray_rad.F90:72-82, mixed_layer.F90:84-95,
 # qe_moist_convection.F90:66-70, damping_driver.f90:42-56, vert_turb_driver.F90:116, diffusivity.F90:127-128, monin_obukhov.F90:88-89
 _MOIST_REF_DEFAULTS = dict(
@@ -197,7 +200,11 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     if moist:
         kw["physics"] = 1
         kw["moist"] = _moist_config(namelist)
-    unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma") else "uneven_sigma", "damping_option": "resolution_dependent",
+    dopt = str(namelist.get("spectral_dynamics_nml", {}).get("damping_option", "resolution_dependent")).lower()
+    if dopt not in _DAMPING_OPTIONS:
+        raise IscaError(f'"{dopt}" is an invalid value for damping_option')                      # spectral_damping.F90:152-153
+    kw["damping_option"] = _DAMPING_OPTIONS[dopt]
+    unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma") else "uneven_sigma", "damping_option": dopt,
                    "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
                    "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}
@@ -239,6 +246,7 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
         return _core                                   # `if(module_is_initialized) return`
     _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
     _run_dir = run_dir
+    _setup_progress_log(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}))
     inp = None if run_dir is None else os.path.join(run_dir, "INPUT")
     try:
         if inp is not None and restart.restart_exists(inp):
@@ -252,11 +260,74 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     return _core
 
 
+# ---- the progress line of spectral_diagnostics -> global_integrals (spectral_dynamics.F90:1836-1840, 1869-1912): every
+# print_interval (spectral_dynamics_nml, (days, seconds), default one day) rank 0 prints "Integration completed through ..." or, with
+# json_logging, the machine-readable line the harness's progress bar parses ({"day":, "second":, "max_speed":, "avg_T":}).
+_progress: dict | None = None
+
+
+def _setup_progress_log(namelist: dict):
+    global _progress
+    nml = {g.lower(): {k.lower(): v for k, v in vals.items()} for g, vals in namelist.items()}
+    sd, mn = nml.get("spectral_dynamics_nml", {}), nml.get("main_nml", {})
+    if "print_interval" not in sd and not sd.get("json_logging", False):
+        _progress = None                                   # library use without a namelist request: silent
+        return
+    pi = sd.get("print_interval", [1, 0])
+    pi = list(pi) if isinstance(pi, (list, tuple)) else [pi, 0]
+    every = (pi[0] * 86400 + (pi[1] if len(pi) > 1 else 0)) / float(_core.cfg.dt_atmos)
+    if every < 1 or every != int(every):
+        raise IscaError("spectral_dynamics_nml: print_interval must be a positive multiple of dt_atmos")
+    cal = str(mn.get("calendar", "no_calendar")).lower()
+    date = list(mn.get("current_date", [0, 0, 0, 0, 0, 0]))
+    _progress = {"every": int(every), "json": bool(sd.get("json_logging", False)), "calendar": cal, "date0": date, "out": sys.stdout}
+
+
+def global_integrals():
+    """spectral_dynamics.F90:1869-1912: maximum wind speed and area mean of the lowest-level temperature of the current level."""
+    c = _need()
+    u, v, t = c.get("ug"), c.get("vg"), c.get("tg")
+    return float(np.sqrt(u * u + v * v).max()), c.area_weighted_global_mean(t[-1])
+
+
+def _progress_line():
+    c, p = _core, _progress
+    secs = int(round(c.info("step") * c.cfg.dt_atmos))
+    max_speed, avg_t = global_integrals()
+    days, rem = divmod(secs, 86400)
+    if p["calendar"] in ("no_calendar", "none"):
+        if p["json"]:
+            line = ' {"day":%6d  ,"second":%6d  ,"max_speed":%13.6E   ,"avg_T":%13.6E   }' % (days, rem, max_speed, avg_t)
+        else:
+            line = " Integration completed through%6d days%6d seconds" % (days, rem)
+    else:                                                   # thirty_day: 12 months of 30 days from main_nml's current_date
+        y0, m0, d0, h0, mi0, s0 = (p["date0"] + [0] * 6)[:6]
+        tot = ((((y0 * 12 + max(m0, 1) - 1) * 30 + max(d0, 1) - 1) * 24 + h0) * 60 + mi0) * 60 + s0 + secs
+        tot, sec = divmod(tot, 60); tot, mnt = divmod(tot, 60); tot, hr = divmod(tot, 24); tot, dy = divmod(tot, 30); yr, mo = divmod(tot, 12)
+        if p["json"]:
+            line = ' {"date": "%04d-%02d-%02d", "time": "%02d:%02d:%02d", "max_speed":%6.1f   ,"avg_T":%6.1f   }' % (
+                yr, mo + 1, dy + 1, hr, mnt, sec, max_speed, avg_t)
+        else:
+            names = (" Jan", " Feb", " Mar", " Apr", " May", " Jun", " Jul", " Aug", " Sep", " Oct", " Nov", " Dec")
+            line = " Integration completed through%5d%s%3d  %2d:%2d:%2d" % (yr, names[mo], dy + 1, hr, mnt, sec)
+    print(line, file=p["out"], flush=True)
+
+
 def atmosphere(nsteps: int = 1):
-    """atmosphere.F90:276-352: one call advances the model by dt_atmos."""
+    """atmosphere.F90:276-352: one call advances the model by dt_atmos (nsteps calls here)."""
     if _core is None:
         raise IscaError("atmosphere: atmosphere module is not initialized")
-    _core.step(nsteps)
+    if _progress is None:
+        _core.step(nsteps)
+        return
+    left = nsteps
+    while left > 0:                                         # stop at every alarm of print_interval
+        done = _core.info("step")
+        chunk = min(left, _progress["every"] - done % _progress["every"])
+        _core.step(chunk)
+        left -= chunk
+        if (done + chunk) % _progress["every"] == 0:
+            _progress_line()
 
 
 def atmosphere_end():

@@ -97,6 +97,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->rank = 0; c->world_size = 1; c->device = 0; c->stream = nullptr; c->legendre_impl = 0;
   // moist package (physics = 1): module defaults overridden by frierson_test_case.py:49-170
   c->physics = 0; c->vert_coord_input = 0;
+  c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
   m.solar_constant = 1360.0; m.del_sol = 1.4; m.del_sw = 0.0; m.ir_tau_eq = 6.0; m.ir_tau_pole = 1.5; m.atm_abs = 0.2; m.odp = 1.0;
@@ -140,9 +141,14 @@ static void check_config(const isca_dyn_config &c) {
   if (c.lon_max & (c.lon_max - 1)) fail("lon_max must be a power of two (Stockham FFT kernel)");
   if (c.lat_max % 8) fail("lat_max must be a multiple of 8");
   if (c.num_levels > 64) fail("num_levels must be <= 64 (one wavefront lane per level in the spectral update)");
-  if (c.raw_filter_coeff != 1.0) fail("raw_filter_coeff must be 1.0");
+  if (!(c.raw_filter_coeff > 0.0 && c.raw_filter_coeff <= 1.0)) fail("raw_filter_coeff must be in (0, 1]");
+  if (c.raw_filter_coeff != 1.0 && c.world_size > 1)
+    fail("raw_filter_coeff /= 1 needs a third transform phase per step, which the sharded step does not have: world_size must be 1");
   if (c.robert_coeff < 0. || c.robert_coeff > 1.) fail("invalid robert_coeff");
   if (c.damping_order < 0 || c.damping_coeff < 0.) fail("invalid damping");
+  if (c.damping_option < 0 || c.damping_option > 2)
+    fail("spectral_damping_init: damping_option must be 0 'resolution_dependent', 1 'exponential_cutoff' or 2 'resolution_independent'");
+  if (c.damping_option == 1 && (c.cutoff_wn < 0 || c.cutoff_wn >= c.num_spherical - 1)) fail("spectral_damping_init: cutoff_wn outside the truncation");
   if ((c.do_energy_correction) && !c.do_mass_correction) fail("energy_correction requires mass_correction");
   if (c.world_size < 1 || c.rank < 0 || c.rank >= c.world_size) fail("invalid rank/world_size");
   if (c.lat_max % c.world_size) fail("lat_max must be divisible by world_size (spec_mpp.F90:69-75)");
@@ -211,6 +217,19 @@ extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
 
 static void upload_wave_matrices(isca_dyn *h, double delta_t) {
   if (h->wave_dt == delta_t) return;
+  if (h->tab.damping_exponential) {                // spectral_damping.F90:186-190: the effective coefficients of a step of this length
+    const Geom &g = h->g;
+    std::vector<double> e[3], cf((size_t)3 * g.Ml * g.N1, 0.0);
+    h->tab.damping_effective(delta_t, e[0], e[1], e[2]);
+    for (int id = 0; id < 3; ++id)
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_local[ml];
+        if (m < 0) continue;
+        for (int n = 0; n < g.N1; ++n) cf[((size_t)id * g.Ml + ml) * g.N1 + n] = e[id][(size_t)n * g.M1 + m];
+      }
+    HIP_CHECK(hipMemcpyAsync(h->d.coef + (size_t)10 * g.Ml * g.N1, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
   h->tab.build_wave_matrices(h->cfg, delta_t);     // implicit.F90:260-264: rebuilt when dt changes
   const int L = h->g.L, nw = h->cfg.num_spherical;
   std::vector<double> wt((size_t)nw * L * L);
@@ -309,10 +328,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       }
     }
     {  // coefficient tables per local m
-      const std::vector<double> *src[11] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
-                                            &T.coef_dym, &T.coef_dx, &T.coef_dyp, &T.tri_mask, &T.damping};
-      std::vector<double> cf((size_t)11 * g.Ml * g.N1, 0.0);
-      for (int id = 0; id < 11; ++id)
+      const std::vector<double> *src[13] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
+                                            &T.coef_dym, &T.coef_dx, &T.coef_dyp, &T.tri_mask, &T.damping, &T.damping_vor, &T.damping_div};
+      std::vector<double> cf((size_t)13 * g.Ml * g.N1, 0.0);     // rows 10-12 (damping): refreshed per delta_t with 'exponential_cutoff'
+      for (int id = 0; id < 13; ++id)
         for (int ml = 0; ml < g.Ml; ++ml) {
           const int m = h->h_m_local[ml];
           if (m < 0) continue;
@@ -367,6 +386,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.g_dtu = dalloc<double>(h, ng3); d.g_dtv = dalloc<double>(h, ng3); d.g_dtT = dalloc<double>(h, ng3);
     d.g_E = dalloc<double>(h, ng3); d.g_dtlp = dalloc<double>(h, ng2);
     d.s_dtvor = dalloc<double>(h, ns3); d.s_dtdiv = dalloc<double>(h, ns3); d.s_dtT = dalloc<double>(h, ns3); d.s_dtlp = dalloc<double>(h, ns2);
+    if (cfg->raw_filter_coeff != 1.0) {
+      d.part_vor = dalloc<double>(h, ns3); d.part_div = dalloc<double>(h, ns3); d.part_t = dalloc<double>(h, ns3); d.part_lp = dalloc<double>(h, ns2);
+      d.tr_part = dalloc<double>(h, ng3);
+    }
     // ---- work buffers sized for the largest batch (7L+3 level-fields)
     h->cap_cols = 7 * g.L + 3;
     const size_t nF = (size_t)g.P * g.Ml * g.Jl * 2 * h->cap_cols, nS = (size_t)g.Ml * g.N1 * 2 * h->cap_cols;
@@ -414,7 +437,15 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr;
     bool pure_sigma = true;
     for (double v : T.pk) if (v != 0.0) pure_sigma = false;
-    h->tracer_on = pure_sigma && (cfg->num_tracers > 0) && (g.Jl >= 4) && (g.L >= 5) && !getenv("ISCA_NO_TRACER");
+    // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need pure sigma levels, >= 4
+    // latitude rows per rank and >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be
+    // dropped without a word; num_tracers = 0 is the way to run without one (field_table without tracers).
+    const bool tracer_can = pure_sigma && (g.Jl >= 4) && (g.L >= 5);
+    if (cfg->num_tracers > 0 && !tracer_can)
+      fail("spectral_dynamics_init: the grid tracer needs pure sigma levels (pk = 0), num_levels >= 5 and lat_max / world_size >= 4; "
+           "set num_tracers = 0 to run without it");
+    h->tracer_env_off = getenv("ISCA_NO_TRACER") != nullptr;   // measurement switch, reported by isca_dyn_get_info("tracer_env_off")
+    h->tracer_on = tracer_can && (cfg->num_tracers > 0) && !h->tracer_env_off;
     if (cfg->physics == 1) {                  // idealized_moist_phys_init: tables, surface state, tendency arrays
       if (!h->tracer_on) fail("idealized_moist_phys: the specific-humidity grid tracer is not available in this configuration");
       h->moist = moist_create(h->cfg, T);
@@ -789,8 +820,29 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
   if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
+// raw_filter_coeff /= 1: the reference completes the filter of the NEW level after its grid fields have been synthesised
+// (complete_robert_filter, spectral_dynamics.F90:1031), so u, v, T, ps, vor, div of that level stay those of the unadjusted spectral
+// state while the next step's gradients of T and ln ps (:855, :890) come from the adjusted one: a third transform phase.
+static void raw_filter_phase(isca_dyn *h, const StepScalars &sc) {
+  const Geom &g = h->g;
+  Dev &d = h->d;
+  { Timed t(h, "raw_adjust"); launch_raw_adjust(*h, sc.fut, h->stream); }
+  FieldList fl;
+  fl.nf = 4;
+  double *gp[4] = {d.dxT, d.dyT, d.dxlp, d.dylp};
+  int off = 0;
+  for (int i = 0; i < 4; ++i) { fl.g[i] = gp[i]; fl.nlev[i] = i < 2 ? g.L : 1; fl.off[i] = off; fl.op[i] = OP_COSM; off += fl.nlev[i]; }
+  fl.ncol = off;
+  const int C = 2 * fl.ncol;
+  Timed t(h, "raw_gradients");
+  launch_spec_gradient(g, d, d.ts[sc.fut], d.Si, C, 0, g.L, g.L, h->stream);
+  launch_spec_gradient(g, d, d.lnps[sc.fut], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
+  launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, 0, h->cfg.legendre_impl, h->stream);
+  launch_fft_inverse(g, d, fl, d.Fi_g, h->stream);
+}
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+  if (h->cfg.raw_filter_coeff != 1.0) raw_filter_phase(h, sc);
   if (h->diag_mask) {   // spectral_diagnostics(Time_next, psg(future), ug(future), ...) at the end of atmosphere (atmosphere.F90:344)
     Timed t(h, "diagnostics"); launch_diag_accumulate(*h, sc.fut, h->stream);
     h->diag_count += 1;
@@ -1119,6 +1171,7 @@ extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
   else if (nm == "lat_start") *value = h->g.j0;
   else if (nm == "m_local") *value = h->g.Ml; else if (nm == "kernels_per_step") *value = h->kernels_per_step;
   else if (nm == "tracer") *value = h->tracer_on ? 1 : 0;
+  else if (nm == "tracer_env_off") *value = h->tracer_env_off ? 1 : 0;
   else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
   else fail("unknown info " + nm);
   API_END

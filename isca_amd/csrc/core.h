@@ -85,6 +85,8 @@ struct Dev {
   double *Ff_g, *Ff_s, *Fi_s, *Fi_g;                // Fourier buffers (grid side / spectral side)
   double *Sf, *Si;                                  // spectral work [Ml][N1][Cf], [Ml][N1][Ci]
   double *s_dtvor, *s_dtdiv, *s_dtT, *s_dtlp;       // spectral tendencies [Ml][N1][L]
+  // raw_filter_coeff /= 1 only: prev - 2 cur of the spectral fields and of the grid tracer (leapfrog_2level_A's part_filt_*)
+  double *part_vor = nullptr, *part_div = nullptr, *part_t = nullptr, *part_lp = nullptr, *tr_part = nullptr;
   double *partials;                                 // block partial sums
   double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18]
   double *scratch_g[4], *scratch_s[4];              // API transforms
@@ -129,7 +131,8 @@ struct isca_dyn {
   int n_active = 0;
   bool fuse_synth = false;
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
-  bool tracer_on = false;           // advect the grid tracer (single rank)
+  bool tracer_on = false;           // advect the grid tracer
+  bool tracer_env_off = false;      // ISCA_NO_TRACER was set when the handle was created
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers
   unsigned diag_mask = 0;           // spectral_diagnostics fields being accumulated (bit = index in DIAG_NAMES)
   long diag_count = 0;              // send_data calls since the last reset

@@ -60,6 +60,7 @@ void launch_spec_gradient(const Geom &g, const Dev &d, const double *state, doub
 void launch_spec_tendencies(const isca_dyn &h, hipStream_t s);                       // S1
 void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s);    // S2
 void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s);         // S3
+void launch_raw_adjust(const isca_dyn &h, int fut, hipStream_t s);                   // future half of the RAW filter (raw_filter_coeff /= 1)
 void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, double robert, double *const st[4][3],
                               double *const dtend[4], hipStream_t s);                 // parts of S2 on caller data
 

@@ -22,7 +22,7 @@ __device__ __forceinline__ double2 cscale(double s, double2 a) { return make_dou
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ double2 ctimes_i(double2 a) { return make_double2(-a.y, a.x); }   // cmplx(-aimag, real)
 
-enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP, C_MASK, C_DAMP, C_COUNT };
+enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP, C_MASK, C_DAMP, C_DAMP_VOR, C_DAMP_DIV, C_COUNT };
 
 // =====================================================================================================
 // Longitude FFT (grid_fourier.F90:129-179, fft99.F90:578-727): real <-> half-complex of length I = 2^p,
@@ -510,6 +510,10 @@ struct SpecUpdateArgs {
   const int *m_local;
   int C;
   double delta_t, xi, ref_p, ref_t, robert, eddy_sponge, zmu_sponge, zmv_sponge;
+  // raw_filter_coeff /= 1 (Robert-Asselin-Williams): the part of the filter that is known before the new level exists,
+  // prev - 2 cur (leapfrog_2level_A's part_filt_*), is kept for the end of the step (leapfrog_2level_B); null when raw = 1
+  double raw;
+  double2 *part_vor, *part_div, *part_t, *part_lp;
 };
 
 __device__ __forceinline__ void lin_tp(double2 dv, int lane, int L, double dp, double dlog1, double dlog3, double ref_t,
@@ -553,6 +557,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
   const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
   const double eig = COEF(C_EIG, ml, n), dmp = COEF(C_DAMP, ml, n);   // read before the first store (scalar path)
+  const double dmp_v = COEF(C_DAMP_VOR, ml, n), dmp_d = COEF(C_DAMP_DIV, ml, n);
   const int mglob = a.m_local[ml];
   const double2 zero = make_double2(0., 0.);
   // unconditional loads (idx is valid for every lane) masked afterwards: `c ? lvalue : lvalue` on a double2 selects
@@ -638,8 +643,8 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   // --- damping
   if (!(MODE & SU_NO_DAMPING)) {
     const double cf = 1.0 / (1.0 + dmp * a.delta_t);
-    dt_vor = cscale(cf, csub(dt_vor, cscale(dmp, vprev)));
-    dt_div = cscale(cf, csub(dt_div, cscale(dmp, dprev)));
+    dt_vor = cscale(1.0 / (1.0 + dmp_v * a.delta_t), csub(dt_vor, cscale(dmp_v, vprev)));
+    dt_div = cscale(1.0 / (1.0 + dmp_d * a.delta_t), csub(dt_div, cscale(dmp_d, dprev)));
     dt_t = cscale(cf, csub(dt_t, cscale(dmp, tprev)));
     if (lane == 0 && (a.eddy_sponge != 0.0 || a.zmu_sponge != 0.0 || a.zmv_sponge != 0.0)) {   // sponge on the top level (:236-245, :281-290)
       const double sv = (mglob != 0) ? a.eddy_sponge * eig : a.zmu_sponge * eig;
@@ -652,21 +657,41 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }
     return;
   }
-  // --- leapfrog_2level_A then _B (Robert filter, raw_filter_coeff = 1)
-  const double rc = a.robert, dtt = a.delta_t;
-#define LEAP(PREV, CUR, DT, ARR, IDX, GUARD)                                        \
+  // --- leapfrog_2level_A then the `current` half of _B (leapfrog.F90:58-105); rc = robert_coeff * raw_filter_coeff.  The `future`
+  // half of _B (only with raw_filter_coeff /= 1) is applied at the end of the step, after the grid fields have been synthesised from
+  // the unadjusted new level like the reference does (spectral_dynamics.F90:933-937 before :1031), by k_raw_adjust.
+  const double rc = a.robert * a.raw, dtt = a.delta_t;
+#define LEAP(PREV, CUR, DT, ARR, PART, IDX, GUARD)                                  \
   {                                                                                 \
     const double2 part = make_double2(PREV.x - 2.0 * CUR.x, PREV.y - 2.0 * CUR.y);  \
     const double2 nf = make_double2(PREV.x + dtt * DT.x, PREV.y + dtt * DT.y);      \
     double2 nc = make_double2(CUR.x + rc * part.x, CUR.y + rc * part.y);            \
     nc = make_double2(nc.x + rc * nf.x, nc.y + rc * nf.y);                          \
-    if (GUARD) { ARR##_c[IDX] = nc; ARR##_f[IDX] = nf; }                            \
+    if (GUARD) { ARR##_c[IDX] = nc; ARR##_f[IDX] = nf; if (PART) PART[IDX] = part; } \
   }
-  LEAP(vprev, vcur, dt_vor, a.vors, idx, act)
-  LEAP(dprev, dcur, dt_div, a.divs, idx, act)
-  LEAP(tprev, tcur, dt_t, a.ts, idx, act)
-  LEAP(lprev, lcur, dt_lp, a.lnps, mn, lane == 0)
+  LEAP(vprev, vcur, dt_vor, a.vors, a.part_vor, idx, act)
+  LEAP(dprev, dcur, dt_div, a.divs, a.part_div, idx, act)
+  LEAP(tprev, tcur, dt_t, a.ts, a.part_t, idx, act)
+  LEAP(lprev, lcur, dt_lp, a.lnps, a.part_lp, mn, lane == 0)
 #undef LEAP
+}
+
+// leapfrog_2level_B's future half for raw_filter_coeff /= 1 (leapfrog.F90:101-102, called from complete_robert_filter at the very end
+// of spectral_dynamics, :1031): a(future) += robert (raw - 1) (part_filt + a(future)), on the retained coefficients of the four fields
+__global__ void k_raw_adjust(size_t n3, size_t n2, double f, double2 *vor, double2 *div, double2 *ts, double2 *lnps,
+                             const double2 *__restrict__ pv, const double2 *__restrict__ pd, const double2 *__restrict__ pt,
+                             const double2 *__restrict__ pl) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  auto adj = [&](double2 *x, const double2 *p) { double2 v = x[i]; const double2 q = p[i]; v.x += f * (q.x + v.x); v.y += f * (q.y + v.y); x[i] = v; };
+  if (i < n3) { adj(vor, pv); adj(div, pd); adj(ts, pt); }
+  if (i < n2) adj(lnps, pl);
+}
+void launch_raw_adjust(const isca_dyn &h, int fut, hipStream_t s) {
+  const Geom &g = h.g;
+  const size_t n3 = (size_t)g.Ml * g.N1 * g.L, n2 = (size_t)g.Ml * g.N1;
+  hipLaunchKernelGGL(k_raw_adjust, grid1d(n3), dim3(256), 0, s, n3, n2, h.cfg.robert_coeff * (h.cfg.raw_filter_coeff - 1.0), (double2 *)h.d.vors[fut],
+                     (double2 *)h.d.divs[fut], (double2 *)h.d.ts[fut], (double2 *)h.d.lnps[fut], (const double2 *)h.d.part_vor,
+                     (const double2 *)h.d.part_div, (const double2 *)h.d.part_t, (const double2 *)h.d.part_lp);
 }
 
 void launch_spec_tendencies(const isca_dyn &h, hipStream_t s) {
@@ -686,6 +711,8 @@ static SpecUpdateArgs spec_update_args(const isca_dyn &h, const StepScalars &sc)
   a.Sf = h.d.Sf; a.C = h.Cf;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
+  a.raw = h.cfg.raw_filter_coeff;
+  a.part_vor = (double2 *)h.d.part_vor; a.part_div = (double2 *)h.d.part_div; a.part_t = (double2 *)h.d.part_t; a.part_lp = (double2 *)h.d.part_lp;
   return a;
 }
 void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -707,6 +734,7 @@ void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, doub
   a.lnps_p = (double2 *)st[3][0]; a.lnps_c = (double2 *)st[3][1]; a.lnps_f = (double2 *)st[3][2];
   a.dtvor = (double2 *)dtend[0]; a.dtdiv = (double2 *)dtend[1]; a.dtT = (double2 *)dtend[2]; a.dtlp = (double2 *)dtend[3];
   a.robert = robert;
+  a.part_vor = a.part_div = a.part_t = a.part_lp = nullptr;
   const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
   const dim3 grid((unsigned)(h.n_active / 4)), block(256);
   if (stage == 0) hipLaunchKernelGGL(k_spec_update<SU_GIVEN | SU_STOP_IMPLICIT>, grid, block, lds, s, g, a);
@@ -1228,6 +1256,7 @@ struct TracerArgs {
   const int *kmask;
   double *wcol;
   double dx, dt, flux, rdamp, robert;
+  double *tr_part;
 };
 
 // tracer_source_sink (hs_forcing.F90:683-724): surface flux into the lowest level, linear sink
@@ -1578,7 +1607,7 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
       const double trf = rk + a.dt * rdt;
       // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): everything was read at the top
       const double q0 = tr_q0_of(a, g, k, tpv[t], tav[t], ps);
-      newc[t] = tcv[t] + a.robert * (tpv[t] - 2.0 * tcv[t]);      // leapfrog part A on the grid tracer (:1164-1167)
+      newc[t] = tcv[t] + a.robert * (tpv[t] - 2.0 * tcv[t]);      // leapfrog part A on the grid tracer (:1164-1167); robert includes raw_filter_coeff
       newf[t] = trf;
       // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
       const double msk = (k >= km) ? 1.0 : 0.0;
@@ -1589,7 +1618,11 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   }
 #pragma unroll
   for (int t = 0; t < CH; ++t)
-    if (t < nk) { const size_t q = (size_t)(k0 + t) * lev + c2; a.tr_cur[q] = newc[t]; a.tr_fut[q] = newf[t]; }
+    if (t < nk) {
+      const size_t q = (size_t)(k0 + t) * lev + c2;
+      a.tr_cur[q] = newc[t]; a.tr_fut[q] = newf[t];
+      if (a.tr_part) a.tr_part[q] = tpv[t] - 2.0 * tcv[t];        // part_filt_tr (:1164), for the future half of the RAW filter
+    }
   red[0][w][tid] = s0; red[1][w][tid] = s1; red[2][w][tid] = s2; red[3][w][tid] = s3; red[4][w][tid] = s4;
   __syncthreads();
   if (w < 5) {
@@ -1610,7 +1643,8 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.rcdx = d.fv_rcdx; a.rdyy = d.fv_rdyy; a.rcdy = d.fv_rcdy; a.rdy = d.fv_rdy; a.ppm = d.ppm_tab;
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
-  a.robert = h.cfg.robert_coeff;
+  a.robert = h.cfg.robert_coeff * h.cfg.raw_filter_coeff;
+  a.tr_part = d.tr_part;
   if (h.cfg.physics != 0) {     // sphum / the caller's tracer: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
     a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0;
   }
@@ -1815,6 +1849,8 @@ struct FixerArgs {
   double sumw_nlon;        // global_sum_of_wts * num_lon
   double robert;
   int do_mass, do_energy, do_water;
+  double raw;                 // raw_filter_coeff; tr_part: prev - 2 cur of the tracer (RAW filter), null when raw = 1
+  const double *tr_part;
 };
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
@@ -1875,8 +1911,13 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
           double2 f = fv[u], c = cv[u];
           if (kk[u] >= km0[u]) f.x *= wfac;
           if (kk[u] >= km1[u]) f.y *= wfac;
-          c.x += a.robert * f.x; c.y += a.robert * f.y;
-          *(double2 *)(a.tr_fut + i) = f; *(double2 *)(a.tr_cur + i) = c; *(double2 *)(a.tratm_fut + i) = f;
+          c.x += a.robert * a.raw * f.x; c.y += a.robert * a.raw * f.y;
+          *(double2 *)(a.tratm_fut + i) = f;                  // atmosphere_mod's copy is taken before the filter is completed (:1028)
+          if (a.tr_part) {                                    // leapfrog_2level_B's future half (leapfrog.F90:102)
+            const double2 pt = *(const double2 *)(a.tr_part + i);
+            f.x += a.robert * (a.raw - 1.0) * (pt.x + f.x); f.y += a.robert * (a.raw - 1.0) * (pt.y + f.y);
+          }
+          *(double2 *)(a.tr_fut + i) = f; *(double2 *)(a.tr_cur + i) = c;
         }
       }
     }
@@ -1898,12 +1939,12 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
       if (k == 0 && a.do_mass) {
         const double dl = s2 * log(factor);
         a.lnps_fut[mn].x += dl;
-        a.lnps_cur[mn].x += a.robert * dl;
+        a.lnps_cur[mn].x += a.robert * a.raw * dl;
       }
       if (k < g.L && a.do_energy) {
         const double dtc = s2 * tcorr;
         a.ts_fut[mn * g.L + k].x += dtc;
-        a.ts_cur[mn * g.L + k].x += a.robert * dtc;
+        a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
       }
     }
   }
@@ -1935,7 +1976,7 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   double sumw = 0.0;
   for (double w : h.tab.wts_lat) sumw += w;
   a.sumw_nlon = sumw * g.I;
-  a.robert = h.cfg.robert_coeff;
+  a.robert = h.cfg.robert_coeff; a.raw = h.cfg.raw_filter_coeff; a.tr_part = h.d.tr_part;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
   const size_t n3 = (size_t)g.Jl * g.I * g.L;
   const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);

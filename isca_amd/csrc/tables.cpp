@@ -173,10 +173,34 @@ void Tables::build(const isca_dyn_config &c) {
       coef_alpp[q] = sw * eps[qp] / radius;
       coef_dyp[q] = (sw + 2.0) * eps[qp] / radius;
     }
-  // --- spectral_damping.F90:124-127 ('resolution_dependent')
-  damping.assign(NM, 0);
-  const double eref = eigen[(size_t)(c.num_spherical - 1) * M1 + 0];
-  for (size_t q = 0; q < NM; ++q) damping[q] = c.damping_coeff * std::pow(eigen[q] / eref, c.damping_order);
+  // --- spectral_damping_init (spectral_damping.F90:56-168)
+  {
+    const double cv = c.damping_coeff_vor < 0. ? c.damping_coeff : c.damping_coeff_vor, cd = c.damping_coeff_div < 0. ? c.damping_coeff : c.damping_coeff_div;
+    const int ov = c.damping_order_vor < 0 ? c.damping_order : c.damping_order_vor, od = c.damping_order_div < 0 ? c.damping_order : c.damping_order_div;
+    damping.assign(NM, 0); damping_vor.assign(NM, 0); damping_div.assign(NM, 0);
+    damping_coeffs[0] = c.damping_coeff; damping_coeffs[1] = cv; damping_coeffs[2] = cd;
+    damping_exponential = c.damping_option == 1;
+    const double eref = eigen[(size_t)(c.num_spherical - 1) * M1 + 0];
+    if (c.damping_option == 0) {                 // 'resolution_dependent' (:124-127)
+      for (size_t q = 0; q < NM; ++q) {
+        damping[q] = c.damping_coeff * std::pow(eigen[q] / eref, c.damping_order);
+        damping_vor[q] = cv * std::pow(eigen[q] / eref, ov);
+        damping_div[q] = cd * std::pow(eigen[q] / eref, od);
+      }
+    } else if (c.damping_option == 1) {          // 'exponential_cutoff' (:129-146): one exponent table for the three
+      const double ecut = eigen[(size_t)c.cutoff_wn * M1 + 0], scut = std::sqrt(ecut), sref = std::sqrt(eref);
+      for (size_t q = 0; q < NM; ++q) {
+        const double v = (eigen[q] / ecut > 1.) ? std::pow((std::sqrt(eigen[q]) - scut) / (sref - scut), c.damping_order) : 0.0;
+        damping[q] = damping_vor[q] = damping_div[q] = v;
+      }
+    } else {                                     // 'resolution_independent' (:148-151)
+      for (size_t q = 0; q < NM; ++q) {
+        damping[q] = c.damping_coeff * std::pow(eigen[q], c.damping_order);
+        damping_vor[q] = cv * std::pow(eigen[q], ov);
+        damping_div[q] = cd * std::pow(eigen[q], od);
+      }
+    }
+  }
   // --- vertical coordinate: init/vert_coordinate.F90:248-273 ('uneven_sigma', zero_top)
   pk.assign(L + 1, 0.0); bk.assign(L + 1, 0.0);
   if (c.vert_coord_input) {                    // 'input': vert_coordinate_nml's pk, bk as given (vert_coordinate.F90:150-160)
@@ -298,6 +322,15 @@ void Tables::build(const isca_dyn_config &c) {
 }
 
 // implicit.F90:221-237
+// compute_spectral_damping (spectral_damping.F90:186-190, :216-220, :263-267): the coefficient applied in a step of length delta_t
+void Tables::damping_effective(double delta_t, std::vector<double> &t, std::vector<double> &vor, std::vector<double> &div) const {
+  t = damping; vor = damping_vor; div = damping_div;
+  if (!damping_exponential) return;
+  std::vector<double> *out[3] = {&t, &vor, &div};
+  for (int i = 0; i < 3; ++i)
+    for (double &v : *out[i]) v = (std::exp(std::log(delta_t * damping_coeffs[i] + 1.0) * v) - 1.0) / delta_t;
+}
+
 void Tables::build_wave_matrices(const isca_dyn_config &c, double dt) {
   xi = dt * c.alpha_implicit;
   const int ntw = c.num_spherical - 1;

@@ -22,7 +22,12 @@ struct Tables {
   std::vector<double> legendre;                  // [J/2][N1][M1]  (Fortran (m,n,j))
   // spherical.F90 coefficient tables, [N1][M1]
   std::vector<double> eigen, coef_uvm, coef_uvc, coef_uvp, coef_alpm, coef_alpp, coef_dym, coef_dx, coef_dyp, tri_mask;
-  std::vector<double> damping;                   // [N1][M1], same for vor/div/T with default options
+  // spectral_damping.F90:124-156: tables for T (and tracers), vorticity, divergence, [N1][M1].  With 'exponential_cutoff' they hold the
+  // EXPONENT of the filter and the effective coefficient depends on the step's delta_t (damping_effective)
+  std::vector<double> damping, damping_vor, damping_div;
+  bool damping_exponential = false;
+  double damping_coeffs[3] = {0., 0., 0.};        // damping_coeff, _vor, _div as used by the exponential form
+  void damping_effective(double delta_t, std::vector<double> &t, std::vector<double> &vor, std::vector<double> &div) const;
   std::vector<double> pk, bk, dpk, dbk;          // [L+1], [L]
   // implicit.F90
   std::vector<double> ref_ln_p_half, ref_ln_p_full, h_impl, div_mat;   // [L+1],[L],[L],[L*L] (row-major k,kk)

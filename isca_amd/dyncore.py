@@ -59,6 +59,8 @@ class _CConfig(C.Structure):
         ("physics", C.c_int), ("vert_coord_input", C.c_int),
         ("pk_input", C.c_double * (MAX_LEVELS + 1)), ("bk_input", C.c_double * (MAX_LEVELS + 1)),
         ("moist", _CMoistConfig), ("radius", C.c_double), ("omega", C.c_double),
+        ("damping_option", C.c_int), ("cutoff_wn", C.c_int), ("damping_coeff_vor", C.c_double), ("damping_coeff_div", C.c_double),
+        ("damping_order_vor", C.c_int), ("damping_order_div", C.c_int),
     ]
 
 

@@ -42,6 +42,11 @@ class Config:
     damping_order: int = 4
     damping_coeff: float = 1.15740741e-4
     damping_option: str = "resolution_dependent"
+    cutoff_wn: int = 15
+    damping_coeff_vor: float = -1.0
+    damping_coeff_div: float = -1.0
+    damping_order_vor: int = -1
+    damping_order_div: int = -1
     robert_coeff: float = 0.04
     raw_filter_coeff: float = 1.0
     alpha_implicit: float = 0.5
@@ -210,12 +215,27 @@ class SpectralCore:
         self.coriolis = 2 * self.cfg.omega * self.sin_lat                      # spectral_dynamics.F90:445
         # --- damping: spectral_damping.F90:124-156 ---
         eig = self.eigen_laplacian
-        if c.damping_option != "resolution_dependent":
-            raise NotImplementedError(c.damping_option)
+        cv = c.damping_coeff if c.damping_coeff_vor < 0 else c.damping_coeff_vor
+        cd = c.damping_coeff if c.damping_coeff_div < 0 else c.damping_coeff_div
+        ov = c.damping_order if c.damping_order_vor < 0 else c.damping_order_vor
+        od = c.damping_order if c.damping_order_div < 0 else c.damping_order_div
         ref = eig[c.num_spherical - 1, 0]
-        self.damping = c.damping_coeff * ((eig / ref) ** c.damping_order)
-        self.damping_vor = self.damping.copy()
-        self.damping_div = self.damping.copy()
+        self.damping_exponential = c.damping_option == "exponential_cutoff"
+        self.damping_coeffs = {"t": c.damping_coeff, "vor": cv, "div": cd}
+        if c.damping_option == "resolution_dependent":
+            self.damping = c.damping_coeff * ((eig / ref) ** c.damping_order)
+            self.damping_vor = cv * ((eig / ref) ** ov)
+            self.damping_div = cd * ((eig / ref) ** od)
+        elif c.damping_option == "exponential_cutoff":                      # spectral_damping.F90:129-146
+            se, cut = np.sqrt(eig), eig[c.cutoff_wn, 0]
+            d = np.where(eig / cut > 1, ((se - np.sqrt(cut)) / (np.sqrt(ref) - np.sqrt(cut))) ** c.damping_order, 0.0)
+            self.damping, self.damping_vor, self.damping_div = d, d.copy(), d.copy()
+        elif c.damping_option == "resolution_independent":
+            self.damping = c.damping_coeff * (eig ** c.damping_order)
+            self.damping_vor = cv * (eig ** ov)
+            self.damping_div = cd * (eig ** od)
+        else:
+            raise ValueError(c.damping_option)
         self.damping_eddy_sponge = c.eddy_sponge_coeff * eig
         self.damping_zmu_sponge = c.zmu_sponge_coeff * eig[:, 0]
         self.damping_zmv_sponge = c.zmv_sponge_coeff * eig[:, 0]
@@ -595,6 +615,8 @@ class SpectralCore:
     # ----------------------------------------------------------------------------------------
     def compute_spectral_damping(self, spec, dt_spec, dt, kind="t"):
         d = {"t": self.damping, "vor": self.damping_vor, "div": self.damping_div}[kind]
+        if self.damping_exponential:                                         # spectral_damping.F90:186-190
+            d = (np.exp(np.log(dt * self.damping_coeffs[kind] + 1.0) * d) - 1.0) / dt
         coeff = 1.0 / (1.0 + d * dt)
         out = coeff * (dt_spec - d * spec)
         if kind in ("vor", "div"):

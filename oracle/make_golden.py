@@ -364,16 +364,17 @@ def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=120
     return out
 
 
-def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None):
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra=""):
+    """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win)"""
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
-        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps)
+        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra)
         stdout = run_harness(d)
         out = read_outputs(d, res, L)
     if keep is not None:
         out = {k: v for k, v in out.items() if keep(k)}
     m = re.search(r"REF_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
     out["final_Tmin_Tmax_maxabsU"] = np.array([float(x) for x in m.groups()])
-    meta = dict(res=res, num_levels=L, dt_atmos=float(dt), nsteps=nsteps)
+    meta = dict(res=res, num_levels=L, dt_atmos=float(dt), nsteps=nsteps, extra=extra)
     out.update({"meta_" + k: np.array(v) for k, v in meta.items()})
     return out
 
@@ -429,6 +430,17 @@ def main():
             "T21", 100, (1, 100), nml=SHALLOW_NML + " &constants_nml\n    radius = 55000.e3, omega = 1.6e-4\n /\n",
             keep=lambda k: k.startswith("tab_") or re.match(r"st_(u|v|vor|div|h|tr|trs|vors|hs)_000(001|100)$", k)),
         "tables_T42": lambda: golden_run("T42", 2, 0, (), keep=lambda k: k.startswith("tab_")),
+        # options of spectral_damping_init (spectral_damping.F90:124-156) on short T21L8 runs (36 steps): the exponential cut-off filter,
+        # whose effective coefficient depends on the step's delta_t, and separate vorticity / divergence coefficients and orders
+        "run_T21L8_damping_exponential": lambda: golden_run(
+            "T21", 8, 36, (36,), extra="damping_option = 'exponential_cutoff', cutoff_wn = 10, damping_order = 3, damping_coeff = 2.3e-4, "
+            "damping_coeff_vor = 1.2e-4, damping_coeff_div = 4.6e-4", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
+        "run_T21L8_damping_vor_div": lambda: golden_run(
+            "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
+            "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
+        "run_T21L8_damping_res_independent": lambda: golden_run(
+            "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
     }
     for name, fn in jobs.items():
         if a.only and a.only != name:

@@ -153,6 +153,29 @@ def test_external_physics_seam(golden_dir):
     dc.close(); ref.close()
 
 
+@pytest.mark.parametrize("case,opts", [
+    ("exponential", dict(damping_option=1, cutoff_wn=10, damping_order=3, damping_coeff=2.3e-4, damping_coeff_vor=1.2e-4, damping_coeff_div=4.6e-4)),
+    ("vor_div", dict(damping_option=0, damping_order=4, damping_coeff_vor=3.0e-4, damping_order_vor=2, damping_coeff_div=6.0e-4, damping_order_div=3)),
+    ("res_independent", dict(damping_option=2, damping_order=2, damping_coeff=2.0e16))])
+def test_golden_damping_options(golden_dir, case, opts):
+    """spectral_damping_init's options (spectral_damping.F90:124-156): 'exponential_cutoff' (effective coefficient per delta_t),
+    separate vorticity / divergence coefficients and orders, 'resolution_independent' -- 36 steps at T21L8 against the reference run."""
+    g = np.load(os.path.join(golden_dir, f"run_T21L8_damping_{case}.npz"))
+    dc = make("T21", 8, **opts); dc.cold_start()
+    dc.step(36)
+    err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_000036"]).max() / max(np.abs(g[f"st_{k}_000036"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+           for k in ("ug", "vg", "tg", "psg")}
+    err["tr"] = rel(dc.get("tr"), g["st_tr1_000036"])
+    print("damping option", case, err)
+    assert max(err.values()) < 1e-9, err
+    dc.close()
+    from isca_amd import atmosphere as atm
+    with pytest.raises(dyncore.IscaError, match="invalid value for damping_option"):
+        atm.config_from_namelist({"spectral_dynamics_nml": {"damping_option": "spectral_viscosity"}})
+    c = atm.config_from_namelist({"spectral_dynamics_nml": {"damping_option": "exponential_cutoff", "cutoff_wn": 12}})
+    assert (c.damping_option, c.cutoff_wn) == (1, 12)
+
+
 def test_golden_T170L60_stress_config(golden_dir):
     """BASELINE configs[4] at its full size (T170L60 Held-Suarez, dt = 150 s): steps 1 and 8 from the cold start against the reference
     run, on the committed [5::6, ::16, ::16] sample (ps: [::8, ::8]); winds as a fraction of max(|u|, 1 m/s)."""
@@ -268,10 +291,11 @@ def test_edge_sizes_vs_oracle(res, L, steps):
     lane per level in the spectral update), level counts that leave wavefronts partly empty."""
     dyncore.RESOLUTIONS.setdefault("T5", dict(lon_max=16, lat_max=8, num_fourier=5, num_spherical=6))
     dyncore.RESOLUTIONS.setdefault("T10", dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11))
-    dc = make(res, L); dc.cold_start()
+    dc = make(res, L, **({} if L >= 5 else {"num_tracers": 0})); dc.cold_start()     # below 5 levels: configured without the tracer
     sc = oracle(res, L); sc.cold_start()
     dc.step(steps)
     tracer = bool(dc.info("tracer"))
+    assert tracer == (L >= 5)
     for _ in range(steps):
         sc.step(with_tracer=tracer)
     c = sc.current
@@ -366,7 +390,9 @@ def test_constants_nml_radius_omega():
     """constants_nml radius / omega: the transforms do not depend on the radius, the derivative operators scale with 1/a, the Laplacian
     with 1/a^2, the Coriolis parameter with omega (the 3-D core's tables are the ones the sibling cores use)."""
     rng = np.random.default_rng(5)
-    e, m = make("T21", 3), make("T21", 3, radius=3389.5e3, omega=7.088e-5)        # Earth, Mars
+    with pytest.raises(dyncore.IscaError, match="num_tracers = 0"):               # 3 levels cannot carry the PPM-advected tracer: FATAL, not dropped
+        make("T21", 3)
+    e, m = make("T21", 3, num_tracers=0), make("T21", 3, radius=3389.5e3, omega=7.088e-5, num_tracers=0)        # Earth, Mars
     g = rng.standard_normal((3, e.J, e.I))
     s = e.trans_grid_to_spherical(g)
     assert np.array_equal(s, m.trans_grid_to_spherical(g))
@@ -416,6 +442,30 @@ def test_atmosphere_module_mirror(golden_dir):
 
 # ------------------------------------------------------------------ restart files
 ALL_STATE = ("vors", "divs", "ts", "ln_ps", "ug", "vg", "tg", "psg", "tr", "tr_atm", "vorg", "divg", "wg_full")
+
+
+def test_progress_log_line(capsys):
+    """global_integrals (spectral_dynamics.F90:1869-1912): every print_interval the JSON line the harness's progress bar parses, with the
+    reference's own numbers for configs[0] (maximum wind speed, area mean of the lowest-level temperature after one day)."""
+    import json as _json
+    from isca_amd import atmosphere as atm, configs
+    nml = configs.held_suarez()
+    nml["spectral_dynamics_nml"].update(num_levels=25, json_logging=True, print_interval=[0, 43200])
+    nml["main_nml"] = {"dt_atmos": 600, "calendar": "no_calendar"}
+    core = atm.atmosphere_init(nml, resolution="T21")
+    atm.atmosphere(100); atm.atmosphere(44)                 # alarms at steps 72 and 144, across two calls
+    lines = [_json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.strip().startswith("{")]
+    assert [(d["day"], d["second"]) for d in lines] == [(0, 43200), (1, 0)]
+    u, v, t = core.get("ug"), core.get("vg"), core.get("tg")
+    assert abs(lines[1]["max_speed"] - np.sqrt(u * u + v * v).max()) < 1e-5 and abs(lines[1]["avg_T"] - core.area_weighted_global_mean(t[-1])) < 1e-3
+    assert abs(np.abs(u).max() - 1.148573) < 1e-5           # SURVEY 8c: max |u| = 1.148573 m/s after 144 steps (max_speed also counts v)
+    atm.atmosphere_end()
+    nml["main_nml"] = {"dt_atmos": 600, "calendar": "thirty_day", "current_date": [2000, 1, 1, 0, 0, 0]}
+    atm.atmosphere_init(nml, resolution="T21")
+    atm.atmosphere(72)
+    (d,) = [_json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.strip().startswith("{")]
+    assert (d["date"], d["time"]) == ("2000-01-01", "12:00:00")
+    atm.atmosphere_end()
 
 
 @pytest.mark.parametrize("first", [1, 9])

@@ -17,9 +17,9 @@ def rel(a, b):
     return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300)
 
 
-def core(res, L):
+def core(res, L, **options):
     lon, lat, nf, ns = RES[res]
-    return SpectralCore(Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns, num_levels=L))
+    return SpectralCore(Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns, num_levels=L, **options))
 
 
 @pytest.fixture(scope="module", params=[("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6)])
@@ -161,6 +161,28 @@ def test_trajectory_T21L25_one_day(golden_dir):
     assert abs(np.abs(s["ug"]).max() - umax) < 1e-9
     # SURVEY 8c anchors printed by the survey probe
     assert abs(tmin - 262.169090) < 1e-6 and abs(tmax - 272.371035) < 1e-6 and abs(umax - 1.148573) < 1e-6
+
+
+DAMPING_CASES = {       # the option sets of oracle/make_golden.py's run_T21L8_damping_* jobs (spectral_damping.F90:124-156)
+    "exponential": dict(damping_option="exponential_cutoff", cutoff_wn=10, damping_order=3, damping_coeff=2.3e-4, damping_coeff_vor=1.2e-4,
+                        damping_coeff_div=4.6e-4),
+    "vor_div": dict(damping_option="resolution_dependent", damping_order=4, damping_coeff_vor=3.0e-4, damping_order_vor=2, damping_coeff_div=6.0e-4,
+                    damping_order_div=3),
+    "res_independent": dict(damping_option="resolution_independent", damping_order=2, damping_coeff=2.0e16),
+}
+
+
+@pytest.mark.parametrize("case", sorted(DAMPING_CASES))
+def test_damping_options(golden_dir, case):
+    """The options of spectral_damping_init in the numpy restatement against 36 reference steps at T21L8."""
+    g = np.load(os.path.join(golden_dir, f"run_T21L8_damping_{case}.npz"))
+    sc = core("T21", 8, **DAMPING_CASES[case]); sc.cold_start()
+    for _ in range(36):
+        sc.step()
+    s = sc.state()
+    for k in ("ug", "vg"):
+        assert np.max(np.abs(s[k] - g[f"st_{k}_000036"])) < 1e-11, k
+    assert rel(s["tg"], g["st_tg_000036"]) < 1e-12 and rel(s["psg"], g["st_psg_000036"]) < 1e-12
 
 
 def test_tracer_kernels(kern):

@@ -1,13 +1,20 @@
 #!/bin/bash
 # Copy the summaries produced by tools/collect_profiles.sh (gpurun_out/prof_final) into profiles/ under this round's names.
-#   usage: bash tools/publish_profiles.sh [round-tag, default r01]
+#   usage: bash tools/publish_profiles.sh [round-tag, default r02]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r01}
-S=gpurun_out/prof_final
-cp $S/kernel_stats_summary.csv profiles/${R}_T85L40_kernel_stats.csv
-cp $S/stats/bench_kernel_stats.csv profiles/${R}_T85L40_kernel_stats_rocprofv3_raw.csv
-cp $S/pmc_summary.csv profiles/${R}_T85L40_pmc_summary.csv
-cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json
-grep '^{' $S/bench_stats.log | tail -1 > profiles/${R}_T85L40_bench_under_rocprof.json
+R=${1:-r02}
+T=gpurun_out/prof_final
+for W in T85L40 T170L60 T85L40_moist; do
+  S=$T/$W
+  [ -d $S ] || continue
+  cp $S/kernel_stats_summary.csv profiles/${R}_${W}_kernel_stats.csv
+  cp $S/stats/bench_kernel_stats.csv profiles/${R}_${W}_kernel_stats_rocprofv3_raw.csv
+  if [ -f $S/pmc_summary.csv ] && [ $(wc -l < $S/pmc_summary.csv) -gt 1 ]; then
+    cp $S/pmc_summary.csv profiles/${R}_${W}_pmc_summary.csv
+    if [ $W = T85L40 ]; then cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json; else cp $S/pmc_traffic.json profiles/${R}_${W}_pmc_traffic.json; fi
+  fi
+  grep '^{' $S/bench_stats.log | tail -1 > profiles/${R}_${W}_bench_under_rocprof.json || true
+done
+grep '^{' $T/bench_T85L40.json.log | tail -1 > profiles/${R}_T85L40_bench.json
 ls -la profiles/
