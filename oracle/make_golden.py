@@ -438,6 +438,10 @@ def main():
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
+        # Robert-Asselin-Williams filter (leapfrog.F90:58-105 with raw_filter_coeff /= 1): the new level's spectral state is adjusted
+        # AFTER its grid fields have been synthesised (spectral_dynamics.F90:1031)
+        "run_T21L8_raw_filter": lambda: golden_run(
+            "T21", 8, 36, (2, 3, 36), extra="raw_filter_coeff = 0.7", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(02|03|36)$", k) is not None),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -185,6 +185,23 @@ def test_damping_options(golden_dir, case):
     assert rel(s["tg"], g["st_tg_000036"]) < 1e-12 and rel(s["psg"], g["st_psg_000036"]) < 1e-12
 
 
+def test_raw_filter(golden_dir):
+    """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
+    state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_raw_filter.npz"))
+    sc = core("T21", 8, raw_filter_coeff=0.7); sc.cold_start()
+    for i in range(1, 37):
+        sc.step()
+        if i in (2, 3, 36):
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+            # the harness sees what atmosphere_mod sees: the tracer copy taken BEFORE the filter is completed (atmosphere.F90:95,
+            # spectral_dynamics.F90:1028), and no spectral arrays (its st_ts etc. are re-analysed from the grid fields)
+            assert rel(sc.tr_atm[sc.current], g[f"st_tr1_{tag}"]) < 1e-11
+
+
 def test_tracer_kernels(kern):
     """van Leer horizontal advection (fv_advection.F90:126-560, incl. Courant numbers > 1) and PPM vertical
     advection (vert_advection.F90:301-438) of the grid tracer."""
