@@ -111,6 +111,13 @@ int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out);
 int isca_dyn_destroy(isca_dyn_t *h);
 const char *isca_last_error(void);
 
+/* get_topography (init/spectral_init_cond.F90:167-308): the surface geopotential spectral_init_cond hands to spectral_dynamics, as
+ * data: the GLOBAL (lon_max, lat_max) field in m2/s2, the same on every rank, set before isca_dyn_cold_start (or before the set_state
+ * calls of a restart).  Default: flat.  It enters the initial surface pressure (spectral_initialize_fields.F90:85), the hydrostatic
+ * integral (press_and_geopot.F90:331) and the heights of isca_dyn_get_state("z_full" / "z_half").  get_surf_geopotential
+ * (spectral_dynamics.F90:1342) = isca_dyn_get_state(h, "surf_geopotential", ...) (local band). */
+int isca_dyn_set_surf_geopotential(isca_dyn_t *h, const double *global_field, size_t count);
+
 /* read_restart_or_do_coldstart (spectral_dynamics.F90:580-630) + spectral_initialize_fields */
 int isca_dyn_cold_start(isca_dyn_t *h);
 

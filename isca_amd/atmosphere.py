@@ -197,6 +197,9 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
         if k.lower() not in ("radius", "omega"):
             raise IscaError(f"constants_nml: {k} cannot be changed (only radius and omega)")
         kw[k.lower()] = v
+    ic = {k.lower(): v for k, v in (namelist.get("spectral_init_cond_nml") or {}).items()}     # topography_option: atmosphere_init
+    if "initial_temperature" in ic:
+        kw["initial_temperature"] = ic["initial_temperature"]
     if moist:
         kw["physics"] = 1
         kw["moist"] = _moist_config(namelist)
@@ -235,6 +238,59 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
 
 
 # ---------------------------------------------------------------- atmosphere_mod
+def gaussian_topog(namelist: dict, deg_lon, deg_lat):
+    """gaussian_topog_init (shared/topography/gaussian_topog.F90:135-160, :215-259): the sum of the gaussian_topog_nml mountains, in m,
+    on the [lat, lon] grid."""
+    nml = {k.lower(): v for k, v in (namelist.get("gaussian_topog_nml") or {}).items()}
+    def arr(name):
+        v = nml.get(name, [])
+        return [float(x) for x in (v if isinstance(v, (list, tuple)) else [v])]
+    height = arr("height")
+    lon, lat = np.asarray(deg_lon) * np.pi / 180.0, np.asarray(deg_lat) * np.pi / 180.0
+    z = np.zeros((lat.size, lon.size))
+    tpi = 2.0 * np.pi
+    dtr = tpi / 360.0
+    for n, hgt in enumerate(height):
+        if hgt == 0.0:
+            continue
+        par = lambda name: (arr(name)[n] if n < len(arr(name)) else 0.0) * dtr     # namelist arrays default to 0 (:86-92)
+        olon, olat, wlon, wlat, rlon, rlat = par("olon"), par("olat"), par("wlon"), par("wlat"), par("rlon"), par("rlat")
+        dy = np.abs(lat - olat)
+        yy = np.maximum(0.0, dy - rlat) / wlat
+        dx = np.abs(lon - olon)
+        dx = np.minimum(dx, np.abs(dx - tpi))
+        xx = np.maximum(0.0, dx - rlon) / wlon
+        z += hgt * np.exp(-xx[None, :] ** 2 - yy[:, None] ** 2)
+    return z
+
+
+def _get_topography(namelist: dict, surf_height):
+    """get_topography (init/spectral_init_cond.F90:167-308): topography_option 'flat' | 'gaussian' (gaussian_topog_nml) | 'input' (the
+    [lat, lon] height field of INPUT/<topog_file_name> handed over as `surf_height`, spectrally truncated; the ocean-mask smoothing of
+    ocean_topog_smoothing /= 0 is not carried)."""
+    nml = {g.lower(): {k.lower(): v for k, v in vals.items()} for g, vals in namelist.items()}
+    opt = str(nml.get("spectral_init_cond_nml", {}).get("topography_option", "flat")).lower()
+    c = _core
+    if opt == "flat":
+        if surf_height is not None:
+            raise IscaError("surf_height given but topography_option = 'flat'")
+        return
+    if opt == "gaussian":
+        z = gaussian_topog(nml, c.table("deg_lon"), c.table("deg_lat"))
+        c.set_surf_geopotential(dyncore.GRAV * z)                                       # no truncation on this branch (:300-303)
+    elif opt == "input":
+        if surf_height is None:
+            raise IscaError("get_topography: topography_option=\"input\" needs the height field (atmosphere_init(..., surf_height=array))")
+        if float(nml.get("spectral_dynamics_nml", {}).get("ocean_topog_smoothing", 0.93)) != 0.0:
+            raise IscaError("get_topography: only ocean_topog_smoothing = 0 (spectral truncation of the topography) is supported")
+        if c.cfg.world_size != 1:
+            raise IscaError("get_topography: 'input' topography is truncated with the single-rank transforms; hand sharded runs the truncated field")
+        g = dyncore.GRAV * np.asarray(surf_height, dtype=np.float64)
+        c.set_surf_geopotential(c.trans_filter(g))                                       # grid -> spherical -> grid (:229-235)
+    else:
+        raise IscaError(f'"{opt}" is an invalid value for topography_option.')
+
+
 def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str | None = None, **overrides):
     """atmosphere.F90:120-272: spectral_dynamics_init + (restart | cold start) + hs_forcing_init.
 
@@ -244,8 +300,15 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     global _core, _run_dir
     if _core is not None:
         return _core                                   # `if(module_is_initialized) return`
+    surf_height = overrides.pop("surf_height", None)
     _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
     _run_dir = run_dir
+    try:
+        _get_topography(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}), surf_height)
+    except Exception:
+        _core.close()
+        _core = None
+        raise
     _setup_progress_log(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}))
     inp = None if run_dir is None else os.path.join(run_dir, "INPUT")
     try:

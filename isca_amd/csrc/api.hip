@@ -383,6 +383,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     d.vorg = dalloc<double>(h, ng3); d.divg = dalloc<double>(h, ng3); d.dxT = dalloc<double>(h, ng3); d.dyT = dalloc<double>(h, ng3);
     d.dxlp = dalloc<double>(h, ng2); d.dylp = dalloc<double>(h, ng2); d.wg_full = dalloc<double>(h, ng3);
+    d.surf_geop = dalloc<double>(h, ng2);
+    HIP_CHECK(hipMemsetAsync(d.surf_geop, 0, ng2 * sizeof(double), h->stream));         // flat until isca_dyn_set_surf_geopotential
     d.g_dtu = dalloc<double>(h, ng3); d.g_dtv = dalloc<double>(h, ng3); d.g_dtT = dalloc<double>(h, ng3);
     d.g_E = dalloc<double>(h, ng3); d.g_dtlp = dalloc<double>(h, ng2);
     d.s_dtvor = dalloc<double>(h, ns3); d.s_dtdiv = dalloc<double>(h, ns3); d.s_dtT = dalloc<double>(h, ns3); d.s_dtlp = dalloc<double>(h, ns2);
@@ -594,8 +596,10 @@ static void cold_start_single(isca_dyn *h) {
   HIP_CHECK(hipMemsetAsync(d.divs[0], 0, ns3 * sizeof(double), h->stream));
   dev_uv_from_vd(h, d.vors[0], d.divs[0], d.ug[0], d.vg[0], L);
   std::vector<double> tg(ng3, h->cfg.initial_temperature), lnp(ng2, std::log(h->cfg.reference_sea_level_press));
+  if (!h->h_surf_geop.empty())      // ln_psg = log(initial_sea_level_press) - surf_geopotential/(rdgas*initial_temperature)  (spectral_initialize_fields.F90:85)
+    for (size_t i = 0; i < ng2; ++i) lnp[i] -= h->h_surf_geop[(size_t)g.j0 * g.I + i] / (RDGAS * h->cfg.initial_temperature);
   h2d(h, d.tg[0], tg.data(), ng3);
-  h2d(h, d.psg[0], lnp.data(), ng2);                       // flat topography: ln ps = log(p_ref)
+  h2d(h, d.psg[0], lnp.data(), ng2);
   dev_g2s(h, d.tg[0], d.ts[0], L, 1, OP_NONE);
   dev_s2g(h, d.ts[0], d.tg[0], L, OP_NONE);
   dev_g2s(h, d.psg[0], d.lnps[0], 1, 1, OP_NONE);
@@ -634,6 +638,7 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
   if (name == "vorg") { count = ng3; return d.vorg; }
   if (name == "divg") { count = ng3; return d.divg; }
   if (name == "wg_full") { count = ng3; return d.wg_full; }
+  if (name == "surf_geopotential") { count = ng2; return d.surf_geop; }      // local band; to SET it use isca_dyn_set_surf_geopotential
   if (name == "t_surf" || name == "precip") {
     if (h->cfg.physics != 1) fail("get/set_state: " + name + " exists only with the moist physics package");
     count = ng2; return name == "t_surf" ? d.t_surf : d.precip;
@@ -1090,6 +1095,20 @@ extern "C" int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count) 
   API_END
 }
 
+// get_topography (spectral_init_cond.F90:167-308) hands spectral_dynamics a surface geopotential; here the caller does: the GLOBAL
+// (lon_max, lat_max) field, the same on every rank, before isca_dyn_cold_start or a restart's set_state calls.  It enters the initial
+// surface pressure (spectral_initialize_fields.F90:85), the hydrostatic integral of the dynamics (press_and_geopot.F90:331) and the
+// heights handed to the physics.  The reference's own smoothing / truncation of the field is the caller's business (isca_amd/atmosphere.py).
+extern "C" int isca_dyn_set_surf_geopotential(isca_dyn_t *h, const double *global_field, size_t count) {
+  API_BEGIN
+  if (!h || !global_field) fail("null argument");
+  const Geom &g = h->g;
+  if (count != (size_t)g.J * g.I) fail("set_surf_geopotential: the field must have lon_max * lat_max values");
+  h->h_surf_geop.assign(global_field, global_field + count);
+  h2d(h, h->d.surf_geop, global_field + (size_t)g.j0 * g.I, (size_t)g.Jl * g.I);
+  API_END
+}
+
 extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
   API_BEGIN
   if (!h) fail("null handle");
@@ -1101,6 +1120,8 @@ extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
   isca_dyn_t *g1 = nullptr;
   if (isca_dyn_create(&c1, &g1)) fail(std::string("cold start: ") + isca_last_error());
   try {
+    if (!h->h_surf_geop.empty() && isca_dyn_set_surf_geopotential(g1, h->h_surf_geop.data(), h->h_surf_geop.size()))
+      fail(std::string("cold start: ") + isca_last_error());
     cold_start_single(g1);
     const Geom &g = h->g;
     const Geom &G = g1->g;

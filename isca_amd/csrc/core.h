@@ -68,6 +68,7 @@ struct Dev {
   double *ug[2], *vg[2], *tg[2], *psg[2], *tr[2];   // grid, two time levels
   double *vorg, *divg, *dxT, *dyT, *dxlp, *dylp;    // grid, at `current`
   double *diag_acc[32] = {};                        // diagnostics: running sums of the selected fields
+  double *surf_geop = nullptr;   // [Jl][I] surface geopotential (get_topography, spectral_init_cond.F90:167-308); zero = flat
   double *wg_full;
   double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
   double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
@@ -128,6 +129,7 @@ struct isca_dyn {
   double wave_dt = -1.0;
   int ml_of_m0 = -1;
   std::vector<int> h_m_local, h_slot_of_m, h_m_of_slot;
+  std::vector<double> h_surf_geop;  // global (lat_max, lon_max) surface geopotential as handed over (empty = flat)
   int n_active = 0;
   bool fuse_synth = false;
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream

@@ -816,6 +816,7 @@ struct ColumnArgs {
   double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg, *psp_copy;
   int *kmask; double water_limit;
   const double *phu, *phv, *pht;           // tendencies of the physics package when it is not hs_forcing (k_column<CH, true>)
+  const double *surf_geop;                 // [Jl][I] lower boundary of the hydrostatic integral (press_and_geopot.F90:331)
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   if (w == NW - 1) a.dtlp[c2] = (0.0 - total) / ps;     // (dt_psg - dmean_tot)/psg (:873, :1102)
   // ---- hydrostatic integral bottom-up within the chunk, Phi + KE (:350-356, :902)
   {
-    double gh = below;
+    double gh = below + a.surf_geop[c2];
 #pragma unroll
     for (int i = CH - 1; i >= 0; --i) {
       if (i < nk) {
@@ -1070,7 +1071,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
   a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
-  a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT;
+  a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
@@ -1109,10 +1110,10 @@ void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const
   hipLaunchKernelGGL(k_hs_forcing, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, dt, p_half, p_full, u, v, t, udt, vdt, tdt);
 }
 
-// compute_pressures_and_heights (press_and_geopot.F90:363-387), flat topography
+// compute_pressures_and_heights (press_and_geopot.F90:363-387)
 __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const double *__restrict__ bk,
-                                    const double *__restrict__ t, const double *__restrict__ psg, double *p_full,
-                                    double *p_half, double *z_full, double *z_half) {
+                                    const double *__restrict__ t, const double *__restrict__ psg, const double *__restrict__ surf_geop,
+                                    double *p_full, double *p_half, double *z_full, double *z_half) {
   const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t lev = (size_t)g.Jl * g.I;
   if (c2 >= lev) return;
@@ -1132,8 +1133,8 @@ __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const
     p_full[c2 + k * lev] = exp(lf);
     ph_k = ph_n;
   }
-  double gh = 0.0;
-  z_half[c2 + (size_t)L * lev] = 0.0;
+  double gh = surf_geop[c2];
+  z_half[c2 + (size_t)L * lev] = gh / GRAV;
   const int ktop = (pk[0] == 0.0) ? 1 : 0;
   for (int k = L - 1; k >= 0; --k) {
     const double ph0 = pk[k] + bk[k] * ps, ph1 = pk[k + 1] + bk[k + 1] * ps;
@@ -1149,7 +1150,7 @@ __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const
 }
 void launch_pressures_heights(const isca_dyn &h, const double *t, const double *ps, double *p_full, double *p_half,
                               double *z_full, double *z_half, hipStream_t s) {
-  hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, p_full, p_half, z_full, z_half);
+  hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, h.d.surf_geop, p_full, p_half, z_full, z_half);
 }
 
 // pressure_variables (press_and_geopot.F90:152-221, simmons_and_burridge): p_half, ln_p_half, p_full, ln_p_full
@@ -1171,16 +1172,16 @@ __global__ void k_pressure_variables(Geom g, const double *__restrict__ pk, cons
     ph_k = ph_n; l_k = l_n;
   }
 }
-// compute_geopotential (press_and_geopot.F90:327-359), dry, flat surface
-__global__ void k_geopotential(Geom g, const double *__restrict__ pk, const double *__restrict__ t,
+// compute_geopotential (press_and_geopot.F90:327-359), dry; the handle's surface geopotential
+__global__ void k_geopotential(Geom g, const double *__restrict__ pk, const double *__restrict__ surf_geop, const double *__restrict__ t,
                                const double *__restrict__ ln_p_half, const double *__restrict__ ln_p_full,
                                double *geopot_full, double *geopot_half) {
   const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t lev = (size_t)g.Jl * g.I;
   if (c2 >= lev) return;
   const int L = g.L, ktop = (pk[0] == 0.0) ? 1 : 0;
-  double gh = 0.0;
-  geopot_half[c2 + (size_t)L * lev] = 0.0;
+  double gh = surf_geop[c2];
+  geopot_half[c2 + (size_t)L * lev] = gh;                     // geopot_half(:,:,num_levels+1) = surf_geopotential (:331)
   if (ktop == 1) geopot_half[c2] = 0.0;
   for (int k = L - 1; k >= 0; --k) {
     const double tk = t[c2 + k * lev], l1 = ln_p_half[c2 + (k + 1) * lev];
@@ -1192,7 +1193,7 @@ void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_ha
   hipLaunchKernelGGL(k_pressure_variables, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, ps, p_half, ln_p_half, p_full, ln_p_full);
 }
 void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s) {
-  hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, t, ln_p_half, ln_p_full, gf, gh);
+  hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.surf_geop, t, ln_p_half, ln_p_full, gf, gh);
 }
 // mass_weighted_global_integral (global_integral.F90:49-81): per-latitude sums of wts * sum_k field*dp, one block per row
 __global__ void k_mass_weighted_rows(Geom g, const double *__restrict__ dpk, const double *__restrict__ dbk,

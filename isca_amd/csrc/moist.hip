@@ -275,7 +275,7 @@ static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
 // compute_pressures_and_heights (press_and_geopot.F90:363-387, flat surface, no virtual temperature) of both time levels
 // (atmosphere.F90:296-303): the previous level needs pressures only (nothing reads its heights), the current one both.
 struct PressArgs {
-  const double *pk, *bk;
+  const double *pk, *bk, *surf_geop;
   const double *t[2], *ps[2];
   double *p_full[2], *p_half[2], *z_full, *z_half;
   int ncol, L;
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(64) void k_moist_heights(PressArgs a) {
   const int L = a.L;
   const size_t c = (size_t)col, s = (size_t)a.ncol;
   const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
-  double gh = 0.0;
-  a.z_half[c + (size_t)L * s] = 0.0;
+  double gh = a.surf_geop[c];
+  a.z_half[c + (size_t)L * s] = gh / GRAV;
   for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
     double zf[8], dz[8];
 #pragma unroll
@@ -338,7 +338,7 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
   double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L;
   PressArgs a;
-  a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L;
+  a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L; a.surf_geop = d.surf_geop;
   a.t[0] = d.tg[sc.prev]; a.ps[0] = d.psg[sc.prev]; a.t[1] = d.tg[sc.cur]; a.ps[1] = d.psg[sc.cur];
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);

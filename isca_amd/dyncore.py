@@ -88,6 +88,7 @@ def load_library():
         "isca_dyn_create": [C.POINTER(_CConfig), C.POINTER(H)],
         "isca_dyn_destroy": [H],
         "isca_dyn_cold_start": [H],
+        "isca_dyn_set_surf_geopotential": [H, dp, C.c_size_t],
         "isca_dyn_step": [H, C.c_int, C.c_int],
         "isca_dyn_synchronize": [H],
         "isca_dyn_dynamics": [H, dp, dp, dp, dp, C.c_int, C.c_int],
@@ -150,7 +151,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start",
+    "isca_last_error", "isca_dyn_config_default", "isca_dyn_create", "isca_dyn_destroy", "isca_dyn_cold_start", "isca_dyn_set_surf_geopotential",
     "isca_dyn_step", "isca_dyn_synchronize", "isca_dyn_dynamics", "isca_dyn_set_tendencies", "isca_dyn_delta_t", "isca_dyn_step_phase",
     "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
@@ -167,6 +168,8 @@ EXPORTED_SYMBOLS = [
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check",
     "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter", "isca_config_sizes",
 ]
+
+GRAV = 9.80          # shared/constants/constants.F90 (constants_nml default), as in csrc/tables.h
 
 # RESOLUTIONS of the reference's Python harness (src/extra/python/isca/experiment.py:29-57)
 RESOLUTIONS = {
@@ -258,7 +261,7 @@ class DynCore:
     # -- shapes
     def _shape(self, name):
         L, Jl, I, N1, M1 = self.L, self.Jl, self.I, self.N1, self.M1
-        if name in ("psg", "dxlp", "dylp", "g_dtlp", "t_surf", "precip"):
+        if name in ("psg", "dxlp", "dylp", "g_dtlp", "t_surf", "precip", "surf_geopotential"):
             return (Jl, I), False
         if name in ("p_half", "z_half"):
             return (L + 1, Jl, I), False
@@ -267,6 +270,13 @@ class DynCore:
         if name in ("ln_ps", "s_dtlp"):
             return (N1, M1), True
         return (L, Jl, I), False
+
+    def set_surf_geopotential(self, global_field):
+        """get_topography's result (m2/s2) as a global [lat_max, lon_max] array, before cold_start / a restart's set calls."""
+        a = np.ascontiguousarray(global_field, dtype=np.float64)
+        if a.shape != (self.J, self.I):
+            raise IscaError(f"set_surf_geopotential: shape {a.shape} != {(self.J, self.I)}")
+        self._check(self.lib.isca_dyn_set_surf_geopotential(self._h, _dptr(a), a.size))
 
     def get(self, name: str, time_level: int = 1):
         shape, cplx = self._shape(name)

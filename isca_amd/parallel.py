@@ -235,6 +235,7 @@ class ShardedDynCore(dyncore.DynCore):
         try:
             restart.read_restart(one, directory)
             self.set_time_pointers(one.info("previous"), one.info("current"), one.info("step"))
+            self.set_surf_geopotential(one.get("surf_geopotential"))       # the file's topography (global; every rank keeps its band)
             j0, jl = self.info("lat_start"), self.Jl
             levels = (0, 1) if one.info("previous") != one.info("current") else (1,)
             for tl in levels:
@@ -261,7 +262,7 @@ class _GatheredView:
         for nm in ("vors", "divs", "ts", "ln_ps"):
             for tl in (0, 1):
                 self._cache[nm, tl] = sh.gather_spectral(nm, tl)
-        grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full"] + (["tr", "tr_atm"] if sh.info("tracer") else []) + \
+        grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full", "surf_geopotential"] + (["tr", "tr_atm"] if sh.info("tracer") else []) + \
                 (["t_surf"] if sh.cfg.physics == 1 else [])
         for nm in grids:
             for tl in (0, 1):

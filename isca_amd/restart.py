@@ -98,7 +98,7 @@ def write_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
         w.put(tracer_name, _levels(core, "tr"))
     w.put("vorg", [core.get("vorg")])
     w.put("divg", [core.get("divg")])
-    w.put("surf_geopotential", [np.zeros((core.Jl, core.I))])
+    w.put("surf_geopotential", [core.get("surf_geopotential")])
     w.close()
 
     w = _Writer(os.path.join(directory, "atmosphere.res.nc"))
@@ -158,8 +158,7 @@ def read_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
     for nm in ("pk", "bk"):
         if not np.array_equal(sd[nm].reshape(sd[nm].shape[0], -1)[0], core.table(nm)):
             raise IscaError(f"read_restart: {nm} of the restart file differs from the vertical coordinate of the namelist")
-    if np.any(sd["surf_geopotential"] != 0.0):
-        raise IscaError("read_restart: non-zero surf_geopotential (topography) is not supported")
+    core.set_surf_geopotential(np.asarray(sd["surf_geopotential"]).reshape(-1, J, I)[0])       # spectral_dynamics.F90:575: the restart file's topography, not get_topography's
 
     core.set_time_pointers(prev, cur, 0 if prev == cur else 1)
     has_tracer = bool(core.info("tracer"))

@@ -28,7 +28,7 @@ RES = {"T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
 
-def input_nml(res, num_levels, extra=""):
+def input_nml(res, num_levels, extra="", extra_groups=""):
     lon, lat, nf, ns = RES[res]
     # namelist of exp/test_cases/held_suarez/held_suarez_test_case.py:45-98
     return f""" &atmosphere_nml
@@ -57,6 +57,7 @@ def input_nml(res, num_levels, extra=""):
  &fms_nml
     domains_stack_size = 2000000
  /
+{extra_groups}
 """
 
 
@@ -142,10 +143,10 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), m
         f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
 
 
-def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra=""):
+def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
-    open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra))
+    open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra, extra_groups))
     open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     ds = ", ".join(str(s) for s in dump_steps) if dump_steps else "-1"
@@ -364,17 +365,27 @@ def golden_shallow_run(res="T21", nsteps=200, dump_steps=(1, 2, 10, 200), dt=120
     return out
 
 
-def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra=""):
-    """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win)"""
+GAUSSIAN_TOPOG_GROUPS = """ &spectral_init_cond_nml
+    topography_option = 'gaussian'
+ /
+ &gaussian_topog_nml
+    height = 2500., 1500., olon = 90., 250., olat = 40., -30., wlon = 25., 20., wlat = 15., 12., rlon = 0., 5., rlat = 0., 3.
+ /
+"""
+
+
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups=""):
+    """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win); `extra_groups`: whole
+    namelist groups appended to input.nml"""
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
-        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra)
+        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra, extra_groups=extra_groups)
         stdout = run_harness(d)
         out = read_outputs(d, res, L)
     if keep is not None:
         out = {k: v for k, v in out.items() if keep(k)}
     m = re.search(r"REF_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout)
     out["final_Tmin_Tmax_maxabsU"] = np.array([float(x) for x in m.groups()])
-    meta = dict(res=res, num_levels=L, dt_atmos=float(dt), nsteps=nsteps, extra=extra)
+    meta = dict(res=res, num_levels=L, dt_atmos=float(dt), nsteps=nsteps, extra=extra + extra_groups)
     out.update({"meta_" + k: np.array(v) for k, v in meta.items()})
     return out
 
@@ -442,6 +453,11 @@ def main():
         # AFTER its grid fields have been synthesised (spectral_dynamics.F90:1031)
         "run_T21L8_raw_filter": lambda: golden_run(
             "T21", 8, 36, (2, 3, 36), extra="raw_filter_coeff = 0.7", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(02|03|36)$", k) is not None),
+        # topography: two Gaussian mountains (get_topography 'gaussian', spectral_init_cond.F90:299-303; gaussian_topog.F90:215-259) --
+        # initial surface pressure over the orography, surf_geopotential in the hydrostatic integral
+        "run_T21L8_topography": lambda: golden_run(
+            "T21", 8, 36, (1, 36), extra_groups=GAUSSIAN_TOPOG_GROUPS,
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|36)$", k) is not None),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

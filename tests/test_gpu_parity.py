@@ -205,6 +205,44 @@ def test_golden_raw_filter(golden_dir):
         make("T21", 8, raw_filter_coeff=1.5)
 
 
+def test_golden_topography(golden_dir, tmp_path):
+    """Non-zero surface geopotential (get_topography 'gaussian': two mountains of gaussian_topog_nml): initial surface pressure over the
+    orography (spectral_initialize_fields.F90:85), surf_geopotential as the lower boundary of the hydrostatic integral
+    (press_and_geopot.F90:331) -- steps 1 and 36 at T21L8 against the reference run; the restart files carry the field."""
+    from isca_amd import atmosphere as atm, configs, restart
+    g = np.load(os.path.join(golden_dir, "run_T21L8_topography.npz"))
+    nml = configs.held_suarez()
+    nml["spectral_dynamics_nml"]["num_levels"] = 8
+    nml["spectral_init_cond_nml"] = {"topography_option": "gaussian"}
+    nml["gaussian_topog_nml"] = {"height": [2500., 1500.], "olon": [90., 250.], "olat": [40., -30.], "wlon": [25., 20.], "wlat": [15., 12.],
+                                 "rlon": [0., 5.], "rlat": [0., 3.]}
+    dc = atm.atmosphere_init(nml, resolution="T21")
+    sg = dc.get("surf_geopotential")
+    assert abs(sg.max() / 9.80 - 2500.0) < 60.0 and sg.min() >= 0.0              # the higher peak, sampled on the Gaussian grid
+    done = 0
+    for n in (1, 36):
+        atm.atmosphere(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg")}
+        err["tr"] = float(np.abs(dc.get("tr") - g[f"st_tr1_{n:06d}"]).max() / np.abs(g[f"st_tr1_{n:06d}"]).max())
+        print("topography, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    zh = dc.get("z_half")
+    assert rel(zh[-1], sg / 9.80) < 1e-15                                       # heights start at the orography
+    restart.write_restart(dc, str(tmp_path))
+    ref = {k: dc.get(k) for k in ("ug", "tg", "psg")}
+    atm.atmosphere(5)
+    want = {k: dc.get(k) for k in ("ug", "tg", "psg")}
+    atm.atmosphere_end()
+    b = make("T21", 8); restart.read_restart(b, str(tmp_path))                   # a flat handle: the file brings the topography along
+    assert np.array_equal(b.get("surf_geopotential"), sg) and all(np.array_equal(b.get(k), ref[k]) for k in ref)
+    b.step(5)
+    assert all(np.array_equal(b.get(k), want[k]) for k in want)
+    b.close()
+    with pytest.raises(dyncore.IscaError, match="invalid value for topography_option"):
+        atm.atmosphere_init({"spectral_init_cond_nml": {"topography_option": "moon"}, "main_nml": {"dt_atmos": 600}}, resolution="T21")
+
+
 def test_golden_T170L60_stress_config(golden_dir):
     """BASELINE configs[4] at its full size (T170L60 Held-Suarez, dt = 150 s): steps 1 and 8 from the cold start against the reference
     run, on the committed [5::6, ::16, ::16] sample (ps: [::8, ::8]); winds as a fraction of max(|u|, 1 m/s)."""

@@ -158,11 +158,13 @@ def test_restart_file_round_trip_on_host(tmp_path):
                     self.store["psg", tl] = 1e5 + rng.standard_normal((8, 16))
                 for nm in ("vorg", "divg", "wg_full"):
                     self.store[nm, 0] = self.store[nm, 1]
+                self.store["surf_geopotential", 1] = 100.0 * rng.standard_normal((8, 16))
 
         def info(self, k): return self.ptr[k]
         def table(self, k): return np.linspace(0, 1, 4) if k == "bk" else np.zeros(4)
         def get(self, nm, tl=1): return self.store[nm, tl]
         def set(self, nm, v, tl=1): self.store[nm, tl] = np.array(v)
+        def set_surf_geopotential(self, v): self.store["surf_geopotential", 1] = np.array(v)
         def set_time_pointers(self, p, c, s): self.ptr.update(previous=p, current=c, step=s)
         def refresh_derived(self): self.refreshed = True
 
