@@ -113,7 +113,7 @@ def dominant_roofline(kt, kern, traffic, traffic_source):
     if dom is None:
         return None
     c = kern[dom]
-    name = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop", "fft_fwd": "k_fft_fwd", "fft_inv": "k_fft_inv",
+    name = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop:fused", "fft_fwd": "k_fft_fwd", "fft_inv": "k_fft_inv",
             "moist_physics": "k_moist_physics"}[dom]
     mfma = c["bound"] == "mfma"
     ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)

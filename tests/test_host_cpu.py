@@ -304,6 +304,13 @@ def test_test_case_config_files(lib):
     assert fr.moist.rhbm == 0.7 and fr.moist.Tmin == 160.0 and fr.moist.constant_gust == 0.0
 
 
+def test_integration_doc_in_sync():
+    """INTEGRATION.md prints bindings/fortran/isca_dyn_c.F90 (the block a maintainer copies): regenerate with
+    tools/gen_integration_snippet.py when the module changes."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_integration_snippet.py"), "--check"])
+    assert r.returncode == 0, "INTEGRATION.md is out of date: run python tools/gen_integration_snippet.py"
+
+
 def test_fortran_binding_abi(lib, tmp_path):
     """bindings/fortran/isca_dyn_c.F90 (the bind(C) module for the reference's language) compiles with the image's flang and its
     derived types have the library's struct sizes; defaults read back through them (no GPU needed)."""

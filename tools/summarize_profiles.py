@@ -23,7 +23,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*/"))):
 def short(name):
     n = name.replace("(anonymous namespace)::", "").split("(")[0]
     n = n.replace("void ", "").replace("isca::", "")
-    return n.split("<")[0]
+    base = n.split("<")[0]
+    if base == "k_leg_inv_coop" and "<" in n:       # <NW, JTG, FUSED, WPS>: the step's fused synthesis vs the staged one of the API transforms
+        args = [a.strip() for a in n.split("<", 1)[1].rstrip(">").split(",")]
+        base += ":fused" if args[2] == "true" else ":staged"
+    return base
 bytes_per_launch = {}
 for k, cs in tot.items():
     if "isca::" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
