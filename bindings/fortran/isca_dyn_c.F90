@@ -7,6 +7,7 @@ implicit none
 public
 
 integer, parameter :: ISCA_MAX_LEVELS = 128
+integer, parameter :: ISCA_MAX_TRACERS = 4
 
 type, bind(C) :: isca_moist_config
   real(c_double) :: roughness_mom, roughness_heat, roughness_moist
@@ -56,6 +57,8 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: damping_option, cutoff_wn
   real(c_double) :: damping_coeff_vor, damping_coeff_div
   integer(c_int) :: damping_order_vor, damping_order_div
+  integer(c_int) :: tracer_spectral(ISCA_MAX_TRACERS)
+  real(c_double) :: tracer_robert_coeff(ISCA_MAX_TRACERS)
 end type
 
 interface

@@ -30,6 +30,7 @@ extern "C" {
 typedef struct isca_dyn isca_dyn_t;
 
 #define ISCA_MAX_LEVELS 128
+#define ISCA_MAX_TRACERS 4
 
 /* Parameters of the moist physics package, physics = 1: idealized_moist_phys with the options of the Frierson grey-radiation
  * aquaplanet (exp/test_cases/frierson/frierson_test_case.py:49-170): SIMPLE_BETTS_MILLER convection, lscale_cond,
@@ -73,7 +74,7 @@ typedef struct isca_dyn_config {
   double initial_temperature;   /* spectral_init_cond_nml, default 264 */
   double initial_sphum;
   double valid_range_t[2];
-  int num_tracers;              /* grid tracers carried (dry field_table: 1 = sphum) */
+  int num_tracers;              /* prognostic tracers of the field_table, 0..ISCA_MAX_TRACERS (dry field_table: 1 = sphum); see tracer_spectral below */
   /* hs_forcing_nml */
   double t_zero, t_strat, delh, delv, eps, sigma_b, ka, ks, kf;
   int do_conserve_energy;
@@ -99,6 +100,14 @@ typedef struct isca_dyn_config {
   int damping_option, cutoff_wn;
   double damping_coeff_vor, damping_coeff_div;
   int damping_order_vor, damping_order_div;
+  /* field_table entries of tracers 2..num_tracers (spectral_dynamics_init, spectral_dynamics.F90:316-352; entry [k] describes tracer k+1,
+   * entry [0] is ignored: tracer 1 is the grid tracer the water fixer and the physics know as sphum).  tracer_spectral: the entry's
+   * numerical_representation, 0 = 'grid' (van Leer horizontally, advect_vert = finite_volume_parabolic like tracer 1), 1 = 'spectral'
+   * (horizontal_advection of the spectral coefficients, advect_vert = second_centered, hole_filling = off: the defaults of :145-147;
+   * damped like temperature, :1146).  tracer_robert_coeff: the entry's robert_coeff, negative = robert_coeff (:340-351).
+   * More than one tracer: single rank, raw_filter_coeff = 1.  State names "tr2".."tr4", "tr_atm2".., and "trs2".. (spectral). */
+  int tracer_spectral[ISCA_MAX_TRACERS];
+  double tracer_robert_coeff[ISCA_MAX_TRACERS];
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

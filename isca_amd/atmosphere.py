@@ -291,9 +291,69 @@ def _get_topography(namelist: dict, surf_height):
         raise IscaError(f'"{opt}" is an invalid value for topography_option.')
 
 
-def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str | None = None, **overrides):
+# ---- field_table (FMS field_manager format; the atmosphere's entries as spectral_dynamics_init reads them, spectral_dynamics.F90:316-409)
+def parse_field_table(text: str) -> list[dict]:
+    """Entries of a field_table: '"TRACER", "atmos_mod", "name"' followed by '"method", "value"[, "parameters"]' lines, closed by '/'.
+    Returns one dict per atmos_mod tracer: name and {method: (value, parameters)}; other models' entries are skipped."""
+    out = []
+    body = "\n".join(ln.split("#", 1)[0] for ln in text.splitlines())
+    for entry in body.split("/"):
+        rows = [[f.strip().strip('"').strip("'").strip() for f in ln.split(",")] for ln in entry.splitlines() if ln.strip()]
+        if not rows:
+            continue
+        head = rows[0]
+        if len(head) < 3 or head[0].upper() != "TRACER":
+            raise IscaError(f"field_table: entry does not start with \"TRACER\", \"model\", \"name\": {rows[0]}")
+        if head[1].lower() not in ("atmos_mod", "atmos"):
+            continue
+        methods = {r[0].lower(): (r[1] if len(r) > 1 else "", r[2] if len(r) > 2 else "") for r in rows[1:]}
+        out.append(dict(name=head[2].lower(), methods=methods))
+    return out
+
+
+def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = None):
+    """(config keys, tracer names) for the library.  What the kernels implement is what the reference's own field_tables use: tracer 1 a
+    'grid' tracer (van Leer + finite_volume_parabolic, the sphum entry), further tracers either that or 'spectral' with the defaults
+    (advect_vert = second_centered, hole_filling = off); anything else is refused by name rather than run as something else."""
+    if len(entries) > dyncore.MAX_TRACERS:
+        raise IscaError(f"field_table: {len(entries)} tracers, at most {dyncore.MAX_TRACERS} are carried")
+    spectral, robert, names = [], [], []
+    for k, e in enumerate(entries):
+        m = e["methods"]
+        rep = m.get("numerical_representation", ("spectral", ""))[0].lower()      # default_representation (:145)
+        if rep not in ("grid", "spectral"):
+            raise IscaError(f"spectral_dynamics_init: {rep} is an invalid numerical_representation")            # :359-360
+        adv = m.get("advect_vert", ("second_centered", ""))[0].lower()
+        if adv not in ("second_centered", "fourth_centered", "van_leer_linear", "finite_volume_parabolic"):
+            raise IscaError(f"spectral_dynamics_init: {adv} is an invalid advect_vert")                           # :406-407
+        want = "finite_volume_parabolic" if rep == "grid" else "second_centered"
+        if adv != want:
+            raise IscaError(f"field_table: tracer {e['name']}: advect_vert = {adv} is not available for a {rep} tracer (only {want})")
+        if rep == "spectral" and m.get("hole_filling", ("off", ""))[0].lower() == "on":
+            raise IscaError(f"field_table: tracer {e['name']}: hole_filling = on is not available")
+        if k == 0 and rep != "grid":
+            raise IscaError(f"field_table: the first tracer ({e['name']}) must be a grid tracer")
+        if "tracer_sms" in m:
+            raise IscaError(f"field_table: tracer {e['name']}: tracer_sms is not available (hs_forcing_nml's trflux / trsink apply to every tracer)")
+        rc = -1.0                                                                   # the dynamics' robert_coeff (:347,351)
+        if "robert_filter" in m:
+            scheme, params = m["robert_filter"]
+            if scheme.lower() == "off":
+                rc = 0.0                                                            # :341-342
+            else:
+                for item in params.replace(" ", "").split(","):
+                    if item.lower().startswith("robert_coeff="):
+                        rc = float(item.split("=", 1)[1])
+        if k == 0 and rc >= 0.0 and robert_coeff is not None and rc != robert_coeff:
+            raise IscaError(f"field_table: tracer {e['name']}: a robert_coeff of its own is only available from the second tracer on")
+        spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"])
+    return dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert), names
+
+
+def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str | None = None, field_table: str | None = None, **overrides):
     """atmosphere.F90:120-272: spectral_dynamics_init + (restart | cold start) + hs_forcing_init.
 
+    `field_table`: the text of the run's field_table (tracer_manager); without it the dry default applies (one grid tracer, sphum).
     With `run_dir` the reference's file protocol applies: `run_dir/INPUT/spectral_dynamics.res.nc` (+
     `atmosphere.res.nc`) is read when present (atmosphere.F90:197-223, spectral_dynamics.F90:509-575),
     otherwise the model cold-starts; atmosphere_end() then writes `run_dir/RESTART/`."""
@@ -301,7 +361,15 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     if _core is not None:
         return _core                                   # `if(module_is_initialized) return`
     surf_height = overrides.pop("surf_height", None)
+    names = None
+    if field_table is not None:          # text of the run's field_table (Experiment: field_table_file); None = the dry default, one sphum grid tracer
+        nml = parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {})
+        sd = {k.lower(): v for k, v in {g.lower(): v for g, v in nml.items()}.get("spectral_dynamics_nml", {}).items()}
+        keys, names = tracers_from_field_table(parse_field_table(field_table), sd.get("robert_coeff"))
+        overrides = {**keys, **overrides}
     _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
+    if names:
+        _core.tracer_names = names
     _run_dir = run_dir
     try:
         _get_topography(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}), surf_height)

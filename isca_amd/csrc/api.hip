@@ -97,6 +97,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->rank = 0; c->world_size = 1; c->device = 0; c->stream = nullptr; c->legendre_impl = 0;
   // moist package (physics = 1): module defaults overridden by frierson_test_case.py:49-170
   c->physics = 0; c->vert_coord_input = 0;
+  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -164,6 +165,16 @@ static void check_config(const isca_dyn_config &c) {
   }
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
+  if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
+  if (c.num_tracers > 1) {
+    if (c.world_size != 1) fail("more than one tracer: single rank only (the sharded step carries the sphum-like grid tracer only)");
+    if (c.raw_filter_coeff != 1.0) fail("more than one tracer: raw_filter_coeff must be 1");
+    for (int k = 1; k < c.num_tracers; ++k) {
+      if (c.tracer_spectral[k] != 0 && c.tracer_spectral[k] != 1)
+        fail("spectral_dynamics_init: tracer_spectral must be 0 ('grid') or 1 ('spectral'): any other numerical_representation is invalid");
+      if (c.tracer_robert_coeff[k] > 1.0) fail("tracer_robert_coeff must be <= 1 (negative = robert_coeff)");
+    }
+  }
   if (c.physics == 1) {
     if (c.num_tracers < 1) fail("idealized_moist_phys needs the sphum tracer (num_tracers >= 1)");
     if (c.num_levels < 3 || c.num_levels > 62) fail("idealized_moist_phys: num_levels must be in 3..62");
@@ -406,6 +417,18 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
     d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
     d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
+    for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
+      for (int t = 0; t < 2; ++t) {
+        d.trx[t][e] = dalloc<double>(h, ng3); d.trx_atm[t][e] = dalloc<double>(h, ng3);
+        HIP_CHECK(hipMemsetAsync(d.trx[t][e], 0, ng3 * sizeof(double), h->stream));
+        HIP_CHECK(hipMemsetAsync(d.trx_atm[t][e], 0, ng3 * sizeof(double), h->stream));
+        if (cfg->tracer_spectral[e + 1]) {
+          d.trxs[t][e] = dalloc<double>(h, ns3);
+          HIP_CHECK(hipMemsetAsync(d.trxs[t][e], 0, ns3 * sizeof(double), h->stream));
+        }
+      }
+      if (!d.wcol_x) d.wcol_x = dalloc<double>(h, 5 * ng2);
+    }
     HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
@@ -460,6 +483,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (cfg->physics == 2) {                  // the caller's physics: only the arrays its tendencies are handed over in (zero until then)
       d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3); d.ph_dtq = dalloc<double>(h, ng3);
       for (double *p : {d.ph_dtu, d.ph_dtv, d.ph_dtT, d.ph_dtq}) HIP_CHECK(hipMemsetAsync(p, 0, ng3 * sizeof(double), h->stream));
+      for (int e = 0; e + 1 < cfg->num_tracers; ++e) {
+        d.ph_dtqx[e] = dalloc<double>(h, ng3);
+        HIP_CHECK(hipMemsetAsync(d.ph_dtqx[e], 0, ng3 * sizeof(double), h->stream));
+      }
     }
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
@@ -614,6 +641,10 @@ static void cold_start_single(isca_dyn *h) {
   std::vector<double> tr(ng3, h->cfg.initial_sphum);
   h2d(h, d.tr[0], tr.data(), ng3); h2d(h, d.tr[1], tr.data(), ng3);
   h2d(h, d.tr_atm[0], tr.data(), ng3); h2d(h, d.tr_atm[1], tr.data(), ng3);
+  for (int e = 0; e < 3; ++e) for (int t = 0; t < 2; ++t) {
+    for (double *p : {d.trx[t][e], d.trx_atm[t][e]}) if (p) HIP_CHECK(hipMemsetAsync(p, 0, ng3 * sizeof(double), h->stream));
+    if (d.trxs[t][e]) HIP_CHECK(hipMemsetAsync(d.trxs[t][e], 0, ns3 * sizeof(double), h->stream));
+  }
   HIP_CHECK(hipMemsetAsync(d.wg_full, 0, ng3 * sizeof(double), h->stream));
   if (h->cfg.physics == 1) launch_t_surf_init(*h, h->stream);       // mixed_layer_init, prescribe_initial_dist
   HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -634,6 +665,17 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
   if (name == "tr") { count = ng3; return d.tr[tl]; }
   if (name == "tr_atm") { count = ng3; return d.tr_atm[tl]; }
   if (name == "trh") { count = ng3; return d.trh; }
+  for (int e = 0; e < 3; ++e) {       // "tr2".."tr4", "tr_atm2"..: tracers 2..num_tracers
+    const std::string n = std::to_string(e + 2);
+    if (name == "tr" + n || name == "tr_atm" + n || name == "trs" + n) {
+      if (!d.trx[0][e]) fail("get/set_state: " + name + ": num_tracers is " + std::to_string(h->cfg.num_tracers));
+      if (name[2] == 's') {
+        if (!d.trxs[0][e]) fail("get/set_state: " + name + ": tracer " + n + " is a grid tracer");
+        kind = 1; count = (size_t)g.L * g.N1 * g.M1 * 2; return d.trxs[tl][e];
+      }
+      count = ng3; return name[2] == '_' ? d.trx_atm[tl][e] : d.trx[tl][e];
+    }
+  }
   if (name == "psg") { count = ng2; return d.psg[tl]; }
   if (name == "vorg") { count = ng3; return d.vorg; }
   if (name == "divg") { count = ng3; return d.divg; }
@@ -740,6 +782,8 @@ extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
   for (auto &x : ps) x = std::log(x);
   h2d(h, d.scratch_g[0], ps.data(), ng2);
   dev_g2s(h, d.scratch_g[0], d.lnps[tl], 1, 1, OP_NONE);
+  for (int e = 0; e < 3; ++e)        // spectral tracers: their coefficients from the grid values handed in (:1447-1451)
+    if (d.trxs[tl][e]) dev_g2s(h, d.trx[tl][e], d.trxs[tl][e], L, 1, OP_NONE);
   if (tl == h->current) refresh_derived(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   API_END
@@ -845,9 +889,39 @@ static void raw_filter_phase(isca_dyn *h, const StepScalars &sc) {
   launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, 0, h->cfg.legendre_impl, h->stream);
   launch_fft_inverse(g, d, fl, d.Fi_g, h->stream);
 }
+// A 'spectral' tracer's step (update_tracers, spectral_dynamics.F90:1133-1154, with num_steps = 1): the physics tendency, minus the
+// horizontal advection of the current coefficients by the current winds (:1134), plus the second-centred vertical advection of the
+// current grid values (:1139-1141), transformed, damped like temperature, stepped (:1144-1148) and synthesised (:1154).  These are
+// the staged transforms on the work buffers the step has finished with; the field_table's dry default has no such tracer.
+static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
+  const Geom &g = h->g;
+  Dev &d = h->d;
+  const size_t ng3 = (size_t)g.L * g.Jl * g.I;
+  double *dt_tr = d.scratch_g[2], *dt_trs = d.scratch_s[1];
+  if (h->cfg.physics == 2) dcopy(h, dt_tr, d.ph_dtqx[e], ng3);
+  else {
+    HIP_CHECK(hipMemsetAsync(dt_tr, 0, ng3 * sizeof(double), h->stream));
+    if (h->cfg.physics == 0) launch_tracer_source_sink(*h, d.psg[sc.cur], d.trx_atm[sc.prev][e], dt_tr, h->stream);
+  }
+  FieldList fl = pair_list(d.scratch_g[0], d.scratch_g[1], g.L, OP_COSM);
+  launch_spec_gradient(g, d, d.trxs[sc.cur][e], d.Si, 2 * fl.ncol, 0, g.L, g.L, h->stream);
+  run_inverse(h, fl, 1);
+  launch_hadv_combine(g, d.ug[sc.cur], d.vg[sc.cur], d.scratch_g[0], d.scratch_g[1], dt_tr, g.L, h->stream);
+  launch_vert_advection_centered(*h, d.wg, d.psg[sc.cur], d.trx[sc.cur][e], dt_tr, h->stream);
+  dev_g2s(h, dt_tr, dt_trs, g.L, 1, OP_NONE);
+  launch_spec_tracer_update(*h, sc, e, dt_trs, h->stream);
+  dev_s2g(h, d.trxs[sc.fut][e], d.trx[sc.fut][e], g.L, OP_NONE);
+}
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
   if (h->cfg.raw_filter_coeff != 1.0) raw_filter_phase(h, sc);
+  if (h->tracer_on) {
+    Timed t(h, "tracers_2_up");
+    for (int e = 0; e + 1 < h->cfg.num_tracers; ++e) {     // tracers 2..num_tracers (their transport, if 'grid', ran beside tracer 1's)
+      if (h->cfg.tracer_spectral[e + 1]) spectral_tracer_step(h, sc, e);
+      launch_tracer_finish(*h, sc, e, h->stream);
+    }
+  }
   if (h->diag_mask) {   // spectral_diagnostics(Time_next, psg(future), ug(future), ...) at the end of atmosphere (atmosphere.F90:344)
     Timed t(h, "diagnostics"); launch_diag_accumulate(*h, sc.fut, h->stream);
     h->diag_count += 1;
@@ -912,6 +986,11 @@ static void stage_tendencies(isca_dyn *h, const double *dt_ug, const double *dt_
   for (int i = 0; i < 4; ++i) {
     if (!src[i]) HIP_CHECK(hipMemsetAsync(dst[i], 0, ng3 * sizeof(double), h->stream));
     else HIP_CHECK(hipMemcpyAsync(dst[i], src[i], ng3 * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+  }
+  for (int e = 0; e + 1 < h->cfg.num_tracers; ++e) {              // dt_tracers(:,:,:,ntr): tracer index slowest
+    if (!dt_tracers) HIP_CHECK(hipMemsetAsync(h->d.ph_dtqx[e], 0, ng3 * sizeof(double), h->stream));
+    else HIP_CHECK(hipMemcpyAsync(h->d.ph_dtqx[e], dt_tracers + (size_t)(e + 1) * ng3, ng3 * sizeof(double),
+                                  on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
   }
   if (!on_device) HIP_CHECK(hipStreamSynchronize(h->stream));      // the caller may reuse its arrays
 }

@@ -67,6 +67,9 @@ void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, doub
 // ---- grid-space kernels
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s);
+void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s);
+void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s);
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply

@@ -1633,6 +1633,10 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   }
 }
 
+// robert_coeff of field_table entry k+1 (spectral_dynamics.F90:340-351): its own, or the dynamics' one
+static double tracer_robert(const isca_dyn &h, int k) {
+  return h.cfg.tracer_robert_coeff[k] >= 0.0 ? h.cfg.tracer_robert_coeff[k] : h.cfg.robert_coeff;
+}
 static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   const Dev &d = h.d;
   TracerArgs a;
@@ -1680,6 +1684,77 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
   launch_tracer_vert_kernel(g, a, s);
+  // further 'grid' tracers of the field_table (update_tracers' loop, spectral_dynamics.F90:1132,1155-1180): the same transport, their own
+  // time levels; the column sums go to a spare array (only tracer 1 is water) and the filter's `future` term is added at the end of the step
+  for (int e = 0; e + 1 < h.cfg.num_tracers; ++e) {
+    if (h.cfg.tracer_spectral[e + 1]) continue;
+    TracerArgs b = a;
+    b.trp = h.d.trx[sc.prev][e]; b.tr_cur = h.d.trx[sc.cur][e]; b.tr_fut = h.d.trx[sc.fut][e]; b.wcol = h.d.wcol_x; b.tr_part = nullptr;
+    b.robert = tracer_robert(h, e + 1);
+    if (h.cfg.physics == 0) b.tratm_p = h.d.trx_atm[sc.prev][e];              // hs_forcing's source and sink act on every tracer (hs_forcing.F90:248-265)
+    else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
+    else { b.tratm_p = b.trp; b.flux = 0.0; b.rdamp = 0.0; }                   // idealized_moist_phys only has a tendency for sphum
+    hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, b);
+    launch_tracer_vert_kernel(g, b, s);
+  }
+}
+
+// ---- tracers 2..num_tracers: the end-of-step pieces
+// grid tracer: leapfrog_2level_B (spectral_dynamics.F90:1484) a(current) += robert a(future), and atmosphere_mod's copy of the new level
+__global__ void k_tracer_finish(size_t n, double robert, const double *__restrict__ fut, double *__restrict__ cur, double *__restrict__ atm_fut) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const double f = fut[i]; if (cur) cur[i] += robert * f; atm_fut[i] = f; }
+}
+void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s) {
+  const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
+  // a spectral tracer's grid values at `current` are not filtered (only its coefficients are, :1148 and :1482)
+  double *cur = h.cfg.tracer_spectral[e + 1] ? nullptr : h.d.trx[sc.cur][e];
+  hipLaunchKernelGGL(k_tracer_finish, grid1d(n), dim3(256), 0, s, n, tracer_robert(h, e + 1), h.d.trx[sc.fut][e], cur, h.d.trx_atm[sc.fut][e]);
+}
+// vert_advection(dt, w, dz, r, rdt, scheme = SECOND_CENTERED, form = ADVECTIVE_FORM) (vert_advection.F90:158-193, 461-465) with
+// dz = p_half(k+1) - p_half(k) = dpk + dbk ps; the tendency is added to rdt (update_tracers, spectral_dynamics.F90:1139-1141)
+__global__ void k_vert_advection_centered(Geom g, const double *__restrict__ w, const double *__restrict__ ps, const double *__restrict__ dpk,
+                                          const double *__restrict__ dbk, const double *__restrict__ r, double *__restrict__ rdt) {
+  const size_t lev = (size_t)g.Jl * g.I, n = lev * g.L;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = (int)(i / lev);
+  const size_t c2 = i - (size_t)k * lev;
+  const double rk = r[i], w0 = w[i], w1 = w[i + lev];
+  const double f0 = (k == 0) ? w0 * rk : w0 * (0.5 * (rk + r[i - lev]));
+  const double f1 = (k == g.L - 1) ? w1 * rk : w1 * (0.5 * (r[i + lev] + rk));
+  const double dz = dpk[k] + dbk[k] * ps[c2];
+  rdt[i] = rdt[i] + -(f1 - f0 - rk * (w1 - w0)) / dz;
+}
+void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s) {
+  const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
+  hipLaunchKernelGGL(k_vert_advection_centered, grid1d(n), dim3(256), 0, s, h.g, w, ps, h.d.dpk, h.d.dbk, r, rdt);
+}
+// spectral tracer: compute_spectral_damping (spectral_damping.F90:172-201, the coefficients temperature uses) on dt_trs, leapfrog_2level_A
+// (leapfrog.F90:58-84) and _B's `current` half (:100); one thread per coefficient and level, each reads its three time levels first
+// (previous aliases future from the second step on, current on the first)
+__global__ void k_spec_tracer_update(Geom g, const double *__restrict__ coef, double delta_t, double robert, const double2 *__restrict__ dt_trs,
+                                     const double2 *prev, double2 *cur, double2 *fut) {
+  const size_t n = (size_t)g.Ml * g.N1 * g.L;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t mn = i / g.L;
+  const double dmp = coef[(size_t)C_DAMP * g.Ml * g.N1 + mn];
+  const double2 p = prev[i], c = cur[i];
+  double2 dt = dt_trs[i];
+  const double cf = 1.0 / (1.0 + dmp * delta_t);
+  dt = cscale(cf, csub(dt, cscale(dmp, p)));
+  const double2 part = make_double2(p.x - 2.0 * c.x, p.y - 2.0 * c.y);
+  const double2 nf = make_double2(p.x + delta_t * dt.x, p.y + delta_t * dt.y);
+  double2 nc = make_double2(c.x + robert * part.x, c.y + robert * part.y);
+  nc = make_double2(nc.x + robert * nf.x, nc.y + robert * nf.y);
+  cur[i] = nc; fut[i] = nf;
+}
+void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s) {
+  const Geom &g = h.g;
+  const size_t n = (size_t)g.Ml * g.N1 * g.L;
+  hipLaunchKernelGGL(k_spec_tracer_update, grid1d(n), dim3(256), 0, s, g, h.d.coef, sc.delta_t, tracer_robert(h, e + 1), (const double2 *)dt_trs,
+                     (const double2 *)h.d.trxs[sc.prev][e], (double2 *)h.d.trxs[sc.cur][e], (double2 *)h.d.trxs[sc.fut][e]);
 }
 
 // The same two kernels on caller fields (C-ABI entry points isca_a_grid_horiz_advection / isca_vert_advection_ppm):

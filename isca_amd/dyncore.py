@@ -23,6 +23,7 @@ class IscaError(RuntimeError):
 
 
 MAX_LEVELS = 128          # ISCA_MAX_LEVELS
+MAX_TRACERS = 4           # ISCA_MAX_TRACERS
 
 
 class _CMoistConfig(C.Structure):
@@ -61,6 +62,7 @@ class _CConfig(C.Structure):
         ("moist", _CMoistConfig), ("radius", C.c_double), ("omega", C.c_double),
         ("damping_option", C.c_int), ("cutoff_wn", C.c_int), ("damping_coeff_vor", C.c_double), ("damping_coeff_div", C.c_double),
         ("damping_order_vor", C.c_int), ("damping_order_div", C.c_int),
+        ("tracer_spectral", C.c_int * MAX_TRACERS), ("tracer_robert_coeff", C.c_double * MAX_TRACERS),
     ]
 
 
@@ -198,6 +200,12 @@ def default_config(resolution: str | None = None, **overrides) -> _CConfig:
             for i, x in enumerate(v):
                 arr[i] = float(x)
             c.vert_coord_input = 1
+        elif k in ("tracer_spectral", "tracer_robert_coeff"):   # field_table entries, [k] = tracer k+1
+            if len(v) > MAX_TRACERS:
+                raise IscaError(f"{k}: more than {MAX_TRACERS} tracers")
+            arr = getattr(c, k)
+            for i, x in enumerate(v):
+                arr[i] = x
         elif k == "moist":
             for mk, mv in v.items():
                 if not hasattr(c.moist, mk):
@@ -236,6 +244,7 @@ class DynCore:
         self.I, self.J, self.L = cfg.lon_max, cfg.lat_max, cfg.num_levels
         self.M1, self.N1 = cfg.num_fourier + 1, cfg.num_spherical + 1
         self.Jl = self.info("lat_local")
+        self.tracer_names = ["sphum"] + [f"tracer{k + 1}" for k in range(1, max(cfg.num_tracers, 1))]   # field_table names (restart variables)
 
     # -- plumbing
     def _check(self, rc):
@@ -265,7 +274,7 @@ class DynCore:
             return (Jl, I), False
         if name in ("p_half", "z_half"):
             return (L + 1, Jl, I), False
-        if name in ("vors", "divs", "ts", "s_dtvor", "s_dtdiv", "s_dtT"):
+        if name in ("vors", "divs", "ts", "s_dtvor", "s_dtdiv", "s_dtT", "trs2", "trs3", "trs4"):
             return (L, N1, M1), True
         if name in ("ln_ps", "s_dtlp"):
             return (N1, M1), True

@@ -42,6 +42,7 @@ class Experiment:
         self.namelist: dict = {}
         self.diag_table = DiagTable()                 # experiment.py:79; history files land in the run's data folder
         self.resolution: str | None = None
+        self.field_table_file: str | None = None      # experiment.py:75: the run's field_table; None = the dry default (one grid tracer, sphum)
         self.log = logging.getLogger("isca_amd.experiment")
 
     # ---- namelist handling (experiment.py:121-143)
@@ -117,7 +118,11 @@ class Experiment:
         nsteps = self.steps_per_run()
         dt = self.namelist["main_nml"]["dt_atmos"]
         try:
-            core = atm.atmosphere_init(copy.deepcopy(self.namelist), run_dir=self.rundir)
+            ft = None
+            if self.field_table_file is not None:
+                with open(self.field_table_file) as f:
+                    ft = f.read()
+            core = atm.atmosphere_init(copy.deepcopy(self.namelist), run_dir=self.rundir, field_table=ft)
             hist = [History(core, spec, dt, os.path.join(self.rundir, name + ".nc"), start_seconds=(i - 1) * nsteps * dt)
                     for name, spec in self.diag_table.files.items() if spec["fields"]]
             collector = DiagCollector(core, hist)         # one set of device sums, shared by all files of the table

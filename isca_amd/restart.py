@@ -75,13 +75,26 @@ def _levels(core: DynCore, name):
     return out
 
 
-def write_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
+def _tracers(core: DynCore, tracer_name: str | None):
+    """(file name, grid state name, atmosphere copy name, spectral state name or None) per prognostic tracer (spectral_dynamics.F90:1520-1527)"""
+    if not core.info("tracer"):
+        return []
+    names = list(core.tracer_names)
+    if tracer_name is not None:
+        names[0] = tracer_name
+    out = [(names[0], "tr", "tr_atm", None)]
+    for k in range(1, core.cfg.num_tracers):
+        out.append((names[k], f"tr{k + 1}", f"tr_atm{k + 1}", f"trs{k + 1}" if core.cfg.tracer_spectral[k] else None))
+    return out
+
+
+def write_restart(core: DynCore, directory: str, tracer_name: str | None = None):
     """spectral_dynamics_end + atmosphere_end: write both restart files into `directory`."""
     if core.cfg.world_size != 1:
         raise IscaError("write_restart: gather the bands on one rank first (world_size == 1 only)")
     os.makedirs(directory, exist_ok=True)
     prev, cur = core.info("previous"), core.info("current")
-    has_tracer = bool(core.info("tracer"))
+    tracers = _tracers(core, tracer_name)
 
     w = _Writer(os.path.join(directory, "spectral_dynamics.res.nc"))
     w.put("previous", [float(prev + 1)] * 2)
@@ -94,8 +107,12 @@ def write_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
         w.put(nm + "_imag", [np.ascontiguousarray(a.imag) for a in lv])
     for nm in GRID3 + ("psg",):
         w.put(nm, _levels(core, nm))
-    if has_tracer:
-        w.put(tracer_name, _levels(core, "tr"))
+    for name, grid, _, spec in tracers:
+        w.put(name, _levels(core, grid))
+        if spec is not None:
+            lv = _levels(core, spec)
+            w.put(name + "_real", [np.ascontiguousarray(a.real) for a in lv])
+            w.put(name + "_imag", [np.ascontiguousarray(a.imag) for a in lv])
     w.put("vorg", [core.get("vorg")])
     w.put("divg", [core.get("divg")])
     w.put("surf_geopotential", [core.get("surf_geopotential")])
@@ -105,8 +122,8 @@ def write_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
     w.put("time_pointers", [np.array([prev + 1.0, cur + 1.0])] * 2)
     for nm in GRID3 + ("psg",):
         w.put(nm, _levels(core, nm))
-    if has_tracer:
-        w.put(tracer_name, _levels(core, "tr_atm"))
+    for name, _, atm_copy, _ in tracers:
+        w.put(name, _levels(core, atm_copy))
     w.put("wg_full", [core.get("wg_full")])
     w.close()
 
@@ -128,7 +145,7 @@ def restart_exists(directory: str) -> bool:
     return os.path.exists(os.path.join(directory, "spectral_dynamics.res.nc"))
 
 
-def read_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
+def read_restart(core: DynCore, directory: str, tracer_name: str | None = None):
     """The restart branch of spectral_dynamics_init/atmosphere_init: load both time levels into the device
     state, restore the leapfrog pointers and rebuild the derived grid fields."""
     if core.cfg.world_size != 1:
@@ -161,7 +178,7 @@ def read_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
     core.set_surf_geopotential(np.asarray(sd["surf_geopotential"]).reshape(-1, J, I)[0])       # spectral_dynamics.F90:575: the restart file's topography, not get_topography's
 
     core.set_time_pointers(prev, cur, 0 if prev == cur else 1)
-    has_tracer = bool(core.info("tracer"))
+    tracers = _tracers(core, tracer_name)
     for nt in (0, 1):
         tl = 0 if (nt == prev and prev != cur) else 1
         if prev != cur or nt == cur:
@@ -173,11 +190,13 @@ def read_restart(core: DynCore, directory: str, tracer_name: str = "sphum"):
                     raise IscaError(f"read_restart: {nm} of atmosphere.res and spectral_dynamics.res differ")
                 core.set(nm, sd[nm][nt], tl)
             core.set("psg", sd["psg"][nt].reshape(J, I), tl)
-            if has_tracer:
-                if tracer_name not in sd:
-                    raise IscaError(f"read_restart: tracer {tracer_name} not in the restart file")
-                core.set("tr", sd[tracer_name][nt], tl)
-                core.set("tr_atm", (at if at is not None else sd)[tracer_name][nt], tl)
+            for name, grid, atm_copy, spec in tracers:
+                if name not in sd or (spec is not None and name + "_real" not in sd):
+                    raise IscaError(f"read_restart: tracer {name} not in the restart file")
+                core.set(grid, sd[name][nt], tl)
+                core.set(atm_copy, (at if at is not None else sd)[name][nt], tl)
+                if spec is not None:
+                    core.set(spec, sd[name + "_real"][nt] + 1j * sd[name + "_imag"][nt], tl)
     if at is not None:
         core.set("wg_full", at["wg_full"][0])
     if core.cfg.physics == 1:                                    # mixed_layer_init: restart file, else the prescribed distribution

@@ -24,6 +24,22 @@ FIELD_TABLE = '''"TRACER", "atmos_mod", "sphum"
           "profile_type", "fixed",   "surface_value=0.0" /
 '''
 
+# three tracers: sphum as above, a second grid tracer with its own robert_coeff, and a spectral tracer with the defaults of
+# spectral_dynamics.F90:145-147 (advect_vert = second_centered, hole_filling = off).  hs_forcing's tracer_source_sink feeds all three.
+FIELD_TABLE_3 = FIELD_TABLE + '''"TRACER", "atmos_mod", "age_grid"
+          "longname",  "second grid tracer"
+          "units",     "none"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic"
+          "robert_filter",            "on", "robert_coeff=0.05"
+          "profile_type", "fixed",   "surface_value=0.0" /
+"TRACER", "atmos_mod", "age_spec"
+          "longname",  "spectral tracer"
+          "units",     "none"
+          "numerical_representation", "spectral"
+          "profile_type", "fixed",   "surface_value=0.0" /
+'''
+
 RES = {"T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
@@ -143,11 +159,11 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), m
         f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
 
 
-def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups=""):
+def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
     open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra, extra_groups))
-    open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)
+    open(os.path.join(d, "field_table"), "w").write(field_table)
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     ds = ", ".join(str(s) for s in dump_steps) if dump_steps else "-1"
     open(os.path.join(d, "harness.nml"), "w").write(
@@ -374,11 +390,12 @@ GAUSSIAN_TOPOG_GROUPS = """ &spectral_init_cond_nml
 """
 
 
-def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups=""):
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE):
     """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win); `extra_groups`: whole
     namelist groups appended to input.nml"""
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
-        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra, extra_groups=extra_groups)
+        prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra, extra_groups=extra_groups,
+                       field_table=field_table)
         stdout = run_harness(d)
         out = read_outputs(d, res, L)
     if keep is not None:
@@ -410,6 +427,10 @@ def main():
         "run_T21L25_10day": lambda: golden_run(
             "T21", 25, 1440, (1440,),
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_001440$", k) is not None),
+        # three tracers (grid sphum, a second grid tracer with robert_coeff = 0.05, a spectral tracer): spectral_dynamics.F90:1132-1183
+        "run_T21L8_three_tracers": lambda: golden_run(
+            "T21", 8, 40, (1, 2, 3, 40), field_table=FIELD_TABLE_3,
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr1|tr2|tr3)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,

@@ -217,6 +217,8 @@ character(len=8) :: tag
 complex, allocatable, dimension(:,:,:) :: vors, divs, ts
 complex, allocatable, dimension(:,:)   :: lnps
 real,    allocatable, dimension(:,:)   :: lnpsg
+integer :: ntr
+character(len=1) :: trno
 write(tag,'(i6.6)') n
 call dump3('st_ug_'//trim(tag)//'.bin', ug(:,:,:,current))
 call dump3('st_vg_'//trim(tag)//'.bin', vg(:,:,:,current))
@@ -225,7 +227,10 @@ call dump2('st_psg_'//trim(tag)//'.bin', psg(:,:,current))
 call dump3('st_wg_full_'//trim(tag)//'.bin', wg_full)
 call dump3('st_p_full_'//trim(tag)//'.bin', p_full(:,:,:,current))
 call dump3('st_z_full_'//trim(tag)//'.bin', z_full(:,:,:,current))
-if(num_tracers > 0) call dump3('st_tr1_'//trim(tag)//'.bin', grid_tracers(:,:,:,current,1))
+do ntr = 1, num_tracers
+  write(trno,'(i1)') ntr
+  call dump3('st_tr'//trno//'_'//trim(tag)//'.bin', grid_tracers(:,:,:,current,ntr))
+enddo
 ! spectral state re-derived through the public API (the module-private arrays have no getter)
 allocate(vors(ms:me,ns:ne,num_levels), divs(ms:me,ns:ne,num_levels), ts(ms:me,ns:ne,num_levels))
 allocate(lnps(ms:me,ns:ne), lnpsg(is:ie,js:je))

@@ -176,6 +176,49 @@ def test_golden_damping_options(golden_dir, case, opts):
     assert (c.damping_option, c.cutoff_wn) == (1, 12)
 
 
+def test_golden_three_tracers(golden_dir):
+    """A field_table with three tracers (update_tracers' loop, spectral_dynamics.F90:1132-1183): sphum (grid, PPM), a second grid tracer with
+    its own robert_coeff = 0.05, and a spectral tracer (spectral horizontal advection, second-centred vertical advection, damped like
+    temperature), all fed by hs_forcing's source/sink.  40 steps at T21L8 against the reference run; the dynamics must not notice."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_three_tracers.npz"))
+    opts = dict(num_tracers=3, tracer_spectral=[0, 0, 1], tracer_robert_coeff=[-1.0, 0.05, -1.0])
+    dc = make("T21", 8, **opts); dc.cold_start()
+    done = 0
+    for n in (1, 2, 3, 40):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k == "ug" else 1e-300))
+               for k in ("ug", "tg", "psg")}
+        for k, gk in (("tr", "tr1"), ("tr2", "tr2"), ("tr3", "tr3")):
+            err[k] = rel(dc.get(k), g[f"st_{gk}_{n:06d}"])
+        print("three tracers, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    # the spectral tracer's coefficients are the transform of its grid values (trans_spherical_to_grid of spec_tracers(future), :1154)
+    assert rel(dc.trans_spherical_to_grid(dc.get("trs3")), dc.get("tr3")) < 1e-12
+    # restart: every tracer's time levels and the spectral coefficients round-trip, the run continues bit for bit
+    names = ["ug", "vg", "tg", "psg", "tr", "tr_atm", "tr2", "tr_atm2", "tr3", "tr_atm3", "vors", "divs", "ts", "ln_ps", "trs3"]
+    saved = {(k, t): dc.get(k, t) for k in names for t in (0, 1)}
+    prev, cur, steps = dc.info("previous"), dc.info("current"), dc.info("step")
+    dc.step(5)
+    want = {k: dc.get(k) for k in ("tg", "tr", "tr2", "tr3")}
+    dc.close()
+    dc = make("T21", 8, **opts)
+    dc.set_time_pointers(prev, cur, steps)
+    for (k, t), v in saved.items():
+        dc.set(k, v, t)
+    dc.refresh_derived()
+    dc.step(5)
+    for k, v in want.items():
+        assert np.array_equal(dc.get(k), v), k
+    dc.close()
+    # a second tracer on a sharded run, with the RAW filter, or with an unknown representation is refused
+    with pytest.raises(dyncore.IscaError, match="single rank"):
+        make("T21", 8, num_tracers=2, world_size=2, rank=0)
+    with pytest.raises(dyncore.IscaError, match="raw_filter_coeff must be 1"):
+        make("T21", 8, num_tracers=2, raw_filter_coeff=0.7)
+    with pytest.raises(dyncore.IscaError, match="numerical_representation"):
+        make("T21", 8, num_tracers=2, tracer_spectral=[0, 2])
+
+
 def test_golden_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (leapfrog.F90:58-105): the step gets a third transform phase -- grid u, v, T, ps, vor, div of the new level
     from the unadjusted spectral state, its RAW adjustment afterwards (spectral_dynamics.F90:1031), the next step's gradients from the

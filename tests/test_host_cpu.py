@@ -142,7 +142,8 @@ def test_restart_file_round_trip_on_host(tmp_path):
 
     class Host:
         L, J, Jl, I, N1, M1 = 3, 8, 8, 16, 7, 6
-        cfg = types.SimpleNamespace(world_size=1, physics=0)
+        cfg = types.SimpleNamespace(world_size=1, physics=0, num_tracers=3, tracer_spectral=[0, 0, 1])
+        tracer_names = ["sphum", "age_grid", "age_spec"]
 
         def __init__(self, seed=None):
             self.ptr = {"previous": 1, "current": 0, "tracer": 1, "step": 5}
@@ -150,10 +151,10 @@ def test_restart_file_round_trip_on_host(tmp_path):
             if seed is not None:
                 rng = np.random.default_rng(seed)
                 for tl in (0, 1):
-                    for nm in ("vors", "divs", "ts"):
+                    for nm in ("vors", "divs", "ts", "trs3"):
                         self.store[nm, tl] = rng.standard_normal((3, 7, 6)) + 1j * rng.standard_normal((3, 7, 6))
                     self.store["ln_ps", tl] = rng.standard_normal((7, 6)) + 1j * rng.standard_normal((7, 6))
-                    for nm in ("ug", "vg", "tg", "tr", "tr_atm", "vorg", "divg", "wg_full"):
+                    for nm in ("ug", "vg", "tg", "tr", "tr_atm", "tr2", "tr_atm2", "tr3", "tr_atm3", "vorg", "divg", "wg_full"):
                         self.store[nm, tl] = rng.standard_normal((3, 8, 16))
                     self.store["psg", tl] = 1e5 + rng.standard_normal((8, 16))
                 for nm in ("vorg", "divg", "wg_full"):
@@ -177,6 +178,9 @@ def test_restart_file_round_trip_on_host(tmp_path):
     dims = f.variables["vors_real"].dimensions
     assert dims[0] == "Time" and [d[:5] for d in dims[1:]] == ["zaxis", "yaxis", "xaxis"]
     assert f.variables["vors_real"].shape == (2, 3, 7, 6) and f.variables["psg"].shape == (2, 1, 8, 16)
+    # every field_table tracer under its own name, a spectral one also as <name>_real / <name>_imag (spectral_dynamics.F90:1520-1527)
+    assert np.array_equal(f.variables["age_grid"][1], a.store["tr2", 0]) and np.array_equal(f.variables["age_spec"][0], a.store["tr3", 1])
+    assert np.array_equal(f.variables["age_spec_imag"][0], a.store["trs3", 1].imag) and "age_grid_real" not in f.variables
     f.close()
     b = Host()
     restart.read_restart(b, str(tmp_path))
@@ -331,3 +335,39 @@ def test_fortran_binding_abi(lib, tmp_path):
     assert vals == [0.04, 0.2, 6376.0e3, 800.0]
     sib = r.stdout.split("SIBLINGS")[1].split()[:4]
     assert [float(x) for x in sib[:3]] == [3.e4, 172800.0, 8.e-5] and int(sib[3]) == 4
+
+
+def test_field_table_entries():
+    """tracer_manager's field_table as spectral_dynamics_init reads it (spectral_dynamics.F90:316-409): representation, vertical
+    scheme, the tracer's own robert_coeff; what the kernels do not implement is refused by name."""
+    from isca_amd import atmosphere as atm
+    from isca_amd.dyncore import IscaError
+    text = '''# dry default plus two more
+"TRACER", "atmos_mod", "sphum"
+          "longname",  "specific humidity"
+          "numerical_representation", "grid"
+          "hole_filling", "off"
+          "advect_vert", "finite_volume_parabolic"
+          "robert_filter", "on"
+          "profile_type", "fixed", "surface_value=0.0" /
+"TRACER", "land_mod", "sphum"
+          "longname", "not ours" /
+"TRACER", "atmos_mod", "Age_Grid"
+          "numerical_representation", "grid"
+          "advect_vert", "finite_volume_parabolic"
+          "robert_filter", "on", "robert_coeff=0.05" /
+"TRACER", "atmos_mod", "age_spec"
+          "robert_filter", "off" /
+'''
+    entries = atm.parse_field_table(text)
+    assert [e["name"] for e in entries] == ["sphum", "age_grid", "age_spec"]
+    keys, names = atm.tracers_from_field_table(entries, 0.03)
+    assert keys == dict(num_tracers=3, tracer_spectral=[0, 0, 1], tracer_robert_coeff=[-1.0, 0.05, 0.0]) and names[2] == "age_spec"
+    for bad, msg in (('"TRACER", "atmos_mod", "x"\n "numerical_representation", "grid" /', "advect_vert = second_centered is not available"),
+                     ('"TRACER", "atmos_mod", "x"\n "numerical_representation", "wavelet" /', "invalid numerical_representation"),
+                     ('"TRACER", "atmos_mod", "x"\n "advect_vert", "upwind" /', "invalid advect_vert"),
+                     ('"TRACER", "atmos_mod", "x" /', "must be a grid tracer"),
+                     (text + '"TRACER", "atmos_mod", "y"\n "hole_filling", "on" /', "hole_filling = on"),
+                     (text * 2, "at most 4")):
+        with pytest.raises(IscaError, match=msg):
+            atm.tracers_from_field_table(atm.parse_field_table(bad))
