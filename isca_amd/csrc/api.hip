@@ -196,7 +196,7 @@ static void build_field_lists(isca_dyn *h) {
   int off = 0;
   for (int i = 0; i < 5; ++i) { f.g[i] = fg[i]; f.nlev[i] = (i < 4) ? L : 1; f.off[i] = off; f.op[i] = OP_NONE; off += f.nlev[i]; }
   f.ncol = off;
-  h->Cf = 2 * f.ncol;
+  h->Cf = col_pitch(f.ncol);
 }
 // inverse batch targets depend on the time level that receives the new state
 static FieldList inverse_list(isca_dyn *h, int tl) {
@@ -405,7 +405,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     // ---- work buffers sized for the largest batch (7L+3 level-fields)
     h->cap_cols = 7 * g.L + 3;
-    const size_t nF = (size_t)g.P * g.Ml * g.Jl * 2 * h->cap_cols, nS = (size_t)g.Ml * g.N1 * 2 * h->cap_cols;
+    const size_t nF = (size_t)g.P * g.Ml * g.Jl * col_pitch(h->cap_cols), nS = (size_t)g.Ml * g.N1 * col_pitch(h->cap_cols);
     d.Ff_g = dalloc<double>(h, nF); d.Fi_s = dalloc<double>(h, nF);
     if (g.P == 1) { d.Ff_s = d.Ff_g; d.Fi_g = d.Fi_s; }
     else { d.Ff_s = dalloc<double>(h, nF); d.Fi_g = dalloc<double>(h, nF); }
@@ -490,7 +490,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     for (int i = 0; i < 4; ++i) { d.scratch_g[i] = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.scratch_s[i] = dalloc<double>(h, (size_t)g.Ml * g.N1 * (g.L + 1) * 2); }
     build_field_lists(h);
-    h->Ci = 2 * (7 * g.L + 3);
+    h->Ci = col_pitch(7 * g.L + 3);
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
     h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl);
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
@@ -513,12 +513,12 @@ static void require_single(isca_dyn *h, const char *what) {
   if (h->g.P != 1) fail(std::string(what) + ": only available with world_size == 1 (use the phase API)");
 }
 static void run_inverse(isca_dyn *h, const FieldList &fl, int full) {    // Si -> grid
-  const int C = 2 * fl.ncol;
+  const int C = col_pitch(fl.ncol);
   { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, C, full, h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
 }
 static void run_forward(isca_dyn *h, const FieldList &fl, int full) {    // grid -> Sf
-  const int C = 2 * fl.ncol;
+  const int C = col_pitch(fl.ncol);
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, fl, h->d.Ff_g, h->stream); }
   { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, C, full, h->cfg.legendre_impl, h->stream); }
 }
@@ -531,30 +531,30 @@ static FieldList pair_list(double *a, double *b, int nlev, int op) {
 // device spectral state [ml][n][nlev] -> grid (trans_spherical_to_grid)
 static void dev_s2g(isca_dyn *h, const double *spec, double *grid, int nlev, int op) {
   FieldList fl = single_list(grid, nlev, op);
-  launch_spec_pack(h->g, spec, h->d.Si, 2 * fl.ncol, 0, nlev, h->stream);
+  launch_spec_pack(h->g, spec, h->d.Si, col_pitch(fl.ncol), 0, nlev, h->stream);
   run_inverse(h, fl, 1);
 }
 static void dev_g2s(isca_dyn *h, double *grid, double *spec, int nlev, int do_trunc, int op) {
   FieldList fl = single_list(grid, nlev, op);
   run_forward(h, fl, 1);
-  launch_spec_unpack(h->g, h->d, h->d.Sf, spec, 2 * fl.ncol, 0, nlev, do_trunc, h->stream);
+  launch_spec_unpack(h->g, h->d, h->d.Sf, spec, col_pitch(fl.ncol), 0, nlev, do_trunc, h->stream);
 }
 static void dev_uv_from_vd(isca_dyn *h, const double *vor, const double *div, double *u, double *v, int nlev) {
   FieldList fl = pair_list(u, v, nlev, OP_COSM);
-  launch_spec_ucos_vcos(h->g, h->d, vor, div, h->d.Si, 2 * fl.ncol, 0, nlev, nlev, h->stream);
+  launch_spec_ucos_vcos(h->g, h->d, vor, div, h->d.Si, col_pitch(fl.ncol), 0, nlev, nlev, h->stream);
   run_inverse(h, fl, 1);
 }
 static void dev_vd_from_uv(isca_dyn *h, double *u, double *v, double *vor, double *div, int nlev) {
   FieldList fl = pair_list(u, v, nlev, OP_COSM);
   run_forward(h, fl, 1);
-  launch_spec_vor_div(h->g, h->d, h->d.Sf, 2 * fl.ncol, 0, nlev, vor, div, nlev, h->stream);
+  launch_spec_vor_div(h->g, h->d, h->d.Sf, col_pitch(fl.ncol), 0, nlev, vor, div, nlev, h->stream);
 }
 
 // all grid fields at time level tl (+ vorg, divg, gradients) from the spectral state at tl
 static void synthesize_level(isca_dyn *h, int tl) {
   FieldList fl = inverse_list(h, tl);
   if (h->fuse_synth) {     // the step's own synthesis kernel: a restarted run then continues bit for bit
-    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, 2 * fl.ncol, 0, h->cfg.legendre_impl, h->stream, tl); }
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, col_pitch(fl.ncol), 0, h->cfg.legendre_impl, h->stream, tl); }
     { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
     return;
   }
@@ -882,7 +882,7 @@ static void raw_filter_phase(isca_dyn *h, const StepScalars &sc) {
   int off = 0;
   for (int i = 0; i < 4; ++i) { fl.g[i] = gp[i]; fl.nlev[i] = i < 2 ? g.L : 1; fl.off[i] = off; fl.op[i] = OP_COSM; off += fl.nlev[i]; }
   fl.ncol = off;
-  const int C = 2 * fl.ncol;
+  const int C = col_pitch(fl.ncol);
   Timed t(h, "raw_gradients");
   launch_spec_gradient(g, d, d.ts[sc.fut], d.Si, C, 0, g.L, g.L, h->stream);
   launch_spec_gradient(g, d, d.lnps[sc.fut], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
@@ -904,7 +904,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
     if (h->cfg.physics == 0) launch_tracer_source_sink(*h, d.psg[sc.cur], d.trx_atm[sc.prev][e], dt_tr, h->stream);
   }
   FieldList fl = pair_list(d.scratch_g[0], d.scratch_g[1], g.L, OP_COSM);
-  launch_spec_gradient(g, d, d.trxs[sc.cur][e], d.Si, 2 * fl.ncol, 0, g.L, g.L, h->stream);
+  launch_spec_gradient(g, d, d.trxs[sc.cur][e], d.Si, col_pitch(fl.ncol), 0, g.L, g.L, h->stream);
   run_inverse(h, fl, 1);
   launch_hadv_combine(g, d.ug[sc.cur], d.vg[sc.cur], d.scratch_g[0], d.scratch_g[1], dt_tr, g.L, h->stream);
   launch_vert_advection_centered(*h, d.wg, d.psg[sc.cur], d.trx[sc.cur][e], dt_tr, h->stream);
@@ -915,7 +915,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
   if (h->cfg.raw_filter_coeff != 1.0) raw_filter_phase(h, sc);
-  if (h->tracer_on) {
+  if (h->tracer_on && h->cfg.num_tracers > 1) {
     Timed t(h, "tracers_2_up");
     for (int e = 0; e + 1 < h->cfg.num_tracers; ++e) {     // tracers 2..num_tracers (their transport, if 'grid', ran beside tracer 1's)
       if (h->cfg.tracer_spectral[e + 1]) spectral_tracer_step(h, sc, e);
@@ -1347,7 +1347,7 @@ extern "C" int isca_horizontal_advection(isca_dyn_t *h, const double *field_spec
   Dev &d = h->d;
   spec_host_to_dev(h, field_spec, d.scratch_s[0], nlev);
   FieldList fl = pair_list(d.scratch_g[0], d.scratch_g[1], nlev, OP_COSM);
-  launch_spec_gradient(h->g, d, d.scratch_s[0], d.Si, 2 * fl.ncol, 0, nlev, nlev, h->stream);
+  launch_spec_gradient(h->g, d, d.scratch_s[0], d.Si, col_pitch(fl.ncol), 0, nlev, nlev, h->stream);
   run_inverse(h, fl, 1);
   h2d(h, d.scratch_g[2], u, n); h2d(h, d.scratch_g[3], v, n);
   // tendency buffer: reuse g_E as scratch only when no step is in flight (host-synchronous API)
@@ -1361,7 +1361,7 @@ extern "C" int isca_horizontal_advection(isca_dyn_t *h, const double *field_spec
 // host fourier layout: (m, lat, lev) complex with m = 0..num_fourier
 static void fourier_host_to_dev(isca_dyn *h, const double *host, double *dev, int nlev) {
   const Geom &g = h->g;
-  const int C = 2 * nlev;
+  const int C = col_pitch(nlev);
   std::vector<double> tmp((size_t)g.Ml * g.Jl * C, 0.0);
   for (int k = 0; k < nlev; ++k) for (int j = 0; j < g.J; ++j) for (int m = 0; m < g.M1; ++m) {
     const size_t src = (((size_t)k * g.J + j) * g.M1 + m) * 2, dst = ((size_t)h->h_slot_of_m[m] * g.Jl + j) * C + 2 * k;
@@ -1371,7 +1371,7 @@ static void fourier_host_to_dev(isca_dyn *h, const double *host, double *dev, in
 }
 static void fourier_dev_to_host(isca_dyn *h, const double *dev, double *host, int nlev) {
   const Geom &g = h->g;
-  const int C = 2 * nlev;
+  const int C = col_pitch(nlev);
   std::vector<double> tmp((size_t)g.Ml * g.Jl * C);
   d2h(h, tmp.data(), dev, tmp.size());
   for (int k = 0; k < nlev; ++k) for (int j = 0; j < g.J; ++j) for (int m = 0; m < g.M1; ++m) {
@@ -1383,8 +1383,8 @@ extern "C" int isca_trans_spherical_to_fourier(isca_dyn_t *h, const double *sphe
   API_BEGIN
   require_single(h, "trans_spherical_to_fourier"); check_nlev(h, nlev);
   spec_host_to_dev(h, spherical, h->d.scratch_s[0], nlev);
-  launch_spec_pack(h->g, h->d.scratch_s[0], h->d.Si, 2 * nlev, 0, nlev, h->stream);
-  launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, 2 * nlev, 1, h->cfg.legendre_impl, h->stream);
+  launch_spec_pack(h->g, h->d.scratch_s[0], h->d.Si, col_pitch(nlev), 0, nlev, h->stream);
+  launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, col_pitch(nlev), 1, h->cfg.legendre_impl, h->stream);
   fourier_dev_to_host(h, h->d.Fi_s, fourier, nlev);
   API_END
 }
@@ -1392,8 +1392,8 @@ extern "C" int isca_trans_fourier_to_spherical(isca_dyn_t *h, const double *four
   API_BEGIN
   require_single(h, "trans_fourier_to_spherical"); check_nlev(h, nlev);
   fourier_host_to_dev(h, fourier, h->d.Ff_s, nlev);
-  launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, 2 * nlev, 1, h->cfg.legendre_impl, h->stream);
-  launch_spec_unpack(h->g, h->d, h->d.Sf, h->d.scratch_s[0], 2 * nlev, 0, nlev, 0, h->stream);
+  launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, col_pitch(nlev), 1, h->cfg.legendre_impl, h->stream);
+  launch_spec_unpack(h->g, h->d, h->d.Sf, h->d.scratch_s[0], col_pitch(nlev), 0, nlev, 0, h->stream);
   spec_dev_to_host(h, h->d.scratch_s[0], spherical, nlev);
   API_END
 }
@@ -1769,18 +1769,19 @@ extern "C" int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, d
   HIP_CHECK(hipMalloc((void **)&grid, ngrid * sizeof(double)));
   // band-limited random coefficients already in Si (deterministic LCG), synthesised once
   {
-    std::vector<double> s((size_t)g.Ml * g.N1 * 2 * nfields, 0.0);
+    const int C = col_pitch(nfields);
+    std::vector<double> s((size_t)g.Ml * g.N1 * C, 0.0);
     unsigned long long st = 20260927ULL;
     for (int ml = 0; ml < g.Ml; ++ml) for (int n = 0; n < g.N1 - 1 - h->h_m_local[ml]; ++n) for (int c = 0; c < 2 * nfields; ++c) {
       st = st * 6364136223846793005ULL + 1442695040888963407ULL;
       const double r = ((double)(st >> 11) / 9007199254740992.0) - 0.5;
       const double tot = h->h_m_local[ml] + n;
-      s[((size_t)ml * g.N1 + n) * 2 * nfields + c] = (h->h_m_local[ml] == 0 && (c & 1)) ? 0.0 : r / ((1 + tot) * (1 + tot));
+      s[((size_t)ml * g.N1 + n) * C + c] = (h->h_m_local[ml] == 0 && (c & 1)) ? 0.0 : r / ((1 + tot) * (1 + tot));
     }
     h2d(h, h->d.Si, s.data(), s.size());
   }
   FieldList fl = single_list(grid, nfields, OP_NONE);
-  const int C = 2 * nfields;
+  const int C = col_pitch(nfields);
   hipEvent_t ev[5][2];
   for (auto &e : ev) { hipEventCreate(&e[0]); hipEventCreate(&e[1]); }
   double acc[5] = {0, 0, 0, 0, 0};

@@ -23,6 +23,11 @@ constexpr int MAX_FIELDS = 12;
 // One batched transform = a list of level-fields.  Grid side: pointers to [nlev][Jl][I] arrays.
 // Column index of (field f, level k, re/im) in the Fourier / spectral work buffers: 2*(off[f]+k)+ri.
 enum GridOp { OP_NONE = 0, OP_COSM = 1, OP_EXP = 2 };
+// Doubles per row of the Fourier / spectral work buffers holding `ncol` complex level-fields: padded to whole 128-byte lines, so that the
+// FFT kernels' per-wavenumber pieces (8 or 16 columns) and the Legendre kernels' column tiles start on a line (the few padding columns are
+// transformed like the others and never read back)
+inline int col_pitch(int ncol) { return (2 * ncol + 15) & ~15; }
+
 struct FieldList {
   int nf;
   int ncol;                 // real level-fields = sum(nlev)

@@ -267,41 +267,269 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
   }
 }
 
+
+// ---- lon_max = 256 / 512 (NC = 128 / 256): the same three Stockham passes (radix 8, 8 or 4, 4) with less LDS traffic and two
+// block barriers per item.  The generic kernels above are LDS-bound: three in-place passes + the split make 5 writes and 6 reads of
+// every row per transform.  Here a row is held by NC/8 threads with 8 elements each, element tr + TPR i in register i: that is
+// the input set of the thread's first-pass butterfly (stride NC/8) and the output set of its last-pass butterflies (stride S3, one
+// block per row), so the first pass runs on the registers the row was loaded into and -- inverse -- the last pass is stored from
+// registers: 3 writes + 4 reads.  A row's threads sit in one wavefront, whose LDS operations execute in program order, so the
+// passes need no block barrier (two per item remain, around the transposed access to the Fourier buffer).  Same butterflies, same
+// twiddles, same order as fft_row: bit-identical results.
+template <int NC> struct Fft3 {
+  static constexpr int TPR = NC / 8, R = 256 / TPR, R2 = (NC == 128) ? 4 : 8, S3 = 8 * R2, NB2 = NC / R2, BF2 = NB2 / TPR, BF3 = (NC / 4) / TPR;
+  static constexpr int rs = NC + NC / 8 + 1;
+};
+template <int NC, bool INV, bool TWREG> struct FftTw {
+  double2 w1[TWREG ? 8 : 1], w2[TWREG ? Fft3<NC>::BF2 : 1][TWREG ? Fft3<NC>::R2 : 1];
+  const double2 *twl;
+  __device__ __forceinline__ void init(const double2 *__restrict__ tw, const double2 *twl_, int tr) {
+    twl = twl_;
+    if constexpr (TWREG) {
+#pragma unroll
+      for (int j = 1; j < 8; ++j) w1[j] = get(tw, 2 * j * tr);
+#pragma unroll
+      for (int u = 0; u < Fft3<NC>::BF2; ++u)
+#pragma unroll
+        for (int j = 1; j < Fft3<NC>::R2; ++j) w2[u][j] = get(tw, 16 * j * ((tr + Fft3<NC>::TPR * u) >> 3));
+    }
+  }
+  static __device__ __forceinline__ double2 get(const double2 *t, int k) { double2 w = t[k]; if (INV) w.y = -w.y; return w; }
+  __device__ __forceinline__ double2 p1(int j, int tr) const { if constexpr (TWREG) return w1[j]; else return get(twl, 2 * j * tr); }
+  __device__ __forceinline__ double2 p2(int u, int j, int p) const { if constexpr (TWREG) return w2[u][j]; else return get(twl, 16 * j * p); }
+};
+// z[i] = element tr + TPR i in; transform out in the same layout.  `row` = the row's LDS storage.
+template <int NC, bool INV, bool TWREG> __device__ __forceinline__ void fft3_row(double2 (&z)[8], double2 *row, const FftTw<NC, INV, TWREG> &w, int tr) {
+  constexpr int TPR = Fft3<NC>::TPR, R2 = Fft3<NC>::R2, S3 = Fft3<NC>::S3, BF2 = Fft3<NC>::BF2, BF3 = Fft3<NC>::BF3;
+  // pass 1: radix 8, stride 1, butterfly b = tr: inputs b + (NC/8) j = registers, outputs 8 b + j
+  dftR<INV, 8>(z);
+  row[fpad(8 * tr)] = z[0];
+#pragma unroll
+  for (int j = 1; j < 8; ++j) row[fpad(8 * tr + j)] = cmul(z[j], w.p1(j, tr));
+  __builtin_amdgcn_wave_barrier();
+  {  // pass 2: radix R2, stride 8, in place
+    double2 v[BF2][R2];
+    const int q = tr & 7;
+#pragma unroll
+    for (int u = 0; u < BF2; ++u) {
+      const int p = (tr + TPR * u) >> 3;
+#pragma unroll
+      for (int j = 0; j < R2; ++j) v[u][j] = row[fpad(q + 8 * (p + (NC / (8 * R2)) * j))];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < BF2; ++u) {
+      const int p = (tr + TPR * u) >> 3;
+      dftR<INV, R2>(v[u]);
+      row[fpad(q + 8 * (R2 * p))] = v[u][0];
+#pragma unroll
+      for (int j = 1; j < R2; ++j) row[fpad(q + 8 * (R2 * p + j))] = cmul(v[u][j], w.p2(u, j, p));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // pass 3: radix 4, stride S3, one block: butterfly q = tr + TPR u, inputs / outputs q + S3 j = registers u + BF3 j; twiddle twl[0] = 1
+  const double2 one = make_double2(1.0, INV ? -0.0 : 0.0);
+#pragma unroll
+  for (int u = 0; u < BF3; ++u) {
+    double2 v[4];
+    const int q = tr + TPR * u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = row[fpad(q + S3 * j)];
+    dftR<INV, 4>(v);
+    z[u] = v[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) z[u + BF3 * j] = cmul(v[j], one);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NC, bool TWREG>
+__global__ __launch_bounds__(256) void k_fft_fwd3(Geom g, FieldList fl, const double *__restrict__ cosm, const int *__restrict__ slot_of_m,
+                                                  const double2 *__restrict__ tw, double *__restrict__ Fg, int C, int GX) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TPR = Fft3<NC>::TPR, R = Fft3<NC>::R, rs = Fft3<NC>::rs;
+  double2 *buf = (double2 *)smem, *twl = buf + R * rs;
+  int *slot = (int *)(twl + 2 * NC);                    // Fourier-buffer slot of wavenumber m (above the truncation: that of m = 0)
+  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
+  for (int m = t; m < NC; m += 256) slot[m] = slot_of_m[m < g.M1 ? m : 0];
+  FftTw<NC, false, TWREG> w;
+  w.init(tw, twl, tr);
+  const int rr = t % R;
+  const double inv_n = 1.0 / (double)g.I;
+  const int NG = GX * g.Jl;
+  double2 zn[8];
+  double scale_n = 0.0;
+  auto request = [&](int item, double2 (&z)[8], double &scale) {         // a padding row re-reads a valid row and gets scale 0
+    const int gx = item % GX, jl = item / GX;
+    const int c = gx * R + r;
+    const double2 *src = (const double2 *)(fl.g[0] + (size_t)jl * g.I);
+    scale = 0.0;
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      const int k = c - fl.off[f];
+      src = (const double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
+      scale = (fl.op[f] == OP_COSM) ? cosm[jl] : 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = src[tr + TPR * i];
+  };
+  double2 *row = buf + r * rs;
+  int item = fft_first_item();
+  if (item < NG) request(item, zn, scale_n);
+  __syncthreads();                                     // twl, slot
+  for (; item < NG; item += gridDim.x) {
+    const int gx = item % GX, jl = item / GX;
+    double2 z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = make_double2(zn[i].x * scale_n, zn[i].y * scale_n);
+    if (item + (int)gridDim.x < NG) request(item + gridDim.x, zn, scale_n);       // in flight during the transform
+    fft3_row<NC, false, TWREG>(z, row, w, tr);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[fpad(tr + TPR * i)] = z[i];
+    __syncthreads();
+    // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
+    const int cc = gx * R + rr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = t / R + TPR * i;
+      if (m < g.M1) {
+        const double2 zk = buf[rr * rs + fpad(m)];
+        const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
+        const double2 e = cscale(0.5, cadd(zk, zc));
+        const double2 dd = csub(zk, zc);
+        const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+        double2 X = cadd(e, cmul(twl[m], o));
+        X.x *= inv_n; X.y *= inv_n;
+        if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot[m] * g.Jl + jl) * C + 2 * cc) = X;
+      }
+    }
+    __syncthreads();                                   // the rows are rewritten by the next item
+  }
+}
+
+template <int NC, bool TWREG>
+__global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const double *__restrict__ cosm, const int *__restrict__ slot_of_m,
+                                                  const double2 *__restrict__ tw, const double *__restrict__ Fg, int C, int GX) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TPR = Fft3<NC>::TPR, R = Fft3<NC>::R, rs = Fft3<NC>::rs;
+  double2 *buf = (double2 *)smem, *twl = buf + R * rs;
+  int *slot = (int *)(twl + 2 * NC);
+  const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
+  for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
+  for (int m = t; m < NC; m += 256) slot[m] = slot_of_m[m < g.M1 ? m : 0];
+  FftTw<NC, true, TWREG> w;
+  w.init(tw, twl, tr);
+  const int rr = t % R;
+  const int NG = GX * g.Jl;
+  double2 Xn[8];
+  __syncthreads();                                     // twl, slot
+  auto request = [&](int item, double2 (&X)[8]) {      // wavenumbers above the truncation re-read m = 0 and are zeroed
+    const int gx = item % GX, jl = item / GX;
+    const int ccl = min(gx * R + rr, fl.ncol - 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) X[i] = *(const double2 *)(Fg + ((size_t)slot[t / R + TPR * i] * g.Jl + jl) * C + 2 * ccl);
+  };
+  double2 *row = buf + r * rs;
+  int item = fft_first_item();
+  if (item < NG) request(item, Xn);
+  for (; item < NG; item += gridDim.x) {
+    const int gx = item % GX, jl = item / GX;
+    {  // transforms.F90:424 zeroes everything above the truncation
+      const int cc = gx * R + rr;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = t / R + TPR * i;
+        double2 x = (m < g.M1 && cc < fl.ncol) ? Xn[i] : make_double2(0., 0.);
+        if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
+        buf[rr * rs + fpad(m)] = x;
+      }
+    }
+    if (item + (int)gridDim.x < NG) request(item + gridDim.x, Xn);               // in flight during the transform
+    __syncthreads();
+    double2 z[8];
+    // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = tr + TPR * i;
+      const double2 xk = row[fpad(k)];
+      const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(row[fpad(NC - k)]);
+      const double2 e = cadd(xk, xc);
+      const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
+      z[i] = make_double2(e.x - o.y, e.y + o.x);
+    }
+    __builtin_amdgcn_wave_barrier();
+    fft3_row<NC, true, TWREG>(z, row, w, tr);
+    const int c = gx * R + r;
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      const int k = c - fl.off[f];
+      double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
+      const int op = fl.op[f];
+      const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        double2 v = z[i];
+        if (op == OP_EXP) { v.x = exp(v.x); v.y = exp(v.y); }
+        else { v.x *= scale; v.y *= scale; }
+        dst[tr + TPR * i] = v;
+      }
+    }
+    __syncthreads();                                   // the rows are rewritten by the next item
+  }
+}
+
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
 static unsigned fft_grid(int items) {                  // persistent blocks: at most 3 per CU of the 256 (LDS-limited residency; measured
   const int cap = 768;                                 // against 512 / 1024 / 1536), and the same number of items for every block
   const int rounds = (items + cap - 1) / cap;
   return (unsigned)((items + rounds - 1) / rounds);
 }
+static bool fft_old() { static const bool v = getenv("ISCA_FFT_OLD") != nullptr; return v; }   // measurement switch: the generic LDS passes
+static bool fft_twreg() { static const bool v = getenv("ISCA_FFT_TWLDS") == nullptr; return v; }    // pass twiddles in registers (default) or read from LDS
+static size_t fft3_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2) + NC * sizeof(int); }
+static dim3 fft3_grid(int items) {                     // persistent blocks of 256 threads: 2 per CU (~196 VGPRs; measured against 3 and 4 per CU)
+  static const int cap = getenv("ISCA_FFT_CAP") ? atoi(getenv("ISCA_FFT_CAP")) : 512;
+  const int rounds = (items + cap - 1) / cap;
+  return dim3((unsigned)((items + rounds - 1) / rounds));
+}
 static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
-  const int C = 2 * fl.ncol, NC = g.I / 2;
+  const int C = col_pitch(fl.ncol), NC = g.I / 2;
   const int R = fft_rows(NC);
   const int GX = (fl.ncol + R - 1) / R;
   dim3 grid(fft_grid(GX * g.Jl));
   const size_t lds = fft_lds_bytes(NC);
+#define LF3(N, TW) hipLaunchKernelGGL((k_fft_fwd3<N, TW>), fft3_grid(GX * g.Jl), dim3(256), fft3_lds_bytes(NC), s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
 #define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
-    case 128: LF(128); break; case 256: LF(256); break;
+    case 128: if (fft_old()) LF(128); else if (fft_twreg()) LF3(128, true); else LF3(128, false); break;
+    case 256: if (fft_old()) LF(256); else if (fft_twreg()) LF3(256, true); else LF3(256, false); break;
     default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
   }
 #undef LF
+#undef LF3
 }
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
-  const int C = 2 * fl.ncol, NC = g.I / 2;
+  const int C = col_pitch(fl.ncol), NC = g.I / 2;
   const int R = fft_rows(NC);
   const int GX = (fl.ncol + R - 1) / R;
   dim3 grid(fft_grid(GX * g.Jl));
   const size_t lds = fft_lds_bytes(NC);
+#define LI3(N, TW) hipLaunchKernelGGL((k_fft_inv3<N, TW>), fft3_grid(GX * g.Jl), dim3(256), fft3_lds_bytes(NC), s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
 #define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
-    case 128: LI(128); break; case 256: LI(256); break;
+    case 128: if (fft_old()) LI(128); else if (fft_twreg()) LI3(128, true); else LI3(128, false); break;
+    case 256: if (fft_old()) LI(256); else if (fft_twreg()) LI3(256, true); else LI3(256, false); break;
     default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
   }
 #undef LI
+#undef LI3
 }
 
 // =====================================================================================================

@@ -232,6 +232,7 @@ class ShardedDynCore(dyncore.DynCore):
             setattr(c1, f, getattr(self.cfg, f))
         c1.rank, c1.world_size, c1.stream = 0, 1, None
         one = dyncore.DynCore(c1)
+        one.tracer_names = list(self.tracer_names)
         try:
             restart.read_restart(one, directory)
             self.set_time_pointers(one.info("previous"), one.info("current"), one.info("step"))
@@ -256,7 +257,8 @@ class _GatheredView:
     def __init__(self, sh: ShardedDynCore):
         import types
         self._sh = sh
-        self.cfg = types.SimpleNamespace(world_size=1, physics=sh.cfg.physics)
+        self.cfg = types.SimpleNamespace(world_size=1, physics=sh.cfg.physics, num_tracers=min(sh.cfg.num_tracers, 1), tracer_spectral=[0])
+        self.tracer_names = list(sh.tracer_names)        # a sharded run carries the first (grid) tracer only
         self.L, self.J, self.Jl, self.I, self.N1, self.M1 = sh.L, sh.J, sh.J, sh.I, sh.N1, sh.M1
         self._cache = {}
         for nm in ("vors", "divs", "ts", "ln_ps"):
