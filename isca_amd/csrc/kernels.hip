@@ -2283,7 +2283,7 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.robert = h.cfg.robert_coeff; a.raw = h.cfg.raw_filter_coeff; a.tr_part = h.d.tr_part;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
   const size_t n3 = (size_t)g.Jl * g.I * g.L;
-  const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
+  const unsigned nblk = (unsigned)std::min<size_t>(512, (n3 / 2 + 255) / 256);     // every block re-reduces the partials: 512 measured against 256 / 1024 / 2048
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
 
