@@ -59,6 +59,7 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: damping_order_vor, damping_order_div
   integer(c_int) :: tracer_spectral(ISCA_MAX_TRACERS)
   real(c_double) :: tracer_robert_coeff(ISCA_MAX_TRACERS)
+  integer(c_int) :: use_virtual_temperature
 end type
 
 interface

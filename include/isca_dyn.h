@@ -108,6 +108,10 @@ typedef struct isca_dyn_config {
    * More than one tracer: single rank, raw_filter_coeff = 1.  State names "tr2".."tr4", "tr_atm2".., and "trs2".. (spectral). */
   int tracer_spectral[ISCA_MAX_TRACERS];
   double tracer_robert_coeff[ISCA_MAX_TRACERS];
+  /* use_virtual_temperature (spectral_dynamics_nml, default .false.): T (1 + (rvgas/rdgas - 1) q), q = tracer 1, in the pressure-gradient
+   * and energy-conversion terms of four_in_one (spectral_dynamics.F90:857-864), in compute_geopotential and in the heights of
+   * compute_pressures_and_heights (press_and_geopot.F90:246-256, 340-355).  Ignored without tracer 1 (the reference's dry_model). */
+  int use_virtual_temperature;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -218,7 +218,10 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 if str(v).lower() != unsupported[k].lower():
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
                 continue
-            if k in ("use_virtual_temperature", "use_implicit", "make_symmetric"):      # one value implemented each
+            if k == "use_virtual_temperature":
+                kw[k] = int(bool(v))
+                continue
+            if k in ("use_implicit", "make_symmetric"):      # one value implemented each
                 want = k == "use_implicit"
                 if bool(v) != want:
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{want}")')

@@ -98,6 +98,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   // moist package (physics = 1): module defaults overridden by frierson_test_case.py:49-170
   c->physics = 0; c->vert_coord_input = 0;
   for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
+  c->use_virtual_temperature = 0;
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -494,7 +495,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
     h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl);
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0);
+    if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -724,7 +726,9 @@ extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_leve
     // compute_pressures_and_heights of the requested level (atmosphere.F90:229-241, 331-338)
     const int tl = (time_level == 0) ? h->previous : h->current;
     double *pf = h->d.scratch_g[0], *ph = h->d.scratch_g[1], *zf = h->d.scratch_g[2], *zh = h->d.scratch_g[3];
-    launch_pressures_heights(*h, h->d.tg[tl], h->d.psg[tl], pf, ph, zf, zh, h->stream);
+    const double *tq = h->d.tg[tl];
+    if (virtual_t_on(*h)) { launch_virtual_t(*h, h->d.tg[tl], h->d.tr_atm[tl], h->d.tv, h->stream); tq = h->d.tv; }      // atmosphere's tracer copy (atmosphere.F90:235-240, 335-337)
+    launch_pressures_heights(*h, tq, h->d.psg[tl], pf, ph, zf, zh, h->stream);
     const bool half = (nm == "p_half" || nm == "z_half");
     const size_t need = ng2 * (g.L + (half ? 1 : 0));
     if (count != need) fail("get_state: wrong element count for " + nm);

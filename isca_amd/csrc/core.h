@@ -78,6 +78,7 @@ struct Dev {
   double *wg;                // [L+1][Jl][I] vertical mass flux at interfaces (four_in_one), for the tracer
   double *tr_atm[2];         // atmosphere_mod's own (never Robert-filtered) copy of the grid tracer
   double *trh;               // tracer after the horizontal van Leer step
+  double *tv = nullptr;      // virtual temperature work array (use_virtual_temperature)
   // tracers 2..num_tracers ([e] = tracer e+2): grid values, atmosphere_mod's copy, spectral coefficients (spectral tracers only),
   // and the column sums the transport kernel writes for tracer 1's water fixer (unused here)
   double *trx[2][3] = {}, *trx_atm[2][3] = {}, *trxs[2][3] = {}, *wcol_x = nullptr, *ph_dtqx[3] = {};

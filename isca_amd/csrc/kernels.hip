@@ -1045,6 +1045,7 @@ struct ColumnArgs {
   int *kmask; double water_limit;
   const double *phu, *phv, *pht;           // tendencies of the physics package when it is not hs_forcing (k_column<CH, true>)
   const double *surf_geop;                 // [Jl][I] lower boundary of the hydrostatic integral (press_and_geopot.F90:331)
+  const double *tv;                        // virtual temperature of the current level (k_column<CH, EXT, true>: use_virtual_temperature)
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1077,7 +1078,7 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
 // everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
-template <int CH, bool EXT>
+template <int CH, bool EXT, bool VIRT>
 __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
@@ -1105,6 +1106,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   }
   const double wts_j = a.wts[jl], cosm = a.cosm[jl], cor = a.coriolis[jl], rad_lat = a.rad_lat[jl];
   double u[CH], v[CH], t[CH], dm[CH];
+  double tvv[VIRT ? CH : 1];                // virtual_t of four_in_one / compute_geopotential (spectral_dynamics.F90:857-868); t itself is advected
+#define TV(i) (VIRT ? tvv[VIRT ? (i) : 0] : t[i])
   // every global load of the block is issued here, before the barrier of the vertical scans: one memory
   // round trip per block instead of two (the loads below the barrier could not start before it)
   // (chunks of more than 5 levels would not fit the register file that way: they read these six below the barrier)
@@ -1115,6 +1118,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     const int k = k0 + (i < nk ? i : 0);
     const size_t q = c2 + (size_t)k * lev;
     u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
+    if (VIRT) tvv[VIRT ? i : 0] = a.tv[q];
     if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q]; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   for (int i = 0; i < CH; ++i) {
     const int k = k0 + (i < nk ? i : 0);
     csum += dm[i];
-    asum += (i < nk && k >= ktop) ? RDGAS * t[i] * (lph[i + 1] - lph[i]) : 0.0;
+    asum += (i < nk && k >= ktop) ? RDGAS * TV(i) * (lph[i + 1] - lph[i]) : 0.0;
   }
   lds_dm[w * 64 + tid] = csum;
   lds_a[w * 64 + tid] = asum;
@@ -1208,12 +1212,12 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
       const double x1 = (bk_r[i + 1] * dlog_1 + bk_r[i] * dlog_2) * dp_inv;
       const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
-      const double uc = u[i], vc = v[i], tc = t[i];
-      dt_u = dt_u - RDGAS * tc * x2;
-      dt_v = dt_v - RDGAS * tc * x3;
+      const double uc = u[i], vc = v[i], tc = t[i], tvc = TV(i);
+      dt_u = dt_u - RDGAS * tvc * x2;
+      dt_v = dt_v - RDGAS * tvc * x3;
       const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
       const double x5 = x4 - uc * x2 - vc * x3;
-      dt_t = dt_t - KAPPA * tc * x5;
+      dt_t = dt_t - KAPPA * tvc * x5;
       a.wg_full[q] = -x5 * p_full;
       nbelow += (p_full < a.water_limit) ? 1 : 0;
       dmean_tot = dmean_tot + dm[i];
@@ -1253,8 +1257,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     for (int i = CH - 1; i >= 0; --i) {
       if (i < nk) {
         const size_t q = c2 + (size_t)(k0 + i) * lev;
-        a.E[q] = gh + RDGAS * t[i] * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]);
-        if (k0 + i >= ktop) gh = gh + RDGAS * t[i] * (lph[i + 1] - lph[i]);
+        a.E[q] = gh + RDGAS * TV(i) * (lph[i + 1] - lpf[i]) + .5 * (u[i] * u[i] + v[i] * v[i]);
+        if (k0 + i >= ktop) gh = gh + RDGAS * TV(i) * (lph[i + 1] - lph[i]);
       }
     }
   }
@@ -1281,8 +1285,20 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   }
 }
 
+#undef TV
+
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
 
+// virtual_t = T (1 + (rvgas/rdgas - 1) q) (spectral_dynamics.F90:436-438, 858; press_and_geopot.F90:248, 342)
+__global__ void k_virtual_t(size_t n, const double *__restrict__ t, const double *__restrict__ q, double *__restrict__ tv) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tv[i] = t[i] * (1.0 + (RVGAS / RDGAS - 1.0) * q[i]);
+}
+bool virtual_t_on(const isca_dyn &h) { return h.cfg.use_virtual_temperature && h.tracer_on; }    // `.not. dry_model`
+void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, double *tv, hipStream_t s) {
+  const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
+  hipLaunchKernelGGL(k_virtual_t, grid1d(n), dim3(256), 0, s, n, t, q, tv);
+}
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
@@ -1304,7 +1320,12 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
-#define LC(N) do { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false>), grid, block, lds, s, g, a); } while (0)
+  a.tv = virtual_t_on(h) ? d.tv : nullptr;
+  if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
+#define LC(N) do { \
+    if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
+    else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
+    else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
   switch (CH) {
     case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;

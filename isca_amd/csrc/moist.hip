@@ -340,6 +340,10 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   PressArgs a;
   a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L; a.surf_geop = d.surf_geop;
   a.t[0] = d.tg[sc.prev]; a.ps[0] = d.psg[sc.prev]; a.t[1] = d.tg[sc.cur]; a.ps[1] = d.psg[sc.cur];
+  if (virtual_t_on(h)) {      // heights of the current level from its virtual temperature (atmosphere.F90:335-337: grid_tracers of that level)
+    launch_virtual_t(h, d.tg[sc.cur], d.tr_atm[sc.cur], d.tv, s);
+    a.t[1] = d.tv;
+  }
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_moist_heights, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, a);

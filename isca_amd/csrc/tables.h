@@ -11,6 +11,7 @@ constexpr double RADIUS_EARTH = 6376.0e3;   // shared/constants/constants.F90:25
 constexpr double OMEGA_EARTH = 7.2921150e-5;
 constexpr double GRAV = 9.80;
 constexpr double RDGAS = 287.04;
+constexpr double RVGAS = 461.50;      // constants.F90: gas constant of water vapour (use_virtual_temperature)
 constexpr double KAPPA = 2.0 / 7.0;
 constexpr double CP_AIR = RDGAS / KAPPA;
 constexpr double PI = 3.14159265358979323846;

@@ -63,6 +63,7 @@ class _CConfig(C.Structure):
         ("damping_option", C.c_int), ("cutoff_wn", C.c_int), ("damping_coeff_vor", C.c_double), ("damping_coeff_div", C.c_double),
         ("damping_order_vor", C.c_int), ("damping_order_div", C.c_int),
         ("tracer_spectral", C.c_int * MAX_TRACERS), ("tracer_robert_coeff", C.c_double * MAX_TRACERS),
+        ("use_virtual_temperature", C.c_int),
     ]
 
 

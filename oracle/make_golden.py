@@ -83,7 +83,7 @@ FRIERSON_BK = [0.000000, 0.0117665, 0.0196679, 0.0315244, 0.0485411, 0.0719344, 
 MOIST_EXE = os.path.join(HERE, "_ref", "ref_moist_harness.x")
 
 
-def moist_input_nml(res, num_levels=25):
+def moist_input_nml(res, num_levels=25, extra=""):
     """namelist of exp/test_cases/frierson/frierson_test_case.py:49-170 (config 3 of BASELINE.json): its 25 levels from
     vert_coordinate_nml, or (num_levels != 25: the T85L40 size of BASELINE configs[3]) `uneven_sigma` levels with the test case's
     scale_heights / exponent / surf_res"""
@@ -139,7 +139,7 @@ def moist_input_nml(res, num_levels=25):
     damping_order = 4, water_correction_limit = 200.e2, reference_sea_level_press = 1.0e5, num_levels = {num_levels},
     valid_range_t = 100., 800., initial_sphum = 2.e-6, vert_coord_option = '{vco}', surf_res = 0.5,
     scale_heights = 11.0, exponent = 7.0, robert_coeff = 0.03,
-    lon_max = {lon}, lat_max = {lat}, num_fourier = {nf}, num_spherical = {ns}
+    lon_max = {lon}, lat_max = {lat}, num_fourier = {nf}, num_spherical = {ns}{extra}
  /
  &vert_coordinate_nml
     bk = {bk},
@@ -148,10 +148,10 @@ def moist_input_nml(res, num_levels=25):
 """
 
 
-def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run", num_levels=25):
+def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run", num_levels=25, extra=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
-    open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res, num_levels))
+    open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res, num_levels, (",\n    " + extra) if extra else ""))
     open(os.path.join(d, "field_table"), "w").write(FIELD_TABLE)       # src/extra/model/isca/field_table: the same sphum entry
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     fmt = lambda t: ", ".join(str(s) for s in t) if t else "-1"
@@ -293,11 +293,11 @@ def golden_moist_kernels(res="T21", L=25, nsteps=2400, dt=720, stride=13):
     return out
 
 
-def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt=720, keep=None):
+def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt=720, keep=None, extra=""):
     """The reference moist model (Frierson physics) from its cold start: grid state u, v, T, q, ps at `dump_steps`."""
     lon, lat, nf, ns = RES[res]
     with tempfile.TemporaryDirectory(prefix="refmr_") as d:
-        prepare_moist_rundir(d, res, nsteps, dt=dt, dump_steps=dump_steps, num_levels=L)
+        prepare_moist_rundir(d, res, nsteps, dt=dt, dump_steps=dump_steps, num_levels=L, extra=extra)
         stdout = run_harness(d, exe=MOIST_EXE)
         out = {}
         for fn in sorted(os.listdir(d)):
@@ -431,6 +431,13 @@ def main():
         "run_T21L8_three_tracers": lambda: golden_run(
             "T21", 8, 40, (1, 2, 3, 40), field_table=FIELD_TABLE_3,
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr1|tr2|tr3)_", k) is not None),
+        # use_virtual_temperature = .true.: dry core with the hs tracer as q (tiny effect, tight tolerance) and the moist model (q ~ 1e-2)
+        "run_T21L8_virtual_t": lambda: golden_run(
+            "T21", 8, 60, (2, 60), extra="use_virtual_temperature = .true.",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|z_full)_", k) is not None),
+        "moist_run_T21L25_virtual_t": lambda: golden_moist_run(
+            nsteps=40, dump_steps=(1, 2, 10, 40), extra="use_virtual_temperature = .true.",
+            keep=lambda k: re.match(r"st_(ug|tg|q|psg)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,

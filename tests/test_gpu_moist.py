@@ -128,6 +128,35 @@ def test_moist_trajectory_T21L25(golden_dir):
     dc.close()
 
 
+def test_moist_virtual_temperature(golden_dir):
+    """use_virtual_temperature = .true. in the moist model (q ~ 1e-2: a 0.6 % change of the pressure-gradient and energy-conversion terms
+    and of the heights the physics sees): 40 steps from the cold start against the reference run with the same flag, same error measure
+    and tolerances as the T21L25 trajectory; without the flag the run is visibly a different one."""
+    g = np.load(os.path.join(golden_dir, "moist_run_T21L25_virtual_t.npz"))
+    nml = moist_namelist("T21", float(g["meta_dt_atmos"]))
+    nml["spectral_dynamics_nml"]["use_virtual_temperature"] = True
+    dc = dyncore.DynCore(atm.config_from_namelist(nml))
+    assert dc.cfg.use_virtual_temperature == 1
+    dc.cold_start()
+    done = 0
+    tol = {1: 1e-11, 2: 1e-10, 10: 1e-9, 40: 3e-9}
+    for n in (1, 2, 10, 40):
+        dc.step(n - done)
+        done = n
+        err = {}
+        for mine, ref in (("ug", "ug"), ("tg", "tg"), ("tr", "q"), ("psg", "psg")):
+            key = "st_%s_%06d" % (ref, n)
+            scale = max(float(np.abs(g[key]).max()), 1.0 if ref == "ug" else 0.0)
+            err[ref] = float(np.abs(dc.get(mine) - g[key]).max()) / scale
+        print("moist, virtual temperature, step", n, err)
+        assert max(err.values()) < tol[n], (n, err)
+    dc.close()
+    plain = moist_core(dt=float(g["meta_dt_atmos"]))
+    plain.cold_start(); plain.step(40)
+    assert float(np.abs(plain.get("ug") - g["st_ug_000040"]).max()) > 1e-4          # the flag matters: m/s after 40 steps
+    plain.close()
+
+
 def test_moist_climate_12day(golden_dir):
     """12 days (1440 steps): the convection scheme makes the model chaotic on this time scale - two runs of the REFERENCE differing
     by 5e-12 in the initial humidity end 0.4 m/s, 0.2 K, 7 Pa apart pointwise (zonal means 0.02 m/s, 0.01 K) - so the check is on

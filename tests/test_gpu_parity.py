@@ -219,6 +219,34 @@ def test_golden_three_tracers(golden_dir):
         make("T21", 8, num_tracers=2, tracer_spectral=[0, 2])
 
 
+def test_golden_virtual_temperature(golden_dir):
+    """use_virtual_temperature = .true. with the dry core's hs tracer as q (spectral_dynamics.F90:857-868, press_and_geopot.F90:246-256,
+    340-355): q ~ 1e-5 changes u by ~1e-6 m/s in 60 steps, the comparison with the reference run is at 1e-9; z_full of
+    compute_pressures_and_heights uses the virtual temperature too."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_virtual_t.npz"))
+    dc = make("T21", 8, use_virtual_temperature=1); dc.cold_start()
+    plain = make("T21", 8); plain.cold_start()
+    done = 0
+    for n in (2, 60):
+        dc.step(n - done); plain.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg", "z_full")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print("virtual temperature, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    off = float(np.abs(plain.get("ug") - g["st_ug_000060"]).max())
+    print("without the flag: max |du| vs the fixture", off)
+    assert off > 1e-8                                   # the fixture does pin the option
+    # without a tracer the model is the reference's dry_model: the flag is ignored (spectral_dynamics.F90:857)
+    dry = make("T21", 8, use_virtual_temperature=1, num_tracers=0, do_water_correction=0); dry.cold_start(); dry.step(3)
+    ref = make("T21", 8, num_tracers=0, do_water_correction=0); ref.cold_start(); ref.step(3)
+    assert np.array_equal(dry.get("ug"), ref.get("ug"))
+    for c in (dc, plain, dry, ref):
+        c.close()
+    from isca_amd import atmosphere as atm
+    assert atm.config_from_namelist({"spectral_dynamics_nml": {"use_virtual_temperature": True}}).use_virtual_temperature == 1
+
+
 def test_golden_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (leapfrog.F90:58-105): the step gets a third transform phase -- grid u, v, T, ps, vor, div of the new level
     from the unadjusted spectral state, its RAW adjustment afterwards (spectral_dynamics.F90:1031), the next step's gradients from the
