@@ -113,12 +113,13 @@ def dominant_roofline(kt, kern, traffic, traffic_source):
     if dom is None:
         return None
     c = kern[dom]
-    name = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop:fused", "fft_fwd": "k_fft_fwd", "fft_inv": "k_fft_inv",
+    name = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop:fused", "fft_fwd": "k_fft_fwd3", "fft_inv": "k_fft_inv3",
             "moist_physics": "k_moist_physics"}[dom]
     mfma = c["bound"] == "mfma"
     ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)
     return {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
-            "frac": ach / peak, "traffic": traffic.get(name), "traffic_source": traffic_source if traffic.get(name) is not None else None,
+            "frac": ach / peak, "traffic": traffic.get(name, traffic.get(name.rstrip("3"))),          # k_fft_*3: lon_max >= 256; generic kernels below
+            "traffic_source": traffic_source if traffic.get(name, traffic.get(name.rstrip("3"))) is not None else None,
             "avg_launch_ms": c["ms"]}
 
 
