@@ -1144,7 +1144,8 @@ extern "C" int isca_dyn_synchronize(isca_dyn_t *h) {
 extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
   API_BEGIN
   if (!h || !h->have_state) fail("isca_dyn_step_phase: no state");
-  const StepScalars sc = step_scalars(h);
+  StepScalars sc = step_scalars(h);
+  sc.keep_spec_tend = 1;
   switch (phase) {
     case 0: upload_wave_matrices(h, sc.delta_t); phase0(h, sc); break;
     case 1: phase1(h, sc); break;

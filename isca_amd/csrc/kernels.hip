@@ -821,8 +821,10 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     dt_vor = sel2(act, cscale(mk, dt_vor));
     dt_div = sel2(act, cadd(cscale(mk, dt_div), cscale(eig, E)));   // dt_divs - laplacian(Phi+KE), laplacian = -eigen
     dt_t = sel2(act, Tt);
-    if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }      // kept for diagnostics/tests
-    if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
+    if (a.dtvor) {                       // locals of the reference's step: stored only for the phase-by-phase API (get_state "s_dtvor" ...)
+      if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }
+      if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
+    }
   }
   double2 dps, dts;
   if (!(MODE & SU_NO_IMPLICIT)) {
@@ -947,7 +949,9 @@ void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   const Geom &g = h.g;
   const SpecUpdateArgs a = spec_update_args(h, sc);
   const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
-  hipLaunchKernelGGL(k_spec_update<0>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, a);
+  SpecUpdateArgs b = a;
+  if (!sc.keep_spec_tend) b.dtvor = b.dtdiv = b.dtT = b.dtlp = nullptr;
+  hipLaunchKernelGGL(k_spec_update<0>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, b);
 }
 // parts of the same kernel on caller data: stage 0 implicit_correction, 1 spectral damping, 2 leapfrog A+B.
 // st[v][t]: v = vors, divs, ts, ln_ps; t = previous, current, future.  dtend: dt_vors, dt_divs, dt_ts, dt_ln_ps.
