@@ -147,7 +147,8 @@ int isca_dyn_synchronize(isca_dyn_t *h);
  * the new level, "wg_full", "p_full", "p_half", "z_full").  The physics reads the PREVIOUS level's u, v, T, tracer ("tr_atm": the
  * never-filtered copy atmosphere_mod keeps, atmosphere.F90:95) and the CURRENT level's pressures, as atmosphere.F90:304-317 passes them,
  * and isca_dyn_delta_t gives its time step (dt_atmos on the first step, else 2 dt_atmos).  dt_psg: the physics packages of this path
- * leave it zero (atmosphere.F90:298); not carried.  isca_dyn_set_tendencies hands the arrays over without stepping, for a sharded run
+ * leave it zero (atmosphere.F90:298); not carried.  dt_tracers is (lon, lat_local, lev, num_tracers): one block per tracer of the
+ * field_table, tracer index slowest, like the reference's array.  isca_dyn_set_tendencies hands the arrays over without stepping, for a sharded run
  * driven phase by phase (isca_dyn_step_phase). */
 int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const double *dt_vg, const double *dt_tg, const double *dt_tracers,
                       int on_device, int sync);

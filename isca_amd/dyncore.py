@@ -451,12 +451,17 @@ class DynCore:
 
     def _tend_ptrs(self, arrs):
         keep, ptrs = [], []
-        for a in arrs:
+        ntr = max(self.cfg.num_tracers, 1)
+        for i, a in enumerate(arrs):
             if a is None:
                 ptrs.append(None)
             else:
                 a = np.ascontiguousarray(a, dtype=np.float64)
-                if a.shape != (self.L, self.Jl, self.I):
+                want = (self.L, self.Jl, self.I)
+                if i == 3 and ntr > 1:                      # dt_tracers(:,:,:,ntr): one (lev, lat, lon) block per tracer, tracer index slowest
+                    if a.shape != (ntr,) + want:
+                        raise IscaError(f"dt_tracers must be a ({ntr}, lev, lat_local, lon) array: one block per tracer of the field_table")
+                elif a.shape != want:
                     raise IscaError("physics tendencies must be (lev, lat_local, lon) arrays")
                 keep.append(a); ptrs.append(_dptr(a))
         return keep, ptrs

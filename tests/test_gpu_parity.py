@@ -210,6 +210,20 @@ def test_golden_three_tracers(golden_dir):
     for k, v in want.items():
         assert np.array_equal(dc.get(k), v), k
     dc.close()
+    # the caller's physics (physics = 2) hands dt_tracers(:,:,:,ntr) for every tracer: hs_forcing evaluated on the host == fused forcing
+    ref = make("T21", 8, **opts); ref.cold_start()
+    ext = make("T21", 8, physics=2, **opts); ext.cold_start()
+    for _ in range(8):
+        dt = ext.delta_t()
+        ph, pf = ext.get("p_half", 1), ext.get("p_full", 1)
+        du, dv, dT = ext.hs_forcing(dt, ph, pf, ext.get("ug", 0), ext.get("vg", 0), ext.get("tg", 0))
+        ext.dynamics(du, dv, dT, np.stack([ext.hs_tracer_source_sink(ph[-1], ext.get(n, 0)) for n in ("tr_atm", "tr_atm2", "tr_atm3")]))
+    ref.step(8)
+    for k in ("ug", "tg", "tr", "tr2", "tr3"):
+        assert rel(ext.get(k), ref.get(k)) < 1e-10, k
+    with pytest.raises(dyncore.IscaError, match="one block per tracer"):
+        ext.dynamics(du, dv, dT, du)
+    ref.close(); ext.close()
     # a second tracer on a sharded run, with the RAW filter, or with an unknown representation is refused
     with pytest.raises(dyncore.IscaError, match="single rank"):
         make("T21", 8, num_tracers=2, world_size=2, rank=0)
