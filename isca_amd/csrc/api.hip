@@ -136,10 +136,10 @@ static void check_config(const isca_dyn_config &c) {
   // check_dynamics_nml (spectral_dynamics.F90:666-755) + what this implementation supports
   if (c.num_fourier <= 0 || c.num_spherical <= 0 || c.num_levels <= 0) fail("invalid resolution");
   if (c.fourier_inc != 1) fail("fourier_inc must be 1");
-  if (!c.triang_trunc) fail("only triangular truncation is supported");
-  if (c.num_spherical != c.num_fourier + 1) fail("num_spherical must equal num_fourier+1 (triangular truncation)");
+  if (!c.triang_trunc && c.world_size != 1) fail("triang_trunc = .false. (rhomboidal truncation): single rank only");
+  if (c.num_spherical != c.num_fourier + 1) fail("num_spherical must equal num_fourier+1");
   if (c.lon_max < 3 * c.num_fourier + 1) fail("number of longitude points is too small for number of fourier waves");
-  if (2 * c.lat_max < 3 * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");
+  if (2 * c.lat_max < (c.triang_trunc ? 3 : 5) * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");
   if (c.lon_max & (c.lon_max - 1)) fail("lon_max must be a power of two (Stockham FFT kernel)");
   if (c.lat_max % 8) fail("lat_max must be a multiple of 8");
   if (c.num_levels > 64) fail("num_levels must be <= 64 (one wavefront lane per level in the spectral update)");
@@ -243,7 +243,7 @@ static void upload_wave_matrices(isca_dyn *h, double delta_t) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   h->tab.build_wave_matrices(h->cfg, delta_t);     // implicit.F90:260-264: rebuilt when dt changes
-  const int L = h->g.L, nw = h->cfg.num_spherical;
+  const int L = h->g.L, nw = h->tab.n_wave;
   std::vector<double> wt((size_t)nw * L * L);
   for (int w = 0; w < nw; ++w)
     for (int k = 0; k < L; ++k)
@@ -354,7 +354,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     {
       // retained (m,n) of my wavenumbers grouped by total wavenumber m+n, each group padded to a multiple of 4
       std::vector<int> act;
-      for (int Lw = 0; Lw < cfg->num_spherical; ++Lw) {
+      for (int Lw = 0; Lw < (cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->num_fourier); ++Lw) {
         for (int ml = 0; ml < g.Ml; ++ml) {
           const int m = h->h_m_local[ml], n = Lw - m;
           if (m < 0 || n < 0 || n >= g.N1) continue;
@@ -378,7 +378,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       for (int k = g.L; k < 64; ++k) iv[2 * 64 + k] = 1.0;
       d.impl_vec = dupload(h, iv);
     }
-    d.wave_mat_t = dalloc<double>(h, (size_t)cfg->num_spherical * g.L * g.L);
+    d.wave_mat_t = dalloc<double>(h, (size_t)(cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->num_fourier) * g.L * g.L);
     {
       std::vector<double> tw((size_t)2 * g.I);
       for (int k = 0; k < g.I; ++k) { tw[2 * k] = T.tw_re[k]; tw[2 * k + 1] = T.tw_im[k]; }
@@ -493,7 +493,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     build_field_lists(h);
     h->Ci = col_pitch(7 * g.L + 3);
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
-    h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl);
+    h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc;      // the fused gather has the triangle's bounds built in
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
@@ -561,7 +561,7 @@ static void synthesize_level(isca_dyn *h, int tl) {
     return;
   }
   { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, tl, h->stream); }
-  run_inverse(h, fl, 0);
+  run_inverse(h, fl, h->cfg.triang_trunc ? 0 : 1);
 }
 
 // host (m,n,lev) Fortran <-> device [ml][n][lev] complex
@@ -858,13 +858,13 @@ static void phase_tracer(isca_dyn *h, const StepScalars &sc) {
   HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
-  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, 0, h->cfg.legendre_impl, h->stream); }
+  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, h->cfg.triang_trunc ? 0 : 1, h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
     Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut);
   } else {
     { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
-    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream); }
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, h->cfg.triang_trunc ? 0 : 1, h->cfg.legendre_impl, h->stream); }
   }
 }
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
@@ -1252,7 +1252,7 @@ extern "C" int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host,
   else if (nm == "sin_hem") v = &T.sin_hem; else if (nm == "wts_hem") v = &T.wts_hem;
   else if (nm == "wave_matrix") {
     if (T.wave_dt < 0) fail("wave matrices not built yet (run a step)");
-    const int L = T.L, nw = h->cfg.num_spherical;
+    const int L = T.L, nw = T.n_wave;
     tmp.resize((size_t)nw * L * L);
     for (int w = 0; w < nw; ++w) for (int k = 0; k < L; ++k) for (int k2 = 0; k2 < L; ++k2)
       tmp[((size_t)w * L + k2) * L + k] = T.wave_matrix[((size_t)w * L + k) * L + k2];   // Fortran (k,k2,w)
@@ -1536,6 +1536,7 @@ extern "C" int isca_compute_vor_div(isca_dyn_t *h, const double *u_div_cos, cons
 extern "C" int isca_triangular_truncation(isca_dyn_t *h, double *spherical, int nlev) {
   API_BEGIN
   check_nlev(h, nlev);
+  if (!h->cfg.triang_trunc) fail("triangular_truncation: the handle carries the rhomboidal mask (triang_trunc = .false.)");
   Dev &d = h->d;
   spec_host_to_dev(h, spherical, d.scratch_s[0], nlev);
   launch_spec_pack(h->g, d.scratch_s[0], d.Si, 2 * nlev, 0, nlev, h->stream);

@@ -154,7 +154,9 @@ void Tables::build(const isca_dyn_config &c) {
     for (int m = 0; m < M1; ++m) {
       const size_t q = (size_t)n * M1 + m;
       const double fw = m, sw = m + n;
-      if (m + n > c.num_spherical - 1) tri_mask[q] = 0.0;
+      // the model's truncation: triangle_mask (spherical.F90:190-195), or -- triang_trunc = .false. -- rhomboidal_truncation's
+      // `spherical(:,num_spherical,:) = 0` (spherical.F90:622): only the extra row goes
+      if (c.triang_trunc ? (m + n > c.num_spherical - 1) : (n == c.num_spherical)) tri_mask[q] = 0.0;
       eps[q] = std::sqrt((sw * sw - fw * fw) / (4.0 * sw * sw - 1.0));
       eigen[q] = sw * (sw + 1.0) / (radius * radius);
       if (m + n > 0) {
@@ -333,7 +335,8 @@ void Tables::damping_effective(double delta_t, std::vector<double> &t, std::vect
 
 void Tables::build_wave_matrices(const isca_dyn_config &c, double dt) {
   xi = dt * c.alpha_implicit;
-  const int ntw = c.num_spherical - 1;
+  const int ntw = c.triang_trunc ? c.num_spherical - 1 : c.num_spherical - 1 + c.fourier_inc * c.num_fourier;      // num_total_wavenumbers
+  n_wave = ntw + 1;
   wave_matrix.assign((size_t)(ntw + 1) * L * L, 0.0);
   std::vector<double> a((size_t)L * L);
   for (int Lw = 0; Lw <= ntw; ++Lw) {

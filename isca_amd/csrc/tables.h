@@ -18,6 +18,7 @@ constexpr double PI = 3.14159265358979323846;
 
 struct Tables {
   int I, J, M1, N1, L;
+  int n_wave = 0;                                // wave matrices: total wavenumbers 0..num_total_wavenumbers (spectral_dynamics.F90:430-434)
   std::vector<double> sin_hem, wts_hem;          // [J/2], pole-most first
   std::vector<double> sin_lat, wts_lat, cos_lat, cosm_lat, deg_lat, rad_lat, deg_lon, coriolis;  // [J] / [I]
   std::vector<double> legendre;                  // [J/2][N1][M1]  (Fortran (m,n,j))
@@ -35,7 +36,7 @@ struct Tables {
   std::vector<double> tau_mat, gamma_mat, nu_vec;                      // [L*L],[L*L],[L]
   double ref_surf_p, ref_t;
   double radius = RADIUS_EARTH, omega = OMEGA_EARTH;   // constants_nml
-  std::vector<double> wave_matrix;               // [num_spherical][L][L] for wave_dt
+  std::vector<double> wave_matrix;               // [n_wave][L][L] for wave_dt
   double wave_dt = -1.0, xi = 0.0;
   // hs
   double tka, tks, vkf, trsink_s;

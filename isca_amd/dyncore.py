@@ -182,6 +182,7 @@ RESOLUTIONS = {
     "T170": dict(lon_max=512, lat_max=256, num_fourier=170, num_spherical=171),
     # small test resolutions (not in the reference's table)
     "T10": dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11),
+    "R10": dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=11, triang_trunc=0),      # rhomboidal: 2 lat_max >= 5 (num_spherical - 1) + 1
 }
 
 
@@ -307,7 +308,7 @@ class DynCore:
         n = {"sin_lat": self.J, "wts_lat": self.J, "deg_lat": self.J, "deg_lon": self.I, "pk": self.L + 1,
              "bk": self.L + 1, "legendre": (self.J // 2) * self.N1 * self.M1, "eigen_laplacian": self.N1 * self.M1,
              "sin_hem": self.J // 2, "wts_hem": self.J // 2, "fixer": 32,
-             "wave_matrix": self.cfg.num_spherical * self.L * self.L}[name]
+             "wave_matrix": (self.cfg.num_spherical + (0 if self.cfg.triang_trunc else self.cfg.num_fourier)) * self.L * self.L}[name]
         a = np.zeros(n)
         self._check(self.lib.isca_dyn_get_table(self._h, name.encode(), _dptr(a), a.size))
         if name == "legendre":
@@ -315,7 +316,7 @@ class DynCore:
         elif name == "eigen_laplacian":
             a = a.reshape(self.N1, self.M1)
         elif name == "wave_matrix":
-            a = a.reshape(self.cfg.num_spherical, self.L, self.L)
+            a = a.reshape(-1, self.L, self.L)
         return a
 
     # -- model

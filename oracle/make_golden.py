@@ -40,7 +40,7 @@ FIELD_TABLE_3 = FIELD_TABLE + '''"TRACER", "atmos_mod", "age_grid"
           "profile_type", "fixed",   "surface_value=0.0" /
 '''
 
-RES = {"T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
+RES = {"R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
 
@@ -438,6 +438,10 @@ def main():
         "moist_run_T21L25_virtual_t": lambda: golden_moist_run(
             nsteps=40, dump_steps=(1, 2, 10, 40), extra="use_virtual_temperature = .true.",
             keep=lambda k: re.match(r"st_(ug|tg|q|psg)_", k) is not None),
+        # rhomboidal truncation (triang_trunc = .false.: every m keeps n = 0..num_spherical-1; 5/2 latitudes per meridional wave)
+        "run_R10L8_rhomboidal": lambda: golden_run(
+            "R10", 8, 36, (1, 2, 36), extra="triang_trunc = .false.",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|vors|ts|lnps)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,

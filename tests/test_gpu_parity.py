@@ -261,6 +261,39 @@ def test_golden_virtual_temperature(golden_dir):
     assert atm.config_from_namelist({"spectral_dynamics_nml": {"use_virtual_temperature": True}}).use_virtual_temperature == 1
 
 
+def test_golden_rhomboidal_truncation(golden_dir, tmp_path):
+    """triang_trunc = .false. (rhomboidal_truncation, spherical.F90:603-644: every zonal wavenumber keeps n = 0..num_spherical-1; wave
+    matrices up to total wavenumber num_fourier + num_spherical - 1, spectral_dynamics.F90:430-434; 5/2 latitudes per meridional wave):
+    36 steps at R10L8 against the reference run; the staged synthesis with rectangular bounds; restart continues bit for bit."""
+    g = np.load(os.path.join(golden_dir, "run_R10L8_rhomboidal.npz"))
+    dc = make("R10", 8); dc.cold_start()
+    assert dc.cfg.triang_trunc == 0 and dc.info("kernels_per_step") >= 11
+    done = 0
+    for n in (1, 2, 36):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print("rhomboidal, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    v = dc.get("vors")
+    assert np.abs(v[:, -1]).max() == 0.0 and np.abs(v[:, -2, 5:]).max() > 0.0          # only the extra row is cut: (m >= 5, n = 10) lies outside the triangle
+    assert dc.table("wave_matrix").size == (11 + 10) * 8 * 8
+    from isca_amd import restart
+    restart.write_restart(dc, str(tmp_path))
+    dc.step(4)
+    again = make("R10", 8); restart.read_restart(again, str(tmp_path)); again.step(4)
+    for k in ("ug", "tg", "psg", "tr", "vors"):
+        assert np.array_equal(dc.get(k), again.get(k)), k
+    with pytest.raises(dyncore.IscaError, match="rhomboidal mask"):
+        dc.triangular_truncation(v)
+    dc.close(); again.close()
+    with pytest.raises(dyncore.IscaError, match="too small for number of meridional waves"):
+        make("T10", 8, triang_trunc=0)                                                     # 16 latitudes: fine for the triangle only
+    with pytest.raises(dyncore.IscaError, match="single rank"):
+        make("R10", 8, world_size=2, rank=0)
+
+
 def test_golden_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (leapfrog.F90:58-105): the step gets a third transform phase -- grid u, v, T, ps, vor, div of the new level
     from the unadjusted spectral state, its RAW adjustment afterwards (spectral_dynamics.F90:1031), the next step's gradients from the
@@ -432,7 +465,7 @@ def test_error_behaviour():
     dc = make("T21", 10); dc.cold_start(); dc.step(3); dc.close()                     # default range: fine
     for bad, msg in ((dict(raw_filter_coeff=1.5), "raw_filter_coeff"),
                      (dict(fourier_inc=2), "fourier_inc"), (dict(world_size=3), "world_size"), (dict(dt_atmos=0.0), "dt_atmos"),
-                     (dict(triang_trunc=0), "triangular"), (dict(do_mass_correction=0), "mass_correction")):
+                     (dict(triang_trunc=0), "too small for number of meridional waves"), (dict(do_mass_correction=0), "mass_correction")):
         with pytest.raises(dyncore.IscaError, match=msg):
             make("T21", 25, **bad)
 
