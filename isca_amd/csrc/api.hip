@@ -135,9 +135,10 @@ extern "C" int isca_wavenumber_dealing(int num_fourier, int world_size, int *m_o
 static void check_config(const isca_dyn_config &c) {
   // check_dynamics_nml (spectral_dynamics.F90:666-755) + what this implementation supports
   if (c.num_fourier <= 0 || c.num_spherical <= 0 || c.num_levels <= 0) fail("invalid resolution");
-  if (c.fourier_inc != 1) fail("fourier_inc must be 1");
+  if (c.fourier_inc <= 0) fail(std::to_string(c.fourier_inc) + " is an invalid value for fourier_inc.");
+  if (c.fourier_inc != 1 && c.world_size != 1) fail("fourier_inc /= 1: single rank only");
   if (!c.triang_trunc && c.world_size != 1) fail("triang_trunc = .false. (rhomboidal truncation): single rank only");
-  if (c.num_spherical != c.num_fourier + 1) fail("num_spherical must equal num_fourier+1");
+  if (c.num_spherical != c.num_fourier * c.fourier_inc + 1) fail("num_spherical must equal num_fourier * fourier_inc + 1");
   if (c.lon_max < 3 * c.num_fourier + 1) fail("number of longitude points is too small for number of fourier waves");
   if (2 * c.lat_max < (c.triang_trunc ? 3 : 5) * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");
   if (c.lon_max & (c.lon_max - 1)) fail("lon_max must be a power of two (Stockham FFT kernel)");
@@ -188,6 +189,9 @@ static void check_config(const isca_dyn_config &c) {
   }
 }
 
+// Legendre kernels with rectangular bounds (every n of every wavenumber) instead of the triangle n <= num_spherical - m they have built in:
+// rhomboidal truncation, and fourier_inc /= 1 (the triangle is then n <= num_spherical - m * fourier_inc; what lies outside is zero anyway)
+static int rect_bounds(const isca_dyn *h) { return (h->cfg.triang_trunc && h->cfg.fourier_inc == 1) ? 0 : 1; }
 static void build_field_lists(isca_dyn *h) {
   const int L = h->g.L;
   Dev &d = h->d;
@@ -354,9 +358,9 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     {
       // retained (m,n) of my wavenumbers grouped by total wavenumber m+n, each group padded to a multiple of 4
       std::vector<int> act;
-      for (int Lw = 0; Lw < (cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->num_fourier); ++Lw) {
+      for (int Lw = 0; Lw < (cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->fourier_inc * cfg->num_fourier); ++Lw) {
         for (int ml = 0; ml < g.Ml; ++ml) {
-          const int m = h->h_m_local[ml], n = Lw - m;
+          const int m = h->h_m_local[ml], n = Lw - m * cfg->fourier_inc;
           if (m < 0 || n < 0 || n >= g.N1) continue;
           if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) act.push_back(ml * g.N1 + n);
         }
@@ -378,7 +382,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       for (int k = g.L; k < 64; ++k) iv[2 * 64 + k] = 1.0;
       d.impl_vec = dupload(h, iv);
     }
-    d.wave_mat_t = dalloc<double>(h, (size_t)(cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->num_fourier) * g.L * g.L);
+    d.wave_mat_t = dalloc<double>(h, (size_t)(cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->fourier_inc * cfg->num_fourier) * g.L * g.L);
     {
       std::vector<double> tw((size_t)2 * g.I);
       for (int k = 0; k < g.I; ++k) { tw[2 * k] = T.tw_re[k]; tw[2 * k + 1] = T.tw_im[k]; }
@@ -493,7 +497,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     build_field_lists(h);
     h->Ci = col_pitch(7 * g.L + 3);
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
-    h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc;      // the fused gather has the triangle's bounds built in
+    h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc && cfg->fourier_inc == 1;      // the fused gather has the triangle's bounds built in
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
@@ -561,7 +565,7 @@ static void synthesize_level(isca_dyn *h, int tl) {
     return;
   }
   { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, tl, h->stream); }
-  run_inverse(h, fl, h->cfg.triang_trunc ? 0 : 1);
+  run_inverse(h, fl, rect_bounds(h));
 }
 
 // host (m,n,lev) Fortran <-> device [ml][n][lev] complex
@@ -858,13 +862,13 @@ static void phase_tracer(isca_dyn *h, const StepScalars &sc) {
   HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
-  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, h->cfg.triang_trunc ? 0 : 1, h->cfg.legendre_impl, h->stream); }
+  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
     Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut);
   } else {
     { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
-    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, h->cfg.triang_trunc ? 0 : 1, h->cfg.legendre_impl, h->stream); }
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   }
 }
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums

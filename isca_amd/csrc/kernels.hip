@@ -736,7 +736,7 @@ struct SpecUpdateArgs {
   double2 *dtvor, *dtdiv, *dtT, *dtlp;
   const double *coef, *impl_vec, *wave_t, *Sf;
   const int *m_local;
-  int C;
+  int C, fourier_inc;
   double delta_t, xi, ref_p, ref_t, robert, eddy_sponge, zmu_sponge, zmv_sponge;
   // raw_filter_coeff /= 1 (Robert-Asselin-Williams): the part of the filter that is known before the new level exists,
   // prev - 2 cur (leapfrog_2level_A's part_filt_*), is kept for the end of the step (leapfrog_2level_B); null when raw = 1
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   // the list is grouped by total wavenumber (padded with -1), so the 4 wavefronts of a block share one matrix
   const int mn0 = a.active[blockIdx.x * 4];
   {
-    const int Lw = a.m_local[mn0 / g.N1] + mn0 % g.N1;
+    const int Lw = a.m_local[mn0 / g.N1] * a.fourier_inc + mn0 % g.N1;
     const double *W = a.wave_t + (size_t)Lw * L * L;     // L*L may be odd: plain 8-byte copies
     for (int i = threadIdx.x; i < L * L; i += 256) ws[i] = W[i];
   }
@@ -938,7 +938,7 @@ static SpecUpdateArgs spec_update_args(const isca_dyn &h, const StepScalars &sc)
   a.active = h.d.mn_active; a.nactive = h.n_active;
   a.dtvor = (double2 *)h.d.s_dtvor; a.dtdiv = (double2 *)h.d.s_dtdiv; a.dtT = (double2 *)h.d.s_dtT; a.dtlp = (double2 *)h.d.s_dtlp;
   a.coef = h.d.coef; a.impl_vec = h.d.impl_vec; a.wave_t = h.d.wave_mat_t; a.m_local = h.d.m_local;
-  a.Sf = h.d.Sf; a.C = h.Cf;
+  a.Sf = h.d.Sf; a.C = h.Cf; a.fourier_inc = h.cfg.fourier_inc;
   a.delta_t = sc.delta_t; a.xi = sc.xi; a.ref_p = h.tab.ref_surf_p; a.ref_t = h.tab.ref_t; a.robert = h.cfg.robert_coeff;
   a.eddy_sponge = h.cfg.eddy_sponge_coeff; a.zmu_sponge = h.cfg.zmu_sponge_coeff; a.zmv_sponge = h.cfg.zmv_sponge_coeff;
   a.raw = h.cfg.raw_filter_coeff;

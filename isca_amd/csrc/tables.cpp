@@ -37,29 +37,32 @@ void compute_gaussian(int n_hem, std::vector<double> &sin_hem, std::vector<doubl
   }
 }
 
-// gauss_and_legendre.F90:47-108 (fourier_inc = 1); leg[j][n][m]
-void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg) {
+// gauss_and_legendre.F90:47-108; leg[j][n][m]: the polynomials of every zonal wavenumber up to num_fourier * fourier_inc by the
+// recursions, every fourier_inc-th one kept
+void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg, int fourier_inc) {
   const int M1 = num_fourier + 1, N1 = num_spherical + 1, nlat = (int)sin_hem.size();
-  std::vector<double> eps((size_t)N1 * M1), poly((size_t)N1 * M1), b(M1, 0.0);
+  const int F1 = num_fourier * fourier_inc + 1;
+  std::vector<double> eps((size_t)N1 * F1), poly((size_t)N1 * F1), b(F1, 0.0);
   for (int n = 0; n < N1; ++n)
-    for (int m = 0; m < M1; ++m) {
+    for (int m = 0; m < F1; ++m) {
       double m2 = (double)m * m, l2 = (double)(m + n) * (m + n);
-      eps[(size_t)n * M1 + m] = std::sqrt((l2 - m2) / (4.0 * l2 - 1.0));
+      eps[(size_t)n * F1 + m] = std::sqrt((l2 - m2) / (4.0 * l2 - 1.0));
     }
-  for (int m = 1; m < M1; ++m) b[m] = std::sqrt(0.5 * (2.0 * (double)m + 1.0) / (double)m);
+  for (int m = 1; m < F1; ++m) b[m] = std::sqrt(0.5 * (2.0 * (double)m + 1.0) / (double)m);
   leg.assign((size_t)nlat * N1 * M1, 0.0);
   for (int j = 0; j < nlat; ++j) {
     const double s = sin_hem[j];
     const double c = std::sqrt(1 - s * s);
     poly[0] = std::sqrt(0.5);
-    for (int m = 1; m < M1; ++m) poly[m] = b[m] * c * poly[m - 1];
-    for (int m = 0; m < M1; ++m) poly[M1 + m] = s * poly[m] / eps[M1 + m];
+    for (int m = 1; m < F1; ++m) poly[m] = b[m] * c * poly[m - 1];
+    for (int m = 0; m < F1; ++m) poly[F1 + m] = s * poly[m] / eps[F1 + m];
     for (int n = 2; n < N1; ++n)
-      for (int m = 0; m < M1; ++m)
-        poly[(size_t)n * M1 + m] =
-            (s * poly[(size_t)(n - 1) * M1 + m] - eps[(size_t)(n - 1) * M1 + m] * poly[(size_t)(n - 2) * M1 + m]) /
-            eps[(size_t)n * M1 + m];
-    for (size_t q = 0; q < (size_t)N1 * M1; ++q) leg[(size_t)j * N1 * M1 + q] = poly[q];
+      for (int m = 0; m < F1; ++m)
+        poly[(size_t)n * F1 + m] =
+            (s * poly[(size_t)(n - 1) * F1 + m] - eps[(size_t)(n - 1) * F1 + m] * poly[(size_t)(n - 2) * F1 + m]) /
+            eps[(size_t)n * F1 + m];
+    for (int n = 0; n < N1; ++n)
+      for (int m = 0; m < M1; ++m) leg[((size_t)j * N1 + n) * M1 + m] = poly[(size_t)n * F1 + (size_t)m * fourier_inc];
   }
 }
 
@@ -142,8 +145,8 @@ void Tables::build(const isca_dyn_config &c) {
     coriolis[j] = 2 * omega * sin_lat[j];              // spectral_dynamics.F90:445
   }
   deg_lon.resize(I);
-  for (int i = 0; i < I; ++i) deg_lon[i] = i * 360.0 / (double)I;   // grid_fourier.F90:109-118
-  compute_legendre(c.num_fourier, c.num_spherical, sin_hem, legendre);
+  for (int i = 0; i < I; ++i) deg_lon[i] = i * (360.0 / (double)c.fourier_inc) / (double)I;   // grid_fourier.F90:105-118: a 360/fourier_inc sector
+  compute_legendre(c.num_fourier, c.num_spherical, sin_hem, legendre, c.fourier_inc);
   // --- spherical.F90:137-216
   const size_t NM = (size_t)N1 * M1;
   eigen.assign(NM, 0); coef_uvm.assign(NM, 0); coef_uvc.assign(NM, 0); coef_uvp.assign(NM, 0);
@@ -153,13 +156,13 @@ void Tables::build(const isca_dyn_config &c) {
   for (int n = 0; n < N1; ++n)
     for (int m = 0; m < M1; ++m) {
       const size_t q = (size_t)n * M1 + m;
-      const double fw = m, sw = m + n;
+      const double fw = m * c.fourier_inc, sw = fw + n;      // the zonal wavenumber of index m is m * fourier_inc (spherical.F90:182-183)
       // the model's truncation: triangle_mask (spherical.F90:190-195), or -- triang_trunc = .false. -- rhomboidal_truncation's
       // `spherical(:,num_spherical,:) = 0` (spherical.F90:622): only the extra row goes
-      if (c.triang_trunc ? (m + n > c.num_spherical - 1) : (n == c.num_spherical)) tri_mask[q] = 0.0;
+      if (c.triang_trunc ? (sw > c.num_spherical - 1) : (n == c.num_spherical)) tri_mask[q] = 0.0;
       eps[q] = std::sqrt((sw * sw - fw * fw) / (4.0 * sw * sw - 1.0));
       eigen[q] = sw * (sw + 1.0) / (radius * radius);
-      if (m + n > 0) {
+      if (sw > 0) {
         coef_uvm[q] = -radius * eps[q] / sw;
         coef_uvc[q] = -radius * fw / (sw * (sw + 1.0));
       }
@@ -170,7 +173,7 @@ void Tables::build(const isca_dyn_config &c) {
   for (int n = 0; n < N1 - 1; ++n)
     for (int m = 0; m < M1; ++m) {
       const size_t q = (size_t)n * M1 + m, qp = (size_t)(n + 1) * M1 + m;
-      const double sw = m + n;
+      const double sw = m * c.fourier_inc + n;
       coef_uvp[q] = -radius * eps[qp] / (sw + 1.0);
       coef_alpp[q] = sw * eps[qp] / radius;
       coef_dyp[q] = (sw + 2.0) * eps[qp] / radius;
@@ -312,7 +315,7 @@ void Tables::build(const isca_dyn_config &c) {
     for (int j = 0; j <= J + 1; ++j) { fv_dyp[j] = dyF(j) / (dyF(j) + dyF(j + 1)); fv_dym[j] = dyF(j) / (dyF(j - 1) + dyF(j)); }
     for (auto &v : fv_dy) v = v * radius;
     for (auto &v : fv_dyy) v = v * radius;
-    fv_dx = 2.0 * PI * radius / (double)I;
+    fv_dx = ((360.0 / (double)c.fourier_inc) / 360.0) * 2.0 * PI * radius / (double)I;      // fv_advection.F90:108 with degrees_lon = 360/fourier_inc
   }
   // --- FFT twiddles
   tw_re.resize(I); tw_im.resize(I);

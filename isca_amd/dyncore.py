@@ -182,6 +182,7 @@ RESOLUTIONS = {
     "T170": dict(lon_max=512, lat_max=256, num_fourier=170, num_spherical=171),
     # small test resolutions (not in the reference's table)
     "T10": dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11),
+    "S10": dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=21, fourier_inc=2),         # zonal wavenumbers 0, 2, .., 20 on a 180-degree sector
     "R10": dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=11, triang_trunc=0),      # rhomboidal: 2 lat_max >= 5 (num_spherical - 1) + 1
 }
 

@@ -40,7 +40,7 @@ FIELD_TABLE_3 = FIELD_TABLE + '''"TRACER", "atmos_mod", "age_grid"
           "profile_type", "fixed",   "surface_value=0.0" /
 '''
 
-RES = {"R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
+RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
 
@@ -442,6 +442,10 @@ def main():
         "run_R10L8_rhomboidal": lambda: golden_run(
             "R10", 8, 36, (1, 2, 36), extra="triang_trunc = .false.",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|vors|ts|lnps)_", k) is not None),
+        # fourier_inc = 2: zonal wavenumbers 0, 2, .., 20 on a 180-degree sector of 32 longitudes, triangular truncation at 20
+        "run_S10L8_fourier_inc2": lambda: golden_run(
+            "S10", 8, 36, (1, 2, 36), extra="fourier_inc = 2",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,
