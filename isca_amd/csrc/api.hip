@@ -162,8 +162,6 @@ static void check_config(const isca_dyn_config &c) {
     for (int k = 0; k < c.num_levels; ++k)
       if (!(c.pk_input[k + 1] + c.bk_input[k + 1] * c.reference_sea_level_press > c.pk_input[k] + c.bk_input[k] * c.reference_sea_level_press))
         fail("vert_coordinate_nml: pk/bk must give increasing half-level pressures");
-    for (int k = 0; k <= c.num_levels; ++k)
-      if (c.pk_input[k] != 0.0) fail("vert_coord_option = 'input': only pure sigma levels (pk = 0) are supported");
   }
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
@@ -462,17 +460,17 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         ppm[2 * L + k] = z0 + x * y * d1 * d2; ppm[3 * L + k] = dz[k - 1] * n3 * d3 * d2; ppm[4 * L + k] = dz[k] * n4 * d4 * d2;
       }
       d.fv_rcdx = dupload(h, rcdx); d.fv_rdyy = dupload(h, rdyy); d.fv_rcdy = dupload(h, rcdy); d.fv_rdy = dupload(h, rdy);
-      d.ppm_tab = dupload(h, ppm);
+      bool sigma = true;
+      for (double v : T.pk) if (v != 0.0) sigma = false;
+      d.ppm_tab = sigma ? dupload(h, ppm) : nullptr;      // hybrid levels: the tracer kernel forms the weights per column
     }
     h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr;
-    bool pure_sigma = true;
-    for (double v : T.pk) if (v != 0.0) pure_sigma = false;
-    // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need pure sigma levels, >= 4
-    // latitude rows per rank and >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be
-    // dropped without a word; num_tracers = 0 is the way to run without one (field_table without tracers).
-    const bool tracer_can = pure_sigma && (g.Jl >= 4) && (g.L >= 5);
+    // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need >= 4 latitude rows per rank and
+    // >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be dropped without a word;
+    // num_tracers = 0 is the way to run without one (field_table without tracers).
+    const bool tracer_can = (g.Jl >= 4) && (g.L >= 5);
     if (cfg->num_tracers > 0 && !tracer_can)
-      fail("spectral_dynamics_init: the grid tracer needs pure sigma levels (pk = 0), num_levels >= 5 and lat_max / world_size >= 4; "
+      fail("spectral_dynamics_init: the grid tracer needs num_levels >= 5 and lat_max / world_size >= 4; "
            "set num_tracers = 0 to run without it");
     h->tracer_env_off = getenv("ISCA_NO_TRACER") != nullptr;   // measurement switch, reported by isca_dyn_get_info("tracer_env_off")
     h->tracer_on = tracer_can && (cfg->num_tracers > 0) && !h->tracer_env_off;
@@ -1621,8 +1619,7 @@ extern "C" int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const
 extern "C" int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt) {
   API_BEGIN
   const Geom &g = h->g;
-  if (!h->d.ppm_tab) fail("vert_advection_ppm: not available");
-  for (double v : h->tab.pk) if (v != 0.0) fail("vert_advection_ppm: pure sigma levels only");
+  if (!h->d.fv_c) fail("vert_advection_ppm: not available");
   const size_t n2 = (size_t)g.Jl * g.I, n3 = n2 * g.L;
   DevTmp t(h);
   double *dw = t.up(w, n2 * (g.L + 1)), *ps = t.up(surf_p, n2), *dr = t.up(r, n3), *rn = t.alloc(n3);

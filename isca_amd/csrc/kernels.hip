@@ -1730,9 +1730,10 @@ __device__ void ppm_cell_global(const TracerArgs &a, const Geom &g, size_t c2, d
 
 // Block = 64 columns x NW wavefronts, wavefront w owns levels [w*CH, w*CH+CH) like the column kernel; every thread
 // reconstructs its CH+2 cells from CH+8 column values held in registers (no LDS, no barriers in the main part).
-// Pure sigma coordinates (pk = 0, the only vertical coordinate supported): dz = dbk*ps, so the slope and edge
-// weights of slope_z / compute_weights are independent of the column and come from the host table a.ppm.
-template <int CH, int MAXW>      // MAXW = wavefronts per block: 8, or 12 (chunks of 5 levels) for 41..60 levels
+// Pure sigma coordinates (pk = 0: HYB = false): dz = dbk*ps, so the slope and edge weights of slope_z / compute_weights are independent
+// of the column and come from the host table a.ppm.  Hybrid levels (pk /= 0: HYB = true): the weights are formed per column from the
+// layer thicknesses the thread holds anyway (ppm_slope / ppm_edge, the helpers of the Courant > 1 path).
+template <int CH, int MAXW, bool HYB>      // MAXW = wavefronts per block: 8, or 12 (chunks of 5 levels) for 41..60 levels
 __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a) {
   __shared__ double red[5][MAXW][64];
   const int L = g.L;
@@ -1767,7 +1768,8 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   for (int t = 0; t < CH + 4; ++t) {
     const int kc = k0 - 2 + t;
     double s_ = 0.0;
-    if (kc >= 1 && kc <= L - 2) {
+    if (HYB) s_ = ppm_slope(rv + t + 2, dv + t + 2, kc, L);
+    else if (kc >= 1 && kc <= L - 2) {
       const double rm1 = rv[t + 1], r0 = rv[t + 2], rp1 = rv[t + 3];
       s_ = a.ppm[0 * L + kc] * (rp1 - r0) + a.ppm[1 * L + kc] * (r0 - rm1);
       const double rmin = fmin(fmin(rm1, r0), rp1), rmax = fmax(fmax(rm1, r0), rp1);
@@ -1781,8 +1783,10 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   for (int t = 0; t < CH + 3; ++t) {
     const int kc = k0 - 1 + t;                    // cell kc = rv index t+3, slope index t+1
     double e = 0.0;
-    if (kc >= 2 && kc <= L - 2)
-      e = rv[t + 2] + a.ppm[2 * L + kc] * (rv[t + 3] - rv[t + 2]) - a.ppm[3 * L + kc] * sl[t + 1] + a.ppm[4 * L + kc] * sl[t];
+    if (kc >= 2 && kc <= L - 2) {
+      if (HYB) e = ppm_edge(rv + t + 3, dv + t + 3, sl[t + 1], sl[t]);
+      else e = rv[t + 2] + a.ppm[2 * L + kc] * (rv[t + 3] - rv[t + 2]) - a.ppm[3 * L + kc] * sl[t + 1] + a.ppm[4 * L + kc] * sl[t];
+    }
     ed[t] = e;
   }
   // limited parabolas of cells k0-1 .. k0+CH
@@ -1919,12 +1923,13 @@ static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStr
   const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64));
   if (g.L > 40 && g.L <= 60) {                  // 12 wavefronts of 5 levels (164 VGPRs, 3 wavefronts per SIMD) instead of 8 of 8 (207)
     const int NW = (g.L + 4) / 5;
-    hipLaunchKernelGGL((k_tracer_vert<5, 12>), grid, dim3(64 * NW), 0, s, g, a);
+    if (a.ppm) hipLaunchKernelGGL((k_tracer_vert<5, 12, false>), grid, dim3(64 * NW), 0, s, g, a);
+    else hipLaunchKernelGGL((k_tracer_vert<5, 12, true>), grid, dim3(64 * NW), 0, s, g, a);
     return;
   }
   const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums
   const dim3 block(64 * NW);
-#define LT(N) hipLaunchKernelGGL((k_tracer_vert<N, 8>), grid, block, 0, s, g, a)
+#define LT(N) do { if (a.ppm) hipLaunchKernelGGL((k_tracer_vert<N, 8, false>), grid, block, 0, s, g, a); else hipLaunchKernelGGL((k_tracer_vert<N, 8, true>), grid, block, 0, s, g, a); } while (0)   // a.ppm: the pure-sigma weight table, null with hybrid levels
   switch (CH) {
     case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
     case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;

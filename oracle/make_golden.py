@@ -390,6 +390,15 @@ GAUSSIAN_TOPOG_GROUPS = """ &spectral_init_cond_nml
 """
 
 
+HYBRID_BK = [0.0, 0.0, 0.05, 0.15, 0.30, 0.50, 0.70, 0.87, 1.0]
+HYBRID_PK = [0.0, 2000.0, 6000.0, 8000.0, 7000.0, 5000.0, 2500.0, 800.0, 0.0]
+HYBRID_LEVELS_GROUP = """ &vert_coordinate_nml
+    bk = %s,
+    pk = %s
+ /
+""" % (", ".join(str(b) for b in HYBRID_BK), ", ".join(str(p) for p in HYBRID_PK))
+
+
 def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE):
     """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win); `extra_groups`: whole
     namelist groups appended to input.nml"""
@@ -446,6 +455,10 @@ def main():
         "run_S10L8_fourier_inc2": lambda: golden_run(
             "S10", 8, 36, (1, 2, 36), extra="fourier_inc = 2",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_", k) is not None),
+        # hybrid levels (vert_coord_option = 'input' with pk /= 0: pressure levels aloft, sigma at the ground) with the grid tracer
+        "run_T21L8_hybrid": lambda: golden_run(
+            "T21", 8, 48, (1, 2, 48), extra="vert_coord_option = 'input'", extra_groups=HYBRID_LEVELS_GROUP,
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,
