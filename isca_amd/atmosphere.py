@@ -10,6 +10,7 @@ grid (lon,lat,lev) <-> [lev,lat,lon], spectral (m,n,lev) <-> [lev,n,m].
 """
 from __future__ import annotations
 
+import math
 import os
 import sys
 import re
@@ -164,6 +165,45 @@ def parse_namelist(text: str) -> dict:
     return out
 
 
+_V197_BK = [0.0, .0089163, .0342936, .0740741, .1262002, .1886145, .2592592, .3360768, .4170096, .5000000, .5829904, .6639231, .7407407,
+            .8113854, .8737997, .9259259, .9657064, .9910837, 1.0]                                           # compute_v197_sigma (:276-294)
+_MCM_BK = [0.0, .03, .0707, .1311, .2102, .3036, .4062, .5138, .6226, .7284, .8255, .9066, .9640, .9933, 1.0]  # compute_old_model_sigma (:296-310)
+
+
+def named_vert_coord(option, num_levels, scale_heights, surf_res, exponent, p_press, p_sigma, reference_press):
+    """(pk, bk) of vert_coord_option = 'hybrid' | 'mcm' | 'v197' (init/vert_coordinate.F90:89-157): 'hybrid' blends an uneven-sigma profile
+    used as sigma (b) with the same profile used as pressure (a) through transition() = sin^2 between p_press and p_sigma."""
+    if option == "v197" or option == "mcm":
+        bk = _V197_BK if option == "v197" else _MCM_BK
+        if num_levels != len(bk) - 1:
+            raise IscaError(f"compute_{'v197' if option == 'v197' else 'old_model'}_sigma: num_levels={num_levels} It must be {len(bk) - 1}")
+        return [0.0] * len(bk), list(bk)
+    if scale_heights == 0. or exponent == 0.:
+        raise IscaError("compute_vert_coord: zero is an invalid value for scale_heights / exponent.")
+    if not (0. < surf_res <= 1.0):
+        raise IscaError(f"compute_vert_coord: the namelist parameter surf_res must be < 1.0, but surf_res={surf_res}")
+    if p_sigma < p_press:
+        raise IscaError(f"compute_vert_coord: p_sigma must be greater than p_press, but p_sigma={p_sigma}  p_press={p_press}")
+    s2 = 1.0 - surf_res
+    prof = []
+    for k in range(num_levels):                        # compute_uneven_sigma(..., zero_top = .false.) (:248-273)
+        zeta = 1. - (float(k) / float(num_levels))
+        z = surf_res * zeta + s2 * (zeta ** exponent)
+        prof.append(math.exp(-z * scale_heights))
+    prof.append(1.0)
+    pk, bk = [], []
+    for p in prof:                                     # transition (:161-183)
+        if p <= p_press:
+            f = 0.0
+        elif p >= p_sigma:
+            f = 1.0
+        else:
+            f = (math.sin(0.5 * math.pi * (p - p_press) / (p_sigma - p_press))) ** 2
+        pk.append(reference_press * (0.0 * f + p * (1.0 - f)))
+        bk.append(p * f + 0.0 * (1.0 - f))
+    return pk, bk
+
+
 def config_from_namelist(namelist: dict | str | None, resolution: str | None = None, **overrides):
     """Build the C config from namelist groups (dict as in held_suarez_test_case.py:45-98, or input.nml text).  Variables a given
     namelist leaves out take the reference's MODULE defaults (_REF_DEFAULTS), as they do when the reference reads that input.nml;
@@ -182,6 +222,13 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
         nl = overrides.get("num_levels", namelist.get("spectral_dynamics_nml", {}).get("num_levels", kw.get("num_levels", 25)))
         kw["bk_input"] = [float(k) / float(nl) for k in range(nl)] + [1.0]
         kw["pk_input"] = [0.0] * (nl + 1)
+    if vco in ("hybrid", "mcm", "v197"):     # compute_vert_coord's other options (init/vert_coordinate.F90:124-152): formed here, handed over like 'input'
+        sd = {k.lower(): v for k, v in namelist.get("spectral_dynamics_nml", {}).items()}
+        nl = overrides.get("num_levels", sd.get("num_levels", kw.get("num_levels", 25)))
+        kw["pk_input"], kw["bk_input"] = named_vert_coord(
+            vco, nl, sd.get("scale_heights", kw.get("scale_heights", 4.0)), sd.get("surf_res", kw.get("surf_res", 0.1)),
+            sd.get("exponent", kw.get("exponent", 2.5)), sd.get("p_press", 0.1), sd.get("p_sigma", 0.3),
+            sd.get("reference_sea_level_press", kw.get("reference_sea_level_press", 101325.0)))
     if vco == "input":
         if not vc or "bk" not in vc:
             raise IscaError("vert_coord_option = 'input' needs vert_coordinate_nml with bk (and pk)")
@@ -207,7 +254,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     if dopt not in _DAMPING_OPTIONS:
         raise IscaError(f'"{dopt}" is an invalid value for damping_option')                      # spectral_damping.F90:152-153
     kw["damping_option"] = _DAMPING_OPTIONS[dopt]
-    unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma") else "uneven_sigma", "damping_option": dopt,
+    unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma", "hybrid", "mcm", "v197") else "uneven_sigma", "damping_option": dopt,
                    "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
                    "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}
@@ -225,6 +272,8 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 want = k == "use_implicit"
                 if bool(v) != want:
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{want}")')
+                continue
+            if k in ("p_press", "p_sigma"):           # vert_coord_option = 'hybrid' (used above)
                 continue
             if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
                      "graceful_shutdown", "ocean_topog_smoothing"):

@@ -459,6 +459,10 @@ def main():
         "run_T21L8_hybrid": lambda: golden_run(
             "T21", 8, 48, (1, 2, 48), extra="vert_coord_option = 'input'", extra_groups=HYBRID_LEVELS_GROUP,
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_", k) is not None),
+        # vert_coord_option = 'hybrid' (compute_vert_coord: uneven-sigma profile blended into pressure levels above p_press): levels + 24 steps
+        "run_T21L12_hybrid_option": lambda: golden_run(
+            "T21", 12, 24, (24,), extra="vert_coord_option = 'hybrid', p_press = 0.15, p_sigma = 0.45, scale_heights = 5.0, exponent = 3.0, surf_res = 0.3",
+            keep=lambda k: k in ("tab_pk", "tab_bk") or re.match(r"st_(ug|tg|psg|tr1)_", k) is not None),
         # tables only (Gauss nodes/weights, Legendre) at T42; T85 kept as a strided sample
         # Frierson column physics (configs[3]'s chain) routine by routine on a spun-up T21L25 moist state
         "moist_kernels_T21L25": golden_moist_kernels,

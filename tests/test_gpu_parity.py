@@ -346,6 +346,26 @@ def test_golden_hybrid_levels(golden_dir):
     assert c.vert_coord_input == 1 and c.pk_input[3] == 8000.0
 
 
+def test_golden_hybrid_option(golden_dir):
+    """vert_coord_option = 'hybrid' through the namelist mirror: 12 levels whose top half level is NOT at p = 0 (the column kernel's
+    `top0 = false` branch of the Simmons-Burridge full-level pressure), pressure levels aloft; 24 steps against the reference run."""
+    from isca_amd import atmosphere as atm
+    g = np.load(os.path.join(golden_dir, "run_T21L12_hybrid_option.npz"))
+    nml = {"spectral_dynamics_nml": dict(dyncore.RESOLUTIONS["T21"], num_levels=12, vert_coord_option="hybrid", p_press=0.15, p_sigma=0.45,
+                                        scale_heights=5.0, exponent=3.0, surf_res=0.3, reference_sea_level_press=1.0e5, damping_order=4,
+                                        water_correction_limit=200.e2, valid_range_t=[100., 800.], initial_sphum=0.0, robert_coeff=0.04),
+           "main_nml": {"dt_atmos": 600},
+           "hs_forcing_nml": dict(t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=True)}
+    dc = dyncore.DynCore(atm.config_from_namelist(nml))
+    assert np.array_equal(dc.table("pk"), g["tab_pk"]) and np.array_equal(dc.table("bk"), g["tab_bk"])
+    dc.cold_start(); dc.step(24)
+    err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_000024"]).max() / max(np.abs(g[f"st_{k}_000024"]).max(), 1.0 if k == "ug" else 1e-300)) for k in ("ug", "tg", "psg")}
+    err["tr"] = rel(dc.get("tr"), g["st_tr1_000024"])
+    print("vert_coord_option = 'hybrid', 24 steps", err)
+    assert max(err.values()) < 1e-9, err
+    dc.close()
+
+
 def test_golden_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (leapfrog.F90:58-105): the step gets a third transform phase -- grid u, v, T, ps, vor, div of the new level
     from the unadjusted spectral state, its RAW adjustment afterwards (spectral_dynamics.F90:1031), the next step's gradients from the

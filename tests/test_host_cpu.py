@@ -124,7 +124,7 @@ def test_namelist_to_config(lib):
     from isca_amd import configs
     fr = atm.config_from_namelist(configs.frierson())
     assert fr.physics == 1 and fr.moist.depth == 2.5 and fr.moist.ir_tau_eq == 6.0 and fr.moist.tau_bm == 7200.0   # set / module default
-    d = {"spectral_dynamics_nml": {"damping_order": 4, "vert_coord_option": "hybrid"}}
+    d = {"spectral_dynamics_nml": {"damping_order": 4, "vert_coord_option": "pressure"}}
     with pytest.raises(dyncore.IscaError, match="vert_coord_option"):
         atm.config_from_namelist(d, "T21")
     with pytest.raises(dyncore.IscaError, match="not initialized"):
@@ -371,3 +371,23 @@ def test_field_table_entries():
                      (text * 2, "at most 4")):
         with pytest.raises(IscaError, match=msg):
             atm.tracers_from_field_table(atm.parse_field_table(bad))
+
+
+def test_named_vertical_coordinates(golden_dir):
+    """compute_vert_coord's 'hybrid', 'mcm' and 'v197' (init/vert_coordinate.F90:124-152, 276-310) in the host mirror: the hybrid levels
+    bit for bit against the pk, bk the reference built for the same namelist."""
+    import numpy as np
+    from isca_amd import atmosphere as atm
+    from isca_amd.dyncore import IscaError
+    g = np.load(os.path.join(golden_dir, "run_T21L12_hybrid_option.npz"))
+    pk, bk = atm.named_vert_coord("hybrid", 12, 5.0, 0.3, 3.0, 0.15, 0.45, 1.0e5)
+    assert np.array_equal(pk, g["tab_pk"]) and np.array_equal(bk, g["tab_bk"]) and pk[0] > 0.0 and bk[-1] == 1.0
+    c = atm.config_from_namelist({"spectral_dynamics_nml": dict(num_levels=12, vert_coord_option="hybrid", p_press=0.15, p_sigma=0.45, scale_heights=5.0,
+                                                                exponent=3.0, surf_res=0.3, reference_sea_level_press=1.0e5)})
+    assert c.vert_coord_input == 1 and [c.pk_input[k] for k in range(13)] == list(g["tab_pk"])
+    assert atm.config_from_namelist({"spectral_dynamics_nml": dict(num_levels=18, vert_coord_option="v197")}).bk_input[9] == 0.5
+    assert atm.config_from_namelist({"spectral_dynamics_nml": dict(num_levels=14, vert_coord_option="mcm")}).bk_input[1] == 0.03
+    with pytest.raises(IscaError, match="It must be 18"):
+        atm.config_from_namelist({"spectral_dynamics_nml": dict(num_levels=20, vert_coord_option="v197")})
+    with pytest.raises(IscaError, match="p_sigma must be greater than p_press"):
+        atm.named_vert_coord("hybrid", 12, 5.0, 0.3, 3.0, 0.5, 0.4, 1.0e5)
