@@ -464,7 +464,11 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       for (double v : T.pk) if (v != 0.0) sigma = false;
       d.ppm_tab = sigma ? dupload(h, ppm) : nullptr;      // hybrid levels: the tracer kernel forms the weights per column
     }
-    h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr;
+    // Tracer kernels on the side stream (fork after the column kernel, join before the fixer sums) pay for themselves from about T85 up:
+    // at T42L25 / T21L25 the two cross-stream waits cost more than the overlap hides (0.105 -> 0.094 and 0.100 -> 0.083 ms per step
+    // with the tracer on the main stream), at T85L40 the side stream saves 0.04 ms.  One rank only: a sharded step hides them under its exchange.
+    h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr ||
+                       (g.P == 1 && (size_t)g.L * g.Jl * g.I < 500000 && getenv("ISCA_TRACER_CONCURRENT") == nullptr);
     // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need >= 4 latitude rows per rank and
     // >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be dropped without a word;
     // num_tracers = 0 is the way to run without one (field_table without tracers).
