@@ -286,7 +286,8 @@ def main():
                    "kernels_per_step": core.info("kernels_per_step"), "exchanges_per_step": "1 halo + 2 all-to-all + 1 all-reduce (tracer transport under the first all-to-all)" if a.gpus > 1 else 0,
                    "exchange_driver": (("RCCL calls issued by the library on the step's stream" if getattr(core, "native", False)
                                         else f"torch.distributed ({backend}) between the device phases") if a.gpus > 1 else None),
-                   "grid_tracer": ("sphum advected (van Leer + PPM) on a concurrent stream" if a.gpus == 1
+                   "grid_tracer": (("sphum advected (van Leer + PPM) on a concurrent stream" if core.I * core.J * L >= 500000 or os.environ.get("ISCA_TRACER_CONCURRENT")
+                                    else "sphum advected (van Leer + PPM) on the main stream (small grid)") if a.gpus == 1
                                    else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
     }
