@@ -57,15 +57,15 @@ typedef struct isca_moist_config {
  * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
 typedef struct isca_dyn_config {
   int lon_max, lat_max, num_fourier, num_spherical, num_levels;
-  int fourier_inc;              /* must be 1 */
-  int triang_trunc;             /* must be 1 */
+  int fourier_inc;              /* spherical.F90:40,182: index m is zonal wavenumber m * fourier_inc (1 = the whole circle); /= 1: world_size 1 only */
+  int triang_trunc;             /* 1: triangular truncation; 0: rhomboidal (spherical.F90:603-644), world_size 1 only */
   double dt_atmos;              /* seconds */
   /* spectral_dynamics_nml */
   int damping_order;            /* see damping_option at the end of the struct */
   double damping_coeff;
   double eddy_sponge_coeff, zmu_sponge_coeff, zmv_sponge_coeff;
   double robert_coeff;
-  double raw_filter_coeff;      /* must be 1.0 (pure Robert filter, the reference default) */
+  double raw_filter_coeff;      /* in (0, 1]; 1.0 = the pure Robert filter (reference default); < 1: Robert-Asselin-Williams (leapfrog.F90:58-105) */
   double alpha_implicit;
   double reference_sea_level_press;
   double scale_heights, exponent, surf_res;   /* vert_coord_option = 'uneven_sigma' */

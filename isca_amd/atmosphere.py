@@ -369,6 +369,13 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
     (advect_vert = second_centered, hole_filling = off); anything else is refused by name rather than run as something else."""
     if len(entries) > dyncore.MAX_TRACERS:
         raise IscaError(f"field_table: {len(entries)} tracers, at most {dyncore.MAX_TRACERS} are carried")
+    # The reference finds the humidity tracer by NAME (nhum = get_tracer_index('sphum') or 'mix_rat', spectral_dynamics.F90:316-332;
+    # dry_model when neither exists); the library's tracer 1 is the one initial_sphum, the water correction, the virtual temperature
+    # and the moist physics act on.  So the humidity entry has to come first, and a table without one runs as the dry model.
+    hum = [k for k, e in enumerate(entries) if e["name"] in ("sphum", "mix_rat")]
+    if hum and hum[0] != 0:
+        raise IscaError(f"field_table: the humidity tracer ({entries[hum[0]]['name']}) must be the first atmos_mod entry "
+                        f"(the first entry is {entries[0]['name']}): tracer 1 is the one the water correction, virtual temperature and moist physics use")
     spectral, robert, names = [], [], []
     for k, e in enumerate(entries):
         m = e["methods"]
@@ -396,10 +403,14 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
                 for item in params.replace(" ", "").split(","):
                     if item.lower().startswith("robert_coeff="):
                         rc = float(item.split("=", 1)[1])
-        if k == 0 and rc >= 0.0 and robert_coeff is not None and rc != robert_coeff:
+        dyn_rc = 0.04 if robert_coeff is None else robert_coeff                    # spectral_dynamics_nml's module default (:166)
+        if k == 0 and rc >= 0.0 and rc != dyn_rc:
             raise IscaError(f"field_table: tracer {e['name']}: a robert_coeff of its own is only available from the second tracer on")
         spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"])
-    return dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert), names
+    keys = dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert)
+    if entries and not hum:            # dry_model: no humidity anywhere -- tracer 1 starts at 0 like every other tracer, no virtual temperature
+        keys.update(initial_sphum=0.0, use_virtual_temperature=False, _dry_model=True)
+    return keys, names
 
 
 def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str | None = None, field_table: str | None = None, **overrides):
@@ -418,6 +429,14 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
         nml = parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {})
         sd = {k.lower(): v for k, v in {g.lower(): v for g, v in nml.items()}.get("spectral_dynamics_nml", {}).items()}
         keys, names = tracers_from_field_table(parse_field_table(field_table), sd.get("robert_coeff"))
+        if keys.pop("_dry_model", False):
+            # initialize_corrections / compute_corrections (spectral_dynamics.F90:1245-1248, 1328-1331)
+            if sd.get("do_water_correction", True) and overrides.get("do_water_correction", True):
+                raise IscaError("compute_corrections: do_water_correction must be .false. in a dry model (default is .true.)")
+            at = {k.lower(): v for k, v in {g.lower(): v for g, v in nml.items()}.get("atmosphere_nml", {}).items()}
+            if at.get("idealized_moist_model", False):
+                raise IscaError("idealized_moist_phys: the field_table has no specific-humidity tracer (sphum / mix_rat)")
+            overrides = {**overrides, "initial_sphum": 0.0, "use_virtual_temperature": False}
         overrides = {**keys, **overrides}
     _core = dyncore.DynCore(config_from_namelist(namelist, resolution, **overrides))
     if names:
@@ -434,8 +453,11 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     try:
         if inp is not None and restart.restart_exists(inp):
             restart.read_restart(_core, inp)
+            _read_model_time(inp)
         else:
             _core.cold_start()
+        if _progress is not None:
+            _progress["step0"] = _core.info("step")         # 0 after a cold start, 0 or 1 after a restart
     except Exception:
         _core.close()
         _core = None
@@ -463,7 +485,48 @@ def _setup_progress_log(namelist: dict):
         raise IscaError("spectral_dynamics_nml: print_interval must be a positive multiple of dt_atmos")
     cal = str(mn.get("calendar", "no_calendar")).lower()
     date = list(mn.get("current_date", [0, 0, 0, 0, 0, 0]))
-    _progress = {"every": int(every), "json": bool(sd.get("json_logging", False)), "calendar": cal, "date0": date, "out": sys.stdout}
+    if cal in ("no_calendar", "none"):       # atmos_model.F90:218-223: date(1:2) = 0, date(3:6) = current_time
+        date = [0, 0] + (list(mn.get("current_time", [0, 0, 0, 0])) + [0] * 4)[:4]
+    _progress = {"every": int(every), "json": bool(sd.get("json_logging", False)), "calendar": cal, "date0": date, "out": sys.stdout,
+                 "step0": 0}
+
+
+# ---- the model time across run segments: the main program's RESTART/atmos_model.res (atmos_model.F90:198-202, 397-406) holds the date the
+# run ended at and the calendar type; a run that finds INPUT/atmos_model.res continues from that date (progress lines, print_interval alarm).
+_CALENDAR_TYPES = {"no_calendar": 0, "none": 0, "thirty_day": 1, "julian": 2, "gregorian": 3, "noleap": 4}
+
+
+def _date_after(date0, calendar: str, secs: int):
+    """date0 (year, month, day, hour, minute, second) advanced by secs: no_calendar counts days in date(3); thirty_day: 12 months of 30 days"""
+    y0, m0, d0, h0, mi0, s0 = (list(date0) + [0] * 6)[:6]
+    if calendar in ("no_calendar", "none"):
+        tot = ((d0 * 24 + h0) * 60 + mi0) * 60 + s0 + secs
+        days, rem = divmod(tot, 86400)
+        return [0, 0, days, rem // 3600, rem % 3600 // 60, rem % 60]
+    tot = ((((y0 * 12 + max(m0, 1) - 1) * 30 + max(d0, 1) - 1) * 24 + h0) * 60 + mi0) * 60 + s0 + secs
+    tot, sec = divmod(tot, 60); tot, mnt = divmod(tot, 60); tot, hr = divmod(tot, 24); tot, dy = divmod(tot, 30); yr, mo = divmod(tot, 12)
+    return [yr, mo + 1, dy + 1, hr, mnt, sec]
+
+
+def _read_model_time(inp: str):
+    path = os.path.join(inp, "atmos_model.res")
+    if _progress is None or not os.path.exists(path):
+        return
+    with open(path) as f:
+        rows = [ln.split() for ln in f.read().splitlines() if ln.strip()]
+    _progress["date0"] = [int(x) for x in rows[0][:6]]
+
+
+def _write_model_time(resdir: str):
+    if _progress is None:
+        return
+    secs = int(round((_core.info("step") - _progress["step0"]) * _core.cfg.dt_atmos))
+    date = _date_after(_progress["date0"], _progress["calendar"], secs)
+    os.makedirs(resdir, exist_ok=True)
+    with open(os.path.join(resdir, "atmos_model.res"), "w") as f:
+        f.write("%6d%6d%6d%6d%6d%6d        Current model time: year, month, day, hour, minute, second\n" % tuple(date))
+        f.write("%6d        (Calendar: no_calendar=0, thirty_day_months=1, julian=2, gregorian=3, noleap=4)\n"
+                % _CALENDAR_TYPES.get(_progress["calendar"], 0))
 
 
 def global_integrals():
@@ -475,18 +538,18 @@ def global_integrals():
 
 def _progress_line():
     c, p = _core, _progress
-    secs = int(round(c.info("step") * c.cfg.dt_atmos))
+    secs = int(round((c.info("step") - p["step0"]) * c.cfg.dt_atmos))      # since this run began; date0 is where it began (a restart: where the last one ended)
     max_speed, avg_t = global_integrals()
-    days, rem = divmod(secs, 86400)
+    date = _date_after(p["date0"], p["calendar"], secs)
+    days, rem = date[2], (date[3] * 60 + date[4]) * 60 + date[5]
     if p["calendar"] in ("no_calendar", "none"):
         if p["json"]:
             line = ' {"day":%6d  ,"second":%6d  ,"max_speed":%13.6E   ,"avg_T":%13.6E   }' % (days, rem, max_speed, avg_t)
         else:
             line = " Integration completed through%6d days%6d seconds" % (days, rem)
     else:                                                   # thirty_day: 12 months of 30 days from main_nml's current_date
-        y0, m0, d0, h0, mi0, s0 = (p["date0"] + [0] * 6)[:6]
-        tot = ((((y0 * 12 + max(m0, 1) - 1) * 30 + max(d0, 1) - 1) * 24 + h0) * 60 + mi0) * 60 + s0 + secs
-        tot, sec = divmod(tot, 60); tot, mnt = divmod(tot, 60); tot, hr = divmod(tot, 24); tot, dy = divmod(tot, 30); yr, mo = divmod(tot, 12)
+        yr, mo, dy, hr, mnt, sec = date
+        mo, dy = mo - 1, dy - 1
         if p["json"]:
             line = ' {"date": "%04d-%02d-%02d", "time": "%02d:%02d:%02d", "max_speed":%6.1f   ,"avg_T":%6.1f   }' % (
                 yr, mo + 1, dy + 1, hr, mnt, sec, max_speed, avg_t)
@@ -504,8 +567,8 @@ def atmosphere(nsteps: int = 1):
         _core.step(nsteps)
         return
     left = nsteps
-    while left > 0:                                         # stop at every alarm of print_interval
-        done = _core.info("step")
+    while left > 0:                                         # stop at every alarm of print_interval (counted from the start of this run)
+        done = _core.info("step") - _progress["step0"]
         chunk = min(left, _progress["every"] - done % _progress["every"])
         _core.step(chunk)
         left -= chunk
@@ -520,6 +583,7 @@ def atmosphere_end():
         try:
             if _run_dir is not None:
                 restart.write_restart(_core, os.path.join(_run_dir, "RESTART"))
+                _write_model_time(os.path.join(_run_dir, "RESTART"))
         finally:
             _core.close()
             _core = None

@@ -112,6 +112,22 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   return 0;
 }
 
+static const double PEND_ROWS[12] = {1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0};    // Dev::pend with nothing pending
+// Lazy fixers: apply what is pending on the two time levels in place, so that the stored tg, psg, tr, tr_atm are the model's values
+// (host reads and writes of the state, restart files, diagnostics, the transforms of complete_update / refresh_derived).
+static void materialize(isca_dyn *h) {
+  const bool any = h->thermo_pending[0] || h->thermo_pending[1] || h->tr_state[0] != isca::TR_MAT || h->tr_state[1] != isca::TR_MAT;
+  if (!any) return;
+  if (h->in_step) fail("the model state cannot be read or written in the middle of a step driven phase by phase");
+  launch_fixer_materialize(*h, h->stream);
+  HIP_CHECK(hipMemcpyAsync(h->d.pend, PEND_ROWS, sizeof(PEND_ROWS), hipMemcpyHostToDevice, h->stream));
+  h->thermo_pending[0] = h->thermo_pending[1] = false;
+  h->tr_state[0] = h->tr_state[1] = isca::TR_MAT;
+}
+static bool is_lazy_field(const std::string &nm) {
+  return nm == "tg" || nm == "psg" || nm == "tr" || nm == "tr_atm" || nm == "p_full" || nm == "p_half" || nm == "z_full" || nm == "z_half";
+}
+
 static void deal_wavenumbers(int M1, int P, std::vector<int> &m_of_slot, int &Ml) {
   // boustrophedon over ranks: round r deals m = r*P .. r*P+P-1 left-to-right (r even) or right-to-left
   Ml = (M1 + P - 1) / P;
@@ -420,6 +436,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
     d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
     d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
+    d.pend = dupload(h, std::vector<double>(PEND_ROWS, PEND_ROWS + 12));
     for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
       for (int t = 0; t < 2; ++t) {
         d.trx[t][e] = dalloc<double>(h, ng3); d.trx_atm[t][e] = dalloc<double>(h, ng3);
@@ -502,6 +519,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc && cfg->fourier_inc == 1;      // the fused gather has the triangle's bounds built in
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
+    // Lazy fixers (core.h): for the plain configurations -- one grid tracer at most, Robert filter without the RAW term, no virtual
+    // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
+    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 &&
+                  getenv("ISCA_EAGER_FIXERS") == nullptr;
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
@@ -615,6 +636,12 @@ static void dcopy(isca_dyn *h, double *dst, const double *src, size_t n) {
 // ---------------------------------------------------------------------------------------------------
 // cold start: spectral_initialize_fields.F90:45-135 + spectral_dynamics.F90:580-630
 // ---------------------------------------------------------------------------------------------------
+static void reset_pending(isca_dyn *h) {       // a state written from scratch has nothing pending on it
+  HIP_CHECK(hipMemcpy(h->d.pend, PEND_ROWS, sizeof(PEND_ROWS), hipMemcpyHostToDevice));
+  h->thermo_pending[0] = h->thermo_pending[1] = false;
+  h->tr_state[0] = h->tr_state[1] = isca::TR_MAT;
+  h->in_step = false;
+}
 static void cold_start_single(isca_dyn *h) {
   const Geom &g = h->g;
   Dev &d = h->d;
@@ -657,6 +684,7 @@ static void cold_start_single(isca_dyn *h) {
   if (h->cfg.physics == 1) launch_t_surf_init(*h, h->stream);       // mixed_layer_init, prescribe_initial_dist
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true; h->phys_calls = 0;
+  reset_pending(h);
 }
 
 static const char *GRID3[] = {"ug", "vg", "tg", "tr"};
@@ -728,6 +756,7 @@ extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_leve
   const Geom &g = h->g;
   const std::string nm(name);
   const size_t ng2 = (size_t)g.Jl * g.I;
+  if (is_lazy_field(nm)) materialize(h);
   if (nm == "p_full" || nm == "p_half" || nm == "z_full" || nm == "z_half") {
     // compute_pressures_and_heights of the requested level (atmosphere.F90:229-241, 331-338)
     const int tl = (time_level == 0) ? h->previous : h->current;
@@ -753,6 +782,7 @@ extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_leve
 extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_level, const double *host, size_t count) {
   API_BEGIN
   if (!h || !name || !host) fail("null argument");
+  if (is_lazy_field(name)) materialize(h);
   size_t cnt; int kind;
   double *p = state_ptr(h, name, time_level, cnt, kind);
   if (!p) fail(std::string("set_state: unknown field ") + name);
@@ -766,6 +796,7 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
 // vorg, divg and the gradient fields of the `current` level from its spectral state; the caller's grid
 // u, v, T, ps of that level are kept bit for bit (the synthesis would reproduce them only to roundoff)
 static void refresh_derived(isca_dyn *h) {
+  materialize(h);
   Dev &d = h->d;
   const int tl = h->current;
   const size_t ng2 = (size_t)h->g.Jl * h->g.I, ng3 = ng2 * h->g.L;
@@ -781,6 +812,7 @@ static void refresh_derived(isca_dyn *h) {
 extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
   API_BEGIN
   require_single(h, "complete_update");
+  materialize(h);
   const int tl = (time_level == 0) ? h->previous : h->current;
   Dev &d = h->d;
   const int L = h->g.L;
@@ -807,6 +839,7 @@ extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int curre
   if (!h) fail("null handle");
   if (previous < 0 || previous > 1 || current < 0 || current > 1) fail("set_time_pointers: time levels are 0 or 1");
   if (step_count < 0) fail("set_time_pointers: negative step count");
+  materialize(h);
   h->previous = previous; h->current = current; h->step_count = step_count;
   h->phys_calls = 0;         // idealized_moist_phys_init sets gust = 1 again after a restart
   API_END
@@ -833,6 +866,7 @@ static StepScalars step_scalars(isca_dyn *h) {
   return sc;
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
+  h->in_step = true;
   if (h->cfg.physics == 1) {
     { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream); }
     { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream); }
@@ -896,7 +930,7 @@ static void raw_filter_phase(isca_dyn *h, const StepScalars &sc) {
   Timed t(h, "raw_gradients");
   launch_spec_gradient(g, d, d.ts[sc.fut], d.Si, C, 0, g.L, g.L, h->stream);
   launch_spec_gradient(g, d, d.lnps[sc.fut], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
-  launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, 0, h->cfg.legendre_impl, h->stream);
+  launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, rect_bounds(h), h->cfg.legendre_impl, h->stream);     // (rhomboidal: every n of every wavenumber)
   launch_fft_inverse(g, d, fl, d.Fi_g, h->stream);
 }
 // A 'spectral' tracer's step (update_tracers, spectral_dynamics.F90:1133-1154, with num_steps = 1): the physics tendency, minus the
@@ -923,7 +957,12 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
   dev_s2g(h, d.trxs[sc.fut][e], d.trx[sc.fut][e], g.L, OP_NONE);
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
-  { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+  if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
+    { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
+    h->thermo_pending[sc.fut] = true;
+    if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
+  } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+  h->in_step = false;
   if (h->cfg.raw_filter_coeff != 1.0) raw_filter_phase(h, sc);
   if (h->tracer_on && h->cfg.num_tracers > 1) {
     Timed t(h, "tracers_2_up");
@@ -933,6 +972,10 @@ static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, poi
     }
   }
   if (h->diag_mask) {   // spectral_diagnostics(Time_next, psg(future), ug(future), ...) at the end of atmosphere (atmosphere.F90:344)
+    if (h->lazy_fix) {  // the diagnostics read the stored fields: with them on, the pending corrections are applied every step
+      h->previous = sc.cur; h->current = sc.fut;     // (materialize takes the newest level from the time pointers)
+      Timed t(h, "fixer_materialize"); materialize(h);
+    }
     Timed t(h, "diagnostics"); launch_diag_accumulate(*h, sc.fut, h->stream);
     h->diag_count += 1;
   }
@@ -1240,6 +1283,7 @@ extern "C" int isca_dyn_cold_start(isca_dyn_t *h) {
       spec(g1->d.ts[t], h->d.ts[t], g.L); spec(g1->d.lnps[t], h->d.lnps[t], 1);
     }
     h->previous = 0; h->current = 0; h->step_count = 0; h->have_state = true; h->phys_calls = 0;
+    reset_pending(h);
   } catch (...) { isca_dyn_destroy(g1); throw; }
   isca_dyn_destroy(g1);
   API_END

@@ -19,6 +19,9 @@ struct MoistState;
   } while (0)
 
 constexpr int MAX_FIELDS = 12;
+// grid-tracer buffers of a time level under lazy fixers: materialised; just produced (tr_atm holds it uncorrected, tr is stale);
+// Robert-filtered except for the `future` term (tr holds that, tr_atm the uncorrected unfiltered copy)
+enum TracerState { TR_MAT = 0, TR_NEW = 1, TR_FILT = 2 };
 
 // One batched transform = a list of level-fields.  Grid side: pointers to [nlev][Jl][I] arrays.
 // Column index of (field f, level k, re/im) in the Fourier / spectral work buffers: 2*(off[f]+k)+ri.
@@ -84,7 +87,8 @@ struct Dev {
   double *trx[2][3] = {}, *trx_atm[2][3] = {}, *trxs[2][3] = {}, *wcol_x = nullptr, *ph_dtqx[3] = {};
   double *halo_send, *halo_recv;   // [2 sides][3][L][2][I] tracer halo rows (lo, hi)
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
-  int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit
+  int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit: byte 0 this step, byte 1 the step before, byte 2 ...
+  double *pend;              // [3][4] fixer scalars PENDING on time level 0 / 1 (mass factor, temperature correction, water factor, -); row 2: identity
   double *wcol;              // [5][Jl][I] column sums for the water fixer
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
   double *fv_rcdx, *fv_rdyy, *fv_rcdy, *fv_rdy;              // reciprocals used by the kernels
@@ -150,4 +154,10 @@ struct isca_dyn {
   isca::MoistState *moist = nullptr;   // tables of the moist physics package (physics = 1)
   long phys_calls = 0;              // calls of the physics since create / restart (gust is 1 m/s on the first)
   isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
+  // Lazy fixers: compute_corrections' scalars and the grid tracer's leapfrog_2level_B stay pending on the new level and are applied by
+  // the next steps' kernels as they read it (no pass over the fields at the end of the step); materialised for every host access.
+  bool lazy_fix = false;
+  int tr_state[2] = {0, 0};         // TracerState of the tracer buffers of time level 0 / 1
+  bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
+  bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
 };

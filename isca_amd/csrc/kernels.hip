@@ -22,6 +22,24 @@ __device__ __forceinline__ double2 cscale(double s, double2 a) { return make_dou
 __device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ double2 ctimes_i(double2 a) { return make_double2(-a.y, a.x); }   // cmplx(-aimag, real)
 
+// ---- pending fixer corrections (lazy fixers)
+// The mass / energy / water corrections of compute_corrections (spectral_dynamics.F90:1213-1283) and the `future` term of the grid
+// tracer's Robert filter (leapfrog_2level_B, :1484) can stay PENDING on a time level: the stored fields are the uncorrected ones and every
+// reader applies the level's three scalars (pend[4*tl + 0..2] = mass factor, temperature correction, water factor; row 2 = identity) on
+// the fly.  The products below must round exactly like the stored result of the materialising kernel would, whatever expression they
+// feed, so they are kept out of the compiler's multiply-add contraction.
+constexpr int PEND_FACTOR = 0, PEND_TCORR = 1, PEND_WFAC = 2, PEND_IDENTITY = 8;
+__device__ __forceinline__ double mul_nc(double a, double b) {
+#pragma clang fp contract(off)
+  const double r = a * b;
+  return r;
+}
+// water factor of one value: applied where p_full >= water_correction_limit, i.e. from level `km` (of the column) down
+__device__ __forceinline__ double water_corr(double q, int k, int km, double wfac) { return mul_nc(q, (k >= km) ? wfac : 1.0); }
+// The column kernel keeps, per column, the number of levels above the water-correction limit of the last three steps in one word
+// (byte 0: this step, byte 1: the step before, ...): a pending water factor belongs to the pressures of the step that produced the level.
+__device__ __forceinline__ int kmask_byte(int word, int b) { return (word >> (8 * b)) & 0xff; }
+
 enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP, C_MASK, C_DAMP, C_DAMP_VOR, C_DAMP_DIV, C_COUNT };
 
 // =====================================================================================================
@@ -1046,10 +1064,11 @@ struct ColumnArgs {
   const double *up, *vp, *tp, *psp;        // previous
   const double *vor, *div, *dxT, *dyT, *dxlp, *dylp;
   double *dtu, *dtv, *dtT, *E, *dtlp, *wg_full, *partials, *wg, *psp_copy;
-  int *kmask; double water_limit;
+  int *kmask; const int *kmask_rd; double water_limit;   // kmask: null without the grid tracer; kmask_rd: the same array, always valid
   const double *phu, *phv, *pht;           // tendencies of the physics package when it is not hs_forcing (k_column<CH, true>)
   const double *surf_geop;                 // [Jl][I] lower boundary of the hydrostatic integral (press_and_geopot.F90:331)
   const double *tv;                        // virtual temperature of the current level (k_column<CH, EXT, true>: use_virtual_temperature)
+  const double *pend_c, *pend_p;           // pending fixer scalars of the current / previous level (identity row when nothing is pending)
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1095,7 +1114,9 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   const int jl = col / I;
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
   const int k0 = w * CH, nk = min(CH, L - k0);          // nk >= 1 by construction of NW
-  const double ps = a.ps[c2], psp = a.psp[c2];
+  const double tc_c = a.pend_c[PEND_TCORR], tc_p = a.pend_p[PEND_TCORR];       // T(level) = stored + pending temperature correction
+  const double ps = mul_nc(a.ps[c2], a.pend_c[PEND_FACTOR]), psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
+  const int kmw_old = a.kmask_rd[c2];                   // (always a valid array: no load under a branch)
   const double dx_ps = ps * a.dxlp[c2], dy_ps = ps * a.dylp[c2];
   const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
   const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
@@ -1121,15 +1142,15 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   for (int i = 0; i < CH; ++i) {
     const int k = k0 + (i < nk ? i : 0);
     const size_t q = c2 + (size_t)k * lev;
-    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
+    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q] + tc_c;
     if (VIRT) tvv[VIRT ? i : 0] = a.tv[q];
-    if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q]; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
+    if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q] + tc_p; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
   // neighbours across the chunk boundary for the centred vertical fluxes
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
-  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
-  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
+  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q] + tc_c; }
+  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q] + tc_c; }
 #pragma unroll
   for (int i = 0; i < CH; ++i) {          // mass divergence of the layer (four_in_one :1064-1067)
     const double dp = dpk_r[i] + dbk_r[i] * ps;
@@ -1186,7 +1207,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const int k = k0 + i;
       const size_t q = c2 + (size_t)k * lev;
       const double l_h0 = lph[i], l_h1 = lph[i + 1], l_f = lpf[i];
-      const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q];
+      const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q] + tc_p;
       const double voi = EARLY ? vov[EARLY ? i : 0] : a.vor[q], dxti = EARLY ? dxv[EARLY ? i : 0] : a.dxT[q], dyti = EARLY ? dyv[EARLY ? i : 0] : a.dyT[q];
       const double p_full = exp(l_f);
       double dt_u, dt_v, dt_t;
@@ -1279,7 +1300,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   if (a.kmask && w == 0) {
     int cnt = 0;
     for (int ww = 0; ww < NW; ++ww) cnt += lds_cnt[ww * 64 + tid];
-    a.kmask[c2] = cnt;
+    a.kmask[c2] = (kmw_old << 8) | cnt;
   }
   if (threadIdx.x == 0) {
     double e = 0.0;
@@ -1317,9 +1338,10 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
-  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.psp_copy = d.psp_copy;
+  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.kmask_rd = d.kmask; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
+  a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
@@ -1511,6 +1533,12 @@ struct TracerArgs {
   double *wcol;
   double dx, dt, flux, rdamp, robert;
   double *tr_part;
+  // Lazy fixers (see mul_nc above).  The previous level's tracer is trp + rb * U(cur): the `future` term of its Robert filter
+  // (leapfrog_2level_B) is still to be added, U(cur) = tr_b with the current level's pending water factor; rb = 0 (and tr_b = trp)
+  // when nothing is pending.  tratm_p and tr_cur_rd carry the pending water factors of pend_a / pend_c; ps_cur the mass factor of pend_c.
+  const double *tr_b, *tr_cur_rd;
+  const double *pend_a, *pend_c;
+  double rb;
 };
 
 // tracer_source_sink (hs_forcing.F90:683-724): surface flux into the lowest level, linear sink
@@ -1518,10 +1546,14 @@ __device__ __forceinline__ double tr_source_sink(const TracerArgs &a, const Geom
   const double src = (k == g.L - 1) ? a.flux / (a.dpk[k] + a.dbk[k] * a.ps_cur[c2]) : 0.0;
   return src - a.rdamp * tr_atm;
 }
-__device__ __forceinline__ double tr_q0(const TracerArgs &a, const Geom &g, int k, size_t q, size_t c2) {
-  return a.trp[q] + a.dt * tr_source_sink(a, g, k, c2, a.tratm_p[q]);
+// previous-level tracer and atmosphere_mod's copy with what is pending on them applied (kw: the column's water-mask word)
+__device__ __forceinline__ double tr_prev_of(const TracerArgs &a, int k, int kw, double trp, double trb) {
+  return fma(a.rb, water_corr(trb, k, kmask_byte(kw, 1), a.pend_c[PEND_WFAC]), trp);
 }
-// the same from values already in registers (ps is only used at the lowest level)
+__device__ __forceinline__ double tr_atm_of(const TracerArgs &a, int k, int kw, double tratm) {
+  return water_corr(tratm, k, kmask_byte(kw, 2), a.pend_a[PEND_WFAC]);
+}
+// q0 from values already in registers (ps is only used at the lowest level)
 __device__ __forceinline__ double tr_q0_of(const TracerArgs &a, const Geom &g, int k, double tr_prev, double tr_atm, double ps) {
   const double src = (k == g.L - 1) ? a.flux / (a.dpk[k] + a.dbk[k] * ps) : 0.0;
   return tr_prev + a.dt * (src - a.rdamp * tr_atm);
@@ -1562,7 +1594,8 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
   // already holds q0), then the LDS writes.  A virtual row across a pole is the mirror row seen half-way round the
   // globe (fv_advection.F90:150-164): it is read rotated by I/2, so every later access is at the thread's own i and
   // only q0 and u (gathered at other longitudes) have to live in LDS.
-  double tq[NR], ta[NR], tu[NR], tv[NR];
+  double tq[NR], ta[NR], tu[NR], tv[NR], tb[NR];
+  int kw[NR];
   const size_t fs = (size_t)g.L * 2 * I;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -1572,22 +1605,24 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
     const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
     const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
     loc[r] = jl >= 0 && jl < g.Jl;
-    const size_t q = (size_t)k * lev + (size_t)(loc[r] ? jl : 0) * I + is;
+    const size_t c2r = (size_t)(loc[r] ? jl : 0) * I + is;
+    const size_t q = (size_t)k * lev + c2r;
     const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + is;
     const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
     const double *pq = loc[r] ? a.trp + q : hb + o, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
     tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
+    tb[r] = *(loc[r] ? a.tr_b + q : pq); kw[r] = a.kmask[c2r];                 // what is pending on the previous level (halo rows arrive finished)
   }
   double psr[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {                                                // surface flux only enters the lowest level
     const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
-    psr[r] = (k == g.L - 1 && loc[r]) ? a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + is] : 1.0;
+    psr[r] = (k == g.L - 1 && loc[r]) ? mul_nc(a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + is], a.pend_c[PEND_FACTOR]) : 1.0;
   }
   double q0r[NR], vr[NR];                                                       // own-longitude values stay in registers
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    q0r[r] = loc[r] ? tr_q0_of(a, g, k, tq[r], ta[r], psr[r]) : tq[r];
+    q0r[r] = loc[r] ? tr_q0_of(a, g, k, tr_prev_of(a, k, kw[r], tq[r], tb[r]), tr_atm_of(a, k, kw[r], ta[r]), psr[r]) : tq[r];
     vr[r] = mir[r] ? -tv[r] : tv[r];
     qs[r * I + i] = q0r[r];
     us[r * I + i] = tu[r];
@@ -1676,7 +1711,10 @@ __global__ void k_tracer_pack_halo(Geom g, TracerArgs a) {
   const size_t lev = (size_t)g.Jl * g.I, c2 = (size_t)jl * g.I + i, q = (size_t)k * lev + c2;
   double *dst = side ? a.send_hi : a.send_lo;
   const size_t o = ((size_t)k * 2 + hr) * g.I + i, fs = (size_t)g.L * 2 * g.I;
-  dst[o] = tr_q0(a, g, k, q, c2); dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q];
+  const int kw = a.kmask[c2];
+  const double ps = mul_nc(a.ps_cur[c2], a.pend_c[PEND_FACTOR]);
+  dst[o] = tr_q0_of(a, g, k, tr_prev_of(a, k, kw, a.trp[q], a.tr_b[q]), tr_atm_of(a, k, kw, a.tratm_p[q]), ps);
+  dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q];
 }
 
 // PPM reconstruction of one cell from the column values around it (slope_z :505-568 with limiters, non-linear
@@ -1741,7 +1779,7 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   const size_t lev = (size_t)g.Jl * g.I;
   const size_t c2 = (size_t)blockIdx.x * 64 + tid;
   const int k0 = w * CH, nk = min(CH, L - k0);
-  const double ps = a.ps_cur[c2];
+  const double ps = mul_nc(a.ps_cur[c2], a.pend_c[PEND_FACTOR]);
   constexpr int NV = CH + 8;                     // cells k0-4 .. k0+CH+3
   double rv[NV], dv[NV];
 #pragma unroll
@@ -1758,9 +1796,16 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
 #pragma unroll
   for (int t = 0; t < CH; ++t) {
     const size_t q = (size_t)min(k0 + t, L - 1) * lev + c2;
-    tpv[t] = a.trp[q]; tav[t] = a.tratm_p[q]; tcv[t] = a.tr_cur[q];
+    tpv[t] = a.trp[q]; tav[t] = a.tratm_p[q]; tcv[t] = a.tr_cur_rd[q];
   }
-  const int km = a.kmask[c2];
+  const int kmw = a.kmask[c2], km = kmask_byte(kmw, 0);
+#pragma unroll
+  for (int t = 0; t < CH; ++t) {                 // what is pending on the two older levels (lazy fixers; identities otherwise)
+    const int k = min(k0 + t, L - 1);
+    tcv[t] = water_corr(tcv[t], k, kmask_byte(kmw, 1), a.pend_c[PEND_WFAC]);
+    tpv[t] = fma(a.rb, tcv[t], tpv[t]);
+    tav[t] = tr_atm_of(a, k, kmw, tav[t]);
+  }
   const double psp = a.ps_prev[c2];
   // limited slopes of cells k0-2 .. k0+CH+1 (rv index t+2), once each
   double sl[CH + 4];
@@ -1907,8 +1952,16 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
   a.robert = h.cfg.robert_coeff * h.cfg.raw_filter_coeff;
   a.tr_part = d.tr_part;
+  // pending fixers (identity rows unless lazy_fix): the mass factor on ps(cur), the water factors on the two older tracer levels
+  a.pend_c = d.pend + 4 * sc.cur; a.pend_a = d.pend + 4 * sc.prev;
+  a.tr_b = a.trp; a.tr_cur_rd = a.tr_cur; a.rb = 0.0;
+  if (h.lazy_fix) {
+    a.tr_fut = d.tr_atm[sc.fut];                                            // the new level is kept once, uncorrected, where atmosphere_mod's copy lives
+    if (h.tr_state[sc.cur] == TR_NEW) a.tr_cur_rd = d.tr_atm[sc.cur];       // ... so that is where the current level is read from
+    if (h.tr_state[sc.prev] == TR_FILT) { a.rb = h.cfg.robert_coeff; a.tr_b = d.tr_atm[sc.cur]; }   // leapfrog_2level_B's `a(current) += robert a(future)` of the last step
+  }
   if (h.cfg.physics != 0) {     // sphum / the caller's tracer: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
-    a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0;
+    a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0; a.pend_a = d.pend + PEND_IDENTITY;
   }
   a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + (size_t)3 * h.g.L * 2 * h.g.I;
   a.send_lo = d.halo_send; a.send_hi = d.halo_send + (size_t)3 * h.g.L * 2 * h.g.I;
@@ -1948,6 +2001,7 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     if (h.cfg.tracer_spectral[e + 1]) continue;
     TracerArgs b = a;
     b.trp = h.d.trx[sc.prev][e]; b.tr_cur = h.d.trx[sc.cur][e]; b.tr_fut = h.d.trx[sc.fut][e]; b.wcol = h.d.wcol_x; b.tr_part = nullptr;
+    b.tr_b = b.trp; b.tr_cur_rd = b.tr_cur; b.rb = 0.0; b.pend_a = h.d.pend + PEND_IDENTITY;        // (more than one tracer: the fixers are applied eagerly)
     b.robert = tracer_robert(h, e + 1);
     if (h.cfg.physics == 0) b.tratm_p = h.d.trx_atm[sc.prev][e];              // hs_forcing's source and sink act on every tracer (hs_forcing.F90:248-265)
     else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
@@ -2023,6 +2077,7 @@ void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, con
   TracerArgs a = tracer_args(h, sc);
   a.ua = u; a.va = v; a.trp = q; a.tratm_p = q; a.trh = q_new; a.ps_cur = ps;   // ps only enters the (zero) surface flux
   a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
+  a.tr_b = q; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
   const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
 }
@@ -2033,6 +2088,7 @@ void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const dou
   TracerArgs a = tracer_args(h, sc);
   a.trh = const_cast<double *>(r); a.wg = w; a.ps_cur = ps; a.ps_prev = ps; a.trp = dummy_a; a.tratm_p = dummy_a;
   a.tr_cur = dummy_b; a.tr_fut = r_new; a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
+  a.tr_b = dummy_a; a.tr_cur_rd = dummy_b; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
   launch_tracer_vert_kernel(g, a, s);
 }
 // tracer_source_sink (hs_forcing.F90:683-724) on caller fields: rst += flux/dp at the lowest level - tr/sink
@@ -2186,6 +2242,45 @@ struct FixerArgs {
   double raw;                 // raw_filter_coeff; tr_part: prev - 2 cur of the tracer (RAW filter), null when raw = 1
   const double *tr_part;
 };
+// compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums
+__device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs &a, double &factor, double &tcorr, double &wfac) {
+  factor = 1.0; tcorr = 0.0; wfac = 1.0;
+  const double mean_ps_prev = r_[0] / a.sumw_nlon;
+  const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
+  if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
+  if (a.do_energy) {
+    const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
+    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+  }
+  if (a.do_water && a.tr_fut) {
+    const double nrm = 1.0 / a.sumw_nlon / GRAV;
+    const double water_prev = r_[5] * nrm;
+    const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
+    const double corr = (r_[8] + factor * r_[9]) * nrm;
+    const double notc = water_tmp - corr;
+    if (water_tmp > 0.) {
+      wfac = water_prev / water_tmp;
+      wfac = wfac * (1. + notc / corr) - notc / corr;
+    }
+  }
+}
+// the (0,0) coefficients of ln ps and T follow the grid corrections (:1231, :1241), also on the Robert-filtered `current` level (:1470-1473)
+__device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, double factor, double tcorr) {
+  if (a.ml0 < 0) return;
+  const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
+  const double s2 = sqrt(2.);
+  const int k = threadIdx.x;
+  if (k == 0 && a.do_mass) {
+    const double dl = s2 * log(factor);
+    a.lnps_fut[mn].x += dl;
+    a.lnps_cur[mn].x += a.robert * a.raw * dl;
+  }
+  if (k < g.L && a.do_energy) {
+    const double dtc = s2 * tcorr;
+    a.ts_fut[mn * g.L + k].x += dtc;
+    a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
+  }
+}
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
 // Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
@@ -2197,27 +2292,8 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
   }
-  double factor = 1.0, tcorr = 0.0, wfac = 1.0;
-  {
-    const double mean_ps_prev = r_[0] / a.sumw_nlon;
-    const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
-    if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
-    if (a.do_energy) {
-      const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
-      tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
-    }
-    if (a.do_water && a.tr_fut) {       // compute_corrections :1245-1283 (with mj's correction limit)
-      const double nrm = 1.0 / a.sumw_nlon / GRAV;
-      const double water_prev = r_[5] * nrm;
-      const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
-      const double corr = (r_[8] + factor * r_[9]) * nrm;
-      const double notc = water_tmp - corr;
-      if (water_tmp > 0.) {
-        wfac = water_prev / water_tmp;
-        wfac = wfac * (1. + notc / corr) - notc / corr;
-      }
-    }
-  }
+  double factor, tcorr, wfac;
+  fixer_scalars(r_, a, factor, tcorr, wfac);
   // 32-bit element indices (a 3-D field has < 2^31 elements): the 64-bit i / lev would expand into a branchy routine
   const unsigned lev = (unsigned)(g.Jl * g.I), n3 = lev * (unsigned)g.L;
   const unsigned first = (blockIdx.x * 256u + threadIdx.x) * 2u, stride = gridDim.x * 512u;
@@ -2233,7 +2309,7 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
         kk[u] = (int)(i / lev);
         const unsigned c2 = i - (unsigned)kk[u] * lev;
         fv[u] = *(const double2 *)(a.tr_fut + i); cv[u] = *(const double2 *)(a.tr_cur + i);
-        km0[u] = a.kmask[c2]; km1[u] = a.kmask[c2 + 1];
+        km0[u] = kmask_byte(a.kmask[c2], 0); km1[u] = kmask_byte(a.kmask[c2 + 1], 0);
       }
     }
 #pragma unroll
@@ -2243,9 +2319,8 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
         *(double2 *)(a.tg + i) = make_double2(tv[u].x + tcorr, tv[u].y + tcorr);
         if (a.tr_fut) {   // water factor where p_full >= limit, then leapfrog part B (:1484) and atmosphere_mod's copy (:1028)
           double2 f = fv[u], c = cv[u];
-          if (kk[u] >= km0[u]) f.x *= wfac;
-          if (kk[u] >= km1[u]) f.y *= wfac;
-          c.x += a.robert * a.raw * f.x; c.y += a.robert * a.raw * f.y;
+          f.x = water_corr(f.x, kk[u], km0[u], wfac); f.y = water_corr(f.y, kk[u], km1[u], wfac);
+          c.x = fma(a.robert * a.raw, f.x, c.x); c.y = fma(a.robert * a.raw, f.y, c.y);
           *(double2 *)(a.tratm_fut + i) = f;                  // atmosphere_mod's copy is taken before the filter is completed (:1028)
           if (a.tr_part) {                                    // leapfrog_2level_B's future half (leapfrog.F90:102)
             const double2 pt = *(const double2 *)(a.tr_part + i);
@@ -2257,7 +2332,7 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
     }
   }
   for (unsigned i = first; i < lev; i += stride) {
-    double2 p = *(double2 *)(a.psg + i); p.x *= factor; p.y *= factor; *(double2 *)(a.psg + i) = p;
+    double2 p = *(double2 *)(a.psg + i); p.x = mul_nc(p.x, factor); p.y = mul_nc(p.y, factor); *(double2 *)(a.psg + i) = p;
   }
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) {
@@ -2266,21 +2341,73 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
       // valid_range_t (spectral_dynamics.F90:940): running extremes of the new temperatures since the host last looked
       if (a.reduce_here) { a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx); }
     }
-    if (a.ml0 >= 0) {
-      const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
-      const double s2 = sqrt(2.);
-      const int k = threadIdx.x;
-      if (k == 0 && a.do_mass) {
-        const double dl = s2 * log(factor);
-        a.lnps_fut[mn].x += dl;
-        a.lnps_cur[mn].x += a.robert * a.raw * dl;
-      }
-      if (k < g.L && a.do_energy) {
-        const double dtc = s2 * tcorr;
-        a.ts_fut[mn * g.L + k].x += dtc;
-        a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
-      }
+    fixer_patch_spectral(g, a, factor, tcorr);
+  }
+}
+// Lazy fixers: the same scalars, but nothing is applied to the grid fields -- they are left PENDING on the new time level
+// (pend[4 * fut + 0..2]) and every later reader of that level applies them (k_column, the tracer kernels; k_fixer_materialize
+// for the host).  One block; the (0,0) spectral coefficients are patched here as in k_fixer_apply.
+__global__ __launch_bounds__(256) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
+  __shared__ double sh[4][NRED + 2];
+  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
+  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
+  else {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
+  }
+  double factor, tcorr, wfac;
+  fixer_scalars(r_, a, factor, tcorr, wfac);
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
+    a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
+    if (a.reduce_here) { a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx); }
+    pend_fut[PEND_FACTOR] = factor; pend_fut[PEND_TCORR] = tcorr; pend_fut[PEND_WFAC] = wfac;
+  }
+  fixer_patch_spectral(g, a, factor, tcorr);
+}
+// What is pending on the two time levels, applied in place (before the host reads or writes state, restart files, diagnostics):
+// afterwards tg, psg, tr and tr_atm of both levels hold what the eager k_fixer_apply would have left.
+struct MaterializeArgs {
+  double *tg[2], *psg[2], *tr[2], *tr_atm[2];
+  const double *pend;           // [2][4]
+  const int *kmask;
+  int tstate[2];                // tracer buffers: TR_MAT / TR_NEW / TR_FILT
+  int mbyte[2];                 // byte of the water-mask word that belongs to each buffer
+  int thermo[2];                // mass factor / temperature correction pending on this level
+  double robert;
+};
+__global__ __launch_bounds__(256) void k_fixer_materialize(Geom g, MaterializeArgs a) {
+  const unsigned lev = (unsigned)(g.Jl * g.I), n3 = lev * (unsigned)g.L;
+  const unsigned i = (blockIdx.x * 256u + threadIdx.x) * 2u;
+  if (i >= n3) return;
+  double w[2], tc[2], fac[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { fac[b] = a.pend[4 * b + PEND_FACTOR]; tc[b] = a.pend[4 * b + PEND_TCORR]; w[b] = a.pend[4 * b + PEND_WFAC]; }
+  const int k = (int)(i / lev);
+  const unsigned c2 = i - (unsigned)k * lev;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (a.thermo[b]) {
+      double2 t = *(double2 *)(a.tg[b] + i); t.x += tc[b]; t.y += tc[b]; *(double2 *)(a.tg[b] + i) = t;
+      if (i < lev) { double2 p = *(double2 *)(a.psg[b] + i); p.x = mul_nc(p.x, fac[b]); p.y = mul_nc(p.y, fac[b]); *(double2 *)(a.psg[b] + i) = p; }
     }
+  }
+  if (a.tstate[0] == TR_MAT && a.tstate[1] == TR_MAT) return;
+  const int kw0 = a.kmask[c2], kw1 = a.kmask[c2 + 1];
+  double2 U[2], F[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    U[b] = *(const double2 *)(a.tr_atm[b] + i); F[b] = *(const double2 *)(a.tr[b] + i);
+    if (a.tstate[b] != TR_MAT) {
+      U[b].x = water_corr(U[b].x, k, kmask_byte(kw0, a.mbyte[b]), w[b]); U[b].y = water_corr(U[b].y, k, kmask_byte(kw1, a.mbyte[b]), w[b]);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    if (a.tstate[b] == TR_MAT) continue;
+    double2 f = U[b];                                                       // TR_NEW: the level itself
+    if (a.tstate[b] == TR_FILT) { f.x = fma(a.robert, U[1 - b].x, F[b].x); f.y = fma(a.robert, U[1 - b].y, F[b].y); }
+    *(double2 *)(a.tr_atm[b] + i) = U[b]; *(double2 *)(a.tr[b] + i) = f;
   }
 }
 
@@ -2295,7 +2422,7 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   if (g.P > 1)   // the host all-reduces red[0..9] between the phases
     hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
-void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   const Geom &g = h.g;
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
@@ -2312,9 +2439,32 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   a.sumw_nlon = sumw * g.I;
   a.robert = h.cfg.robert_coeff; a.raw = h.cfg.raw_filter_coeff; a.tr_part = h.d.tr_part;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
+  return a;
+}
+void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  const FixerArgs a = fixer_args(h, sc);
   const size_t n3 = (size_t)g.Jl * g.I * g.L;
   const unsigned nblk = (unsigned)std::min<size_t>(512, (n3 / 2 + 255) / 256);     // every block re-reduces the partials: 512 measured against 256 / 1024 / 2048
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
+}
+void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const FixerArgs a = fixer_args(h, sc);
+  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+}
+// tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)
+void launch_fixer_materialize(const isca_dyn &h, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  MaterializeArgs a;
+  for (int b = 0; b < 2; ++b) {
+    a.tg[b] = d.tg[b]; a.psg[b] = d.psg[b]; a.tr[b] = d.tr[b]; a.tr_atm[b] = d.tr_atm[b];
+    a.tstate[b] = h.tracer_on ? h.tr_state[b] : TR_MAT; a.thermo[b] = h.thermo_pending[b] ? 1 : 0;
+    a.mbyte[b] = (b == h.current) ? 0 : 1;
+  }
+  a.pend = d.pend; a.kmask = d.kmask; a.robert = h.cfg.robert_coeff;
+  const unsigned n3 = (unsigned)(g.Jl * g.I * g.L);
+  hipLaunchKernelGGL(k_fixer_materialize, dim3((n3 / 2 + 255) / 256), dim3(256), 0, s, g, a);
 }
 
 // =====================================================================================================

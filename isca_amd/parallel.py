@@ -130,6 +130,7 @@ class ShardedDynCore(dyncore.DynCore):
                 else:
                     self.native = True
             if why is not None:
+                self.close()       # the device handle and its stream: a failed attempt must not leak them (bench.py retries in the same process)
                 # a silent fall-back would be a silent order-of-magnitude slowdown: torch.distributed between the phases has to be asked for
                 raise dyncore.IscaError(f"native RCCL exchange not available ({why}); set ISCA_COMM=torch to drive the exchanges through "
                                         "torch.distributed between the device phases")

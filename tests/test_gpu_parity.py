@@ -725,6 +725,46 @@ def test_progress_log_line(capsys):
     atm.atmosphere_end()
 
 
+@pytest.mark.parametrize("res,L,ext", [("T21", 25, False), ("T42", 25, False), ("T21", 12, True)])
+def test_lazy_fixers_equal_eager(monkeypatch, res, L, ext):
+    """The fixers' corrections (compute_corrections, spectral_dynamics.F90:1213-1283) and the grid tracer's leapfrog_2level_B (:1484) are
+    left pending on the new level and applied by the next steps' kernels as they read it; ISCA_EAGER_FIXERS=1 applies them with a pass over
+    the fields at the end of the step like the reference does.  Both must give the same state BIT FOR BIT -- also when the host looks at
+    the state in between (materialisation) and with the tendencies of a caller's physics (physics = 2)."""
+    rng = np.random.default_rng(7)
+    kw = dict(physics=2) if ext else {}
+
+    def run(eager, looks):
+        if eager:
+            monkeypatch.setenv("ISCA_EAGER_FIXERS", "1")
+        else:
+            monkeypatch.delenv("ISCA_EAGER_FIXERS", raising=False)
+        dc = make(res, L, **kw)
+        dc.cold_start()
+        tend = [1e-6 * rng.standard_normal((L, dc.Jl, dc.I)) for _ in range(4)] if ext else None
+        done = 0
+        for stop in looks + [24]:
+            if ext:
+                for _ in range(stop - done):
+                    dc.dynamics(tend[0], tend[1], 1e-2 * tend[2], 1e-3 * np.abs(tend[3]))
+            else:
+                dc.step(stop - done)
+            done = stop
+            dc.get("tg"); dc.get("tr", 0)
+        out = {(k, tl): dc.get(k, tl) for k in ALL_STATE for tl in (0, 1)}
+        fx = dc.table("fixer")[16:19]
+        dc.close()
+        return out, fx
+
+    rng = np.random.default_rng(7); lazy, fl = run(False, [])
+    rng = np.random.default_rng(7); lazy_looked, _ = run(False, [1, 2, 7])
+    rng = np.random.default_rng(7); eager, fe = run(True, [])
+    assert np.array_equal(fl, fe) and fe[0] != 1.0 and fe[1] != 0.0 and fe[2] != 1.0      # the corrections are not trivially absent
+    for key in lazy:
+        assert np.array_equal(lazy[key], eager[key]), key
+        assert np.array_equal(lazy_looked[key], eager[key]), key
+
+
 @pytest.mark.parametrize("first", [1, 9])
 def test_restart_is_bit_exact(tmp_path, first):
     """run(N) == run(n1) + atmosphere_end + atmosphere_init(restart) + run(N - n1), bit for bit, through the

@@ -371,6 +371,20 @@ def test_field_table_entries():
                      (text * 2, "at most 4")):
         with pytest.raises(IscaError, match=msg):
             atm.tracers_from_field_table(atm.parse_field_table(bad))
+    # the humidity tracer is found by NAME (nhum = get_tracer_index('sphum' | 'mix_rat')): it must be tracer 1; without one the model is dry
+    grid = '"TRACER", "atmos_mod", "%s"\n "numerical_representation", "grid"\n "advect_vert", "finite_volume_parabolic" /\n'
+    with pytest.raises(IscaError, match="must be the first atmos_mod entry"):
+        atm.tracers_from_field_table(atm.parse_field_table(grid % "age" + grid % "sphum"))
+    keys, names = atm.tracers_from_field_table(atm.parse_field_table(grid % "age"))
+    assert keys["_dry_model"] and keys["initial_sphum"] == 0.0 and keys["use_virtual_temperature"] is False and names == ["age"]
+    keys, _ = atm.tracers_from_field_table(atm.parse_field_table(grid % "mix_rat"))
+    assert "_dry_model" not in keys
+    # a robert_coeff of its own on tracer 1 is compared with the dynamics' effective value: the module default 0.04 when the namelist omits it
+    own = '"TRACER", "atmos_mod", "sphum"\n "numerical_representation", "grid"\n "advect_vert", "finite_volume_parabolic"\n "robert_filter", "on", "robert_coeff=%s" /'
+    with pytest.raises(IscaError, match="robert_coeff of its own"):
+        atm.tracers_from_field_table(atm.parse_field_table(own % "0.05"))
+    atm.tracers_from_field_table(atm.parse_field_table(own % "0.04"))
+    atm.tracers_from_field_table(atm.parse_field_table(own % "0.05"), 0.05)
 
 
 def test_named_vertical_coordinates(golden_dir):
