@@ -26,6 +26,13 @@ extern "C" const char *isca_last_error(void) { return g_last_error.c_str(); }
   return 0;
 
 static void fail(const std::string &m) { throw std::runtime_error(m); }
+static bool getenv_once(const char *name) {          // measurement switches: looked up once per name
+  static std::mutex mu; static std::vector<std::pair<std::string, bool>> seen;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &e : seen) if (e.first == name) return e.second;
+  seen.emplace_back(name, getenv(name) != nullptr);
+  return seen.back().second;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // kernel timing (HIP events on the handle's stream)
@@ -449,7 +456,13 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       }
       if (!d.wcol_x) d.wcol_x = dalloc<double>(h, 5 * ng2);
     }
-    HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    {  // the tracer's side stream; ISCA_TRACER_PRIO=high|low asks for a queue priority other than the main stream's (measurement switch)
+      int lo = 0, hi = 0;
+      const char *pr = getenv("ISCA_TRACER_PRIO");
+      if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
+      else HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
@@ -987,8 +1000,9 @@ static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, poi
 // One step of the latitude-band sharded model with the exchanges issued on the same stream through RCCL:
 // lat -> m all-to-all (transpose_fourier), m -> lat all-to-all (reverse_transpose_fourier), the tracer's 2-row halo
 // exchange (mpp_update_domains in fv_advection) and the all-reduce of the 10 fixer sums.  Nothing returns to the host.
-static void sharded_step(isca_dyn *h) {
-  const StepScalars sc = step_scalars(h);
+static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
+  StepScalars sc = step_scalars(h);
+  sc.store_wg_full = store_wg_full;
   const Geom &g = h->g;
   isca::Comm &c = *h->comm;
   upload_wave_matrices(h, sc.delta_t);
@@ -1015,8 +1029,12 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   if (h->cfg.physics == 2 && nsteps != 0)
     fail("isca_dyn_step: physics = 2 has no physics of its own: hand the tendencies to isca_dyn_dynamics, one call per step");
   for (int i = 0; i < nsteps; ++i) {
-    if (h->g.P > 1) { sharded_step(h); continue; }
-    const StepScalars sc = step_scalars(h);
+    // wg_full (omega) is an output only: the last step of the call stores it, and every step while a diagnostic of omega accumulates
+    // (or the moist package runs, whose restart and diagnostics see it too)
+    const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->cfg.physics == 1 || getenv_once("ISCA_ALWAYS_WG_FULL");
+    if (h->g.P > 1) { sharded_step(h, store_wg); continue; }
+    StepScalars sc = step_scalars(h);
+    sc.store_wg_full = store_wg;
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }

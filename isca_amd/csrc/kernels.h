@@ -8,6 +8,7 @@ struct StepScalars {      // per-step scalars passed by value to kernels
   double delta_t;         // dt or 2 dt
   double xi;              // alpha_implicit * delta_t
   int prev, cur, fut;
+  int store_wg_full = 1;   // 0: a step inside a run of steps of one isca_dyn_step call, whose omega nobody can read (and no diagnostic wants)
   int keep_spec_tend = 0;  // k_spec_update also stores dt_vors, dt_divs, dt_ts, dt_ln_ps (locals of spectral_dynamics; kept for the phase-by-phase API's get_state)
 };
 

@@ -1069,6 +1069,7 @@ struct ColumnArgs {
   const double *surf_geop;                 // [Jl][I] lower boundary of the hydrostatic integral (press_and_geopot.F90:331)
   const double *tv;                        // virtual temperature of the current level (k_column<CH, EXT, true>: use_virtual_temperature)
   const double *pend_c, *pend_p;           // pending fixer scalars of the current / previous level (identity row when nothing is pending)
+  int store_wg_full;                       // wg_full (omega; a diagnostic and restart field) is only stored by steps after which the host can look
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
       const double x5 = x4 - uc * x2 - vc * x3;
       dt_t = dt_t - KAPPA * tvc * x5;
-      a.wg_full[q] = -x5 * p_full;
+      if (a.store_wg_full) a.wg_full[q] = -x5 * p_full;
       nbelow += (p_full < a.water_limit) ? 1 : 0;
       dmean_tot = dmean_tot + dm[i];
       const double wg_n = (k + 1 < L) ? (-dmean_tot + total * bk_r[i + 1]) : 0.0;
@@ -1342,6 +1343,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.water_limit = h.cfg.water_correction_limit;
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
+  a.store_wg_full = sc.store_wg_full;
   const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
   const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
@@ -2192,11 +2194,24 @@ __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, c
 #pragma unroll
   for (int c = 0; c < NRED; ++c) acc[c] = 0.;
   double mn = INFINITY, mx = -INFINITY;
-  for (int i = threadIdx.x; i < nb; i += 256) {
-    acc[0] += pprev[2 * i]; acc[1] += pprev[2 * i + 1];
+  // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
+  // one memory round trip per four sets instead of one per set, the same sums bit for bit
+  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
+    double v[4][NRED + 2];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[2 + c] += pfut[NPART * i + c];
-    mn = fmin(mn, pfut[NPART * i + 8]); mx = fmax(mx, pfut[NPART * i + 9]);
+    for (int r = 0; r < 4; ++r) {
+      const int i = min(i0 + 256 * r, nb - 1);
+      v[r][0] = pprev[2 * i]; v[r][1] = pprev[2 * i + 1];
+#pragma unroll
+      for (int c = 0; c < NPART; ++c) v[r][2 + c] = pfut[NPART * i + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (i0 + 256 * r < nb) {
+#pragma unroll
+        for (int c = 0; c < NRED; ++c) acc[c] += v[r][c];
+        mn = fmin(mn, v[r][NRED]); mx = fmax(mx, v[r][NRED + 1]);
+      }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

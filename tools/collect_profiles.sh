@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for profiles/ on the GPU box (usage: bash tools/collect_profiles.sh [round-tag, default r02]):
+# Collect the rocprofv3 evidence for profiles/ on the GPU box (usage: bash tools/collect_profiles.sh [round-tag]):
 #   1. kernel trace + stats of the headline bench command (T85L40), of the T170L60 workload and of the moist (Frierson) configuration
 #   2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE; SQ wave/wait/VALU/MFMA counters) with --kernel-trace only, T85L40 and T170L60
 # Outputs land in gpurun_out/prof_final/<workload>/ ; tools/summarize_profiles.py turns them into small files, tools/publish_profiles.sh
