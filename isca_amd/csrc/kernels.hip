@@ -2119,84 +2119,19 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
 constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
-__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
-                                                    const double *__restrict__ t, const double *__restrict__ psg,
-                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH,
-                                                    const double *__restrict__ wcol) {
-  __shared__ double sred[4][8];
-  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
-  const int col = blockIdx.x * 64 + tid;
-  const int jl = col / g.I;
-  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
-  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
-  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
-    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
-  }
-  const double wgt = wts[jl], ps = psg[c2];
-  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
-    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
-    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
-  }
-  double sa = 0.0, sb = 0.0;
-  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
-  bool nan = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i < nk) {
-      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
-      sa += e * dpk[k0 + i];
-      sb += e * dbk[k0 + i];
-      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
-      nan = nan || !(tt[i] == tt[i]);
-    }
-  }
-  if (nan) tmx = INFINITY;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
-    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
-  }
-  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
-  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    s0 += __shfl_down(s0, off, 64);
-    s1 += __shfl_down(s1, off, 64);
-    s2 += __shfl_down(s2, off, 64);
-  }
-  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
-  __syncthreads();
-  if (w == 0) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
-      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
-    }
-  }
-  if (threadIdx.x == 0) {
-    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
-    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
-    double *p = partials + NPART * (size_t)blockIdx.x;
-    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
-  }
-}
 // Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
 // strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
 // the totals.  Deterministic and identical in every block that calls it.
-__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+__device__ __forceinline__ void fixer_totals(const double *pprev, const double *pfut, int nb,
                                              double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
+  const bool active = threadIdx.x < 256;           // a larger block: its first four wavefronts do the sums, in the order a 256-thread block does
   double acc[NRED];
 #pragma unroll
   for (int c = 0; c < NRED; ++c) acc[c] = 0.;
   double mn = INFINITY, mx = -INFINITY;
   // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
   // one memory round trip per four sets instead of one per set, the same sums bit for bit
-  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
+  for (int i0 = threadIdx.x; active && i0 < nb; i0 += 4 * 256) {
     double v[4][NRED + 2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -2219,7 +2154,7 @@ __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, c
     for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
     mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
   }
-  if ((threadIdx.x & 63) == 0) {
+  if (active && (threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
     sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
@@ -2294,6 +2229,112 @@ __device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerA
     const double dtc = s2 * tcorr;
     a.ts_fut[mn * g.L + k].x += dtc;
     a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
+  }
+}
+// TAIL (lazy fixers on one rank): the block that finishes last also does what k_fixer_finish does -- totals of all block partials in
+// the fixed order, compute_corrections' scalars left pending on the new level, the (0,0) spectral patch -- so the step needs no further
+// launch between the sums and the next column kernel.  Hand-off between workgroups on different XCDs (whose L2s are not coherent):
+// every block publishes its partials with write-through (agent-scope relaxed atomic) stores, drains them, and draws a ticket; the
+// block with the last ticket makes one agent-scope acquire and reads the partials with plain loads.
+struct FixerTail { FixerArgs fa; double *pend_fut; unsigned *ticket; };
+template <bool TAIL>
+__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ t, const double *__restrict__ psg,
+                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                                    const double *__restrict__ wts, double *partials, int CH,
+                                                    const double *__restrict__ wcol, FixerTail tail) {
+  __shared__ double sred[4][8];
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int col = blockIdx.x * 64 + tid;
+  const int jl = col / g.I;
+  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
+  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
+  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
+    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
+  }
+  const double wgt = wts[jl], ps = psg[c2];
+  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
+    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
+  }
+  double sa = 0.0, sb = 0.0;
+  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nk) {
+      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
+      sa += e * dpk[k0 + i];
+      sb += e * dbk[k0 + i];
+      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
+      nan = nan || !(tt[i] == tt[i]);
+    }
+  }
+  if (nan) tmx = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
+    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
+  }
+  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
+  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
+    }
+  }
+  if (threadIdx.x == 0) {
+    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
+    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
+    double *p = partials + NPART * (size_t)blockIdx.x;
+    const double pv[NPART] = {s0, a1, a2, t0, t1, t2, t3, t4, bmn, bmx};
+#pragma unroll
+    for (int c = 0; c < NPART; ++c) {
+      if (TAIL) __hip_atomic_store(p + c, pv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through
+      else p[c] = pv[c];
+    }
+  }
+  if constexpr (TAIL) {
+    __shared__ int s_last;
+    __shared__ double sh[4][NRED + 2];
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my partials have left before the ticket is drawn
+      const unsigned tk = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (tk == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *tail.ticket = 0u;                                           // for the next launch
+    }
+    __syncthreads();
+    const FixerArgs &a = tail.fa;
+    double r_[NRED], tmn, tmx;
+    fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
+    double factor, tcorr, wfac;
+    fixer_scalars(r_, a, factor, tcorr, wfac);
+    if (threadIdx.x == 0) {
+      for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
+      a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
+      a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx);
+      tail.pend_fut[PEND_FACTOR] = factor; tail.pend_fut[PEND_TCORR] = tcorr; tail.pend_fut[PEND_WFAC] = wfac;
+    }
+    fixer_patch_spectral(g, a, factor, tcorr);
   }
 }
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
@@ -2426,14 +2467,29 @@ __global__ __launch_bounds__(256) void k_fixer_materialize(Geom g, MaterializeAr
   }
 }
 
-void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
+static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc);
+// true when k_fixer_sums' last block can do k_fixer_finish's work: lazy fixers, one rank, at least four wavefronts per block
+bool fixer_sums_has_tail(const isca_dyn &h) {
+  static const bool off = getenv("ISCA_NO_FIXER_TAIL") != nullptr;       // measurement switch: the separate k_fixer_finish launch
+  const int CH = (h.g.L + 7) / 8, NW = (h.g.L + CH - 1) / CH;
+  return h.lazy_fix && h.g.P == 1 && NW >= 4 && !off;
+}
+void launch_fixer_sums(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
+  const int fut = sc.fut;
   const int nb = (int)column_partials_count(h);
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
-                     h.tracer_on ? d.wcol : (const double *)nullptr);
+  FixerTail tail{};
+  if (fixer_sums_has_tail(h)) {
+    tail.fa = fixer_args(h, sc); tail.pend_fut = d.pend + 4 * sc.fut; tail.ticket = d.ticket;
+    hipLaunchKernelGGL(k_fixer_sums<true>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
+                       h.tracer_on ? d.wcol : (const double *)nullptr, tail);
+    return;
+  }
+  hipLaunchKernelGGL(k_fixer_sums<false>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
+                     h.tracer_on ? d.wcol : (const double *)nullptr, tail);
   if (g.P > 1)   // the host all-reduces red[0..9] between the phases
     hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
