@@ -444,7 +444,6 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
     d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
     d.pend = dupload(h, std::vector<double>(PEND_ROWS, PEND_ROWS + 12));
-    d.ticket = dalloc<unsigned>(h, 4);
     for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
       for (int t = 0; t < 2; ++t) {
         d.trx[t][e] = dalloc<double>(h, ng3); d.trx_atm[t][e] = dalloc<double>(h, ng3);
@@ -537,7 +536,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) - (fixer_sums_has_tail(*h) ? 1 : 0);
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -925,7 +924,7 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
   if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc, h->stream); }
+  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
 // raw_filter_coeff /= 1: the reference completes the filter of the NEW level after its grid fields have been synthesised
 // (complete_robert_filter, spectral_dynamics.F90:1031), so u, v, T, ps, vor, div of that level stay those of the unadjusted spectral
@@ -972,7 +971,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-    if (!fixer_sums_has_tail(*h)) { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }     // else: done by the last block of k_fixer_sums
+    { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
     h->thermo_pending[sc.fut] = true;
     if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
   } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }

@@ -88,7 +88,6 @@ struct Dev {
   double *halo_send, *halo_recv;   // [2 sides][3][L][2][I] tracer halo rows (lo, hi)
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit: byte 0 this step, byte 1 the step before, byte 2 ...
-  unsigned *ticket = nullptr; // arrival counter of k_fixer_sums' blocks (zero between launches)
   double *pend;              // [3][4] fixer scalars PENDING on time level 0 / 1 (mass factor, temperature correction, water factor, -); row 2: identity
   double *wcol;              // [5][Jl][I] column sums for the water fixer
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)

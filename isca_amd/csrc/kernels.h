@@ -75,8 +75,7 @@ void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipSt
 void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s);
 void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s);
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
-void launch_fixer_sums(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R1: partial sums over the local band (+ R2 in its last block: fixer_sums_has_tail)
-bool fixer_sums_has_tail(const isca_dyn &h);
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s);  // R2 with lazy fixers: reduce + scalars, left pending on the new level
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s);                    // apply what is pending on both time levels in place

@@ -1565,19 +1565,38 @@ __device__ __forceinline__ double vl_limit(double slope, double qm, double q0, d
   return copysign(1.0, slope) * fmin(fmin(fabs(slope), 2.0 * (q0 - q_min)), 2.0 * (q_max - q0));
 }
 
+// Values of the lanes to the left / right (longitude i -+ 1) without LDS storage: a DPP wavefront shift, and for the first / last lane
+// of a wavefront the neighbouring wavefront's edge value through a small LDS array (periodic in longitude: the block is one row).
+__device__ __forceinline__ double dpp_from_left(double v) {    // lane l receives lane l-1 (lane 0: undefined)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);      // wave_shr:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_from_right(double v) {   // lane l receives lane l+1 (lane 63: undefined)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);      // wave_shl:1
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // one block = RB consecutive latitude rows of one level, one thread per longitude (lon_max = 2^p; single rank:
 // all rows are local).  RB+4 source rows are staged once (q0, u, q + semi_x(q)), RB+2 rows of v.
+// LDS holds only what is gathered at a data-dependent longitude (q0 of the source rows for semi_x, q2 and its slope for the van Leer
+// x flux): 10 rows of lon_max doubles, 40 KB at lon_max = 512, so that a block fits beside the persistent FFT blocks of the main stream
+// (with u and the flux row also in LDS it was 78 KB and found no room while they ran: 554 us next to the main stream at T170L60
+// against 152 us alone).
 constexpr int TR_RB = 4;
+constexpr int TR_LDS_ROWS = TR_RB + 4 + 2;
 __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TR_RB, NR = RB + 4;
   const int I = g.I, J = g.J, IM = I - 1;
   double *qs = (double *)smem;        // [NR][I] q0 of virtual rows j0-2..j0+RB+1 (rows across a pole already rotated by I/2)
-  double *us = qs + NR * I;           // [NR][I] u of those rows
-  double *q2 = us + NR * I;           // [I]
+  double *q2 = qs + NR * I;           // [I]
   double *sx = q2 + I;                // [I]
-  double *fl = sx + I;                // [I]
   __shared__ int any_big[RB];
+  __shared__ double edge_first[2 * RB][8], edge_last[RB][8];      // lane 0 / lane 63 values of every wavefront: u of the RB rows; the x flux
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  const int wl = (wv + nwv - 1) % nwv, wr = (wv + 1) % nwv;        // wavefronts holding longitudes i - 1 of my lane 0 / i + 1 of my lane 63
   // Workgroups go round-robin over the 8 XCDs; neighbouring row blocks share 4 of their 8 source rows, so the tile index is
   // permuted to give each XCD (= each L2) a contiguous run of row blocks (whole levels) instead of every eighth one.
   int tbx = blockIdx.x, tby = blockIdx.y;
@@ -1627,7 +1646,11 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
     q0r[r] = loc[r] ? tr_q0_of(a, g, k, tr_prev_of(a, k, kw[r], tq[r], tb[r]), tr_atm_of(a, k, kw[r], ta[r]), psr[r]) : tq[r];
     vr[r] = mir[r] ? -tv[r] : tv[r];
     qs[r * I + i] = q0r[r];
-    us[r * I + i] = tu[r];
+  }
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr) {
+    if (lane == 0) edge_first[rr][wv] = tu[rr + 2];
+    if (lane == 63) edge_last[rr][wv] = tu[rr + 2];
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
@@ -1646,8 +1669,11 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RB; ++rr) {   // u at the cell faces, Courant numbers of the x fluxes, block-wide flag for the integer part
     const int r = rr + 2;
-    ucl[rr] = 0.5 * (us[r * I + im] + tu[r]);
-    ucr[rr] = 0.5 * (tu[r] + us[r * I + ip]);
+    double u_l = dpp_from_left(tu[r]), u_r = dpp_from_right(tu[r]);
+    if (lane == 0) u_l = edge_last[rr][wl];
+    if (lane == 63) u_r = edge_first[rr][wr];
+    ucl[rr] = 0.5 * (u_l + tu[r]);
+    ucr[rr] = 0.5 * (tu[r] + u_r);
     bx[rr] = ucl[rr] * a.dt * a.rcdx[j0 + rr];
     if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
   }
@@ -1679,10 +1705,13 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
     {
       const double bb = b - trunc(b);
       const int ii = (i - 1 - (int)floor(b)) & IM;
-      fl[i] = fxi + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
+      const double fl_i = fxi + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
+      double fl_r = dpp_from_right(fl_i);                 // the flux through the face at i + 1
+      if (lane == 0) edge_first[RB + rr][wv] = fl_i;
+      __syncthreads();
+      if (lane == 63) fl_r = edge_first[RB + rr][wr];
+      dq = dq - (fl_r - fl_i) * (1.0 / a.dt);
     }
-    __syncthreads();
-    dq = dq - (fl[ip] - fl[i]) * (1.0 / a.dt);
     {  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
       double sl[3];
 #pragma unroll
@@ -1994,7 +2023,7 @@ static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStr
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   TracerArgs a = tracer_args(h, sc);
-  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
+  const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
   launch_tracer_vert_kernel(g, a, s);
   // further 'grid' tracers of the field_table (update_tracers' loop, spectral_dynamics.F90:1132,1155-1180): the same transport, their own
@@ -2080,7 +2109,7 @@ void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, con
   a.ua = u; a.va = v; a.trp = q; a.tratm_p = q; a.trh = q_new; a.ps_cur = ps;   // ps only enters the (zero) surface flux
   a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
   a.tr_b = q; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
-  const size_t ldsh = (size_t)(2 * (TR_RB + 4) + 3) * g.I * sizeof(double);
+  const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
   hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
 }
 void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
@@ -2119,19 +2148,84 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
 constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
+__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ t, const double *__restrict__ psg,
+                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH,
+                                                    const double *__restrict__ wcol) {
+  __shared__ double sred[4][8];
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int col = blockIdx.x * 64 + tid;
+  const int jl = col / g.I;
+  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
+  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
+  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
+    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
+  }
+  const double wgt = wts[jl], ps = psg[c2];
+  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
+    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
+  }
+  double sa = 0.0, sb = 0.0;
+  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nk) {
+      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
+      sa += e * dpk[k0 + i];
+      sb += e * dbk[k0 + i];
+      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
+      nan = nan || !(tt[i] == tt[i]);
+    }
+  }
+  if (nan) tmx = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
+    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
+  }
+  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
+  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
+    }
+  }
+  if (threadIdx.x == 0) {
+    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
+    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
+    double *p = partials + NPART * (size_t)blockIdx.x;
+    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
+  }
+}
 // Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
 // strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
 // the totals.  Deterministic and identical in every block that calls it.
-__device__ __forceinline__ void fixer_totals(const double *pprev, const double *pfut, int nb,
+__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
                                              double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
-  const bool active = threadIdx.x < 256;           // a larger block: its first four wavefronts do the sums, in the order a 256-thread block does
   double acc[NRED];
 #pragma unroll
   for (int c = 0; c < NRED; ++c) acc[c] = 0.;
   double mn = INFINITY, mx = -INFINITY;
   // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
   // one memory round trip per four sets instead of one per set, the same sums bit for bit
-  for (int i0 = threadIdx.x; active && i0 < nb; i0 += 4 * 256) {
+  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
     double v[4][NRED + 2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -2154,7 +2248,7 @@ __device__ __forceinline__ void fixer_totals(const double *pprev, const double *
     for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
     mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
   }
-  if (active && (threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
     sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
@@ -2229,112 +2323,6 @@ __device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerA
     const double dtc = s2 * tcorr;
     a.ts_fut[mn * g.L + k].x += dtc;
     a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
-  }
-}
-// TAIL (lazy fixers on one rank): the block that finishes last also does what k_fixer_finish does -- totals of all block partials in
-// the fixed order, compute_corrections' scalars left pending on the new level, the (0,0) spectral patch -- so the step needs no further
-// launch between the sums and the next column kernel.  Hand-off between workgroups on different XCDs (whose L2s are not coherent):
-// every block publishes its partials with write-through (agent-scope relaxed atomic) stores, drains them, and draws a ticket; the
-// block with the last ticket makes one agent-scope acquire and reads the partials with plain loads.
-struct FixerTail { FixerArgs fa; double *pend_fut; unsigned *ticket; };
-template <bool TAIL>
-__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
-                                                    const double *__restrict__ t, const double *__restrict__ psg,
-                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                                    const double *__restrict__ wts, double *partials, int CH,
-                                                    const double *__restrict__ wcol, FixerTail tail) {
-  __shared__ double sred[4][8];
-  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
-  const int col = blockIdx.x * 64 + tid;
-  const int jl = col / g.I;
-  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
-  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
-  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
-    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
-  }
-  const double wgt = wts[jl], ps = psg[c2];
-  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
-    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
-    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
-  }
-  double sa = 0.0, sb = 0.0;
-  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
-  bool nan = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i < nk) {
-      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
-      sa += e * dpk[k0 + i];
-      sb += e * dbk[k0 + i];
-      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
-      nan = nan || !(tt[i] == tt[i]);
-    }
-  }
-  if (nan) tmx = INFINITY;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
-    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
-  }
-  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
-  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    s0 += __shfl_down(s0, off, 64);
-    s1 += __shfl_down(s1, off, 64);
-    s2 += __shfl_down(s2, off, 64);
-  }
-  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
-  __syncthreads();
-  if (w == 0) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
-      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
-    }
-  }
-  if (threadIdx.x == 0) {
-    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
-    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
-    double *p = partials + NPART * (size_t)blockIdx.x;
-    const double pv[NPART] = {s0, a1, a2, t0, t1, t2, t3, t4, bmn, bmx};
-#pragma unroll
-    for (int c = 0; c < NPART; ++c) {
-      if (TAIL) __hip_atomic_store(p + c, pv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through
-      else p[c] = pv[c];
-    }
-  }
-  if constexpr (TAIL) {
-    __shared__ int s_last;
-    __shared__ double sh[4][NRED + 2];
-    if (threadIdx.x == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my partials have left before the ticket is drawn
-      const unsigned tk = __hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (tk == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      *tail.ticket = 0u;                                           // for the next launch
-    }
-    __syncthreads();
-    const FixerArgs &a = tail.fa;
-    double r_[NRED], tmn, tmx;
-    fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
-    double factor, tcorr, wfac;
-    fixer_scalars(r_, a, factor, tcorr, wfac);
-    if (threadIdx.x == 0) {
-      for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
-      a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
-      a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx);
-      tail.pend_fut[PEND_FACTOR] = factor; tail.pend_fut[PEND_TCORR] = tcorr; tail.pend_fut[PEND_WFAC] = wfac;
-    }
-    fixer_patch_spectral(g, a, factor, tcorr);
   }
 }
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
@@ -2467,29 +2455,14 @@ __global__ __launch_bounds__(256) void k_fixer_materialize(Geom g, MaterializeAr
   }
 }
 
-static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc);
-// true when k_fixer_sums' last block can do k_fixer_finish's work: lazy fixers, one rank, at least four wavefronts per block
-bool fixer_sums_has_tail(const isca_dyn &h) {
-  static const bool off = getenv("ISCA_NO_FIXER_TAIL") != nullptr;       // measurement switch: the separate k_fixer_finish launch
-  const int CH = (h.g.L + 7) / 8, NW = (h.g.L + CH - 1) / CH;
-  return h.lazy_fix && h.g.P == 1 && NW >= 4 && !off;
-}
-void launch_fixer_sums(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
-  const int fut = sc.fut;
   const int nb = (int)column_partials_count(h);
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-  FixerTail tail{};
-  if (fixer_sums_has_tail(h)) {
-    tail.fa = fixer_args(h, sc); tail.pend_fut = d.pend + 4 * sc.fut; tail.ticket = d.ticket;
-    hipLaunchKernelGGL(k_fixer_sums<true>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
-                       h.tracer_on ? d.wcol : (const double *)nullptr, tail);
-    return;
-  }
-  hipLaunchKernelGGL(k_fixer_sums<false>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
-                     h.tracer_on ? d.wcol : (const double *)nullptr, tail);
+  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
+                     h.tracer_on ? d.wcol : (const double *)nullptr);
   if (g.P > 1)   // the host all-reduces red[0..9] between the phases
     hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
