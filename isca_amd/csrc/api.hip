@@ -247,8 +247,6 @@ extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
-  if (h->ev_sums) hipEventDestroy(h->ev_sums);
-  if (h->ev_finish) hipEventDestroy(h->ev_finish);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return 0;
@@ -438,7 +436,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (g.P == 1) { d.Ff_s = d.Ff_g; d.Fi_g = d.Fi_s; }
     else { d.Ff_s = dalloc<double>(h, nF); d.Fi_g = dalloc<double>(h, nF); }
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
-    d.partials = dalloc<double>(h, 14 * (ng2 / 64 + 1));     // [2][2 nb] of the column kernel (double-buffered) + [10 nb] of k_fixer_sums
+    d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
@@ -538,12 +536,6 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    {  // the column kernel reduces the fixers' block partials itself when its first four wavefronts exist (fixer_totals' 256-thread order)
-      const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-      h->col_reduce = h->lazy_fix && g.P == 1 && NW >= 4 && getenv("ISCA_NO_COL_REDUCE") == nullptr;
-    }
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_sums, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_finish, hipEventDisableTiming));
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
@@ -886,23 +878,14 @@ static StepScalars step_scalars(isca_dyn *h) {
   sc.xi = sc.delta_t * h->cfg.alpha_implicit;
   return sc;
 }
-// k_fixer_finish of the last step may still be running on the side stream (col_reduce): everything ordered after this on the main
-// stream sees its results (pending scalars, (0,0) spectral patch, red[])
-static void join_finish(isca_dyn *h) {
-  if (!h->finish_inflight) return;
-  HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_finish, 0));
-  h->finish_inflight = false;
-}
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   h->in_step = true;
-  h->col_parity ^= 1;
   if (h->cfg.physics == 1) {
     { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream); }
     { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream); }
     h->phys_calls++;
   }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
-  join_finish(h);       // (long done by the time the column kernel ends: the wait is free, and covers every later reader)
   if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
     if (h->g.P > 1) {
       Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // the tracer itself runs once the halo rows are in
@@ -988,13 +971,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
 }
 static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
   if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-    if (h->col_reduce) {   // beside the next column kernel, which derives the two scalars it needs itself
-      HIP_CHECK(hipEventRecord(h->ev_sums, h->stream));
-      HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_sums, 0));
-      { Timed t(h, "fixer_finish", h->stream2); launch_fixer_finish(*h, sc, h->stream2); }
-      HIP_CHECK(hipEventRecord(h->ev_finish, h->stream2));
-      h->finish_inflight = true;
-    } else { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
+    { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
     h->thermo_pending[sc.fut] = true;
     if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
   } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
@@ -1010,7 +987,6 @@ static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, poi
   if (h->diag_mask) {   // spectral_diagnostics(Time_next, psg(future), ug(future), ...) at the end of atmosphere (atmosphere.F90:344)
     if (h->lazy_fix) {  // the diagnostics read the stored fields: with them on, the pending corrections are applied every step
       h->previous = sc.cur; h->current = sc.fut;     // (materialize takes the newest level from the time pointers)
-      join_finish(h);
       Timed t(h, "fixer_materialize"); materialize(h);
     }
     Timed t(h, "diagnostics"); launch_diag_accumulate(*h, sc.fut, h->stream);
@@ -1062,7 +1038,6 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }
-  join_finish(h);
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_valid_range(h);
@@ -1111,7 +1086,6 @@ extern "C" int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const doubl
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }
-  join_finish(h);
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_valid_range(h);
@@ -1243,7 +1217,7 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
     case 0: upload_wave_matrices(h, sc.delta_t); phase0(h, sc); break;
     case 1: phase1(h, sc); break;
     case 2: phase2(h, sc); break;
-    case 3: phase3(h, sc); join_finish(h); break;
+    case 3: phase3(h, sc); break;
     case 4: phase_tracer(h, sc); break;
     default: fail("invalid phase");
   }

@@ -160,10 +160,4 @@ struct isca_dyn {
   int tr_state[2] = {0, 0};         // TracerState of the tracer buffers of time level 0 / 1
   bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
   bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
-  // ... and with col_reduce the next column kernel derives the scalars it needs itself (ColumnArgs::own_scalars) while k_fixer_finish
-  // runs on the side stream
-  bool col_reduce = false;
-  int col_parity = 0;               // which half of the column kernel's block partials this step writes
-  bool finish_inflight = false;     // k_fixer_finish launched on stream2 and not yet waited for by the main stream
-  hipEvent_t ev_sums = nullptr, ev_finish = nullptr;
 };

@@ -1051,81 +1051,6 @@ void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s) {
                      (const double2 *)h.d.lnps[tl], h.d.Si, h.Ci);
 }
 
-// ---- global sums of the fixers, shared by the column kernel (lazy fixers: it derives the scalars of the level it reads itself) and the
-// fixer kernels further down
-constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
-constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
-// Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
-// strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
-// the totals.  Deterministic and identical in every block that calls it.
-__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                             double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
-  double acc[NRED];
-#pragma unroll
-  for (int c = 0; c < NRED; ++c) acc[c] = 0.;
-  double mn = INFINITY, mx = -INFINITY;
-  // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
-  // one memory round trip per four sets instead of one per set, the same sums bit for bit
-  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
-    double v[4][NRED + 2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = min(i0 + 256 * r, nb - 1);
-      v[r][0] = pprev[2 * i]; v[r][1] = pprev[2 * i + 1];
-#pragma unroll
-      for (int c = 0; c < NPART; ++c) v[r][2 + c] = pfut[NPART * i + c];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (i0 + 256 * r < nb) {
-#pragma unroll
-        for (int c = 0; c < NRED; ++c) acc[c] += v[r][c];
-        mn = fmin(mn, v[r][NRED]); mx = fmax(mx, v[r][NRED + 1]);
-      }
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
-    mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
-    sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < NRED; ++c) tot[c] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
-  tmin = fmin(fmin(sh[0][NRED], sh[1][NRED]), fmin(sh[2][NRED], sh[3][NRED]));
-  tmax = fmax(fmax(sh[0][NRED + 1], sh[1][NRED + 1]), fmax(sh[2][NRED + 1], sh[3][NRED + 1]));
-}
-// compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums.  Several kernels
-// evaluate this for the same sums and must get the same bits: no multiply-add contraction, whatever the surrounding code.
-__device__ __forceinline__ void fixer_scalars_of(const double *r_, double sumw_nlon, int do_mass, int do_energy, int do_water,
-                                                 double &factor, double &tcorr, double &wfac) {
-#pragma clang fp contract(off)
-  factor = 1.0; tcorr = 0.0; wfac = 1.0;
-  const double mean_ps_prev = r_[0] / sumw_nlon;
-  const double mean_en_prev = r_[1] / sumw_nlon / GRAV;
-  if (do_mass) factor = mean_ps_prev / (r_[2] / sumw_nlon);
-  if (do_energy) {
-    const double mean_en_tmp = (r_[3] + factor * r_[4]) / sumw_nlon / GRAV;
-    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
-  }
-  if (do_water) {
-    const double nrm = 1.0 / sumw_nlon / GRAV;
-    const double water_prev = r_[5] * nrm;
-    const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
-    const double corr = (r_[8] + factor * r_[9]) * nrm;
-    const double notc = water_tmp - corr;
-    if (water_tmp > 0.) {
-      wfac = water_prev / water_tmp;
-      wfac = wfac * (1. + notc / corr) - notc / corr;
-    }
-  }
-}
-
 // =====================================================================================================
 // Grid-point column kernel: hs_forcing (hs_forcing.F90:148-272) at the PREVIOUS level with CURRENT
 // pressures (atmosphere.F90:304-311), pressure_variables (press_and_geopot.F90:152-221), four_in_one
@@ -1145,12 +1070,6 @@ struct ColumnArgs {
   const double *tv;                        // virtual temperature of the current level (k_column<CH, EXT, true>: use_virtual_temperature)
   const double *pend_c, *pend_p;           // pending fixer scalars of the current / previous level (identity row when nothing is pending)
   int store_wg_full;                       // wg_full (omega; a diagnostic and restart field) is only stored by steps after which the host can look
-  // own_scalars (lazy fixers, one rank): the fixer scalars pending on the current level are derived here, from the block partials the last
-  // step's kernels left, instead of being read from pend_c -- the kernel that writes them there (k_fixer_finish) then runs beside this one
-  // on the side stream and the step has no launch between the fixer sums and the next column kernel on its critical path
-  int own_scalars, fix_nb, fix_do_mass, fix_do_energy;
-  const double *fix_pprev, *fix_pfut;
-  double fix_sumw_nlon;
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1196,15 +1115,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   const int jl = col / I;
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
   const int k0 = w * CH, nk = min(CH, L - k0);          // nk >= 1 by construction of NW
-  double tc_c = a.pend_c[PEND_TCORR], fac_c = a.pend_c[PEND_FACTOR];           // T(level) = stored + pending temperature correction
-  const double tc_p = a.pend_p[PEND_TCORR];
-  if (a.own_scalars) {
-    __shared__ double fsh[4][NRED + 2];
-    double r_[NRED], tmn_, tmx_, wf_;
-    fixer_totals(a.fix_pprev, a.fix_pfut, a.fix_nb, fsh, r_, tmn_, tmx_);
-    fixer_scalars_of(r_, a.fix_sumw_nlon, a.fix_do_mass, a.fix_do_energy, 0, fac_c, tc_c, wf_);
-  }
-  const double ps = mul_nc(a.ps[c2], fac_c), psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
+  const double tc_c = a.pend_c[PEND_TCORR], tc_p = a.pend_p[PEND_TCORR];       // T(level) = stored + pending temperature correction
+  const double ps = mul_nc(a.ps[c2], a.pend_c[PEND_FACTOR]), psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
   const int kmw_old = a.kmask_rd[c2];                   // (always a valid array: no load under a branch)
   const double dx_ps = ps * a.dxlp[c2], dy_ps = ps * a.dylp[c2];
   const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
@@ -1421,12 +1333,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.psp = d.psg[sc.prev];
   a.vor = d.vorg; a.div = d.divg; a.dxT = d.dxT; a.dyT = d.dyT; a.dxlp = d.dxlp; a.dylp = d.dylp;
   a.dtu = d.g_dtu; a.dtv = d.g_dtv; a.dtT = d.g_dtT; a.E = d.g_E; a.dtlp = d.g_dtlp; a.wg_full = d.wg_full;
-  const size_t nbc = column_partials_count(h);
-  a.partials = d.partials + 2 * nbc * h.col_parity;       // double-buffered: other blocks may still be reading the last step's (own_scalars)
-  a.own_scalars = (h.col_reduce && h.thermo_pending[sc.cur]) ? 1 : 0;
-  a.fix_pprev = d.partials + 2 * nbc * (1 - h.col_parity); a.fix_pfut = d.partials + 4 * nbc; a.fix_nb = (int)nbc;
-  a.fix_do_mass = h.cfg.do_mass_correction; a.fix_do_energy = h.cfg.do_energy_correction;
-  { double sumw = 0.0; for (double w : h.tab.wts_lat) sumw += w; a.fix_sumw_nlon = sumw * g.I; }
+  a.partials = d.partials;
   a.pk = d.pk; a.bk = d.bk; a.dpk = d.dpk; a.dbk = d.dbk; a.cosm = d.cosm_lat_l; a.coriolis = d.coriolis_l;
   a.rad_lat = d.rad_lat_l; a.wts = d.wts_lat_l;
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
@@ -2239,6 +2146,8 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 //   red[16] mass_correction_factor, red[17] temperature_correction, red[18] water_correction_factor
 // =====================================================================================================
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
+constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
+constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
@@ -2305,6 +2214,51 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
   }
 }
+// Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
+// strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
+// the totals.  Deterministic and identical in every block that calls it.
+__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                             double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
+  double acc[NRED];
+#pragma unroll
+  for (int c = 0; c < NRED; ++c) acc[c] = 0.;
+  double mn = INFINITY, mx = -INFINITY;
+  // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
+  // one memory round trip per four sets instead of one per set, the same sums bit for bit
+  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
+    double v[4][NRED + 2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = min(i0 + 256 * r, nb - 1);
+      v[r][0] = pprev[2 * i]; v[r][1] = pprev[2 * i + 1];
+#pragma unroll
+      for (int c = 0; c < NPART; ++c) v[r][2 + c] = pfut[NPART * i + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (i0 + 256 * r < nb) {
+#pragma unroll
+        for (int c = 0; c < NRED; ++c) acc[c] += v[r][c];
+        mn = fmin(mn, v[r][NRED]); mx = fmax(mx, v[r][NRED + 1]);
+      }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+    mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
+    sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NRED; ++c) tot[c] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
+  tmin = fmin(fmin(sh[0][NRED], sh[1][NRED]), fmin(sh[2][NRED], sh[3][NRED]));
+  tmax = fmax(fmax(sh[0][NRED + 1], sh[1][NRED + 1]), fmax(sh[2][NRED + 1], sh[3][NRED + 1]));
+}
 // red[0..9] <- totals, for the host all-reduce between the phases when world_size > 1
 __global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
                                                       double *__restrict__ red) {
@@ -2332,8 +2286,27 @@ struct FixerArgs {
   double raw;                 // raw_filter_coeff; tr_part: prev - 2 cur of the tracer (RAW filter), null when raw = 1
   const double *tr_part;
 };
+// compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums
 __device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs &a, double &factor, double &tcorr, double &wfac) {
-  fixer_scalars_of(r_, a.sumw_nlon, a.do_mass, a.do_energy, a.do_water && a.tr_fut, factor, tcorr, wfac);
+  factor = 1.0; tcorr = 0.0; wfac = 1.0;
+  const double mean_ps_prev = r_[0] / a.sumw_nlon;
+  const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
+  if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
+  if (a.do_energy) {
+    const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
+    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+  }
+  if (a.do_water && a.tr_fut) {
+    const double nrm = 1.0 / a.sumw_nlon / GRAV;
+    const double water_prev = r_[5] * nrm;
+    const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
+    const double corr = (r_[8] + factor * r_[9]) * nrm;
+    const double notc = water_tmp - corr;
+    if (water_tmp > 0.) {
+      wfac = water_prev / water_tmp;
+      wfac = wfac * (1. + notc / corr) - notc / corr;
+    }
+  }
 }
 // the (0,0) coefficients of ln ps and T follow the grid corrections (:1231, :1241), also on the Robert-filtered `current` level (:1470-1473)
 __device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, double factor, double tcorr) {
@@ -2486,18 +2459,18 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
   const int nb = (int)column_partials_count(h);
-  double *p2 = d.partials + 4 * (size_t)nb;
+  double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
   hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
                      h.tracer_on ? d.wcol : (const double *)nullptr);
   if (g.P > 1)   // the host all-reduces red[0..9] between the phases
-    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials + 2 * (size_t)nb * h.col_parity, p2, nb, d.red);
+    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
 }
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   const Geom &g = h.g;
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
-  a.red = h.d.red; a.pprev = h.d.partials + 2 * (size_t)nb * h.col_parity; a.pfut = h.d.partials + 4 * (size_t)nb; a.nb = nb;
+  a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
   a.reduce_here = (g.P == 1);
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
