@@ -1595,8 +1595,9 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
   double *sx = q2 + I;                // [I]
   __shared__ int any_big[RB];
   __shared__ double edge_first[2 * RB][8], edge_last[RB][8];      // lane 0 / lane 63 values of every wavefront: u of the RB rows; the x flux
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-  const int wl = (wv + nwv - 1) % nwv, wr = (wv + 1) % nwv;        // wavefronts holding longitudes i - 1 of my lane 0 / i + 1 of my lane 63
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+  const int last = min(63, I - 1);                                  // a row shorter than a wavefront (lon_max = 32): its last lane
+  const int wl = (wv + nwv - 1) % nwv, wr = (wv + 1) % nwv;        // wavefronts holding longitudes i - 1 of my lane 0 / i + 1 of my last lane
   // Workgroups go round-robin over the 8 XCDs; neighbouring row blocks share 4 of their 8 source rows, so the tile index is
   // permuted to give each XCD (= each L2) a contiguous run of row blocks (whole levels) instead of every eighth one.
   int tbx = blockIdx.x, tby = blockIdx.y;
@@ -1650,7 +1651,7 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
 #pragma unroll
   for (int rr = 0; rr < RB; ++rr) {
     if (lane == 0) edge_first[rr][wv] = tu[rr + 2];
-    if (lane == 63) edge_last[rr][wv] = tu[rr + 2];
+    if (lane == last) edge_last[rr][wv] = tu[rr + 2];
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
@@ -1671,7 +1672,7 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
     const int r = rr + 2;
     double u_l = dpp_from_left(tu[r]), u_r = dpp_from_right(tu[r]);
     if (lane == 0) u_l = edge_last[rr][wl];
-    if (lane == 63) u_r = edge_first[rr][wr];
+    if (lane == last) u_r = edge_first[rr][wr];
     ucl[rr] = 0.5 * (u_l + tu[r]);
     ucr[rr] = 0.5 * (tu[r] + u_r);
     bx[rr] = ucl[rr] * a.dt * a.rcdx[j0 + rr];
@@ -1709,7 +1710,7 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
       double fl_r = dpp_from_right(fl_i);                 // the flux through the face at i + 1
       if (lane == 0) edge_first[RB + rr][wv] = fl_i;
       __syncthreads();
-      if (lane == 63) fl_r = edge_first[RB + rr][wr];
+      if (lane == last) fl_r = edge_first[RB + rr][wr];
       dq = dq - (fl_r - fl_i) * (1.0 / a.dt);
     }
     {  // vanleer_sphere (:268-304) on q1 with slope_sphere (:546-565)
@@ -2214,57 +2215,46 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
   }
 }
-// Sum of the block partials (2 per block from the column kernel, 8 per block from k_fixer_sums) in a fixed order:
-// strided per-thread sums, wavefront butterflies, then the 4 wavefront results through LDS.  All 256 threads return
-// the totals.  Deterministic and identical in every block that calls it.
+// Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from
+// k_fixer_sums) by ONE block of NT threads, in a fixed order.  Lane layout: value c = t & 15 (0..1 the column kernel's sums, 2..9
+// k_fixer_sums', 10 min, 11 max), group g = t >> 4: a thread folds the sets g, g + NT/16, ... of its value with eight loads in flight,
+// the four groups of a wavefront meet in two shuffles, the wavefronts in LDS.  (The first version had every thread fold all twelve
+// values of its sets and needed 72 cross-lane steps per wavefront: 5-7 us, the larger part of k_fixer_finish.)
+template <int NT>
 __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                             double (*sh)[NRED + 2], double *tot, double &tmin, double &tmax) {
-  double acc[NRED];
+                                             double (*sh)[16], double *tot, double &tmin, double &tmax) {
+  constexpr int NG = NT / 16, NWV = NT / 64;
+  const int t = threadIdx.x, c = t & 15, g = t >> 4, cc = min(c, NRED + 1);
+  const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
+  const int st = cc < 2 ? 2 : NPART;
+  auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
+  double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
+  for (int i0 = g; i0 < nb; i0 += 8 * NG) {
+    double v[8];
 #pragma unroll
-  for (int c = 0; c < NRED; ++c) acc[c] = 0.;
-  double mn = INFINITY, mx = -INFINITY;
-  // four of a thread's strided sets are requested together (clamped addresses) and then added in the order of the plain loop:
-  // one memory round trip per four sets instead of one per set, the same sums bit for bit
-  for (int i0 = threadIdx.x; i0 < nb; i0 += 4 * 256) {
-    double v[4][NRED + 2];
+    for (int r = 0; r < 8; ++r) v[r] = p0[(size_t)st * min(i0 + NG * r, nb - 1)];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = min(i0 + 256 * r, nb - 1);
-      v[r][0] = pprev[2 * i]; v[r][1] = pprev[2 * i + 1];
-#pragma unroll
-      for (int c = 0; c < NPART; ++c) v[r][2 + c] = pfut[NPART * i + c];
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (i0 + 256 * r < nb) {
-#pragma unroll
-        for (int c = 0; c < NRED; ++c) acc[c] += v[r][c];
-        mn = fmin(mn, v[r][NRED]); mx = fmax(mx, v[r][NRED + 1]);
-      }
+    for (int r = 0; r < 8; ++r)
+      if (i0 + NG * r < nb) acc = fold(acc, v[r]);
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-    for (int c = 0; c < NRED; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
-    mn = fmin(mn, __shfl_xor(mn, off, 64)); mx = fmax(mx, __shfl_xor(mx, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int c = 0; c < NRED; ++c) sh[threadIdx.x >> 6][c] = acc[c];
-    sh[threadIdx.x >> 6][NRED] = mn; sh[threadIdx.x >> 6][NRED + 1] = mx;
-  }
+  acc = fold(acc, __shfl_xor(acc, 16, 64));
+  acc = fold(acc, __shfl_xor(acc, 32, 64));
+  if ((t & 63) < 16) sh[t >> 6][c] = acc;
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < NRED; ++c) tot[c] = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
-  tmin = fmin(fmin(sh[0][NRED], sh[1][NRED]), fmin(sh[2][NRED], sh[3][NRED]));
-  tmax = fmax(fmax(sh[0][NRED + 1], sh[1][NRED + 1]), fmax(sh[2][NRED + 1], sh[3][NRED + 1]));
+  for (int k = 0; k < NRED + 2; ++k) {
+    double x = sh[0][k];
+    for (int w = 1; w < NWV; ++w) x = k < NRED ? x + sh[w][k] : (k == NRED ? fmin(x, sh[w][k]) : fmax(x, sh[w][k]));
+    if (k < NRED) tot[k] = x; else if (k == NRED) tmin = x; else tmax = x;
+  }
 }
-// red[0..9] <- totals, for the host all-reduce between the phases when world_size > 1
-__global__ __launch_bounds__(256) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                                      double *__restrict__ red) {
-  __shared__ double sh[4][NRED + 2];
+// red[0..9] <- totals: for the all-reduce between the phases when world_size > 1, and for k_fixer_apply (the eager path)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                     double *__restrict__ red) {
+  __shared__ double sh[NT / 64][16];
   double tot[NRED], tmn, tmx;
-  fixer_totals(pprev, pfut, nb, sh, tot, tmn, tmx);
+  fixer_totals<NT>(pprev, pfut, nb, sh, tot, tmn, tmx);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) red[c] = tot[c];
@@ -2288,6 +2278,7 @@ struct FixerArgs {
 };
 // compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums
 __device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs &a, double &factor, double &tcorr, double &wfac) {
+#pragma clang fp contract(off)      // k_fixer_apply and k_fixer_finish must get the same bits from the same sums
   factor = 1.0; tcorr = 0.0; wfac = 1.0;
   const double mean_ps_prev = r_[0] / a.sumw_nlon;
   const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
@@ -2309,33 +2300,40 @@ __device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs 
   }
 }
 // the (0,0) coefficients of ln ps and T follow the grid corrections (:1231, :1241), also on the Robert-filtered `current` level (:1470-1473)
-__device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, double factor, double tcorr) {
-  if (a.ml0 < 0) return;
+// (two halves: the coefficients are requested before the scalars are known, so that only their stores follow the reduction)
+struct SpecPatch { double lf, lc, tf, tc; };
+__device__ __forceinline__ SpecPatch fixer_patch_load(const Geom &g, const FixerArgs &a) {
+  SpecPatch p = {0., 0., 0., 0.};
+  if (a.ml0 < 0) return p;
   const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
+  const int k = min((int)threadIdx.x, g.L - 1);
+  p.lf = a.lnps_fut[mn].x; p.lc = a.lnps_cur[mn].x; p.tf = a.ts_fut[mn * g.L + k].x; p.tc = a.ts_cur[mn * g.L + k].x;
+  return p;
+}
+__device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, const SpecPatch &p, double factor, double tcorr) {
+  if (a.ml0 < 0) return;
+  const size_t mn = (size_t)a.ml0 * g.N1;
   const double s2 = sqrt(2.);
   const int k = threadIdx.x;
   if (k == 0 && a.do_mass) {
     const double dl = s2 * log(factor);
-    a.lnps_fut[mn].x += dl;
-    a.lnps_cur[mn].x += a.robert * a.raw * dl;
+    a.lnps_fut[mn].x = p.lf + dl;
+    a.lnps_cur[mn].x = p.lc + a.robert * a.raw * dl;
   }
   if (k < g.L && a.do_energy) {
     const double dtc = s2 * tcorr;
-    a.ts_fut[mn * g.L + k].x += dtc;
-    a.ts_cur[mn * g.L + k].x += a.robert * a.raw * dtc;
+    a.ts_fut[mn * g.L + k].x = p.tf + dtc;
+    a.ts_cur[mn * g.L + k].x = p.tc + a.robert * a.raw * dtc;
   }
 }
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
 // Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
 __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
-  __shared__ double sh[4][NRED + 2];
-  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
-  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
-  else {
+  double r_[NRED];
 #pragma unroll
-    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
-  }
+  for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
+  const SpecPatch sp = (blockIdx.x == 0) ? fixer_patch_load(g, a) : SpecPatch{0., 0., 0., 0.};
   double factor, tcorr, wfac;
   fixer_scalars(r_, a, factor, tcorr, wfac);
   // 32-bit element indices (a 3-D field has < 2^31 elements): the 64-bit i / lev would expand into a branchy routine
@@ -2379,22 +2377,20 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
     double2 p = *(double2 *)(a.psg + i); p.x = mul_nc(p.x, factor); p.y = mul_nc(p.y, factor); *(double2 *)(a.psg + i) = p;
   }
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) {
-      for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
-      a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
-      // valid_range_t (spectral_dynamics.F90:940): running extremes of the new temperatures since the host last looked
-      if (a.reduce_here) { a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx); }
-    }
-    fixer_patch_spectral(g, a, factor, tcorr);
+    if (threadIdx.x == 0) { a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac; }
+    fixer_patch_spectral(g, a, sp, factor, tcorr);
   }
 }
 // Lazy fixers: the same scalars, but nothing is applied to the grid fields -- they are left PENDING on the new time level
 // (pend[4 * fut + 0..2]) and every later reader of that level applies them (k_column, the tracer kernels; k_fixer_materialize
 // for the host).  One block; the (0,0) spectral coefficients are patched here as in k_fixer_apply.
-__global__ __launch_bounds__(256) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
-  __shared__ double sh[4][NRED + 2];
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
+  __shared__ double sh[NT / 64][16];
   double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
-  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
+  const SpecPatch sp = fixer_patch_load(g, a);
+  const double mn_old = a.red[20], mx_old = a.red[21];
+  if (a.reduce_here) fixer_totals<NT>(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
   else {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
@@ -2404,10 +2400,10 @@ __global__ __launch_bounds__(256) void k_fixer_finish(Geom g, FixerArgs a, doubl
   if (threadIdx.x == 0) {
     for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
     a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
-    if (a.reduce_here) { a.red[20] = fmin(a.red[20], tmn); a.red[21] = fmax(a.red[21], tmx); }
+    if (a.reduce_here) { a.red[20] = fmin(mn_old, tmn); a.red[21] = fmax(mx_old, tmx); }
     pend_fut[PEND_FACTOR] = factor; pend_fut[PEND_TCORR] = tcorr; pend_fut[PEND_WFAC] = wfac;
   }
-  fixer_patch_spectral(g, a, factor, tcorr);
+  fixer_patch_spectral(g, a, sp, factor, tcorr);
 }
 // What is pending on the two time levels, applied in place (before the host reads or writes state, restart files, diagnostics):
 // afterwards tg, psg, tr and tr_atm of both levels hold what the eager k_fixer_apply would have left.
@@ -2463,15 +2459,19 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
   hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
                      h.tracer_on ? d.wcol : (const double *)nullptr);
-  if (g.P > 1)   // the host all-reduces red[0..9] between the phases
-    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
+  // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
+  // on one rank k_fixer_finish folds them itself
+  if (g.P > 1 || !h.lazy_fix) {
+    if (nb > 512) hipLaunchKernelGGL(k_fixer_reduce<1024>, dim3(1), dim3(1024), 0, s, d.partials, p2, nb, d.red);
+    else hipLaunchKernelGGL(k_fixer_reduce<256>, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
+  }
 }
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   const Geom &g = h.g;
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
   a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
-  a.reduce_here = (g.P == 1);
+  a.reduce_here = (g.P == 1 && h.lazy_fix);      // k_fixer_finish folds the partials itself; otherwise k_fixer_reduce (+ the all-reduce) left red[0..9]
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
   a.psg = h.d.psg[sc.fut]; a.tg = h.d.tg[sc.fut];
@@ -2489,12 +2489,13 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   const Geom &g = h.g;
   const FixerArgs a = fixer_args(h, sc);
   const size_t n3 = (size_t)g.Jl * g.I * g.L;
-  const unsigned nblk = (unsigned)std::min<size_t>(512, (n3 / 2 + 255) / 256);     // every block re-reduces the partials: 512 measured against 256 / 1024 / 2048
+  const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const FixerArgs a = fixer_args(h, sc);
-  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+  if (a.nb > 512) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+  else hipLaunchKernelGGL(k_fixer_finish<256>, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
 }
 // tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s) {
