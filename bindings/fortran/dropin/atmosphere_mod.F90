@@ -1,0 +1,84 @@
+! atmosphere_mod -- the reference's driver interface (atmos_spectral/driver/solo/atmosphere.F90:78: atmosphere_init, atmosphere,
+! atmosphere_end, atmosphere_domain) with the whole step on the device: atmosphere(Time) is ONE call of isca_dyn_step -- hs_forcing (or,
+! with atmosphere_nml: idealized_moist_model, the Frierson column chain), spectral_dynamics, the pressures and heights of the new level --
+! and nothing crosses PCIe.  The main program (atmos_solo/atmos_model.F90:115-142) calls these four names and nothing else of the core.
+!
+! Restart files are written and read by the Python host mirror (isca_amd/restart.py, the reference's variable set in netCDF-3); from
+! Fortran the model cold-starts (this image has no netCDF for fms_io).
+module atmosphere_mod
+
+#ifdef INTERNAL_FILE_NML
+use mpp_mod, only: input_nml_file
+#else
+use fms_mod, only: open_namelist_file
+#endif
+use iso_c_binding
+use fms_mod,            only: error_mesg, FATAL, check_nml_error, close_file
+use time_manager_mod,   only: time_type
+use field_manager_mod,  only: MODEL_ATMOS
+use tracer_manager_mod, only: get_number_tracers
+use mpp_domains_mod,    only: domain2d, mpp_define_domains
+use tracer_type_mod,    only: tracer_type
+use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics_end
+use isca_dyn_c
+use isca_dropin_mod
+
+implicit none
+private
+public :: atmosphere_init, atmosphere, atmosphere_end, atmosphere_domain
+
+logical :: idealized_moist_model = .false.
+namelist /atmosphere_nml/ idealized_moist_model
+
+type(tracer_type), allocatable, dimension(:) :: tracer_attributes
+logical :: module_is_initialized = .false.
+logical :: dry_model
+integer :: nhum
+
+contains
+
+subroutine atmosphere_init(Time_init, Time, Time_step_in)
+type(time_type), intent(in) :: Time_init, Time, Time_step_in
+integer :: io, ierr, unit, num_tracers
+if(module_is_initialized) return
+#ifdef INTERNAL_FILE_NML
+read(input_nml_file, nml=atmosphere_nml, iostat=io)
+ierr = check_nml_error(io, 'atmosphere_nml')
+#else
+unit = open_namelist_file()
+ierr = 1
+do while(ierr /= 0)
+  read(unit, nml=atmosphere_nml, iostat=io, end=20)
+  ierr = check_nml_error(io, 'atmosphere_nml')
+enddo
+20 call close_file(unit)
+#endif
+if(idealized_moist_model) call error_mesg('atmosphere_init','idealized_moist_model: create the core with physics = 1 and the '// &
+  'idealized_moist_phys namelists through isca_dyn_config%moist (bindings/fortran/drive_frierson.F90); this front end runs hs_forcing', FATAL)
+call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
+allocate(tracer_attributes(num_tracers))
+dropin_physics = 0                   ! hs_forcing inside the device step (atmosphere.F90:304-311)
+call spectral_dynamics_init(Time, Time_step_in, tracer_attributes, dry_model, nhum)
+module_is_initialized = .true.
+end subroutine atmosphere_init
+
+subroutine atmosphere(Time)
+type(time_type), intent(in) :: Time
+if(.not. module_is_initialized) call error_mesg('atmosphere','atmosphere module is not initialized', FATAL)
+call chk(isca_dyn_step(core, 1_c_int, 1_c_int), 'atmosphere')
+end subroutine atmosphere
+
+subroutine atmosphere_end
+if(.not. module_is_initialized) return
+call spectral_dynamics_end(tracer_attributes)
+deallocate(tracer_attributes)
+module_is_initialized = .false.
+end subroutine atmosphere_end
+
+subroutine atmosphere_domain(Domain)
+type(domain2d), intent(inout) :: Domain
+call need_core('atmosphere_domain')
+call mpp_define_domains((/1, nlon, 1, nlat/), (/1, 1/), Domain)      ! one process holds the whole grid; the GPUs' bands are the library's
+end subroutine atmosphere_domain
+
+end module atmosphere_mod

@@ -1,0 +1,407 @@
+! spectral_dynamics_mod -- the reference's module name and public procedures (atmos_spectral/model/spectral_dynamics.F90:95-98) in front
+! of the MI355X core: spectral_dynamics_init reads the reference's namelists and field_table and creates the device core
+! (isca_dyn_create, physics = 2: the host keeps its physics package), spectral_dynamics is isca_dyn_dynamics followed by the copies
+! the reference returns to its caller (spectral_dynamics.F90:780-795, :1023-1028).
+!
+! Not here: restart files (fms_io / netCDF; the Python host mirror isca_amd/restart.py writes and reads them), topography options
+! other than 'flat', vert_coord_option other than 'even_sigma' / 'uneven_sigma', initial_state_option other than 'quiescent'.  Each is
+! refused with error_mesg(..., FATAL) naming the option.
+module spectral_dynamics_mod
+
+#ifdef INTERNAL_FILE_NML
+use mpp_mod, only: input_nml_file
+#else
+use fms_mod, only: open_namelist_file
+#endif
+use iso_c_binding
+use fms_mod,            only: error_mesg, FATAL, NOTE, check_nml_error, mpp_pe, mpp_root_pe, stdlog, lowercase, uppercase, close_file
+use constants_mod,      only: radius, omega
+use time_manager_mod,   only: time_type, get_time
+use field_manager_mod,  only: MODEL_ATMOS, parse
+use tracer_manager_mod, only: get_number_tracers, get_tracer_names, query_method, get_tracer_index, NO_TRACER
+use tracer_type_mod,    only: tracer_type
+use isca_dyn_c
+use isca_dropin_mod
+
+implicit none
+private
+
+public :: spectral_dynamics_init, spectral_dynamics, spectral_dynamics_end, get_num_levels
+public :: get_use_virtual_temperature, get_reference_sea_level_press, get_surf_geopotential
+public :: get_pk_bk, complete_robert_filter, complete_update_of_future
+public :: get_axis_id, spectral_diagnostics, get_initial_fields
+
+character(len=8), parameter :: default_advect_vert = 'second_centered', default_representation = 'spectral', default_hole_filling = 'off'
+
+! ---- spectral_dynamics_nml: the reference's variables and defaults (spectral_dynamics.F90:152-224)
+logical :: do_mass_correction = .true., do_water_correction = .true., do_energy_correction = .true., use_virtual_temperature = .false., &
+           use_implicit = .true., triang_trunc = .true., graceful_shutdown = .false., make_symmetric = .false.
+integer :: damping_order = 2, damping_order_vor = -1, damping_order_div = -1, cutoff_wn = 15, lon_max = 128, lat_max = 64, &
+           num_fourier = 42, num_spherical = 43, fourier_inc = 1, num_levels = 18, num_steps = 1
+integer, dimension(2) :: print_interval = (/1, 0/)
+character(len=64) :: vert_coord_option = 'even_sigma', damping_option = 'resolution_dependent', vert_advect_uv = default_advect_vert, &
+                     vert_advect_t = default_advect_vert, vert_difference_option = 'simmons_and_burridge', initial_state_option = 'quiescent'
+real :: damping_coeff = 1.15740741e-4, damping_coeff_vor = -1., damping_coeff_div = -1., eddy_sponge_coeff = 0., zmu_sponge_coeff = 0., &
+        zmv_sponge_coeff = 0., robert_coeff = .04, alpha_implicit = .5, longitude_origin = 0., scale_heights = 4., surf_res = .1, &
+        p_press = .1, p_sigma = .3, exponent = 2.5, ocean_topog_smoothing = .93, initial_sphum = 0.0, reference_sea_level_press = 101325., &
+        water_correction_limit = 0.0, raw_filter_coeff = 1.0
+logical :: json_logging = .false.
+real, dimension(2) :: valid_range_t = (/100., 500./)
+namelist /spectral_dynamics_nml/ use_virtual_temperature, damping_option, cutoff_wn, damping_order, damping_coeff, damping_order_vor,  &
+                                 damping_coeff_vor, damping_order_div, damping_coeff_div, do_mass_correction, do_water_correction,     &
+                                 do_energy_correction, vert_advect_uv, vert_advect_t, use_implicit, longitude_origin, robert_coeff,     &
+                                 alpha_implicit, vert_difference_option, reference_sea_level_press, lon_max, lat_max, num_levels,       &
+                                 num_fourier, num_spherical, fourier_inc, triang_trunc, vert_coord_option, scale_heights, surf_res,     &
+                                 p_press, p_sigma, exponent, ocean_topog_smoothing, initial_sphum, valid_range_t, eddy_sponge_coeff,    &
+                                 zmu_sponge_coeff, zmv_sponge_coeff, print_interval, num_steps, initial_state_option,                  &
+                                 water_correction_limit, raw_filter_coeff, graceful_shutdown, json_logging, make_symmetric
+
+! ---- spectral_init_cond_nml (init/spectral_init_cond.F90:68-74)
+real :: initial_temperature = 264.
+character(len=64) :: topography_option = 'flat', topog_file_name = 'topography.data.nc', topog_field_name = 'zsurf'
+character(len=256) :: land_field_name = 'land_mask'
+namelist /spectral_init_cond_nml/ initial_temperature, topography_option, topog_file_name, topog_field_name, land_field_name
+
+! ---- hs_forcing_nml (atmos_param/hs_forcing/hs_forcing.F90:76-122): the library takes the Held-Suarez parameters when the core is
+! created, so they are read here, ahead of hs_forcing_init
+logical :: no_forcing = .false., do_conserve_energy = .true., relax_to_specified_wind = .false.
+real :: t_zero = 315., t_strat = 200., delh = 60., delv = 10., eps = 0., sigma_b = 0.7, P00 = 1.e5, p_trop = 1.e4, alpha = 2./7, ka = -40., &
+        ks = -4., kf = -1., trflux = 1.e-5, trsink = -4., local_heating_srfamp = 0.0, local_heating_xwidth = 10., local_heating_ywidth = 10., &
+        local_heating_xcenter = 180., local_heating_ycenter = 45., local_heating_vert_decay = 1.e4, peri_time = 0.25, smaxis = 1.5e6, &
+        albedo = 0.3, lapse = 6.5, h_a = 2, tau_s = 5, heat_capacity = 4.2e6, ml_depth = 1, spinup_time = 10800., orbital_period = 365.25
+character(len=256) :: local_heating_option = '', local_heating_file = '', u_wind_file = 'u', v_wind_file = 'v', &
+                      equilibrium_t_option = 'Held_Suarez', equilibrium_t_file = 'temp', stratosphere_t_option = 'extend_tp'
+namelist /hs_forcing_nml/ no_forcing, t_zero, t_strat, delh, delv, eps, sigma_b, ka, ks, kf, do_conserve_energy, trflux, trsink,        &
+                          local_heating_srfamp, local_heating_xwidth, local_heating_ywidth, local_heating_xcenter, local_heating_ycenter, &
+                          local_heating_vert_decay, local_heating_option, local_heating_file, relax_to_specified_wind, u_wind_file,     &
+                          v_wind_file, equilibrium_t_option, equilibrium_t_file, p_trop, alpha, peri_time, smaxis, albedo, lapse, h_a,  &
+                          tau_s, orbital_period, heat_capacity, ml_depth, spinup_time, stratosphere_t_option, P00
+
+logical :: module_is_initialized = .false.
+logical :: dry_model
+integer :: nhum, num_tracers
+real :: dt_real
+
+contains
+
+!===============================================================================================
+subroutine read_nml(which)
+  character(len=*), intent(in) :: which
+  integer :: io, ierr, unit
+#ifdef INTERNAL_FILE_NML
+  if(which == 'dyn') read(input_nml_file, nml=spectral_dynamics_nml, iostat=io)
+  if(which == 'ini') read(input_nml_file, nml=spectral_init_cond_nml, iostat=io)
+  if(which == 'hs')  read(input_nml_file, nml=hs_forcing_nml, iostat=io)
+  if(which == 'dyn') ierr = check_nml_error(io, 'spectral_dynamics_nml')
+  if(which == 'ini') ierr = check_nml_error(io, 'spectral_init_cond_nml')
+  if(which == 'hs')  ierr = check_nml_error(io, 'hs_forcing_nml')
+#else
+  unit = open_namelist_file()
+  ierr = 1
+  do while(ierr /= 0)
+    if(which == 'dyn') read(unit, nml=spectral_dynamics_nml, iostat=io, end=20)
+    if(which == 'ini') read(unit, nml=spectral_init_cond_nml, iostat=io, end=20)
+    if(which == 'hs')  read(unit, nml=hs_forcing_nml, iostat=io, end=20)
+    ierr = check_nml_error(io, which)
+  enddo
+20 call close_file(unit)
+#endif
+end subroutine read_nml
+
+!===============================================================================================
+subroutine spectral_dynamics_init(Time, Time_step_in, tracer_attributes, dry_model_out, nhum_out, ocean_mask)
+
+type(time_type), intent(in) :: Time, Time_step_in
+type(tracer_type), intent(inout), dimension(:) :: tracer_attributes
+logical, intent(out) :: dry_model_out
+integer, intent(out) :: nhum_out
+logical, optional, intent(in), dimension(:,:) :: ocean_mask
+
+type(isca_dyn_config) :: cfg
+integer :: ntr, nsphum, nmix_rat, seconds, days, k
+real :: robert_coeff_tracers
+character(len=32) :: scheme, params
+character(len=128) :: tname, longname, units
+
+if(module_is_initialized) return
+
+call read_nml('dyn'); call read_nml('ini'); call read_nml('hs')
+if(mpp_pe() == mpp_root_pe()) write(stdlog(), nml=spectral_dynamics_nml)
+
+if(damping_order_vor == -1 ) damping_order_vor = damping_order
+if(damping_order_div == -1 ) damping_order_div = damping_order
+if(damping_coeff_vor == -1.) damping_coeff_vor = damping_coeff
+if(damping_coeff_div == -1.) damping_coeff_div = damping_coeff
+
+! what the device core does not carry is refused by name (check_dynamics_nml's own tests are the library's: isca_dyn_create)
+if(uppercase(trim(vert_advect_uv)) /= 'SECOND_CENTERED') &
+  call error_mesg('spectral_dynamics_init','"'//trim(vert_advect_uv)//'" is not a supported value for vert_advect_uv (second_centered only).', FATAL)
+if(uppercase(trim(vert_advect_t)) /= 'SECOND_CENTERED') &
+  call error_mesg('spectral_dynamics_init','"'//trim(vert_advect_t)//'" is not a supported value for vert_advect_t (second_centered only).', FATAL)
+if(.not. use_implicit) call error_mesg('spectral_dynamics_init','use_implicit = .false. is not a supported value.', FATAL)
+if(trim(vert_difference_option) /= 'simmons_and_burridge') &
+  call error_mesg('spectral_dynamics_init','"'//trim(vert_difference_option)//'" is not a supported value for vert_difference_option.', FATAL)
+if(trim(initial_state_option) /= 'quiescent') &
+  call error_mesg('spectral_dynamics_init','"'//trim(initial_state_option)//'" is not a supported value for initial_state_option.', FATAL)
+if(trim(topography_option) /= 'flat') &
+  call error_mesg('spectral_dynamics_init','"'//trim(topography_option)//'" is not a supported value for topography_option here: hand the '// &
+                  'surface geopotential to the library (isca_dyn_set_surf_geopotential).', FATAL)
+if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
+if(make_symmetric) call error_mesg('spectral_dynamics_init','make_symmetric = .true. is not a supported value.', FATAL)
+if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
+if(no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind) &
+  call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing is carried by the device core.', FATAL)
+
+call chk(isca_dyn_config_default(cfg), 'spectral_dynamics_init')
+cfg%lon_max = lon_max; cfg%lat_max = lat_max; cfg%num_fourier = num_fourier; cfg%num_spherical = num_spherical
+cfg%num_levels = num_levels; cfg%fourier_inc = fourier_inc; cfg%triang_trunc = merge(1, 0, triang_trunc)
+call get_time(Time_step_in, seconds, days)
+dt_real = 86400*days + seconds
+cfg%dt_atmos = dt_real
+cfg%damping_order = damping_order; cfg%damping_coeff = damping_coeff
+cfg%damping_order_vor = damping_order_vor; cfg%damping_order_div = damping_order_div
+cfg%damping_coeff_vor = damping_coeff_vor; cfg%damping_coeff_div = damping_coeff_div; cfg%cutoff_wn = cutoff_wn
+select case(trim(damping_option))
+  case('resolution_dependent');   cfg%damping_option = 0
+  case('exponential_cutoff');     cfg%damping_option = 1
+  case('resolution_independent'); cfg%damping_option = 2
+  case default
+    call error_mesg('spectral_damping_init','"'//trim(damping_option)//'" is not a valid value for damping_option.', FATAL)
+end select
+cfg%eddy_sponge_coeff = eddy_sponge_coeff; cfg%zmu_sponge_coeff = zmu_sponge_coeff; cfg%zmv_sponge_coeff = zmv_sponge_coeff
+cfg%robert_coeff = robert_coeff; cfg%raw_filter_coeff = raw_filter_coeff; cfg%alpha_implicit = alpha_implicit
+cfg%reference_sea_level_press = reference_sea_level_press
+cfg%do_mass_correction = merge(1, 0, do_mass_correction); cfg%do_energy_correction = merge(1, 0, do_energy_correction)
+cfg%do_water_correction = merge(1, 0, do_water_correction); cfg%water_correction_limit = water_correction_limit
+cfg%initial_temperature = initial_temperature; cfg%initial_sphum = initial_sphum; cfg%valid_range_t = valid_range_t
+cfg%use_virtual_temperature = merge(1, 0, use_virtual_temperature)
+cfg%radius = radius; cfg%omega = omega
+cfg%t_zero = t_zero; cfg%t_strat = t_strat; cfg%delh = delh; cfg%delv = delv; cfg%eps = eps; cfg%sigma_b = sigma_b
+cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_conserve_energy)
+cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
+cfg%physics = dropin_physics                ! 2: the caller keeps its physics package and spectral_dynamics receives its tendencies
+select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coordinate.F90:124-152)
+  case('uneven_sigma')
+    cfg%vert_coord_input = 0; cfg%scale_heights = scale_heights; cfg%exponent = exponent; cfg%surf_res = surf_res
+  case('even_sigma')
+    cfg%vert_coord_input = 1
+    do k = 0, num_levels
+      cfg%pk_input(k+1) = 0.; cfg%bk_input(k+1) = real(k)/real(num_levels)
+    enddo
+  case default
+    call error_mesg('spectral_dynamics_init','"'//trim(vert_coord_option)//'" is not a supported value for vert_coord_option here '// &
+                    '(even_sigma, uneven_sigma; the others through pk_input / bk_input of the library).', FATAL)
+end select
+
+! ---- the field_table, as the reference reads it (spectral_dynamics.F90:316-409)
+call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
+if(num_tracers > ISCA_MAX_TRACERS) call error_mesg('spectral_dynamics_init','more prognostic tracers than the device core carries', FATAL)
+if(size(tracer_attributes) < num_tracers) call error_mesg('spectral_dynamics_init','size(tracer_attributes) is too small', FATAL)
+cfg%num_tracers = num_tracers
+do ntr = 1, num_tracers
+  call get_tracer_names(MODEL_ATMOS, ntr, tname, longname, units)
+  tracer_attributes(ntr)%name = lowercase(tname)
+  tracer_attributes(ntr)%numerical_representation = default_representation
+  if(query_method('numerical_representation', MODEL_ATMOS, ntr, scheme)) tracer_attributes(ntr)%numerical_representation = scheme
+  tracer_attributes(ntr)%advect_vert = default_advect_vert
+  if(query_method('advect_vert', MODEL_ATMOS, ntr, scheme)) tracer_attributes(ntr)%advect_vert = scheme
+  tracer_attributes(ntr)%hole_filling = default_hole_filling
+  if(query_method('hole_filling', MODEL_ATMOS, ntr, scheme)) tracer_attributes(ntr)%hole_filling = scheme
+  tracer_attributes(ntr)%robert_coeff = robert_coeff
+  if(query_method('robert_filter', MODEL_ATMOS, ntr, scheme, params)) then
+    if(uppercase(scheme) == 'OFF') then
+      tracer_attributes(ntr)%robert_coeff = 0.0
+    else if(parse(params, 'robert_coeff', robert_coeff_tracers) == 1) then
+      tracer_attributes(ntr)%robert_coeff = robert_coeff_tracers
+    endif
+  endif
+  select case(trim(tracer_attributes(ntr)%numerical_representation))
+    case('spectral')
+      tracer_attributes(ntr)%advect_horiz = 'spectral'; cfg%tracer_spectral(ntr) = 1
+      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'SECOND_CENTERED') &
+        call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%advect_vert)//' is not available for a spectral tracer here', FATAL)
+    case('grid')
+      tracer_attributes(ntr)%advect_horiz = 'van_leer'; cfg%tracer_spectral(ntr) = 0
+      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'FINITE_VOLUME_PARABOLIC') &
+        call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%advect_vert)//' is not available for a grid tracer here', FATAL)
+    case default
+      call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%numerical_representation)//' is an invalid numerical_representation', FATAL)
+  end select
+  cfg%tracer_robert_coeff(ntr) = tracer_attributes(ntr)%robert_coeff
+enddo
+nsphum   = get_tracer_index(MODEL_ATMOS, 'sphum')
+nmix_rat = get_tracer_index(MODEL_ATMOS, 'mix_rat')
+if(nsphum /= NO_TRACER .and. nmix_rat /= NO_TRACER) &
+  call error_mesg('spectral_dynamics_init','sphum and mix_rat cannot both be specified as tracers at the same time', FATAL)
+nhum = 0
+if(nsphum /= NO_TRACER) nhum = nsphum
+if(nmix_rat /= NO_TRACER) nhum = nmix_rat
+dry_model = (nhum == 0)
+if(.not. dry_model .and. nhum /= 1) &       ! the library's tracer 1 is the one the water correction and the virtual temperature act on
+  call error_mesg('spectral_dynamics_init','the humidity tracer must be the first atmos_mod entry of the field_table', FATAL)
+if(dry_model .and. num_tracers > 0) then
+  if(do_water_correction) call error_mesg('compute_corrections','do_water_correction must be .false. in a dry model (default is .true.)', FATAL)
+  cfg%initial_sphum = 0.0; cfg%use_virtual_temperature = 0
+endif
+dry_model_out = dry_model
+nhum_out = nhum
+
+! ---- the device core, cold-started (restart files: not from Fortran, see the header)
+call chk(isca_dyn_create(cfg, core), 'spectral_dynamics_init')
+call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
+core_ready = .true.
+nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
+virtual_t = use_virtual_temperature; ref_sea_level_press = reference_sea_level_press
+module_is_initialized = .true.
+
+end subroutine spectral_dynamics_init
+
+!===============================================================================================
+subroutine get_initial_fields(ug_out, vg_out, tg_out, psg_out, grid_tracers_out)
+real, intent(out), dimension(:,:,:)   :: ug_out, vg_out, tg_out
+real, intent(out), dimension(:,:)     :: psg_out
+real, intent(out), dimension(:,:,:,:) :: grid_tracers_out
+integer(c_long) :: step
+integer :: ntr
+call need_core('get_initial_fields')
+call chk(isca_dyn_get_info(core, cstr('step'), step), 'get_initial_fields')
+if(step /= 0) call error_mesg('get_initial_fields','This routine may be called only to get the initial values after a cold_start', FATAL)
+call get_grid3('ug', 1, ug_out); call get_grid3('vg', 1, vg_out); call get_grid3('tg', 1, tg_out); call get_grid2('psg', 1, psg_out)
+do ntr = 1, ntrace
+  call get_grid3(tracer_name(ntr, .false.), 1, grid_tracers_out(:,:,:,ntr))
+enddo
+end subroutine get_initial_fields
+
+! the library's name of tracer ntr: 'tr', 'tr2', ... ('tr_atm', 'tr_atm2', ...: the copy atmosphere_mod works with)
+function tracer_name(ntr, atm) result(nm)
+integer, intent(in) :: ntr
+logical, intent(in) :: atm
+character(len=8) :: nm
+nm = merge('tr_atm', 'tr    ', atm)
+if(ntr > 1) write(nm, '(a,i1)') trim(nm), ntr
+end function tracer_name
+
+!===============================================================================================
+subroutine spectral_dynamics(Time, psg_final, ug_final, vg_final, tg_final, tracer_attributes, grid_tracers_final, &
+                             time_level_out, dt_psg, dt_ug, dt_vg, dt_tg, dt_tracers, wg_full, p_full, p_half, z_full)
+
+type(time_type), intent(in) :: Time
+real, intent(out), dimension(:,:)       :: psg_final
+real, intent(out), dimension(:,:,:)     :: ug_final, vg_final, tg_final
+real, intent(out), dimension(:,:,:,:,:) :: grid_tracers_final
+type(tracer_type), intent(inout), dimension(:) :: tracer_attributes
+integer, intent(in)                     :: time_level_out
+real, intent(inout), dimension(:,:)     :: dt_psg
+real, intent(inout), dimension(:,:,:)   :: dt_ug, dt_vg, dt_tg
+real, intent(inout), dimension(:,:,:,:) :: dt_tracers
+real, intent(out),   dimension(:,:,:)   :: wg_full
+real, intent(in),    dimension(:,:,:)   :: p_full, z_full
+real, intent(in),    dimension(:,:,:)   :: p_half
+integer :: ntr
+real(c_double), allocatable :: tnd(:)
+
+call need_core('spectral_dynamics')
+if(any(dt_psg /= 0.)) call error_mesg('spectral_dynamics','a physics tendency of surface pressure is not carried by the device core', FATAL)
+! one step: spectral_dynamics.F90:780-1034 on the device with the caller's tendencies
+allocate(tnd(max(size(dt_tracers), 1)))
+if(size(dt_tracers) > 0) tnd = reshape(dt_tracers, (/size(dt_tracers)/))
+call chk(isca_dyn_dynamics(core, dt_ug, dt_vg, dt_tg, tnd, 0_c_int, 1_c_int), 'spectral_dynamics')
+! psg_final = psg(:,:,current) etc. (:1023-1028): the new time level; the tracers as atmosphere_mod keeps them (not Robert-filtered)
+call get_grid2('psg', 1, psg_final)
+call get_grid3('ug', 1, ug_final); call get_grid3('vg', 1, vg_final); call get_grid3('tg', 1, tg_final)
+do ntr = 1, ntrace
+  call get_grid3(tracer_name(ntr, .true.), 1, grid_tracers_final(:,:,:,time_level_out,ntr))
+enddo
+call get_grid3('wg_full', 1, wg_full)
+end subroutine spectral_dynamics
+
+!===============================================================================================
+! complete_robert_filter (:1456-1490) is part of the device step; complete_update_of_future (:1416-1454) re-derives the spectral side of
+! the new level after the caller changed its grid fields
+subroutine complete_robert_filter(tracer_attributes, part_filt_ln_ps, part_filt_vors, part_filt_divs, part_filt_ts, part_filt_trs, part_filt_tr)
+type(tracer_type), intent(inout), dimension(:) :: tracer_attributes
+complex, intent(in), dimension(:,:) :: part_filt_ln_ps
+complex, intent(in), dimension(:,:,:) :: part_filt_vors, part_filt_divs, part_filt_ts
+complex, intent(in), dimension(:,:,:,:) :: part_filt_trs
+real, intent(in), dimension(:,:,:,:) :: part_filt_tr
+call error_mesg('complete_robert_filter','the device step completes the Robert filter itself: this routine must not be called', FATAL)
+end subroutine complete_robert_filter
+
+subroutine complete_update_of_future(psg, ug, vg, tg, tracer_attributes, grid_tracers)
+real, intent(in), dimension(:,:)     :: psg
+real, intent(in), dimension(:,:,:)   :: ug, vg, tg
+type(tracer_type), intent(in), dimension(:) :: tracer_attributes
+real, intent(in), dimension(:,:,:,:) :: grid_tracers
+integer :: ntr
+call need_core('complete_update_of_future')
+call chk(isca_dyn_set_state(core, cstr('psg'), 1_c_int, reshape(psg, (/size(psg)/)), size(psg, kind=c_size_t)), 'complete_update_of_future')
+call chk(isca_dyn_set_state(core, cstr('ug'), 1_c_int, reshape(ug, (/size(ug)/)), size(ug, kind=c_size_t)), 'complete_update_of_future')
+call chk(isca_dyn_set_state(core, cstr('vg'), 1_c_int, reshape(vg, (/size(vg)/)), size(vg, kind=c_size_t)), 'complete_update_of_future')
+call chk(isca_dyn_set_state(core, cstr('tg'), 1_c_int, reshape(tg, (/size(tg)/)), size(tg, kind=c_size_t)), 'complete_update_of_future')
+do ntr = 1, ntrace
+  call chk(isca_dyn_set_state(core, cstr(tracer_name(ntr, .false.)), 1_c_int, reshape(grid_tracers(:,:,:,ntr), (/size(tg)/)), &
+                              size(tg, kind=c_size_t)), 'complete_update_of_future')
+  call chk(isca_dyn_set_state(core, cstr(tracer_name(ntr, .true.)), 1_c_int, reshape(grid_tracers(:,:,:,ntr), (/size(tg)/)), &
+                              size(tg, kind=c_size_t)), 'complete_update_of_future')
+enddo
+call chk(isca_dyn_complete_update(core, 1_c_int), 'complete_update_of_future')
+end subroutine complete_update_of_future
+
+!===============================================================================================
+subroutine spectral_dynamics_end(tracer_attributes, Time)
+type(tracer_type), intent(in), dimension(:) :: tracer_attributes
+type(time_type), intent(in), optional :: Time
+if(.not. module_is_initialized) return
+call chk(isca_dyn_destroy(core), 'spectral_dynamics_end')
+core = c_null_ptr; core_ready = .false.; module_is_initialized = .false.
+end subroutine spectral_dynamics_end
+
+! the diagnostics of the dynamical core are accumulated on the device (isca_dyn_diag_select / isca_dyn_diag_read); diag_manager's
+! send_data protocol is not driven from here
+subroutine spectral_diagnostics(Time, p_surf, u_grid, v_grid, t_grid, wg_full, tr_grid, time_level)
+type(time_type), intent(in) :: Time
+real, intent(in), dimension(:,:)       :: p_surf
+real, intent(in), dimension(:,:,:)     :: u_grid, v_grid, t_grid, wg_full
+real, intent(in), dimension(:,:,:,:,:) :: tr_grid
+integer, intent(in) :: time_level
+end subroutine spectral_diagnostics
+
+!===============================================================================================
+subroutine get_num_levels(num_levels_out)
+integer, intent(out) :: num_levels_out
+call need_core('get_num_levels')
+num_levels_out = nlev
+end subroutine get_num_levels
+
+subroutine get_use_virtual_temperature(use_virtual_temperature_out)
+logical, intent(out) :: use_virtual_temperature_out
+call need_core('get_use_virtual_temperature')
+use_virtual_temperature_out = virtual_t
+end subroutine get_use_virtual_temperature
+
+subroutine get_reference_sea_level_press(reference_sea_level_press_out)
+real, intent(out) :: reference_sea_level_press_out
+call need_core('get_reference_sea_level_press')
+reference_sea_level_press_out = ref_sea_level_press
+end subroutine get_reference_sea_level_press
+
+subroutine get_surf_geopotential(surf_geopotential_out)
+real, intent(out), dimension(:,:) :: surf_geopotential_out
+call need_core('get_surf_geopotential')
+call get_grid2('surf_geopotential', 1, surf_geopotential_out)
+end subroutine get_surf_geopotential
+
+subroutine get_pk_bk(pk_out, bk_out)
+real, intent(out), dimension(:) :: pk_out, bk_out
+call need_core('get_pk_bk')
+if(size(pk_out) /= nlev+1 .or. size(bk_out) /= nlev+1) call error_mesg('get_pk_bk','pk_out and bk_out must have num_levels+1 values', FATAL)
+call get_table1('pk', pk_out); call get_table1('bk', bk_out)
+end subroutine get_pk_bk
+
+! the axes diag_manager would know the dynamics' fields by: none are registered from here
+function get_axis_id()
+integer, dimension(4) :: get_axis_id
+get_axis_id = 0
+end function get_axis_id
+
+end module spectral_dynamics_mod

@@ -120,6 +120,122 @@ interface
   integer(c_int) function isca_area_weighted_global_mean(h, field2d, mean) bind(C)
     import; type(c_ptr), value :: h; real(c_double), intent(in) :: field2d(*); real(c_double), intent(out) :: mean
   end function
+  ! ---- the rest of transforms_mod / spherical_mod on caller arrays (Fortran layouts, num_levels <= nlev)
+  integer(c_int) function isca_vor_div_from_uv_grid(h, u, v, vor, div, nlev) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: u(*), v(*)
+    complex(c_double_complex), intent(out) :: vor(*), div(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_uv_grid_from_vor_div(h, vor, div, u, v, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: vor(*), div(*)
+    real(c_double), intent(out) :: u(*), v(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_horizontal_advection(h, field_spec, u, v, tendency, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: field_spec(*)
+    real(c_double), intent(in) :: u(*), v(*); real(c_double), intent(inout) :: tendency(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_spherical_to_fourier(h, spherical, fourier, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: spherical(*)
+    complex(c_double_complex), intent(out) :: fourier(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_fourier_to_spherical(h, fourier, spherical, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: fourier(*)
+    complex(c_double_complex), intent(out) :: spherical(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_grid_to_fourier(h, grid, fourier, nlev) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: grid(*)
+    complex(c_double_complex), intent(out) :: fourier(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_fourier_to_grid(h, fourier, grid, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: fourier(*)
+    real(c_double), intent(out) :: grid(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_trans_filter(h, grid, filter, nlev) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(inout) :: grid(*); type(c_ptr), value :: filter; integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_divide_by_cos(h, grid, nlev, power) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(inout) :: grid(*); integer(c_int), value :: nlev, power
+  end function
+  integer(c_int) function isca_compute_laplacian(h, spherical, laplacian, nlev, power) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: spherical(*)
+    complex(c_double_complex), intent(out) :: laplacian(*); integer(c_int), value :: nlev, power
+  end function
+  integer(c_int) function isca_compute_gradient_cos(h, spherical, deriv_lon, deriv_lat, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: spherical(*)
+    complex(c_double_complex), intent(out) :: deriv_lon(*), deriv_lat(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_compute_ucos_vcos(h, vorticity, divergence, u_cos, v_cos, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: vorticity(*), divergence(*)
+    complex(c_double_complex), intent(out) :: u_cos(*), v_cos(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_compute_vor_div(h, u_div_cos, v_div_cos, vorticity, divergence, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(in) :: u_div_cos(*), v_div_cos(*)
+    complex(c_double_complex), intent(out) :: vorticity(*), divergence(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_triangular_truncation(h, spherical, nlev) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(inout) :: spherical(*); integer(c_int), value :: nlev
+  end function
+  integer(c_int) function isca_compute_gaussian(n_hem, sin_hem, wts_hem) bind(C)
+    import; integer(c_int), value :: n_hem; real(c_double), intent(out) :: sin_hem(*), wts_hem(*)
+  end function
+  integer(c_int) function isca_compute_legendre(num_fourier, fourier_inc, num_spherical, sin_lat, n_lat, legendre) bind(C)
+    import; integer(c_int), value :: num_fourier, fourier_inc, num_spherical, n_lat
+    real(c_double), intent(in) :: sin_lat(*); real(c_double), intent(out) :: legendre(*)
+  end function
+  ! ---- the routines of the step on caller arrays (press_and_geopot_mod, implicit_mod, spectral_damping_mod, leapfrog_mod,
+  !      vert_advection_mod, fv_advection_mod, global_integral_mod)
+  integer(c_int) function isca_pressure_variables(h, surf_p, p_half, ln_p_half, p_full, ln_p_full) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: surf_p(*)
+    real(c_double), intent(out) :: p_half(*), ln_p_half(*), p_full(*), ln_p_full(*)
+  end function
+  integer(c_int) function isca_compute_geopotential(h, t, ln_p_half, ln_p_full, geopot_full, geopot_half) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: t(*), ln_p_half(*), ln_p_full(*)
+    real(c_double), intent(out) :: geopot_full(*), geopot_half(*)
+  end function
+  integer(c_int) function isca_compute_pressures_and_heights(h, t, ps, q, z_full, z_half, p_full, p_half) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: t(*), ps(*); type(c_ptr), value :: q
+    real(c_double), intent(out) :: z_full(*), z_half(*), p_full(*), p_half(*)
+  end function
+  integer(c_int) function isca_implicit_correction(h, dt_divs, dt_ts, dt_ln_ps, divs_previous, divs_current, ts_previous, ts_current, &
+                                                   ln_ps_previous, ln_ps_current, delta_t) bind(C)
+    import; type(c_ptr), value :: h; complex(c_double_complex), intent(inout) :: dt_divs(*), dt_ts(*), dt_ln_ps(*)
+    complex(c_double_complex), intent(in) :: divs_previous(*), divs_current(*), ts_previous(*), ts_current(*), ln_ps_previous(*), ln_ps_current(*)
+    real(c_double), value :: delta_t
+  end function
+  integer(c_int) function isca_compute_spectral_damping(h, which, field_previous, dt_field, delta_t) bind(C)
+    import; type(c_ptr), value :: h; integer(c_int), value :: which; complex(c_double_complex), intent(in) :: field_previous(*)
+    complex(c_double_complex), intent(inout) :: dt_field(*); real(c_double), value :: delta_t
+  end function
+  integer(c_int) function isca_leapfrog_2level_a(h, n, prev, cur, fut, dt_a, delta_t, robert_coeff, raw_filter_coeff, part) bind(C)
+    import; type(c_ptr), value :: h; integer(c_size_t), value :: n; type(c_ptr), value :: prev, cur, fut, dt_a, part
+    real(c_double), value :: delta_t, robert_coeff, raw_filter_coeff
+  end function
+  integer(c_int) function isca_leapfrog_2level_b(h, n, cur, fut, part, robert_coeff, raw_filter_coeff) bind(C)
+    import; type(c_ptr), value :: h; integer(c_size_t), value :: n; type(c_ptr), value :: cur, fut, part
+    real(c_double), value :: robert_coeff, raw_filter_coeff
+  end function
+  integer(c_int) function isca_vert_advection_ppm(h, dt, w, surf_p, r, rdt) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), value :: dt; real(c_double), intent(in) :: w(*), surf_p(*), r(*)
+    real(c_double), intent(out) :: rdt(*)
+  end function
+  integer(c_int) function isca_vert_advection_centered(h, w, surf_p, r, rdt) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: w(*), surf_p(*), r(*); real(c_double), intent(out) :: rdt(*)
+  end function
+  integer(c_int) function isca_a_grid_horiz_advection(h, u, v, q, dt, tendency) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: u(*), v(*), q(*); real(c_double), value :: dt
+    real(c_double), intent(inout) :: tendency(*)
+  end function
+  integer(c_int) function isca_mass_weighted_global_integral(h, field, surf_press, integral) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: field(*), surf_press(*); real(c_double), intent(out) :: integral
+  end function
+  integer(c_int) function isca_dyn_complete_update(h, time_level) bind(C)
+    import; type(c_ptr), value :: h; integer(c_int), value :: time_level
+  end function
+  integer(c_int) function isca_dyn_set_surf_geopotential(h, global_field, count) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: global_field(*); integer(c_size_t), value :: count
+  end function
+  integer(c_int) function isca_dyn_get_info(h, name, value) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), intent(out) :: value
+  end function
   function isca_last_error() bind(C) result(msg)
     import; type(c_ptr) :: msg
   end function

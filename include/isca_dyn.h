@@ -268,6 +268,20 @@ int isca_compute_geopotential(isca_dyn_t *h, const double *t, const double *ln_p
 int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v, const double *q, double dt, double *tendency);   /* fv_advection.F90:126-207; tendency is accumulated */
 int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt);   /* vert_advection.F90:70-478, FINITE_VOLUME_PARABOLIC / ADVECTIVE_FORM, dz = dpk + dbk*surf_p */
 int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, const double *r, double *rdt);      /* hs_forcing.F90:683-724; rdt is accumulated */
+int isca_vert_advection_centered(isca_dyn_t *h, const double *w, const double *surf_p, const double *r, double *rdt);   /* vert_advection.F90:185-193, 467-470: SECOND_CENTERED / ADVECTIVE_FORM, dz = dpk + dbk*surf_p; rdt = the tendency */
+/* press_and_geopot.F90:363-387 compute_pressures_and_heights(t_grid, ps_grid, surf_geopotential, z_full, z_half, p_full, p_half [, q_grid]):
+ * the handle's surface geopotential; q (NULL = none) enters through the virtual temperature when use_virtual_temperature is set */
+int isca_compute_pressures_and_heights(isca_dyn_t *h, const double *t, const double *ps, const double *q, double *z_full, double *z_half,
+                                       double *p_full, double *p_half);
+/* leapfrog.F90:58-105 on n real values (a complex array = 2 n of them): leapfrog_2level_A -- part = prev - 2 cur; cur += robert part raw;
+ * fut = prev + delta_t dt_a (fut may be prev's storage) -- and leapfrog_2level_B -- cur += robert fut raw; fut += robert (part + fut) (raw - 1) */
+int isca_leapfrog_2level_a(isca_dyn_t *h, size_t n, const double *prev, double *cur, double *fut, const double *dt_a, double delta_t,
+                           double robert_coeff, double raw_filter_coeff, double *part);
+int isca_leapfrog_2level_b(isca_dyn_t *h, size_t n, double *cur, double *fut, const double *part, double robert_coeff, double raw_filter_coeff);
+/* gauss_and_legendre.F90:111-183 compute_gaussian(sin_hem, wts_hem, n_hem) and :47-108 compute_legendre(legendre, num_fourier, fourier_inc,
+ * num_spherical, sin_lat, n_lat), legendre(0:num_fourier, 0:num_spherical, n_lat): host tables, no handle */
+int isca_compute_gaussian(int n_hem, double *sin_hem, double *wts_hem);
+int isca_compute_legendre(int num_fourier, int fourier_inc, int num_spherical, const double *sin_lat, int n_lat, double *legendre);
 
 /* the three stages of the spectral update, run by the step's own kernel on caller data (num_levels 3-D arrays) */
 int isca_implicit_correction(isca_dyn_t *h, double *dt_divs, double *dt_ts, double *dt_ln_ps, const double *divs_previous,

@@ -1318,6 +1318,7 @@ extern "C" int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host,
   else if (nm == "deg_lon") v = &T.deg_lon; else if (nm == "pk") v = &T.pk; else if (nm == "bk") v = &T.bk;
   else if (nm == "legendre") v = &T.legendre; else if (nm == "eigen_laplacian") v = &T.eigen;
   else if (nm == "sin_hem") v = &T.sin_hem; else if (nm == "wts_hem") v = &T.wts_hem;
+  else if (nm == "lon_boundaries") v = &T.lon_boundaries; else if (nm == "lat_boundaries") v = &T.lat_boundaries;     // transforms.F90:313-325 (radians)
   else if (nm == "wave_matrix") {
     if (T.wave_dt < 0) fail("wave matrices not built yet (run a step)");
     const int L = T.L, nw = T.n_wave;
@@ -1705,6 +1706,81 @@ extern "C" int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, c
   double *ps = t.up(surf_p, n2), *dr = t.up(r, n3), *dd = t.up(rdt, n3);
   launch_tracer_source_sink(*h, ps, dr, dd, h->stream);
   d2h(h, rdt, dd, n3);
+  API_END
+}
+
+// vert_advection.F90:70-478 vert_advection(dt, w, dz, r, rdt, scheme = SECOND_CENTERED, form = ADVECTIVE_FORM), dz = dpk + dbk * surf_p
+extern "C" int isca_vert_advection_centered(isca_dyn_t *h, const double *w, const double *surf_p, const double *r, double *rdt) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I, n3 = n2 * g.L;
+  DevTmp t(h);
+  double *dw = t.up(w, n2 * (g.L + 1)), *ps = t.up(surf_p, n2), *dr = t.up(r, n3), *dd = t.alloc(n3, true);
+  launch_vert_advection_centered(*h, dw, ps, dr, dd, h->stream);
+  d2h(h, rdt, dd, n3);
+  API_END
+}
+// press_and_geopot.F90:363-387 compute_pressures_and_heights on caller fields (the handle's surface geopotential)
+extern "C" int isca_compute_pressures_and_heights(isca_dyn_t *h, const double *t, const double *ps, const double *q, double *z_full, double *z_half,
+                                                  double *p_full, double *p_half) {
+  API_BEGIN
+  if (!h || !t || !ps) fail("null argument");
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I, n3 = n2 * g.L, n3h = n2 * (g.L + 1);
+  DevTmp tmp(h);
+  double *dt_ = tmp.up(t, n3), *dps = tmp.up(ps, n2), *pf = tmp.alloc(n3), *ph = tmp.alloc(n3h), *zf = tmp.alloc(n3), *zh = tmp.alloc(n3h);
+  const double *tq = dt_;
+  if (q && h->cfg.use_virtual_temperature) {         // press_and_geopot.F90:246-256, 340-355
+    double *dq = tmp.up(q, n3), *tv = tmp.alloc(n3);
+    launch_virtual_t(*h, dt_, dq, tv, h->stream);
+    tq = tv;
+  }
+  launch_pressures_heights(*h, tq, dps, pf, ph, zf, zh, h->stream);
+  if (p_full) d2h(h, p_full, pf, n3);
+  if (p_half) d2h(h, p_half, ph, n3h);
+  if (z_full) d2h(h, z_full, zf, n3);
+  if (z_half) d2h(h, z_half, zh, n3h);
+  API_END
+}
+// leapfrog.F90:58-105 on caller arrays
+extern "C" int isca_leapfrog_2level_a(isca_dyn_t *h, size_t n, const double *prev, double *cur, double *fut, const double *dt_a, double delta_t,
+                                      double robert_coeff, double raw_filter_coeff, double *part) {
+  API_BEGIN
+  if (!h || !prev || !cur || !fut || !dt_a) fail("null argument");
+  DevTmp t(h);
+  double *dc = t.up(cur, n), *dp = (prev == cur) ? dc : t.up(prev, n);
+  double *df = (fut == prev) ? dp : ((fut == cur) ? dc : t.alloc(n));
+  double *dd = t.up(dt_a, n), *dpt = part ? t.alloc(n) : nullptr;
+  launch_leapfrog_a(n, dp, dc, df, dd, delta_t, robert_coeff, raw_filter_coeff, dpt, h->stream);
+  d2h(h, cur, dc, n);
+  if (fut != cur) d2h(h, fut, df, n);
+  if (part) d2h(h, part, dpt, n);
+  API_END
+}
+extern "C" int isca_leapfrog_2level_b(isca_dyn_t *h, size_t n, double *cur, double *fut, const double *part, double robert_coeff, double raw_filter_coeff) {
+  API_BEGIN
+  if (!h || !cur || !fut || !part) fail("null argument");
+  DevTmp t(h);
+  double *dc = t.up(cur, n), *df = t.up(fut, n), *dp = t.up(part, n);
+  launch_leapfrog_b(n, dc, df, dp, robert_coeff, raw_filter_coeff, h->stream);
+  d2h(h, cur, dc, n); d2h(h, fut, df, n);
+  API_END
+}
+// gauss_and_legendre.F90: host tables (init-time in the reference too)
+extern "C" int isca_compute_gaussian(int n_hem, double *sin_hem, double *wts_hem) {
+  API_BEGIN
+  if (n_hem < 1 || !sin_hem || !wts_hem) fail("compute_gaussian: invalid argument");
+  std::vector<double> s_, w_;
+  compute_gaussian(n_hem, s_, w_);
+  std::memcpy(sin_hem, s_.data(), n_hem * sizeof(double)); std::memcpy(wts_hem, w_.data(), n_hem * sizeof(double));
+  API_END
+}
+extern "C" int isca_compute_legendre(int num_fourier, int fourier_inc, int num_spherical, const double *sin_lat, int n_lat, double *legendre) {
+  API_BEGIN
+  if (num_fourier < 0 || num_spherical < 0 || fourier_inc < 1 || n_lat < 1 || !sin_lat || !legendre) fail("compute_legendre: invalid argument");
+  std::vector<double> leg;
+  compute_legendre(num_fourier, num_spherical, std::vector<double>(sin_lat, sin_lat + n_lat), leg, fourier_inc);
+  std::memcpy(legendre, leg.data(), leg.size() * sizeof(double));
   API_END
 }
 

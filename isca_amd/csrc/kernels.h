@@ -73,6 +73,9 @@ void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, doubl
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s);
 void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s);
+void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, const double *dta, double delta_t, double robert, double raw,
+                       double *part, hipStream_t s);
+void launch_leapfrog_b(size_t n, double *cur, double *fut, const double *part, double robert, double raw, hipStream_t s);
 void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s);
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band

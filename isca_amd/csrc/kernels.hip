@@ -2074,6 +2074,33 @@ void launch_vert_advection_centered(const isca_dyn &h, const double *w, const do
   const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
   hipLaunchKernelGGL(k_vert_advection_centered, grid1d(n), dim3(256), 0, s, h.g, w, ps, h.d.dpk, h.d.dbk, r, rdt);
 }
+// leapfrog_2level_A / _B (leapfrog.F90:58-105) on caller arrays (the C-ABI entry points behind leapfrog_mod): every value is read before
+// anything is written, so `fut` may be the storage of `prev` (two time levels) or of `cur` (the first step)
+__global__ void k_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, const double *__restrict__ dta, double delta_t,
+                             double robert, double raw, double *part) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p = prev[i], c = cur[i];
+  const double pt = p - 2.0 * c;
+  const double f = p + delta_t * dta[i], cn = c + robert * pt * raw;
+  if (part) part[i] = pt;
+  if (fut == cur) { cur[i] = f; }           // previous == current == future makes no sense; future == current: the new level wins (leapfrog.F90:74-76)
+  else { cur[i] = cn; fut[i] = f; }
+}
+__global__ void k_leapfrog_b(size_t n, double *cur, double *fut, const double *__restrict__ part, double robert, double raw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double c = cur[i], f = fut[i];
+  cur[i] = c + robert * f * raw;
+  fut[i] = f + robert * (part[i] + f) * (raw - 1.0);
+}
+void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, const double *dta, double delta_t, double robert, double raw,
+                       double *part, hipStream_t s) {
+  hipLaunchKernelGGL(k_leapfrog_a, grid1d(n), dim3(256), 0, s, n, prev, cur, fut, dta, delta_t, robert, raw, part);
+}
+void launch_leapfrog_b(size_t n, double *cur, double *fut, const double *part, double robert, double raw, hipStream_t s) {
+  hipLaunchKernelGGL(k_leapfrog_b, grid1d(n), dim3(256), 0, s, n, cur, fut, part, robert, raw);
+}
 // spectral tracer: compute_spectral_damping (spectral_damping.F90:172-201, the coefficients temperature uses) on dt_trs, leapfrog_2level_A
 // (leapfrog.F90:58-84) and _B's `current` half (:100); one thread per coefficient and level, each reads its three time levels first
 // (previous aliases future from the second step on, current on the first)
@@ -2229,12 +2256,13 @@ __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, c
   const int st = cc < 2 ? 2 : NPART;
   auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
   double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
-  for (int i0 = g; i0 < nb; i0 += 8 * NG) {
-    double v[8];
+  constexpr int U = 16;                              // loads in flight per thread: one round trip up to 16 NT / 16 = NT sets
+  for (int i0 = g; i0 < nb; i0 += U * NG) {
+    double v[U];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = p0[(size_t)st * min(i0 + NG * r, nb - 1)];
+    for (int r = 0; r < U; ++r) v[r] = p0[(size_t)st * min(i0 + NG * r, nb - 1)];
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < U; ++r)
       if (i0 + NG * r < nb) acc = fold(acc, v[r]);
   }
   acc = fold(acc, __shfl_xor(acc, 16, 64));
@@ -2462,7 +2490,7 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
   // on one rank k_fixer_finish folds them itself
   if (g.P > 1 || !h.lazy_fix) {
-    if (nb > 512) hipLaunchKernelGGL(k_fixer_reduce<1024>, dim3(1), dim3(1024), 0, s, d.partials, p2, nb, d.red);
+    if (nb > 256) hipLaunchKernelGGL(k_fixer_reduce<1024>, dim3(1), dim3(1024), 0, s, d.partials, p2, nb, d.red);
     else hipLaunchKernelGGL(k_fixer_reduce<256>, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
   }
 }
@@ -2494,7 +2522,7 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
 }
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const FixerArgs a = fixer_args(h, sc);
-  if (a.nb > 512) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+  if (a.nb > 256) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
   else hipLaunchKernelGGL(k_fixer_finish<256>, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
 }
 // tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)

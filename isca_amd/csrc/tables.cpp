@@ -302,6 +302,9 @@ void Tables::build(const isca_dyn_config &c) {
     double sum_wts = 0.;
     for (int j = 0; j < J - 1; ++j) { sum_wts = sum_wts + wts_lat[j]; yy[j + 1] = std::asin(sum_wts - 1.); }
     yy[J] = .5 * PI;
+    lat_boundaries = yy;                                 // get_grid_boundaries (transforms.F90:313-325), longitude_origin = 0
+    lon_boundaries.resize(I + 1);
+    for (int i = 0; i <= I; ++i) lon_boundaries[i] = ((i + 1) - 1.5) * (2 * PI / I);
     fv_c.resize(J); fv_cc.resize(J + 1); fv_dy.assign(J + 4, 0.0); fv_dyy.assign(J + 1, 0.0);
     fv_dyp.resize(J + 2); fv_dym.resize(J + 2);
     for (int j = 0; j < J; ++j) { y[j] = 0.5 * (yy[j + 1] + yy[j]); fv_c[j] = std::cos(y[j]); }

@@ -20,6 +20,7 @@ struct Tables {
   int I, J, M1, N1, L;
   int n_wave = 0;                                // wave matrices: total wavenumbers 0..num_total_wavenumbers (spectral_dynamics.F90:430-434)
   std::vector<double> sin_hem, wts_hem;          // [J/2], pole-most first
+  std::vector<double> lon_boundaries, lat_boundaries;   // [I+1], [J+1] cell edges in radians (transforms.F90:313-325)
   std::vector<double> sin_lat, wts_lat, cos_lat, cosm_lat, deg_lat, rad_lat, deg_lon, coriolis;  // [J] / [I]
   std::vector<double> legendre;                  // [J/2][N1][M1]  (Fortran (m,n,j))
   // spherical.F90 coefficient tables, [N1][M1]

@@ -135,6 +135,12 @@ def load_library():
         "isca_a_grid_horiz_advection": [H, dp, dp, dp, C.c_double, dp],
         "isca_vert_advection_ppm": [H, C.c_double, dp, dp, dp, dp],
         "isca_hs_tracer_source_sink": [H, dp, dp, dp],
+        "isca_vert_advection_centered": [H, dp, dp, dp, dp],
+        "isca_compute_pressures_and_heights": [H, dp, dp, dp, dp, dp, dp, dp],
+        "isca_leapfrog_2level_a": [H, C.c_size_t, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp],
+        "isca_leapfrog_2level_b": [H, C.c_size_t, dp, dp, dp, C.c_double, C.c_double],
+        "isca_compute_gaussian": [C.c_int, dp, dp],
+        "isca_compute_legendre": [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp],
         "isca_implicit_correction": [H, dp, dp, dp, dp, dp, dp, dp, dp, dp, C.c_double],
         "isca_compute_spectral_damping": [H, C.c_int, dp, dp, C.c_double],
         "isca_leapfrog": [H, dp, dp, dp, C.c_double, C.c_double],
@@ -168,6 +174,8 @@ EXPORTED_SYMBOLS = [
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
     "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
+    "isca_vert_advection_centered", "isca_compute_pressures_and_heights", "isca_leapfrog_2level_a", "isca_leapfrog_2level_b",
+    "isca_compute_gaussian", "isca_compute_legendre",
     "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check",
     "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter", "isca_config_sizes",
 ]

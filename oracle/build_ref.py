@@ -58,6 +58,23 @@ TARGETS = {
     "barotropic": dict(harness="ref_barotropic_harness.F90", exe="ref_barotropic_harness.x", build="build_barotropic",
                        scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_barotropic"],
                        cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"], skip=("socrates", "rrtm_radiation", "atmos_column")),
+    # The module-level drop-in (bindings/fortran/dropin): THIS REPOSITORY's modules under the reference's names (spectral_dynamics_mod,
+    # transforms_mod, press_and_geopot_mod, hs_forcing_mod, ...) in front of isca_amd/lib/libisca_dyn.so, compiled together with the
+    # reference's own infrastructure modules (fms_mod, time_manager_mod, tracer_manager_mod, ... from src/shared, in place) and linked with
+    # the SAME oracle/ref_harness.F90 as the "dry" target: the harness then drives the GPU library through the reference's interface.
+    "dropin": dict(harness="ref_harness.F90", exe="ref_harness_gpu.x", build="build_dropin", scan=["shared"],
+                   own=[os.path.join(os.path.dirname(HERE), "bindings", "fortran", "isca_dyn_c.F90"),
+                        os.path.join(os.path.dirname(HERE), "bindings", "fortran", "dropin")],
+                   cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"],
+                   link=["-L" + os.path.join(os.path.dirname(HERE), "isca_amd", "lib"), "-lisca_dyn", "-Wl,-rpath,$ORIGIN/../../isca_amd/lib"]),
+    # ... and the main program's side of it: bindings/fortran/dropin/drive_atmos_model.F90 (atmos_model's time loop) on this
+    # repository's atmosphere_mod
+    "dropin_atmos": dict(harness=os.path.join(os.path.dirname(HERE), "bindings", "fortran", "dropin", "drive_atmos_model.F90"),
+                         exe="drive_atmos_model_gpu.x", build="build_dropin_atmos", scan=["shared"],
+                         own=[os.path.join(os.path.dirname(HERE), "bindings", "fortran", "isca_dyn_c.F90"),
+                              os.path.join(os.path.dirname(HERE), "bindings", "fortran", "dropin")],
+                         cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"],
+                         link=["-L" + os.path.join(os.path.dirname(HERE), "isca_amd", "lib"), "-lisca_dyn", "-Wl,-rpath,$ORIGIN/../../isca_amd/lib"]),
 }
 # One compiler-compatibility edit, applied to a BUILD-TIME COPY under oracle/_ref/<build>/compat/ (git-ignored, never in
 # this repository): qe_moist_convection.F90 indexes lcl_temp_table with a variable declared `real` (get_lcl_temp, :1060,
@@ -119,6 +136,14 @@ def build_target(name):
                     p = os.path.join(root, n)
                     files[p] = scan(p)
     mod2file = {}
+    for src in t.get("own", []):          # this repository's modules first: they take the reference's module names
+        own_files = [src] if os.path.isfile(src) else [os.path.join(src, n) for n in sorted(os.listdir(src)) if n.endswith(".F90")]
+        for p in own_files:
+            if p == os.path.join(HERE, t["harness"]):
+                continue
+            files[p] = scan(p)
+            for m in files[p][0]:
+                mod2file[m] = p
     for p, (mods, _, is_prog) in files.items():
         if is_prog and not mods:
             continue
@@ -155,7 +180,7 @@ def build_target(name):
         if os.path.exists(o) and stamps.get(p) == h and not rebuilt_any:
             continue
         src = p
-        rel = os.path.relpath(p, SRC)
+        rel = os.path.relpath(p, SRC) if p.startswith(SRC) else os.path.relpath(p, os.path.dirname(HERE))
         if rel in COMPAT_EDITS:
             text = open(p, errors="replace").read()
             for old, new in COMPAT_EDITS[rel]:
@@ -185,17 +210,18 @@ def build_target(name):
                 print("C helper failed (skipped):", c, r.stderr[-500:])
                 continue
         cobjs.append(o)
-    ho = os.path.join(BLD, t["harness"][:-4] + ".o")
+    ho = os.path.join(BLD, os.path.basename(t["harness"])[:-4] + ".o")
     cmd = [FLANG] + FFLAGS + t["cppdefs"] + inc + ["-module-dir", BLD, "-c", harness, "-o", ho]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         print("FAILED harness:"); print(r.stderr[-6000:]); return 1
     exe = os.path.join(OUT, t["exe"])
-    cmd = [FLANG, "-o", exe, ho] + objs + cobjs + ["-Wl,--unresolved-symbols=ignore-all"]
+    cmd = [FLANG, "-o", exe, ho] + objs + cobjs + t.get("link", []) + ["-Wl,--unresolved-symbols=ignore-all"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         print("FAILED link:"); print(r.stderr[-6000:]); return 1
-    print("built", exe, "from", len(order), "reference Fortran files")
+    nown = sum(1 for p in order if not p.startswith(SRC))
+    print("built", exe, "from", len(order) - nown, "reference Fortran files" + (" and %d of this repository's" % nown if nown else ""))
     return 0
 
 
