@@ -31,7 +31,7 @@ public :: get_use_virtual_temperature, get_reference_sea_level_press, get_surf_g
 public :: get_pk_bk, complete_robert_filter, complete_update_of_future
 public :: get_axis_id, spectral_diagnostics, get_initial_fields
 
-character(len=8), parameter :: default_advect_vert = 'second_centered', default_representation = 'spectral', default_hole_filling = 'off'
+character(len=32), parameter :: default_advect_vert = 'second_centered', default_representation = 'spectral', default_hole_filling = 'off'
 
 ! ---- spectral_dynamics_nml: the reference's variables and defaults (spectral_dynamics.F90:152-224)
 logical :: do_mass_correction = .true., do_water_correction = .true., do_energy_correction = .true., use_virtual_temperature = .false., &
