@@ -3,7 +3,7 @@
 #   usage: bash tools/publish_profiles.sh [round-tag, default r02]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 T=gpurun_out/prof_final
 for W in T85L40 T170L60 T85L40_moist; do
   S=$T/$W
