@@ -161,11 +161,14 @@ int isca_dyn_delta_t(isca_dyn_t *h, double *delta_t);
  * phase 1: Legendre analysis, spectral update, Legendre synthesis -> send buffer "inv"
  * phase 2: inverse FFT, fixer partial sums  -> 8 doubles to all-reduce (isca_dyn_reduce_buffer)
  * phase 3: fixers applied, time levels rotated.
+ * raw_filter_coeff /= 1 (Robert-Asselin-Williams, leapfrog.F90:88-105) ends the step with phases 5 and 6 instead of 3: phase 5 = the fixers,
+ *          the filter's adjustment of the new spectral level and the Legendre synthesis of the gradients taken from it -> send buffer
+ *          "raw" (which = 2: 2 L + 2 level-fields); phase 6 = their FFT, time levels rotated.
  * phase 4 (between 0 and 1, after the halo rows of the grid tracer have been exchanged and before the "fwd" all-to-all): the tracer's
  *          transport, on the handle's side stream, so that it runs under the exchange; a no-op without the tracer.
  * The host performs the all-to-all / all-reduce between phases (isca_amd/parallel.py). */
 int isca_dyn_step_phase(isca_dyn_t *h, int phase);
-int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv*/, void **send, void **recv,
+int isca_dyn_exchange_buffers(isca_dyn_t *h, int which /*0 fwd, 1 inv, 2 raw*/, void **send, void **recv,
                               size_t *bytes_per_peer);
 int isca_dyn_reduce_buffer(isca_dyn_t *h, void **buf, size_t *count);
 /* grid-tracer halo rows (the mpp_update_domains of fv_advection.F90:161-162,259): after phase 0 the host sends

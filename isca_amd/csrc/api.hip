@@ -168,8 +168,6 @@ static void check_config(const isca_dyn_config &c) {
   if (c.lat_max % 8) fail("lat_max must be a multiple of 8");
   if (c.num_levels > 64) fail("num_levels must be <= 64 (one wavefront lane per level in the spectral update)");
   if (!(c.raw_filter_coeff > 0.0 && c.raw_filter_coeff <= 1.0)) fail("raw_filter_coeff must be in (0, 1]");
-  if (c.raw_filter_coeff != 1.0 && c.world_size > 1)
-    fail("raw_filter_coeff /= 1 needs a third transform phase per step, which the sharded step does not have: world_size must be 1");
   if (c.robert_coeff < 0. || c.robert_coeff > 1.) fail("invalid robert_coeff");
   if (c.damping_order < 0 || c.damping_coeff < 0.) fail("invalid damping");
   if (c.damping_option < 0 || c.damping_option > 2)
@@ -190,7 +188,9 @@ static void check_config(const isca_dyn_config &c) {
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
   if (c.num_tracers > 1) {
-    if (c.world_size != 1) fail("more than one tracer: single rank only (the sharded step carries the sphum-like grid tracer only)");
+    for (int k = 1; k < c.num_tracers; ++k)
+      if (c.world_size != 1 && c.tracer_spectral[k] != 0)
+        fail("a 'spectral' tracer needs transforms of its own, which the sharded step does not exchange: world_size must be 1 (further 'grid' tracers are carried)");
     if (c.raw_filter_coeff != 1.0) fail("more than one tracer: raw_filter_coeff must be 1");
     for (int k = 1; k < c.num_tracers; ++k) {
       if (c.tracer_spectral[k] != 0 && c.tracer_spectral[k] != 1)
@@ -441,7 +441,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
-    d.halo_send = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I); d.halo_recv = dalloc<double>(h, (size_t)2 * 3 * g.L * 2 * g.I);
+    d.halo_send = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers)); d.halo_recv = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers));
     d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
     d.pend = dupload(h, std::vector<double>(PEND_ROWS, PEND_ROWS + 12));
     for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
@@ -929,22 +929,34 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
 // raw_filter_coeff /= 1: the reference completes the filter of the NEW level after its grid fields have been synthesised
 // (complete_robert_filter, spectral_dynamics.F90:1031), so u, v, T, ps, vor, div of that level stay those of the unadjusted spectral
 // state while the next step's gradients of T and ln ps (:855, :890) come from the adjusted one: a third transform phase.
-static void raw_filter_phase(isca_dyn *h, const StepScalars &sc) {
+// Two halves around the m -> lat exchange of the sharded model (on one rank the two Fourier views are the same buffer):
+// raw_phase_a adjusts the new spectral level and synthesises the four gradient fields as far as the Fourier rows of my wavenumbers,
+// raw_phase_b transforms the rows of my latitudes to the grid.
+static FieldList raw_field_list(isca_dyn *h) {
   const Geom &g = h->g;
   Dev &d = h->d;
-  { Timed t(h, "raw_adjust"); launch_raw_adjust(*h, sc.fut, h->stream); }
   FieldList fl;
   fl.nf = 4;
   double *gp[4] = {d.dxT, d.dyT, d.dxlp, d.dylp};
   int off = 0;
   for (int i = 0; i < 4; ++i) { fl.g[i] = gp[i]; fl.nlev[i] = i < 2 ? g.L : 1; fl.off[i] = off; fl.op[i] = OP_COSM; off += fl.nlev[i]; }
   fl.ncol = off;
-  const int C = col_pitch(fl.ncol);
+  return fl;
+}
+static int raw_pitch(const isca_dyn *h) { return col_pitch(2 * h->g.L + 2); }
+static void raw_phase_a(isca_dyn *h, const StepScalars &sc) {
+  const Geom &g = h->g;
+  Dev &d = h->d;
+  { Timed t(h, "raw_adjust"); launch_raw_adjust(*h, sc.fut, h->stream); }
+  const int C = raw_pitch(h);
   Timed t(h, "raw_gradients");
   launch_spec_gradient(g, d, d.ts[sc.fut], d.Si, C, 0, g.L, g.L, h->stream);
   launch_spec_gradient(g, d, d.lnps[sc.fut], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
   launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, rect_bounds(h), h->cfg.legendre_impl, h->stream);     // (rhomboidal: every n of every wavenumber)
-  launch_fft_inverse(g, d, fl, d.Fi_g, h->stream);
+}
+static void raw_phase_b(isca_dyn *h) {
+  Timed t(h, "raw_gradients_fft");
+  launch_fft_inverse(h->g, h->d, raw_field_list(h), h->d.Fi_g, h->stream);
 }
 // A 'spectral' tracer's step (update_tracers, spectral_dynamics.F90:1133-1154, with num_steps = 1): the physics tendency, minus the
 // horizontal advection of the current coefficients by the current winds (:1134), plus the second-centred vertical advection of the
@@ -969,14 +981,21 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
   launch_spec_tracer_update(*h, sc, e, dt_trs, h->stream);
   dev_s2g(h, d.trxs[sc.fut][e], d.trx[sc.fut][e], g.L, OP_NONE);
 }
-static void phase3(isca_dyn *h, const StepScalars &sc) {          // fixers, pointer rotation
-  if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-    { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
-    h->thermo_pending[sc.fut] = true;
-    if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
-  } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+// part 0: the whole phase; sharded with raw_filter_coeff /= 1 the exchange of the re-synthesised gradients' Fourier rows lies between
+// part 1 (fixers, the filter's adjustment, Legendre synthesis) and part 2 (their FFT, everything else, pointer rotation)
+static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          // fixers, pointer rotation
+  const bool raw = h->cfg.raw_filter_coeff != 1.0;
+  if (part != 2) {
+    if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
+      { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
+      h->thermo_pending[sc.fut] = true;
+      if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
+    } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
+    if (raw) raw_phase_a(h, sc);
+    if (part == 1) return;
+  }
   h->in_step = false;
-  if (h->cfg.raw_filter_coeff != 1.0) raw_filter_phase(h, sc);
+  if (raw) raw_phase_b(h);
   if (h->tracer_on && h->cfg.num_tracers > 1) {
     Timed t(h, "tracers_2_up");
     for (int e = 0; e + 1 < h->cfg.num_tracers; ++e) {     // tracers 2..num_tracers (their transport, if 'grid', ran beside tracer 1's)
@@ -1008,7 +1027,7 @@ static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
   upload_wave_matrices(h, sc.delta_t);
   phase0(h, sc);
   if (h->tracer_on) {   // the tracer's halo rows first (small), so that its transport runs under the all-to-all
-    const size_t n = (size_t)3 * g.L * 2 * g.I;
+    const size_t n = halo_doubles(g, h->cfg.num_tracers);
     { Timed t(h, "halo"); c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream); }
     phase_tracer(h, sc);
   }
@@ -1017,7 +1036,11 @@ static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
   { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
   phase2(h, sc);
   { Timed t(h, "all_reduce"); c.all_reduce_sum(h->d.red, 10, h->stream); }
-  phase3(h, sc);
+  if (h->cfg.raw_filter_coeff != 1.0) {    // a third exchange: the Fourier rows of the gradients re-synthesised from the adjusted level
+    phase3(h, sc, 1);
+    { Timed t(h, "all_to_all_raw"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * raw_pitch(h), h->stream); }
+    phase3(h, sc, 2);
+  } else phase3(h, sc);
 }
 
 extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
@@ -1126,7 +1149,7 @@ extern "C" int isca_dyn_comm_check(isca_dyn_t *h) {
   isca::Comm &c = *h->comm;
   const int P = g.P, me = g.rank;
   const size_t blk = (size_t)g.Ml * g.Jl * h->Cf;                   // doubles per peer of the forward exchange
-  const size_t nh = h->tracer_on ? (size_t)3 * g.L * 2 * g.I : 0;
+  const size_t nh = h->tracer_on ? halo_doubles(g, h->cfg.num_tracers) : 0;
   std::vector<double> send(blk * P), recv(blk * P, -1.0);
   for (int q = 0; q < P; ++q)
     for (size_t i = 0; i < blk; ++i) send[q * blk + i] = 1000.0 * me + q + 1e-3 * (double)(i % 997);
@@ -1217,7 +1240,11 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
     case 0: upload_wave_matrices(h, sc.delta_t); phase0(h, sc); break;
     case 1: phase1(h, sc); break;
     case 2: phase2(h, sc); break;
-    case 3: phase3(h, sc); break;
+    case 3:
+      if (h->g.P > 1 && h->cfg.raw_filter_coeff != 1.0) fail("step_phase(3): with raw_filter_coeff /= 1 a sharded step ends with phases 5, exchange 2, 6");
+      phase3(h, sc); break;
+    case 5: phase3(h, sc, 1); break;
+    case 6: phase3(h, sc, 2); break;
     case 4: phase_tracer(h, sc); break;
     default: fail("invalid phase");
   }
@@ -1226,16 +1253,16 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
 extern "C" int isca_dyn_exchange_buffers(isca_dyn_t *h, int which, void **send, void **recv, size_t *bytes_per_peer) {
   API_BEGIN
   const Geom &g = h->g;
-  const int C = which == 0 ? h->Cf : h->Ci;
+  const int C = which == 0 ? h->Cf : (which == 1 ? h->Ci : raw_pitch(h));
   if (which == 0) { *send = h->d.Ff_g; *recv = h->d.Ff_s; }
-  else if (which == 1) { *send = h->d.Fi_s; *recv = h->d.Fi_g; }
+  else if (which == 1 || which == 2) { *send = h->d.Fi_s; *recv = h->d.Fi_g; }      // 2: the RAW filter's gradient batch (2 L + 2 level-fields)
   else fail("invalid buffer id");
   *bytes_per_peer = (size_t)g.Ml * g.Jl * C * sizeof(double);
   API_END
 }
 extern "C" int isca_dyn_halo_buffers(isca_dyn_t *h, void **send_lo, void **send_hi, void **recv_lo, void **recv_hi, size_t *bytes) {
   API_BEGIN
-  const size_t n = (size_t)3 * h->g.L * 2 * h->g.I;
+  const size_t n = halo_doubles(h->g, h->cfg.num_tracers);
   *send_lo = h->d.halo_send; *send_hi = h->d.halo_send + n; *recv_lo = h->d.halo_recv; *recv_hi = h->d.halo_recv + n;
   *bytes = h->tracer_on ? n * sizeof(double) : 0;
   API_END

@@ -85,7 +85,7 @@ struct Dev {
   // tracers 2..num_tracers ([e] = tracer e+2): grid values, atmosphere_mod's copy, spectral coefficients (spectral tracers only),
   // and the column sums the transport kernel writes for tracer 1's water fixer (unused here)
   double *trx[2][3] = {}, *trx_atm[2][3] = {}, *trxs[2][3] = {}, *wcol_x = nullptr, *ph_dtqx[3] = {};
-  double *halo_send, *halo_recv;   // [2 sides][3][L][2][I] tracer halo rows (lo, hi)
+  double *halo_send, *halo_recv;   // [2 sides][3 + more grid tracers][L][2][I] tracer halo rows (lo, hi): q0 of tracer 1, u, v, q0 of the further grid tracers
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit: byte 0 this step, byte 1 the step before, byte 2 ...
   double *pend;              // [3][4] fixer scalars PENDING on time level 0 / 1 (mass factor, temperature correction, water factor, -); row 2: identity
@@ -109,6 +109,9 @@ struct Dev {
   double *t_surf = nullptr, *precip = nullptr;      // [Jl][I] mixed-layer temperature; rain rate of the last step
   double *moist_work = nullptr;                     // p_full/p_half/z_full/z_half of both time levels
 };
+
+// doubles per side of the tracer halo buffers: (q0, u, v) + one q0 per further grid tracer, two rows of every level each
+inline size_t halo_doubles(const Geom &g, int num_tracers) { return (size_t)(3 + (num_tracers > 1 ? num_tracers - 1 : 0)) * g.L * 2 * g.I; }
 
 struct KernelTimer {
   bool enabled = false;

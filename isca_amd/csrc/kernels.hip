@@ -1541,6 +1541,7 @@ struct TracerArgs {
   const double *tr_b, *tr_cur_rd;
   const double *pend_a, *pend_c;
   double rb;
+  size_t halo_q;                             // offset of this tracer's q0 rows in the halo buffers (0: tracer 1; 3 + e field blocks: tracer e + 2)
 };
 
 // tracer_source_sink (hs_forcing.F90:683-724): surface flux into the lowest level, linear sink
@@ -1586,7 +1587,12 @@ __device__ __forceinline__ double dpp_from_right(double v) {   // lane l receive
 // against 152 us alone).
 constexpr int TR_RB = 4;
 constexpr int TR_LDS_ROWS = TR_RB + 4 + 2;
-__global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
+// WPE: wavefronts per SIMD the register allocation must leave room for.  At lon_max = 512 a block is 8 wavefronts, two per SIMD: with
+// 135 registers it finds no SIMD with room beside the main stream's Legendre blocks (2 x 128 registers per SIMD); held to 128 (WPE = 4, 7
+// spilled dwords) the kernel runs beside them -- T170L60 step 1.155 -> 1.113 ms on the same box; at lon_max <= 256 (1 wavefront per
+// SIMD and block) the unconstrained allocation is the faster one (0.277 vs 0.281 ms at T85L40).  WPE = 5 (96 registers) spills 39 dwords: slower.
+template <int WPE>
+__global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TR_RB, NR = RB + 4;
   const int I = g.I, J = g.J, IM = I - 1;
@@ -1631,7 +1637,7 @@ __global__ __launch_bounds__(512) void k_tracer_horiz(Geom g, TracerArgs a) {
     const size_t q = (size_t)k * lev + c2r;
     const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + is;
     const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
-    const double *pq = loc[r] ? a.trp + q : hb + o, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
+    const double *pq = loc[r] ? a.trp + q : hb + o + a.halo_q, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
     tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
     tb[r] = *(loc[r] ? a.tr_b + q : pq); kw[r] = a.kmask[c2r];                 // what is pending on the previous level (halo rows arrive finished)
   }
@@ -1745,8 +1751,8 @@ __global__ void k_tracer_pack_halo(Geom g, TracerArgs a) {
   const size_t o = ((size_t)k * 2 + hr) * g.I + i, fs = (size_t)g.L * 2 * g.I;
   const int kw = a.kmask[c2];
   const double ps = mul_nc(a.ps_cur[c2], a.pend_c[PEND_FACTOR]);
-  dst[o] = tr_q0_of(a, g, k, tr_prev_of(a, k, kw, a.trp[q], a.tr_b[q]), tr_atm_of(a, k, kw, a.tratm_p[q]), ps);
-  dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q];
+  dst[o + a.halo_q] = tr_q0_of(a, g, k, tr_prev_of(a, k, kw, a.trp[q], a.tr_b[q]), tr_atm_of(a, k, kw, a.tratm_p[q]), ps);
+  if (a.halo_q == 0) { dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q]; }      // the winds once, with tracer 1
 }
 
 // PPM reconstruction of one cell from the column values around it (slope_z :505-568 with limiters, non-linear
@@ -1995,14 +2001,37 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   if (h.cfg.physics != 0) {     // sphum / the caller's tracer: the source is the physics tendency, q0 = tr(prev) + dt * dt_tracers (0 - (-1) x = x exactly)
     a.tratm_p = d.ph_dtq; a.flux = 0.0; a.rdamp = -1.0; a.pend_a = d.pend + PEND_IDENTITY;
   }
-  a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + (size_t)3 * h.g.L * 2 * h.g.I;
-  a.send_lo = d.halo_send; a.send_hi = d.halo_send + (size_t)3 * h.g.L * 2 * h.g.I;
+  a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + halo_doubles(h.g, h.cfg.num_tracers);
+  a.send_lo = d.halo_send; a.send_hi = d.halo_send + halo_doubles(h.g, h.cfg.num_tracers);
+  a.halo_q = 0;
   return a;
+}
+// tracer e + 2 of the field_table (a further 'grid' tracer): the same transport on its own time levels; the column sums go to a spare array
+// (only tracer 1 is water), the filter's `future` term is added at the end of the step (k_tracer_finish), its halo rows have their own block
+static TracerArgs further_tracer_args(const isca_dyn &h, const StepScalars &sc, const TracerArgs &a, int e) {
+  TracerArgs b = a;
+  b.trp = h.d.trx[sc.prev][e]; b.tr_cur = h.d.trx[sc.cur][e]; b.tr_fut = h.d.trx[sc.fut][e]; b.wcol = h.d.wcol_x; b.tr_part = nullptr;
+  b.tr_b = b.trp; b.tr_cur_rd = b.tr_cur; b.rb = 0.0; b.pend_a = h.d.pend + PEND_IDENTITY;        // (more than one tracer: the fixers are applied eagerly)
+  b.robert = tracer_robert(h, e + 1);
+  b.halo_q = (size_t)(3 + e) * h.g.L * 2 * h.g.I;
+  if (h.cfg.physics == 0) b.tratm_p = h.d.trx_atm[sc.prev][e];              // hs_forcing's source and sink act on every tracer (hs_forcing.F90:248-265)
+  else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
+  else { b.tratm_p = b.trp; b.flux = 0.0; b.rdamp = 0.0; }                   // idealized_moist_phys only has a tendency for sphum
+  return b;
 }
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   TracerArgs a = tracer_args(h, sc);
   hipLaunchKernelGGL(k_tracer_pack_halo, dim3(g.L, 4), dim3(g.I), 0, s, g, a);
+  for (int e = 0; e + 1 < h.cfg.num_tracers; ++e) {
+    if (h.cfg.tracer_spectral[e + 1]) continue;
+    hipLaunchKernelGGL(k_tracer_pack_halo, dim3(g.L, 4), dim3(g.I), 0, s, g, further_tracer_args(h, sc, a, e));
+  }
+}
+static void launch_tracer_horiz_kernel(const Geom &g, const TracerArgs &a, size_t ldsh, hipStream_t s) {
+  const dim3 grid((g.Jl + TR_RB - 1) / TR_RB, g.L), block(g.I);
+  if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);
+  else hipLaunchKernelGGL(k_tracer_horiz<1>, grid, block, ldsh, s, g, a);
 }
 static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64));
@@ -2025,20 +2054,14 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   TracerArgs a = tracer_args(h, sc);
   const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
-  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+  launch_tracer_horiz_kernel(g, a, ldsh, s);
   launch_tracer_vert_kernel(g, a, s);
   // further 'grid' tracers of the field_table (update_tracers' loop, spectral_dynamics.F90:1132,1155-1180): the same transport, their own
   // time levels; the column sums go to a spare array (only tracer 1 is water) and the filter's `future` term is added at the end of the step
   for (int e = 0; e + 1 < h.cfg.num_tracers; ++e) {
     if (h.cfg.tracer_spectral[e + 1]) continue;
-    TracerArgs b = a;
-    b.trp = h.d.trx[sc.prev][e]; b.tr_cur = h.d.trx[sc.cur][e]; b.tr_fut = h.d.trx[sc.fut][e]; b.wcol = h.d.wcol_x; b.tr_part = nullptr;
-    b.tr_b = b.trp; b.tr_cur_rd = b.tr_cur; b.rb = 0.0; b.pend_a = h.d.pend + PEND_IDENTITY;        // (more than one tracer: the fixers are applied eagerly)
-    b.robert = tracer_robert(h, e + 1);
-    if (h.cfg.physics == 0) b.tratm_p = h.d.trx_atm[sc.prev][e];              // hs_forcing's source and sink act on every tracer (hs_forcing.F90:248-265)
-    else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
-    else { b.tratm_p = b.trp; b.flux = 0.0; b.rdamp = 0.0; }                   // idealized_moist_phys only has a tendency for sphum
-    hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, b);
+    const TracerArgs b = further_tracer_args(h, sc, a, e);
+    launch_tracer_horiz_kernel(g, b, ldsh, s);
     launch_tracer_vert_kernel(g, b, s);
   }
 }
@@ -2138,7 +2161,7 @@ void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, con
   a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
   a.tr_b = q; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
   const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
-  hipLaunchKernelGGL(k_tracer_horiz, dim3((g.Jl + TR_RB - 1) / TR_RB, g.L), dim3(g.I), ldsh, s, g, a);
+  launch_tracer_horiz_kernel(g, a, ldsh, s);
 }
 void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
                         double *dummy_a, double *dummy_b, hipStream_t s) {

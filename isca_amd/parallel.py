@@ -93,7 +93,8 @@ class ShardedDynCore(dyncore.DynCore):
         cfg.stream = self._stream.cuda_stream
         super().__init__(cfg)
         self._bufs = []
-        for which in (0, 1):
+        self._raw = cfg.raw_filter_coeff != 1.0        # Robert-Asselin-Williams: a third exchange at the end of the step (gradient batch)
+        for which in (0, 1, 2) if self._raw else (0, 1):
             s, r, nbytes = self.exchange_buffers(which)
             tot = nbytes * cfg.world_size
             self._bufs.append((torch.as_tensor(_DevPtr(s, tot), device="cuda"), torch.as_tensor(_DevPtr(r, tot), device="cuda")))
@@ -145,7 +146,12 @@ class ShardedDynCore(dyncore.DynCore):
         exchange(self._bufs[1][0], self._bufs[1][1], self.group)    # m -> lat   (reverse_transpose_fourier)
         self.step_phase(2)                                          # inverse FFT + local fixer sums
         allreduce_sum(self._red, self.group)                        # global means
-        self.step_phase(3)                                          # fixers, time-level rotation
+        if self._raw:        # leapfrog_2level_B's future half changes the new spectral level: its gradients are synthesised again
+            self.step_phase(5)                                      # fixers, the filter's adjustment, Legendre synthesis of the gradients
+            exchange(self._bufs[2][0], self._bufs[2][1], self.group)
+            self.step_phase(6)                                      # their FFT, time-level rotation
+        else:
+            self.step_phase(3)                                      # fixers, time-level rotation
 
     def _agree(self, err):
         """error_mesg(..., FATAL) stops every PE: a rank whose band left valid_range_t must not leave the others in the next collective"""
@@ -244,6 +250,7 @@ class ShardedDynCore(dyncore.DynCore):
                 for nm in ("vors", "divs", "ts", "ln_ps"):
                     self.set(nm, one.get(nm, tl), tl)
                 names = ("ug", "vg", "tg", "psg") + (("tr", "tr_atm") if self.info("tracer") else ())
+                names += tuple(f"{nm}{k + 1}" for k in range(1, self.cfg.num_tracers if self.info("tracer") else 0) for nm in ("tr", "tr_atm"))
                 for nm in names:
                     self.set(nm, one.get(nm, tl)[..., j0:j0 + jl, :], tl)
             for nm in ("vorg", "divg", "dxT", "dyT", "dxlp", "dylp", "wg_full") + (("t_surf",) if self.cfg.physics == 1 else ()):
@@ -258,14 +265,16 @@ class _GatheredView:
     def __init__(self, sh: ShardedDynCore):
         import types
         self._sh = sh
-        self.cfg = types.SimpleNamespace(world_size=1, physics=sh.cfg.physics, num_tracers=min(sh.cfg.num_tracers, 1), tracer_spectral=[0])
-        self.tracer_names = list(sh.tracer_names)        # a sharded run carries the first (grid) tracer only
+        ntr = sh.cfg.num_tracers if sh.info("tracer") else 0
+        self.cfg = types.SimpleNamespace(world_size=1, physics=sh.cfg.physics, num_tracers=ntr, tracer_spectral=[0] * max(ntr, 1))
+        self.tracer_names = list(sh.tracer_names)        # a sharded run carries grid tracers only
         self.L, self.J, self.Jl, self.I, self.N1, self.M1 = sh.L, sh.J, sh.J, sh.I, sh.N1, sh.M1
         self._cache = {}
         for nm in ("vors", "divs", "ts", "ln_ps"):
             for tl in (0, 1):
                 self._cache[nm, tl] = sh.gather_spectral(nm, tl)
         grids = ["ug", "vg", "tg", "psg", "vorg", "divg", "wg_full", "surf_geopotential"] + (["tr", "tr_atm"] if sh.info("tracer") else []) + \
+                [f"{nm}{k + 1}" for k in range(1, ntr) for nm in ("tr", "tr_atm")] + \
                 (["t_surf"] if sh.cfg.physics == 1 else [])
         for nm in grids:
             for tl in (0, 1):

@@ -627,8 +627,9 @@ def test_T85L40_long_run_stays_physical():
 
 
 # ------------------------------------------------------------------ (d) latitude-band sharding on the device path
-@pytest.mark.parametrize("world,res,levels", [(2, "T21", 25), (4, "T21", 25), (8, "T85", 40)])
-def test_sharded_device_path_matches_single(world, res, levels):
+@pytest.mark.parametrize("world,res,levels,raw,tracers", [(2, "T21", 25, 1.0, 1), (4, "T21", 25, 1.0, 1), (8, "T85", 40, 1.0, 1), (2, "T21", 12, 0.7, 1),
+                                                          (4, "T21", 12, 0.53, 1), (2, "T21", 12, 1.0, 3), (4, "T21", 8, 1.0, 2)])
+def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     """N ranks share this box's GPU (gloo, host-staged exchange): the device kernels run with the sharded layouts
     (latitude bands, dealt wavenumbers, tracer halos) and must reproduce the single-rank model; the last case is the
     exact decomposition of the 8-GPU headline run (16 rows and 11 wavenumbers per rank).  Also: restart of a sharded run."""
@@ -637,7 +638,8 @@ def test_sharded_device_path_matches_single(world, res, levels):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + world),
            os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8" if world < 8 else "4",
-           "--res", res, "--levels", str(levels)]
+           "--res", res, "--levels", str(levels), "--raw", str(raw),     # raw /= 1: the Robert-Asselin-Williams filter's third exchange
+           "--tracers", str(tracers)]                                       # further grid tracers: halo rows of their own
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
