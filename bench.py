@@ -263,7 +263,7 @@ def main():
                     "ms_per_step": 1e3 * float(e1.item()) / a.steps, "scaling": "weak", "note": "independent ensemble members, one per GPU"}
     exchange_ms = None
     if world > 1:       # what each rank spent in the exchanges of a step (HIP events around the RCCL calls the library issues)
-        mine = {k: round(v, 5) for k, v in kt.items() if k in ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce")}
+        mine = {k: round(v, 5) for k, v in kt.items() if k in ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce", "all_to_all_raw")}
         mine["driver"] = "native RCCL" if getattr(core, "native", False) else f"torch.distributed ({backend})"
         exchange_ms = [None] * world
         dist.all_gather_object(exchange_ms, mine)

@@ -224,9 +224,10 @@ def test_golden_three_tracers(golden_dir):
     with pytest.raises(dyncore.IscaError, match="one block per tracer"):
         ext.dynamics(du, dv, dT, du)
     ref.close(); ext.close()
-    # a second tracer on a sharded run, with the RAW filter, or with an unknown representation is refused
-    with pytest.raises(dyncore.IscaError, match="single rank"):
-        make("T21", 8, num_tracers=2, world_size=2, rank=0)
+    # a spectral tracer on a sharded run (further grid tracers are carried there: test_sharded_device_path_matches_single), a second tracer
+    # with the RAW filter, or one with an unknown representation is refused
+    with pytest.raises(dyncore.IscaError, match="'spectral' tracer needs transforms of its own"):
+        make("T21", 8, num_tracers=2, tracer_spectral=[0, 1, 0, 0], world_size=2, rank=0)
     with pytest.raises(dyncore.IscaError, match="raw_filter_coeff must be 1"):
         make("T21", 8, num_tracers=2, raw_filter_coeff=0.7)
     with pytest.raises(dyncore.IscaError, match="numerical_representation"):

@@ -22,6 +22,11 @@ done
 # moist configuration (BASELINE configs[3] at T85L40): kernel stats of 300 steps after spin-up
 OUT=$TOP/T85L40_moist; mkdir -p $OUT
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python tools/dev/moist_bench.py > $OUT/bench_stats.log 2>&1
+i=0
+for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD"; do      # HBM traffic and issue counters of the moist column kernel
+  i=$((i+1))
+  timeout 200 rocprofv3 --kernel-trace --pmc $pm --output-format csv -d $OUT/pmc_$i -o p -- python tools/dev/moist_bench.py T85 40 300 short > $OUT/pmc_$i.log 2>&1
+done
 python tools/summarize_profiles.py $OUT
 # the plain bench line of the headline workload (no profiler attached)
 unset ISCA_BENCH_NO_EXTRA
