@@ -378,16 +378,18 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     {
       // retained (m,n) of my wavenumbers grouped by total wavenumber m+n, each group padded to a multiple of 4
+      // one descriptor per wavefront of k_spec_update: {n (-1: padding), ml, global m, total wavenumber of the block's wave matrix}:
+      // one 16-byte scalar load instead of the chain list entry -> m_local[ml] -> (m, n) arithmetic in front of the first state load
       std::vector<int> act;
       for (int Lw = 0; Lw < (cfg->triang_trunc ? cfg->num_spherical : cfg->num_spherical + cfg->fourier_inc * cfg->num_fourier); ++Lw) {
         for (int ml = 0; ml < g.Ml; ++ml) {
           const int m = h->h_m_local[ml], n = Lw - m * cfg->fourier_inc;
           if (m < 0 || n < 0 || n >= g.N1) continue;
-          if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) act.push_back(ml * g.N1 + n);
+          if (T.tri_mask[(size_t)n * g.M1 + m] != 0.0) { act.push_back(n); act.push_back(ml); act.push_back(m); act.push_back(Lw); }
         }
-        while (act.size() % 4) act.push_back(-1);
+        while ((act.size() / 4) % 4) { act.push_back(-1); act.push_back(0); act.push_back(0); act.push_back(Lw); }
       }
-      h->n_active = (int)act.size();
+      h->n_active = (int)(act.size() / 4);
       d.mn_active = dupload(h, act);
     }
     d.pk = dupload(h, T.pk); d.bk = dupload(h, T.bk); d.dpk = dupload(h, T.dpk); d.dbk = dupload(h, T.dbk);
@@ -806,6 +808,8 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
   API_END
 }
 
+static void raw_gradients_a(isca_dyn *h, int tl);
+static void raw_phase_b(isca_dyn *h);
 // vorg, divg and the gradient fields of the `current` level from its spectral state; the caller's grid
 // u, v, T, ps of that level are kept bit for bit (the synthesis would reproduce them only to roundoff)
 static void refresh_derived(isca_dyn *h) {
@@ -816,6 +820,10 @@ static void refresh_derived(isca_dyn *h) {
   dcopy(h, d.scratch_g[0], d.ug[tl], ng3); dcopy(h, d.scratch_g[1], d.vg[tl], ng3);
   dcopy(h, d.scratch_g[2], d.tg[tl], ng3); dcopy(h, d.scratch_g[3], d.psg[tl], ng2);
   synthesize_level(h, tl);
+  if (h->cfg.raw_filter_coeff != 1.0) {      // the running model takes the gradients of the (adjusted) level through the RAW phase's own
+    raw_gradients_a(h, tl);                  // kernels (raw_filter_phase): the same here, so that a restarted run continues bit for bit
+    raw_phase_b(h);
+  }
   dcopy(h, d.ug[tl], d.scratch_g[0], ng3); dcopy(h, d.vg[tl], d.scratch_g[1], ng3);
   dcopy(h, d.tg[tl], d.scratch_g[2], ng3); dcopy(h, d.psg[tl], d.scratch_g[3], ng2);
 }
@@ -944,15 +952,18 @@ static FieldList raw_field_list(isca_dyn *h) {
   return fl;
 }
 static int raw_pitch(const isca_dyn *h) { return col_pitch(2 * h->g.L + 2); }
-static void raw_phase_a(isca_dyn *h, const StepScalars &sc) {
+static void raw_gradients_a(isca_dyn *h, int tl) {        // gradients of T and ln ps of spectral level tl as far as the Fourier rows of my wavenumbers
   const Geom &g = h->g;
   Dev &d = h->d;
-  { Timed t(h, "raw_adjust"); launch_raw_adjust(*h, sc.fut, h->stream); }
   const int C = raw_pitch(h);
   Timed t(h, "raw_gradients");
-  launch_spec_gradient(g, d, d.ts[sc.fut], d.Si, C, 0, g.L, g.L, h->stream);
-  launch_spec_gradient(g, d, d.lnps[sc.fut], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
+  launch_spec_gradient(g, d, d.ts[tl], d.Si, C, 0, g.L, g.L, h->stream);
+  launch_spec_gradient(g, d, d.lnps[tl], d.Si, C, 2 * g.L, 2 * g.L + 1, 1, h->stream);
   launch_legendre_inverse(g, d, d.Si, d.Fi_s, C, rect_bounds(h), h->cfg.legendre_impl, h->stream);     // (rhomboidal: every n of every wavenumber)
+}
+static void raw_phase_a(isca_dyn *h, const StepScalars &sc) {
+  { Timed t(h, "raw_adjust"); launch_raw_adjust(*h, sc.fut, h->stream); }
+  raw_gradients_a(h, sc.fut);
 }
 static void raw_phase_b(isca_dyn *h) {
   Timed t(h, "raw_gradients_fft");

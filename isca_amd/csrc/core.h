@@ -69,7 +69,7 @@ struct Dev {
   double *pk, *bk, *dpk, *dbk;
   double *wave_mat_t;        // [num_spherical][L(k')][L(k)]  transposed wave matrices
   double *tau_t, *gamma_t;   // unused by the scan formulation; kept for checks
-  int *mn_active;            // [n_active] indices ml*N1+n of the retained (m,n) of my wavenumbers
+  int *mn_active;            // [n_active][4] {n, ml, m, total wavenumber} of the retained (m,n) of my wavenumbers, grouped by total wavenumber (padding: n = -1)
   double *impl_vec;          // [6][L+1]: ref_ln_p_half, ref_ln_p_full, h, dp_ref, ...
   double *tw;                // [I/2][2] twiddles exp(-2 pi i k/I)
   // ---- prognostic state

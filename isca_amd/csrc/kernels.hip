@@ -785,17 +785,18 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   double *ws = (double *)(xsb + 4 * 64);             // [L][L] transposed wave matrix of this block's total wavenumber
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int L = g.L;
-  // the list is grouped by total wavenumber (padded with -1), so the 4 wavefronts of a block share one matrix
-  const int mn0 = a.active[blockIdx.x * 4];
-  {
-    const int Lw = a.m_local[mn0 / g.N1] * a.fourier_inc + mn0 % g.N1;
-    const double *W = a.wave_t + (size_t)Lw * L * L;     // L*L may be odd: plain 8-byte copies
-    for (int i = threadIdx.x; i < L * L; i += 256) ws[i] = W[i];
-  }
-  const int mn_raw = a.active[blockIdx.x * 4 + wave];   // retained (m,n) only: outside the triangle the state stays zero
-  const bool idle = mn_raw < 0;                          // padding entry: helps with the copy, computes on (0,0), stores nothing
-  const int mn = idle ? 0 : mn_raw;
-  const int n = mn % g.N1, ml = mn / g.N1;
+  // the list is grouped by total wavenumber (padded), so the 4 wavefronts of a block share one matrix
+  const int4 ent = ((const int4 *)a.active)[blockIdx.x * 4 + wave];      // {n, ml, m, total wavenumber}: one scalar load
+  // the block's wave matrix -> LDS: the first eight values per thread are requested here, in front of the state loads, and stored
+  // below (a plain copy loop paid one round trip per 256 values -- seven in front of everything else at L = 40)
+  const double *W = a.wave_t + (size_t)ent.w * L * L;    // L*L may be odd: 8-byte copies
+  const int LL = L * L;
+  double wv[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) wv[r] = W[min(r * 256 + (int)threadIdx.x, LL - 1)];
+  const bool idle = ent.x < 0;                           // padding entry: helps with the copy, computes on (0,0), stores nothing
+  const int n = idle ? 0 : ent.x, ml = ent.y;            // retained (m,n) only: outside the triangle the state stays zero
+  const int mn = ml * g.N1 + n;
   const double *coef = a.coef;
   const bool act = lane < L && !idle;
   const int kk = (lane < L) ? lane : 0;
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
   const double eig = COEF(C_EIG, ml, n), dmp = COEF(C_DAMP, ml, n);   // read before the first store (scalar path)
   const double dmp_v = COEF(C_DAMP_VOR, ml, n), dmp_d = COEF(C_DAMP_DIV, ml, n);
-  const int mglob = a.m_local[ml];
+  const int mglob = ent.z;
   const double2 zero = make_double2(0., 0.);
   // unconditional loads (idx is valid for every lane) masked afterwards: `c ? lvalue : lvalue` on a double2 selects
   // an address and would push both operands into scratch memory
@@ -842,6 +843,17 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     if (a.dtvor) {                       // locals of the reference's step: stored only for the phase-by-phase API (get_state "s_dtvor" ...)
       if (act) { a.dtvor[idx] = dt_vor; a.dtdiv[idx] = dt_div; a.dtT[idx] = dt_t; }
       if (lane == 0 && !idle) a.dtlp[mn] = dt_lp;
+    }
+  }
+  for (int base = 0; base < LL; base += 8 * 256) {       // (a second pass of eight from L = 46 up)
+    if (base > 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) wv[r] = W[min(base + r * 256 + (int)threadIdx.x, LL - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int i = base + r * 256 + (int)threadIdx.x;
+      if (i < LL) ws[i] = wv[r];
     }
   }
   double2 dps, dts;

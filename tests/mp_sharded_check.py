@@ -68,6 +68,12 @@ def main():
     sh.step(4); sh2.step(4)
     same = all(np.array_equal(sh.get(k, tl), sh2.get(k, tl)) for k in ("ug", "vg", "tg", "psg", "tr", "vors", "divs", "ts", "ln_ps") + tuple(more) + (("t_surf",) if a.moist else ())
                for tl in (0, 1))
+    if not same:
+        for k in ("ug", "vg", "tg", "psg", "tr", "vors", "divs", "ts", "ln_ps"):
+            for tl in (0, 1):
+                d_ = np.max(np.abs(sh.get(k, tl) - sh2.get(k, tl)))
+                if d_ > 0:
+                    print(f"  rank {rank}: restart differs in {k}[{tl}] by {d_:.3e}", flush=True)
     flags = [None] * world
     dist.all_gather_object(flags, bool(same))
     if rank == 0:
