@@ -207,3 +207,8 @@ def read_restart(core: DynCore, directory: str, tracer_name: str | None = None):
                 raise IscaError("mixed_layer_init: resolution of mixed_layer.res does not match the namelist")
             core.set("t_surf", ts.reshape(-1, J, I)[0])
     core.refresh_derived()
+    # vorg, divg are restart variables of the reference too (spectral_dynamics.F90:1518-1519, read back :566-567): with raw_filter_coeff /= 1
+    # they belong to the new level BEFORE the filter's adjustment (:933-934 vs :1031), which the adjusted spectral state cannot give back
+    if "vorg" in sd and "divg" in sd:
+        core.set("vorg", np.asarray(sd["vorg"]).reshape(-1, L, J, I)[0])
+        core.set("divg", np.asarray(sd["divg"]).reshape(-1, L, J, I)[0])
