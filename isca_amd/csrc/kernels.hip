@@ -1160,6 +1160,21 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q] + tc_p; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
+#ifdef COLUMN_PREFETCH
+  // experiment: touch the input lines of the tile this CU will probably get next (block + gridDim/2), one 4-byte load per 128-byte line,
+  // so that its loads find them in L2 / the infinity cache while this block computes
+  int pf_sink = 0;
+  if (2 * blockIdx.x < gridDim.x) {
+    const size_t c2n = (size_t)(blockIdx.x + gridDim.x / 2) * 64;
+    const double *arr[10] = {a.u, a.v, a.t, a.up, a.vp, a.tp, a.vor, a.div, a.dxT, a.dyT};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int id = tid + 64 * r;                       // (array, level of my chunk, quarter of the 512-byte row)
+      const int qd = id & 3, li = (id >> 2) % CH, ar = (id >> 2) / CH;
+      if (ar < 10 && li < nk) pf_sink += *(const int *)(arr[ar] + c2n + (size_t)(k0 + li) * lev + 16 * qd);
+    }
+  }
+#endif
   // neighbours across the chunk boundary for the centred vertical fluxes
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
   if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q] + tc_c; }
@@ -1320,6 +1335,9 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     for (int ww = 0; ww < NW; ++ww) e += lds_e[ww];
     a.partials[2 * blockIdx.x] = s_ps;
     a.partials[2 * blockIdx.x + 1] = e;
+#ifdef COLUMN_PREFETCH
+    if (pf_sink == 0x7fffffff) a.partials[0] = 0.0;      // (keeps the touches alive)
+#endif
   }
 }
 
@@ -2304,12 +2322,15 @@ __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, c
   acc = fold(acc, __shfl_xor(acc, 32, 64));
   if ((t & 63) < 16) sh[t >> 6][c] = acc;
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NRED + 2; ++k) {
-    double x = sh[0][k];
-    for (int w = 1; w < NWV; ++w) x = k < NRED ? x + sh[w][k] : (k == NRED ? fmin(x, sh[w][k]) : fmax(x, sh[w][k]));
-    if (k < NRED) tot[k] = x; else if (k == NRED) tmin = x; else tmax = x;
+  if (t < NRED + 2) {                                 // one thread per value folds the wavefronts' results, in wavefront order
+    double x = sh[0][t];
+    for (int w = 1; w < NWV; ++w) x = fold(x, sh[w][t]);
+    sh[0][t] = x;                                     // (thread t is the only reader of column t)
   }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NRED; ++k) tot[k] = sh[0][k];
+  tmin = sh[0][NRED]; tmax = sh[0][NRED + 1];
 }
 // red[0..9] <- totals: for the all-reduce between the phases when world_size > 1, and for k_fixer_apply (the eager path)
 template <int NT>
