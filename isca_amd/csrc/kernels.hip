@@ -1160,21 +1160,6 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q] + tc_p; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
-#ifdef COLUMN_PREFETCH
-  // experiment: touch the input lines of the tile this CU will probably get next (block + gridDim/2), one 4-byte load per 128-byte line,
-  // so that its loads find them in L2 / the infinity cache while this block computes
-  int pf_sink = 0;
-  if (2 * blockIdx.x < gridDim.x) {
-    const size_t c2n = (size_t)(blockIdx.x + gridDim.x / 2) * 64;
-    const double *arr[10] = {a.u, a.v, a.t, a.up, a.vp, a.tp, a.vor, a.div, a.dxT, a.dyT};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int id = tid + 64 * r;                       // (array, level of my chunk, quarter of the 512-byte row)
-      const int qd = id & 3, li = (id >> 2) % CH, ar = (id >> 2) / CH;
-      if (ar < 10 && li < nk) pf_sink += *(const int *)(arr[ar] + c2n + (size_t)(k0 + li) * lev + 16 * qd);
-    }
-  }
-#endif
   // neighbours across the chunk boundary for the centred vertical fluxes
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
   if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q] + tc_c; }
@@ -1335,9 +1320,6 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
     for (int ww = 0; ww < NW; ++ww) e += lds_e[ww];
     a.partials[2 * blockIdx.x] = s_ps;
     a.partials[2 * blockIdx.x + 1] = e;
-#ifdef COLUMN_PREFETCH
-    if (pf_sink == 0x7fffffff) a.partials[0] = 0.0;      // (keeps the touches alive)
-#endif
   }
 }
 
