@@ -520,6 +520,10 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     constexpr int FD = 4, NTG = 3;                   // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): DESIGN.md
     a.RG = (a.NTP + NTG - 1) / NTG;
     const dim3 grid(leg_grid(g.Ml, a.CB * a.RG));
+    static const int fd = env_int("ISCA_LEG_FD", 0);       // measurement switch: ring depth 8 / 16 with one wavefront per SIMD
+    if (fd == 8 && a.KS % 8 == 0) hipLaunchKernelGGL((k_leg_fwd<8, NTG, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    else if (fd == 16 && a.KS % 16 == 0) hipLaunchKernelGGL((k_leg_fwd<16, NTG, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    else
     hipLaunchKernelGGL((k_leg_fwd<FD, NTG, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     TRACE_DUMP(trace_fwd)
   } else {
