@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries produced by tools/collect_profiles.sh (gpurun_out/prof_final) into profiles/ under this round's names.
-#   usage: bash tools/publish_profiles.sh [round-tag, default r02]
+#   usage: bash tools/publish_profiles.sh [round-tag, default r03]
 set -e
 cd "$(dirname "$0")/.."
 R=${1:-r03}
@@ -14,7 +14,7 @@ for W in T85L40 T170L60 T85L40_moist; do
     cp $S/pmc_summary.csv profiles/${R}_${W}_pmc_summary.csv
     if [ $W = T85L40 ]; then cp $S/pmc_traffic.json profiles/${R}_pmc_traffic.json; else cp $S/pmc_traffic.json profiles/${R}_${W}_pmc_traffic.json; fi
   fi
-  grep '^{' $S/bench_stats.log | tail -1 > profiles/${R}_${W}_bench_under_rocprof.json || true
+  if grep -q '^{' $S/bench_stats.log; then grep '^{' $S/bench_stats.log | tail -1 > profiles/${R}_${W}_bench_under_rocprof.json; fi      # the moist run prints no bench line
 done
 grep '^{' $T/bench_T85L40.json.log | tail -1 > profiles/${R}_T85L40_bench.json
 ls -la profiles/
