@@ -246,6 +246,7 @@ extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   moist_destroy(h->moist);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_fork0) hipEventDestroy(h->ev_fork0);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -444,7 +445,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
     d.halo_send = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers)); d.halo_recv = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers));
-    d.kmask = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
+    d.kmask = dalloc<int>(h, ng2 + 2); d.kmask_old = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
     d.pend = dupload(h, std::vector<double>(PEND_ROWS, PEND_ROWS + 12));
     for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
       for (int t = 0; t < 2; ++t) {
@@ -466,6 +467,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       else HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     }
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
     d.fv_dyy = dupload(h, T.fv_dyy); d.fv_dyp = dupload(h, T.fv_dyp); d.fv_dym = dupload(h, T.fv_dym);
@@ -501,6 +503,14 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // with the tracer on the main stream), at T85L40 the side stream saves 0.04 ms.  One rank only: a sharded step hides them under its exchange.
     h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr ||
                        (g.P == 1 && (size_t)g.L * g.Jl * g.I < 500000 && getenv("ISCA_TRACER_CONCURRENT") == nullptr);
+    // ISCA_TRACER_EARLY=1 (measurement switch): the horizontal tracer kernel starts beside the column kernel instead of after it.  At T170L60
+    // the main stream waits ~130 us for the side stream at the join, but starting the tracer earlier only moves the contention: the column
+    // kernel beside it takes 365 us instead of 258 and the step 0.979 against 0.974 ms (T85L40: 0.215 against 0.188) -- the step is bound by
+    // the sum of the bytes, not by the order of the kernels.  Off by default.
+    {
+      const char *e = getenv("ISCA_TRACER_EARLY");
+      h->tracer_early = e && e[0] == '1';
+    }
     // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need >= 4 latitude rows per rank and
     // >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be dropped without a word;
     // num_tracers = 0 is the way to run without one (field_table without tracers).
@@ -893,8 +903,18 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream); }
     h->phys_calls++;
   }
+  // fork: the tracer's vertical kernel needs the column kernel's vertical velocity; its horizontal kernel only state that exists when the
+  // step starts (the column kernel's mask word of the step BEFORE: kmask_old), so it can start beside the column kernel (tracer_early:
+  // measured, not faster).  Joined before the fixer sums.
+  const bool side = h->tracer_on && h->g.P == 1 && !h->tracer_serial, early = side && h->tracer_early;
+  std::swap(h->d.kmask, h->d.kmask_old);          // the column kernel reads the old word and writes the new one
+  if (early) {
+    HIP_CHECK(hipEventRecord(h->ev_fork0, h->stream));
+    HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork0, 0));
+    { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2, 0); }
+  }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
-  if (h->tracer_on) {   // fork: the tracer only needs the column kernel's outputs; joined before the fixer sums
+  if (h->tracer_on) {
     if (h->g.P > 1) {
       Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // the tracer itself runs once the halo rows are in
     } else if (h->tracer_serial) {
@@ -902,7 +922,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     } else {
       HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
       HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
+      { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2, early ? 1 : -1); }
       HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
     }
   }
@@ -1586,7 +1606,7 @@ extern "C" int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t
   const double *u = tmp.up(u_prev, nf), *v = tmp.up(v_prev, nf), *t = tmp.up(t_prev, nf), *q = tmp.up(q_prev, nf), *php = tmp.up(p_half_prev, nh),
                *pfp = tmp.up(p_full_prev, nf), *phc = tmp.up(p_half_cur, nh), *pfc = tmp.up(p_full_cur, nf), *zhc = tmp.up(z_half_cur, nh),
                *zfc = tmp.up(z_full_cur, nf), *lat = tmp.up(rad_lat, ncol);
-  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(3 * nh);
+  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(4 * nh);
   launch_moist_physics_on(*h, ncol, delta_t, gust, lat, u, v, t, q, php, pfp, phc, pfc, zhc, zfc, ts, du, dv, dt, dq, pr, wk, h->stream);
   d2h(h, t_surf, ts, ncol); d2h(h, dt_u, du, nf); d2h(h, dt_v, dv, nf); d2h(h, dt_t, dt, nf); d2h(h, dt_q, dq, nf);
   if (precip) d2h(h, precip, pr, ncol);

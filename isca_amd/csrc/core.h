@@ -88,6 +88,8 @@ struct Dev {
   double *halo_send, *halo_recv;   // [2 sides][3 + more grid tracers][L][2][I] tracer halo rows (lo, hi): q0 of tracer 1, u, v, q0 of the further grid tracers
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit: byte 0 this step, byte 1 the step before, byte 2 ...
+  int *kmask_old;            // the word of the step before (the column kernel reads it and writes kmask; phase0 swaps the two): what the horizontal
+                             // tracer kernel reads, so that it does not depend on this step's column kernel
   double *pend;              // [3][4] fixer scalars PENDING on time level 0 / 1 (mass factor, temperature correction, water factor, -); row 2: identity
   double *wcol;              // [5][Jl][I] column sums for the water fixer
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
@@ -132,7 +134,7 @@ struct isca_dyn {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipStream_t stream2 = nullptr;    // grid-tracer transport runs here, concurrently with the spectral pipeline
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_join = nullptr;
   int previous = 0, current = 0;
   long step_count = 0;
   bool have_state = false;
@@ -149,6 +151,7 @@ struct isca_dyn {
   int n_active = 0;
   bool fuse_synth = false;
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
+  bool tracer_early = false;        // the horizontal tracer kernel forks BEFORE the column kernel (ISCA_TRACER_EARLY=1; see spectral_dynamics_init)
   bool tracer_on = false;           // advect the grid tracer
   bool tracer_env_off = false;      // ISCA_NO_TRACER was set when the handle was created
   int cap_cols = 0;                 // capacity (level-fields) of the Fourier/spectral work buffers

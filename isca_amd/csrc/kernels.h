@@ -70,7 +70,7 @@ void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, doub
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 bool virtual_t_on(const isca_dyn &h);
 void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, double *tv, hipStream_t s);
-void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part = -1);
 void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s);
 void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s);
 void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, const double *dta, double delta_t, double robert, double raw,

@@ -1351,7 +1351,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
-  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.kmask_rd = d.kmask; a.psp_copy = d.psp_copy;
+  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.kmask_rd = d.kmask_old; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
@@ -1543,7 +1543,7 @@ struct TracerArgs {
   const double *ppm;                         // [6][L] pure-sigma PPM weights: slope A,B ; edge z1,z2,z3 ; (unused)
   const double *halo_lo, *halo_hi;           // [3 (q0,u,v)][L][2][I] rows j0-2,j0-1 / j0+Jl,j0+Jl+1 received from the neighbour bands
   double *send_lo, *send_hi;                 // same layout: my rows 0,1 / Jl-2,Jl-1
-  const int *kmask;
+  const int *kmask, *kmask_old;              // the column kernel's word of this step / of the step before (horizontal kernel, halo rows)
   double *wcol;
   double dx, dt, flux, rdamp, robert;
   double *tr_part;
@@ -1651,7 +1651,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     const double *hb = (jl < 0) ? a.halo_lo : a.halo_hi;
     const double *pq = loc[r] ? a.trp + q : hb + o + a.halo_q, *pu = loc[r] ? a.ua + q : hb + o + fs, *pv = loc[r] ? a.va + q : hb + o + 2 * fs;
     tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
-    tb[r] = *(loc[r] ? a.tr_b + q : pq); kw[r] = a.kmask[c2r];                 // what is pending on the previous level (halo rows arrive finished)
+    tb[r] = *(loc[r] ? a.tr_b + q : pq); kw[r] = a.kmask_old[c2r] << 8;                // what is pending on the previous level (halo rows arrive finished)
   }
   double psr[NR];
 #pragma unroll
@@ -1761,7 +1761,7 @@ __global__ void k_tracer_pack_halo(Geom g, TracerArgs a) {
   const size_t lev = (size_t)g.Jl * g.I, c2 = (size_t)jl * g.I + i, q = (size_t)k * lev + c2;
   double *dst = side ? a.send_hi : a.send_lo;
   const size_t o = ((size_t)k * 2 + hr) * g.I + i, fs = (size_t)g.L * 2 * g.I;
-  const int kw = a.kmask[c2];
+  const int kw = a.kmask_old[c2] << 8;
   const double ps = mul_nc(a.ps_cur[c2], a.pend_c[PEND_FACTOR]);
   dst[o + a.halo_q] = tr_q0_of(a, g, k, tr_prev_of(a, k, kw, a.trp[q], a.tr_b[q]), tr_atm_of(a, k, kw, a.tratm_p[q]), ps);
   if (a.halo_q == 0) { dst[o + fs] = a.ua[q]; dst[o + 2 * fs] = a.va[q]; }      // the winds once, with tracer 1
@@ -1996,7 +1996,7 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.ps_cur = d.psg[sc.cur]; a.ps_prev = d.psp_copy; a.wg = d.wg;   // psg(prev) storage is rewritten by the synthesis running concurrently
   a.trh = d.trh; a.tr_fut = d.tr[sc.fut]; a.tr_cur = d.tr[sc.cur];
   a.c = d.fv_c; a.cc = d.fv_cc; a.dy = d.fv_dy; a.dyy = d.fv_dyy; a.dyp = d.fv_dyp; a.dym = d.fv_dym;
-  a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.wcol = d.wcol;
+  a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.kmask_old = d.kmask_old; a.wcol = d.wcol;
   a.rcdx = d.fv_rcdx; a.rdyy = d.fv_rdyy; a.rcdy = d.fv_rcdy; a.rdy = d.fv_rdy; a.ppm = d.ppm_tab;
   a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
   a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
@@ -2062,11 +2062,13 @@ static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStr
   }
 #undef LT
 }
-void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+// part 0: tracer 1's horizontal kernel (needs nothing of this step's column kernel); part 1: everything after it; -1: both
+void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part) {
   const Geom &g = h.g;
   TracerArgs a = tracer_args(h, sc);
   const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
-  launch_tracer_horiz_kernel(g, a, ldsh, s);
+  if (part != 1) launch_tracer_horiz_kernel(g, a, ldsh, s);
+  if (part == 0) return;
   launch_tracer_vert_kernel(g, a, s);
   // further 'grid' tracers of the field_table (update_tracers' loop, spectral_dynamics.F90:1132,1155-1180): the same transport, their own
   // time levels; the column sums go to a spare array (only tracer 1 is water) and the filter's `future` term is added at the end of the step

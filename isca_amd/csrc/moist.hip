@@ -19,7 +19,7 @@ struct MoistArgs {
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
-  double *work;                         // [3][L+1][ncol] work arrays when they do not fit LDS
+  double *work;                         // [4][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3)
   double delta_t, dt_atmos, gust, albedo;
   double rough_mom, rough_heat, rough_moist;
   moist::SatTable sat;
@@ -36,10 +36,14 @@ struct MoistArgs {
 // the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the
 // grid layout.  LMAX only sizes the private arrays of the convection scheme.
 // A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
-// on its 64 columns where the chain allows it: wavefront 0 does convection + condensation while wavefront 1 does radiation,
-// surface fluxes and the sponge; they meet at one barrier, wavefront 0 adds wavefront 1's heating in the reference's order
-// (dt_tg = ((conv + cond) + rad) + sponge) and goes on with the boundary layer and the implicit diffusion.  With blockDim = 64
-// the same code runs the three parts one after the other.
+// on its 64 columns where the chain allows it: wavefront 0 does the convection while wavefront 1 does radiation, surface fluxes and
+// the sponge; they meet at one barrier, after which wavefront 0 runs the condensation -- storing dt_tg with wavefront 1's heating
+// added in the reference's order (dt_tg = ((conv + cond) + rad) + sponge) -- the boundary layer and the implicit diffusion.  With
+// blockDim = 64 the same code runs the parts one after the other.
+// Every pass over a level array that leaves the chip costs HBM time here (32 768 columns x 14 fields do not fit the L2s, so a re-read
+// is a miss: rocprofv3 counted 712 MB per launch for 147 MB of fields, r03 profile): values that have one reader are handed over in LDS
+// (the convection's deltas in the parcel's arrays), sums are formed where their result is stored (dt_tg above), known zeros are not
+// stored and re-read (dt_ug, dt_vg below the sponge), and the convection scheme keeps one private level array (Tv) instead of five.
 constexpr int MOIST_NX = 20;       // scalars handed from wavefront 1 to wavefront 0 through work array 0 (needs L + 1 >= MOIST_NX)
 // Phase timing for kernel experiments (tools/dev/moist_phase_times.py): built with -DMOIST_TIMING=p the kernel stamps wall_clock64 (10 ns
 // ticks) at the marks of phase p (1: convection + condensation, 2: radiation + surface flux + sponge, 3: after the barrier) and stores,
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
   // the radiation / sponge wavefront keeps its two level arrays and the scalars it hands over in the global work area, so that LDS
   // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
-  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s;
+  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
@@ -73,46 +77,20 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   double t_surf = 0.0, net_sw = 0.0, lw_down_surf = 0.0;
   moist::SurfFlux sf;
   MT_DECL
-  if (role == 0) {
-    // ---- convection (:862-880): deltas over the step, then rates
-    double rain, cape, cin;
-    int flag, klzb, klcl;
-    double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
-    const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
-    moist::qe_moist_convection<LMAX>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, dtT, dtq, rain, cape, cin, flag, klzb, klcl,
-                                     nullptr, nullptr, s, pc);
-    MT(1, 1)
-    double precip = rain / delta_t;
-    // ---- large-scale condensation on the convectively adjusted profile (:975-997); dt_tg = (0 + conv_dt_tg) + cond_dt_tg
-    double rain_ls;
-    moist::lscale_cond(a.sat, L,
-                       [&](int k, double &t, double &q, double &ct, double &cq) {      // the convection's deltas are read once, here
-                         ct = dtT[k * s]; cq = dtq[k * s];
-                         t = ct + tp[k * s]; q = cq + qp[k * s];
-                       },
-                       a.pf_p + c, a.ph_p + c, s,
-                       [&](int k, double td, double qd, double ct, double cq) {
-                         dtT[k * s] = ct / delta_t + td / delta_t;
-                         dtq[k * s] = cq / delta_t + qd / delta_t;
-                       },
-                       rain_ls);
-    precip = precip + rain_ls / delta_t;
-    if (a.precip) a.precip[c] = precip;
-    MT(1, 2) MT_STORE(1)
-  }
+  // ---- wavefront nroles-1: grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
   if (role == nroles - 1) {
-    // ---- grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
     const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
     t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
-    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, r0, r1, s, insolation, sw_tau_0, net_sw, lw_down_surf);
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, r0, r1, r3, s, insolation, sw_tau_0, net_sw, lw_down_surf);
     MT(2, 1)
     const size_t low = (size_t)(L - 1) * s;
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
     MT(2, 2)
-    for (int k = 0; k < L; ++k) { w2[k * sw] = 0.0; dtu[k * s] = 0.0; dtv[k * s] = 0.0; }
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, s, insolation, sw_tau_0, w2, sw);
+    for (int k = 0; k < L; ++k) w2[k * sw] = 0.0;
+    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; }       // below the sponge dt_ug, dt_vg stay zero until the diffusion: not stored
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, r3, s, w2, sw);
     MT(2, 3)
     // ---- Rayleigh sponge (:1228-1237): momentum tendencies in place, its heating into work array 1 (radiation is done with it)
     for (int k = 0; k < nray; ++k) r1[(size_t)k * s] = 0.0;
@@ -123,8 +101,39 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
 #pragma unroll
       for (int i = 0; i < MOIST_NX; ++i) r0[(size_t)i * s] = x[i];
     }
+    MT(2, 4) MT_STORE(2)
   }
-  if (role == nroles - 1) { MT(2, 4) MT_STORE(2) }
+  // ---- wavefront 0: convection (:862-880) and large-scale condensation on the convectively adjusted profile (:975-997).  The convection's
+  //      deltas stay where the parcel was (LDS, or the private arrays): the condensation is their only reader, and it leaves
+  //      (0 + conv_dt_tg) + cond_dt_tg in the same place for the diffusion below; dt_qg = (0 + conv) + cond goes to memory
+  double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
+  const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
+  if (role == 0) {
+    double rain, cape, cin;
+    int flag, klzb, klcl;
+    moist::qe_moist_convection<LMAX, false>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
+                                            klcl, nullptr, nullptr, pc.sw, pc);
+    MT(1, 1)
+    double precip = rain / delta_t;
+    double rain_ls;
+    moist::lscale_cond(a.sat, L,
+                       [&](int k, double &t, double &q, double &ct, double &cq) {
+                         ct = pc.wTp[k * pc.sw]; cq = pc.wrp[k * pc.sw];
+                         t = ct + tp[k * s]; q = cq + qp[k * s];
+                       },
+                       a.pf_p + c, a.ph_p + c, s,
+                       [&](int k, double td, double qd, double ct, double cq) {
+                         pc.wTp[k * pc.sw] = ct / delta_t + td / delta_t;
+                         dtq[k * s] = cq / delta_t + qd / delta_t;
+                       },
+                       rain_ls);
+    precip = precip + rain_ls / delta_t;
+#if !defined(MOIST_TIMING) || MOIST_TIMING != 2
+    if (a.precip) a.precip[c] = precip;
+#endif
+    MT(1, 2) MT_STORE(1)
+  }
+  // ---- the two wavefronts meet here; wavefront 0 goes on alone
   if (nroles == 2) {
     __syncthreads();
     if (role != 0) return;
@@ -136,36 +145,30 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     sf.b_star = x[13]; t_surf = x[14]; net_sw = x[15]; lw_down_surf = x[16];
   }
   MT(3, 0)
-  // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order
-  for (int k0 = 0; k0 < L; k0 += MP_U) {         // loads of a chunk first: a store to dtT may alias the next level's load for all the compiler knows
-    double t[MP_U], sp[MP_U];
-#pragma unroll
-    for (int i = 0; i < MP_U; ++i) {
-      t[i] = dtT[(size_t)min(k0 + i, L - 1) * s];
-      sp[i] = r1[(size_t)min(k0 + i, max(nray - 1, 0)) * s];
-    }
-#pragma unroll
-    for (int i = 0; i < MP_U; ++i) {
-      const int k = k0 + i;
-      if (k < L) {
-        double x = t[i] + w2[k * sw];
-        if (k < nray) x = x + sp[i];
-        dtT[(size_t)k * s] = x;
-      }
-    }
-  }
+  // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order (:880, :997, :1162, :1237), formed where it is read: by the boundary-layer depth
+  //      (lowest levels only) and by the momentum diffusion's downward sweep, which reads each level's parts before its e, f overwrite them
+  //      and stores the sum for the upward sweep.  dt_ug, dt_vg are zero below the sponge: known, not read.
+  const int nr1 = max(nray - 1, 0);
+  auto heat_in = [&](int k) {
+    const double sp = r1[(size_t)min(k, nr1) * s];
+    double x = pc.wTp[k * pc.sw] + w2[k * sw];
+    if (k < nray) x = x + sp;
+    return x;
+  };
+  auto du_in = [&](int k) { const double x = dtu[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
+  auto dv_in = [&](int k) { const double x = dtv[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
   MT(3, 1)
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
   {
-    const double h = moist::pbl_depth(a.dif, L, delta_t, tp, up, vp, s, dtT, dtu, dtv, s, a.zf_c + c, a.zh_c + c, s);
+    const double h = moist::pbl_depth_f(a.dif, L, delta_t, tp, up, vp, s, heat_in, du_in, dv_in, a.zf_c + c, a.zh_c + c, s);
     MT(3, 2)
     moist::PblProfile pbl;
     pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
     const moist::VdiffWork w{w0, w1, w2, sw};
     moist::VdiffSurf S;
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
-    moist::vert_diff_momentum(L, delta_t, up, vp, tp, s, moist::PblProfile::Km{pbl}, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
-                              sf.dtaudu_atm, sf.dtaudv_atm, dtu, dtv, dtT, s, nullptr, 0, w, S);
+    moist::vert_diff_momentum_f(L, delta_t, up, vp, tp, s, moist::PblProfile::Km{pbl}, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
+                                sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, heat_in, dtu, dtv, dtT, s, nullptr, 0, w, S);
     MT(3, 3)
     moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
     MT(3, 4)
@@ -383,6 +386,6 @@ void launch_t_surf_init(const isca_dyn &h, hipStream_t s) {
   hipLaunchKernelGGL(k_t_surf_init, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, h.g.I, h.d.rad_lat_l, h.cfg.moist.tconst,
                      h.cfg.moist.delta_T, h.d.t_surf);
 }
-size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 7 * (g.L + 1)); }
+size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 8 * (g.L + 1)); }
 
 }  // namespace isca

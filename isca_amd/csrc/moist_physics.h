@@ -153,34 +153,43 @@ struct GrayRadParams {
   double solar_constant = 1360.0, del_sol = 1.4, del_sw = 0.0, ir_tau_eq = 6.0, ir_tau_pole = 1.5, atm_abs = 0.0, odp = 1.0,
          sw_diff = 0.0, linear_tau = 0.1, wv_exponent = 4.0, solar_exponent = 4.0, diabatic_acce = 1.0;
 };
-// Downward pass: fills lw_down[0..L] (caller storage, unit stride) and lw_dtrans[0..L-1], returns the surface fluxes.
+// Downward pass: fills lw_down[0..L] (caller storage, stride sw), lw_dtrans[0..L-1] and sw_down[0..L] (the downward shortwave flux on
+// the half levels, which the reference evaluates again in the upward pass: here that pass reads it), returns the surface fluxes.
+// (p/p0)^wv_exponent and (p/p0)^solar_exponent are one pow when the two exponents are equal (the defaults: 4).
 MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, const double *p_half, int s,
-                         double *lw_down, double *lw_dtrans, int sw, double &insolation, double &sw_tau_0, double &net_surf_sw_down,
-                         double &surf_lw_down) {
+                         double *lw_down, double *lw_dtrans, double *sw_down, int sw, double &insolation, double &sw_tau_0,
+                         double &net_surf_sw_down, double &surf_lw_down) {
   const double sl = sin(lat), sl2 = sl * sl;
   const double p2 = (1. - 3. * sl2) / 4.;
   insolation = 0.25 * p.solar_constant * (1.0 + p.del_sol * p2 + p.del_sw * sl);
   sw_tau_0 = (1.0 - p.sw_diff * sl2) * p.atm_abs;
   double lw_tau_0 = p.ir_tau_eq + (p.ir_tau_pole - p.ir_tau_eq) * sl2;
   lw_tau_0 = lw_tau_0 * p.odp;
-  double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pow(p_half[0] / PSTD_MKS, p.wv_exponent));
+  const bool one_pow = p.solar_exponent == p.wv_exponent;
+  const double pw0 = pow(p_half[0] / PSTD_MKS, p.wv_exponent);
+  double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pw0);
   lw_down[0] = 0.;
-  double lwd = 0.;
+  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : pow(p_half[0] / PSTD_MKS, p.solar_exponent)));
+  double lwd = 0., swd_last = 0.;
   for (int k0 = 0; k0 < L; k0 += MP_U) {
-    double ph[MP_U], tk[MP_U], tau_n[MP_U];
+    double ph[MP_U], tk[MP_U], tau_n[MP_U], swd[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < L) ? k0 + i : L - 1;
       ph[i] = p_half[(k + 1) * s]; tk[i] = t[k * s];
     }
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i)
-      tau_n[i] = lw_tau_0 * (p.linear_tau * ph[i] / PSTD_MKS + (1.0 - p.linear_tau) * pow(ph[i] / PSTD_MKS, p.wv_exponent));
+    for (int i = 0; i < MP_U; ++i) {
+      const double pw = pow(ph[i] / PSTD_MKS, p.wv_exponent);
+      tau_n[i] = lw_tau_0 * (p.linear_tau * ph[i] / PSTD_MKS + (1.0 - p.linear_tau) * pw);
+      swd[i] = insolation * exp(-sw_tau_0 * (one_pow ? pw : pow(ph[i] / PSTD_MKS, p.solar_exponent)));
+    }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       if (k0 + i < L) {
         const double dtr = exp(-(tau_n[i] - tau_k));
         lw_dtrans[(k0 + i) * sw] = dtr;
+        sw_down[(k0 + i + 1) * sw] = swd[i]; swd_last = swd[i];
         const double b = STEFAN * pow4(tk[i]);
         lwd = lwd * dtr + b * (1. - dtr);
         lw_down[(k0 + i + 1) * sw] = lwd;
@@ -189,27 +198,24 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
     }
   }
   surf_lw_down = lwd;
-  const double sw_surf = insolation * exp(-sw_tau_0 * pow(p_half[L * s] / PSTD_MKS, p.solar_exponent));
-  net_surf_sw_down = sw_surf * (1. - albedo);
+  net_surf_sw_down = swd_last * (1. - albedo);
 }
 // Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, const double *p_half, int s,
-                       const double *lw_down, const double *lw_dtrans, int sw, double insolation, double sw_tau_0, double *tdt, int st) {
+                       const double *lw_down, const double *lw_dtrans, const double *sw_down, int sw, double *tdt, int st) {
   const double b_surf = STEFAN * pow4(t_surf);
-  const double ph_surf = p_half[L * s];
-  const double sw_up = albedo * (insolation * exp(-sw_tau_0 * pow(ph_surf / PSTD_MKS, p.solar_exponent)));
+  const double ph_surf = p_half[L * s], sw_surf = sw_down[L * sw];
+  const double sw_up = albedo * sw_surf;
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
-  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - insolation * exp(-sw_tau_0 * pow(ph_surf / PSTD_MKS, p.solar_exponent)));
+  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - sw_surf);
   double ph_n = ph_surf;
   for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
     double tk[MP_U], ph[MP_U], td[MP_U], swd[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      tk[i] = t[k * s]; ph[i] = p_half[k * s]; td[i] = tdt[k * st];
+      tk[i] = t[k * s]; ph[i] = p_half[k * s]; td[i] = tdt[k * st]; swd[i] = sw_down[k * sw];
     }
-    MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) swd[i] = insolation * exp(-sw_tau_0 * pow(ph[i] / PSTD_MKS, p.solar_exponent));
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
@@ -254,9 +260,12 @@ MP_HD double qe_get_lcl_temp(const QeParams &p, double value) {
   return p.lcl_temp_table[iv_floor] * w_ceil - p.lcl_temp_table[iv_floor - 1] * (w_ceil - 1);
 }
 
-template <int LMAX>
-struct QeColumn {            // work arrays of one column, 1-based (the parcel's Tp, rp: see QeParcel)
-  double Tv[LMAX + 2], Tref[LMAX + 2], qref[LMAX + 2], dT[LMAX + 2], dq[LMAX + 2];
+// Work arrays of one column, 1-based.  The parcel's Tp, rp live in caller storage (QeParcel) and the relaxation deltas dT, dq take that
+// storage over once the reference profiles have consumed the parcel (each level's Tp, rp are read before its dT, dq are written); the
+// reference profiles themselves are only kept when the caller wants them (WANT_REF: the host tests; the device kernel does not).
+template <int LMAX, bool WANT_REF>
+struct QeColumn {
+  double Tv[LMAX + 2], Tref[WANT_REF ? LMAX + 2 : 1], qref[WANT_REF ? LMAX + 2 : 1];
 };
 // The parcel's temperature and mixing ratio, written level by level in the ascent and read back by the reference profiles, live in
 // caller storage: wTp[(k-1)*sw], wrp[(k-1)*sw] for level k = 1..L (LDS on the device; in thread-private arrays every store of the
@@ -267,12 +276,16 @@ struct QeParcel {
   MP_HD double &rp(int k) const { return wrp[(k - 1) * sw]; }
 };
 
-template <int LMAX>
+// deltaT / deltaq may BE the parcel storage (deltaT == pc.wTp, deltaq == pc.wrp, so == pc.sw): the deltas are then left where they are.
+template <int LMAX, bool WANT_REF = true>
 MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, double dt, const double *Tin_, const double *qin_,
                                const double *p_full_, const double *p_half_, int s, double *deltaT, double *deltaq, double &rain,
                                double &cape_out, double &cin_out, int &convflag, int &kLZB_out, int &kLCL_out, double *Tref_out,
                                double *qref_out, int so, const QeParcel &pc) {
-  QeColumn<LMAX> c;
+  QeColumn<LMAX, WANT_REF> c;
+  auto dT = [&](int k) -> double & { return pc.wTp[(k - 1) * pc.sw]; };      // valid from the reference-profile pass on
+  auto dq = [&](int k) -> double & { return pc.wrp[(k - 1) * pc.sw]; };
+  auto set_ref = [&](int k, double tref, double qref) { if (WANT_REF) { c.Tref[k] = tref; c.qref[k] = qref; } };
   auto Tin = [&](int k) { return Tin_[(k - 1) * s]; };
   auto qin = [&](int k) { return qin_[(k - 1) * s]; };
   auto rin = [&](int k) { const double q = qin_[(k - 1) * s]; return q / (1.0 - q); };
@@ -286,7 +299,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   };
   auto to_model = [&](int k1, int k2) {                                   // set_profiles_to_full_model_values (:1034-1047)
     MP_UNROLL
-    for (int k = k1; k <= k2; ++k) { c.Tref[k] = Tin(k); c.qref[k] = qin(k); c.dT[k] = 0.; c.dq[k] = 0.; }
+    for (int k = k1; k <= k2; ++k) { set_ref(k, Tin(k), qin(k)); dT(k) = 0.; dq(k) = 0.; }
   };
   for (int k0 = 1; k0 <= L; k0 += MP_U) {               // chunks: the loads of MP_U levels are in flight together
     double tt[MP_U], qq[MP_U];
@@ -295,7 +308,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 + i;
-      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); c.dT[k] = 0.; c.dq[k] = 0.; pc.Tp(k) = tt[i]; pc.rp(k) = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }
+      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
     }
   }
   // ---- CAPE_calculation (:383-446)
@@ -437,21 +450,20 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         const int k = k0 + i;
         if (k <= L) {
           double tref = tp[i], qref = 0.0;
-          c.Tref[k] = tref;
           if (k >= kb) {
             const double eref = P.rhbm * pfv[i] * rp[i] / (rp[i] + (RDGAS / RVGAS));
-            const double r = qe_mixing_ratio(eref, pfv[i]);
+            const double r = qe_mixing_ratio(eref, pfv[i]);       // (the reference also stores it as the parcel's rp, which nothing reads again)
             qref = r / (1 + r);
-            pc.rp(k) = r; c.qref[k] = qref;
           }
-          if (k <= kmodel) { tref = ti[i]; qref = qi[i]; c.Tref[k] = tref; c.qref[k] = qref; c.dT[k] = 0.; c.dq[k] = 0.; }
+          if (k <= kmodel) { tref = ti[i]; qref = qi[i]; dT(k) = 0.; dq(k) = 0.; }
+          set_ref(k, tref, qref);
           if (k >= kb) {
-            const double dq = -(qi[i] - qref) * dt / P.tau_bm;
-            c.dq[k] = dq;
-            Pq = Pq + dq * (ph0[i] - ph1[i]);
-            const double dT = -(ti[i] - tref) * dt / P.tau_bm;
-            c.dT[k] = dT;
-            Pt = Pt + (CP_AIR / (HLV + QE_SMALL)) * dT * (ph1[i] - ph0[i]);
+            const double dqk = -(qi[i] - qref) * dt / P.tau_bm;
+            dq(k) = dqk;
+            Pq = Pq + dqk * (ph0[i] - ph1[i]);
+            const double dTk = -(ti[i] - tref) * dt / P.tau_bm;
+            dT(k) = dTk;
+            Pt = Pt + (CP_AIR / (HLV + QE_SMALL)) * dTk * (ph1[i] - ph0[i]);
           }
         }
       }
@@ -463,37 +475,37 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       if (Pq > Pt) {                                  // do_change_time_scale_deepconv (:992-1008)
         const double invtau_q = Pt / Pq / P.tau_bm;
         MP_UNROLL
-        for (int k = kLZB; k <= ks; ++k) c.dq[k] = P.tau_bm * invtau_q * c.dq[k];
+        for (int k = kLZB; k <= ks; ++k) dq(k) = P.tau_bm * invtau_q * dq(k);
         Pq = Pt;
       } else {                                        // do_change_Tref_deepconv (:957-988)
         double deltak = 0.;
         MP_UNROLL
-        for (int k = kLZB; k <= ks; ++k) deltak = deltak - (c.dT[k] + (HLV / CP_AIR) * c.dq[k]) * (ph(k + 1) - ph(k));
+        for (int k = kLZB; k <= ks; ++k) deltak = deltak - (dT(k) + (HLV / CP_AIR) * dq(k)) * (ph(k + 1) - ph(k));
         deltak = deltak / (ph(ks + 1) - ph(kLZB));
         MP_UNROLL
-        for (int k = kLZB; k <= ks; ++k) { c.Tref[k] = c.Tref[k] + deltak * P.tau_bm / dt; c.dT[k] = c.dT[k] + deltak; }
+        for (int k = kLZB; k <= ks; ++k) { if (WANT_REF) c.Tref[k] = c.Tref[k] + deltak * P.tau_bm / dt; dT(k) = dT(k) + deltak; }
       }
     } else if (Pt > 0) {
       // ---- do_shallow_convection (:800-840) with level_of_zero_precip (:844-888)
       int k = kLZB;
       bool found = false;
       while ((Pq < 0.) && (k <= ks)) {
-        Pq = Pq - c.dq[k] * (ph(k) - ph(k + 1)) / GRAV;
+        Pq = Pq - dq(k) * (ph(k) - ph(k + 1)) / GRAV;
         k = k + 1;
       }
       const int k_top = k - 1;
       if (Pq > 0.) found = true;
       if (k_top > kLZB) to_model(kLZB, k_top - 1);
       if (found) {                                    // change_Tref_LZB_shallowconv (:893-930)
-        const double cc = Pq * GRAV / (c.dq[k_top] * (ph(k_top + 1) - ph(k_top)));
-        c.dq[k_top] = c.dq[k_top] * cc;
-        c.dT[k_top] = c.dT[k_top] * cc;
+        const double cc = Pq * GRAV / (dq(k_top) * (ph(k_top + 1) - ph(k_top)));
+        dq(k_top) = dq(k_top) * cc;
+        dT(k_top) = dT(k_top) * cc;
         double deltak = 0.;
         MP_UNROLL
-        for (int kk = k_top; kk <= ks; ++kk) deltak = deltak + c.dT[kk] * (ph(kk) - ph(kk + 1));
+        for (int kk = k_top; kk <= ks; ++kk) deltak = deltak + dT(kk) * (ph(kk) - ph(kk + 1));
         deltak = deltak / (ph(ks + 1) - ph(k_top));
         if (k_top != ks)
-          for (int kk = k_top; kk <= ks; ++kk) { c.dT[kk] = c.dT[kk] + deltak; c.Tref[kk] = c.Tref[kk] + deltak * P.tau_bm / dt; }
+          for (int kk = k_top; kk <= ks; ++kk) { dT(kk) = dT(kk) + deltak; if (WANT_REF) c.Tref[kk] = c.Tref[kk] + deltak * P.tau_bm / dt; }
       } else {
         if (k_top == kLZB) to_model(ks, ks); else to_model(kLZB, k_top);
       }
@@ -507,12 +519,18 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     to_model(1, ks);
   }
   rain = Pq;
-  MP_UNROLL_ALL
-  for (int k = 1; k <= LMAX; ++k) {          // fixed trip count: the reads of the work arrays are issued together
-    if (k > L) break;
-    deltaT[(k - 1) * so] = c.dT[k]; deltaq[(k - 1) * so] = c.dq[k];
-    if (Tref_out) Tref_out[(k - 1) * so] = c.Tref[k];
-    if (qref_out) qref_out[(k - 1) * so] = c.qref[k];
+  if (deltaT != pc.wTp) {
+    MP_UNROLL_ALL
+    for (int k = 1; k <= LMAX; ++k) {          // fixed trip count: the reads of the work arrays are issued together
+      if (k > L) break;
+      deltaT[(k - 1) * so] = dT(k); deltaq[(k - 1) * so] = dq(k);
+    }
+  }
+  if (WANT_REF) {
+    for (int k = 1; k <= L; ++k) {
+      if (Tref_out) Tref_out[(k - 1) * so] = c.Tref[k];
+      if (qref_out) qref_out[(k - 1) * so] = c.qref[k];
+    }
   }
 }
 
@@ -702,8 +720,10 @@ MP_HD double mo_diff_t(const MoParams &mo, const DiffusivityParams &dp, double z
 }
 // pbl_depth (:364-444), do_simple: the height where the bulk Richardson number of the provisional profile first exceeds
 // rich_crit_pbl, searched upward from the lowest level.  Nothing is stored: each level is visited once.
-MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
-                       const double *tdt, const double *udt, const double *vdt, int st, const double *z_full, const double *z_half, int sz) {
+// tdt(k), udt(k), vdt(k): the tendencies so far as functions of the level (memory reads inside them must be unconditional)
+template <class TDT, class UDT, class VDT>
+MP_HD double pbl_depth_f(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
+                         TDT tdt, UDT udt, VDT vdt, const double *z_full, const double *z_half, int sz) {
   const double gcp = GRAV / CP_AIR;
   const double z_surf = z_half[L * sz];
   double tbot = 0.0, h1 = 0.0, rich1 = 0.0, h = 0.0;
@@ -713,7 +733,7 @@ MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const doub
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
       zf[i] = z_full[k * sz]; tt[i] = tm[k * s]; uu[i] = um[k * s]; vv[i] = vm[k * s];
-      const double a = tdt[k * st], b = udt[k * st], c = vdt[k * st];
+      const double a = tdt(k), b = udt(k), c = vdt(k);
       tt[i] = tt[i] + dt * a; uu[i] = uu[i] + dt * b; vv[i] = vv[i] + dt * c;
     }
     MP_UNROLL_ALL
@@ -730,6 +750,11 @@ MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const doub
     }
   }
   return h;
+}
+MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
+                       const double *tdt, const double *udt, const double *vdt, int st, const double *z_full, const double *z_half, int sz) {
+  return pbl_depth_f(dp, L, dt, tm, um, vm, s, [&](int k) { return tdt[k * st]; }, [&](int k) { return udt[k * st]; },
+                     [&](int k) { return vdt[k * st]; }, z_full, z_half, sz);
 }
 // diffusivity_pbl (:448-510) as a function of the interface: k_m, k_t on the interface above full level k (k >= 1; 0 at k = 0)
 struct PblProfile {
@@ -801,19 +826,24 @@ MP_HD void diff_surface(double mu_delt, double nu, double e_n1, double f_delt_n1
 }
 struct DownResult { double mu_delt_n, nu_n, e_n1, f1_delt_n1, f2_delt_n1, delta_1_n, delta_2_n; };
 // vert_diff_down_2 for the pair (x1, x2) with tendencies (d1, d2), diffusivity diff(k) on the interface above level k.
-template <class X1, class X2, class D1, class D2, class DIFF>
+// aux: a value per level the caller wants read in the load phase of the level's chunk and handed back in its store phase (NoAux: nothing)
+struct NoAux {
+  MP_HD double load(int) const { return 0.0; }
+  MP_HD void store(int, double) const {}
+};
+template <class X1, class X2, class D1, class D2, class DIFF, class AUX = NoAux>
 MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF diff, const double *t, int s, const double *p_half,
-                           const double *z_full, int sp, const VdiffWork &w) {
+                           const double *z_full, int sp, const VdiffWork &w, AUX aux = AUX()) {
   DownResult r;
   double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
   double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = p_half[0];
   for (int k0 = 0; k0 < L; k0 += MP_U) {
-    double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U], zr[MP_U];
+    double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U], zr[MP_U], ax[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // everything level k0+i needs from memory: its own tendencies, the fields of the level below
       const int k = (k0 + i < L) ? k0 + i : L - 1, kn = (k + 1 < L) ? k + 1 : L - 1;
       phn[i] = p_half[(k + 1) * sp]; tn[i] = t[kn * s]; zn[i] = z_full[kn * sp]; x1n[i] = x1(kn); x2n[i] = x2(kn);
-      dd1[i] = d1(k); dd2[i] = d2(k); zr[i] = diff.raw(kn);
+      dd1[i] = d1(k); dd2[i] = d2(k); zr[i] = diff.raw(kn); ax[i] = aux.load(k);
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // the diffusivities from what was loaded (branches, but no memory access behind them)
@@ -852,18 +882,31 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
         fl1_k = fl1_n; fl2_k = fl2_n; nu_k = nu_n; x1_k = x1n[i]; x2_k = x2n[i]; t_k = tn[i]; z_k = zn[i]; ph_k = ph_n;
       }
     }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      if (k0 + i < L) aux.store(k0 + i, ax[i]);
   }
   return r;
 }
 }  // namespace vd
 
 // uv_vert_diff (:560-623): dt_u, dt_v become the final tendencies, the dissipated kinetic energy is added to dt_t.
-template <class DIFFM>
-MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
-                              const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u,
-                              double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
-  const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return u[k * s]; }, [&](int k) { return v[k * s]; },
-                                         [&](int k) { return dt_u[k * st]; }, [&](int k) { return dt_v[k * st]; }, diff_m, t, s, p_half, z_full, sp, w);
+// du_in(k), dv_in(k), dt_in(k): the incoming tendencies as functions of the level (the device kernel knows dt_u, dt_v to be zero below the
+// sponge and forms dt_t from its parts; memory reads inside them must be unconditional); the final ones are stored to dt_u, dt_v, dt_t.
+// dt_in(k) is evaluated in the DOWNWARD sweep (it may read what that sweep's e, f then overwrite) and parked in dt_t for the upward one.
+template <class DTIN>
+struct DtPark {
+  DTIN in; double *dt_t; int st;
+  MP_HD double load(int k) const { return in(k); }
+  MP_HD void store(int k, double v) const { dt_t[k * st] = v; }
+};
+template <class DIFFM, class DUIN, class DVIN, class DTIN>
+MP_HD void vert_diff_momentum_f(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
+                                const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in,
+                                DTIN dt_in, double *dt_u, double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w,
+                                VdiffSurf &S) {
+  const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return u[k * s]; }, [&](int k) { return v[k * s]; }, du_in, dv_in, diff_m, t, s,
+                                         p_half, z_full, sp, w, DtPark<DTIN>{dt_in, dt_t, st});
   double delta_u_n = r.delta_1_n, delta_v_n = r.delta_2_n;
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f1_delt_n1, dtau_du, tau_u, 1.0, delta_u_n);
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f2_delt_n1, dtau_dv, tau_v, 1.0, delta_v_n);
@@ -875,7 +918,7 @@ MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double 
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      uk[i] = u[k * s]; vk[i] = v[k * s]; du0[i] = dt_u[k * st]; dv0[i] = dt_v[k * st]; dt0[i] = dt_t[k * st];
+      uk[i] = u[k * s]; vk[i] = v[k * s]; du0[i] = du_in(k); dv0[i] = dv_in(k); dt0[i] = dt_t[k * st];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -897,6 +940,13 @@ MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double 
       }
     }
   }
+}
+template <class DIFFM>
+MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
+                              const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u,
+                              double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
+  vert_diff_momentum_f(L, delt, u, v, t, s, diff_m, p_half, z_full, sp, tau_u, tau_v, dtau_du, dtau_dv, [&](int k) { return dt_u[k * st]; },
+                       [&](int k) { return dt_v[k * st]; }, [&](int k) { return dt_t[k * st]; }, dt_u, dt_v, dt_t, st, diss_heat, sh, w, S);
 }
 // vert_diff_down_2 for dry static energy and humidity + the Tri_surf hand-over (gcm_vert_diff_down :372-404)
 template <class DIFFT>

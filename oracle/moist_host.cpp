@@ -41,11 +41,11 @@ void mh_lscale_cond(int L, int ncol, const double *tin, const double *qin, const
 void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const double *albedo, const double *t_surf, const double *t,
                  const double *p_half, double *net_sw, double *lw_down_surf, double *tdt) {
   GrayRadParams p; p.atm_abs = atm_abs;
-  std::vector<double> lwd(L + 1), ltr(L);
+  std::vector<double> lwd(L + 1), ltr(L), swd(L + 1);
   for (int c = 0; c < ncol; ++c) {
     double ins, tau0;
-    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, ins, tau0, net_sw[c], lw_down_surf[c]);
-    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, ins, tau0, tdt + c, ncol);
+    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), swd.data(), 1, ins, tau0, net_sw[c], lw_down_surf[c]);
+    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), swd.data(), 1, tdt + c, ncol);
   }
 }
 // out: 21 doubles per column in the order of struct SurfFlux
