@@ -1606,7 +1606,7 @@ extern "C" int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t
   const double *u = tmp.up(u_prev, nf), *v = tmp.up(v_prev, nf), *t = tmp.up(t_prev, nf), *q = tmp.up(q_prev, nf), *php = tmp.up(p_half_prev, nh),
                *pfp = tmp.up(p_full_prev, nf), *phc = tmp.up(p_half_cur, nh), *pfc = tmp.up(p_full_cur, nf), *zhc = tmp.up(z_half_cur, nh),
                *zfc = tmp.up(z_full_cur, nf), *lat = tmp.up(rad_lat, ncol);
-  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(4 * nh);
+  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(5 * nh);
   launch_moist_physics_on(*h, ncol, delta_t, gust, lat, u, v, t, q, php, pfp, phc, pfc, zhc, zfc, ts, du, dv, dt, dq, pr, wk, h->stream);
   d2h(h, t_surf, ts, ncol); d2h(h, dt_u, du, nf); d2h(h, dt_v, dv, nf); d2h(h, dt_t, dt, nf); d2h(h, dt_q, dq, nf);
   if (precip) d2h(h, precip, pr, ncol);

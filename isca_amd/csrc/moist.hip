@@ -19,7 +19,7 @@ struct MoistArgs {
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
-  double *work;                         // [4][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3)
+  double *work;                         // [5][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3), the sponge's heating (4)
   double delta_t, dt_atmos, gust, albedo;
   double rough_mom, rough_heat, rough_moist;
   moist::SatTable sat;
@@ -36,10 +36,10 @@ struct MoistArgs {
 // the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the
 // grid layout.  LMAX only sizes the private arrays of the convection scheme.
 // A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
-// on its 64 columns where the chain allows it: wavefront 0 does the convection while wavefront 1 does radiation, surface fluxes and
-// the sponge; they meet at one barrier, after which wavefront 0 runs the condensation -- storing dt_tg with wavefront 1's heating
-// added in the reference's order (dt_tg = ((conv + cond) + rad) + sponge) -- the boundary layer and the implicit diffusion.  With
-// blockDim = 64 the same code runs the parts one after the other.
+// on its 64 columns where the chain allows it: wavefront 0 does the sponge, the convection and the condensation (66 + 8 us at T85L40) while
+// wavefront 1 does the radiation and the surface fluxes (70 us); they meet at one barrier, after which wavefront 0 goes on alone with the
+// boundary layer and the implicit diffusion (59 us), wavefront 1's heating entering dt_tg in the reference's order
+// (dt_tg = ((conv + cond) + rad) + sponge).  With blockDim = 64 the same code runs the parts one after the other.
 // Every pass over a level array that leaves the chip costs HBM time here (32 768 columns x 14 fields do not fit the L2s, so a re-read
 // is a miss: rocprofv3 counted 712 MB per launch for 147 MB of fields, r03 profile): values that have one reader are handed over in LDS
 // (the convection's deltas in the parcel's arrays), sums are formed where their result is stored (dt_tg above), known zeros are not
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
   // the radiation / sponge wavefront keeps its two level arrays and the scalars it hands over in the global work area, so that LDS
   // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
-  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s;
+  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s, *r4 = r0 + (size_t)4 * (L + 1) * s;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
@@ -89,12 +89,8 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
     MT(2, 2)
     for (int k = 0; k < L; ++k) w2[k * sw] = 0.0;
-    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; }       // below the sponge dt_ug, dt_vg stay zero until the diffusion: not stored
     moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, r3, s, w2, sw);
     MT(2, 3)
-    // ---- Rayleigh sponge (:1228-1237): momentum tendencies in place, its heating into work array 1 (radiation is done with it)
-    for (int k = 0; k < nray; ++k) r1[(size_t)k * s] = 0.0;
-    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r1, s);
     if (nroles == 2) {
       const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
                                   sf.dedq_atm, sf.dtaudu_atm, sf.dtaudv_atm, sf.u_star, sf.b_star, t_surf, net_sw, lw_down_surf, 0., 0., 0.};
@@ -109,6 +105,10 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
   const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
   if (role == 0) {
+    // ---- Rayleigh sponge (:1228-1237; here because the radiation wavefront is the longer of the two in front of the barrier): momentum
+    //      tendencies of the sponge levels in place (below them dt_ug, dt_vg stay zero until the diffusion: not stored), its heating into work array 4
+    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; r4[(size_t)k * s] = 0.0; }
+    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s);
     double rain, cape, cin;
     int flag, klzb, klcl;
     moist::qe_moist_convection<LMAX, false>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   //      and stores the sum for the upward sweep.  dt_ug, dt_vg are zero below the sponge: known, not read.
   const int nr1 = max(nray - 1, 0);
   auto heat_in = [&](int k) {
-    const double sp = r1[(size_t)min(k, nr1) * s];
+    const double sp = r4[(size_t)min(k, nr1) * s];
     double x = pc.wTp[k * pc.sw] + w2[k * sw];
     if (k < nray) x = x + sp;
     return x;
@@ -386,6 +386,6 @@ void launch_t_surf_init(const isca_dyn &h, hipStream_t s) {
   hipLaunchKernelGGL(k_t_surf_init, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, h.g.I, h.d.rad_lat_l, h.cfg.moist.tconst,
                      h.cfg.moist.delta_T, h.d.t_surf);
 }
-size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 8 * (g.L + 1)); }
+size_t moist_work_doubles(const Geom &g) { return (size_t)g.Jl * g.I * (size_t)(4 * g.L + 9 * (g.L + 1)); }
 
 }  // namespace isca

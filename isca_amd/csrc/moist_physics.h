@@ -855,8 +855,17 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
       const int k = k0 + i;
       if (k < L) {
         const double ph_n = phn[i];
-        const double mu = GRAV / (ph_n - ph_k);                       // compute_mu
         double nu_n = 0.0, e1, e2, fl1_n = 0.0, fl2_n = 0.0;
+        if (k < L - 1 && df[i] == 0.0 && nu_k == 0.0) {
+          // No diffusion across either interface of this level -- every level above the boundary layer, three quarters of the column: the
+          // general path below then computes nu = 0, a = c = -0, b = g = 1, e = 0 and f = the incoming tendencies with four divisions per level.
+          // The same values without them (a zero tendency may come out as +0 where the general path leaves -0).
+          e_prev = 0.0; f1_prev = dd1[i] + 0.0; f2_prev = dd2[i] + 0.0;
+          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
+          fl1_k = 0.0; fl2_k = 0.0; nu_k = 0.0; x1_k = x1n[i]; x2_k = x2n[i]; t_k = tn[i]; z_k = zn[i]; ph_k = ph_n;
+          continue;
+        }
+        const double mu = GRAV / (ph_n - ph_k);                       // compute_mu
         if (k < L - 1) {
           const double rho_half = 2.0 * ph_n / (RDGAS * (tn[i] + t_k));   // compute_nu, no virtual temperature
           nu_n = rho_half * df[i] / (z_k - zn[i]);
