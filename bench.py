@@ -100,7 +100,7 @@ def kernel_rooflines(kt, I, J, M1, N, L):
             b = nlf * (8.0 * I * J + 16.0 * M1 * J)                  # one grid pass + one truncated Fourier pass
             kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": b / (kt[nm] * 1e-3) / 1e9}
     if "moist_physics" in kt:                                        # 4 fields + 2 x 2 pressures + 2 heights in, 4 tendencies out
-        kern["moist_physics"] = {"bound": "hbm (latency-bound in practice: a dependent fp64 chain per column, DESIGN.md 9)", "ms": kt["moist_physics"],
+        kern["moist_physics"] = {"bound": "hbm (a dependent chain per column whose level arrays do not fit the L2s: every re-read is HBM latency; traffic = 3.7x the algorithmic bytes, DESIGN.md 11)", "ms": kt["moist_physics"],
                                  "achieved_GBs": 14.0 * field_bytes / (kt["moist_physics"] * 1e-3) / 1e9}
     return kern
 

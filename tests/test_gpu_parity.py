@@ -768,6 +768,24 @@ def test_lazy_fixers_equal_eager(monkeypatch, res, L, ext):
         assert np.array_equal(lazy_looked[key], eager[key]), key
 
 
+@pytest.mark.parametrize("eager", [False, True])
+def test_tracer_fork_before_column_kernel(monkeypatch, eager):
+    """ISCA_TRACER_EARLY=1 starts the tracer's horizontal kernel beside the column kernel instead of behind it (measured, not faster:
+    DESIGN.md 11).  It may, because that kernel reads the column kernel's level-count word of the step BEFORE (kmask_old): same state
+    bit for bit, with the pending fixers and with the eager ones (T42L25: large enough for the side stream)."""
+    def run(early):
+        monkeypatch.setenv("ISCA_TRACER_CONCURRENT", "1")
+        (monkeypatch.setenv("ISCA_TRACER_EARLY", "1") if early else monkeypatch.delenv("ISCA_TRACER_EARLY", raising=False))
+        (monkeypatch.setenv("ISCA_EAGER_FIXERS", "1") if eager else monkeypatch.delenv("ISCA_EAGER_FIXERS", raising=False))
+        dc = make("T42", 25); dc.cold_start(); dc.step(30)
+        out = {(k, tl): dc.get(k, tl) for k in ALL_STATE for tl in (0, 1)}
+        dc.close()
+        return out
+    late, early = run(False), run(True)
+    for key in late:
+        assert np.array_equal(late[key], early[key]), key
+
+
 @pytest.mark.parametrize("first,raw", [(1, 1.0), (9, 1.0), (7, 0.7)])
 def test_restart_is_bit_exact(tmp_path, first, raw):
     """run(N) == run(n1) + atmosphere_end + atmosphere_init(restart) + run(N - n1), bit for bit, through the
