@@ -14,11 +14,13 @@ struct MoistArgs {
   int ncol, L, I;                       // columns, levels, columns per latitude row (for rad_lat_row)
   const double *up, *vp, *tp, *qp;      // previous time level [L][ncol]
   const double *pf_p, *ph_p;            // pressures of the previous level (convection, condensation)
-  const double *pf_c, *ph_c, *zf_c, *zh_c;   // pressures and heights of the current level (everything else)
+    const double *pf_c, *ph_c; double *zf_c, *zh_c;   // pressures and heights of the current level (everything else)
   const double *rad_lat_row, *rad_lat_col;   // latitude by row (grid) or by column (caller fields)
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
+  const double *surf_geop;              // non-null: zf_c / zh_c hold the hydrostatic increments of k_moist_pressures and this kernel sums them (moist_heights_scan)
+  int ktop;
   double *work;                         // [5][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3), the sponge's heating (4)
   double delta_t, dt_atmos, gust, albedo;
   double rough_mom, rough_heat, rough_moist;
@@ -57,6 +59,28 @@ constexpr int MOIST_NX = 20;       // scalars handed from wavefront 1 to wavefro
 #define MT(p, i)
 #define MT_STORE(p)
 #endif
+// The hydrostatic sum, bottom-up, of one column: z_full / z_half arrive as the layers' increments (k_moist_pressures) and leave as heights; 8 levels of
+// increments requested together.  (Was a kernel of its own: 512 wavefronts, five memory round trips, 12 us; the radiation wavefront does it on the way.)
+__device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, double *z_full, double *z_half, size_t s) {
+  z_half[(size_t)L * s] = gh / GRAV;
+  for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
+    double zf[8], dz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      zf[i] = z_full[(size_t)k * s]; dz[i] = z_half[(size_t)k * s];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = k0 - i;
+      if (k >= 0) {
+        z_full[(size_t)k * s] = (gh + zf[i]) / GRAV;
+        if (k >= ktop) gh = gh + dz[i];
+        z_half[(size_t)k * s] = (k >= ktop) ? gh / GRAV : 0.0;
+      }
+    }
+  }
+}
 template <int LMAX, bool LDSW>
 __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
@@ -79,6 +103,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   MT_DECL
   // ---- wavefront nroles-1: grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
   if (role == nroles - 1) {
+    if (a.surf_geop) moist_heights_scan(a.surf_geop[c], L, a.ktop, a.zf_c + c, a.zh_c + c, (size_t)s);      // (its first reader is the surface flux below)
     const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
     t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
@@ -308,33 +333,6 @@ __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
     a.z_half[c + (size_t)k * s] = (k >= ktop) ? RDGAS * tk * (l1 - l0) : 0.0;
   }
 }
-// (2) the hydrostatic sum, bottom-up, one thread per column, 8 levels of increments requested together
-__global__ __launch_bounds__(64) void k_moist_heights(PressArgs a) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= a.ncol) return;
-  const int L = a.L;
-  const size_t c = (size_t)col, s = (size_t)a.ncol;
-  const int ktop = (a.pk[0] == 0.0) ? 1 : 0;
-  double gh = a.surf_geop[c];
-  a.z_half[c + (size_t)L * s] = gh / GRAV;
-  for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
-    double zf[8], dz[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = (k0 - i >= 0) ? k0 - i : 0;
-      zf[i] = a.z_full[c + (size_t)k * s]; dz[i] = a.z_half[c + (size_t)k * s];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = k0 - i;
-      if (k >= 0) {
-        a.z_full[c + (size_t)k * s] = (gh + zf[i]) / GRAV;
-        if (k >= ktop) gh = gh + dz[i];
-        a.z_half[c + (size_t)k * s] = (k >= ktop) ? gh / GRAV : 0.0;
-      }
-    }
-  }
-}
 void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
   const size_t lev = (size_t)h.g.Jl * h.g.I;
@@ -348,8 +346,7 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
     a.t[1] = d.tv;
   }
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
-  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_moist_heights, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
@@ -361,6 +358,7 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
   a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
   a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
+  a.surf_geop = d.surf_geop; a.ktop = (h.tab.pk[0] == 0.0) ? 1 : 0;
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
   a.work = zh_p + lev * (h.g.L + 1);
   a.delta_t = sc.delta_t;
@@ -375,7 +373,7 @@ void launch_moist_physics_on(const isca_dyn &h, int ncol, double delta_t, double
   MoistArgs a = moist_args(h);
   a.work = work;
   a.ncol = ncol; a.I = 1;
-  a.up = u; a.vp = v; a.tp = t; a.qp = q; a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
+  a.up = u; a.vp = v; a.tp = t; a.qp = q; a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = const_cast<double *>(zf_c); a.zh_c = const_cast<double *>(zh_c);      // (heights given: not summed, not written)
   a.rad_lat_row = nullptr; a.rad_lat_col = rad_lat;
   a.t_surf = t_surf; a.dtu = dtu; a.dtv = dtv; a.dtT = dtT; a.dtq = dtq; a.precip = precip;
   a.delta_t = delta_t; a.gust = gust;
