@@ -192,18 +192,23 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     const moist::VdiffWork w{w0, w1, w2, sw};
     moist::VdiffSurf S;
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
-    moist::vert_diff_momentum_f(L, delta_t, up, vp, tp, s, moist::PblProfile::Km{pbl}, a.ph_c + c, a.zf_c + c, s, tau_u, tau_v,
-                                sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, heat_in, dtu, dtv, dtT, s, nullptr, 0, w, S);
-    MT(3, 3)
-    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
+    {
+      const auto r = moist::vd::down_pair(L, delta_t, [&](int k) { return up[(size_t)k * s]; }, [&](int k) { return vp[(size_t)k * s]; }, du_in, dv_in,
+                                          moist::PblProfile::Km{pbl}, tp, s, a.ph_c + c, a.zf_c + c, s, w,
+                                          moist::DtPark<decltype(heat_in)>{heat_in, dtT, s});      // = vert_diff_momentum_f, its two halves
+      MT(3, 3)
+      moist::vert_diff_momentum_up_f(r, L, delta_t, up, vp, s, tau_u, tau_v, sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, dtu, dtv, dtT, s, nullptr, 0, w, S);
+    }
     MT(3, 4)
+    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
+    MT(3, 5)
     moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
-    MT(3, 5)
+    MT(3, 6)
     moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s);
   }
   a.t_surf[c] = t_surf;
-  MT(3, 6) MT_STORE(3)
+  MT(3, 7) MT_STORE(3)
 }
 
 // mixed_layer_init with prescribe_initial_dist (mixed_layer.F90:455-460): t_surf = tconst - delta_T (3 sin^2 lat - 1)/3

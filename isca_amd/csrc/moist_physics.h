@@ -902,6 +902,10 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
 // uv_vert_diff (:560-623): dt_u, dt_v become the final tendencies, the dissipated kinetic energy is added to dt_t.
 // du_in(k), dv_in(k), dt_in(k): the incoming tendencies as functions of the level (the device kernel knows dt_u, dt_v to be zero below the
 // sponge and forms dt_t from its parts; memory reads inside them must be unconditional); the final ones are stored to dt_u, dt_v, dt_t.
+template <class DUIN, class DVIN>
+MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, const double *u, const double *v, int s, double &tau_u, double &tau_v,
+                                   double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in, double *dt_u, double *dt_v, double *dt_t, int st,
+                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S);
 // dt_in(k) is evaluated in the DOWNWARD sweep (it may read what that sweep's e, f then overwrite) and parked in dt_t for the upward one.
 template <class DTIN>
 struct DtPark {
@@ -916,6 +920,14 @@ MP_HD void vert_diff_momentum_f(int L, double delt, const double *u, const doubl
                                 VdiffSurf &S) {
   const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return u[k * s]; }, [&](int k) { return v[k * s]; }, du_in, dv_in, diff_m, t, s,
                                          p_half, z_full, sp, w, DtPark<DTIN>{dt_in, dt_t, st});
+  vert_diff_momentum_up_f(r, L, delt, u, v, s, tau_u, tau_v, dtau_du, dtau_dv, du_in, dv_in, dt_u, dt_v, dt_t, st, diss_heat, sh, w, S);
+}
+// the surface closure and the upward sweep of uv_vert_diff (the second half of vert_diff_momentum_f: a function of its own so that a caller can
+// do -- or time -- the two halves separately)
+template <class DUIN, class DVIN>
+MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, const double *u, const double *v, int s, double &tau_u, double &tau_v,
+                                   double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in, double *dt_u, double *dt_v, double *dt_t, int st,
+                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
   double delta_u_n = r.delta_1_n, delta_v_n = r.delta_2_n;
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f1_delt_n1, dtau_du, tau_u, 1.0, delta_u_n);
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f2_delt_n1, dtau_dv, tau_v, 1.0, delta_v_n);

@@ -4,7 +4,7 @@ import os, sys, subprocess
 sys.path.insert(0, '/root/repo')
 MARKS = {1: ["qe_moist_convection", "lscale_cond"],
          2: ["gray_rad_down", "surface_flux", "zero + gray_rad_up", "rayleigh sponge"],
-         3: ["dt_tg sum", "pbl_depth", "pbl profile + vert_diff_momentum", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
+         3: ["dt_tg sum", "pbl_depth", "pbl profile + momentum down", "momentum up", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
 if len(sys.argv) > 1:
     import numpy as np
     from isca_amd import dyncore
