@@ -296,7 +296,25 @@ __global__ __launch_bounds__(FftCfg<NC>::R * 16) void k_fft_inv(Geom g, FieldLis
 // twiddles, same order as fft_row: bit-identical results.
 template <int NC> struct Fft3 {
   static constexpr int TPR = NC / 8, R = 256 / TPR, R2 = (NC == 128) ? 4 : 8, S3 = 8 * R2, NB2 = NC / R2, BF2 = NB2 / TPR, BF3 = (NC / 4) / TPR;
-  static constexpr int rs = NC + NC / 8 + 1;
+#ifndef FFT3_SWIZZLE
+#define FFT3_SWIZZLE 1
+#endif
+  static constexpr int rs = FFT3_SWIZZLE ? NC : NC + NC / 8 + 1;
+};
+// Where element e of row r lives (in double2 = 16-byte slots).  Padded layout (the generic kernels', round 2): r * (NC + NC/8 + 1) + e + e/8 -- every
+// READ of a row paid one extra LDS cycle (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.26-0.30; tools/dev/fft_lds_model.py reproduces 0.286: a read
+// group spans elements 0-3 and 12-15 of one row and 4-11 of the next, and the padding slot at element 8 shifts one onto another).  XOR swizzle, no
+// padding: the low three slot bits of e are XORed with bits 3..5 of e (the first pass's 8 lanes at a stride of 8 elements hit 8 slots) and with
+// the row (the transposed phase's 8 lanes on 8 rows do too), slot bit 3 with bit 3 of the row (its 16 lanes on 16 rows): any aligned run of 16
+// elements of a row still fills an aligned run of 16 slots.  Model: 0.024 forward / 0.091 inverse at lon_max = 256 (the reversed index N - k of the
+// merge is a run that straddles two blocks).
+template <int NC> struct FftRow {
+  int base, rx, rb3;
+  __device__ __forceinline__ explicit FftRow(int r) : base(r * Fft3<NC>::rs), rx(r & 7), rb3((r >> 3) & 1) {}
+  __device__ __forceinline__ int at(int e) const {
+    if (FFT3_SWIZZLE) return base + (e & ~15) + ((((e >> 3) ^ rb3) & 1) << 3) + ((e ^ (e >> 3) ^ rx) & 7);
+    return base + fpad(e);
+  }
 };
 template <int NC, bool INV, bool TWREG> struct FftTw {
   double2 w1[TWREG ? 8 : 1], w2[TWREG ? Fft3<NC>::BF2 : 1][TWREG ? Fft3<NC>::R2 : 1];
@@ -316,14 +334,14 @@ template <int NC, bool INV, bool TWREG> struct FftTw {
   __device__ __forceinline__ double2 p1(int j, int tr) const { if constexpr (TWREG) return w1[j]; else return get(twl, 2 * j * tr); }
   __device__ __forceinline__ double2 p2(int u, int j, int p) const { if constexpr (TWREG) return w2[u][j]; else return get(twl, 16 * j * p); }
 };
-// z[i] = element tr + TPR i in; transform out in the same layout.  `row` = the row's LDS storage.
-template <int NC, bool INV, bool TWREG> __device__ __forceinline__ void fft3_row(double2 (&z)[8], double2 *row, const FftTw<NC, INV, TWREG> &w, int tr) {
+// z[i] = element tr + TPR i in; transform out in the same layout.  `ix` = where the row's elements live in buf.
+template <int NC, bool INV, bool TWREG> __device__ __forceinline__ void fft3_row(double2 (&z)[8], double2 *buf, const FftRow<NC> &ix, const FftTw<NC, INV, TWREG> &w, int tr) {
   constexpr int TPR = Fft3<NC>::TPR, R2 = Fft3<NC>::R2, S3 = Fft3<NC>::S3, BF2 = Fft3<NC>::BF2, BF3 = Fft3<NC>::BF3;
   // pass 1: radix 8, stride 1, butterfly b = tr: inputs b + (NC/8) j = registers, outputs 8 b + j
   dftR<INV, 8>(z);
-  row[fpad(8 * tr)] = z[0];
+  buf[ix.at(8 * tr)] = z[0];
 #pragma unroll
-  for (int j = 1; j < 8; ++j) row[fpad(8 * tr + j)] = cmul(z[j], w.p1(j, tr));
+  for (int j = 1; j < 8; ++j) buf[ix.at(8 * tr + j)] = cmul(z[j], w.p1(j, tr));
   __builtin_amdgcn_wave_barrier();
   {  // pass 2: radix R2, stride 8, in place
     double2 v[BF2][R2];
@@ -332,16 +350,16 @@ template <int NC, bool INV, bool TWREG> __device__ __forceinline__ void fft3_row
     for (int u = 0; u < BF2; ++u) {
       const int p = (tr + TPR * u) >> 3;
 #pragma unroll
-      for (int j = 0; j < R2; ++j) v[u][j] = row[fpad(q + 8 * (p + (NC / (8 * R2)) * j))];
+      for (int j = 0; j < R2; ++j) v[u][j] = buf[ix.at(q + 8 * (p + (NC / (8 * R2)) * j))];
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < BF2; ++u) {
       const int p = (tr + TPR * u) >> 3;
       dftR<INV, R2>(v[u]);
-      row[fpad(q + 8 * (R2 * p))] = v[u][0];
+      buf[ix.at(q + 8 * (R2 * p))] = v[u][0];
 #pragma unroll
-      for (int j = 1; j < R2; ++j) row[fpad(q + 8 * (R2 * p + j))] = cmul(v[u][j], w.p2(u, j, p));
+      for (int j = 1; j < R2; ++j) buf[ix.at(q + 8 * (R2 * p + j))] = cmul(v[u][j], w.p2(u, j, p));
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -352,7 +370,7 @@ template <int NC, bool INV, bool TWREG> __device__ __forceinline__ void fft3_row
     double2 v[4];
     const int q = tr + TPR * u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = row[fpad(q + S3 * j)];
+    for (int j = 0; j < 4; ++j) v[j] = buf[ix.at(q + S3 * j)];
     dftR<INV, 4>(v);
     z[u] = v[0];
 #pragma unroll
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(256) void k_fft_fwd3(Geom g, FieldList fl, const do
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = src[tr + TPR * i];
   };
-  double2 *row = buf + r * rs;
+  const FftRow<NC> ix(r), ixr(rr);
   int item = fft_first_item();
   if (item < NG) request(item, zn, scale_n);
   __syncthreads();                                     // twl, slot
@@ -403,9 +421,9 @@ __global__ __launch_bounds__(256) void k_fft_fwd3(Geom g, FieldList fl, const do
 #pragma unroll
     for (int i = 0; i < 8; ++i) z[i] = make_double2(zn[i].x * scale_n, zn[i].y * scale_n);
     if (item + (int)gridDim.x < NG) request(item + gridDim.x, zn, scale_n);       // in flight during the transform
-    fft3_row<NC, false, TWREG>(z, row, w, tr);
+    fft3_row<NC, false, TWREG>(z, buf, ix, w, tr);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) row[fpad(tr + TPR * i)] = z[i];
+    for (int i = 0; i < 8; ++i) buf[ix.at(tr + TPR * i)] = z[i];
     __syncthreads();
     // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I
     const int cc = gx * R + rr;
@@ -413,8 +431,8 @@ __global__ __launch_bounds__(256) void k_fft_fwd3(Geom g, FieldList fl, const do
     for (int i = 0; i < 8; ++i) {
       const int m = t / R + TPR * i;
       if (m < g.M1) {
-        const double2 zk = buf[rr * rs + fpad(m)];
-        const double2 zc = cconj(buf[rr * rs + fpad((NC - m) & (NC - 1))]);
+        const double2 zk = buf[ixr.at(m)];
+        const double2 zc = cconj(buf[ixr.at((NC - m) & (NC - 1))]);
         const double2 e = cscale(0.5, cadd(zk, zc));
         const double2 dd = csub(zk, zc);
         const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
 #pragma unroll
     for (int i = 0; i < 8; ++i) X[i] = *(const double2 *)(Fg + ((size_t)slot[t / R + TPR * i] * g.Jl + jl) * C + 2 * ccl);
   };
-  double2 *row = buf + r * rs;
+  const FftRow<NC> ix(r), ixr(rr);
   int item = fft_first_item();
   if (item < NG) request(item, Xn);
   for (; item < NG; item += gridDim.x) {
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
         const int m = t / R + TPR * i;
         double2 x = (m < g.M1 && cc < fl.ncol) ? Xn[i] : make_double2(0., 0.);
         if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
-        buf[rr * rs + fpad(m)] = x;
+        buf[ixr.at(m)] = x;
       }
     }
     if (item + (int)gridDim.x < NG) request(item + gridDim.x, Xn);               // in flight during the transform
@@ -471,14 +489,14 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = tr + TPR * i;
-      const double2 xk = row[fpad(k)];
-      const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(row[fpad(NC - k)]);
+      const double2 xk = buf[ix.at(k)];
+      const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(buf[ix.at(NC - k)]);
       const double2 e = cadd(xk, xc);
       const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
       z[i] = make_double2(e.x - o.y, e.y + o.x);
     }
     __builtin_amdgcn_wave_barrier();
-    fft3_row<NC, true, TWREG>(z, row, w, tr);
+    fft3_row<NC, true, TWREG>(z, buf, ix, w, tr);
     const int c = gx * R + r;
     if (c < fl.ncol) {
       int f = 0;

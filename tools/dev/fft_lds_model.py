@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""LDS bank-conflict model of k_fft_fwd3 / k_fft_inv3 (MI355X_MICROARCH.md "LDS": ds_read_b128 = 4 lane groups of 16 in the interleave below,
+"""LDS bank-conflict model of k_fft_fwd3 / k_fft_inv3 (the XOR swizzle at the end of the output is what the kernels use since round 3: FftRow in kernels.hip)
+LDS bank-conflict model of k_fft_fwd3 / k_fft_inv3 (MI355X_MICROARCH.md "LDS": ds_read_b128 = 4 lane groups of 16 in the interleave below,
 bank slot = (byte address / 16) mod 16; ds_write_b128 = 8 groups of 8 contiguous lanes, slot = (address / 16) mod 8; an extra distinct
 address on a busy slot costs one LDS cycle).  Enumerates every b128 access of one work item for a row layout addr(row, e) = row * RS + pad(e)
 and prints extra cycles / base cycles -- the ratio SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE should approach.  usage: fft_lds_model.py [NC]"""
@@ -87,3 +88,11 @@ if __name__ == "__main__":
     print("best layouts (extra cycles, RS, shift, mul):", best[:8])
     e, RS, sh, mul = best[0]
     evaluate(lambda row, x: row * RS + x + (x >> sh) * mul, True)
+    # XOR swizzle (no padding: row pitch NC): the low three slot bits of element e are XORed with bits 3..5 of e and with the row, its
+    # slot bit 3 with bit 3 of the row
+    def swz(row, e):
+        low = (e ^ (e >> 3) ^ row) & 7
+        b3 = ((e >> 3) ^ (row >> 3)) & 1
+        return row * NC + (e & ~15) + (b3 << 3) + low
+    print("XOR swizzle, row pitch NC:")
+    evaluate(swz, True)
