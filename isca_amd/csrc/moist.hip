@@ -34,9 +34,9 @@ struct MoistArgs {
   int do_damping;
 };
 
-// Three work arrays of L+1 levels per column (radiation: lw_down, lw_dtrans, its heating; diffusion: e, f_1, f_2) live in LDS when
-// the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41), else in a global buffer with the
-// grid layout.  LMAX only sizes the private arrays of the convection scheme.
+// Three work arrays of L+1 levels per column (0, 1: the parcel, then the convection's deltas, then the diffusion's e, f_1; 2: the radiative
+// heating, then f_2) live in LDS when the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41); up to
+// L = 63 arrays 0 and 1 do and array 2 is a global buffer with the grid layout; beyond that all three are.  LMAX only sizes the private arrays of the convection scheme.
 // A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
 // on its 64 columns where the chain allows it: wavefront 0 does the sponge, the convection and the condensation (66 + 8 us at T85L40) while
 // wavefront 1 does the radiation and the surface fluxes (70 us); they meet at one barrier, after which wavefront 0 goes on alone with the
@@ -81,16 +81,18 @@ __device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, d
     }
   }
 }
-template <int LMAX, bool LDSW>
+template <int LMAX, int NLDS>      // NLDS: how many of the three work arrays live in LDS (3, 2: arrays 0 and 1, or 0)
 __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
+  constexpr bool LDSW = NLDS >= 2;
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
   const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nroles = blockDim.x >> 6;
   const int col = min(blockIdx.x * 64 + lane, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
   const int L = a.L, s = a.ncol;
   const size_t c = (size_t)col;
-  const int sw = LDSW ? 64 : a.ncol;
+  const int sw = LDSW ? 64 : a.ncol, sw2 = (NLDS == 3) ? 64 : a.ncol;
   double *w0 = LDSW ? lds_work + lane : a.work + c;
-  double *w1 = w0 + (size_t)(L + 1) * sw, *w2 = w1 + (size_t)(L + 1) * sw;
+  double *w1 = w0 + (size_t)(L + 1) * sw;
+  double *w2 = (NLDS == 3) ? w1 + (size_t)(L + 1) * sw : a.work + c + (size_t)2 * (L + 1) * a.ncol;
   // the radiation / sponge wavefront keeps its two level arrays and the scalars it hands over in the global work area, so that LDS
   // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
   double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s, *r4 = r0 + (size_t)4 * (L + 1) * s;
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
     MT(2, 2)
-    for (int k = 0; k < L; ++k) w2[k * sw] = 0.0;
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, r3, s, w2, sw);
+    for (int k = 0; k < L; ++k) w2[k * sw2] = 0.0;
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, r3, s, w2, sw2);
     MT(2, 3)
     if (nroles == 2) {
       const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   const int nr1 = max(nray - 1, 0);
   auto heat_in = [&](int k) {
     const double sp = r4[(size_t)min(k, nr1) * s];
-    double x = pc.wTp[k * pc.sw] + w2[k * sw];
+    double x = pc.wTp[k * pc.sw] + w2[k * sw2];
     if (k < nray) x = x + sp;
     return x;
   };
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     MT(3, 2)
     moist::PblProfile pbl;
     pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
-    const moist::VdiffWork w{w0, w1, w2, sw};
+    const moist::VdiffWork w{w0, w1, w2, sw, sw2};
     moist::VdiffSurf S;
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
     {
@@ -293,12 +295,15 @@ static MoistArgs moist_args(const isca_dyn &h) {
 static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
   const bool two = a.L + 1 >= MOIST_NX && !getenv("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
   const dim3 grid((a.ncol + 63) / 64), block(two ? 128 : 64);
-  const size_t lds = (size_t)3 * 64 * (a.L + 1) * sizeof(double);
-  const bool in_lds = lds <= 65536 && !getenv("ISCA_MOIST_GLOBAL_WORK");
+  const size_t lds1 = (size_t)64 * (a.L + 1) * sizeof(double);        // one work array of a block
+  const bool glob = getenv("ISCA_MOIST_GLOBAL_WORK") != nullptr;
+  int nlds = glob ? 0 : (3 * lds1 <= 65536 ? 3 : (2 * lds1 <= 65536 ? 2 : 0));            // L <= 41: all three; L <= 63: arrays 0 and 1 (parcel / deltas / e, f1)
+  if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);      // (tests: the variants of larger level counts at a small one)
 #define LM(N)                                                                                          \
   do {                                                                                                 \
-    if (in_lds) hipLaunchKernelGGL((k_moist_physics<N, true>), grid, block, lds, s, a);                \
-    else hipLaunchKernelGGL((k_moist_physics<N, false>), grid, block, 0, s, a);                        \
+    if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3>), grid, block, 3 * lds1, s, a);           \
+    else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2>), grid, block, 2 * lds1, s, a);      \
+    else hipLaunchKernelGGL((k_moist_physics<N, 0>), grid, block, 0, s, a);                            \
   } while (0)
   if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
 #undef LM

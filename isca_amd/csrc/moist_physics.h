@@ -805,7 +805,7 @@ struct PblProfile {
 // f_2 (needed again by the upward sweep) are stored, in caller storage (w[k * sw]: LDS on the device).
 // ------------------------------------------------------------------------------------------------
 struct VdiffSurf { double dtmass, dflux_t, delta_t, dflux_q, delta_q, delta_u, delta_v; };
-struct VdiffWork { double *e, *f1, *f2; int sw; };
+struct VdiffWork { double *e, *f1, *f2; int sw, sw2; };      // strides of e, f1 / of f2 (which may live elsewhere)
 
 namespace vd {
 // A diffusivity profile is handed to the sweeps in two steps, raw(k) = whatever has to come from memory for interface k and
@@ -861,7 +861,7 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
           // general path below then computes nu = 0, a = c = -0, b = g = 1, e = 0 and f = the incoming tendencies with four divisions per level.
           // The same values without them (a zero tendency may come out as +0 where the general path leaves -0).
           e_prev = 0.0; f1_prev = dd1[i] + 0.0; f2_prev = dd2[i] + 0.0;
-          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
+          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw2] = f2_prev;
           fl1_k = 0.0; fl2_k = 0.0; nu_k = 0.0; x1_k = x1n[i]; x2_k = x2n[i]; t_k = tn[i]; z_k = zn[i]; ph_k = ph_n;
           continue;
         }
@@ -883,7 +883,7 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
         } else if (k < L - 1) {
           const double g = 1.0 / (b + c * e_prev);
           e_prev = -a * g; f1_prev = (e1 - c * f1_prev) * g; f2_prev = (e2 - c * f2_prev) * g;
-          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw] = f2_prev;
+          w.e[k * w.sw] = e_prev; w.f1[k * w.sw] = f1_prev; w.f2[k * w.sw2] = f2_prev;
         } else {
           r.mu_delt_n = mu * delt; r.nu_n = nu_k; r.e_n1 = e_prev; r.f1_delt_n1 = f1_prev * delt; r.f2_delt_n1 = f2_prev * delt;
           r.delta_1_n = e1 * delt; r.delta_2_n = e2 * delt;
@@ -945,7 +945,7 @@ MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, 
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
       if (k >= 0) {
-        if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw]; }
+        if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw2]; }
         const double du = xu - du0[i], dv = xv - dv0[i];
         dh[i] = -cp_inv * ((uk[i] + half_delt * du) * du + (vk[i] + half_delt * dv) * dv);
         du0[i] = xu; dv0[i] = xv;
@@ -989,7 +989,7 @@ MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf 
   MP_UNROLL
   for (int k = L - 2; k >= 0; --k) {
     const double e = w.e[k * w.sw];
-    xt = e * xt + w.f1[k * w.sw]; xq = e * xq + w.f2[k * w.sw];
+    xt = e * xt + w.f1[k * w.sw]; xq = e * xq + w.f2[k * w.sw2];
     dt_t[k * st] = xt; dt_q[k * st] = xq;
   }
 }

@@ -88,7 +88,7 @@ void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u
   std::vector<double> we(L), wf1(L), wf2(L);
   (void)p_full;
   for (int c = 0; c < ncol; ++c) {
-    VdiffWork w{we.data(), wf1.data(), wf2.data(), 1};
+    VdiffWork w{we.data(), wf1.data(), wf2.data(), 1, 1};
     VdiffSurf S;
     double tu = flux_u[c], tv = flux_v[c];
     vert_diff_momentum(L, delt, u + c, v + c, t + c, ncol, vd::TableDiff{diff_m + c, ncol}, p_half + c, z_full + c, ncol, tu, tv,
