@@ -318,29 +318,41 @@ struct PressArgs {
   double *p_full[2], *p_half[2], *z_full, *z_half;
   int ncol, L;
 };
-// (1) level-parallel part: one thread per (column, level, time level): p_half, p_full, and for the current level the two hydrostatic
-//     increments of that layer, left in z_full / z_half for the scan
+// (1) level-parallel part: one thread per (column, group of MP_PK levels, time level): p_half, p_full, and for the current level the two
+//     hydrostatic increments of each layer, left in z_full / z_half for the sum in k_moist_physics.  (One thread per level computed every
+//     log p_half twice -- the kernel is VALU-bound on log / exp / divide: 18 of its 23 us -- a group computes it once per half level.)
+constexpr int MP_PK = 4;
 __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.ncol) return;
-  const int k = blockIdx.y, tl = blockIdx.z, L = a.L;
+  const int k0 = blockIdx.y * MP_PK, tl = blockIdx.z, L = a.L;
   const size_t c = (size_t)col, s = (size_t)a.ncol;
   const double ps = a.ps[tl][c];
   const double *pk = a.pk, *bk = a.bk;
   const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
   const int ktop = (pk[0] == 0.0) ? 1 : 0;
-  const double ph0 = pk[k] + bk[k] * ps, ph1 = pk[k + 1] + bk[k + 1] * ps;
-  const double l0 = (top0 && k == 0) ? 0.0 : log(ph0), l1 = log(ph1);
-  double lf;
-  if (top0 && k == 0) lf = l1 - 1.0;
-  else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
-  a.p_full[tl][c + (size_t)k * s] = exp(lf);
-  a.p_half[tl][c + (size_t)k * s] = ph0;
-  if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
-  if (tl == 1) {
-    const double tk = a.t[1][c + (size_t)k * s];
-    a.z_full[c + (size_t)k * s] = RDGAS * tk * (l1 - lf);
-    a.z_half[c + (size_t)k * s] = (k >= ktop) ? RDGAS * tk * (l1 - l0) : 0.0;
+  double tk[MP_PK];
+#pragma unroll
+  for (int i = 0; i < MP_PK; ++i) tk[i] = (tl == 1) ? a.t[1][c + (size_t)min(k0 + i, L - 1) * s] : 0.0;
+  double ph0 = pk[k0] + bk[k0] * ps;
+  double l0 = (top0 && k0 == 0) ? 0.0 : log(ph0);
+#pragma unroll
+  for (int i = 0; i < MP_PK; ++i) {
+    const int k = k0 + i;
+    if (k < L) {
+      const double ph1 = pk[k + 1] + bk[k + 1] * ps, l1 = log(ph1);
+      double lf;
+      if (top0 && k == 0) lf = l1 - 1.0;
+      else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
+      a.p_full[tl][c + (size_t)k * s] = exp(lf);
+      a.p_half[tl][c + (size_t)k * s] = ph0;
+      if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
+      if (tl == 1) {
+        a.z_full[c + (size_t)k * s] = RDGAS * tk[i] * (l1 - lf);
+        a.z_half[c + (size_t)k * s] = (k >= ktop) ? RDGAS * tk[i] * (l1 - l0) : 0.0;
+      }
+      ph0 = ph1; l0 = l1;
+    }
   }
 }
 void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -356,7 +368,7 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
     a.t[1] = d.tv;
   }
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
-  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), h.g.L, 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
+  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Dev &d = h.d;
