@@ -3,6 +3,7 @@
 // (consecutive lanes = consecutive longitudes: every level access of a wavefront is one coalesced row segment).
 // The column routines themselves are in moist_physics.h (shared with the host build the CPU tests check against the
 // reference); this file holds the driver kernel in the reference's call order, the table upload and the launchers.
+#include <type_traits>
 #include "core.h"
 #include "kernels.h"
 #include "moist.h"
@@ -19,6 +20,7 @@ struct MoistArgs {
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
+  const double *pk, *bk, *ps_p, *ps_c;  // in the model's step (SIG kernels): the half-level pressures are pk + bk ps, formed where they are needed; ph_p / ph_c unused
   const double *surf_geop;              // non-null: zf_c / zh_c hold the hydrostatic increments of k_moist_pressures and this kernel sums them (moist_heights_scan)
   int ktop;
   double *work;                         // [5][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3), the sponge's heating (4)
@@ -81,7 +83,7 @@ __device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, d
     }
   }
 }
-template <int LMAX, int NLDS>      // NLDS: how many of the three work arrays live in LDS (3, 2: arrays 0 and 1, or 0)
+template <int LMAX, int NLDS, bool SIG>      // NLDS: how many of the three work arrays live in LDS (3, 2: arrays 0 and 1, or 0); SIG: p_half from (pk, bk, ps)
 __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   constexpr bool LDSW = NLDS >= 2;
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
@@ -97,6 +99,10 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
   double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s, *r4 = r0 + (size_t)4 * (L + 1) * s;
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
+  using PHT = typename std::conditional<SIG, moist::PHalfSigma, const double *>::type;
+  PHT php, phc;                         // half-level pressures of the previous / current time level
+  if constexpr (SIG) { php = moist::PHalfSigma{a.pk, a.bk, a.ps_p[c]}; phc = moist::PHalfSigma{a.pk, a.bk, a.ps_c[c]}; }
+  else { php = a.ph_p + c; phc = a.ph_c + c; }
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
   const double delta_t = a.delta_t;
   const int nray = a.do_damping ? a.ray.nlev_rayfric : 0;
@@ -109,14 +115,14 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
     t_surf = a.t_surf[c];
     double insolation, sw_tau_0;
-    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, a.ph_c + c, s, r0, r1, r3, s, insolation, sw_tau_0, net_sw, lw_down_surf);
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, phc, s, r0, r1, r3, s, insolation, sw_tau_0, net_sw, lw_down_surf);
     MT(2, 1)
     const size_t low = (size_t)(L - 1) * s;
-    moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], a.ph_c[c + (size_t)L * s], t_surf,
+    moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], moist::ph_at(phc, s, L), t_surf,
                         a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
     MT(2, 2)
     for (int k = 0; k < L; ++k) w2[k * sw2] = 0.0;
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, a.ph_c + c, s, r0, r1, r3, s, w2, sw2);
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, phc, s, r0, r1, r3, s, w2, sw2);
     MT(2, 3)
     if (nroles == 2) {
       const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s);
     double rain, cape, cin;
     int flag, klzb, klcl;
-    moist::qe_moist_convection<LMAX, false>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, a.ph_p + c, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
+    moist::qe_moist_convection<LMAX, false, PHT>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, php, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
                                             klcl, nullptr, nullptr, pc.sw, pc);
     MT(1, 1)
     double precip = rain / delta_t;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
                          ct = pc.wTp[k * pc.sw]; cq = pc.wrp[k * pc.sw];
                          t = ct + tp[k * s]; q = cq + qp[k * s];
                        },
-                       a.pf_p + c, a.ph_p + c, s,
+                       a.pf_p + c, php, s,
                        [&](int k, double td, double qd, double ct, double cq) {
                          pc.wTp[k * pc.sw] = ct / delta_t + td / delta_t;
                          dtq[k * s] = cq / delta_t + qd / delta_t;
@@ -196,13 +202,13 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     double tau_u = sf.flux_u, tau_v = sf.flux_v;
     {
       const auto r = moist::vd::down_pair(L, delta_t, [&](int k) { return up[(size_t)k * s]; }, [&](int k) { return vp[(size_t)k * s]; }, du_in, dv_in,
-                                          moist::PblProfile::Km{pbl}, tp, s, a.ph_c + c, a.zf_c + c, s, w,
+                                          moist::PblProfile::Km{pbl}, tp, s, phc, a.zf_c + c, s, w,
                                           moist::DtPark<decltype(heat_in)>{heat_in, dtT, s});      // = vert_diff_momentum_f, its two halves
       MT(3, 3)
       moist::vert_diff_momentum_up_f(r, L, delta_t, up, vp, s, tau_u, tau_v, sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, dtu, dtv, dtT, s, nullptr, 0, w, S);
     }
     MT(3, 4)
-    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, a.ph_c + c, a.zf_c + c, s, dtT, dtq, s, w, S);
+    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, phc, a.zf_c + c, s, dtT, dtq, s, w, S);
     MT(3, 5)
     moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
                        sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
@@ -301,9 +307,15 @@ static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
   if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);      // (tests: the variants of larger level counts at a small one)
 #define LM(N)                                                                                          \
   do {                                                                                                 \
-    if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3>), grid, block, 3 * lds1, s, a);           \
-    else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2>), grid, block, 2 * lds1, s, a);      \
-    else hipLaunchKernelGGL((k_moist_physics<N, 0>), grid, block, 0, s, a);                            \
+    if (a.pk) {                                                                                        \
+      if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3, true>), grid, block, 3 * lds1, s, a);      \
+      else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2, true>), grid, block, 2 * lds1, s, a); \
+      else hipLaunchKernelGGL((k_moist_physics<N, 0, true>), grid, block, 0, s, a);                       \
+    } else {                                                                                           \
+      if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3, false>), grid, block, 3 * lds1, s, a);     \
+      else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2, false>), grid, block, 2 * lds1, s, a);\
+      else hipLaunchKernelGGL((k_moist_physics<N, 0, false>), grid, block, 0, s, a);                      \
+    }                                                                                                  \
   } while (0)
   if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
 #undef LM
@@ -316,10 +328,18 @@ struct PressArgs {
   const double *pk, *bk, *surf_geop;
   const double *t[2], *ps[2];
   double *p_full[2], *p_half[2], *z_full, *z_half;
-  int ncol, L;
+  int ncol, L, store_half;
 };
+// Above 41 levels (the moist kernel's third work array in a global buffer, 131 072 columns at T170L60: the kernel is throughput-bound and every
+// pass over a level array is 15 us of HBM time) the half-level pressures are not stored: k_moist_physics forms pk + bk ps where it needs them
+// (T170L60: k_moist_pressures 131 -> 97 us, k_moist_physics 1227 -> 1187).  Up to 41 levels they are: at T85L40 the kernel is a latency chain
+// that the scalar loads of pk, bk lengthen by what the 73 MB it no longer reads would have bought (161 -> 164 us).
+static bool moist_sigma_half(int L) {      // ISCA_MOIST_PHALF=sigma|arrays: one or the other at any level count (tests, measurements)
+  if (const char *e = getenv("ISCA_MOIST_PHALF")) return e[0] == 's';
+  return (size_t)3 * 64 * (L + 1) * sizeof(double) > 65536;
+}
 // (1) level-parallel part: one thread per (column, group of MP_PK levels, time level): p_half, p_full, and for the current level the two
-//     hydrostatic increments of each layer, left in z_full / z_half for the sum in k_moist_physics.  (One thread per level computed every
+//     hydrostatic increments of each layer, left in z_full / z_half for the sum in k_moist_physics.  (p_half is stored only for the level counts whose k_moist_physics reads it: moist_sigma_half.)  (One thread per level computed every
 //     log p_half twice -- the kernel is VALU-bound on log / exp / divide: 18 of its 23 us -- a group computes it once per half level.)
 constexpr int MP_PK = 4;
 __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
@@ -345,8 +365,10 @@ __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
       if (top0 && k == 0) lf = l1 - 1.0;
       else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
       a.p_full[tl][c + (size_t)k * s] = exp(lf);
-      a.p_half[tl][c + (size_t)k * s] = ph0;
-      if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
+      if (a.store_half) {
+        a.p_half[tl][c + (size_t)k * s] = ph0;
+        if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
+      }
       if (tl == 1) {
         a.z_full[c + (size_t)k * s] = RDGAS * tk[i] * (l1 - lf);
         a.z_half[c + (size_t)k * s] = (k >= ktop) ? RDGAS * tk[i] * (l1 - l0) : 0.0;
@@ -368,6 +390,7 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
     a.t[1] = d.tv;
   }
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
+  a.store_half = moist_sigma_half(h.g.L) ? 0 : 1;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -381,6 +404,7 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
   a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
   a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
   a.surf_geop = d.surf_geop; a.ktop = (h.tab.pk[0] == 0.0) ? 1 : 0;
+  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = d.psg[sc.prev]; a.ps_c = d.psg[sc.cur]; }
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
   a.work = zh_p + lev * (h.g.L + 1);
   a.delta_t = sc.delta_t;

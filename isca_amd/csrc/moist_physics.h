@@ -98,19 +98,26 @@ MP_HD void compute_qs_n(const SatTable &t, const double (&temp)[N], const double
 // saturation adjustment where q > qsat, re-evaporation of the falling precipitation in the layers below
 // (precip_evap :215-252); returns the deltas (not rates) and the rain in kg/m2.
 // ------------------------------------------------------------------------------------------------
+// Half-level pressures reach the routines below either as an array (a pointer, read with the stride the routine is given: the reference's
+// interface, the host tests, isca_idealized_moist_phys on caller columns) or -- inside the model's step -- as the vertical coordinate and the
+// column's surface pressure, p_half(k) = pk(k) + bk(k) ps formed where it is needed: the same values (k_moist_pressures stored exactly this
+// expression) without an array that every routine reads again from HBM (seven passes over a level array per step of the column kernel).
+struct PHalfSigma { const double *pk, *bk; double ps; };
+MP_HD double ph_at(const double *p, int s, int k) { return p[k * s]; }
+MP_HD double ph_at(const PHalfSigma &p, int, int k) { return p.pk[k] + p.bk[k] * p.ps; }
 // load(k, t, q, x, y): temperature and humidity of level k plus two values of the caller's that come from memory and are handed on
 // to out(k, t_delta, q_delta, x, y) - so that everything a chunk of levels reads is requested before anything is stored.
-template <class LOAD, class OUT>
-MP_HD void lscale_cond(const SatTable &st, int L, LOAD load, const double *pfull, const double *phalf, int s, OUT out, double &rain) {
+template <class LOAD, class OUT, class PH>
+MP_HD void lscale_cond(const SatTable &st, int L, LOAD load, const double *pfull, PH phalf, int s, OUT out, double &rain) {
   const double hlcp = HLV / CP_AIR;
   double exq = 0.0, precip = 0.0;
-  double ph_k = phalf[0];
+  double ph_k = ph_at(phalf, s, 0);
   for (int k0 = 0; k0 < L; k0 += MP_U) {
     double tk[MP_U], qk[MP_U], pf[MP_U], phn[MP_U], qsat[MP_U], dqsat[MP_U], tdo[MP_U], qdo[MP_U], ax[MP_U], ay[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < L) ? k0 + i : L - 1;
-      load(k, tk[i], qk[i], ax[i], ay[i]); pf[i] = pfull[k * s]; phn[i] = phalf[(k + 1) * s];
+      load(k, tk[i], qk[i], ax[i], ay[i]); pf[i] = pfull[k * s]; phn[i] = ph_at(phalf, s, k + 1);
     }
     compute_qs_n<MP_U>(st, tk, pf, qsat, dqsat);
     MP_UNROLL_ALL
@@ -156,7 +163,8 @@ struct GrayRadParams {
 // Downward pass: fills lw_down[0..L] (caller storage, stride sw), lw_dtrans[0..L-1] and sw_down[0..L] (the downward shortwave flux on
 // the half levels, which the reference evaluates again in the upward pass: here that pass reads it), returns the surface fluxes.
 // (p/p0)^wv_exponent and (p/p0)^solar_exponent are one pow when the two exponents are equal (the defaults: 4).
-MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, const double *p_half, int s,
+template <class PH>
+MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, PH p_half, int s,
                          double *lw_down, double *lw_dtrans, double *sw_down, int sw, double &insolation, double &sw_tau_0,
                          double &net_surf_sw_down, double &surf_lw_down) {
   const double sl = sin(lat), sl2 = sl * sl;
@@ -166,17 +174,18 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   double lw_tau_0 = p.ir_tau_eq + (p.ir_tau_pole - p.ir_tau_eq) * sl2;
   lw_tau_0 = lw_tau_0 * p.odp;
   const bool one_pow = p.solar_exponent == p.wv_exponent;
-  const double pw0 = pow(p_half[0] / PSTD_MKS, p.wv_exponent);
-  double tau_k = lw_tau_0 * (p.linear_tau * p_half[0] / PSTD_MKS + (1.0 - p.linear_tau) * pw0);
+  const double ph_top = ph_at(p_half, s, 0);
+  const double pw0 = pow(ph_top / PSTD_MKS, p.wv_exponent);
+  double tau_k = lw_tau_0 * (p.linear_tau * ph_top / PSTD_MKS + (1.0 - p.linear_tau) * pw0);
   lw_down[0] = 0.;
-  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : pow(p_half[0] / PSTD_MKS, p.solar_exponent)));
+  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : pow(ph_top / PSTD_MKS, p.solar_exponent)));
   double lwd = 0., swd_last = 0.;
   for (int k0 = 0; k0 < L; k0 += MP_U) {
     double ph[MP_U], tk[MP_U], tau_n[MP_U], swd[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < L) ? k0 + i : L - 1;
-      ph[i] = p_half[(k + 1) * s]; tk[i] = t[k * s];
+      ph[i] = ph_at(p_half, s, k + 1); tk[i] = t[k * s];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -201,10 +210,11 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   net_surf_sw_down = swd_last * (1. - albedo);
 }
 // Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.
-MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, const double *p_half, int s,
+template <class PH>
+MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, PH p_half, int s,
                        const double *lw_down, const double *lw_dtrans, const double *sw_down, int sw, double *tdt, int st) {
   const double b_surf = STEFAN * pow4(t_surf);
-  const double ph_surf = p_half[L * s], sw_surf = sw_down[L * sw];
+  const double ph_surf = ph_at(p_half, s, L), sw_surf = sw_down[L * sw];
   const double sw_up = albedo * sw_surf;
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
   double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - sw_surf);
@@ -214,7 +224,7 @@ MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_su
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      tk[i] = t[k * s]; ph[i] = p_half[k * s]; td[i] = tdt[k * st]; swd[i] = sw_down[k * sw];
+      tk[i] = t[k * s]; ph[i] = ph_at(p_half, s, k); td[i] = tdt[k * st]; swd[i] = sw_down[k * sw];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -277,9 +287,9 @@ struct QeParcel {
 };
 
 // deltaT / deltaq may BE the parcel storage (deltaT == pc.wTp, deltaq == pc.wrp, so == pc.sw): the deltas are then left where they are.
-template <int LMAX, bool WANT_REF = true>
+template <int LMAX, bool WANT_REF = true, class PH = const double *>
 MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, double dt, const double *Tin_, const double *qin_,
-                               const double *p_full_, const double *p_half_, int s, double *deltaT, double *deltaq, double &rain,
+                               const double *p_full_, PH p_half_, int s, double *deltaT, double *deltaq, double &rain,
                                double &cape_out, double &cin_out, int &convflag, int &kLZB_out, int &kLCL_out, double *Tref_out,
                                double *qref_out, int so, const QeParcel &pc) {
   QeColumn<LMAX, WANT_REF> c;
@@ -290,7 +300,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   auto qin = [&](int k) { return qin_[(k - 1) * s]; };
   auto rin = [&](int k) { const double q = qin_[(k - 1) * s]; return q / (1.0 - q); };
   auto pf = [&](int k) { return p_full_[(k - 1) * s]; };
-  auto ph = [&](int k) { return p_half_[(k - 1) * s]; };
+  auto ph = [&](int k) { return ph_at(p_half_, s, k - 1); };
   const int ks = L;                                                       // k_surface
   auto set_nocape = [&](double &pLZB, int &kLZB, int &kLFC, double &CIN) {  // set_values_if_nocape (:1014-1030)
     pLZB = pf(1); kLZB = 0; kLFC = 0; CIN = 0.;
@@ -831,18 +841,18 @@ struct NoAux {
   MP_HD double load(int) const { return 0.0; }
   MP_HD void store(int, double) const {}
 };
-template <class X1, class X2, class D1, class D2, class DIFF, class AUX = NoAux>
-MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF diff, const double *t, int s, const double *p_half,
+template <class X1, class X2, class D1, class D2, class DIFF, class PH, class AUX = NoAux>
+MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF diff, const double *t, int s, PH p_half,
                            const double *z_full, int sp, const VdiffWork &w, AUX aux = AUX()) {
   DownResult r;
   double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
-  double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = p_half[0];
+  double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = ph_at(p_half, sp, 0);
   for (int k0 = 0; k0 < L; k0 += MP_U) {
     double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U], zr[MP_U], ax[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // everything level k0+i needs from memory: its own tendencies, the fields of the level below
       const int k = (k0 + i < L) ? k0 + i : L - 1, kn = (k + 1 < L) ? k + 1 : L - 1;
-      phn[i] = p_half[(k + 1) * sp]; tn[i] = t[kn * s]; zn[i] = z_full[kn * sp]; x1n[i] = x1(kn); x2n[i] = x2(kn);
+      phn[i] = ph_at(p_half, sp, k + 1); tn[i] = t[kn * s]; zn[i] = z_full[kn * sp]; x1n[i] = x1(kn); x2n[i] = x2(kn);
       dd1[i] = d1(k); dd2[i] = d2(k); zr[i] = diff.raw(kn); ax[i] = aux.load(k);
     }
     MP_UNROLL_ALL
@@ -913,8 +923,8 @@ struct DtPark {
   MP_HD double load(int k) const { return in(k); }
   MP_HD void store(int k, double v) const { dt_t[k * st] = v; }
 };
-template <class DIFFM, class DUIN, class DVIN, class DTIN>
-MP_HD void vert_diff_momentum_f(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
+template <class DIFFM, class DUIN, class DVIN, class DTIN, class PH>
+MP_HD void vert_diff_momentum_f(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, PH p_half,
                                 const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in,
                                 DTIN dt_in, double *dt_u, double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w,
                                 VdiffSurf &S) {
@@ -962,16 +972,16 @@ MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, 
     }
   }
 }
-template <class DIFFM>
-MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, const double *p_half,
+template <class DIFFM, class PH>
+MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double *v, const double *t, int s, DIFFM diff_m, PH p_half,
                               const double *z_full, int sp, double &tau_u, double &tau_v, double dtau_du, double dtau_dv, double *dt_u,
                               double *dt_v, double *dt_t, int st, double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
   vert_diff_momentum_f(L, delt, u, v, t, s, diff_m, p_half, z_full, sp, tau_u, tau_v, dtau_du, dtau_dv, [&](int k) { return dt_u[k * st]; },
                        [&](int k) { return dt_v[k * st]; }, [&](int k) { return dt_t[k * st]; }, dt_u, dt_v, dt_t, st, diss_heat, sh, w, S);
 }
 // vert_diff_down_2 for dry static energy and humidity + the Tri_surf hand-over (gcm_vert_diff_down :372-404)
-template <class DIFFT>
-MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double *q, int s, DIFFT diff_t, const double *p_half,
+template <class DIFFT, class PH>
+MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double *q, int s, DIFFT diff_t, PH p_half,
                                const double *z_full, int sp, const double *dt_t, const double *dt_q, int st, const VdiffWork &w, VdiffSurf &S) {
   const double gcp = GRAV / CP_AIR;
   const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return t[k * s] + z_full[k * sp] * gcp; }, [&](int k) { return q[k * s]; },

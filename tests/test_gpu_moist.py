@@ -76,6 +76,22 @@ def test_moist_work_arrays_in_global_memory(golden_dir):
     dc.close()
 
 
+def test_moist_half_level_pressures_on_the_fly(monkeypatch):
+    """Above 41 levels the moist kernels do not store the half-level pressures: k_moist_physics forms pk + bk ps where it needs them
+    (ISCA_MOIST_PHALF=sigma forces that at 25 levels, =arrays the stored ones).  The same model state bit for bit after 30 steps."""
+    def run(mode):
+        monkeypatch.setenv("ISCA_MOIST_PHALF", mode)
+        dc = moist_core()
+        dc.cold_start(); dc.step(30)
+        out = {k: dc.get(k) for k in ("ug", "vg", "tg", "psg")}
+        out["q"] = dc.get("tr", 1); out["t_surf"] = dc.get("t_surf")
+        dc.close()
+        return out
+    a, b = run("arrays"), run("sigma")
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_moist_trajectory_T85L40(golden_dir):
     """BASELINE configs[3] at its full size: the Frierson model at T85L40 (uneven_sigma levels of the test case's scale_heights / exponent,
     dt = 300 s) from the cold start against the reference run after 1, 12 and 144 steps (12 hours), on the committed
