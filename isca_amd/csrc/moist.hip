@@ -40,9 +40,10 @@ struct MoistArgs {
 // heating, then f_2) live in LDS when the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41); up to
 // L = 63 arrays 0 and 1 do and array 2 is a global buffer with the grid layout; beyond that all three are.  LMAX only sizes the private arrays of the convection scheme.
 // A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
-// on its 64 columns where the chain allows it: wavefront 0 does the sponge, the convection and the condensation (66 + 8 us at T85L40) while
-// wavefront 1 does the radiation and the surface fluxes (70 us); they meet at one barrier, after which wavefront 0 goes on alone with the
-// boundary layer and the implicit diffusion (59 us), wavefront 1's heating entering dt_tg in the reference's order
+// on its 64 columns where the chain allows it: wavefront 0 does the convection and the condensation (T85L40: 66 us in the first days after a
+// cold start, 98 us with a mean of 85 and up to 119 for the convection alone after 35 days, when it rains) while wavefront 1 does the height
+// sum, the radiation, the surface fluxes and the sponge (84 / 98 us); they meet at one barrier, after which wavefront 0 goes on alone with the
+// boundary layer and the implicit diffusion (53-59 us), wavefront 1's heating entering dt_tg in the reference's order
 // (dt_tg = ((conv + cond) + rad) + sponge).  With blockDim = 64 the same code runs the parts one after the other.
 // Every pass over a level array that leaves the chip costs HBM time here (32 768 columns x 14 fields do not fit the L2s, so a re-read
 // is a miss: rocprofv3 counted 712 MB per launch for 147 MB of fields, r03 profile): values that have one reader are handed over in LDS
@@ -124,6 +125,11 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
     for (int k = 0; k < L; ++k) w2[k * sw2] = 0.0;
     moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, phc, s, r0, r1, r3, s, w2, sw2);
     MT(2, 3)
+    // ---- Rayleigh sponge (:1228-1237; on this wavefront because in a spun-up model the convection wavefront is the longer of the two in front of
+    //      the barrier -- 107 against 90 us after 35 days, where the cold start's first days have 66 against 78): momentum tendencies of the sponge
+    //      levels in place (below them dt_ug, dt_vg stay zero until the diffusion: not stored), its heating into work array 4
+    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; r4[(size_t)k * s] = 0.0; }
+    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s);
     if (nroles == 2) {
       const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
                                   sf.dedq_atm, sf.dtaudu_atm, sf.dtaudv_atm, sf.u_star, sf.b_star, t_surf, net_sw, lw_down_surf, 0., 0., 0.};
@@ -138,10 +144,6 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
   const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
   if (role == 0) {
-    // ---- Rayleigh sponge (:1228-1237; here because the radiation wavefront is the longer of the two in front of the barrier): momentum
-    //      tendencies of the sponge levels in place (below them dt_ug, dt_vg stay zero until the diffusion: not stored), its heating into work array 4
-    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; r4[(size_t)k * s] = 0.0; }
-    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s);
     double rain, cape, cin;
     int flag, klzb, klcl;
     moist::qe_moist_convection<LMAX, false, PHT>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, php, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,

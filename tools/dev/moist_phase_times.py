@@ -10,7 +10,7 @@ if len(sys.argv) > 1:
     from isca_amd import dyncore
     ph = int(sys.argv[1])
     cfg = dyncore.default_config("T85", num_levels=40, physics=1, dt_atmos=300.0, initial_sphum=2e-6, robert_coeff=0.03, scale_heights=11.0, exponent=7.0)
-    dc = dyncore.DynCore(cfg); dc.cold_start(); dc.step(400)
+    dc = dyncore.DynCore(cfg); dc.cold_start(); dc.step(int(os.environ.get('MOIST_SPINUP', '400')))      # (10000 steps = 35 days: convection active everywhere)
     p = dc.get("precip").reshape(-1, 8) * 0.01        # us; column c holds mark interval c % 8
     tot = 0.0
     for i, nm in enumerate(MARKS[ph]):
