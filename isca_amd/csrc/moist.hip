@@ -142,13 +142,20 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   //      deltas stay where the parcel was (LDS, or the private arrays): the condensation is their only reader, and it leaves
   //      (0 + conv_dt_tg) + cond_dt_tg in the same place for the diffusion below; dt_qg = (0 + conv) + cond goes to memory
   double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
-  const moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
+  moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
+#if defined(MOIST_TIMING) && MOIST_TIMING == 5      // phase 5: inside the convection scheme (marks in moist_physics.h)
+  pc.marks = mt_;
+#endif
   if (role == 0) {
     double rain, cape, cin;
     int flag, klzb, klcl;
     moist::qe_moist_convection<LMAX, false, PHT>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, php, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
                                             klcl, nullptr, nullptr, pc.sw, pc);
     MT(1, 1)
+#if defined(MOIST_TIMING) && MOIST_TIMING == 5
+    { const long long t_ = wall_clock64(); for (int i_ = 6; i_ < 9; ++i_) mt_[i_] = t_; }
+    MT_STORE(5)
+#endif
     double precip = rain / delta_t;
     double rain_ls;
     moist::lscale_cond(a.sat, L,
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
                        },
                        rain_ls);
     precip = precip + rain_ls / delta_t;
-#if !defined(MOIST_TIMING) || MOIST_TIMING != 2
+#if !defined(MOIST_TIMING) || (MOIST_TIMING != 2 && MOIST_TIMING != 5)
     if (a.precip) a.precip[c] = precip;
 #endif
     MT(1, 2) MT_STORE(1)

@@ -282,6 +282,12 @@ struct QeColumn {
 // ascent is a memory operation that the loads of the next level then queue behind).
 struct QeParcel {
   double *wTp, *wrp; int sw;
+#ifdef MOIST_TIMING
+  long long *marks = nullptr;      // timing builds (moist.hip): wall_clock64 stamps at the QE_MARK points of qe_moist_convection
+#define QE_MARK(i) if (MOIST_TIMING == 5 && pc.marks) { const long long t_ = wall_clock64(); for (int i_ = i; i_ < 9; ++i_) pc.marks[i_] = t_; }
+#else
+#define QE_MARK(i)
+#endif
   MP_HD double &Tp(int k) const { return wTp[(k - 1) * sw]; }
   MP_HD double &rp(int k) const { return wrp[(k - 1) * sw]; }
 };
@@ -311,16 +317,18 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     MP_UNROLL
     for (int k = k1; k <= k2; ++k) { set_ref(k, Tin(k), qin(k)); dT(k) = 0.; dq(k) = 0.; }
   };
-  for (int k0 = 1; k0 <= L; k0 += MP_U) {               // chunks: the loads of MP_U levels are in flight together
-    double tt[MP_U], qq[MP_U];
+  constexpr int IU = 20;                                // (first thing in the kernel, two arrays: the registers for 20 levels at once are free)
+  for (int k0 = 1; k0 <= L; k0 += IU) {                 // chunks: the loads of IU levels are in flight together
+    double tt[IU], qq[IU];
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) { const int k = (k0 + i <= L) ? k0 + i : L; tt[i] = Tin(k); qq[i] = qin(k); }
+    for (int i = 0; i < IU; ++i) { const int k = (k0 + i <= L) ? k0 + i : L; tt[i] = Tin(k); qq[i] = qin(k); }
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) {
+    for (int i = 0; i < IU; ++i) {
       const int k = k0 + i;
       if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
     }
   }
+  QE_MARK(1)
   // ---- CAPE_calculation (:383-446)
   bool nocape = true, saturated = false, skip = false;
   double CAPE = 0., CIN = 0., pLZB = 0., pLCL = 0.;
@@ -395,6 +403,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       }
     }
   }
+  QE_MARK(2)
   // ---- CAPE_above_LCL (:587-668)
   if (skip) {
     if (nocape) set_nocape(pLZB, kLZB, kLFC, CIN);
@@ -436,6 +445,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       }
     }
   }
+  QE_MARK(3)
   cape_out = CAPE; cin_out = CIN; kLZB_out = kLZB; kLCL_out = kLCL;
   (void)kLFC; (void)pLZB;
   convflag = 0;
@@ -480,6 +490,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     }
     Pq = Pq / GRAV;
     Pt = Pt / GRAV;
+    QE_MARK(4)
     if ((Pq > 0) && (Pt > 0)) {
       convflag = 2;
       if (Pq > Pt) {                                  // do_change_time_scale_deepconv (:992-1008)
@@ -529,6 +540,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     to_model(1, ks);
   }
   rain = Pq;
+  QE_MARK(5)
   if (deltaT != pc.wTp) {
     MP_UNROLL_ALL
     for (int k = 1; k <= LMAX; ++k) {          // fixed trip count: the reads of the work arrays are issued together

@@ -4,6 +4,7 @@ import os, sys, subprocess
 sys.path.insert(0, '/root/repo')
 MARKS = {1: ["qe_moist_convection", "lscale_cond"],
          2: ["gray_rad_down", "surface_flux", "zero + gray_rad_up", "rayleigh sponge"],
+         5: ["init pass (Tv, parcel)", "below the LCL", "ascent above the LCL", "reference profiles + Pq, Pt", "deep / shallow adjustment", "(end)"],
          3: ["dt_tg sum", "pbl_depth", "pbl profile + momentum down", "momentum up", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
 if len(sys.argv) > 1:
     import numpy as np
@@ -19,7 +20,7 @@ if len(sys.argv) > 1:
     print(f"  phase {ph}  total {tot:.1f} us")
 else:
     only = os.environ.get('MOIST_PHASES')
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 5):
         if only and str(v) not in only.split(','): continue
         env = dict(os.environ, ISCA_DYN_LIB=f"/root/repo/isca_amd/lib/libisca_dyn_mt{v}.so")
         subprocess.run([sys.executable, __file__, str(v)], env=env)
