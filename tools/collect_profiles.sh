@@ -19,12 +19,14 @@ for W in T85L40 T170L60; do
   done
   python tools/summarize_profiles.py $OUT
 done
-# moist configuration (BASELINE configs[3] at T85L40): kernel stats of 300 steps after spin-up
+# moist configuration (BASELINE configs[3] at T85L40) in a spun-up state: the profiler collects for 2 s from second 9 of a run that spins up
+# 10 000 steps (35 days: it rains; the moist kernel is 25 % slower than in the first days after the cold start) and then keeps stepping
 OUT=$TOP/T85L40_moist; mkdir -p $OUT
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python tools/dev/moist_bench.py > $OUT/bench_stats.log 2>&1
+timeout 300 rocprofv3 --collection-period 9:2:1 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python tools/dev/moist_bench.py T85 40 300 spunup > $OUT/bench_stats.log 2>&1
 i=0
 for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD"; do      # HBM traffic and issue counters of the moist column kernel
   i=$((i+1))
+  # (the counter passes are of steps 60-100 after the cold start: rocprofv3 --pmc with --collection-period dumped core, and 10 000 steps under --pmc take too long)
   timeout 200 rocprofv3 --kernel-trace --pmc $pm --output-format csv -d $OUT/pmc_$i -o p -- python tools/dev/moist_bench.py T85 40 300 short > $OUT/pmc_$i.log 2>&1
 done
 python tools/summarize_profiles.py $OUT

@@ -8,7 +8,13 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 dt = float(sys.argv[3]) if len(sys.argv) > 3 else 300.0
 cfg = dyncore.default_config(res, num_levels=L, physics=1, dt_atmos=dt, initial_sphum=2e-6, robert_coeff=0.03, scale_heights=11.0, exponent=7.0)
 dc = dyncore.DynCore(cfg); dc.cold_start()
-short = len(sys.argv) > 4          # a short run for the counter passes
+mode = sys.argv[4] if len(sys.argv) > 4 else ""
+if mode == "spunup":               # for the profiler (rocprofv3 --collection-period 9:2:1): 35 days of spin-up, then steps for ~7 s
+    dc.step(10000)
+    t0 = time.time(); dc.step(16000); t1 = time.time()
+    print(f"{res}L{L} moist, steps 10000-26000: {(t1-t0)/16000*1e3:.4f} ms/step")
+    sys.exit(0)
+short = mode == "short"            # a short run for the counter passes
 dc.step(60 if short else 200)
 for rep in range(1 if short else 2):
     n_ = 40 if short else 500
