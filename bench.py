@@ -312,6 +312,7 @@ def main():
     if a.gpus == 1 and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_steps)
     if a.gpus == 1 and a.workload == "T85L40" and not os.environ.get("ISCA_BENCH_NO_EXTRA"):
+        core.close()                                   # (everything of the headline core has been read; the others start on an empty device)
         out["other_workloads"] = other_workloads(local_rank)
     print(json.dumps(out))
 
