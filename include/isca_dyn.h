@@ -57,8 +57,8 @@ typedef struct isca_moist_config {
  * hs_forcing_nml (hs_forcing.F90:76-122), main_nml dt_atmos (atmos_model.F90:111). */
 typedef struct isca_dyn_config {
   int lon_max, lat_max, num_fourier, num_spherical, num_levels;
-  int fourier_inc;              /* spherical.F90:40,182: index m is zonal wavenumber m * fourier_inc (1 = the whole circle); /= 1: world_size 1 only */
-  int triang_trunc;             /* 1: triangular truncation; 0: rhomboidal (spherical.F90:603-644), world_size 1 only */
+  int fourier_inc;              /* spherical.F90:40,182: index m is zonal wavenumber m * fourier_inc (1 = the whole circle) */
+  int triang_trunc;             /* 1: triangular truncation; 0: rhomboidal (spherical.F90:603-644) */
   double dt_atmos;              /* seconds */
   /* spectral_dynamics_nml */
   int damping_order;            /* see damping_option at the end of the struct */
@@ -105,7 +105,7 @@ typedef struct isca_dyn_config {
    * numerical_representation, 0 = 'grid' (van Leer horizontally, advect_vert = finite_volume_parabolic like tracer 1), 1 = 'spectral'
    * (horizontal_advection of the spectral coefficients, advect_vert = second_centered, hole_filling = off: the defaults of :145-147;
    * damped like temperature, :1146).  tracer_robert_coeff: the entry's robert_coeff, negative = robert_coeff (:340-351).
-   * More than one tracer: single rank, raw_filter_coeff = 1.  State names "tr2".."tr4", "tr_atm2".., and "trs2".. (spectral). */
+   * More than one tracer: raw_filter_coeff = 1; a 'spectral' tracer: world_size 1 (further 'grid' tracers run sharded).  State names "tr2".."tr4", "tr_atm2".., and "trs2".. (spectral). */
   int tracer_spectral[ISCA_MAX_TRACERS];
   double tracer_robert_coeff[ISCA_MAX_TRACERS];
   /* use_virtual_temperature (spectral_dynamics_nml, default .false.): T (1 + (rvgas/rdgas - 1) q), q = tracer 1, in the pressure-gradient

@@ -159,8 +159,6 @@ static void check_config(const isca_dyn_config &c) {
   // check_dynamics_nml (spectral_dynamics.F90:666-755) + what this implementation supports
   if (c.num_fourier <= 0 || c.num_spherical <= 0 || c.num_levels <= 0) fail("invalid resolution");
   if (c.fourier_inc <= 0) fail(std::to_string(c.fourier_inc) + " is an invalid value for fourier_inc.");
-  if (c.fourier_inc != 1 && c.world_size != 1) fail("fourier_inc /= 1: single rank only");
-  if (!c.triang_trunc && c.world_size != 1) fail("triang_trunc = .false. (rhomboidal truncation): single rank only");
   if (c.num_spherical != c.num_fourier * c.fourier_inc + 1) fail("num_spherical must equal num_fourier * fourier_inc + 1");
   if (c.lon_max < 3 * c.num_fourier + 1) fail("number of longitude points is too small for number of fourier waves");
   if (2 * c.lat_max < (c.triang_trunc ? 3 : 5) * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");

@@ -629,7 +629,7 @@ def test_T85L40_long_run_stays_physical():
 
 # ------------------------------------------------------------------ (d) latitude-band sharding on the device path
 @pytest.mark.parametrize("world,res,levels,raw,tracers", [(2, "T21", 25, 1.0, 1), (4, "T21", 25, 1.0, 1), (8, "T85", 40, 1.0, 1), (2, "T21", 12, 0.7, 1),
-                                                          (4, "T21", 12, 0.53, 1), (2, "T21", 12, 1.0, 3), (4, "T21", 8, 1.0, 2)])
+                                                          (4, "T21", 12, 0.53, 1), (2, "T21", 12, 1.0, 3), (4, "T21", 8, 1.0, 2), (2, "R10", 8, 1.0, 1), (2, "S10", 8, 1.0, 1)])      # R10: rhomboidal truncation; S10: fourier_inc = 2
 def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     """N ranks share this box's GPU (gloo, host-staged exchange): the device kernels run with the sharded layouts
     (latitude bands, dealt wavenumbers, tracer halos) and must reproduce the single-rank model; the last case is the
