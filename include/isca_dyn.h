@@ -254,6 +254,13 @@ int isca_dyn_comm_init(isca_dyn_t *h, const void *id128);
  * this rank received wrong data (the host driver then keeps the exchanges in torch.distributed) */
 int isca_dyn_comm_check(isca_dyn_t *h);
 int isca_comm_selftest(int device, double *max_err);     /* one-rank communicator: load RCCL, run every collective once */
+/* With ISCA_COMM=ipc in the environment of the rank that draws the id, the communicator is a host-staged exchange through files
+ * mapped by every rank instead of RCCL (isca_amd/csrc/comm_ipc.cpp): ranks may then SHARE one GPU, so the sharded C++ step loop --
+ * the exchange schedule that stands for transpose_fourier / reverse_transpose_fourier (transforms.F90:970-1056),
+ * mpp_update_domains (fv_advection.F90:161-162) and mpp_sum -- can be verified with 2, 4, 8 processes on a one-GPU box.
+ * Every exchange synchronises stream and host: a verification vehicle, not a fast path.  ISCA_IPC_TIMEOUT_S (120): how long a
+ * rank waits for the others before it stops with an error; a rank whose step throws releases its peers with an error. */
+const char *isca_dyn_comm_kind(isca_dyn_t *h);           /* "rccl", "ipc", or "" without a communicator */
 
 /* --- components of the step on caller fields (world_size == 1) -------------------------------------
  * Each entry replaces one public routine the reference's callers use on its own, and runs the kernel or

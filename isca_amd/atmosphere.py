@@ -456,8 +456,7 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
             _read_model_time(inp)
         else:
             _core.cold_start()
-        if _progress is not None:
-            _progress["step0"] = _core.info("step")         # 0 after a cold start, 0 or 1 after a restart
+        _clock["step0"] = _core.info("step")                # 0 after a cold start, 0 or 1 after a restart
     except Exception:
         _core.close()
         _core = None
@@ -468,13 +467,25 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
 # ---- the progress line of spectral_diagnostics -> global_integrals (spectral_dynamics.F90:1836-1840, 1869-1912): every
 # print_interval (spectral_dynamics_nml, (days, seconds), default one day) rank 0 prints "Integration completed through ..." or, with
 # json_logging, the machine-readable line the harness's progress bar parses ({"day":, "second":, "max_speed":, "avg_T":}).
-_progress: dict | None = None
+_progress: dict | None = None      # the printer (print_interval / json_logging asked for), or None
+_clock: dict | None = None         # the model time of this run: calendar, the date it began at, the step count it began at -- always kept
+
+
+_CALENDAR_ALIASES = {"none": "no_calendar", "thirty_day_months": "thirty_day", "no_leap": "noleap"}
 
 
 def _setup_progress_log(namelist: dict):
-    global _progress
+    global _progress, _clock
     nml = {g.lower(): {k.lower(): v for k, v in vals.items()} for g, vals in namelist.items()}
     sd, mn = nml.get("spectral_dynamics_nml", {}), nml.get("main_nml", {})
+    cal = str(mn.get("calendar", "no_calendar")).lower()
+    cal = _CALENDAR_ALIASES.get(cal, cal)
+    if cal not in _CALENDAR_TYPES:
+        raise IscaError(f"main_nml: calendar = '{cal}' is not a supported value (no_calendar, thirty_day, julian, gregorian, noleap)")
+    date = list(mn.get("current_date", [0, 0, 0, 0, 0, 0]))
+    if cal == "no_calendar":                 # atmos_model.F90:218-223: date(1:2) = 0, date(3:6) = current_time
+        date = [0, 0] + (list(mn.get("current_time", [0, 0, 0, 0])) + [0] * 4)[:4]
+    _clock = {"calendar": cal, "date0": date, "step0": 0}
     if "print_interval" not in sd and not sd.get("json_logging", False):
         _progress = None                                   # library use without a namelist request: silent
         return
@@ -483,50 +494,76 @@ def _setup_progress_log(namelist: dict):
     every = (pi[0] * 86400 + (pi[1] if len(pi) > 1 else 0)) / float(_core.cfg.dt_atmos)
     if every < 1 or every != int(every):
         raise IscaError("spectral_dynamics_nml: print_interval must be a positive multiple of dt_atmos")
-    cal = str(mn.get("calendar", "no_calendar")).lower()
-    date = list(mn.get("current_date", [0, 0, 0, 0, 0, 0]))
-    if cal in ("no_calendar", "none"):       # atmos_model.F90:218-223: date(1:2) = 0, date(3:6) = current_time
-        date = [0, 0] + (list(mn.get("current_time", [0, 0, 0, 0])) + [0] * 4)[:4]
-    _progress = {"every": int(every), "json": bool(sd.get("json_logging", False)), "calendar": cal, "date0": date, "out": sys.stdout,
-                 "step0": 0}
+    _progress = {"every": int(every), "json": bool(sd.get("json_logging", False)), "out": sys.stdout}
 
 
 # ---- the model time across run segments: the main program's RESTART/atmos_model.res (atmos_model.F90:198-202, 397-406) holds the date the
-# run ended at and the calendar type; a run that finds INPUT/atmos_model.res continues from that date (progress lines, print_interval alarm).
-_CALENDAR_TYPES = {"no_calendar": 0, "none": 0, "thirty_day": 1, "julian": 2, "gregorian": 3, "noleap": 4}
+# run ended at and the calendar type; a run that finds INPUT/atmos_model.res continues from that date AND calendar (the file overrides
+# main_nml, atmos_model.F90:198-202), whether or not a progress line was asked for.
+_CALENDAR_TYPES = {"no_calendar": 0, "thirty_day": 1, "julian": 2, "gregorian": 3, "noleap": 4}
+_CALENDAR_NAMES = {v: k for k, v in _CALENDAR_TYPES.items()}
+_MONTH_DAYS = (31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31)
+
+
+def _is_leap(calendar: str, year: int) -> bool:
+    """time_manager.F90: julian -- every fourth year; gregorian -- the 100 / 400 year exceptions; noleap -- never"""
+    if calendar == "julian":
+        return year % 4 == 0
+    if calendar == "gregorian":
+        return year % 4 == 0 and (year % 100 != 0 or year % 400 == 0)
+    return False
 
 
 def _date_after(date0, calendar: str, secs: int):
-    """date0 (year, month, day, hour, minute, second) advanced by secs: no_calendar counts days in date(3); thirty_day: 12 months of 30 days"""
+    """date0 (year, month, day, hour, minute, second) advanced by secs.  no_calendar counts days in date(3); thirty_day has 12 months of
+    30 days; julian / gregorian / noleap have the real months (with their leap-year rules)."""
     y0, m0, d0, h0, mi0, s0 = (list(date0) + [0] * 6)[:6]
-    if calendar in ("no_calendar", "none"):
+    if calendar == "no_calendar":
         tot = ((d0 * 24 + h0) * 60 + mi0) * 60 + s0 + secs
         days, rem = divmod(tot, 86400)
         return [0, 0, days, rem // 3600, rem % 3600 // 60, rem % 60]
-    tot = ((((y0 * 12 + max(m0, 1) - 1) * 30 + max(d0, 1) - 1) * 24 + h0) * 60 + mi0) * 60 + s0 + secs
-    tot, sec = divmod(tot, 60); tot, mnt = divmod(tot, 60); tot, hr = divmod(tot, 24); tot, dy = divmod(tot, 30); yr, mo = divmod(tot, 12)
-    return [yr, mo + 1, dy + 1, hr, mnt, sec]
+    if calendar == "thirty_day":
+        tot = ((((y0 * 12 + max(m0, 1) - 1) * 30 + max(d0, 1) - 1) * 24 + h0) * 60 + mi0) * 60 + s0 + secs
+        tot, sec = divmod(tot, 60); tot, mnt = divmod(tot, 60); tot, hr = divmod(tot, 24); tot, dy = divmod(tot, 30); yr, mo = divmod(tot, 12)
+        return [yr, mo + 1, dy + 1, hr, mnt, sec]
+    yr, mo, dy = y0, max(m0, 1), max(d0, 1)
+    days, rem = divmod((h0 * 60 + mi0) * 60 + s0 + secs, 86400)
+    dy += days
+    while True:
+        n = _MONTH_DAYS[mo - 1] + (1 if mo == 2 and _is_leap(calendar, yr) else 0)
+        if dy <= n:
+            break
+        dy -= n
+        mo += 1
+        if mo > 12:
+            mo, yr = 1, yr + 1
+    return [yr, mo, dy, rem // 3600, rem % 3600 // 60, rem % 60]
 
 
 def _read_model_time(inp: str):
     path = os.path.join(inp, "atmos_model.res")
-    if _progress is None or not os.path.exists(path):
+    if _clock is None or not os.path.exists(path):
         return
     with open(path) as f:
         rows = [ln.split() for ln in f.read().splitlines() if ln.strip()]
-    _progress["date0"] = [int(x) for x in rows[0][:6]]
+    _clock["date0"] = [int(x) for x in rows[0][:6]]
+    if len(rows) > 1:
+        try:
+            _clock["calendar"] = _CALENDAR_NAMES[int(rows[1][0])]
+        except (KeyError, ValueError):
+            raise IscaError(f"{path}: calendar type {rows[1][0]!r} is not one of 0..4")
 
 
 def _write_model_time(resdir: str):
-    if _progress is None:
+    if _clock is None:
         return
-    secs = int(round((_core.info("step") - _progress["step0"]) * _core.cfg.dt_atmos))
-    date = _date_after(_progress["date0"], _progress["calendar"], secs)
+    secs = int(round((_core.info("step") - _clock["step0"]) * _core.cfg.dt_atmos))
+    date = _date_after(_clock["date0"], _clock["calendar"], secs)
     os.makedirs(resdir, exist_ok=True)
     with open(os.path.join(resdir, "atmos_model.res"), "w") as f:
         f.write("%6d%6d%6d%6d%6d%6d        Current model time: year, month, day, hour, minute, second\n" % tuple(date))
         f.write("%6d        (Calendar: no_calendar=0, thirty_day_months=1, julian=2, gregorian=3, noleap=4)\n"
-                % _CALENDAR_TYPES.get(_progress["calendar"], 0))
+                % _CALENDAR_TYPES[_clock["calendar"]])
 
 
 def global_integrals():
@@ -537,17 +574,17 @@ def global_integrals():
 
 
 def _progress_line():
-    c, p = _core, _progress
-    secs = int(round((c.info("step") - p["step0"]) * c.cfg.dt_atmos))      # since this run began; date0 is where it began (a restart: where the last one ended)
+    c, p, k = _core, _progress, _clock
+    secs = int(round((c.info("step") - k["step0"]) * c.cfg.dt_atmos))      # since this run began; date0 is where it began (a restart: where the last one ended)
     max_speed, avg_t = global_integrals()
-    date = _date_after(p["date0"], p["calendar"], secs)
+    date = _date_after(k["date0"], k["calendar"], secs)
     days, rem = date[2], (date[3] * 60 + date[4]) * 60 + date[5]
-    if p["calendar"] in ("no_calendar", "none"):
+    if k["calendar"] == "no_calendar":
         if p["json"]:
             line = ' {"day":%6d  ,"second":%6d  ,"max_speed":%13.6E   ,"avg_T":%13.6E   }' % (days, rem, max_speed, avg_t)
         else:
             line = " Integration completed through%6d days%6d seconds" % (days, rem)
-    else:                                                   # thirty_day: 12 months of 30 days from main_nml's current_date
+    else:                                                   # a calendar with months, from main_nml's current_date
         yr, mo, dy, hr, mnt, sec = date
         mo, dy = mo - 1, dy - 1
         if p["json"]:
@@ -568,7 +605,7 @@ def atmosphere(nsteps: int = 1):
         return
     left = nsteps
     while left > 0:                                         # stop at every alarm of print_interval (counted from the start of this run)
-        done = _core.info("step") - _progress["step0"]
+        done = _core.info("step") - _clock["step0"]
         chunk = min(left, _progress["every"] - done % _progress["every"])
         _core.step(chunk)
         left -= chunk

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <mutex>
 #include <cstdlib>
+#include <memory>
 
 using namespace isca;
 
@@ -1045,6 +1046,19 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   h->step_count += 1;
 }
 
+// A step that ends in an exception must not leave the handle "in the middle of a step" (every later get_state / set_time_pointers
+// would refuse), nor its peers waiting in the next exchange (error_mesg(..., FATAL) stops every PE).
+struct StepGuard {
+  isca_dyn *h; bool ok = false;
+  explicit StepGuard(isca_dyn *h_) : h(h_) {}
+  void done() { ok = true; }
+  ~StepGuard() {
+    if (ok) return;
+    h->in_step = false;
+    if (h->comm) h->comm->abort();
+  }
+};
+
 // One step of the latitude-band sharded model with the exchanges issued on the same stream through RCCL:
 // lat -> m all-to-all (transpose_fourier), m -> lat all-to-all (reverse_transpose_fourier), the tracer's 2-row halo
 // exchange (mpp_update_domains in fv_advection) and the all-reduce of the 10 fixer sums.  Nothing returns to the host.
@@ -1080,6 +1094,7 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     fail("isca_dyn_step: world_size > 1 needs isca_dyn_comm_init first (or drive isca_dyn_step_phase and the exchanges from the host)");
   if (h->cfg.physics == 2 && nsteps != 0)
     fail("isca_dyn_step: physics = 2 has no physics of its own: hand the tendencies to isca_dyn_dynamics, one call per step");
+  StepGuard guard(h);
   for (int i = 0; i < nsteps; ++i) {
     // wg_full (omega) is an output only: the last step of the call stores it, and every step while a diagnostic of omega accumulates
     // (or the moist package runs, whose restart and diagnostics see it too)
@@ -1090,6 +1105,7 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }
+  guard.done();
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_valid_range(h);
@@ -1106,6 +1122,7 @@ static void stage_tendencies(isca_dyn *h, const double *dt_ug, const double *dt_
   const size_t ng3 = (size_t)h->g.L * h->g.Jl * h->g.I;
   const double *src[4] = {dt_ug, dt_vg, dt_tg, dt_tracers};
   double *dst[4] = {h->d.ph_dtu, h->d.ph_dtv, h->d.ph_dtT, h->d.ph_dtq};
+  if (h->cfg.num_tracers == 0) src[3] = nullptr;      // a field_table without tracers: dt_tracers has no elements (a Fortran caller cannot pass NULL)
   for (int i = 0; i < 4; ++i) {
     if (!src[i]) HIP_CHECK(hipMemsetAsync(dst[i], 0, ng3 * sizeof(double), h->stream));
     else HIP_CHECK(hipMemcpyAsync(dst[i], src[i], ng3 * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
@@ -1131,6 +1148,7 @@ extern "C" int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const doubl
   if (!h->have_state) fail("isca_dyn_dynamics: no state (call isca_dyn_cold_start or set_state first)");
   if (h->g.P > 1 && !h->comm)
     fail("isca_dyn_dynamics: world_size > 1 needs isca_dyn_comm_init first (or isca_dyn_set_tendencies + isca_dyn_step_phase driven by the host)");
+  StepGuard guard(h);
   stage_tendencies(h, dt_ug, dt_vg, dt_tg, dt_tracers, on_device);
   if (h->g.P > 1) sharded_step(h);
   else {
@@ -1138,6 +1156,7 @@ extern "C" int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const doubl
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }
+  guard.done();
   if (sync) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     check_valid_range(h);
@@ -1165,9 +1184,11 @@ extern "C" int isca_dyn_comm_init(isca_dyn_t *h, const void *id128) {
   if (!h || !id128) fail("null argument");
   if (h->comm) fail("comm_init: communicator already initialised");
   HIP_CHECK(hipSetDevice(h->cfg.device));
-  h->comm = new isca::Comm(id128, h->cfg.rank, h->cfg.world_size);
+  h->comm = isca::Comm::create(id128, h->cfg.rank, h->cfg.world_size);
   API_END
 }
+// "rccl" or "ipc" (comm.h), "" without a communicator
+extern "C" const char *isca_dyn_comm_kind(isca_dyn_t *h) { return h && h->comm ? h->comm->kind() : ""; }
 // Cross-rank check of the communicator before the step trusts it: every collective of the sharded step moves rank-tagged
 // patterns through the step's own buffers (all-to-all + halo in one group, plain all-to-all, all-reduce) and each rank verifies
 // what it received.  Collective over all ranks; non-zero = this rank saw wrong data (the caller then falls back).
@@ -1225,7 +1246,8 @@ extern "C" int isca_comm_selftest(int device, double *max_err) {
   HIP_CHECK(hipSetDevice(device));
   char id[isca::Comm::UNIQUE_ID_BYTES];
   isca::Comm::unique_id(id);
-  isca::Comm c(id, 0, 1);
+  std::unique_ptr<isca::Comm> cp(isca::Comm::create(id, 0, 1));
+  isca::Comm &c = *cp;
   const size_t n = 4096;
   std::vector<double> a(n), b(n, 0.0), r(16);
   for (size_t i = 0; i < n; ++i) a[i] = 0.25 * (double)i - 7.0;
@@ -1265,6 +1287,7 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
   if (!h || !h->have_state) fail("isca_dyn_step_phase: no state");
   StepScalars sc = step_scalars(h);
   sc.keep_spec_tend = 1;
+  try {
   switch (phase) {
     case 0: upload_wave_matrices(h, sc.delta_t); phase0(h, sc); break;
     case 1: phase1(h, sc); break;
@@ -1277,6 +1300,7 @@ extern "C" int isca_dyn_step_phase(isca_dyn_t *h, int phase) {
     case 4: phase_tracer(h, sc); break;
     default: fail("invalid phase");
   }
+  } catch (...) { h->in_step = false; throw; }       // a failed phase must not lock the state behind "in the middle of a step"
   API_END
 }
 extern "C" int isca_dyn_exchange_buffers(isca_dyn_t *h, int which, void **send, void **recv, size_t *bytes_per_peer) {

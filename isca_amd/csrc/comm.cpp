@@ -54,13 +54,34 @@ void ck(int rc, const char *what) {
 }
 }  // namespace
 
+class RcclComm final : public Comm {
+ public:
+  RcclComm(const void *id128, int rank, int world);
+  ~RcclComm() override;
+  const char *kind() const override { return "rccl"; }
+  void all_to_all(const double *send, double *recv, size_t count, hipStream_t s) override;
+  void halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s) override;
+  void all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
+                            double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s) override;
+  void all_reduce_sum(double *buf, size_t count, hipStream_t s) override;
+
+ private:
+  void *comm_ = nullptr;
+};
+
 void Comm::unique_id(void *id128) {
+  if (ipc_id_requested()) { ipc_unique_id(id128); return; }
   UniqueId id;
   ck(api().GetUniqueId(&id), "ncclGetUniqueId");
   std::memcpy(id128, &id, sizeof(id));
 }
 
-Comm::Comm(const void *id128, int rank, int world) : rank_(rank), world_(world) {
+Comm *Comm::create(const void *id128, int rank, int world) {
+  if (is_ipc_id(id128)) return make_ipc_comm(id128, rank, world);
+  return new RcclComm(id128, rank, world);
+}
+
+RcclComm::RcclComm(const void *id128, int rank, int world) : Comm(rank, world) {
   UniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   comm_t c = nullptr;
@@ -68,11 +89,11 @@ Comm::Comm(const void *id128, int rank, int world) : rank_(rank), world_(world) 
   comm_ = c;
 }
 
-Comm::~Comm() {
+RcclComm::~RcclComm() {
   if (comm_) api().CommDestroy(comm_);
 }
 
-void Comm::all_to_all(const double *send, double *recv, size_t count, hipStream_t s) {
+void RcclComm::all_to_all(const double *send, double *recv, size_t count, hipStream_t s) {
   Api &a = api();
   ck(a.GroupStart(), "ncclGroupStart");
   for (int p = 0; p < world_; ++p) {
@@ -82,7 +103,7 @@ void Comm::all_to_all(const double *send, double *recv, size_t count, hipStream_
   ck(a.GroupEnd(), "ncclGroupEnd");
 }
 
-void Comm::halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s) {
+void RcclComm::halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s) {
   if (world_ == 1 || count == 0) return;
   Api &a = api();
   ck(a.GroupStart(), "ncclGroupStart");
@@ -97,7 +118,7 @@ void Comm::halo(const double *send_lo, const double *send_hi, double *recv_lo, d
   ck(a.GroupEnd(), "ncclGroupEnd");
 }
 
-void Comm::all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
+void RcclComm::all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
                                 double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s) {
   Api &a = api();
   ck(a.GroupStart(), "ncclGroupStart");
@@ -116,7 +137,7 @@ void Comm::all_to_all_with_halo(const double *send, double *recv, size_t count, 
   ck(a.GroupEnd(), "ncclGroupEnd");
 }
 
-void Comm::all_reduce_sum(double *buf, size_t count, hipStream_t s) {
+void RcclComm::all_reduce_sum(double *buf, size_t count, hipStream_t s) {
   ck(api().AllReduce(buf, buf, count, kDouble, kSum, comm_, s), "ncclAllReduce");
 }
 

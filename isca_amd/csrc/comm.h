@@ -10,28 +10,40 @@
 
 namespace isca {
 
-struct RcclApi;
-
+// Two implementations behind one interface, chosen by the 128-byte id the ranks share:
+//  * RCCL (default): grouped ncclSend/ncclRecv + ncclAllReduce on the step's stream, one GPU per rank;
+//  * "ipc" (ISCA_COMM=ipc when the id is drawn; comm_ipc.cpp): host-staged exchange through files mapped by every rank -- N processes
+//    that may SHARE one GPU run the same C++ exchange schedule (isca_dyn_step's sharded loop) without RCCL, which refuses two ranks on
+//    one device.  A verification vehicle for 1-GPU boxes, not a fast path: every exchange synchronises the stream and the host.
 class Comm {
  public:
   static constexpr int UNIQUE_ID_BYTES = 128;
   static void unique_id(void *id128);                                    // throws std::runtime_error
-  Comm(const void *id128, int rank, int world);                          // collective over all ranks
-  ~Comm();
+  static Comm *create(const void *id128, int rank, int world);           // collective over all ranks
+  virtual ~Comm() {}
   int rank() const { return rank_; }
   int world() const { return world_; }
+  virtual const char *kind() const = 0;
   // equal blocks: block p of `send` goes to rank p, block q of `recv` comes from rank q (count doubles each)
-  void all_to_all(const double *send, double *recv, size_t count, hipStream_t s);
+  virtual void all_to_all(const double *send, double *recv, size_t count, hipStream_t s) = 0;
   // rows for the neighbouring latitude bands: lo <-> rank-1, hi <-> rank+1 (no wrap-around)
-  void halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s);
-  // both of the above in one RCCL group (one fused send/recv kernel instead of two)
-  void all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
-                            double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s);
-  void all_reduce_sum(double *buf, size_t count, hipStream_t s);         // in place
+  virtual void halo(const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, size_t count, hipStream_t s) = 0;
+  // both of the above in one group (RCCL: one fused send/recv kernel instead of two)
+  virtual void all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
+                                    double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s) = 0;
+  virtual void all_reduce_sum(double *buf, size_t count, hipStream_t s) = 0;         // in place
+  // this rank cannot go on (an exception on its way to the caller): peers blocked in an exchange stop with an error instead of waiting
+  virtual void abort() noexcept {}
 
- private:
-  void *comm_ = nullptr;
+ protected:
+  Comm(int rank, int world) : rank_(rank), world_(world) {}
   int rank_, world_;
 };
+
+// comm_ipc.cpp
+bool ipc_id_requested();                       // ISCA_COMM=ipc in the environment of the rank that draws the id
+void ipc_unique_id(void *id128);
+bool is_ipc_id(const void *id128);
+Comm *make_ipc_comm(const void *id128, int rank, int world);
 
 }  // namespace isca

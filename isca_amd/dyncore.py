@@ -155,6 +155,7 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.isca_dyn_comm_kind.argtypes, lib.isca_dyn_comm_kind.restype = [H], C.c_char_p
     _lib = lib
     return lib
 
@@ -176,7 +177,7 @@ EXPORTED_SYMBOLS = [
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_vert_advection_centered", "isca_compute_pressures_and_heights", "isca_leapfrog_2level_a", "isca_leapfrog_2level_b",
     "isca_compute_gaussian", "isca_compute_legendre",
-    "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check",
+    "isca_comm_get_unique_id", "isca_dyn_comm_init", "isca_comm_selftest", "isca_dyn_comm_check", "isca_dyn_comm_kind",
     "isca_dyn_diag_select", "isca_dyn_diag_read", "isca_idealized_moist_phys", "isca_trans_filter", "isca_config_sizes",
 ]
 

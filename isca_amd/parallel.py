@@ -103,10 +103,14 @@ class ShardedDynCore(dyncore.DynCore):
         ptrs, hbytes = self.halo_buffers()
         self._halo = [torch.as_tensor(_DevPtr(p, hbytes), device="cuda") for p in ptrs] if hbytes else None
         # Native mode: the library issues the exchanges itself through RCCL on our stream and a whole run of steps is one
-        # call (no Python, no torch between the kernels).  Default with the nccl backend; ISCA_COMM=torch|native overrides.
+        # call (no Python, no torch between the kernels).  Default with the nccl backend; ISCA_COMM=torch|native|ipc overrides
+        # (ipc: the same C++ step loop over the library's host-staged exchange, for ranks that share one GPU -- csrc/comm_ipc.cpp;
+        # the library reads the variable itself when rank 0 draws the communicator id).
         self.native = False
         mode = os.environ.get("ISCA_COMM", "native" if dist.get_backend(group) == "nccl" else "torch")
-        if mode == "native":
+        if mode not in ("native", "ipc", "torch"):
+            raise dyncore.IscaError(f"ISCA_COMM={mode!r}: expected native, ipc or torch")
+        if mode in ("native", "ipc"):
             box = [None]
             if cfg.rank == 0:
                 buf = C.create_string_buffer(128)
@@ -133,7 +137,7 @@ class ShardedDynCore(dyncore.DynCore):
             if why is not None:
                 self.close()       # the device handle and its stream: a failed attempt must not leak them (bench.py retries in the same process)
                 # a silent fall-back would be a silent order-of-magnitude slowdown: torch.distributed between the phases has to be asked for
-                raise dyncore.IscaError(f"native RCCL exchange not available ({why}); set ISCA_COMM=torch to drive the exchanges through "
+                raise dyncore.IscaError(f"native exchange ({mode}) not available ({why}); set ISCA_COMM=torch to drive the exchanges through "
                                         "torch.distributed between the device phases")
 
     def _torch_step(self):

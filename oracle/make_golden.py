@@ -532,9 +532,9 @@ def main():
         np.savez_compressed(path, **out)
         print(f"run_T42L25: {os.path.getsize(path)/1e6:.2f} MB")
     if not a.only or a.only == "run_T85L40":
-        # the benchmark configuration itself (T85L40, dt = 300 s), 20 steps from the cold start; 3-D fields kept as the
-        # [::4, ::8, ::8] sample (every 4th level, 8th latitude and longitude), ps as [::4, ::4]
-        out = golden_run("T85", 40, 20, (20,), dt=300, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000020$", k) is not None)
+        # the benchmark configuration itself (T85L40, dt = 300 s), steps 20 and 288 (one day) from the cold start; 3-D fields kept
+        # as the [::4, ::8, ::8] sample (every 4th level, 8th latitude and longitude), ps as [::4, ::4]   (~2 min of reference time)
+        out = golden_run("T85", 40, 288, (20, 288), dt=300, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000(020|288)$", k) is not None)
         for k in list(out):
             if k.startswith("st_"):
                 a3 = out.pop(k)
@@ -556,9 +556,9 @@ def main():
         np.savez_compressed(path, **out)
         print(f"moist_run_T85L40: {os.path.getsize(path)/1e6:.2f} MB")
     if a.only == "run_T170L60":
-        # BASELINE configs[4] at its full size: T170L60 Held-Suarez, dt = 150 s, steps 1 and 8 from the cold start;
+        # BASELINE configs[4] at its full size: T170L60 Held-Suarez, dt = 150 s, steps 1, 8 and 96 (4 hours) from the cold start;
         # 3-D fields kept as the [5::6, ::16, ::16] sample (every 6th level up to the lowest one), ps as [::8, ::8]
-        out = golden_run("T170", 60, 8, (1, 8), dt=150, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_00000(1|8)$", k) is not None)
+        out = golden_run("T170", 60, 96, (1, 8, 96), dt=150, keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|08|96)$", k) is not None)
         for k in list(out):
             if k.startswith("st_"):
                 a3 = out.pop(k)

@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--moist", action="store_true", help="the moist physics package (Frierson) instead of hs_forcing")
     ap.add_argument("--raw", type=float, default=1.0, help="raw_filter_coeff (/= 1: the Robert-Asselin-Williams filter's third exchange)")
     ap.add_argument("--tracers", type=int, default=1, help="grid tracers of the field_table (further ones: their own halo rows)")
+    ap.add_argument("--expect-comm", default="", help="'ipc': the library's own C++ step loop must be the driver (ISCA_COMM=ipc), not torch")
+    ap.add_argument("--fatal", action="store_true", help="valid_range_t that only SOME bands leave: every rank must raise")
     a = ap.parse_args()
     import torch, torch.distributed as dist
     from isca_amd import dyncore
@@ -30,6 +32,34 @@ def main():
         extra.update(num_tracers=a.tracers, tracer_robert_coeff=[-1.0, 0.05, 0.0, -1.0])
     more = [f"tr{k + 1}" for k in range(1, a.tracers)]
     sh = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, **extra))
+    if a.expect_comm:
+        kind = sh.lib.isca_dyn_comm_kind(sh._h).decode()
+        assert sh.native and kind == a.expect_comm, (sh.native, kind)
+    if a.fatal:
+        # Held-Suarez forcing warms the low latitudes of the 264 K cold start past 266 K within a day; poleward of 70 degrees the
+        # equilibrium temperature stays below: with 8 bands at T21 the two polar ranks never leave the range, the others do --
+        # error_mesg(..., FATAL) stops every PE (spectral_dynamics.F90:940-972)
+        sh.close()
+        cfg = dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, valid_range_t=(100.0, 266.0), **extra)
+        sh = ShardedDynCore(cfg)
+        sh.cold_start()
+        raised = None
+        try:
+            for _ in range(12):
+                sh.step(12)
+        except dyncore.IscaError as e:
+            raised = str(e)
+        tmax = float(sh.get("tg").max())
+        flags = [None] * world
+        dist.all_gather_object(flags, (raised, tmax))
+        if rank == 0:
+            left = [t > 266.0 for _, t in flags]
+            print("fatal test: per-rank (message, Tmax):", flags)
+            ok = all(m is not None and "valid" in m.lower() for m, _ in flags) and (world < 8 or not all(left)) and any(left)
+            print("SHARDED_CHECK", "OK" if ok else "FAILED")
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     sh.cold_start()
     sh.step(a.steps)
     got = {k: sh.gather_grid(k) for k in ["ug", "vg", "tg", "tr"] + more}

@@ -645,6 +645,30 @@ def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("world,res,levels,raw,tracers,extra", [
+    (2, "T21", 25, 1.0, 1, []), (4, "T42", 25, 1.0, 1, []), (8, "T85", 40, 1.0, 1, []),
+    (2, "T21", 8, 0.7, 1, []),                 # the RAW filter's third exchange
+    (4, "T21", 8, 1.0, 2, []),                 # a second grid tracer's halo rows
+    (2, "T21", 25, 1.0, 1, ["--moist"]),       # the moist package behind the same loop
+    (8, "T21", 10, 1.0, 1, ["--fatal"]),       # FATAL on some ranks only: every rank raises, nobody hangs in an exchange
+])
+def test_sharded_native_loop(world, res, levels, raw, tracers, extra):
+    """The library's OWN sharded step loop (api.hip sharded_step: halo exchange, lat -> m all-to-all, m -> lat all-to-all, all-reduce,
+    the RAW filter's third exchange -- issued from C++ inside isca_dyn_step(n), what an 8-GPU run executes) with N processes sharing
+    this box's GPU: ISCA_COMM=ipc swaps RCCL (which refuses two ranks per device) for the library's host-staged exchange behind the
+    same isca::Comm interface.  Against the single-rank run at 1e-10, restart of the sharded run bit for bit, and a FATAL on some
+    ranks.  Replaces transpose_fourier / reverse_transpose_fourier (transforms.F90:970-1056), spec_mpp.F90:61-80."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29700 + world),
+           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8" if world < 8 else "4",
+           "--res", res, "--levels", str(levels), "--raw", str(raw), "--tracers", str(tracers), "--expect-comm", "ipc"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc", ISCA_IPC_TIMEOUT_S="300")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
+    assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_constants_nml_radius_omega():
     """constants_nml radius / omega: the transforms do not depend on the radius, the derivative operators scale with 1/a, the Laplacian
     with 1/a^2, the Coriolis parameter with omega (the 3-D core's tables are the ones the sibling cores use)."""

@@ -405,3 +405,28 @@ def test_named_vertical_coordinates(golden_dir):
         atm.config_from_namelist({"spectral_dynamics_nml": dict(num_levels=20, vert_coord_option="v197")})
     with pytest.raises(IscaError, match="p_sigma must be greater than p_press"):
         atm.named_vert_coord("hybrid", 12, 5.0, 0.3, 3.0, 0.5, 0.4, 1.0e5)
+
+
+def test_model_time_calendars(tmp_path):
+    """RESTART/atmos_model.res (atmos_model.F90:198-202, 397-406): the date a segment ends at in each of time_manager's calendars, and
+    the calendar type a restart file carries overriding main_nml."""
+    from isca_amd import atmosphere as atm
+    day = 86400
+    assert atm._date_after([0, 0, 3, 0, 0, 0], "no_calendar", 2 * day + 3661) == [0, 0, 5, 1, 1, 1]
+    assert atm._date_after([1, 1, 1, 0, 0, 0], "thirty_day", 45 * day) == [1, 2, 16, 0, 0, 0]
+    assert atm._date_after([1, 12, 30, 0, 0, 0], "thirty_day", day) == [2, 1, 1, 0, 0, 0]
+    assert atm._date_after([2001, 12, 31, 23, 0, 0], "noleap", 7200) == [2002, 1, 1, 1, 0, 0]
+    assert atm._date_after([2000, 2, 28, 0, 0, 0], "noleap", 2 * day) == [2000, 3, 2, 0, 0, 0]
+    assert atm._date_after([1900, 2, 28, 0, 0, 0], "julian", 2 * day) == [1900, 3, 1, 0, 0, 0]          # every fourth year
+    assert atm._date_after([1900, 2, 28, 0, 0, 0], "gregorian", 2 * day) == [1900, 3, 2, 0, 0, 0]       # not 1900
+    assert atm._date_after([2000, 2, 28, 0, 0, 0], "gregorian", 2 * day) == [2000, 3, 1, 0, 0, 0]       # but 2000
+    assert atm._date_after([2003, 1, 1, 0, 0, 0], "julian", 366 * day + 365 * day) == [2005, 1, 1, 0, 0, 0]   # 2004 is a leap year
+    # a restart file's calendar type wins over the namelist's
+    (tmp_path / "atmos_model.res").write_text("  2004     2    28     0     0     0        Current model time\n     2        (Calendar: ...)\n")
+    atm._clock = {"calendar": "thirty_day", "date0": [0] * 6, "step0": 0}
+    try:
+        atm._read_model_time(str(tmp_path))
+        assert atm._clock["calendar"] == "julian" and atm._clock["date0"] == [2004, 2, 28, 0, 0, 0]
+        assert atm._date_after(atm._clock["date0"], atm._clock["calendar"], 2 * day) == [2004, 3, 1, 0, 0, 0]
+    finally:
+        atm._clock = None
