@@ -1,7 +1,7 @@
 ! atmosphere_mod -- the reference's driver interface (atmos_spectral/driver/solo/atmosphere.F90:78: atmosphere_init, atmosphere,
 ! atmosphere_end, atmosphere_domain) with the whole step on the device: atmosphere(Time) is ONE call of isca_dyn_step -- hs_forcing (or,
-! with atmosphere_nml: idealized_moist_model, the Frierson column chain), spectral_dynamics, the pressures and heights of the new level --
-! and nothing crosses PCIe.  The main program (atmos_solo/atmos_model.F90:115-142) calls these four names and nothing else of the core.
+! with atmosphere_nml: idealized_moist_model = .true., the Frierson column chain whose namelists idealized_moist_phys_init reads),
+! spectral_dynamics, the pressures and heights of the new level -- queued on the device's stream; nothing crosses PCIe.  The main program (atmos_solo/atmos_model.F90:115-142) calls these four names and nothing else of the core.
 !
 ! Restart files are written and read by the Python host mirror (isca_amd/restart.py, the reference's variable set in netCDF-3); from
 ! Fortran the model cold-starts (this image has no netCDF for fms_io).
@@ -20,6 +20,7 @@ use tracer_manager_mod, only: get_number_tracers
 use mpp_domains_mod,    only: domain2d, mpp_define_domains
 use tracer_type_mod,    only: tracer_type
 use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics_end
+use idealized_moist_phys_mod, only: idealized_moist_phys_init, idealized_moist_phys_end
 use isca_dyn_c
 use isca_dropin_mod
 
@@ -34,6 +35,8 @@ type(tracer_type), allocatable, dimension(:) :: tracer_attributes
 logical :: module_is_initialized = .false.
 logical :: dry_model
 integer :: nhum
+integer :: steps_queued = 0
+integer, parameter :: sync_every = 256
 
 contains
 
@@ -53,23 +56,39 @@ do while(ierr /= 0)
 enddo
 20 call close_file(unit)
 #endif
-if(idealized_moist_model) call error_mesg('atmosphere_init','idealized_moist_model: create the core with physics = 1 and the '// &
-  'idealized_moist_phys namelists through isca_dyn_config%moist (bindings/fortran/drive_frierson.F90); this front end runs hs_forcing', FATAL)
 call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
 allocate(tracer_attributes(num_tracers))
-dropin_physics = 0                   ! hs_forcing inside the device step (atmosphere.F90:304-311)
+if(idealized_moist_model) then
+  call idealized_moist_phys_init     ! atmosphere.F90:246-262: the namelists of the Frierson chain, which then runs inside the device step
+  dropin_physics = 1
+else
+  dropin_physics = 0                 ! hs_forcing inside the device step (atmosphere.F90:304-311)
+endif
 call spectral_dynamics_init(Time, Time_step_in, tracer_attributes, dry_model, nhum)
+if(idealized_moist_model .and. dry_model) call error_mesg('atmosphere_init', &
+  'idealized_moist_phys: the field_table has no specific-humidity tracer (sphum / mix_rat)', FATAL)
+steps_queued = 0
 module_is_initialized = .true.
 end subroutine atmosphere_init
 
 subroutine atmosphere(Time)
 type(time_type), intent(in) :: Time
 if(.not. module_is_initialized) call error_mesg('atmosphere','atmosphere module is not initialized', FATAL)
-call chk(isca_dyn_step(core, 1_c_int, 1_c_int), 'atmosphere')
+! the step is QUEUED on the core's stream (sync = 0): the host returns at once and the main program's loop runs ahead of the device, as
+! isca_amd's own step(n) does.  The device is waited for -- and valid_range_t checked (spectral_dynamics.F90:940-972: FATAL) -- every
+! sync_every calls, whenever state is read (isca_dyn_get_state synchronises), and in atmosphere_end.
+call chk(isca_dyn_step(core, 1_c_int, 0_c_int), 'atmosphere')
+steps_queued = steps_queued + 1
+if(steps_queued >= sync_every) then
+  call chk(isca_dyn_synchronize(core), 'atmosphere')
+  steps_queued = 0
+endif
 end subroutine atmosphere
 
 subroutine atmosphere_end
 if(.not. module_is_initialized) return
+call chk(isca_dyn_synchronize(core), 'atmosphere_end')
+if(idealized_moist_model) call idealized_moist_phys_end
 call spectral_dynamics_end(tracer_attributes)
 deallocate(tracer_attributes)
 module_is_initialized = .false.

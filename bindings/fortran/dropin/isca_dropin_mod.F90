@@ -21,8 +21,13 @@ integer, save :: nlon = 0, nlat = 0, nlev = 0, nfour = 0, nsph = 0      ! lon_ma
 integer, save :: ntrace = 0                                                ! prognostic tracers of the field_table
 logical, save :: virtual_t = .false.
 integer, save :: dropin_physics = 2     ! isca_dyn_config%physics of the core spectral_dynamics_init creates: 2 = the caller's physics (spectral_dynamics
-                                        ! receives its tendencies); atmosphere_mod sets 0 (hs_forcing inside the device step)
+                                        ! receives its tendencies); atmosphere_mod sets 0 (hs_forcing inside the device step) or 1 (the Frierson chain)
 real, save :: ref_sea_level_press = 101325.
+logical, save :: triang = .true.        ! spectral_dynamics_nml: triang_trunc, fourier_inc of the core (get_triang_trunc, get_fourier_inc)
+integer, save :: finc = 1
+! atmosphere_nml: idealized_moist_model -- the namelist values idealized_moist_phys_init collected for isca_dyn_config%moist (physics = 1)
+type(isca_moist_config), save :: dropin_moist
+logical, save :: dropin_moist_set = .false.
 
 contains
 

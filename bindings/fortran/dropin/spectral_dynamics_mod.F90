@@ -3,9 +3,12 @@
 ! (isca_dyn_create, physics = 2: the host keeps its physics package), spectral_dynamics is isca_dyn_dynamics followed by the copies
 ! the reference returns to its caller (spectral_dynamics.F90:780-795, :1023-1028).
 !
+! With isca_dropin_mod%dropin_physics = 1 (atmosphere_mod, atmosphere_nml: idealized_moist_model) the core is created with the Frierson
+! column chain and the namelist values idealized_moist_phys_init collected.  vert_coord_option: 'even_sigma', 'uneven_sigma' and 'input'
+! (vert_coordinate_nml's pk, bk).
 ! Not here: restart files (fms_io / netCDF; the Python host mirror isca_amd/restart.py writes and reads them), topography options
-! other than 'flat', vert_coord_option other than 'even_sigma' / 'uneven_sigma', initial_state_option other than 'quiescent'.  Each is
-! refused with error_mesg(..., FATAL) naming the option.
+! other than 'flat' and 'gaussian', vert_coord_option 'hybrid' / 'mcm' / 'v197' (isca_amd.atmosphere.named_vert_coord), initial_state_option
+! other than 'quiescent'.  Each is refused with error_mesg(..., FATAL) naming the option.
 module spectral_dynamics_mod
 
 #ifdef INTERNAL_FILE_NML
@@ -77,6 +80,11 @@ namelist /hs_forcing_nml/ no_forcing, t_zero, t_strat, delh, delv, eps, sigma_b,
                           v_wind_file, equilibrium_t_option, equilibrium_t_file, p_trop, alpha, peri_time, smaxis, albedo, lapse, h_a,  &
                           tau_s, orbital_period, heat_capacity, ml_depth, spinup_time, stratosphere_t_option, P00
 
+! ---- vert_coordinate_nml (init/vert_coordinate.F90:80-83), read when vert_coord_option = 'input'
+integer, parameter :: max_levels = 100
+real, dimension(max_levels+1) :: pk = 0., bk = 0.
+namelist /vert_coordinate_nml/ pk, bk
+
 logical :: module_is_initialized = .false.
 logical :: dry_model
 integer :: nhum, num_tracers
@@ -92,6 +100,8 @@ subroutine read_nml(which)
   if(which == 'dyn') read(input_nml_file, nml=spectral_dynamics_nml, iostat=io)
   if(which == 'ini') read(input_nml_file, nml=spectral_init_cond_nml, iostat=io)
   if(which == 'hs')  read(input_nml_file, nml=hs_forcing_nml, iostat=io)
+  if(which == 'vc')  read(input_nml_file, nml=vert_coordinate_nml, iostat=io)
+  if(which == 'vc')  ierr = check_nml_error(io, 'vert_coordinate_nml')
   if(which == 'dyn') ierr = check_nml_error(io, 'spectral_dynamics_nml')
   if(which == 'ini') ierr = check_nml_error(io, 'spectral_init_cond_nml')
   if(which == 'hs')  ierr = check_nml_error(io, 'hs_forcing_nml')
@@ -102,6 +112,7 @@ subroutine read_nml(which)
     if(which == 'dyn') read(unit, nml=spectral_dynamics_nml, iostat=io, end=20)
     if(which == 'ini') read(unit, nml=spectral_init_cond_nml, iostat=io, end=20)
     if(which == 'hs')  read(unit, nml=hs_forcing_nml, iostat=io, end=20)
+    if(which == 'vc')  read(unit, nml=vert_coordinate_nml, iostat=io, end=20)
     ierr = check_nml_error(io, which)
   enddo
 20 call close_file(unit)
@@ -149,7 +160,7 @@ if(trim(topography_option) /= 'flat') &
 if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
 if(make_symmetric) call error_mesg('spectral_dynamics_init','make_symmetric = .true. is not a supported value.', FATAL)
 if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
-if(no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind) &
+if(dropin_physics /= 1 .and. (no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
   call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing is carried by the device core.', FATAL)
 
 call chk(isca_dyn_config_default(cfg), 'spectral_dynamics_init')
@@ -188,10 +199,21 @@ select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coor
     do k = 0, num_levels
       cfg%pk_input(k+1) = 0.; cfg%bk_input(k+1) = real(k)/real(num_levels)
     enddo
+  case('input')                             ! read_namelist (init/vert_coordinate.F90:187-216): the half levels of vert_coordinate_nml
+    call read_nml('vc')
+    if(num_levels + 1 > size(cfg%pk_input)) call error_mesg('spectral_dynamics_init','more levels than the device core carries', FATAL)
+    if(all(bk(1:num_levels+1) == 0.) .and. all(pk(1:num_levels+1) == 0.)) call error_mesg('read_namelist in vert_coordinate_mod', &
+      'No levels specified in namelist vert_coordinate_nml or namelist is missing ', FATAL)
+    cfg%vert_coord_input = 1
+    cfg%pk_input(1:num_levels+1) = pk(1:num_levels+1); cfg%bk_input(1:num_levels+1) = bk(1:num_levels+1)
   case default
     call error_mesg('spectral_dynamics_init','"'//trim(vert_coord_option)//'" is not a supported value for vert_coord_option here '// &
-                    '(even_sigma, uneven_sigma; the others through pk_input / bk_input of the library).', FATAL)
+                    '(even_sigma, uneven_sigma, input; hybrid / mcm / v197 through pk_input / bk_input of the library).', FATAL)
 end select
+if(dropin_physics == 1) then                ! the Frierson chain inside the device step: idealized_moist_phys_init's namelist values
+  if(.not. dropin_moist_set) call error_mesg('spectral_dynamics_init','physics = 1 without idealized_moist_phys_init', FATAL)
+  cfg%moist = dropin_moist
+endif
 
 ! ---- the field_table, as the reference reads it (spectral_dynamics.F90:316-409)
 call get_number_tracers(MODEL_ATMOS, num_prog=num_tracers)
@@ -252,6 +274,7 @@ call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
 core_ready = .true.
 nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
 virtual_t = use_virtual_temperature; ref_sea_level_press = reference_sea_level_press
+triang = triang_trunc; finc = fourier_inc
 module_is_initialized = .true.
 
 end subroutine spectral_dynamics_init

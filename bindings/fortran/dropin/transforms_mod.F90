@@ -108,13 +108,13 @@ call need_core('get_num_spherical'); num_spherical_out = nsph
 end subroutine get_num_spherical
 subroutine get_fourier_inc(fourier_inc_out)
 integer, intent(out) :: fourier_inc_out
-call need_core('get_fourier_inc'); fourier_inc_out = (nsph - 1)/max(nfour, 1)
+call need_core('get_fourier_inc'); fourier_inc_out = finc
 end subroutine get_fourier_inc
 subroutine get_triang_trunc(triang_trunc_out)
 logical, intent(out) :: triang_trunc_out
 real :: eig(0:nfour, 0:nsph)
 call need_core('get_triang_trunc')
-triang_trunc_out = .true.        ! (the rhomboidal mask is an option of the library's config; this front end creates the triangular one)
+triang_trunc_out = triang
 end subroutine get_triang_trunc
 
 subroutine get_deg_lon(deg_lon_out)

@@ -81,6 +81,10 @@ interface
   integer(c_int) function isca_dyn_step(h, nsteps, sync) bind(C)
     import; type(c_ptr), value :: h; integer(c_int), value :: nsteps, sync
   end function
+  ! wait for the steps queued with sync = 0 and check valid_range_t (spectral_dynamics.F90:940-972)
+  integer(c_int) function isca_dyn_synchronize(h) bind(C)
+    import; type(c_ptr), value :: h
+  end function
   ! spectral_dynamics(..., dt_ug, dt_vg, dt_tg, dt_tracers, ...) after a physics package of the caller's own (physics = 2):
   ! (lon, lat, lev) tendency arrays; hs_forcing / tracer_source_sink of hs_forcing_mod on caller fields
   integer(c_int) function isca_dyn_dynamics(h, dt_ug, dt_vg, dt_tg, dt_tracers, on_device, sync) bind(C)

@@ -895,6 +895,11 @@ static StepScalars step_scalars(isca_dyn *h) {
   sc.xi = sc.delta_t * h->cfg.alpha_implicit;
   return sc;
 }
+// the grid tracer's transport under two timer names (the horizontal and the vertical kernel; part as in launch_tracer)
+static void timed_tracer(isca_dyn *h, const StepScalars &sc, hipStream_t st, int part = -1) {
+  if (part != 1) { Timed t(h, "tracer_horiz", st); launch_tracer(*h, sc, st, 0); }
+  if (part != 0) { Timed t(h, "tracer_vert", st); launch_tracer(*h, sc, st, 1); }
+}
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   h->in_step = true;
   if (h->cfg.physics == 1) {
@@ -910,18 +915,18 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   if (early) {
     HIP_CHECK(hipEventRecord(h->ev_fork0, h->stream));
     HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork0, 0));
-    { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2, 0); }
+    timed_tracer(h, sc, h->stream2, 0);
   }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->tracer_on) {
     if (h->g.P > 1) {
       Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // the tracer itself runs once the halo rows are in
     } else if (h->tracer_serial) {
-      Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream);
+      timed_tracer(h, sc, h->stream);
     } else {
       HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
       HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-      { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2, early ? 1 : -1); }
+      timed_tracer(h, sc, h->stream2, early ? 1 : -1);
       HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
     }
   }
@@ -931,10 +936,10 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
 // BEFORE the lat -> m all-to-all, on the side stream: it then runs under that exchange and the spectral pipeline, like on one GPU.
 static void phase_tracer(isca_dyn *h, const StepScalars &sc) {
   if (!h->tracer_on || h->g.P == 1) return;
-  if (h->tracer_serial) { Timed t(h, "tracer"); launch_tracer(*h, sc, h->stream); return; }
+  if (h->tracer_serial) { timed_tracer(h, sc, h->stream); return; }
   HIP_CHECK(hipEventRecord(h->ev_fork, h->stream));
   HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-  { Timed t(h, "tracer", h->stream2); launch_tracer(*h, sc, h->stream2); }
+  timed_tracer(h, sc, h->stream2);
   HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis

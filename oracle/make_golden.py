@@ -416,6 +416,44 @@ def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_gr
     return out
 
 
+def golden_developed(res="T42", L=25, day=60, dt=600, more=(1, 10), track=24):
+    """A DEVELOPED state and the steps after it (configs[1] of BASELINE.json, T42L25 Held-Suarez): the reference runs `day` days from
+    its cold start -- baroclinic eddies at finite amplitude, Courant numbers, polar rows, the sponge and the fixers all see weather --,
+    dumps BOTH time levels (harness.nml dump_full_at; the filtered levels followed through the public API, ref_harness.F90
+    track_filter), then `more` further steps.  Inputs: the full two-level state; outputs: strided samples + extremes."""
+    lon, lat, nf, ns = RES[res]
+    n0 = day * 86400 // dt
+    with tempfile.TemporaryDirectory(prefix="refdev_") as d:
+        prepare_rundir(d, res, L, "run", nsteps=n0 + max(more), dt=dt, dump_steps=[n0 + m for m in more])
+        with open(os.path.join(d, "harness.nml"), "w") as f:
+            f.write(f" &harness_nml\n   mode = 'run', nsteps = {n0 + max(more)}, dt_atmos = {int(dt)}, dump_steps = "
+                    f"{', '.join(str(n0 + m) for m in more)}, dump_tables = .false., track_from = {n0 - track}, dump_full_at = {n0}\n /\n")
+        stdout = run_harness(d, timeout=6 * 3600)
+        out = {}
+        sh = shapes(res, L)
+        for fn in sorted(os.listdir(d)):
+            if not fn.endswith(".bin") or not (fn.startswith("rs_") or fn.startswith("st_")):
+                continue
+            name, raw = fn[:-4], np.fromfile(os.path.join(d, fn))
+            if name.startswith("rs_"):
+                if re.match(r"rs_(vors|divs|ts)_", name):
+                    out[name] = raw.view(np.complex128).reshape(sh["spec"])
+                elif name.startswith("rs_lnps"):
+                    out[name] = raw.view(np.complex128).reshape(sh["spec2"])
+                else:
+                    out[name] = raw.reshape(sh["grid"] if raw.size == np.prod(sh["grid"]) else sh["grid2"])
+            elif re.match(r"st_(ug|vg|tg|psg|tr1)_", name) and int(name[-6:]) > n0:
+                a3 = raw.reshape(sh["grid"] if raw.size == np.prod(sh["grid"]) else sh["grid2"])
+                key = "after%d_%s" % (int(name[-6:]) - n0, name[3:-7])
+                out[key + ("_s222" if a3.ndim == 3 else "")] = np.ascontiguousarray(a3[::2, ::2, ::2] if a3.ndim == 3 else a3)
+                out[key + "_minmax"] = np.array([a3.min(), a3.max()])
+    m = re.search(r"REF_DEVELOPED max\|u\|,max\|v\|,Tmin,Tmax=\s*(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["developed_maxu_maxv_Tmin_Tmax"] = np.array([float(x) for x in m.groups()])
+    out.update({"meta_res": np.array(res), "meta_num_levels": np.array(L), "meta_dt_atmos": np.array(float(dt)), "meta_step0": np.array(n0),
+                "meta_more": np.array(more)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -566,6 +604,12 @@ def main():
         path = os.path.join(GOLD, "run_T170L60.npz")
         np.savez_compressed(path, **out)
         print(f"run_T170L60: {os.path.getsize(path)/1e6:.2f} MB")
+    if a.only == "developed_T42L25":
+        # the developed-state restart fixture (~25 min of reference time; 20 MB: the full two-level state is the INPUT)
+        out = golden_developed()
+        path = os.path.join(GOLD, "developed_T42L25.npz")
+        np.savez_compressed(path, **out)
+        print(f"developed_T42L25: {os.path.getsize(path)/1e6:.2f} MB,", out["developed_maxu_maxv_Tmin_Tmax"])
     if not a.only or a.only == "tables_T85":
         out = golden_run("T85", 2, 0, (), keep=lambda k: k.startswith("tab_"))
         leg = out.pop("tab_legendre")

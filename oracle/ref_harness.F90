@@ -51,7 +51,14 @@ character(len=16) :: mode = 'run'
 integer :: nsteps = 1, dt_atmos = 600
 integer, dimension(64) :: dump_steps = -1
 logical :: dump_tables = .true.
-namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, dump_tables
+! developed-state restart fixture: the module keeps its spectral arrays (and its Robert-filtered tracer levels) private, so from step
+! track_from on the driver follows the filter itself through public routines -- s(k) = the spectral state of the grid fields of
+! step k (vor_div_from_uv_grid, trans_grid_to_spherical: equal to the module's own to roundoff), filtered level
+! F(k) = (s(k) + robert*(F(k-1) - 2 s(k))) + robert*s(k+1)  (leapfrog_2level_A/B, leapfrog.F90:58-105 with raw_filter_coeff = 1);
+! the start value F = s is forgotten as robert**steps (0.04**16 ~ 4e-23) -- and at step dump_full_at writes BOTH time levels (rs_*).
+integer :: track_from = -1, dump_full_at = -1
+real    :: robert_coeff = 0.04      ! spectral_dynamics_nml's value (the module does not export it)
+namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, dump_tables, track_from, dump_full_at, robert_coeff
 
 type(time_type) :: Time, Time_step, Time_next
 type(tracer_type), allocatable, dimension(:) :: tracer_attributes
@@ -70,6 +77,9 @@ real, allocatable, dimension(:,:,:,:)   :: dt_tracers
 real, allocatable, dimension(:,:)       :: dt_psg, surf_geopotential
 real, allocatable, dimension(:)         :: deg_lon, deg_lat, rad_lonb, rad_latb, pk, bk, sin_lat, wts_lat
 real, allocatable, dimension(:,:)       :: rad_lon_2d, rad_lat_2d, rad_lonb_2d, rad_latb_2d
+complex, allocatable, dimension(:,:,:)  :: sc_vor, sc_div, sc_t, sn_vor, sn_div, sn_t, f_vor, f_div, f_t
+complex, allocatable, dimension(:,:)    :: sc_lp, sn_lp, f_lp
+real, allocatable, dimension(:,:,:,:)   :: f_tr
 
 open(newunit=unit, file='harness.nml', status='old', action='read')
 read(unit, nml=harness_nml)
@@ -157,6 +167,8 @@ if(trim(mode) == 'run') then
     call one_step()
     call system_clock(c1)
     t_loop = t_loop + real(c1-c0,8)/real(crate,8)
+    if(track_from >= 0 .and. istep >= track_from) call track_filter(istep == track_from)
+    if(istep == dump_full_at) call dump_both_levels()
     if(any(dump_steps == istep)) call dump_state(istep)
   enddo
   write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
@@ -209,6 +221,69 @@ previous = current
 current  = future
 Time = Time_next
 end subroutine one_step
+
+!--------------------------------------------------------------------------------------------------
+subroutine spec_of_current(vs, ds, tts, lps)
+complex, intent(out) :: vs(ms:,ns:,:), ds(ms:,ns:,:), tts(ms:,ns:,:), lps(ms:,ns:)
+real, allocatable :: lnpsg(:,:)
+allocate(lnpsg(is:ie,js:je))
+call vor_div_from_uv_grid(ug(:,:,:,current), vg(:,:,:,current), vs, ds)
+call trans_grid_to_spherical(tg(:,:,:,current), tts)
+lnpsg = log(psg(:,:,current))
+call trans_grid_to_spherical(lnpsg, lps)
+deallocate(lnpsg)
+end subroutine spec_of_current
+
+subroutine track_filter(first)
+logical, intent(in) :: first
+integer :: ntr
+real :: rq
+if(first) then
+  allocate(sc_vor(ms:me,ns:ne,num_levels), sc_div(ms:me,ns:ne,num_levels), sc_t(ms:me,ns:ne,num_levels), sc_lp(ms:me,ns:ne))
+  allocate(sn_vor(ms:me,ns:ne,num_levels), sn_div(ms:me,ns:ne,num_levels), sn_t(ms:me,ns:ne,num_levels), sn_lp(ms:me,ns:ne))
+  allocate(f_vor(ms:me,ns:ne,num_levels), f_div(ms:me,ns:ne,num_levels), f_t(ms:me,ns:ne,num_levels), f_lp(ms:me,ns:ne))
+  allocate(f_tr(is:ie,js:je,num_levels,num_tracers))
+  call spec_of_current(sc_vor, sc_div, sc_t, sc_lp)
+  f_vor = sc_vor; f_div = sc_div; f_t = sc_t; f_lp = sc_lp
+  f_tr = grid_tracers(:,:,:,current,:)
+  return
+endif
+! the step just taken made s(k+1) (= current now); sc_* is s(k) (= previous now), f_* the filtered level k-1
+call spec_of_current(sn_vor, sn_div, sn_t, sn_lp)
+f_vor = sc_vor + robert_coeff*(f_vor - 2.0*sc_vor); f_vor = f_vor + robert_coeff*sn_vor
+f_div = sc_div + robert_coeff*(f_div - 2.0*sc_div); f_div = f_div + robert_coeff*sn_div
+f_t   = sc_t   + robert_coeff*(f_t   - 2.0*sc_t  ); f_t   = f_t   + robert_coeff*sn_t
+f_lp  = sc_lp  + robert_coeff*(f_lp  - 2.0*sc_lp ); f_lp  = f_lp  + robert_coeff*sn_lp
+do ntr = 1, num_tracers
+  rq = tracer_attributes(ntr)%robert_coeff
+  f_tr(:,:,:,ntr) = grid_tracers(:,:,:,previous,ntr) + rq*(f_tr(:,:,:,ntr) - 2.0*grid_tracers(:,:,:,previous,ntr))
+  f_tr(:,:,:,ntr) = f_tr(:,:,:,ntr) + rq*grid_tracers(:,:,:,current,ntr)
+enddo
+sc_vor = sn_vor; sc_div = sn_div; sc_t = sn_t; sc_lp = sn_lp
+end subroutine track_filter
+
+subroutine dump_both_levels()
+! what a restart of spectral_dynamics_mod + atmosphere_mod holds (spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375)
+integer :: ntr
+character(len=1) :: trno
+call dumpc3('rs_vors_cur.bin', sc_vor);  call dumpc3('rs_divs_cur.bin', sc_div)
+call dumpc3('rs_ts_cur.bin', sc_t);      call dumpc2('rs_lnps_cur.bin', sc_lp)
+call dumpc3('rs_vors_prev.bin', f_vor);  call dumpc3('rs_divs_prev.bin', f_div)
+call dumpc3('rs_ts_prev.bin', f_t);      call dumpc2('rs_lnps_prev.bin', f_lp)
+call dump3('rs_ug_cur.bin', ug(:,:,:,current));   call dump3('rs_ug_prev.bin', ug(:,:,:,previous))
+call dump3('rs_vg_cur.bin', vg(:,:,:,current));   call dump3('rs_vg_prev.bin', vg(:,:,:,previous))
+call dump3('rs_tg_cur.bin', tg(:,:,:,current));   call dump3('rs_tg_prev.bin', tg(:,:,:,previous))
+call dump2('rs_psg_cur.bin', psg(:,:,current));   call dump2('rs_psg_prev.bin', psg(:,:,previous))
+call dump3('rs_wg_full.bin', wg_full)
+do ntr = 1, num_tracers
+  write(trno,'(i1)') ntr
+  call dump3('rs_tr'//trno//'_cur.bin', grid_tracers(:,:,:,current,ntr))          ! the dynamics' and atmosphere_mod's newest level
+  call dump3('rs_tr'//trno//'_prev_atm.bin', grid_tracers(:,:,:,previous,ntr))    ! atmosphere_mod's (unfiltered) previous level
+  call dump3('rs_tr'//trno//'_prev_filt.bin', f_tr(:,:,:,ntr))                    ! the dynamics' Robert-filtered previous level
+enddo
+write(*,'(a,4es16.8)') 'REF_DEVELOPED max|u|,max|v|,Tmin,Tmax=', maxval(abs(ug(:,:,:,current))), maxval(abs(vg(:,:,:,current))), &
+     minval(tg(:,:,:,current)), maxval(tg(:,:,:,current))
+end subroutine dump_both_levels
 
 !--------------------------------------------------------------------------------------------------
 subroutine dump_state(n)

@@ -98,3 +98,52 @@ def test_atmos_model_loop_on_atmosphere_mod(tmp_path, golden_dir):
     sc = SpectralCore(Config.resolution("T21", 25))
     (mean_ps,) = [float(x) for x in re.search(r"DRIVE_MEAN_PS\s*(\S+)", stdout).groups()]
     assert abs(mean_ps - sc.area_weighted_global_mean(g["st_psg_000144"])) < 1e-6
+
+
+def test_atmos_model_loop_frierson_through_atmosphere_mod(tmp_path, golden_dir):
+    """BASELINE configs[3]'s model behind the reference's module interface: atmosphere_nml idealized_moist_model = .true. makes this
+    repository's atmosphere_mod call idealized_moist_phys_init (atmosphere.F90:246-262), which reads the Frierson test case's namelists
+    IN FORTRAN -- idealized_moist_phys_nml, two_stream_gray_rad_nml, mixed_layer_nml, qe_moist_convection_nml, lscale_cond_nml,
+    sat_vapor_pres_nml, damping_driver_nml, vert_turb_driver_nml, diffusivity_nml, surface_flux_nml, and vert_coordinate_nml's 25 levels --
+    and creates the core with physics = 1; atmos_model's loop then queues one device step per atmosphere(Time).  144 steps against the
+    reference run of the same input.nml (moist tolerances of tests/test_gpu_moist.py)."""
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    d = str(tmp_path / "run")
+    mg.prepare_moist_rundir(d, "T21", 144, dt=720)
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 144, dt_atmos = 720\n /\n")
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    g = np.load(os.path.join(golden_dir, "moist_run_T21L25.npz"))
+    tg, ug, q = g["st_tg_000144"], g["st_ug_000144"], g["st_q_000144"]
+    tmin, tmax, umax = [float(x) for x in re.search(r"DRIVE_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout).groups()]
+    assert abs(tmin - tg.min()) < 1e-7 and abs(tmax - tg.max()) < 1e-7 and abs(umax - np.abs(ug).max()) < 1e-7
+    qmax, qpt = [float(x) for x in re.search(r"DRIVE_TRACER qmax,q\(10,16,nlev\)=\s*(\S+)\s+(\S+)", stdout).groups()]
+    assert abs(qmax - q.max()) < 1e-10 and abs(qpt - q[24, 15, 9]) < 1e-10
+    # an option the device package does not implement is refused by name, from Fortran, like the reference's own "not a valid value" FATALs
+    nml = open(os.path.join(d, "input.nml")).read().replace("convection_scheme = 'SIMPLE_BETTS_MILLER'", "convection_scheme = 'FULL_BETTS_MILLER'")
+    open(os.path.join(d, "input.nml"), "w").write(nml)
+    with pytest.raises(RuntimeError, match="is not a supported value for convection_scheme"):
+        mg.run_harness(d, exe=exe, timeout=300)
+
+
+def test_atmosphere_mod_queues_steps(tmp_path):
+    """atmosphere(Time) queues its step (isca_dyn_step(core, 1, sync = 0)): the main program's loop runs ahead of the device, and the
+    drop-in's step costs what the library's own step(n) costs -- DRIVE_TIMING of a T42L25 run against DynCore.step on the same box."""
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    import time
+    from oracle import make_golden as mg
+    from isca_amd import dyncore
+    d = str(tmp_path / "run")
+    mg.prepare_rundir(d, "T42", 25, "run", nsteps=1, dt=600)
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 4000, dt_atmos = 600\n /\n")
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    ms_dropin = float(re.search(r"DRIVE_TIMING steps=\s*\d+\s+seconds=\s*\S+\s+ms_per_step=\s*(\S+)", stdout).group(1))
+    dc = dyncore.DynCore(dyncore.default_config("T42", num_levels=25)); dc.cold_start(); dc.step(1000)
+    t0 = time.perf_counter(); dc.step(3000); ms_lib = 1e3 * (time.perf_counter() - t0) / 3000
+    dc.close()
+    print("T42L25: atmosphere(Time) %.4f ms per step, DynCore.step(n) %.4f ms per step" % (ms_dropin, ms_lib))
+    assert ms_dropin < 1.25 * ms_lib + 0.01, (ms_dropin, ms_lib)
