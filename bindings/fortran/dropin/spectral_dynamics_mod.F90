@@ -145,11 +145,6 @@ if(damping_coeff_vor == -1.) damping_coeff_vor = damping_coeff
 if(damping_coeff_div == -1.) damping_coeff_div = damping_coeff
 
 ! what the device core does not carry is refused by name (check_dynamics_nml's own tests are the library's: isca_dyn_create)
-if(uppercase(trim(vert_advect_uv)) /= 'SECOND_CENTERED') &
-  call error_mesg('spectral_dynamics_init','"'//trim(vert_advect_uv)//'" is not a supported value for vert_advect_uv (second_centered only).', FATAL)
-if(uppercase(trim(vert_advect_t)) /= 'SECOND_CENTERED') &
-  call error_mesg('spectral_dynamics_init','"'//trim(vert_advect_t)//'" is not a supported value for vert_advect_t (second_centered only).', FATAL)
-if(.not. use_implicit) call error_mesg('spectral_dynamics_init','use_implicit = .false. is not a supported value.', FATAL)
 if(trim(vert_difference_option) /= 'simmons_and_burridge') &
   call error_mesg('spectral_dynamics_init','"'//trim(vert_difference_option)//'" is not a supported value for vert_difference_option.', FATAL)
 if(trim(initial_state_option) /= 'quiescent') &
@@ -190,6 +185,8 @@ cfg%radius = radius; cfg%omega = omega
 cfg%t_zero = t_zero; cfg%t_strat = t_strat; cfg%delh = delh; cfg%delv = delv; cfg%eps = eps; cfg%sigma_b = sigma_b
 cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_conserve_energy)
 cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
+cfg%vert_advect_uv = advect_scheme(vert_advect_uv, 'vert_advect_uv'); cfg%vert_advect_t = advect_scheme(vert_advect_t, 'vert_advect_t')
+cfg%use_implicit = merge(1, 0, use_implicit)
 cfg%physics = dropin_physics                ! 2: the caller keeps its physics package and spectral_dynamics receives its tendencies
 select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coordinate.F90:124-152)
   case('uneven_sigma')
@@ -278,6 +275,21 @@ triang = triang_trunc; finc = fourier_inc
 module_is_initialized = .true.
 
 end subroutine spectral_dynamics_init
+
+!===============================================================================================
+! spectral_dynamics.F90:280-301
+integer function advect_scheme(name, what)
+character(len=*), intent(in) :: name, what
+select case(uppercase(trim(name)))
+  case('SECOND_CENTERED');         advect_scheme = 0
+  case('FOURTH_CENTERED');         advect_scheme = 1
+  case('VAN_LEER_LINEAR');         advect_scheme = 2
+  case('FINITE_VOLUME_PARABOLIC'); advect_scheme = 3
+  case default
+    advect_scheme = -1
+    call error_mesg('spectral_dynamics_init','"'//trim(name)//'"'//' is not a valid value for '//trim(what)//'.', FATAL)
+end select
+end function advect_scheme
 
 !===============================================================================================
 subroutine get_initial_fields(ug_out, vg_out, tg_out, psg_out, grid_tracers_out)

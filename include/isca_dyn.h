@@ -112,6 +112,15 @@ typedef struct isca_dyn_config {
    * and energy-conversion terms of four_in_one (spectral_dynamics.F90:857-864), in compute_geopotential and in the heights of
    * compute_pressures_and_heights (press_and_geopot.F90:246-256, 340-355).  Ignored without tracer 1 (the reference's dry_model). */
   int use_virtual_temperature;
+  /* vert_advect_uv / vert_advect_t (spectral_dynamics_nml, spectral_dynamics.F90:280-301): the scheme of vert_advection
+   * (atmos_shared/vert_advection/vert_advection.F90:69-478, ADVECTIVE_FORM) for u, v and for T --
+   * 0 'second_centered' (the default, fused into the column kernel), 1 'fourth_centered' (on the current level, :878,885),
+   * 2 'van_leer_linear', 3 'finite_volume_parabolic' (both on the PREVIOUS level with the step's delta_t, :879,886).
+   * A value other than 0 adds one kernel to the step (the scheme on whole columns). */
+  int vert_advect_uv, vert_advect_t;
+  /* use_implicit (spectral_dynamics_nml, default .true. = 1; spectral_dynamics.F90:469-481, 906): 0 = no implicit_correction of the
+   * divergence / temperature / surface-pressure tendencies: explicit leapfrog of the gravity waves (needs a short dt_atmos). */
+  int use_implicit;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -66,10 +66,11 @@ _REF_DEFAULTS = dict(
     eddy_sponge_coeff=0., zmu_sponge_coeff=0., zmv_sponge_coeff=0., robert_coeff=.04, alpha_implicit=.5, scale_heights=4., surf_res=.1,
     exponent=2.5, initial_sphum=0.0, reference_sea_level_press=101325., water_correction_limit=0.0, raw_filter_coeff=1.0,
     valid_range_t=(100., 500.), dt_atmos=0.0, cutoff_wn=15, damping_coeff_vor=-1., damping_coeff_div=-1., damping_order_vor=-1,
-    damping_order_div=-1,
+    damping_order_div=-1, vert_advect_uv=0, vert_advect_t=0, use_implicit=1,
     t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=1, trflux=1.e-5,
     trsink=-4., P00=1.e5)
 _REF_VERT_COORD_OPTION = "even_sigma"            # spectral_dynamics.F90:175
+_VERT_ADVECT_SCHEMES = {"SECOND_CENTERED": 0, "FOURTH_CENTERED": 1, "VAN_LEER_LINEAR": 2, "FINITE_VOLUME_PARABOLIC": 3}     # spectral_dynamics.F90:280-301
 _DAMPING_OPTIONS = {"resolution_dependent": 0, "exponential_cutoff": 1, "resolution_independent": 2}     # spectral_damping.F90:124-153
 # moist package, isca_moist_config members: idealized_moist_phys.F90:136-138, two_stream_gray_rad.F90:72-82, mixed_layer.F90:84-95,
 # qe_moist_convection.F90:66-70, damping_driver.f90:42-56, vert_turb_driver.F90:116, diffusivity.F90:127-128, monin_obukhov.F90:88-89
@@ -255,8 +256,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
         raise IscaError(f'"{dopt}" is an invalid value for damping_option')                      # spectral_damping.F90:152-153
     kw["damping_option"] = _DAMPING_OPTIONS[dopt]
     unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma", "hybrid", "mcm", "v197") else "uneven_sigma", "damping_option": dopt,
-                   "vert_difference_option": "simmons_and_burridge", "vert_advect_uv": "second_centered",
-                   "vert_advect_t": "second_centered", "initial_state_option": "quiescent",
+                   "vert_difference_option": "simmons_and_burridge", "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}
     for grp in _NML_GROUPS:
         for k, v in (namelist or {}).get(grp, {}).items():
@@ -265,13 +265,17 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 if str(v).lower() != unsupported[k].lower():
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
                 continue
-            if k == "use_virtual_temperature":
+            if k in ("use_virtual_temperature", "use_implicit"):
                 kw[k] = int(bool(v))
                 continue
-            if k in ("use_implicit", "make_symmetric"):      # one value implemented each
-                want = k == "use_implicit"
-                if bool(v) != want:
-                    raise IscaError(f'"{v}" is not a supported value for {k} (only "{want}")')
+            if k in ("vert_advect_uv", "vert_advect_t"):     # spectral_dynamics.F90:280-301
+                if str(v).upper() not in _VERT_ADVECT_SCHEMES:
+                    raise IscaError(f'"{v}" is not a valid value for {k}.')
+                kw[k] = _VERT_ADVECT_SCHEMES[str(v).upper()]
+                continue
+            if k == "make_symmetric":                        # one value implemented
+                if bool(v):
+                    raise IscaError(f'"{v}" is not a supported value for {k} (only "False")')
                 continue
             if k in ("p_press", "p_sigma"):           # vert_coord_option = 'hybrid' (used above)
                 continue

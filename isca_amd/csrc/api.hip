@@ -107,6 +107,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->physics = 0; c->vert_coord_input = 0;
   for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
   c->use_virtual_temperature = 0;
+  c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1;
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -183,6 +184,10 @@ static void check_config(const isca_dyn_config &c) {
       if (!(c.pk_input[k + 1] + c.bk_input[k + 1] * c.reference_sea_level_press > c.pk_input[k] + c.bk_input[k] * c.reference_sea_level_press))
         fail("vert_coordinate_nml: pk/bk must give increasing half-level pressures");
   }
+  if (c.vert_advect_uv < 0 || c.vert_advect_uv > 3)
+    fail("spectral_dynamics_init: \"" + std::to_string(c.vert_advect_uv) + "\" is not a valid value for vert_advect_uv.");
+  if (c.vert_advect_t < 0 || c.vert_advect_t > 3)
+    fail("spectral_dynamics_init: \"" + std::to_string(c.vert_advect_t) + "\" is not a valid value for vert_advect_t.");
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
@@ -389,6 +394,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         }
         while ((act.size() / 4) % 4) { act.push_back(-1); act.push_back(0); act.push_back(0); act.push_back(Lw); }
       }
+      // whole blocks of padding up to a multiple of 8 blocks: k_spec_update gives every XCD a CONTIGUOUS eighth of the list (the blocks of one
+      // total wavenumber share a wave matrix, those of neighbouring ones the rows n - 1 / n + 1 of the forward batch: one L2 fetches them once)
+      const int last_lw = act.empty() ? 0 : act[act.size() - 1];
+      while ((act.size() / 16) % 8) for (int q = 0; q < 4; ++q) { act.push_back(-1); act.push_back(0); act.push_back(0); act.push_back(last_lw); }
       h->n_active = (int)(act.size() / 4);
       d.mn_active = dupload(h, act);
     }
@@ -545,9 +554,11 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     // Lazy fixers (core.h): for the plain configurations -- one grid tracer at most, Robert filter without the RAW term, no virtual
     // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
-    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 &&
+    // (a vertical advection scheme other than second-centred reads the stored previous level in a kernel of its own: eager fixers)
+    const bool vadv_ext = cfg->vert_advect_uv != 0 || cfg->vert_advect_t != 0;
+    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1);    // eager fixers: sums, totals, apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -918,6 +929,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     timed_tracer(h, sc, h->stream2, 0);
   }
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
+  if (h->cfg.vert_advect_uv != 0 || h->cfg.vert_advect_t != 0) { Timed t(h, "vert_advection"); launch_vert_advection_schemes(*h, sc, h->stream); }
   if (h->tracer_on) {
     if (h->g.P > 1) {
       Timed t(h, "tracer_halo"); launch_tracer_pack_halo(*h, sc, h->stream);     // the tracer itself runs once the halo rows are in

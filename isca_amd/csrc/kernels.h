@@ -68,6 +68,8 @@ void launch_spec_update_stage(const isca_dyn &h, int stage, double delta_t, doub
 
 // ---- grid-space kernels
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+// vert_advect_uv / vert_advect_t other than second_centered: the scheme on whole columns, added to the column kernel's tendencies
+void launch_vert_advection_schemes(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 bool virtual_t_on(const isca_dyn &h);
 void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, double *tv, hipStream_t s);
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part = -1);

@@ -804,7 +804,11 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int L = g.L;
   // the list is grouped by total wavenumber (padded), so the 4 wavefronts of a block share one matrix
-  const int4 ent = ((const int4 *)a.active)[blockIdx.x * 4 + wave];      // {n, ml, m, total wavenumber}: one scalar load
+  // workgroups go round-robin over the 8 XCDs: block b of the launch takes list position (b % 8) * (G / 8) + b / 8, so that each XCD works
+  // on a contiguous run of total wavenumbers (G is a multiple of 8: the host pads the list)
+  const int G = gridDim.x, bx = blockIdx.x;
+  const int blk = (G & 7) ? bx : (bx & 7) * (G >> 3) + (bx >> 3);
+  const int4 ent = ((const int4 *)a.active)[blk * 4 + wave];      // {n, ml, m, total wavenumber}: one scalar load
   // the block's wave matrix -> LDS: the first eight values per thread are requested here, in front of the state loads, and stored
   // below (a plain copy loop paid one round trip per 256 values -- seven in front of everything else at L = 40)
   const double *W = a.wave_t + (size_t)ent.w * L * L;    // L*L may be odd: 8-byte copies
@@ -999,7 +1003,9 @@ void launch_spec_update(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   const size_t lds = (size_t)4 * 64 * sizeof(double2) + (size_t)g.L * g.L * sizeof(double);
   SpecUpdateArgs b = a;
   if (!sc.keep_spec_tend) b.dtvor = b.dtdiv = b.dtT = b.dtlp = nullptr;
-  hipLaunchKernelGGL(k_spec_update<0>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, b);
+  // use_implicit = .false. (spectral_dynamics.F90:906): the same kernel without implicit_correction
+  if (h.cfg.use_implicit) hipLaunchKernelGGL(k_spec_update<0>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, b);
+  else hipLaunchKernelGGL(k_spec_update<SU_NO_IMPLICIT>, dim3((unsigned)(h.n_active / 4)), dim3(256), lds, s, g, b);
 }
 // parts of the same kernel on caller data: stage 0 implicit_correction, 1 spectral damping, 2 leapfrog A+B.
 // st[v][t]: v = vors, divs, ts, ln_ps; t = previous, current, future.  dtend: dt_vors, dt_divs, dt_ts, dt_ln_ps.
@@ -1100,6 +1106,7 @@ struct ColumnArgs {
   const double *tv;                        // virtual temperature of the current level (k_column<CH, EXT, true>: use_virtual_temperature)
   const double *pend_c, *pend_p;           // pending fixer scalars of the current / previous level (identity row when nothing is pending)
   int store_wg_full;                       // wg_full (omega; a diagnostic and restart field) is only stored by steps after which the host can look
+  int vadv_skip;                           // bit 0 / 1: the vertical advection of u, v / of T is another scheme's (k_vert_advection_scheme adds it)
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
@@ -1290,9 +1297,11 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
         const double fu1 = (k + 1 < L) ? wg_n * (0.5 * (ukp + uc)) : wg_n * uc;
         const double fv1 = (k + 1 < L) ? wg_n * (0.5 * (vkp + vc)) : wg_n * vc;
         const double ft1 = (k + 1 < L) ? wg_n * (0.5 * (tkp + tc)) : wg_n * tc;
-        dt_u = dt_u + (-(fu1 - fu0 - uc * dw) / dp);
-        dt_v = dt_v + (-(fv1 - fv0 - vc * dw) / dp);
-        dt_t = dt_t + (-(ft1 - ft0 - tc * dw) / dp);
+        if (!(a.vadv_skip & 1)) {
+          dt_u = dt_u + (-(fu1 - fu0 - uc * dw) / dp);
+          dt_v = dt_v + (-(fv1 - fv0 - vc * dw) / dp);
+        }
+        if (!(a.vadv_skip & 2)) dt_t = dt_t + (-(ft1 - ft0 - tc * dw) / dp);
       }
       // ---- horizontal T advection (transforms.F90:828), vorticity/Coriolis terms (:895-896)
       dt_t = dt_t - uc * dxti - vc * dyti;
@@ -1369,7 +1378,8 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.delta_t = sc.delta_t; a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
-  a.wg = h.tracer_on ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.kmask_rd = d.kmask_old; a.psp_copy = d.psp_copy;
+  a.vadv_skip = (h.cfg.vert_advect_uv != 0 ? 1 : 0) | (h.cfg.vert_advect_t != 0 ? 2 : 0);
+  a.wg = (h.tracer_on || a.vadv_skip) ? d.wg : nullptr; a.kmask = h.tracer_on ? d.kmask : nullptr; a.kmask_rd = d.kmask_old; a.psp_copy = d.psp_copy;
   a.water_limit = h.cfg.water_correction_limit;
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
@@ -1389,6 +1399,139 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
   }
 #undef LC
+}
+
+// ---- vert_advection with the schemes the column kernel does not fuse (vert_advection.F90:69-478; spectral_dynamics.F90:877-888):
+// FOURTH_CENTERED (uniform-spacing form, second order next to the top and the ground), FINITE_VOLUME_LINEAR = VAN_LEER_LINEAR (slope_z
+// with limiters, upstream value at the half time step), FINITE_VOLUME_PARABOLIC (compute_weights + slope_z(linear = .false.), Colella &
+// Woodward's monotonicity constraint, the extension for Courant numbers > 1), all in ADVECTIVE_FORM:
+//   rdt = -(flux(k+1) - flux(k) - r (w(k+1) - w(k))) / dz ,  dz = dpk + dbk ps of the CURRENT level (:876), w = the column kernel's wg.
+// One thread per column, the column's values in private arrays: an option path (one more launch, ~4 field passes), not the default.
+constexpr int VADV_MAXL = 64;
+template <int SCHEME>
+__device__ void vadv_column(int L, double dt, const double *w, const double *dz, const double *r, double *rdt) {
+  double flux[VADV_MAXL + 1];
+  flux[0] = w[0] * r[0];
+  flux[L] = w[L] * r[L - 1];
+  if (SCHEME == 1) {                 // FOURTH_CENTERED
+    const double c1 = 7. / 12., c2 = 1. / 12.;
+    for (int k = 2; k <= L - 2; ++k) flux[k] = w[k] * (c1 * (r[k] + r[k - 1]) - c2 * (r[k + 1] + r[k - 2]));
+    flux[1] = w[1] * (0.5 * (r[1] + r[0]));
+    flux[L - 1] = w[L - 1] * (0.5 * (r[L - 1] + r[L - 2]));
+  } else {
+    // slope_z: SCHEME 2 linear = .true., SCHEME 3 linear = .false.; limiters on in both
+    double slp[VADV_MAXL];
+    for (int k = 1; k <= L - 2; ++k) {
+      const double gk = (r[k] - r[k - 1]) / (dz[k] + dz[k - 1]), gk1 = (r[k + 1] - r[k]) / (dz[k + 1] + dz[k]);
+      double s;
+      if (SCHEME == 2) s = (gk1 + gk) * dz[k];
+      else s = (gk1 * (2. * dz[k - 1] + dz[k]) + gk * (2. * dz[k + 1] + dz[k])) * dz[k] / (dz[k - 1] + dz[k] + dz[k + 1]);
+      const double rmin = fmin(fmin(r[k - 1], r[k]), r[k + 1]), rmax = fmax(fmax(r[k - 1], r[k]), r[k + 1]);
+      slp[k] = copysign(1.0, s) * fmin(fmin(fabs(s), 2. * (r[k] - rmin)), 2. * (rmax - r[k]));
+    }
+    slp[0] = 0.0; slp[L - 1] = 0.0;
+    if (SCHEME == 2) {
+      for (int k = 1; k <= L - 1; ++k) {
+        double rst;
+        if (w[k] >= 0.) { const double cn = dt * w[k] / dz[k - 1]; rst = r[k - 1] + 0.5 * slp[k - 1] * (1. - cn); }
+        else { const double cn = -dt * w[k] / dz[k]; rst = r[k] - 0.5 * slp[k] * (1. - cn); }
+        flux[k] = w[k] * rst;
+      }
+    } else {
+      double rl[VADV_MAXL], rr[VADV_MAXL];
+      for (int k = 2; k <= L - 2; ++k) {            // compute_weights (:600-645) on the fly; the interface between layers k-1 and k
+        const double d1 = 1.0 / (dz[k - 1] + dz[k]), d2 = 1.0 / (dz[k - 2] + dz[k - 1] + dz[k] + dz[k + 1]);
+        const double d3 = 1.0 / (2 * dz[k - 1] + dz[k]), d4 = 1.0 / (dz[k - 1] + 2 * dz[k]);
+        const double n3 = dz[k - 2] + dz[k - 1], n4 = dz[k] + dz[k + 1];
+        const double x = n3 * d3 - n4 * d4, y = 2.0 * dz[k - 1] * dz[k];
+        const double z0 = dz[k - 1] * d1, z1 = z0 + x * y * d1 * d2, z2 = dz[k - 1] * n3 * d3 * d2, z3 = dz[k] * n4 * d4 * d2;
+        rl[k] = r[k - 1] + z1 * (r[k] - r[k - 1]) - z2 * slp[k] + z3 * slp[k - 1];
+        rr[k - 1] = rl[k];
+      }
+      rl[1] = r[1] - 0.5 * slp[1]; rr[L - 2] = r[L - 2] + 0.5 * slp[L - 2];
+      rl[0] = r[0] - 0.5 * slp[0]; rr[0] = r[0] + 0.5 * slp[0];
+      rl[L - 1] = r[L - 1] - 0.5 * slp[L - 1]; rr[L - 1] = r[L - 1] + 0.5 * slp[L - 1];
+      for (int k = 0; k < L; ++k) {                  // Colella and Woodward (1984), Equation 1.10
+        if ((rr[k] - r[k]) * (r[k] - rl[k]) <= 0.0) { rl[k] = r[k]; rr[k] = r[k]; }
+        if (k == 0 || k == L - 1) continue;
+        const double rm = rr[k] - rl[k], aa = rm * (r[k] - 0.5 * (rr[k] + rl[k])), bb = rm * rm / 6.;
+        if (aa > bb) rl[k] = 3.0 * r[k] - 2.0 * rr[k];
+        if (aa < -bb) rr[k] = 3.0 * r[k] - 2.0 * rl[k];
+      }
+      const double tt = 2. / 3.;
+      for (int k = 1; k <= L - 1; ++k) {
+        double rst, xx, cn, rsum = 0.;
+        int kk;
+        if (w[k] >= 0.) {
+          cn = dt * w[k] / dz[k - 1]; kk = k - 1;
+          if (cn > 1.) {
+            double dzsum = 0.; const double dtw = dt * w[k];
+            while (dzsum + dz[kk] < dtw) { if (kk == 0) break; dzsum += dz[kk]; rsum += r[kk]; --kk; }
+            xx = (dtw - dzsum) / dz[kk];
+          } else xx = cn;
+          const double rm = rr[kk] - rl[kk];
+          double r6 = 6.0 * (r[kk] - 0.5 * (rr[kk] + rl[kk]));
+          if (kk == 0) r6 = 0.;
+          rst = rr[kk] - 0.5 * xx * (rm - (1.0 - tt * xx) * r6);
+        } else {
+          cn = -dt * w[k] / dz[k]; kk = k;
+          if (cn > 1.) {
+            double dzsum = 0.; const double dtw = -dt * w[k];
+            while (dzsum + dz[kk] < dtw) { if (kk == 0) break; dzsum += dz[kk]; rsum += r[kk]; ++kk; }     // (:414: `if (kk == ks) exit`, as written)
+            xx = (dtw - dzsum) / dz[kk];
+          } else xx = cn;
+          const double rm = rr[kk] - rl[kk];
+          double r6 = 6.0 * (r[kk] - 0.5 * (rr[kk] + rl[kk]));
+          if (kk == L - 1) r6 = 0.;
+          rst = rl[kk] + 0.5 * xx * (rm + (1.0 - tt * xx) * r6);
+        }
+        if (cn > 1.) rst = (xx * rst + rsum) / cn;
+        flux[k] = w[k] * rst;
+      }
+    }
+  }
+  for (int k = 0; k < L; ++k) rdt[k] = -(flux[k + 1] - flux[k] - r[k] * (w[k + 1] - w[k])) / dz[k];
+}
+struct VadvArgs {
+  const double *wg, *ps, *dpk, *dbk, *cosm;
+  const double *f[3];      // u, v, T at the time level the scheme works on
+  double *dt[3];           // dt_u cos^-1, dt_v cos^-1 (the column kernel's scaling: transforms.F90:764-770), dt_T
+  int scheme[3];           // 0: nothing to add (second-centred: done by the column kernel)
+  double delta_t;
+};
+__global__ __launch_bounds__(64) void k_vert_advection_scheme(Geom g, VadvArgs a) {
+  const size_t lev = (size_t)g.Jl * g.I, c2 = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (c2 >= lev) return;
+  const int L = g.L, jl = (int)(c2 / g.I);
+  double w[VADV_MAXL + 1], dz[VADV_MAXL], r[VADV_MAXL], rdt[VADV_MAXL];
+  const double ps = a.ps[c2];
+  for (int k = 0; k <= L; ++k) w[k] = a.wg[c2 + (size_t)k * lev];
+  w[0] = 0.0;                                         // (the column kernel stores the interfaces 1..L; the top one carries no flux)
+  for (int k = 0; k < L; ++k) dz[k] = a.dpk[k] + a.dbk[k] * ps;
+  for (int f = 0; f < 3; ++f) {
+    if (!a.scheme[f]) continue;
+    for (int k = 0; k < L; ++k) r[k] = a.f[f][c2 + (size_t)k * lev];
+    if (a.scheme[f] == 1) vadv_column<1>(L, a.delta_t, w, dz, r, rdt);
+    else if (a.scheme[f] == 2) vadv_column<2>(L, a.delta_t, w, dz, r, rdt);
+    else vadv_column<3>(L, a.delta_t, w, dz, r, rdt);
+    const double sc = (f < 2) ? a.cosm[jl] : 1.0;
+    for (int k = 0; k < L; ++k) { const size_t q = c2 + (size_t)k * lev; a.dt[f][q] = a.dt[f][q] + rdt[k] * sc; }
+  }
+}
+void launch_vert_advection_schemes(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  if (g.L < 4 || g.L > VADV_MAXL) throw std::runtime_error("vert_advect_uv / vert_advect_t other than second_centered need 4..64 levels");
+  VadvArgs a;
+  a.wg = d.wg; a.ps = d.psg[sc.cur]; a.dpk = d.dpk; a.dbk = d.dbk; a.cosm = d.cosm_lat_l; a.delta_t = sc.delta_t;
+  const int suv = h.cfg.vert_advect_uv, st = h.cfg.vert_advect_t;
+  // fourth_centered acts on the current level, the finite-volume schemes on the previous one (spectral_dynamics.F90:878-879, 885-886)
+  const int tuv = (suv == 1) ? sc.cur : sc.prev, tt = (st == 1) ? sc.cur : sc.prev;
+  a.f[0] = d.ug[tuv]; a.f[1] = d.vg[tuv]; a.f[2] = d.tg[tt];
+  a.dt[0] = d.g_dtu; a.dt[1] = d.g_dtv; a.dt[2] = d.g_dtT;
+  a.scheme[0] = a.scheme[1] = suv; a.scheme[2] = st;
+  const size_t lev = (size_t)g.Jl * g.I;
+  hipLaunchKernelGGL(k_vert_advection_scheme, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, g, a);
 }
 
 // standalone hs_forcing on caller fields (for the C-ABI entry point / parity tests)

@@ -83,7 +83,7 @@ struct TraceRec { long long t0, t1, ta, tb; unsigned hw_id, xcc, ml, what; };   
 #endif
 
 struct LegFwdArgs {
-  const double *frag;      // [Ml][KS][2][NTP][64]
+  const double *frag;      // [Ml][KS/2][2][NTP][64][2]: the pieces of k-steps 2q and 2q + 1 side by side (one 16-byte load per lane brings both)
   const double *Fs;        // Fourier rows, spectral-side view
   double *S;               // [Ml][N1][C]
   const int *m_local;
@@ -100,25 +100,33 @@ __device__ __forceinline__ void leg_fwd_item(const Geom &g, const LegFwdArgs &a,
   const bool cok = c < a.C;
   const int cc = cok ? c : 0;
   const int lg = g.log2Jl, Ml = g.Ml, C = a.C, J = g.J;
-  const int ks_stride = 2 * a.NTP * 64, par_stride = a.NTP * 64;
-  const double *fr = a.frag + (size_t)ml * a.KS * ks_stride + t0 * 64 + lane;
+  // Table pieces come as 16-byte loads, two k-steps per request: a vector-memory instruction costs the CU's address unit the same ~16
+  // cycles whether a lane asks for 8 or for 16 bytes (tools/micro/mfma_f64_probe.hip: a table streamed with 8-byte loads arrives at
+  // 32 B/clk/CU, with 16-byte loads at 64), and the pieces are most of this kernel's requests.
+  static_assert(FD % 2 == 0, "ring of k-step pairs");
+  constexpr int FP = FD / 2;
+  const int kp_stride = 2 * a.NTP * 128, par_stride = a.NTP * 128;
+  const double *fr = a.frag + (size_t)ml * (a.KS / 2) * kp_stride + t0 * 128 + 2 * lane;
   const double *Fs = a.Fs;
   double4_t acc[TT][2];
 #pragma unroll
   for (int t = 0; t < TT; ++t) { acc[t][0] = (double4_t){0., 0., 0., 0.}; acc[t][1] = (double4_t){0., 0., 0., 0.}; }
   double2 xs[FD], xn[FD];
-  double af[FD][TT];
-  auto load = [&](int slot, int ks) {                  // table pieces and Fourier rows of k-step ks (slot is a constant after unrolling)
-    const double *p = fr + ks * ks_stride;
+  double2 af[FP][TT];
+  auto load = [&](int ps, int kp) {                    // table pieces and Fourier rows of k-steps 2 kp, 2 kp + 1 (ps is a constant after unrolling)
+    const double *p = fr + kp * kp_stride;
 #pragma unroll
-    for (int t = 0; t < NE; ++t) af[slot][t] = p[t * 64];
+    for (int t = 0; t < NE; ++t) af[ps][t] = *(const double2 *)(p + t * 128);
 #pragma unroll
-    for (int t = 0; t < NO; ++t) af[slot][NE + t] = p[par_stride + t * 64];
-    const int jp = ks * 4 + kq;
-    xs[slot] = *(const double2 *)(Fs + frow32(jp, ml, C, lg, Ml) + cc);
-    xn[slot] = *(const double2 *)(Fs + frow32(J - 1 - jp, ml, C, lg, Ml) + cc);
+    for (int t = 0; t < NO; ++t) af[ps][NE + t] = *(const double2 *)(p + par_stride + t * 128);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int jp = (2 * kp + h) * 4 + kq;
+      xs[2 * ps + h] = *(const double2 *)(Fs + frow32(jp, ml, C, lg, Ml) + cc);
+      xn[2 * ps + h] = *(const double2 *)(Fs + frow32(J - 1 - jp, ml, C, lg, Ml) + cc);
+    }
   };
-  auto block = [&](auto morec, int ks0) {              // FD k-steps; refills each slot with k-step + FD once it has been consumed
+  auto block = [&](auto morec, int ks0) {              // FD k-steps; refills a pair slot with the pair FD k-steps on once both halves are consumed
     constexpr bool MORE = decltype(morec)::value != 0;
 #pragma unroll
     for (int d = 0; d < FD; ++d) {
@@ -126,21 +134,23 @@ __device__ __forceinline__ void leg_fwd_item(const Geom &g, const LegFwdArgs &a,
       const double2 bo = make_double2(xn[d].x - xs[d].x, xn[d].y - xs[d].y);   // x_odd  = F(north) - F(south)   (:312)
 #pragma unroll
       for (int t = 0; t < NE; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[d][t], be.x, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[d][t], be.y, acc[t][1], 0, 0, 0);
+        const double av = (d & 1) ? af[d >> 1][t].y : af[d >> 1][t].x;
+        acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, be.x, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, be.y, acc[t][1], 0, 0, 0);
       }
 #pragma unroll
       for (int t = 0; t < NO; ++t) {
-        acc[NE + t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[d][NE + t], bo.x, acc[NE + t][0], 0, 0, 0);
-        acc[NE + t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[d][NE + t], bo.y, acc[NE + t][1], 0, 0, 0);
+        const double av = (d & 1) ? af[d >> 1][NE + t].y : af[d >> 1][NE + t].x;
+        acc[NE + t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bo.x, acc[NE + t][0], 0, 0, 0);
+        acc[NE + t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bo.y, acc[NE + t][1], 0, 0, 0);
       }
-      if (MORE) load(d, ks0 + d + FD);
+      if (MORE && (d & 1)) load(d >> 1, (ks0 + FD) / 2 + (d >> 1));
       __builtin_amdgcn_sched_barrier(0);               // keep the k-steps apart: a hoisted fold would wait for the whole ring
     }
   };
   const int KS = a.KS;                                 // a multiple of FD
 #pragma unroll
-  for (int d = 0; d < FD; ++d) load(d, d);
+  for (int ps = 0; ps < FP; ++ps) load(ps, ps);
   for (int ks0 = 0; ks0 < KS - FD; ks0 += FD) {
     block(IC<1>(), ks0);
 #ifdef LEG_TRACE
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256, WPS) void k_leg_fwd(Geom g, LegFwdArgs a TRACE
 // in the loop.   kinds: 0 copy | 1 u cos from (div; vor) | 2 v cos from (vor; div) | 3 d/dx cos | 4 d/dy cos
 // ---------------------------------------------------------------------------------------------------------------------
 struct LegInvArgs {
-  const double *frag;      // [Ml][2][NKS][JT][64]
+  const double *frag;      // [Ml][2][NKS/2][JT][64][2]: the pieces of k-steps 2q and 2q + 1 side by side (16-byte loads, see leg_fwd_item)
   const double *S;         // staged spectral rows [Ml][N1][C] (not FUSED)
   double *Fs;
   const int *m_local;
@@ -219,8 +229,10 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
   const int NGR = (nks0 + NW - 1) / NW;
   const bool dup = wave * JTG >= a.JT;                // more wavefronts than tiles (small grids): repeat the last tiles, store nothing
   const int jt0 = dup ? a.JT - JTG : wave * JTG;
-  const int ks_stride = a.JT * 64, par_stride = a.NKS * a.JT * 64;
-  const double *fr = a.frag + (size_t)ml * 2 * par_stride + jt0 * 64 + lane;
+  constexpr bool PAIR = NW % 2 == 0;                  // table pieces as 16-byte loads of two k-steps (one wavefront per block: 8-byte loads)
+  constexpr int NA = PAIR ? NW / 2 : NW;
+  const int kp_stride = a.JT * 128, par_stride = (a.NKS / 2) * a.JT * 128;
+  const double *fr = a.frag + (size_t)ml * 2 * par_stride + jt0 * 128 + 2 * lane;
   const double2 *pc = nullptr, *pn = nullptr;       // centre array, neighbour array at (ml, n = 0, level)
   int stride = 0;                                   // double2 per n
   const double4_t *pcoef = nullptr;
@@ -252,7 +264,7 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int jt = 0; jt < JTG; ++jt) { acc[p][jt][0] = (double4_t){0., 0., 0., 0.}; acc[p][jt][1] = (double4_t){0., 0., 0., 0.}; }
-  double af[NW][2][JTG];
+  double2 af[NA][2][JTG];                              // PAIR: .x / .y = the piece of the even / odd k-step; else .x only
   double2 zc[2], zn[4];
   double4_t cf[2];
   int gks = 0;                                         // k-step whose rows are in zc / zn / cf
@@ -292,27 +304,40 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
       Bbuf[((buf * NW + wave) * 2 + p) * 64 + lane] = v;
     }
   };
-  auto afload = [&](int q, int ks) {
-    const double *p = fr + min(ks, a.NKS - 1) * ks_stride;
+  auto afload = [&](int q, int ks) {                   // PAIR: slot q holds k-steps 2 ks', 2 ks' + 1 with ks' = ks (a pair index)
+    if constexpr (PAIR) {
+      const double *p = fr + min(ks, a.NKS / 2 - 1) * kp_stride;
 #pragma unroll
-    for (int jt = 0; jt < JTG; ++jt) { af[q][0][jt] = p[jt * 64]; af[q][1][jt] = p[par_stride + jt * 64]; }
+      for (int jt = 0; jt < JTG; ++jt) { af[q][0][jt] = *(const double2 *)(p + jt * 128); af[q][1][jt] = *(const double2 *)(p + par_stride + jt * 128); }
+    } else {
+      const int kc = min(ks, a.NKS - 1);
+      const double *p = fr + (kc >> 1) * kp_stride + (kc & 1);
+#pragma unroll
+      for (int jt = 0; jt < JTG; ++jt) { af[q][0][jt].x = p[jt * 128]; af[q][1][jt].x = p[par_stride + jt * 128]; }
+    }
   };
   double2 bq[2][2];                                    // rows of the current and the next k-step, read from LDS one k-step ahead
   auto bread = [&](int q, int buf) {
     bq[q & 1][0] = Bbuf[((buf * NW + q) * 2 + 0) * 64 + lane];
     bq[q & 1][1] = Bbuf[((buf * NW + q) * 2 + 1) * 64 + lane];
   };
+  auto piece = [&](int q, int par, int jt) -> double {
+    if constexpr (PAIR) return (q & 1) ? af[q >> 1][par][jt].y : af[q >> 1][par][jt].x;
+    else return af[q][par][jt].x;
+  };
   auto mfmas = [&](int q) {
     const double2 b0 = bq[q & 1][0], b1 = bq[q & 1][1];
 #pragma unroll
     for (int jt = 0; jt < JTG; ++jt) {
-      acc[0][jt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q][0][jt], b0.x, acc[0][jt][0], 0, 0, 0);
-      acc[0][jt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q][0][jt], b0.y, acc[0][jt][1], 0, 0, 0);
+      const double av = piece(q, 0, jt);
+      acc[0][jt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0.x, acc[0][jt][0], 0, 0, 0);
+      acc[0][jt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0.y, acc[0][jt][1], 0, 0, 0);
     }
 #pragma unroll
     for (int jt = 0; jt < JTG; ++jt) {
-      acc[1][jt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q][1][jt], b1.x, acc[1][jt][0], 0, 0, 0);
-      acc[1][jt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q][1][jt], b1.y, acc[1][jt][1], 0, 0, 0);
+      const double av = piece(q, 1, jt);
+      acc[1][jt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1.x, acc[1][jt][0], 0, 0, 0);
+      acc[1][jt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1.y, acc[1][jt][1], 0, 0, 0);
     }
   };
   // ---- prologue: rows of group 0 into LDS, requests for group 1, table pieces of group 0.  Requests retire in order, so the
@@ -320,7 +345,7 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
   // exactly the pieces needed, with everything requested later still in flight.
   gload(wave);
 #pragma unroll
-  for (int q = 0; q < NW; ++q) afload(q, q);
+  for (int q = 0; q < NA; ++q) afload(q, q);
   __builtin_amdgcn_sched_barrier(0);
   gstore(0);
   gload(NW + wave);
@@ -334,7 +359,8 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
     for (int q = 0; q < NW; ++q) {
       if (q + 1 < NW) bread(q + 1, buf);
       mfmas(q);
-      afload(q, (G + 1) * NW + q);
+      if constexpr (PAIR) { if (q & 1) afload(q >> 1, ((G + 1) * NW + q) >> 1); }      // both halves of the pair consumed: the pair one group on
+      else afload(q, (G + 1) * NW + q);
       __builtin_amdgcn_sched_barrier(0);
     }
     gstore(1 - buf);                                   // rows of group G + 1 (requested one group ago)
@@ -488,14 +514,14 @@ void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<
         for (int t = 0; t < NTP; ++t)
           for (int l = 0; l < 64; ++l) {
             const int n = 2 * (16 * t + (l & 15)) + par, jp = 4 * ks + (l >> 4);
-            fwd[((((size_t)ml * KS + ks) * 2 + par) * NTP + t) * 64 + l] = P(n, jp) * T.wts_hem[jp];
+            fwd[(((((size_t)ml * (KS / 2) + (ks >> 1)) * 2 + par) * NTP + t) * 64 + l) * 2 + (ks & 1)] = P(n, jp) * T.wts_hem[jp];
           }
     for (int par = 0; par < 2; ++par)
       for (int ks = 0; ks < NKS; ++ks)
         for (int jt = 0; jt < JT; ++jt)
           for (int l = 0; l < 64; ++l) {
             const int n = 2 * (4 * ks + (l >> 4)) + par, jp = 16 * jt + (l & 15);
-            inv[((((size_t)ml * 2 + par) * NKS + ks) * JT + jt) * 64 + l] = P(n, jp);
+            inv[(((((size_t)ml * 2 + par) * (NKS / 2) + (ks >> 1)) * JT + jt) * 64 + l) * 2 + (ks & 1)] = P(n, jp);
           }
     const int nlim = N1 - m;                          // the fused synthesis is the step's: triangular bounds
     for (int n = 0; n < nlim; ++n) {

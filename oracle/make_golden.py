@@ -549,6 +549,21 @@ def main():
         "run_T21L8_topography": lambda: golden_run(
             "T21", 8, 36, (1, 36), extra_groups=GAUSSIAN_TOPOG_GROUPS,
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|36)$", k) is not None),
+        # vert_advect_uv / vert_advect_t other than second_centered (spectral_dynamics.F90:280-301, 877-888; vert_advection.F90:173-438):
+        # fourth-centred for both; van Leer for the winds with the piecewise-parabolic scheme for temperature (both on the previous level)
+        "run_T21L8_vadv_fourth": lambda: golden_run(
+            "T21", 8, 36, (1, 2, 36), extra="vert_advect_uv = 'fourth_centered', vert_advect_t = 'fourth_centered'",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
+        "run_T21L8_vadv_finite_volume": lambda: golden_run(
+            "T21", 8, 36, (1, 2, 36), extra="vert_advect_uv = 'van_leer_linear', vert_advect_t = 'finite_volume_parabolic'",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
+        "run_T21L8_vadv_ppm_uv": lambda: golden_run(
+            "T21", 8, 36, (36,), extra="vert_advect_uv = 'finite_volume_parabolic', vert_advect_t = 'van_leer_linear'",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
+        # use_implicit = .false. (spectral_dynamics.F90:906): explicit leapfrog of the gravity waves, dt_atmos = 300 s
+        "run_T21L8_explicit": lambda: golden_run(
+            "T21", 8, 48, (1, 2, 48), dt=300, extra="use_implicit = .false.",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|48)$", k) is not None),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

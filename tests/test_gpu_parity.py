@@ -132,6 +132,43 @@ def test_golden_T85L40_benchmark_config(golden_dir):
     dc.close()
 
 
+def test_developed_state_steps_vs_reference(golden_dir):
+    """A DEVELOPED state of configs[1] (T42L25 Held-Suarez, day 60 of the reference run: baroclinic eddies at finite amplitude) handed over as
+    a restart would be -- both time levels of the spectral and grid state, the dynamics' Robert-filtered tracer level and atmosphere_mod's
+    copy (spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375; dumped by oracle/ref_harness.F90 `dump_full_at`) -- then 1 and 10 more
+    steps against the reference's own: the van Leer kernel's Courant shift and polar rows, the sponge, the fixers and the lazy corrections
+    see weather, not the state at rest of the cold-start fixtures.  SURVEY 8d: one step 1e-11, ten steps 1e-10."""
+    g = np.load(os.path.join(golden_dir, "developed_T42L25.npz"))
+    umax, vmax = g["developed_maxu_maxv_Tmin_Tmax"][:2]
+    assert umax > 30.0 and vmax > 10.0, (umax, vmax)               # the fixture IS a developed flow
+    dc = make("T42", 25); dc.cold_start()
+    dc.set_time_pointers(0, 1, int(g["meta_step0"]))
+    for tl, tag in ((0, "prev"), (1, "cur")):                       # time_level 0 = previous, 1 = current
+        for nm in ("vors", "divs", "ts"):
+            dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
+        dc.set("ln_ps", g[f"rs_lnps_{tag}"], tl)
+        for nm in ("ug", "vg", "tg", "psg"):
+            dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
+    dc.set("tr", g["rs_tr1_prev_filt"], 0); dc.set("tr_atm", g["rs_tr1_prev_atm"], 0)
+    dc.set("tr", g["rs_tr1_cur"], 1); dc.set("tr_atm", g["rs_tr1_cur"], 1)
+    dc.set("wg_full", g["rs_wg_full"])
+    dc.refresh_derived()
+    done = 0
+    for n, tol in ((1, 1e-11), (10, 1e-10)):
+        dc.step(n - done); done = n
+        err = {}
+        for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1")):
+            ref = g[f"after{n}_{gk}_s222"]
+            err[k] = float(np.abs(dc.get(k)[::2, ::2, ::2] - ref).max() / np.abs(ref).max())
+            lo, hi = g[f"after{n}_{gk}_minmax"]
+            a = dc.get(k)
+            assert abs(a.min() - lo) <= tol * max(abs(lo), abs(hi)) and abs(a.max() - hi) <= tol * max(abs(lo), abs(hi)), (n, k)
+        err["psg"] = rel(dc.get("psg"), g[f"after{n}_psg"])
+        print("developed T42L25 state +", n, "steps vs the reference:", err)
+        assert max(err.values()) < tol, (n, err)
+    dc.close()
+
+
 def test_external_physics_seam(golden_dir):
     """physics = 2 (the spectral_dynamics seam of atmosphere.F90:300-329): the host evaluates hs_forcing on the fields the library hands
     out and gives the tendencies to isca_dyn_dynamics.  One day at T21L25: against the reference run (1e-9) and against the library's own
@@ -177,6 +214,42 @@ def test_golden_damping_options(golden_dir, case, opts):
         atm.config_from_namelist({"spectral_dynamics_nml": {"damping_option": "spectral_viscosity"}})
     c = atm.config_from_namelist({"spectral_dynamics_nml": {"damping_option": "exponential_cutoff", "cutoff_wn": 12}})
     assert (c.damping_option, c.cutoff_wn) == (1, 12)
+
+
+@pytest.mark.parametrize("case,opts,steps,dt", [
+    ("vadv_fourth", dict(vert_advect_uv=1, vert_advect_t=1), (1, 2, 36), 600.0),
+    ("vadv_finite_volume", dict(vert_advect_uv=2, vert_advect_t=3), (1, 2, 36), 600.0),
+    ("vadv_ppm_uv", dict(vert_advect_uv=3, vert_advect_t=2), (36,), 600.0),
+    ("explicit", dict(use_implicit=0), (1, 2, 48), 300.0)])
+def test_golden_dynamics_options(golden_dir, case, opts, steps, dt):
+    """Options of spectral_dynamics_nml the namelist offers beside the test cases' values, each against a reference run at T21L8:
+    vert_advect_uv / vert_advect_t = 'fourth_centered' | 'van_leer_linear' | 'finite_volume_parabolic' (spectral_dynamics.F90:280-301,
+    877-888; vert_advection.F90:173-438: the finite-volume schemes advect the PREVIOUS level) and use_implicit = .false. (:906: explicit
+    gravity waves, dt_atmos = 300 s).  Restart in the middle of such a run continues bit for bit."""
+    g = np.load(os.path.join(golden_dir, f"run_T21L8_{case}.npz"))
+    dc = make("T21", 8, dt_atmos=dt, **opts); dc.cold_start()
+    done = 0
+    for n in steps:
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print(case, "step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    dc.close()
+    # the option is not a no-op: the default scheme lands somewhere else
+    ref = make("T21", 8, dt_atmos=dt); ref.cold_start(); ref.step(steps[-1])
+    assert rel(ref.get("tg"), g[f"st_tg_{steps[-1]:06d}"]) > 1e-8
+    ref.close()
+    from isca_amd import atmosphere as atm
+    c = atm.config_from_namelist({"spectral_dynamics_nml": {"vert_advect_uv": "van_leer_linear", "vert_advect_t": "FINITE_VOLUME_PARABOLIC",
+                                                            "use_implicit": False}, "main_nml": {"dt_atmos": 300}})
+    assert (c.vert_advect_uv, c.vert_advect_t, c.use_implicit) == (2, 3, 0)
+    with pytest.raises(dyncore.IscaError, match="is not a valid value for vert_advect_t"):
+        atm.config_from_namelist({"spectral_dynamics_nml": {"vert_advect_t": "upstream"}})
 
 
 def test_golden_three_tracers(golden_dir):
