@@ -6,9 +6,10 @@
 ! With isca_dropin_mod%dropin_physics = 1 (atmosphere_mod, atmosphere_nml: idealized_moist_model) the core is created with the Frierson
 ! column chain and the namelist values idealized_moist_phys_init collected.  vert_coord_option: 'even_sigma', 'uneven_sigma' and 'input'
 ! (vert_coordinate_nml's pk, bk).
-! Not here: restart files (fms_io / netCDF; the Python host mirror isca_amd/restart.py writes and reads them), topography options
-! other than 'flat' and 'gaussian', vert_coord_option 'hybrid' / 'mcm' / 'v197' (isca_amd.atmosphere.named_vert_coord), initial_state_option
-! other than 'quiescent'.  Each is refused with error_mesg(..., FATAL) naming the option.
+! vert_coord_option 'hybrid' / 'mcm' / 'v197' are formed here (named_vert_coord); topography_option 'gaussian' through the reference's own
+! gaussian_topog_mod.  Not here: restart files (fms_io / netCDF; the Python host mirror isca_amd/restart.py writes and reads them),
+! topography_option = 'input' (a netCDF height field), initial_state_option other than 'quiescent'.  Each is refused with
+! error_mesg(..., FATAL) naming the option.
 module spectral_dynamics_mod
 
 #ifdef INTERNAL_FILE_NML
@@ -18,7 +19,8 @@ use fms_mod, only: open_namelist_file
 #endif
 use iso_c_binding
 use fms_mod,            only: error_mesg, FATAL, NOTE, check_nml_error, mpp_pe, mpp_root_pe, stdlog, lowercase, uppercase, close_file
-use constants_mod,      only: radius, omega
+use constants_mod,      only: radius, omega, grav, pi
+use gaussian_topog_mod, only: gaussian_topog_init
 use time_manager_mod,   only: time_type, get_time
 use field_manager_mod,  only: MODEL_ATMOS, parse
 use tracer_manager_mod, only: get_number_tracers, get_tracer_names, query_method, get_tracer_index, NO_TRACER
@@ -149,11 +151,10 @@ if(trim(vert_difference_option) /= 'simmons_and_burridge') &
   call error_mesg('spectral_dynamics_init','"'//trim(vert_difference_option)//'" is not a supported value for vert_difference_option.', FATAL)
 if(trim(initial_state_option) /= 'quiescent') &
   call error_mesg('spectral_dynamics_init','"'//trim(initial_state_option)//'" is not a supported value for initial_state_option.', FATAL)
-if(trim(topography_option) /= 'flat') &
-  call error_mesg('spectral_dynamics_init','"'//trim(topography_option)//'" is not a supported value for topography_option here: hand the '// &
-                  'surface geopotential to the library (isca_dyn_set_surf_geopotential).', FATAL)
+if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian') &
+  call error_mesg('spectral_dynamics_init','"'//trim(topography_option)//'" is not a supported value for topography_option here (flat, '// &
+                  'gaussian; a height field read from a file: hand the surface geopotential to the library, isca_dyn_set_surf_geopotential).', FATAL)
 if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
-if(make_symmetric) call error_mesg('spectral_dynamics_init','make_symmetric = .true. is not a supported value.', FATAL)
 if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
 if(dropin_physics /= 1 .and. (no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
   call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing is carried by the device core.', FATAL)
@@ -186,7 +187,7 @@ cfg%t_zero = t_zero; cfg%t_strat = t_strat; cfg%delh = delh; cfg%delv = delv; cf
 cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_conserve_energy)
 cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
 cfg%vert_advect_uv = advect_scheme(vert_advect_uv, 'vert_advect_uv'); cfg%vert_advect_t = advect_scheme(vert_advect_t, 'vert_advect_t')
-cfg%use_implicit = merge(1, 0, use_implicit)
+cfg%use_implicit = merge(1, 0, use_implicit); cfg%make_symmetric = merge(1, 0, make_symmetric)
 cfg%physics = dropin_physics                ! 2: the caller keeps its physics package and spectral_dynamics receives its tendencies
 select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coordinate.F90:124-152)
   case('uneven_sigma')
@@ -203,9 +204,10 @@ select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coor
       'No levels specified in namelist vert_coordinate_nml or namelist is missing ', FATAL)
     cfg%vert_coord_input = 1
     cfg%pk_input(1:num_levels+1) = pk(1:num_levels+1); cfg%bk_input(1:num_levels+1) = bk(1:num_levels+1)
+  case('hybrid', 'mcm', 'v197')             ! compute_vert_coord's other options (init/vert_coordinate.F90:124-152), formed here
+    call named_vert_coord(cfg)
   case default
-    call error_mesg('spectral_dynamics_init','"'//trim(vert_coord_option)//'" is not a supported value for vert_coord_option here '// &
-                    '(even_sigma, uneven_sigma, input; hybrid / mcm / v197 through pk_input / bk_input of the library).', FATAL)
+    call error_mesg('compute_vert_coord','"'//trim(vert_coord_option)//'" is not a valid value for vert_coord_option.', FATAL)
 end select
 if(dropin_physics == 1) then                ! the Frierson chain inside the device step: idealized_moist_phys_init's namelist values
   if(.not. dropin_moist_set) call error_mesg('spectral_dynamics_init','physics = 1 without idealized_moist_phys_init', FATAL)
@@ -267,14 +269,73 @@ nhum_out = nhum
 
 ! ---- the device core, cold-started (restart files: not from Fortran, see the header)
 call chk(isca_dyn_create(cfg, core), 'spectral_dynamics_init')
-call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
 core_ready = .true.
+if(trim(topography_option) == 'gaussian') call gaussian_topography      ! get_topography (init/spectral_init_cond.F90:299-303)
+call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
 nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
 virtual_t = use_virtual_temperature; ref_sea_level_press = reference_sea_level_press
 triang = triang_trunc; finc = fourier_inc
 module_is_initialized = .true.
 
 end subroutine spectral_dynamics_init
+
+!===============================================================================================
+! get_topography, topography_option = 'gaussian': gaussian_topog_nml's mountains (shared/topography/gaussian_topog.F90, the reference's
+! own module) on the core's grid, handed to the library as the surface geopotential before the cold start
+subroutine gaussian_topography
+real, allocatable :: dlon(:), dlat(:), zs(:,:)
+real(c_double), allocatable :: buf(:)
+allocate(dlon(lon_max), dlat(lat_max), zs(lon_max, lat_max), buf(lon_max*lat_max))
+call get_table1('deg_lon', dlon); call get_table1('deg_lat', dlat)
+call gaussian_topog_init(dlon*pi/180, dlat*pi/180, zs)
+buf = reshape(grav*zs, (/lon_max*lat_max/))
+call chk(isca_dyn_set_surf_geopotential(core, buf, size(buf, kind=c_size_t)), 'get_topography')
+end subroutine gaussian_topography
+
+!===============================================================================================
+! compute_vert_coord (init/vert_coordinate.F90:89-157) for 'hybrid' (an uneven-sigma profile, compute_uneven_sigma with zero_top = .false.
+! :248-273, used as sigma below p_sigma and as pressure above p_press, blended by transition() :161-183), 'mcm' (compute_old_model_sigma
+! :296-310) and 'v197' (compute_v197_sigma :276-294): the half levels go to the library like vert_coordinate_nml's
+subroutine named_vert_coord(cfg)
+type(isca_dyn_config), intent(inout) :: cfg
+real, parameter :: v197(19) = (/ 0.0, .0089163, .0342936, .0740741, .1262002, .1886145, .2592592, .3360768, .4170096, .5000000, .5829904, &
+                                 .6639231, .7407407, .8113854, .8737997, .9259259, .9657064, .9910837, 1.0 /)
+real, parameter :: mcm(15) = (/ 0.0, .03, .0707, .1311, .2102, .3036, .4062, .5138, .6226, .7284, .8255, .9066, .9640, .9933, 1.0 /)
+real :: zeta, z, p, f
+integer :: k
+cfg%vert_coord_input = 1
+cfg%pk_input = 0.; cfg%bk_input = 0.
+select case(trim(vert_coord_option))
+  case('v197')
+    if(num_levels /= 18) call error_mesg('compute_v197_sigma','num_levels must be 18', FATAL)
+    cfg%bk_input(1:19) = v197
+  case('mcm')
+    if(num_levels /= 14) call error_mesg('compute_old_model_sigma','num_levels must be 14', FATAL)
+    cfg%bk_input(1:15) = mcm
+  case('hybrid')
+    if(scale_heights == 0. .or. exponent == 0.) call error_mesg('compute_vert_coord','zero is an invalid value for scale_heights / exponent.', FATAL)
+    if(surf_res <= 0. .or. surf_res > 1.0) call error_mesg('compute_vert_coord','the namelist parameter surf_res must be < 1.0', FATAL)
+    if(p_sigma < p_press) call error_mesg('compute_vert_coord','p_sigma must be greater than p_press', FATAL)
+    do k = 1, num_levels + 1
+      if(k <= num_levels) then
+        zeta = 1. - (real(k-1)/real(num_levels))
+        z = surf_res*zeta + (1.0 - surf_res)*(zeta**exponent)
+        p = exp(-z*scale_heights)
+      else
+        p = 1.0
+      endif
+      if(p <= p_press) then
+        f = 0.0
+      else if(p >= p_sigma) then
+        f = 1.0
+      else
+        f = (sin(0.5*pi*(p - p_press)/(p_sigma - p_press)))**2
+      endif
+      cfg%pk_input(k) = reference_sea_level_press*(0.0*f + p*(1.0 - f))
+      cfg%bk_input(k) = p*f + 0.0*(1.0 - f)
+    enddo
+end select
+end subroutine named_vert_coord
 
 !===============================================================================================
 ! spectral_dynamics.F90:280-301

@@ -62,6 +62,7 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: use_virtual_temperature
   integer(c_int) :: vert_advect_uv, vert_advect_t      ! 0 second_centered, 1 fourth_centered, 2 van_leer_linear, 3 finite_volume_parabolic
   integer(c_int) :: use_implicit
+  integer(c_int) :: make_symmetric
 end type
 
 interface

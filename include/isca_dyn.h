@@ -121,6 +121,9 @@ typedef struct isca_dyn_config {
   /* use_implicit (spectral_dynamics_nml, default .true. = 1; spectral_dynamics.F90:469-481, 906): 0 = no implicit_correction of the
    * divergence / temperature / surface-pressure tendencies: explicit leapfrog of the gravity waves (needs a short dt_atmos). */
   int use_implicit;
+  /* make_symmetric (spectral_dynamics_nml, default .false.; spherical.F90:185): the truncation mask also drops every zonal wavenumber
+   * m > 0 -- a zonally symmetric model (exp/test_cases/axisymmetric). */
+  int make_symmetric;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

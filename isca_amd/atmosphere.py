@@ -66,7 +66,7 @@ _REF_DEFAULTS = dict(
     eddy_sponge_coeff=0., zmu_sponge_coeff=0., zmv_sponge_coeff=0., robert_coeff=.04, alpha_implicit=.5, scale_heights=4., surf_res=.1,
     exponent=2.5, initial_sphum=0.0, reference_sea_level_press=101325., water_correction_limit=0.0, raw_filter_coeff=1.0,
     valid_range_t=(100., 500.), dt_atmos=0.0, cutoff_wn=15, damping_coeff_vor=-1., damping_coeff_div=-1., damping_order_vor=-1,
-    damping_order_div=-1, vert_advect_uv=0, vert_advect_t=0, use_implicit=1,
+    damping_order_div=-1, vert_advect_uv=0, vert_advect_t=0, use_implicit=1, make_symmetric=0,
     t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=1, trflux=1.e-5,
     trsink=-4., P00=1.e5)
 _REF_VERT_COORD_OPTION = "even_sigma"            # spectral_dynamics.F90:175
@@ -265,17 +265,13 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 if str(v).lower() != unsupported[k].lower():
                     raise IscaError(f'"{v}" is not a supported value for {k} (only "{unsupported[k]}")')
                 continue
-            if k in ("use_virtual_temperature", "use_implicit"):
+            if k in ("use_virtual_temperature", "use_implicit", "make_symmetric"):
                 kw[k] = int(bool(v))
                 continue
             if k in ("vert_advect_uv", "vert_advect_t"):     # spectral_dynamics.F90:280-301
                 if str(v).upper() not in _VERT_ADVECT_SCHEMES:
                     raise IscaError(f'"{v}" is not a valid value for {k}.')
                 kw[k] = _VERT_ADVECT_SCHEMES[str(v).upper()]
-                continue
-            if k == "make_symmetric":                        # one value implemented
-                if bool(v):
-                    raise IscaError(f'"{v}" is not a supported value for {k} (only "False")')
                 continue
             if k in ("p_press", "p_sigma"):           # vert_coord_option = 'hybrid' (used above)
                 continue

@@ -107,7 +107,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->physics = 0; c->vert_coord_input = 0;
   for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
   c->use_virtual_temperature = 0;
-  c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1;
+  c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1; c->make_symmetric = 0;
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;

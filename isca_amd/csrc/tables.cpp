@@ -160,6 +160,7 @@ void Tables::build(const isca_dyn_config &c) {
       // the model's truncation: triangle_mask (spherical.F90:190-195), or -- triang_trunc = .false. -- rhomboidal_truncation's
       // `spherical(:,num_spherical,:) = 0` (spherical.F90:622): only the extra row goes
       if (c.triang_trunc ? (sw > c.num_spherical - 1) : (n == c.num_spherical)) tri_mask[q] = 0.0;
+      if (c.make_symmetric && m > 0) tri_mask[q] = 0.0;     // make_symmetric (spherical.F90:185): a zonally symmetric model
       eps[q] = std::sqrt((sw * sw - fw * fw) / (4.0 * sw * sw - 1.0));
       eigen[q] = sw * (sw + 1.0) / (radius * radius);
       if (sw > 0) {

@@ -64,7 +64,7 @@ class _CConfig(C.Structure):
         ("damping_order_vor", C.c_int), ("damping_order_div", C.c_int),
         ("tracer_spectral", C.c_int * MAX_TRACERS), ("tracer_robert_coeff", C.c_double * MAX_TRACERS),
         ("use_virtual_temperature", C.c_int),
-        ("vert_advect_uv", C.c_int), ("vert_advect_t", C.c_int), ("use_implicit", C.c_int),
+        ("vert_advect_uv", C.c_int), ("vert_advect_t", C.c_int), ("use_implicit", C.c_int), ("make_symmetric", C.c_int),
     ]
 
 

@@ -564,6 +564,10 @@ def main():
         "run_T21L8_explicit": lambda: golden_run(
             "T21", 8, 48, (1, 2, 48), dt=300, extra="use_implicit = .false.",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|48)$", k) is not None),
+        # make_symmetric = .true. (spherical.F90:185; exp/test_cases/axisymmetric): every zonal wavenumber m > 0 is truncated away
+        "run_T21L8_symmetric": lambda: golden_run(
+            "T21", 8, 48, (1, 48), extra="make_symmetric = .true.",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|48)$", k) is not None),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -147,3 +147,28 @@ def test_atmosphere_mod_queues_steps(tmp_path):
     dc.close()
     print("T42L25: atmosphere(Time) %.4f ms per step, DynCore.step(n) %.4f ms per step" % (ms_dropin, ms_lib))
     assert ms_dropin < 1.25 * ms_lib + 0.01, (ms_dropin, ms_lib)
+
+
+@pytest.mark.parametrize("fixture,levels,nsteps,extra,groups", [
+    ("run_T21L8_topography", 8, 36, "", "topo"),
+    ("run_T21L12_hybrid_option", 12, 24,
+     "vert_coord_option = 'hybrid', p_press = 0.15, p_sigma = 0.45, scale_heights = 5.0, exponent = 3.0, surf_res = 0.3", ""),
+    ("run_T21L8_vadv_finite_volume", 8, 36, "vert_advect_uv = 'van_leer_linear', vert_advect_t = 'finite_volume_parabolic'", ""),
+    ("run_T21L8_symmetric", 8, 48, "make_symmetric = .true.", ""),
+])
+def test_atmosphere_mod_options_from_fortran(tmp_path, golden_dir, fixture, levels, nsteps, extra, groups):
+    """Options the drop-in front end forwards instead of refusing, each from the reference's own input.nml through atmos_model's loop on
+    this repository's atmosphere_mod, against the reference run's final extremes: topography_option = 'gaussian' (gaussian_topog_nml through
+    the reference's gaussian_topog_mod, spectral_init_cond.F90:299-303), vert_coord_option = 'hybrid' (compute_vert_coord,
+    vert_coordinate.F90:124-152, formed in Fortran), vert_advect_uv / vert_advect_t, make_symmetric."""
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    d = str(tmp_path / "run")
+    mg.prepare_rundir(d, "T21", levels, "run", nsteps=nsteps, dt=600, extra=extra, extra_groups=mg.GAUSSIAN_TOPOG_GROUPS if groups == "topo" else "")
+    open(os.path.join(d, "drive.nml"), "w").write(f" &drive_nml\n   nsteps = {nsteps}, dt_atmos = 600\n /\n")
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    vals = [float(x) for x in re.search(r"DRIVE_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout).groups()]
+    assert np.max(np.abs(np.array(vals) - g["final_Tmin_Tmax_maxabsU"])) < 1e-9, (vals, g["final_Tmin_Tmax_maxabsU"])

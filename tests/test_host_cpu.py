@@ -117,8 +117,7 @@ def test_namelist_to_config(lib):
     assert [m.bk_input[k] for k in (0, 5, 10)] == [0.0, 0.5, 1.0]                        # vert_coord_option defaults to 'even_sigma'
     assert atm.config_from_namelist(None, "T21").scale_heights == 6.0                    # no namelist: the Held-Suarez test case
     assert atm.config_from_namelist({"spectral_dynamics_nml": {"use_implicit": False}}).use_implicit == 0 and m.use_implicit == 1
-    with pytest.raises(dyncore.IscaError, match="make_symmetric"):
-        atm.config_from_namelist({"spectral_dynamics_nml": {"make_symmetric": True}})
+    assert atm.config_from_namelist({"spectral_dynamics_nml": {"make_symmetric": True}}).make_symmetric == 1 and m.make_symmetric == 0
     assert atm.config_from_namelist({"spectral_dynamics_nml": {"use_virtual_temperature": True}}).use_virtual_temperature == 1
     with pytest.raises(dyncore.IscaError, match="convection_scheme is not set"):          # moist options whose reference default is not implemented
         atm.config_from_namelist({"atmosphere_nml": {"idealized_moist_model": True}})
