@@ -368,6 +368,12 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         build_legendre_fragments(g, T, h->h_m_local, ff, fi, sc);
         d.leg_fwd_frag = dupload(h, ff); d.leg_inv_frag = dupload(h, fi); d.leg_scoef = dupload(h, sc);
       }
+      // fused FFT + Legendre analysis of the step (one rank, lon_max = 256, triangular truncation): ISCA_FUSE_FFT_LEG=1
+      if (getenv("ISCA_FUSE_FFT_LEG") && atoi(getenv("ISCA_FUSE_FFT_LEG")) != 0 && fused_forward_ok(g) && cfg->triang_trunc && cfg->fourier_inc == 1) {
+        std::vector<double> fz; std::vector<int> dz;
+        const int nt = build_fused_fwd_tables(g, T, h->h_m_local, fz, dz);
+        if (nt) { d.fz_frag = dupload(h, fz); d.fz_desc = dupload(h, dz); d.fz_NT = nt; h->fuse_fwd = true; }
+      }
     }
     {  // coefficient tables per local m
       const std::vector<double> *src[13] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
@@ -558,7 +564,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     const bool vadv_ext = cfg->vert_advect_uv != 0 || cfg->vert_advect_t != 0;
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -942,7 +948,8 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
       HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
     }
   }
-  { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
+  if (h->fuse_fwd) { Timed t(h, "fft_leg_fwd"); launch_fft_legendre_forward(h->g, h->d, h->fl_fwd, h->d.Sf, h->stream); }
+  else { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
 // Sharded runs: the grid tracer's transport, issued when the neighbours' halo rows have arrived (fv_advection's mpp_update_domains) and
 // BEFORE the lat -> m all-to-all, on the side stream: it then runs under that exchange and the spectral pipeline, like on one GPU.
@@ -955,7 +962,7 @@ static void phase_tracer(isca_dyn *h, const StepScalars &sc) {
   HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
 }
 static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, spectral update, synthesis
-  { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
+  if (!h->fuse_fwd) { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
     Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut);

@@ -65,6 +65,10 @@ struct Dev {
   double *leg_fwd_frag;      // [Ml][Jh/4][2][NHP/16][64]
   double *leg_inv_frag;      // [Ml][2][NHP/4][Jh/16][64]
   double *leg_scoef;         // [Ml][N1+16][5][4]
+  // fused FFT + Legendre analysis (kernels.hip k_fft_leg_fwd; one rank, lon_max = 256): the table in 4x4x4 fragment order per MFMA wavefront
+  double *fz_frag = nullptr; // [4][Jh/8][NT][64][2]
+  int *fz_desc = nullptr;    // [4][NT][2] {ml, 16 * tile | nlim << 16}, ml = -1: padding
+  int fz_NT = 0;
   double *coef;              // [9][Ml][N1]: eigen,uvm,uvc,uvp,alpm,alpp,dym,dx,dyp ; [9]=mask ; [10]=damping
   double *pk, *bk, *dpk, *dbk;
   double *wave_mat_t;        // [num_spherical][L(k')][L(k)]  transposed wave matrices
@@ -150,6 +154,7 @@ struct isca_dyn {
   std::vector<double> h_surf_geop;  // global (lat_max, lon_max) surface geopotential as handed over (empty = flat)
   int n_active = 0;
   bool fuse_synth = false;
+  bool fuse_fwd = false;            // FFT + Legendre analysis of the step's forward batch in one kernel (ISCA_FUSE_FFT_LEG)
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_early = false;        // the horizontal tracer kernel forks BEFORE the column kernel (ISCA_TRACER_EARLY=1; see spectral_dynamics_init)
   bool tracer_on = false;           // advect the grid tracer

@@ -40,6 +40,10 @@ void launch_sw_tracer_tend(int n, const double *u, const double *v, const double
 // ---- transforms
 void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s);
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s);
+// fused forward transform of the step (grid -> spectral work rows, no Fourier buffer): tables built at create when the geometry fits
+int build_fused_fwd_tables(const Geom &g, const Tables &T, const std::vector<int> &m_local, std::vector<double> &frag, std::vector<int> &desc);
+void launch_fft_legendre_forward(const Geom &g, const Dev &d, const FieldList &fl, double *S, hipStream_t s);
+bool fused_forward_ok(const Geom &g);
 // legendre.hip: true when the MFMA kernels cover this geometry; fragment-ordered tables built at create
 bool legendre_mfma_ok(const Geom &g, int impl);
 void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<int> &m_local, std::vector<double> &fwd,

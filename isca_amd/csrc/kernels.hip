@@ -517,6 +517,182 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
   }
 }
 
+// =====================================================================================================
+// Fused analysis: longitude FFT + Legendre transform of the step's forward batch in ONE kernel -- the truncated Fourier rows
+// (grid_fourier.F90:129-179 -> spherical_fourier.F90:264-339) never leave the chip.  One rank (no lat <-> m exchange to feed), lon_max = 256.
+//
+// A block owns TWO level-fields (4 real columns) for ALL latitudes and ALL wavenumbers, because the quadrature sums of every (m, n) must stay
+// in accumulators while the block walks the latitudes: 8 wavefronts in two roles, pipelined over chunks of 8 latitude pairs --
+//   wavefronts 0-3 (FFT):  a 16-thread group per (level-field, pair): loads the northern and the southern row, forms x_even = N + S and
+//      x_odd = N - S on the GRID values (the FFT is linear: the fold of spherical_fourier.F90:311-312 done in front of it), transforms both
+//      rows (the same three Stockham passes as k_fft_fwd3, wavefront-synchronous), splits, and leaves the coefficients m <= M in LDS as
+//      E/O[pair][parity][m][column];
+//   wavefronts 4-7 (MFMA): v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4 products per instruction, here 8 even + 8 odd n of one
+//      wavenumber x 4 latitude pairs x 4 columns (lane maps found with tools/micro/mfma_f64_probe.hip: A[b][i][k] lane 16k+4b+i,
+//      B[b][k][j] lane 16k+4b+j, D[b][i][j] lane 16i+4b+j); a 16-column tile would be three quarters empty.  Each wavefront owns NT tiles
+//      (16 n of one m; the host deals the triangle's tiles round-robin) with their accumulators in registers for the whole kernel, streams
+//      its part of the fragment-ordered table (16-byte loads: the pieces of a chunk's two k-steps side by side) through a ring, and reads
+//      B from the E/O buffer the FFT wavefronts filled during the chunk before.
+// One block barrier per chunk.  Algorithmic bytes: the grid rows in, the spectral rows out; the table (2.4 MB at T85) comes from L2.
+// =====================================================================================================
+constexpr int FZ_PC = 8;            // latitude pairs per chunk (two k-steps of 4)
+struct FusedFwdArgs {
+  const double *frag;               // [4][NCH][NT][64][2]
+  const int *desc;                  // [4][NT][2]: {ml (-1: padding), 16 * tile | nlim << 16}
+  double *S;                        // [Ml][N1][C]
+  int C, NCH, MP;                   // MP: odd wavenumber pitch of the E/O buffers (bank spread)
+  int dbg;                          // measurement only (ISCA_FZ_DBG): 1 the FFT wavefronts, 2 the MFMA wavefronts skip their work (wrong results)
+};
+template <int NT>
+__global__ __launch_bounds__(512, 2) void k_fft_leg_fwd(Geom g, FieldList fl, const double *__restrict__ cosm, const double2 *__restrict__ tw,
+                                                        FusedFwdArgs a) {
+  constexpr int NC = 128, TPR = 16, PF = 8;
+  static_assert(NT % PF == 0, "ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double2 *buf = (double2 *)smem;                          // [16 rows][NC]: the FFT groups' rows (FftRow swizzle)
+  double2 *twl = buf + 16 * NC;                            // [2 NC] exp(-2 pi i k / I)
+  double *eo = (double *)(twl + 2 * NC);                   // [2 buffers][FZ_PC][2 parities][MP][4 columns]
+  const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+  for (int k = t; k < 2 * NC; k += 512) twl[k] = tw[k];
+  const int MP = a.MP, NCH = a.NCH, J = g.J, I = g.I;
+  const int EOB = FZ_PC * 2 * MP * 4;                      // doubles per E/O buffer
+  __syncthreads();
+  if (wave < 4) {
+    // ------------------------------------------------------------------ FFT role
+    const int r = t >> 4, tr = t & 15, lfl = r >> 3, jpl = r & 7;
+    const int c = blockIdx.x * 2 + lfl;
+    const double *base = fl.g[0];
+    int op = OP_NONE;
+    bool valid = false;
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      base = fl.g[f] + (size_t)(c - fl.off[f]) * J * I;
+      op = fl.op[f];
+      valid = true;
+    }
+    FftTw<NC, false, true> w;
+    w.init(tw, twl, tr);
+    const FftRow<NC> ix(r);
+    const double inv_n = 1.0 / (double)I;
+    double2 zn[8], zs[8];
+    double sn = 0.0, ss = 0.0;
+    auto request = [&](int ch) {                           // the pair's two rows (a padding column re-reads valid rows and gets scale 0)
+      const int jp = ch * FZ_PC + jpl;
+      const double2 *ps = (const double2 *)(base + (size_t)jp * I), *pn = (const double2 *)(base + (size_t)(J - 1 - jp) * I);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { zs[i] = ps[tr + TPR * i]; zn[i] = pn[tr + TPR * i]; }
+      ss = valid ? ((op == OP_COSM) ? cosm[jp] : 1.0) : 0.0;
+      sn = valid ? ((op == OP_COSM) ? cosm[J - 1 - jp] : 1.0) : 0.0;
+    };
+    request(0);
+    for (int ch = 0; ch <= NCH; ++ch) {
+      if (ch < NCH && !(a.dbg & 1)) {
+        double *dst = eo + (ch & 1) * EOB + (size_t)(jpl * 2) * MP * 4 + 2 * lfl;
+        const double sgn_n = sn, sgn_s = ss;
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+          double2 z[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const double2 vn = make_double2(zn[i].x * sgn_n, zn[i].y * sgn_n), vs = make_double2(zs[i].x * sgn_s, zs[i].y * sgn_s);
+            // x_even = north + south, x_odd = north - south   (spherical_fourier.F90:311-312)
+            z[i] = par ? make_double2(vn.x - vs.x, vn.y - vs.y) : make_double2(vn.x + vs.x, vn.y + vs.y);
+          }
+          if (par == 1 && ch + 1 < NCH) request(ch + 1);           // the next chunk's rows: in flight during the second transform and the wait at the barrier
+          fft3_row<NC, false, true>(z, buf, ix, w, tr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) buf[ix.at(tr + TPR * i)] = z[i];
+          __builtin_amdgcn_wave_barrier();
+          // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I   (as k_fft_fwd3)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int m = tr + TPR * i;
+            if (m < g.M1) {
+              const double2 zk = buf[ix.at(m)];
+              const double2 zc = cconj(buf[ix.at((NC - m) & (NC - 1))]);
+              const double2 e = cscale(0.5, cadd(zk, zc));
+              const double2 dd = csub(zk, zc);
+              const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+              double2 X = cadd(e, cmul(twl[m], o));
+              X.x *= inv_n; X.y *= inv_n;
+              *(double2 *)(dst + ((size_t)par * MP + m) * 4) = X;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();                         // the row is rewritten by the next transform
+        }
+      }
+      __syncthreads();                                             // chunk ch is in E/O[ch & 1]; chunk ch - 1 has been consumed
+    }
+  } else {
+    // ------------------------------------------------------------------ MFMA role
+    const int wv = wave - 4;
+    const int k = lane >> 4, b = (lane >> 2) & 3, j = lane & 3, par = b >> 1;
+    const int boff = ((k * 2 + par) * MP) * 4 + j;                 // + 32 MP per k-step of the chunk, + EOB per buffer, + 4 m
+    const int *dsc = a.desc + (size_t)wv * NT * 2;
+    const double2 *fr = (const double2 *)a.frag + (size_t)wv * NCH * NT * 64 + lane;
+    const int total = NCH * NT;
+    double acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] = 0.0;
+    double2 ring[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) ring[d] = fr[(size_t)d * 64];
+    // where a tile's wavenumber sits in the E/O rows (4 ml doubles), two tiles per register: a descriptor read inside the loop would put a
+    // scalar-memory round trip in front of every LDS read (measured: 75 us for the kernel instead of 25)
+    unsigned mo[NT / 2];
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) mo[q] = (unsigned)(4 * max(dsc[4 * q], 0)) | ((unsigned)(4 * max(dsc[4 * q + 2], 0)) << 16);
+    __syncthreads();                                               // (the FFT wavefronts' barrier of chunk 0)
+    for (int ch = 0; ch < NCH; ++ch) {
+      const double *eb = eo + (ch & 1) * EOB + boff;
+      if (!(a.dbg & 2))
+#pragma unroll
+      for (int gq = 0; gq < NT / PF; ++gq) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+          const int q = gq * PF + d;
+          const double *bp = eb + ((mo[q >> 1] >> (16 * (q & 1))) & 0xffffu);
+          const double b0 = bp[0], b1 = bp[32 * MP];
+          const double2 av = ring[d];
+          const int nxt = min(ch * NT + q + PF, total - 1);        // clamped at the end: re-reads, no branch around the load
+          ring[d] = fr[(size_t)nxt * 64];
+          acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av.x, b0, acc[q], 0, 0, 0);
+          acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(av.y, b1, acc[q], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    // D[b][i][jj] sits in lane 16 i + 4 b + jj: n = 16 tile + 2 (4 (b & 1) + i) + (b >> 1), column 4 blockIdx.x + jj
+    const int iD = lane >> 4, e = 4 * (b & 1) + iD;
+    double *Sp = a.S + 4 * blockIdx.x + j;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int ml = dsc[2 * q], w1 = dsc[2 * q + 1];
+      const int n = (w1 & 0xffff) + 2 * e + par, nlim = w1 >> 16;
+      if (ml >= 0 && n < nlim) Sp[((size_t)ml * g.N1 + n) * a.C] = acc[q];
+    }
+  }
+}
+bool fused_forward_ok(const Geom &g) { return g.P == 1 && g.I == 256 && g.Jh % FZ_PC == 0 && g.M1 <= 96; }
+void launch_fft_legendre_forward(const Geom &g, const Dev &d, const FieldList &fl, double *S, hipStream_t s) {
+  FusedFwdArgs a;
+  a.frag = d.fz_frag; a.desc = d.fz_desc; a.S = S; a.C = col_pitch(fl.ncol); a.NCH = g.Jh / FZ_PC; a.MP = g.M1 | 1;
+  static const int dbg = getenv("ISCA_FZ_DBG") ? atoi(getenv("ISCA_FZ_DBG")) : 0;
+  a.dbg = dbg;
+  const size_t lds = (size_t)(16 * 128 + 2 * 128) * sizeof(double2) + (size_t)2 * FZ_PC * 2 * a.MP * 4 * sizeof(double);
+  const dim3 grid((unsigned)((fl.ncol + 1) / 2));
+#define LZ(N)                                                                                                              \
+  do {                                                                                                                     \
+    static bool attr = false;                                                                                              \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)k_fft_leg_fwd<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+    hipLaunchKernelGGL(k_fft_leg_fwd<N>, grid, dim3(512), lds, s, g, fl, d.cosm_lat_l, (const double2 *)d.tw, a);          \
+  } while (0)
+  if (d.fz_NT == 24) LZ(24); else if (d.fz_NT == 48) LZ(48); else if (d.fz_NT == 72) LZ(72);
+  else throw std::runtime_error("fused analysis: unsupported tile count");
+#undef LZ
+}
+
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
 static unsigned fft_grid(int items) {                  // persistent blocks: at most 3 per CU of the 256 (LDS-limited residency; measured
   const int cap = 768;                                 // against 512 / 1024 / 1536), and the same number of items for every block

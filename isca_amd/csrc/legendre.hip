@@ -537,6 +537,44 @@ void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<
   }
 }
 
+// Tables of the fused analysis (kernels.hip k_fft_leg_fwd): the triangle's tiles of 16 n dealt round-robin to the four MFMA wavefronts of a
+// block, and P(m, n, j') w(j') in the operand order of v_mfma_f64_4x4x4_4b_f64 -- A[b][i][k] in lane 16 k + 4 b + i with b < 2 the tile's even
+// n (n = 16 T + 2 (4 (b & 1) + i)), b >= 2 its odd n, k the latitude pair inside the k-step -- per (wavefront, chunk of 8 pairs, tile), the
+// pieces of the chunk's two k-steps side by side.  Returns NT (tiles per wavefront, padded to the kernel's instantiations) or 0.
+int build_fused_fwd_tables(const Geom &g, const Tables &T, const std::vector<int> &m_local, std::vector<double> &frag, std::vector<int> &desc) {
+  struct Tile { int ml, m, n0, nlim; };
+  std::vector<Tile> tiles;
+  for (int ml = 0; ml < g.Ml; ++ml) {
+    const int m = m_local[ml];
+    if (m < 0) continue;
+    const int nlim = g.N1 - m;
+    for (int n0 = 0; n0 < nlim; n0 += 16) tiles.push_back({ml, m, n0, nlim});
+  }
+  const int per = ((int)tiles.size() + 3) / 4;
+  const int NT = per <= 24 ? 24 : (per <= 48 ? 48 : (per <= 72 ? 72 : 0));
+  if (!NT) return 0;
+  const int NCH = g.Jh / 8, N1 = g.N1;
+  frag.assign((size_t)4 * NCH * NT * 64 * 2, 0.0);
+  desc.assign((size_t)4 * NT * 2, 0);
+  for (int w = 0; w < 4; ++w)
+    for (int t = 0; t < NT; ++t) {
+      const size_t gi = (size_t)4 * t + w;
+      int *dq = &desc[((size_t)w * NT + t) * 2];
+      if (gi >= tiles.size()) { dq[0] = -1; dq[1] = 0; continue; }
+      const Tile &tl = tiles[gi];
+      dq[0] = tl.ml; dq[1] = tl.n0 | (tl.nlim << 16);
+      for (int c = 0; c < NCH; ++c)
+        for (int l = 0; l < 64; ++l)
+          for (int h = 0; h < 2; ++h) {
+            const int k = l >> 4, b = (l >> 2) & 3, i = l & 3;
+            const int n = tl.n0 + 2 * (4 * (b & 1) + i) + (b >> 1), jp = 8 * c + 4 * h + k;
+            const double v = (n < tl.nlim) ? T.legendre[((size_t)jp * N1 + n) * g.M1 + tl.m] * T.wts_hem[jp] : 0.0;
+            frag[((((size_t)w * NCH + c) * NT + t) * 64 + l) * 2 + h] = v;
+          }
+    }
+  return NT;
+}
+
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (legendre_mfma_ok(g, impl) && C % 2 == 0) {
     LegFwdArgs a;

@@ -132,6 +132,29 @@ def test_golden_T85L40_benchmark_config(golden_dir):
     dc.close()
 
 
+def test_fused_fft_legendre_analysis(golden_dir, monkeypatch):
+    """ISCA_FUSE_FFT_LEG=1: the forward batch's FFT and Legendre transform in ONE kernel (k_fft_leg_fwd: the Fourier rows stay in LDS, the
+    quadrature sums of every (m, n) in v_mfma_f64_4x4x4 accumulators) -- measured slower than the two kernels it replaces at T85L40 (74
+    against 42 us, DESIGN.md 11 "Round 4") and therefore off by default, but correct: the benchmark configuration against the reference run
+    like the default path (the fold N +- S is done on the grid rows in front of the FFT, so the two paths differ in the last bits only)."""
+    g = np.load(os.path.join(golden_dir, "run_T85L40.npz"))
+    monkeypatch.setenv("ISCA_FUSE_FFT_LEG", "1")
+    dc = make("T85", 40, dt_atmos=300.0); dc.cold_start()
+    assert dc.info("kernels_per_step") == 9
+    monkeypatch.delenv("ISCA_FUSE_FFT_LEG")
+    ref = make("T85", 40, dt_atmos=300.0); ref.cold_start()
+    dc.step(20); ref.step(20)
+    err = {}
+    for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1")):
+        r = g["st_%s_000020_s488" % gk]
+        err[k] = float(np.abs(dc.get(k)[::4, ::8, ::8] - r).max() / max(np.abs(r).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+    err["psg"] = rel(dc.get("psg")[::4, ::4], g["st_psg_000020_s44"])
+    print("fused analysis, T85L40, 20 steps vs the reference:", err)
+    assert max(err.values()) < 1e-9, err
+    assert rel(dc.get("ts"), ref.get("ts")) < 1e-11 and rel(dc.get("vors"), ref.get("vors")) < 1e-9      # the two paths: roundoff apart
+    dc.close(); ref.close()
+
+
 def test_developed_state_steps_vs_reference(golden_dir):
     """A DEVELOPED state of configs[1] (T42L25 Held-Suarez, day 60 of the reference run: baroclinic eddies at finite amplitude) handed over as
     a restart would be -- both time levels of the spectral and grid state, the dynamics' Robert-filtered tracer level and atmosphere_mod's
