@@ -383,10 +383,36 @@ def main():
         one.close()
         replicas = {"value": world * sim_years_per_day(float(e1.item()) / a.steps, dt), "unit": "sim_years/day (sum over members)",
                     "ms_per_step": 1e3 * float(e1.item()) / a.steps, "scaling": "weak", "note": "independent ensemble members, one per GPU"}
+    variants = None
+    if world > 1 and getattr(core, "native", False) and not os.environ.get("ISCA_BENCH_NO_VARIANTS"):
+        # One multi-GPU shot, two exchange drivers: beside the timed native loop (the library issues the exchanges on the step's stream) the
+        # same sharded model with torch.distributed between the device phases (4 host round trips per step) -- what the in-library loop buys.
+        prev = os.environ.get("ISCA_COMM")
+        os.environ["ISCA_COMM"] = "torch"
+        try:
+            alt = ShardedDynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, rank=rank, world_size=world, device=local_rank))
+            alt.cold_start(); alt.step(a.warmup + 20, sync=True)
+            barrier(); torch.cuda.synchronize()
+            t_v = time.perf_counter()
+            alt.step(a.steps, sync=True)
+            torch.cuda.synchronize(); barrier()
+            e_v = torch.tensor([time.perf_counter() - t_v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(e_v, op=dist.ReduceOp.MAX)
+            alt.close()
+            variants = {"exchanges issued by the library (timed above)": {"ms_per_step": 1e3 * sec_per_step},
+                        "torch.distributed between the device phases": {"ms_per_step": 1e3 * float(e_v.item()) / a.steps}}
+        except Exception as e:                                       # noqa: BLE001
+            variants = {"error": str(e)[:200]}
+        finally:
+            if prev is None:
+                os.environ.pop("ISCA_COMM", None)
+            else:
+                os.environ["ISCA_COMM"] = prev
     exchange_ms = None
     if world > 1:       # what each rank spent in the exchanges of a step (HIP events around the RCCL calls the library issues)
         mine = {k: round(v, 5) for k, v in kt.items() if k in ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce", "all_to_all_raw")}
-        mine["driver"] = "native RCCL" if getattr(core, "native", False) else f"torch.distributed ({backend})"
+        kind = core.lib.isca_dyn_comm_kind(core._h).decode() if getattr(core, "native", False) else ""
+        mine["driver"] = (f"native ({kind}): exchanges issued by the library" if kind else f"torch.distributed ({backend})")
         exchange_ms = [None] * world
         dist.all_gather_object(exchange_ms, mine)
     if rank != 0:
@@ -423,6 +449,8 @@ def main():
         out["replicas"] = replicas
     if exchange_ms is not None:
         out["exchange_ms"] = exchange_ms          # per rank; kernel_ms holds rank 0's kernels
+    if variants is not None:
+        out["variants"] = variants
     if world > 1 and native_error is not None:
         out["native_exchange_error"] = native_error
     if a.gpus == 1 and a.cpu_steps > 0:

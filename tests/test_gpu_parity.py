@@ -1121,6 +1121,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["replicas"]["value"] > 0 and "workload" in d["config"]
 
 
+def test_bench_two_ranks_native_loop_and_variants():
+    """bench.py --gpus 2 with the library issuing the exchanges itself (ISCA_COMM=ipc on this one-GPU box; RCCL on a node): the line names
+    the exchange driver per rank, carries `exchange_ms`, the 500-step figure, and a `variants` block -- the same sharded model with
+    torch.distributed between the device phases -- so that one multi-GPU run yields the comparison."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29656", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--workload", "T21L25"]
+    env = dict(os.environ, ISCA_BENCH_BACKEND="gloo", ISCA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc",
+               ISCA_BENCH_SPINUP_S="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steady"]["steps"] >= 500
+    assert all("native (ipc)" in e["driver"] and "all_to_all_fwd" in e for e in d["exchange_ms"])
+    v = d["variants"]
+    assert len(v) == 2 and all(x["ms_per_step"] > 0 for x in v.values()), v
+
+
 def test_rccl_comm_check_single_rank():
     """isca_dyn_comm_check (rank-tagged patterns through the step's exchange buffers) on a one-rank communicator: the path every
     rank runs before the native exchange driver is trusted."""
