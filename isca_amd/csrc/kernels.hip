@@ -1653,7 +1653,9 @@ __device__ void vadv_column(int L, double dt, const double *w, const double *dz,
           cn = -dt * w[k] / dz[k]; kk = k;
           if (cn > 1.) {
             double dzsum = 0.; const double dtw = -dt * w[k];
-            while (dzsum + dz[kk] < dtw) { if (kk == 0) break; dzsum += dz[kk]; rsum += r[kk]; ++kk; }     // (:414: `if (kk == ks) exit`, as written)
+            // (:414 reads `if (kk == ks) exit` in this branch too, which never stops a downward walk; a flow that crosses the ground within one
+            //  step walks off the column there -- here it stops at the lowest layer, and valid_range_t reports the blown-up state)
+            while (dzsum + dz[kk] < dtw) { if (kk == L - 1) break; dzsum += dz[kk]; rsum += r[kk]; ++kk; }
             xx = (dtw - dzsum) / dz[kk];
           } else xx = cn;
           const double rm = rr[kk] - rl[kk];
@@ -2053,7 +2055,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     sx[i] = vl_limit(((q2[ip] - q2[i]) + (q2[i] - q2[im])) / 2, q2[im], q2[i], q2[ip]);
     double fxi = 0.0;
     if (any_big[rr]) {               // integer_flux_x (:494-527), modular form
-      const int n_ = (int)b;
+      const int n_ = (int)fmin(fmax(b, -(double)I), (double)I);      // (a Courant number beyond one turn of the circle is a blown-up state: bounded walk)
       if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fxi += q2[(i - t) & IM]; }
       else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fxi -= q2[(i + t) & IM]; }
     }
@@ -2268,7 +2270,8 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
         const double dtw = up ? a.dt * wk : -a.dt * wk;
         double dzk = dvd;
         while (dzsum + dzk < dtw) {
-          if (kd == 0) break;                                 // the reference stops at kk == 1 (up) / ks (down)
+          if (kd == (up ? 0 : g.L - 1)) break;                // the reference stops at kk == 1 going up; going down (`kk == ks`, :414) it never does:
+                                                              // a blown-up state must not walk off the column (memory fault) before valid_range_t reports it
           dzsum += dzk; rsum += a.trh[(size_t)kd * lev + c2];
           kd += up ? -1 : 1;
           dzk = a.dpk[kd] + a.dbk[kd] * ps;
