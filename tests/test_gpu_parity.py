@@ -1142,6 +1142,29 @@ def test_bench_two_ranks_native_loop_and_variants():
     assert len(v) == 2 and all(x["ms_per_step"] > 0 for x in v.values()), v
 
 
+def test_blown_up_run_is_a_fatal_not_a_fault():
+    """A run that blows up (dt_atmos far beyond the CFL limit) must end like the reference's -- FATAL 'temperatures out of valid range'
+    (spectral_dynamics.F90:940-972) at the next synchronisation -- not in a memory fault or an endless loop of a kernel whose walk lengths
+    depend on the data (van Leer's integer Courant shift, the PPM's Courant > 1 extension).  In a subprocess with a time limit."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from isca_amd import dyncore\n"
+        "for kw in (dict(), dict(vert_advect_uv=3, vert_advect_t=3)):\n"
+        "    dc = dyncore.DynCore(dyncore.default_config('T21', num_levels=8, dt_atmos=21600.0, **kw)); dc.cold_start()\n"
+        "    try:\n"
+        "        for _ in range(60): dc.step(10)\n"
+        "        print('NO_FATAL')\n"
+        "    except dyncore.IscaError as e:\n"
+        "        print('FATAL:', str(e)[:120])\n"
+        "    dc.close()\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("FATAL", "NO_FATAL"))]
+    assert len(lines) == 2 and all(ln.startswith("FATAL") and "valid range" in ln.lower() for ln in lines), r.stdout
+
+
 def test_rccl_comm_check_single_rank():
     """isca_dyn_comm_check (rank-tagged patterns through the step's exchange buffers) on a one-rank communicator: the path every
     rank runs before the native exchange driver is trusted."""
