@@ -171,4 +171,5 @@ struct isca_dyn {
   int tr_state[2] = {0, 0};         // TracerState of the tracer buffers of time level 0 / 1
   bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
   bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
+  double *host_red = nullptr;       // pinned: the fixer scalars / temperature extremes read back at a synchronisation point
 };
