@@ -192,6 +192,48 @@ def test_developed_state_steps_vs_reference(golden_dir):
     dc.close()
 
 
+def test_restart_files_from_reference_state(golden_dir, tmp_path):
+    """The restart FILES with a state the REFERENCE produced: `spectral_dynamics.res.nc` / `atmosphere.res.nc` (the reference's variable set,
+    spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375) are written from the reference's two time levels at day 60 -- spectral fields,
+    grid fields, the dynamics' Robert-filtered tracer level in the first file and atmosphere_mod's unfiltered copy in the second, the time
+    pointers -- and the model is started from `INPUT/` through atmosphere_init with the test case's namelist, as a restarted run would be:
+    1 and 10 steps later it stands where the reference stands.  (The reference cannot write netCDF in this image; its state is.)"""
+    import types
+    from isca_amd import atmosphere as atm, configs, restart
+    g = np.load(os.path.join(golden_dir, "developed_T42L25.npz"))
+    helper = make("T42", 25)                                   # tables and the synthesis of vorg / divg (restart variables, :1518-1519)
+    vorg, divg = helper.trans_spherical_to_grid(g["rs_vors_cur"]), helper.trans_spherical_to_grid(g["rs_divs_cur"])
+    state = {("vors", 0): g["rs_vors_prev"], ("vors", 1): g["rs_vors_cur"], ("divs", 0): g["rs_divs_prev"], ("divs", 1): g["rs_divs_cur"],
+             ("ts", 0): g["rs_ts_prev"], ("ts", 1): g["rs_ts_cur"], ("ln_ps", 0): g["rs_lnps_prev"], ("ln_ps", 1): g["rs_lnps_cur"],
+             ("tr", 0): g["rs_tr1_prev_filt"], ("tr", 1): g["rs_tr1_cur"], ("tr_atm", 0): g["rs_tr1_prev_atm"], ("tr_atm", 1): g["rs_tr1_cur"],
+             ("vorg", 1): vorg, ("divg", 1): divg, ("wg_full", 1): g["rs_wg_full"],
+             ("surf_geopotential", 1): np.zeros((helper.J, helper.I))}
+    for nm in ("ug", "vg", "tg", "psg"):
+        state[nm, 0], state[nm, 1] = g[f"rs_{nm}_prev"], g[f"rs_{nm}_cur"]
+    view = types.SimpleNamespace(
+        cfg=types.SimpleNamespace(world_size=1, physics=0, num_tracers=1, tracer_spectral=[0]), tracer_names=["sphum"],
+        info=lambda k: {"previous": 0, "current": 1, "tracer": 1}[k], table=helper.table,
+        get=lambda name, tl=1: state[name, tl])
+    run = tmp_path / "run"
+    restart.write_restart(view, str(run / "INPUT"))
+    helper.close()
+    nml = configs.held_suarez()
+    nml["spectral_dynamics_nml"]["num_levels"] = 25
+    core = atm.atmosphere_init(nml, resolution="T42", run_dir=str(run))
+    try:
+        assert core.info("previous") != core.info("current")
+        done = 0
+        for n, tol in ((1, 1e-11), (10, 1e-10)):
+            atm.atmosphere(n - done); done = n
+            err = {k: float(np.abs(core.get(k)[::2, ::2, ::2] - g[f"after{n}_{gk}_s222"]).max() / np.abs(g[f"after{n}_{gk}_s222"]).max())
+                   for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1"))}
+            err["psg"] = rel(core.get("psg"), g[f"after{n}_psg"])
+            print("restart files written from the reference's day-60 state, +", n, "steps:", err)
+            assert max(err.values()) < tol, (n, err)
+    finally:
+        atm.atmosphere_end()
+
+
 def test_external_physics_seam(golden_dir):
     """physics = 2 (the spectral_dynamics seam of atmosphere.F90:300-329): the host evaluates hs_forcing on the fields the library hands
     out and gives the tendencies to isca_dyn_dynamics.  One day at T21L25: against the reference run (1e-9) and against the library's own
