@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--raw", type=float, default=1.0, help="raw_filter_coeff (/= 1: the Robert-Asselin-Williams filter's third exchange)")
     ap.add_argument("--tracers", type=int, default=1, help="grid tracers of the field_table (further ones: their own halo rows)")
     ap.add_argument("--expect-comm", default="", help="'ipc': the library's own C++ step loop must be the driver (ISCA_COMM=ipc), not torch")
+    ap.add_argument("--opts", default="", help="further integer configuration keys, e.g. vert_advect_uv=2,vert_advect_t=3,use_implicit=0")
     ap.add_argument("--fatal", action="store_true", help="valid_range_t that only SOME bands leave: every rank must raise")
     a = ap.parse_args()
     import torch, torch.distributed as dist
@@ -30,6 +31,9 @@ def main():
         extra["raw_filter_coeff"] = a.raw
     if a.tracers > 1:
         extra.update(num_tracers=a.tracers, tracer_robert_coeff=[-1.0, 0.05, 0.0, -1.0])
+    for kv in filter(None, a.opts.split(",")):
+        k, v = kv.split("=")
+        extra[k] = float(v) if "." in v else int(v)
     more = [f"tr{k + 1}" for k in range(1, a.tracers)]
     sh = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, **extra))
     if a.expect_comm:

@@ -796,6 +796,8 @@ def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     (4, "T21", 8, 1.0, 2, []),                 # a second grid tracer's halo rows
     (2, "T21", 25, 1.0, 1, ["--moist"]),       # the moist package behind the same loop
     (8, "T21", 10, 1.0, 1, ["--fatal"]),       # FATAL on some ranks only: every rank raises, nobody hangs in an exchange
+    (2, "T21", 8, 1.0, 1, ["--opts", "vert_advect_uv=2,vert_advect_t=3"]),      # van Leer / PPM vertical advection of u, v, T (column-local: no exchange of its own)
+    (4, "T21", 8, 1.0, 1, ["--opts", "use_implicit=0,dt_atmos=300.0"]),
 ])
 def test_sharded_native_loop(world, res, levels, raw, tracers, extra):
     """The library's OWN sharded step loop (api.hip sharded_step: halo exchange, lat -> m all-to-all, m -> lat all-to-all, all-reduce,
