@@ -27,6 +27,8 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group(a.backend)
     extra = dict(physics=1, initial_sphum=2e-6, robert_coeff=0.03, dt_atmos=720.0) if a.moist else {}
+    if a.res in ("T85", "T170"):            # the benchmark configurations' time steps
+        extra["dt_atmos"] = 300.0 if a.res == "T85" else 150.0
     if a.raw != 1.0:
         extra["raw_filter_coeff"] = a.raw
     if a.tracers > 1:

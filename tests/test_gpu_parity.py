@@ -796,6 +796,8 @@ def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     (4, "T21", 8, 1.0, 2, []),                 # a second grid tracer's halo rows
     (2, "T21", 25, 1.0, 1, ["--moist"]),       # the moist package behind the same loop
     (8, "T21", 10, 1.0, 1, ["--fatal"]),       # FATAL on some ranks only: every rank raises, nobody hangs in an exchange
+    (8, "T85", 40, 1.0, 1, ["--moist"]),       # BASELINE configs[3]'s 8-GPU decomposition: the Frierson model at T85L40, 16 rows per rank
+    (4, "T170", 60, 1.0, 1, []),               # BASELINE configs[4] (T170L60) sharded
     (2, "T21", 8, 1.0, 1, ["--opts", "vert_advect_uv=2,vert_advect_t=3"]),      # van Leer / PPM vertical advection of u, v, T (column-local: no exchange of its own)
     (4, "T21", 8, 1.0, 1, ["--opts", "use_implicit=0,dt_atmos=300.0"]),
 ])
@@ -809,7 +811,7 @@ def test_sharded_native_loop(world, res, levels, raw, tracers, extra):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(29700 + world),
-           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8" if world < 8 else "4",
+           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8" if (world < 8 and res != "T170") else "4",
            "--res", res, "--levels", str(levels), "--raw", str(raw), "--tracers", str(tracers), "--expect-comm", "ipc"] + extra
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc", ISCA_IPC_TIMEOUT_S="300")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
