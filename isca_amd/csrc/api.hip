@@ -690,6 +690,7 @@ static void reset_pending(isca_dyn *h) {       // a state written from scratch h
   h->thermo_pending[0] = h->thermo_pending[1] = false;
   h->tr_state[0] = h->tr_state[1] = isca::TR_MAT;
   h->in_step = false;
+  h->moist_pcache = false;
 }
 static void cold_start_single(isca_dyn *h) {
   const Geom &g = h->g;
@@ -839,6 +840,7 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
   if (kind == 0) h2d(h, p, host, cnt);
   else spec_host_to_dev(h, host, p, kind == 1 ? h->g.L : 1);
   h->have_state = true;
+  h->moist_pcache = false;
   API_END
 }
 
@@ -897,6 +899,7 @@ extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int curre
   materialize(h);
   h->previous = previous; h->current = current; h->step_count = step_count;
   h->phys_calls = 0;         // idealized_moist_phys_init sets gust = 1 again after a restart
+  h->moist_pcache = false;
   API_END
 }
 // ... then rebuild what the step keeps between calls but the restart file does not hold.
@@ -928,8 +931,13 @@ static void timed_tracer(isca_dyn *h, const StepScalars &sc, hipStream_t st, int
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
   h->in_step = true;
   if (h->cfg.physics == 1) {
-    { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream); }
-    { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream); }
+    // the previous level's pressures are what the step before computed for its current level (grid p_s of a level is final once its
+    // fixers are applied; every state write drops the cache): only the current level's are computed then (k_moist_pressures 20 -> 11 us)
+    const bool cached = h->moist_pcache && sc.prev != sc.cur && !getenv_once("ISCA_MOIST_NO_PCACHE");
+    const int slot_prev = cached ? h->moist_pslot : 0, slot_cur = 1 - slot_prev;
+    { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream, slot_prev, slot_cur, cached); }
+    { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream, slot_prev, slot_cur); }
+    h->moist_pslot = slot_cur; h->moist_pcache = true;
     h->phys_calls++;
   }
   // fork: the tracer's vertical kernel needs the column kernel's vertical velocity; its horizontal kernel only state that exists when the

@@ -164,6 +164,10 @@ struct isca_dyn {
   long diag_count = 0;              // send_data calls since the last reset
   isca::MoistState *moist = nullptr;   // tables of the moist physics package (physics = 1)
   long phys_calls = 0;              // calls of the physics since create / restart (gust is 1 m/s on the first)
+  // moist package: the pressures of the step's CURRENT level are the next step's PREVIOUS-level pressures (the grid p_s of a level does not
+  // change once its fixers are applied): slot moist_pslot of the work area holds them while moist_pcache is true (reset by every state write)
+  int moist_pslot = 0;
+  bool moist_pcache = false;
   isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
   // Lazy fixers: compute_corrections' scalars and the grid tracer's leapfrog_2level_B stay pending on the new level and are applied by
   // the next steps' kernels as they read it (no pass over the fields at the end of the step); materialised for every host access.

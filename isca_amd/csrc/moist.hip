@@ -338,6 +338,7 @@ struct PressArgs {
   const double *t[2], *ps[2];
   double *p_full[2], *p_half[2], *z_full, *z_half;
   int ncol, L, store_half;
+  int tl0;                 // first time level of the launch (1: the previous level's pressures are cached)
 };
 // Above 41 levels (the moist kernel's third work array in a global buffer, 131 072 columns at T170L60: the kernel is throughput-bound and every
 // pass over a level array is 15 us of HBM time) the half-level pressures are not stored: k_moist_physics forms pk + bk ps where it needs them
@@ -354,7 +355,7 @@ constexpr int MP_PK = 4;
 __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= a.ncol) return;
-  const int k0 = blockIdx.y * MP_PK, tl = blockIdx.z, L = a.L;
+  const int k0 = blockIdx.y * MP_PK, tl = blockIdx.z + a.tl0, L = a.L;
   const size_t c = (size_t)col, s = (size_t)a.ncol;
   const double ps = a.ps[tl][c];
   const double *pk = a.pk, *bk = a.bk;
@@ -386,11 +387,23 @@ __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
     }
   }
 }
-void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+// the work buffer: two (p_full, p_half) areas, then z_full, z_half of the current level, ...
+struct MoistWork { double *pf[2], *ph[2], *zf_c, *zh_c, *rest; };
+static MoistWork moist_work_layout(const isca_dyn &h) {
+  const size_t lev = (size_t)h.g.Jl * h.g.I;
+  const int L = h.g.L;
+  MoistWork w;
+  w.pf[0] = h.d.moist_work; w.ph[0] = w.pf[0] + lev * L; w.pf[1] = w.ph[0] + lev * (L + 1); w.ph[1] = w.pf[1] + lev * L;
+  w.zf_c = w.ph[1] + lev * (L + 1); w.zh_c = w.zf_c + lev * L;
+  w.rest = w.zh_c + lev * (L + 1);
+  return w;
+}
+void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int slot_prev, int slot_cur, bool prev_cached) {
   const Dev &d = h.d;
   const size_t lev = (size_t)h.g.Jl * h.g.I;
-  double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
-  double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L;
+  const MoistWork w = moist_work_layout(h);
+  double *pf_p = w.pf[slot_prev], *ph_p = w.ph[slot_prev], *pf_c = w.pf[slot_cur], *ph_c = w.ph[slot_cur];
+  double *zf_c = w.zf_c, *zh_c = w.zh_c;
   PressArgs a;
   a.pk = d.pk; a.bk = d.bk; a.ncol = (int)lev; a.L = h.g.L; a.surf_geop = d.surf_geop;
   a.t[0] = d.tg[sc.prev]; a.ps[0] = d.psg[sc.prev]; a.t[1] = d.tg[sc.cur]; a.ps[1] = d.psg[sc.cur];
@@ -400,13 +413,15 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   }
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
   a.store_half = moist_sigma_half(h.g.L) ? 0 : 1;
-  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
+  a.tl0 = prev_cached ? 1 : 0;
+  hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, prev_cached ? 1 : 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
-void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int slot_prev, int slot_cur) {
   const Dev &d = h.d;
   const size_t lev = (size_t)h.g.Jl * h.g.I;
-  double *pf_p = d.moist_work, *ph_p = pf_p + lev * h.g.L, *pf_c = ph_p + lev * (h.g.L + 1), *ph_c = pf_c + lev * h.g.L;
-  double *zf_c = ph_c + lev * (h.g.L + 1), *zh_c = zf_c + lev * h.g.L, *zf_p = zh_c + lev * (h.g.L + 1), *zh_p = zf_p + lev * h.g.L;
+  const MoistWork w = moist_work_layout(h);
+  double *pf_p = w.pf[slot_prev], *ph_p = w.ph[slot_prev], *pf_c = w.pf[slot_cur], *ph_c = w.ph[slot_cur];
+  double *zf_c = w.zf_c, *zh_c = w.zh_c, *zf_p = w.rest, *zh_p = zf_p + lev * h.g.L;
   MoistArgs a = moist_args(h);
   a.ncol = (int)lev; a.I = h.g.I;
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
