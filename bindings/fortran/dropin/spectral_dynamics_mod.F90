@@ -147,8 +147,8 @@ if(damping_coeff_vor == -1.) damping_coeff_vor = damping_coeff
 if(damping_coeff_div == -1.) damping_coeff_div = damping_coeff
 
 ! what the device core does not carry is refused by name (check_dynamics_nml's own tests are the library's: isca_dyn_create)
-if(trim(vert_difference_option) /= 'simmons_and_burridge') &
-  call error_mesg('spectral_dynamics_init','"'//trim(vert_difference_option)//'" is not a supported value for vert_difference_option.', FATAL)
+if(trim(vert_difference_option) /= 'simmons_and_burridge' .and. trim(vert_difference_option) /= 'mcm') &        ! press_and_geopot.F90:216-219
+  call error_mesg('pressure_variables','"'//trim(vert_difference_option)//'" is not a valid value for vert_difference_option', FATAL)
 if(trim(initial_state_option) /= 'quiescent') &
   call error_mesg('spectral_dynamics_init','"'//trim(initial_state_option)//'" is not a supported value for initial_state_option.', FATAL)
 if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian') &
@@ -188,6 +188,7 @@ cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_c
 cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
 cfg%vert_advect_uv = advect_scheme(vert_advect_uv, 'vert_advect_uv'); cfg%vert_advect_t = advect_scheme(vert_advect_t, 'vert_advect_t')
 cfg%use_implicit = merge(1, 0, use_implicit); cfg%make_symmetric = merge(1, 0, make_symmetric)
+cfg%vert_difference_option = merge(1, 0, trim(vert_difference_option) == 'mcm')
 cfg%physics = dropin_physics                ! 2: the caller keeps its physics package and spectral_dynamics receives its tendencies
 select case(trim(vert_coord_option))        ! compute_vert_coord (init/vert_coordinate.F90:124-152)
   case('uneven_sigma')
@@ -239,6 +240,7 @@ do ntr = 1, num_tracers
   select case(trim(tracer_attributes(ntr)%numerical_representation))
     case('spectral')
       tracer_attributes(ntr)%advect_horiz = 'spectral'; cfg%tracer_spectral(ntr) = 1
+      if(lowercase(trim(tracer_attributes(ntr)%hole_filling)) == 'on') cfg%tracer_hole_filling(ntr) = 1      ! water_borrowing (spectral_dynamics.F90:1142)
       if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'SECOND_CENTERED') &
         call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%advect_vert)//' is not available for a spectral tracer here', FATAL)
     case('grid')

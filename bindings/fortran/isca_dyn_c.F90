@@ -63,6 +63,8 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: vert_advect_uv, vert_advect_t      ! 0 second_centered, 1 fourth_centered, 2 van_leer_linear, 3 finite_volume_parabolic
   integer(c_int) :: use_implicit
   integer(c_int) :: make_symmetric
+  integer(c_int) :: vert_difference_option             ! 0 simmons_and_burridge, 1 mcm
+  integer(c_int) :: tracer_hole_filling(ISCA_MAX_TRACERS)
 end type
 
 interface

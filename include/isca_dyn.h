@@ -124,6 +124,16 @@ typedef struct isca_dyn_config {
   /* make_symmetric (spectral_dynamics_nml, default .false.; spherical.F90:185): the truncation mask also drops every zonal wavenumber
    * m > 0 -- a zonally symmetric model (exp/test_cases/axisymmetric). */
   int make_symmetric;
+  /* vert_difference_option (spectral_dynamics_nml; spectral_dynamics.F90:1084, press_and_geopot.F90:196, 242, implicit.F90:404, 447):
+   * 0 'simmons_and_burridge' (the default), 1 'mcm' -- full-level pressures at the arithmetic mean of the half levels, the pressure-gradient
+   * term as R T grad(p_s)/p_s, the energy-conversion term with (sum above + half the layer's own mass divergence)/p_full, and the
+   * matching linear operator of the semi-implicit scheme. */
+  int vert_difference_option;
+  /* hole_filling of the field_table entries of tracers 2..num_tracers ([k] = tracer k+1 as in tracer_spectral; 1 = 'on'): water_borrowing
+   * (atmos_spectral/model/water_borrowing.F90:38-136) on a 'spectral' tracer's tendency -- a negative value of the previous level is filled from
+   * its four neighbours on the latitude circle and in the column when together they hold enough (spectral_dynamics.F90:1142-1144).  Ignored for
+   * 'grid' tracers like the reference (:364-367). */
+  int tracer_hole_filling[ISCA_MAX_TRACERS];
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -66,11 +66,12 @@ _REF_DEFAULTS = dict(
     eddy_sponge_coeff=0., zmu_sponge_coeff=0., zmv_sponge_coeff=0., robert_coeff=.04, alpha_implicit=.5, scale_heights=4., surf_res=.1,
     exponent=2.5, initial_sphum=0.0, reference_sea_level_press=101325., water_correction_limit=0.0, raw_filter_coeff=1.0,
     valid_range_t=(100., 500.), dt_atmos=0.0, cutoff_wn=15, damping_coeff_vor=-1., damping_coeff_div=-1., damping_order_vor=-1,
-    damping_order_div=-1, vert_advect_uv=0, vert_advect_t=0, use_implicit=1, make_symmetric=0,
+    damping_order_div=-1, vert_advect_uv=0, vert_advect_t=0, use_implicit=1, make_symmetric=0, vert_difference_option=0,
     t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=1, trflux=1.e-5,
     trsink=-4., P00=1.e5)
 _REF_VERT_COORD_OPTION = "even_sigma"            # spectral_dynamics.F90:175
 _VERT_ADVECT_SCHEMES = {"SECOND_CENTERED": 0, "FOURTH_CENTERED": 1, "VAN_LEER_LINEAR": 2, "FINITE_VOLUME_PARABOLIC": 3}     # spectral_dynamics.F90:280-301
+_VERT_DIFFERENCE_OPTIONS = {"simmons_and_burridge": 0, "mcm": 1}     # spectral_dynamics.F90:1063, 1084
 _DAMPING_OPTIONS = {"resolution_dependent": 0, "exponential_cutoff": 1, "resolution_independent": 2}     # spectral_damping.F90:124-153
 # moist package, isca_moist_config members: idealized_moist_phys.F90:136-138, two_stream_gray_rad.F90:72-82, mixed_layer.F90:84-95,
 # qe_moist_convection.F90:66-70, damping_driver.f90:42-56, vert_turb_driver.F90:116, diffusivity.F90:127-128, monin_obukhov.F90:88-89
@@ -256,7 +257,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
         raise IscaError(f'"{dopt}" is an invalid value for damping_option')                      # spectral_damping.F90:152-153
     kw["damping_option"] = _DAMPING_OPTIONS[dopt]
     unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma", "hybrid", "mcm", "v197") else "uneven_sigma", "damping_option": dopt,
-                   "vert_difference_option": "simmons_and_burridge", "initial_state_option": "quiescent",
+                   "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}
     for grp in _NML_GROUPS:
         for k, v in (namelist or {}).get(grp, {}).items():
@@ -267,6 +268,11 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 continue
             if k in ("use_virtual_temperature", "use_implicit", "make_symmetric"):
                 kw[k] = int(bool(v))
+                continue
+            if k == "vert_difference_option":                # press_and_geopot.F90:164, 196, 216-219
+                if str(v).lower() not in _VERT_DIFFERENCE_OPTIONS:
+                    raise IscaError(f'"{v}" is not a valid value for vert_difference_option')
+                kw[k] = _VERT_DIFFERENCE_OPTIONS[str(v).lower()]
                 continue
             if k in ("vert_advect_uv", "vert_advect_t"):     # spectral_dynamics.F90:280-301
                 if str(v).upper() not in _VERT_ADVECT_SCHEMES:
@@ -366,7 +372,8 @@ def parse_field_table(text: str) -> list[dict]:
 def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = None):
     """(config keys, tracer names) for the library.  What the kernels implement is what the reference's own field_tables use: tracer 1 a
     'grid' tracer (van Leer + finite_volume_parabolic, the sphum entry), further tracers either that or 'spectral' with the defaults
-    (advect_vert = second_centered, hole_filling = off); anything else is refused by name rather than run as something else."""
+    (advect_vert = second_centered; hole_filling = on runs water_borrowing on its tendency); anything else is refused by name rather than run as
+    something else."""
     if len(entries) > dyncore.MAX_TRACERS:
         raise IscaError(f"field_table: {len(entries)} tracers, at most {dyncore.MAX_TRACERS} are carried")
     # The reference finds the humidity tracer by NAME (nhum = get_tracer_index('sphum') or 'mix_rat', spectral_dynamics.F90:316-332;
@@ -376,7 +383,7 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
     if hum and hum[0] != 0:
         raise IscaError(f"field_table: the humidity tracer ({entries[hum[0]]['name']}) must be the first atmos_mod entry "
                         f"(the first entry is {entries[0]['name']}): tracer 1 is the one the water correction, virtual temperature and moist physics use")
-    spectral, robert, names = [], [], []
+    spectral, robert, names, holes = [], [], [], []
     for k, e in enumerate(entries):
         m = e["methods"]
         rep = m.get("numerical_representation", ("spectral", ""))[0].lower()      # default_representation (:145)
@@ -388,8 +395,7 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
         want = "finite_volume_parabolic" if rep == "grid" else "second_centered"
         if adv != want:
             raise IscaError(f"field_table: tracer {e['name']}: advect_vert = {adv} is not available for a {rep} tracer (only {want})")
-        if rep == "spectral" and m.get("hole_filling", ("off", ""))[0].lower() == "on":
-            raise IscaError(f"field_table: tracer {e['name']}: hole_filling = on is not available")
+        hole = 1 if rep == "spectral" and m.get("hole_filling", ("off", ""))[0].lower() == "on" else 0    # water_borrowing (:1142); ignored for grid tracers (:364-367)
         if k == 0 and rep != "grid":
             raise IscaError(f"field_table: the first tracer ({e['name']}) must be a grid tracer")
         if "tracer_sms" in m:
@@ -406,8 +412,8 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
         dyn_rc = 0.04 if robert_coeff is None else robert_coeff                    # spectral_dynamics_nml's module default (:166)
         if k == 0 and rc >= 0.0 and rc != dyn_rc:
             raise IscaError(f"field_table: tracer {e['name']}: a robert_coeff of its own is only available from the second tracer on")
-        spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"])
-    keys = dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert)
+        spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"]); holes.append(hole)
+    keys = dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert, tracer_hole_filling=holes)
     if entries and not hum:            # dry_model: no humidity anywhere -- tracer 1 starts at 0 like every other tracer, no virtual temperature
         keys.update(initial_sphum=0.0, use_virtual_temperature=False, _dry_model=True)
     return keys, names

@@ -38,13 +38,20 @@ def build(force=False, verbose=True):
         return LIB
     objs = []
     procs = []
+    # per-unit digests (the unit's source + every header / .inc + its flags): only what changed is recompiled
+    old_units = json.load(open(stamp)).get("units", {}) if os.path.exists(stamp) and not force else {}
+    shared = [p for p in srcs if p.endswith((".h", ".inc"))]
+    units = {}
     for src, extra in UNITS:
         obj = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        units[src] = hashlib.sha1((_digest(shared + [os.path.join(CSRC, src)]) + " ".join(COMMON + extra)).encode()).hexdigest()
+        objs.append(obj)
+        if os.path.exists(obj) and old_units.get(src) == units[src]:
+            continue
         cmd = [HIPCC] + COMMON + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
@@ -55,7 +62,7 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
-    json.dump({"digest": dig}, open(stamp, "w"))
+    json.dump({"digest": dig, "units": units}, open(stamp, "w"))
     if verbose:
         print("built", LIB)
     return LIB

@@ -108,6 +108,8 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
   c->use_virtual_temperature = 0;
   c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1; c->make_symmetric = 0;
+  c->vert_difference_option = 0;
+  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) c->tracer_hole_filling[k] = 0;
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -164,7 +166,13 @@ static void check_config(const isca_dyn_config &c) {
   if (c.num_spherical != c.num_fourier * c.fourier_inc + 1) fail("num_spherical must equal num_fourier * fourier_inc + 1");
   if (c.lon_max < 3 * c.num_fourier + 1) fail("number of longitude points is too small for number of fourier waves");
   if (2 * c.lat_max < (c.triang_trunc ? 3 : 5) * (c.num_spherical - 1) + 1) fail("number of latitude points is too small for number of meridional waves");
-  if (c.lon_max & (c.lon_max - 1)) fail("lon_max must be a power of two (Stockham FFT kernel)");
+  {  // fft99's set99 (fft99.F90:83-120): an even length whose half has no prime factor above 5
+    int n = c.lon_max;
+    if (n < 16 || n > 512 || (n & 1)) fail("lon_max must be even, between 16 and 512");
+    n /= 2;
+    for (int f : {2, 3, 5}) while (n % f == 0) n /= f;
+    if (n != 1) fail("lon_max / 2 must have no prime factor above 5 (fft99's set99)");
+  }
   if (c.lat_max % 8) fail("lat_max must be a multiple of 8");
   if (c.num_levels > 64) fail("num_levels must be <= 64 (one wavefront lane per level in the spectral update)");
   if (!(c.raw_filter_coeff > 0.0 && c.raw_filter_coeff <= 1.0)) fail("raw_filter_coeff must be in (0, 1]");
@@ -188,6 +196,8 @@ static void check_config(const isca_dyn_config &c) {
     fail("spectral_dynamics_init: \"" + std::to_string(c.vert_advect_uv) + "\" is not a valid value for vert_advect_uv.");
   if (c.vert_advect_t < 0 || c.vert_advect_t > 3)
     fail("spectral_dynamics_init: \"" + std::to_string(c.vert_advect_t) + "\" is not a valid value for vert_advect_t.");
+  if (c.vert_difference_option < 0 || c.vert_difference_option > 1)      // press_and_geopot.F90:216-219
+    fail("pressure_variables: \"" + std::to_string(c.vert_difference_option) + "\" is not a valid value for vert_difference_option");
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
@@ -417,13 +427,22 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     d.pk = dupload(h, T.pk); d.bk = dupload(h, T.bk); d.dpk = dupload(h, T.dpk); d.dbk = dupload(h, T.dbk);
     {
-      std::vector<double> iv(5 * 64, 0.0);
+      // rows 0, 1: the two weights of linear_tp_tendency, dt_t = -kappa T_ref (above * c3 + own * c1) / dp (implicit.F90:446-468) -- dlog_3 and dlog_1
+      // of the reference column for simmons_and_burridge, dp / p_full and dp / (2 p_full) for 'mcm'; 2: dp; 3: h; 4, 5: dlog_f and dlog_3 of
+      // linear_geopotential (:329-359), the same for both options
+      std::vector<double> iv(6 * 64, 0.0);
       for (int k = 0; k < g.L; ++k) {
+        const double dp = T.dpk[k] + T.dbk[k] * T.ref_surf_p;
         iv[0 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_full[k];
         iv[1 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_half[k];
-        iv[2 * 64 + k] = T.dpk[k] + T.dbk[k] * T.ref_surf_p;
+        if (cfg->vert_difference_option == 1) {
+          const double p_full_ref = 0.5 * (T.pk[k + 1] + T.pk[k]) + 0.5 * (T.bk[k + 1] + T.bk[k]) * T.ref_surf_p;
+          iv[0 * 64 + k] = 0.5 * dp / p_full_ref; iv[1 * 64 + k] = dp / p_full_ref;
+        }
+        iv[2 * 64 + k] = dp;
         iv[3 * 64 + k] = T.h_impl[k];
         iv[4 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_full[k];
+        iv[5 * 64 + k] = T.ref_ln_p_half[k + 1] - T.ref_ln_p_half[k];
       }
       for (int k = g.L; k < 64; ++k) iv[2 * 64 + k] = 1.0;
       d.impl_vec = dupload(h, iv);
@@ -1047,6 +1066,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
   run_inverse(h, fl, 1);
   launch_hadv_combine(g, d.ug[sc.cur], d.vg[sc.cur], d.scratch_g[0], d.scratch_g[1], dt_tr, g.L, h->stream);
   launch_vert_advection_centered(*h, d.wg, d.psg[sc.cur], d.trx[sc.cur][e], dt_tr, h->stream);
+  if (h->cfg.tracer_hole_filling[e + 1]) launch_water_borrowing(*h, d.psg[sc.cur], d.trx[sc.prev][e], dt_tr, sc.delta_t, h->stream);     // :1142-1144
   dev_g2s(h, dt_tr, dt_trs, g.L, 1, OP_NONE);
   launch_spec_tracer_update(*h, sc, e, dt_trs, h->stream);
   dev_s2g(h, d.trxs[sc.fut][e], d.trx[sc.fut][e], g.L, OP_NONE);

@@ -693,6 +693,169 @@ void launch_fft_legendre_forward(const Geom &g, const Dev &d, const FieldList &f
 #undef LZ
 }
 
+// ---- lon_max = 2^a 3^b 5^c that is not a power of two (the lengths fft99's set99 factors, fft99.F90:83-120; its radix-3 / radix-5 passes
+// :876-1228): the same real <-> half-complex scheme -- one complex Stockham transform of length NC = I/2 and the even/odd split -- with the
+// factor list at run time: passes of radix 4, 2, 3, 5 out of place between two LDS copies of the row (the Stockham form proper: no
+// in-register staging, so the pass loop needs no compile-time bounds).  Not a tuned path (the benchmark resolutions are powers of two):
+// 16 threads per row, 16 / 8 / 4 rows per block (what fits 64 KB of LDS), one work item per block.
+struct FftMixed { int nf, radix[12]; };
+template <bool INV> __device__ __forceinline__ void dft3(double2 &a0, double2 &a1, double2 &a2) {
+  const double s3 = INV ? 0.86602540378443864676 : -0.86602540378443864676;     // sin(-+2 pi / 3)
+  const double2 t1 = cadd(a1, a2), t2 = make_double2(a0.x - 0.5 * t1.x, a0.y - 0.5 * t1.y);
+  const double2 d = csub(a1, a2), t3 = make_double2(-s3 * d.y, s3 * d.x);          // i s3 (a1 - a2)
+  a0 = cadd(a0, t1); a1 = cadd(t2, t3); a2 = csub(t2, t3);
+}
+template <bool INV> __device__ __forceinline__ void dft5(double2 (&v)[5]) {
+  const double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;         // cos(2 pi / 5), cos(4 pi / 5)
+  const double s1 = INV ? 0.95105651629515357212 : -0.95105651629515357212;       // sin(-+2 pi / 5)
+  const double s2 = INV ? 0.58778525229247312917 : -0.58778525229247312917;       // sin(-+4 pi / 5)
+  const double2 a = cadd(v[1], v[4]), b = cadd(v[2], v[3]), c = csub(v[1], v[4]), d = csub(v[2], v[3]);
+  const double2 x0 = v[0];
+  const double2 p1 = make_double2(x0.x + c1 * a.x + c2 * b.x, x0.y + c1 * a.y + c2 * b.y);
+  const double2 p2 = make_double2(x0.x + c2 * a.x + c1 * b.x, x0.y + c2 * a.y + c1 * b.y);
+  const double2 q1 = make_double2(-(s1 * c.y + s2 * d.y), s1 * c.x + s2 * d.x);    // i (s1 c + s2 d)
+  const double2 q2 = make_double2(-(s2 * c.y - s1 * d.y), s2 * c.x - s1 * d.x);    // i (s2 c - s1 d)
+  v[0] = cadd(x0, cadd(a, b));
+  v[1] = cadd(p1, q1); v[4] = csub(p1, q1);
+  v[2] = cadd(p2, q2); v[3] = csub(p2, q2);
+}
+// one pass of radix R at stride S: y[q + S (R p + j)] = w^(S j p) DFT_R(x[q + S (p + M j)])_j, M = NC / (R S), w = exp(-+2 pi i / NC); tw[k] = exp(-2 pi i k / (2 NC))
+template <bool INV, int R> __device__ __forceinline__ void mixed_pass(const double2 *x, double2 *y, const double2 *twl, int NC, int S, int tr) {
+  const int NB = NC / R, M = NB / S;
+  for (int b = tr; b < NB; b += 16) {
+    const int p = b / S, q = b - p * S;
+    double2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = x[q + S * (p + j * M)];
+    if constexpr (R == 3) dft3<INV>(v[0], v[1], v[2]);
+    else if constexpr (R == 5) dft5<INV>(v);
+    else dftR<INV, R>(v);
+    y[q + S * (R * p)] = v[0];
+#pragma unroll
+    for (int j = 1; j < R; ++j) {
+      double2 w = twl[2 * S * j * p];
+      if (INV) w.y = -w.y;
+      y[q + S * (R * p + j)] = cmul(v[j], w);
+    }
+  }
+}
+// all passes of a row; returns the buffer that holds the result
+template <bool INV> __device__ __forceinline__ double2 *mixed_row(double2 *x, double2 *y, const double2 *twl, int NC, const FftMixed &fm, int tr) {
+  int S = 1;
+  for (int f = 0; f < fm.nf; ++f) {
+    const int R = fm.radix[f];
+    if (R == 4) mixed_pass<INV, 4>(x, y, twl, NC, S, tr);
+    else if (R == 2) mixed_pass<INV, 2>(x, y, twl, NC, S, tr);
+    else if (R == 3) mixed_pass<INV, 3>(x, y, twl, NC, S, tr);
+    else mixed_pass<INV, 5>(x, y, twl, NC, S, tr);
+    S *= R;
+    __syncthreads();
+    double2 *t = x; x = y; y = t;
+  }
+  return x;
+}
+static int fft_mixed_rows(int NC) { return NC <= 112 ? 16 : (NC <= 224 ? 8 : 4); }
+__global__ __launch_bounds__(256) void k_fft_fwd_mixed(Geom g, FieldList fl, FftMixed fm, const double *__restrict__ cosm, const int *__restrict__ slot_of_m,
+                                                                const double2 *__restrict__ tw, double *__restrict__ Fg, int C, int GX, int R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NC = g.I / 2, NT = R * 16;
+  double2 *bufa = (double2 *)smem, *bufb = bufa + R * NC, *twl = bufb + R * NC;
+  const int t = threadIdx.x, r = t >> 4, tr = t & 15, rr = t % R;
+  for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
+  const double inv_n = 1.0 / (double)g.I;
+  const int item = blockIdx.x, gx = item % GX, jl = item / GX;
+  {
+    const int c = gx * R + r;
+    const double2 *src = (const double2 *)(fl.g[0] + (size_t)jl * g.I);
+    double scale = 0.0;                     // a padding row re-reads a valid row and gets scale 0
+    if (c < fl.ncol) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      src = (const double2 *)(fl.g[f] + ((size_t)(c - fl.off[f]) * g.Jl + jl) * g.I);
+      scale = (fl.op[f] == OP_COSM) ? cosm[jl] : 1.0;
+    }
+    for (int n = tr; n < NC; n += 16) { const double2 z = src[n]; bufa[r * NC + n] = make_double2(z.x * scale, z.y * scale); }
+  }
+  __syncthreads();
+  const double2 *res = mixed_row<false>(bufa + r * NC, bufb + r * NC, twl, NC, fm, tr) - r * NC;      // (the same buffer for every row: nf is uniform)
+  // X[k] = E[k] + W_I^k O[k];  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2 ; c(k) = X[k]/I   (thread = (row rr, wavenumber m): Fourier rows are column-contiguous)
+  const int cc = gx * R + rr;
+  for (int m = t / R; m < g.M1; m += 16) {
+    const double2 zk = res[rr * NC + m];
+    const double2 zc = cconj(res[rr * NC + (m == 0 ? 0 : NC - m)]);
+    const double2 e = cscale(0.5, cadd(zk, zc));
+    const double2 dd = csub(zk, zc);
+    const double2 o = make_double2(0.5 * dd.y, -0.5 * dd.x);
+    double2 X = cadd(e, cmul(twl[m], o));
+    X.x *= inv_n; X.y *= inv_n;
+    if (cc < fl.ncol) *(double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * cc) = X;
+  }
+}
+__global__ __launch_bounds__(256) void k_fft_inv_mixed(Geom g, FieldList fl, FftMixed fm, const double *__restrict__ cosm, const int *__restrict__ slot_of_m,
+                                                                const double2 *__restrict__ tw, const double *__restrict__ Fg, int C, int GX, int R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NC = g.I / 2, NT = R * 16;
+  double2 *bufa = (double2 *)smem, *bufb = bufa + R * NC, *twl = bufb + R * NC;
+  const int t = threadIdx.x, r = t >> 4, tr = t & 15, rr = t % R;
+  for (int k = t; k < 2 * NC; k += NT) twl[k] = tw[k];
+  const int item = blockIdx.x, gx = item % GX, jl = item / GX;
+  {  // truncated coefficients m = 0..M; transforms.F90:424 zeroes everything above the truncation
+    const int cc = gx * R + rr, ccl = min(cc, fl.ncol - 1);
+    for (int m = t / R; m < NC; m += 16) {
+      double2 x = make_double2(0., 0.);
+      if (m < g.M1 && cc < fl.ncol) x = *(const double2 *)(Fg + ((size_t)slot_of_m[m] * g.Jl + jl) * C + 2 * ccl);
+      if (m == 0) x.y = 0.0;          // the real inverse FFT never references the imaginary part of the mean
+      bufa[rr * NC + m] = x;
+    }
+  }
+  __syncthreads();
+  // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0
+  for (int k = tr; k < NC; k += 16) {
+    const double2 xk = bufa[r * NC + k];
+    const double2 xc = (k == 0) ? make_double2(0., 0.) : cconj(bufa[r * NC + NC - k]);
+    const double2 e = cadd(xk, xc);
+    const double2 o = cmul(cconj(twl[k]), csub(xk, xc));
+    bufb[r * NC + k] = make_double2(e.x - o.y, e.y + o.x);
+  }
+  __syncthreads();
+  const double2 *res = mixed_row<true>(bufb + r * NC, bufa + r * NC, twl, NC, fm, tr);
+  const int c = gx * R + r;
+  if (c < fl.ncol) {
+    int f = 0;
+    while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+    double2 *dst = (double2 *)(fl.g[f] + ((size_t)(c - fl.off[f]) * g.Jl + jl) * g.I);
+    const int op = fl.op[f];
+    const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
+    for (int n = tr; n < NC; n += 16) {
+      double2 z = res[n];
+      if (op == OP_EXP) { z.x = exp(z.x); z.y = exp(z.y); }
+      else { z.x *= scale; z.y *= scale; }
+      dst[n] = z;
+    }
+  }
+}
+// the factors of NC = lon_max / 2: fours first, then a two, then threes and fives (any order gives the transform; larger strides last keep the
+// early passes' accesses contiguous); false when a prime factor above 5 is left (set99 refuses those lengths too)
+bool fft_mixed_factors(int NC, FftMixed &fm) {
+  fm.nf = 0;
+  int n = NC;
+  while (n % 4 == 0) { fm.radix[fm.nf++] = 4; n /= 4; }
+  if (n % 2 == 0) { fm.radix[fm.nf++] = 2; n /= 2; }
+  while (n % 3 == 0) { fm.radix[fm.nf++] = 3; n /= 3; }
+  while (n % 5 == 0) { fm.radix[fm.nf++] = 5; n /= 5; }
+  return n == 1 && fm.nf <= 12;
+}
+static void launch_fft_mixed(bool inverse, const Geom &g, const Dev &d, const FieldList &fl, double *Fg, hipStream_t s) {
+  FftMixed fm;
+  const int NC = g.I / 2;
+  if ((g.I & 1) || !fft_mixed_factors(NC, fm)) throw std::runtime_error("fft: lon_max must be even with no prime factor above 5 (fft99.F90:83-120)");
+  const int R = fft_mixed_rows(NC);
+  const int C = col_pitch(fl.ncol), GX = (fl.ncol + R - 1) / R;
+  const size_t lds = (size_t)(2 * R * NC + 2 * NC) * sizeof(double2);
+  if (inverse) hipLaunchKernelGGL(k_fft_inv_mixed, dim3((unsigned)(GX * g.Jl)), dim3(R * 16), lds, s, g, fl, fm, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, (const double *)Fg, C, GX, R);
+  else hipLaunchKernelGGL(k_fft_fwd_mixed, dim3((unsigned)(GX * g.Jl)), dim3(R * 16), lds, s, g, fl, fm, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX, R);
+}
+
 static int fft_rows(int NC) { return NC >= 256 ? 8 : 16; }
 static unsigned fft_grid(int items) {                  // persistent blocks: at most 3 per CU of the 256 (LDS-limited residency; measured
   const int cap = 768;                                 // against 512 / 1024 / 1536), and the same number of items for every block
@@ -721,7 +884,7 @@ void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double
     case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
     case 128: if (fft_old()) LF(128); else if (fft_twreg()) LF3(128, true); else LF3(128, false); break;
     case 256: if (fft_old()) LF(256); else if (fft_twreg()) LF3(256, true); else LF3(256, false); break;
-    default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
+    default: launch_fft_mixed(false, g, d, fl, Fg, s);
   }
 #undef LF
 #undef LF3
@@ -738,7 +901,7 @@ void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const 
     case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
     case 128: if (fft_old()) LI(128); else if (fft_twreg()) LI3(128, true); else LI3(128, false); break;
     case 256: if (fft_old()) LI(256); else if (fft_twreg()) LI3(256, true); else LI3(256, false); break;
-    default: throw std::runtime_error("fft: lon_max must be a power of two between 16 and 512");
+    default: launch_fft_mixed(true, g, d, fl, const_cast<double *>(Fg), s);
   }
 #undef LI
 #undef LI3
@@ -940,7 +1103,8 @@ __device__ __forceinline__ double wave_last(double v) {   // value held by lane 
 // S2: one wavefront per retained (m,n), lane = level.  implicit_correction (implicit.F90:241-325) with
 // the L x L wave matrix applied by lane-broadcast mat-vec, spectral damping (spectral_damping.F90:172-291),
 // leapfrog_2level_A + the Robert filter completion leapfrog_2level_B (leapfrog.F90:58-105) for
-// raw_filter_coeff = 1.  impl_vec rows: 0 dlog_1, 1 dlog_3, 2 dp_ref, 3 h, 4 dlogf = lph(k+1)-lpf(k)
+// raw_filter_coeff = 1.  impl_vec rows: 0, 1 the weights of linear_tp_tendency (dlog_1, dlog_3; other values for vert_difference_option = 'mcm'),
+// 2 dp_ref, 3 h, 4 dlogf = lph(k+1)-lpf(k), 5 dlog_3 (linear_geopotential)
 // -----------------------------------------------------------------------------------------------------
 struct SpecUpdateArgs {
   double2 *vors_p, *vors_c, *vors_f, *divs_p, *divs_c, *divs_f, *ts_p, *ts_c, *ts_f, *lnps_p, *lnps_c, *lnps_f;
@@ -1000,7 +1164,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
   const int kk = (lane < L) ? lane : 0;
   const size_t idx = (size_t)mn * L + kk;
   const double dlog1 = a.impl_vec[0 * 64 + kk], dlog3 = a.impl_vec[1 * 64 + kk], dp = a.impl_vec[2 * 64 + kk];
-  const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk];
+  const double hk = a.impl_vec[3 * 64 + kk], dlogf = a.impl_vec[4 * 64 + kk], dlog3g = a.impl_vec[5 * 64 + kk];
   const double eig = COEF(C_EIG, ml, n), dmp = COEF(C_DAMP, ml, n);   // read before the first store (scalar path)
   const double dmp_v = COEF(C_DAMP_VOR, ml, n), dmp_d = COEF(C_DAMP_DIV, ml, n);
   const int mglob = ent.z;
@@ -1063,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_spec_update(Geom g, SpecUpdateArgs a) {
     const double2 ts_temp = cadd(csub(tprev, tcur), cscale(a.xi, dt_t));
     const double2 ps_temp = cadd(csub(lprev, lcur), cscale(a.xi, dt_lp));
     {  // linear_geopotential (:329-359) with del_ln_p = 0: suffix sums of RDGAS*T'*dlog3 below the level
-      const double2 av = sel2(act && lane >= 1, cscale(RDGAS * dlog3, ts_temp));
+      const double2 av = sel2(act && lane >= 1, cscale(RDGAS * dlog3g, ts_temp));
       double2 inc;
       inc.x = wave_incl_scan(av.x, lane);
       inc.y = wave_incl_scan(av.y, lane);
@@ -1315,7 +1479,9 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // The two vertical scans (mass-divergence prefix, hydrostatic suffix) are chunk sums exchanged through LDS,
 // everything else is local to a thread's <= CH levels, so all loads of a thread are independent and in flight
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
-template <int CH, bool EXT, bool VIRT>
+// MCM: vert_difference_option = 'mcm' (press_and_geopot.F90:196-210, spectral_dynamics.F90:1084-1099): p_full = the mean of the two half levels,
+// the pressure-gradient term with grad(p_s)/p_s, the conversion term with (sum above + half the layer's own)/p_full.
+template <int CH, bool EXT, bool VIRT, bool MCM = false>
 __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
@@ -1372,6 +1538,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   }
   // ln p at my half levels k0..k0+nk and full levels (press_and_geopot.F90:165-194)
   double lph[CH + 1], lpf[CH];
+  double pfm[MCM ? CH : 1];                 // 'mcm': p_full itself (the reference forms it first and takes its logarithm)
   {
     const double ph0 = pk_r[0] + bk_r[0] * ps;
     lph[0] = (top0 && k0 == 0) ? 0.0 : log(ph0);
@@ -1382,7 +1549,8 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double ph_n = pk_r[i + 1] + bk_r[i + 1] * ps;      // (levels past the chunk end are computed but never used)
       const double l_n = log(ph_n);
       lph[i + 1] = l_n;
-      if (top0 && k == 0) lpf[i] = l_n - 1.0;
+      if (MCM) { const double pm = 0.5 * (ph_n + ph_k); pfm[MCM ? i : 0] = pm; lpf[i] = log(pm); }
+      else if (top0 && k == 0) lpf[i] = l_n - 1.0;
       else lpf[i] = l_n - (1.0 - ph_k * (l_n - lph[i]) / (ph_n - ph_k));
       ph_k = ph_n;
     }
@@ -1423,7 +1591,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double l_h0 = lph[i], l_h1 = lph[i + 1], l_f = lpf[i];
       const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q] + tc_p;
       const double voi = EARLY ? vov[EARLY ? i : 0] : a.vor[q], dxti = EARLY ? dxv[EARLY ? i : 0] : a.dxT[q], dyti = EARLY ? dyv[EARLY ? i : 0] : a.dyT[q];
-      const double p_full = exp(l_f);
+      const double p_full = MCM ? pfm[MCM ? i : 0] : exp(l_f);
       double dt_u, dt_v, dt_t;
       if (EXT) {   // physics tendencies computed beforehand (idealized_moist_phys, atmosphere.F90:304-317)
         dt_u = a.phu[q]; dt_v = a.phv[q]; dt_t = a.pht[q];
@@ -1450,11 +1618,11 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
       const double dp = dpk_r[i] + dbk_r[i] * ps, dp_inv = 1 / dp;
       const double dlog_1 = l_h1 - l_f, dlog_2 = l_f - l_h0, dlog_3 = l_h1 - l_h0;
       const double x1 = (bk_r[i + 1] * dlog_1 + bk_r[i] * dlog_2) * dp_inv;
-      const double x2 = x1 * dx_ps, x3 = x1 * dy_ps;
+      const double x2 = MCM ? dx_ps * rps : x1 * dx_ps, x3 = MCM ? dy_ps * rps : x1 * dy_ps;
       const double uc = u[i], vc = v[i], tc = t[i], tvc = TV(i);
       dt_u = dt_u - RDGAS * tvc * x2;
       dt_v = dt_v - RDGAS * tvc * x3;
-      const double x4 = (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
+      const double x4 = MCM ? (dmean_tot + 0.5 * dm[i]) / p_full : (dmean_tot * dlog_3 + dm[i] * dlog_1) * dp_inv;
       const double x5 = x4 - uc * x2 - vc * x3;
       dt_t = dt_t - KAPPA * tvc * x5;
       if (a.store_wg_full) a.wg_full[q] = -x5 * p_full;
@@ -1567,7 +1735,11 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.tv = virtual_t_on(h) ? d.tv : nullptr;
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
 #define LC(N) do { \
-    if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
+    if (h.cfg.vert_difference_option == 1) { \
+      if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true, true>), grid, block, lds, s, g, a); } \
+      else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false, true>), grid, block, lds, s, g, a); \
+      else hipLaunchKernelGGL((k_column<N, false, false, true>), grid, block, lds, s, g, a); } \
+    else if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
     else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
     else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
   switch (CH) {
@@ -1741,7 +1913,7 @@ void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const
 // compute_pressures_and_heights (press_and_geopot.F90:363-387)
 __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const double *__restrict__ bk,
                                     const double *__restrict__ t, const double *__restrict__ psg, const double *__restrict__ surf_geop,
-                                    double *p_full, double *p_half, double *z_full, double *z_half) {
+                                    double *p_full, double *p_half, double *z_full, double *z_half, bool mcm) {
   const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t lev = (size_t)g.Jl * g.I;
   if (c2 >= lev) return;
@@ -1758,7 +1930,7 @@ __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const
     double lf;
     if (top0 && k == 0) lf = l_n - 1.0;
     else lf = l_n - (1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k));
-    p_full[c2 + k * lev] = exp(lf);
+    p_full[c2 + k * lev] = mcm ? 0.5 * (ph_n + ph_k) : exp(lf);
     ph_k = ph_n;
   }
   double gh = surf_geop[c2];
@@ -1768,7 +1940,8 @@ __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const
     const double ph0 = pk[k] + bk[k] * ps, ph1 = pk[k + 1] + bk[k + 1] * ps;
     const double l0 = (top0 && k == 0) ? 0.0 : log(ph0), l1 = log(ph1);
     double lf;
-    if (top0 && k == 0) lf = l1 - 1.0;
+    if (mcm) lf = log(0.5 * (ph1 + ph0));
+    else if (top0 && k == 0) lf = l1 - 1.0;
     else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
     const double tk = t[c2 + k * lev];
     z_full[c2 + k * lev] = (gh + RDGAS * tk * (l1 - lf)) / GRAV;
@@ -1778,13 +1951,13 @@ __global__ void k_pressures_heights(Geom g, const double *__restrict__ pk, const
 }
 void launch_pressures_heights(const isca_dyn &h, const double *t, const double *ps, double *p_full, double *p_half,
                               double *z_full, double *z_half, hipStream_t s) {
-  hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, h.d.surf_geop, p_full, p_half, z_full, z_half);
+  hipLaunchKernelGGL(k_pressures_heights, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, t, ps, h.d.surf_geop, p_full, p_half, z_full, z_half, h.cfg.vert_difference_option == 1);
 }
 
 // pressure_variables (press_and_geopot.F90:152-221, simmons_and_burridge): p_half, ln_p_half, p_full, ln_p_full
 __global__ void k_pressure_variables(Geom g, const double *__restrict__ pk, const double *__restrict__ bk,
                                      const double *__restrict__ psg, double *p_half, double *ln_p_half, double *p_full,
-                                     double *ln_p_full) {
+                                     double *ln_p_full, bool mcm) {
   const size_t c2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t lev = (size_t)g.Jl * g.I;
   if (c2 >= lev) return;
@@ -1795,8 +1968,11 @@ __global__ void k_pressure_variables(Geom g, const double *__restrict__ pk, cons
   for (int k = 0; k < g.L; ++k) {
     const double ph_n = pk[k + 1] + bk[k + 1] * ps, l_n = log(ph_n);
     p_half[c2 + (k + 1) * lev] = ph_n; ln_p_half[c2 + (k + 1) * lev] = l_n;
+    if (mcm) { const double pm = 0.5 * (ph_n + ph_k); p_full[c2 + k * lev] = pm; ln_p_full[c2 + k * lev] = log(pm); }       // press_and_geopot.F90:196-200
+    else {
     const double lf = (top0 && k == 0) ? l_n - 1.0 : l_n - (1.0 - ph_k * (l_n - l_k) / (ph_n - ph_k));
     ln_p_full[c2 + k * lev] = lf; p_full[c2 + k * lev] = exp(lf);
+    }
     ph_k = ph_n; l_k = l_n;
   }
 }
@@ -1818,7 +1994,7 @@ __global__ void k_geopotential(Geom g, const double *__restrict__ pk, const doub
   }
 }
 void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full, hipStream_t s) {
-  hipLaunchKernelGGL(k_pressure_variables, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, ps, p_half, ln_p_half, p_full, ln_p_full);
+  hipLaunchKernelGGL(k_pressure_variables, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, ps, p_half, ln_p_half, p_full, ln_p_full, h.cfg.vert_difference_option == 1);
 }
 void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s) {
   hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.surf_geop, t, ln_p_half, ln_p_full, gf, gh);
@@ -1942,18 +2118,24 @@ constexpr int TR_LDS_ROWS = TR_RB + 4 + 2;
 // 135 registers it finds no SIMD with room beside the main stream's Legendre blocks (2 x 128 registers per SIMD); held to 128 (WPE = 4, 7
 // spilled dwords) the kernel runs beside them -- T170L60 step 1.155 -> 1.113 ms on the same box; at lon_max <= 256 (1 wavefront per
 // SIMD and block) the unconstrained allocation is the faster one (0.277 vs 0.281 ms at T85L40).  WPE = 5 (96 registers) spills 39 dwords: slower.
-template <int WPE>
+// P2: lon_max is a power of two (longitudes wrap with a mask); otherwise (lon_max = 2^a 3^b 5^c, the mixed-radix FFT's lengths) with a remainder.
+template <bool P2> __device__ __forceinline__ int wrap_lon(int x, int I) {
+  if (P2) return x & (I - 1);
+  const int w = x % I;
+  return w < 0 ? w + I : w;
+}
+template <int WPE, bool P2 = true>
 __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TR_RB, NR = RB + 4;
-  const int I = g.I, J = g.J, IM = I - 1;
+  const int I = g.I, J = g.J;
   double *qs = (double *)smem;        // [NR][I] q0 of virtual rows j0-2..j0+RB+1 (rows across a pole already rotated by I/2)
   double *q2 = qs + NR * I;           // [I]
   double *sx = q2 + I;                // [I]
   __shared__ int any_big[RB];
   __shared__ double edge_first[2 * RB][8], edge_last[RB][8];      // lane 0 / lane 63 values of every wavefront: u of the RB rows; the x flux
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
-  const int last = min(63, I - 1);                                  // a row shorter than a wavefront (lon_max = 32): its last lane
+  const int last = min(63, I - 1 - 64 * (int)(threadIdx.x >> 6));   // the wavefront's last lane (a row, or its tail, shorter than a wavefront: lon_max = 32, 96, 160)
   const int wl = (wv + nwv - 1) % nwv, wr = (wv + 1) % nwv;        // wavefronts holding longitudes i - 1 of my lane 0 / i + 1 of my last lane
   // Workgroups go round-robin over the 8 XCDs; neighbouring row blocks share 4 of their 8 source rows, so the tile index is
   // permuted to give each XCD (= each L2) a contiguous run of row blocks (whole levels) instead of every eighth one.
@@ -1981,7 +2163,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     const int jv = j0 + r - 2;
     mir[r] = jv < 0 || jv >= J;
     jsrc[r] = jv < 0 ? -jv - 1 : (jv >= J ? 2 * J - 1 - jv : jv);
-    const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
+    const int is = mir[r] ? wrap_lon<P2>(i + (I >> 1), I) : i;
     const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
     loc[r] = jl >= 0 && jl < g.Jl;
     const size_t c2r = (size_t)(loc[r] ? jl : 0) * I + is;
@@ -1995,7 +2177,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
   double psr[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {                                                // surface flux only enters the lowest level
-    const int is = mir[r] ? ((i + (I >> 1)) & IM) : i;
+    const int is = mir[r] ? wrap_lon<P2>(i + (I >> 1), I) : i;
     psr[r] = (k == g.L - 1 && loc[r]) ? mul_nc(a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + is], a.pend_c[PEND_FACTOR]) : 1.0;
   }
   double q0r[NR], vr[NR];                                                       // own-longitude values stay in registers
@@ -2018,11 +2200,11 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
   for (int r = 0; r < NR; ++r) {      // semi_x (:376-411) on each source row
     const double b = tu[r] * hdt * a.rcdx[jsrc[r]];
     const double fb = floor(b);
-    const int il = (i - 1 - (int)fb) & IM, ir = (il + 1) & IM;
+    const int il = wrap_lon<P2>(i - 1 - (int)fb, I), ir = wrap_lon<P2>(il + 1, I);
     const double bb = b - fb, qc = q0r[r];
     q1r[r] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
   }
-  const int im = (i - 1) & IM, ip = (i + 1) & IM;
+  const int im = wrap_lon<P2>(i - 1, I), ip = wrap_lon<P2>(i + 1, I);
   double bx[RB], ucl[RB], ucr[RB];
 #pragma unroll
   for (int rr = 0; rr < RB; ++rr) {   // u at the cell faces, Courant numbers of the x fluxes, block-wide flag for the integer part
@@ -2056,13 +2238,13 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     double fxi = 0.0;
     if (any_big[rr]) {               // integer_flux_x (:494-527), modular form
       const int n_ = (int)fmin(fmax(b, -(double)I), (double)I);      // (a Courant number beyond one turn of the circle is a blown-up state: bounded walk)
-      if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fxi += q2[(i - t) & IM]; }
-      else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fxi -= q2[(i + t) & IM]; }
+      if (n_ >= 1) { for (int t = 1; t <= n_; ++t) fxi += q2[wrap_lon<P2>(i - t, I)]; }
+      else if (n_ <= -1) { for (int t = 0; t < -n_; ++t) fxi -= q2[wrap_lon<P2>(i + t, I)]; }
     }
     __syncthreads();
     {
       const double bb = b - trunc(b);
-      const int ii = (i - 1 - (int)floor(b)) & IM;
+      const int ii = wrap_lon<P2>(i - 1 - (int)floor(b), I);
       const double fl_i = fxi + bb * (q2[ii] + 0.5 * sx[ii] * (copysign(1.0, bb) - bb));
       double fl_r = dpp_from_right(fl_i);                 // the flux through the face at i + 1
       if (lane == 0) edge_first[RB + rr][wv] = fl_i;
@@ -2382,7 +2564,10 @@ void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream
 }
 static void launch_tracer_horiz_kernel(const Geom &g, const TracerArgs &a, size_t ldsh, hipStream_t s) {
   const dim3 grid((g.Jl + TR_RB - 1) / TR_RB, g.L), block(g.I);
-  if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);
+  if (g.I & (g.I - 1)) {        // lon_max with factors 3, 5: longitudes wrap with a remainder
+    if (g.I > 256) hipLaunchKernelGGL((k_tracer_horiz<4, false>), grid, block, ldsh, s, g, a);
+    else hipLaunchKernelGGL((k_tracer_horiz<1, false>), grid, block, ldsh, s, g, a);
+  } else if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);
   else hipLaunchKernelGGL(k_tracer_horiz<1>, grid, block, ldsh, s, g, a);
 }
 static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStream_t s) {
@@ -2450,6 +2635,52 @@ __global__ void k_vert_advection_centered(Geom g, const double *__restrict__ w, 
 void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s) {
   const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
   hipLaunchKernelGGL(k_vert_advection_centered, grid1d(n), dim3(256), 0, s, h.g, w, ps, h.d.dpk, h.d.dbk, r, rdt);
+}
+// water_borrowing (atmos_spectral/model/water_borrowing.F90:38-136; hole_filling = 'on' of a 'spectral' tracer, spectral_dynamics.F90:1142-1144): a
+// negative value q(i,k) of the PREVIOUS level is filled from its neighbours on the latitude circle (i-1, i+1, wrapping) and in the column (k-1, k+1)
+// when together they hold enough (total = sum_nb q dp + q dp > 0): its tendency gets -q/dt, each neighbour's (ratio - 1) q_nb/dt, ratio = total /
+// neighbouring water.  The reference sweeps the circle (alternating direction) and scatters; q is only read, so every hole's contribution is
+// independent and the sweep fixes nothing but the order of the additions: here every cell GATHERS -- its own hole and the holes among its four
+// neighbours, each evaluated from the hole's own five-point stencil.  dp = dpk + dbk p_s of the current level (update_tracers' p_half).
+__device__ __forceinline__ double wb_ratio_m1(const Geom &g, const double *__restrict__ q, const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                              const double *__restrict__ psrow, size_t row, size_t lev, int i, int k) {
+  // (ratio - 1) of the hole at (i, k) of latitude row `row` (offset of its first longitude in a level), or 0 when it is no hole / cannot be filled
+  const int I = g.I, im = (i == 0) ? I - 1 : i - 1, ip = (i == I - 1) ? 0 : i + 1;
+  const size_t o = (size_t)k * lev + row;
+  const double qc = q[o + i];
+  if (!(qc < 0.)) return 0.0;
+  double nb = q[o + im] * (dpk[k] + dbk[k] * psrow[im]);
+  nb = nb + q[o + ip] * (dpk[k] + dbk[k] * psrow[ip]);
+  if (k != 0) nb = nb + q[o - lev + i] * (dpk[k - 1] + dbk[k - 1] * psrow[i]);
+  if (k != g.L - 1) nb = nb + q[o + lev + i] * (dpk[k + 1] + dbk[k + 1] * psrow[i]);
+  const double total = nb + qc * (dpk[k] + dbk[k] * psrow[i]);
+  return (total > 0.) ? total / nb - 1.0 : 0.0;
+}
+__global__ void k_water_borrowing(Geom g, const double *__restrict__ dpk, const double *__restrict__ dbk, const double *__restrict__ ps,
+                                  const double *__restrict__ q, double *__restrict__ dt_q, double delta_t) {
+  const size_t lev = (size_t)g.Jl * g.I, n = lev * g.L;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int k = (int)(idx / lev);
+  const size_t c2 = idx - (size_t)k * lev;
+  const int I = g.I, jl = (int)(c2 / I), i = (int)(c2 - (size_t)jl * I);
+  const size_t row = (size_t)jl * I;
+  const double *psrow = ps + row;
+  const int im = (i == 0) ? I - 1 : i - 1, ip = (i == I - 1) ? 0 : i + 1;
+  const double qc = q[idx];
+  double t = dt_q[idx];
+  // the reference's order of events for one cell does not exist (they interleave with the sweep); this one is fixed: own hole, west, east, above, below
+  // (a hole that can be filled has 0 < total < neighbouring water: ratio - 1 /= 0)
+  if (wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k) != 0.0) t = t - qc / delta_t;
+  t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, im, k) * qc / delta_t;
+  t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, ip, k) * qc / delta_t;
+  if (k != 0) t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k - 1) * qc / delta_t;
+  if (k != g.L - 1) t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k + 1) * qc / delta_t;
+  dt_q[idx] = t;
+}
+void launch_water_borrowing(const isca_dyn &h, const double *ps, const double *q_prev, double *dt_q, double delta_t, hipStream_t s) {
+  const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
+  hipLaunchKernelGGL(k_water_borrowing, grid1d(n), dim3(256), 0, s, h.g, h.d.dpk, h.d.dbk, ps, q_prev, dt_q, delta_t);
 }
 // leapfrog_2level_A / _B (leapfrog.F90:58-105) on caller arrays (the C-ABI entry points behind leapfrog_mod): every value is read before
 // anything is written, so `fut` may be the storage of `prev` (two time levels) or of `cur` (the first step)

@@ -267,7 +267,7 @@ MoistState *moist_create(const isca_dyn_config &cfg, const Tables &tab) {
   // damping_driver_init (damping_driver.f90:411-420) with the reference pressures of idealized_moist_phys_init (:620-629)
   const int L = cfg.num_levels;
   std::vector<double> lph, lpf;
-  pressure_variables_1d(tab.pk, tab.bk, moist::PSTD_MKS, lph, lpf);
+  pressure_variables_1d(tab.pk, tab.bk, moist::PSTD_MKS, lph, lpf, cfg.vert_difference_option == 1);
   int best = 0;
   double bestv = INFINITY;
   for (int k = 0; k <= L; ++k) {
@@ -339,6 +339,7 @@ struct PressArgs {
   double *p_full[2], *p_half[2], *z_full, *z_half;
   int ncol, L, store_half;
   int tl0;                 // first time level of the launch (1: the previous level's pressures are cached)
+  int mcm;                 // vert_difference_option = 'mcm': p_full = the mean of the half levels (press_and_geopot.F90:196-200)
 };
 // Above 41 levels (the moist kernel's third work array in a global buffer, 131 072 columns at T170L60: the kernel is throughput-bound and every
 // pass over a level array is 15 us of HBM time) the half-level pressures are not stored: k_moist_physics forms pk + bk ps where it needs them
@@ -372,9 +373,10 @@ __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
     if (k < L) {
       const double ph1 = pk[k + 1] + bk[k + 1] * ps, l1 = log(ph1);
       double lf;
-      if (top0 && k == 0) lf = l1 - 1.0;
+      if (a.mcm) lf = log(0.5 * (ph1 + ph0));
+      else if (top0 && k == 0) lf = l1 - 1.0;
       else lf = l1 - (1.0 - ph0 * (l1 - l0) / (ph1 - ph0));
-      a.p_full[tl][c + (size_t)k * s] = exp(lf);
+      a.p_full[tl][c + (size_t)k * s] = a.mcm ? 0.5 * (ph1 + ph0) : exp(lf);
       if (a.store_half) {
         a.p_half[tl][c + (size_t)k * s] = ph0;
         if (k == L - 1) a.p_half[tl][c + (size_t)L * s] = ph1;
@@ -414,6 +416,7 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
   a.store_half = moist_sigma_half(h.g.L) ? 0 : 1;
   a.tl0 = prev_cached ? 1 : 0;
+  a.mcm = h.cfg.vert_difference_option == 1;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, prev_cached ? 1 : 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
 void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int slot_prev, int slot_cur) {

@@ -98,14 +98,20 @@ bool invert_matrix(std::vector<double> &a, int n) {
 }
 
 
-// model/press_and_geopot.F90:152-221 for a single column (simmons_and_burridge)
+// model/press_and_geopot.F90:152-221 for a single column (simmons_and_burridge; 'mcm': :196-210)
 void pressure_variables_1d(const std::vector<double> &pk, const std::vector<double> &bk, double ps,
-                           std::vector<double> &ln_p_half, std::vector<double> &ln_p_full) {
+                           std::vector<double> &ln_p_half, std::vector<double> &ln_p_full, bool mcm) {
   const int L = (int)pk.size() - 1;
   std::vector<double> p_half(L + 1);
   ln_p_half.assign(L + 1, 0.0);
   ln_p_full.assign(L, 0.0);
   for (int k = 0; k <= L; ++k) p_half[k] = pk[k] + bk[k] * ps;
+  if (mcm) {
+    for (int k = 0; k < L; ++k) ln_p_full[k] = std::log(0.5 * (p_half[k + 1] + p_half[k]));
+    const bool top0 = pk[0] == 0.0 && bk[0] == 0.0;
+    for (int k = top0 ? 1 : 0; k <= L; ++k) ln_p_half[k] = std::log(p_half[k]);
+    return;
+  }
   if (pk[0] == 0.0 && bk[0] == 0.0) {
     for (int k = 1; k <= L; ++k) ln_p_half[k] = std::log(p_half[k]);
     for (int k = 1; k < L; ++k) {
@@ -226,13 +232,14 @@ void Tables::build(const isca_dyn_config &c) {
   // --- implicit_init + build_matrix: model/implicit.F90:79-217 (ref T = 300 K: spectral_dynamics.F90:473)
   ref_t = 300.0;
   ref_surf_p = c.reference_sea_level_press;
-  pressure_variables_1d(pk, bk, ref_surf_p, ref_ln_p_half, ref_ln_p_full);
+  const bool mcm = c.vert_difference_option == 1;
+  pressure_variables_1d(pk, bk, ref_surf_p, ref_ln_p_half, ref_ln_p_full, mcm);
   std::vector<double> del_ln_p_half(L + 1), del_ln_p_full(L), l1h, l1, l2h, l2;
   for (int k = 1; k <= L; ++k) del_ln_p_half[k] = bk[k] / (pk[k] + bk[k] * ref_surf_p);
   del_ln_p_half[0] = (pk[0] == 0.0) ? 1.0 / ref_surf_p : bk[0] / (pk[0] + bk[0] * ref_surf_p);
   const double epsv = 1.e-5;
-  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 - 0.5 * epsv), l1h, l1);
-  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 + 0.5 * epsv), l2h, l2);
+  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 - 0.5 * epsv), l1h, l1, mcm);
+  pressure_variables_1d(pk, bk, ref_surf_p * (1.0 + 0.5 * epsv), l2h, l2, mcm);
   for (int k = 0; k < L; ++k) del_ln_p_full[k] = (l2[k] - l1[k]) / (epsv * ref_surf_p);
   // linear_tp_tendency_1d (implicit.F90:414-480) and linear_geopotential_1d (:329-359) on unit vectors
   auto tp_tend = [&](const std::vector<double> &div, double &dt_p, std::vector<double> &dt_t) {
@@ -244,6 +251,10 @@ void Tables::build(const isca_dyn_config &c) {
       const double dlog_1 = ref_ln_p_half[k + 1] - ref_ln_p_full[k];
       const double dlog_3 = ref_ln_p_half[k + 1] - ref_ln_p_half[k];
       const double dmean = div[k] * dp;
+      if (mcm) {       // implicit.F90:447-456
+        const double p_full_ref = 0.5 * (pk[k + 1] + pk[k]) + 0.5 * (bk[k + 1] + bk[k]) * ref_surf_p;
+        dt_t[k] = -(KAPPA * ref_t / p_full_ref) * (dmean_tot + 0.5 * dmean);
+      } else
       dt_t[k] = -KAPPA * ref_t * (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv;
       dmean_tot = dmean_tot + dmean;
       vv[k + 1] = -dmean_tot;
@@ -281,7 +292,8 @@ void Tables::build(const isca_dyn_config &c) {
   for (int k = 0; k < L; ++k) {   // pres_grad_funct :389-411
     const double dlog_1 = ref_ln_p_half[k + 1] - ref_ln_p_full[k];
     const double dlog_2 = ref_ln_p_full[k] - ref_ln_p_half[k];
-    const double h1 = RDGAS * ref_t * (bk[k + 1] * dlog_1 + bk[k] * dlog_2) / (dpk[k] + dbk[k] * ref_surf_p);
+    const double h1 = mcm ? RDGAS * ref_t / ref_surf_p        // pres_grad_funct, 'mcm' (:404-408)
+                          : RDGAS * ref_t * (bk[k + 1] * dlog_1 + bk[k] * dlog_2) / (dpk[k] + dbk[k] * ref_surf_p);
     h_impl[k] = h1 + h2[k];
   }
   div_mat.assign((size_t)L * L, 0.0);

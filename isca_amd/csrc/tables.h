@@ -54,7 +54,7 @@ struct Tables {
 
 // pressure_variables for one column (press_and_geopot.F90:152-221): ln p at half and full levels
 void pressure_variables_1d(const std::vector<double> &pk, const std::vector<double> &bk, double ps, std::vector<double> &ln_p_half,
-                           std::vector<double> &ln_p_full);
+                           std::vector<double> &ln_p_full, bool mcm = false);
 void compute_gaussian(int n_hem, std::vector<double> &sin_hem, std::vector<double> &wts_hem);
 void compute_legendre(int num_fourier, int num_spherical, const std::vector<double> &sin_hem, std::vector<double> &leg, int fourier_inc = 1);
 bool invert_matrix(std::vector<double> &a, int n);   // Gauss-Jordan with pivoting; returns false if singular

@@ -65,6 +65,7 @@ class _CConfig(C.Structure):
         ("tracer_spectral", C.c_int * MAX_TRACERS), ("tracer_robert_coeff", C.c_double * MAX_TRACERS),
         ("use_virtual_temperature", C.c_int),
         ("vert_advect_uv", C.c_int), ("vert_advect_t", C.c_int), ("use_implicit", C.c_int), ("make_symmetric", C.c_int),
+        ("vert_difference_option", C.c_int), ("tracer_hole_filling", C.c_int * MAX_TRACERS),
     ]
 
 
@@ -190,6 +191,11 @@ RESOLUTIONS = {
     "T42": dict(lon_max=128, lat_max=64, num_fourier=42, num_spherical=43),
     "T85": dict(lon_max=256, lat_max=128, num_fourier=85, num_spherical=86),
     "T170": dict(lon_max=512, lat_max=256, num_fourier=170, num_spherical=171),
+    # lon_max with factors 3 and 5 (fft99 takes n/2 = 2^a 3^b 5^c; the mixed-radix FFT kernels)
+    "T31": dict(lon_max=96, lat_max=48, num_fourier=31, num_spherical=32),
+    "T53": dict(lon_max=160, lat_max=80, num_fourier=53, num_spherical=54),
+    "T63": dict(lon_max=192, lat_max=96, num_fourier=63, num_spherical=64),
+    "T127": dict(lon_max=384, lat_max=192, num_fourier=127, num_spherical=128),
     # small test resolutions (not in the reference's table)
     "T10": dict(lon_max=32, lat_max=16, num_fourier=10, num_spherical=11),
     "S10": dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=21, fourier_inc=2),         # zonal wavenumbers 0, 2, .., 20 on a 180-degree sector
@@ -213,7 +219,7 @@ def default_config(resolution: str | None = None, **overrides) -> _CConfig:
             for i, x in enumerate(v):
                 arr[i] = float(x)
             c.vert_coord_input = 1
-        elif k in ("tracer_spectral", "tracer_robert_coeff"):   # field_table entries, [k] = tracer k+1
+        elif k in ("tracer_spectral", "tracer_robert_coeff", "tracer_hole_filling"):   # field_table entries, [k] = tracer k+1
             if len(v) > MAX_TRACERS:
                 raise IscaError(f"{k}: more than {MAX_TRACERS} tracers")
             arr = getattr(c, k)

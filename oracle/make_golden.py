@@ -40,7 +40,11 @@ FIELD_TABLE_3 = FIELD_TABLE + '''"TRACER", "atmos_mod", "age_grid"
           "profile_type", "fixed",   "surface_value=0.0" /
 '''
 
+# the same three tracers with hole_filling = on for the spectral one: water_borrowing (atmos_spectral/model/water_borrowing.F90) on its tendency
+FIELD_TABLE_3_HOLES = FIELD_TABLE_3.replace('"numerical_representation", "spectral"', '"numerical_representation", "spectral"\n          "hole_filling", "on"')
+
 RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
+       "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54),        # lon_max = 2^5 3 and 2^5 5: the radix-3 and radix-5 passes of fft99 (fft99.F90:876-1228)
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
 
@@ -537,6 +541,9 @@ def main():
         "run_T21L8_damping_exponential": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'exponential_cutoff', cutoff_wn = 10, damping_order = 3, damping_coeff = 2.3e-4, "
             "damping_coeff_vor = 1.2e-4, damping_coeff_div = 4.6e-4", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
+        "run_T21L8_hole_filling": lambda: golden_run(
+            "T21", 8, 60, (1, 2, 3, 40, 60), field_table=FIELD_TABLE_3_HOLES,
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr1|tr2|tr3)_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),
@@ -568,6 +575,20 @@ def main():
         "run_T21L8_symmetric": lambda: golden_run(
             "T21", 8, 48, (1, 48), extra="make_symmetric = .true.",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|48)$", k) is not None),
+        # vert_difference_option = 'mcm' (spectral_dynamics.F90:1084, press_and_geopot.F90:196, 242, implicit.F90:404, 447): mid-point full-level pressures,
+        # the old model's four_in_one and linear operator; on the test case's sigma levels and on the 'mcm' vertical coordinate (vert_coordinate.F90:148)
+        "run_T21L8_mcm": lambda: golden_run(
+            "T21", 8, 48, (1, 2, 48), extra="vert_difference_option = 'mcm'",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_0000(01|02|48)$", k) is not None),
+        "run_T21L14_mcm_coord": lambda: golden_run(
+            "T21", 14, 36, (1, 36), extra="vert_difference_option = 'mcm', vert_coord_option = 'mcm'",
+            keep=lambda k: k in ("tab_pk", "tab_bk") or re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_0000(01|36)$", k) is not None),
+        # lon_max with factors 3 and 5 (fft99's set99 takes n/2 = 2^a 3^b 5^c): every public routine at T31 (96 x 48), runs at T31 and T53 (160 x 80)
+        "kernels_T31L4": lambda: golden_kernels("T31", 4, 20260929),
+        "run_T31L8": lambda: golden_run(
+            "T31", 8, 36, (1, 2, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
+        "run_T53L8": lambda: golden_run(
+            "T53", 8, 36, (1, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|36)$", k) is not None),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -155,12 +155,13 @@ def test_atmosphere_mod_queues_steps(tmp_path):
      "vert_coord_option = 'hybrid', p_press = 0.15, p_sigma = 0.45, scale_heights = 5.0, exponent = 3.0, surf_res = 0.3", ""),
     ("run_T21L8_vadv_finite_volume", 8, 36, "vert_advect_uv = 'van_leer_linear', vert_advect_t = 'finite_volume_parabolic'", ""),
     ("run_T21L8_symmetric", 8, 48, "make_symmetric = .true.", ""),
+    ("run_T21L14_mcm_coord", 14, 36, "vert_difference_option = 'mcm', vert_coord_option = 'mcm'", ""),
 ])
 def test_atmosphere_mod_options_from_fortran(tmp_path, golden_dir, fixture, levels, nsteps, extra, groups):
     """Options the drop-in front end forwards instead of refusing, each from the reference's own input.nml through atmos_model's loop on
     this repository's atmosphere_mod, against the reference run's final extremes: topography_option = 'gaussian' (gaussian_topog_nml through
     the reference's gaussian_topog_mod, spectral_init_cond.F90:299-303), vert_coord_option = 'hybrid' (compute_vert_coord,
-    vert_coordinate.F90:124-152, formed in Fortran), vert_advect_uv / vert_advect_t, make_symmetric."""
+    vert_coordinate.F90:124-152, formed in Fortran), vert_advect_uv / vert_advect_t, make_symmetric, vert_difference_option = 'mcm' on the 'mcm' levels."""
     exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")

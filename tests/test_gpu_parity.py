@@ -34,7 +34,8 @@ def rand_spec(rng, sc, L):
 
 # ------------------------------------------------------------------ (a) against the reference's own outputs
 @pytest.mark.parametrize("name,res,L,impl", [("kernels_T10L8", "T10", 8, 1), ("kernels_T21L6", "T21", 6, 0),
-                                             ("kernels_T21L6", "T21", 6, 1)])
+                                             ("kernels_T21L6", "T21", 6, 1),
+                                             ("kernels_T31L4", "T31", 4, 0)])       # lon_max = 96 = 2^5 3: the mixed-radix FFT kernels (fft99's radix-3 pass)
 def test_golden_kernels(golden_dir, name, res, L, impl):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     dc = make(res, L, legendre_impl=impl)
@@ -319,6 +320,111 @@ def test_golden_dynamics_options(golden_dir, case, opts, steps, dt):
     assert (c.vert_advect_uv, c.vert_advect_t, c.use_implicit) == (2, 3, 0)
     with pytest.raises(dyncore.IscaError, match="is not a valid value for vert_advect_t"):
         atm.config_from_namelist({"spectral_dynamics_nml": {"vert_advect_t": "upstream"}})
+
+
+@pytest.mark.parametrize("res,steps", [("T31", (1, 2, 36)), ("T53", (1, 36))])
+def test_golden_lon_max_with_factors_3_5(golden_dir, res, steps):
+    """lon_max = 96 = 2^5 3 (T31) and 160 = 2^5 5 (T53): fft99's set99 factors n/2 into 2, 3 and 5 (fft99.F90:83-120, radix-3 / radix-5 passes
+    :876-1228); here the mixed-radix Stockham kernels (k_fft_fwd_mixed / k_fft_inv_mixed) and the van Leer kernel's remainder wrap.  36 steps of the
+    Held-Suarez test case against the reference run at those resolutions; the transform pair is a projection."""
+    g = np.load(os.path.join(golden_dir, f"run_{res}L8.npz"))
+    dc = make(res, 8); dc.cold_start()
+    done = 0
+    for n in steps:
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print(res, "step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
+    t, u = dc.get("tg"), dc.get("ug")
+    assert abs(t.min() - tmin) < 1e-9 and abs(t.max() - tmax) < 1e-9 and abs(np.abs(u).max() - umax) < 1e-9
+    rng = np.random.default_rng(5)
+    s = rng.standard_normal((3, dc.N1, dc.M1)) + 1j * rng.standard_normal((3, dc.N1, dc.M1))
+    s[..., 0] = s[..., 0].real
+    m, n = np.meshgrid(np.arange(dc.M1), np.arange(dc.N1))
+    s = s * (m + n <= dc.cfg.num_spherical - 1)
+    dc3 = make(res, 3)
+    assert rel(dc3.trans_grid_to_spherical(dc3.trans_spherical_to_grid(s)), s) < 1e-13
+    dc3.close(); dc.close()
+    with pytest.raises(dyncore.IscaError, match="no prime factor above 5"):
+        make("T21", 8, lon_max=112, lat_max=64)            # 56 = 2^3 7
+
+
+def test_golden_vert_difference_mcm(golden_dir):
+    """vert_difference_option = 'mcm' (spectral_dynamics.F90:1084-1099 four_in_one, press_and_geopot.F90:196-210 pressure_variables,
+    implicit.F90:404-408, 447-456 the linear operator): 48 steps on the test case's sigma levels, and 36 steps on the 'mcm' vertical coordinate
+    (vert_coordinate.F90:148, 14 levels) through the namelist mirror, each against the reference run -- state, p_full and z_full."""
+    from isca_amd import atmosphere as atm
+    g = np.load(os.path.join(golden_dir, "run_T21L8_mcm.npz"))
+    dc = make("T21", 8, vert_difference_option=1); dc.cold_start()
+    done = 0
+    for n in (1, 2, 48):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg", "p_full", "z_full")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print("vert_difference_option = 'mcm', step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    # the routines of press_and_geopot_mod on the handle: mid-point full levels
+    ps = dc.get("psg")
+    ph, lph, pf, lpf = dc.pressure_variables(ps)
+    assert np.array_equal(pf, 0.5 * (ph[1:] + ph[:-1])) and rel(lpf, np.log(pf)) < 1e-15 and rel(pf, dc.get("p_full")) < 1e-15
+    dc.close()
+    ref = make("T21", 8); ref.cold_start(); ref.step(48)           # not a no-op
+    assert rel(ref.get("tg"), g["st_tg_000048"]) > 1e-7
+    ref.close()
+    g = np.load(os.path.join(golden_dir, "run_T21L14_mcm_coord.npz"))
+    nml = {"spectral_dynamics_nml": dict(dyncore.RESOLUTIONS["T21"], num_levels=14, vert_coord_option="mcm", vert_difference_option="mcm",
+                                        reference_sea_level_press=1.0e5, damping_order=4, water_correction_limit=200.e2, valid_range_t=[100., 800.],
+                                        initial_sphum=0.0, robert_coeff=0.04),
+           "main_nml": {"dt_atmos": 600},
+           "hs_forcing_nml": dict(t_zero=315., t_strat=200., delh=60., delv=10., eps=0., sigma_b=0.7, ka=-40., ks=-4., kf=-1., do_conserve_energy=True)}
+    cfg = atm.config_from_namelist(nml)
+    assert cfg.vert_difference_option == 1
+    dc = dyncore.DynCore(cfg)
+    assert np.array_equal(dc.table("pk"), g["tab_pk"]) and np.array_equal(dc.table("bk"), g["tab_bk"])
+    dc.cold_start()
+    done = 0
+    for n in (1, 36):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+               for k in ("ug", "vg", "tg", "psg", "p_full", "z_full")}
+        err["tr"] = rel(dc.get("tr"), g[f"st_tr1_{n:06d}"])
+        print("vert_difference_option = vert_coord_option = 'mcm', step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    dc.close()
+    with pytest.raises(dyncore.IscaError, match="is not a valid value for vert_difference_option"):
+        atm.config_from_namelist({"spectral_dynamics_nml": {"vert_difference_option": "arakawa"}})
+
+
+def test_golden_hole_filling(golden_dir):
+    """hole_filling = 'on' for a spectral tracer: water_borrowing (atmos_spectral/model/water_borrowing.F90:38-136, spectral_dynamics.F90:1142-1144)
+    fills negative values of the previous level from the four neighbours on the latitude circle and in the column.  The reference's three-tracer
+    table with that option, 60 steps at T21L8 (a fifth of the spectral tracer's values are negative by then); without the option the tracer is 8e-4
+    of its maximum away."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_hole_filling.npz"))
+    opts = dict(num_tracers=3, tracer_spectral=[0, 0, 1], tracer_robert_coeff=[-1.0, 0.05, -1.0])
+    dc = make("T21", 8, tracer_hole_filling=[0, 0, 1], **opts); dc.cold_start()
+    off = make("T21", 8, **opts); off.cold_start()
+    done = 0
+    for n in (1, 2, 3, 40, 60):
+        dc.step(n - done); off.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k == "ug" else 1e-300))
+               for k in ("ug", "tg", "psg")}
+        for k, gk in (("tr", "tr1"), ("tr2", "tr2"), ("tr3", "tr3")):
+            err[k] = rel(dc.get(k), g[f"st_{gk}_{n:06d}"])
+        print("hole_filling = on, step", n, err, "without:", rel(off.get("tr3"), g[f"st_tr3_{n:06d}"]))
+        assert max(err.values()) < 1e-9, (n, err)
+    assert rel(off.get("tr3"), g["st_tr3_000060"]) > 1e-5           # the option is not a no-op
+    assert np.array_equal(off.get("tg"), dc.get("tg"))              # and the dynamics do not notice
+    dc.close(); off.close()
+    from isca_amd import atmosphere as atm
+    table = atm.parse_field_table('"TRACER", "atmos_mod", "sphum"\n "numerical_representation", "grid"\n "advect_vert", "finite_volume_parabolic" /\n'
+                                  '"TRACER", "atmos_mod", "age"\n "numerical_representation", "spectral"\n "hole_filling", "on" /\n')
+    keys, _ = atm.tracers_from_field_table(table)
+    assert keys["tracer_hole_filling"] == [0, 1]
 
 
 def test_golden_three_tracers(golden_dir):
@@ -1101,7 +1207,7 @@ def test_experiment_restart_chaining(tmp_path):
 
 
 # ------------------------------------------------------------------ every public routine on the path, one by one
-@pytest.mark.parametrize("name,res,L", [("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6)])
+@pytest.mark.parametrize("name,res,L", [("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6), ("kernels_T31L4", "T31", 4)])
 def test_golden_components(golden_dir, name, res, L):
     """The reference's own outputs of the routines its callers use one at a time (spherical_mod operators,
     press_and_geopot_mod, global_integral_mod, fv_advection_mod, vert_advection_mod PPM, tracer_source_sink),
