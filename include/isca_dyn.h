@@ -227,6 +227,21 @@ int isca_dyn_refresh_derived(isca_dyn_t *h);
  * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
 int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
 int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer" */
+/* Restart files written and read by the library itself, in the netCDF classic / 64-bit-offset format (what fms_io writes), without a netCDF
+ * library: <directory>/spectral_dynamics.res.nc (spectral_dynamics_end, spectral_dynamics.F90:1502-1531: previous, current, pk, bk,
+ * vors/divs/ts/ln_ps _real/_imag, ug, vg, tg, psg, every tracer by its field_table name (+ _real/_imag for a 'spectral' one), vorg, divg,
+ * surf_geopotential), <directory>/atmosphere.res.nc (atmosphere_end, atmosphere.F90:362-375: time_pointers, ug, vg, tg, psg, atmosphere_mod's
+ * tracer copies, wg_full) and, with the moist package, <directory>/mixed_layer.res.nc (t_surf; mixed_layer.F90:813) -- two records along Time,
+ * one per leapfrog level, fms_io's xaxis_N / yaxis_N / zaxis_N naming.  isca_dyn_read_restart is the restart branch of
+ * read_restart_or_do_coldstart (:509-575) + atmosphere_init (atmosphere.F90:197-223): resolution checks with the reference's messages, both time
+ * levels, the time pointers, the file's surface geopotential, then isca_dyn_refresh_derived.  tracer_names: comma-separated field_table names of
+ * tracers 1..num_tracers (NULL: "sphum", "tracer2", ...).  world_size 1.  The same files are written and read by isca_amd/restart.py. */
+int isca_dyn_write_restart(isca_dyn_t *h, const char *directory, const char *tracer_names);
+int isca_dyn_read_restart(isca_dyn_t *h, const char *directory, const char *tracer_names);
+int isca_dyn_restart_exists(const char *directory);     /* file_exist('INPUT/spectral_dynamics.res.nc') (spectral_dynamics.F90:512) */
+/* the file layer alone (no device): writes a small fms_io-style file to out_path (if given); sums[0..2] = sum, first, last value of record
+ * `record` of variable var_name of in_path (if given) */
+int isca_restart_file_selftest(const char *out_path, const char *in_path, const char *var_name, int record, double *sums);
 
 /* --- transforms_mod entry points (host buffers, Fortran layouts; nlev = size of 3rd dim) --- */
 int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev);   /* transforms.F90:379 */

@@ -13,6 +13,7 @@ UNITS = [  # (source, extra flags)
     ("tables.cpp", ["-ffp-contract=off"]),      # host tables: reproduce the reference's non-FMA fp64 results
     ("comm.cpp", []),                           # RCCL bound with dlopen (no link-time dependency)
     ("comm_ipc.cpp", []),                       # host-staged exchange for ranks sharing one GPU (verification of the sharded C++ loop)
+    ("restart_nc.cpp", []),                     # restart files in the netCDF classic format (no netCDF library)
     ("kernels.hip", []),
     ("legendre.hip", []),
     ("moist.hip", ["-ffp-contract=off"]),       # moist column physics: no contraction, like the reference build (regime tests)

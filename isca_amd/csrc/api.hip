@@ -12,6 +12,7 @@ using namespace isca;
 
 static thread_local std::string g_last_error;
 extern "C" const char *isca_last_error(void) { return g_last_error.c_str(); }
+void isca_internal_set_error(const std::string &m) { g_last_error = m; }      // for the library's other compile units (restart_nc.cpp)
 
 #define API_BEGIN try {
 #define API_END                                   \

@@ -111,6 +111,10 @@ def load_library():
         "isca_dyn_refresh_derived": [H],
         "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
         "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+        "isca_dyn_write_restart": [H, C.c_char_p, C.c_char_p],
+        "isca_dyn_read_restart": [H, C.c_char_p, C.c_char_p],
+        "isca_dyn_restart_exists": [C.c_char_p],
+        "isca_restart_file_selftest": [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, dp],
         "isca_trans_spherical_to_grid": [H, dp, dp, C.c_int],
         "isca_trans_grid_to_spherical": [H, dp, dp, C.c_int, C.c_int],
         "isca_vor_div_from_uv_grid": [H, dp, dp, dp, dp, C.c_int],
@@ -168,7 +172,7 @@ EXPORTED_SYMBOLS = [
     "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
-    "isca_dyn_get_table", "isca_dyn_get_info", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
+    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
@@ -367,6 +371,17 @@ class DynCore:
 
     def complete_update(self, time_level: int = 1):
         self._check(self.lib.isca_dyn_complete_update(self._h, time_level))
+
+    def write_restart_files(self, directory: str, tracer_names=None):
+        """spectral_dynamics_end + atmosphere_end (+ mixed_layer_end) by the library's own netCDF-classic writer (isca_dyn_write_restart): the same
+        files isca_amd.restart.write_restart writes through scipy."""
+        names = None if tracer_names is None else ",".join(tracer_names).encode()
+        self._check(self.lib.isca_dyn_write_restart(self._h, str(directory).encode(), names))
+
+    def read_restart_files(self, directory: str, tracer_names=None):
+        """The restart branch of spectral_dynamics_init / atmosphere_init by the library's own reader (isca_dyn_read_restart)."""
+        names = None if tracer_names is None else ",".join(tracer_names).encode()
+        self._check(self.lib.isca_dyn_read_restart(self._h, str(directory).encode(), names))
 
     def set_time_pointers(self, previous: int, current: int, step_count: int = 0):
         self._check(self.lib.isca_dyn_set_time_pointers(self._h, previous, current, step_count))

@@ -584,7 +584,7 @@ def main():
             "T21", 14, 36, (1, 36), extra="vert_difference_option = 'mcm', vert_coord_option = 'mcm'",
             keep=lambda k: k in ("tab_pk", "tab_bk") or re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_0000(01|36)$", k) is not None),
         # lon_max with factors 3 and 5 (fft99's set99 takes n/2 = 2^a 3^b 5^c): every public routine at T31 (96 x 48), runs at T31 and T53 (160 x 80)
-        "kernels_T31L4": lambda: golden_kernels("T31", 4, 20260929),
+        "kernels_T31L6": lambda: golden_kernels("T31", 6, 20260929),
         "run_T31L8": lambda: golden_run(
             "T31", 8, 36, (1, 2, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
         "run_T53L8": lambda: golden_run(
