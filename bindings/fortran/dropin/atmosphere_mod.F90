@@ -3,8 +3,8 @@
 ! with atmosphere_nml: idealized_moist_model = .true., the Frierson column chain whose namelists idealized_moist_phys_init reads),
 ! spectral_dynamics, the pressures and heights of the new level -- queued on the device's stream; nothing crosses PCIe.  The main program (atmos_solo/atmos_model.F90:115-142) calls these four names and nothing else of the core.
 !
-! Restart files are written and read by the Python host mirror (isca_amd/restart.py, the reference's variable set in netCDF-3); from
-! Fortran the model cold-starts (this image has no netCDF for fms_io).
+! Restart files (the reference's variable set, netCDF classic format): spectral_dynamics_init reads INPUT/*.res.nc when they exist, spectral_dynamics_end
+! writes RESTART/spectral_dynamics.res.nc, atmosphere.res.nc and mixed_layer.res.nc through the library (this image has no netCDF for fms_io).
 module atmosphere_mod
 
 #ifdef INTERNAL_FILE_NML

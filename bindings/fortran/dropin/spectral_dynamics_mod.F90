@@ -7,7 +7,8 @@
 ! column chain and the namelist values idealized_moist_phys_init collected.  vert_coord_option: 'even_sigma', 'uneven_sigma' and 'input'
 ! (vert_coordinate_nml's pk, bk).
 ! vert_coord_option 'hybrid' / 'mcm' / 'v197' are formed here (named_vert_coord); topography_option 'gaussian' through the reference's own
-! gaussian_topog_mod.  Not here: restart files (fms_io / netCDF; the Python host mirror isca_amd/restart.py writes and reads them),
+! gaussian_topog_mod.  Restart files: INPUT/*.res.nc are read and RESTART/*.res.nc written by the library's own netCDF-classic code
+! (isca_dyn_read_restart / isca_dyn_write_restart; the same files isca_amd/restart.py handles).  Not here:
 ! topography_option = 'input' (a netCDF height field), initial_state_option other than 'quiescent'.  Each is refused with
 ! error_mesg(..., FATAL) naming the option.
 module spectral_dynamics_mod
@@ -90,6 +91,7 @@ namelist /vert_coordinate_nml/ pk, bk
 logical :: module_is_initialized = .false.
 logical :: dry_model
 integer :: nhum, num_tracers
+character(len=256) :: tracer_name_list = ' '       ! the field_table names of the prognostic tracers, comma-separated: the restart files' variable names
 real :: dt_real
 
 contains
@@ -269,11 +271,21 @@ endif
 dry_model_out = dry_model
 nhum_out = nhum
 
-! ---- the device core, cold-started (restart files: not from Fortran, see the header)
+! ---- the device core: read_restart_or_do_coldstart (spectral_dynamics.F90:509-630) -- INPUT/spectral_dynamics.res.nc (+ atmosphere.res.nc,
+!      mixed_layer.res.nc), read by the library's own netCDF-classic reader, or the cold start
 call chk(isca_dyn_create(cfg, core), 'spectral_dynamics_init')
 core_ready = .true.
-if(trim(topography_option) == 'gaussian') call gaussian_topography      ! get_topography (init/spectral_init_cond.F90:299-303)
-call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
+tracer_name_list = ' '
+do ntr = 1, num_tracers
+  tracer_name_list = trim(tracer_name_list)//trim(tracer_attributes(ntr)%name)
+  if(ntr < num_tracers) tracer_name_list = trim(tracer_name_list)//','
+enddo
+if(isca_dyn_restart_exists('INPUT'//c_null_char) /= 0) then
+  call chk(isca_dyn_read_restart(core, 'INPUT'//c_null_char, trim(tracer_name_list)//c_null_char), 'spectral_dynamics_init')
+else
+  if(trim(topography_option) == 'gaussian') call gaussian_topography      ! get_topography (init/spectral_init_cond.F90:299-303)
+  call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
+endif
 nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
 virtual_t = use_virtual_temperature; ref_sea_level_press = reference_sea_level_press
 triang = triang_trunc; finc = fourier_inc
@@ -450,6 +462,9 @@ subroutine spectral_dynamics_end(tracer_attributes, Time)
 type(tracer_type), intent(in), dimension(:) :: tracer_attributes
 type(time_type), intent(in), optional :: Time
 if(.not. module_is_initialized) return
+! RESTART/spectral_dynamics.res.nc (:1502-1531) and -- written by atmosphere_end and mixed_layer_end in the reference -- atmosphere.res.nc,
+! mixed_layer.res.nc: one call of the library's writer
+call chk(isca_dyn_write_restart(core, 'RESTART'//c_null_char, trim(tracer_name_list)//c_null_char), 'spectral_dynamics_end')
 call chk(isca_dyn_destroy(core), 'spectral_dynamics_end')
 core = c_null_ptr; core_ready = .false.; module_is_initialized = .false.
 end subroutine spectral_dynamics_end

@@ -245,6 +245,17 @@ interface
   integer(c_int) function isca_dyn_get_info(h, name, value) bind(C)
     import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), intent(out) :: value
   end function
+  ! restart files (spectral_dynamics.res.nc, atmosphere.res.nc, mixed_layer.res.nc) written / read by the library's own netCDF-classic code:
+  ! spectral_dynamics_end (spectral_dynamics.F90:1502-1531) + atmosphere_end (atmosphere.F90:362-375); read_restart_or_do_coldstart (:509-575)
+  integer(c_int) function isca_dyn_write_restart(h, directory, tracer_names) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: directory(*), tracer_names(*)
+  end function
+  integer(c_int) function isca_dyn_read_restart(h, directory, tracer_names) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: directory(*), tracer_names(*)
+  end function
+  integer(c_int) function isca_dyn_restart_exists(directory) bind(C)
+    import; character(kind=c_char), intent(in) :: directory(*)
+  end function
   function isca_last_error() bind(C) result(msg)
     import; type(c_ptr) :: msg
   end function

@@ -1083,6 +1083,67 @@ def test_tracer_fork_before_column_kernel(monkeypatch, eager):
         assert np.array_equal(late[key], early[key]), key
 
 
+@pytest.mark.parametrize("case", ["three_tracers", "cold", "moist"])
+def test_native_restart_files(tmp_path, case):
+    """isca_dyn_write_restart / isca_dyn_read_restart (the library's own netCDF-classic writer and reader, csrc/restart_nc.cpp: what the Fortran drop-in's
+    spectral_dynamics_end / spectral_dynamics_init use) against the Python mirror isca_amd/restart.py (scipy): both write the same variables with the
+    same values, each reads what the other wrote, and a run continued from either equals the uninterrupted one bit for bit
+    (spectral_dynamics.F90:509-575, 1502-1531; atmosphere.F90:197-223, 362-375; mixed_layer.F90:324-327, 813)."""
+    from isca_amd import restart
+    from scipy.io import netcdf_file
+    if case == "moist":
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "moist_kernels_T21L25.npz"))
+        L, kw = 25, dict(physics=1, dt_atmos=720.0, bk_input=list(g["tab_bk"]), pk_input=list(g["tab_pk"]))
+        names = None
+    else:
+        L, kw = 8, dict(num_tracers=3, tracer_spectral=[0, 0, 1], tracer_robert_coeff=[-1.0, 0.05, -1.0])
+        names = ["sphum", "age_grid", "age_spec"]
+    first, more = (0 if case == "cold" else 9), 5         # right after the cold start both records hold the same level (previous == current)
+    dc = make("T21", L, **kw); dc.cold_start()
+    if first:
+        dc.step(first)
+    d_nat, d_py = str(tmp_path / "native"), str(tmp_path / "python")
+    dc.write_restart_files(d_nat, names)
+    if names:
+        dc.tracer_names = list(names)
+    restart.write_restart(dc, d_py)
+    files = ["spectral_dynamics.res.nc", "atmosphere.res.nc"] + (["mixed_layer.res.nc"] if case == "moist" else [])
+    for fn in files:                                       # the same variables, dimensions and values
+        a, b = netcdf_file(os.path.join(d_nat, fn), "r", mmap=False), netcdf_file(os.path.join(d_py, fn), "r", mmap=False)
+        assert set(a.variables) == set(b.variables), (fn, set(a.variables) ^ set(b.variables))
+        for k, v in b.variables.items():
+            if k == "Time" or "axis_" in k:
+                assert np.array_equal(a.variables[k][:], v[:]) and a.variables[k].cartesian_axis == v.cartesian_axis
+                continue
+            assert a.variables[k].dimensions[0] == "Time" and a.variables[k].shape == v.shape, (fn, k)
+            nrec = 1 if k in ("vorg", "divg", "surf_geopotential", "wg_full", "t_surf") else 2      # (a one-record variable's second record is padding)
+            assert np.array_equal(a.variables[k][:nrec], v[:nrec]), (fn, k)
+        a.close(); b.close()
+    pointers = (dc.info("previous"), dc.info("current"))
+    if case == "moist":      # a start sets the gust back to 1 m/s (idealized_moist_phys_init), in the reference as here: compare with the run put into that state
+        dc.set_time_pointers(pointers[0], pointers[1], dc.info("step"))
+    dc.step(more)
+    state = ["ug", "vg", "tg", "psg", "tr", "tr_atm", "vors", "divs", "ts", "ln_ps"] + (["tr2", "tr3", "trs3", "tr_atm3"] if names else ["t_surf"])
+    want = {k: dc.get(k) for k in state}
+    dc.close()
+    a = make("T21", L, **kw)
+    if names:
+        a.tracer_names = list(names)
+    restart.read_restart(a, d_nat)                         # scipy reads what the library wrote
+    b = make("T21", L, **kw)
+    b.read_restart_files(d_py, names)                      # the library reads what scipy wrote
+    for core in (a, b):
+        assert (core.info("previous"), core.info("current")) == pointers and (pointers[0] == pointers[1]) == (first == 0)
+        core.step(more)
+        for k, v in want.items():
+            assert np.array_equal(core.get(k), v), (case, k)
+    a.close(); b.close()
+    c2 = make("T21", L + 2, **{k: v for k, v in kw.items() if k not in ("bk_input", "pk_input")})        # field_size checks (:512-531)
+    with pytest.raises(dyncore.IscaError, match="Resolution of restart data does not match resolution specified on namelist"):
+        c2.read_restart_files(d_nat, names)
+    c2.close()
+
+
 @pytest.mark.parametrize("first,raw", [(1, 1.0), (9, 1.0), (7, 0.7)])
 def test_restart_is_bit_exact(tmp_path, first, raw):
     """run(N) == run(n1) + atmosphere_end + atmosphere_init(restart) + run(N - n1), bit for bit, through the

@@ -432,3 +432,43 @@ def test_model_time_calendars(tmp_path):
         assert atm._date_after(atm._clock["date0"], atm._clock["calendar"], 2 * day) == [2004, 3, 1, 0, 0, 0]
     finally:
         atm._clock = None
+
+
+def test_restart_file_layer_against_scipy(tmp_path):
+    """The library's netCDF-classic writer and reader (csrc/restart_nc.cpp; no device needed): scipy reads the file it writes -- dimensions,
+    fms_io's axis variables with cartesian_axis, two records -- and it reads files scipy writes (64-bit offset and classic, doubles and floats,
+    the single-record-variable layout), failing with read_data's wording on a missing variable."""
+    import ctypes as C
+    import numpy as np
+    from scipy.io import netcdf_file
+    from isca_amd import dyncore
+    lib = dyncore.load_library()
+    sums = (C.c_double * 3)()
+    out = str(tmp_path / "a.nc").encode()
+    assert lib.isca_restart_file_selftest(out, out, b"two_level", 1, sums) == 0 and list(sums) == [121785.0, 2000.25, 2059.25]
+    f = netcdf_file(out.decode(), "r", mmap=False)
+    assert f.dimensions["Time"] is None and f.dimensions["zaxis_1"] == 3 and f.dimensions["yaxis_1"] == 4 and f.dimensions["xaxis_1"] == 5
+    v = f.variables["two_level"]
+    assert v.dimensions == ("Time", "zaxis_1", "yaxis_1", "xaxis_1") and v.shape == (2, 3, 4, 5)
+    assert np.array_equal(v[:].reshape(2, 60), 1000.0 * np.arange(1, 3)[:, None] + np.arange(60)[None, :] + 0.25)
+    assert np.array_equal(f.variables["one_level"][0].ravel(), -1.0 / np.arange(1, 21)) and f.variables["one_level"].dimensions[1] == "zaxis_2"
+    assert np.array_equal(f.variables["scalar"][:].ravel(), [1.0, 2.0]) and np.array_equal(f.variables["Time"][:], [1.0, 2.0])
+    assert np.array_equal(f.variables["yaxis_1"][:], [1, 2, 3, 4]) and f.variables["yaxis_1"].cartesian_axis == b"Y" and f.variables["Time"].cartesian_axis == b"T"
+    f.close()
+    for version in (1, 2):
+        p = str(tmp_path / f"b{version}.nc")
+        g = netcdf_file(p, "w", version=version)
+        g.createDimension("Time", None); g.createDimension("xaxis_1", 7)
+        x = g.createVariable("xaxis_1", "d", ("xaxis_1",)); x[:] = np.arange(7.0); x.cartesian_axis = "X"
+        w = g.createVariable("probe", "d", ("Time", "xaxis_1")); w[0] = np.arange(7.0) * 1.5; w[1] = np.arange(7.0) * -2.25
+        q = g.createVariable("probe32", "f", ("Time", "xaxis_1")); q[0] = np.arange(7.0); q[1] = np.arange(7.0) + 0.5
+        g.close()
+        for var, rec, want in ((b"probe", 0, [31.5, 0.0, 9.0]), (b"probe", 1, [-47.25, 0.0, -13.5]), (b"probe32", 1, [24.5, 0.5, 6.5]), (b"xaxis_1", 0, [21.0, 0.0, 6.0])):
+            assert lib.isca_restart_file_selftest(None, p.encode(), var, rec, sums) == 0 and list(sums) == want, (version, var, rec, list(sums))
+    p = str(tmp_path / "c.nc")
+    g = netcdf_file(p, "w", version=1); g.createDimension("Time", None); g.createDimension("x", 3)
+    w = g.createVariable("only", "d", ("Time", "x")); w[0] = [1, 2, 3]; w[1] = [4, 5, 6]; w[2] = [7, 8, 9]; g.close()
+    assert lib.isca_restart_file_selftest(None, p.encode(), b"only", 2, sums) == 0 and list(sums) == [24.0, 7.0, 9.0]
+    assert lib.isca_restart_file_selftest(None, p.encode(), b"nothere", 0, sums) == 1 and b"has no variable nothere" in lib.isca_last_error()
+    open(p, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    assert lib.isca_restart_file_selftest(None, p.encode(), b"only", 0, sums) == 1 and b"netCDF-4" in lib.isca_last_error()
