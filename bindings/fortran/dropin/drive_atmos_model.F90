@@ -13,13 +13,13 @@ use tracer_manager_mod, only: register_tracers
 use diag_manager_mod,   only: diag_manager_init
 use atmosphere_mod,     only: atmosphere_init, atmosphere, atmosphere_end
 use spectral_dynamics_mod, only: get_num_levels
-use transforms_mod,     only: get_grid_domain, area_weighted_global_mean
+use transforms_mod,     only: get_grid_domain, get_lat_max, area_weighted_global_mean
 use isca_dropin_mod,    only: get_grid3, get_grid2
 implicit none
 integer :: nsteps = 144, dt_atmos = 600
 namelist /drive_nml/ nsteps, dt_atmos
 type(time_type) :: Time, Time_init, Time_step
-integer :: ntrace, ntprog, ntdiag, ntfamily, na, unit, is, ie, js, je, nlev
+integer :: ntrace, ntprog, ntdiag, ntfamily, na, unit, is, ie, js, je, nlev, latmax
 real, allocatable :: tg(:,:,:), ug(:,:,:), psg(:,:), q(:,:,:)
 integer(kind=8) :: c0, c1, c2, crate
 integer :: warm
@@ -58,8 +58,10 @@ call get_grid3('tg', 1, tg); call get_grid3('ug', 1, ug)
 write(*,'(a,3es24.16)') 'DRIVE_STATE Tmin,Tmax,maxabsU=', minval(tg), maxval(tg), maxval(abs(ug))
 if(ntprog > 0) then
   call get_grid3('tr', 1, q)
-  write(*,'(a,2es24.16)') 'DRIVE_TRACER qmax,q(10,16,nlev)=', maxval(q), q(is+9, js+15, nlev)
+  write(*,'(a,2es24.16)') 'DRIVE_TRACER qmax,q(10,16,nlev)=', maxval(q), q(is+9, min(js+15, je), nlev)
 endif
-write(*,'(a,es24.16)') 'DRIVE_MEAN_PS', area_weighted_global_mean(psg)
+call get_lat_max(latmax)
+write(*,'(a,2i6)') 'DRIVE_ROWS js,je=', js, je       ! this process's latitude band (all rows with one rank)
+if(je - js + 1 == latmax) write(*,'(a,es24.16)') 'DRIVE_MEAN_PS', area_weighted_global_mean(psg)
 call atmosphere_end
 end program drive_atmos_model

@@ -19,6 +19,10 @@ type(c_ptr), save :: core = c_null_ptr      ! isca_dyn_t* of this process
 logical, save :: core_ready = .false.
 integer, save :: nlon = 0, nlat = 0, nlev = 0, nfour = 0, nsph = 0      ! lon_max, lat_max, num_levels, num_fourier, num_spherical
 integer, save :: ntrace = 0                                                ! prognostic tracers of the field_table
+! The decomposition (spec_mpp.F90:61-80, atmosphere_domain): this process holds the latitude rows js_loc..je_loc of every longitude -- all of them with
+! one rank; the library deals the zonal wavenumbers itself.  Rank and number of ranks come from the environment (isca_env_rank: the mpp of this build
+! has no MPI), the exchanges are the library's (RCCL over xGMI; ISCA_COMM=ipc: host-staged, ranks may share a GPU).
+integer, save :: my_rank = 0, num_ranks = 1, js_loc = 1, je_loc = 0
 logical, save :: virtual_t = .false.
 integer, save :: dropin_physics = 2     ! isca_dyn_config%physics of the core spectral_dynamics_init creates: 2 = the caller's physics (spectral_dynamics
                                         ! receives its tendencies); atmosphere_mod sets 0 (hs_forcing inside the device step) or 1 (the Frierson chain)

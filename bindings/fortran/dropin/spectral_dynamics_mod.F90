@@ -134,6 +134,8 @@ logical, optional, intent(in), dimension(:,:) :: ocean_mask
 
 type(isca_dyn_config) :: cfg
 integer :: ntr, nsphum, nmix_rat, seconds, days, k
+integer(c_int) :: env_rank, env_world, env_local
+integer(c_long) :: info_val
 real :: robert_coeff_tracers
 character(len=32) :: scheme, params
 character(len=128) :: tname, longname, units
@@ -273,8 +275,17 @@ nhum_out = nhum
 
 ! ---- the device core: read_restart_or_do_coldstart (spectral_dynamics.F90:509-630) -- INPUT/spectral_dynamics.res.nc (+ atmosphere.res.nc,
 !      mixed_layer.res.nc), read by the library's own netCDF-classic reader, or the cold start
+! the decomposition: rank / number of ranks from the environment (this mpp has no MPI: mpp_pe() is 0 everywhere), latitude bands to the ranks, the
+! communicator's id through ISCA_COMM_ID_FILE; collective over the ranks (isca_dyn_comm_init_env is a no-op with one)
+call chk(isca_env_rank(env_rank, env_world, env_local), 'spectral_dynamics_init')
+cfg%rank = env_rank; cfg%world_size = env_world; cfg%device = env_local
+my_rank = env_rank; num_ranks = env_world
 call chk(isca_dyn_create(cfg, core), 'spectral_dynamics_init')
 core_ready = .true.
+call chk(isca_dyn_comm_init_env(core), 'spectral_dynamics_init')
+call chk(isca_dyn_get_info(core, 'lat_local'//c_null_char, info_val), 'spectral_dynamics_init'); je_loc = int(info_val)
+call chk(isca_dyn_get_info(core, 'lat_start'//c_null_char, info_val), 'spectral_dynamics_init'); js_loc = int(info_val) + 1
+je_loc = js_loc + je_loc - 1
 tracer_name_list = ' '
 do ntr = 1, num_tracers
   tracer_name_list = trim(tracer_name_list)//trim(tracer_attributes(ntr)%name)

@@ -83,7 +83,7 @@ end function transforms_are_initialized
 subroutine get_grid_domain(is, ie, js, je)
 integer, intent(out) :: is, ie, js, je
 call need_core('get_grid_domain')
-is = 1; ie = nlon; js = 1; je = nlat
+is = 1; ie = nlon; js = js_loc; je = je_loc          ! latitude bands (spec_mpp.F90:61-80): all rows with one rank
 end subroutine get_grid_domain
 subroutine get_spec_domain(ms, me, ns, ne)
 integer, intent(out) :: ms, me, ns, ne
@@ -121,17 +121,30 @@ subroutine get_deg_lon(deg_lon_out)
 real, intent(out), dimension(:) :: deg_lon_out
 call need_core('get_deg_lon'); call get_table1('deg_lon', deg_lon_out)
 end subroutine get_deg_lon
+! the latitude tables of THIS process's rows (the reference's getters return (js:je); transforms.F90:853-914), or the whole table when asked for lat_max values
+subroutine get_lat_rows(name, a)
+character(len=*), intent(in) :: name
+real, intent(out) :: a(:)
+real, allocatable :: whole(:)
+if(size(a) == nlat) then
+  call get_table1(name, a)
+else if(size(a) == je_loc - js_loc + 1) then
+  allocate(whole(nlat)); call get_table1(name, whole); a = whole(js_loc:je_loc)
+else
+  call error_mesg('get_'//name, 'the argument does not have the number of local latitudes', FATAL)
+endif
+end subroutine get_lat_rows
 subroutine get_deg_lat(deg_lat_out)
 real, intent(out), dimension(:) :: deg_lat_out
-call need_core('get_deg_lat'); call get_table1('deg_lat', deg_lat_out)
+call need_core('get_deg_lat'); call get_lat_rows('deg_lat', deg_lat_out)
 end subroutine get_deg_lat
 subroutine get_sin_lat(sin_lat_out)
 real, intent(out), dimension(:) :: sin_lat_out
-call need_core('get_sin_lat'); call get_table1('sin_lat', sin_lat_out)
+call need_core('get_sin_lat'); call get_lat_rows('sin_lat', sin_lat_out)
 end subroutine get_sin_lat
 subroutine get_wts_lat(wts_lat_out)
 real, intent(out), dimension(:) :: wts_lat_out
-call need_core('get_wts_lat'); call get_table1('wts_lat', wts_lat_out)
+call need_core('get_wts_lat'); call get_lat_rows('wts_lat', wts_lat_out)
 end subroutine get_wts_lat
 subroutine get_cos_lat(cos_lat_out)      ! spherical_fourier.F90:467-484: cos_lat = sqrt(1 - sin_lat**2); cosm = 1/cos; cosm2 = 1/cos**2
 real, intent(out), dimension(:) :: cos_lat_out

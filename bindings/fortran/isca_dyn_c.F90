@@ -256,6 +256,13 @@ interface
   integer(c_int) function isca_dyn_restart_exists(directory) bind(C)
     import; character(kind=c_char), intent(in) :: directory(*)
   end function
+  ! a host without MPI of its own: rank / ranks / rank on the node from the environment, the communicator's id through ISCA_COMM_ID_FILE
+  integer(c_int) function isca_env_rank(rank, world_size, local_rank) bind(C)
+    import; integer(c_int), intent(out) :: rank, world_size, local_rank
+  end function
+  integer(c_int) function isca_dyn_comm_init_env(h) bind(C)
+    import; type(c_ptr), value :: h
+  end function
   function isca_last_error() bind(C) result(msg)
     import; type(c_ptr) :: msg
   end function

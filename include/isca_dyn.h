@@ -235,7 +235,9 @@ int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step"
  * one per leapfrog level, fms_io's xaxis_N / yaxis_N / zaxis_N naming.  isca_dyn_read_restart is the restart branch of
  * read_restart_or_do_coldstart (:509-575) + atmosphere_init (atmosphere.F90:197-223): resolution checks with the reference's messages, both time
  * levels, the time pointers, the file's surface geopotential, then isca_dyn_refresh_derived.  tracer_names: comma-separated field_table names of
- * tracers 1..num_tracers (NULL: "sphum", "tracer2", ...).  world_size 1.  The same files are written and read by isca_amd/restart.py. */
+ * tracers 1..num_tracers (NULL: "sphum", "tracer2", ...).  With more than one rank every rank writes / reads its own piece, named as fms_io names the
+ * pieces of a distributed file (<name>.nc.NNNN): its latitude band of the grid fields, its zonal wavenumbers of the spectral arrays; the same number
+ * of ranks reads them back.  The one-rank files are the ones isca_amd/restart.py writes and reads. */
 int isca_dyn_write_restart(isca_dyn_t *h, const char *directory, const char *tracer_names);
 int isca_dyn_read_restart(isca_dyn_t *h, const char *directory, const char *tracer_names);
 int isca_dyn_restart_exists(const char *directory);     /* file_exist('INPUT/spectral_dynamics.res.nc') (spectral_dynamics.F90:512) */
@@ -298,6 +300,14 @@ int isca_comm_selftest(int device, double *max_err);     /* one-rank communicato
  * Every exchange synchronises stream and host: a verification vehicle, not a fast path.  ISCA_IPC_TIMEOUT_S (120): how long a
  * rank waits for the others before it stops with an error; a rank whose step throws releases its peers with an error. */
 const char *isca_dyn_comm_kind(isca_dyn_t *h);           /* "rccl", "ipc", or "" without a communicator */
+/* For a host without a message-passing layer of its own -- the Fortran drop-in when mpp is built without MPI (mpp_pe() = 0 everywhere), or any
+ * launcher that only exports environment variables: the decomposition contract of spec_mpp.F90:61-80 / atmosphere_domain (atmosphere.F90:390) is then
+ * carried by the environment.  isca_env_rank: rank, number of ranks and rank on the node from ISCA_RANK / ISCA_WORLD_SIZE / ISCA_LOCAL_RANK, else
+ * torchrun's RANK / WORLD_SIZE / LOCAL_RANK, Open MPI's OMPI_COMM_WORLD_*, PMI_RANK / PMI_SIZE, SLURM_PROCID / SLURM_NTASKS (one rank when none is
+ * set).  isca_dyn_comm_init_env (collective; no-op with one rank): rank 0 draws the id and leaves it in the file ISCA_COMM_ID_FILE names, the others
+ * wait for it, then isca_dyn_comm_init + isca_dyn_comm_check on every rank. */
+int isca_env_rank(int *rank, int *world_size, int *local_rank);
+int isca_dyn_comm_init_env(isca_dyn_t *h);
 
 /* --- components of the step on caller fields (world_size == 1) -------------------------------------
  * Each entry replaces one public routine the reference's callers use on its own, and runs the kernel or

@@ -2,6 +2,7 @@
 #include "kernels.h"
 #include "moist.h"
 #include <cstring>
+#include <unistd.h>
 #include <cmath>
 #include <algorithm>
 #include <mutex>
@@ -1240,6 +1241,55 @@ extern "C" int isca_dyn_comm_init(isca_dyn_t *h, const void *id128) {
   if (h->comm) fail("comm_init: communicator already initialised");
   HIP_CHECK(hipSetDevice(h->cfg.device));
   h->comm = isca::Comm::create(id128, h->cfg.rank, h->cfg.world_size);
+  API_END
+}
+// A host without a message-passing layer of its own (the Fortran drop-in on an mpp built without MPI; any launcher that only sets environment
+// variables): the rank and the number of ranks from the environment, and the 128-byte id handed from rank 0 to the others through a file.
+// isca_env_rank: ISCA_RANK / ISCA_WORLD_SIZE, else what torchrun (RANK / WORLD_SIZE / LOCAL_RANK), Open MPI (OMPI_COMM_WORLD_RANK / _SIZE /
+// _LOCAL_RANK), MPICH / Slurm (PMI_RANK / PMI_SIZE, SLURM_PROCID / SLURM_NTASKS / SLURM_LOCALID) export; one rank when none is set.
+extern "C" int isca_env_rank(int *rank, int *world_size, int *local_rank) {
+  static const char *const names[][3] = {{"ISCA_RANK", "ISCA_WORLD_SIZE", "ISCA_LOCAL_RANK"}, {"RANK", "WORLD_SIZE", "LOCAL_RANK"},
+                                         {"OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK"},
+                                         {"PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID"}, {"SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID"}};
+  int r = 0, w = 1, l = -1;
+  for (const auto &n : names) {
+    const char *a = getenv(n[0]), *b = getenv(n[1]);
+    if (a && b && *a && *b) { r = atoi(a); w = atoi(b); if (const char *c = getenv(n[2])) l = atoi(c); break; }
+  }
+  if (w < 1 || r < 0 || r >= w) { g_last_error = "isca_env_rank: inconsistent rank / world size in the environment"; return 1; }
+  if (rank) *rank = r;
+  if (world_size) *world_size = w;
+  if (local_rank) *local_rank = l < 0 ? r : l;
+  return 0;
+}
+// collective: rank 0 draws the id (isca_comm_get_unique_id: RCCL's, or the host-staged exchange's with ISCA_COMM=ipc) and leaves it in the file
+// ISCA_COMM_ID_FILE names (written under another name and renamed: never seen half-written); the others wait for the file (ISCA_IPC_TIMEOUT_S,
+// 120 s); everybody then runs isca_dyn_comm_init and isca_dyn_comm_check.  The file is removed by rank 0 once every rank has answered the check.
+extern "C" int isca_dyn_comm_init_env(isca_dyn_t *h) {
+  API_BEGIN
+  if (!h) fail("null argument");
+  if (h->cfg.world_size == 1) return 0;
+  const char *path = getenv("ISCA_COMM_ID_FILE");
+  if (!path || !*path) fail("comm_init_env: ISCA_COMM_ID_FILE (a path every rank can read) is not set");
+  unsigned char id[128];
+  if (h->cfg.rank == 0) {
+    if (isca_comm_get_unique_id(id)) fail(g_last_error);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0 || rename(tmp.c_str(), path) != 0) fail(std::string("comm_init_env: cannot write ") + path);
+  } else {
+    const double limit = getenv("ISCA_IPC_TIMEOUT_S") ? atof(getenv("ISCA_IPC_TIMEOUT_S")) : 120.0;
+    double waited = 0.0;
+    for (;;) {
+      FILE *f = fopen(path, "rb");
+      if (f) { const size_t n = fread(id, 1, 128, f); fclose(f); if (n == 128) break; }
+      if (waited > limit) fail(std::string("comm_init_env: rank 0 did not leave the communicator id in ") + path);
+      usleep(20000); waited += 0.02;
+    }
+  }
+  if (isca_dyn_comm_init(h, id)) fail(g_last_error);
+  if (isca_dyn_comm_check(h)) fail(g_last_error);
+  if (h->cfg.rank == 0) remove(path);          // (every rank has read it: the check is collective)
   API_END
 }
 // "rccl" or "ipc" (comm.h), "" without a communicator

@@ -300,10 +300,19 @@ void set(isca_dyn_t *h, const std::string &name, int tl, const double *v, size_t
   if (isca_dyn_set_state(h, name.c_str(), tl, v, n)) fail(std::string("spectral_dynamics_init: ") + isca_last_error());
 }
 
+// With more than one rank every rank writes and reads files of its own, named as fms_io names the pieces of a distributed file (<name>.nc.NNNN,
+// NNNN = the rank): its latitude band of the grid fields, and the spectral arrays at full size with the coefficients of ITS zonal wavenumbers (zero
+// elsewhere: get_state / set_state move exactly those).  Such a set is read back by the same number of ranks.
+std::string rank_suffix(const isca_dyn *h) {
+  if (h->cfg.world_size == 1) return "";
+  char buf[16];
+  snprintf(buf, sizeof buf, ".%04d", h->cfg.rank);
+  return buf;
+}
 void write_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
-  if (h->cfg.world_size != 1) fail("write_restart: gather the bands on one rank first (world_size == 1 only)");
   mkdir(dir.c_str(), 0777);
-  const size_t L = h->g.L, J = h->g.J, I = h->g.I, N1 = h->g.N1, M1 = h->g.M1;
+  const std::string sfx = rank_suffix(h);
+  const size_t L = h->g.L, J = h->g.Jl, I = h->g.I, N1 = h->g.N1, M1 = h->g.M1;
   const int prev = h->previous, cur = h->current;
   // record nt of a two-level variable = storage slot nt (Fortran time level nt + 1): the current level sits in record `cur`, the previous one
   // in the other; after a cold start both records hold the same values (spectral_dynamics.F90:617-625)
@@ -337,7 +346,10 @@ void write_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
       if (!t.spec.empty()) spec(f, t.name, t.spec, L);
     }
     grid(f, "vorg", "vorg", 1, L); grid(f, "divg", "divg", 1, L); grid(f, "surf_geopotential", "surf_geopotential", 1, 1);
-    f.close(dir + "/spectral_dynamics.res.nc");
+    if (h->cfg.world_size > 1) {     // a piece also carries what one rank re-derives from the spectral state (isca_dyn_refresh_derived): the gradients of T and ln p_s the step keeps
+      grid(f, "dxT", "dxT", 1, L); grid(f, "dyT", "dyT", 1, L); grid(f, "dxlp", "dxlp", 1, 1); grid(f, "dylp", "dylp", 1, 1);
+    }
+    f.close(dir + "/spectral_dynamics.res.nc" + sfx);
   }
   {
     RestartFile f;       // atmosphere.F90:362-375
@@ -345,21 +357,21 @@ void write_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
     grid(f, "ug", "ug", 2, L); grid(f, "vg", "vg", 2, L); grid(f, "tg", "tg", 2, L); grid(f, "psg", "psg", 2, 1);
     for (const auto &t : tracers) grid(f, t.name, t.atm, 2, L);
     grid(f, "wg_full", "wg_full", 1, L);
-    f.close(dir + "/atmosphere.res.nc");
+    f.close(dir + "/atmosphere.res.nc" + sfx);
   }
   if (h->cfg.physics == 1) {
     RestartFile f;       // mixed_layer_end
     grid(f, "t_surf", "t_surf", 1, 1);
-    f.close(dir + "/mixed_layer.res.nc");
+    f.close(dir + "/mixed_layer.res.nc" + sfx);
   }
 }
 
 void read_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
-  if (h->cfg.world_size != 1) fail("read_restart: world_size == 1 only");
-  const size_t L = h->g.L, J = h->g.J, I = h->g.I, N1 = h->g.N1, M1 = h->g.M1;
-  Nc3File sd(dir + "/spectral_dynamics.res.nc");
+  const std::string sfx = rank_suffix(h);
+  const size_t L = h->g.L, J = h->g.Jl, I = h->g.I, N1 = h->g.N1, M1 = h->g.M1;
+  Nc3File sd(dir + "/spectral_dynamics.res.nc" + sfx);
   std::unique_ptr<Nc3File> at;
-  if (file_exists(dir + "/atmosphere.res.nc")) at.reset(new Nc3File(dir + "/atmosphere.res.nc"));
+  if (file_exists(dir + "/atmosphere.res.nc" + sfx)) at.reset(new Nc3File(dir + "/atmosphere.res.nc" + sfx));
   auto last = [](const RVar &v, int back) { return v.shape.size() > (size_t)back ? v.shape[v.shape.size() - 1 - back] : (size_t)1; };
   {   // field_size checks of spectral_dynamics.F90:519-545
     const RVar &v = sd.var("vors_real");
@@ -385,9 +397,17 @@ void read_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
     if (v.size() != L + 1 || memcmp(v.data(), t.data(), (L + 1) * 8) != 0)
       fail(std::string("read_restart: ") + nm + " of the restart file differs from the vertical coordinate of the namelist");
   }
-  {   // spectral_dynamics.F90:575: the restart file's topography, not get_topography's
-    const auto sg = sd.read("surf_geopotential", 0);
-    if (sg.size() != J * I || isca_dyn_set_surf_geopotential(h, sg.data(), sg.size())) fail(std::string("read_restart: surf_geopotential: ") + isca_last_error());
+  {   // spectral_dynamics.F90:575: the restart file's topography, not get_topography's (the library takes the GLOBAL field: the bands of every rank's file)
+    std::vector<double> sg;
+    for (int q = 0; q < h->cfg.world_size; ++q) {
+      char qs[16]; snprintf(qs, sizeof qs, ".%04d", q);
+      std::unique_ptr<Nc3File> other;
+      if (h->cfg.world_size > 1 && q != h->cfg.rank) other.reset(new Nc3File(dir + "/spectral_dynamics.res.nc" + qs));
+      const auto band = (other ? *other : sd).read("surf_geopotential", 0);
+      if (band.size() != J * I) fail("read_restart: surf_geopotential of the restart file does not match the namelist's resolution" + std::string(h->cfg.world_size > 1 ? " and number of ranks" : ""));
+      sg.insert(sg.end(), band.begin(), band.end());
+    }
+    if (isca_dyn_set_surf_geopotential(h, sg.data(), sg.size())) fail(std::string("read_restart: surf_geopotential: ") + isca_last_error());
   }
   if (isca_dyn_set_time_pointers(h, prev, cur, prev == cur ? 0 : 1)) fail(isca_last_error());
   const auto tracers = tracer_files(h, names);
@@ -416,13 +436,19 @@ void read_restart(isca_dyn_t *h, const std::string &dir, const char *names) {
     }
   }
   if (at && at->has("wg_full")) { const auto v = at->read("wg_full", 0); set(h, "wg_full", 1, v.data(), v.size()); }
-  if (h->cfg.physics == 1 && file_exists(dir + "/mixed_layer.res.nc")) {      // mixed_layer_init: the restart file, else the prescribed distribution
-    Nc3File ml(dir + "/mixed_layer.res.nc");
+  if (h->cfg.physics == 1 && file_exists(dir + "/mixed_layer.res.nc" + sfx)) {      // mixed_layer_init: the restart file, else the prescribed distribution
+    Nc3File ml(dir + "/mixed_layer.res.nc" + sfx);
     const auto v = ml.read("t_surf", 0);
     if (v.size() != J * I) fail("mixed_layer_init: resolution of mixed_layer.res does not match the namelist");
     set(h, "t_surf", 1, v.data(), v.size());
   }
-  if (isca_dyn_refresh_derived(h)) fail(isca_last_error());
+  if (h->cfg.world_size > 1) {
+    for (const char *nm : {"dxT", "dyT", "dxlp", "dylp"}) {
+      if (!sd.has(nm)) fail(std::string("read_restart: the piece of a distributed restart file lacks ") + nm);
+      const auto v = sd.read(nm, 0);
+      set(h, nm, 1, v.data(), v.size());
+    }
+  } else if (isca_dyn_refresh_derived(h)) fail(isca_last_error());
   // vorg, divg are restart variables of the reference too (spectral_dynamics.F90:1518-1519, read back :566-567): with raw_filter_coeff /= 1 they
   // belong to the new level BEFORE the filter's adjustment (:933-934 vs :1031), which the adjusted spectral state cannot give back
   if (sd.has("vorg") && sd.has("divg")) {
@@ -448,8 +474,8 @@ extern "C" int isca_dyn_read_restart(isca_dyn_t *h, const char *directory, const
   read_restart(h, directory, tracer_names);
   RS_END
 }
-extern "C" int isca_dyn_restart_exists(const char *directory) {
-  return directory && file_exists(std::string(directory) + "/spectral_dynamics.res.nc") ? 1 : 0;
+extern "C" int isca_dyn_restart_exists(const char *directory) {      // (one file, or the pieces of a distributed one)
+  return directory && (file_exists(std::string(directory) + "/spectral_dynamics.res.nc") || file_exists(std::string(directory) + "/spectral_dynamics.res.nc.0000")) ? 1 : 0;
 }
 // The file layer alone, without a device (the CPU tests): writes a small fms_io-style file with known contents to `out_path` (when given) and
 // returns in sums[0..2] the sum, the first and the last value of variable `var_name`, record `record`, of `in_path` (when given).

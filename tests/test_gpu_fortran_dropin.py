@@ -239,3 +239,50 @@ def test_atmosphere_mod_restarts_from_fortran(tmp_path, golden_dir, moist):
         t, u = dc.get("tg"), dc.get("ug")
         assert [t.min(), t.max(), np.abs(u).max()] == whole[:3]
         dc.close()
+
+
+def test_atmosphere_mod_sharded_fortran_host(tmp_path):
+    """A multi-rank Fortran host (the decomposition contract of spec_mpp.F90:61-80 / atmosphere_domain, atmosphere.F90:390): two processes of atmos_model's
+    loop on this repository's atmosphere_mod, each holding a latitude band (get_grid_domain returns its rows), the library dealing the zonal
+    wavenumbers and issuing the lat <-> m exchanges itself (transforms.F90:970-1056) -- rank and number of ranks from the environment
+    (isca_env_rank: this mpp has no MPI), the communicator's id through ISCA_COMM_ID_FILE, ISCA_COMM=ipc because the two share this box's GPU.
+    36 steps against the one-process run; then 20 steps, RESTART/*.res.nc.NNNN (every rank's piece of a distributed file), and 16 more from INPUT/:
+    exactly where the two-rank run without the restart lands."""
+    import subprocess
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+
+    def prepare(d, nsteps):
+        mg.prepare_rundir(d, "T21", 8, "run", nsteps=nsteps, dt=600)
+        open(os.path.join(d, "drive.nml"), "w").write(f" &drive_nml\n   nsteps = {nsteps}, dt_atmos = 600\n /\n")
+        return d
+
+    def run_ranks(d, nranks):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc", ISCA_IPC_TIMEOUT_S="300", ISCA_WORLD_SIZE=str(nranks), ISCA_LOCAL_RANK="0",
+                   ISCA_COMM_ID_FILE=os.path.join(d, "comm_id"))
+        procs = [subprocess.Popen(f"ulimit -s unlimited; exec {exe}", shell=True, cwd=d, executable="/bin/bash", text=True, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, env=dict(env, ISCA_RANK=str(r))) for r in range(nranks)]
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+        rows, st = [], []
+        for o in outs:
+            rows.append(tuple(int(x) for x in re.search(r"DRIVE_ROWS js,je=\s*(\d+)\s+(\d+)", o).groups()))
+            st.append([float(x) for x in re.search(r"DRIVE_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", o).groups()])
+        return rows, [min(s[0] for s in st), max(s[1] for s in st), max(s[2] for s in st)]
+
+    rows1, one = run_ranks(prepare(str(tmp_path / "one"), 36), 1)
+    rows2, two = run_ranks(prepare(str(tmp_path / "two"), 36), 2)
+    assert rows1 == [(1, 32)] and rows2 == [(1, 16), (17, 32)], (rows1, rows2)
+    print("one rank:", one, " two ranks:", two)
+    assert max(abs(a - b) for a, b in zip(one, two)) < 1e-10, (one, two)
+    d1 = prepare(str(tmp_path / "seg1"), 20)
+    run_ranks(d1, 2)
+    for fn in ("spectral_dynamics.res.nc", "atmosphere.res.nc"):
+        for r in range(2):
+            assert os.path.exists(os.path.join(d1, "RESTART", f"{fn}.{r:04d}")), (fn, r)
+    d2 = prepare(str(tmp_path / "seg2"), 16)
+    os.rename(os.path.join(d1, "RESTART"), os.path.join(d2, "INPUT"))
+    _, cont = run_ranks(d2, 2)
+    assert cont == two, (two, cont)
