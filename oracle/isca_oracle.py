@@ -55,6 +55,7 @@ class Config:
     exponent: float = 7.5
     surf_res: float = 0.5
     vert_coord_option: str = "uneven_sigma"
+    vert_difference_option: str = "simmons_and_burridge"     # or 'mcm' (spectral_dynamics.F90:1084, press_and_geopot.F90:196, implicit.F90:404, 447)
     do_mass_correction: bool = True
     do_energy_correction: bool = True
     do_water_correction: bool = True
@@ -379,6 +380,11 @@ class SpectralCore:
         p_half = self.pk.reshape((-1,) + (1,) * ps.ndim) + self.bk.reshape((-1,) + (1,) * ps.ndim) * ps
         ln_p_half = np.zeros(sh)
         ln_p_full = np.zeros((self.L,) + ps.shape)
+        if self.cfg.vert_difference_option == "mcm":            # :196-210
+            p_full = 0.5 * (p_half[1:] + p_half[:-1])
+            k0 = 1 if (self.pk[0] == 0.0 and self.bk[0] == 0.0) else 0
+            ln_p_half[k0:] = np.log(p_half[k0:])
+            return p_half, ln_p_half, p_full, np.log(p_full)
         if self.pk[0] == 0.0 and self.bk[0] == 0.0:
             ln_p_half[1:] = np.log(p_half[1:])
             for k in range(1, self.L):
@@ -425,13 +431,14 @@ class SpectralCore:
             dlog_1 = ln_p_half[k + 1] - ln_p_full[k]
             dlog_2 = ln_p_full[k] - ln_p_half[k]
             dlog_3 = ln_p_half[k + 1] - ln_p_half[k]
+            mcm = self.cfg.vert_difference_option == "mcm"      # :1084-1099
             x1 = (self.bk[k + 1] * dlog_1 + self.bk[k] * dlog_2) * dp_inv
-            x2 = x1 * dx_ps
-            x3 = x1 * dy_ps
+            x2 = dx_ps * (1.0 / ps) if mcm else x1 * dx_ps
+            x3 = dy_ps * (1.0 / ps) if mcm else x1 * dy_ps
             dt_u[k] = dt_u[k] - RDGAS * t[k] * x2
             dt_v[k] = dt_v[k] - RDGAS * t[k] * x3
             dmean = divg[k] * dp + self.dbk[k] * (u[k] * dx_ps + v[k] * dy_ps)
-            x4 = (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
+            x4 = (dmean_tot + 0.5 * dmean) / p_full[k] if mcm else (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
             x5 = x4 - u[k] * x2 - v[k] * x3
             dt_t[k] = dt_t[k] - KAPPA * t[k] * x5
             wg_full[k] = -x5 * p_full[k]
@@ -513,7 +520,11 @@ class SpectralCore:
             dlog_1 = self.ref_ln_p_half[k + 1] - self.ref_ln_p_full[k]
             dlog_3 = self.ref_ln_p_half[k + 1] - self.ref_ln_p_half[k]
             dmean = div[k] * dp
-            dt_t[k] = -KAPPA * t_ref[k] * (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
+            if self.cfg.vert_difference_option == "mcm":        # :447-456
+                p_full_ref = 0.5 * (self.pk[k + 1] + self.pk[k]) + 0.5 * (self.bk[k + 1] + self.bk[k]) * self.ref_surf_p_implicit
+                dt_t[k] = -(KAPPA * t_ref[k] / p_full_ref) * (dmean_tot + 0.5 * dmean)
+            else:
+                dt_t[k] = -KAPPA * t_ref[k] * (dmean_tot * dlog_3 + dmean * dlog_1) * dp_inv
             dmean_tot = dmean_tot + dmean
             vert_vel[k + 1] = -dmean_tot
         dt_p_surf = -dmean_tot
@@ -567,6 +578,8 @@ class SpectralCore:
         dlog_1 = self.ref_ln_p_half[1:] - self.ref_ln_p_full
         dlog_2 = self.ref_ln_p_full - self.ref_ln_p_half[:-1]
         h1 = RDGAS * t * (self.bk[1:] * dlog_1 + self.bk[:-1] * dlog_2) / (self.dpk + self.dbk * pref)
+        if c.vert_difference_option == "mcm":                   # pres_grad_funct :404-408
+            h1 = RDGAS * t / pref
         h2 = self.linear_geopotential(np.zeros(L), del_ln_p_half, del_ln_p_full)
         self.h = h1 + h2
         self.div_mat = np.outer(self.h, nu) + gamma @ tau

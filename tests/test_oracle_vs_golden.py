@@ -185,6 +185,20 @@ def test_damping_options(golden_dir, case):
     assert rel(s["tg"], g["st_tg_000036"]) < 1e-12 and rel(s["psg"], g["st_psg_000036"]) < 1e-12
 
 
+def test_vert_difference_mcm(golden_dir):
+    """vert_difference_option = 'mcm' (four_in_one spectral_dynamics.F90:1084-1099, pressure_variables press_and_geopot.F90:196-210, the linear
+    operator implicit.F90:404-408, 447-456) in the numpy restatement against 48 reference steps at T21L8."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_mcm.npz"))
+    sc = core("T21", 8, vert_difference_option="mcm"); sc.cold_start()
+    for i in range(1, 49):
+        sc.step()
+        if i in (1, 2, 48):
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
