@@ -204,9 +204,6 @@ static void check_config(const isca_dyn_config &c) {
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
   if (c.num_tracers > 1) {
-    for (int k = 1; k < c.num_tracers; ++k)
-      if (c.world_size != 1 && c.tracer_spectral[k] != 0)
-        fail("a 'spectral' tracer needs transforms of its own, which the sharded step does not exchange: world_size must be 1 (further 'grid' tracers are carried)");
     if (c.raw_filter_coeff != 1.0) fail("more than one tracer: raw_filter_coeff must be 1");
     for (int k = 1; k < c.num_tracers; ++k) {
       if (c.tracer_spectral[k] != 0 && c.tracer_spectral[k] != 1)
@@ -611,14 +608,25 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
 static void require_single(isca_dyn *h, const char *what) {
   if (h->g.P != 1) fail(std::string(what) + ": only available with world_size == 1 (use the phase API)");
 }
+// The staged transform pair on more than one rank: the lat <-> m exchange (transpose_fourier / reverse_transpose_fourier, transforms.F90:970-1056)
+// between the two stages, issued by the library's communicator like the step's own -- blocks of Ml * Jl * C doubles per peer, whatever the
+// batch's column pitch C.  (Without a communicator the host drives the step phase by phase and these transforms are not reachable.)
+static void staged_exchange(isca_dyn *h, const double *send, double *recv, int C, const char *what) {
+  if (h->g.P == 1) return;
+  if (!h->comm) fail(std::string(what) + ": on more than one rank the transform's exchange needs the library's communicator (isca_dyn_comm_init)");
+  Timed t(h, what);
+  h->comm->all_to_all(send, recv, (size_t)h->g.Ml * h->g.Jl * C, h->stream);
+}
 static void run_inverse(isca_dyn *h, const FieldList &fl, int full) {    // Si -> grid
   const int C = col_pitch(fl.ncol);
   { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, C, full, h->cfg.legendre_impl, h->stream); }
+  staged_exchange(h, h->d.Fi_s, h->d.Fi_g, C, "all_to_all_inv");
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
 }
 static void run_forward(isca_dyn *h, const FieldList &fl, int full) {    // grid -> Sf
   const int C = col_pitch(fl.ncol);
   { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, fl, h->d.Ff_g, h->stream); }
+  staged_exchange(h, h->d.Ff_g, h->d.Ff_s, C, "all_to_all_fwd");
   { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, C, full, h->cfg.legendre_impl, h->stream); }
 }
 static FieldList single_list(double *gptr, int nlev, int op) {

@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--moist", action="store_true", help="the moist physics package (Frierson) instead of hs_forcing")
     ap.add_argument("--raw", type=float, default=1.0, help="raw_filter_coeff (/= 1: the Robert-Asselin-Williams filter's third exchange)")
     ap.add_argument("--tracers", type=int, default=1, help="grid tracers of the field_table (further ones: their own halo rows)")
+    ap.add_argument("--spectral", type=int, default=0, help="this tracer (2..) is a 'spectral' one with hole_filling = on: its transforms' exchanges are the library's (native loop only)")
     ap.add_argument("--expect-comm", default="", help="'ipc': the library's own C++ step loop must be the driver (ISCA_COMM=ipc), not torch")
     ap.add_argument("--opts", default="", help="further integer configuration keys, e.g. vert_advect_uv=2,vert_advect_t=3,use_implicit=0")
     ap.add_argument("--fatal", action="store_true", help="valid_range_t that only SOME bands leave: every rank must raise")
@@ -33,6 +34,9 @@ def main():
         extra["raw_filter_coeff"] = a.raw
     if a.tracers > 1:
         extra.update(num_tracers=a.tracers, tracer_robert_coeff=[-1.0, 0.05, 0.0, -1.0])
+    if a.spectral:
+        extra.update(tracer_spectral=[1 if k + 1 == a.spectral else 0 for k in range(4)], tracer_hole_filling=[1 if k + 1 == a.spectral else 0 for k in range(4)],
+                     tracer_robert_coeff=[-1.0, 0.05, -1.0, -1.0])
     for kv in filter(None, a.opts.split(",")):
         k, v = kv.split("=")
         extra[k] = float(v) if "." in v else int(v)
@@ -91,14 +95,23 @@ def main():
             err = np.max(np.abs(v[..., owned] - r[..., owned])) / max(np.max(np.abs(r)), 1e-300)
             print(f"  spectral {k:6s} (rank-0 wavenumbers) err={err:.3e}")
             ok &= bool(err < 1e-10)
-    # restart of the sharded run: rank 0 writes the combined files, every rank reads its band back
+    # restart of the sharded run: rank 0 writes the combined files, every rank reads its band back; with a spectral tracer (whose coefficients the
+    # gathered files do not carry) every rank writes and reads its own piece through the library (isca_dyn_write_restart: <name>.nc.NNNN)
     import tempfile
     box = [tempfile.mkdtemp(prefix="isca_res_") if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    sh.write_restart(box[0])
-    dist.barrier()
-    sh2 = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, **extra))
-    sh2.read_restart(box[0])
+    sh2 = None
+    if a.spectral:
+        more = more + [f"trs{a.spectral}"]
+        sh.write_restart_files(box[0])
+        dist.barrier()
+        sh2 = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, **extra))
+        sh2.read_restart_files(box[0])
+    else:
+        sh.write_restart(box[0])
+        dist.barrier()
+        sh2 = ShardedDynCore(dyncore.default_config(a.res, num_levels=a.levels, rank=rank, world_size=world, device=dev, **extra))
+        sh2.read_restart(box[0])
     if a.moist:      # a restarted moist run starts with gust = 1 m/s again (idealized_moist_phys_init): put the running one in the same state
         sh.set_time_pointers(sh.info("previous"), sh.info("current"), sh.info("step"))
     sh.step(4); sh2.step(4)

@@ -906,6 +906,8 @@ def test_sharded_device_path_matches_single(world, res, levels, raw, tracers):
     (4, "T170", 60, 1.0, 1, []),               # BASELINE configs[4] (T170L60) sharded
     (2, "T21", 8, 1.0, 1, ["--opts", "vert_advect_uv=2,vert_advect_t=3"]),      # van Leer / PPM vertical advection of u, v, T (column-local: no exchange of its own)
     (4, "T21", 8, 1.0, 1, ["--opts", "use_implicit=0,dt_atmos=300.0"]),
+    (2, "T21", 8, 1.0, 3, ["--spectral", "3"]),            # a 'spectral' tracer (hole_filling = on) sharded: its three transforms' exchanges are the library's
+    (4, "T42", 8, 1.0, 3, ["--spectral", "2"]),
 ])
 def test_sharded_native_loop(world, res, levels, raw, tracers, extra):
     """The library's OWN sharded step loop (api.hip sharded_step: halo exchange, lat -> m all-to-all, m -> lat all-to-all, all-reduce,
