@@ -662,6 +662,7 @@ static void synthesize_level(isca_dyn *h, int tl) {
   FieldList fl = inverse_list(h, tl);
   if (h->fuse_synth) {     // the step's own synthesis kernel: a restarted run then continues bit for bit
     { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, col_pitch(fl.ncol), 0, h->cfg.legendre_impl, h->stream, tl); }
+    staged_exchange(h, h->d.Fi_s, h->d.Fi_g, col_pitch(fl.ncol), "all_to_all_inv");
     { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
     return;
   }
@@ -875,6 +876,7 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
 
 static void raw_gradients_a(isca_dyn *h, int tl);
 static void raw_phase_b(isca_dyn *h);
+static int raw_pitch(const isca_dyn *h);
 // vorg, divg and the gradient fields of the `current` level from its spectral state; the caller's grid
 // u, v, T, ps of that level are kept bit for bit (the synthesis would reproduce them only to roundoff)
 static void refresh_derived(isca_dyn *h) {
@@ -887,6 +889,7 @@ static void refresh_derived(isca_dyn *h) {
   synthesize_level(h, tl);
   if (h->cfg.raw_filter_coeff != 1.0) {      // the running model takes the gradients of the (adjusted) level through the RAW phase's own
     raw_gradients_a(h, tl);                  // kernels (raw_filter_phase): the same here, so that a restarted run continues bit for bit
+    staged_exchange(h, h->d.Fi_s, h->d.Fi_g, raw_pitch(h), "all_to_all_raw");
     raw_phase_b(h);
   }
   dcopy(h, d.ug[tl], d.scratch_g[0], ng3); dcopy(h, d.vg[tl], d.scratch_g[1], ng3);
@@ -897,7 +900,8 @@ static void refresh_derived(isca_dyn *h) {
 // its grid fields, then every derived grid field of that level
 extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
   API_BEGIN
-  require_single(h, "complete_update");
+  if (!h) fail("null handle");
+  if (h->g.P != 1 && !h->comm) require_single(h, "complete_update");      // (collective over the ranks with the library's communicator)
   materialize(h);
   const int tl = (time_level == 0) ? h->previous : h->current;
   Dev &d = h->d;
@@ -935,7 +939,7 @@ extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int curre
 extern "C" int isca_dyn_refresh_derived(isca_dyn_t *h) {
   API_BEGIN
   if (!h || !h->have_state) fail("refresh_derived: no state");
-  require_single(h, "refresh_derived");
+  if (h->g.P != 1 && !h->comm) require_single(h, "refresh_derived");      // (collective over the ranks with the library's communicator: the synthesis' exchange)
   refresh_derived(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   API_END

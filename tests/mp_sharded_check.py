@@ -95,6 +95,22 @@ def main():
             err = np.max(np.abs(v[..., owned] - r[..., owned])) / max(np.max(np.abs(r)), 1e-300)
             print(f"  spectral {k:6s} (rank-0 wavenumbers) err={err:.3e}")
             ok &= bool(err < 1e-10)
+    if a.expect_comm:
+        # isca_dyn_refresh_derived on more than one rank (collective; the synthesis' lat <-> m exchange through the library's communicator): the
+        # step's own synthesis kernels re-derive vorg, divg and the gradients of the current level bit for bit
+        # (with the RAW filter vorg, divg belong to the new level BEFORE its adjustment, spectral_dynamics.F90:933-934 vs :1031: a restart takes them from the file)
+        names = ("dxT", "dyT", "dxlp", "dylp") + (("vorg", "divg") if a.raw == 1.0 else ())
+        before = {k: sh.get(k) for k in names}
+        vd = {k: sh.get(k) for k in ("vorg", "divg")}
+        sh.refresh_derived()
+        if a.raw != 1.0:
+            sh.set("vorg", vd["vorg"]); sh.set("divg", vd["divg"])
+        same_d = all(np.array_equal(before[k], sh.get(k)) for k in names)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(same_d))
+        if rank == 0:
+            print(f"sharded x{world} refresh_derived reproduces the derived fields on every rank: {all(flags)}")
+            ok &= all(flags)
     # restart of the sharded run: rank 0 writes the combined files, every rank reads its band back; with a spectral tracer (whose coefficients the
     # gathered files do not carry) every rank writes and reads its own piece through the library (isca_dyn_write_restart: <name>.nc.NNNN)
     import tempfile
