@@ -91,15 +91,16 @@ KERNEL_OF = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": 
              "fixer_sums": "k_fixer_sums", "fixer_finish": "k_fixer_finish"}
 
 
-def algorithmic_bytes(I, J, M1, N, L, tracer=True):
+def algorithmic_bytes(I, J, M1, N, L, tracer=True, nlf_inv=None):
     """SURVEY 8d / DESIGN.md 4: ALGORITHMIC bytes per launch of the step's kernels (every array touched once) -- the numerator of `achieved`"""
     field = 8.0 * I * J * L
     tri = 16.0 * (N + 1) * (N + 2) / 2 * L                             # one complex 3-D spectral field inside the triangle
     fourier = lambda nlf: nlf * 16.0 * M1 * J                          # the Fourier rows of nlf level-fields
     spec = lambda nlf: nlf * 16.0 * (N + 1) * (N + 4) / 2
+    nlf_inv = nlf_inv or 7 * L + 3       # level-fields of the Legendre synthesis: 6 L + 2 when the inverse FFT forms d/dx of T and ln ps from their Fourier rows
     b = {"column": 14.0 * field,                                       # ~14 L-level field passes
-         "fft_fwd": (4 * L + 1) * 8.0 * I * J + fourier(4 * L + 1), "fft_inv": (7 * L + 3) * 8.0 * I * J + fourier(7 * L + 3),
-         "legendre_fwd": fourier(4 * L + 1) + spec(4 * L + 1), "legendre_inv": fourier(7 * L + 3) + spec(7 * L + 3),
+         "fft_fwd": (4 * L + 1) * 8.0 * I * J + fourier(4 * L + 1), "fft_inv": (7 * L + 3) * 8.0 * I * J + fourier(nlf_inv),
+         "legendre_fwd": fourier(4 * L + 1) + spec(4 * L + 1), "legendre_inv": fourier(nlf_inv) + spec(nlf_inv),
          "spec_update": 5.0 * 3.0 * tri,                               # read prev, cur, tendency; write cur, future -- of vors, divs, ts
          "fixer_sums": 3.0 * field}
     if tracer:
@@ -108,17 +109,17 @@ def algorithmic_bytes(I, J, M1, N, L, tracer=True):
     return b
 
 
-def kernel_rooflines(kt, I, J, M1, N, L):
+def kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=None):
     """Per-kernel achieved rates from the HIP-event durations `kt` (ms) and the ALGORITHMIC work per launch."""
     field_bytes = 8.0 * I * J * L
     leg_flops_lf = J * (N + 1) * (N + 4)                             # per level-field
-    alg = algorithmic_bytes(I, J, M1, N, L)
+    alg = algorithmic_bytes(I, J, M1, N, L, nlf_inv=nlf_inv)
     kern = {}
     for nm in ("column", "fft_fwd", "fft_inv", "spec_update", "fixer_sums", "tracer_horiz", "tracer_vert"):
         if nm in kt and kt[nm] > 0:
             g = alg[nm] / (kt[nm] * 1e-3) / 1e9
             kern[nm] = {"bound": "hbm", "ms": kt[nm], "achieved_GBs": g, "frac": g / HBM_PEAK_GBS}
-    for nm, nlf in (("legendre_fwd", 4 * L + 1), ("legendre_inv", 7 * L + 3)):
+    for nm, nlf in (("legendre_fwd", 4 * L + 1), ("legendre_inv", nlf_inv or 7 * L + 3)):       # the flops of the level-fields the kernel actually transforms
         if nm in kt and kt[nm] > 0:
             tf = nlf * leg_flops_lf / (kt[nm] * 1e-3) / 1e12
             kern[nm] = {"bound": "mfma", "ms": kt[nm], "achieved_TFs": tf, "frac": tf / FP64_MFMA_PEAK_TF,
@@ -145,16 +146,16 @@ def dominant_roofline(kt, kern, traffic, traffic_source):
             "frac": ach / peak, "traffic": tr, "traffic_source": traffic_source if tr is not None else None, "avg_launch_ms": c["ms"]}
 
 
-def step_bytes(kt, traffic, traffic_source, I, J, M1, N, L):
+def step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=None):
     """Step level: the algorithmic MINIMUM -- every array touched once, i.e. the transforms WITHOUT the Fourier intermediate,
     which a fused Legendre <-> FFT stage would keep on chip -- against the sum of the kernels' counter-measured HBM bytes (committed PMC
     passes); `fourier_intermediate_bytes` is what the separate FFT and Legendre kernels move on top of the minimum by construction."""
-    alg = algorithmic_bytes(I, J, M1, N, L, tracer="tracer_horiz" in kt)
+    alg = algorithmic_bytes(I, J, M1, N, L, tracer="tracer_horiz" in kt, nlf_inv=nlf_inv)
     nlf = 11 * L + 4
     transforms = nlf * (8.0 * I * J + 16.0 * (N + 1) * (N + 4) / 2)
     a = transforms + sum(v for k, v in alg.items() if k in kt and not k.startswith(("fft_", "legendre_")))
     pm = [traffic.get(KERNEL_OF[k], traffic.get(KERNEL_OF[k].rstrip("3"))) for k in kt if k in KERNEL_OF and k != "moist_physics"]
-    out = {"algorithmic_bytes": a, "fourier_intermediate_bytes": 2.0 * nlf * 16.0 * M1 * J}
+    out = {"algorithmic_bytes": a, "fourier_intermediate_bytes": 2.0 * (4 * L + 1 + (nlf_inv or 7 * L + 3)) * 16.0 * M1 * J}
     if pm and all(x is not None for x in pm):
         out.update({"pmc_bytes": sum(pm), "pmc_over_algorithmic": sum(pm) / a, "pmc_source": traffic_source})
     return out
@@ -245,7 +246,7 @@ def other_workloads(device):
             core.cold_start(); core.step(nwarm)
             t0 = time.time(); core.step(nstep); sec = (time.time() - t0) / nstep
             core.kernel_times(True); core.step(min(nstep, 100)); kt = core.kernel_times(False)
-            kern = kernel_rooflines(kt, core.I, core.J, core.M1, core.cfg.num_fourier, core.L)
+            kern = kernel_rooflines(kt, core.I, core.J, core.M1, core.cfg.num_fourier, core.L, nlf_inv=core.info("inverse_batch"))
             traffic, src = load_traffic(name.split()[0] + ("_moist" if "Frierson" in name else ""))
             res[name] = {"ms_per_step": round(1e3 * sec, 4), "sim_years/day": round(sim_years_per_day(sec, kw["dt_atmos"]), 1),
                          "roofline": dominant_roofline(kt, kern, traffic, src), "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
@@ -420,11 +421,12 @@ def main():
     I, J, M1, N = core.I, core.J, core.M1, core.cfg.num_fourier
     # algorithmic bytes/flops per launch (DESIGN.md "Kernels") over the HIP-event durations of this run
     traffic, traffic_source = load_traffic(a.workload)
-    kern = kernel_rooflines(kt, I, J, M1, N, L)
+    nlf_inv = core.info("inverse_batch")
+    kern = kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=nlf_inv)
     roof = dominant_roofline(kt, kern, traffic, traffic_source)
     if roof is not None and roof["bound"] == "hbm":
         inv = {v: k for k, v in KERNEL_OF.items()}
-        roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(I, J, M1, N, L).get(inv.get(roof["kernel"]))
+        roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(I, J, M1, N, L, nlf_inv=nlf_inv).get(inv.get(roof["kernel"]))
     out = {
         "metric": "simulated-years/day at T85L40 Held-Suarez" if a.workload == "T85L40" else f"simulated-years/day at {a.workload} Held-Suarez",
         "value": sim_years_per_day(sec_per_step, dt), "unit": "sim_years/day", "n_gpus": a.gpus, "steps": a.steps,
@@ -439,7 +441,7 @@ def main():
                                     else "sphum advected (van Leer + PPM) on the main stream (small grid)") if a.gpus == 1
                                    else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
-        "step_bytes": step_bytes(kt, traffic, traffic_source, I, J, M1, N, L),
+        "step_bytes": step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=nlf_inv),
         "legendre_frac_of_fp64_mfma_peak": {k: round(kern[k]["frac"], 4) for k in ("legendre_fwd", "legendre_inv") if k in kern},
     }
     if steady_ms is not None:

@@ -227,7 +227,7 @@ int isca_dyn_refresh_derived(isca_dyn_t *h);
 /* tables: "sin_lat","wts_lat","deg_lat","deg_lon","pk","bk","legendre" (m,n,lat_max/2),
  * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
 int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
-int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer" */
+int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer","inverse_batch" (level-fields of the step's synthesis batch: 7 L + 3, or 6 L + 2 when the inverse FFT forms the x-derivatives) */
 /* Restart files written and read by the library itself, in the netCDF classic / 64-bit-offset format (what fms_io writes), without a netCDF
  * library: <directory>/spectral_dynamics.res.nc (spectral_dynamics_end, spectral_dynamics.F90:1502-1531: previous, current, pk, bk,
  * vors/divs/ts/ln_ps _real/_imag, ug, vg, tg, psg, every tracer by its field_table name (+ _real/_imag for a 'spectral' one), vorg, divg,

@@ -248,6 +248,15 @@ static FieldList inverse_list(isca_dyn *h, int tl) {
   int off = 0;
   for (int i = 0; i < 10; ++i) { f.g[i] = ig[i]; f.nlev[i] = (i < 7) ? L : 1; f.off[i] = off; f.op[i] = ops[i]; off += f.nlev[i]; }
   f.ncol = off;
+  if (h->dx_fourier) {
+    // d/dx of T and of ln p_s are i m / a times their Fourier coefficients (compute_gradient_cos' x part, spherical.F90:270-301; coef_dx = m fourier_inc / a),
+    // which the batch holds anyway: no Legendre synthesis, no Fourier rows and (sharded) no exchange volume of their own -- 6 L + 2 level-fields instead of
+    // 7 L + 3; the inverse FFT reads T's / ln p_s's rows a second time for them
+    const int boff[10] = {0, L, 2 * L, 3 * L, 4 * L, 4 * L, 5 * L, 6 * L, 6 * L, 6 * L + 1};
+    for (int i = 0; i < 10; ++i) { f.boff[i] = boff[i]; f.dx[i] = (i == 5 || i == 8) ? 1 : 0; }
+    f.nbuf = 6 * L + 2;
+    f.dxfac = (double)h->cfg.fourier_inc / h->cfg.radius;
+  }
   return f;
 }
 
@@ -583,6 +592,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
     h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc && cfg->fourier_inc == 1;      // the fused gather has the triangle's bounds built in
     if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
+    // x-derivatives in Fourier space: with the fused synthesis, the plain Robert filter (the RAW filter re-synthesises the gradients from the adjusted
+    // level in a batch of their own) and the lon_max = 256 / 512 FFT kernels
+    h->dx_fourier = h->fuse_synth && cfg->raw_filter_coeff == 1.0 && g.I >= 256 && (g.I & (g.I - 1)) == 0 && !getenv("ISCA_NO_DX_FOURIER") && !getenv("ISCA_FFT_OLD");
+    if (h->dx_fourier) h->Ci = col_pitch(6 * g.L + 2);
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     // Lazy fixers (core.h): for the plain configurations -- one grid tracer at most, Robert filter without the RAW term, no virtual
     // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
@@ -661,8 +674,9 @@ static void dev_vd_from_uv(isca_dyn *h, double *u, double *v, double *vor, doubl
 static void synthesize_level(isca_dyn *h, int tl) {
   FieldList fl = inverse_list(h, tl);
   if (h->fuse_synth) {     // the step's own synthesis kernel: a restarted run then continues bit for bit
-    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, col_pitch(fl.ncol), 0, h->cfg.legendre_impl, h->stream, tl); }
-    staged_exchange(h, h->d.Fi_s, h->d.Fi_g, col_pitch(fl.ncol), "all_to_all_inv");
+    const int C = col_pitch(fl.nbuf ? fl.nbuf : fl.ncol);
+    { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, C, 0, h->cfg.legendre_impl, h->stream, tl, h->dx_fourier); }
+    staged_exchange(h, h->d.Fi_s, h->d.Fi_g, C, "all_to_all_inv");
     { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
     return;
   }
@@ -1014,7 +1028,7 @@ static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, s
   if (!h->fuse_fwd) { Timed t(h, "legendre_fwd"); launch_legendre_forward(h->g, h->d, h->d.Ff_s, h->d.Sf, h->Cf, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   { Timed t(h, "spec_update"); launch_spec_update(*h, sc, h->stream); }
   if (h->fuse_synth) {
-    Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut);
+    Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, 0, h->cfg.legendre_impl, h->stream, sc.fut, h->dx_fourier);
   } else {
     { Timed t(h, "spec_synth_inputs"); launch_spec_synthesis_inputs(*h, sc.fut, h->stream); }
     { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
@@ -1543,6 +1557,7 @@ extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
   else if (nm == "tracer") *value = h->tracer_on ? 1 : 0;
   else if (nm == "tracer_env_off") *value = h->tracer_env_off ? 1 : 0;
   else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
+  else if (nm == "inverse_batch") *value = h->dx_fourier ? 6 * h->g.L + 2 : 7 * h->g.L + 3;      // level-fields of the step's Legendre synthesis
   else fail("unknown info " + nm);
   API_END
 }

@@ -38,6 +38,13 @@ struct FieldList {
   int nlev[MAX_FIELDS];
   int off[MAX_FIELDS];
   int op[MAX_FIELDS];       // applied to grid values: inverse: after FFT; forward: before FFT
+  // x-derivatives taken in Fourier space (inverse direction, k_fft_inv3): with nbuf != 0 the Fourier buffer holds nbuf columns, field f's rows come from
+  // buffer columns boff[f] + k, and a field with dx[f] != 0 is i m dxfac times the rows of the field it names -- d/d(lambda) / a of a field whose
+  // Fourier coefficients are in the buffer anyway (compute_gradient_cos' x part, spherical.F90:270-301, applied after the Legendre sum instead of before)
+  int nbuf = 0;
+  int boff[MAX_FIELDS] = {};
+  int dx[MAX_FIELDS] = {};
+  double dxfac = 0.0;
 };
 
 // geometry shared by all kernels
@@ -154,6 +161,7 @@ struct isca_dyn {
   std::vector<double> h_surf_geop;  // global (lat_max, lon_max) surface geopotential as handed over (empty = flat)
   int n_active = 0;
   bool fuse_synth = false;
+  bool dx_fourier = false;          // the step's synthesis batch carries no x-derivative fields: k_fft_inv3 forms dT/dx and d ln ps/dx from the Fourier rows of T and ln ps
   bool fuse_fwd = false;            // FFT + Legendre analysis of the step's forward batch in one kernel (ISCA_FUSE_FFT_LEG)
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_early = false;        // the horizontal tracer kernel forks BEFORE the column kernel (ISCA_TRACER_EARLY=1; see spectral_dynamics_init)

@@ -50,7 +50,7 @@ void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<
                               std::vector<double> &inv, std::vector<double> &scoef);
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s);
 // fused_tl >= 0: build the inverse-batch columns on the fly from the spectral state at that time level (S unused)
-void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl = -1);
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl = -1, int dxf = 0);
 
 // ---- spectral-space kernels
 // pack a spectral state array [Ml][N1][nlev] (complex) into columns of a work buffer, and back

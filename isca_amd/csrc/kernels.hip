@@ -455,21 +455,35 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
   const int t = threadIdx.x, r = t / TPR, tr = t % TPR;
   for (int k = t; k < 2 * NC; k += 256) twl[k] = tw[k];
   for (int m = t; m < NC; m += 256) slot[m] = slot_of_m[m < g.M1 ? m : 0];
+  int *rowc = slot + NC;                               // [ncol] row of the field list -> buffer column | x-derivative flag << 30 (FieldList::nbuf)
+  if (fl.nbuf)
+    for (int c = t; c < fl.ncol; c += 256) {
+      int f = 0;
+      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+      rowc[c] = (fl.boff[f] + (c - fl.off[f])) | (fl.dx[f] ? 1 << 30 : 0);
+    }
   FftTw<NC, true, TWREG> w;
   w.init(tw, twl, tr);
   const int rr = t % R;
   const int NG = GX * g.Jl;
   double2 Xn[8];
-  __syncthreads();                                     // twl, slot
-  auto request = [&](int item, double2 (&X)[8]) {      // wavenumbers above the truncation re-read m = 0 and are zeroed
+  __syncthreads();                                     // twl, slot, rowc
+  double dxn = -1.0;                                   // >= 0: the requested row is an x-derivative, i m dxn times the rows of the field it was read from
+  auto request = [&](int item, double2 (&X)[8], double &dxs) {      // wavenumbers above the truncation re-read m = 0 and are zeroed
     const int gx = item % GX, jl = item / GX;
-    const int ccl = min(gx * R + rr, fl.ncol - 1);
+    int ccl = min(gx * R + rr, fl.ncol - 1);
+    dxs = -1.0;
+    if (fl.nbuf) {                                     // the row's field decides which buffer column holds its coefficients (table built below)
+      const int rc = rowc[ccl];
+      ccl = rc & 0x3fffffff;
+      if (rc >> 30) dxs = fl.dxfac;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) X[i] = *(const double2 *)(Fg + ((size_t)slot[t / R + TPR * i] * g.Jl + jl) * C + 2 * ccl);
   };
   const FftRow<NC> ix(r), ixr(rr);
   int item = fft_first_item();
-  if (item < NG) request(item, Xn);
+  if (item < NG) request(item, Xn, dxn);
   for (; item < NG; item += gridDim.x) {
     const int gx = item % GX, jl = item / GX;
     {  // transforms.F90:424 zeroes everything above the truncation
@@ -478,11 +492,12 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
       for (int i = 0; i < 8; ++i) {
         const int m = t / R + TPR * i;
         double2 x = (m < g.M1 && cc < fl.ncol) ? Xn[i] : make_double2(0., 0.);
+        if (dxn >= 0.0) { const double dm = dxn * (double)m; x = make_double2(-dm * x.y, dm * x.x); }      // i m / a times the coefficient
         if (m == 0) x.y = 0.0;   // the real inverse FFT never references the imaginary part of the mean
         buf[ixr.at(m)] = x;
       }
     }
-    if (item + (int)gridDim.x < NG) request(item + gridDim.x, Xn);               // in flight during the transform
+    if (item + (int)gridDim.x < NG) request(item + gridDim.x, Xn, dxn);          // in flight during the transform
     __syncthreads();
     double2 z[8];
     // Z'[k] = (X[k] + conj X[Nc-k]) + i conj(W^k) (X[k] - conj X[Nc-k]),  X[Nc] = 0
@@ -864,7 +879,7 @@ static unsigned fft_grid(int items) {                  // persistent blocks: at 
 }
 static bool fft_old() { static const bool v = getenv("ISCA_FFT_OLD") != nullptr; return v; }   // measurement switch: the generic LDS passes
 static bool fft_twreg() { static const bool v = getenv("ISCA_FFT_TWLDS") == nullptr; return v; }    // pass twiddles in registers (default) or read from LDS
-static size_t fft3_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2) + NC * sizeof(int); }
+static size_t fft3_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2) + (NC + 7 * ISCA_MAX_LEVELS + 3) * sizeof(int); }      // rows, twiddles, slot of m, k_fft_inv3's row table
 static dim3 fft3_grid(int items) {                     // persistent blocks of 256 threads: 2 per CU (~196 VGPRs; measured against 3 and 4 per CU)
   static const int cap = getenv("ISCA_FFT_CAP") ? atoi(getenv("ISCA_FFT_CAP")) : 512;
   const int rounds = (items + cap - 1) / cap;
@@ -890,7 +905,8 @@ void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double
 #undef LF3
 }
 void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const double *Fg, hipStream_t s) {
-  const int C = col_pitch(fl.ncol), NC = g.I / 2;
+  const int C = col_pitch(fl.nbuf ? fl.nbuf : fl.ncol), NC = g.I / 2;
+  if (fl.nbuf && (NC < 128 || (NC & (NC - 1)) || fft_old())) throw std::runtime_error("fft: x-derivatives in Fourier space need the lon_max = 256 / 512 kernels");
   const int R = fft_rows(NC);
   const int GX = (fl.ncol + R - 1) / R;
   dim3 grid(fft_grid(GX * g.Jl));

@@ -208,7 +208,17 @@ struct LegInvArgs {
   const double *scoef;     // FUSED: [Ml][NR][5][4]
   int C, full, CB;         // CB: 32-column groups (= blocks) per wavenumber
   int NKS, JT, NR;         // k-steps per parity in the table (NHP/4), latitude tiles (Jh/16), rows of scoef per wavenumber
+  int dxf;                 // FUSED: the batch has no x-derivative columns (6 L + 2 level-fields: div, vor, u, v, T, dT/dy, ln ps, d ln ps / dy): the inverse FFT
+                           // forms them from the Fourier rows of T and ln ps (FieldList::dx)
 };
+// level-field index of a fused synthesis column -> field number of the full batch (0 div, 1 vor, 2 u, 3 v, 4 T, 5 dT/dx, 6 dT/dy, 7 ln ps, 8, 9 its gradient) and level
+__device__ __forceinline__ int leg_inv_field(int lf, int L, int dxf, int &k) {
+  const int n3 = dxf ? 6 : 7;
+  int f;
+  if (lf < n3 * L) { f = lf / L; k = lf - f * L; if (dxf && f == 5) f = 6; }
+  else { f = 7 + (lf - n3 * L); k = 0; if (dxf && f == 8) f = 9; }
+  return f;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Block = (wavenumber, 32-column group); its NW wavefronts own JTG latitude tiles each (all of them
@@ -239,8 +249,8 @@ __device__ __forceinline__ void leg_inv_coop(const Geom &g, const LegInvArgs &a,
   int soff = 0;                                     // not FUSED: offset of (ml, n = 0, c) in S
   if (FUSED) {
     const int lfr = c >> 1, lf = cok ? lfr : 0;
-    int f = 7 + (lf - 7 * L), k = 0;
-    if (lf < 7 * L) { f = lf / L; k = lf - f * L; }
+    int k;
+    const int f = leg_inv_field(lf, L, a.dxf, k);
     stride = (f < 7) ? L : 1;
     const size_t e0 = (f < 7) ? (size_t)ml * N1 * L + k : (size_t)ml * N1;
     const double2 *vor = (const double2 *)a.vor + e0, *div = (const double2 *)a.div + e0;
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void k_leg_inv_coop(Geom g, LegInvArg
   if (FUSED) {
     // columns that are plain copies of a state array (div, vor, T, ln ps) need no neighbour rows: block-uniform test
     const int L = g.L, lf0 = c0 >> 1, lf1 = min(lf0 + 15, (a.C >> 1) - 1);
-    auto field = [&](int lf) { return lf < 7 * L ? lf / L : 7 + (lf - 7 * L); };
+    auto field = [&](int lf) { int k_; return leg_inv_field(lf, L, a.dxf, k_); };
     const int f0 = field(lf0), f1 = field(lf1);
     if (f0 == f1 && (f0 == 0 || f0 == 1 || f0 == 4 || f0 == 7)) leg_inv_coop<NW, JTG, true, false>(g, a, ml, m, c0, wave, lane, Bbuf TRACE_PASS);
     else leg_inv_coop<NW, JTG, true, true>(g, a, ml, m, c0, wave, lane, Bbuf TRACE_PASS);
@@ -596,13 +606,13 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
   }
 }
 
-void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl) {
+void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, double *Fs, int C, int full, int impl, hipStream_t s, int fused_tl, int dxf) {
   const bool mfma = legendre_mfma_ok(g, impl) && C % 2 == 0;
   if (fused_tl >= 0 && !mfma) throw std::runtime_error("fused synthesis needs the MFMA Legendre kernel");
   if (mfma) {
     LegInvArgs a;
     a.frag = d.leg_inv_frag; a.S = S; a.Fs = Fs; a.m_local = d.m_local; a.C = C; a.full = full;
-    a.vor = a.div = a.ts = a.lnps = nullptr; a.scoef = d.leg_scoef;
+    a.vor = a.div = a.ts = a.lnps = nullptr; a.scoef = d.leg_scoef; a.dxf = dxf;
     if (fused_tl >= 0) {
       if (full) throw std::runtime_error("fused synthesis: triangular bounds only");
       a.vor = d.vors[fused_tl]; a.div = d.divs[fused_tl]; a.ts = d.ts[fused_tl]; a.lnps = d.lnps[fused_tl];

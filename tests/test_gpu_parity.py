@@ -475,10 +475,12 @@ def test_golden_three_tracers(golden_dir):
     with pytest.raises(dyncore.IscaError, match="one block per tracer"):
         ext.dynamics(du, dv, dT, du)
     ref.close(); ext.close()
-    # a spectral tracer on a sharded run (further grid tracers are carried there: test_sharded_device_path_matches_single), a second tracer
-    # with the RAW filter, or one with an unknown representation is refused
-    with pytest.raises(dyncore.IscaError, match="'spectral' tracer needs transforms of its own"):
-        make("T21", 8, num_tracers=2, tracer_spectral=[0, 1, 0, 0], world_size=2, rank=0)
+    # a second tracer with the RAW filter, or one with an unknown representation is refused; a spectral tracer on a sharded run is carried since round 4
+    # (its transforms' exchanges are the library's: test_sharded_native_loop[...--spectral...]) -- the handle is created, a step without the communicator is refused
+    sh = make("T21", 8, num_tracers=2, tracer_spectral=[0, 1, 0, 0], world_size=2, rank=0); sh.cold_start()
+    with pytest.raises(dyncore.IscaError, match="needs isca_dyn_comm_init first"):
+        sh.step(1)
+    sh.close()
     with pytest.raises(dyncore.IscaError, match="raw_filter_coeff must be 1"):
         make("T21", 8, num_tracers=2, raw_filter_coeff=0.7)
     with pytest.raises(dyncore.IscaError, match="numerical_representation"):

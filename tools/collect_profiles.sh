@@ -18,6 +18,7 @@ for W in T85L40 T170L60; do
     timeout 200 rocprofv3 --kernel-trace --pmc $pm --output-format csv -d $OUT/pmc_$i -o p -- python bench.py --workload $W --steps 40 --warmup 10 --cpu-steps 0 > $OUT/pmc_$i.log 2>&1
   done
   python tools/summarize_profiles.py $OUT
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete      # the raw traces: gpurun brings back 64 MiB at most
 done
 # moist configuration (BASELINE configs[3] at T85L40) in a spun-up state: the profiler collects for 2 s from second 9 of a run that spins up
 # 10 000 steps (35 days: it rains; the moist kernel is 25 % slower than in the first days after the cold start) and then keeps stepping
@@ -30,6 +31,7 @@ for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
   timeout 200 rocprofv3 --kernel-trace --pmc $pm --output-format csv -d $OUT/pmc_$i -o p -- python tools/dev/moist_bench.py T85 40 300 short > $OUT/pmc_$i.log 2>&1
 done
 python tools/summarize_profiles.py $OUT
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 # the plain bench line of the headline workload (no profiler attached)
 unset ISCA_BENCH_NO_EXTRA
 timeout 600 python bench.py --steps 500 --warmup 50 > $TOP/bench_T85L40.json.log 2>&1
