@@ -255,6 +255,9 @@ static FieldList inverse_list(isca_dyn *h, int tl) {
     const int boff[10] = {0, L, 2 * L, 3 * L, 4 * L, 4 * L, 5 * L, 6 * L, 6 * L, 6 * L + 1};
     for (int i = 0; i < 10; ++i) { f.boff[i] = boff[i]; f.dx[i] = (i == 5 || i == 8) ? 1 : 0; }
     f.nbuf = 6 * L + 2;
+    // the rows of T and dT/dx alternate (both read T's coefficients: one work item, mostly one load instruction, instead of a second pass over them from
+    // L2 or -- at T170L60 -- from HBM); ln p_s and its x-derivative are neighbours in the list anyway
+    f.il_a = 4; f.il_b = 5; f.off[5] = f.off[4];
     f.dxfac = (double)h->cfg.fourier_inc / h->cfg.radius;
   }
   return f;

@@ -45,6 +45,9 @@ struct FieldList {
   int boff[MAX_FIELDS] = {};
   int dx[MAX_FIELDS] = {};
   double dxfac = 0.0;
+  // the rows of fields il_a and il_b alternate (a's level k, b's level k, a's level k + 1, ...) from row off[il_a] on: a field and its x-derivative side by
+  // side, so that the two rows' reads of the same Fourier coefficients fall into one work item (and mostly one load instruction) of k_fft_inv3
+  int il_a = -1, il_b = -1;
 };
 
 // geometry shared by all kernels

@@ -445,6 +445,17 @@ __global__ __launch_bounds__(256) void k_fft_fwd3(Geom g, FieldList fl, const do
   }
 }
 
+// row c of a field list -> (field, level); FieldList::il_a / il_b: two fields whose rows alternate
+__device__ __forceinline__ int fl_row(const FieldList &fl, int c, int &k) {
+  if (fl.il_a >= 0) {
+    const int base = fl.off[fl.il_a], d = c - base;
+    if (d >= 0 && d < 2 * fl.nlev[fl.il_a]) { k = d >> 1; return (d & 1) ? fl.il_b : fl.il_a; }
+  }
+  int f = 0;
+  while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
+  k = c - fl.off[f];
+  return f;
+}
 template <int NC, bool TWREG>
 __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const double *__restrict__ cosm, const int *__restrict__ slot_of_m,
                                                   const double2 *__restrict__ tw, const double *__restrict__ Fg, int C, int GX) {
@@ -458,9 +469,9 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
   int *rowc = slot + NC;                               // [ncol] row of the field list -> buffer column | x-derivative flag << 30 (FieldList::nbuf)
   if (fl.nbuf)
     for (int c = t; c < fl.ncol; c += 256) {
-      int f = 0;
-      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
-      rowc[c] = (fl.boff[f] + (c - fl.off[f])) | (fl.dx[f] ? 1 << 30 : 0);
+      int k;
+      const int f = fl_row(fl, c, k);
+      rowc[c] = (fl.boff[f] + k) | (fl.dx[f] ? 1 << 30 : 0);
     }
   FftTw<NC, true, TWREG> w;
   w.init(tw, twl, tr);
@@ -514,9 +525,8 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
     fft3_row<NC, true, TWREG>(z, buf, ix, w, tr);
     const int c = gx * R + r;
     if (c < fl.ncol) {
-      int f = 0;
-      while (f + 1 < fl.nf && c >= fl.off[f + 1]) ++f;
-      const int k = c - fl.off[f];
+      int k;
+      const int f = fl_row(fl, c, k);
       double2 *dst = (double2 *)(fl.g[f] + ((size_t)k * g.Jl + jl) * g.I);
       const int op = fl.op[f];
       const double scale = (op == OP_COSM) ? cosm[jl] : 1.0;
