@@ -251,14 +251,18 @@ static FieldList inverse_list(isca_dyn *h, int tl) {
   if (h->dx_fourier) {
     // d/dx of T and of ln p_s are i m / a times their Fourier coefficients (compute_gradient_cos' x part, spherical.F90:270-301; coef_dx = m fourier_inc / a),
     // which the batch holds anyway: no Legendre synthesis, no Fourier rows and (sharded) no exchange volume of their own -- 6 L + 2 level-fields instead of
-    // 7 L + 3; the inverse FFT reads T's / ln p_s's rows a second time for them
-    const int boff[10] = {0, L, 2 * L, 3 * L, 4 * L, 4 * L, 5 * L, 6 * L, 6 * L, 6 * L + 1};
-    for (int i = 0; i < 10; ++i) { f.boff[i] = boff[i]; f.dx[i] = (i == 5 || i == 8) ? 1 : 0; }
+    // 7 L + 3.  Buffer columns: div, vor, u, v, dT/dy, T, ln p_s, d ln p_s/dy.  Rows of the list: the same order with dT/dx's rows ALTERNATING with T's (both
+    // read T's coefficients: one work item, mostly one load instruction) and d ln p_s/dx next to ln p_s -- so rows and buffer columns run in the same order and
+    // the rows in front of the T block map to the same column number: an item's run of columns starts where it did (128-byte lines), which a block of
+    // derivative rows anywhere else in the list would shift for everything behind it (measured at T170L60: +88 MB of re-read lines per launch).
+    double *gp[10] = {d.divg, d.vorg, d.ug[tl], d.vg[tl], d.dyT, d.tg[tl], d.dxT, d.psg[tl], d.dxlp, d.dylp};
+    const int op2[10] = {OP_NONE, OP_NONE, OP_COSM, OP_COSM, OP_COSM, OP_NONE, OP_COSM, OP_EXP, OP_COSM, OP_COSM};
+    const int off2[10] = {0, L, 2 * L, 3 * L, 4 * L, 5 * L, 5 * L, 7 * L, 7 * L + 1, 7 * L + 2};
+    const int boff[10] = {0, L, 2 * L, 3 * L, 4 * L, 5 * L, 5 * L, 6 * L, 6 * L, 6 * L + 1};
+    for (int i = 0; i < 10; ++i) { f.g[i] = gp[i]; f.op[i] = op2[i]; f.off[i] = off2[i]; f.nlev[i] = (i < 7) ? L : 1; f.boff[i] = boff[i]; f.dx[i] = (i == 6 || i == 8) ? 1 : 0; }
     f.nbuf = 6 * L + 2;
-    // the rows of T and dT/dx alternate (both read T's coefficients: one work item, mostly one load instruction, instead of a second pass over them from
-    // L2 or -- at T170L60 -- from HBM); ln p_s and its x-derivative are neighbours in the list anyway
-    f.il_a = 4; f.il_b = 5; f.off[5] = f.off[4];
     f.dxfac = (double)h->cfg.fourier_inc / h->cfg.radius;
+    f.il_a = 5; f.il_b = 6;
   }
   return f;
 }

@@ -208,14 +208,14 @@ struct LegInvArgs {
   const double *scoef;     // FUSED: [Ml][NR][5][4]
   int C, full, CB;         // CB: 32-column groups (= blocks) per wavenumber
   int NKS, JT, NR;         // k-steps per parity in the table (NHP/4), latitude tiles (Jh/16), rows of scoef per wavenumber
-  int dxf;                 // FUSED: the batch has no x-derivative columns (6 L + 2 level-fields: div, vor, u, v, T, dT/dy, ln ps, d ln ps / dy): the inverse FFT
+  int dxf;                 // FUSED: the batch has no x-derivative columns (6 L + 2 level-fields: div, vor, u, v, dT/dy, T, ln ps, d ln ps / dy): the inverse FFT
                            // forms them from the Fourier rows of T and ln ps (FieldList::dx)
 };
 // level-field index of a fused synthesis column -> field number of the full batch (0 div, 1 vor, 2 u, 3 v, 4 T, 5 dT/dx, 6 dT/dy, 7 ln ps, 8, 9 its gradient) and level
 __device__ __forceinline__ int leg_inv_field(int lf, int L, int dxf, int &k) {
   const int n3 = dxf ? 6 : 7;
   int f;
-  if (lf < n3 * L) { f = lf / L; k = lf - f * L; if (dxf && f == 5) f = 6; }
+  if (lf < n3 * L) { f = lf / L; k = lf - f * L; if (dxf && f >= 4) f = (f == 4) ? 6 : 4; }      // (dxf: column group 4 is dT/dy, 5 is T)
   else { f = 7 + (lf - n3 * L); k = 0; if (dxf && f == 8) f = 9; }
   return f;
 }
