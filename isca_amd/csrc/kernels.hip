@@ -893,7 +893,11 @@ static size_t fft3_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC /
 static dim3 fft3_grid(int items) {                     // persistent blocks of 256 threads: 2 per CU (~196 VGPRs; measured against 3 and 4 per CU)
   static const int cap = getenv("ISCA_FFT_CAP") ? atoi(getenv("ISCA_FFT_CAP")) : 512;
   const int rounds = (items + cap - 1) / cap;
-  return dim3((unsigned)((items + rounds - 1) / rounds));
+  // a multiple of 8 blocks: fft_first_item then gives each XCD a contiguous run of items (neighbouring items share 128-byte lines of the Fourier buffer);
+  // with any other count it falls back to item = block, i.e. neighbours on different L2s.  (ISCA_FFT_G8=0: the count as it was, for measurements.)
+  static const bool g8 = !(getenv("ISCA_FFT_G8") && atoi(getenv("ISCA_FFT_G8")) == 0);
+  const int G = (items + rounds - 1) / rounds;
+  return dim3((unsigned)(g8 ? (G + 7) / 8 * 8 : G));
 }
 static size_t fft_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2); }
 
