@@ -322,10 +322,11 @@ def gaussian_topog(namelist: dict, deg_lon, deg_lat):
     return z
 
 
-def _get_topography(namelist: dict, surf_height):
+def _get_topography(namelist: dict, surf_height, land_mask=None):
     """get_topography (init/spectral_init_cond.F90:167-308): topography_option 'flat' | 'gaussian' (gaussian_topog_nml) | 'input' (the
-    [lat, lon] height field of INPUT/<topog_file_name> handed over as `surf_height`, spectrally truncated; the ocean-mask smoothing of
-    ocean_topog_smoothing /= 0 is not carried)."""
+    [lat, lon] height field `zsurf` and land mask `land_mask` of INPUT/<topog_file_name>, handed over as `surf_height` / `land_mask`:
+    spectrally truncated with ocean_topog_smoothing = 0, else regularised over the ocean -- compute_lambda + regularize of
+    topog_regularization_mod, :236-245; the namelist's DEFAULT is 0.93)."""
     nml = {g.lower(): {k.lower(): v for k, v in vals.items()} for g, vals in namelist.items()}
     opt = str(nml.get("spectral_init_cond_nml", {}).get("topography_option", "flat")).lower()
     c = _core
@@ -339,12 +340,22 @@ def _get_topography(namelist: dict, surf_height):
     elif opt == "input":
         if surf_height is None:
             raise IscaError("get_topography: topography_option=\"input\" needs the height field (atmosphere_init(..., surf_height=array))")
-        if float(nml.get("spectral_dynamics_nml", {}).get("ocean_topog_smoothing", 0.93)) != 0.0:
-            raise IscaError("get_topography: only ocean_topog_smoothing = 0 (spectral truncation of the topography) is supported")
+        smoothing = float(nml.get("spectral_dynamics_nml", {}).get("ocean_topog_smoothing", 0.93))          # spectral_dynamics.F90:184
         if c.cfg.world_size != 1:
             raise IscaError("get_topography: 'input' topography is truncated with the single-rank transforms; hand sharded runs the truncated field")
         g = dyncore.GRAV * np.asarray(surf_height, dtype=np.float64)
-        c.set_surf_geopotential(c.trans_filter(g))                                       # grid -> spherical -> grid (:229-235)
+        if smoothing == 0.0:
+            c.set_surf_geopotential(c.trans_filter(g))                                   # grid -> spherical -> grid (:229-235)
+        else:
+            if land_mask is None:
+                raise IscaError("get_topography: ocean_topog_smoothing /= 0 needs the land mask of the topography file (atmosphere_init(..., land_mask=array)); "
+                                "ocean_topog_smoothing = 0 only truncates")
+            from . import topog_regularization as tr
+            ocean = ~(np.asarray(land_mask, dtype=np.float64) > 0.0)                     # where(land_ones > 0.) ocean_mask = .false. (:223-227)
+            lam, _ = tr.compute_lambda(c, smoothing, ocean, g)
+            smoothed, frac = tr.regularize(c, lam, ocean, g)
+            print(f"\nMessage from subroutine get_topography:\nlambda={lam:16.8e}  fraction_smoothed={frac:16.8e}\n")
+            c.set_surf_geopotential(smoothed)
     else:
         raise IscaError(f'"{opt}" is an invalid value for topography_option.')
 
@@ -430,6 +441,7 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     if _core is not None:
         return _core                                   # `if(module_is_initialized) return`
     surf_height = overrides.pop("surf_height", None)
+    land_mask = overrides.pop("land_mask", None)
     names = None
     if field_table is not None:          # text of the run's field_table (Experiment: field_table_file); None = the dry default, one sphum grid tracer
         nml = parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {})
@@ -449,7 +461,7 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
         _core.tracer_names = names
     _run_dir = run_dir
     try:
-        _get_topography(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}), surf_height)
+        _get_topography(parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {}), surf_height, land_mask)
     except Exception:
         _core.close()
         _core = None

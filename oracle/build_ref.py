@@ -58,6 +58,10 @@ TARGETS = {
     "barotropic": dict(harness="ref_barotropic_harness.F90", exe="ref_barotropic_harness.x", build="build_barotropic",
                        scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_barotropic"],
                        cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"], skip=("socrates", "rrtm_radiation", "atmos_column")),
+    # topog_regularization_mod (ocean_topog_smoothing /= 0) driven through its two public routines: oracle/ref_topog_harness.F90
+    "topog": dict(harness="ref_topog_harness.F90", exe="ref_topog_harness.x", build="build_topog",
+                  scan=["shared", "atmos_spectral", "atmos_shared", "atmos_param/hs_forcing"],
+                  cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8"]),
     # The module-level drop-in (bindings/fortran/dropin): THIS REPOSITORY's modules under the reference's names (spectral_dynamics_mod,
     # transforms_mod, press_and_geopot_mod, hs_forcing_mod, ...) in front of isca_amd/lib/libisca_dyn.so, compiled together with the
     # reference's own infrastructure modules (fms_mod, time_manager_mod, tracer_manager_mod, ... from src/shared, in place) and linked with

@@ -420,6 +420,38 @@ def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_gr
     return out
 
 
+TOPOG_EXE = os.path.join(HERE, "_ref", "ref_topog_harness.x")
+
+
+def topog_inputs(res, seed=20260930):
+    """A synthetic land mask (two continents and an island chain) and height field (mountain ranges on the land, zero over the ocean) in m, [lat, lon]"""
+    lon, lat, nf, ns = RES[res]
+    rng = np.random.default_rng(seed)
+    x = (np.arange(lon) + 0.5) / lon * 360.0
+    y = -90.0 + (np.arange(lat) + 0.5) / lat * 180.0
+    X, Y = np.meshgrid(x, y)
+    land = ((np.abs(X - 90.0) < 40.0) & (np.abs(Y - 35.0) < 30.0)) | ((np.abs(X - 260.0) < 25.0) & (np.abs(Y + 10.0) < 45.0)) | \
+           ((np.abs(Y + 60.0) < 8.0) & (np.abs(((X - 150.0) % 40.0) - 20.0) < 6.0))
+    h = 3500.0 * np.exp(-((X - 95.0) / 15.0) ** 2 - ((Y - 35.0) / 9.0) ** 2) + 2500.0 * np.exp(-((X - 255.0) / 6.0) ** 2 - ((Y + 15.0) / 30.0) ** 2) + 300.0
+    h = h * (1.0 + 0.05 * rng.standard_normal(h.shape))
+    return np.where(land, h, 0.0), land.astype(np.float64)
+
+
+def golden_topog(res="T21", smoothing=0.8):
+    """topog_regularization_mod (ocean_topog_smoothing /= 0): compute_lambda + regularize of the reference on a synthetic height field and land mask"""
+    height, land = topog_inputs(res)
+    with tempfile.TemporaryDirectory(prefix="reft_") as d:
+        prepare_rundir(d, res, 8, "run", nsteps=1, dt=600)
+        open(os.path.join(d, "topog_harness.nml"), "w").write(f" &topog_harness_nml\n   ocean_topog_smoothing = {smoothing}\n /\n")
+        height.tofile(os.path.join(d, "in_height.bin")); land.tofile(os.path.join(d, "in_land.bin"))
+        stdout = run_harness(d, exe=TOPOG_EXE)
+        smoothed = np.fromfile(os.path.join(d, "out_smoothed.bin")).reshape(height.shape)
+        lam, frac = np.fromfile(os.path.join(d, "out_lambda_fraction.bin"))
+    print(re.findall(r"Message from subroutine regularize.*", stdout)[-3:])
+    return dict(in_height=height, in_land=land, out_smoothed_geopotential=smoothed, out_lambda=np.array(lam), out_fraction_smoothed=np.array(frac),
+                meta_res=np.array(res), meta_ocean_topog_smoothing=np.array(smoothing))
+
+
 def golden_developed(res="T42", L=25, day=60, dt=600, more=(1, 10), track=24):
     """A DEVELOPED state and the steps after it (configs[1] of BASELINE.json, T42L25 Held-Suarez): the reference runs `day` days from
     its cold start -- baroclinic eddies at finite amplitude, Courant numbers, polar rows, the sponge and the fixers all see weather --,
@@ -589,6 +621,9 @@ def main():
             "T31", 8, 36, (1, 2, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
         "run_T53L8": lambda: golden_run(
             "T53", 8, 36, (1, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|36)$", k) is not None),
+        # ocean_topog_smoothing (topog_regularization.F90): the reference's compute_lambda + regularize on a synthetic land mask and height field
+        "topog_regularize_T21": lambda: golden_topog("T21", 0.8),
+        "topog_regularize_T42": lambda: golden_topog("T42", 0.9),
         "run_T21L8_damping_res_independent": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_independent', damping_order = 2, damping_coeff = 2.0e16",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

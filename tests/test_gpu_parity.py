@@ -352,6 +352,39 @@ def test_golden_lon_max_with_factors_3_5(golden_dir, res, steps):
         make("T21", 8, lon_max=112, lat_max=64)            # 56 = 2^3 7
 
 
+@pytest.mark.parametrize("res", ["T21", "T42"])
+def test_golden_ocean_topog_smoothing(golden_dir, res):
+    """ocean_topog_smoothing /= 0 (topog_regularization.F90: compute_lambda :75-150, regularize :153-290 -- what get_topography does to an 'input' /
+    'interpolated' topography, spectral_init_cond.F90:236-245): the reference's two public routines, driven by oracle/ref_topog_harness.F90 on a
+    synthetic height field and land mask, against isca_amd/topog_regularization.py on the device's transforms: the same lambda from the secant
+    iteration, the same smoothed geopotential; then through the namelist mirror (topography_option = 'input' with the field and mask handed over)."""
+    from isca_amd import atmosphere as atm, topog_regularization as tr
+    g = np.load(os.path.join(golden_dir, f"topog_regularize_{res}.npz"))
+    dc = make(res, 8)
+    geop = dyncore.GRAV * g["in_height"]
+    ocean = ~(g["in_land"] > 0)
+    lam, frac = tr.compute_lambda(dc, float(g["meta_ocean_topog_smoothing"]), ocean, geop)
+    smoothed, frac2 = tr.regularize(dc, lam, ocean, geop)
+    err = rel(smoothed, g["out_smoothed_geopotential"])
+    print(res, "lambda", lam, float(g["out_lambda"]), "fraction", frac, float(g["out_fraction_smoothed"]), "smoothed geopotential err", err)
+    assert abs(lam / float(g["out_lambda"]) - 1) < 1e-9 and abs(frac - float(g["out_fraction_smoothed"])) < 1e-10 and frac2 == frac
+    assert err < 1e-9
+    assert rel(smoothed, geop) > 1e-2                           # it does something: the ripples over the ocean are gone
+    dc.close()
+    nml = {"spectral_dynamics_nml": dict(dyncore.RESOLUTIONS[res], num_levels=8, ocean_topog_smoothing=float(g["meta_ocean_topog_smoothing"]),
+                                        reference_sea_level_press=1.0e5, valid_range_t=[100., 800.]),
+           "spectral_init_cond_nml": {"topography_option": "input"}, "main_nml": {"dt_atmos": 600}}
+    with pytest.raises(dyncore.IscaError, match="needs the land mask"):
+        atm.atmosphere_init(nml, surf_height=g["in_height"])
+    core = atm.atmosphere_init(nml, surf_height=g["in_height"], land_mask=g["in_land"])
+    try:
+        assert rel(core.get("surf_geopotential"), g["out_smoothed_geopotential"]) < 1e-9
+        atm.atmosphere(3)
+        assert np.isfinite(core.get("tg")).all()
+    finally:
+        atm.atmosphere_end()
+
+
 def test_golden_vert_difference_mcm(golden_dir):
     """vert_difference_option = 'mcm' (spectral_dynamics.F90:1084-1099 four_in_one, press_and_geopot.F90:196-210 pressure_variables,
     implicit.F90:404-408, 447-456 the linear operator): 48 steps on the test case's sigma levels, and 36 steps on the 'mcm' vertical coordinate
