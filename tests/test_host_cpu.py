@@ -472,3 +472,32 @@ def test_restart_file_layer_against_scipy(tmp_path):
     assert lib.isca_restart_file_selftest(None, p.encode(), b"nothere", 0, sums) == 1 and b"has no variable nothere" in lib.isca_last_error()
     open(p, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
     assert lib.isca_restart_file_selftest(None, p.encode(), b"only", 0, sums) == 1 and b"netCDF-4" in lib.isca_last_error()
+
+
+def test_env_rank_sources(monkeypatch):
+    """isca_env_rank (the decomposition of a host without MPI of its own: the Fortran drop-in): ISCA_* first, then what torchrun, Open MPI, PMI and Slurm
+    export; one rank when nothing is set; inconsistent values are an error."""
+    import ctypes as C
+    from isca_amd import dyncore
+    lib = dyncore.load_library()
+    names = ["ISCA_RANK", "ISCA_WORLD_SIZE", "ISCA_LOCAL_RANK", "RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE",
+             "OMPI_COMM_WORLD_LOCAL_RANK", "PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID", "SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID"]
+
+    def ask(**env):
+        for n in names:
+            monkeypatch.delenv(n, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        r, w, l = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        rc = lib.isca_env_rank(C.byref(r), C.byref(w), C.byref(l))
+        return rc, r.value, w.value, l.value
+
+    assert ask() == (0, 0, 1, 0)
+    assert ask(ISCA_RANK=3, ISCA_WORLD_SIZE=8, ISCA_LOCAL_RANK=0) == (0, 3, 8, 0)
+    assert ask(RANK=5, WORLD_SIZE=8, LOCAL_RANK=5) == (0, 5, 8, 5)                       # torchrun
+    assert ask(OMPI_COMM_WORLD_RANK=2, OMPI_COMM_WORLD_SIZE=4, OMPI_COMM_WORLD_LOCAL_RANK=2) == (0, 2, 4, 2)
+    assert ask(PMI_RANK=1, PMI_SIZE=2) == (0, 1, 2, 1)                                   # no local rank given: the rank
+    assert ask(SLURM_PROCID=6, SLURM_NTASKS=16, SLURM_LOCALID=6) == (0, 6, 16, 6)
+    assert ask(ISCA_RANK=1, ISCA_WORLD_SIZE=2, RANK=7, WORLD_SIZE=8)[:3] == (0, 1, 2)    # ISCA_* wins
+    rc = ask(ISCA_RANK=4, ISCA_WORLD_SIZE=4)[0]
+    assert rc == 1 and b"inconsistent rank" in lib.isca_last_error()
