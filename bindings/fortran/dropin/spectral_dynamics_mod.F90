@@ -9,7 +9,7 @@
 ! vert_coord_option 'hybrid' / 'mcm' / 'v197' are formed here (named_vert_coord); topography_option 'gaussian' through the reference's own
 ! gaussian_topog_mod.  Restart files: INPUT/*.res.nc are read and RESTART/*.res.nc written by the library's own netCDF-classic code
 ! (isca_dyn_read_restart / isca_dyn_write_restart; the same files isca_amd/restart.py handles).  Not here:
-! topography_option = 'input' (a netCDF height field), initial_state_option other than 'quiescent'.  Each is refused with
+! topography_option = 'interpolated' (the data files of topography_mod), initial_state_option other than 'quiescent'.  Each is refused with
 ! error_mesg(..., FATAL) naming the option.
 module spectral_dynamics_mod
 
@@ -19,7 +19,7 @@ use mpp_mod, only: input_nml_file
 use fms_mod, only: open_namelist_file
 #endif
 use iso_c_binding
-use fms_mod,            only: error_mesg, FATAL, NOTE, check_nml_error, mpp_pe, mpp_root_pe, stdlog, lowercase, uppercase, close_file
+use fms_mod,            only: error_mesg, FATAL, NOTE, check_nml_error, mpp_pe, mpp_root_pe, stdlog, lowercase, uppercase, close_file, file_exist
 use constants_mod,      only: radius, omega, grav, pi
 use gaussian_topog_mod, only: gaussian_topog_init
 use time_manager_mod,   only: time_type, get_time
@@ -155,9 +155,9 @@ if(trim(vert_difference_option) /= 'simmons_and_burridge' .and. trim(vert_differ
   call error_mesg('pressure_variables','"'//trim(vert_difference_option)//'" is not a valid value for vert_difference_option', FATAL)
 if(trim(initial_state_option) /= 'quiescent') &
   call error_mesg('spectral_dynamics_init','"'//trim(initial_state_option)//'" is not a supported value for initial_state_option.', FATAL)
-if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian') &
-  call error_mesg('spectral_dynamics_init','"'//trim(topography_option)//'" is not a supported value for topography_option here (flat, '// &
-                  'gaussian; a height field read from a file: hand the surface geopotential to the library, isca_dyn_set_surf_geopotential).', FATAL)
+if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian' .and. trim(topography_option) /= 'input') &
+  call error_mesg('get_topography','"'//trim(topography_option)//'" is not a supported value for topography_option here (flat, gaussian, input; '// &
+                  "'interpolated' needs the data files of topography_mod)", FATAL)
 if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
 if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
 if(dropin_physics /= 1 .and. (no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
@@ -295,6 +295,7 @@ if(isca_dyn_restart_exists('INPUT'//c_null_char) /= 0) then
   call chk(isca_dyn_read_restart(core, 'INPUT'//c_null_char, trim(tracer_name_list)//c_null_char), 'spectral_dynamics_init')
 else
   if(trim(topography_option) == 'gaussian') call gaussian_topography      ! get_topography (init/spectral_init_cond.F90:299-303)
+  if(trim(topography_option) == 'input') call input_topography            ! (:186-245)
   call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
 endif
 nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
@@ -303,6 +304,31 @@ triang = triang_trunc; finc = fourier_inc
 module_is_initialized = .true.
 
 end subroutine spectral_dynamics_init
+
+!===============================================================================================
+! get_topography, topography_option = 'input' (init/spectral_init_cond.F90:186-245): the height field and the land mask of INPUT/<topog_file_name>
+! (read_data by variable name: the library's netCDF-classic reader), then truncation or -- ocean_topog_smoothing /= 0, the default 0.93 --
+! the regularisation over the ocean, both the library's (isca_dyn_set_topography)
+subroutine input_topography
+real(c_double), allocatable :: zs(:), land(:)
+real(c_double) :: lam, frac
+integer(c_size_t) :: n, nread
+character(len=256) :: path
+path = 'INPUT/'//trim(topog_file_name)
+if(.not. file_exist(trim(path))) call error_mesg('get_topography','topography_option="'//trim(topography_option)//'"'// &
+                     ' but '//trim(path)//' does not exist', FATAL)
+n = int(lon_max, c_size_t)*int(lat_max, c_size_t)
+allocate(zs(n), land(n))
+call chk(isca_nc_read_variable(trim(path)//c_null_char, trim(topog_field_name)//c_null_char, 0_c_int, zs, n, nread), 'get_topography')
+if(nread /= n) call error_mesg('get_topography','Topography file contains data on another grid than the atmos model grid', FATAL)
+call chk(isca_nc_read_variable(trim(path)//c_null_char, trim(land_field_name)//c_null_char, 0_c_int, land, n, nread), 'get_topography')
+if(nread /= n) call error_mesg('get_topography','Land file contains data on another grid than the atmos model grid', FATAL)
+call chk(isca_dyn_set_topography(core, zs, land, real(ocean_topog_smoothing, c_double), lam, frac), 'get_topography')
+if(ocean_topog_smoothing /= 0.) then
+  print '(/,"Message from subroutine get_topography:")'
+  print '("lambda=",1pe16.8,"  fraction_smoothed=",1pe16.8,/)', lam, frac
+endif
+end subroutine input_topography
 
 !===============================================================================================
 ! get_topography, topography_option = 'gaussian': gaussian_topog_nml's mountains (shared/topography/gaussian_topog.F90, the reference's

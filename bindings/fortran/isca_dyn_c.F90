@@ -256,6 +256,16 @@ interface
   integer(c_int) function isca_dyn_restart_exists(directory) bind(C)
     import; character(kind=c_char), intent(in) :: directory(*)
   end function
+  ! get_topography for topography_option = 'input' (spectral_init_cond.F90:186-245): height and land mask on the global grid -> the handle's surface geopotential
+  ! (truncated, or regularised over the ocean: topog_regularization_mod); read_data of a netCDF classic file without netCDF
+  integer(c_int) function isca_dyn_set_topography(h, height, land_mask, ocean_topog_smoothing, lambda, fraction_smoothed) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: height(*), land_mask(*); real(c_double), value :: ocean_topog_smoothing
+    real(c_double), intent(out) :: lambda, fraction_smoothed
+  end function
+  integer(c_int) function isca_nc_read_variable(path, var_name, record, out, count, count_out) bind(C)
+    import; character(kind=c_char), intent(in) :: path(*), var_name(*); integer(c_int), value :: record
+    real(c_double), intent(out) :: out(*); integer(c_size_t), value :: count; integer(c_size_t), intent(out) :: count_out
+  end function
   ! a host without MPI of its own: rank / ranks / rank on the node from the environment, the communicator's id through ISCA_COMM_ID_FILE
   integer(c_int) function isca_env_rank(rank, world_size, local_rank) bind(C)
     import; integer(c_int), intent(out) :: rank, world_size, local_rank

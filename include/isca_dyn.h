@@ -153,6 +153,18 @@ const char *isca_last_error(void);
  * integral (press_and_geopot.F90:331) and the heights of isca_dyn_get_state("z_full" / "z_half").  get_surf_geopotential
  * (spectral_dynamics.F90:1342) = isca_dyn_get_state(h, "surf_geopotential", ...) (local band). */
 int isca_dyn_set_surf_geopotential(isca_dyn_t *h, const double *global_field, size_t count);
+/* get_topography with topography_option = 'input' (init/spectral_init_cond.F90:186-245) on data handed over: the GLOBAL (lon_max, lat_max) height field in m
+ * (the file's topog_field_name, 'zsurf') and land mask (land_field_name; > 0 = land; may be NULL with ocean_topog_smoothing = 0).  The surface
+ * geopotential g * height is spectrally truncated (ocean_topog_smoothing = 0, :231-235) or regularised over the ocean -- compute_lambda + regularize of
+ * topog_regularization_mod (init/topog_regularization.F90:75-290; the namelist's default 0.93) -- and becomes the handle's surface geopotential.
+ * lambda / fraction_smoothed (may be NULL): what get_topography prints.  world_size 1; before isca_dyn_cold_start. */
+int isca_dyn_set_topography(isca_dyn_t *h, const double *height, const double *land_mask, double ocean_topog_smoothing, double *lambda, double *fraction_smoothed);
+/* the two public routines of topog_regularization_mod on caller fields ((lon, lat) global; ocean_mask: 1 = ocean, 0 = land) */
+int isca_topog_regularize(isca_dyn_t *h, double lambda, const double *ocean_mask, const double *field, double *smoothed, double *fraction_smoothed);
+int isca_topog_compute_lambda(isca_dyn_t *h, double ocean_topog_smoothing, const double *ocean_mask, const double *field, double *lambda, double *fraction_smoothed);
+/* read_data for a host without netCDF (the Fortran drop-in reads INPUT/<topog_file_name> with it): record `record` of a variable of a netCDF classic /
+ * 64-bit-offset file as doubles; count_out = its number of values, copied to out when out != NULL and count >= count_out */
+int isca_nc_read_variable(const char *path, const char *var_name, int record, double *out, size_t count, size_t *count_out);
 
 /* read_restart_or_do_coldstart (spectral_dynamics.F90:580-630) + spectral_initialize_fields */
 int isca_dyn_cold_start(isca_dyn_t *h);

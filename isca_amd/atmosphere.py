@@ -341,21 +341,7 @@ def _get_topography(namelist: dict, surf_height, land_mask=None):
         if surf_height is None:
             raise IscaError("get_topography: topography_option=\"input\" needs the height field (atmosphere_init(..., surf_height=array))")
         smoothing = float(nml.get("spectral_dynamics_nml", {}).get("ocean_topog_smoothing", 0.93))          # spectral_dynamics.F90:184
-        if c.cfg.world_size != 1:
-            raise IscaError("get_topography: 'input' topography is truncated with the single-rank transforms; hand sharded runs the truncated field")
-        g = dyncore.GRAV * np.asarray(surf_height, dtype=np.float64)
-        if smoothing == 0.0:
-            c.set_surf_geopotential(c.trans_filter(g))                                   # grid -> spherical -> grid (:229-235)
-        else:
-            if land_mask is None:
-                raise IscaError("get_topography: ocean_topog_smoothing /= 0 needs the land mask of the topography file (atmosphere_init(..., land_mask=array)); "
-                                "ocean_topog_smoothing = 0 only truncates")
-            from . import topog_regularization as tr
-            ocean = ~(np.asarray(land_mask, dtype=np.float64) > 0.0)                     # where(land_ones > 0.) ocean_mask = .false. (:223-227)
-            lam, _ = tr.compute_lambda(c, smoothing, ocean, g)
-            smoothed, frac = tr.regularize(c, lam, ocean, g)
-            print(f"\nMessage from subroutine get_topography:\nlambda={lam:16.8e}  fraction_smoothed={frac:16.8e}\n")
-            c.set_surf_geopotential(smoothed)
+        c.set_topography(surf_height, land_mask, smoothing)                              # isca_dyn_set_topography: truncation (:231-235) or regularisation (:236-245)
     else:
         raise IscaError(f'"{opt}" is an invalid value for topography_option.')
 

@@ -477,6 +477,21 @@ extern "C" int isca_dyn_read_restart(isca_dyn_t *h, const char *directory, const
 extern "C" int isca_dyn_restart_exists(const char *directory) {      // (one file, or the pieces of a distributed one)
   return directory && (file_exists(std::string(directory) + "/spectral_dynamics.res.nc") || file_exists(std::string(directory) + "/spectral_dynamics.res.nc.0000")) ? 1 : 0;
 }
+// A variable of a netCDF classic file for a host that has no netCDF of its own (the Fortran drop-in: INPUT/<topog_file_name>'s zsurf and land_mask, what
+// read_data does in get_topography, spectral_init_cond.F90:186-222): record `record` of a record variable (or the whole fixed variable) as doubles.
+// count_out = the number of values; they are copied when out != NULL and count >= count_out.
+extern "C" int isca_nc_read_variable(const char *path, const char *var_name, int record, double *out, size_t count, size_t *count_out) {
+  RS_BEGIN
+  if (!path || !var_name) fail("null argument");
+  Nc3File f(path);
+  const auto v = f.read(var_name, record);
+  if (count_out) *count_out = v.size();
+  if (out) {
+    if (count < v.size()) fail(std::string("read_data: ") + var_name + " of " + path + " holds " + std::to_string(v.size()) + " values, the buffer " + std::to_string(count));
+    std::copy(v.begin(), v.end(), out);
+  }
+  RS_END
+}
 // The file layer alone, without a device (the CPU tests): writes a small fms_io-style file with known contents to `out_path` (when given) and
 // returns in sums[0..2] the sum, the first and the last value of variable `var_name`, record `record`, of `in_path` (when given).
 extern "C" int isca_restart_file_selftest(const char *out_path, const char *in_path, const char *var_name, int record, double *sums) {

@@ -111,6 +111,10 @@ def load_library():
         "isca_dyn_refresh_derived": [H],
         "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
         "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+        "isca_dyn_set_topography": [H, dp, dp, C.c_double, dp, dp],
+        "isca_topog_regularize": [H, C.c_double, dp, dp, dp, dp],
+        "isca_topog_compute_lambda": [H, C.c_double, dp, dp, dp, dp],
+        "isca_nc_read_variable": [C.c_char_p, C.c_char_p, C.c_int, dp, C.c_size_t, C.POINTER(C.c_size_t)],
         "isca_env_rank": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "isca_dyn_comm_init_env": [H],
         "isca_dyn_write_restart": [H, C.c_char_p, C.c_char_p],
@@ -174,7 +178,7 @@ EXPORTED_SYMBOLS = [
     "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
-    "isca_dyn_get_table", "isca_dyn_get_info", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
+    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_set_topography", "isca_topog_regularize", "isca_topog_compute_lambda", "isca_nc_read_variable", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
@@ -311,6 +315,22 @@ class DynCore:
         if a.shape != (self.J, self.I):
             raise IscaError(f"set_surf_geopotential: shape {a.shape} != {(self.J, self.I)}")
         self._check(self.lib.isca_dyn_set_surf_geopotential(self._h, _dptr(a), a.size))
+
+    def set_topography(self, surf_height, land_mask=None, ocean_topog_smoothing=0.0):
+        """get_topography with topography_option = 'input' on data handed over (isca_dyn_set_topography): the [lat_max, lon_max] height field in m and, for
+        ocean_topog_smoothing /= 0, the land mask (> 0 = land).  Returns (lambda, fraction smoothed) -- zeros when the field is only truncated."""
+        hgt = np.ascontiguousarray(surf_height, dtype=np.float64)
+        if hgt.shape != (self.J, self.I):
+            raise IscaError(f"set_topography: shape {hgt.shape} != {(self.J, self.I)}")
+        land = None if land_mask is None else np.ascontiguousarray(land_mask, dtype=np.float64)
+        if land is not None and land.shape != hgt.shape:
+            raise IscaError(f"set_topography: land mask of shape {land.shape} != {hgt.shape}")
+        lam, frac = C.c_double(), C.c_double()
+        self._check(self.lib.isca_dyn_set_topography(self._h, _dptr(hgt), None if land is None else _dptr(land), float(ocean_topog_smoothing),
+                                                     C.cast(C.byref(lam), C.POINTER(C.c_double)), C.cast(C.byref(frac), C.POINTER(C.c_double))))
+        if ocean_topog_smoothing != 0.0:
+            print(f"\nMessage from subroutine get_topography:\nlambda={lam.value:16.8e}  fraction_smoothed={frac.value:16.8e}\n")
+        return lam.value, frac.value
 
     def get(self, name: str, time_level: int = 1):
         shape, cplx = self._shape(name)

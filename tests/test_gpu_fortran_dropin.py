@@ -299,3 +299,45 @@ def test_atmosphere_mod_sharded_fortran_host(tmp_path, nranks, moist):
         assert max(abs(a - b) for a, b in zip(cont1, cont)) < 1e-8, (cont1, cont)
     else:
         assert cont == two, (two, cont)
+
+
+def test_atmosphere_mod_input_topography_from_fortran(tmp_path, golden_dir):
+    """topography_option = 'input' from Fortran (get_topography, spectral_init_cond.F90:186-245): spectral_dynamics_init reads zsurf and land_mask of
+    INPUT/topography.data.nc with the library's netCDF-classic reader and hands them to isca_dyn_set_topography -- regularised over the ocean with the
+    namelist's ocean_topog_smoothing (topog_regularization_mod; fixture of the reference's routines: test_golden_ocean_topog_smoothing).  24 steps
+    through atmos_model's loop land where the Python mirror lands with the same field and mask handed over."""
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    from scipy.io import netcdf_file
+    from isca_amd import atmosphere as atm, dyncore
+    g = np.load(os.path.join(golden_dir, "topog_regularize_T21.npz"))
+    smoothing = float(g["meta_ocean_topog_smoothing"])
+    d = str(tmp_path / "run")
+    groups = " &spectral_init_cond_nml\n    topography_option = 'input'\n /\n"
+    mg.prepare_rundir(d, "T21", 8, "run", nsteps=24, dt=600, extra=f"ocean_topog_smoothing = {smoothing}", extra_groups=groups)
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 24, dt_atmos = 600\n /\n")
+    f = netcdf_file(os.path.join(d, "INPUT", "topography.data.nc"), "w", version=2)        # what the harness's topography files look like: (lat, lon) fields
+    f.createDimension("lat", 32); f.createDimension("lon", 64)
+    z = f.createVariable("zsurf", "d", ("lat", "lon")); z[:] = g["in_height"]
+    lm = f.createVariable("land_mask", "f", ("lat", "lon")); lm[:] = g["in_land"]
+    f.close()
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    lam = float(re.search(r"lambda=\s*(\S+)\s+fraction_smoothed=\s*(\S+)", stdout).group(1))
+    assert abs(lam / float(g["out_lambda"]) - 1) < 1e-7, (lam, float(g["out_lambda"]))       # (printed with 9 digits)
+    vals = [float(x) for x in re.search(r"DRIVE_STATE Tmin,Tmax,maxabsU=\s*(\S+)\s+(\S+)\s+(\S+)", stdout).groups()]
+    nml = atm.parse_namelist(open(os.path.join(d, "input.nml")).read())
+    nml["main_nml"] = {"dt_atmos": 600}
+    core = atm.atmosphere_init(nml, surf_height=g["in_height"], land_mask=g["in_land"])
+    try:
+        assert rel_(core.get("surf_geopotential"), g["out_smoothed_geopotential"]) < 1e-9
+        atm.atmosphere(24)
+        t, u = core.get("tg"), core.get("ug")
+        assert [t.min(), t.max(), np.abs(u).max()] == vals, (vals, [t.min(), t.max(), np.abs(u).max()])
+    finally:
+        atm.atmosphere_end()
+
+
+def rel_(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
