@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B of this tree against an earlier commit inside ONE GPU-box visit (boxes differ by +-2 %): alternating bench runs of both trees.
+#   git worktree add -f build/old <commit> && rm -rf build/old/tests/golden build/old/profiles && (cd build/old && python -m isca_amd.build)
+#   gpurun -- 'bash tools/ab_old_new.sh'          (build/ is git-ignored and travels with the snapshot; remove the worktree afterwards)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab1
 export ISCA_BENCH_NO_EXTRA=1
