@@ -522,9 +522,13 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
       else HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     }
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    // fork / join of the side stream: dependencies between kernels of ONE device -- no system-scope fence when the event is recorded (the default writes the
+    // caches back and invalidates them for the host and other devices: measured 7.4 us between k_column and k_fft_fwd3 and 6.5 us in front of k_fixer_sums at
+    // T85L40 against 0-1.7 us between the other kernels, tools/kernel_gaps.sh).  ISCA_EVENT_SYSTEM_FENCE=1: the default flags.
+    const unsigned evf = hipEventDisableTiming | (getenv("ISCA_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, evf));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, evf));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, evf));
     d.fv_c = dupload(h, T.fv_c); d.fv_cc = dupload(h, T.fv_cc); d.fv_dy = dupload(h, T.fv_dy);
     d.fv_dyy = dupload(h, T.fv_dyy); d.fv_dyp = dupload(h, T.fv_dyp); d.fv_dym = dupload(h, T.fv_dym);
     {
