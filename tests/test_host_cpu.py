@@ -501,3 +501,51 @@ def test_env_rank_sources(monkeypatch):
     assert ask(ISCA_RANK=1, ISCA_WORLD_SIZE=2, RANK=7, WORLD_SIZE=8)[:3] == (0, 1, 2)    # ISCA_* wins
     rc = ask(ISCA_RANK=4, ISCA_WORLD_SIZE=4)[0]
     assert rc == 1 and b"inconsistent rank" in lib.isca_last_error()
+
+
+def test_restart_file_reader_property(tmp_path):
+    """The reader of csrc/restart_nc.cpp on files scipy writes with random dimensions, variable orders, types and record counts (hypothesis): every record of
+    every variable comes back as written -- the header walk (names and attributes with their padding, 32- / 64-bit offsets) and the record layout
+    (slabs of every record variable in definition order, 4-byte padding of short types, the single-record-variable case)."""
+    import ctypes as C
+    import numpy as np
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from scipy.io import netcdf_file
+    from isca_amd import dyncore
+    lib = dyncore.load_library()
+    sums = (C.c_double * 3)()
+    counter = [0]
+
+    var = st.tuples(st.sampled_from("dfih"), st.booleans(), st.integers(1, 3), st.integers(1, 5), st.text("abcxyz_", min_size=1, max_size=9))
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(version=st.sampled_from([1, 2]), nrec=st.integers(1, 4), variables=st.lists(var, min_size=1, max_size=5), seed=st.integers(0, 2 ** 31))
+    def check(version, nrec, variables, seed):
+        rng = np.random.default_rng(seed)
+        counter[0] += 1
+        path = str(tmp_path / f"p{counter[0]}.nc")
+        f = netcdf_file(path, "w", version=version)
+        f.createDimension("Time", None)
+        want, names = {}, set()
+        for i, (typ, rec, ny, nx, nm) in enumerate(variables):
+            name = f"{nm}{i}"
+            if name in names:
+                continue
+            names.add(name)
+            f.createDimension(f"y{i}", ny); f.createDimension(f"x{i}", nx)
+            dims = (("Time",) if rec else ()) + (f"y{i}", f"x{i}")
+            v = f.createVariable(name, typ, dims)
+            v.long_name = "x" * (i + 1)                      # attributes of every padding length
+            if typ in "df":
+                data = rng.standard_normal(((nrec,) if rec else ()) + (ny, nx)).astype(np.float64 if typ == "d" else np.float32)
+            else:
+                data = rng.integers(-1000, 1000, ((nrec,) if rec else ()) + (ny, nx)).astype(np.int32 if typ == "i" else np.int16)
+            v[:] = data
+            want[name] = (rec, data)
+        f.close()
+        for name, (rec, data) in want.items():
+            for r in range(nrec if rec else 1):
+                blk = np.asarray(data[r] if rec else data, dtype=np.float64).ravel()
+                assert lib.isca_restart_file_selftest(None, path.encode(), name.encode(), r, sums) == 0, lib.isca_last_error()
+                assert np.isclose(sums[0], blk.sum(), rtol=1e-12, atol=1e-9) and sums[1] == blk[0] and sums[2] == blk[-1], (name, r, list(sums), blk)
+    check()
