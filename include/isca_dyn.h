@@ -318,7 +318,8 @@ const char *isca_dyn_comm_kind(isca_dyn_t *h);           /* "rccl", "ipc", or ""
  * carried by the environment.  isca_env_rank: rank, number of ranks and rank on the node from ISCA_RANK / ISCA_WORLD_SIZE / ISCA_LOCAL_RANK, else
  * torchrun's RANK / WORLD_SIZE / LOCAL_RANK, Open MPI's OMPI_COMM_WORLD_*, PMI_RANK / PMI_SIZE, SLURM_PROCID / SLURM_NTASKS (one rank when none is
  * set).  isca_dyn_comm_init_env (collective; no-op with one rank): rank 0 draws the id and leaves it in the file ISCA_COMM_ID_FILE names, the others
- * wait for it, then isca_dyn_comm_init + isca_dyn_comm_check on every rank. */
+ * wait for it (a file older than the waiting process by more than a minute is an earlier run's and is ignored; rank 0 removes its file once every rank has
+ * answered the check), then isca_dyn_comm_init + isca_dyn_comm_check on every rank. */
 int isca_env_rank(int *rank, int *world_size, int *local_rank);
 int isca_dyn_comm_init_env(isca_dyn_t *h);
 

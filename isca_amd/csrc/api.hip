@@ -3,6 +3,8 @@
 #include "moist.h"
 #include <cstring>
 #include <unistd.h>
+#include <sys/stat.h>
+#include <ctime>
 #include <cmath>
 #include <algorithm>
 #include <mutex>
@@ -1311,14 +1313,17 @@ extern "C" int isca_dyn_comm_init_env(isca_dyn_t *h) {
   unsigned char id[128];
   if (h->cfg.rank == 0) {
     if (isca_comm_get_unique_id(id)) fail(g_last_error);
+    remove(path);                              // (an earlier run's)
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0 || rename(tmp.c_str(), path) != 0) fail(std::string("comm_init_env: cannot write ") + path);
   } else {
     const double limit = getenv("ISCA_IPC_TIMEOUT_S") ? atof(getenv("ISCA_IPC_TIMEOUT_S")) : 120.0;
     double waited = 0.0;
-    for (;;) {
-      FILE *f = fopen(path, "rb");
+    const time_t born = time(nullptr);        // a file left behind by an earlier run (rank 0 removes its own after use; a crashed run may not have) is not this run's id:
+    for (;;) {                                // only a file written after this process came up, give or take a minute between the ranks' starts, is accepted
+      struct stat st;
+      FILE *f = (stat(path, &st) == 0 && st.st_mtime + 60 >= born) ? fopen(path, "rb") : nullptr;
       if (f) { const size_t n = fread(id, 1, 128, f); fclose(f); if (n == 128) break; }
       if (waited > limit) fail(std::string("comm_init_env: rank 0 did not leave the communicator id in ") + path);
       usleep(20000); waited += 0.02;
