@@ -69,6 +69,9 @@ class Config:
     radius: float = 6376.0e3      # constants_nml
     omega: float = 7.2921150e-5
     num_tracers: int = 1          # the dry field_table carries one grid tracer (sphum)
+    # further field_table entries after sphum (update_tracers' loop, spectral_dynamics.F90:1132-1183): dicts with
+    # kind = 'grid' | 'spectral', robert_coeff (None: the namelist's), hole_filling (spectral only: water_borrowing.F90)
+    extra_tracers: tuple = ()
     # hs_forcing_nml
     t_zero: float = 315.0
     t_strat: float = 200.0
@@ -88,7 +91,8 @@ class Config:
     def resolution(name: str, num_levels: int, **kw) -> "Config":
         # src/extra/python/isca/experiment.py:29-57
         table = {"T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43),
-                 "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
+                 "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171),
+                 "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54)}        # lon_max with factors 3 and 5 (fft99's set99)
         lon, lat, nf, ns = table[name]
         return Config(lon_max=lon, lat_max=lat, num_fourier=nf, num_spherical=ns,
                       num_levels=num_levels, **kw)
@@ -671,6 +675,16 @@ class SpectralCore:
         tr = np.full((L, J, I), c.initial_sphum)
         self.tr = two(tr)
         self.tr_atm = two(tr)
+        # tracers other than sphum start from zero (allocate_fields :661-662; only sphum/mix_rat get initial_sphum, :581-584)
+        self.xtr = []
+        for spec in c.extra_tracers:
+            z = np.zeros((L, J, I))
+            x = dict(kind=spec.get("kind", "grid"), rc=spec.get("robert_coeff"), holes=bool(spec.get("hole_filling", False)), g=two(z), atm=two(z))
+            if x["rc"] is None:
+                x["rc"] = c.robert_coeff
+            if x["kind"] == "spectral":
+                x["s"] = two(self.trans_grid_to_spherical(z))                  # :627-628
+            self.xtr.append(x)
         self.previous = 0
         self.current = 0
         self.step_count = 0
@@ -702,6 +716,9 @@ class SpectralCore:
         else:
             dt_u, dt_v, dt_t = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur],
                                                self.ug[prev], self.vg[prev], self.tg[prev])
+        for x in self.xtr if with_tracer else ():                            # hs_forcing's loop over rdt(:,:,:,n), hs_forcing.F90:248-266
+            x["dt"] = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur], self.ug[prev], self.vg[prev], self.tg[prev],
+                                      x["atm"][prev], np.zeros_like(x["g"][prev]))[3]
         dt_ps = np.zeros((self.J, self.I))
         # --- initialize_corrections :1306-1338
         if c.do_mass_correction:
@@ -771,6 +788,12 @@ class SpectralCore:
             else:
                 self.tr[cur] = tr_cur_new
             self.tr[fut] = tr_future
+            for x in self.xtr:
+                if x["kind"] == "spectral":
+                    self._update_spectral_tracer(x, u, v, wg, p_half, delta_t, prev, cur, fut)
+                else:
+                    g = x["g"]
+                    g[cur], g[fut], x["part"] = self.update_grid_tracer(g[prev], g[cur], x["dt"], u, v, wg, p_half, delta_t, rc=x["rc"])
         # --- compute_corrections :1213-1302
         if c.do_mass_correction:
             mean_ps_tmp = self.area_weighted_global_mean(self.psg[fut])
@@ -795,6 +818,8 @@ class SpectralCore:
                 self.tr[fut] = np.where(mask, f * q, q)
         if with_tracer:
             self.tr_atm[fut] = self.tr[fut].copy()
+            for x in self.xtr:
+                x["atm"][fut] = x["g"][fut].copy()
         self.previous, self.current = cur, fut
         # --- complete_robert_filter :1456-1490 (leapfrog_2level_B with swapped pointers)
         for name in ("ln_ps", "vors", "divs", "ts"):
@@ -804,6 +829,10 @@ class SpectralCore:
         if with_tracer:                                                      # leapfrog_2level_B on the grid tracer :1484
             self.tr[cur] = self.tr[cur] + rc * self.tr[fut] * raw
             self.tr[fut] = self.tr[fut] + rc * (part_tr + self.tr[fut]) * (raw - 1.0)
+            for x in self.xtr:                                               # :1479-1486, each with its own robert_coeff
+                a = x["s"] if x["kind"] == "spectral" else x["g"]
+                a[cur] = a[cur] + x["rc"] * a[fut] * raw
+                a[fut] = a[fut] + x["rc"] * (x["part"] + a[fut]) * (raw - 1.0)
         self.wg_full = wg_full
         self.p_full[cur], self.p_half[cur] = p_full, p_half       # intent(out) of spectral_dynamics
         self._pressures_and_heights(fut)                          # atmosphere.F90:331-338
@@ -1036,17 +1065,67 @@ class SpectralCore:
             flux[k] = wk * np.where(wk >= 0., rst_p, rst_m)
         return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
 
-    def update_grid_tracer(self, tr_prev, tr_cur, dt_tr, u, v, wg, p_half, delta_t):
+    def update_grid_tracer(self, tr_prev, tr_cur, dt_tr, u, v, wg, p_half, delta_t, rc=None):
         """update_tracers, 'grid' branch (spectral_dynamics.F90:1155-1180); returns (tr_cur filtered part A, tr_future)."""
         tr_future = tr_prev + delta_t * dt_tr
         dq = self.a_grid_horiz_advection(u, v, tr_future, delta_t, np.zeros_like(tr_future))
         tr_future = tr_future + delta_t * dq
         dp = p_half[1:] - p_half[:-1]
         tr_future = tr_future + delta_t * self.vert_advection_ppm(delta_t, wg, dp, tr_future)
-        rc, raw = self.cfg.robert_coeff, self.cfg.raw_filter_coeff
+        rc, raw = (self.cfg.robert_coeff if rc is None else rc), self.cfg.raw_filter_coeff
         part = tr_prev - 2.0 * tr_cur
         tr_cur_new = tr_cur + rc * part * raw
         return tr_cur_new, tr_future, part
+
+    def _update_spectral_tracer(self, x, u, v, wg, p_half, delta_t, prev, cur, fut):
+        """update_tracers, 'spectral' branch (spectral_dynamics.F90:1133-1154): spectral horizontal advection of the current coefficients,
+        second-centred vertical advection of the current grid values, water_borrowing if asked for, damping like temperature's
+        (compute_spectral_damping without a kind, spectral_damping.F90:172-200), leapfrog_2level_A, synthesis of the new level."""
+        dt = self.horizontal_advection(x["s"][cur], u, v, x["dt"])
+        dp = p_half[1:] - p_half[:-1]
+        dt = dt + self.vert_advection_second_centered(wg, dp, x["g"][cur])
+        if x["holes"]:
+            dt = self.water_borrowing(dt, x["g"][prev], cur, p_half, delta_t)
+        dts = self.compute_spectral_damping(x["s"][prev], self.trans_grid_to_spherical(dt), delta_t, "t")
+        a, raw = x["s"], self.cfg.raw_filter_coeff
+        x["part"] = a[prev] - 2.0 * a[cur]                                  # leapfrog.F90:73
+        newfut = a[prev] + delta_t * dts
+        a[cur] = a[cur] + x["rc"] * x["part"] * raw
+        a[fut] = newfut
+        x["g"][fut] = self.trans_spherical_to_grid(a[fut])
+
+    @staticmethod
+    def water_borrowing(dt_q, q, current, p_half, delta_t):
+        """atmos_spectral/model/water_borrowing.F90:37-112: a negative cell whose four/six neighbours (east, west, above, below) hold enough
+        water to cover it is brought to zero by the tendency and the neighbours are scaled down by the same mass; cells are visited west
+        to east when `current` (1-based in the reference) is even, east to west when odd -- only the order of the additions depends on
+        it, q itself is not changed inside the loop."""
+        L, J, I = q.shape
+        dp = p_half[1:] - p_half[:-1]
+        out = dt_q.copy()
+        cur1 = current + 1                                                   # the reference's time-level index
+        ks, js, is_ = np.nonzero(q < 0.0)
+        order = np.lexsort((is_ if cur1 % 2 == 0 else -is_, ks, js))        # j outermost, then k, then i in sweep direction
+        for n in order:
+            k, j, i = int(ks[n]), int(js[n]), int(is_[n])
+            iw, ie = (i - 1) % I, (i + 1) % I
+            nb = q[k, j, iw] * dp[k, j, iw]
+            nb = nb + q[k, j, ie] * dp[k, j, ie]
+            if k != 0:
+                nb = nb + q[k - 1, j, i] * dp[k - 1, j, i]
+            if k != L - 1:
+                nb = nb + q[k + 1, j, i] * dp[k + 1, j, i]
+            total = nb + q[k, j, i] * dp[k, j, i]
+            if total > 0.0:
+                ratio = total / nb
+                out[k, j, i] -= q[k, j, i] / delta_t
+                out[k, j, iw] += (ratio - 1) * q[k, j, iw] / delta_t
+                out[k, j, ie] += (ratio - 1) * q[k, j, ie] / delta_t
+                if k != 0:
+                    out[k - 1, j, i] += (ratio - 1) * q[k - 1, j, i] / delta_t
+                if k != L - 1:
+                    out[k + 1, j, i] += (ratio - 1) * q[k + 1, j, i] / delta_t
+        return out
 
     # convenience
     def state(self):

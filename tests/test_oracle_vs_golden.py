@@ -10,7 +10,8 @@ import pytest
 
 from oracle.isca_oracle import Config, SpectralCore
 
-RES = {"T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86)}
+RES = {"T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22), "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86),
+       "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54)}
 
 
 def rel(a, b):
@@ -197,6 +198,43 @@ def test_vert_difference_mcm(golden_dir):
             for k in ("ug", "vg"):
                 assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
             assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+
+
+@pytest.mark.parametrize("res", ["T31", "T53"])
+def test_lon_max_with_factors_3_5(golden_dir, res):
+    """lon_max = 96 = 2^5 3 (T31) and 160 = 2^5 5 (T53) -- the reference's fft99 takes n/2 = 2^a 3^b 5^c: the numpy restatement, whose FFT takes
+    any length, against the reference steps at L8 -- the CPU-side pin of the fixtures the mixed-radix HIP kernels are held to."""
+    g = np.load(os.path.join(golden_dir, f"run_{res}L8.npz"))
+    marks = sorted(int(k[-6:]) for k in g.files if k.startswith("st_tg_"))
+    sc = core(res, 8); sc.cold_start()
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+
+
+@pytest.mark.parametrize("name,holes", [("run_T21L8_three_tracers", False), ("run_T21L8_hole_filling", True)])
+def test_three_tracers(golden_dir, name, holes):
+    """update_tracers' loop over a field_table with three entries (spectral_dynamics.F90:1132-1183): sphum (grid), a second grid tracer with
+    robert_coeff = 0.05, and a spectral tracer -- without and with hole_filling = on (water_borrowing.F90:37-112, which changes the
+    spectral tracer from the step its first negative value appears).  The numpy restatement against the reference run at every stored
+    step: the CPU-side pin of the fixtures test_golden_three_tracers / test_golden_hole_filling hold the HIP path to."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    marks = sorted(int(k[-6:]) for k in g.files if k.startswith("st_tr3_"))
+    sc = core("T21", 8, extra_tracers=(dict(kind="grid", robert_coeff=0.05), dict(kind="spectral", hole_filling=holes))); sc.cold_start()
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            cur, tag = sc.current, f"{i:06d}"
+            assert rel(sc.tg[cur], g[f"st_tg_{tag}"]) < 1e-12 and rel(sc.psg[cur], g[f"st_psg_{tag}"]) < 1e-12
+            assert rel(sc.tr[cur], g[f"st_tr1_{tag}"]) < 1e-11 and rel(sc.xtr[0]["g"][cur], g[f"st_tr2_{tag}"]) < 1e-11, tag
+            assert rel(sc.xtr[1]["g"][cur], g[f"st_tr3_{tag}"]) < 1e-11, tag
+    if holes:          # the borrowing did something: the plain run's spectral tracer is elsewhere by the last common step
+        plain = np.load(os.path.join(golden_dir, "run_T21L8_three_tracers.npz"))
+        assert rel(g["st_tr3_000040"], plain["st_tr3_000040"]) > 1e-6
 
 
 def test_raw_filter(golden_dir):
