@@ -7,7 +7,7 @@ implicit none
 public
 
 integer, parameter :: ISCA_MAX_LEVELS = 128
-integer, parameter :: ISCA_MAX_TRACERS = 4
+integer, parameter :: ISCA_MAX_TRACERS = 8
 
 type, bind(C) :: isca_moist_config
   real(c_double) :: roughness_mom, roughness_heat, roughness_moist

@@ -30,7 +30,7 @@ extern "C" {
 typedef struct isca_dyn isca_dyn_t;
 
 #define ISCA_MAX_LEVELS 128
-#define ISCA_MAX_TRACERS 4
+#define ISCA_MAX_TRACERS 8
 
 /* Parameters of the moist physics package, physics = 1: idealized_moist_phys with the options of the Frierson grey-radiation
  * aquaplanet (exp/test_cases/frierson/frierson_test_case.py:49-170): SIMPLE_BETTS_MILLER convection, lscale_cond,

@@ -783,7 +783,7 @@ static void cold_start_single(isca_dyn *h) {
   std::vector<double> tr(ng3, h->cfg.initial_sphum);
   h2d(h, d.tr[0], tr.data(), ng3); h2d(h, d.tr[1], tr.data(), ng3);
   h2d(h, d.tr_atm[0], tr.data(), ng3); h2d(h, d.tr_atm[1], tr.data(), ng3);
-  for (int e = 0; e < 3; ++e) for (int t = 0; t < 2; ++t) {
+  for (int e = 0; e < ISCA_MAX_TRACERS - 1; ++e) for (int t = 0; t < 2; ++t) {
     for (double *p : {d.trx[t][e], d.trx_atm[t][e]}) if (p) HIP_CHECK(hipMemsetAsync(p, 0, ng3 * sizeof(double), h->stream));
     if (d.trxs[t][e]) HIP_CHECK(hipMemsetAsync(d.trxs[t][e], 0, ns3 * sizeof(double), h->stream));
   }
@@ -808,7 +808,7 @@ static double *state_ptr(isca_dyn *h, const std::string &name, int tlev, size_t 
   if (name == "tr") { count = ng3; return d.tr[tl]; }
   if (name == "tr_atm") { count = ng3; return d.tr_atm[tl]; }
   if (name == "trh") { count = ng3; return d.trh; }
-  for (int e = 0; e < 3; ++e) {       // "tr2".."tr4", "tr_atm2"..: tracers 2..num_tracers
+  for (int e = 0; e < ISCA_MAX_TRACERS - 1; ++e) {       // "tr2".."tr8", "tr_atm2"..: tracers 2..num_tracers
     const std::string n = std::to_string(e + 2);
     if (name == "tr" + n || name == "tr_atm" + n || name == "trs" + n) {
       if (!d.trx[0][e]) fail("get/set_state: " + name + ": num_tracers is " + std::to_string(h->cfg.num_tracers));
@@ -941,7 +941,7 @@ extern "C" int isca_dyn_complete_update(isca_dyn_t *h, int time_level) {
   for (auto &x : ps) x = std::log(x);
   h2d(h, d.scratch_g[0], ps.data(), ng2);
   dev_g2s(h, d.scratch_g[0], d.lnps[tl], 1, 1, OP_NONE);
-  for (int e = 0; e < 3; ++e)        // spectral tracers: their coefficients from the grid values handed in (:1447-1451)
+  for (int e = 0; e < ISCA_MAX_TRACERS - 1; ++e)        // spectral tracers: their coefficients from the grid values handed in (:1447-1451)
     if (d.trxs[tl][e]) dev_g2s(h, d.trx[tl][e], d.trxs[tl][e], L, 1, OP_NONE);
   if (tl == h->current) refresh_derived(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));

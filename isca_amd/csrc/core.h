@@ -98,7 +98,7 @@ struct Dev {
   double *tv = nullptr;      // virtual temperature work array (use_virtual_temperature)
   // tracers 2..num_tracers ([e] = tracer e+2): grid values, atmosphere_mod's copy, spectral coefficients (spectral tracers only),
   // and the column sums the transport kernel writes for tracer 1's water fixer (unused here)
-  double *trx[2][3] = {}, *trx_atm[2][3] = {}, *trxs[2][3] = {}, *wcol_x = nullptr, *ph_dtqx[3] = {};
+  double *trx[2][ISCA_MAX_TRACERS - 1] = {}, *trx_atm[2][ISCA_MAX_TRACERS - 1] = {}, *trxs[2][ISCA_MAX_TRACERS - 1] = {}, *wcol_x = nullptr, *ph_dtqx[ISCA_MAX_TRACERS - 1] = {};
   double *halo_send, *halo_recv;   // [2 sides][3 + more grid tracers][L][2][I] tracer halo rows (lo, hi): q0 of tracer 1, u, v, q0 of the further grid tracers
   double *psp_copy;          // [Jl][I] psg(previous) saved by the column kernel for the concurrent tracer stream
   int *kmask;                // [Jl][I] number of levels with p_full < water_correction_limit: byte 0 this step, byte 1 the step before, byte 2 ...

@@ -23,7 +23,7 @@ class IscaError(RuntimeError):
 
 
 MAX_LEVELS = 128          # ISCA_MAX_LEVELS
-MAX_TRACERS = 4           # ISCA_MAX_TRACERS
+MAX_TRACERS = 8           # ISCA_MAX_TRACERS
 
 
 class _CMoistConfig(C.Structure):

@@ -43,6 +43,23 @@ FIELD_TABLE_3 = FIELD_TABLE + '''"TRACER", "atmos_mod", "age_grid"
 # the same three tracers with hole_filling = on for the spectral one: water_borrowing (atmos_spectral/model/water_borrowing.F90) on its tendency
 FIELD_TABLE_3_HOLES = FIELD_TABLE_3.replace('"numerical_representation", "spectral"', '"numerical_representation", "spectral"\n          "hole_filling", "on"')
 
+# six tracers (more than the four the library carried before): the three above, a third grid tracer (robert_coeff = 0.08), a spectral one with
+# robert_coeff = 0.02 and a spectral one with hole_filling = on -- every entry differs from the others in what update_tracers does with it
+FIELD_TABLE_6 = FIELD_TABLE_3 + '''"TRACER", "atmos_mod", "grid_three"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic"
+          "robert_filter",            "on", "robert_coeff=0.08"
+          "profile_type", "fixed",   "surface_value=0.0" /
+"TRACER", "atmos_mod", "spec_two"
+          "numerical_representation", "spectral"
+          "robert_filter",            "on", "robert_coeff=0.02"
+          "profile_type", "fixed",   "surface_value=0.0" /
+"TRACER", "atmos_mod", "spec_holes"
+          "numerical_representation", "spectral"
+          "hole_filling", "on"
+          "profile_type", "fixed",   "surface_value=0.0" /
+'''
+
 RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54),        # lon_max = 2^5 3 and 2^5 5: the radix-3 and radix-5 passes of fft99 (fft99.F90:876-1228)
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
@@ -576,6 +593,9 @@ def main():
         "run_T21L8_hole_filling": lambda: golden_run(
             "T21", 8, 60, (1, 2, 3, 40, 60), field_table=FIELD_TABLE_3_HOLES,
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr1|tr2|tr3)_", k) is not None),
+        "run_T21L8_six_tracers": lambda: golden_run(
+            "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE_6,
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr[1-6])_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -432,6 +432,43 @@ def test_golden_vert_difference_mcm(golden_dir):
         atm.config_from_namelist({"spectral_dynamics_nml": {"vert_difference_option": "arakawa"}})
 
 
+def test_golden_six_tracers(golden_dir, tmp_path):
+    """A field_table with six tracers (ISCA_MAX_TRACERS = 8; four until round 4): sphum, grid tracers with robert_coeff 0.05 and 0.08, spectral tracers
+    with the default filter, with robert_coeff 0.02 and with hole_filling -- no two are treated alike by update_tracers (spectral_dynamics.F90:1132-1183)
+    and by step 40 every pair is more than 1e-4 of its maximum apart.  40 steps at T21L8 against the reference run, then the native restart files."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_six_tracers.npz"))
+    opts = dict(num_tracers=6, tracer_spectral=[0, 0, 1, 0, 1, 1], tracer_robert_coeff=[-1.0, 0.05, -1.0, 0.08, 0.02, -1.0],
+                tracer_hole_filling=[0, 0, 0, 0, 0, 1])
+    dc = make("T21", 8, **opts); dc.cold_start()
+    names = ["tr"] + [f"tr{k}" for k in range(2, 7)]
+    done = 0
+    for n in (1, 2, 40):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k == "ug" else 1e-300))
+               for k in ("ug", "tg", "psg")}
+        for i, k in enumerate(names):
+            err[k] = rel(dc.get(k), g[f"st_tr{i + 1}_{n:06d}"])
+        print("six tracers, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    for i in range(6):
+        for j in range(i + 1, 6):
+            assert rel(dc.get(names[i]), dc.get(names[j])) > 1e-5, (i, j)
+    # restart files with six tracers: written, read into a fresh core, the run continues bit for bit
+    field_names = ["sphum", "age_grid", "age_spec", "grid_three", "spec_two", "spec_holes"]
+    dc.write_restart_files(str(tmp_path), field_names)
+    dc.step(4)
+    want = {k: dc.get(k) for k in ["tg"] + names}
+    dc.close()
+    dc = make("T21", 8, **opts)
+    dc.read_restart_files(str(tmp_path), field_names)
+    dc.step(4)
+    for k, v in want.items():
+        assert np.array_equal(dc.get(k), v), k
+    dc.close()
+    with pytest.raises(dyncore.IscaError, match="num_tracers must be 0..8"):
+        make("T21", 8, num_tracers=9)
+
+
 def test_golden_hole_filling(golden_dir):
     """hole_filling = 'on' for a spectral tracer: water_borrowing (atmos_spectral/model/water_borrowing.F90:38-136, spectral_dynamics.F90:1142-1144)
     fills negative values of the previous level from the four neighbours on the latitude circle and in the column.  The reference's three-tracer

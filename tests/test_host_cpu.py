@@ -370,7 +370,7 @@ def test_field_table_entries():
                      ('"TRACER", "atmos_mod", "x"\n "numerical_representation", "wavelet" /', "invalid numerical_representation"),
                      ('"TRACER", "atmos_mod", "x"\n "advect_vert", "upwind" /', "invalid advect_vert"),
                      ('"TRACER", "atmos_mod", "x" /', "must be a grid tracer"),
-                     (text * 2, "at most 4")):
+                     (text * 3, "at most 8")):
         with pytest.raises(IscaError, match=msg):
             atm.tracers_from_field_table(atm.parse_field_table(bad))
     # the humidity tracer is found by NAME (nhum = get_tracer_index('sphum' | 'mix_rat')): it must be tracer 1; without one the model is dry

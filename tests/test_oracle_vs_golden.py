@@ -237,6 +237,22 @@ def test_three_tracers(golden_dir, name, holes):
         assert rel(g["st_tr3_000040"], plain["st_tr3_000040"]) > 1e-6
 
 
+def test_six_tracers(golden_dir):
+    """Six field_table entries (grid with robert_coeff default / 0.05 / 0.08, spectral with the default filter / robert_coeff 0.02 / hole_filling):
+    the numpy restatement against the reference run the HIP path's test_golden_six_tracers uses."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_six_tracers.npz"))
+    sc = core("T21", 8, extra_tracers=(dict(kind="grid", robert_coeff=0.05), dict(kind="spectral"), dict(kind="grid", robert_coeff=0.08),
+                                      dict(kind="spectral", robert_coeff=0.02), dict(kind="spectral", hole_filling=True)))
+    sc.cold_start()
+    for i in range(1, 41):
+        sc.step()
+        if i in (1, 2, 40):
+            cur, tag = sc.current, f"{i:06d}"
+            assert rel(sc.tr[cur], g[f"st_tr1_{tag}"]) < 1e-11
+            for n, x in enumerate(sc.xtr):
+                assert rel(x["g"][cur], g[f"st_tr{n + 2}_{tag}"]) < 1e-11, (n + 2, tag)
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
