@@ -136,8 +136,8 @@ type(isca_dyn_config) :: cfg
 integer :: ntr, nsphum, nmix_rat, seconds, days, k
 integer(c_int) :: env_rank, env_world, env_local
 integer(c_long) :: info_val
-real :: robert_coeff_tracers
-character(len=32) :: scheme, params
+real :: robert_coeff_tracers, sms_value
+character(len=128) :: scheme, params
 character(len=128) :: tname, longname, units
 
 if(module_is_initialized) return
@@ -255,6 +255,14 @@ do ntr = 1, num_tracers
       call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%numerical_representation)//' is an invalid numerical_representation', FATAL)
   end select
   cfg%tracer_robert_coeff(ntr) = tracer_attributes(ntr)%robert_coeff
+  if(query_method('tracer_sms', MODEL_ATMOS, ntr, scheme, params)) then       ! hs_forcing's source and sink of this entry (hs_forcing.F90:251-261)
+    cfg%tracer_sms(ntr) = 1; cfg%tracer_flux(ntr) = 0.; cfg%tracer_sink(ntr) = 0.      ! 'none' (no tendency) and 'off' (flux = sink = 0) come to the same
+    if(uppercase(trim(scheme)) /= 'NONE' .and. uppercase(trim(scheme)) /= 'OFF') then
+      cfg%tracer_flux(ntr) = trflux; cfg%tracer_sink(ntr) = trsink
+      if(parse(params, 'flux', sms_value) == 1) cfg%tracer_flux(ntr) = sms_value
+      if(parse(params, 'sink', sms_value) == 1) cfg%tracer_sink(ntr) = sms_value
+    endif
+  endif
 enddo
 nsphum   = get_tracer_index(MODEL_ATMOS, 'sphum')
 nmix_rat = get_tracer_index(MODEL_ATMOS, 'mix_rat')

@@ -65,6 +65,8 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: make_symmetric
   integer(c_int) :: vert_difference_option             ! 0 simmons_and_burridge, 1 mcm
   integer(c_int) :: tracer_hole_filling(ISCA_MAX_TRACERS)
+  integer(c_int) :: tracer_sms(ISCA_MAX_TRACERS)       ! 1: the entry's own tracer_flux / tracer_sink instead of hs_forcing_nml's trflux / trsink
+  real(c_double) :: tracer_flux(ISCA_MAX_TRACERS), tracer_sink(ISCA_MAX_TRACERS)
 end type
 
 interface

@@ -135,6 +135,12 @@ typedef struct isca_dyn_config {
    * its four neighbours on the latitude circle and in the column when together they hold enough (spectral_dynamics.F90:1142-1144).  Ignored for
    * 'grid' tracers like the reference (:364-367). */
   int tracer_hole_filling[ISCA_MAX_TRACERS];
+  /* tracer_sms of the field_table entries ([k] = tracer k+1, tracer 1 included): hs_forcing's source and sink per tracer (hs_forcing.F90:250-265).
+   * tracer_sms[k] = 0: hs_forcing_nml's trflux / trsink (no tracer_sms method in the entry); 1: tracer_flux[k] / tracer_sink[k] (the entry's
+   * "flux=" / "sink=" parameters, each defaulting to the namelist value; sink < 0 in days like trsink; 'off' and 'none' are flux = sink = 0:
+   * no tendency from hs_forcing).  Only with physics = 0 (hs_forcing is the physics). */
+  int tracer_sms[ISCA_MAX_TRACERS];
+  double tracer_flux[ISCA_MAX_TRACERS], tracer_sink[ISCA_MAX_TRACERS];
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

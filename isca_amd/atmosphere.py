@@ -347,13 +347,43 @@ def _get_topography(namelist: dict, surf_height, land_mask=None):
 
 
 # ---- field_table (FMS field_manager format; the atmosphere's entries as spectral_dynamics_init reads them, spectral_dynamics.F90:316-409)
+def _field_table_fields(line: str) -> list[str]:
+    """The comma-separated fields of one field_table line; a comma inside quotes belongs to the field ("flux=2.5e-5, sink=-2.0" is one parameter string)."""
+    fields, cur, quote = [], "", None
+    for ch in line:
+        if quote:
+            if ch == quote:
+                quote = None
+            else:
+                cur += ch
+        elif ch in "\"'":
+            quote = ch
+        elif ch == ",":
+            fields.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    fields.append(cur.strip())
+    return fields
+
+
 def parse_field_table(text: str) -> list[dict]:
     """Entries of a field_table: '"TRACER", "atmos_mod", "name"' followed by '"method", "value"[, "parameters"]' lines, closed by '/'.
     Returns one dict per atmos_mod tracer: name and {method: (value, parameters)}; other models' entries are skipped."""
     out = []
     body = "\n".join(ln.split("#", 1)[0] for ln in text.splitlines())
-    for entry in body.split("/"):
-        rows = [[f.strip().strip('"').strip("'").strip() for f in ln.split(",")] for ln in entry.splitlines() if ln.strip()]
+    entries, cur, quote = [], "", None             # an entry ends at a '/' outside quotes ("units", "kg/kg" is a field)
+    for ch in body:
+        if quote:
+            quote = None if ch == quote else quote
+        elif ch in "\"'":
+            quote = ch
+        elif ch == "/":
+            entries.append(cur); cur = ""
+            continue
+        cur += ch
+    entries.append(cur)
+    for entry in entries:
+        rows = [_field_table_fields(ln) for ln in entry.splitlines() if ln.strip()]
         if not rows:
             continue
         head = rows[0]
@@ -366,7 +396,7 @@ def parse_field_table(text: str) -> list[dict]:
     return out
 
 
-def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = None):
+def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = None, trflux: float = 1.e-5, trsink: float = -4.0):
     """(config keys, tracer names) for the library.  What the kernels implement is what the reference's own field_tables use: tracer 1 a
     'grid' tracer (van Leer + finite_volume_parabolic, the sphum entry), further tracers either that or 'spectral' with the defaults
     (advect_vert = second_centered; hole_filling = on runs water_borrowing on its tendency); anything else is refused by name rather than run as
@@ -380,7 +410,7 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
     if hum and hum[0] != 0:
         raise IscaError(f"field_table: the humidity tracer ({entries[hum[0]]['name']}) must be the first atmos_mod entry "
                         f"(the first entry is {entries[0]['name']}): tracer 1 is the one the water correction, virtual temperature and moist physics use")
-    spectral, robert, names, holes = [], [], [], []
+    spectral, robert, names, holes, sms = [], [], [], [], []
     for k, e in enumerate(entries):
         m = e["methods"]
         rep = m.get("numerical_representation", ("spectral", ""))[0].lower()      # default_representation (:145)
@@ -395,8 +425,20 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
         hole = 1 if rep == "spectral" and m.get("hole_filling", ("off", ""))[0].lower() == "on" else 0    # water_borrowing (:1142); ignored for grid tracers (:364-367)
         if k == 0 and rep != "grid":
             raise IscaError(f"field_table: the first tracer ({e['name']}) must be a grid tracer")
+        sms_k = None                                                                # hs_forcing's source and sink for this entry (hs_forcing.F90:251-261)
         if "tracer_sms" in m:
-            raise IscaError(f"field_table: tracer {e['name']}: tracer_sms is not available (hs_forcing_nml's trflux / trsink apply to every tracer)")
+            scheme, params = m["tracer_sms"]
+            if scheme.upper() in ("NONE", "OFF"):                                   # `cycle` / flux = sink = 0: no tendency either way
+                sms_k = (0.0, 0.0)
+            else:
+                fl, sk = (None, None)
+                for item in params.replace(" ", "").split(","):
+                    if item.lower().startswith("flux="):
+                        fl = float(item.split("=", 1)[1])
+                    elif item.lower().startswith("sink="):
+                        sk = float(item.split("=", 1)[1])
+                sms_k = (fl, sk)
+        sms.append(sms_k)
         rc = -1.0                                                                   # the dynamics' robert_coeff (:347,351)
         if "robert_filter" in m:
             scheme, params = m["robert_filter"]
@@ -411,6 +453,10 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
             raise IscaError(f"field_table: tracer {e['name']}: a robert_coeff of its own is only available from the second tracer on")
         spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"]); holes.append(hole)
     keys = dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert, tracer_hole_filling=holes)
+    if any(x is not None for x in sms):        # a parameter the entry leaves out keeps hs_forcing_nml's value (trflux, trsink: the arguments)
+        keys.update(tracer_sms=[0 if x is None else 1 for x in sms],
+                    tracer_flux=[0.0 if x is None else float(trflux if x[0] is None else x[0]) for x in sms],
+                    tracer_sink=[0.0 if x is None else float(trsink if x[1] is None else x[1]) for x in sms])
     if entries and not hum:            # dry_model: no humidity anywhere -- tracer 1 starts at 0 like every other tracer, no virtual temperature
         keys.update(initial_sphum=0.0, use_virtual_temperature=False, _dry_model=True)
     return keys, names
@@ -432,7 +478,9 @@ def atmosphere_init(namelist=None, resolution: str | None = None, run_dir: str |
     if field_table is not None:          # text of the run's field_table (Experiment: field_table_file); None = the dry default, one sphum grid tracer
         nml = parse_namelist(namelist) if isinstance(namelist, str) else (namelist or {})
         sd = {k.lower(): v for k, v in {g.lower(): v for g, v in nml.items()}.get("spectral_dynamics_nml", {}).items()}
-        keys, names = tracers_from_field_table(parse_field_table(field_table), sd.get("robert_coeff"))
+        hs = {k.lower(): v for k, v in {g.lower(): v for g, v in nml.items()}.get("hs_forcing_nml", {}).items()}
+        keys, names = tracers_from_field_table(parse_field_table(field_table), sd.get("robert_coeff"),
+                                               overrides.get("trflux", hs.get("trflux", 1.e-5)), overrides.get("trsink", hs.get("trsink", -4.0)))
         if keys.pop("_dry_model", False):
             # initialize_corrections / compute_corrections (spectral_dynamics.F90:1245-1248, 1328-1331)
             if sd.get("do_water_correction", True) and overrides.get("do_water_correction", True):

@@ -113,7 +113,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->use_virtual_temperature = 0;
   c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1; c->make_symmetric = 0;
   c->vert_difference_option = 0;
-  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) c->tracer_hole_filling[k] = 0;
+  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_hole_filling[k] = 0; c->tracer_sms[k] = 0; c->tracer_flux[k] = 0.0; c->tracer_sink[k] = 0.0; }
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -1100,7 +1100,7 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
   if (h->cfg.physics == 2) dcopy(h, dt_tr, d.ph_dtqx[e], ng3);
   else {
     HIP_CHECK(hipMemsetAsync(dt_tr, 0, ng3 * sizeof(double), h->stream));
-    if (h->cfg.physics == 0) launch_tracer_source_sink(*h, d.psg[sc.cur], d.trx_atm[sc.prev][e], dt_tr, h->stream);
+    if (h->cfg.physics == 0) launch_tracer_source_sink(*h, d.psg[sc.cur], d.trx_atm[sc.prev][e], dt_tr, h->stream, e + 1);
   }
   FieldList fl = pair_list(d.scratch_g[0], d.scratch_g[1], g.L, OP_COSM);
   launch_spec_gradient(g, d, d.trxs[sc.cur][e], d.Si, col_pitch(fl.ncol), 0, g.L, g.L, h->stream);

@@ -104,7 +104,7 @@ void launch_mass_weighted_rows(const isca_dyn &h, const double *f, const double 
 void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, const double *q, const double *ps, double dt, double *q_new, hipStream_t s);
 void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,
                         double *dummy_a, double *dummy_b, hipStream_t s);
-void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s);
+void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s, int k = -1);   // k: the field_table entry whose tracer_sms applies (-1: hs_forcing_nml's trflux / trsink)
 
 // spectral_diagnostics (spectral_dynamics.F90:1705-1867): add this step's fields to the running sums
 constexpr int NDIAG = 22;

@@ -2538,6 +2538,13 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
 }
 
 // robert_coeff of field_table entry k+1 (spectral_dynamics.F90:340-351): its own, or the dynamics' one
+// hs_forcing's source and sink for field_table entry k (0-based; hs_forcing.F90:250-265): the entry's tracer_sms values or hs_forcing_nml's
+static double tracer_sms_flux(const isca_dyn &h, int k) { return (k >= 0 && h.cfg.tracer_sms[k]) ? h.cfg.tracer_flux[k] : h.cfg.trflux; }
+static double tracer_sms_rdamp(const isca_dyn &h, int k) {
+  double r = (k >= 0 && h.cfg.tracer_sms[k]) ? h.cfg.tracer_sink[k] : h.cfg.trsink;       // tracer_source_sink, hs_forcing.F90:697-699
+  if (r < 0.) r = -86400. * r;
+  return r > 0. ? 1. / r : r;
+}
 static double tracer_robert(const isca_dyn &h, int k) {
   return h.cfg.tracer_robert_coeff[k] >= 0.0 ? h.cfg.tracer_robert_coeff[k] : h.cfg.robert_coeff;
 }
@@ -2550,8 +2557,8 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.c = d.fv_c; a.cc = d.fv_cc; a.dy = d.fv_dy; a.dyy = d.fv_dyy; a.dyp = d.fv_dyp; a.dym = d.fv_dym;
   a.dpk = d.dpk; a.dbk = d.dbk; a.wts = d.wts_lat_l; a.kmask = d.kmask; a.kmask_old = d.kmask_old; a.wcol = d.wcol;
   a.rcdx = d.fv_rcdx; a.rdyy = d.fv_rdyy; a.rcdy = d.fv_rcdy; a.rdy = d.fv_rdy; a.ppm = d.ppm_tab;
-  a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = h.cfg.trflux;
-  a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;
+  a.dx = h.tab.fv_dx; a.dt = sc.delta_t; a.flux = tracer_sms_flux(h, 0);
+  a.rdamp = tracer_sms_rdamp(h, 0);
   a.robert = h.cfg.robert_coeff * h.cfg.raw_filter_coeff;
   a.tr_part = d.tr_part;
   // pending fixers (identity rows unless lazy_fix): the mass factor on ps(cur), the water factors on the two older tracer levels
@@ -2578,7 +2585,7 @@ static TracerArgs further_tracer_args(const isca_dyn &h, const StepScalars &sc, 
   b.tr_b = b.trp; b.tr_cur_rd = b.tr_cur; b.rb = 0.0; b.pend_a = h.d.pend + PEND_IDENTITY;        // (more than one tracer: the fixers are applied eagerly)
   b.robert = tracer_robert(h, e + 1);
   b.halo_q = (size_t)(3 + e) * h.g.L * 2 * h.g.I;
-  if (h.cfg.physics == 0) b.tratm_p = h.d.trx_atm[sc.prev][e];              // hs_forcing's source and sink act on every tracer (hs_forcing.F90:248-265)
+  if (h.cfg.physics == 0) { b.tratm_p = h.d.trx_atm[sc.prev][e]; b.flux = tracer_sms_flux(h, e + 1); b.rdamp = tracer_sms_rdamp(h, e + 1); }   // hs_forcing's source and sink act on every tracer, each with its tracer_sms (hs_forcing.F90:248-265)
   else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
   else { b.tratm_p = b.trp; b.flux = 0.0; b.rdamp = 0.0; }                   // idealized_moist_phys only has a tendency for sphum
   return b;
@@ -2797,11 +2804,11 @@ __global__ void k_tracer_source_sink(Geom g, TracerArgs a, const double *__restr
   const size_t c2 = idx % lev;
   rdt[idx] += tr_source_sink(a, g, k, c2, tr[idx]);
 }
-void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s) {
+void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double *tr, double *rdt, hipStream_t s, int k) {
   StepScalars sc{};
   TracerArgs a = tracer_args(h, sc);
   a.ps_cur = ps;
-  a.flux = h.cfg.trflux; a.rdamp = h.tab.trsink_s > 0. ? 1. / h.tab.trsink_s : 0.0;   // hs_forcing's own, whatever physics the handle steps with
+  a.flux = tracer_sms_flux(h, k); a.rdamp = tracer_sms_rdamp(h, k);   // hs_forcing's own, whatever physics the handle steps with
   hipLaunchKernelGGL(k_tracer_source_sink, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, tr, rdt);
 }
 

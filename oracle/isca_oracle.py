@@ -70,8 +70,10 @@ class Config:
     omega: float = 7.2921150e-5
     num_tracers: int = 1          # the dry field_table carries one grid tracer (sphum)
     # further field_table entries after sphum (update_tracers' loop, spectral_dynamics.F90:1132-1183): dicts with
-    # kind = 'grid' | 'spectral', robert_coeff (None: the namelist's), hole_filling (spectral only: water_borrowing.F90)
+    # kind = 'grid' | 'spectral', robert_coeff (None: the namelist's), hole_filling (spectral only: water_borrowing.F90),
+    # sms = (flux, sink) of the entry's tracer_sms method (hs_forcing.F90:251-261; 'off' / 'none' = (0, 0); None inside: the namelist's)
     extra_tracers: tuple = ()
+    sphum_sms: tuple = None       # the same for tracer 1
     # hs_forcing_nml
     t_zero: float = 315.0
     t_strat: float = 200.0
@@ -468,7 +470,7 @@ class SpectralCore:
     # ----------------------------------------------------------------------------------------
     # Held-Suarez forcing (atmos_param/hs_forcing/hs_forcing.F90:148-272,508-724)
     # ----------------------------------------------------------------------------------------
-    def hs_forcing(self, dt, p_half, p_full, u, v, t, tr=None, tr_dt=None):
+    def hs_forcing(self, dt, p_half, p_full, u, v, t, tr=None, tr_dt=None, sms=None):
         c = self.cfg
         ps = p_half[-1]
         rps = 1.0 / ps
@@ -498,9 +500,14 @@ class SpectralCore:
         out = [utnd, vtnd, tdt]
         if tr is not None:                                                   # :240-263, 683-724
             rst = tr + dt * tr_dt
-            rdamp = 1.0 / self.trsink if self.trsink > 0 else 0.0
+            flux, rdamp = c.trflux, self.trsink
+            if sms is not None:                                              # the entry's tracer_sms: (flux, sink), :251-261 (None: the namelist's)
+                flux = c.trflux if sms[0] is None else sms[0]
+                rdamp = c.trsink if sms[1] is None else sms[1]
+                rdamp = -86400.0 * rdamp if rdamp < 0 else rdamp             # tracer_source_sink :697-698
+            rdamp = 1.0 / rdamp if rdamp > 0 else 0.0
             source = np.zeros_like(tr)
-            source[-1] = c.trflux / (p_half[-1] - p_half[-2])
+            source[-1] = flux / (p_half[-1] - p_half[-2])
             out.append(tr_dt + source - rdamp * rst)
         return tuple(out)
 
@@ -679,7 +686,8 @@ class SpectralCore:
         self.xtr = []
         for spec in c.extra_tracers:
             z = np.zeros((L, J, I))
-            x = dict(kind=spec.get("kind", "grid"), rc=spec.get("robert_coeff"), holes=bool(spec.get("hole_filling", False)), g=two(z), atm=two(z))
+            x = dict(kind=spec.get("kind", "grid"), rc=spec.get("robert_coeff"), holes=bool(spec.get("hole_filling", False)), sms=spec.get("sms"),
+                     g=two(z), atm=two(z))
             if x["rc"] is None:
                 x["rc"] = c.robert_coeff
             if x["kind"] == "spectral":
@@ -712,13 +720,13 @@ class SpectralCore:
             # atmosphere_mod keeps its OWN grid_tracers copy (atmosphere.F90:95,326), which only ever receives
             # the new level (spectral_dynamics.F90:1028): physics sees the un-Robert-filtered tracer
             dt_u, dt_v, dt_t, dt_tr = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur], self.ug[prev],
-                                                      self.vg[prev], self.tg[prev], self.tr_atm[prev], np.zeros_like(self.tr[prev]))
+                                                      self.vg[prev], self.tg[prev], self.tr_atm[prev], np.zeros_like(self.tr[prev]), sms=c.sphum_sms)
         else:
             dt_u, dt_v, dt_t = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur],
                                                self.ug[prev], self.vg[prev], self.tg[prev])
         for x in self.xtr if with_tracer else ():                            # hs_forcing's loop over rdt(:,:,:,n), hs_forcing.F90:248-266
             x["dt"] = self.hs_forcing(delta_t, self.p_half[cur], self.p_full[cur], self.ug[prev], self.vg[prev], self.tg[prev],
-                                      x["atm"][prev], np.zeros_like(x["g"][prev]))[3]
+                                      x["atm"][prev], np.zeros_like(x["g"][prev]), sms=x["sms"])[3]
         dt_ps = np.zeros((self.J, self.I))
         # --- initialize_corrections :1306-1338
         if c.do_mass_correction:

@@ -60,6 +60,32 @@ FIELD_TABLE_6 = FIELD_TABLE_3 + '''"TRACER", "atmos_mod", "grid_three"
           "profile_type", "fixed",   "surface_value=0.0" /
 '''
 
+# tracer_sms (hs_forcing.F90:251-261): sphum with a flux and a sink of its own, a grid tracer with only "flux=" (the sink stays hs_forcing_nml's), a
+# spectral tracer switched 'off', a spectral one with only "sink=" in seconds, a grid tracer with 'none' (entries 3 and 5 get nothing from hs_forcing
+# and stay zero) and one without the method (trflux, trsink)
+FIELD_TABLE_SMS = '''"TRACER", "atmos_mod", "sphum"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic"
+          "tracer_sms", "on", "flux=2.5e-5, sink=-2.0" /
+"TRACER", "atmos_mod", "g_flux"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic"
+          "tracer_sms", "on", "flux=4.0e-5" /
+"TRACER", "atmos_mod", "s_off"
+          "numerical_representation", "spectral"
+          "tracer_sms", "off" /
+"TRACER", "atmos_mod", "s_sink"
+          "numerical_representation", "spectral"
+          "tracer_sms", "on", "sink=86400." /
+"TRACER", "atmos_mod", "g_none"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic"
+          "tracer_sms", "none" /
+"TRACER", "atmos_mod", "g_plain"
+          "numerical_representation", "grid"
+          "advect_vert",              "finite_volume_parabolic" /
+'''
+
 RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54),        # lon_max = 2^5 3 and 2^5 5: the radix-3 and radix-5 passes of fft99 (fft99.F90:876-1228)
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
@@ -595,6 +621,9 @@ def main():
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr1|tr2|tr3)_", k) is not None),
         "run_T21L8_six_tracers": lambda: golden_run(
             "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE_6,
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr[1-6])_", k) is not None),
+        "run_T21L8_tracer_sms": lambda: golden_run(
+            "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE_SMS,
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr[1-6])_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "

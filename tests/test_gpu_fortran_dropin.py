@@ -175,6 +175,25 @@ def test_atmosphere_mod_options_from_fortran(tmp_path, golden_dir, fixture, leve
     assert np.max(np.abs(np.array(vals) - g["final_Tmin_Tmax_maxabsU"])) < 1e-9, (vals, g["final_Tmin_Tmax_maxabsU"])
 
 
+def test_atmosphere_mod_tracer_sms_from_fortran(tmp_path, golden_dir):
+    """tracer_sms of the field_table (hs_forcing.F90:251-261) read on the Fortran side (query_method + parse in spectral_dynamics_init of the drop-in)
+    and handed to the library: six tracers, sphum with "flux=2.5e-5, sink=-2.0"; 40 steps of atmos_model's loop against the reference run."""
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    d = str(tmp_path / "run")
+    mg.prepare_rundir(d, "T21", 8, "run", nsteps=40, dt=600, field_table=mg.FIELD_TABLE_SMS)
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 40, dt_atmos = 600\n /\n")
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    g = np.load(os.path.join(golden_dir, "run_T21L8_tracer_sms.npz"))
+    q = g["st_tr1_000040"]                                 # (lev, lat, lon)
+    qmax, qpt = [float(x) for x in re.search(r"DRIVE_TRACER qmax,q\(10,16,nlev\)=\s*(\S+)\s+(\S+)", stdout).groups()]
+    assert abs(qmax - q.max()) < 1e-9 * q.max() and abs(qpt - q[-1, 15, 9]) < 1e-9 * q.max(), (qmax, q.max(), qpt, q[-1, 15, 9])
+    plain = np.load(os.path.join(golden_dir, "run_T21L8_six_tracers.npz"))["st_tr1_000040"]
+    assert abs(q.max() - plain.max()) > 0.1 * plain.max()          # the entry's own flux and sink matter
+
+
 @pytest.mark.parametrize("moist", [False, True])
 def test_atmosphere_mod_restarts_from_fortran(tmp_path, golden_dir, moist):
     """The restart branch from the Fortran side (read_restart_or_do_coldstart, spectral_dynamics.F90:509-575; spectral_dynamics_end :1502-1531;

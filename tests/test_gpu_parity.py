@@ -469,6 +469,37 @@ def test_golden_six_tracers(golden_dir, tmp_path):
         make("T21", 8, num_tracers=9)
 
 
+def test_golden_tracer_sms(golden_dir):
+    """tracer_sms of the field_table (hs_forcing.F90:251-261): hs_forcing's surface source and global sink per tracer -- sphum with a flux and a sink of
+    its own, a grid tracer with only "flux=" (sink from hs_forcing_nml), a spectral tracer switched 'off', a spectral one with only "sink=" (seconds), a
+    grid tracer with 'none', one without the method.  40 steps at T21L8 against the reference run, the configuration taken from the field_table text
+    the reference ran with (isca_amd.atmosphere.tracers_from_field_table); entries 3 and 5 get nothing and stay exactly zero."""
+    from isca_amd import atmosphere as atm
+    g = np.load(os.path.join(golden_dir, "run_T21L8_tracer_sms.npz"))
+    grid = '"TRACER", "atmos_mod", "%s"\n "numerical_representation", "grid"\n "advect_vert", "finite_volume_parabolic"\n'
+    spec = '"TRACER", "atmos_mod", "%s"\n "numerical_representation", "spectral"\n'
+    table = (grid % "sphum" + ' "tracer_sms", "on", "flux=2.5e-5, sink=-2.0" /\n' + grid % "g_flux" + ' "tracer_sms", "on", "flux=4.0e-5" /\n'
+             + spec % "s_off" + ' "tracer_sms", "off" /\n' + spec % "s_sink" + ' "tracer_sms", "on", "sink=86400." /\n'
+             + grid % "g_none" + ' "tracer_sms", "none" /\n' + grid % "g_plain" + ' /\n')
+    keys, names = atm.tracers_from_field_table(atm.parse_field_table(table))
+    assert keys["tracer_sms"] == [1, 1, 1, 1, 1, 0] and keys["tracer_flux"][:5] == [2.5e-5, 4.0e-5, 0.0, 1.e-5, 0.0]
+    assert keys["tracer_sink"][:5] == [-2.0, -4.0, 0.0, 86400., 0.0] and names[3] == "s_sink"
+    dc = make("T21", 8, **keys); dc.cold_start()
+    tr = ["tr"] + [f"tr{k}" for k in range(2, 7)]
+    done = 0
+    for n in (1, 2, 40):
+        dc.step(n - done); done = n
+        err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k == "ug" else 1e-300))
+               for k in ("ug", "tg", "psg")}
+        for i, k in enumerate(tr):
+            want = g[f"st_tr{i + 1}_{n:06d}"]
+            err[k] = rel(dc.get(k), want) if np.abs(want).max() > 0 else float(np.abs(dc.get(k)).max())
+        print("tracer_sms, step", n, err)
+        assert max(err.values()) < 1e-9, (n, err)
+    assert not dc.get("tr3").any() and not dc.get("tr5").any() and dc.get("tr2").max() > 2e-5
+    dc.close()
+
+
 def test_golden_hole_filling(golden_dir):
     """hole_filling = 'on' for a spectral tracer: water_borrowing (atmos_spectral/model/water_borrowing.F90:38-136, spectral_dynamics.F90:1142-1144)
     fills negative values of the previous level from the four neighbours on the latitude circle and in the column.  The reference's three-tracer

@@ -373,6 +373,19 @@ def test_field_table_entries():
                      (text * 3, "at most 8")):
         with pytest.raises(IscaError, match=msg):
             atm.tracers_from_field_table(atm.parse_field_table(bad))
+    # the layout of the reference's own tables (src/extra/model/*/field_table): a '/' and commas inside quoted fields, tabs, parameter strings
+    ref_style = ('"TRACER", "atmos_mod", "sphum"\n          "longname",  "specific humidity"\n          "units",     "kg/kg"\n'
+                 '          "numerical_representation", "grid"\n\t  "hole_filling",             "off"\n'
+                 '          "advect_vert",              "finite_volume_parabolic"\n          "robert_filter",            "on"\n'
+                 '          "tracer_sms", "on", "flux=2.5e-5, sink=-2.0"\n          "profile_type", "fixed",   "surface_value=0.0" /\n'
+                 '"TRACER", "atmos_mod", "age"\n "units", "m/s/day"\n "tracer_sms", "OFF" /\n"TRACER", "atmos_mod", "dust"\n "tracer_sms", "on", "sink=3600." /\n')
+    ent = atm.parse_field_table(ref_style)
+    assert [e["name"] for e in ent] == ["sphum", "age", "dust"] and ent[0]["methods"]["units"] == ("kg/kg", "")
+    assert ent[0]["methods"]["tracer_sms"] == ("on", "flux=2.5e-5, sink=-2.0") and ent[0]["methods"]["profile_type"] == ("fixed", "surface_value=0.0")
+    # tracer_sms (hs_forcing.F90:251-261): own flux / sink, the one left out from hs_forcing_nml (here trflux = 3e-5), 'off' = no source and no sink
+    ksms, _ = atm.tracers_from_field_table(ent, None, 3.e-5, -5.0)
+    assert ksms["tracer_sms"] == [1, 1, 1] and ksms["tracer_flux"] == [2.5e-5, 0.0, 3.e-5] and ksms["tracer_sink"] == [-2.0, 0.0, 3600.]
+    assert "tracer_sms" not in keys
     # the humidity tracer is found by NAME (nhum = get_tracer_index('sphum' | 'mix_rat')): it must be tracer 1; without one the model is dry
     grid = '"TRACER", "atmos_mod", "%s"\n "numerical_representation", "grid"\n "advect_vert", "finite_volume_parabolic" /\n'
     with pytest.raises(IscaError, match="must be the first atmos_mod entry"):

@@ -253,6 +253,27 @@ def test_six_tracers(golden_dir):
                 assert rel(x["g"][cur], g[f"st_tr{n + 2}_{tag}"]) < 1e-11, (n + 2, tag)
 
 
+def test_tracer_sms(golden_dir):
+    """tracer_sms (hs_forcing.F90:251-261): per-entry flux / sink of hs_forcing's tracer source -- own values, one of the two left at the namelist's,
+    'off' and 'none' (no tendency: those tracers stay exactly zero).  The numpy restatement against the reference run."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_tracer_sms.npz"))
+    sc = core("T21", 8, sphum_sms=(2.5e-5, -2.0), extra_tracers=(
+        dict(kind="grid", sms=(4.0e-5, None)), dict(kind="spectral", sms=(0., 0.)), dict(kind="spectral", sms=(None, 86400.)),
+        dict(kind="grid", sms=(0., 0.)), dict(kind="grid")))
+    sc.cold_start()
+    for i in range(1, 41):
+        sc.step()
+        if i in (1, 2, 40):
+            cur, tag = sc.current, f"{i:06d}"
+            assert rel(sc.tr[cur], g[f"st_tr1_{tag}"]) < 1e-11
+            for n, x in enumerate(sc.xtr):
+                want = g[f"st_tr{n + 2}_{tag}"]
+                if n in (1, 3):
+                    assert not want.any() and not x["g"][cur].any()
+                else:
+                    assert rel(x["g"][cur], want) < 1e-11, (n + 2, tag)
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
