@@ -59,6 +59,7 @@ write(*,'(a,3es24.16)') 'DRIVE_STATE Tmin,Tmax,maxabsU=', minval(tg), maxval(tg)
 if(ntprog > 0) then
   call get_grid3('tr', 1, q)
   write(*,'(a,2es24.16)') 'DRIVE_TRACER qmax,q(10,16,nlev)=', maxval(q), q(is+9, min(js+15, je), nlev)
+  if(nlev > 1) write(*,'(a,es24.16)') 'DRIVE_TRACER_ALOFT max q(:,:,nlev-1)=', maxval(q(:,:,nlev-1))    ! (what the vertical advection carried up)
 endif
 call get_lat_max(latmax)
 write(*,'(a,2i6)') 'DRIVE_ROWS js,je=', js, je       ! this process's latitude band (all rows with one rank)

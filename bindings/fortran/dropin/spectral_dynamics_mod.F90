@@ -245,12 +245,10 @@ do ntr = 1, num_tracers
     case('spectral')
       tracer_attributes(ntr)%advect_horiz = 'spectral'; cfg%tracer_spectral(ntr) = 1
       if(lowercase(trim(tracer_attributes(ntr)%hole_filling)) == 'on') cfg%tracer_hole_filling(ntr) = 1      ! water_borrowing (spectral_dynamics.F90:1142)
-      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'SECOND_CENTERED') &
-        call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%advect_vert)//' is not available for a spectral tracer here', FATAL)
+      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'SECOND_CENTERED') cfg%tracer_advect_vert(ntr) = advect_scheme(tracer_attributes(ntr)%advect_vert, 'advect_vert')
     case('grid')
       tracer_attributes(ntr)%advect_horiz = 'van_leer'; cfg%tracer_spectral(ntr) = 0
-      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'FINITE_VOLUME_PARABOLIC') &
-        call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%advect_vert)//' is not available for a grid tracer here', FATAL)
+      if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'FINITE_VOLUME_PARABOLIC') cfg%tracer_advect_vert(ntr) = advect_scheme(tracer_attributes(ntr)%advect_vert, 'advect_vert')
     case default
       call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%numerical_representation)//' is an invalid numerical_representation', FATAL)
   end select

@@ -67,6 +67,7 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: tracer_hole_filling(ISCA_MAX_TRACERS)
   integer(c_int) :: tracer_sms(ISCA_MAX_TRACERS)       ! 1: the entry's own tracer_flux / tracer_sink instead of hs_forcing_nml's trflux / trsink
   real(c_double) :: tracer_flux(ISCA_MAX_TRACERS), tracer_sink(ISCA_MAX_TRACERS)
+  integer(c_int) :: tracer_advect_vert(ISCA_MAX_TRACERS)   ! -1 the representation's standard scheme, 0 second_centered .. 3 finite_volume_parabolic
 end type
 
 interface

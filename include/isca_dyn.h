@@ -141,6 +141,12 @@ typedef struct isca_dyn_config {
    * no tendency from hs_forcing).  Only with physics = 0 (hs_forcing is the physics). */
   int tracer_sms[ISCA_MAX_TRACERS];
   double tracer_flux[ISCA_MAX_TRACERS], tracer_sink[ISCA_MAX_TRACERS];
+  /* advect_vert of the field_table entries ([k] = tracer k+1, tracer 1 included; spectral_dynamics.F90:395-408): -1 = the standard scheme of the
+   * entry's representation (the one the fused kernels implement: 'grid' finite_volume_parabolic, 'spectral' second_centered), else
+   * 0 second_centered, 1 fourth_centered, 2 van_leer_linear, 3 finite_volume_parabolic.  A 'grid' tracer applies it to the new level after the
+   * horizontal step (:1161); a 'spectral' tracer to the current level (centred schemes) or the previous one (finite-volume schemes, :1135-1141).
+   * A non-standard scheme runs vert_advection on whole columns in a kernel of its own (4..64 levels), like vert_advect_uv / vert_advect_t. */
+  int tracer_advect_vert[ISCA_MAX_TRACERS];
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

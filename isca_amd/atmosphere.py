@@ -410,7 +410,7 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
     if hum and hum[0] != 0:
         raise IscaError(f"field_table: the humidity tracer ({entries[hum[0]]['name']}) must be the first atmos_mod entry "
                         f"(the first entry is {entries[0]['name']}): tracer 1 is the one the water correction, virtual temperature and moist physics use")
-    spectral, robert, names, holes, sms = [], [], [], [], []
+    spectral, robert, names, holes, sms, vert = [], [], [], [], [], []
     for k, e in enumerate(entries):
         m = e["methods"]
         rep = m.get("numerical_representation", ("spectral", ""))[0].lower()      # default_representation (:145)
@@ -419,9 +419,9 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
         adv = m.get("advect_vert", ("second_centered", ""))[0].lower()
         if adv not in ("second_centered", "fourth_centered", "van_leer_linear", "finite_volume_parabolic"):
             raise IscaError(f"spectral_dynamics_init: {adv} is an invalid advect_vert")                           # :406-407
-        want = "finite_volume_parabolic" if rep == "grid" else "second_centered"
-        if adv != want:
-            raise IscaError(f"field_table: tracer {e['name']}: advect_vert = {adv} is not available for a {rep} tracer (only {want})")
+        # the scheme the fused kernels implement for the representation is handed over as -1, any other one by its number (tracer_advect_vert)
+        std = "finite_volume_parabolic" if rep == "grid" else "second_centered"
+        vert.append(-1 if adv == std else ("second_centered", "fourth_centered", "van_leer_linear", "finite_volume_parabolic").index(adv))
         hole = 1 if rep == "spectral" and m.get("hole_filling", ("off", ""))[0].lower() == "on" else 0    # water_borrowing (:1142); ignored for grid tracers (:364-367)
         if k == 0 and rep != "grid":
             raise IscaError(f"field_table: the first tracer ({e['name']}) must be a grid tracer")
@@ -453,6 +453,8 @@ def tracers_from_field_table(entries: list[dict], robert_coeff: float | None = N
             raise IscaError(f"field_table: tracer {e['name']}: a robert_coeff of its own is only available from the second tracer on")
         spectral.append(1 if rep == "spectral" else 0); robert.append(rc); names.append(e["name"]); holes.append(hole)
     keys = dict(num_tracers=len(entries), tracer_spectral=spectral, tracer_robert_coeff=robert, tracer_hole_filling=holes)
+    if any(v >= 0 for v in vert):
+        keys["tracer_advect_vert"] = vert
     if any(x is not None for x in sms):        # a parameter the entry leaves out keeps hs_forcing_nml's value (trflux, trsink: the arguments)
         keys.update(tracer_sms=[0 if x is None else 1 for x in sms],
                     tracer_flux=[0.0 if x is None else float(trflux if x[0] is None else x[0]) for x in sms],

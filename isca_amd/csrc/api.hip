@@ -113,7 +113,7 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   c->use_virtual_temperature = 0;
   c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1; c->make_symmetric = 0;
   c->vert_difference_option = 0;
-  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_hole_filling[k] = 0; c->tracer_sms[k] = 0; c->tracer_flux[k] = 0.0; c->tracer_sink[k] = 0.0; }
+  for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_hole_filling[k] = 0; c->tracer_sms[k] = 0; c->tracer_flux[k] = 0.0; c->tracer_sink[k] = 0.0; c->tracer_advect_vert[k] = -1; }
   c->damping_option = 0; c->cutoff_wn = 15; c->damping_coeff_vor = c->damping_coeff_div = -1.0; c->damping_order_vor = c->damping_order_div = -1;
   isca_moist_config &m = c->moist;
   m.roughness_mom = m.roughness_heat = m.roughness_moist = 3.21e-05;
@@ -205,6 +205,10 @@ static void check_config(const isca_dyn_config &c) {
   if (!(c.radius > 0.0)) fail("constants_nml: radius must be positive");
   if (c.physics < 0 || c.physics > 2) fail("physics must be 0 (hs_forcing), 1 (idealized_moist_phys) or 2 (tendencies supplied by the caller)");
   if (c.num_tracers < 0 || c.num_tracers > ISCA_MAX_TRACERS) fail("num_tracers must be 0.." + std::to_string(ISCA_MAX_TRACERS));
+  for (int k = 0; k < c.num_tracers; ++k)
+    if (c.tracer_advect_vert[k] < -1 || c.tracer_advect_vert[k] > 3)
+      fail("spectral_dynamics_init: tracer_advect_vert must be -1 (the representation's standard scheme) or 0..3 (second_centered, fourth_centered, "
+           "van_leer_linear, finite_volume_parabolic): any other advect_vert is invalid");
   if (c.num_tracers > 1) {
     if (c.raw_filter_coeff != 1.0) fail("more than one tracer: raw_filter_coeff must be 1");
     for (int k = 1; k < c.num_tracers; ++k) {
@@ -614,7 +618,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
     // (a vertical advection scheme other than second-centred reads the stored previous level in a kernel of its own: eager fixers)
     const bool vadv_ext = cfg->vert_advect_uv != 0 || cfg->vert_advect_t != 0;
-    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext &&
+    const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
+    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext && tr1_std &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1106,7 +1111,10 @@ static void spectral_tracer_step(isca_dyn *h, const StepScalars &sc, int e) {
   launch_spec_gradient(g, d, d.trxs[sc.cur][e], d.Si, col_pitch(fl.ncol), 0, g.L, g.L, h->stream);
   run_inverse(h, fl, 1);
   launch_hadv_combine(g, d.ug[sc.cur], d.vg[sc.cur], d.scratch_g[0], d.scratch_g[1], dt_tr, g.L, h->stream);
-  launch_vert_advection_centered(*h, d.wg, d.psg[sc.cur], d.trx[sc.cur][e], dt_tr, h->stream);
+  // vert_advection with the entry's advect_vert (:1135-1141): the centred schemes on the current level, the finite-volume ones on the previous
+  const int vs = tracer_vert_scheme(*h, e + 1);
+  if (vs == 0) launch_vert_advection_centered(*h, d.wg, d.psg[sc.cur], d.trx[sc.cur][e], dt_tr, h->stream);
+  else launch_vert_advection_field(*h, vs, d.psg[sc.cur], d.trx[vs == 1 ? sc.cur : sc.prev][e], dt_tr, sc.delta_t, h->stream);
   if (h->cfg.tracer_hole_filling[e + 1]) launch_water_borrowing(*h, d.psg[sc.cur], d.trx[sc.prev][e], dt_tr, sc.delta_t, h->stream);     // :1142-1144
   dev_g2s(h, dt_tr, dt_trs, g.L, 1, OP_NONE);
   launch_spec_tracer_update(*h, sc, e, dt_trs, h->stream);

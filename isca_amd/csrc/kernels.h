@@ -79,6 +79,8 @@ void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, doubl
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part = -1);
 void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s);
 void launch_vert_advection_centered(const isca_dyn &h, const double *w, const double *ps, const double *r, double *rdt, hipStream_t s);
+void launch_vert_advection_field(const isca_dyn &h, int scheme, const double *ps, const double *r, double *rdt, double delta_t, hipStream_t s);
+int tracer_vert_scheme(const isca_dyn &h, int k);     // advect_vert of field_table entry k (0-based): 0 second_centered .. 3 finite_volume_parabolic
 // water_borrowing (hole_filling = 'on' of a 'spectral' tracer): dt_q corrected from the previous level's values q_prev, dp of surface pressure ps
 void launch_water_borrowing(const isca_dyn &h, const double *ps, const double *q_prev, double *dt_q, double delta_t, hipStream_t s);
 void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, const double *dta, double delta_t, double robert, double raw,

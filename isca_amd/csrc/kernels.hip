@@ -1791,7 +1791,9 @@ __device__ void vadv_column(int L, double dt, const double *w, const double *dz,
   double flux[VADV_MAXL + 1];
   flux[0] = w[0] * r[0];
   flux[L] = w[L] * r[L - 1];
-  if (SCHEME == 1) {                 // FOURTH_CENTERED
+  if (SCHEME == 0) {                 // SECOND_CENTERED (:175-180)
+    for (int k = 1; k <= L - 1; ++k) flux[k] = w[k] * (0.5 * (r[k] + r[k - 1]));
+  } else if (SCHEME == 1) {          // FOURTH_CENTERED
     const double c1 = 7. / 12., c2 = 1. / 12.;
     for (int k = 2; k <= L - 2; ++k) flux[k] = w[k] * (c1 * (r[k] + r[k - 1]) - c2 * (r[k + 1] + r[k - 2]));
     flux[1] = w[1] * (0.5 * (r[1] + r[0]));
@@ -1910,6 +1912,20 @@ void launch_vert_advection_schemes(const isca_dyn &h, const StepScalars &sc, hip
   a.f[0] = d.ug[tuv]; a.f[1] = d.vg[tuv]; a.f[2] = d.tg[tt];
   a.dt[0] = d.g_dtu; a.dt[1] = d.g_dtv; a.dt[2] = d.g_dtT;
   a.scheme[0] = a.scheme[1] = suv; a.scheme[2] = st;
+  const size_t lev = (size_t)g.Jl * g.I;
+  hipLaunchKernelGGL(k_vert_advection_scheme, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, g, a);
+}
+
+// one field with a scheme other than second_centered: rdt += vert_advection(delta_t, wg, dp(ps), r) -- a 'spectral' tracer's advect_vert
+// (spectral_dynamics.F90:1135-1141: fourth_centered on the current level, the finite-volume schemes on the previous one)
+void launch_vert_advection_field(const isca_dyn &h, int scheme, const double *ps, const double *r, double *rdt, double delta_t, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  if (g.L < 4 || g.L > VADV_MAXL) throw std::runtime_error("advect_vert other than second_centered needs 4..64 levels");
+  VadvArgs a;
+  a.wg = d.wg; a.ps = ps; a.dpk = d.dpk; a.dbk = d.dbk; a.cosm = d.cosm_lat_l; a.delta_t = delta_t;
+  a.f[0] = a.f[1] = nullptr; a.dt[0] = a.dt[1] = nullptr; a.scheme[0] = a.scheme[1] = 0;
+  a.f[2] = r; a.dt[2] = rdt; a.scheme[2] = scheme;
   const size_t lev = (size_t)g.Jl * g.I;
   hipLaunchKernelGGL(k_vert_advection_scheme, dim3((unsigned)((lev + 63) / 64)), dim3(64), 0, s, g, a);
 }
@@ -2537,6 +2553,45 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   }
 }
 
+// A 'grid' tracer whose advect_vert is not finite_volume_parabolic (update_tracers, spectral_dynamics.F90:1161: vert_advection with the entry's
+// scheme on tr_future after the horizontal step): one thread per column, the column in private arrays (vadv_column), then the same update,
+// filter part and column sums as k_tracer_vert.  An option path: the reference's own field_tables all use finite_volume_parabolic.
+template <int SCHEME>
+__global__ __launch_bounds__(64) void k_tracer_vert_scheme(Geom g, TracerArgs a) {
+  const size_t lev = (size_t)g.Jl * g.I, c2 = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (c2 >= lev) return;
+  const int L = g.L;
+  double w[VADV_MAXL + 1], dz[VADV_MAXL], r[VADV_MAXL], rdt[VADV_MAXL];
+  double tpv[VADV_MAXL], tav[VADV_MAXL], tcv[VADV_MAXL];
+  const double ps = mul_nc(a.ps_cur[c2], a.pend_c[PEND_FACTOR]), psp = a.ps_prev[c2];
+  const int kmw = a.kmask[c2], km = kmask_byte(kmw, 0);
+  for (int k = 0; k <= L; ++k) w[k] = a.wg[c2 + (size_t)k * lev];
+  w[0] = 0.0;
+  for (int k = 0; k < L; ++k) {         // tr(prev) aliases tr(fut) from the second step on: everything is read before the first store
+    const size_t q = c2 + (size_t)k * lev;
+    dz[k] = a.dpk[k] + a.dbk[k] * ps;
+    r[k] = a.trh[q];
+    tcv[k] = water_corr(a.tr_cur_rd[q], k, kmask_byte(kmw, 1), a.pend_c[PEND_WFAC]);
+    tpv[k] = fma(a.rb, tcv[k], a.trp[q]);
+    tav[k] = tr_atm_of(a, k, kmw, a.tratm_p[q]);
+  }
+  vadv_column<SCHEME>(L, a.dt, w, dz, r, rdt);
+  double s0 = 0., s1 = 0., s2 = 0., s3 = 0., s4 = 0.;
+  for (int k = 0; k < L; ++k) {
+    const size_t q = c2 + (size_t)k * lev;
+    const double trf = r[k] + a.dt * rdt[k];
+    const double q0 = tr_q0_of(a, g, k, tpv[k], tav[k], ps);
+    a.tr_cur[q] = tcv[k] + a.robert * (tpv[k] - 2.0 * tcv[k]);
+    a.tr_fut[q] = trf;
+    if (a.tr_part) a.tr_part[q] = tpv[k] - 2.0 * tcv[k];
+    const double msk = (k >= km) ? 1.0 : 0.0;
+    s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
+    s1 += trf * a.dpk[k]; s2 += trf * a.dbk[k];
+    s3 += msk * trf * a.dpk[k]; s4 += msk * trf * a.dbk[k];
+  }
+  a.wcol[0 * lev + c2] = s0; a.wcol[1 * lev + c2] = s1; a.wcol[2 * lev + c2] = s2; a.wcol[3 * lev + c2] = s3; a.wcol[4 * lev + c2] = s4;
+}
+
 // robert_coeff of field_table entry k+1 (spectral_dynamics.F90:340-351): its own, or the dynamics' one
 // hs_forcing's source and sink for field_table entry k (0-based; hs_forcing.F90:250-265): the entry's tracer_sms values or hs_forcing_nml's
 static double tracer_sms_flux(const isca_dyn &h, int k) { return (k >= 0 && h.cfg.tracer_sms[k]) ? h.cfg.tracer_flux[k] : h.cfg.trflux; }
@@ -2544,6 +2599,11 @@ static double tracer_sms_rdamp(const isca_dyn &h, int k) {
   double r = (k >= 0 && h.cfg.tracer_sms[k]) ? h.cfg.tracer_sink[k] : h.cfg.trsink;       // tracer_source_sink, hs_forcing.F90:697-699
   if (r < 0.) r = -86400. * r;
   return r > 0. ? 1. / r : r;
+}
+// advect_vert of field_table entry k (0-based): the entry's, or the representation's standard one (grid: finite_volume_parabolic, spectral: second_centered)
+int tracer_vert_scheme(const isca_dyn &h, int k) {
+  const int v = h.cfg.tracer_advect_vert[k];
+  return v >= 0 ? v : ((k > 0 && h.cfg.tracer_spectral[k]) ? 0 : 3);
 }
 static double tracer_robert(const isca_dyn &h, int k) {
   return h.cfg.tracer_robert_coeff[k] >= 0.0 ? h.cfg.tracer_robert_coeff[k] : h.cfg.robert_coeff;
@@ -2607,8 +2667,15 @@ static void launch_tracer_horiz_kernel(const Geom &g, const TracerArgs &a, size_
   } else if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);
   else hipLaunchKernelGGL(k_tracer_horiz<1>, grid, block, ldsh, s, g, a);
 }
-static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStream_t s) {
+static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStream_t s, int scheme = 3) {
   const dim3 grid((unsigned)((size_t)g.Jl * g.I / 64));
+  if (scheme != 3) {                              // the entry's advect_vert: 0 second_centered, 1 fourth_centered, 2 van_leer_linear
+    if (g.L < 4 || g.L > VADV_MAXL) throw std::runtime_error("advect_vert other than finite_volume_parabolic needs 4..64 levels");
+    if (scheme == 0) hipLaunchKernelGGL(k_tracer_vert_scheme<0>, grid, dim3(64), 0, s, g, a);
+    else if (scheme == 1) hipLaunchKernelGGL(k_tracer_vert_scheme<1>, grid, dim3(64), 0, s, g, a);
+    else hipLaunchKernelGGL(k_tracer_vert_scheme<2>, grid, dim3(64), 0, s, g, a);
+    return;
+  }
   if (g.L > 40 && g.L <= 60) {                  // 12 wavefronts of 5 levels (164 VGPRs, 3 wavefronts per SIMD) instead of 8 of 8 (207)
     const int NW = (g.L + 4) / 5;
     if (a.ppm) hipLaunchKernelGGL((k_tracer_vert<5, 12, false>), grid, dim3(64 * NW), 0, s, g, a);
@@ -2631,14 +2698,14 @@ void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int 
   const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
   if (part != 1) launch_tracer_horiz_kernel(g, a, ldsh, s);
   if (part == 0) return;
-  launch_tracer_vert_kernel(g, a, s);
+  launch_tracer_vert_kernel(g, a, s, tracer_vert_scheme(h, 0));
   // further 'grid' tracers of the field_table (update_tracers' loop, spectral_dynamics.F90:1132,1155-1180): the same transport, their own
   // time levels; the column sums go to a spare array (only tracer 1 is water) and the filter's `future` term is added at the end of the step
   for (int e = 0; e + 1 < h.cfg.num_tracers; ++e) {
     if (h.cfg.tracer_spectral[e + 1]) continue;
     const TracerArgs b = further_tracer_args(h, sc, a, e);
     launch_tracer_horiz_kernel(g, b, ldsh, s);
-    launch_tracer_vert_kernel(g, b, s);
+    launch_tracer_vert_kernel(g, b, s, tracer_vert_scheme(h, e + 1));
   }
 }
 

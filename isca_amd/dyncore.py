@@ -67,6 +67,7 @@ class _CConfig(C.Structure):
         ("vert_advect_uv", C.c_int), ("vert_advect_t", C.c_int), ("use_implicit", C.c_int), ("make_symmetric", C.c_int),
         ("vert_difference_option", C.c_int), ("tracer_hole_filling", C.c_int * MAX_TRACERS),
         ("tracer_sms", C.c_int * MAX_TRACERS), ("tracer_flux", C.c_double * MAX_TRACERS), ("tracer_sink", C.c_double * MAX_TRACERS),
+        ("tracer_advect_vert", C.c_int * MAX_TRACERS),
     ]
 
 
@@ -230,7 +231,7 @@ def default_config(resolution: str | None = None, **overrides) -> _CConfig:
             for i, x in enumerate(v):
                 arr[i] = float(x)
             c.vert_coord_input = 1
-        elif k in ("tracer_spectral", "tracer_robert_coeff", "tracer_hole_filling", "tracer_sms", "tracer_flux", "tracer_sink"):   # field_table entries, [k] = tracer k+1
+        elif k in ("tracer_spectral", "tracer_robert_coeff", "tracer_hole_filling", "tracer_sms", "tracer_flux", "tracer_sink", "tracer_advect_vert"):   # field_table entries, [k] = tracer k+1
             if len(v) > MAX_TRACERS:
                 raise IscaError(f"{k}: more than {MAX_TRACERS} tracers")
             arr = getattr(c, k)

@@ -71,9 +71,11 @@ class Config:
     num_tracers: int = 1          # the dry field_table carries one grid tracer (sphum)
     # further field_table entries after sphum (update_tracers' loop, spectral_dynamics.F90:1132-1183): dicts with
     # kind = 'grid' | 'spectral', robert_coeff (None: the namelist's), hole_filling (spectral only: water_borrowing.F90),
+    # advect_vert (None: grid finite_volume_parabolic, spectral second_centered),
     # sms = (flux, sink) of the entry's tracer_sms method (hs_forcing.F90:251-261; 'off' / 'none' = (0, 0); None inside: the namelist's)
     extra_tracers: tuple = ()
     sphum_sms: tuple = None       # the same for tracer 1
+    sphum_advect_vert: str = "finite_volume_parabolic"
     # hs_forcing_nml
     t_zero: float = 315.0
     t_strat: float = 200.0
@@ -686,7 +688,7 @@ class SpectralCore:
         self.xtr = []
         for spec in c.extra_tracers:
             z = np.zeros((L, J, I))
-            x = dict(kind=spec.get("kind", "grid"), rc=spec.get("robert_coeff"), holes=bool(spec.get("hole_filling", False)), sms=spec.get("sms"),
+            x = dict(kind=spec.get("kind", "grid"), rc=spec.get("robert_coeff"), holes=bool(spec.get("hole_filling", False)), sms=spec.get("sms"), vert=spec.get("advect_vert"),
                      g=two(z), atm=two(z))
             if x["rc"] is None:
                 x["rc"] = c.robert_coeff
@@ -790,7 +792,8 @@ class SpectralCore:
         if tmin < c.valid_range_t[0] or tmax > c.valid_range_t[1]:
             raise FloatingPointError("temperatures out of valid range")      # :940-972
         if with_tracer:                                                      # update_tracers :1007
-            tr_cur_new, tr_future, part_tr = self.update_grid_tracer(self.tr[prev], self.tr[cur], dt_tr, u, v, wg, p_half, delta_t)
+            tr_cur_new, tr_future, part_tr = self.update_grid_tracer(self.tr[prev], self.tr[cur], dt_tr, u, v, wg, p_half, delta_t,
+                                                                          advect_vert=c.sphum_advect_vert)
             if prev == cur:
                 self.tr[cur] = tr_cur_new
             else:
@@ -801,7 +804,8 @@ class SpectralCore:
                     self._update_spectral_tracer(x, u, v, wg, p_half, delta_t, prev, cur, fut)
                 else:
                     g = x["g"]
-                    g[cur], g[fut], x["part"] = self.update_grid_tracer(g[prev], g[cur], x["dt"], u, v, wg, p_half, delta_t, rc=x["rc"])
+                    g[cur], g[fut], x["part"] = self.update_grid_tracer(g[prev], g[cur], x["dt"], u, v, wg, p_half, delta_t, rc=x["rc"],
+                                                                        advect_vert=x["vert"] or "finite_volume_parabolic")
         # --- compute_corrections :1213-1302
         if c.do_mass_correction:
             mean_ps_tmp = self.area_weighted_global_mean(self.psg[fut])
@@ -1027,6 +1031,49 @@ class SpectralCore:
         slope[0] = 0.0; slope[-1] = 0.0
         return slope
 
+    @staticmethod
+    def vert_advection_fourth_centered(w, dz, r):
+        """vert_advection_3d, scheme=FOURTH_CENTERED, no mask (:239-276): fourth order inside, second order at the two interfaces next to the ends."""
+        L = r.shape[0]
+        flux = np.zeros_like(w)
+        flux[0] = w[0] * r[0]
+        flux[L] = w[L] * r[L - 1]
+        flux[2:L - 1] = w[2:L - 1] * (7. / 12. * (r[2:L - 1] + r[1:L - 2]) - 1. / 12. * (r[3:L] + r[0:L - 3]))
+        flux[1] = w[1] * (0.5 * (r[1] + r[0]))
+        flux[L - 1] = w[L - 1] * (0.5 * (r[L - 1] + r[L - 2]))
+        return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
+
+    @staticmethod
+    def vert_advection_van_leer(dt, w, dz, r):
+        """vert_advection_3d, scheme=VAN_LEER_LINEAR = FINITE_VOLUME_LINEAR (:279-299) with slope_z(limit=.true., linear=.true.) (:505-568)."""
+        L = r.shape[0]
+        grad = np.zeros_like(r)
+        grad[1:] = (r[1:] - r[:-1]) / (dz[1:] + dz[:-1])
+        slope = np.zeros_like(r)
+        slope[1:-1] = (grad[2:] + grad[1:-1]) * dz[1:-1]
+        rmin = np.minimum(np.minimum(r[:-2], r[1:-1]), r[2:]); rmax = np.maximum(np.maximum(r[:-2], r[1:-1]), r[2:])
+        slope[1:-1] = np.where(slope[1:-1] >= 0, 1.0, -1.0) * np.minimum(np.minimum(np.abs(slope[1:-1]), 2. * (r[1:-1] - rmin)), 2. * (rmax - r[1:-1]))
+        flux = np.zeros_like(w)
+        flux[0] = w[0] * r[0]
+        flux[L] = w[L] * r[L - 1]
+        wk = w[1:L]
+        up = r[:-1] + 0.5 * slope[:-1] * (1. - dt * wk / dz[:-1])
+        dn = r[1:] - 0.5 * slope[1:] * (1. + dt * wk / dz[1:])
+        flux[1:L] = wk * np.where(wk >= 0., up, dn)
+        return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
+
+    def vert_advection(self, scheme, dt, w, dz, r):
+        """vert_advection with one of the four schemes spectral_dynamics_mod offers (spectral_dynamics.F90:280-301, 395-408), ADVECTIVE_FORM."""
+        if scheme == "second_centered":
+            return self.vert_advection_second_centered(w, dz, r)
+        if scheme == "fourth_centered":
+            return self.vert_advection_fourth_centered(w, dz, r)
+        if scheme == "van_leer_linear":
+            return self.vert_advection_van_leer(dt, w, dz, r)
+        if scheme == "finite_volume_parabolic":
+            return self.vert_advection_ppm(dt, w, dz, r)
+        raise ValueError(scheme)
+
     def vert_advection_ppm(self, dt, w, dz, r):
         """vert_advection_3d, scheme=FINITE_VOLUME_PARABOLIC, form=ADVECTIVE_FORM (:301-438, :467-470)."""
         L = r.shape[0]
@@ -1073,13 +1120,13 @@ class SpectralCore:
             flux[k] = wk * np.where(wk >= 0., rst_p, rst_m)
         return -(flux[1:] - flux[:-1] - r * (w[1:] - w[:-1])) / dz
 
-    def update_grid_tracer(self, tr_prev, tr_cur, dt_tr, u, v, wg, p_half, delta_t, rc=None):
+    def update_grid_tracer(self, tr_prev, tr_cur, dt_tr, u, v, wg, p_half, delta_t, rc=None, advect_vert="finite_volume_parabolic"):
         """update_tracers, 'grid' branch (spectral_dynamics.F90:1155-1180); returns (tr_cur filtered part A, tr_future)."""
         tr_future = tr_prev + delta_t * dt_tr
         dq = self.a_grid_horiz_advection(u, v, tr_future, delta_t, np.zeros_like(tr_future))
         tr_future = tr_future + delta_t * dq
         dp = p_half[1:] - p_half[:-1]
-        tr_future = tr_future + delta_t * self.vert_advection_ppm(delta_t, wg, dp, tr_future)
+        tr_future = tr_future + delta_t * self.vert_advection(advect_vert, delta_t, wg, dp, tr_future)
         rc, raw = (self.cfg.robert_coeff if rc is None else rc), self.cfg.raw_filter_coeff
         part = tr_prev - 2.0 * tr_cur
         tr_cur_new = tr_cur + rc * part * raw
@@ -1091,7 +1138,8 @@ class SpectralCore:
         (compute_spectral_damping without a kind, spectral_damping.F90:172-200), leapfrog_2level_A, synthesis of the new level."""
         dt = self.horizontal_advection(x["s"][cur], u, v, x["dt"])
         dp = p_half[1:] - p_half[:-1]
-        dt = dt + self.vert_advection_second_centered(wg, dp, x["g"][cur])
+        scheme = x["vert"] or "second_centered"                              # centred schemes on the current level, finite-volume ones on the previous (:1135-1141)
+        dt = dt + self.vert_advection(scheme, delta_t, wg, dp, x["g"][cur if scheme.endswith("centered") else prev])
         if x["holes"]:
             dt = self.water_borrowing(dt, x["g"][prev], cur, p_half, delta_t)
         dts = self.compute_spectral_damping(x["s"][prev], self.trans_grid_to_spherical(dt), delta_t, "t")

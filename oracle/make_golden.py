@@ -86,6 +86,27 @@ FIELD_TABLE_SMS = '''"TRACER", "atmos_mod", "sphum"
           "advect_vert",              "finite_volume_parabolic" /
 '''
 
+# advect_vert per entry (spectral_dynamics.F90:395-408): sphum as always, 'grid' tracers with second_centered (no advect_vert line: the module's default),
+# fourth_centered and van_leer_linear, 'spectral' tracers with fourth_centered (current level), van_leer_linear and finite_volume_parabolic (previous level)
+FIELD_TABLE_VERT = FIELD_TABLE + '''"TRACER", "atmos_mod", "g_second"
+          "numerical_representation", "grid" /
+"TRACER", "atmos_mod", "g_fourth"
+          "numerical_representation", "grid"
+          "advect_vert",              "fourth_centered" /
+"TRACER", "atmos_mod", "g_vanleer"
+          "numerical_representation", "grid"
+          "advect_vert",              "van_leer_linear" /
+"TRACER", "atmos_mod", "s_fourth"
+          "numerical_representation", "spectral"
+          "advect_vert",              "fourth_centered" /
+"TRACER", "atmos_mod", "s_vanleer"
+          "numerical_representation", "spectral"
+          "advect_vert",              "van_leer_linear" /
+"TRACER", "atmos_mod", "s_ppm"
+          "numerical_representation", "spectral"
+          "advect_vert",              "finite_volume_parabolic" /
+'''
+
 RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T10": (32, 16, 10, 11), "T21": (64, 32, 21, 22),
        "T31": (96, 48, 31, 32), "T53": (160, 80, 53, 54),        # lon_max = 2^5 3 and 2^5 5: the radix-3 and radix-5 passes of fft99 (fft99.F90:876-1228)
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
@@ -625,6 +646,13 @@ def main():
         "run_T21L8_tracer_sms": lambda: golden_run(
             "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE_SMS,
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr[1-6])_", k) is not None),
+        "run_T21L8_tracer_advect_vert": lambda: golden_run(
+            "T21", 8, 60, (1, 2, 3, 60), field_table=FIELD_TABLE_VERT,
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr[1-7])_", k) is not None),
+        # sphum itself with advect_vert = van_leer_linear (the water correction then acts on a tracer the option kernel advected)
+        "run_T21L8_sphum_van_leer": lambda: golden_run(
+            "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE.replace('"finite_volume_parabolic"', '"van_leer_linear"'),
+            keep=lambda k: re.match(r"st_(ug|tg|psg|tr1)_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

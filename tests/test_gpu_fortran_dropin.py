@@ -192,6 +192,17 @@ def test_atmosphere_mod_tracer_sms_from_fortran(tmp_path, golden_dir):
     assert abs(qmax - q.max()) < 1e-9 * q.max() and abs(qpt - q[-1, 15, 9]) < 1e-9 * q.max(), (qmax, q.max(), qpt, q[-1, 15, 9])
     plain = np.load(os.path.join(golden_dir, "run_T21L8_six_tracers.npz"))["st_tr1_000040"]
     assert abs(q.max() - plain.max()) > 0.1 * plain.max()          # the entry's own flux and sink matter
+    # advect_vert of an entry other than the fused scheme (here sphum with van_leer_linear), also read on the Fortran side
+    d = str(tmp_path / "vert")
+    mg.prepare_rundir(d, "T21", 8, "run", nsteps=40, dt=600, field_table=mg.FIELD_TABLE.replace('"finite_volume_parabolic"', '"van_leer_linear"'))
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 40, dt_atmos = 600\n /\n")
+    stdout = mg.run_harness(d, exe=exe, timeout=900)
+    q = np.load(os.path.join(golden_dir, "run_T21L8_sphum_van_leer.npz"))["st_tr1_000040"]
+    qmax, qpt = [float(x) for x in re.search(r"DRIVE_TRACER qmax,q\(10,16,nlev\)=\s*(\S+)\s+(\S+)", stdout).groups()]
+    assert abs(qmax - q.max()) < 1e-9 * q.max() and abs(qpt - q[-1, 15, 9]) < 1e-9 * q.max(), (qmax, q.max(), qpt, q[-1, 15, 9])
+    (aloft,) = [float(x) for x in re.search(r"DRIVE_TRACER_ALOFT max q\(:,:,nlev-1\)=\s*(\S+)", stdout).groups()]
+    assert abs(aloft - q[-2].max()) < 1e-9 * q[-2].max(), (aloft, q[-2].max())
+    assert abs(q[-2].max() - plain[-2].max()) > 1e-5 * plain[-2].max()      # (not what finite_volume_parabolic carries up)
 
 
 @pytest.mark.parametrize("moist", [False, True])

@@ -366,7 +366,11 @@ def test_field_table_entries():
     # hole_filling = on: water_borrowing on a spectral tracer's tendency (spectral_dynamics.F90:1142); ignored with the reference's warning for a grid tracer (:364-367)
     k4, _ = atm.tracers_from_field_table(atm.parse_field_table(text + '"TRACER", "atmos_mod", "y"\n "hole_filling", "on" /'))
     assert k4["tracer_hole_filling"] == [0, 0, 0, 1] and k4["tracer_spectral"][3] == 1
-    for bad, msg in (('"TRACER", "atmos_mod", "x"\n "numerical_representation", "grid" /', "advect_vert = second_centered is not available"),
+    # advect_vert other than the representation's fused scheme goes over by number (tracer_advect_vert; -1 = the standard one)
+    kv, _ = atm.tracers_from_field_table(atm.parse_field_table(text + '"TRACER", "atmos_mod", "x"\n "numerical_representation", "grid" /\n'
+                                                               '"TRACER", "atmos_mod", "y"\n "advect_vert", "van_leer_linear" /'))
+    assert kv["tracer_advect_vert"] == [-1, -1, -1, 0, 2] and "tracer_advect_vert" not in keys
+    for bad, msg in (
                      ('"TRACER", "atmos_mod", "x"\n "numerical_representation", "wavelet" /', "invalid numerical_representation"),
                      ('"TRACER", "atmos_mod", "x"\n "advect_vert", "upwind" /', "invalid advect_vert"),
                      ('"TRACER", "atmos_mod", "x" /', "must be a grid tracer"),

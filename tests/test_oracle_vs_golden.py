@@ -274,6 +274,30 @@ def test_tracer_sms(golden_dir):
                     assert rel(x["g"][cur], want) < 1e-11, (n + 2, tag)
 
 
+def test_tracer_advect_vert(golden_dir):
+    """advect_vert per field_table entry: 'grid' tracers with second_centered / fourth_centered / van_leer_linear, 'spectral' tracers with fourth_centered
+    (current level) / van_leer_linear / finite_volume_parabolic (previous level), and sphum itself with van_leer_linear -- the numpy restatement of
+    vert_advection.F90:173-438 against the reference runs the HIP path's test_golden_tracer_advect_vert uses."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_tracer_advect_vert.npz"))
+    sc = core("T21", 8, extra_tracers=(dict(kind="grid", advect_vert="second_centered"), dict(kind="grid", advect_vert="fourth_centered"),
+                                      dict(kind="grid", advect_vert="van_leer_linear"), dict(kind="spectral", advect_vert="fourth_centered"),
+                                      dict(kind="spectral", advect_vert="van_leer_linear"), dict(kind="spectral", advect_vert="finite_volume_parabolic")))
+    sc.cold_start()
+    for i in range(1, 61):
+        sc.step()
+        if i in (1, 2, 3, 60):
+            cur, tag = sc.current, f"{i:06d}"
+            assert rel(sc.tr[cur], g[f"st_tr1_{tag}"]) < 1e-11
+            for n, x in enumerate(sc.xtr):
+                assert rel(x["g"][cur], g[f"st_tr{n + 2}_{tag}"]) < 1e-11, (n + 2, tag)
+    g = np.load(os.path.join(golden_dir, "run_T21L8_sphum_van_leer.npz"))
+    sc = core("T21", 8, sphum_advect_vert="van_leer_linear"); sc.cold_start()
+    for i in range(1, 41):
+        sc.step()
+        if i in (1, 2, 40):
+            assert rel(sc.tr[sc.current], g[f"st_tr1_{i:06d}"]) < 1e-11 and rel(sc.tg[sc.current], g[f"st_tg_{i:06d}"]) < 1e-12, i
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
