@@ -106,7 +106,7 @@ typedef struct isca_dyn_config {
    * (horizontal_advection of the spectral coefficients, advect_vert = second_centered, hole_filling = off: the defaults of :145-147;
    * damped like temperature, :1146).  tracer_robert_coeff: the entry's robert_coeff, negative = robert_coeff (:340-351).
    * More than one tracer: raw_filter_coeff = 1; a 'spectral' tracer on more than one rank needs the library's communicator (isca_dyn_comm_init: its
-   * transforms' exchanges are issued like the step's own); further 'grid' tracers also run under the host-driven phase API.  State names "tr2".."tr4", "tr_atm2".., and "trs2".. (spectral). */
+   * transforms' exchanges are issued like the step's own); further 'grid' tracers also run under the host-driven phase API.  State names "tr2".."tr8", "tr_atm2".., and "trs2".. (spectral). */
   int tracer_spectral[ISCA_MAX_TRACERS];
   double tracer_robert_coeff[ISCA_MAX_TRACERS];
   /* use_virtual_temperature (spectral_dynamics_nml, default .false.): T (1 + (rvgas/rdgas - 1) q), q = tracer 1, in the pressure-gradient
