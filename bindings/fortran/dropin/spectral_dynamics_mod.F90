@@ -160,8 +160,8 @@ if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian'
                   "'interpolated' needs the data files of topography_mod)", FATAL)
 if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
 if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
-if(dropin_physics /= 1 .and. (no_forcing .or. trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
-  call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing is carried by the device core.', FATAL)
+if(dropin_physics /= 1 .and. (trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
+  call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing (or no_forcing) is carried by the device core.', FATAL)
 
 call chk(isca_dyn_config_default(cfg), 'spectral_dynamics_init')
 cfg%lon_max = lon_max; cfg%lat_max = lat_max; cfg%num_fourier = num_fourier; cfg%num_spherical = num_spherical
@@ -190,6 +190,9 @@ cfg%radius = radius; cfg%omega = omega
 cfg%t_zero = t_zero; cfg%t_strat = t_strat; cfg%delh = delh; cfg%delv = delv; cfg%eps = eps; cfg%sigma_b = sigma_b
 cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_conserve_energy)
 cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
+if(no_forcing) then      ! hs_forcing returns at once (hs_forcing.F90:174): zero coefficients give exactly zero tendencies, no tracer source or sink
+  cfg%ka = 0.; cfg%ks = 0.; cfg%kf = 0.; cfg%trflux = 0.; cfg%trsink = 0.
+endif
 cfg%vert_advect_uv = advect_scheme(vert_advect_uv, 'vert_advect_uv'); cfg%vert_advect_t = advect_scheme(vert_advect_t, 'vert_advect_t')
 cfg%use_implicit = merge(1, 0, use_implicit); cfg%make_symmetric = merge(1, 0, make_symmetric)
 cfg%vert_difference_option = merge(1, 0, trim(vert_difference_option) == 'mcm')
@@ -253,7 +256,7 @@ do ntr = 1, num_tracers
       call error_mesg('spectral_dynamics_init', trim(tracer_attributes(ntr)%numerical_representation)//' is an invalid numerical_representation', FATAL)
   end select
   cfg%tracer_robert_coeff(ntr) = tracer_attributes(ntr)%robert_coeff
-  if(query_method('tracer_sms', MODEL_ATMOS, ntr, scheme, params)) then       ! hs_forcing's source and sink of this entry (hs_forcing.F90:251-261)
+  if(query_method('tracer_sms', MODEL_ATMOS, ntr, scheme, params) .and. .not. no_forcing) then       ! hs_forcing's source and sink of this entry (hs_forcing.F90:251-261)
     cfg%tracer_sms(ntr) = 1; cfg%tracer_flux(ntr) = 0.; cfg%tracer_sink(ntr) = 0.      ! 'none' (no tendency) and 'off' (flux = sink = 0) come to the same
     if(uppercase(trim(scheme)) /= 'NONE' .and. uppercase(trim(scheme)) /= 'OFF') then
       cfg%tracer_flux(ntr) = trflux; cfg%tracer_sink(ntr) = trsink

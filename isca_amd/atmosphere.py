@@ -22,6 +22,11 @@ from .dyncore import IscaError, RESOLUTIONS
 _core: dyncore.DynCore | None = None
 _run_dir: str | None = None
 _NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
+# hs_forcing_nml values that belong to local_heating_option / relax_to_specified_wind / equilibrium_t_option other than 'Held_Suarez' (hs_forcing.F90:86-118)
+_HS_UNUSED_PARAMETERS = ("local_heating_srfamp", "local_heating_xwidth", "local_heating_ywidth", "local_heating_xcenter", "local_heating_ycenter",
+                         "local_heating_vert_decay", "local_heating_file", "u_wind_file", "v_wind_file", "equilibrium_t_file", "p_trop", "alpha",
+                         "peri_time", "smaxis", "albedo", "lapse", "h_a", "tau_s", "orbital_period", "heat_capacity", "ml_depth", "spinup_time",
+                         "stratosphere_t_option")
 
 # ---- moist physics package (atmosphere_nml: idealized_moist_model = .true.; exp/test_cases/frierson/frierson_test_case.py:49-170)
 # namelist variables handed to the C config (group -> {variable: isca_moist_config member})
@@ -259,6 +264,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
     unsupported = {"vert_coord_option": vco if vco in ("input", "even_sigma", "hybrid", "mcm", "v197") else "uneven_sigma", "damping_option": dopt,
                    "initial_state_option": "quiescent",
                    "equilibrium_t_option": "Held_Suarez"}
+    no_forcing = False
     for grp in _NML_GROUPS:
         for k, v in (namelist or {}).get(grp, {}).items():
             k = k.lower()
@@ -281,6 +287,16 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 continue
             if k in ("p_press", "p_sigma"):           # vert_coord_option = 'hybrid' (used above)
                 continue
+            if grp == "hs_forcing_nml":
+                if k == "no_forcing":                 # hs_forcing returns at once (hs_forcing.F90:174): no drag, no heating, no tracer source
+                    no_forcing = bool(v)
+                    continue
+                if k == "local_heating_option" and str(v).strip() == "" or k == "relax_to_specified_wind" and not v:
+                    continue
+                if k in ("local_heating_option", "relax_to_specified_wind"):
+                    raise IscaError(f"hs_forcing_nml: {k} = {v!r} is not carried by the device core (only the Held-Suarez forcing, or no_forcing)")
+                if k in _HS_UNUSED_PARAMETERS:        # values of the branches above, without effect while those are off
+                    continue
             if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
                      "graceful_shutdown", "ocean_topog_smoothing"):
                 continue
@@ -292,6 +308,10 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                 v = v[0]
             kw[k] = tuple(v) if isinstance(v, list) else v
     kw.update(overrides)
+    if no_forcing:      # zero coefficients give exactly zero tendencies in the fused forcing (0 * finite); no tracer source or sink for any entry
+        kw.update(ka=0.0, ks=0.0, kf=0.0, trflux=0.0, trsink=0.0)
+        for k in ("tracer_sms", "tracer_flux", "tracer_sink"):
+            kw.pop(k, None)
     return dyncore.default_config(resolution, **kw)
 
 

@@ -112,7 +112,7 @@ RES = {"S10": (32, 32, 10, 21), "R10": (32, 32, 10, 11), "T5": (16, 8, 5, 6), "T
        "T42": (128, 64, 42, 43), "T85": (256, 128, 85, 86), "T170": (512, 256, 170, 171)}
 
 
-def input_nml(res, num_levels, extra="", extra_groups=""):
+def input_nml(res, num_levels, extra="", extra_groups="", hs_extra=""):
     lon, lat, nf, ns = RES[res]
     # namelist of exp/test_cases/held_suarez/held_suarez_test_case.py:45-98
     return f""" &atmosphere_nml
@@ -134,6 +134,7 @@ def input_nml(res, num_levels, extra="", extra_groups=""):
  &hs_forcing_nml
     t_zero = 315., t_strat = 200., delh = 60., delv = 10., eps = 0., sigma_b = 0.7,
     ka = -40., ks = -4., kf = -1., do_conserve_energy = .true.
+    {hs_extra}
  /
  &diag_manager_nml
     mix_snapshot_average_fields = .false.
@@ -227,10 +228,10 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), m
         f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
 
 
-def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE):
+def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
-    open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra, extra_groups))
+    open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra, extra_groups, hs_extra))
     open(os.path.join(d, "field_table"), "w").write(field_table)
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     ds = ", ".join(str(s) for s in dump_steps) if dump_steps else "-1"
@@ -467,12 +468,12 @@ HYBRID_LEVELS_GROUP = """ &vert_coordinate_nml
 """ % (", ".join(str(b) for b in HYBRID_BK), ", ".join(str(p) for p in HYBRID_PK))
 
 
-def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE):
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra=""):
     """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win); `extra_groups`: whole
     namelist groups appended to input.nml"""
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
         prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra, extra_groups=extra_groups,
-                       field_table=field_table)
+                       field_table=field_table, hs_extra=hs_extra)
         stdout = run_harness(d)
         out = read_outputs(d, res, L)
     if keep is not None:
@@ -653,6 +654,11 @@ def main():
         "run_T21L8_sphum_van_leer": lambda: golden_run(
             "T21", 8, 40, (1, 2, 40), field_table=FIELD_TABLE.replace('"finite_volume_parabolic"', '"van_leer_linear"'),
             keep=lambda k: re.match(r"st_(ug|tg|psg|tr1)_", k) is not None),
+        # hs_forcing_nml: no_forcing = .true. (hs_forcing returns at once, hs_forcing.F90:174: no drag, no heating, no tracer source) over the two
+        # Gaussian mountains -- the adiabatic adjustment of the isothermal rest state to the orography
+        "run_T21L8_no_forcing": lambda: golden_run(
+            "T21", 8, 48, (1, 2, 48), extra_groups=GAUSSIAN_TOPOG_GROUPS, hs_extra="no_forcing = .true.",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -800,6 +800,37 @@ def test_golden_raw_filter(golden_dir):
         make("T21", 8, raw_filter_coeff=1.5)
 
 
+def test_golden_no_forcing(golden_dir):
+    """hs_forcing_nml: no_forcing = .true. (hs_forcing returns before doing anything, hs_forcing.F90:174): no drag, no heating, no tracer source.  The
+    mirror of atmosphere_init maps it onto zero coefficients of the fused forcing (0 x finite = exactly no tendency).  The adiabatic adjustment of
+    the isothermal rest state to two Gaussian mountains, 48 steps at T21L8 against the reference run; the tracer stays exactly zero."""
+    from isca_amd import atmosphere as atm, configs
+    g = np.load(os.path.join(golden_dir, "run_T21L8_no_forcing.npz"))
+    nml = configs.held_suarez()
+    nml["spectral_dynamics_nml"]["num_levels"] = 8
+    nml["hs_forcing_nml"]["no_forcing"] = True
+    nml["hs_forcing_nml"]["local_heating_option"] = ""             # (inert keys of the reference's namelist are accepted)
+    nml["hs_forcing_nml"]["local_heating_srfamp"] = 3.0
+    nml["spectral_init_cond_nml"] = {"topography_option": "gaussian"}
+    nml["gaussian_topog_nml"] = {"height": [2500., 1500.], "olon": [90., 250.], "olat": [40., -30.], "wlon": [25., 20.], "wlat": [15., 12.],
+                                 "rlon": [0., 5.], "rlat": [0., 3.]}
+    dc = atm.atmosphere_init(nml, resolution="T21")
+    try:
+        done = 0
+        for n in (1, 2, 48):
+            atm.atmosphere(n - done); done = n
+            err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+                   for k in ("ug", "vg", "tg", "psg")}
+            print("no_forcing, step", n, err)
+            assert max(err.values()) < 1e-9, (n, err)
+            assert not dc.get("tr").any() and not g[f"st_tr1_{n:06d}"].any()
+    finally:
+        atm.atmosphere_end()
+    nml["hs_forcing_nml"]["local_heating_option"] = "Isidoro"
+    with pytest.raises(dyncore.IscaError, match="local_heating_option = 'Isidoro' is not carried"):
+        atm.atmosphere_init(nml, resolution="T21")
+
+
 def test_golden_topography(golden_dir, tmp_path):
     """Non-zero surface geopotential (get_topography 'gaussian': two mountains of gaussian_topog_nml): initial surface pressure over the
     orography (spectral_initialize_fields.F90:85), surf_geopotential as the lower boundary of the hydrostatic integral

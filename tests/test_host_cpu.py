@@ -566,3 +566,24 @@ def test_restart_file_reader_property(tmp_path):
                 assert lib.isca_restart_file_selftest(None, path.encode(), name.encode(), r, sums) == 0, lib.isca_last_error()
                 assert np.isclose(sums[0], blk.sum(), rtol=1e-12, atol=1e-9) and sums[1] == blk[0] and sums[2] == blk[-1], (name, r, list(sums), blk)
     check()
+
+
+def test_hs_forcing_nml_no_forcing_and_inert_keys():
+    """hs_forcing_nml in the Python mirror: no_forcing = .true. (hs_forcing.F90:174) becomes zero coefficients and no tracer source for any entry;
+    values that belong to branches which are off are accepted, the branches themselves are refused by name."""
+    from isca_amd import atmosphere as atm, configs
+    from isca_amd.dyncore import IscaError
+    nml = configs.held_suarez()
+    nml["hs_forcing_nml"].update(no_forcing=True, local_heating_option="", local_heating_srfamp=3.0, relax_to_specified_wind=False, p_trop=2.e4)
+    c = atm.config_from_namelist(nml, "T21", tracer_sms=[1], tracer_flux=[3.e-5], tracer_sink=[-2.0])
+    assert (c.ka, c.ks, c.kf, c.trflux, c.trsink) == (0.0, 0.0, 0.0, 0.0, 0.0) and list(c.tracer_sms) == [0] * len(c.tracer_sms)
+    nml["hs_forcing_nml"]["no_forcing"] = False
+    c = atm.config_from_namelist(nml, "T21")
+    assert (c.ka, c.kf, c.trflux) == (-40.0, -1.0, 1.e-5)
+    for key, val in (("local_heating_option", "Isidoro"), ("relax_to_specified_wind", True)):
+        bad = configs.held_suarez(); bad["hs_forcing_nml"][key] = val
+        with pytest.raises(IscaError, match=key):
+            atm.config_from_namelist(bad, "T21")
+    bad = configs.held_suarez(); bad["hs_forcing_nml"]["equilibrium_t_option"] = "top_down"
+    with pytest.raises(IscaError, match="equilibrium_t_option"):
+        atm.config_from_namelist(bad, "T21")

@@ -298,6 +298,31 @@ def test_tracer_advect_vert(golden_dir):
             assert rel(sc.tr[sc.current], g[f"st_tr1_{i:06d}"]) < 1e-11 and rel(sc.tg[sc.current], g[f"st_tg_{i:06d}"]) < 1e-12, i
 
 
+@pytest.mark.parametrize("name,coeffs,marks", [("run_T21L8_topography", {}, (1, 36)),
+                                               ("run_T21L8_no_forcing", dict(ka=0., ks=0., kf=0., trflux=0., trsink=0.), (1, 2, 48))])
+def test_topography_and_no_forcing(golden_dir, name, coeffs, marks):
+    """Two Gaussian mountains (gaussian_topog_nml; the surface geopotential spectrally truncated like get_topography does) with the Held-Suarez
+    forcing, and the same with hs_forcing_nml's no_forcing = .true. -- restated as zero coefficients, which is what the front ends hand to the
+    library: the numpy restatement against the reference runs."""
+    from isca_amd import atmosphere as atm
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sc = core("T21", 8, **coeffs)
+    nml = {"gaussian_topog_nml": {"height": [2500., 1500.], "olon": [90., 250.], "olat": [40., -30.], "wlon": [25., 20.], "wlat": [15., 12.],
+                                  "rlon": [0., 5.], "rlat": [0., 3.]}}
+    z = atm.gaussian_topog(nml, np.arange(sc.I) * 360.0 / sc.I, np.degrees(sc.rad_lat))
+    sc.surf_geopotential = sc.trans_spherical_to_grid(sc.trans_grid_to_spherical(9.80 * z))
+    sc.cold_start()
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+            if coeffs:
+                assert not sc.tr[sc.current].any() and not g[f"st_tr1_{tag}"].any()
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
