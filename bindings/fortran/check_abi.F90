@@ -20,4 +20,7 @@ endif
 if(isca_shallow_config_default(sw) /= 0 .or. isca_barotropic_config_default(bt) /= 0) stop 6
 write(*,'(a,3es16.8,i4)') 'SIBLINGS ', sw%h_0, sw%stirring%decay_time, bt%zeta_0, bt%m_0
 write(*,'(a,4es16.8)') 'DEFAULTS ', cfg%robert_coeff, cfg%moist%atm_abs, cfg%radius, cfg%valid_range_t(2)
+! the members at the end of the struct (a shifted member in front of them would show here)
+write(*,'(a,2es16.8,5i4)') 'TAIL ', cfg%tracer_robert_coeff(ISCA_MAX_TRACERS), cfg%tracer_sink(ISCA_MAX_TRACERS), cfg%use_implicit, &
+     cfg%tracer_hole_filling(ISCA_MAX_TRACERS), cfg%tracer_sms(1), cfg%tracer_advect_vert(1), cfg%tracer_advect_vert(ISCA_MAX_TRACERS)
 end program check_abi_prog

@@ -333,6 +333,8 @@ def test_fortran_binding_abi(lib, tmp_path):
     assert r.stdout.split("ABI_OK")[1].split()[:5] == ["64", "32", "21", "22", "25"]
     vals = [float(x) for x in r.stdout.split("DEFAULTS")[1].split()[:4]]
     assert vals == [0.04, 0.2, 6376.0e3, 800.0]
+    tail = r.stdout.split("TAIL")[1].split()[:7]         # tracer_robert_coeff(8), tracer_sink(8), use_implicit, tracer_hole_filling(8), tracer_sms(1), tracer_advect_vert(1), (8)
+    assert [float(x) for x in tail[:2]] == [-1.0, 0.0] and [int(x) for x in tail[2:]] == [1, 0, 0, -1, -1]
     sib = r.stdout.split("SIBLINGS")[1].split()[:4]
     assert [float(x) for x in sib[:3]] == [3.e4, 172800.0, 8.e-5] and int(sib[3]) == 4
 
