@@ -5,7 +5,12 @@ may import this module, and only as the checker.  The product (isca_amd/) never 
 
 Pinned against the reference itself: oracle/make_golden.py runs oracle/_ref/ref_harness.x (the
 reference's own Fortran, compiled in place by oracle/build_ref.py) and commits its outputs as
-tests/golden/*.npz; tests/test_oracle_vs_golden.py checks every function here against them.
+tests/golden/*.npz; tests/test_oracle_vs_golden.py checks every function here against them --
+the public routines one by one, the default step, and one reference run per option Config carries
+(damping options, RAW filter, mcm differencing, vertical coordinates, rhomboidal truncation,
+fourier_inc, vert_advect_uv/t, use_implicit, make_symmetric, use_virtual_temperature, topography,
+no_forcing as zero coefficients, further field_table tracers with robert_coeff / hole_filling /
+tracer_sms / advect_vert, lon_max with factors 3 and 5).
 
 Array conventions.  The reference is Fortran column-major: grid (lon, lat, lev), spectral
 (m, n, lev) with n the meridional index (total wavenumber = m + n).  Here arrays are the SAME
@@ -24,6 +29,7 @@ RADIUS = 6376.0e3
 OMEGA = 7.2921150e-5
 GRAV = 9.80
 RDGAS = 287.04
+RVGAS = 461.50
 KAPPA = 2.0 / 7.0
 CP_AIR = RDGAS / KAPPA
 PI = 3.14159265358979323846
@@ -54,8 +60,19 @@ class Config:
     scale_heights: float = 6.0
     exponent: float = 7.5
     surf_res: float = 0.5
-    vert_coord_option: str = "uneven_sigma"
+    vert_coord_option: str = "uneven_sigma"                  # or 'input' with pk_input, bk_input (num_levels + 1 values each)
+    pk_input: tuple = ()
+    bk_input: tuple = ()
+    p_press: float = 0.1          # vert_coord_option = 'hybrid' (spectral_dynamics.F90:180-181)
+    p_sigma: float = 0.3
     vert_difference_option: str = "simmons_and_burridge"     # or 'mcm' (spectral_dynamics.F90:1084, press_and_geopot.F90:196, implicit.F90:404, 447)
+    vert_advect_uv: str = "second_centered"       # spectral_dynamics.F90:280-301, 877-888: centred schemes on the current level, finite-volume ones on the previous
+    vert_advect_t: str = "second_centered"
+    use_implicit: bool = True                     # :906: .false. skips implicit_correction
+    triang_trunc: bool = True                     # .false.: rhomboidal (every m keeps n = 0..num_spherical-1; transforms.F90:516-520, 773-780)
+    fourier_inc: int = 1                          # zonal wavenumbers 0, inc, 2 inc, .. on a 360/inc degree sector
+    use_virtual_temperature: bool = False         # :857-871, press_and_geopot.F90:246-256, 340-348 (q = tracer 1)
+    make_symmetric: bool = False                  # spherical.F90:185: the truncation mask also drops every m > 0
     do_mass_correction: bool = True
     do_energy_correction: bool = True
     do_water_correction: bool = True
@@ -157,8 +174,33 @@ def compute_legendre(num_fourier: int, num_spherical: int, sin_hem: np.ndarray):
     return leg
 
 
-def compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent):
-    """atmos_spectral/init/vert_coordinate.F90:248-273 (zero_top=.true.); returns (pk, bk)."""
+def compute_vert_coord(option, num_levels, scale_heights, surf_res, exponent, p_press, p_sigma, reference_press):
+    """compute_vert_coord (init/vert_coordinate.F90:89-157) for the options formed from numbers: returns (pk, bk)."""
+    if option == "even_sigma":                                                # :231-246
+        return np.zeros(num_levels + 1), np.arange(num_levels + 1) / float(num_levels)
+    if option == "uneven_sigma":
+        return compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent)
+    if option == "hybrid":                                                     # :139-145 with transition(), :162-184
+        _, b_sigma = compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent, zero_top=False)
+        a_sigma = np.zeros_like(b_sigma)
+        b_press, a_press = np.zeros_like(b_sigma), b_sigma.copy()             # the same profile as a pure pressure coordinate
+        x = (b_sigma - p_press) / (p_sigma - p_press)
+        f = np.where(b_sigma <= p_press, 0.0, np.where(b_sigma >= p_sigma, 1.0, np.sin(0.5 * PI * x) ** 2))
+        a = a_sigma * f + a_press * (1.0 - f)
+        b = b_sigma * f + b_press * (1.0 - f)
+        return reference_press * a, b
+    if option == "mcm":                                                        # compute_old_model_sigma :309-322
+        assert num_levels == 14
+        return np.zeros(15), np.array([0.0, .03, .0707, .1311, .2102, .3036, .4062, .5138, .6226, .7284, .8255, .9066, .9640, .9933, 1.0])
+    if option == "v197":                                                       # :290-306
+        assert num_levels == 18
+        return np.zeros(19), np.array([0.0, .0089163, .0342936, .0740741, .1262002, .1886145, .2592592, .3360768, .4170096, .5000000, .5829904,
+                                       .6639231, .7407407, .8113854, .8737997, .9259259, .9657064, .9910837, 1.0])
+    raise NotImplementedError(option)
+
+
+def compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent, zero_top=True):
+    """atmos_spectral/init/vert_coordinate.F90:248-273; returns (pk, bk)."""
     b = np.zeros(num_levels + 1)
     s2 = 1.0 - surf_res
     for k in range(1, num_levels + 1):
@@ -166,7 +208,8 @@ def compute_uneven_sigma(num_levels, scale_heights, surf_res, exponent):
         z = surf_res * zeta + s2 * (zeta ** exponent)
         b[k - 1] = math.exp(-z * scale_heights)
     b[num_levels] = 1.0
-    b[0] = 0.0
+    if zero_top:
+        b[0] = 0.0
     return np.zeros(num_levels + 1), b
 
 
@@ -193,14 +236,19 @@ class SpectralCore:
         self.deg_lon = np.arange(I) * 360.0 / I                       # grid_fourier.F90:109-118
         self.rad_lat = self.deg_lat * PI / 180.0                      # atmosphere.F90:248-251
         # --- Legendre: spherical_fourier.F90:376-394 ---
-        self.legendre = compute_legendre(c.num_fourier, c.num_spherical, self.sin_hem)   # [j,n,m]
+        inc = c.fourier_inc                                                  # zonal wavenumbers 0, inc, 2 inc, ..: every inc-th column of the table (:100-104)
+        self.legendre = compute_legendre(c.num_fourier * inc, c.num_spherical, self.sin_hem)[:, :, ::inc]   # [j,n,m]
         self.legendre_wts = self.legendre * self.wts_hem[:, None, None]
         # --- spherical.F90:137-216 ---
-        m = np.arange(M1, dtype=np.float64)[None, :] + 0 * np.arange(N1)[:, None]
+        m = inc * np.arange(M1, dtype=np.float64)[None, :] + 0 * np.arange(N1)[:, None]
         n = np.arange(N1, dtype=np.float64)[:, None] + 0 * m
         Lw = m + n
         self.fourier_wave, self.spherical_wave = m, Lw
         self.triangle_mask = np.where(Lw > c.num_spherical - 1, 0.0, 1.0)
+        if not c.triang_trunc:                                               # rhomboidal_truncation without arguments: the row n = num_spherical (spherical.F90:620)
+            self.triangle_mask = np.ones_like(Lw); self.triangle_mask[N1 - 1, :] = 0.0
+        if c.make_symmetric:                                                 # spherical.F90:185
+            self.triangle_mask = np.where(m > 0, 0.0, self.triangle_mask)
         with np.errstate(invalid="ignore", divide="ignore"):
             eps = np.sqrt((Lw ** 2 - m ** 2) / (4.0 * Lw ** 2 - 1.0))
             self.epsilon = eps
@@ -216,9 +264,12 @@ class SpectralCore:
         self.coef_dx = m / self.cfg.radius
         self.coef_dyp[:-1] = (Lw[:-1] + 2.0) * eps[1:] / self.cfg.radius
         # --- vertical coordinate + derived (spectral_dynamics.F90:456-462) ---
-        if c.vert_coord_option != "uneven_sigma":
-            raise NotImplementedError(c.vert_coord_option)
-        self.pk, self.bk = compute_uneven_sigma(self.L, c.scale_heights, c.surf_res, c.exponent)
+        if c.vert_coord_option == "input":                                  # vert_coordinate_nml's pk, bk (init/vert_coordinate.F90:139-146)
+            self.pk, self.bk = np.asarray(c.pk_input, dtype=np.float64), np.asarray(c.bk_input, dtype=np.float64)
+            assert self.pk.size == self.L + 1 and self.bk.size == self.L + 1
+        else:
+            self.pk, self.bk = compute_vert_coord(c.vert_coord_option, self.L, c.scale_heights, c.surf_res, c.exponent, c.p_press, c.p_sigma,
+                                                  c.reference_sea_level_press)
         self.dpk = self.pk[1:] - self.pk[:-1]
         self.dbk = self.bk[1:] - self.bk[:-1]
         self.coriolis = 2 * self.cfg.omega * self.sin_lat                      # spectral_dynamics.F90:445
@@ -249,6 +300,7 @@ class SpectralCore:
         self.damping_zmu_sponge = c.zmu_sponge_coeff * eig[:, 0]
         self.damping_zmv_sponge = c.zmv_sponge_coeff * eig[:, 0]
         # --- implicit: implicit.F90:79-217 ---
+        self.num_total_wavenumbers = c.num_spherical - 1 + (0 if c.triang_trunc else c.fourier_inc * c.num_fourier)     # spectral_dynamics.F90:430-434
         self._implicit_init()
         self._wave_dt = None
         # --- HS constants: hs_forcing.F90:391-410 ---
@@ -408,9 +460,11 @@ class SpectralCore:
         p_full = np.exp(ln_p_full)
         return p_half, ln_p_half, p_full, ln_p_full
 
-    def compute_geopotential(self, t, ln_p_half, ln_p_full):
-        """press_and_geopot.F90:314-359 (dry: virtual_t = t)."""
+    def compute_geopotential(self, t, ln_p_half, ln_p_full, q=None):
+        """press_and_geopot.F90:314-359; with use_virtual_temperature and q given, T (1 + (rvgas/rdgas - 1) q) (:340-348)."""
         L = self.L
+        if self.cfg.use_virtual_temperature and q is not None:
+            t = t * (1. + (RVGAS / RDGAS - 1.) * q)
         gh = np.zeros((L + 1,) + t.shape[1:])
         gh[L] = self.surf_geopotential if t.ndim == 3 else 0.0
         ktop = 1 if self.pk[0] == 0.0 else 0
@@ -419,10 +473,10 @@ class SpectralCore:
         gf = gh[1:] + RDGAS * t * (ln_p_half[1:] - ln_p_full)
         return gf, gh
 
-    def compute_pressures_and_heights(self, t, ps):
+    def compute_pressures_and_heights(self, t, ps, q=None):
         """press_and_geopot.F90:363-387."""
         p_half, ln_p_half, p_full, ln_p_full = self.pressure_variables(ps)
-        zf, zh = self.compute_geopotential(t, ln_p_half, ln_p_full)
+        zf, zh = self.compute_geopotential(t, ln_p_half, ln_p_full, q)
         return zf / GRAV, zh / GRAV, p_full, p_half
 
     def four_in_one(self, divg, u, v, t, ps, ln_p_half, ln_p_full, p_full, dx_ps, dy_ps,
@@ -601,7 +655,7 @@ class SpectralCore:
     def build_wave_matrices(self, dt):
         """implicit.F90:221-237."""
         self.xi = dt * self.cfg.alpha_implicit
-        ntw = self.cfg.num_spherical - 1
+        ntw = self.num_total_wavenumbers
         L = self.L
         self.wave_matrix = np.zeros((ntw + 1, L, L))
         for Lw in range(ntw + 1):
@@ -625,7 +679,7 @@ class SpectralCore:
         dt_divs = dt_divs + self.eigen_laplacian * (geopot + self.h[:, None, None] * ps_temp * pref)
         # per-(m,n) L x L matvec :268-277
         Lw = self.spherical_wave.astype(int)
-        ntw = self.cfg.num_spherical - 1
+        ntw = self.num_total_wavenumbers
         out = dt_divs.copy()
         ok = Lw <= ntw
         Wsel = self.wave_matrix[np.where(ok, Lw, 0)]              # [n,m,L,L]
@@ -707,7 +761,7 @@ class SpectralCore:
         self.wg_full = np.zeros((L, J, I))
 
     def _pressures_and_heights(self, lev):
-        zf, zh, pf, ph = self.compute_pressures_and_heights(self.tg[lev], self.psg[lev])
+        zf, zh, pf, ph = self.compute_pressures_and_heights(self.tg[lev], self.psg[lev], self.tr_atm[lev])     # atmosphere.F90:229-241, 331-338
         self.z_full[lev], self.z_half[lev], self.p_full[lev], self.p_half[lev] = zf, zh, pf, ph
 
     def step(self, with_tracer=True):
@@ -745,15 +799,18 @@ class SpectralCore:
         dx_ps = self.divide_by_cos(self.psg[cur] * self.trans_spherical_to_grid(dxs))
         dy_ps = self.divide_by_cos(self.psg[cur] * self.trans_spherical_to_grid(dys))
         u, v, t = self.ug[cur], self.vg[cur], self.tg[cur]
+        tv = t * (1.0 + (RVGAS / RDGAS - 1.0) * self.tr[cur]) if (c.use_virtual_temperature and with_tracer) else t     # :857-861
         dt_ps, wg, wg_full, dt_t, dt_u, dt_v = self.four_in_one(
-            self.divg, u, v, t, self.psg[cur], ln_p_half, ln_p_full, p_full, dx_ps, dy_ps,
+            self.divg, u, v, tv, self.psg[cur], ln_p_half, ln_p_full, p_full, dx_ps, dy_ps,
             dt_ps, dt_t, dt_u, dt_v)
-        phig_full, _ = self.compute_geopotential(t, ln_p_half, ln_p_full)
+        phig_full, _ = self.compute_geopotential(t, ln_p_half, ln_p_full, self.tr[cur] if with_tracer else None)        # :866-871
         dt_ln_ps = self.trans_grid_to_spherical(dt_ps / self.psg[cur])
         dp = p_half[1:] - p_half[:-1]
-        dt_u = dt_u + self.vert_advection_second_centered(wg, dp, u)
-        dt_v = dt_v + self.vert_advection_second_centered(wg, dp, v)
-        dt_t = dt_t + self.vert_advection_second_centered(wg, dp, t)
+        lev_uv = cur if c.vert_advect_uv.endswith("centered") else prev     # :877-888
+        lev_t = cur if c.vert_advect_t.endswith("centered") else prev
+        dt_u = dt_u + self.vert_advection(c.vert_advect_uv, delta_t, wg, dp, self.ug[lev_uv])
+        dt_v = dt_v + self.vert_advection(c.vert_advect_uv, delta_t, wg, dp, self.vg[lev_uv])
+        dt_t = dt_t + self.vert_advection(c.vert_advect_t, delta_t, wg, dp, self.tg[lev_t])
         dt_t = self.horizontal_advection(self.ts[cur], u, v, dt_t)
         dt_ts = self.trans_grid_to_spherical(dt_t)
         absvor = self.vorg + self.coriolis[None, :, None]
@@ -767,8 +824,9 @@ class SpectralCore:
                         g_E=phig_full + 0.5 * (u ** 2 + v ** 2), g_dtlp=dt_ps / self.psg[cur], wg_full=wg_full,
                         s_dtvor=dt_vors, s_dtdiv=dt_divs, s_dtT=dt_ts, s_dtlp=dt_ln_ps)
         # --- implicit, damping, leapfrog :906-931
-        dt_divs, dt_ts, dt_ln_ps = self.implicit_correction(
-            dt_divs, dt_ts, dt_ln_ps, self.divs, self.ts, self.ln_ps, delta_t, prev, cur)
+        if c.use_implicit:
+            dt_divs, dt_ts, dt_ln_ps = self.implicit_correction(
+                dt_divs, dt_ts, dt_ln_ps, self.divs, self.ts, self.ln_ps, delta_t, prev, cur)
         dt_vors = self.compute_spectral_damping(self.vors[prev], dt_vors, delta_t, "vor")
         dt_divs = self.compute_spectral_damping(self.divs[prev], dt_divs, delta_t, "div")
         dt_ts = self.compute_spectral_damping(self.ts[prev], dt_ts, delta_t, "t")
@@ -880,7 +938,7 @@ class SpectralCore:
         fv["dy_minus"] = np.array([dyF(j) / (dyF(j - 1) + dyF(j)) for j in range(0, J + 2)])
         fv["dy"] = dy * self.cfg.radius                     # Fortran dy(j) = fv['dy'][j+1]
         fv["dyy"] = dyy * self.cfg.radius                   # Fortran dyy(j) = fv['dyy'][j-1]
-        fv["dx"] = 2.0 * PI * self.cfg.radius / float(I)
+        fv["dx"] = (1.0 / self.cfg.fourier_inc) * 2.0 * PI * self.cfg.radius / float(I)      # fv_advection.F90:108: the grid spans 360/fourier_inc degrees
         self._fv = fv
         return fv
 

@@ -323,6 +323,82 @@ def test_topography_and_no_forcing(golden_dir, name, coeffs, marks):
                 assert not sc.tr[sc.current].any() and not g[f"st_tr1_{tag}"].any()
 
 
+@pytest.mark.parametrize("name,options", [
+    ("run_T21L8_vadv_fourth", dict(vert_advect_uv="fourth_centered", vert_advect_t="fourth_centered")),
+    ("run_T21L8_vadv_finite_volume", dict(vert_advect_uv="van_leer_linear", vert_advect_t="finite_volume_parabolic")),
+    ("run_T21L8_vadv_ppm_uv", dict(vert_advect_uv="finite_volume_parabolic", vert_advect_t="van_leer_linear")),
+    ("run_T21L8_explicit", dict(use_implicit=False, dt_atmos=300.0)),
+    ("run_T21L8_symmetric", dict(make_symmetric=True)),
+    ("run_T21L8_virtual_t", dict(use_virtual_temperature=True)),
+])
+def test_dynamics_options(golden_dir, name, options):
+    """Options of spectral_dynamics_nml the HIP path carries with these fixtures, restated in numpy and pinned to the same reference runs:
+    vert_advect_uv / vert_advect_t (spectral_dynamics.F90:877-888: the centred schemes on the current level, the finite-volume ones on the previous
+    one with the step's delta_t), use_implicit = .false. (:906), make_symmetric (spherical.F90:185), use_virtual_temperature (:857-871,
+    press_and_geopot.F90:246-256, 340-348: tracer 1 as q in four_in_one, the geopotential and the heights)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    marks = sorted(int(k[-6:]) for k in g.files if k.startswith("st_tg_"))
+    sc = core("T21", 8, **options); sc.cold_start()
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+            assert rel(sc.tr[sc.current], g[f"st_tr1_{tag}"]) < 1e-11
+            if f"st_z_full_{tag}" in g.files:
+                assert rel(sc.z_full[sc.current], g[f"st_z_full_{tag}"]) < 1e-12
+
+
+@pytest.mark.parametrize("name,shape", [("run_R10L8_rhomboidal", dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=11, triang_trunc=False)),
+                                        ("run_S10L8_fourier_inc2", dict(lon_max=32, lat_max=32, num_fourier=10, num_spherical=21, fourier_inc=2))])
+def test_truncation_shapes(golden_dir, name, shape):
+    """triang_trunc = .false. (rhomboidal: every zonal wavenumber keeps n = 0..num_spherical-1, rhomboidal_truncation drops the row n = num_spherical,
+    the implicit scheme's matrices reach total wavenumber num_spherical-1 + num_fourier, spectral_dynamics.F90:430-434) and fourier_inc = 2 (zonal
+    wavenumbers 0, 2, .., 20 on a 180-degree sector: every second column of the Legendre table, fv_advection's dx of the sector)."""
+    from oracle.isca_oracle import Config, SpectralCore
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sc = SpectralCore(Config(num_levels=8, **shape)); sc.cold_start()
+    marks = sorted(int(k[-6:]) for k in g.files if k.startswith("st_tg_"))
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            cur, tag = sc.current, f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(getattr(sc, k)[cur] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(sc.tg[cur], g[f"st_tg_{tag}"]) < 1e-12 and rel(sc.psg[cur], g[f"st_psg_{tag}"]) < 1e-12
+            assert rel(sc.tr[cur], g[f"st_tr1_{tag}"]) < 1e-11
+
+
+HYBRID_BK = (0.0, 0.0, 0.05, 0.15, 0.30, 0.50, 0.70, 0.87, 1.0)           # oracle/make_golden.py HYBRID_LEVELS_GROUP
+HYBRID_PK = (0.0, 2000.0, 6000.0, 8000.0, 7000.0, 5000.0, 2500.0, 800.0, 0.0)
+
+
+@pytest.mark.parametrize("name,levels,options", [
+    ("run_T21L8_hybrid", 8, dict(vert_coord_option="input", pk_input=HYBRID_PK, bk_input=HYBRID_BK)),
+    ("run_T21L12_hybrid_option", 12, dict(vert_coord_option="hybrid", p_press=0.15, p_sigma=0.45, scale_heights=5.0, exponent=3.0, surf_res=0.3)),
+    ("run_T21L14_mcm_coord", 14, dict(vert_difference_option="mcm", vert_coord_option="mcm")),
+])
+def test_vertical_coordinates(golden_dir, name, levels, options):
+    """vert_coord_option other than the test case's uneven_sigma (compute_vert_coord, init/vert_coordinate.F90:89-157): hybrid levels from
+    vert_coordinate_nml (pk /= 0: the pressure-dependent layer thicknesses in four_in_one, the implicit scheme's reference profile and the
+    tracer's PPM weights), the 'hybrid' blend of the uneven-sigma profile into pressure levels, the 14 'mcm' levels with the mcm differencing."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sc = core("T21", levels, **options); sc.cold_start()
+    if "tab_pk" in g.files:
+        assert np.array_equal(sc.pk, g["tab_pk"]) and np.max(np.abs(sc.bk - g["tab_bk"])) < 1e-16
+    marks = sorted(int(k[-6:]) for k in g.files if k.startswith("st_tg_"))
+    for i in range(1, marks[-1] + 1):
+        sc.step()
+        if i in marks:
+            cur, tag = sc.current, f"{i:06d}"
+            assert np.max(np.abs(sc.ug[cur] - g[f"st_ug_{tag}"])) < 2e-11
+            for k, have in (("tg", sc.tg), ("psg", sc.psg), ("tr1", sc.tr), ("p_full", sc.p_full), ("z_full", sc.z_full)):
+                if f"st_{k}_{tag}" in g.files:
+                    assert rel(have[cur], g[f"st_{k}_{tag}"]) < (1e-11 if k == "tr1" else 1e-12), (k, tag)
+
+
 def test_raw_filter(golden_dir):
     """raw_filter_coeff = 0.7 (Robert-Asselin-Williams): grid fields of the new level from the unadjusted spectral state, the spectral
     state itself adjusted afterwards (leapfrog_2level_B, spectral_dynamics.F90:1031) -- numpy restatement vs 36 reference steps."""
