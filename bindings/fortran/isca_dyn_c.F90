@@ -248,6 +248,9 @@ interface
   integer(c_int) function isca_dyn_get_info(h, name, value) bind(C)
     import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), intent(out) :: value
   end function
+  integer(c_int) function isca_dyn_set_info(h, name, value) bind(C)       ! "phys_calls": a running moist model handed over through set_state
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), value :: value
+  end function
   ! restart files (spectral_dynamics.res.nc, atmosphere.res.nc, mixed_layer.res.nc) written / read by the library's own netCDF-classic code:
   ! spectral_dynamics_end (spectral_dynamics.F90:1502-1531) + atmosphere_end (atmosphere.F90:362-375); read_restart_or_do_coldstart (:509-575)
   integer(c_int) function isca_dyn_write_restart(h, directory, tracer_names) bind(C)

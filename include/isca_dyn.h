@@ -252,6 +252,10 @@ int isca_dyn_refresh_derived(isca_dyn_t *h);
  * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
 int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
 int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer","inverse_batch" (level-fields of the step's synthesis batch: 7 L + 3, or 6 L + 2 when the inverse FFT forms the x-derivatives) */
+/* What idealized_moist_phys_mod keeps beside the fields, for handing over a RUNNING model through set_state (a restart resets it, as
+ * idealized_moist_phys_init does): "phys_calls" = calls of the physics since init -- 0: the next call is the first (gust = 1 m/s,
+ * idealized_moist_phys.F90:592), > 0: vert_turb_driver's constant_gust (:1262).  Also readable through isca_dyn_get_info. */
+int isca_dyn_set_info(isca_dyn_t *h, const char *name, long value);
 /* Restart files written and read by the library itself, in the netCDF classic / 64-bit-offset format (what fms_io writes), without a netCDF
  * library: <directory>/spectral_dynamics.res.nc (spectral_dynamics_end, spectral_dynamics.F90:1502-1531: previous, current, pk, bk,
  * vors/divs/ts/ln_ps _real/_imag, ug, vg, tg, psg, every tracer by its field_table name (+ _real/_imag for a 'spectral' one), vorg, divg,

@@ -592,6 +592,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3); d.ph_dtq = dalloc<double>(h, ng3);
       d.t_surf = dalloc<double>(h, ng2); d.precip = dalloc<double>(h, ng2);
       d.moist_work = dalloc<double>(h, moist_work_doubles(g));
+      for (int i = 0; i < 2; ++i) { d.cc_dT[i] = dalloc<double>(h, ng3); d.cc_dq[i] = dalloc<double>(h, ng3); d.cc_precip[i] = dalloc<double>(h, ng2); }
+      h->cc_pipeline = !getenv("ISCA_MOIST_NO_PIPELINE");     // the next step's convection beside this step's physics (core.h: cc_valid)
       HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
       launch_t_surf_init(*h, h->stream);      // mixed_layer_init without restart file: the prescribed distribution
     }
@@ -747,12 +749,17 @@ static void dcopy(isca_dyn *h, double *dst, const double *src, size_t n) {
 // ---------------------------------------------------------------------------------------------------
 // cold start: spectral_initialize_fields.F90:45-135 + spectral_dynamics.F90:580-630
 // ---------------------------------------------------------------------------------------------------
+// a state write: the moist package's cached pressures and the convection computed ahead for the next step are of the old state
+static void moist_invalidate(isca_dyn *h) {
+  h->moist_pcache = false;
+  h->cc_valid = false;
+}
 static void reset_pending(isca_dyn *h) {       // a state written from scratch has nothing pending on it
   HIP_CHECK(hipMemcpy(h->d.pend, PEND_ROWS, sizeof(PEND_ROWS), hipMemcpyHostToDevice));
   h->thermo_pending[0] = h->thermo_pending[1] = false;
   h->tr_state[0] = h->tr_state[1] = isca::TR_MAT;
   h->in_step = false;
-  h->moist_pcache = false;
+  moist_invalidate(h);
 }
 static void cold_start_single(isca_dyn *h) {
   const Geom &g = h->g;
@@ -902,7 +909,7 @@ extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_leve
   if (kind == 0) h2d(h, p, host, cnt);
   else spec_host_to_dev(h, host, p, kind == 1 ? h->g.L : 1);
   h->have_state = true;
-  h->moist_pcache = false;
+  moist_invalidate(h);
   API_END
 }
 
@@ -964,7 +971,7 @@ extern "C" int isca_dyn_set_time_pointers(isca_dyn_t *h, int previous, int curre
   materialize(h);
   h->previous = previous; h->current = current; h->step_count = step_count;
   h->phys_calls = 0;         // idealized_moist_phys_init sets gust = 1 again after a restart
-  h->moist_pcache = false;
+  moist_invalidate(h);
   API_END
 }
 // ... then rebuild what the step keeps between calls but the restart file does not hold.
@@ -1001,9 +1008,15 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     const bool cached = h->moist_pcache && sc.prev != sc.cur && !getenv_once("ISCA_MOIST_NO_PCACHE");
     const int slot_prev = cached ? h->moist_pslot : 0, slot_cur = 1 - slot_prev;
     { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream, slot_prev, slot_cur, cached); }
-    { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream, slot_prev, slot_cur); }
+    // convection + condensation read the previous level only: the kernel of the step before has computed them beside its own chain (cc_valid;
+    // the same condition as the cached pressures: no state write since), else they run here, in front
+    int ccs = 0;
+    if (h->cc_valid && cached) ccs = h->cc_slot;
+    else { Timed t(h, "moist_convcond"); launch_moist_convcond(*h, sc.prev, slot_prev, sc.delta_t, ccs, h->stream); }
+    { Timed t(h, "moist_physics"); launch_moist_physics(*h, sc, h->stream, slot_cur, ccs, h->cc_pipeline); }
     h->moist_pslot = slot_cur; h->moist_pcache = true;
     h->phys_calls++;
+    h->cc_valid = h->cc_pipeline; h->cc_slot = 1 - ccs;      // (the next step's: its previous level is this step's current one, its delta_t the leapfrog's 2 dt)
   }
   // fork: the tracer's vertical kernel needs the column kernel's vertical velocity; its horizontal kernel only state that exists when the
   // step starts (the column kernel's mask word of the step BEFORE: kmask_old), so it can start beside the column kernel (tracer_early:
@@ -1582,7 +1595,22 @@ extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
   else if (nm == "tracer_env_off") *value = h->tracer_env_off ? 1 : 0;
   else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
   else if (nm == "inverse_batch") *value = h->dx_fourier ? 6 * h->g.L + 2 : 7 * h->g.L + 3;      // level-fields of the step's Legendre synthesis
+  else if (nm == "phys_calls") *value = h->phys_calls;
   else fail("unknown info " + nm);
+  API_END
+}
+
+// Handing over a RUNNING model (both time levels set through set_state, not a restart): what idealized_moist_phys_mod keeps beside the fields.
+// "phys_calls": calls of the physics package since idealized_moist_phys_init -- 0 makes the next call the first one (gust = 1 m/s,
+// idealized_moist_phys.F90:592; what set_time_pointers leaves, as a restart does), > 0 continues with vert_turb_driver's constant_gust (:1262).
+extern "C" int isca_dyn_set_info(isca_dyn_t *h, const char *name, long value) {
+  API_BEGIN
+  if (!h || !name) fail("null argument");
+  const std::string nm(name);
+  if (nm == "phys_calls") {
+    if (value < 0) fail("set_info: phys_calls must not be negative");
+    h->phys_calls = value;
+  } else fail("set_info: unknown or read-only info " + nm);
   API_END
 }
 
@@ -1783,8 +1811,8 @@ extern "C" int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t
   const double *u = tmp.up(u_prev, nf), *v = tmp.up(v_prev, nf), *t = tmp.up(t_prev, nf), *q = tmp.up(q_prev, nf), *php = tmp.up(p_half_prev, nh),
                *pfp = tmp.up(p_full_prev, nf), *phc = tmp.up(p_half_cur, nh), *pfc = tmp.up(p_full_cur, nf), *zhc = tmp.up(z_half_cur, nh),
                *zfc = tmp.up(z_full_cur, nf), *lat = tmp.up(rad_lat, ncol);
-  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(5 * nh);
-  launch_moist_physics_on(*h, ncol, delta_t, gust, lat, u, v, t, q, php, pfp, phc, pfc, zhc, zfc, ts, du, dv, dt, dq, pr, wk, h->stream);
+  double *ts = tmp.up(t_surf, ncol), *du = tmp.alloc(nf), *dv = tmp.alloc(nf), *dt = tmp.alloc(nf), *dq = tmp.alloc(nf), *pr = tmp.alloc(ncol), *wk = tmp.alloc(5 * nh), *cc = tmp.alloc(2 * nf + ncol);
+  launch_moist_physics_on(*h, ncol, delta_t, gust, lat, u, v, t, q, php, pfp, phc, pfc, zhc, zfc, ts, du, dv, dt, dq, pr, wk, cc, h->stream);
   d2h(h, t_surf, ts, ncol); d2h(h, dt_u, du, nf); d2h(h, dt_v, dv, nf); d2h(h, dt_t, dt, nf); d2h(h, dt_q, dq, nf);
   if (precip) d2h(h, precip, pr, ncol);
   API_END

@@ -124,6 +124,8 @@ struct Dev {
   double *ph_dtu = nullptr, *ph_dtv = nullptr, *ph_dtT = nullptr, *ph_dtq = nullptr;   // tendencies returned by idealized_moist_phys
   double *t_surf = nullptr, *precip = nullptr;      // [Jl][I] mixed-layer temperature; rain rate of the last step
   double *moist_work = nullptr;                     // p_full/p_half/z_full/z_half of both time levels
+  // k_moist_convcond -> k_moist_column, two sets (a step's convection is computed while the step before runs): (conv + cond) rates [L][Jl][I], rain [Jl][I]
+  double *cc_dT[2] = {nullptr, nullptr}, *cc_dq[2] = {nullptr, nullptr}, *cc_precip[2] = {nullptr, nullptr};
 };
 
 // doubles per side of the tracer halo buffers: (q0, u, v) + one q0 per further grid tracer, two rows of every level each
@@ -179,6 +181,11 @@ struct isca_dyn {
   // change once its fixers are applied): slot moist_pslot of the work area holds them while moist_pcache is true (reset by every state write)
   int moist_pslot = 0;
   bool moist_pcache = false;
+  // ... and that level's T, q are the next step's PREVIOUS-level fields, all the convection and the condensation read: k_moist_physics computes the
+  // next step's beside this step's chain (cc_valid: buffer set cc_slot holds the rates of the step about to be taken; dropped by every state write,
+  // after which k_moist_convcond runs in front of the step).  ISCA_MOIST_NO_PIPELINE: every step its own.
+  bool cc_pipeline = false, cc_valid = false;
+  int cc_slot = 0;
   isca::Comm *comm = nullptr;       // RCCL communicator of the sharded step (isca_dyn_comm_init), else the host drives the phases
   // Lazy fixers: compute_corrections' scalars and the grid tracer's leapfrog_2level_B stay pending on the new level and are applied by
   // the next steps' kernels as they read it (no pass over the fields at the end of the step); materialised for every host access.

@@ -20,10 +20,12 @@ struct MoistArgs {
   double *t_surf;                       // mixed-layer temperature, updated
   double *dtu, *dtv, *dtT, *dtq;        // tendencies out
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
+  double *cc_dT, *cc_dq, *cc_precip;    // this step's (conv + cond) heating and moistening rates [L][ncol] and their rain rate [ncol]: written by k_moist_convcond or, a step ahead, by k_moist_physics
+  const double *tn, *qn; double dt_next; double *nx_dT, *nx_dq, *nx_precip; int do_next;   // the NEXT step's convection inside k_moist_physics: its previous level's T, q (pressures: pf_c, ph_c), its delta_t, where its rates go
   const double *pk, *bk, *ps_p, *ps_c;  // in the model's step (SIG kernels): the half-level pressures are pk + bk ps, formed where they are needed; ph_p / ph_c unused
   const double *surf_geop;              // non-null: zf_c / zh_c hold the hydrostatic increments of k_moist_pressures and this kernel sums them (moist_heights_scan)
   int ktop;
-  double *work;                         // [5][L+1][ncol]: the three work arrays when they do not fit LDS; the radiation's level arrays (0, 1, 3), the sponge's heating (4)
+  double *work;                         // [5][L+1][ncol]: B's work arrays 0 and 1 (2 when it does not fit LDS), the sponge's heating (4)
   double delta_t, dt_atmos, gust, albedo;
   double rough_mom, rough_heat, rough_moist;
   moist::SatTable sat;
@@ -34,36 +36,42 @@ struct MoistArgs {
   moist::DiffusivityParams dif;
   moist::MixedLayerParams ml;
   int do_damping;
+  int full_sweeps;                      // ISCA_MOIST_FULL_SWEEPS: the implicit diffusion's sweeps over every level (not only the boundary layer's)
 };
 
-// Three work arrays of L+1 levels per column (0, 1: the parcel, then the convection's deltas, then the diffusion's e, f_1; 2: the radiative
-// heating, then f_2) live in LDS when the block's 3 x 64 x (L+1) doubles fit the 64 KB a block may take without opting in (L <= 41); up to
-// L = 63 arrays 0 and 1 do and array 2 is a global buffer with the grid layout; beyond that all three are.  LMAX only sizes the private arrays of the convection scheme.
-// A column is a chain of latency-bound recurrences and a T85 grid is only 512 wavefronts of columns, so a block runs TWO wavefronts
-// on its 64 columns where the chain allows it: wavefront 0 does the convection and the condensation (T85L40: 66 us in the first days after a
-// cold start, 98 us with a mean of 85 and up to 119 for the convection alone after 35 days, when it rains) while wavefront 1 does the height
-// sum, the radiation, the surface fluxes and the sponge (84 / 98 us); they meet at one barrier, after which wavefront 0 goes on alone with the
-// boundary layer and the implicit diffusion (53-59 us), wavefront 1's heating entering dt_tg in the reference's order
-// (dt_tg = ((conv + cond) + rad) + sponge).  With blockDim = 64 the same code runs the parts one after the other.
-// Every pass over a level array that leaves the chip costs HBM time here (32 768 columns x 14 fields do not fit the L2s, so a re-read
-// is a miss: rocprofv3 counted 712 MB per launch for 147 MB of fields, r03 profile): values that have one reader are handed over in LDS
-// (the convection's deltas in the parcel's arrays), sums are formed where their result is stored (dt_tg above), known zeros are not
-// stored and re-read (dt_ug, dt_vg below the sponge), and the convection scheme keeps one private level array (Tv) instead of five.
-constexpr int MOIST_NX = 20;       // scalars handed from wavefront 1 to wavefront 0 through work array 0 (needs L + 1 >= MOIST_NX)
-// Phase timing for kernel experiments (tools/dev/moist_phase_times.py): built with -DMOIST_TIMING=p the kernel stamps wall_clock64 (10 ns
-// ticks) at the marks of phase p (1: convection + condensation, 2: radiation + surface flux + sponge, 3: after the barrier) and stores,
-// in lane i of every wavefront, the time between marks i and i+1 in place of the precipitation.
+// Round 5: the convection runs a step AHEAD.
+// qe_moist_convection and lscale_cond read only PREVIOUS-level fields (T, q and that level's pressures, idealized_moist_phys.F90:862-880, :975-997),
+// and a step's previous level is the step before's current level, whose grid fields are final once THAT step's fixers have run.  So the convection
+// of step n+1 does not depend on step n's dynamics -- nor on anything else step n's physics computes: in the kernel of step n it is the work of
+// the second wavefront of each block of 64 columns, beside the chain that IS step n's:
+//   wavefront B: grey radiation down and up, surface fluxes, then boundary layer + implicit diffusion with the mixed layer (this step; it reads the
+//                (conv + cond) rates the kernel of the step before left in one of two buffer sets);
+//   wavefront A: the height sum and the Rayleigh sponge of this step (flagged to B through LDS), then convection + condensation of the NEXT step
+//                into the other buffer set.
+// Rounds 1-4 ran convection -> condensation -> diffusion of one step as one chain per block (the radiation beside the first two): 178 us of
+// dependent work at T85L40 once it rains, 194-197 us per launch.  Now the two chains are ~125-160 and ~137 us and independent.  The first step after a
+// state write has nothing computed ahead: k_moist_convcond (the same column code, one wavefront per 64 columns) runs in front of it.
+// Work arrays of L+1 levels per column: A's parcel (T, r) in LDS arrays 0 and 1; B's three (0: lw_down, then the diffusion's e; 1: lw_dtrans, then f_1;
+// 2: sw_down, then the radiative heating, then f_2) -- array 2 in LDS, 0 and 1 in the global work area: B reads and writes them a chunk of levels at a
+// time, beside loads it waits for anyway, and its sweeps cover the boundary layer only -- when 3 x 64 x (L+1) doubles fit the 64 KB a block may take
+// without opting in (L <= 41); up to L = 63 the parcel is in LDS and B's arrays are global; beyond that everything is (the parcel thread-private).
+// (Measured and not kept: a 166 K window of the saturation table in LDS instead of B's array -- the ascent's dependent lookups already hit the
+// CU's L1, the kernel went 138 -> 157 us)
+// dt_tg = ((conv + cond) + rad) + sponge in the reference's order (:880, :997, :1162, :1237), formed where it is read.
+// Phase timing for kernel experiments (tools/dev/moist_phase_times.py): built with -DMOIST_TIMING=p the kernels stamp wall_clock64 (10 ns
+// ticks) at the marks of phase p (1: convection + condensation, 5: inside the convection scheme, 2: radiation + surface fluxes, 4: height sum + sponge,
+// 3: boundary layer + diffusion) and store, in lane i of every wavefront, the time between marks i and i+1 in place of the precipitation.
 #ifdef MOIST_TIMING
 #define MT_DECL long long mt_[9]; for (int i_ = 0; i_ < 9; ++i_) mt_[i_] = wall_clock64();
 #define MT(p, i) if (MOIST_TIMING == p) { const long long t_ = wall_clock64(); for (int i_ = i; i_ < 9; ++i_) mt_[i_] = t_; }
-#define MT_STORE(p) if (MOIST_TIMING == p) { long long d_ = 0; for (int i_ = 0; i_ < 8; ++i_) if ((lane & 7) == i_) d_ = mt_[i_ + 1] - mt_[i_]; a.precip[c] = (double)d_; }
+#define MT_STORE(p, dst) if (MOIST_TIMING == p) { long long d_ = 0; for (int i_ = 0; i_ < 8; ++i_) if ((lane & 7) == i_) d_ = mt_[i_ + 1] - mt_[i_]; (dst)[c] = (double)d_; }
 #else
 #define MT_DECL
 #define MT(p, i)
-#define MT_STORE(p)
+#define MT_STORE(p, dst)
 #endif
 // The hydrostatic sum, bottom-up, of one column: z_full / z_half arrive as the layers' increments (k_moist_pressures) and leave as heights; 8 levels of
-// increments requested together.  (Was a kernel of its own: 512 wavefronts, five memory round trips, 12 us; the radiation wavefront does it on the way.)
+// increments requested together.  (Was a kernel of its own: 512 wavefronts, five memory round trips, 12 us.)
 __device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, double *z_full, double *z_half, size_t s) {
   z_half[(size_t)L * s] = gh / GRAV;
   for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
@@ -84,148 +92,190 @@ __device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, d
     }
   }
 }
-template <int LMAX, int NLDS, bool SIG>      // NLDS: how many of the three work arrays live in LDS (3, 2: arrays 0 and 1, or 0); SIG: p_half from (pk, bk, ps)
+// convection (:862-880) and large-scale condensation on the convectively adjusted profile (:975-997) of ONE column: T, q, p_full, p_half of the
+// previous time level of the step in question.  The convection's deltas stay where the parcel was (LDS, or the private arrays): the condensation is
+// their only reader; (0 + conv_dt_tg) + cond_dt_tg, dt_qg = (0 + conv) + cond and the rain rate go to memory.
+template <int LMAX, bool TV_EXT, class PHT>
+__device__ __forceinline__ void moist_convcond_column(const MoistArgs &a, const moist::SatTable &sat, int L, int s, const double *tp, const double *qp, const double *pf, PHT php,
+                                                      double delta_t, double *ccT, double *ccq, double &precip_out, moist::QeParcel &pc) {
+  double rain, cape, cin;
+  int flag, klzb, klcl;
+  moist::qe_moist_convection<LMAX, false, PHT, TV_EXT>(sat, a.qe, L, delta_t, tp, qp, pf, php, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb, klcl,
+                                                       nullptr, nullptr, pc.sw, pc);
+  double precip = rain / delta_t;
+  double rain_ls;
+  moist::lscale_cond(sat, L,
+                     [&](int k, double &t, double &q, double &ct, double &cq) {
+                       ct = pc.wTp[k * pc.sw]; cq = pc.wrp[k * pc.sw];
+                       t = ct + tp[k * s]; q = cq + qp[k * s];
+                     },
+                     pf, php, s,
+                     [&](int k, double td, double qd, double ct, double cq) {
+                       ccT[(size_t)k * s] = ct / delta_t + td / delta_t;
+                       ccq[(size_t)k * s] = cq / delta_t + qd / delta_t;
+                     },
+                     rain_ls);
+  precip_out = precip + rain_ls / delta_t;
+}
+// ---- convection + condensation alone, for a step that has nothing computed ahead (the first one, or after a state write), for
+//      isca_idealized_moist_phys on caller columns and for ISCA_MOIST_NO_PIPELINE.  NLDS: 3 = parcel T, r and Tv in LDS; 2 = the parcel in LDS, Tv
+//      thread-private; 0 = all thread-private.
+template <int LMAX, int NLDS, bool SIG>
+__global__ __launch_bounds__(64) void k_moist_convcond(MoistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  const int lane = threadIdx.x & 63;
+  const int col = min(blockIdx.x * 64 + lane, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
+  const int L = a.L, s = a.ncol;
+  const size_t c = (size_t)col;
+  using PHT = typename std::conditional<SIG, moist::PHalfSigma, const double *>::type;
+  PHT php;                         // half-level pressures of the previous time level
+  if constexpr (SIG) php = moist::PHalfSigma{a.pk, a.bk, a.ps_p[c]};
+  else php = a.ph_p + c;
+  MT_DECL
+  double ptp[NLDS >= 2 ? 1 : LMAX], prp[NLDS >= 2 ? 1 : LMAX];
+  moist::QeParcel pc = NLDS >= 2 ? moist::QeParcel{lds_work + lane, lds_work + lane + (size_t)(L + 1) * 64, 64} : moist::QeParcel{ptp, prp, 1};
+  if (NLDS == 3) pc.wTv = lds_work + lane + (size_t)2 * (L + 1) * 64;
+#if defined(MOIST_TIMING) && MOIST_TIMING == 5      // phase 5: inside the convection scheme (marks in moist_physics.h)
+  pc.marks = mt_;
+#endif
+  double precip;
+  moist_convcond_column<LMAX, NLDS == 3, PHT>(a, a.sat, L, s, a.tp + c, a.qp + c, a.pf_p + c, php, a.delta_t, a.cc_dT + c, a.cc_dq + c, precip, pc);
+  a.cc_precip[c] = precip;
+  MT(1, 1) MT_STORE(1, a.cc_precip) MT_STORE(5, a.cc_precip)
+}
+
+// ---- the physics of one step (idealized_moist_phys.F90:1054-1340 with this step's (conv + cond) rates from a.cc_*) and, with a.do_next, the convection
+//      + condensation of the next one (its previous level = this step's current one: a.tn, a.qn with the pressures a.pf_c / a.ph_c) into a.nx_*
+template <int LMAX, int NLDS, bool SIG>      // NLDS: 3 = the parcel and B's array 2 in LDS; 2 = the parcel; 0 = nothing.  SIG: p_half from (pk, bk, ps)
 __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
-  constexpr bool LDSW = NLDS >= 2;
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
   const int lane = threadIdx.x & 63, role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nroles = blockDim.x >> 6;
   const int col = min(blockIdx.x * 64 + lane, a.ncol - 1);     // the tail lanes redo the last column (same values stored)
   const int L = a.L, s = a.ncol;
   const size_t c = (size_t)col;
-  const int sw = LDSW ? 64 : a.ncol, sw2 = (NLDS == 3) ? 64 : a.ncol;
-  double *w0 = LDSW ? lds_work + lane : a.work + c;
+  const moist::SatTable &sat = a.sat;
+  // B's work arrays: 0 and 1 in the global work area, 2 in LDS behind the parcel's two when it fits
+  const int sw = a.ncol, sw2 = (NLDS == 3) ? 64 : a.ncol;
+  double *w0 = a.work + c;
   double *w1 = w0 + (size_t)(L + 1) * sw;
-  double *w2 = (NLDS == 3) ? w1 + (size_t)(L + 1) * sw : a.work + c + (size_t)2 * (L + 1) * a.ncol;
-  // the radiation / sponge wavefront keeps its two level arrays and the scalars it hands over in the global work area, so that LDS
-  // arrays 0 and 1 belong to the convection (parcel profile) before the barrier and to the implicit diffusion (e, f) after it
-  double *r0 = a.work + c, *r1 = r0 + (size_t)(L + 1) * s, *r3 = r0 + (size_t)3 * (L + 1) * s, *r4 = r0 + (size_t)4 * (L + 1) * s;
+  double *w2 = (NLDS == 3) ? lds_work + lane + (size_t)2 * (L + 1) * 64 : w0 + (size_t)2 * (L + 1) * sw;
+  double *r4 = a.work + c + (size_t)4 * (L + 1) * s;           // the sponge's heating (its levels only)
   const double *tp = a.tp + c, *qp = a.qp + c, *up = a.up + c, *vp = a.vp + c;
   using PHT = typename std::conditional<SIG, moist::PHalfSigma, const double *>::type;
-  PHT php, phc;                         // half-level pressures of the previous / current time level
-  if constexpr (SIG) { php = moist::PHalfSigma{a.pk, a.bk, a.ps_p[c]}; phc = moist::PHalfSigma{a.pk, a.bk, a.ps_c[c]}; }
-  else { php = a.ph_p + c; phc = a.ph_c + c; }
+  PHT phc;                         // half-level pressures of the current time level
+  if constexpr (SIG) phc = moist::PHalfSigma{a.pk, a.bk, a.ps_c[c]};
+  else phc = a.ph_c + c;
   double *dtu = a.dtu + c, *dtv = a.dtv + c, *dtT = a.dtT + c, *dtq = a.dtq + c;
+  const double *ccT = a.cc_dT + c, *ccq = a.cc_dq + c;
   const double delta_t = a.delta_t;
   const int nray = a.do_damping ? a.ray.nlev_rayfric : 0;
-  double t_surf = 0.0, net_sw = 0.0, lw_down_surf = 0.0;
-  moist::SurfFlux sf;
   MT_DECL
-  // ---- wavefront nroles-1: grey radiation down (:1054-1061), surface fluxes (:1077-1153), radiation up (:1156-1162): heating into work array 2
-  if (role == nroles - 1) {
-    if (a.surf_geop) moist_heights_scan(a.surf_geop[c], L, a.ktop, a.zf_c + c, a.zh_c + c, (size_t)s);      // (its first reader is the surface flux below)
-    const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
-    t_surf = a.t_surf[c];
-    double insolation, sw_tau_0;
-    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, phc, s, r0, r1, r3, s, insolation, sw_tau_0, net_sw, lw_down_surf);
-    MT(2, 1)
-    const size_t low = (size_t)(L - 1) * s;
-    moist::surface_flux(a.sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], moist::ph_at(phc, s, L), t_surf,
-                        a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
-    MT(2, 2)
-    for (int k = 0; k < L; ++k) w2[k * sw2] = 0.0;
-    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, phc, s, r0, r1, r3, s, w2, sw2);
-    MT(2, 3)
-    // ---- Rayleigh sponge (:1228-1237; on this wavefront because in a spun-up model the convection wavefront is the longer of the two in front of
-    //      the barrier -- 107 against 90 us after 35 days, where the cold start's first days have 66 against 78): momentum tendencies of the sponge
-    //      levels in place (below them dt_ug, dt_vg stay zero until the diffusion: not stored), its heating into work array 4
-    for (int k = 0; k < nray; ++k) { dtu[k * s] = 0.0; dtv[k * s] = 0.0; r4[(size_t)k * s] = 0.0; }
-    if (nray) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s);
-    if (nroles == 2) {
-      const double x[MOIST_NX] = {sf.flux_t, sf.flux_q, sf.flux_r, sf.flux_u, sf.flux_v, sf.dhdt_surf, sf.dedt_surf, sf.drdt_surf, sf.dhdt_atm,
-                                  sf.dedq_atm, sf.dtaudu_atm, sf.dtaudv_atm, sf.u_star, sf.b_star, t_surf, net_sw, lw_down_surf, 0., 0., 0.};
-#pragma unroll
-      for (int i = 0; i < MOIST_NX; ++i) r0[(size_t)i * s] = x[i];
-    }
-    MT(2, 4) MT_STORE(2)
-  }
-  // ---- wavefront 0: convection (:862-880) and large-scale condensation on the convectively adjusted profile (:975-997).  The convection's
-  //      deltas stay where the parcel was (LDS, or the private arrays): the condensation is their only reader, and it leaves
-  //      (0 + conv_dt_tg) + cond_dt_tg in the same place for the diffusion below; dt_qg = (0 + conv) + cond goes to memory
-  double ptp[LDSW ? 1 : LMAX], prp[LDSW ? 1 : LMAX];                    // work arrays in global memory: the parcel stays thread-private
-  moist::QeParcel pc = LDSW ? moist::QeParcel{w0, w1, sw} : moist::QeParcel{ptp, prp, 1};
-#if defined(MOIST_TIMING) && MOIST_TIMING == 5      // phase 5: inside the convection scheme (marks in moist_physics.h)
-  pc.marks = mt_;
-#endif
-  if (role == 0) {
-    double rain, cape, cin;
-    int flag, klzb, klcl;
-    moist::qe_moist_convection<LMAX, false, PHT>(a.sat, a.qe, L, delta_t, tp, qp, a.pf_p + c, php, s, pc.wTp, pc.wrp, rain, cape, cin, flag, klzb,
-                                            klcl, nullptr, nullptr, pc.sw, pc);
-    MT(1, 1)
+  // ---- wavefront A: convection + condensation of the NEXT step (nothing of this step's: the two wavefronts share no data)
+  if (role == 0 && a.do_next) {
+    double ptp[NLDS >= 2 ? 1 : LMAX], prp[NLDS >= 2 ? 1 : LMAX];
+    moist::QeParcel pc = NLDS >= 2 ? moist::QeParcel{lds_work + lane, lds_work + lane + (size_t)(L + 1) * 64, 64} : moist::QeParcel{ptp, prp, 1};
 #if defined(MOIST_TIMING) && MOIST_TIMING == 5
-    { const long long t_ = wall_clock64(); for (int i_ = 6; i_ < 9; ++i_) mt_[i_] = t_; }
-    MT_STORE(5)
+    pc.marks = mt_;
 #endif
-    double precip = rain / delta_t;
-    double rain_ls;
-    moist::lscale_cond(a.sat, L,
-                       [&](int k, double &t, double &q, double &ct, double &cq) {
-                         ct = pc.wTp[k * pc.sw]; cq = pc.wrp[k * pc.sw];
-                         t = ct + tp[k * s]; q = cq + qp[k * s];
-                       },
-                       a.pf_p + c, php, s,
-                       [&](int k, double td, double qd, double ct, double cq) {
-                         pc.wTp[k * pc.sw] = ct / delta_t + td / delta_t;
-                         dtq[k * s] = cq / delta_t + qd / delta_t;
-                       },
-                       rain_ls);
-    precip = precip + rain_ls / delta_t;
-#if !defined(MOIST_TIMING) || (MOIST_TIMING != 2 && MOIST_TIMING != 5)
-    if (a.precip) a.precip[c] = precip;
+    double precip;
+    moist_convcond_column<LMAX, false, PHT>(a, sat, L, s, a.tn + c, a.qn + c, a.pf_c + c, phc, a.dt_next, a.nx_dT + c, a.nx_dq + c, precip, pc);
+    a.nx_precip[c] = precip;
+    MT(1, 1) MT_STORE(1, a.precip) MT_STORE(5, a.precip)
+  }
+  if (nroles == 2 && role == 0) return;
+  // ---- wavefront B (the only one of a one-wavefront block): this step.  The height sum (first reader: the surface fluxes)
+  if (a.surf_geop) moist_heights_scan(a.surf_geop[c], L, a.ktop, a.zf_c + c, a.zh_c + c, (size_t)s);
+  MT(2, 1)
+  // ---- wavefront B: grey radiation down (:1054-1061) and up (:1156-1162; it needs the surface temperature, not the surface fluxes): the heating lands
+  //      in work array 2, where the downward shortwave flux was
+  double t_surf = a.t_surf[c];
+  double net_sw, lw_down_surf;
+  {
+    const double lat = a.rad_lat_col ? a.rad_lat_col[c] : a.rad_lat_row[col / a.I];
+    double insolation, sw_tau_0;
+    moist::gray_rad_down(a.rad, L, lat, a.albedo, tp, phc, s, w0, w1, sw, w2, sw2, insolation, sw_tau_0, net_sw, lw_down_surf);
+    MT(2, 2)
+    moist::gray_rad_up(a.rad, L, a.albedo, t_surf, tp, phc, s, w0, w1, sw, w2, sw2, w2, sw2, true);
+    MT(2, 3)
+  }
+  // ---- surface fluxes (:1077-1153)
+  moist::SurfFlux sf;
+  {
+    const size_t low = (size_t)(L - 1) * s;
+    moist::surface_flux(sat, a.mo, tp[low], qp[low], up[low], vp[low], a.pf_c[c + low], a.zf_c[c + low], moist::ph_at(phc, s, L), t_surf,
+                        a.rough_mom, a.rough_heat, a.rough_moist, a.rough_mom, a.gust, sf);
+  }
+  MT(2, 4)
+  // ---- the Rayleigh sponge (:1228-1237): momentum tendencies of the sponge levels in place (below them dt_ug, dt_vg stay zero until the diffusion:
+  //      not stored), its heating into work array 4
+  if (nray) {
+    if (a.ray.conserve_energy) moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s, true);
+    else {
+      for (int k = 0; k < nray; ++k) r4[(size_t)k * s] = 0.0;
+      moist::rayleigh_damping(a.ray, delta_t, a.pf_c + c, up, vp, s, dtu, dtv, s, r4, s, true);
+    }
+  }
+  MT(2, 5) MT_STORE(2, a.precip)
+#if !defined(MOIST_TIMING)
+  if (a.precip) a.precip[c] = a.cc_precip[c];
 #endif
-    MT(1, 2) MT_STORE(1)
-  }
-  // ---- the two wavefronts meet here; wavefront 0 goes on alone
-  if (nroles == 2) {
-    __syncthreads();
-    if (role != 0) return;
-    double x[MOIST_NX];
-#pragma unroll
-    for (int i = 0; i < MOIST_NX; ++i) x[i] = r0[(size_t)i * s];
-    sf.flux_t = x[0]; sf.flux_q = x[1]; sf.flux_r = x[2]; sf.flux_u = x[3]; sf.flux_v = x[4]; sf.dhdt_surf = x[5]; sf.dedt_surf = x[6];
-    sf.drdt_surf = x[7]; sf.dhdt_atm = x[8]; sf.dedq_atm = x[9]; sf.dtaudu_atm = x[10]; sf.dtaudv_atm = x[11]; sf.u_star = x[12];
-    sf.b_star = x[13]; t_surf = x[14]; net_sw = x[15]; lw_down_surf = x[16];
-  }
   MT(3, 0)
   // ---- dt_tg = ((conv + cond) + rad) + sponge, in that order (:880, :997, :1162, :1237), formed where it is read: by the boundary-layer depth
   //      (lowest levels only) and by the momentum diffusion's downward sweep, which reads each level's parts before its e, f overwrite them
-  //      and stores the sum for the upward sweep.  dt_ug, dt_vg are zero below the sponge: known, not read.
+  //      and stores the sum for the upward sweep.  dt_ug, dt_vg are zero below the sponge: known, not read.  Two forms of each: with the sponge's
+  //      terms (the test of the level becomes a branch with the load behind it: one memory round trip per LEVEL, found in the ISA) for the top of the
+  //      column, and without them for everything at or below level nray -- where the boundary layer is.
   const int nr1 = max(nray - 1, 0);
-  auto heat_in = [&](int k) {
+  auto heat_sp = [&](int k) {
     const double sp = r4[(size_t)min(k, nr1) * s];
-    double x = pc.wTp[k * pc.sw] + w2[k * sw2];
+    double x = ccT[(size_t)k * s] + w2[k * sw2];
     if (k < nray) x = x + sp;
     return x;
   };
-  auto du_in = [&](int k) { const double x = dtu[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
-  auto dv_in = [&](int k) { const double x = dtv[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
+  auto du_sp = [&](int k) { const double x = dtu[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
+  auto dv_sp = [&](int k) { const double x = dtv[(size_t)min(k, nr1) * s]; return (k < nray) ? x : 0.0; };
+  auto heat_lo = [&](int k) { return ccT[(size_t)k * s] + w2[k * sw2]; };
+  auto zero_lo = [](int) { return 0.0; };
+  auto dq_in = [&](int k) { return ccq[(size_t)k * s]; };
   MT(3, 1)
   // ---- boundary-layer diffusivities (:1242-1262), implicit vertical diffusion with the mixed layer (:1292-1330)
-  {
-    const double h = moist::pbl_depth_f(a.dif, L, delta_t, tp, up, vp, s, heat_in, du_in, dv_in, a.zf_c + c, a.zh_c + c, s);
-    MT(3, 2)
-    moist::PblProfile pbl;
-    pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
-    const moist::VdiffWork w{w0, w1, w2, sw, sw2};
-    moist::VdiffSurf S;
-    double tau_u = sf.flux_u, tau_v = sf.flux_v;
-    {
-      const auto r = moist::vd::down_pair(L, delta_t, [&](int k) { return up[(size_t)k * s]; }, [&](int k) { return vp[(size_t)k * s]; }, du_in, dv_in,
-                                          moist::PblProfile::Km{pbl}, tp, s, phc, a.zf_c + c, s, w,
-                                          moist::DtPark<decltype(heat_in)>{heat_in, dtT, s});      // = vert_diff_momentum_f, its two halves
-      MT(3, 3)
-      moist::vert_diff_momentum_up_f(r, L, delta_t, up, vp, s, tau_u, tau_v, sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, dtu, dtv, dtT, s, nullptr, 0, w, S);
-    }
+  int kstop;
+  const double h = moist::pbl_depth_f2(a.dif, L, delta_t, tp, up, vp, s, heat_sp, du_sp, dv_sp, heat_lo, zero_lo, zero_lo, nray, a.zf_c + c, a.zh_c + c, s, &kstop);
+  // No interface at or above level kstop carries diffusion (the depth lies below that level's height): the four sweeps of the implicit diffusion
+  // run over the boundary layer only -- from the highest kstop of the wavefront's 64 columns down, typically a quarter of the column -- and the
+  // levels above take their tendencies in one streaming pass (moist_physics.h: vert_diff_passthrough).  a.full_sweeps (ISCA_MOIST_FULL_SWEEPS): all levels.
+  int kb = kstop;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) kb = min(kb, __shfl_xor(kb, off));
+  kb = __builtin_amdgcn_readfirstlane(a.full_sweeps ? 0 : min(kb, L - 2));
+  MT(3, 2)
+  const int ksp = min(nray, kb);
+  moist::vert_diff_passthrough(0, ksp, du_sp, dv_sp, heat_sp, dq_in, dtu, dtv, dtT, dtq, s);        // the sponge levels
+  moist::vert_diff_passthrough(ksp, kb, zero_lo, zero_lo, heat_lo, dq_in, dtu, dtv, dtT, dtq, s);    // between the sponge and the boundary layer
+  MT(3, 3)
+  moist::PblProfile pbl;
+  pbl.init(a.mo, a.dif, h, sf.u_star, sf.b_star, a.zh_c + c, s, L);
+  const moist::VdiffWork w{w0, w1, w2, sw, sw2};
+  moist::VdiffSurf S;
+  double tau_u = sf.flux_u, tau_v = sf.flux_v;
+  auto momentum = [&](auto heat_in, auto du_in, auto dv_in) {
+    const auto r = moist::vd::down_pair(L, delta_t, [&](int k) { return up[(size_t)k * s]; }, [&](int k) { return vp[(size_t)k * s]; }, du_in, dv_in,
+                                        moist::PblProfile::Km{pbl}, tp, s, phc, a.zf_c + c, s, w,
+                                        moist::DtPark<decltype(heat_in)>{heat_in, dtT, s}, kb);      // = vert_diff_momentum_f, its two halves
     MT(3, 4)
-    moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, phc, a.zf_c + c, s, dtT, dtq, s, w, S);
-    MT(3, 5)
-    moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
-                       sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
-    MT(3, 6)
-    moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s);
-  }
+    moist::vert_diff_momentum_up_f(r, L, delta_t, up, vp, s, tau_u, tau_v, sf.dtaudu_atm, sf.dtaudv_atm, du_in, dv_in, dtu, dtv, dtT, s, nullptr, 0, w, S, kb);
+  };
+  if (kb >= nray) momentum(heat_lo, zero_lo, zero_lo);       // (the boundary layer lies below the sponge)
+  else momentum(heat_sp, du_sp, dv_sp);
+  MT(3, 5)
+  moist::vert_diff_heat_down(L, delta_t, tp, qp, s, moist::PblProfile::Kt{pbl}, phc, a.zf_c + c, s, dtT, ccq, s, w, S, kb);
+  MT(3, 6)
+  moist::mixed_layer(a.ml, a.dt_atmos, t_surf, sf.flux_t, sf.flux_q, sf.flux_r, net_sw, lw_down_surf, S, sf.dhdt_surf, sf.dedt_surf,
+                     sf.drdt_surf, sf.dhdt_atm, sf.dedq_atm);
+  MT(3, 7)
+  moist::vert_diff_up(L, delta_t, w, S, dtT, dtq, s, kb);
   a.t_surf[c] = t_surf;
-  MT(3, 7) MT_STORE(3)
+  MT(3, 8) MT_STORE(3, a.precip)
 }
 
 // mixed_layer_init with prescribe_initial_dist (mixed_layer.F90:455-460): t_surf = tconst - delta_T (3 sin^2 lat - 1)/3
@@ -305,26 +355,53 @@ static MoistArgs moist_args(const isca_dyn &h) {
   a.ml.heat_capacity = mc.depth * (1.035e3 * 3989.24495292815);       // depth*RHO_CP (mixed_layer.F90:514)
   a.ml.evaporation = mc.evaporation != 0; a.ml.ocean_qflux = 0.0;
   a.dt_atmos = h.cfg.dt_atmos;
+  a.full_sweeps = getenv("ISCA_MOIST_FULL_SWEEPS") ? 1 : 0;
   return a;
 }
-static void launch_moist_kernel(const MoistArgs &a, hipStream_t s) {
-  const bool two = a.L + 1 >= MOIST_NX && !getenv("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
+// LDS per block: one work array is 64 x (L+1) doubles.  ISCA_MOIST_GLOBAL_WORK / ISCA_MOIST_LDS_ARRAYS=2 (tests, measurements): the variants of larger
+// level counts at a small one; ISCA_MOIST_CC_LDS=0|2|3: the convection kernel's alone (its LDS footprint beside the dynamics kernels it runs under).
+static int moist_nlds(int L, const char *own_env) {
+  const size_t lds1 = (size_t)64 * (L + 1) * sizeof(double);
+  int nlds = getenv("ISCA_MOIST_GLOBAL_WORK") ? 0 : (3 * lds1 <= 65536 ? 3 : (2 * lds1 <= 65536 ? 2 : 0));      // L <= 41: all three; L <= 63: arrays 0 and 1
+  if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);
+  if (own_env) if (const char *e = getenv(own_env)) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);
+  return nlds;
+}
+static void launch_moist_convcond_kernel(const MoistArgs &a, hipStream_t s) {
+  const dim3 grid((a.ncol + 63) / 64), block(64);
+  const size_t lds1 = (size_t)64 * (a.L + 1) * sizeof(double);
+  const int nlds = moist_nlds(a.L, "ISCA_MOIST_CC_LDS");
+#define LM(N)                                                                                            \
+  do {                                                                                                   \
+    if (a.pk) {                                                                                          \
+      if (nlds == 3) hipLaunchKernelGGL((k_moist_convcond<N, 3, true>), grid, block, 3 * lds1, s, a);      \
+      else if (nlds == 2) hipLaunchKernelGGL((k_moist_convcond<N, 2, true>), grid, block, 2 * lds1, s, a); \
+      else hipLaunchKernelGGL((k_moist_convcond<N, 0, true>), grid, block, 0, s, a);                       \
+    } else {                                                                                             \
+      if (nlds == 3) hipLaunchKernelGGL((k_moist_convcond<N, 3, false>), grid, block, 3 * lds1, s, a);     \
+      else if (nlds == 2) hipLaunchKernelGGL((k_moist_convcond<N, 2, false>), grid, block, 2 * lds1, s, a);\
+      else hipLaunchKernelGGL((k_moist_convcond<N, 0, false>), grid, block, 0, s, a);                      \
+    }                                                                                                    \
+  } while (0)
+  if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
+#undef LM
+}
+static void launch_moist_physics_kernel(const MoistArgs &a, hipStream_t s) {
+  const bool two = !getenv("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
   const dim3 grid((a.ncol + 63) / 64), block(two ? 128 : 64);
-  const size_t lds1 = (size_t)64 * (a.L + 1) * sizeof(double);        // one work array of a block
-  const bool glob = getenv("ISCA_MOIST_GLOBAL_WORK") != nullptr;
-  int nlds = glob ? 0 : (3 * lds1 <= 65536 ? 3 : (2 * lds1 <= 65536 ? 2 : 0));            // L <= 41: all three; L <= 63: arrays 0 and 1 (parcel / deltas / e, f1)
-  if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);      // (tests: the variants of larger level counts at a small one)
-#define LM(N)                                                                                          \
-  do {                                                                                                 \
-    if (a.pk) {                                                                                        \
+  const size_t lds1 = (size_t)64 * (a.L + 1) * sizeof(double);
+  const int nlds = moist_nlds(a.L, nullptr);
+#define LM(N)                                                                                           \
+  do {                                                                                                  \
+    if (a.pk) {                                                                                         \
       if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3, true>), grid, block, 3 * lds1, s, a);      \
       else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2, true>), grid, block, 2 * lds1, s, a); \
       else hipLaunchKernelGGL((k_moist_physics<N, 0, true>), grid, block, 0, s, a);                       \
-    } else {                                                                                           \
+    } else {                                                                                            \
       if (nlds == 3) hipLaunchKernelGGL((k_moist_physics<N, 3, false>), grid, block, 3 * lds1, s, a);     \
       else if (nlds == 2) hipLaunchKernelGGL((k_moist_physics<N, 2, false>), grid, block, 2 * lds1, s, a);\
       else hipLaunchKernelGGL((k_moist_physics<N, 0, false>), grid, block, 0, s, a);                      \
-    }                                                                                                  \
+    }                                                                                                   \
   } while (0)
   if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
 #undef LM
@@ -419,38 +496,60 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   a.mcm = h.cfg.vert_difference_option == 1;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, prev_cached ? 1 : 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
-void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int slot_prev, int slot_cur) {
+// convection + condensation of the step whose PREVIOUS level is time level `level` (its pressures in slot pslot of the work area), leapfrog step
+// delta_t, into buffer set ccslot (idealized_moist_phys.F90:862-880, :975-997)
+void launch_moist_convcond(const isca_dyn &h, int level, int pslot, double delta_t, int ccslot, hipStream_t s) {
   const Dev &d = h.d;
   const size_t lev = (size_t)h.g.Jl * h.g.I;
   const MoistWork w = moist_work_layout(h);
-  double *pf_p = w.pf[slot_prev], *ph_p = w.ph[slot_prev], *pf_c = w.pf[slot_cur], *ph_c = w.ph[slot_cur];
-  double *zf_c = w.zf_c, *zh_c = w.zh_c, *zf_p = w.rest, *zh_p = zf_p + lev * h.g.L;
+  MoistArgs a = moist_args(h);
+  a.ncol = (int)lev; a.I = h.g.I;
+  a.tp = d.tg[level]; a.qp = d.tr_atm[level];
+  a.pf_p = w.pf[pslot]; a.ph_p = w.ph[pslot];
+  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = d.psg[level]; }
+  a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
+  a.delta_t = delta_t;
+  launch_moist_convcond_kernel(a, s);
+}
+// the physics of one step on the model state: previous-level fields, pressures and heights of the current one, the convection's rates from buffer
+// set ccslot; next: also the NEXT step's convection + condensation (previous level = this step's current one, delta_t = 2 dt_atmos) into the other set
+void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int slot_cur, int ccslot, bool next) {
+  const Dev &d = h.d;
+  const size_t lev = (size_t)h.g.Jl * h.g.I;
+  const MoistWork w = moist_work_layout(h);
+  double *zf_p = w.rest, *zh_p = zf_p + lev * h.g.L;
   MoistArgs a = moist_args(h);
   a.ncol = (int)lev; a.I = h.g.I;
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
-  a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = zf_c; a.zh_c = zh_c;
+  a.pf_c = w.pf[slot_cur]; a.ph_c = w.ph[slot_cur]; a.zf_c = w.zf_c; a.zh_c = w.zh_c;
   a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
   a.surf_geop = d.surf_geop; a.ktop = (h.tab.pk[0] == 0.0) ? 1 : 0;
-  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = d.psg[sc.prev]; a.ps_c = d.psg[sc.cur]; }
+  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_c = d.psg[sc.cur]; }
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
+  a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
+  a.do_next = next ? 1 : 0;
+  a.tn = d.tg[sc.cur]; a.qn = d.tr_atm[sc.cur]; a.dt_next = 2 * h.cfg.dt_atmos;
+  a.nx_dT = d.cc_dT[1 - ccslot]; a.nx_dq = d.cc_dq[1 - ccslot]; a.nx_precip = d.cc_precip[1 - ccslot];
   a.work = zh_p + lev * (h.g.L + 1);
   a.delta_t = sc.delta_t;
   a.gust = h.phys_calls == 0 ? 1.0 : h.cfg.moist.constant_gust;    // gust = 1 until vert_turb_driver has run once (:592, :1262)
-  launch_moist_kernel(a, s);
+  launch_moist_physics_kernel(a, s);
 }
-// the same on caller columns (device pointers, [lev][ncol])
+// the same on caller columns (device pointers, [lev][ncol]); work: 5 (L+1) ncol doubles, cc: (2 L + 1) ncol doubles
 void launch_moist_physics_on(const isca_dyn &h, int ncol, double delta_t, double gust, const double *rad_lat, const double *u, const double *v,
                              const double *t, const double *q, const double *ph_p, const double *pf_p, const double *ph_c, const double *pf_c,
                              const double *zh_c, const double *zf_c, double *t_surf, double *dtu, double *dtv, double *dtT, double *dtq,
-                             double *precip, double *work, hipStream_t s) {
+                             double *precip, double *work, double *cc, hipStream_t s) {
   MoistArgs a = moist_args(h);
   a.work = work;
   a.ncol = ncol; a.I = 1;
   a.up = u; a.vp = v; a.tp = t; a.qp = q; a.pf_p = pf_p; a.ph_p = ph_p; a.pf_c = pf_c; a.ph_c = ph_c; a.zf_c = const_cast<double *>(zf_c); a.zh_c = const_cast<double *>(zh_c);      // (heights given: not summed, not written)
   a.rad_lat_row = nullptr; a.rad_lat_col = rad_lat;
   a.t_surf = t_surf; a.dtu = dtu; a.dtv = dtv; a.dtT = dtT; a.dtq = dtq; a.precip = precip;
+  a.cc_dT = cc; a.cc_dq = cc + (size_t)h.g.L * ncol; a.cc_precip = cc + (size_t)2 * h.g.L * ncol;
   a.delta_t = delta_t; a.gust = gust;
-  launch_moist_kernel(a, s);
+  launch_moist_convcond_kernel(a, s);
+  launch_moist_physics_kernel(a, s);
 }
 void launch_t_surf_init(const isca_dyn &h, hipStream_t s) {
   const int ncol = h.g.Jl * h.g.I;

@@ -156,16 +156,19 @@ MP_HD void lscale_cond(const SatTable &st, int L, LOAD load, const double *pfull
 // optical depth sw_tau_0 (p/p0)^solar_exponent, grey LW with lw_tau_0(lat) (linear_tau p/p0 + (1-linear_tau)(p/p0)^wv_exponent).
 // ------------------------------------------------------------------------------------------------
 MP_HD double pow4(double x) { return x * x * x * x; }     // x**4 as the reference build expands it, ((x x) x) x
+// (p/p0)**wv_exponent, (p/p0)**solar_exponent with REAL exponents (namelist variables): the library pow, except for the value every test case sets,
+// 4, taken as three multiplications -- within 3 ulp of pow, and a third of gray_rad_down's time on the device (pow is ~0.4 us per level there).
+MP_HD double gray_pow(double x, double e) { return (e == 4.0) ? pow4(x) : pow(x, e); }
 struct GrayRadParams {
   double solar_constant = 1360.0, del_sol = 1.4, del_sw = 0.0, ir_tau_eq = 6.0, ir_tau_pole = 1.5, atm_abs = 0.0, odp = 1.0,
          sw_diff = 0.0, linear_tau = 0.1, wv_exponent = 4.0, solar_exponent = 4.0, diabatic_acce = 1.0;
 };
-// Downward pass: fills lw_down[0..L] (caller storage, stride sw), lw_dtrans[0..L-1] and sw_down[0..L] (the downward shortwave flux on
+// Downward pass: fills lw_down[0..L] (caller storage, stride sw), lw_dtrans[0..L-1] and sw_down[0..L] (stride ssw; the downward shortwave flux on
 // the half levels, which the reference evaluates again in the upward pass: here that pass reads it), returns the surface fluxes.
 // (p/p0)^wv_exponent and (p/p0)^solar_exponent are one pow when the two exponents are equal (the defaults: 4).
 template <class PH>
 MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, PH p_half, int s,
-                         double *lw_down, double *lw_dtrans, double *sw_down, int sw, double &insolation, double &sw_tau_0,
+                         double *lw_down, double *lw_dtrans, int sw, double *sw_down, int ssw, double &insolation, double &sw_tau_0,
                          double &net_surf_sw_down, double &surf_lw_down) {
   const double sl = sin(lat), sl2 = sl * sl;
   const double p2 = (1. - 3. * sl2) / 4.;
@@ -175,10 +178,10 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   lw_tau_0 = lw_tau_0 * p.odp;
   const bool one_pow = p.solar_exponent == p.wv_exponent;
   const double ph_top = ph_at(p_half, s, 0);
-  const double pw0 = pow(ph_top / PSTD_MKS, p.wv_exponent);
+  const double pw0 = gray_pow(ph_top / PSTD_MKS, p.wv_exponent);
   double tau_k = lw_tau_0 * (p.linear_tau * ph_top / PSTD_MKS + (1.0 - p.linear_tau) * pw0);
   lw_down[0] = 0.;
-  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : pow(ph_top / PSTD_MKS, p.solar_exponent)));
+  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : gray_pow(ph_top / PSTD_MKS, p.solar_exponent)));
   double lwd = 0., swd_last = 0.;
   for (int k0 = 0; k0 < L; k0 += MP_U) {
     double ph[MP_U], tk[MP_U], tau_n[MP_U], swd[MP_U];
@@ -189,16 +192,16 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
-      const double pw = pow(ph[i] / PSTD_MKS, p.wv_exponent);
+      const double pw = gray_pow(ph[i] / PSTD_MKS, p.wv_exponent);
       tau_n[i] = lw_tau_0 * (p.linear_tau * ph[i] / PSTD_MKS + (1.0 - p.linear_tau) * pw);
-      swd[i] = insolation * exp(-sw_tau_0 * (one_pow ? pw : pow(ph[i] / PSTD_MKS, p.solar_exponent)));
+      swd[i] = insolation * exp(-sw_tau_0 * (one_pow ? pw : gray_pow(ph[i] / PSTD_MKS, p.solar_exponent)));
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       if (k0 + i < L) {
         const double dtr = exp(-(tau_n[i] - tau_k));
         lw_dtrans[(k0 + i) * sw] = dtr;
-        sw_down[(k0 + i + 1) * sw] = swd[i]; swd_last = swd[i];
+        sw_down[(k0 + i + 1) * ssw] = swd[i]; swd_last = swd[i];
         const double b = STEFAN * pow4(tk[i]);
         lwd = lwd * dtr + b * (1. - dtr);
         lw_down[(k0 + i + 1) * sw] = lwd;
@@ -209,31 +212,35 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   surf_lw_down = lwd;
   net_surf_sw_down = swd_last * (1. - albedo);
 }
-// Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.
+// Upward pass: temperature tendency of the radiative flux divergence, accumulated into tdt.  tdt_is_zero: the caller's tendency so far is zero and
+// is not read (0 + x is still formed, so the stored bits are those of an accumulation into a zeroed array) -- tdt may then BE sw_down (same
+// stride): level k's shortwave flux is read in the load phase of k's chunk, its heating stored at the chunk's end, and the chunks walk upward.
 template <class PH>
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, PH p_half, int s,
-                       const double *lw_down, const double *lw_dtrans, const double *sw_down, int sw, double *tdt, int st) {
+                       const double *lw_down, const double *lw_dtrans, int sw, const double *sw_down, int ssw, double *tdt, int st,
+                       bool tdt_is_zero = false) {
   const double b_surf = STEFAN * pow4(t_surf);
-  const double ph_surf = ph_at(p_half, s, L), sw_surf = sw_down[L * sw];
+  const double ph_surf = ph_at(p_half, s, L), sw_surf = sw_down[L * ssw];
   const double sw_up = albedo * sw_surf;
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
   double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - sw_surf);
   double ph_n = ph_surf;
   for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
-    double tk[MP_U], ph[MP_U], td[MP_U], swd[MP_U];
+    double tk[MP_U], ph[MP_U], td[MP_U], swd[MP_U], dtrs[MP_U], lwd[MP_U];
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) {
+    for (int i = 0; i < MP_U; ++i) {       // everything the chunk reads, the downward pass's arrays included (they may live in global memory)
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      tk[i] = t[k * s]; ph[i] = ph_at(p_half, s, k); td[i] = tdt[k * st]; swd[i] = sw_down[k * sw];
+      tk[i] = t[k * s]; ph[i] = ph_at(p_half, s, k); swd[i] = sw_down[k * ssw]; dtrs[i] = lw_dtrans[k * sw]; lwd[i] = lw_down[k * sw];
+      td[i] = tdt_is_zero ? 0.0 : tdt[k * st];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
       if (k >= 0) {
         const double b = STEFAN * pow4(tk[i]);
-        const double dtr = lw_dtrans[k * sw];
+        const double dtr = dtrs[i];
         const double lw_up_k = lw_up_n * dtr + b * (1.0 - dtr);
-        const double flux_k = (lw_up_k - lw_down[k * sw]) + (sw_up - swd[i]);
+        const double flux_k = (lw_up_k - lwd[i]) + (sw_up - swd[i]);
         const double tdt_rad = p.diabatic_acce * (flux_n - flux_k) * GRAV / (CP_AIR * (ph_n - ph[i]));
         td[i] = td[i] + tdt_rad;
         lw_up_n = lw_up_k; flux_n = flux_k; ph_n = ph[i];
@@ -273,15 +280,17 @@ MP_HD double qe_get_lcl_temp(const QeParams &p, double value) {
 // Work arrays of one column, 1-based.  The parcel's Tp, rp live in caller storage (QeParcel) and the relaxation deltas dT, dq take that
 // storage over once the reference profiles have consumed the parcel (each level's Tp, rp are read before its dT, dq are written); the
 // reference profiles themselves are only kept when the caller wants them (WANT_REF: the host tests; the device kernel does not).
-template <int LMAX, bool WANT_REF>
+template <int LMAX, bool WANT_REF, bool TV_EXT = false>
 struct QeColumn {
-  double Tv[LMAX + 2], Tref[WANT_REF ? LMAX + 2 : 1], qref[WANT_REF ? LMAX + 2 : 1];
+  double Tv[TV_EXT ? 1 : LMAX + 2], Tref[WANT_REF ? LMAX + 2 : 1], qref[WANT_REF ? LMAX + 2 : 1];
 };
 // The parcel's temperature and mixing ratio, written level by level in the ascent and read back by the reference profiles, live in
 // caller storage: wTp[(k-1)*sw], wrp[(k-1)*sw] for level k = 1..L (LDS on the device; in thread-private arrays every store of the
 // ascent is a memory operation that the loads of the next level then queue behind).
 struct QeParcel {
   double *wTp, *wrp; int sw;
+  double *wTv = nullptr;           // TV_EXT: the environment's virtual temperature in caller storage too (stride sw; the device kernel: a third LDS array
+                                   // instead of a thread-private one, which was 424 bytes of scratch per lane)
 #ifdef MOIST_TIMING
   long long *marks = nullptr;      // timing builds (moist.hip): wall_clock64 stamps at the QE_MARK points of qe_moist_convection
 #define QE_MARK(i) if (MOIST_TIMING == 5 && pc.marks) { const long long t_ = wall_clock64(); for (int i_ = i; i_ < 9; ++i_) pc.marks[i_] = t_; }
@@ -293,12 +302,13 @@ struct QeParcel {
 };
 
 // deltaT / deltaq may BE the parcel storage (deltaT == pc.wTp, deltaq == pc.wrp, so == pc.sw): the deltas are then left where they are.
-template <int LMAX, bool WANT_REF = true, class PH = const double *>
+template <int LMAX, bool WANT_REF = true, class PH = const double *, bool TV_EXT = false>
 MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, double dt, const double *Tin_, const double *qin_,
                                const double *p_full_, PH p_half_, int s, double *deltaT, double *deltaq, double &rain,
                                double &cape_out, double &cin_out, int &convflag, int &kLZB_out, int &kLCL_out, double *Tref_out,
                                double *qref_out, int so, const QeParcel &pc) {
-  QeColumn<LMAX, WANT_REF> c;
+  QeColumn<LMAX, WANT_REF, TV_EXT> c;
+  auto Tv = [&](int k) -> double & { if constexpr (TV_EXT) return pc.wTv[(k - 1) * pc.sw]; else return c.Tv[k]; };
   auto dT = [&](int k) -> double & { return pc.wTp[(k - 1) * pc.sw]; };      // valid from the reference-profile pass on
   auto dq = [&](int k) -> double & { return pc.wrp[(k - 1) * pc.sw]; };
   auto set_ref = [&](int k, double tref, double qref) { if (WANT_REF) { c.Tref[k] = tref; c.qref[k] = qref; } };
@@ -325,7 +335,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     MP_UNROLL_ALL
     for (int i = 0; i < IU; ++i) {
       const int k = k0 + i;
-      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; c.Tv[k] = qe_virtual_temp(tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
+      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; Tv(k) = qe_virtual_temp(tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
     }
   }
   QE_MARK(1)
@@ -359,10 +369,10 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       int k = ks;
       CIN = 0.;
       {
-        double pfk = pf(ks), ph1 = ph(ks + 1), phk = ph(ks), tvk = c.Tv[ks];        // next level requested one iteration ahead
+        double pfk = pf(ks), ph1 = ph(ks + 1), phk = ph(ks), tvk = Tv(ks);        // next level requested one iteration ahead
         while (k >= 1 && pfk > pLCL) {
           const int kn = (k > 1) ? k - 1 : 1;
-          const double pfn = pf(kn), phn = ph(kn), tvn = c.Tv[kn];
+          const double pfn = pf(kn), phn = ph(kn), tvn = Tv(kn);
           const double Tpk = theta0 * pow(pfk / QE_PREF, KAPPA);
           pc.Tp(k) = Tpk;
           pc.rp(k) = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
@@ -392,10 +402,10 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
           } else {
             pc.rp(kLCL) = qe_mixing_ratio(lookup_es(st, pc.Tp(kLCL)), pf(kLCL));
             const double tvp = qe_virtual_temp(pc.Tp(kLCL), pc.rp(kLCL));
-            if ((tvp < c.Tv[kLCL]) && nocape) {
-              CIN = CIN + RDGAS * (c.Tv[kLCL] - tvp) * log(ph(kLCL + 1) / ph(kLCL));
+            if ((tvp < Tv(kLCL)) && nocape) {
+              CIN = CIN + RDGAS * (Tv(kLCL) - tvp) * log(ph(kLCL + 1) / ph(kLCL));
             } else {
-              CAPE = CAPE + RDGAS * (tvp - c.Tv[kLCL]) * log(ph(kLCL + 1) / ph(kLCL));
+              CAPE = CAPE + RDGAS * (tvp - Tv(kLCL)) * log(ph(kLCL + 1) / ph(kLCL));
               if (nocape) { nocape = false; kLFC = kLCL; }
             }
           }
@@ -412,10 +422,10 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       // the parcel's previous level stays in registers; pressures and Tv of the next level are requested one iteration ahead, so their
       // latency hides behind this level's log / table-lookup chain
       double Tp1 = pc.Tp(kLCL), rp1 = pc.rp(kLCL);
-      double pf1 = pf(kLCL), pfk = pf(kLCL - 1), ph1 = ph(kLCL), phk = ph(kLCL - 1), tvk = c.Tv[kLCL - 1];
+      double pf1 = pf(kLCL), pfk = pf(kLCL - 1), ph1 = ph(kLCL), phk = ph(kLCL - 1), tvk = Tv(kLCL - 1);
       for (int k = kLCL - 1; k >= 1; --k) {
         const int kn = (k > 1) ? k - 1 : 1;
-        const double pfn = pf(kn), phn = ph(kn), tvn = c.Tv[kn];
+        const double pfn = pf(kn), phn = ph(kn), tvn = Tv(kn);
         double a = KAPPA * Tp1 + (HLV / CP_AIR) * rp1;
         double b = (HLV * HLV) * rp1 / (CP_AIR * RVGAS * (Tp1 * Tp1));
         double dtdlnp = a / (1.0 + b);
@@ -563,12 +573,12 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
 // ------------------------------------------------------------------------------------------------
 struct MoParams { double rich_crit = 2.0, drag_min = 1.e-05, zeta_trans = 0.5; };
 MP_HD double mo_phi_t(const MoParams &p, double zeta) {
-  if (zeta < 0.0) return pow(1 - 16.0 * zeta, -0.5);
+  if (zeta < 0.0) return 1.0 / sqrt(1 - 16.0 * zeta);      // (1 - 16 zeta)**(-0.5): within an ulp of pow, a quarter of its time on the device
   const double b_stab = 1.0 / p.rich_crit;
   return 1.0 + zeta * (5.0 + b_stab * zeta) / (1.0 + zeta);
 }
 MP_HD double mo_phi_m(const MoParams &p, double zeta) {
-  if (zeta < 0.0) { const double x = pow(1 - 16.0 * zeta, -0.5); return sqrt(x); }
+  if (zeta < 0.0) { const double x = 1.0 / sqrt(1 - 16.0 * zeta); return sqrt(x); }
   const double b_stab = 1.0 / p.rich_crit;
   return 1.0 + zeta * (5.0 + b_stab * zeta) / (1.0 + zeta);
 }
@@ -694,14 +704,16 @@ MP_HD void surface_flux(const SatTable &st, const MoParams &mo, double t_atm, do
 // removed goes into heat (do_conserve_energy).  nlev_rayfric and rfactr are set up by the host (:411-420).
 // ------------------------------------------------------------------------------------------------
 struct RayleighParams { int nlev_rayfric = 0; double rfactr = 0.0, sponge_pbottom = 50.0; bool conserve_energy = true; };
+// zero_in: the incoming tendencies of the sponge levels are zero and are not read (0 + x is still formed)
 MP_HD void rayleigh_damping(const RayleighParams &p, double dt, const double *pfull, const double *u, const double *v, int s, double *udt,
-                            double *vdt, int st, double *tdt, int stt) {
+                            double *vdt, int st, double *tdt, int stt, bool zero_in = false) {
   for (int k0 = 0; k0 < p.nlev_rayfric; k0 += MP_U) {
     double pf[MP_U], uk[MP_U], vk[MP_U], ud[MP_U], vd[MP_U], td[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 + i < p.nlev_rayfric) ? k0 + i : p.nlev_rayfric - 1;
-      pf[i] = pfull[k * s]; uk[i] = u[k * s]; vk[i] = v[k * s]; ud[i] = udt[k * st]; vd[i] = vdt[k * st]; td[i] = tdt[k * stt];
+      pf[i] = pfull[k * s]; uk[i] = u[k * s]; vk[i] = v[k * s];
+      ud[i] = zero_in ? 0.0 : udt[k * st]; vd[i] = zero_in ? 0.0 : vdt[k * st]; td[i] = zero_in ? 0.0 : tdt[k * stt];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -743,35 +755,59 @@ MP_HD double mo_diff_t(const MoParams &mo, const DiffusivityParams &dp, double z
 // pbl_depth (:364-444), do_simple: the height where the bulk Richardson number of the provisional profile first exceeds
 // rich_crit_pbl, searched upward from the lowest level.  Nothing is stored: each level is visited once.
 // tdt(k), udt(k), vdt(k): the tendencies so far as functions of the level (memory reads inside them must be unconditional)
-template <class TDT, class UDT, class VDT>
-MP_HD double pbl_depth_f(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
-                         TDT tdt, UDT udt, VDT vdt, const double *z_full, const double *z_half, int sz) {
+// kstop (optional): the level at which the search stopped (L - 1 if it never did).  The depth returned lies below that level's height, so every
+// interface at or above it has no diffusion (diffusivity_pbl is zero from the depth upward): levels 0 .. kstop-1 are untouched by the implicit diffusion.
+// pbl_depth_f2: two sets of tendency functions -- (tdt, udt, vdt) valid at every level and (tdt_lo, udt_lo, vdt_lo) valid at the levels k >= klim only
+// (the device kernel's: below the sponge its tendency functions need no sponge terms, and a function that tests the level for them costs the chunk
+// its single memory round trip: the compiler turns the test into a branch and sinks the load behind it); a chunk that lies at or below klim takes the
+// second set.
+template <class TDT, class UDT, class VDT, class TDT2, class UDT2, class VDT2>
+MP_HD double pbl_depth_f2(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
+                          TDT tdt, UDT udt, VDT vdt, TDT2 tdt_lo, UDT2 udt_lo, VDT2 vdt_lo, int klim, const double *z_full, const double *z_half, int sz,
+                          int *kstop = nullptr) {
   const double gcp = GRAV / CP_AIR;
+  if (kstop) *kstop = L - 1;
   const double z_surf = z_half[L * sz];
-  double tbot = 0.0, h1 = 0.0, rich1 = 0.0, h = 0.0;
-  for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
-    double zf[MP_U], tt[MP_U], uu[MP_U], vv[MP_U];
+  double tbot = 0.0, h1 = 0.0, rich1 = 0.0, h = 0.0, result = 0.0;
+  bool found = false;
+  auto chunk = [&](int k0, auto &ft, auto &fu, auto &fv) {
+    double zf[MP_U], tt[MP_U], uu[MP_U], vv[MP_U], ta[MP_U], ua[MP_U], va[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
       zf[i] = z_full[k * sz]; tt[i] = tm[k * s]; uu[i] = um[k * s]; vv[i] = vm[k * s];
-      const double a = tdt(k), b = udt(k), c = vdt(k);
-      tt[i] = tt[i] + dt * a; uu[i] = uu[i] + dt * b; vv[i] = vv[i] + dt * c;
+      ta[i] = ft(k); ua[i] = fu(k); va[i] = fv(k);
     }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) { tt[i] = tt[i] + dt * ta[i]; uu[i] = uu[i] + dt * ua[i]; vv[i] = vv[i] + dt * va[i]; }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
-      if (k < 0) break;
+      if (k < 0 || found) break;
       const double zfa = zf[i] - z_surf;
       const double svcp = tt[i] + gcp * zfa;
       if (k == L - 1) tbot = svcp;
       const double rich2 = zfa * GRAV * (svcp - tbot) / tbot / (uu[i] * uu[i] + vv[i] * vv[i] + dp.small);
       if (k == L - 1) { h1 = zfa; h = h1; rich1 = rich2; continue; }
-      if (rich2 > dp.rich_crit_pbl) return zfa + (h1 - zfa) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1);
+      if (rich2 > dp.rich_crit_pbl) {
+        if (kstop) *kstop = k;
+        result = zfa + (h1 - zfa) * (rich2 - dp.rich_crit_pbl) / (rich2 - rich1);
+        found = true;
+        break;
+      }
       rich1 = rich2; h1 = zfa;
     }
+  };
+  for (int k0 = L - 1; k0 >= 0 && !found; k0 -= MP_U) {
+    if (k0 - (MP_U - 1) >= klim) chunk(k0, tdt_lo, udt_lo, vdt_lo);
+    else chunk(k0, tdt, udt, vdt);
   }
-  return h;
+  return found ? result : h;
+}
+template <class TDT, class UDT, class VDT>
+MP_HD double pbl_depth_f(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
+                         TDT tdt, UDT udt, VDT vdt, const double *z_full, const double *z_half, int sz, int *kstop = nullptr) {
+  return pbl_depth_f2(dp, L, dt, tm, um, vm, s, tdt, udt, vdt, tdt, udt, vdt, L + 1, z_full, z_half, sz, kstop);
 }
 MP_HD double pbl_depth(const DiffusivityParams &dp, int L, double dt, const double *tm, const double *um, const double *vm, int s,
                        const double *tdt, const double *udt, const double *vdt, int st, const double *z_full, const double *z_half, int sz) {
@@ -853,13 +889,16 @@ struct NoAux {
   MP_HD double load(int) const { return 0.0; }
   MP_HD void store(int, double) const {}
 };
+// kb > 0: the caller knows that no interface at or above level kb carries diffusion (pbl_depth_f's kstop); the sweep starts at level kb (nothing is
+// stored for the levels above, whose e = 0, f = the incoming tendency: vert_diff_passthrough) -- the values it produces are those of the whole sweep,
+// except that a ZERO may come out with the other sign.
 template <class X1, class X2, class D1, class D2, class DIFF, class PH, class AUX = NoAux>
 MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF diff, const double *t, int s, PH p_half,
-                           const double *z_full, int sp, const VdiffWork &w, AUX aux = AUX()) {
+                           const double *z_full, int sp, const VdiffWork &w, AUX aux = AUX(), int kb = 0) {
   DownResult r;
   double fl1_k = 0.0, fl2_k = 0.0, nu_k = 0.0, e_prev = 0.0, f1_prev = 0.0, f2_prev = 0.0;
-  double x1_k = x1(0), x2_k = x2(0), t_k = t[0], z_k = z_full[0], ph_k = ph_at(p_half, sp, 0);
-  for (int k0 = 0; k0 < L; k0 += MP_U) {
+  double x1_k = x1(kb), x2_k = x2(kb), t_k = t[kb * s], z_k = z_full[kb * sp], ph_k = ph_at(p_half, sp, kb);
+  for (int k0 = kb; k0 < L; k0 += MP_U) {
     double phn[MP_U], tn[MP_U], zn[MP_U], x1n[MP_U], x2n[MP_U], dd1[MP_U], dd2[MP_U], df[MP_U], zr[MP_U], ax[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // everything level k0+i needs from memory: its own tendencies, the fields of the level below
@@ -927,7 +966,7 @@ MP_HD DownResult down_pair(int L, double delt, X1 x1, X2 x2, D1 d1, D2 d2, DIFF 
 template <class DUIN, class DVIN>
 MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, const double *u, const double *v, int s, double &tau_u, double &tau_v,
                                    double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in, double *dt_u, double *dt_v, double *dt_t, int st,
-                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S);
+                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S, int kb = 0);
 // dt_in(k) is evaluated in the DOWNWARD sweep (it may read what that sweep's e, f then overwrite) and parked in dt_t for the upward one.
 template <class DTIN>
 struct DtPark {
@@ -949,25 +988,26 @@ MP_HD void vert_diff_momentum_f(int L, double delt, const double *u, const doubl
 template <class DUIN, class DVIN>
 MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, const double *u, const double *v, int s, double &tau_u, double &tau_v,
                                    double dtau_du, double dtau_dv, DUIN du_in, DVIN dv_in, double *dt_u, double *dt_v, double *dt_t, int st,
-                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S) {
+                                   double *diss_heat, int sh, const VdiffWork &w, VdiffSurf &S, int kb) {
   double delta_u_n = r.delta_1_n, delta_v_n = r.delta_2_n;
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f1_delt_n1, dtau_du, tau_u, 1.0, delta_u_n);
   vd::diff_surface(r.mu_delt_n, r.nu_n, r.e_n1, r.f2_delt_n1, dtau_dv, tau_v, 1.0, delta_v_n);
   S.delta_u = delta_u_n; S.delta_v = delta_v_n;
   double xu = delta_u_n / delt, xv = delta_v_n / delt;                              // vert_diff_up (:914-947)
   const double half_delt = 0.5 * delt, cp_inv = 1.0 / CP_AIR;
-  for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
-    double uk[MP_U], vk[MP_U], du0[MP_U], dv0[MP_U], dt0[MP_U], dh[MP_U];
+  for (int k0 = L - 1; k0 >= kb; k0 -= MP_U) {
+    double uk[MP_U], vk[MP_U], du0[MP_U], dv0[MP_U], dt0[MP_U], dh[MP_U], ee[MP_U], ff1[MP_U], ff2[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
-      const int k = (k0 - i >= 0) ? k0 - i : 0;
+      const int k = (k0 - i >= kb) ? k0 - i : kb, ke = (k < L - 1) ? k : L - 2;      // (e, f of the downward sweep: levels kb .. L-2; they may live in global memory)
       uk[i] = u[k * s]; vk[i] = v[k * s]; du0[i] = du_in(k); dv0[i] = dv_in(k); dt0[i] = dt_t[k * st];
+      ee[i] = w.e[ke * w.sw]; ff1[i] = w.f1[ke * w.sw]; ff2[i] = w.f2[ke * w.sw2];
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
-      if (k >= 0) {
-        if (k < L - 1) { const double e = w.e[k * w.sw]; xu = e * xu + w.f1[k * w.sw]; xv = e * xv + w.f2[k * w.sw2]; }
+      if (k >= kb) {
+        if (k < L - 1) { const double e = ee[i]; xu = e * xu + ff1[i]; xv = e * xv + ff2[i]; }
         const double du = xu - du0[i], dv = xv - dv0[i];
         dh[i] = -cp_inv * ((uk[i] + half_delt * du) * du + (vk[i] + half_delt * dv) * dv);
         du0[i] = xu; dv0[i] = xv;
@@ -977,7 +1017,7 @@ MP_HD void vert_diff_momentum_up_f(const vd::DownResult &r, int L, double delt, 
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
       const int k = k0 - i;
-      if (k >= 0) {
+      if (k >= kb) {
         dt_u[k * st] = du0[i]; dt_v[k * st] = dv0[i]; dt_t[k * st] = dt0[i];
         if (diss_heat) diss_heat[k * sh] = dh[i];
       }
@@ -994,10 +1034,11 @@ MP_HD void vert_diff_momentum(int L, double delt, const double *u, const double 
 // vert_diff_down_2 for dry static energy and humidity + the Tri_surf hand-over (gcm_vert_diff_down :372-404)
 template <class DIFFT, class PH>
 MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double *q, int s, DIFFT diff_t, PH p_half,
-                               const double *z_full, int sp, const double *dt_t, const double *dt_q, int st, const VdiffWork &w, VdiffSurf &S) {
+                               const double *z_full, int sp, const double *dt_t, const double *dt_q, int st, const VdiffWork &w, VdiffSurf &S, int kb = 0) {
   const double gcp = GRAV / CP_AIR;
   const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return t[k * s] + z_full[k * sp] * gcp; }, [&](int k) { return q[k * s]; },
-                                         [&](int k) { return dt_t[k * st]; }, [&](int k) { return dt_q[k * st]; }, diff_t, t, s, p_half, z_full, sp, w);
+                                         [&](int k) { return dt_t[k * st]; }, [&](int k) { return dt_q[k * st]; }, diff_t, t, s, p_half, z_full, sp, w,
+                                         vd::NoAux(), kb);
   S.delta_t = r.delta_1_n + r.mu_delt_n * r.nu_n * r.f1_delt_n1;
   S.dflux_t = -r.nu_n * (1.0 - r.e_n1);
   S.delta_q = r.delta_2_n + r.mu_delt_n * r.nu_n * r.f2_delt_n1;
@@ -1005,14 +1046,42 @@ MP_HD void vert_diff_heat_down(int L, double delt, const double *t, const double
   S.dtmass = r.mu_delt_n;
 }
 // gcm_vert_diff_up: final dt_t, dt_q
-MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st) {
+MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf &S, double *dt_t, double *dt_q, int st, int kb = 0) {
   double xt = S.delta_t / delt, xq = S.delta_q / delt;
   dt_t[(L - 1) * st] = xt; dt_q[(L - 1) * st] = xq;
-  MP_UNROLL
-  for (int k = L - 2; k >= 0; --k) {
-    const double e = w.e[k * w.sw];
-    xt = e * xt + w.f1[k * w.sw]; xq = e * xq + w.f2[k * w.sw2];
-    dt_t[k * st] = xt; dt_q[k * st] = xq;
+  for (int k0 = L - 2; k0 >= kb; k0 -= MP_U) {      // chunks: e, f_1, f_2 of MP_U levels requested together (they may live in global memory)
+    double ee[MP_U], ff1[MP_U], ff2[MP_U], ot[MP_U], oq[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 - i >= kb) ? k0 - i : kb;
+      ee[i] = w.e[k * w.sw]; ff1[i] = w.f1[k * w.sw]; ff2[i] = w.f2[k * w.sw2];
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      if (k0 - i >= kb) { xt = ee[i] * xt + ff1[i]; xq = ee[i] * xq + ff2[i]; }
+      ot[i] = xt; oq[i] = xq;
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      if (k0 - i >= kb) { dt_t[(k0 - i) * st] = ot[i]; dt_q[(k0 - i) * st] = oq[i]; }
+  }
+}
+// The levels 0 .. kb-1 above the boundary layer, which the sweeps started at kb leave out: with e = 0 and f = the incoming tendency the whole sweeps
+// give them dt_u = du_in + 0, dt_v = dv_in + 0, dt_t = dt_in + 0 (the dissipation of a zero wind increment is a zero), dt_q = dq_in + 0 -- a plain
+// streaming pass, every load of a chunk in flight at once and no recurrence.
+template <class DUIN, class DVIN, class DTIN, class DQIN>
+MP_HD void vert_diff_passthrough(int ka, int kb, DUIN du_in, DVIN dv_in, DTIN dt_in, DQIN dq_in, double *dt_u, double *dt_v, double *dt_t, double *dt_q,
+                                 int st) {      // levels ka .. kb-1
+  for (int k0 = ka; k0 < kb; k0 += MP_U) {
+    double a[MP_U], b[MP_U], c[MP_U], d[MP_U];
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i) {
+      const int k = (k0 + i < kb) ? k0 + i : kb - 1;
+      a[i] = du_in(k); b[i] = dv_in(k); c[i] = dt_in(k); d[i] = dq_in(k);
+    }
+    MP_UNROLL_ALL
+    for (int i = 0; i < MP_U; ++i)
+      if (k0 + i < kb) { const int k = k0 + i; dt_u[k * st] = a[i] + 0.0; dt_v[k * st] = b[i] + 0.0; dt_t[k * st] = c[i] + 0.0; dt_q[k * st] = d[i] + 0.0; }
   }
 }
 

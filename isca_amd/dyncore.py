@@ -113,6 +113,7 @@ def load_library():
         "isca_dyn_refresh_derived": [H],
         "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
         "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
+        "isca_dyn_set_info": [H, C.c_char_p, C.c_long],
         "isca_dyn_set_topography": [H, dp, dp, C.c_double, dp, dp],
         "isca_topog_regularize": [H, C.c_double, dp, dp, dp, dp],
         "isca_topog_compute_lambda": [H, C.c_double, dp, dp, dp, dp],
@@ -180,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
-    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_set_topography", "isca_topog_regularize", "isca_topog_compute_lambda", "isca_nc_read_variable", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
+    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_set_info", "isca_dyn_set_topography", "isca_topog_regularize", "isca_topog_compute_lambda", "isca_nc_read_variable", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
@@ -297,6 +298,10 @@ class DynCore:
         v = C.c_long()
         self._check(self.lib.isca_dyn_get_info(self._h, name.encode(), C.byref(v)))
         return v.value
+
+    def set_info(self, name: str, value: int):
+        """what idealized_moist_phys_mod keeps beside the fields ("phys_calls"): handing over a running model through set()"""
+        self._check(self.lib.isca_dyn_set_info(self._h, name.encode(), int(value)))
 
     # -- shapes
     def _shape(self, name):

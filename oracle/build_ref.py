@@ -49,7 +49,9 @@ TARGETS = {
                   scan=["shared", "atmos_spectral", "atmos_shared", "atmos_param", "coupler"],
                   cppdefs=["-DINTERNAL_FILE_NML", "-DOVERLOAD_C8", "-DRRTM_NO_COMPILE", "-DSOC_NO_COMPILE"],
                   # external (non-module) procedures the `use` graph cannot see: the Monin-Obukhov kernels called by monin_obukhov_mod
-                  extra=["atmos_param/monin_obukhov/monin_obukhov_kernel.F90"]),
+                  extra=["atmos_param/monin_obukhov/monin_obukhov_kernel.F90"],
+                  # oracle/ref_peek.c: read access to one module-private array of the reference (t_surf), see that file's header
+                  own_c=["ref_peek.c"]),
     # sibling core: src/atmos_spectral_shallow + the stirring module it shares with the barotropic core
     "shallow": dict(harness="ref_shallow_harness.F90", exe="ref_shallow_harness.x", build="build_shallow",
                     scan=["shared", "atmos_spectral/tools", "atmos_spectral/model", "atmos_shared", "atmos_spectral_shallow",
@@ -213,6 +215,12 @@ def build_target(name):
             if r.returncode != 0:
                 print("C helper failed (skipped):", c, r.stderr[-500:])
                 continue
+        cobjs.append(o)
+    for c in t.get("own_c", []):          # this repository's C helpers of the harness (oracle/*.c)
+        o = os.path.join(BLD, c[:-2] + "_own_c.o")
+        r = subprocess.run([CC, "-O2", "-c", os.path.join(HERE, c), "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            print("FAILED:", c, r.stderr[-2000:]); return 1
         cobjs.append(o)
     ho = os.path.join(BLD, os.path.basename(t["harness"])[:-4] + ".o")
     cmd = [FLANG] + FFLAGS + t["cppdefs"] + inc + ["-module-dir", BLD, "-c", harness, "-o", ho]

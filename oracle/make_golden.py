@@ -217,7 +217,7 @@ def moist_input_nml(res, num_levels=25, extra=""):
 """
 
 
-def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run", num_levels=25, extra=""):
+def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), mode="run", num_levels=25, extra="", harness_extra=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
     open(os.path.join(d, "input.nml"), "w").write(moist_input_nml(res, num_levels, (",\n    " + extra) if extra else ""))
@@ -225,7 +225,7 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), m
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     fmt = lambda t: ", ".join(str(s) for s in t) if t else "-1"
     open(os.path.join(d, "harness.nml"), "w").write(
-        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}\n /\n")
+        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}{harness_extra}\n /\n")
 
 
 def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra=""):
@@ -378,6 +378,46 @@ def golden_moist_run(res="T21", L=25, nsteps=144, dump_steps=(1, 2, 10, 144), dt
     m = re.search(r"REF_STATE Tmin,Tmax,maxabsU,qmax=\s*(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", stdout)
     out["final_Tmin_Tmax_maxabsU_qmax"] = np.array([float(x) for x in m.groups()])
     out.update({"meta_res": np.array(res), "meta_num_levels": np.array(L), "meta_dt_atmos": np.array(float(dt)), "meta_nsteps": np.array(nsteps)})
+    return out
+
+
+def golden_moist_developed(res="T42", L=25, day=30, dt=720, more=(1, 10), track=24):
+    """A DEVELOPED state of the reference's MOIST model (configs[3]'s physics at T42L25) and the steps after it: `day` days from the cold
+    start -- it rains, the convection scheme's deep / shallow branches are taken in most tropical columns --, then BOTH time levels
+    (ref_moist_harness.F90: track_from / dump_full_at, the Robert-filtered levels followed through the public API), the mixed layer's
+    t_surf (read through oracle/ref_peek.c) and `more` further steps.  Inputs: the full two-level state; outputs: strided samples + extremes."""
+    lon, lat, nf, ns = RES[res]
+    n0 = day * 86400 // dt
+    with tempfile.TemporaryDirectory(prefix="refmdev_") as d:
+        prepare_moist_rundir(d, res, n0 + max(more), dt=dt, dump_steps=[n0 + m for m in more], num_levels=L,
+                             harness_extra=f", track_from = {n0 - track}, dump_full_at = {n0}, robert_coeff = 0.03")
+        stdout = run_harness(d, exe=MOIST_EXE, timeout=6 * 3600)
+        out = {}
+        sh = shapes(res, L)
+        for fn in sorted(os.listdir(d)):
+            if not fn.endswith(".bin") or not (fn.startswith("rs_") or fn.startswith("st_")):
+                continue
+            name, raw = fn[:-4], np.fromfile(os.path.join(d, fn))
+            if name.startswith("rs_"):
+                if re.match(r"rs_(vors|divs|ts)_", name):
+                    out[name] = raw.view(np.complex128).reshape(sh["spec"])
+                elif name.startswith("rs_lnps"):
+                    out[name] = raw.view(np.complex128).reshape(sh["spec2"])
+                else:
+                    out[name] = raw.reshape(sh["grid"] if raw.size == np.prod(sh["grid"]) else sh["grid2"])
+            elif re.match(r"st_(ug|vg|tg|psg|q)_", name) and int(name[-6:]) > n0:
+                a3 = raw.reshape(sh["grid"] if raw.size == np.prod(sh["grid"]) else sh["grid2"])
+                key = "after%d_%s" % (int(name[-6:]) - n0, name[3:-7])
+                out[key + ("_s222" if a3.ndim == 3 else "")] = np.ascontiguousarray(a3[::2, ::2, ::2] if a3.ndim == 3 else a3)
+                out[key + "_minmax"] = np.array([a3.min(), a3.max()])
+            elif fn.startswith("tab_"):
+                pass
+        for fn in ("tab_pk.bin", "tab_bk.bin"):
+            out[fn[:-4]] = np.fromfile(os.path.join(d, fn))
+    m = re.search(r"REF_DEVELOPED max\|u\|,max\|v\|,Tmin,Tmax,qmax=\s*(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)", stdout)
+    out["developed_maxu_maxv_Tmin_Tmax_qmax"] = np.array([float(x) for x in m.groups()])
+    out.update({"meta_res": np.array(res), "meta_num_levels": np.array(L), "meta_dt_atmos": np.array(float(dt)), "meta_step0": np.array(n0),
+                "meta_more": np.array(more)})
     return out
 
 
@@ -762,6 +802,14 @@ def main():
         path = os.path.join(GOLD, "run_T170L60.npz")
         np.savez_compressed(path, **out)
         print(f"run_T170L60: {os.path.getsize(path)/1e6:.2f} MB")
+    if a.only and a.only.startswith("moist_developed_"):
+        # the moist model's developed-state fixture (~20 min of reference time at T42L25; `--only moist_developed_T21L25_d2` is a 1-minute dry run of the recipe)
+        m = re.match(r"moist_developed_(T\d+)L(\d+)(?:_d(\d+))?$", a.only)
+        out = golden_moist_developed(m.group(1), int(m.group(2)), day=int(m.group(3) or 30))
+        path = os.path.join(GOLD if not m.group(3) else "/tmp", a.only + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{a.only}: {os.path.getsize(path)/1e6:.2f} MB,", out["developed_maxu_maxv_Tmin_Tmax_qmax"])
+        return
     if a.only == "developed_T42L25":
         # the developed-state restart fixture (~25 min of reference time; 20 MB: the full two-level state is the INPUT)
         out = golden_developed()

@@ -44,8 +44,8 @@ void mh_gray_rad(int L, int ncol, double atm_abs, const double *lat, const doubl
   std::vector<double> lwd(L + 1), ltr(L), swd(L + 1);
   for (int c = 0; c < ncol; ++c) {
     double ins, tau0;
-    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), swd.data(), 1, ins, tau0, net_sw[c], lw_down_surf[c]);
-    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), swd.data(), 1, tdt + c, ncol);
+    gray_rad_down(p, L, lat[c], albedo[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, swd.data(), 1, ins, tau0, net_sw[c], lw_down_surf[c]);
+    gray_rad_up(p, L, albedo[c], t_surf[c], t + c, p_half + c, ncol, lwd.data(), ltr.data(), 1, swd.data(), 1, tdt + c, ncol);
   }
 }
 // out: 21 doubles per column in the order of struct SurfFlux
@@ -103,6 +103,44 @@ void mh_vert_diff(int L, int ncol, double delt, double dt_atmos, const double *u
     const double b[7] = {S.dtmass, S.dflux_t, S.delta_t, S.dflux_q, S.delta_q, S.delta_u, S.delta_v};
     for (int i = 0; i < 7; ++i) surf_ml[c * 7 + i] = b[i];
     vert_diff_up(L, delt, w, S, dt_t + c, dt_q + c, ncol);
+  }
+}
+// The implicit diffusion with its sweeps limited to the boundary layer (down_pair / vert_diff_*_up with kb = pbl_depth_f's kstop, the levels above through
+// vert_diff_passthrough): what the device kernel runs.  Same arguments as mh_vert_diff plus the start level per column.
+void mh_pbl_kstop(int L, int ncol, double dt, const double *tm, const double *um, const double *vm, const double *tdt, const double *udt,
+                  const double *vdt, const double *z_full, const double *z_half, int *kstop) {
+  DiffusivityParams dp;
+  for (int c = 0; c < ncol; ++c)
+    pbl_depth_f(dp, L, dt, tm + c, um + c, vm + c, ncol, [&](int k) { return tdt[k * ncol + c]; }, [&](int k) { return udt[k * ncol + c]; },
+                [&](int k) { return vdt[k * ncol + c]; }, z_full + c, z_half + c, ncol, kstop + c);
+}
+void mh_vert_diff_kb(int L, int ncol, double delt, double dt_atmos, const double *u, const double *v, const double *t, const double *q,
+                     const double *diff_m, const double *diff_t, const double *p_half, const double *z_full, const double *flux_u,
+                     const double *flux_v, const double *dtau_du, const double *dtau_dv, double *dt_u, double *dt_v, double *dt_t, double *dt_q,
+                     double *diss_heat, double *t_surf, const double *flux_t, const double *flux_q, const double *flux_r, const double *net_sw,
+                     const double *lw_down, const double *dhdt_surf, const double *dedt_surf, const double *drdt_surf, const double *dhdt_atm,
+                     const double *dedq_atm, const int *kbs) {
+  MixedLayerParams ml;
+  std::vector<double> we(L), wf1(L), wf2(L);
+  for (int c = 0; c < ncol; ++c) {
+    const int kb = std::min(kbs[c], L - 2);
+    VdiffWork w{we.data(), wf1.data(), wf2.data(), 1, 1};
+    VdiffSurf S;
+    double tu = flux_u[c], tv = flux_v[c];
+    auto du_in = [&](int k) { return dt_u[k * ncol + c]; };
+    auto dv_in = [&](int k) { return dt_v[k * ncol + c]; };
+    auto dt_in = [&](int k) { return dt_t[k * ncol + c]; };
+    auto dq_in = [&](int k) { return dt_q[k * ncol + c]; };
+    vert_diff_passthrough(0, kb, du_in, dv_in, dt_in, dq_in, dt_u + c, dt_v + c, dt_t + c, dt_q + c, ncol);
+    const vd::DownResult r = vd::down_pair(L, delt, [&](int k) { return u[k * ncol + c]; }, [&](int k) { return v[k * ncol + c]; }, du_in, dv_in,
+                                           vd::TableDiff{diff_m + c, ncol}, t + c, ncol, p_half + c, z_full + c, ncol, w,
+                                           DtPark<decltype(dt_in)>{dt_in, dt_t + c, ncol}, kb);
+    vert_diff_momentum_up_f(r, L, delt, u + c, v + c, ncol, tu, tv, dtau_du[c], dtau_dv[c], du_in, dv_in, dt_u + c, dt_v + c, dt_t + c, ncol,
+                            diss_heat + c, ncol, w, S, kb);
+    vert_diff_heat_down(L, delt, t + c, q + c, ncol, vd::TableDiff{diff_t + c, ncol}, p_half + c, z_full + c, ncol, dt_t + c, dt_q + c, ncol, w, S, kb);
+    mixed_layer(ml, dt_atmos, t_surf[c], flux_t[c], flux_q[c], flux_r[c], net_sw[c], lw_down[c], S, dhdt_surf[c], dedt_surf[c], drdt_surf[c],
+                dhdt_atm[c], dedq_atm[c]);
+    vert_diff_up(L, delt, w, S, dt_t + c, dt_q + c, ncol, kb);
   }
 }
 }

@@ -15,7 +15,14 @@
 !                   (st_*), and for the steps in phys_steps the inputs and outputs of that step's idealized_moist_phys call:
 !                   ph_in_* = u, v, T, q at `previous` and `current`, p_half/p_full/z_half/z_full at both levels,
 !                   ph_dt_* = the physics tendencies dt_ug, dt_vg, dt_tg, dt_tracers it returned.
+!                   track_from / dump_full_at (round 5, as in ref_harness.F90): from step track_from on the driver follows the Robert filter
+!                   itself through public routines -- s(k) = the spectral state of step k's grid fields, F(k) = (s(k) + r (F(k-1) - 2 s(k))) +
+!                   r s(k+1) (leapfrog.F90:58-105), likewise the tracer's filtered level -- and at step dump_full_at writes BOTH time levels
+!                   (rs_*) plus the mixed layer's surface temperature.  t_surf is module-private data of idealized_moist_phys_mod with no
+!                   getter; it is READ (never written) through the object file's symbol by oracle/ref_peek.c.
 program ref_moist_harness
+
+use iso_c_binding,         only: c_ptr, c_f_pointer
 
 use constants_mod,         only: constants_init, pi
 use fms_mod,               only: fms_init
@@ -26,7 +33,8 @@ use diag_manager_mod,      only: diag_manager_init
 use tracer_type_mod,       only: tracer_type
 use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics, get_num_levels, &
                                  get_initial_fields, get_surf_geopotential, get_pk_bk, get_axis_id
-use transforms_mod,        only: get_grid_domain, get_spec_domain, get_deg_lon, get_deg_lat, get_grid_boundaries
+use transforms_mod,        only: get_grid_domain, get_spec_domain, get_deg_lon, get_deg_lat, get_grid_boundaries, &
+                                 vor_div_from_uv_grid, trans_grid_to_spherical
 use press_and_geopot_mod,  only: compute_pressures_and_heights
 use idealized_moist_phys_mod, only: idealized_moist_phys_init, idealized_moist_phys
 use sat_vapor_pres_mod,    only: lookup_es, lookup_des
@@ -44,7 +52,19 @@ implicit none
 character(len=16) :: mode = 'run'
 integer :: nsteps = 1, dt_atmos = 720
 integer, dimension(64) :: dump_steps = -1, phys_steps = -1
-namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, phys_steps
+integer :: track_from = -1, dump_full_at = -1
+real    :: robert_coeff = 0.03            ! spectral_dynamics_nml's value in the run's input.nml (the module keeps it private)
+namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, phys_steps, track_from, dump_full_at, robert_coeff
+
+interface
+  function ref_peek_t_surf() bind(C, name='ref_peek_t_surf') result(p)
+    import :: c_ptr
+    type(c_ptr) :: p
+  end function ref_peek_t_surf
+end interface
+complex, allocatable, dimension(:,:,:) :: sc_vor, sc_div, sc_t, sn_vor, sn_div, sn_t, f_vor, f_div, f_t
+complex, allocatable, dimension(:,:)   :: sc_lp, sn_lp, f_lp
+real,    allocatable, dimension(:,:,:,:) :: f_tr
 
 type(time_type) :: Time, Time_step, Time_next
 type(tracer_type), allocatable, dimension(:) :: tracer_attributes
@@ -136,6 +156,8 @@ if(trim(mode) == 'run') then
     call one_step(any(phys_steps == istep))
     call system_clock(c1)
     t_loop = t_loop + real(c1-c0,8)/real(crate,8)
+    if(track_from >= 0 .and. istep >= track_from) call track_filter(istep == track_from)
+    if(istep == dump_full_at) call dump_both_levels()
     if(any(dump_steps == istep)) call dump_state(istep)
   enddo
   write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
@@ -332,6 +354,69 @@ Time = Time_next
 end subroutine one_step
 
 !--------------------------------------------------------------------------------------------------
+subroutine spec_of_current(vs, ds, tts, lps)
+complex, intent(out) :: vs(ms:,ns:,:), ds(ms:,ns:,:), tts(ms:,ns:,:), lps(ms:,ns:)
+real, allocatable :: lnpsg(:,:)
+allocate(lnpsg(is:ie,js:je))
+call vor_div_from_uv_grid(ug(:,:,:,current), vg(:,:,:,current), vs, ds)
+call trans_grid_to_spherical(tg(:,:,:,current), tts)
+lnpsg = log(psg(:,:,current))
+call trans_grid_to_spherical(lnpsg, lps)
+deallocate(lnpsg)
+end subroutine spec_of_current
+
+subroutine track_filter(first)
+logical, intent(in) :: first
+integer :: ntr
+real :: rq
+if(first) then
+  allocate(sc_vor(ms:me,ns:ne,num_levels), sc_div(ms:me,ns:ne,num_levels), sc_t(ms:me,ns:ne,num_levels), sc_lp(ms:me,ns:ne))
+  allocate(sn_vor(ms:me,ns:ne,num_levels), sn_div(ms:me,ns:ne,num_levels), sn_t(ms:me,ns:ne,num_levels), sn_lp(ms:me,ns:ne))
+  allocate(f_vor(ms:me,ns:ne,num_levels), f_div(ms:me,ns:ne,num_levels), f_t(ms:me,ns:ne,num_levels), f_lp(ms:me,ns:ne))
+  allocate(f_tr(is:ie,js:je,num_levels,num_tracers))
+  call spec_of_current(sc_vor, sc_div, sc_t, sc_lp)
+  f_vor = sc_vor; f_div = sc_div; f_t = sc_t; f_lp = sc_lp
+  f_tr = grid_tracers(:,:,:,current,:)
+  return
+endif
+! the step just taken made s(k+1) (= current now); sc_* is s(k) (= previous now), f_* the filtered level k-1
+call spec_of_current(sn_vor, sn_div, sn_t, sn_lp)
+f_vor = sc_vor + robert_coeff*(f_vor - 2.0*sc_vor); f_vor = f_vor + robert_coeff*sn_vor
+f_div = sc_div + robert_coeff*(f_div - 2.0*sc_div); f_div = f_div + robert_coeff*sn_div
+f_t   = sc_t   + robert_coeff*(f_t   - 2.0*sc_t  ); f_t   = f_t   + robert_coeff*sn_t
+f_lp  = sc_lp  + robert_coeff*(f_lp  - 2.0*sc_lp ); f_lp  = f_lp  + robert_coeff*sn_lp
+do ntr = 1, num_tracers
+  rq = tracer_attributes(ntr)%robert_coeff
+  f_tr(:,:,:,ntr) = grid_tracers(:,:,:,previous,ntr) + rq*(f_tr(:,:,:,ntr) - 2.0*grid_tracers(:,:,:,previous,ntr))
+  f_tr(:,:,:,ntr) = f_tr(:,:,:,ntr) + rq*grid_tracers(:,:,:,current,ntr)
+enddo
+sc_vor = sn_vor; sc_div = sn_div; sc_t = sn_t; sc_lp = sn_lp
+end subroutine track_filter
+
+subroutine dump_both_levels()
+! what a restart of spectral_dynamics_mod + atmosphere_mod + mixed_layer_mod holds (spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375,
+! mixed_layer.F90:735-745)
+real, pointer :: ts_ref(:,:)
+call dumpc3('rs_vors_cur.bin', sc_vor);  call dumpc3('rs_divs_cur.bin', sc_div)
+call dumpc3('rs_ts_cur.bin', sc_t);      call dumpc2('rs_lnps_cur.bin', sc_lp)
+call dumpc3('rs_vors_prev.bin', f_vor);  call dumpc3('rs_divs_prev.bin', f_div)
+call dumpc3('rs_ts_prev.bin', f_t);      call dumpc2('rs_lnps_prev.bin', f_lp)
+call dump3('rs_ug_cur.bin', ug(:,:,:,current));   call dump3('rs_ug_prev.bin', ug(:,:,:,previous))
+call dump3('rs_vg_cur.bin', vg(:,:,:,current));   call dump3('rs_vg_prev.bin', vg(:,:,:,previous))
+call dump3('rs_tg_cur.bin', tg(:,:,:,current));   call dump3('rs_tg_prev.bin', tg(:,:,:,previous))
+call dump2('rs_psg_cur.bin', psg(:,:,current));   call dump2('rs_psg_prev.bin', psg(:,:,previous))
+call dump3('rs_wg_full.bin', wg_full)
+call dump3('rs_tr1_cur.bin', grid_tracers(:,:,:,current,nhum))          ! the dynamics' and atmosphere_mod's newest level
+call dump3('rs_tr1_prev_atm.bin', grid_tracers(:,:,:,previous,nhum))    ! atmosphere_mod's (unfiltered) previous level
+call dump3('rs_tr1_prev_filt.bin', f_tr(:,:,:,nhum))                    ! the dynamics' Robert-filtered previous level
+call c_f_pointer(ref_peek_t_surf(), ts_ref, (/nlon, nlat/))
+call dump2('rs_t_surf.bin', ts_ref)
+write(*,'(a,5es16.8)') 'REF_DEVELOPED max|u|,max|v|,Tmin,Tmax,qmax=', maxval(abs(ug(:,:,:,current))), maxval(abs(vg(:,:,:,current))), &
+     minval(tg(:,:,:,current)), maxval(tg(:,:,:,current)), maxval(grid_tracers(:,:,:,current,nhum))
+write(*,'(a,2es16.8)') 'REF_DEVELOPED t_surf min,max=', minval(ts_ref), maxval(ts_ref)
+end subroutine dump_both_levels
+
+!--------------------------------------------------------------------------------------------------
 subroutine dump_state(n)
 integer, intent(in) :: n
 character(len=8) :: tag
@@ -367,5 +452,21 @@ open(newunit=u, file=name, access='stream', form='unformatted', status='replace'
 write(u) a
 close(u)
 end subroutine dump3
+subroutine dumpc2(name, a)
+character(len=*), intent(in) :: name
+complex, intent(in) :: a(:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dumpc2
+subroutine dumpc3(name, a)
+character(len=*), intent(in) :: name
+complex, intent(in) :: a(:,:,:)
+integer :: u
+open(newunit=u, file=name, access='stream', form='unformatted', status='replace')
+write(u) a
+close(u)
+end subroutine dumpc3
 
 end program ref_moist_harness

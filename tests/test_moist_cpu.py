@@ -143,3 +143,45 @@ def test_damping_turbulence_diffusion_mixed_layer(lib, g):
     assert rel(surf_ml[:, 2], g["k_ml_delta_t"]) <= TOL and rel(surf_ml[:, 4], g["k_ml_delta_q"]) <= TOL
     for a, nm in ((du, "u"), (dv, "v"), (dt_t, "t"), (dt_q, "q")):
         assert rel(a, g["k_fin_dt_" + nm]) <= TOL, nm
+
+
+def test_diffusion_limited_to_the_boundary_layer(lib, g):
+    """The device kernel runs the four sweeps of the implicit diffusion over the boundary layer only (from pbl_depth_f's kstop down; the levels above
+    take their tendencies in a streaming pass): same results as the sweeps over the whole column, which the test above holds to the reference --
+    every value equal (a zero may carry the other sign), on the 182 fixture columns, whose boundary layers are 1 to 9 levels deep."""
+    import ctypes as C
+    L, nc = g["k_in_t_prev"].shape
+    delt, du, dv, dt_t, dt_q = _tendencies_before_damping(g)
+    u, v, tm, q = g["k_in_u_prev"], g["k_in_v_prev"], g["k_in_t_prev"], g["k_in_q_prev"]
+    pf, ph, zf, zh = g["k_in_p_full_cur"], g["k_in_p_half_cur"], g["k_in_z_full_cur"], g["k_in_z_half_cur"]
+    lib.mh_rayleigh(L, nc, _nlev_rayfric(g, L), D((1. / 0.25) * (1. / 86400.)), D(5000.), D(delt), P(pf), P(u), P(v), P(du), P(dv), P(dt_t))
+    h, km, kt = np.zeros(nc), np.zeros((L, nc)), np.zeros((L, nc))
+    lib.mh_diffusivity(L, nc, D(delt), P(tm), P(u), P(v), P(dt_t), P(du), P(dv), P(zf), P(zh), P(g["k_sf_ustar"]), P(g["k_sf_bstar"]), P(h), P(km),
+                       P(kt))
+    kstop = np.zeros(nc, dtype=np.int32)
+    lib.mh_pbl_kstop(L, nc, D(delt), P(tm), P(u), P(v), P(dt_t), P(du), P(dv), P(zf), P(zh), kstop.ctypes.data_as(C.POINTER(C.c_int)))
+    # no diffusivity on any interface at or above kstop (k_m[k], k_t[k] sit on the interface above level k)
+    for c in range(nc):
+        assert not km[:kstop[c] + 1, c].any() and not kt[:kstop[c] + 1, c].any(), c
+    assert kstop.min() >= L - 12 and kstop.max() <= L - 1 and len(set(kstop.tolist())) > 3, sorted(set(kstop.tolist()))
+    sf = lambda n: g["k_sf_" + n]
+    out = {}
+    for mode in ("whole", "limited", "wave"):
+        a = [x.copy() for x in (du, dv, dt_t, dt_q)]
+        diss, surf, surf_ml, dtd = np.zeros((L, nc)), np.zeros((nc, 7)), np.zeros((nc, 7)), np.zeros((L, nc))
+        ts = g["k_in_t_surf"].copy()
+        if mode == "whole":
+            lib.mh_vert_diff(L, nc, D(delt), D(delt / 2), P(u), P(v), P(tm), P(q), P(km), P(kt), P(ph), P(pf), P(zf), P(sf("flux_u")), P(sf("flux_v")),
+                             P(sf("dtaudu_atm")), P(sf("dtaudv_atm")), P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(diss), P(surf), P(ts), P(sf("flux_t")),
+                             P(sf("flux_q")), P(sf("flux_r")), P(g["k_rad_net_sw_down"]), P(g["k_rad_lw_down"]), P(sf("dhdt_surf")), P(sf("dedt_surf")),
+                             P(sf("drdt_surf")), P(sf("dhdt_atm")), P(sf("dedq_atm")), P(surf_ml), P(dtd))
+        else:       # "wave": the smallest kstop of a group of 64 columns, as a wavefront takes it
+            kb = kstop.copy() if mode == "limited" else np.repeat([kstop[i:i + 64].min() for i in range(0, nc, 64)], 64)[:nc].astype(np.int32)
+            lib.mh_vert_diff_kb(L, nc, D(delt), D(delt / 2), P(u), P(v), P(tm), P(q), P(km), P(kt), P(ph), P(zf), P(sf("flux_u")), P(sf("flux_v")),
+                                P(sf("dtaudu_atm")), P(sf("dtaudv_atm")), P(a[0]), P(a[1]), P(a[2]), P(a[3]), P(diss), P(ts), P(sf("flux_t")),
+                                P(sf("flux_q")), P(sf("flux_r")), P(g["k_rad_net_sw_down"]), P(g["k_rad_lw_down"]), P(sf("dhdt_surf")),
+                                P(sf("dedt_surf")), P(sf("drdt_surf")), P(sf("dhdt_atm")), P(sf("dedq_atm")), np.ascontiguousarray(kb).ctypes.data_as(C.POINTER(C.c_int)))
+        out[mode] = a + [diss, ts]
+    for mode in ("limited", "wave"):
+        for x, y, nm in zip(out["whole"], out[mode], ("dt_u", "dt_v", "dt_t", "dt_q", "diss_heat", "t_surf")):
+            assert np.array_equal(x, y), (mode, nm, float(np.abs(x - y).max()))

@@ -1,11 +1,12 @@
 """Phase times of k_moist_physics from the MOIST_TIMING builds (tools/build_variant.sh mtP "-DMOIST_TIMING=P" moist, P = 1, 2, 3): lane i of
 every wavefront stores the wall_clock64 ticks (10 ns) between marks i and i+1 of phase P in the precipitation field (moist.hip, MT macros)."""
 import os, sys, subprocess
-sys.path.insert(0, '/root/repo')
-MARKS = {1: ["qe_moist_convection", "lscale_cond"],
-         2: ["gray_rad_down", "surface_flux", "zero + gray_rad_up", "rayleigh sponge"],
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+REPO = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+MARKS = {1: ["convection + condensation of the next step (wavefront A)"],
+         2: ["height sum", "gray_rad_down", "gray_rad_up", "surface_flux", "rayleigh sponge"],
          5: ["init pass (Tv, parcel)", "below the LCL", "ascent above the LCL", "reference profiles + Pq, Pt", "deep / shallow adjustment", "(end)"],
-         3: ["dt_tg sum", "pbl_depth", "pbl profile + momentum down", "momentum up", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
+         3: ["(lambdas)", "pbl_depth + start level", "passthrough", "pbl profile + momentum down", "momentum up", "vert_diff_heat_down", "mixed_layer", "vert_diff_up"]}
 if len(sys.argv) > 1:
     import numpy as np
     from isca_amd import dyncore
@@ -22,5 +23,5 @@ else:
     only = os.environ.get('MOIST_PHASES')
     for v in (1, 2, 3, 5):
         if only and str(v) not in only.split(','): continue
-        env = dict(os.environ, ISCA_DYN_LIB=f"/root/repo/isca_amd/lib/libisca_dyn_mt{v}.so")
+        env = dict(os.environ, ISCA_DYN_LIB=os.path.join(REPO, "isca_amd", "lib", f"libisca_dyn_mt{v}.so"))
         subprocess.run([sys.executable, __file__, str(v)], env=env)
