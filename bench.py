@@ -124,14 +124,27 @@ def kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=None):
             tf = nlf * leg_flops_lf / (kt[nm] * 1e-3) / 1e12
             kern[nm] = {"bound": "mfma", "ms": kt[nm], "achieved_TFs": tf, "frac": tf / FP64_MFMA_PEAK_TF,
                         "achieved_GBs": alg[nm] / (kt[nm] * 1e-3) / 1e9}
-    if "moist_physics" in kt:                                        # 4 fields + 2 x 2 pressures + 2 heights in, 4 tendencies out
-        g = 14.0 * field_bytes / (kt["moist_physics"] * 1e-3) / 1e9
-        kern["moist_physics"] = {"bound": "hbm (a dependent chain per column whose level arrays do not fit the L2s: every re-read is HBM latency; DESIGN.md 11)",
-                                 "ms": kt["moist_physics"], "achieved_GBs": g, "frac": g / HBM_PEAK_GBS}
+    if "moist_physics" in kt:
+        # in: u, v, T, q of the previous level, T, q of the current one (the next step's convection), p_full, p_half, the two height increments, the
+        # (conv + cond) rates of this step (12); out: the two heights, 4 tendencies, the next step's (conv + cond) rates (8)
+        g = 20.0 * field_bytes / (kt["moist_physics"] * 1e-3) / 1e9
+        kern["moist_physics"] = {"bound": "hbm (two dependent chains per 64 columns -- this step's radiation / diffusion and the next step's convection --, one wavefront per SIMD: latency, DESIGN.md 9)",
+                                 "ms": kt["moist_physics"], "achieved_GBs": g, "frac": g / HBM_PEAK_GBS, "algorithmic_field_passes": 20}
     return kern
 
 
-def dominant_roofline(kt, kern, traffic, traffic_source):
+def load_rocprof_us(workload):
+    """rocprofv3 --kernel-trace --stats averages (us per launch) of this same command from the newest committed profile; measured earlier, NOT in this run"""
+    import csv
+    for tag in ("r05", "r04", "r03", "r02"):
+        rel = os.path.join("profiles", f"{tag}_{workload}_kernel_stats.csv")
+        if os.path.exists(os.path.join(REPO, rel)):
+            with open(os.path.join(REPO, rel)) as f:
+                return {r["kernel"].strip('"'): float(r["avg_us"]) for r in csv.DictReader(f)}, rel
+    return {}, None
+
+
+def dominant_roofline(kt, kern, traffic, traffic_source, workload=None):
     """The roofline of the LONGEST kernel of the step, whichever stream it runs on (the tracer kernels of the side stream included)."""
     cand = {k: v for k, v in kt.items() if k in kern}
     dom = max(cand, key=cand.get) if cand else None
@@ -142,8 +155,15 @@ def dominant_roofline(kt, kern, traffic, traffic_source):
     mfma = c["bound"] == "mfma"
     ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)
     tr = traffic.get(name, traffic.get(name.rstrip("3")))                                           # k_fft_*3: lon_max >= 256; generic kernels below
-    return {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
-            "frac": ach / peak, "traffic": tr, "traffic_source": traffic_source if tr is not None else None, "avg_launch_ms": c["ms"]}
+    out = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
+           "frac": ach / peak, "traffic": tr, "traffic_source": traffic_source if tr is not None else None, "avg_launch_ms": c["ms"],
+           "clock": "HIP events recorded on the kernel's stream inside this run (isca_dyn_kernel_times): ~4 us per launch above the kernel's own duration"}
+    if workload:      # the same kernel's duration in the committed rocprofv3 trace of this command, and the fraction it gives
+        rp, src = load_rocprof_us(workload)
+        us = rp.get(name.split(":")[0])
+        if us:
+            out.update({"rocprof_avg_launch_ms": us * 1e-3, "rocprof_frac": (ach * c["ms"] / (us * 1e-3)) / peak, "rocprof_source": src})
+    return out
 
 
 def step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=None):
@@ -231,6 +251,63 @@ def load_traffic(workload):
     return {}, None
 
 
+EXCHANGE_TIMERS = ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce", "all_to_all_raw")
+SIDE_STREAM_TIMERS = ("tracer_horiz", "tracer_vert")
+
+
+def shard_probe(a):
+    """ONE RANK of a P-rank job whose ranks share one GPU and take turns on it (the library's sharded C++ step loop over ISCA_COMM=ipc with
+    ISCA_IPC_SERIALIZE=1: csrc/comm_ipc.cpp): every kernel of the rank runs alone on the device, as it would on a GPU of its own, so the HIP-event
+    durations are the compute times of a 1/P shard.  No torch: the communicator's id travels through ISCA_COMM_ID_FILE."""
+    from isca_amd import dyncore
+    res, L, dt = WORKLOADS[a.workload]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    core = dyncore.DynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, rank=rank, world_size=world, device=0))
+    core.comm_init_env()
+    core.cold_start(); core.step(a.warmup, sync=True)
+    core.kernel_times(True); core.step(a.steps, sync=True); kt = core.kernel_times(False)
+    print("SHARD_PROBE " + json.dumps({"rank": rank, "kernel_ms": kt}), flush=True)
+    core.close()
+
+
+def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240):
+    """The compute half of the scaling curve, measured on ONE GPU: for P = 2, 4, 8 the per-step kernel time of a 1/P latitude-band shard of
+    `workload` (shard_probe above), exchanges excluded -- `main_stream_ms` (the step's critical path without its exchanges), `side_stream_ms`
+    (the tracer's transport, which runs under the first all-to-all and the spectral stage), the slowest rank's.  What it does NOT hold: the
+    exchanges themselves (no xGMI here) and the kernels' gaps.  A failure is reported, not raised."""
+    import subprocess, tempfile, uuid
+    out = {"how": "P processes share this GPU and take turns (ISCA_COMM=ipc, ISCA_IPC_SERIALIZE=1): HIP-event kernel durations of the slowest rank, "
+                  "exchanges excluded; unmeasured on xGMI"}
+    for P in ranks:
+        try:
+            with tempfile.TemporaryDirectory(prefix="shard_") as d:
+                env = dict(os.environ, ISCA_COMM="ipc", ISCA_IPC_SERIALIZE="1", ISCA_IPC_TIMEOUT_S=os.environ.get("ISCA_IPC_TIMEOUT_S", "60"), ISCA_COMM_ID_FILE=os.path.join(d, "id"), ISCA_COMM_NONCE=uuid.uuid4().hex,
+                           WORLD_SIZE=str(P), ISCA_IPC_DIR=d if os.environ.get("ISCA_BENCH_IPC_TMP") else os.environ.get("ISCA_IPC_DIR", ""))
+                procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--shard-probe", "--workload", workload, "--gpus", str(P),
+                                           "--steps", str(steps), "--warmup", str(warmup)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True) for r in range(P)]
+                per_rank = []
+                for pr in procs:
+                    try:
+                        o, e = pr.communicate(timeout=timeout)
+                    except subprocess.TimeoutExpired:
+                        for q in procs:
+                            q.kill()
+                        raise RuntimeError("timeout")
+                    m = [ln for ln in o.splitlines() if ln.startswith("SHARD_PROBE ")]
+                    if pr.returncode != 0 or not m:
+                        raise RuntimeError((e or o)[-200:])
+                    per_rank.append(json.loads(m[-1][len("SHARD_PROBE "):])["kernel_ms"])
+            main = [sum(v for k, v in kt.items() if k not in EXCHANGE_TIMERS and k not in SIDE_STREAM_TIMERS) for kt in per_rank]
+            side = [sum(v for k, v in kt.items() if k in SIDE_STREAM_TIMERS) for kt in per_rank]
+            slow = max(range(P), key=lambda r: main[r])
+            out[f"P={P}"] = {"main_stream_ms": round(main[slow], 5), "side_stream_ms": round(side[slow], 5),
+                             "kernel_ms": {k: round(v, 5) for k, v in per_rank[slow].items() if k not in EXCHANGE_TIMERS}}
+        except Exception as e:                                           # noqa: BLE001
+            out[f"P={P}"] = {"error": str(e)[:200]}
+    return out
+
+
 def other_workloads(device):
     """Informational, outside the timed region and never part of `value`: the other configurations of the same build on this GPU
     (BASELINE configs[3] moist physics at the benchmark resolution, configs[4] T170L60, the sibling cores), each with the roofline of its
@@ -249,7 +326,7 @@ def other_workloads(device):
             kern = kernel_rooflines(kt, core.I, core.J, core.M1, core.cfg.num_fourier, core.L, nlf_inv=core.info("inverse_batch"))
             traffic, src = load_traffic(name.split()[0] + ("_moist" if "Frierson" in name else ""))
             res[name] = {"ms_per_step": round(1e3 * sec, 4), "sim_years/day": round(sim_years_per_day(sec, kw["dt_atmos"]), 1),
-                         "roofline": dominant_roofline(kt, kern, traffic, src), "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
+                         "roofline": dominant_roofline(kt, kern, traffic, src, name.split()[0] + ("_moist" if "Frierson" in name else "")), "kernel_ms": {k: round(v, 5) for k, v in kt.items()},
                          "kernel_roofline": kern}
             core.close()
         except Exception as e:                                           # noqa: BLE001
@@ -274,7 +351,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="T85L40", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=24, help="bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--shard-probe", action="store_true", help="internal: one rank of shard_compute()'s P-rank job (RANK / WORLD_SIZE from the environment)")
     a = ap.parse_args()
+    if a.shard_probe:
+        return shard_probe(a)
     res, L, dt = WORKLOADS[a.workload]
 
     import torch
@@ -423,7 +503,7 @@ def main():
     traffic, traffic_source = load_traffic(a.workload)
     nlf_inv = core.info("inverse_batch")
     kern = kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=nlf_inv)
-    roof = dominant_roofline(kt, kern, traffic, traffic_source)
+    roof = dominant_roofline(kt, kern, traffic, traffic_source, a.workload)
     if roof is not None and roof["bound"] == "hbm":
         inv = {v: k for k, v in KERNEL_OF.items()}
         roof["algorithmic_bytes_per_launch"] = algorithmic_bytes(I, J, M1, N, L, nlf_inv=nlf_inv).get(inv.get(roof["kernel"]))
@@ -441,7 +521,11 @@ def main():
                                     else "sphum advected (van Leer + PPM) on the main stream (small grid)") if a.gpus == 1
                                    else "sphum advected (van Leer + PPM), 2-row halo exchange with the neighbour bands")},
         "roofline": roof, "kernel_ms": {k: round(v, 5) for k, v in kt.items()}, "kernel_roofline": kern,
-        "step_bytes": step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=nlf_inv),
+        "step_bytes": (sb := step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=nlf_inv)),
+        # the whole step against the HBM roofline: algorithmic bytes (every array touched once) over the measured step time
+        "step_roofline": {"bound": "hbm", "achieved": sb["algorithmic_bytes"] / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": sb["algorithmic_bytes"] / sec_per_step / 1e9 / HBM_PEAK_GBS,
+                          "note": "algorithmic_bytes / ms_per_step / peak; 6.3 TB/s is what a copy achieves on this part (MI355X_MICROARCH.md)"},
         "legendre_frac_of_fp64_mfma_peak": {k: round(kern[k]["frac"], 4) for k in ("legendre_fwd", "legendre_inv") if k in kern},
     }
     if steady_ms is not None:
@@ -467,6 +551,8 @@ def main():
     if a.gpus == 1 and a.workload == "T85L40" and not os.environ.get("ISCA_BENCH_NO_EXTRA"):
         core.close()                                   # (everything of the headline core has been read; the others start on an empty device)
         out["other_workloads"] = other_workloads(local_rank)
+        # per-rank compute of a 1/P shard, P = 2, 4, 8, measured on this one GPU (the exchanges over xGMI are what the 8-GPU run adds)
+        out["shard_compute_ms"] = {"T85L40": shard_compute("T85L40"), "T170L60": shard_compute("T170L60", ranks=(4, 8), steps=12, warmup=4)}
     print(json.dumps(out))
 
 

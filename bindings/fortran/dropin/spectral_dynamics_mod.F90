@@ -246,6 +246,8 @@ do ntr = 1, num_tracers
   endif
   select case(trim(tracer_attributes(ntr)%numerical_representation))
     case('spectral')
+      if(ntr == 1) call error_mesg('spectral_dynamics_init', "the first tracer of the field_table is carried as a 'grid' tracer by the device core: "// &
+                                   "numerical_representation 'spectral' is not a supported value for it", FATAL)
       tracer_attributes(ntr)%advect_horiz = 'spectral'; cfg%tracer_spectral(ntr) = 1
       if(lowercase(trim(tracer_attributes(ntr)%hole_filling)) == 'on') cfg%tracer_hole_filling(ntr) = 1      ! water_borrowing (spectral_dynamics.F90:1142)
       if(uppercase(trim(tracer_attributes(ntr)%advect_vert)) /= 'SECOND_CENTERED') cfg%tracer_advect_vert(ntr) = advect_scheme(tracer_attributes(ntr)%advect_vert, 'advect_vert')

@@ -209,6 +209,9 @@ static void check_config(const isca_dyn_config &c) {
     if (c.tracer_advect_vert[k] < -1 || c.tracer_advect_vert[k] > 3)
       fail("spectral_dynamics_init: tracer_advect_vert must be -1 (the representation's standard scheme) or 0..3 (second_centered, fourth_centered, "
            "van_leer_linear, finite_volume_parabolic): any other advect_vert is invalid");
+  if (c.num_tracers > 0 && c.tracer_spectral[0] != 0)
+    fail("spectral_dynamics_init: the first tracer of the field_table (the humidity the water fixer and the physics know) is a 'grid' tracer here: "
+         "numerical_representation 'spectral' is not a supported value for it");
   if (c.num_tracers > 1) {
     if (c.raw_filter_coeff != 1.0) fail("more than one tracer: raw_filter_coeff must be 1");
     for (int k = 1; k < c.num_tracers; ++k) {
@@ -333,13 +336,27 @@ static void sync_and_check_valid_range(isca_dyn *h) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
   const double *red = h->host_red;
   const double tmin = red[20], tmax = red[21];
-  if (tmin > tmax) return;                                   // no step since the last check
-  if (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17])) {
+  const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
+  const bool bad = stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17]));
+  // Sharded with the library's communicator: a rank judges its own band, but error_mesg(..., FATAL) stops EVERY PE (spectral_dynamics.F90:940-972)
+  // -- the verdict is summed over the ranks, so that all of them raise at this synchronisation point instead of the others going on into an
+  // exchange their peer never joins (every rank reaches this point after the same number of steps: the step loop is collective).
+  bool other = false;
+  if (h->comm && h->g.P > 1) {
+    h->host_red[40] = bad ? 1.0 : 0.0;
+    HIP_CHECK(hipMemcpyAsync(h->d.red + 24, h->host_red + 40, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->comm->all_reduce_sum(h->d.red + 24, 1, h->stream);
+    HIP_CHECK(hipMemcpyAsync(h->host_red + 41, h->d.red + 24, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    other = !bad && h->host_red[41] > 0.0;
+  }
+  if (bad) {
     char msg[160];
     snprintf(msg, sizeof(msg), "temperatures out of valid range (min %.3f, max %.3f, valid %.1f..%.1f)", tmin, tmax,
              h->cfg.valid_range_t[0], h->cfg.valid_range_t[1]);
     fail(msg);
   }
+  if (other) fail("temperatures out of valid range on another rank's latitude band");
 }
 
 extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
@@ -1332,12 +1349,18 @@ extern "C" int isca_dyn_comm_init_env(isca_dyn_t *h) {
   const char *path = getenv("ISCA_COMM_ID_FILE");
   if (!path || !*path) fail("comm_init_env: ISCA_COMM_ID_FILE (a path every rank can read) is not set");
   unsigned char id[128];
+  // A file left behind by a run that crashed before rank 0 removed it must not be taken for this launch's: the launcher's ISCA_COMM_NONCE (a job id;
+  // any string, the same on every rank) is written behind the id and the other ranks accept only a file that carries it.  Without the variable the
+  // file's age decides (below), which a relaunch within the minute can defeat: launchers should set the nonce or remove the file first.
+  char nonce[64] = {0};
+  if (const char *e = getenv("ISCA_COMM_NONCE")) snprintf(nonce, sizeof(nonce), "%s", e);
   if (h->cfg.rank == 0) {
     if (isca_comm_get_unique_id(id)) fail(g_last_error);
     remove(path);                              // (an earlier run's)
     const std::string tmp = std::string(path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0 || rename(tmp.c_str(), path) != 0) fail(std::string("comm_init_env: cannot write ") + path);
+    if (!f || fwrite(id, 1, 128, f) != 128 || fwrite(nonce, 1, sizeof(nonce), f) != sizeof(nonce) || fclose(f) != 0 || rename(tmp.c_str(), path) != 0)
+      fail(std::string("comm_init_env: cannot write ") + path);
   } else {
     const double limit = getenv("ISCA_IPC_TIMEOUT_S") ? atof(getenv("ISCA_IPC_TIMEOUT_S")) : 120.0;
     double waited = 0.0;
@@ -1345,7 +1368,12 @@ extern "C" int isca_dyn_comm_init_env(isca_dyn_t *h) {
     for (;;) {                                // only a file written after this process came up, give or take a minute between the ranks' starts, is accepted
       struct stat st;
       FILE *f = (stat(path, &st) == 0 && st.st_mtime + 60 >= born) ? fopen(path, "rb") : nullptr;
-      if (f) { const size_t n = fread(id, 1, 128, f); fclose(f); if (n == 128) break; }
+      if (f) {
+        char theirs[sizeof(nonce)] = {0};
+        const size_t n = fread(id, 1, 128, f), nn = fread(theirs, 1, sizeof(theirs), f);
+        fclose(f);
+        if (n == 128 && nn == sizeof(theirs) && memcmp(theirs, nonce, sizeof(nonce)) == 0) break;      // (another launch's nonce: keep waiting for ours)
+      }
       if (waited > limit) fail(std::string("comm_init_env: rank 0 did not leave the communicator id in ") + path);
       usleep(20000); waited += 0.02;
     }

@@ -8,6 +8,11 @@
 // implementation; replaces mpp_transmit / mpp_update_domains / mpp_sum of the reference (transforms.F90:970-1056,
 // fv_advection.F90:161-162, transforms.F90:1059-1077) for verification runs.  Every call synchronises its stream: not a fast path.
 //
+// ISCA_IPC_SERIALIZE=1 (measurement): the ranks' device work between two exchanges runs ONE RANK AT A TIME -- a rank returns from an exchange only
+// when the rank before it has finished its next segment (its next exchange's stream synchronise passes the turn on).  The kernels of a rank then
+// run alone on the shared GPU, as they would on a GPU of their own, and their HIP-event durations are a 1/P shard's compute times
+// (bench.py: shard_compute_ms).  The wall clock of such a run means nothing.
+//
 // Layout: a header file (barrier words, abort flag) drawn by the rank that makes the id, and one outbox file per rank:
 //   [ reduce area 4 KB | halo to rank-1 | halo to rank+1 | all-to-all blocks [world][count] ]
 // Files live in /dev/shm when it has room (they are sparse: only touched pages exist), else in /tmp; they are unlinked as soon as
@@ -40,6 +45,8 @@ struct Header {                         // zero-filled by ftruncate
   std::atomic<uint32_t> generation;
   std::atomic<uint32_t> aborted;        // 1 + rank of the first rank that gave up
   std::atomic<uint32_t> attached;
+  std::atomic<uint64_t> turn;           // ISCA_IPC_SERIALIZE: whose kernels may run (round * world + rank)
+  std::atomic<uint32_t> free_run;       // ... until a rank leaves (its communicator is destroyed): nobody passes the turn on after its last exchange
 };
 
 struct IpcId {                          // the 128 bytes the ranks share
@@ -73,6 +80,7 @@ class IpcComm final : public Comm {
  public:
   IpcComm(const IpcId &id, int rank, int world) : Comm(rank, world), id_(id) {
     timeout_s_ = env_num("ISCA_IPC_TIMEOUT_S", 120.0);
+    serialize_ = env_num("ISCA_IPC_SERIALIZE", 0.0) != 0.0;
     slot_bytes_ = kReduceBytes + 2 * id.halo_bytes + id.a2a_bytes;
     hdr_ = (Header *)map_file(id.path, kHeaderBytes, false);
     box_.assign(world, nullptr);
@@ -85,13 +93,17 @@ class IpcComm final : public Comm {
       barrier("map");                                       // every rank has every mapping: the names can go
       unlink(box_path(rank).c_str());
       if (rank == 0) unlink(id.path);
+      wait_turn("start");
     } catch (...) {
       abort();
       unmap_all();
       throw;
     }
   }
-  ~IpcComm() override { unmap_all(); }
+  ~IpcComm() override {
+    if (serialize_ && hdr_) hdr_->free_run.store(1, std::memory_order_release);
+    unmap_all();
+  }
   const char *kind() const override { return "ipc"; }
 
   void all_to_all(const double *send, double *recv, size_t count, hipStream_t s) override {
@@ -111,6 +123,7 @@ class IpcComm final : public Comm {
     if (hb && rank_ > 0) hip_ck(hipMemcpyAsync(mine + halo_off(0), send_lo, hb, hipMemcpyDeviceToHost, s), "copy out (halo)");
     if (hb && rank_ < world_ - 1) hip_ck(hipMemcpyAsync(mine + halo_off(1), send_hi, hb, hipMemcpyDeviceToHost, s), "copy out (halo)");
     hip_ck(hipStreamSynchronize(s), "synchronize");
+    pass_turn();
     barrier("exchange: data out");
     for (int q = 0; blk && q < world_; ++q)
       hip_ck(hipMemcpyAsync(recv + (size_t)q * count, box_[q] + a2a_off() + (size_t)rank_ * blk, blk, hipMemcpyHostToDevice, s), "copy in (all-to-all)");
@@ -120,11 +133,13 @@ class IpcComm final : public Comm {
       hip_ck(hipMemcpyAsync(recv_hi, box_[rank_ + 1] + halo_off(0), hb, hipMemcpyHostToDevice, s), "copy in (halo)");
     hip_ck(hipStreamSynchronize(s), "synchronize");
     barrier("exchange: data in");                           // the outboxes may be overwritten again
+    wait_turn("exchange: turn");
   }
   void all_reduce_sum(double *buf, size_t count, hipStream_t s) override {
     if (count * sizeof(double) > kReduceBytes) throw std::runtime_error("ipc comm: all-reduce larger than its area");
     hip_ck(hipMemcpyAsync(box_[rank_], buf, count * sizeof(double), hipMemcpyDeviceToHost, s), "copy out (all-reduce)");
     hip_ck(hipStreamSynchronize(s), "synchronize");
+    pass_turn();
     barrier("all-reduce: data out");
     double tot[kReduceBytes / sizeof(double)];
     for (size_t i = 0; i < count; ++i) tot[i] = 0.0;
@@ -135,6 +150,7 @@ class IpcComm final : public Comm {
     hip_ck(hipMemcpyAsync(buf, tot, count * sizeof(double), hipMemcpyHostToDevice, s), "copy in (all-reduce)");
     hip_ck(hipStreamSynchronize(s), "synchronize");
     barrier("all-reduce: data in");
+    wait_turn("all-reduce: turn");
   }
   void abort() noexcept override {
     if (hdr_) { uint32_t none = 0; hdr_->aborted.compare_exchange_strong(none, (uint32_t)rank_ + 1); }
@@ -147,6 +163,29 @@ class IpcComm final : public Comm {
   void unmap_all() {
     for (auto &b : box_) if (b) { munmap(b, slot_bytes_); b = nullptr; }
     if (hdr_) { munmap(hdr_, kHeaderBytes); hdr_ = nullptr; }
+  }
+  // ISCA_IPC_SERIALIZE: my segment of device work is over (the stream has just been synchronised): the next rank may run its own
+  void pass_turn() {
+    if (!serialize_) return;
+    (void)hipDeviceSynchronize();          // (the side stream's kernels too: nothing of mine runs into the next rank's turn)
+    hdr_->turn.store(round_ * (uint64_t)world_ + (uint64_t)rank_ + 1, std::memory_order_release);
+    ++round_;
+  }
+  // ... and I go on (return to the caller, who queues the next segment) when the rank before me has passed it on
+  void wait_turn(const char *where) {
+    if (!serialize_) return;
+    const uint64_t mine = round_ * (uint64_t)world_ + (uint64_t)rank_;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0; hdr_->turn.load(std::memory_order_acquire) != mine && !hdr_->free_run.load(std::memory_order_acquire); ++spin) {
+      const uint32_t ab = hdr_->aborted.load(std::memory_order_acquire);
+      if (ab) throw std::runtime_error(std::string("ipc comm: rank ") + std::to_string(ab - 1) + " stopped with an error (" + where + ")");
+      if (spin < 200) std::this_thread::yield();
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s_) {
+        abort();
+        throw std::runtime_error(std::string("ipc comm: timed out waiting for the turn (") + where + ")");
+      }
+    }
   }
   // every rank arrives, the last one opens the next generation; a rank that gave up (abort) or never comes (timeout) is an error
   void barrier(const char *where) {
@@ -174,6 +213,8 @@ class IpcComm final : public Comm {
   std::vector<char *> box_;
   size_t slot_bytes_ = 0;
   double timeout_s_ = 120.0;
+  bool serialize_ = false;
+  uint64_t round_ = 0;
 };
 
 }  // namespace

@@ -2747,17 +2747,21 @@ void launch_vert_advection_centered(const isca_dyn &h, const double *w, const do
 // independent and the sweep fixes nothing but the order of the additions: here every cell GATHERS -- its own hole and the holes among its four
 // neighbours, each evaluated from the hole's own five-point stencil.  dp = dpk + dbk p_s of the current level (update_tracers' p_half).
 __device__ __forceinline__ double wb_ratio_m1(const Geom &g, const double *__restrict__ q, const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                              const double *__restrict__ psrow, size_t row, size_t lev, int i, int k) {
-  // (ratio - 1) of the hole at (i, k) of latitude row `row` (offset of its first longitude in a level), or 0 when it is no hole / cannot be filled
+                                              const double *__restrict__ psrow, size_t row, size_t lev, int i, int k, bool *fillable = nullptr) {
+  // (ratio - 1) of the hole at (i, k) of latitude row `row` (offset of its first longitude in a level), or 0 when it is no hole / cannot be filled;
+  // fillable: whether it is a hole that IS filled (negative value, total water of the stencil positive: water_borrowing.F90) -- ratio - 1 rounds to
+  // exactly 0 for a hole 1e-16 of the neighbouring water deep, whose own fill term is still applied
   const int I = g.I, im = (i == 0) ? I - 1 : i - 1, ip = (i == I - 1) ? 0 : i + 1;
   const size_t o = (size_t)k * lev + row;
   const double qc = q[o + i];
+  if (fillable) *fillable = false;
   if (!(qc < 0.)) return 0.0;
   double nb = q[o + im] * (dpk[k] + dbk[k] * psrow[im]);
   nb = nb + q[o + ip] * (dpk[k] + dbk[k] * psrow[ip]);
   if (k != 0) nb = nb + q[o - lev + i] * (dpk[k - 1] + dbk[k - 1] * psrow[i]);
   if (k != g.L - 1) nb = nb + q[o + lev + i] * (dpk[k + 1] + dbk[k + 1] * psrow[i]);
   const double total = nb + qc * (dpk[k] + dbk[k] * psrow[i]);
+  if (fillable) *fillable = total > 0.;
   return (total > 0.) ? total / nb - 1.0 : 0.0;
 }
 __global__ void k_water_borrowing(Geom g, const double *__restrict__ dpk, const double *__restrict__ dbk, const double *__restrict__ ps,
@@ -2774,8 +2778,9 @@ __global__ void k_water_borrowing(Geom g, const double *__restrict__ dpk, const 
   const double qc = q[idx];
   double t = dt_q[idx];
   // the reference's order of events for one cell does not exist (they interleave with the sweep); this one is fixed: own hole, west, east, above, below
-  // (a hole that can be filled has 0 < total < neighbouring water: ratio - 1 /= 0)
-  if (wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k) != 0.0) t = t - qc / delta_t;
+  bool own;
+  (void)wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k, &own);
+  if (own) t = t - qc / delta_t;
   t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, im, k) * qc / delta_t;
   t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, ip, k) * qc / delta_t;
   if (k != 0) t = t + wb_ratio_m1(g, q, dpk, dbk, psrow, row, lev, i, k - 1) * qc / delta_t;

@@ -172,6 +172,10 @@ class Nc3File {
   explicit Nc3File(const std::string &path) : path_(path) {
     f_ = fopen(path.c_str(), "rb");
     if (!f_) fail("read_data: cannot open " + path);
+    try { parse_header(); }
+    catch (...) { fclose(f_); f_ = nullptr; throw; }          // (a constructor that throws runs no destructor: a malformed file must not leak its handle)
+  }
+  void parse_header() {
     unsigned char magic[4];
     need(fread(magic, 1, 4, f_) == 4 && magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F' && (magic[3] == 1 || magic[3] == 2),
          "is not a netCDF classic / 64-bit-offset file (a netCDF-4 file must be converted: nccopy -k 64-bit-offset)");
@@ -219,7 +223,7 @@ class Nc3File {
     uint64_t off = v.begin;
     if (v.rec) {
       if (numrecs_ == 0) fail("read_data: " + path_ + ": " + name + " has no records");
-      off += (uint64_t)std::min<long>(rec, (long)numrecs_ - 1) * recsize_;
+      off += (uint64_t)std::max<long>(0, std::min<long>(rec, (long)numrecs_ - 1)) * recsize_;      // (a negative record: the first)
     }
     const size_t ts = tsize(v.type);
     std::vector<unsigned char> raw(v.count * ts);

@@ -299,6 +299,12 @@ class DynCore:
         self._check(self.lib.isca_dyn_get_info(self._h, name.encode(), C.byref(v)))
         return v.value
 
+    def comm_init_env(self):
+        """world_size > 1 without a message-passing layer on the host: the communicator's id from rank 0 to the others through the file
+        ISCA_COMM_ID_FILE names (ISCA_COMM=ipc: ranks that share one GPU), then the communicator's self-check; isca_dyn_step(n) is then the
+        library's own sharded step loop.  Collective over the ranks."""
+        self._check(self.lib.isca_dyn_comm_init_env(self._h))
+
     def set_info(self, name: str, value: int):
         """what idealized_moist_phys_mod keeps beside the fields ("phys_calls"): handing over a running model through set()"""
         self._check(self.lib.isca_dyn_set_info(self._h, name.encode(), int(value)))

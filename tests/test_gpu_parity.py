@@ -1542,6 +1542,42 @@ def test_bench_two_ranks_native_loop_and_variants():
     assert len(v) == 2 and all(x["ms_per_step"] > 0 for x in v.values()), v
 
 
+def test_bench_eight_ranks_headline_workload_on_one_gpu():
+    """The driver's 8-GPU launch line, run once before the driver runs it: bench.py --gpus 8 on the HEADLINE workload (T85L40: 16 latitude rows and
+    11 zonal wavenumbers per rank) with the library issuing the exchanges (ISCA_COMM=ipc: the eight ranks share this box's GPU; RCCL on a node) --
+    launcher, watchdog, per-rank `exchange_ms`, `replicas` and the `variants` block all execute, one JSON line comes back."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2"]
+    env = dict(os.environ, ISCA_BENCH_BACKEND="gloo", ISCA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc",
+               ISCA_BENCH_SPINUP_S="0", ISCA_BENCH_STEADY="0", ISCA_BENCH_WATCHDOG_S="600")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=repo)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and "T85L40" in d["config"]["workload"] and d["config"]["parallelism"] == "lat-band x8"
+    assert len(d["exchange_ms"]) == 8 and all("native (ipc)" in e["driver"] and "all_to_all_inv" in e and "all_reduce" in e for e in d["exchange_ms"])
+    assert d["replicas"]["value"] > 0 and len(d["variants"]) == 2 and all(x["ms_per_step"] > 0 for x in d["variants"].values()), d.get("variants")
+
+
+def test_bench_shard_compute():
+    """bench.py's `shard_compute_ms`: P processes of the library's sharded step loop share this GPU and take turns on it (ISCA_IPC_SERIALIZE), so each
+    rank's HIP-event kernel times are those of a 1/P shard running alone.  At T42L25: the column kernel of a quarter of the grid takes less than that of
+    half of it, every kernel of the step is there, no exchange is counted."""
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    r = bench.shard_compute("T42L25", ranks=(2, 4), steps=6, warmup=3)
+    assert "error" not in r["P=2"] and "error" not in r["P=4"], r
+    for P in (2, 4):
+        k = r[f"P={P}"]["kernel_ms"]
+        assert {"column", "fft_fwd", "legendre_fwd", "spec_update", "legendre_inv", "fft_inv", "fixer_sums", "tracer_horiz", "tracer_vert"} <= set(k), k
+        assert not set(k) & set(bench.EXCHANGE_TIMERS) and r[f"P={P}"]["main_stream_ms"] > 0
+    assert r["P=4"]["kernel_ms"]["column"] < r["P=2"]["kernel_ms"]["column"] * 1.05, r
+
+
 def test_blown_up_run_is_a_fatal_not_a_fault():
     """A run that blows up (dt_atmos far beyond the CFL limit) must end like the reference's -- FATAL 'temperatures out of valid range'
     (spectral_dynamics.F90:940-972) at the next synchronisation -- not in a memory fault or an endless loop of a kernel whose walk lengths
