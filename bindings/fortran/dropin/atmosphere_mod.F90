@@ -20,6 +20,7 @@ use tracer_manager_mod, only: get_number_tracers
 use mpp_domains_mod,    only: domain2d, mpp_define_domains
 use tracer_type_mod,    only: tracer_type
 use spectral_dynamics_mod, only: spectral_dynamics_init, spectral_dynamics_end
+use transforms_mod,     only: get_grid_domain
 use idealized_moist_phys_mod, only: idealized_moist_phys_init, idealized_moist_phys_end
 use isca_dyn_c
 use isca_dropin_mod
@@ -96,8 +97,12 @@ end subroutine atmosphere_end
 
 subroutine atmosphere_domain(Domain)
 type(domain2d), intent(inout) :: Domain
+integer :: is_d, ie_d, js_d, je_d
 call need_core('atmosphere_domain')
-call mpp_define_domains((/1, nlon, 1, nlat/), (/1, 1/), Domain)      ! one process holds the whole grid; the GPUs' bands are the library's
+! the reference hands back the decomposed grid domain (atmosphere.F90:390: get_grid_domain's).  This mpp has no message passing (every process is
+! PE 0 of 1), so the domain it can describe is this process's own: all longitudes by the latitude band the library gave it (one rank: the whole grid)
+call get_grid_domain(is_d, ie_d, js_d, je_d)
+call mpp_define_domains((/is_d, ie_d, js_d, je_d/), (/1, 1/), Domain)
 end subroutine atmosphere_domain
 
 end module atmosphere_mod

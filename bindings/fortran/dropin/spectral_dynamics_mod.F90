@@ -309,6 +309,14 @@ else
   if(trim(topography_option) == 'input') call input_topography            ! (:186-245)
   call chk(isca_dyn_cold_start(core), 'spectral_dynamics_init')
 endif
+! spectral_diagnostics_init (:1554-1700) and diag_manager's bookkeeping for the fields it registers: the run directory's diag_table is the library's to
+! read -- it accumulates the table's fields on the device every step and appends one record per output interval to <file_name>.nc in the run directory
+! (csrc/history_nc.cpp); an entry of a module the device core does not hold is its FATAL, by name
+if(file_exist('diag_table')) then
+  call get_time(Time, seconds, days)
+  call chk(isca_dyn_diag_open(core, 'diag_table'//c_null_char, '.'//c_null_char, real(days, c_double)*86400._c_double + real(seconds, c_double)), &
+           'spectral_diagnostics_init')
+endif
 nlon = lon_max; nlat = lat_max; nlev = num_levels; nfour = num_fourier; nsph = num_spherical; ntrace = num_tracers
 virtual_t = use_virtual_temperature; ref_sea_level_press = reference_sea_level_press
 triang = triang_trunc; finc = fourier_inc
@@ -513,18 +521,24 @@ if(.not. module_is_initialized) return
 ! RESTART/spectral_dynamics.res.nc (:1502-1531) and -- written by atmosphere_end and mixed_layer_end in the reference -- atmosphere.res.nc,
 ! mixed_layer.res.nc: one call of the library's writer
 call chk(isca_dyn_write_restart(core, 'RESTART'//c_null_char, trim(tracer_name_list)//c_null_char), 'spectral_dynamics_end')
+call chk(isca_dyn_diag_close(core), 'spectral_dynamics_end')        ! the history files (diag_manager_end's part for them)
 call chk(isca_dyn_destroy(core), 'spectral_dynamics_end')
 core = c_null_ptr; core_ready = .false.; module_is_initialized = .false.
 end subroutine spectral_dynamics_end
 
-! the diagnostics of the dynamical core are accumulated on the device (isca_dyn_diag_select / isca_dyn_diag_read); diag_manager's
-! send_data protocol is not driven from here
+! spectral_diagnostics (:1709-1867) sends 20 fields of the new time level to diag_manager after every step (atmosphere.F90:344).  Here the step that
+! produced the level has already added them to the device's running sums, and the library writes the diag_table's files itself (spectral_dynamics_init:
+! isca_dyn_diag_open; one record per output interval, csrc/history_nc.cpp) -- so a host that calls this routine as the reference's does gets the same
+! history files, and nothing crosses PCIe here: the arguments, the host's copies of the new level, are not read.  What is checked is what the
+! reference checks first: that the module is up.
 subroutine spectral_diagnostics(Time, p_surf, u_grid, v_grid, t_grid, wg_full, tr_grid, time_level)
 type(time_type), intent(in) :: Time
 real, intent(in), dimension(:,:)       :: p_surf
 real, intent(in), dimension(:,:,:)     :: u_grid, v_grid, t_grid, wg_full
 real, intent(in), dimension(:,:,:,:,:) :: tr_grid
 integer, intent(in) :: time_level
+if(.not. module_is_initialized) call error_mesg('spectral_diagnostics','dynamics has not been initialized', FATAL)
+if(size(t_grid,3) /= nlev) call error_mesg('spectral_diagnostics','the fields handed over do not have num_levels levels', FATAL)
 end subroutine spectral_diagnostics
 
 !===============================================================================================

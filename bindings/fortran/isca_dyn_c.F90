@@ -248,6 +248,13 @@ interface
   integer(c_int) function isca_dyn_get_info(h, name, value) bind(C)
     import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), intent(out) :: value
   end function
+  ! diag_manager's part for the fields the device accumulates: the run directory's diag_table, one record per output interval appended to <file>.nc
+  integer(c_int) function isca_dyn_diag_open(h, diag_table, directory, start_seconds) bind(C)
+    import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: diag_table(*), directory(*); real(c_double), value :: start_seconds
+  end function
+  integer(c_int) function isca_dyn_diag_close(h) bind(C)
+    import; type(c_ptr), value :: h
+  end function
   integer(c_int) function isca_dyn_set_info(h, name, value) bind(C)       ! "phys_calls": a running moist model handed over through set_state
     import; type(c_ptr), value :: h; character(kind=c_char), intent(in) :: name(*); integer(c_long), value :: value
   end function

@@ -309,6 +309,17 @@ int isca_idealized_moist_phys(isca_dyn_t *h, int ncol, double delta_t, double gu
  * (module atmosphere, idealized_moist_phys.F90:672) and t_surf (module mixed_layer, mixed_layer.F90:359). */
 int isca_dyn_diag_select(isca_dyn_t *h, const char *comma_separated_names);     /* "" switches the accumulation off */
 int isca_dyn_diag_read(isca_dyn_t *h, const char *name, double *host, size_t count, long *nsteps, int reset);   /* mean over the steps since the last reset; host may be NULL */
+/* History files from the library: diag_manager's part for these fields, for a host without Python around it (the Fortran drop-in).  diag_open reads
+ * a diag_table -- the path of the run directory's file, or its text -- in the reference's format (title, base date, "file", freq, "units", format,
+ * "time_units", "long_name" lines and "module", "field", "output_name", "file", "time_sampling", time_avg, "other_opts", precision lines;
+ * src/shared/diag_manager/diag_table.F90, src/extra/python/isca/diagtable.py:5-35), selects the union of its fields on the device, and from then on every
+ * step of isca_dyn_step / isca_dyn_dynamics counts: at the end of each file's output interval one record of time means (time_avg = .true.) or of
+ * samples (.false.) is appended to <directory>/<file>.nc (netCDF classic; lon, lat, pfull, phalf, time, average_T1/_T2/_DT, pk, bk and the fields with
+ * long_name / units / cell_methods as spectral_dynamics.F90:1554-1700 registers them; with more than one rank every rank's band as <file>.nc.NNNN).
+ * start_seconds: the model time at the first step (a restarted run's Time).  Entries of modules the device core does not hold are refused by name.
+ * diag_close finishes the files (a handle destroyed without it leaves them complete up to the last record). */
+int isca_dyn_diag_open(isca_dyn_t *h, const char *diag_table_path_or_text, const char *directory, double start_seconds);
+int isca_dyn_diag_close(isca_dyn_t *h);
 
 /* --- RCCL communicator of the sharded step (world_size > 1) ----------------------------------------
  * With a communicator, isca_dyn_step runs the whole sharded step on the handle's stream: the lat<->m all-to-alls

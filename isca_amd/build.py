@@ -14,6 +14,7 @@ UNITS = [  # (source, extra flags)
     ("comm.cpp", []),                           # RCCL bound with dlopen (no link-time dependency)
     ("comm_ipc.cpp", []),                       # host-staged exchange for ranks sharing one GPU (verification of the sharded C++ loop)
     ("restart_nc.cpp", []),                     # restart files in the netCDF classic format (no netCDF library)
+    ("history_nc.cpp", []),                     # diag_table + history files (diag_manager's part for the fields the device accumulates)
     ("topog.cpp", ["-ffp-contract=off"]),        # get_topography for a handed-over height field: truncation or regularisation over the ocean (host arithmetic)
     ("kernels.hip", []),
     ("legendre.hip", []),

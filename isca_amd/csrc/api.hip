@@ -279,6 +279,7 @@ static FieldList inverse_list(isca_dyn *h, int tl) {
 extern "C" int isca_dyn_destroy(isca_dyn_t *h) {
   if (!h) return 0;
   timer_collect(h);
+  if (h->hist) isca_history_destroy(h);          // (files not closed by isca_dyn_diag_close: every record written so far is complete)
   if (h->comm) { hipStreamSynchronize(h->stream); delete h->comm; h->comm = nullptr; }
   for (void *p : h->allocs) hipFree(p);
   moist_destroy(h->moist);
@@ -1238,11 +1239,14 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
     // wg_full (omega) is an output only: the last step of the call stores it, and every step while a diagnostic of omega accumulates
     // (or the moist package runs, whose restart and diagnostics see it too)
     const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->cfg.physics == 1 || getenv_once("ISCA_ALWAYS_WG_FULL");
-    if (h->g.P > 1) { sharded_step(h, store_wg); continue; }
-    StepScalars sc = step_scalars(h);
-    sc.store_wg_full = store_wg;
-    upload_wave_matrices(h, sc.delta_t);
-    phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
+    if (h->g.P > 1) sharded_step(h, store_wg);
+    else {
+      StepScalars sc = step_scalars(h);
+      sc.store_wg_full = store_wg;
+      upload_wave_matrices(h, sc.delta_t);
+      phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
+    }
+    if (h->hist) isca_history_after_step(h);       // an open diag_table: its files' records as their intervals complete (history_nc.cpp)
   }
   guard.done();
   if (sync) sync_and_check_valid_range(h);
@@ -1292,6 +1296,7 @@ extern "C" int isca_dyn_dynamics(isca_dyn_t *h, const double *dt_ug, const doubl
     upload_wave_matrices(h, sc.delta_t);
     phase0(h, sc); phase1(h, sc); phase2(h, sc); phase3(h, sc);
   }
+  if (h->hist) isca_history_after_step(h);
   guard.done();
   if (sync) sync_and_check_valid_range(h);
   API_END

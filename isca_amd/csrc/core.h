@@ -142,6 +142,8 @@ struct KernelTimer {
 
 }  // namespace isca
 
+struct isca_history;                // history_nc.cpp: the open diag_table of a handle (isca_dyn_diag_open)
+
 struct isca_dyn {
   isca_dyn_config cfg;
   isca::Tables tab;
@@ -194,4 +196,7 @@ struct isca_dyn {
   bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
   bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
   double *host_red = nullptr;       // pinned: the fixer scalars / temperature extremes read back at a synchronisation point
+  isca_history *hist = nullptr;     // history files being written (isca_dyn_diag_open): the step loops call isca_history_after_step
 };
+void isca_history_after_step(isca_dyn *h);      // history_nc.cpp
+void isca_history_destroy(isca_dyn *h);

@@ -114,6 +114,8 @@ def load_library():
         "isca_dyn_get_table": [H, C.c_char_p, dp, C.c_size_t],
         "isca_dyn_get_info": [H, C.c_char_p, C.POINTER(C.c_long)],
         "isca_dyn_set_info": [H, C.c_char_p, C.c_long],
+        "isca_dyn_diag_open": [H, C.c_char_p, C.c_char_p, C.c_double],
+        "isca_dyn_diag_close": [H],
         "isca_dyn_set_topography": [H, dp, dp, C.c_double, dp, dp],
         "isca_topog_regularize": [H, C.c_double, dp, dp, dp, dp],
         "isca_topog_compute_lambda": [H, C.c_double, dp, dp, dp, dp],
@@ -181,7 +183,7 @@ EXPORTED_SYMBOLS = [
     "isca_dyn_exchange_buffers",
     "isca_dyn_reduce_buffer", "isca_dyn_halo_buffers", "isca_wavenumber_dealing", "isca_dyn_get_state", "isca_dyn_set_state", "isca_dyn_complete_update",
     "isca_dyn_set_time_pointers", "isca_dyn_refresh_derived",
-    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_set_info", "isca_dyn_set_topography", "isca_topog_regularize", "isca_topog_compute_lambda", "isca_nc_read_variable", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
+    "isca_dyn_get_table", "isca_dyn_get_info", "isca_dyn_set_info", "isca_dyn_diag_open", "isca_dyn_diag_close", "isca_dyn_set_topography", "isca_topog_regularize", "isca_topog_compute_lambda", "isca_nc_read_variable", "isca_env_rank", "isca_dyn_comm_init_env", "isca_dyn_write_restart", "isca_dyn_read_restart", "isca_dyn_restart_exists", "isca_restart_file_selftest", "isca_trans_spherical_to_grid", "isca_trans_grid_to_spherical",
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
@@ -711,6 +713,13 @@ class DynCore:
         n = C.c_long()
         self._check(self.lib.isca_dyn_diag_read(self._h, name.encode(), _dptr(a), a.size, C.byref(n), 1 if reset else 0))
         return a, n.value
+
+    def diag_open(self, diag_table: str, directory: str = ".", start_seconds: float = 0.0):
+        """history files written by the library itself (csrc/history_nc.cpp): `diag_table` = the path of the reference-format table or its text"""
+        self._check(self.lib.isca_dyn_diag_open(self._h, str(diag_table).encode(), str(directory).encode(), float(start_seconds)))
+
+    def diag_close(self):
+        self._check(self.lib.isca_dyn_diag_close(self._h))
 
     def diag_reset(self, name_of_any_selected_field: str):
         n = C.c_long()

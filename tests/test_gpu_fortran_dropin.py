@@ -334,6 +334,79 @@ def test_atmosphere_mod_sharded_fortran_host(tmp_path, nranks, moist):
         assert cont == two, (two, cont)
 
 
+HS_DIAG_TABLE = """"FMS Model results"
+0 0 0 0 0 0
+# = output files =
+# file_name, output_freq, output_units, format, time_units, long_name
+"atmos_6hourly", 6, "hours", 1, "days", "time",
+
+# = diagnostic field entries =  (exp/test_cases/held_suarez/held_suarez_test_case.py:27-38, on 6-hourly means)
+# module_name, field_name, output_name, file_name, time_sampling, time_avg, other_opts, precision
+"dynamics", "ps", "ps", "atmos_6hourly", "all", .true., "none", 2,
+"dynamics", "bk", "bk", "atmos_6hourly", "all", .false., "none", 2,
+"dynamics", "pk", "pk", "atmos_6hourly", "all", .false., "none", 2,
+"dynamics", "ucomp", "ucomp", "atmos_6hourly", "all", .true., "none", 2,
+"dynamics", "vcomp", "vcomp", "atmos_6hourly", "all", .true., "none", 2,
+"dynamics", "temp", "temp", "atmos_6hourly", "all", .true., "none", 2,
+"dynamics", "vor", "vor", "atmos_6hourly", "all", .true., "none", 2,
+"dynamics", "div", "div", "atmos_6hourly", "all", .true., "none", 2,
+"""
+
+
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_atmosphere_mod_writes_history_files(tmp_path, nranks):
+    """The Fortran host gets its diagnostics: with the Held-Suarez test case's diag_table in the run directory, atmos_model's loop on the drop-in
+    (spectral_dynamics_init -> isca_dyn_diag_open, spectral_dynamics_end -> isca_dyn_diag_close; the device accumulates, the library writes) leaves
+    atmos_6hourly.nc -- the file the Python host mirror writes for the same run (isca_amd/diag.py), every variable equal to 1e-15; with two ranks one
+    piece per rank (atmos_6hourly.nc.0000, .0001: diag_manager's naming of a distributed file), whose latitude bands together are that file to
+    the sharded run's rounding."""
+    import subprocess
+    from scipy.io import netcdf_file
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    from isca_amd import dyncore
+    from isca_amd.diag import DiagTable, History
+    nsteps, L = 72, 8
+    d = str(tmp_path / "run")
+    mg.prepare_rundir(d, "T21", L, "run", nsteps=nsteps, dt=600)
+    open(os.path.join(d, "diag_table"), "w").write(HS_DIAG_TABLE)
+    open(os.path.join(d, "drive.nml"), "w").write(f" &drive_nml\n   nsteps = {nsteps}, dt_atmos = 600\n /\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc", ISCA_IPC_TIMEOUT_S="120", ISCA_WORLD_SIZE=str(nranks), ISCA_LOCAL_RANK="0",
+               ISCA_COMM_ID_FILE=os.path.join(d, "comm_id"))
+    procs = [subprocess.Popen(f"ulimit -s unlimited; exec {exe}", shell=True, cwd=d, executable="/bin/bash", text=True, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, env=dict(env, ISCA_RANK=str(r))) for r in range(nranks)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    # the same run through the Python host mirror
+    diag = DiagTable()
+    diag.add_file("atmos_6hourly", 6, "hours", time_units="days")
+    for nm, avg in (("ps", True), ("bk", False), ("pk", False), ("ucomp", True), ("vcomp", True), ("temp", True), ("vor", True), ("div", True)):
+        diag.add_field("dynamics", nm, time_avg=avg)
+    c = dyncore.DynCore(dyncore.default_config("T21", num_levels=L)); c.cold_start()
+    hist = History(c, diag.files["atmos_6hourly"], 600.0, str(tmp_path / "py.nc"))
+    for _ in range(nsteps // 36):
+        c.step(36); hist.after_steps(36)
+    hist.close(); c.close()
+    ref = netcdf_file(str(tmp_path / "py.nc"), "r", mmap=False)
+    pieces = [netcdf_file(os.path.join(d, "atmos_6hourly.nc" + (f".{r:04d}" if nranks > 1 else "")), "r", mmap=False) for r in range(nranks)]
+    assert set(pieces[0].variables) == set(ref.variables)
+    tol = 1e-15 if nranks == 1 else 1e-11
+    for nm, v in ref.variables.items():
+        if "lat" in v.dimensions:
+            ax = v.dimensions.index("lat")
+            mine = np.concatenate([p.variables[nm][:] for p in pieces], axis=ax)
+        else:
+            mine = pieces[0].variables[nm][:]
+        assert mine.shape == v.shape, nm
+        scale = max(float(np.abs(v[:]).max()), 1e-300)
+        assert float(np.abs(mine - v[:]).max()) <= tol * scale, (nm, float(np.abs(mine - v[:]).max()) / scale)
+    assert ref.variables["temp"].shape[0] == 2 and pieces[0].variables["temp"].cell_methods == b"time: mean"
+    for f in pieces + [ref]:
+        f.close()
+
+
 def test_atmosphere_mod_input_topography_from_fortran(tmp_path, golden_dir):
     """topography_option = 'input' from Fortran (get_topography, spectral_init_cond.F90:186-245): spectral_dynamics_init reads zsurf and land_mask of
     INPUT/topography.data.nc with the library's netCDF-classic reader and hands them to isca_dyn_set_topography -- regularised over the ocean with the

@@ -1678,6 +1678,84 @@ def test_diagnostics_time_means(tmp_path):
     f.close(); c.close()
 
 
+DIAG_TABLE_TWO_FILES = """"FMS Model results"
+0 0 0 0 0 0
+# = output files =
+# file_name, output_freq, output_units, format, time_units, long_name
+"atmos_1h", 1, "hours", 1, "hours", "time",
+"atmos_3h", 3, "hours", 1, "days", "time",
+
+# = diagnostic field entries =
+# module_name, field_name, output_name, file_name, time_sampling, time_avg, other_opts, precision
+"dynamics", "temp", "temp", "atmos_1h", "all", .true., "none", 2,
+"dynamics", "ucomp", "ucomp", "atmos_1h", "all", .true., "none", 2,
+"dynamics", "bk", "bk", "atmos_1h", "all", .false., "none", 2,
+"dynamics", "temp", "temp", "atmos_3h", "all", .true., "none", 2,
+"dynamics", "ps", "ps", "atmos_3h", "all", .true., "none", 2,
+"dynamics", "ucomp_temp", "ucomp_temp", "atmos_3h", "all", .true., "none", 2,
+"dynamics", "vcomp", "vcomp", "atmos_3h", "all", .false., "none", 2,
+"dynamics", "pk", "pk", "atmos_3h", "all", .false., "none", 2,
+"""
+
+
+def _same_history_files(path_a, path_b):
+    from scipy.io import netcdf_file
+    fa, fb = netcdf_file(path_a, "r", mmap=False), netcdf_file(path_b, "r", mmap=False)
+    try:
+        assert set(fa.variables) == set(fb.variables), (sorted(fa.variables), sorted(fb.variables))
+        assert {k: v for k, v in fa.dimensions.items() if v} == {k: v for k, v in fb.dimensions.items() if v}
+        for nm, va in fa.variables.items():
+            vb = fb.variables[nm]
+            assert va.dimensions == vb.dimensions and va.shape == vb.shape, nm
+            assert np.array_equal(va[:], vb[:]), (nm, float(np.abs(va[:] - vb[:]).max()))
+            for att in ("units", "long_name", "cartesian_axis", "cell_methods", "time_avg_info", "positive"):
+                assert getattr(va, att, None) == getattr(vb, att, None), (nm, att)
+        return {nm: v.shape for nm, v in fa.variables.items()}
+    finally:
+        fa.close(); fb.close()
+
+
+def test_history_files_written_by_the_library(tmp_path):
+    """isca_dyn_diag_open: the reference-format diag_table parsed by the library, which then writes the history files itself while isca_dyn_step runs
+    (csrc/history_nc.cpp; what the Fortran drop-in uses).  Two files with different intervals, averaged and sampled fields, the static pk / bk:
+    every variable, attribute and value equals the Python host mirror's files (isca_amd/diag.py) for the same run -- bit for bit."""
+    from isca_amd.diag import DiagCollector, DiagTable, History
+    L = 6
+    table = tmp_path / "diag_table"
+    table.write_text(DIAG_TABLE_TWO_FILES)
+    a = make("T21", L); a.cold_start(); a.step(4)
+    b = make("T21", L); b.cold_start(); b.step(4)
+    a.diag_open(str(table), str(tmp_path / "lib"), start_seconds=4 * 600.0)
+    with pytest.raises(dyncore.IscaError):
+        a.diag_open(str(table), str(tmp_path / "lib"))                          # one table per handle
+    diag = DiagTable()
+    diag.add_file("atmos_1h", 1, "hours")
+    diag.add_file("atmos_3h", 3, "hours", time_units="days")
+    diag.add_field("dynamics", "temp", time_avg=True, files=["atmos_1h"]); diag.add_field("dynamics", "ucomp", time_avg=True, files=["atmos_1h"])
+    diag.add_field("dynamics", "bk", files=["atmos_1h"])
+    diag.add_field("dynamics", "temp", time_avg=True, files=["atmos_3h"]); diag.add_field("dynamics", "ps", time_avg=True, files=["atmos_3h"])
+    diag.add_field("dynamics", "ucomp_temp", time_avg=True, files=["atmos_3h"]); diag.add_field("dynamics", "vcomp", time_avg=False, files=["atmos_3h"])
+    diag.add_field("dynamics", "pk", files=["atmos_3h"])
+    os.makedirs(tmp_path / "py")
+    hist = [History(b, diag.files[nm], 600.0, str(tmp_path / "py" / (nm + ".nc")), start_seconds=4 * 600.0) for nm in ("atmos_1h", "atmos_3h")]
+    col = DiagCollector(b, hist)
+    a.step(20); a.step(16)                                                      # 6 hours; the library cuts its own chunks
+    for _ in range(6):
+        b.step(6); col.after_steps(6)
+    col.close(); a.diag_close()
+    s1 = _same_history_files(str(tmp_path / "lib" / "atmos_1h.nc"), str(tmp_path / "py" / "atmos_1h.nc"))
+    s3 = _same_history_files(str(tmp_path / "lib" / "atmos_3h.nc"), str(tmp_path / "py" / "atmos_3h.nc"))
+    assert s1["temp"][0] == 6 and s3["temp"][0] == 2 and "vcomp" in s3 and "bk" in s1
+    for k in ("ug", "tg", "psg"):
+        assert np.array_equal(a.get(k), b.get(k)), k                           # (the diagnostics do not touch the run)
+    # an entry the device core does not hold is refused by name, a table without entries opens nothing
+    with pytest.raises(dyncore.IscaError, match="teq"):
+        a.diag_open(DIAG_TABLE_TWO_FILES + '"hs_forcing", "teq", "teq", "atmos_1h", "all", .true., "none", 2,\n', str(tmp_path / "lib2"))
+    a.diag_open('"title"\n0 0 0 0 0 0\n', str(tmp_path / "lib3")); a.diag_close()
+    assert not os.path.exists(tmp_path / "lib3")
+    a.close(); b.close()
+
+
 def test_diagnostics_two_history_files(tmp_path):
     """Two files of one diag_table with different intervals and different field lists: each gets the means of its own intervals (the
     device holds one set of sums per handle; DiagCollector takes them off chunk by chunk and every file keeps its own)."""
