@@ -12,6 +12,7 @@ ARCH = "gfx950"
 UNITS = [  # (source, extra flags)
     ("tables.cpp", ["-ffp-contract=off"]),      # host tables: reproduce the reference's non-FMA fp64 results
     ("comm.cpp", []),                           # RCCL bound with dlopen (no link-time dependency)
+    ("comm_peer.hip", []),                      # device-resident exchange between the ranks of one node: stores into hipIpc-mapped peer buffers, one kernel per exchange
     ("comm_ipc.cpp", []),                       # host-staged exchange for ranks sharing one GPU (verification of the sharded C++ loop)
     ("restart_nc.cpp", []),                     # restart files in the netCDF classic format (no netCDF library)
     ("history_nc.cpp", []),                     # diag_table + history files (diag_manager's part for the fields the device accumulates)

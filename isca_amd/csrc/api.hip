@@ -335,6 +335,7 @@ static void sync_and_check_valid_range(isca_dyn *h) {
   HIP_CHECK(hipMemcpyAsync(h->host_red, h->d.red, 22 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(hipMemcpyAsync(h->d.red + 20, h->host_red + 32, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (h->comm) h->comm->check();
   const double *red = h->host_red;
   const double tmin = red[20], tmax = red[21];
   const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
@@ -1323,6 +1324,8 @@ extern "C" int isca_dyn_comm_init(isca_dyn_t *h, const void *id128) {
   if (h->comm) fail("comm_init: communicator already initialised");
   HIP_CHECK(hipSetDevice(h->cfg.device));
   h->comm = isca::Comm::create(id128, h->cfg.rank, h->cfg.world_size);
+  // (ISCA_COMM=peer: the ranks store into each other's receive buffers -- exported and opened here, collectively)
+  h->comm->attach(h->d.Ff_s, h->d.Fi_g, h->tracer_on ? h->d.halo_recv : nullptr, h->tracer_on ? halo_doubles(h->g, h->cfg.num_tracers) : 0);
   API_END
 }
 // A host without a message-passing layer of its own (the Fortran drop-in on an mpp built without MPI; any launcher that only sets environment

@@ -71,6 +71,7 @@ class RcclComm final : public Comm {
 
 void Comm::unique_id(void *id128) {
   if (ipc_id_requested()) { ipc_unique_id(id128); return; }
+  if (peer_id_requested()) { peer_unique_id(id128); return; }
   UniqueId id;
   ck(api().GetUniqueId(&id), "ncclGetUniqueId");
   std::memcpy(id128, &id, sizeof(id));
@@ -78,6 +79,7 @@ void Comm::unique_id(void *id128) {
 
 Comm *Comm::create(const void *id128, int rank, int world) {
   if (is_ipc_id(id128)) return make_ipc_comm(id128, rank, world);
+  if (is_peer_id(id128)) return make_peer_comm(id128, rank, world);
   return new RcclComm(id128, rank, world);
 }
 

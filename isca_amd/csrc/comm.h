@@ -10,11 +10,13 @@
 
 namespace isca {
 
-// Two implementations behind one interface, chosen by the 128-byte id the ranks share:
+// Three implementations behind one interface, chosen by the 128-byte id the ranks share:
 //  * RCCL (default): grouped ncclSend/ncclRecv + ncclAllReduce on the step's stream, one GPU per rank;
 //  * "ipc" (ISCA_COMM=ipc when the id is drawn; comm_ipc.cpp): host-staged exchange through files mapped by every rank -- N processes
 //    that may SHARE one GPU run the same C++ exchange schedule (isca_dyn_step's sharded loop) without RCCL, which refuses two ranks on
 //    one device.  A verification vehicle for 1-GPU boxes, not a fast path: every exchange synchronises the stream and the host.
+//  * "peer" (ISCA_COMM=peer; comm_peer.hip): the ranks of ONE node write into each other's receive buffers (hipIpc), one kernel per exchange, flags
+//    in device memory instead of host hand-shakes.  Verified with N processes on one GPU; not yet run over xGMI.
 class Comm {
  public:
   static constexpr int UNIQUE_ID_BYTES = 128;
@@ -34,11 +36,23 @@ class Comm {
   virtual void all_reduce_sum(double *buf, size_t count, hipStream_t s) = 0;         // in place
   // this rank cannot go on (an exception on its way to the caller): peers blocked in an exchange stop with an error instead of waiting
   virtual void abort() noexcept {}
+  // collective, once: the receive buffers of the sharded step -- the spectral side's Fourier buffer (lat -> m), the grid side's (m -> lat), the
+  // tracer's halo rows (two halves of halo_half doubles: from below, from above; null without tracer) -- for an implementation that writes into
+  // its peers' memory (comm_peer.hip); the others ignore it
+  virtual void attach(double * /*recv_fwd*/, double * /*recv_inv*/, double * /*recv_halo*/, size_t /*halo_half*/) {}
+  // at a host synchronisation point: an exchange that gave up on the device (a peer that never arrived) becomes the error here
+  virtual void check() {}
 
  protected:
   Comm(int rank, int world) : rank_(rank), world_(world) {}
   int rank_, world_;
 };
+
+// comm_peer.hip: ISCA_COMM=peer -- one kernel per exchange that stores into the peers' receive buffers (hipIpc-mapped), flags instead of host hand-shakes
+bool peer_id_requested();
+void peer_unique_id(void *id128);
+bool is_peer_id(const void *id128);
+Comm *make_peer_comm(const void *id128, int rank, int world);
 
 // comm_ipc.cpp
 bool ipc_id_requested();                       // ISCA_COMM=ipc in the environment of the rank that draws the id

@@ -103,14 +103,15 @@ class ShardedDynCore(dyncore.DynCore):
         ptrs, hbytes = self.halo_buffers()
         self._halo = [torch.as_tensor(_DevPtr(p, hbytes), device="cuda") for p in ptrs] if hbytes else None
         # Native mode: the library issues the exchanges itself through RCCL on our stream and a whole run of steps is one
-        # call (no Python, no torch between the kernels).  Default with the nccl backend; ISCA_COMM=torch|native|ipc overrides
-        # (ipc: the same C++ step loop over the library's host-staged exchange, for ranks that share one GPU -- csrc/comm_ipc.cpp;
+        # call (no Python, no torch between the kernels).  Default with the nccl backend; ISCA_COMM=torch|native|ipc|peer overrides
+        # (ipc: the same C++ step loop over the library's host-staged exchange, for ranks that share one GPU -- csrc/comm_ipc.cpp; peer: over the
+        # library's device-resident exchange between the GPUs of one node, stores into hipIpc-mapped peer buffers -- csrc/comm_peer.hip;
         # the library reads the variable itself when rank 0 draws the communicator id).
         self.native = False
         mode = os.environ.get("ISCA_COMM", "native" if dist.get_backend(group) == "nccl" else "torch")
-        if mode not in ("native", "ipc", "torch"):
-            raise dyncore.IscaError(f"ISCA_COMM={mode!r}: expected native, ipc or torch")
-        if mode in ("native", "ipc"):
+        if mode not in ("native", "ipc", "peer", "torch"):
+            raise dyncore.IscaError(f"ISCA_COMM={mode!r}: expected native, ipc, peer or torch")
+        if mode in ("native", "ipc", "peer"):
             box = [None]
             if cfg.rank == 0:
                 buf = C.create_string_buffer(128)

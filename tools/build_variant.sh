@@ -10,7 +10,7 @@ EXTRA=""
 [ "$U" = "moist" ] && EXTRA="-ffp-contract=off"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $EXTRA $2 -c isca_amd/csrc/$U.hip -o $L/${U}_$1.o
 OBJS=""
-for o in tables comm comm_ipc restart_nc history_nc topog kernels legendre moist api; do
+for o in tables comm comm_peer comm_ipc restart_nc history_nc topog kernels legendre moist api; do
   if [ "$o" = "$U" ]; then OBJS="$OBJS $L/${U}_$1.o"; else OBJS="$OBJS $L/$o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $L/libisca_dyn_$1.so $OBJS -ldl
