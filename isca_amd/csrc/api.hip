@@ -1084,9 +1084,20 @@ static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, s
     { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   }
 }
+static bool late_water_fixer(const isca_dyn *h) {
+  static const int env = getenv("ISCA_LATE_WATER_FIXER") ? atoi(getenv("ISCA_LATE_WATER_FIXER")) : 0;      // 1: wherever possible (measurement; see phase2)
+  const bool can = h->lazy_fix && h->g.P == 1 && h->tracer_on && !h->tracer_serial && h->cfg.raw_filter_coeff == 1.0;
+  return can && env > 0;
+}
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
+  // ISCA_LATE_WATER_FIXER=1 (measured, not the default): where the tracer's transport on the side stream ends long after the inverse FFT (110 us at
+  // T170L60) the fixers need not wait for it with everything -- the sums of the new u, v, T, ps and the scalars they give (mass factor, temperature
+  // correction: all the next column kernel needs) first, the join after them, then the water fixer's five sums (one wavefront per 64 columns) and the
+  // scalars once more with the water factor.  Bit-identical (test_late_water_fixer_equals_one_pass) and no faster: at T170L60 0.940 against 0.939 ms
+  // -- k_fixer_sums beside k_tracer_vert takes 60 instead of 49 us and k_tracer_vert 347 instead of 305: both stream, and the step is the sum of its bytes.
+  if (late_water_fixer(h)) { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream, 1); return; }
   if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
@@ -1159,6 +1170,11 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
       { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
+      if (late_water_fixer(h)) {          // (phase2): the join, the water fixer's sums, the scalars again -- now with the water factor, the (0,0) patch not repeated
+        HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        { Timed t(h, "fixer_sums_water"); launch_fixer_sums(*h, sc.fut, h->stream, 2); }
+        { Timed t(h, "fixer_finish_water"); launch_fixer_finish(*h, sc, h->stream, false); }
+      }
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
     } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }

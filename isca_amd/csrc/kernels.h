@@ -88,9 +88,9 @@ void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, c
 void launch_leapfrog_b(size_t n, double *cur, double *fut, const double *part, double robert, double raw, hipStream_t s);
 void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s);
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
-void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s, int part = 0);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
-void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s);  // R2 with lazy fixers: reduce + scalars, left pending on the new level
+void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s, bool patch = true);  // R2 with lazy fixers: reduce + scalars, left pending on the new level
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s);                    // apply what is pending on both time levels in place
 void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const double *p_full, const double *u,
                        const double *v, const double *t, double *udt, double *vdt, double *tdt, hipStream_t s);

@@ -1511,8 +1511,10 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
 // MCM: vert_difference_option = 'mcm' (press_and_geopot.F90:196-210, spectral_dynamics.F90:1084-1099): p_full = the mean of the two half levels,
 // the pressure-gradient term with grad(p_s)/p_s, the conversion term with (sum above + half the layer's own)/p_full.
-template <int CH, bool EXT, bool VIRT, bool MCM = false>
-__global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
+// MAXT: the block's thread count the register allocation is made for -- 512 (8 wavefronts of CH = ceil(L/8) levels: two per SIMD, up to 256 VGPRs),
+// or, for the ISCA_COLUMN_NW=10|14 experiment (more, thinner wavefronts per block: 3 / 4 per SIMD at <= 170 / 128 VGPRs; DESIGN.md 11 "Round 5"), 640 / 896.
+template <int CH, bool EXT, bool VIRT, bool MCM = false, int MAXT = 512, bool EARLY_THIN = true>
+__global__ __launch_bounds__(MAXT) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
   const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
@@ -1546,7 +1548,7 @@ __global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   // every global load of the block is issued here, before the barrier of the vertical scans: one memory
   // round trip per block instead of two (the loads below the barrier could not start before it)
   // (chunks of more than 5 levels would not fit the register file that way: they read these six below the barrier)
-  constexpr bool EARLY = CH <= 5;
+  constexpr bool EARLY = CH <= 5 && (MAXT == 512 || EARLY_THIN);      // (the thin-wavefront experiment: with and without the six fields in registers across the barrier)
   double upv[EARLY ? CH : 1], vpv[EARLY ? CH : 1], tpv[EARLY ? CH : 1], vov[EARLY ? CH : 1], dxv[EARLY ? CH : 1], dyv[EARLY ? CH : 1];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
@@ -1758,8 +1760,12 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
   a.store_wg_full = sc.store_wg_full;
-  const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
-  const int NW = (g.L + CH - 1) / CH;
+  int CH = (g.L + 7) / 8;                       // <= 8 wavefronts per block, CH levels each
+  int NW = (g.L + CH - 1) / CH;
+  // experiment (plain Held-Suarez instantiation only): more wavefronts of fewer levels per block -- ISCA_COLUMN_NW=10 (CH = 4 at L = 40) or 14 (CH = 3)
+  static const int nw_env = getenv("ISCA_COLUMN_NW") ? atoi(getenv("ISCA_COLUMN_NW")) : 0;
+  const bool thin = (nw_env == 10 || nw_env == 14) && g.L == 40 && h.cfg.vert_difference_option != 1 && !virtual_t_on(h) && h.cfg.physics == 0;
+  if (thin) { CH = nw_env == 10 ? 4 : 3; NW = (g.L + CH - 1) / CH; }
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
   a.tv = virtual_t_on(h) ? d.tv : nullptr;
@@ -1772,6 +1778,12 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     else if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
     else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
     else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
+  if (thin) {
+    static const bool late = getenv("ISCA_COLUMN_LATE") != nullptr;      // the six previous-level / gradient fields loaded below the barrier (fewer registers, a second round trip)
+    if (CH == 4) { if (late) hipLaunchKernelGGL((k_column<4, false, false, false, 640, false>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<4, false, false, false, 640>), grid, block, lds, s, g, a); }
+    else { if (late) hipLaunchKernelGGL((k_column<3, false, false, false, 896, false>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<3, false, false, false, 896>), grid, block, lds, s, g, a); }
+    return;
+  }
   switch (CH) {
     case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
@@ -2893,6 +2905,9 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
 constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
+// MODE 0: everything; 1: without the water fixer's sums (p[3..7] untouched); 2: those alone, by blocks of ONE wavefront (no field is read).  1 then 2
+// leave what 0 leaves: the two halves of the step's fixer sums when the tracer's transport finishes long after the inverse FFT (launch_fixer_sums).
+template <int MODE>
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
@@ -2904,15 +2919,25 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   const int jl = col / g.I;
   const size_t c2 = col, lev = (size_t)g.Jl * g.I;
   const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
+  const double wgt = wts[jl], ps = psg[c2];
+  if (MODE == 2) {        // the water fixer's five sums alone
+    double t0 = wgt * wcol[c2], t1 = wgt * wcol[lev + c2], t2 = wgt * wcol[2 * lev + c2] * ps, t3 = wgt * wcol[3 * lev + c2], t4 = wgt * wcol[4 * lev + c2] * ps;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
+    }
+    if (threadIdx.x == 0) { double *p = partials + NPART * (size_t)blockIdx.x; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; }
+    return;
+  }
   double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
     uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
   }
-  const double wgt = wts[jl], ps = psg[c2];
   double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
+  if (MODE == 0 && wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
     t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
     t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
   }
@@ -2956,7 +2981,8 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
     for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
     double *p = partials + NPART * (size_t)blockIdx.x;
-    p[0] = s0; p[1] = a1; p[2] = a2; p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; p[8] = bmn; p[9] = bmx;
+    p[0] = s0; p[1] = a1; p[2] = a2; p[8] = bmn; p[9] = bmx;
+    if (MODE == 0) { p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4; }
   }
 }
 // Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from
@@ -3013,6 +3039,7 @@ struct FixerArgs {
   double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
   const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
   int nb, reduce_here;
+  int patch;               // k_fixer_finish: patch the (0,0) spectral coefficients (not on its second run of a step, after the water sums came in)
   double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
   double *psg, *tg;
   double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
@@ -3136,7 +3163,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
   __shared__ double sh[NT / 64][16];
   double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
-  const SpecPatch sp = fixer_patch_load(g, a);
+  const SpecPatch sp = a.patch ? fixer_patch_load(g, a) : SpecPatch{0., 0., 0., 0.};
   const double mn_old = a.red[20], mx_old = a.red[21];
   if (a.reduce_here) fixer_totals<NT>(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
   else {
@@ -3151,7 +3178,7 @@ __global__ __launch_bounds__(NT) void k_fixer_finish(Geom g, FixerArgs a, double
     if (a.reduce_here) { a.red[20] = fmin(mn_old, tmn); a.red[21] = fmax(mx_old, tmx); }
     pend_fut[PEND_FACTOR] = factor; pend_fut[PEND_TCORR] = tcorr; pend_fut[PEND_WFAC] = wfac;
   }
-  fixer_patch_spectral(g, a, sp, factor, tcorr);
+  if (a.patch) fixer_patch_spectral(g, a, sp, factor, tcorr);
 }
 // What is pending on the two time levels, applied in place (before the host reads or writes state, restart files, diagnostics):
 // afterwards tg, psg, tr and tr_atm of both levels hold what the eager k_fixer_apply would have left.
@@ -3199,14 +3226,17 @@ __global__ __launch_bounds__(256) void k_fixer_materialize(Geom g, MaterializeAr
   }
 }
 
-void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
+// part 0: all sums; 1: those of the new u, v, T, ps (no tracer needed: before the side stream's join); 2: the water fixer's (after it)
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s, int part) {
   const Geom &g = h.g;
   const Dev &d = h.d;
   const int nb = (int)column_partials_count(h);
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH,
-                     h.tracer_on ? d.wcol : (const double *)nullptr);
+  const double *wcol = h.tracer_on ? d.wcol : (const double *)nullptr;
+  if (part == 1) hipLaunchKernelGGL(k_fixer_sums<1>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol);
+  else if (part == 2) { hipLaunchKernelGGL(k_fixer_sums<2>, dim3(nb), dim3(64), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol); return; }
+  else hipLaunchKernelGGL(k_fixer_sums<0>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol);
   // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
   // on one rank k_fixer_finish folds them itself
   if (g.P > 1 || !h.lazy_fix) {
@@ -3231,6 +3261,7 @@ static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   a.sumw_nlon = sumw * g.I;
   a.robert = h.cfg.robert_coeff; a.raw = h.cfg.raw_filter_coeff; a.tr_part = h.d.tr_part;
   a.do_mass = h.cfg.do_mass_correction; a.do_energy = h.cfg.do_energy_correction;
+  a.patch = 1;
   return a;
 }
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
@@ -3240,8 +3271,9 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
-void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  const FixerArgs a = fixer_args(h, sc);
+void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s, bool patch) {
+  FixerArgs a = fixer_args(h, sc);
+  a.patch = patch ? 1 : 0;
   if (a.nb > 256) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
   else hipLaunchKernelGGL(k_fixer_finish<256>, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
 }
