@@ -244,7 +244,7 @@ def load_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE per the gfx950 correction,
     calibrated on k_column's known byte count, + WRITE_SIZE; profiles/README.md).  A number measured earlier, NOT in this run: the
     line says which file it came from."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic.json" if workload == "T85L40" else f"{tag}_{workload}_pmc_traffic.json")
         if os.path.exists(os.path.join(REPO, rel)):
             return json.load(open(os.path.join(REPO, rel))).get("bytes_per_launch", {}), rel
