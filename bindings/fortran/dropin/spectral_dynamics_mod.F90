@@ -160,8 +160,11 @@ if(trim(topography_option) /= 'flat' .and. trim(topography_option) /= 'gaussian'
                   "'interpolated' needs the data files of topography_mod)", FATAL)
 if(num_steps /= 1) call error_mesg('spectral_dynamics_init','num_steps must be 1.', FATAL)
 if(longitude_origin /= 0.) call error_mesg('spectral_dynamics_init','longitude_origin must be 0.', FATAL)
-if(dropin_physics /= 1 .and. (trim(equilibrium_t_option) /= 'Held_Suarez' .or. trim(local_heating_option) /= '' .or. relax_to_specified_wind)) &
-  call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing (or no_forcing) is carried by the device core.', FATAL)
+if(dropin_physics /= 1 .and. (trim(equilibrium_t_option) /= 'Held_Suarez' .or. relax_to_specified_wind)) &
+  call error_mesg('spectral_dynamics_init','hs_forcing_nml: only the Held-Suarez branch of hs_forcing (with local_heating_option = Isidoro, or no_forcing) '// &
+                  'is carried by the device core.', FATAL)
+if(dropin_physics /= 1 .and. trim(local_heating_option) /= '' .and. trim(local_heating_option) /= 'Isidoro') &
+  call error_mesg('hs_forcing_nml','"'//trim(local_heating_option)//'"  is not a supported value for local_heating_option', FATAL)
 
 call chk(isca_dyn_config_default(cfg), 'spectral_dynamics_init')
 cfg%lon_max = lon_max; cfg%lat_max = lat_max; cfg%num_fourier = num_fourier; cfg%num_spherical = num_spherical
@@ -169,6 +172,11 @@ cfg%num_levels = num_levels; cfg%fourier_inc = fourier_inc; cfg%triang_trunc = m
 call get_time(Time_step_in, seconds, days)
 dt_real = 86400*days + seconds
 cfg%dt_atmos = dt_real
+if(dropin_physics /= 1 .and. trim(local_heating_option) == 'Isidoro') then       ! hs_forcing's analytic heat source (hs_forcing.F90:728-769)
+  cfg%local_heating_option = 1; cfg%local_heating_srfamp = local_heating_srfamp; cfg%local_heating_vert_decay = local_heating_vert_decay
+  cfg%local_heating_xwidth = local_heating_xwidth; cfg%local_heating_ywidth = local_heating_ywidth
+  cfg%local_heating_xcenter = local_heating_xcenter; cfg%local_heating_ycenter = local_heating_ycenter
+endif
 cfg%damping_order = damping_order; cfg%damping_coeff = damping_coeff
 cfg%damping_order_vor = damping_order_vor; cfg%damping_order_div = damping_order_div
 cfg%damping_coeff_vor = damping_coeff_vor; cfg%damping_coeff_div = damping_coeff_div; cfg%cutoff_wn = cutoff_wn
@@ -191,7 +199,7 @@ cfg%t_zero = t_zero; cfg%t_strat = t_strat; cfg%delh = delh; cfg%delv = delv; cf
 cfg%ka = ka; cfg%ks = ks; cfg%kf = kf; cfg%do_conserve_energy = merge(1, 0, do_conserve_energy)
 cfg%trflux = trflux; cfg%trsink = trsink; cfg%P00 = P00
 if(no_forcing) then      ! hs_forcing returns at once (hs_forcing.F90:174): zero coefficients give exactly zero tendencies, no tracer source or sink
-  cfg%ka = 0.; cfg%ks = 0.; cfg%kf = 0.; cfg%trflux = 0.; cfg%trsink = 0.
+  cfg%ka = 0.; cfg%ks = 0.; cfg%kf = 0.; cfg%trflux = 0.; cfg%trsink = 0.; cfg%local_heating_option = 0
 endif
 cfg%vert_advect_uv = advect_scheme(vert_advect_uv, 'vert_advect_uv'); cfg%vert_advect_t = advect_scheme(vert_advect_t, 'vert_advect_t')
 cfg%use_implicit = merge(1, 0, use_implicit); cfg%make_symmetric = merge(1, 0, make_symmetric)

@@ -68,6 +68,8 @@ type, bind(C) :: isca_dyn_config
   integer(c_int) :: tracer_sms(ISCA_MAX_TRACERS)       ! 1: the entry's own tracer_flux / tracer_sink instead of hs_forcing_nml's trflux / trsink
   real(c_double) :: tracer_flux(ISCA_MAX_TRACERS), tracer_sink(ISCA_MAX_TRACERS)
   integer(c_int) :: tracer_advect_vert(ISCA_MAX_TRACERS)   ! -1 the representation's standard scheme, 0 second_centered .. 3 finite_volume_parabolic
+  integer(c_int) :: local_heating_option               ! hs_forcing_nml: 0 '' (none), 1 'Isidoro' (hs_forcing.F90:728-769)
+  real(c_double) :: local_heating_srfamp, local_heating_xwidth, local_heating_ywidth, local_heating_xcenter, local_heating_ycenter, local_heating_vert_decay
 end type
 
 interface

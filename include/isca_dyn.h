@@ -147,6 +147,12 @@ typedef struct isca_dyn_config {
    * horizontal step (:1161); a 'spectral' tracer to the current level (centred schemes) or the previous one (finite-volume schemes, :1135-1141).
    * A non-standard scheme runs vert_advection on whole columns in a kernel of its own (4..64 levels), like vert_advect_uv / vert_advect_t. */
   int tracer_advect_vert[ISCA_MAX_TRACERS];
+  /* hs_forcing_nml: local_heating_option (hs_forcing.F90:87-94, 233-238, 728-769): 0 = '' (none), 1 = 'Isidoro' -- an analytic heat source added to the
+   * temperature tendency after the Newtonian damping, srfamp exp(-((lon - xcenter)/xwidth)^2 / 2) exp(-((lat - ycenter)/ywidth)^2 / 2)
+   * exp((p_full - p_s)/vert_decay): local_heating_srfamp in K/day, the widths and centres in degrees, local_heating_vert_decay in Pa.
+   * ('from_file' needs interpolator_mod's data files: outside the device core.)  Only with physics = 0. */
+  int local_heating_option;
+  double local_heating_srfamp, local_heating_xwidth, local_heating_ywidth, local_heating_xcenter, local_heating_ycenter, local_heating_vert_decay;
 } isca_dyn_config;
 
 /* fills the defaults of the reference's namelists + the Held-Suarez test case values */

@@ -22,9 +22,10 @@ from .dyncore import IscaError, RESOLUTIONS
 _core: dyncore.DynCore | None = None
 _run_dir: str | None = None
 _NML_GROUPS = ("spectral_dynamics_nml", "hs_forcing_nml", "main_nml")
-# hs_forcing_nml values that belong to local_heating_option / relax_to_specified_wind / equilibrium_t_option other than 'Held_Suarez' (hs_forcing.F90:86-118)
-_HS_UNUSED_PARAMETERS = ("local_heating_srfamp", "local_heating_xwidth", "local_heating_ywidth", "local_heating_xcenter", "local_heating_ycenter",
-                         "local_heating_vert_decay", "local_heating_file", "u_wind_file", "v_wind_file", "equilibrium_t_file", "p_trop", "alpha",
+# hs_forcing_nml values that belong to local_heating_option = 'from_file' / relax_to_specified_wind / equilibrium_t_option other than 'Held_Suarez' (hs_forcing.F90:86-118)
+_HS_LOCAL_HEATING = ("local_heating_srfamp", "local_heating_xwidth", "local_heating_ywidth", "local_heating_xcenter", "local_heating_ycenter",
+                     "local_heating_vert_decay")
+_HS_UNUSED_PARAMETERS = ("local_heating_file", "u_wind_file", "v_wind_file", "equilibrium_t_file", "p_trop", "alpha",
                          "peri_time", "smaxis", "albedo", "lapse", "h_a", "tau_s", "orbital_period", "heat_capacity", "ml_depth", "spinup_time",
                          "stratosphere_t_option")
 
@@ -293,8 +294,16 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
                     continue
                 if k == "local_heating_option" and str(v).strip() == "" or k == "relax_to_specified_wind" and not v:
                     continue
-                if k in ("local_heating_option", "relax_to_specified_wind"):
-                    raise IscaError(f"hs_forcing_nml: {k} = {v!r} is not carried by the device core (only the Held-Suarez forcing, or no_forcing)")
+                if k == "local_heating_option" and str(v).strip() == "Isidoro":      # the analytic heat source (hs_forcing.F90:728-769); its parameters below
+                    kw["local_heating_option"] = 1
+                    continue
+                if k == "local_heating_option":       # 'from_file' (interpolator_mod's data) or anything else: the reference's own message for an unknown value
+                    raise IscaError(f'hs_forcing_nml: "{v}" is not a supported value for local_heating_option (only \'\' and \'Isidoro\')')
+                if k == "relax_to_specified_wind":
+                    raise IscaError(f"hs_forcing_nml: {k} = {v!r} is not carried by the device core (it needs interpolator_mod's wind files)")
+                if k in _HS_LOCAL_HEATING:            # handed on: used when local_heating_option = 'Isidoro', without effect otherwise
+                    kw[k] = float(v)
+                    continue
                 if k in _HS_UNUSED_PARAMETERS:        # values of the branches above, without effect while those are off
                     continue
             if k in ("days", "hours", "minutes", "seconds", "calendar", "current_date", "print_interval", "num_steps", "json_logging",
@@ -309,7 +318,7 @@ def config_from_namelist(namelist: dict | str | None, resolution: str | None = N
             kw[k] = tuple(v) if isinstance(v, list) else v
     kw.update(overrides)
     if no_forcing:      # zero coefficients give exactly zero tendencies in the fused forcing (0 * finite); no tracer source or sink for any entry
-        kw.update(ka=0.0, ks=0.0, kf=0.0, trflux=0.0, trsink=0.0)
+        kw.update(ka=0.0, ks=0.0, kf=0.0, trflux=0.0, trsink=0.0, local_heating_option=0)
         for k in ("tracer_sms", "tracer_flux", "tracer_sink"):
             kw.pop(k, None)
     return dyncore.default_config(resolution, **kw)

@@ -110,6 +110,9 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
   // moist package (physics = 1): module defaults overridden by frierson_test_case.py:49-170
   c->physics = 0; c->vert_coord_input = 0;
   for (int k = 0; k < ISCA_MAX_TRACERS; ++k) { c->tracer_spectral[k] = 0; c->tracer_robert_coeff[k] = -1.0; }
+  // hs_forcing_nml's local heating (hs_forcing.F90:87-94): off, with the module's default shape
+  c->local_heating_option = 0; c->local_heating_srfamp = 0.0; c->local_heating_xwidth = 10.; c->local_heating_ywidth = 10.;
+  c->local_heating_xcenter = 180.; c->local_heating_ycenter = 45.; c->local_heating_vert_decay = 1.e4;
   c->use_virtual_temperature = 0;
   c->vert_advect_uv = 0; c->vert_advect_t = 0; c->use_implicit = 1; c->make_symmetric = 0;
   c->vert_difference_option = 0;
@@ -209,6 +212,11 @@ static void check_config(const isca_dyn_config &c) {
     if (c.tracer_advect_vert[k] < -1 || c.tracer_advect_vert[k] > 3)
       fail("spectral_dynamics_init: tracer_advect_vert must be -1 (the representation's standard scheme) or 0..3 (second_centered, fourth_centered, "
            "van_leer_linear, finite_volume_parabolic): any other advect_vert is invalid");
+  if (c.local_heating_option != 0 && c.local_heating_option != 1)
+    fail("hs_forcing_nml: local_heating_option must be 0 ('': none) or 1 ('Isidoro'); 'from_file' is not a supported value (interpolator_mod's data files)");
+  if (c.local_heating_option == 1 && c.physics != 0) fail("hs_forcing_nml: local_heating_option belongs to hs_forcing (physics = 0)");
+  if (c.local_heating_option == 1 && (c.local_heating_xwidth == 0. || c.local_heating_ywidth == 0. || c.local_heating_vert_decay == 0.))
+    fail("hs_forcing_nml: local_heating_xwidth, local_heating_ywidth and local_heating_vert_decay must not be zero");
   if (c.num_tracers > 0 && c.tracer_spectral[0] != 0)
     fail("spectral_dynamics_init: the first tracer of the field_table (the humidity the water fixer and the physics know) is a 'grid' tracer here: "
          "numerical_representation 'spectral' is not a supported value for it");
@@ -404,6 +412,21 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.cosm_lat_l = dupload(h, band(T.cosm_lat)); d.wts_lat_l = dupload(h, band(T.wts_lat));
     d.coriolis_l = dupload(h, band(T.coriolis)); d.sin_lat_l = dupload(h, band(T.sin_lat));
     d.rad_lat_l = dupload(h, band(T.rad_lat)); d.wts_lat_g = dupload(h, T.wts_lat);
+    if (cfg->local_heating_option == 1) {      // hs_forcing_init (:373-384) + local_heating's factors of longitude and latitude (:751-758), srfamp folded into the first
+      const double pi = 3.14159265358979323846, twopi = 2. * pi;
+      const double xw = cfg->local_heating_xwidth * pi / 180., yw = cfg->local_heating_ywidth * pi / 180.;
+      const double xc = cfg->local_heating_xcenter * pi / 180., yc = cfg->local_heating_ycenter * pi / 180.;
+      const double srfamp = cfg->local_heating_srfamp / 86400.;
+      std::vector<double> fx(g.I), fy(T.rad_lat.size());
+      for (int i = 0; i < g.I; ++i) {
+        double lon = T.deg_lon[i] * pi / 180.;
+        lon = lon - twopi * std::floor(lon / twopi);
+        const double z = (lon - xc) / xw;
+        fx[i] = srfamp * std::exp(-.5 * (z * z));
+      }
+      for (size_t j = 0; j < fy.size(); ++j) { const double z = (T.rad_lat[j] - yc) / yw; fy[j] = std::exp(-.5 * (z * z)); }
+      d.lh_lon = dupload(h, fx); d.lh_lat_l = dupload(h, band(fy));
+    }
     // ---- Legendre tables for the local wavenumbers, parity-split (spherical_fourier.F90:376-394)
     {
       std::vector<double> pw((size_t)g.Ml * 2 * g.Jh * g.NHP, 0.0), pi((size_t)g.Ml * 2 * g.NHP * g.Jh, 0.0);
@@ -616,6 +639,9 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
       launch_t_surf_init(*h, h->stream);      // mixed_layer_init without restart file: the prescribed distribution
     }
+    if (hs_forcing_separate(*h)) {            // hs_forcing as a kernel of its own in front of the column kernel (local_heating_option): its three tendency arrays
+      d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3);
+    }
     if (cfg->physics == 2) {                  // the caller's physics: only the arrays its tendencies are handed over in (zero until then)
       d.ph_dtu = dalloc<double>(h, ng3); d.ph_dtv = dalloc<double>(h, ng3); d.ph_dtT = dalloc<double>(h, ng3); d.ph_dtq = dalloc<double>(h, ng3);
       for (double *p : {d.ph_dtu, d.ph_dtv, d.ph_dtT, d.ph_dtq}) HIP_CHECK(hipMemsetAsync(p, 0, ng3 * sizeof(double), h->stream));
@@ -640,7 +666,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // (a vertical advection scheme other than second-centred reads the stored previous level in a kernel of its own: eager fixers)
     const bool vadv_ext = cfg->vert_advect_uv != 0 || cfg->vert_advect_t != 0;
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
-    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext && tr1_std &&
+    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1047,6 +1073,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     HIP_CHECK(hipStreamWaitEvent(h->stream2, h->ev_fork0, 0));
     timed_tracer(h, sc, h->stream2, 0);
   }
+  if (hs_forcing_separate(*h)) { Timed t(h, "hs_forcing"); launch_hs_forcing_step(*h, sc, h->stream); }       // (an hs_forcing_nml option the fused kernel does not carry)
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
   if (h->cfg.vert_advect_uv != 0 || h->cfg.vert_advect_t != 0) { Timed t(h, "vert_advection"); launch_vert_advection_schemes(*h, sc, h->stream); }
   if (h->tracer_on) {

@@ -120,6 +120,7 @@ struct Dev {
   double *partials;                                 // block partial sums
   double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18]
   double *scratch_g[4], *scratch_s[4];              // API transforms
+  double *lh_lon = nullptr, *lh_lat_l = nullptr;     // hs_forcing's local_heating_option = 'Isidoro': srfamp x the longitude factor [I], the latitude factor [Jl]
   // ---- moist physics package (physics = 1)
   double *ph_dtu = nullptr, *ph_dtv = nullptr, *ph_dtT = nullptr, *ph_dtq = nullptr;   // tendencies returned by idealized_moist_phys
   double *t_surf = nullptr, *precip = nullptr;      // [Jl][I] mixed-layer temperature; rain rate of the last step

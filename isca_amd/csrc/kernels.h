@@ -88,6 +88,8 @@ void launch_leapfrog_a(size_t n, const double *prev, double *cur, double *fut, c
 void launch_leapfrog_b(size_t n, double *cur, double *fut, const double *part, double robert, double raw, hipStream_t s);
 void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, const double *dt_trs, hipStream_t s);
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
+bool hs_forcing_separate(const isca_dyn &h);       // an hs_forcing_nml option the fused column kernel does not carry: k_hs_forcing_step in front of it
+void launch_hs_forcing_step(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s, int part = 0);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s, bool patch = true);  // R2 with lazy fixers: reduce + scalars, left pending on the new level

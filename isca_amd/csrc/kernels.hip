@@ -1480,11 +1480,13 @@ struct ColumnArgs {
   const double *pk, *bk, *dpk, *dbk, *cosm, *coriolis, *rad_lat, *wts;
   double delta_t, tka, tks, vkf, sigma_b, t_zero, delh, delv, eps, t_strat, P00;
   int do_conserve_energy;
+  const double *lh_lon, *lh_lat;           // local_heating_option = 'Isidoro' (hs_forcing.F90:728-769): srfamp x longitude factor [I], latitude factor [Jl]; null = off
+  double lh_decay;                         // local_heating_vert_decay
 };
 
 __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double ps, double p_full, double up, double vp,
                                          double tp, double sin_lat, double sin2, double cos2, double cos4,
-                                         double &utnd, double &vtnd, double &ttnd) {
+                                         double &utnd, double &vtnd, double &ttnd, double lh_xy = 0.0) {
   // rayleigh_damping (:615-679), dissipative heating (:198-200), newtonian_damping (:508-611)
   const double sigma = p_full * (1. / ps);
   const bool bl = (sigma <= 1.0) && (sigma > a.sigma_b);
@@ -1503,6 +1505,7 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
   teq = fmax(teq, tstr);
   const double tdamp = bl ? a.tka + cos4 * (tcoeff * (sigma - a.sigma_b)) : a.tka;
   ttnd = ttnd + (-tdamp * (tp - teq));
+  if (a.lh_lon) ttnd = ttnd + lh_xy * exp((p_full - ps) / a.lh_decay);      // local_heating (:233-235, :760-761)
 }
 
 // Block = 64 consecutive columns x NW wavefronts; wavefront w owns the contiguous levels [w*CH, w*CH+CH).
@@ -1740,6 +1743,7 @@ void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, doubl
   const size_t n = (size_t)h.g.L * h.g.Jl * h.g.I;
   hipLaunchKernelGGL(k_virtual_t, grid1d(n), dim3(256), 0, s, n, t, q, tv);
 }
+bool hs_forcing_separate(const isca_dyn &h) { return h.cfg.physics == 0 && h.cfg.local_heating_option != 0; }
 void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   const Dev &d = h.d;
@@ -1769,14 +1773,15 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
   a.tv = virtual_t_on(h) ? d.tv : nullptr;
+  const bool ext = h.cfg.physics != 0 || hs_forcing_separate(h);      // the physics tendencies come from arrays (a package's, or k_hs_forcing_step's)
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
 #define LC(N) do { \
     if (h.cfg.vert_difference_option == 1) { \
-      if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true, true>), grid, block, lds, s, g, a); } \
-      else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false, true>), grid, block, lds, s, g, a); \
+      if (a.tv) { if (ext) hipLaunchKernelGGL((k_column<N, true, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true, true>), grid, block, lds, s, g, a); } \
+      else if (ext) hipLaunchKernelGGL((k_column<N, true, false, true>), grid, block, lds, s, g, a); \
       else hipLaunchKernelGGL((k_column<N, false, false, true>), grid, block, lds, s, g, a); } \
-    else if (a.tv) { if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
-    else if (h.cfg.physics != 0) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
+    else if (a.tv) { if (ext) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
+    else if (ext) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
     else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
   if (thin) {
     static const bool late = getenv("ISCA_COLUMN_LATE") != nullptr;      // the six previous-level / gradient fields loaded below the barrier (fewer registers, a second round trip)
@@ -1955,8 +1960,47 @@ __global__ void k_hs_forcing(Geom g, ColumnArgs a, double dt, const double *__re
   const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
   const double ps = p_half[(size_t)g.L * lev + c2];
   double ut, vt, tt;
-  hs_level(a, dt, ps, p_full[idx], u[idx], v[idx], t[idx], sin_lat, sin2, cos2, cos4, ut, vt, tt);
+  const double lh_xy = a.lh_lon ? a.lh_lon[c2 - (size_t)jl * g.I] * a.lh_lat[jl] : 0.0;
+  hs_level(a, dt, ps, p_full[idx], u[idx], v[idx], t[idx], sin_lat, sin2, cos2, cos4, ut, vt, tt, lh_xy);
   udt[idx] += ut; vdt[idx] += vt; tdt[idx] += tt;
+}
+// hs_forcing of the STEP as a kernel of its own, for hs_forcing_nml options the fused column kernel does not carry (local_heating_option): previous-level
+// u, v, T with the current level's pressures (atmosphere.F90:304-311), the tendencies into the arrays the column kernel reads a physics package's from
+// (k_column<CH, EXT = true>).  One thread per (column, level); p_full as the column kernel forms it (exp of the Simmons-Burridge ln p_full, or 'mcm').
+__global__ void k_hs_forcing_step(Geom g, ColumnArgs a, double dt, const double *__restrict__ psg, const double *__restrict__ u, const double *__restrict__ v,
+                                  const double *__restrict__ t, double *udt, double *vdt, double *tdt, int mcm) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lev = (size_t)g.Jl * g.I;
+  if (idx >= lev * g.L) return;
+  const int k = (int)(idx / lev);
+  const size_t c2 = idx - (size_t)k * lev;
+  const int jl = c2 / g.I;
+  const double sin_lat = sin(a.rad_lat[jl]);
+  const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
+  const double ps = psg[c2];
+  const double ph_k = a.pk[k] + a.bk[k] * ps, ph_n = a.pk[k + 1] + a.bk[k + 1] * ps;
+  double p_full;
+  if (mcm) p_full = 0.5 * (ph_n + ph_k);
+  else {
+    const bool top0 = (a.pk[0] == 0.0 && a.bk[0] == 0.0);
+    const double l_n = log(ph_n);
+    p_full = (top0 && k == 0) ? exp(l_n - 1.0) : exp(l_n - (1.0 - ph_k * (l_n - log(ph_k)) / (ph_n - ph_k)));
+  }
+  const double lh_xy = a.lh_lon ? a.lh_lon[c2 - (size_t)jl * g.I] * a.lh_lat[jl] : 0.0;
+  double ut, vt, tt;
+  hs_level(a, dt, ps, p_full, u[idx], v[idx], t[idx], sin_lat, sin2, cos2, cos4, ut, vt, tt, lh_xy);
+  udt[idx] = ut; vdt[idx] = vt; tdt[idx] = tt;
+}
+void launch_hs_forcing_step(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  const Dev &d = h.d;
+  ColumnArgs a = {};
+  a.rad_lat = d.rad_lat_l; a.pk = d.pk; a.bk = d.bk;
+  a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
+  a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
+  a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
+  a.lh_lon = d.lh_lon; a.lh_lat = d.lh_lat_l; a.lh_decay = h.cfg.local_heating_vert_decay;
+  hipLaunchKernelGGL(k_hs_forcing_step, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, sc.delta_t, d.psg[sc.cur], d.ug[sc.prev], d.vg[sc.prev],
+                     d.tg[sc.prev], d.ph_dtu, d.ph_dtv, d.ph_dtT, h.cfg.vert_difference_option == 1 ? 1 : 0);
 }
 void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const double *p_full, const double *u,
                        const double *v, const double *t, double *udt, double *vdt, double *tdt, hipStream_t s) {
@@ -1965,6 +2009,7 @@ void launch_hs_forcing(const isca_dyn &h, double dt, const double *p_half, const
   a.tka = h.tab.tka; a.tks = h.tab.tks; a.vkf = h.tab.vkf; a.sigma_b = h.cfg.sigma_b;
   a.t_zero = h.cfg.t_zero; a.delh = h.cfg.delh; a.delv = h.cfg.delv; a.eps = h.cfg.eps; a.t_strat = h.cfg.t_strat;
   a.P00 = h.cfg.P00; a.do_conserve_energy = h.cfg.do_conserve_energy;
+  a.lh_lon = h.d.lh_lon; a.lh_lat = h.d.lh_lat_l; a.lh_decay = h.cfg.local_heating_vert_decay;
   hipLaunchKernelGGL(k_hs_forcing, grid1d((size_t)h.g.Jl * h.g.I * h.g.L), dim3(256), 0, s, h.g, a, dt, p_half, p_full, u, v, t, udt, vdt, tdt);
 }
 

@@ -68,6 +68,9 @@ class _CConfig(C.Structure):
         ("vert_difference_option", C.c_int), ("tracer_hole_filling", C.c_int * MAX_TRACERS),
         ("tracer_sms", C.c_int * MAX_TRACERS), ("tracer_flux", C.c_double * MAX_TRACERS), ("tracer_sink", C.c_double * MAX_TRACERS),
         ("tracer_advect_vert", C.c_int * MAX_TRACERS),
+        ("local_heating_option", C.c_int), ("local_heating_srfamp", C.c_double), ("local_heating_xwidth", C.c_double),
+        ("local_heating_ywidth", C.c_double), ("local_heating_xcenter", C.c_double), ("local_heating_ycenter", C.c_double),
+        ("local_heating_vert_decay", C.c_double),
     ]
 
 

@@ -107,6 +107,13 @@ class Config:
     trflux: float = 1.0e-5
     trsink: float = -4.0
     P00: float = 1.0e5
+    local_heating_option: str = ""          # '' or 'Isidoro' (hs_forcing.F90:87-94, 728-769)
+    local_heating_srfamp: float = 0.0
+    local_heating_xwidth: float = 10.0
+    local_heating_ywidth: float = 10.0
+    local_heating_xcenter: float = 180.0
+    local_heating_ycenter: float = 45.0
+    local_heating_vert_decay: float = 1.0e4
 
     @staticmethod
     def resolution(name: str, num_levels: int, **kw) -> "Config":
@@ -553,6 +560,17 @@ class SpectralCore:
         teq = np.maximum(the * p_norm ** KAPPA, tstr)
         tdamp = np.where(bl, self.tka + cos_lat_4 * (tcoeff * (sigma - c.sigma_b)), self.tka)
         tdt = tdt + (-tdamp * (t - teq))
+        if c.local_heating_option == "Isidoro":                             # local_heating :233-238, :750-764
+            rad = np.pi / 180.0
+            xw, yw, xc, yc = c.local_heating_xwidth * rad, c.local_heating_ywidth * rad, c.local_heating_xcenter * rad, c.local_heating_ycenter * rad
+            srfamp = c.local_heating_srfamp / 86400.0
+            lon = np.arange(self.I) * 360.0 / self.I * rad
+            lon = lon - 2 * np.pi * np.floor(lon / (2 * np.pi))
+            lon_factor = np.exp(-0.5 * ((lon - xc) / xw) ** 2)[None, :]
+            lat_factor = np.exp(-0.5 * ((self.rad_lat - yc) / yw) ** 2)[:, None]
+            tdt = tdt + srfamp * lon_factor * lat_factor * np.exp((p_full - ps) / c.local_heating_vert_decay)
+        elif c.local_heating_option != "":
+            raise ValueError('"%s"  is not a valid value for local_heating_option' % c.local_heating_option)
         out = [utnd, vtnd, tdt]
         if tr is not None:                                                   # :240-263, 683-724
             rst = tr + dt * tr_dt

@@ -699,6 +699,12 @@ def main():
         "run_T21L8_no_forcing": lambda: golden_run(
             "T21", 8, 48, (1, 2, 48), extra_groups=GAUSSIAN_TOPOG_GROUPS, hs_extra="no_forcing = .true.",
             keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_", k) is not None),
+        # hs_forcing_nml: local_heating_option = 'Isidoro' (hs_forcing.F90:728-769): a Gaussian heat source of 5 K/day at the ground over (120E, 20N),
+        # decaying upward with a scale of 300 hPa, on top of the Held-Suarez forcing
+        "run_T21L8_isidoro": lambda: golden_run(
+            "T21", 8, 48, (1, 2, 48), hs_extra="local_heating_option = 'Isidoro', local_heating_srfamp = 5.0, local_heating_xwidth = 25., "
+            "local_heating_ywidth = 12., local_heating_xcenter = 120., local_heating_ycenter = 20., local_heating_vert_decay = 3.e4",
+            keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_", k) is not None),
         "run_T21L8_damping_vor_div": lambda: golden_run(
             "T21", 8, 36, (36,), extra="damping_option = 'resolution_dependent', damping_order = 4, damping_coeff_vor = 3.0e-4, damping_order_vor = 2, "
             "damping_coeff_div = 6.0e-4, damping_order_div = 3", keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_000036$", k) is not None),

@@ -149,6 +149,10 @@ def test_atmosphere_mod_queues_steps(tmp_path):
     assert ms_dropin < 1.25 * ms_lib + 0.01, (ms_dropin, ms_lib)
 
 
+ISIDORO = ("local_heating_option = 'Isidoro', local_heating_srfamp = 5.0, local_heating_xwidth = 25., local_heating_ywidth = 12., "
+           "local_heating_xcenter = 120., local_heating_ycenter = 20., local_heating_vert_decay = 3.e4")
+
+
 @pytest.mark.parametrize("fixture,levels,nsteps,extra,groups", [
     ("run_T21L8_topography", 8, 36, "", "topo"),
     ("run_T21L12_hybrid_option", 12, 24,
@@ -157,20 +161,21 @@ def test_atmosphere_mod_queues_steps(tmp_path):
     ("run_T21L8_symmetric", 8, 48, "make_symmetric = .true.", ""),
     ("run_T21L14_mcm_coord", 14, 36, "vert_difference_option = 'mcm', vert_coord_option = 'mcm'", ""),
     ("run_T21L8_no_forcing", 8, 48, "", "topo+no_forcing"),
+    ("run_T21L8_isidoro", 8, 48, "", "isidoro"),
 ])
 def test_atmosphere_mod_options_from_fortran(tmp_path, golden_dir, fixture, levels, nsteps, extra, groups):
     """Options the drop-in front end forwards instead of refusing, each from the reference's own input.nml through atmos_model's loop on
     this repository's atmosphere_mod, against the reference run's final extremes: topography_option = 'gaussian' (gaussian_topog_nml through
     the reference's gaussian_topog_mod, spectral_init_cond.F90:299-303), vert_coord_option = 'hybrid' (compute_vert_coord,
     vert_coordinate.F90:124-152, formed in Fortran), vert_advect_uv / vert_advect_t, make_symmetric, vert_difference_option = 'mcm' on the 'mcm' levels, hs_forcing_nml's no_forcing
-    (hs_forcing.F90:174) over the Gaussian mountains."""
+    (hs_forcing.F90:174) over the Gaussian mountains, and its local_heating_option = 'Isidoro' (hs_forcing.F90:728-769)."""
     exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
     from oracle import make_golden as mg
     d = str(tmp_path / "run")
     mg.prepare_rundir(d, "T21", levels, "run", nsteps=nsteps, dt=600, extra=extra, extra_groups=mg.GAUSSIAN_TOPOG_GROUPS if groups.startswith("topo") else "",
-                      hs_extra="no_forcing = .true." if groups.endswith("no_forcing") else "")
+                      hs_extra="no_forcing = .true." if groups.endswith("no_forcing") else ISIDORO if groups == "isidoro" else "")
     open(os.path.join(d, "drive.nml"), "w").write(f" &drive_nml\n   nsteps = {nsteps}, dt_atmos = 600\n /\n")
     stdout = mg.run_harness(d, exe=exe, timeout=900)
     g = np.load(os.path.join(golden_dir, fixture + ".npz"))

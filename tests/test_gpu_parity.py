@@ -826,9 +826,42 @@ def test_golden_no_forcing(golden_dir):
             assert not dc.get("tr").any() and not g[f"st_tr1_{n:06d}"].any()
     finally:
         atm.atmosphere_end()
-    nml["hs_forcing_nml"]["local_heating_option"] = "Isidoro"
-    with pytest.raises(dyncore.IscaError, match="local_heating_option = 'Isidoro' is not carried"):
+    nml["hs_forcing_nml"]["local_heating_option"] = "from_file"
+    with pytest.raises(dyncore.IscaError, match='"from_file" is not a supported value for local_heating_option'):
         atm.atmosphere_init(nml, resolution="T21")
+
+
+def test_golden_isidoro_local_heating(golden_dir):
+    """hs_forcing_nml: local_heating_option = 'Isidoro' (hs_forcing.F90:233-238, 728-769): a Gaussian heat source in longitude and latitude that decays
+    upward from the surface, added to the Held-Suarez temperature tendency.  On the device it is one extra kernel ahead of the column kernel
+    (k_hs_forcing_step), so that the fused Held-Suarez column keeps its registers when the option is off.  48 steps at T21L8 against the
+    reference run; the heating is there (the same run without it differs by far more than the tolerance)."""
+    from isca_amd import atmosphere as atm, configs
+    g = np.load(os.path.join(golden_dir, "run_T21L8_isidoro.npz"))
+    nml = configs.held_suarez()
+    nml["spectral_dynamics_nml"]["num_levels"] = 8
+    nml["hs_forcing_nml"].update(local_heating_option="Isidoro", local_heating_srfamp=5.0, local_heating_xwidth=25., local_heating_ywidth=12.,
+                                 local_heating_xcenter=120., local_heating_ycenter=20., local_heating_vert_decay=3.e4)
+    dc = atm.atmosphere_init(nml, resolution="T21")
+    try:
+        done = 0
+        for n in (1, 2, 48):
+            atm.atmosphere(n - done); done = n
+            err = {k: float(np.abs(dc.get(k) - g[f"st_{k}_{n:06d}"]).max() / max(np.abs(g[f"st_{k}_{n:06d}"]).max(), 1.0 if k in ("ug", "vg") else 1e-300))
+                   for k in ("ug", "vg", "tg", "psg")}
+            print("isidoro, step", n, err)
+            assert max(err.values()) < 1e-9, (n, err)
+        assert rel(dc.get("tr").reshape(g["st_tr1_000048"].shape), g["st_tr1_000048"]) < 1e-9
+        warm = dc.get("tg").copy()
+    finally:
+        atm.atmosphere_end()
+    nml["hs_forcing_nml"]["local_heating_option"] = ""
+    dc = atm.atmosphere_init(nml, resolution="T21")
+    try:
+        atm.atmosphere(48)
+        assert np.abs(dc.get("tg") - warm).max() > 0.1          # (K, after 12 h of 5 K/day at the centre)
+    finally:
+        atm.atmosphere_end()
 
 
 def test_golden_topography(golden_dir, tmp_path):

@@ -582,7 +582,12 @@ def test_hs_forcing_nml_no_forcing_and_inert_keys():
     nml["hs_forcing_nml"]["no_forcing"] = False
     c = atm.config_from_namelist(nml, "T21")
     assert (c.ka, c.kf, c.trflux) == (-40.0, -1.0, 1.e-5)
-    for key, val in (("local_heating_option", "Isidoro"), ("relax_to_specified_wind", True)):
+    iso = configs.held_suarez(); iso["hs_forcing_nml"].update(local_heating_option="Isidoro", local_heating_srfamp=5.0, local_heating_xcenter=120.0)
+    c = atm.config_from_namelist(iso, "T21")
+    assert (c.local_heating_option, c.local_heating_srfamp, c.local_heating_xcenter, c.local_heating_ycenter) == (1, 5.0, 120.0, 45.0)
+    iso["hs_forcing_nml"]["no_forcing"] = True
+    assert atm.config_from_namelist(iso, "T21").local_heating_option == 0
+    for key, val in (("local_heating_option", "from_file"), ("relax_to_specified_wind", True)):
         bad = configs.held_suarez(); bad["hs_forcing_nml"][key] = val
         with pytest.raises(IscaError, match=key):
             atm.config_from_namelist(bad, "T21")

@@ -323,6 +323,24 @@ def test_topography_and_no_forcing(golden_dir, name, coeffs, marks):
                 assert not sc.tr[sc.current].any() and not g[f"st_tr1_{tag}"].any()
 
 
+def test_isidoro_local_heating(golden_dir):
+    """hs_forcing_nml: local_heating_option = 'Isidoro' (hs_forcing.F90:233-238, 728-769) in the numpy restatement against the reference run."""
+    g = np.load(os.path.join(golden_dir, "run_T21L8_isidoro.npz"))
+    sc = core("T21", 8, local_heating_option="Isidoro", local_heating_srfamp=5.0, local_heating_xwidth=25., local_heating_ywidth=12.,
+              local_heating_xcenter=120., local_heating_ycenter=20., local_heating_vert_decay=3.e4)
+    sc.cold_start()
+    for i in range(1, 49):
+        sc.step()
+        if i in (1, 2, 48):
+            s, tag = sc.state(), f"{i:06d}"
+            for k in ("ug", "vg"):
+                assert np.max(np.abs(s[k] - g[f"st_{k}_{tag}"])) < 1e-11, (k, tag)
+            assert rel(s["tg"], g[f"st_tg_{tag}"]) < 1e-12 and rel(s["psg"], g[f"st_psg_{tag}"]) < 1e-12
+    plain = core("T21", 8); plain.cold_start(); plain.step()
+    sc2 = core("T21", 8, local_heating_option="Isidoro", local_heating_srfamp=5.0); sc2.cold_start(); sc2.step()
+    assert np.abs(sc2.state()["tg"] - plain.state()["tg"]).max() > 1e-3
+
+
 @pytest.mark.parametrize("name,options", [
     ("run_T21L8_vadv_fourth", dict(vert_advect_uv="fourth_centered", vert_advect_t="fourth_centered")),
     ("run_T21L8_vadv_finite_volume", dict(vert_advect_uv="van_leer_linear", vert_advect_t="finite_volume_parabolic")),
