@@ -550,6 +550,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
     d.halo_send = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers)); d.halo_recv = dalloc<double>(h, 2 * halo_doubles(g, cfg->num_tracers));
     d.kmask = dalloc<int>(h, ng2 + 2); d.kmask_old = dalloc<int>(h, ng2 + 2); d.wcol = dalloc<double>(h, 5 * ng2); d.psp_copy = dalloc<double>(h, ng2);
+    d.w0blk = dalloc<double>(h, (size_t)g.L * (g.Jl / 4 + 1)); d.w0blk_x = dalloc<double>(h, (size_t)g.L * (g.Jl / 4 + 1));
     d.pend = dupload(h, std::vector<double>(PEND_ROWS, PEND_ROWS + 12));
     for (int e = 0; e + 1 < cfg->num_tracers; ++e) {     // tracers 2..: zero until set (cold start: spectral_init_cond.F90 leaves them 0)
       for (int t = 0; t < 2; ++t) {
@@ -619,6 +620,9 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       const char *e = getenv("ISCA_TRACER_EARLY");
       h->tracer_early = e && e[0] == '1';
     }
+    // ISCA_TRACER_FILTER_IN_VERT=1 (measurement / test switch): the first half of the tracer's Robert filter and the water fixer's "before" sum stay in the
+    // vertical kernel (TracerArgs.filt_horiz off), as they were until round 5
+    h->tracer_filter_in_vert = getenv("ISCA_TRACER_FILTER_IN_VERT") != nullptr;
     // The grid tracer's transport kernels (van Leer with 2-row halos, PPM with a 5-level stencil) need >= 4 latitude rows per rank and
     // >= 5 levels.  A configuration that asks for the tracer where it cannot run is FATAL -- it used to be dropped without a word;
     // num_tracers = 0 is the way to run without one (field_table without tracers).
@@ -1067,6 +1071,9 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   // step starts (the column kernel's mask word of the step BEFORE: kmask_old), so it can start beside the column kernel (tracer_early:
   // measured, not faster).  Joined before the fixer sums.
   const bool side = h->tracer_on && h->g.P == 1 && !h->tracer_serial, early = side && h->tracer_early;
+  // (the filter's first half in the horizontal kernel: not on the first step, where previous and current level share their storage; not when that kernel
+  // starts before the column kernel, which leaves the copy of the previous surface pressure it would sum with and reads the unfiltered current level)
+  h->tr_filt_horiz = h->tracer_on && sc.prev != sc.cur && !early && !h->tracer_filter_in_vert;
   std::swap(h->d.kmask, h->d.kmask_old);          // the column kernel reads the old word and writes the new one
   if (early) {
     HIP_CHECK(hipEventRecord(h->ev_fork0, h->stream));

@@ -106,6 +106,7 @@ struct Dev {
                              // tracer kernel reads, so that it does not depend on this step's column kernel
   double *pend;              // [3][4] fixer scalars PENDING on time level 0 / 1 (mass factor, temperature correction, water factor, -); row 2: identity
   double *wcol;              // [5][Jl][I] column sums for the water fixer
+  double *w0blk = nullptr, *w0blk_x = nullptr;   // [L][row blocks] the horizontal tracer kernel's weighted sums of q0 (TracerArgs.filt_horiz); _x: further tracers (unused sums)
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
   double *fv_rcdx, *fv_rdyy, *fv_rcdy, *fv_rdy;              // reciprocals used by the kernels
   double *ppm_tab;           // [6][L] pure-sigma PPM slope / edge weights
@@ -171,6 +172,8 @@ struct isca_dyn {
   bool fuse_synth = false;
   bool dx_fourier = false;          // the step's synthesis batch carries no x-derivative fields: k_fft_inv3 forms dT/dx and d ln ps/dx from the Fourier rows of T and ln ps
   bool fuse_fwd = false;            // FFT + Legendre analysis of the step's forward batch in one kernel (ISCA_FUSE_FFT_LEG)
+  bool tr_filt_horiz = false;       // this step: the tracer filter's first half and the "water before" sum are the horizontal kernel's (TracerArgs.filt_horiz)
+  bool tracer_filter_in_vert = false;   // ISCA_TRACER_FILTER_IN_VERT=1
   bool tracer_serial = false;       // debugging/profiling: run the tracer kernels on the main stream
   bool tracer_early = false;        // the horizontal tracer kernel forks BEFORE the column kernel (ISCA_TRACER_EARLY=1; see spectral_dynamics_init)
   bool tracer_on = false;           // advect the grid tracer

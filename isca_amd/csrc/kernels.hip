@@ -2172,6 +2172,12 @@ struct TracerArgs {
   const double *pend_a, *pend_c;
   double rb;
   size_t halo_q;                             // offset of this tracer's q0 rows in the halo buffers (0: tracer 1; 3 + e field blocks: tracer e + 2)
+  // filt_horiz: the horizontal kernel -- which holds the previous and the current level of its own rows anyway -- does what needs nothing of the
+  // transport: the first half of the Robert filter (tr_cur, tr_part) and the water fixer's sum over q0 ("before": one weighted sum per block into
+  // w0blk[level][row block]); the vertical kernel then reads two fields instead of five and writes one instead of two.  Off on the very first step
+  // (previous and current level are the same storage there: a block would filter rows its neighbours still read) and with ISCA_TRACER_FILTER_IN_VERT=1.
+  int filt_horiz;
+  double *w0blk;
 };
 
 // tracer_source_sink (hs_forcing.F90:683-724): surface flux into the lowest level, linear sink
@@ -2227,8 +2233,18 @@ template <bool P2> __device__ __forceinline__ int wrap_lon(int x, int I) {
   const int w = x % I;
   return w < 0 ? w + I : w;
 }
+// The kernel stores early (the filtered current level, TracerArgs.filt_horiz) and reads its per-row tables after that: through the constant address
+// space, so that they stay scalar loads (an ordinary load behind a store that may alias goes down the vector path: 133 -> 37 s_load without this).
+typedef const double __attribute__((address_space(4))) kdouble;
+struct TracerTabs {
+  kdouble *cc, *dyp, *dym, *rcdx, *rdyy, *rcdy, *rdy;
+  __device__ explicit TracerTabs(const TracerArgs &a)
+      : cc((kdouble *)a.cc), dyp((kdouble *)a.dyp), dym((kdouble *)a.dym), rcdx((kdouble *)a.rcdx), rdyy((kdouble *)a.rdyy), rcdy((kdouble *)a.rcdy),
+        rdy((kdouble *)a.rdy) {}
+};
 template <int WPE, bool P2 = true>
 __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a) {
+  const TracerTabs T(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RB = TR_RB, NR = RB + 4;
   const int I = g.I, J = g.J;
@@ -2277,6 +2293,20 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     tq[r] = *pq; ta[r] = *(loc[r] ? a.tratm_p + q : pq); tu[r] = *pu; tv[r] = *pv;
     tb[r] = *(loc[r] ? a.tr_b + q : pq); kw[r] = a.kmask_old[c2r] << 8;                // what is pending on the previous level (halo rows arrive finished)
   }
+  // my own rows (always local, never across a pole): the current level where it is not tr_b, the previous surface pressure
+  const bool filt = a.filt_horiz != 0, cur_is_b = a.tr_cur_rd == a.tr_b;
+  double tc[RB], pp[RB];
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr) {
+    const int jl = min(j0 + rr - g.j0, g.Jl - 1);
+    const size_t c2 = (size_t)jl * I + i;
+    tc[rr] = (filt && !cur_is_b) ? a.tr_cur_rd[(size_t)k * lev + c2] : 0.0;
+    pp[rr] = filt ? a.ps_prev[c2] : 0.0;
+  }
+  const double wfac_c = a.pend_c[PEND_WFAC], dpk_k = a.dpk[k], dbk_k = a.dbk[k];
+  double wts_r[RB];
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr) wts_r[rr] = a.wts[min(j0 + rr - g.j0, g.Jl - 1)];
   double psr[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {                                                // surface flux only enters the lowest level
@@ -2284,11 +2314,30 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     psr[r] = (k == g.L - 1 && loc[r]) ? mul_nc(a.ps_cur[(size_t)(jsrc[r] - g.j0) * I + is], a.pend_c[PEND_FACTOR]) : 1.0;
   }
   double q0r[NR], vr[NR];                                                       // own-longitude values stay in registers
+  double w0 = 0.0, newc[RB], part[RB];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    q0r[r] = loc[r] ? tr_q0_of(a, g, k, tr_prev_of(a, k, kw[r], tq[r], tb[r]), tr_atm_of(a, k, kw[r], ta[r]), psr[r]) : tq[r];
+    const double tbc = water_corr(tb[r], k, kmask_byte(kw[r], 1), wfac_c), tpv = fma(a.rb, tbc, tq[r]);      // (= tr_prev_of)
+    q0r[r] = loc[r] ? tr_q0_of(a, g, k, tpv, tr_atm_of(a, k, kw[r], ta[r]), psr[r]) : tq[r];
     vr[r] = mir[r] ? -tv[r] : tv[r];
     qs[r * I + i] = q0r[r];
+    if (r >= 2 && r < 2 + RB) {
+      // leapfrog part A on the grid tracer (spectral_dynamics.F90:1164-1167; robert includes raw_filter_coeff): the current level with what is pending on it
+      const double tcv = cur_is_b ? tbc : water_corr(tc[r - 2], k, kmask_byte(kw[r], 1), wfac_c);
+      part[r - 2] = tpv - 2.0 * tcv;                                            // part_filt_tr (:1164), for the future half of the RAW filter
+      newc[r - 2] = tcv + a.robert * part[r - 2];
+      if (j0 + r - 2 < g.j0 + g.Jl) w0 += wts_r[r - 2] * (q0r[r] * (dpk_k + dbk_k * pp[r - 2]));     // water before (initialize_corrections :1332-1333), area weight applied here
+    }
+  }
+  if (filt) {
+    q2[i] = w0;
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+      if (j0 + rr < g.j0 + g.Jl) {
+        const size_t q = (size_t)k * lev + (size_t)(j0 + rr - g.j0) * I + i;
+        a.tr_cur[q] = newc[rr];
+        if (a.tr_part) a.tr_part[q] = part[rr];
+      }
   }
 #pragma unroll
   for (int rr = 0; rr < RB; ++rr) {
@@ -2297,11 +2346,22 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
   }
   if (i < RB) any_big[i] = 0;
   __syncthreads();
+  if (a.filt_horiz && wv == 0) {                                                // (q2 is next written behind the second barrier)
+    double t0 = 0.0;
+    for (int x = lane; x < I; x += 64) t0 += q2[x];
+    const int nact = min(I, 64);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_down(t0, off, 64);
+      if (lane + off < nact) t0 += o;
+    }
+    if (lane == 0) a.w0blk[(size_t)k * gridDim.x + tbx] = t0;
+  }
   const double hdt = 0.5 * a.dt;
   double q1r[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {      // semi_x (:376-411) on each source row
-    const double b = tu[r] * hdt * a.rcdx[jsrc[r]];
+    const double b = tu[r] * hdt * T.rcdx[jsrc[r]];
     const double fb = floor(b);
     const int il = wrap_lon<P2>(i - 1 - (int)fb, I), ir = wrap_lon<P2>(il + 1, I);
     const double bb = b - fb, qc = q0r[r];
@@ -2317,7 +2377,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     if (lane == last) u_r = edge_first[rr][wr];
     ucl[rr] = 0.5 * (u_l + tu[r]);
     ucr[rr] = 0.5 * (tu[r] + u_r);
-    bx[rr] = ucl[rr] * a.dt * a.rcdx[j0 + rr];
+    bx[rr] = ucl[rr] * a.dt * T.rcdx[j0 + rr];
     if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
   }
   __syncthreads();
@@ -2329,11 +2389,11 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     if (jg >= g.j0 + g.Jl) continue;
     const double q0c = q0r[r], va_c = vr[r];
     // semi_y (:415-433)
-    q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (q0r[r - 1] - q0c) * a.rdyy[jg] : va_c * hdt * (q0c - q0r[r + 1]) * a.rdyy[jg + 1]);
+    q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (q0r[r - 1] - q0c) * T.rdyy[jg] : va_c * hdt * (q0c - q0r[r + 1]) * T.rdyy[jg + 1]);
     const double vc_lo = 0.5 * (vr[r - 1] + va_c), vc_hi = 0.5 * (va_c + vr[r + 1]);
     const double uc_i = ucl[rr], uc_p = ucr[rr];
-    const double rcdy = a.rcdy[jg];
-    double dq = q0c * ((vc_hi * a.cc[jg + 1] - vc_lo * a.cc[jg]) * rcdy + (uc_p - uc_i) * a.rcdx[jg]);
+    const double rcdy = T.rcdy[jg];
+    double dq = q0c * ((vc_hi * T.cc[jg + 1] - vc_lo * T.cc[jg]) * rcdy + (uc_p - uc_i) * T.rcdx[jg]);
     const double b = bx[rr];
     __syncthreads();
     // vanleer_x (:308-347): slope_x, integer part of the Courant number, fractional van Leer flux
@@ -2360,13 +2420,13 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
 #pragma unroll
       for (int t = 1; t <= 3; ++t) {
         const int jf = jg + t - 1;     // Fortran row index j' = 0..J+1 of the virtual row
-        sl[t - 1] = vl_limit((q1r[rr + t + 1] - q1r[rr + t]) * a.dyp[jf] + (q1r[rr + t] - q1r[rr + t - 1]) * a.dym[jf],
+        sl[t - 1] = vl_limit((q1r[rr + t + 1] - q1r[rr + t]) * T.dyp[jf] + (q1r[rr + t] - q1r[rr + t - 1]) * T.dym[jf],
                              q1r[rr + t - 1], q1r[rr + t], q1r[rr + t + 1]);
       }
-      double f_lo = (vc_lo >= 0.0) ? vc_lo * a.cc[jg] * (q1r[rr + 1] + 0.5 * sl[0] * (1.0 - a.dt * a.rdy[jg + 1] * vc_lo))
-                                   : vc_lo * a.cc[jg] * (q1r[rr + 2] - 0.5 * sl[1] * (1.0 + a.dt * a.rdy[jg + 2] * vc_lo));
-      double f_hi = (vc_hi >= 0.0) ? vc_hi * a.cc[jg + 1] * (q1r[rr + 2] + 0.5 * sl[1] * (1.0 - a.dt * a.rdy[jg + 2] * vc_hi))
-                                   : vc_hi * a.cc[jg + 1] * (q1r[rr + 3] - 0.5 * sl[2] * (1.0 + a.dt * a.rdy[jg + 3] * vc_hi));
+      double f_lo = (vc_lo >= 0.0) ? vc_lo * T.cc[jg] * (q1r[rr + 1] + 0.5 * sl[0] * (1.0 - a.dt * T.rdy[jg + 1] * vc_lo))
+                                   : vc_lo * T.cc[jg] * (q1r[rr + 2] - 0.5 * sl[1] * (1.0 + a.dt * T.rdy[jg + 2] * vc_lo));
+      double f_hi = (vc_hi >= 0.0) ? vc_hi * T.cc[jg + 1] * (q1r[rr + 2] + 0.5 * sl[1] * (1.0 - a.dt * T.rdy[jg + 2] * vc_hi))
+                                   : vc_hi * T.cc[jg + 1] * (q1r[rr + 3] - 0.5 * sl[2] * (1.0 + a.dt * T.rdy[jg + 3] * vc_hi));
       if (jg == 0) f_lo = 0.0;
       if (jg == J - 1) f_hi = 0.0;
       dq = dq - rcdy * (f_hi - f_lo);
@@ -2445,7 +2505,8 @@ __device__ void ppm_cell_global(const TracerArgs &a, const Geom &g, size_t c2, d
 // Pure sigma coordinates (pk = 0: HYB = false): dz = dbk*ps, so the slope and edge weights of slope_z / compute_weights are independent
 // of the column and come from the host table a.ppm.  Hybrid levels (pk /= 0: HYB = true): the weights are formed per column from the
 // layer thicknesses the thread holds anyway (ppm_slope / ppm_edge, the helpers of the Courant > 1 path).
-template <int CH, int MAXW, bool HYB>      // MAXW = wavefronts per block: 8, or 12 (chunks of 5 levels) for 41..60 levels
+// FILT: the filter's first half and the "water before" sum are done here (a.filt_horiz off); otherwise the horizontal kernel has done them
+template <int CH, int MAXW, bool HYB, bool FILT>      // MAXW = wavefronts per block: 8, or 12 (chunks of 5 levels) for 41..60 levels
 __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a) {
   __shared__ double red[5][MAXW][64];
   const int L = g.L;
@@ -2466,21 +2527,24 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
 #pragma unroll
   for (int t = 0; t <= CH; ++t) wv[t] = a.wg[(size_t)min(k0 + t, L) * lev + c2];
   // what the update at the end needs, requested now with everything else
-  double tpv[CH], tav[CH], tcv[CH];
-#pragma unroll
-  for (int t = 0; t < CH; ++t) {
-    const size_t q = (size_t)min(k0 + t, L - 1) * lev + c2;
-    tpv[t] = a.trp[q]; tav[t] = a.tratm_p[q]; tcv[t] = a.tr_cur_rd[q];
-  }
+  double tpv[FILT ? CH : 1], tav[FILT ? CH : 1], tcv[FILT ? CH : 1];
   const int kmw = a.kmask[c2], km = kmask_byte(kmw, 0);
+  double psp = 0.0;
+  if (FILT) {
 #pragma unroll
-  for (int t = 0; t < CH; ++t) {                 // what is pending on the two older levels (lazy fixers; identities otherwise)
-    const int k = min(k0 + t, L - 1);
-    tcv[t] = water_corr(tcv[t], k, kmask_byte(kmw, 1), a.pend_c[PEND_WFAC]);
-    tpv[t] = fma(a.rb, tcv[t], tpv[t]);
-    tav[t] = tr_atm_of(a, k, kmw, tav[t]);
+    for (int t = 0; t < CH; ++t) {
+      const size_t q = (size_t)min(k0 + t, L - 1) * lev + c2;
+      tpv[t] = a.trp[q]; tav[t] = a.tratm_p[q]; tcv[t] = a.tr_cur_rd[q];
+    }
+#pragma unroll
+    for (int t = 0; t < CH; ++t) {                 // what is pending on the two older levels (lazy fixers; identities otherwise)
+      const int k = min(k0 + t, L - 1);
+      tcv[t] = water_corr(tcv[t], k, kmask_byte(kmw, 1), a.pend_c[PEND_WFAC]);
+      tpv[t] = fma(a.rb, tcv[t], tpv[t]);
+      tav[t] = tr_atm_of(a, k, kmw, tav[t]);
+    }
+    psp = a.ps_prev[c2];
   }
-  const double psp = a.ps_prev[c2];
   // limited slopes of cells k0-2 .. k0+CH+1 (rv index t+2), once each
   double sl[CH + 4];
 #pragma unroll
@@ -2583,13 +2647,15 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
       const double rk = rv[4 + t];
       const double rdt = -(fx[t + 1] - fx[t] - rk * (wv[t + 1] - wv[t])) / dv[4 + t];
       const double trf = rk + a.dt * rdt;
-      // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): everything was read at the top
-      const double q0 = tr_q0_of(a, g, k, tpv[t], tav[t], ps);
-      newc[t] = tcv[t] + a.robert * (tpv[t] - 2.0 * tcv[t]);      // leapfrog part A on the grid tracer (:1164-1167); robert includes raw_filter_coeff
       newf[t] = trf;
-      // column sums: water before (initialize_corrections :1332-1333) and after (compute_corrections :1249-1262)
+      if (FILT) {
+        // tr(prev) aliases tr(fut) from the second step on (and tr(cur) on the first): everything was read at the top
+        const double q0 = tr_q0_of(a, g, k, tpv[t], tav[t], ps);
+        newc[t] = tcv[t] + a.robert * (tpv[t] - 2.0 * tcv[t]);      // leapfrog part A on the grid tracer (:1164-1167); robert includes raw_filter_coeff
+        s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);                     // water before (initialize_corrections :1332-1333)
+      }
+      // column sums of the water after (compute_corrections :1249-1262)
       const double msk = (k >= km) ? 1.0 : 0.0;
-      s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
       s1 += trf * a.dpk[k]; s2 += trf * a.dbk[k];
       s3 += msk * trf * a.dpk[k]; s4 += msk * trf * a.dbk[k];
     }
@@ -2598,12 +2664,15 @@ __global__ __launch_bounds__(64 * MAXW) void k_tracer_vert(Geom g, TracerArgs a)
   for (int t = 0; t < CH; ++t)
     if (t < nk) {
       const size_t q = (size_t)(k0 + t) * lev + c2;
-      a.tr_cur[q] = newc[t]; a.tr_fut[q] = newf[t];
-      if (a.tr_part) a.tr_part[q] = tpv[t] - 2.0 * tcv[t];        // part_filt_tr (:1164), for the future half of the RAW filter
+      a.tr_fut[q] = newf[t];
+      if (FILT) {
+        a.tr_cur[q] = newc[t];
+        if (a.tr_part) a.tr_part[q] = tpv[t] - 2.0 * tcv[t];        // part_filt_tr (:1164), for the future half of the RAW filter
+      }
     }
   red[0][w][tid] = s0; red[1][w][tid] = s1; red[2][w][tid] = s2; red[3][w][tid] = s3; red[4][w][tid] = s4;
   __syncthreads();
-  if (w < 5) {
+  if (w < 5 && (FILT || w > 0)) {
     double s_ = 0.0;
     for (int ww = 0; ww < NW; ++ww) s_ += red[w][ww][tid];
     a.wcol[(size_t)w * lev + c2] = s_;
@@ -2637,16 +2706,19 @@ __global__ __launch_bounds__(64) void k_tracer_vert_scheme(Geom g, TracerArgs a)
   for (int k = 0; k < L; ++k) {
     const size_t q = c2 + (size_t)k * lev;
     const double trf = r[k] + a.dt * rdt[k];
-    const double q0 = tr_q0_of(a, g, k, tpv[k], tav[k], ps);
-    a.tr_cur[q] = tcv[k] + a.robert * (tpv[k] - 2.0 * tcv[k]);
     a.tr_fut[q] = trf;
-    if (a.tr_part) a.tr_part[q] = tpv[k] - 2.0 * tcv[k];
+    if (!a.filt_horiz) {
+      const double q0 = tr_q0_of(a, g, k, tpv[k], tav[k], ps);
+      a.tr_cur[q] = tcv[k] + a.robert * (tpv[k] - 2.0 * tcv[k]);
+      if (a.tr_part) a.tr_part[q] = tpv[k] - 2.0 * tcv[k];
+      s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
+    }
     const double msk = (k >= km) ? 1.0 : 0.0;
-    s0 += q0 * (a.dpk[k] + a.dbk[k] * psp);
     s1 += trf * a.dpk[k]; s2 += trf * a.dbk[k];
     s3 += msk * trf * a.dpk[k]; s4 += msk * trf * a.dbk[k];
   }
-  a.wcol[0 * lev + c2] = s0; a.wcol[1 * lev + c2] = s1; a.wcol[2 * lev + c2] = s2; a.wcol[3 * lev + c2] = s3; a.wcol[4 * lev + c2] = s4;
+  if (!a.filt_horiz) a.wcol[0 * lev + c2] = s0;
+  a.wcol[1 * lev + c2] = s1; a.wcol[2 * lev + c2] = s2; a.wcol[3 * lev + c2] = s3; a.wcol[4 * lev + c2] = s4;
 }
 
 // robert_coeff of field_table entry k+1 (spectral_dynamics.F90:340-351): its own, or the dynamics' one
@@ -2692,6 +2764,7 @@ static TracerArgs tracer_args(const isca_dyn &h, const StepScalars &sc) {
   a.halo_lo = d.halo_recv; a.halo_hi = d.halo_recv + halo_doubles(h.g, h.cfg.num_tracers);
   a.send_lo = d.halo_send; a.send_hi = d.halo_send + halo_doubles(h.g, h.cfg.num_tracers);
   a.halo_q = 0;
+  a.filt_horiz = h.tr_filt_horiz ? 1 : 0; a.w0blk = d.w0blk;
   return a;
 }
 // tracer e + 2 of the field_table (a further 'grid' tracer): the same transport on its own time levels; the column sums go to a spare array
@@ -2700,7 +2773,7 @@ static TracerArgs further_tracer_args(const isca_dyn &h, const StepScalars &sc, 
   TracerArgs b = a;
   b.trp = h.d.trx[sc.prev][e]; b.tr_cur = h.d.trx[sc.cur][e]; b.tr_fut = h.d.trx[sc.fut][e]; b.wcol = h.d.wcol_x; b.tr_part = nullptr;
   b.tr_b = b.trp; b.tr_cur_rd = b.tr_cur; b.rb = 0.0; b.pend_a = h.d.pend + PEND_IDENTITY;        // (more than one tracer: the fixers are applied eagerly)
-  b.robert = tracer_robert(h, e + 1);
+  b.robert = tracer_robert(h, e + 1); b.w0blk = h.d.w0blk_x;
   b.halo_q = (size_t)(3 + e) * h.g.L * 2 * h.g.I;
   if (h.cfg.physics == 0) { b.tratm_p = h.d.trx_atm[sc.prev][e]; b.flux = tracer_sms_flux(h, e + 1); b.rdamp = tracer_sms_rdamp(h, e + 1); }   // hs_forcing's source and sink act on every tracer, each with its tracer_sms (hs_forcing.F90:248-265)
   else if (h.cfg.physics == 2) b.tratm_p = h.d.ph_dtqx[e];                   // the caller's dt_tracers(:,:,:,ntr)
@@ -2735,18 +2808,23 @@ static void launch_tracer_vert_kernel(const Geom &g, const TracerArgs &a, hipStr
   }
   if (g.L > 40 && g.L <= 60) {                  // 12 wavefronts of 5 levels (164 VGPRs, 3 wavefronts per SIMD) instead of 8 of 8 (207)
     const int NW = (g.L + 4) / 5;
-    if (a.ppm) hipLaunchKernelGGL((k_tracer_vert<5, 12, false>), grid, dim3(64 * NW), 0, s, g, a);
-    else hipLaunchKernelGGL((k_tracer_vert<5, 12, true>), grid, dim3(64 * NW), 0, s, g, a);
+#define LV(HYB) do { if (a.filt_horiz) hipLaunchKernelGGL((k_tracer_vert<5, 12, HYB, false>), grid, dim3(64 * NW), 0, s, g, a); \
+                     else hipLaunchKernelGGL((k_tracer_vert<5, 12, HYB, true>), grid, dim3(64 * NW), 0, s, g, a); } while (0)
+    if (a.ppm) LV(false); else LV(true);
+#undef LV
     return;
   }
   const int CH = std::max(1, (g.L + 7) / 8), NW = (g.L + CH - 1) / CH;    // NW >= 5 needed for the 5 column sums
   const dim3 block(64 * NW);
-#define LT(N) do { if (a.ppm) hipLaunchKernelGGL((k_tracer_vert<N, 8, false>), grid, block, 0, s, g, a); else hipLaunchKernelGGL((k_tracer_vert<N, 8, true>), grid, block, 0, s, g, a); } while (0)   // a.ppm: the pure-sigma weight table, null with hybrid levels
+#define LF(N, HYB) do { if (a.filt_horiz) hipLaunchKernelGGL((k_tracer_vert<N, 8, HYB, false>), grid, block, 0, s, g, a); \
+                        else hipLaunchKernelGGL((k_tracer_vert<N, 8, HYB, true>), grid, block, 0, s, g, a); } while (0)
+#define LT(N) do { if (a.ppm) LF(N, false); else LF(N, true); } while (0)   // a.ppm: the pure-sigma weight table, null with hybrid levels
   switch (CH) {
     case 1: LT(1); break; case 2: LT(2); break; case 3: LT(3); break; case 4: LT(4); break;
     case 5: LT(5); break; case 6: LT(6); break; case 7: LT(7); break; default: LT(8); break;
   }
 #undef LT
+#undef LF
 }
 // part 0: tracer 1's horizontal kernel (needs nothing of this step's column kernel); part 1: everything after it; -1: both
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part) {
@@ -2957,7 +3035,7 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
                                                     const double *__restrict__ wts, double *__restrict__ partials, int CH,
-                                                    const double *__restrict__ wcol) {
+                                                    const double *__restrict__ wcol, const double *__restrict__ w0blk, int n_w0) {
   __shared__ double sred[4][8];
   const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
   const int col = blockIdx.x * 64 + tid;
@@ -2966,7 +3044,9 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
   const double wgt = wts[jl], ps = psg[c2];
   if (MODE == 2) {        // the water fixer's five sums alone
-    double t0 = wgt * wcol[c2], t1 = wgt * wcol[lev + c2], t2 = wgt * wcol[2 * lev + c2] * ps, t3 = wgt * wcol[3 * lev + c2], t4 = wgt * wcol[4 * lev + c2] * ps;
+    // "before": the vertical tracer kernel's column sums, or (w0blk) the horizontal kernel's already weighted block sums, n_w0 of them
+    double t0 = w0blk ? (col < n_w0 ? w0blk[col] : 0.0) : wgt * wcol[c2];
+    double t1 = wgt * wcol[lev + c2], t2 = wgt * wcol[2 * lev + c2] * ps, t3 = wgt * wcol[3 * lev + c2], t4 = wgt * wcol[4 * lev + c2] * ps;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
@@ -2983,7 +3063,8 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   }
   double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
   if (MODE == 0 && wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
-    t0 = wgt * wcol[c2]; t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t0 = w0blk ? (col < n_w0 ? w0blk[col] : 0.0) : wgt * wcol[c2];
+    t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
     t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
   }
   double sa = 0.0, sb = 0.0;
@@ -3279,9 +3360,11 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s, int part) {
   double *p2 = d.partials + 2 * (size_t)nb;
   const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
   const double *wcol = h.tracer_on ? d.wcol : (const double *)nullptr;
-  if (part == 1) hipLaunchKernelGGL(k_fixer_sums<1>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol);
-  else if (part == 2) { hipLaunchKernelGGL(k_fixer_sums<2>, dim3(nb), dim3(64), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol); return; }
-  else hipLaunchKernelGGL(k_fixer_sums<0>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol);
+  const double *w0blk = (h.tracer_on && h.tr_filt_horiz) ? d.w0blk : (const double *)nullptr;
+  const int n_w0 = g.L * ((g.Jl + TR_RB - 1) / TR_RB);
+  if (part == 1) hipLaunchKernelGGL(k_fixer_sums<1>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol, w0blk, n_w0);
+  else if (part == 2) { hipLaunchKernelGGL(k_fixer_sums<2>, dim3(nb), dim3(64), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol, w0blk, n_w0); return; }
+  else hipLaunchKernelGGL(k_fixer_sums<0>, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol, w0blk, n_w0);
   // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
   // on one rank k_fixer_finish folds them itself
   if (g.P > 1 || !h.lazy_fix) {

@@ -1335,9 +1335,11 @@ def test_lazy_fixers_equal_eager(monkeypatch, res, L, ext):
 def test_tracer_fork_before_column_kernel(monkeypatch, eager):
     """ISCA_TRACER_EARLY=1 starts the tracer's horizontal kernel beside the column kernel instead of behind it (measured, not faster:
     DESIGN.md 11).  It may, because that kernel reads the column kernel's level-count word of the step BEFORE (kmask_old): same state
-    bit for bit, with the pending fixers and with the eager ones (T42L25: large enough for the side stream)."""
+    bit for bit, with the pending fixers and with the eager ones (T42L25: large enough for the side stream).  (Both runs with the filter's first
+    half in the vertical kernel: the early kernel cannot take it over, and the water fixer's "before" sum is formed in another order with it.)"""
     def run(early):
         monkeypatch.setenv("ISCA_TRACER_CONCURRENT", "1")
+        monkeypatch.setenv("ISCA_TRACER_FILTER_IN_VERT", "1")
         (monkeypatch.setenv("ISCA_TRACER_EARLY", "1") if early else monkeypatch.delenv("ISCA_TRACER_EARLY", raising=False))
         (monkeypatch.setenv("ISCA_EAGER_FIXERS", "1") if eager else monkeypatch.delenv("ISCA_EAGER_FIXERS", raising=False))
         dc = make("T42", 25); dc.cold_start(); dc.step(30)
@@ -1347,6 +1349,39 @@ def test_tracer_fork_before_column_kernel(monkeypatch, eager):
     late, early = run(False), run(True)
     for key in late:
         assert np.array_equal(late[key], early[key]), key
+
+
+@pytest.mark.parametrize("case", ["lazy", "eager", "three_tracers", "moist", "raw_filter"])
+def test_tracer_filter_half_in_the_horizontal_kernel(monkeypatch, case):
+    """The first half of the grid tracer's Robert filter (leapfrog part A, spectral_dynamics.F90:1164-1167) and the water fixer's global sum over q0
+    (initialize_corrections :1332-1333) are done by the horizontal transport kernel, which holds both older levels of its rows anyway; the vertical kernel
+    then reads two fields instead of five.  Against ISCA_TRACER_FILTER_IN_VERT=1 (the arrangement of rounds 1-4): the filter itself is the same
+    arithmetic; the sum is formed per row block and level instead of per column, so the water factor differs in its last bits and the tracer
+    with it -- 1e-13 relative after 30 steps, everything that does not see the tracer bit for bit."""
+    kw, res, L = {}, "T42", 25
+    if case == "eager":
+        monkeypatch.setenv("ISCA_EAGER_FIXERS", "1")
+    elif case == "three_tracers":
+        kw = dict(num_tracers=3, tracer_robert_coeff=[-1.0, 0.05, -1.0])
+    elif case == "raw_filter":
+        kw = dict(raw_filter_coeff=0.53)
+    elif case == "moist":
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "moist_kernels_T21L25.npz"))
+        res, kw = "T21", dict(physics=1, dt_atmos=720.0, bk_input=list(g["tab_bk"]), pk_input=list(g["tab_pk"]))
+    def run(in_vert):
+        monkeypatch.setenv("ISCA_TRACER_CONCURRENT", "1")
+        (monkeypatch.setenv("ISCA_TRACER_FILTER_IN_VERT", "1") if in_vert else monkeypatch.delenv("ISCA_TRACER_FILTER_IN_VERT", raising=False))
+        dc = make(res, L, **kw); dc.cold_start(); dc.step(30)
+        out = {(k, tl): dc.get(k, tl) for k in ALL_STATE for tl in (0, 1)}
+        if case == "three_tracers":
+            out.update({("tr2", tl): dc.get("tr2", tl) for tl in (0, 1)})
+        dc.close()
+        return out
+    new, old = run(False), run(True)
+    for key in new:
+        scale = max(np.abs(old[key]).max(), 1e-300)
+        assert np.abs(new[key] - old[key]).max() <= 1e-12 * scale, (key, np.abs(new[key] - old[key]).max() / scale)
+    assert np.abs(old[("tr", 1)]).max() > 0
 
 
 @pytest.mark.parametrize("case", ["three_tracers", "cold", "moist"])
