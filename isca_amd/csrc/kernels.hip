@@ -2242,7 +2242,8 @@ struct TracerTabs {
       : cc((kdouble *)a.cc), dyp((kdouble *)a.dyp), dym((kdouble *)a.dym), rcdx((kdouble *)a.rcdx), rdyy((kdouble *)a.rdyy), rcdy((kdouble *)a.rcdy),
         rdy((kdouble *)a.rdy) {}
 };
-template <int WPE, bool P2 = true>
+// LOCAL: one rank -- every source row is in my band (no halo buffers: one address form per row)
+template <int WPE, bool P2 = true, bool LOCAL = false>
 __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a) {
   const TracerTabs T(a);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2284,7 +2285,7 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     jsrc[r] = jv < 0 ? -jv - 1 : (jv >= J ? 2 * J - 1 - jv : jv);
     const int is = mir[r] ? wrap_lon<P2>(i + (I >> 1), I) : i;
     const int jl = jsrc[r] - g.j0;                                              // local row, or in a neighbour's band
-    loc[r] = jl >= 0 && jl < g.Jl;
+    loc[r] = LOCAL || (jl >= 0 && jl < g.Jl);
     const size_t c2r = (size_t)(loc[r] ? jl : 0) * I + is;
     const size_t q = (size_t)k * lev + c2r;
     const size_t o = ((size_t)k * 2 + (loc[r] ? 0 : (jl < 0 ? jl + 2 : jl - g.Jl))) * I + is;
@@ -2368,33 +2369,37 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
     q1r[r] = qc + (bb * qs[r * I + il] + (1.0 - bb) * qs[r * I + ir] - qc);
   }
   const int im = wrap_lon<P2>(i - 1, I), ip = wrap_lon<P2>(i + 1, I);
-  double bx[RB], ucl[RB], ucr[RB];
-#pragma unroll
-  for (int rr = 0; rr < RB; ++rr) {   // u at the cell faces, Courant numbers of the x fluxes, block-wide flag for the integer part
-    const int r = rr + 2;
-    double u_l = dpp_from_left(tu[r]), u_r = dpp_from_right(tu[r]);
+  // u at the cell faces and the Courant number of the x flux: formed here for the block-wide flag of the integer part, and again in the row's own
+  // iteration below (two lane shifts and three products) rather than kept in twelve registers across the whole loop
+  auto faces = [&](int rr, double &uc_l, double &uc_r, double &b) {
+    const double u_c = tu[rr + 2];
+    double u_l = dpp_from_left(u_c), u_r = dpp_from_right(u_c);
     if (lane == 0) u_l = edge_last[rr][wl];
     if (lane == last) u_r = edge_first[rr][wr];
-    ucl[rr] = 0.5 * (u_l + tu[r]);
-    ucr[rr] = 0.5 * (tu[r] + u_r);
-    bx[rr] = ucl[rr] * a.dt * T.rcdx[j0 + rr];
-    if (fabs(bx[rr]) > 1.0) any_big[rr] = 1;
-  }
-  __syncthreads();
-  double res[RB];                      // stored after the loop: with a store inside, the per-row tables would leave the scalar path
+    uc_l = 0.5 * (u_l + u_c);
+    uc_r = 0.5 * (u_c + u_r);
+    b = uc_l * a.dt * T.rcdx[j0 + rr];
+  };
 #pragma unroll
   for (int rr = 0; rr < RB; ++rr) {
+    double uc_l, uc_r, b;
+    faces(rr, uc_l, uc_r, b);
+    if (fabs(b) > 1.0) any_big[rr] = 1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < RB; ++rr) {      // (the row's result is stored inside the loop: the per-row tables are read through the constant address space)
     const int r = rr + 2, jg = j0 + rr;
-    res[rr] = 0.0;
     if (jg >= g.j0 + g.Jl) continue;
-    const double q0c = q0r[r], va_c = vr[r];
+    const double q0c = q0r[r], q0m = q0r[r - 1], q0p = q0r[r + 1];
+    const double va_c = vr[r];
     // semi_y (:415-433)
-    q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (q0r[r - 1] - q0c) * T.rdyy[jg] : va_c * hdt * (q0c - q0r[r + 1]) * T.rdyy[jg + 1]);
+    q2[i] = q0c + ((va_c >= 0.0) ? va_c * hdt * (q0m - q0c) * T.rdyy[jg] : va_c * hdt * (q0c - q0p) * T.rdyy[jg + 1]);
     const double vc_lo = 0.5 * (vr[r - 1] + va_c), vc_hi = 0.5 * (va_c + vr[r + 1]);
-    const double uc_i = ucl[rr], uc_p = ucr[rr];
+    double uc_i, uc_p, b;
+    faces(rr, uc_i, uc_p, b);
     const double rcdy = T.rcdy[jg];
     double dq = q0c * ((vc_hi * T.cc[jg + 1] - vc_lo * T.cc[jg]) * rcdy + (uc_p - uc_i) * T.rcdx[jg]);
-    const double b = bx[rr];
     __syncthreads();
     // vanleer_x (:308-347): slope_x, integer part of the Courant number, fractional van Leer flux
     sx[i] = vl_limit(((q2[ip] - q2[i]) + (q2[i] - q2[im])) / 2, q2[im], q2[i], q2[ip]);
@@ -2431,11 +2436,8 @@ __global__ __launch_bounds__(512, WPE) void k_tracer_horiz(Geom g, TracerArgs a)
       if (jg == J - 1) f_hi = 0.0;
       dq = dq - rcdy * (f_hi - f_lo);
     }
-    res[rr] = q0c + a.dt * dq;
+    a.trh[(size_t)k * lev + (size_t)(jg - g.j0) * I + i] = q0c + a.dt * dq;
   }
-#pragma unroll
-  for (int rr = 0; rr < RB; ++rr)
-    if (j0 + rr < g.j0 + g.Jl) a.trh[(size_t)k * lev + (size_t)(j0 + rr - g.j0) * I + i] = res[rr];
 }
 
 // rows 0,1 and Jl-2,Jl-1 of (q0, u, v) for the neighbouring latitude bands (mpp_update_domains, fv_advection.F90:161-162,259)
@@ -2794,6 +2796,9 @@ static void launch_tracer_horiz_kernel(const Geom &g, const TracerArgs &a, size_
   if (g.I & (g.I - 1)) {        // lon_max with factors 3, 5: longitudes wrap with a remainder
     if (g.I > 256) hipLaunchKernelGGL((k_tracer_horiz<4, false>), grid, block, ldsh, s, g, a);
     else hipLaunchKernelGGL((k_tracer_horiz<1, false>), grid, block, ldsh, s, g, a);
+  } else if (g.P == 1 && !getenv("ISCA_TRACER_HORIZ_GENERIC")) {
+    if (g.I > 256) hipLaunchKernelGGL((k_tracer_horiz<4, true, true>), grid, block, ldsh, s, g, a);
+    else hipLaunchKernelGGL((k_tracer_horiz<1, true, true>), grid, block, ldsh, s, g, a);
   } else if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);
   else hipLaunchKernelGGL(k_tracer_horiz<1>, grid, block, ldsh, s, g, a);
 }
