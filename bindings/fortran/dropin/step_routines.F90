@@ -28,16 +28,20 @@ real, intent(in),  dimension(:,:)   :: surface_p
 call need_core('pressure_variables')
 call chk(isca_pressure_variables(core, surface_p, p_half, ln_p_half, p_full, ln_p_full), 'pressure_variables')
 end subroutine pressure_variables_3d
-! the surface geopotential is the core's own (get_surf_geopotential returns it); the argument is checked against it
+! the caller's surface geopotential is the lower boundary (press_and_geopot.F90:331); q_grid enters with use_virtual_temperature (:340-347)
 subroutine compute_geopotential(t_grid, ln_p_half, ln_p_full, surf_geopotential, geopot_full, geopot_half, q_grid)
 real, intent(in),  dimension(:,:,:) :: t_grid, ln_p_half, ln_p_full
 real, intent(in),  dimension(:,:)   :: surf_geopotential
 real, intent(out), dimension(:,:,:) :: geopot_full, geopot_half
 real, intent(in), optional, dimension(:,:,:) :: q_grid
+real(c_double), allocatable, target :: q(:)
 call need_core('compute_geopotential')
-if(any(surf_geopotential /= 0.)) call error_mesg('compute_geopotential','a surface geopotential other than zero is not available here', FATAL)
-if(present(q_grid) .and. virtual_t) call error_mesg('compute_geopotential','q_grid with use_virtual_temperature is not available here', FATAL)
-call chk(isca_compute_geopotential(core, t_grid, ln_p_half, ln_p_full, geopot_full, geopot_half), 'compute_geopotential')
+if(present(q_grid)) then
+  allocate(q(size(q_grid))); q = reshape(q_grid, (/size(q_grid)/))
+  call chk(isca_compute_geopotential_surf(core, t_grid, ln_p_half, ln_p_full, surf_geopotential, c_loc(q), geopot_full, geopot_half), 'compute_geopotential')
+else       ! (with use_virtual_temperature the library answers like the reference: 'q_grid must be present when use_virtual_temperature=.true.')
+  call chk(isca_compute_geopotential_surf(core, t_grid, ln_p_half, ln_p_full, surf_geopotential, c_null_ptr, geopot_full, geopot_half), 'compute_geopotential')
+endif
 end subroutine compute_geopotential
 subroutine compute_pressures_and_heights_3d(t_grid, ps_grid, surf_geopotential, z_full, z_half, p_full, p_half, q_grid)
 real, intent(in), dimension(:,:,:) :: t_grid

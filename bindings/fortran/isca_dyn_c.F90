@@ -205,6 +205,11 @@ interface
     import; type(c_ptr), value :: h; real(c_double), intent(in) :: t(*), ln_p_half(*), ln_p_full(*)
     real(c_double), intent(out) :: geopot_full(*), geopot_half(*)
   end function
+  integer(c_int) function isca_compute_geopotential_surf(h, t, ln_p_half, ln_p_full, surf_geopotential, q_grid, geopot_full, geopot_half) bind(C)
+    import; type(c_ptr), value :: h; real(c_double), intent(in) :: t(*), ln_p_half(*), ln_p_full(*), surf_geopotential(*)
+    type(c_ptr), value :: q_grid                 ! c_null_ptr: no q_grid given
+    real(c_double), intent(out) :: geopot_full(*), geopot_half(*)
+  end function
   integer(c_int) function isca_compute_pressures_and_heights(h, t, ps, q, z_full, z_half, p_full, p_half) bind(C)
     import; type(c_ptr), value :: h; real(c_double), intent(in) :: t(*), ps(*); type(c_ptr), value :: q
     real(c_double), intent(out) :: z_full(*), z_half(*), p_full(*), p_half(*)

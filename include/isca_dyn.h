@@ -368,7 +368,11 @@ int isca_divide_by_cos(isca_dyn_t *h, double *grid, int nlev, int power);       
 int isca_mass_weighted_global_integral(isca_dyn_t *h, const double *field, const double *surf_press, double *integral);   /* global_integral.F90:49-81 */
 int isca_pressure_variables(isca_dyn_t *h, const double *surf_p, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full);   /* press_and_geopot.F90:152-221 */
 int isca_compute_geopotential(isca_dyn_t *h, const double *t, const double *ln_p_half, const double *ln_p_full,
-                              double *geopot_full, double *geopot_half);                              /* press_and_geopot.F90:327-359, dry, flat surface */
+                              double *geopot_full, double *geopot_half);                              /* press_and_geopot.F90:327-359 on the handle's surface geopotential, without q_grid */
+/* ... with the routine's own arguments: surf_geopotential [lat][lon] (NULL: the handle's), q_grid [lev][lat][lon] (NULL: not given; required, as in the
+   reference :343, when the handle has use_virtual_temperature) */
+int isca_compute_geopotential_surf(isca_dyn_t *h, const double *t, const double *ln_p_half, const double *ln_p_full, const double *surf_geopotential,
+                                   const double *q_grid, double *geopot_full, double *geopot_half);   /* press_and_geopot.F90:314-359 */
 int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v, const double *q, double dt, double *tendency);   /* fv_advection.F90:126-207; tendency is accumulated */
 int isca_vert_advection_ppm(isca_dyn_t *h, double dt, const double *w, const double *surf_p, const double *r, double *rdt);   /* vert_advection.F90:70-478, FINITE_VOLUME_PARABOLIC / ADVECTIVE_FORM, dz = dpk + dbk*surf_p */
 int isca_hs_tracer_source_sink(isca_dyn_t *h, const double *surf_p, const double *r, double *rdt);      /* hs_forcing.F90:683-724; rdt is accumulated */

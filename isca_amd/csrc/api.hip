@@ -2012,6 +2012,26 @@ extern "C" int isca_compute_geopotential(isca_dyn_t *h, const double *t, const d
   d2h(h, geopot_full, gf, n2 * g.L); d2h(h, geopot_half, gh, n2 * (g.L + 1));
   API_END
 }
+// the same with the caller's arguments: surf_geopotential (null: the handle's own), q_grid (null: none given) -- press_and_geopot.F90:314-359
+extern "C" int isca_compute_geopotential_surf(isca_dyn_t *h, const double *t, const double *ln_p_half, const double *ln_p_full, const double *surf_geopotential,
+                                              const double *q, double *geopot_full, double *geopot_half) {
+  API_BEGIN
+  const Geom &g = h->g;
+  const size_t n2 = (size_t)g.Jl * g.I;
+  if (h->cfg.use_virtual_temperature && !q) fail("compute_geopotential: q_grid must be present when use_virtual_temperature=.true.");      // :343
+  DevTmp tmp(h);
+  double *dt_ = tmp.up(t, n2 * g.L), *lph = tmp.up(ln_p_half, n2 * (g.L + 1)), *lpf = tmp.up(ln_p_full, n2 * g.L);
+  double *sg = surf_geopotential ? tmp.up(surf_geopotential, n2) : nullptr;
+  if (h->cfg.use_virtual_temperature) {          // virtual_t = t_grid (1 + (rvgas/rdgas - 1) q_grid) (:340-341)
+    double *dq = tmp.up(q, n2 * g.L), *tv = tmp.alloc(n2 * g.L);
+    launch_virtual_t(*h, dt_, dq, tv, h->stream);
+    dt_ = tv;
+  }
+  double *gf = tmp.alloc(n2 * g.L), *gh = tmp.alloc(n2 * (g.L + 1), true);
+  launch_geopotential(*h, dt_, lph, lpf, gf, gh, h->stream, sg);
+  d2h(h, geopot_full, gf, n2 * g.L); d2h(h, geopot_half, gh, n2 * (g.L + 1));
+  API_END
+}
 // fv_advection.F90:126-207 a_grid_horiz_advection(u, v, q, dt, tendency): tendency += van Leer advective tendency.
 // Runs the step's own tracer kernel without source/sink.
 extern "C" int isca_a_grid_horiz_advection(isca_dyn_t *h, const double *u, const double *v, const double *q, double dt, double *tendency) {

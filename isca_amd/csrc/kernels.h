@@ -103,7 +103,7 @@ void launch_scale_rows(const Geom &g, const Dev &d, double *a, int nlev, hipStre
 
 // component entry points on caller fields
 void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full, hipStream_t s);
-void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s);
+void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s, const double *surf_geop = nullptr);   // surf_geop: the caller's lower boundary, or the handle's own
 void launch_mass_weighted_rows(const isca_dyn &h, const double *f, const double *ps, double *rows, hipStream_t s);
 void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, const double *q, const double *ps, double dt, double *q_new, hipStream_t s);
 void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const double *ps, const double *r, double *r_new,

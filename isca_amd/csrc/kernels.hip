@@ -2099,8 +2099,8 @@ __global__ void k_geopotential(Geom g, const double *__restrict__ pk, const doub
 void launch_pressure_variables(const isca_dyn &h, const double *ps, double *p_half, double *ln_p_half, double *p_full, double *ln_p_full, hipStream_t s) {
   hipLaunchKernelGGL(k_pressure_variables, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.bk, ps, p_half, ln_p_half, p_full, ln_p_full, h.cfg.vert_difference_option == 1);
 }
-void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s) {
-  hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, h.d.surf_geop, t, ln_p_half, ln_p_full, gf, gh);
+void launch_geopotential(const isca_dyn &h, const double *t, const double *ln_p_half, const double *ln_p_full, double *gf, double *gh, hipStream_t s, const double *surf_geop) {
+  hipLaunchKernelGGL(k_geopotential, grid1d((size_t)h.g.Jl * h.g.I, 64), dim3(64), 0, s, h.g, h.d.pk, surf_geop ? surf_geop : h.d.surf_geop, t, ln_p_half, ln_p_full, gf, gh);
 }
 // mass_weighted_global_integral (global_integral.F90:49-81): per-latitude sums of wts * sum_k field*dp, one block per row
 __global__ void k_mass_weighted_rows(Geom g, const double *__restrict__ dpk, const double *__restrict__ dbk,

@@ -152,6 +152,7 @@ def load_library():
         "isca_mass_weighted_global_integral": [H, dp, dp, dp],
         "isca_pressure_variables": [H, dp, dp, dp, dp, dp],
         "isca_compute_geopotential": [H, dp, dp, dp, dp, dp],
+        "isca_compute_geopotential_surf": [H, dp, dp, dp, dp, dp, dp, dp],
         "isca_a_grid_horiz_advection": [H, dp, dp, dp, C.c_double, dp],
         "isca_vert_advection_ppm": [H, C.c_double, dp, dp, dp, dp],
         "isca_hs_tracer_source_sink": [H, dp, dp, dp],
@@ -193,7 +194,7 @@ EXPORTED_SYMBOLS = [
     "isca_bench_transform_pair", "isca_dyn_kernel_times",
     "isca_compute_laplacian", "isca_compute_gradient_cos", "isca_compute_ucos_vcos", "isca_compute_vor_div",
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
-    "isca_compute_geopotential", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
+    "isca_compute_geopotential", "isca_compute_geopotential_surf", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",
     "isca_implicit_correction", "isca_compute_spectral_damping", "isca_leapfrog",
     "isca_vert_advection_centered", "isca_compute_pressures_and_heights", "isca_leapfrog_2level_a", "isca_leapfrog_2level_b",
     "isca_compute_gaussian", "isca_compute_legendre",
@@ -633,10 +634,18 @@ class DynCore:
         self._check(self.lib.isca_pressure_variables(self._h, _dptr(ps), _dptr(ph), _dptr(lph), _dptr(pf), _dptr(lpf)))
         return ph, lph, pf, lpf
 
-    def compute_geopotential(self, t, ln_p_half, ln_p_full):
+    def compute_geopotential(self, t, ln_p_half, ln_p_full, surf_geopotential=None, q_grid=None):
+        """press_and_geopot.F90:314-359.  Without the two optional arguments: on the handle's own surface geopotential, no q_grid."""
         a = [np.ascontiguousarray(x, dtype=np.float64) for x in (t, ln_p_half, ln_p_full)]
         gf = np.zeros((self.L, self.Jl, self.I)); gh = np.zeros((self.L + 1, self.Jl, self.I))
-        self._check(self.lib.isca_compute_geopotential(self._h, *[_dptr(x) for x in a], _dptr(gf), _dptr(gh)))
+        if surf_geopotential is None and q_grid is None:
+            self._check(self.lib.isca_compute_geopotential(self._h, *[_dptr(x) for x in a], _dptr(gf), _dptr(gh)))
+            return gf, gh
+        opt = [None if x is None else np.ascontiguousarray(x, dtype=np.float64) for x in (surf_geopotential, q_grid)]
+        if opt[0] is not None and opt[0].shape != (self.Jl, self.I) or opt[1] is not None and opt[1].shape != a[0].shape:
+            raise IscaError("compute_geopotential: surf_geopotential (lat,lon) / q_grid (lev,lat,lon) expected")
+        self._check(self.lib.isca_compute_geopotential_surf(self._h, *[_dptr(x) for x in a], *[None if x is None else _dptr(x) for x in opt],
+                                                            _dptr(gf), _dptr(gh)))
         return gf, gh
 
     def _grid3(self, *arrs):

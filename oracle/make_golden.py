@@ -301,7 +301,7 @@ def rand_spec(rng, res, L, two_d=False):
     return s
 
 
-def golden_kernels(res, L, seed):
+def golden_kernels(res, L, seed, extra_groups="", keep=None):
     rng = np.random.default_rng(seed)
     lon, lat, nf, ns = RES[res]
     sh = shapes(res, L)
@@ -318,13 +318,16 @@ def golden_kernels(res, L, seed):
     inp["in_wg"] = wg
     inp["in_q"] = np.abs(1.0e-3 * (1.0 + rng.standard_normal(sh["grid"])))          # tracer-like positive field
     with tempfile.TemporaryDirectory(prefix="refk_") as d:
-        prepare_rundir(d, res, L, "kernels", dt=600)
+        prepare_rundir(d, res, L, "kernels", dt=600, extra_groups=extra_groups)
         for k, v in inp.items():
             np.ascontiguousarray(v).tofile(os.path.join(d, k + ".bin"))
         run_harness(d)
         out = read_outputs(d, res, L)
     meta = dict(res=res, num_levels=L, dt_atmos=600.0, seed=seed)
-    return {**{k: v for k, v in inp.items()}, **out, **{"meta_" + k: np.array(v) for k, v in meta.items()}}
+    out = {**{k: v for k, v in inp.items()}, **out}
+    if keep is not None:
+        out = {k: v for k, v in out.items() if keep(k)}
+    return {**out, **{"meta_" + k: np.array(v) for k, v in meta.items()}}
 
 
 def golden_moist_kernels(res="T21", L=25, nsteps=2400, dt=720, stride=13):
@@ -746,6 +749,9 @@ def main():
             keep=lambda k: k in ("tab_pk", "tab_bk") or re.match(r"st_(ug|vg|tg|psg|tr1|z_full|p_full)_0000(01|36)$", k) is not None),
         # lon_max with factors 3 and 5 (fft99's set99 takes n/2 = 2^a 3^b 5^c): every public routine at T31 (96 x 48), runs at T31 and T53 (160 x 80)
         "kernels_T31L6": lambda: golden_kernels("T31", 6, 20260929),
+        # the same harness over the two Gaussian mountains: compute_geopotential with a surface geopotential other than zero (press_and_geopot.F90:331)
+        "kernels_T21L6_topography": lambda: golden_kernels("T21", 6, 20260928, extra_groups=GAUSSIAN_TOPOG_GROUPS,
+                                                           keep=lambda k: re.match(r"out_(geopot_full|geopot_half)$", k) is not None),      # (inputs: those of kernels_T21L6, same seed)
         "run_T31L8": lambda: golden_run(
             "T31", 8, 36, (1, 2, 36), keep=lambda k: re.match(r"st_(ug|vg|tg|psg|tr1)_0000(01|02|36)$", k) is not None),
         "run_T53L8": lambda: golden_run(

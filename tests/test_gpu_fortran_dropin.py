@@ -80,6 +80,25 @@ def test_reference_harness_kernels_on_the_gpu_library(tmp_path, golden_dir):
     assert np.array_equal(out["tab_legendre"], g["tab_legendre"])
 
 
+def test_reference_harness_geopotential_over_topography(tmp_path, golden_dir):
+    """press_and_geopot_mod: compute_geopotential with the caller's surface geopotential (press_and_geopot.F90:331) through the drop-in module: the
+    harness's 'kernels' mode over the two Gaussian mountains of gaussian_topog_nml, against the reference's outputs for the same inputs."""
+    _need_exe()
+    from oracle import make_golden as mg
+    g, t = np.load(os.path.join(golden_dir, "kernels_T21L6.npz")), np.load(os.path.join(golden_dir, "kernels_T21L6_topography.npz"))
+    d = str(tmp_path / "kernels")
+    mg.prepare_rundir(d, "T21", 6, "kernels", dt=600, extra_groups=mg.GAUSSIAN_TOPOG_GROUPS)
+    for k in g.files:
+        if k.startswith("in_"):
+            np.ascontiguousarray(g[k]).tofile(os.path.join(d, k + ".bin"))
+    mg.run_harness(d, exe=EXE, timeout=900)
+    out = mg.read_outputs(d, "T21", 6)
+    for k in ("out_geopot_full", "out_geopot_half"):
+        err = float(np.max(np.abs(out[k] - t[k])) / np.max(np.abs(t[k])))
+        assert err < 1e-13, (k, err)
+    assert np.abs(t["out_geopot_half"][-1]).max() > 2.0e4 and np.abs(out["out_geopot_full"] - g["out_geopot_full"]).max() > 1.0e4
+
+
 def test_atmos_model_loop_on_atmosphere_mod(tmp_path, golden_dir):
     """atmos_model's time loop (atmos_model.F90:115-142) on this repository's atmosphere_mod (atmosphere.F90:78): atmosphere_init reads the
     reference's input.nml / field_table, every atmosphere(Time) is one device step; 144 steps land on the reference run."""

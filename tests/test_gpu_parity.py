@@ -1598,8 +1598,22 @@ def test_golden_components(golden_dir, name, res, L):
     assert rel(pf, g["out_p_full"]) < 1e-13 and rel(lpf, g["out_ln_p_full"]) < 1e-14
     gf, gh = dc.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"])              # press_and_geopot.F90:327
     assert rel(gf, g["out_geopot_full"]) < 1e-13 and rel(gh, g["out_geopot_half"]) < 1e-13
+    if os.path.exists(os.path.join(golden_dir, name + "_topography.npz")):        # ... with the caller's surface geopotential (:331): the same harness over two mountains
+        tg = np.load(os.path.join(golden_dir, name + "_topography.npz"))
+        gf, gh = dc.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"], surf_geopotential=tg["out_geopot_half"][-1])
+        assert rel(gf, tg["out_geopot_full"]) < 1e-13 and rel(gh, tg["out_geopot_half"]) < 1e-13
     assert rel(dc.hs_tracer_source_sink(ps, np.zeros_like(T)), g["out_hs_dt_tr"]) < 1e-13    # hs_forcing.F90:683
     q = g["in_q"]
+    if name == "kernels_T21L6":        # q_grid with use_virtual_temperature (:340-347; the harness calls the routine without it): against the numpy restatement
+        dv, ov = make(res, L, use_virtual_temperature=1), oracle(res, L, use_virtual_temperature=True)
+        sg = np.load(os.path.join(golden_dir, name + "_topography.npz"))["out_geopot_half"][-1]
+        ov.surf_geopotential = sg
+        want = ov.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"], 20.0 * q)
+        got = dv.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"], surf_geopotential=sg, q_grid=20.0 * q)
+        assert rel(got[0], want[0]) < 1e-14 and rel(got[1], want[1]) < 1e-14 and rel(got[0], tg["out_geopot_full"]) > 1e-4
+        with pytest.raises(dyncore.IscaError, match="q_grid must be present when use_virtual_temperature"):
+            dv.compute_geopotential(T, g["out_ln_p_half"], g["out_ln_p_full"], surf_geopotential=sg)
+        dv.close()
     assert rel(dc.vert_advection_ppm(1200.0, g["in_wg"], ps, q), g["out_vadv_ppm"]) < 1e-12  # vert_advection.F90:301
     assert rel(dc.a_grid_horiz_advection(ga, gb, q, 1200.0), g["out_hadv_fv"]) < 1e-12       # fv_advection.F90:126
     assert rel(dc.a_grid_horiz_advection(ga, gb, q, 48000.0), g["out_hadv_fv_bigcfl"]) < 1e-12

@@ -323,6 +323,17 @@ def test_topography_and_no_forcing(golden_dir, name, coeffs, marks):
                 assert not sc.tr[sc.current].any() and not g[f"st_tr1_{tag}"].any()
 
 
+def test_geopotential_over_topography(golden_dir):
+    """compute_geopotential with a surface geopotential other than zero (press_and_geopot.F90:331: the hydrostatic sum starts from it): the harness's
+    'kernels' mode over the two Gaussian mountains, restated in numpy with the surface field the reference reports as geopot_half(:,:,num_levels+1)."""
+    g, t = np.load(os.path.join(golden_dir, "kernels_T21L6.npz")), np.load(os.path.join(golden_dir, "kernels_T21L6_topography.npz"))
+    sc = core("T21", 6)
+    sc.surf_geopotential = t["out_geopot_half"][-1]
+    assert sc.surf_geopotential.max() > 2.0e4 and sc.surf_geopotential.min() < 1.0
+    gf, gh = sc.compute_geopotential(g["in_temp"], g["out_ln_p_half"], g["out_ln_p_full"])
+    assert rel(gf, t["out_geopot_full"]) < 1e-14 and rel(gh, t["out_geopot_half"]) < 1e-14
+
+
 def test_isidoro_local_heating(golden_dir):
     """hs_forcing_nml: local_heating_option = 'Isidoro' (hs_forcing.F90:233-238, 728-769) in the numpy restatement against the reference run."""
     g = np.load(os.path.join(golden_dir, "run_T21L8_isidoro.npz"))
