@@ -280,7 +280,11 @@ int isca_dyn_restart_exists(const char *directory);     /* file_exist('INPUT/spe
  * `record` of variable var_name of in_path (if given) */
 int isca_restart_file_selftest(const char *out_path, const char *in_path, const char *var_name, int record, double *sums);
 
-/* --- transforms_mod entry points (host buffers, Fortran layouts; nlev = size of 3rd dim) --- */
+/* --- transforms_mod entry points (host buffers, Fortran layouts; nlev = size of 3rd dim) ---
+ * On more than one rank the five grid <-> spherical routines (spherical_to_grid, grid_to_spherical, vor_div_from_uv_grid, uv_grid_from_vor_div, trans_filter)
+ * are COLLECTIVE calls through the library's communicator (isca_dyn_comm_init): grid arrays are the rank's latitude band, spectral arrays the whole
+ * (0:num_fourier, 0:num_spherical) window on every rank -- a spectral result is gathered on every rank (the reference hands each rank its window
+ * ms:me, transforms.F90:970-1056).  The remaining ones stay world_size == 1. */
 int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev);   /* transforms.F90:379 */
 int isca_trans_grid_to_spherical(isca_dyn_t *h, const double *grid, double *spherical, int nlev, int do_truncation); /* :462 */
 int isca_vor_div_from_uv_grid(isca_dyn_t *h, const double *u, const double *v, double *vor, double *div, int nlev);  /* :742 */

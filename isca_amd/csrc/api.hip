@@ -794,6 +794,42 @@ static void d2h(isca_dyn *h, double *host, const double *dev, size_t n) {
 static void dcopy(isca_dyn *h, double *dst, const double *src, size_t n) {
   HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
 }
+// A stand-alone transform on more than one rank: the spectral RESULT on every rank with all its wavenumbers (the host arrays have the whole spectral window on every
+// rank: get_spec_domain of the drop-in, DynCore's (n, m) arrays), gathered through the library's communicator -- an all-to-all in which every rank sends its own
+// wavenumbers to everyone, through the buffers of the transform's lat -> m exchange, in chunks of levels that fit them.
+static void spec_dev_to_host_all(isca_dyn *h, const double *dev, double *host, int nlev) {
+  const Geom &g = h->g;
+  if (g.P == 1) { spec_dev_to_host(h, dev, host, nlev); return; }
+  if (!h->comm) fail("a stand-alone transform on more than one rank needs the library's communicator (isca_dyn_comm_init)");
+  const size_t cap = (size_t)g.Ml * g.Jl * col_pitch(h->cap_cols);                       // doubles per peer in Ff_g / Ff_s
+  const int kmax = (int)std::min<size_t>((size_t)nlev, cap / ((size_t)g.Ml * g.N1 * 2));
+  if (kmax < 1) fail("spectral gather: the exchange buffers hold less than one level");
+  std::vector<double> tmp;
+  for (int k0 = 0; k0 < nlev; k0 += kmax) {
+    const int nk = std::min(kmax, nlev - k0);
+    const size_t blk = (size_t)g.Ml * g.N1 * nk * 2;
+    launch_spec_level_chunk(g, dev, h->d.Ff_g, nlev, k0, nk, g.P, h->stream);                 // my [ml][n][k0..k0+nk) block, once per peer
+    { Timed t(h, "all_to_all_fwd"); h->comm->all_to_all(h->d.Ff_g, h->d.Ff_s, blk, h->stream); }
+    tmp.resize((size_t)g.P * blk);
+    d2h(h, tmp.data(), h->d.Ff_s, tmp.size());
+    for (int q = 0; q < g.P; ++q)
+      for (int ml = 0; ml < g.Ml; ++ml) {
+        const int m = h->h_m_of_slot[(size_t)q * g.Ml + ml];
+        if (m < 0) continue;
+        for (int n = 0; n < g.N1; ++n)
+          for (int k = 0; k < nk; ++k) {
+            const size_t src = (size_t)q * blk + (((size_t)ml * g.N1 + n) * nk + k) * 2, dst = (((size_t)(k0 + k) * g.N1 + n) * g.M1 + m) * 2;
+            host[dst] = tmp[src]; host[dst + 1] = tmp[src + 1];
+          }
+      }
+  }
+  h->comm->check();
+}
+// (collective over the ranks when there is more than one)
+static void require_single_or_comm(isca_dyn *h, const char *what) {
+  if (h->g.P != 1 && !h->comm) fail(std::string(what) + ": on more than one rank this is a collective call through the library's communicator (isca_dyn_comm_init); "
+                                    "without one it is only available with world_size == 1");
+}
 
 // ---------------------------------------------------------------------------------------------------
 // cold start: spectral_initialize_fields.F90:45-135 + spectral_dynamics.F90:580-630
@@ -1708,7 +1744,7 @@ static void check_nlev(isca_dyn *h, int nlev) {
 }
 extern "C" int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spherical, double *grid, int nlev) {
   API_BEGIN
-  require_single(h, "trans_spherical_to_grid"); check_nlev(h, nlev);
+  require_single_or_comm(h, "trans_spherical_to_grid"); check_nlev(h, nlev);
   spec_host_to_dev(h, spherical, h->d.scratch_s[0], nlev);
   dev_s2g(h, h->d.scratch_s[0], h->d.scratch_g[0], nlev, OP_NONE);
   d2h(h, grid, h->d.scratch_g[0], (size_t)nlev * h->g.Jl * h->g.I);
@@ -1716,23 +1752,23 @@ extern "C" int isca_trans_spherical_to_grid(isca_dyn_t *h, const double *spheric
 }
 extern "C" int isca_trans_grid_to_spherical(isca_dyn_t *h, const double *grid, double *spherical, int nlev, int do_truncation) {
   API_BEGIN
-  require_single(h, "trans_grid_to_spherical"); check_nlev(h, nlev);
+  require_single_or_comm(h, "trans_grid_to_spherical"); check_nlev(h, nlev);
   h2d(h, h->d.scratch_g[0], grid, (size_t)nlev * h->g.Jl * h->g.I);
   dev_g2s(h, h->d.scratch_g[0], h->d.scratch_s[0], nlev, do_truncation, OP_NONE);
-  spec_dev_to_host(h, h->d.scratch_s[0], spherical, nlev);
+  spec_dev_to_host_all(h, h->d.scratch_s[0], spherical, nlev);
   API_END
 }
 // transforms.F90:555-596 trans_filter(grid [, filter]): grid -> spherical (truncated) -> optional real (m,n) factor -> grid
 extern "C" int isca_trans_filter(isca_dyn_t *h, double *grid, const double *filter, int nlev) {
   API_BEGIN
-  require_single(h, "trans_filter"); check_nlev(h, nlev);
+  require_single_or_comm(h, "trans_filter"); check_nlev(h, nlev);
   const Geom &g = h->g;
   const size_t n = (size_t)nlev * g.Jl * g.I;
   h2d(h, h->d.scratch_g[0], grid, n);
   dev_g2s(h, h->d.scratch_g[0], h->d.scratch_s[0], nlev, 1, OP_NONE);
   if (filter) {
     std::vector<double> sp((size_t)nlev * g.N1 * g.M1 * 2);
-    spec_dev_to_host(h, h->d.scratch_s[0], sp.data(), nlev);
+    spec_dev_to_host(h, h->d.scratch_s[0], sp.data(), nlev);        // (my wavenumbers: all that goes back to the device)
     for (int k = 0; k < nlev; ++k)
       for (size_t q = 0; q < (size_t)g.N1 * g.M1; ++q) {
         sp[((size_t)k * g.N1 * g.M1 + q) * 2] *= filter[q];
@@ -1746,16 +1782,16 @@ extern "C" int isca_trans_filter(isca_dyn_t *h, double *grid, const double *filt
 }
 extern "C" int isca_vor_div_from_uv_grid(isca_dyn_t *h, const double *u, const double *v, double *vor, double *div, int nlev) {
   API_BEGIN
-  require_single(h, "vor_div_from_uv_grid"); check_nlev(h, nlev);
+  require_single_or_comm(h, "vor_div_from_uv_grid"); check_nlev(h, nlev);
   const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
   h2d(h, h->d.scratch_g[0], u, n); h2d(h, h->d.scratch_g[1], v, n);
   dev_vd_from_uv(h, h->d.scratch_g[0], h->d.scratch_g[1], h->d.scratch_s[0], h->d.scratch_s[1], nlev);
-  spec_dev_to_host(h, h->d.scratch_s[0], vor, nlev); spec_dev_to_host(h, h->d.scratch_s[1], div, nlev);
+  spec_dev_to_host_all(h, h->d.scratch_s[0], vor, nlev); spec_dev_to_host_all(h, h->d.scratch_s[1], div, nlev);
   API_END
 }
 extern "C" int isca_uv_grid_from_vor_div(isca_dyn_t *h, const double *vor, const double *div, double *u, double *v, int nlev) {
   API_BEGIN
-  require_single(h, "uv_grid_from_vor_div"); check_nlev(h, nlev);
+  require_single_or_comm(h, "uv_grid_from_vor_div"); check_nlev(h, nlev);
   const size_t n = (size_t)nlev * h->g.Jl * h->g.I;
   spec_host_to_dev(h, vor, h->d.scratch_s[0], nlev); spec_host_to_dev(h, div, h->d.scratch_s[1], nlev);
   dev_uv_from_vd(h, h->d.scratch_s[0], h->d.scratch_s[1], h->d.scratch_g[0], h->d.scratch_g[1], nlev);

@@ -55,6 +55,7 @@ void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, doubl
 // ---- spectral-space kernels
 // pack a spectral state array [Ml][N1][nlev] (complex) into columns of a work buffer, and back
 void launch_spec_pack(const Geom &g, const double *state, double *S, int C, int coloff, int nlev, hipStream_t s);
+void launch_spec_level_chunk(const Geom &g, const double *src, double *dst, int nlev, int k0, int nk, int copies, hipStream_t s);
 void launch_spec_unpack(const Geom &g, const Dev &d, const double *S, double *state, int C, int coloff, int nlev, int mask, hipStream_t s);
 // (vor,div) state -> (ucos,vcos) columns ; (ucos,vcos) columns -> masked (vor,div) state ; gradient_cos
 void launch_spec_ucos_vcos(const Geom &g, const Dev &d, const double *vor, const double *div, double *S, int C, int col_u, int col_v, int nlev, hipStream_t s);

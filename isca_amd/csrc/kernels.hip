@@ -1044,6 +1044,19 @@ __global__ void k_spec_gradient(Geom g, const double *__restrict__ coef, const d
 
 static inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+// levels [k0, k0 + nk) of a spectral array [ml][n][nlev], `copies` times one behind the other (the send blocks of the stand-alone transforms' gather, api.hip)
+__global__ void k_spec_level_chunk(size_t mn_count, const double2 *__restrict__ src, double2 *__restrict__ dst, int nlev, int k0, int nk, int copies) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, blk = mn_count * nk;
+  if (idx >= blk) return;
+  const size_t mn = idx / nk;
+  const int k = (int)(idx - mn * nk);
+  const double2 v = src[mn * nlev + k0 + k];
+  for (int c = 0; c < copies; ++c) dst[(size_t)c * blk + idx] = v;
+}
+void launch_spec_level_chunk(const Geom &g, const double *src, double *dst, int nlev, int k0, int nk, int copies, hipStream_t s) {
+  const size_t mn = (size_t)g.Ml * g.N1;
+  hipLaunchKernelGGL(k_spec_level_chunk, grid1d(mn * nk), dim3(256), 0, s, mn, (const double2 *)src, (double2 *)dst, nlev, k0, nk, copies);
+}
 void launch_spec_pack(const Geom &g, const double *state, double *S, int C, int coloff, int nlev, hipStream_t s) {
   hipLaunchKernelGGL(k_spec_pack, grid1d((size_t)g.Ml * g.N1 * nlev), dim3(256), 0, s, g, (const double2 *)state, S, C, coloff, nlev);
 }

@@ -111,6 +111,34 @@ def main():
         if rank == 0:
             print(f"sharded x{world} refresh_derived reproduces the derived fields on every rank: {all(flags)}")
             ok &= all(flags)
+    if a.expect_comm:
+        # transforms_mod's stand-alone routines on more than one rank (collective: the library's communicator carries the lat <-> m exchange of the
+        # transform and gathers a spectral result on every rank): each rank hands its band of a global field, every rank gets all wavenumbers
+        rng = np.random.default_rng(11)
+        nl = min(a.levels, 5)
+        gu, gv = rng.standard_normal((2, nl, sh.J, sh.I))
+        j0 = sh.info("lat_start")
+        band = slice(j0, j0 + sh.Jl)
+        s_sh = sh.trans_grid_to_spherical(gu[:, band])
+        g_sh = sh.trans_spherical_to_grid(s_sh)
+        vor, div = sh.vor_div_from_uv_grid(gu[:, band], gv[:, band])
+        u2, v2 = sh.uv_grid_from_vor_div(vor, div)
+        f_sh = sh.trans_filter(gu[:, band])
+        box_t = [None]
+        if rank == 0:
+            s_r = ref.trans_grid_to_spherical(gu); vr, dr = ref.vor_div_from_uv_grid(gu, gv); ur, vr2 = ref.uv_grid_from_vor_div(vr, dr)
+            box_t = [dict(s=s_r, g=ref.trans_spherical_to_grid(s_r), vor=vr, div=dr, u=ur, v=vr2, f=ref.trans_filter(gu))]
+        dist.broadcast_object_list(box_t, src=0)
+        w = box_t[0]
+        relerr = lambda x, y: float(np.max(np.abs(x - y)) / max(np.max(np.abs(y)), 1e-300))
+        errs = dict(s=relerr(s_sh, w["s"]), g=relerr(g_sh, w["g"][:, band]), vor=relerr(vor, w["vor"]), div=relerr(div, w["div"]),
+                    u=relerr(u2, w["u"][:, band]), v=relerr(v2, w["v"][:, band]), f=relerr(f_sh, w["f"][:, band]))
+        flags = [None] * world
+        dist.all_gather_object(flags, errs)
+        if rank == 0:
+            worst = {k: max(f[k] for f in flags) for k in errs}
+            print(f"sharded x{world} stand-alone transforms on every rank vs single:", {k: f"{v:.1e}" for k, v in worst.items()})
+            ok &= all(v < 1e-12 for v in worst.values()) and bool(np.abs(w["s"]).max() > 0)
     # restart of the sharded run: rank 0 writes the combined files, every rank reads its band back; with a spectral tracer (whose coefficients the
     # gathered files do not carry) every rank writes and reads its own piece through the library (isca_dyn_write_restart: <name>.nc.NNNN)
     import tempfile
