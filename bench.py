@@ -104,8 +104,11 @@ def algorithmic_bytes(I, J, M1, N, L, tracer=True, nlf_inv=None):
          "spec_update": 5.0 * 3.0 * tri,                               # read prev, cur, tendency; write cur, future -- of vors, divs, ts
          "fixer_sums": 3.0 * field}
     if tracer:
-        b["tracer_horiz"] = 5.0 * field                                # q, u, v, the physics source in; q after the horizontal step out
-        b["tracer_vert"] = 7.0 * field
+        # horizontal: q of the previous level, atmosphere_mod's copy (source / sink), the current level (the pending term of its filter; what the kernel
+        # filters), u, v in; q after the horizontal step and the filtered current level out.  vertical: that q and w in, the new level out (round 5: the
+        # filter's first half moved from the vertical kernel, which read five fields and wrote two, to the horizontal one: 12 -> 10 passes for the pair)
+        b["tracer_horiz"] = 7.0 * field
+        b["tracer_vert"] = 3.0 * field
     return b
 
 
