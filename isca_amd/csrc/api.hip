@@ -639,6 +639,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       d.t_surf = dalloc<double>(h, ng2); d.precip = dalloc<double>(h, ng2);
       d.moist_work = dalloc<double>(h, moist_work_doubles(g));
       for (int i = 0; i < 2; ++i) { d.cc_dT[i] = dalloc<double>(h, ng3); d.cc_dq[i] = dalloc<double>(h, ng3); d.cc_precip[i] = dalloc<double>(h, ng2); }
+      for (int i = 0; i < 2; ++i) { d.m_t[i] = dalloc<double>(h, ng3); d.m_q[i] = dalloc<double>(h, ng3); d.m_ps[i] = dalloc<double>(h, ng2); }       // (lazy fixers: Dev::m_t)
       h->cc_pipeline = !getenv("ISCA_MOIST_NO_PIPELINE");     // the next step's convection beside this step's physics (core.h: cc_valid)
       HIP_CHECK(hipMemsetAsync(d.precip, 0, ng2 * sizeof(double), h->stream));
       launch_t_surf_init(*h, h->stream);      // mixed_layer_init without restart file: the prescribed distribution
@@ -666,11 +667,12 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (h->dx_fourier) h->Ci = col_pitch(6 * g.L + 2);
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     // Lazy fixers (core.h): for the plain configurations -- one grid tracer at most, Robert filter without the RAW term, no virtual
-    // temperature, not the moist package (whose kernels read the stored fields) --; ISCA_EAGER_FIXERS keeps the pass over the fields.
+    // temperature --; ISCA_EAGER_FIXERS keeps the pass over the fields.  With the moist package (round 5) its pressure kernel, which visits the
+    // current level's T anyway, leaves T, q and p_s with the pending scalars applied for the physics kernels (Dev::m_t).
     // (a vertical advection scheme other than second-centred reads the stored previous level in a kernel of its own: eager fixers)
     const bool vadv_ext = cfg->vert_advect_uv != 0 || cfg->vert_advect_t != 0;
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
-    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && cfg->physics != 1 && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
+    h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
     h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
@@ -1718,6 +1720,7 @@ extern "C" int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value) {
   else if (nm == "cf") *value = h->Cf; else if (nm == "ci") *value = h->Ci;
   else if (nm == "inverse_batch") *value = h->dx_fourier ? 6 * h->g.L + 2 : 7 * h->g.L + 3;      // level-fields of the step's Legendre synthesis
   else if (nm == "phys_calls") *value = h->phys_calls;
+  else if (nm == "lazy_fixers") *value = h->lazy_fix ? 1 : 0;
   else fail("unknown info " + nm);
   API_END
 }

@@ -126,6 +126,9 @@ struct Dev {
   double *ph_dtu = nullptr, *ph_dtv = nullptr, *ph_dtT = nullptr, *ph_dtq = nullptr;   // tendencies returned by idealized_moist_phys
   double *t_surf = nullptr, *precip = nullptr;      // [Jl][I] mixed-layer temperature; rain rate of the last step
   double *moist_work = nullptr;                     // p_full/p_half/z_full/z_half of both time levels
+  // lazy fixers with the moist package: T, q (atmosphere_mod's copy) and p_s of a time level with what is pending on it applied, written once by
+  // k_moist_pressures when the level is the current one, in the pressure slot of that level (the physics kernels read these, not the stored fields)
+  double *m_t[2] = {}, *m_q[2] = {}, *m_ps[2] = {};
   // k_moist_convcond -> k_moist_column, two sets (a step's convection is computed while the step before runs): (conv + cond) rates [L][Jl][I], rain [Jl][I]
   double *cc_dT[2] = {nullptr, nullptr}, *cc_dq[2] = {nullptr, nullptr}, *cc_precip[2] = {nullptr, nullptr};
 };

@@ -76,6 +76,8 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 // vert_advect_uv / vert_advect_t other than second_centered: the scheme on whole columns, added to the column kernel's tendencies
 void launch_vert_advection_schemes(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
 bool virtual_t_on(const isca_dyn &h);
+// rows of Dev::pend (lazy fixers, kernels.hip): what is pending on time level tl sits at pend[4 * tl + ...]; row 2 is the identity
+constexpr int PEND_FACTOR = 0, PEND_TCORR = 1, PEND_WFAC = 2, PEND_IDENTITY = 8;
 void launch_virtual_t(const isca_dyn &h, const double *t, const double *q, double *tv, hipStream_t s);
 void launch_tracer(const isca_dyn &h, const StepScalars &sc, hipStream_t s, int part = -1);
 void launch_tracer_finish(const isca_dyn &h, const StepScalars &sc, int e, hipStream_t s);

@@ -28,7 +28,6 @@ __device__ __forceinline__ double2 ctimes_i(double2 a) { return make_double2(-a.
 // reader applies the level's three scalars (pend[4*tl + 0..2] = mass factor, temperature correction, water factor; row 2 = identity) on
 // the fly.  The products below must round exactly like the stored result of the materialising kernel would, whatever expression they
 // feed, so they are kept out of the compiler's multiply-add contraction.
-constexpr int PEND_FACTOR = 0, PEND_TCORR = 1, PEND_WFAC = 2, PEND_IDENTITY = 8;
 __device__ __forceinline__ double mul_nc(double a, double b) {
 #pragma clang fp contract(off)
   const double r = a * b;

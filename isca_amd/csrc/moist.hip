@@ -414,6 +414,10 @@ struct PressArgs {
   const double *pk, *bk, *surf_geop;
   const double *t[2], *ps[2];
   double *p_full[2], *p_half[2], *z_full, *z_half;
+  // lazy fixers (Dev::m_t): the level's T, q, p_s with the pending mass factor, temperature correction and water factor applied, into the level's slot
+  const double *q[2], *pend[2];
+  double *t_out[2], *q_out[2], *ps_out[2];
+  const int *kmask; int mbyte[2], lazy;
   int ncol, L, store_half;
   int tl0;                 // first time level of the launch (1: the previous level's pressures are cached)
   int mcm;                 // vert_difference_option = 'mcm': p_full = the mean of the half levels (press_and_geopot.F90:196-200)
@@ -435,13 +439,28 @@ __global__ __launch_bounds__(256) void k_moist_pressures(PressArgs a) {
   if (col >= a.ncol) return;
   const int k0 = blockIdx.y * MP_PK, tl = blockIdx.z + a.tl0, L = a.L;
   const size_t c = (size_t)col, s = (size_t)a.ncol;
-  const double ps = a.ps[tl][c];
+  double ps = a.ps[tl][c];
   const double *pk = a.pk, *bk = a.bk;
   const bool top0 = (pk[0] == 0.0 && bk[0] == 0.0);
   const int ktop = (pk[0] == 0.0) ? 1 : 0;
   double tk[MP_PK];
 #pragma unroll
-  for (int i = 0; i < MP_PK; ++i) tk[i] = (tl == 1) ? a.t[1][c + (size_t)min(k0 + i, L - 1) * s] : 0.0;
+  for (int i = 0; i < MP_PK; ++i) tk[i] = (tl == 1 || a.lazy) ? a.t[tl][c + (size_t)min(k0 + i, L - 1) * s] : 0.0;
+  if (a.lazy) {       // what k_fixer_apply would have left in the stored fields (compute_corrections, spectral_dynamics.F90:1213-1283), formed here instead
+    double qk[MP_PK];
+#pragma unroll
+    for (int i = 0; i < MP_PK; ++i) qk[i] = a.q[tl][c + (size_t)min(k0 + i, L - 1) * s];
+    const double fac = a.pend[tl][PEND_FACTOR], tc = a.pend[tl][PEND_TCORR], wfac = a.pend[tl][PEND_WFAC];
+    const int km = (a.kmask[c] >> (8 * a.mbyte[tl])) & 0xff;        // levels above water_correction_limit in the step that made this level
+    ps = ps * fac;
+    if (blockIdx.y == 0) a.ps_out[tl][c] = ps;
+#pragma unroll
+    for (int i = 0; i < MP_PK; ++i) {
+      const int k = k0 + i;
+      tk[i] = tk[i] + tc;
+      if (k < L) { a.t_out[tl][c + (size_t)k * s] = tk[i]; a.q_out[tl][c + (size_t)k * s] = qk[i] * ((k >= km) ? wfac : 1.0); }
+    }
+  }
   double ph0 = pk[k0] + bk[k0] * ps;
   double l0 = (top0 && k0 == 0) ? 0.0 : log(ph0);
 #pragma unroll
@@ -493,6 +512,13 @@ void launch_moist_pressures(const isca_dyn &h, const StepScalars &sc, hipStream_
   a.p_full[0] = pf_p; a.p_half[0] = ph_p; a.p_full[1] = pf_c; a.p_half[1] = ph_c; a.z_full = zf_c; a.z_half = zh_c;
   a.store_half = moist_sigma_half(h.g.L) ? 0 : 1;
   a.tl0 = prev_cached ? 1 : 0;
+  a.lazy = h.lazy_fix ? 1 : 0;
+  if (a.lazy) {         // (between steps the mask word's byte 0 belongs to the current level, byte 1 to the previous one: launch_fixer_materialize)
+    a.q[0] = d.tr_atm[sc.prev]; a.q[1] = d.tr_atm[sc.cur]; a.pend[0] = d.pend + 4 * sc.prev; a.pend[1] = d.pend + 4 * sc.cur;
+    a.t_out[0] = d.m_t[slot_prev]; a.q_out[0] = d.m_q[slot_prev]; a.ps_out[0] = d.m_ps[slot_prev];
+    a.t_out[1] = d.m_t[slot_cur]; a.q_out[1] = d.m_q[slot_cur]; a.ps_out[1] = d.m_ps[slot_cur];
+    a.kmask = d.kmask; a.mbyte[0] = 1; a.mbyte[1] = 0;
+  }
   a.mcm = h.cfg.vert_difference_option == 1;
   hipLaunchKernelGGL(k_moist_pressures, dim3((unsigned)((lev + 255) / 256), (h.g.L + MP_PK - 1) / MP_PK, prev_cached ? 1 : 2), dim3(256), 0, s, a);      // (the heights: summed by k_moist_physics)
 }
@@ -504,9 +530,9 @@ void launch_moist_convcond(const isca_dyn &h, int level, int pslot, double delta
   const MoistWork w = moist_work_layout(h);
   MoistArgs a = moist_args(h);
   a.ncol = (int)lev; a.I = h.g.I;
-  a.tp = d.tg[level]; a.qp = d.tr_atm[level];
+  a.tp = h.lazy_fix ? d.m_t[pslot] : d.tg[level]; a.qp = h.lazy_fix ? d.m_q[pslot] : d.tr_atm[level];
   a.pf_p = w.pf[pslot]; a.ph_p = w.ph[pslot];
-  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = d.psg[level]; }
+  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = h.lazy_fix ? d.m_ps[pslot] : d.psg[level]; }
   a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
   a.delta_t = delta_t;
   launch_moist_convcond_kernel(a, s);
@@ -521,14 +547,16 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
   MoistArgs a = moist_args(h);
   a.ncol = (int)lev; a.I = h.g.I;
   a.up = d.ug[sc.prev]; a.vp = d.vg[sc.prev]; a.tp = d.tg[sc.prev]; a.qp = d.tr_atm[sc.prev];
+  if (h.lazy_fix) { a.tp = d.m_t[1 - slot_cur]; a.qp = d.m_q[1 - slot_cur]; }       // (the previous level's slot is the other one)
   a.pf_c = w.pf[slot_cur]; a.ph_c = w.ph[slot_cur]; a.zf_c = w.zf_c; a.zh_c = w.zh_c;
   a.rad_lat_row = d.rad_lat_l; a.rad_lat_col = nullptr;
   a.surf_geop = d.surf_geop; a.ktop = (h.tab.pk[0] == 0.0) ? 1 : 0;
-  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_c = d.psg[sc.cur]; }
+  if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_c = h.lazy_fix ? d.m_ps[slot_cur] : d.psg[sc.cur]; }
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
   a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
   a.do_next = next ? 1 : 0;
   a.tn = d.tg[sc.cur]; a.qn = d.tr_atm[sc.cur]; a.dt_next = 2 * h.cfg.dt_atmos;
+  if (h.lazy_fix) { a.tn = d.m_t[slot_cur]; a.qn = d.m_q[slot_cur]; }
   a.nx_dT = d.cc_dT[1 - ccslot]; a.nx_dq = d.cc_dq[1 - ccslot]; a.nx_precip = d.cc_precip[1 - ccslot];
   a.work = zh_p + lev * (h.g.L + 1);
   a.delta_t = sc.delta_t;

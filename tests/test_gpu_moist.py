@@ -210,6 +210,38 @@ def test_moist_convection_ahead_equals_in_step(monkeypatch):
         assert np.array_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("sigma_half", [False, True])
+def test_moist_lazy_fixers_equal_eager(monkeypatch, sigma_half):
+    """The fixers' corrections left pending on the new level (lazy fixers) in the moist model too: the dynamics' kernels apply them as they read the
+    level, and the physics' pressure kernel -- which visits the current level's T anyway -- leaves T, q (atmosphere_mod's copy) and p_s with the
+    pending scalars applied for the column kernels.  Against ISCA_EAGER_FIXERS=1 (the pass over the fields at the end of every step, as until
+    round 5): 60 steps from the cold start (it rains from step ~30 in this configuration's tropics), with a host read, a state write and a read of
+    the pressures in between, bit for bit; also with the half-level pressures formed on the fly from the corrected p_s."""
+    if sigma_half:
+        monkeypatch.setenv("ISCA_MOIST_PHALF", "sigma")
+    def run(eager, looks):
+        (monkeypatch.setenv("ISCA_EAGER_FIXERS", "1") if eager else monkeypatch.delenv("ISCA_EAGER_FIXERS", raising=False))
+        dc = moist_core()
+        assert bool(dc.info("lazy_fixers")) == (not eager)
+        dc.cold_start()
+        done = 0
+        for stop in looks + [60]:
+            dc.step(stop - done); done = stop
+            if looks:
+                dc.get("tg"); dc.get("p_full")
+                if stop == looks[-1]:
+                    ts = dc.get("t_surf"); dc.set("t_surf", ts)
+        out = {(k, tl): dc.get(k, tl) for k in ("ug", "vg", "tg", "psg", "tr", "tr_atm", "ts", "ln_ps") for tl in (0, 1)}
+        out["t_surf"], out["precip"], out["fixer"] = dc.get("t_surf"), dc.get("precip"), dc.table("fixer")[16:19]
+        dc.close()
+        return out
+    lazy, looked, eager = run(False, []), run(False, [1, 2, 17, 40]), run(True, [])
+    assert eager["fixer"][0] != 1.0 and eager["fixer"][1] != 0.0 and eager["fixer"][2] != 1.0
+    for k in eager:
+        assert np.array_equal(lazy[k], eager[k]), k
+        assert np.array_equal(looked[k], eager[k]), k
+
+
 def test_moist_virtual_temperature(golden_dir):
     """use_virtual_temperature = .true. in the moist model (q ~ 1e-2: a 0.6 % change of the pressure-gradient and energy-conversion terms
     and of the heights the physics sees): 40 steps from the cold start against the reference run with the same flag, same error measure
