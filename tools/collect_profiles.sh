@@ -8,7 +8,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export ISCA_BENCH_NO_EXTRA=1     # only the named workload in the profiled command
 TOP=gpurun_out/prof_final
 rm -rf $TOP; mkdir -p $TOP
-for W in T85L40 T170L60; do
+WL="T85L40 T170L60"; [ "$ONLY" = moist ] && WL=""        # ONLY=moist: the Frierson configuration's files alone
+for W in $WL; do
   OUT=$TOP/$W; mkdir -p $OUT
   S=500; [ $W = T170L60 ] && S=150
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --workload $W --steps $S --warmup 50 --cpu-steps 0 > $OUT/bench_stats.log 2>&1
@@ -32,6 +33,7 @@ for pm in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY S
 done
 python tools/summarize_profiles.py $OUT
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+[ "$ONLY" = moist ] && exit 0
 # the plain bench line of the headline workload (no profiler attached)
 unset ISCA_BENCH_NO_EXTRA
 timeout 600 python bench.py --steps 500 --warmup 50 > $TOP/bench_T85L40.json.log 2>&1

@@ -11,8 +11,8 @@ dc = dyncore.DynCore(cfg); dc.cold_start()
 mode = sys.argv[4] if len(sys.argv) > 4 else ""
 if mode == "spunup":               # for the profiler (rocprofv3 --collection-period 9:2:1): 35 days of spin-up, then steps for ~7 s
     dc.step(10000)
-    t0 = time.time(); dc.step(16000); t1 = time.time()
-    print(f"{res}L{L} moist, steps 10000-26000: {(t1-t0)/16000*1e3:.4f} ms/step")
+    t0 = time.time(); dc.step(30000); t1 = time.time()
+    print(f"{res}L{L} moist, steps 10000-40000: {(t1-t0)/30000*1e3:.4f} ms/step")
     sys.exit(0)
 short = mode == "short"            # a short run for the counter passes
 dc.step(60 if short else 200)
