@@ -3006,6 +3006,7 @@ void launch_fv_horiz_on(const isca_dyn &h, const double *u, const double *v, con
   a.ua = u; a.va = v; a.trp = q; a.tratm_p = q; a.trh = q_new; a.ps_cur = ps;   // ps only enters the (zero) surface flux
   a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
   a.tr_b = q; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
+  a.filt_horiz = 0;                            // (the transport alone: nothing of the model's time levels is touched)
   const size_t ldsh = (size_t)TR_LDS_ROWS * g.I * sizeof(double);
   launch_tracer_horiz_kernel(g, a, ldsh, s);
 }
@@ -3017,6 +3018,7 @@ void launch_ppm_vert_on(const isca_dyn &h, double dt, const double *w, const dou
   a.trh = const_cast<double *>(r); a.wg = w; a.ps_cur = ps; a.ps_prev = ps; a.trp = dummy_a; a.tratm_p = dummy_a;
   a.tr_cur = dummy_b; a.tr_fut = r_new; a.flux = 0.0; a.rdamp = 0.0; a.dt = dt;
   a.tr_b = dummy_a; a.tr_cur_rd = dummy_b; a.rb = 0.0; a.pend_a = a.pend_c = h.d.pend + PEND_IDENTITY;
+  a.filt_horiz = 0;
   launch_tracer_vert_kernel(g, a, s);
 }
 // tracer_source_sink (hs_forcing.F90:683-724) on caller fields: rst += flux/dp at the lowest level - tr/sink

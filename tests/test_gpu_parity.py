@@ -1384,6 +1384,27 @@ def test_tracer_filter_half_in_the_horizontal_kernel(monkeypatch, case):
     assert np.abs(old[("tr", 1)]).max() > 0
 
 
+def test_caller_field_transport_leaves_the_model_state_alone(golden_dir):
+    """a_grid_horiz_advection / vert_advection on caller fields run the step's own tracer kernels; called between steps they must not do what those kernels
+    do for the model inside a step (the filter's first half on the current tracer level, the water fixer's sums): the run continues bit for bit."""
+    g = np.load(os.path.join(golden_dir, "kernels_T21L6.npz"))
+    a, b = make("T21", 6), make("T21", 6)
+    for dc in (a, b):
+        dc.cold_start(); dc.step(9)
+    before = {(k, tl): a.get(k, tl) for k in ("tr", "tr_atm") for tl in (0, 1)}
+    a.step(3)                                              # (pending corrections and the filter's bookkeeping in the state they have between steps)
+    b.step(3)
+    want = a.a_grid_horiz_advection(g["in_grid_a"], g["in_grid_b"], g["in_q"], 1200.0)
+    a.vert_advection_ppm(1200.0, g["in_wg"], g["in_ps"], g["in_q"])
+    assert rel(want, g["out_hadv_fv"]) < 1e-12
+    a.step(5); b.step(5)
+    for k in ALL_STATE:
+        for tl in (0, 1):
+            assert np.array_equal(a.get(k, tl), b.get(k, tl)), (k, tl)
+    assert not np.array_equal(before[("tr", 1)], a.get("tr", 1))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("case", ["three_tracers", "cold", "moist"])
 def test_native_restart_files(tmp_path, case):
     """isca_dyn_write_restart / isca_dyn_read_restart (the library's own netCDF-classic writer and reader, csrc/restart_nc.cpp: what the Fortran drop-in's
