@@ -1298,12 +1298,23 @@ static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
   isca::Comm &c = *h->comm;
   upload_wave_matrices(h, sc.delta_t);
   phase0(h, sc);
-  if (h->tracer_on) {   // the tracer's halo rows first (small), so that its transport runs under the all-to-all
+  // ISCA_HALO_WITH_ALL_TO_ALL=1: the tracer's halo rows travel in the group of the lat -> m all-to-all (Comm::all_to_all_with_halo: one exchange, one
+  // latency hop less on the step's critical path -- three instead of four); the tracer's transport then starts behind that exchange and runs under
+  // the spectral phase instead of under the exchange.  Same results; which order is faster is a question for a node with more than one GPU.
+  static const bool fold_halo = getenv("ISCA_HALO_WITH_ALL_TO_ALL") != nullptr;
+  if (h->tracer_on && fold_halo) {
     const size_t n = halo_doubles(g, h->cfg.num_tracers);
-    { Timed t(h, "halo"); c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream); }
+    { Timed t(h, "all_to_all_fwd"); c.all_to_all_with_halo(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->d.halo_send, h->d.halo_send + n,
+                                                           h->d.halo_recv, h->d.halo_recv + n, n, h->stream); }
     phase_tracer(h, sc);
+  } else {
+    if (h->tracer_on) {   // the tracer's halo rows first (small), so that its transport runs under the all-to-all
+      const size_t n = halo_doubles(g, h->cfg.num_tracers);
+      { Timed t(h, "halo"); c.halo(h->d.halo_send, h->d.halo_send + n, h->d.halo_recv, h->d.halo_recv + n, n, h->stream); }
+      phase_tracer(h, sc);
+    }
+    { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
   }
-  { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
   phase1(h, sc);
   { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
   phase2(h, sc);

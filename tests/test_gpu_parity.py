@@ -1190,6 +1190,21 @@ def test_sharded_native_loop_device_resident_exchange(world, res, levels, raw, t
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("comm,world,levels,tracers", [("ipc", 2, 25, 1), ("ipc", 4, 8, 2), ("peer", 4, 25, 1)])
+def test_sharded_halo_rows_in_the_all_to_all_group(comm, world, levels, tracers):
+    """ISCA_HALO_WITH_ALL_TO_ALL=1: the tracer's halo rows in the group of the lat -> m all-to-all (three exchanges per step instead of four; the
+    transport then runs under the spectral phase).  Same checks as the default order: against the single-rank run at 1e-10, restart bit for bit."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(29760 + world + (10 if comm == "peer" else 0)),
+           os.path.join(repo, "tests", "mp_sharded_check.py"), "--backend", "gloo", "--steps", "8",
+           "--res", "T21", "--levels", str(levels), "--tracers", str(tracers), "--expect-comm", comm]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM=comm, ISCA_IPC_TIMEOUT_S="300", ISCA_PEER_TIMEOUT_S="30", ISCA_HALO_WITH_ALL_TO_ALL="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=repo)
+    assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_constants_nml_radius_omega():
     """constants_nml radius / omega: the transforms do not depend on the radius, the derivative operators scale with 1/a, the Laplacian
     with 1/a^2, the Coriolis parameter with omega (the 3-D core's tables are the ones the sibling cores use)."""
