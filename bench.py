@@ -496,31 +496,42 @@ def main():
         # of the node (ISCA_COMM=peer, csrc/comm_peer.hip: one kernel per exchange that stores into hipIpc-mapped peer buffers).  It has been verified
         # with N processes on one GPU only, so its first run over xGMI must not be able to take this job's line with it: a separate process group,
         # a time limit, and whatever goes wrong is reported as text.
+        def own_job(extra_env, port_offset, timeout=300):
+            """the same command as a torch.distributed.run job of its own, launched by rank 0 (this job's ranks wait at the barrier behind it)"""
+            import subprocess
+            env = dict(os.environ, ISCA_BENCH_NO_VARIANTS="1", ISCA_BENCH_STEADY="0", ISCA_BENCH_WATCHDOG_S="200", **extra_env)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)
+            port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(a.steps), "--warmup", str(a.warmup),
+                   "--workload", a.workload]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                d = json.loads(ln[-1]) if ln else None
+                if d and d.get("value"):
+                    return {"ms_per_step": d["ms_per_step"], "exchange_ms_rank0": d["exchange_ms"][0] if d.get("exchange_ms") else None}
+                return {"error": (d or {}).get("error") or (r.stdout[-200:] + r.stderr[-300:])}
+            except Exception as e:                               # noqa: BLE001
+                return {"error": str(e)[:200]}
         if isinstance(variants, dict) and "error" not in variants and os.environ.get("ISCA_COMM", "native") != "peer":
             peer = None
             if rank == 0:
-                import subprocess
-                env = dict(os.environ, ISCA_COMM="peer", ISCA_BENCH_NO_VARIANTS="1", ISCA_BENCH_STEADY="0", ISCA_PEER_TIMEOUT_S="30", ISCA_BENCH_WATCHDOG_S="200")
-                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
-                    env.pop(k, None)
-                port = int(os.environ.get("MASTER_PORT", "29500")) + 17
-                cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                       "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(world), "--steps", str(a.steps), "--warmup", str(a.warmup),
-                       "--workload", a.workload]
-                try:
-                    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-                    ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
-                    d = json.loads(ln[-1]) if ln else None
-                    if d and d.get("value"):
-                        peer = {"ms_per_step": d["ms_per_step"], "exchange_ms_rank0": d["exchange_ms"][0] if d.get("exchange_ms") else None,
-                                "note": "a job of its own (this one's ranks idle meanwhile); unmeasured on xGMI before this run"}
-                    else:
-                        peer = {"error": (d or {}).get("error") or (r.stdout[-200:] + r.stderr[-300:])}
-                except Exception as e:                               # noqa: BLE001
-                    peer = {"error": str(e)[:200]}
+                peer = own_job({"ISCA_COMM": "peer", "ISCA_PEER_TIMEOUT_S": "30"}, 17)
+                peer["note"] = "a job of its own (this one's ranks idle meanwhile); unmeasured on xGMI before this run"
             barrier()
             if rank == 0:
                 variants["device-resident exchange (ISCA_COMM=peer: stores into hipIpc-mapped peer buffers, one kernel per exchange)"] = peer
+        # A fourth: the tracer's halo rows in the lat -> m all-to-all's group (three exchanges per step instead of four, the transport under the spectral phase
+        # instead of under the exchange): same results (tests); which order is faster only a node with more than one GPU can say -- also a job of its own.
+        if isinstance(variants, dict) and "error" not in variants and not os.environ.get("ISCA_HALO_WITH_ALL_TO_ALL"):
+            folded = None
+            if rank == 0:
+                folded = own_job({"ISCA_HALO_WITH_ALL_TO_ALL": "1"}, 29)
+            barrier()
+            if rank == 0:
+                variants["halo rows in the first all-to-all's group (ISCA_HALO_WITH_ALL_TO_ALL=1: 3 exchanges per step)"] = folded
     exchange_ms = None
     if world > 1:       # what each rank spent in the exchanges of a step (HIP events around the RCCL calls the library issues)
         mine = {k: round(v, 5) for k, v in kt.items() if k in ("halo", "all_to_all_fwd", "all_to_all_inv", "all_reduce", "all_to_all_raw")}

@@ -1703,8 +1703,9 @@ def test_bench_two_ranks_native_loop_and_variants():
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["steady"]["steps"] >= 500
     assert all("native (ipc)" in e["driver"] and "all_to_all_fwd" in e for e in d["exchange_ms"])
     v = d["variants"]
-    assert len(v) == 3 and all(x["ms_per_step"] > 0 for x in v.values()), v            # the library's loop (timed), torch between the phases, and the
-    assert any("ISCA_COMM=peer" in k and "all_to_all_fwd" in x["exchange_ms_rank0"] for k, x in v.items()), v      # device-resident exchange in a job of its own
+    assert len(v) == 4 and all(x["ms_per_step"] > 0 for x in v.values()), v            # the library's loop (timed), torch between the phases, and the
+    assert any("ISCA_COMM=peer" in k and "all_to_all_fwd" in x["exchange_ms_rank0"] for k, x in v.items()), v      # device-resident exchange in a job of its own,
+    assert any("ISCA_HALO_WITH_ALL_TO_ALL" in k and "halo" not in x["exchange_ms_rank0"] and "all_to_all_fwd" in x["exchange_ms_rank0"] for k, x in v.items()), v   # the halo rows folded in
 
 
 def test_bench_eight_ranks_headline_workload_on_one_gpu():
@@ -1723,7 +1724,7 @@ def test_bench_eight_ranks_headline_workload_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["value"] > 0 and "T85L40" in d["config"]["workload"] and d["config"]["parallelism"] == "lat-band x8"
     assert len(d["exchange_ms"]) == 8 and all("native (ipc)" in e["driver"] and "all_to_all_inv" in e and "all_reduce" in e for e in d["exchange_ms"])
-    assert d["replicas"]["value"] > 0 and len(d["variants"]) == 3 and all(x["ms_per_step"] > 0 for x in d["variants"].values()), d.get("variants")
+    assert d["replicas"]["value"] > 0 and len(d["variants"]) == 4 and all(x["ms_per_step"] > 0 for x in d["variants"].values()), d.get("variants")
 
 
 def test_bench_shard_compute():
