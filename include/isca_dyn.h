@@ -257,7 +257,7 @@ int isca_dyn_refresh_derived(isca_dyn_t *h);
 /* tables: "sin_lat","wts_lat","deg_lat","deg_lon","pk","bk","legendre" (m,n,lat_max/2),
  * "eigen_laplacian" (m,n), "wave_matrix" (lev,lev,0:num_spherical-1) for the current delta_t */
 int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host, size_t count);
-int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer","inverse_batch" (level-fields of the step's synthesis batch: 7 L + 3, or 6 L + 2 when the inverse FFT forms the x-derivatives) */
+int isca_dyn_get_info(isca_dyn_t *h, const char *name, long *value);   /* "step","previous","current","lat_local","lat_start","m_local","kernels_per_step","tracer","inverse_batch" (level-fields of the step's synthesis batch: 7 L + 3, or 6 L + 2 when the inverse FFT forms the x-derivatives), "lazy_fixers" (1: the fixers' corrections stay pending on a new level and are applied by its readers) */
 /* What idealized_moist_phys_mod keeps beside the fields, for handing over a RUNNING model through set_state (a restart resets it, as
  * idealized_moist_phys_init does): "phys_calls" = calls of the physics since init -- 0: the next call is the first (gust = 1 m/s,
  * idealized_moist_phys.F90:592), > 0: vert_turb_driver's constant_gust (:1262).  Also readable through isca_dyn_get_info. */
