@@ -496,10 +496,10 @@ def main():
         # of the node (ISCA_COMM=peer, csrc/comm_peer.hip: one kernel per exchange that stores into hipIpc-mapped peer buffers).  It has been verified
         # with N processes on one GPU only, so its first run over xGMI must not be able to take this job's line with it: a separate process group,
         # a time limit, and whatever goes wrong is reported as text.
-        def own_job(extra_env, port_offset, timeout=300):
+        def own_job(extra_env, port_offset, timeout=240):      # (two such jobs, the other ranks at a barrier meanwhile: well inside the process group's and the watchdog's limits)
             """the same command as a torch.distributed.run job of its own, launched by rank 0 (this job's ranks wait at the barrier behind it)"""
             import subprocess
-            env = dict(os.environ, ISCA_BENCH_NO_VARIANTS="1", ISCA_BENCH_STEADY="0", ISCA_BENCH_WATCHDOG_S="200", **extra_env)
+            env = dict(os.environ, ISCA_BENCH_NO_VARIANTS="1", ISCA_BENCH_STEADY="0", ISCA_BENCH_WATCHDOG_S="180", **extra_env)
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
                 env.pop(k, None)
             port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
