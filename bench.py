@@ -268,28 +268,62 @@ def shard_probe(a):
     core = dyncore.DynCore(dyncore.default_config(res, num_levels=L, dt_atmos=dt, rank=rank, world_size=world, device=0))
     core.comm_init_env()
     core.cold_start(); core.step(a.warmup, sync=True)
-    core.kernel_times(True); core.step(a.steps, sync=True); kt = core.kernel_times(False)
-    print("SHARD_PROBE " + json.dumps({"rank": rank, "kernel_ms": kt}), flush=True)
+    core.kernel_times(1); core.step(a.steps, sync=True); kt = core.kernel_times(2)       # one event pair per kernel ...
+    core.step(a.steps, sync=True); seg = core.kernel_times(0)                              # ... then one per run of kernels between two exchanges
+    print("SHARD_PROBE " + json.dumps({"rank": rank, "kernel_ms": kt, "segment_ms": seg}), flush=True)
     core.close()
 
 
-def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240):
-    """The compute half of the scaling curve, measured on ONE GPU: for P = 2, 4, 8 the per-step kernel time of a 1/P latitude-band shard of
-    `workload` (shard_probe above), exchanges excluded -- `main_stream_ms` (the step's critical path without its exchanges), `side_stream_ms`
-    (the tracer's transport, which runs under the first all-to-all and the spectral stage), the slowest rank's.  What it does NOT hold: the
-    exchanges themselves (no xGMI here) and the kernels' gaps.  A failure is reported, not raised."""
+def keep_clocks_main(seconds):
+    """internal (--keep-clocks S): a process of its own that keeps one idle wavefront per XCD resident for S seconds (isca_bench_keep_clocks), so that a
+    job whose ranks take turns on this GPU is not measured at the clocks of an idle device; ends when its stdin closes"""
+    from isca_amd import dyncore
+    lib = dyncore.load_library()
+    if lib.isca_bench_keep_clocks(0, float(seconds)) != 0:
+        raise SystemExit("keep_clocks: " + lib.isca_last_error().decode())
+    print("KEEP_CLOCKS on", flush=True)
+    sys.stdin.read()
+    lib.isca_bench_keep_clocks(0, 0.0)
+
+
+def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240, keep_clocks=True, extra_env=None, rocprof_dir=None):
+    """The compute half of the scaling curve, measured on ONE GPU: for P = 2, 4, 8 the per-step device time of a 1/P latitude-band shard of
+    `workload` (shard_probe above), exchanges excluded, the slowest rank's --
+      `main_stream_ms`   sum of the main stream's kernels, one HIP-event pair per kernel (each pair adds ~4 us to what it brackets);
+      `segments_ms`      sum of the four runs of kernels between the step's exchanges, one event pair per run: what the rank's stream is busy
+                         per step, launch gaps included -- the number to add the exchanges to;
+      `side_stream_ms`   the tracer's transport, which runs under the first all-to-all and the spectral stage.
+    keep_clocks: one idle wavefront per XCD stays resident meanwhile (isca_bench_keep_clocks) -- the ranks take turns with a host hand-shake
+    in between, and an idle device clocks down.  rocprof_dir: rank 0 runs under rocprofv3 --kernel-trace --stats (its kernels' own durations).
+    What this does NOT hold: the exchanges themselves (no xGMI here).  A failure is reported, not raised."""
     import subprocess, tempfile, uuid
-    out = {"how": "P processes share this GPU and take turns (ISCA_COMM=ipc, ISCA_IPC_SERIALIZE=1): HIP-event kernel durations of the slowest rank, "
-                  "exchanges excluded; unmeasured on xGMI"}
+    out = {"how": "P processes share this GPU and take turns (ISCA_COMM=ipc, ISCA_IPC_SERIALIZE=1): HIP-event durations of the slowest rank, "
+                  "exchanges excluded; main_stream_ms = per-kernel event pairs summed, segments_ms = one pair per run of kernels between two exchanges"
+                  + ("; one idle wavefront per XCD kept resident so that the device keeps its clocks" if keep_clocks else "") + "; unmeasured on xGMI"}
+    keeper = None
+    if keep_clocks:
+        try:
+            keeper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--keep-clocks", str(min(600, 3 * timeout))], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            for ln in keeper.stdout:
+                if ln.startswith("KEEP_CLOCKS"):
+                    break
+            else:
+                raise RuntimeError("the keeper did not start")
+        except Exception as e:                                           # noqa: BLE001
+            out["keep_clocks_error"] = str(e)[:100]; keeper = None
     for P in ranks:
         try:
             with tempfile.TemporaryDirectory(prefix="shard_") as d:
                 env = dict(os.environ, ISCA_COMM="ipc", ISCA_IPC_SERIALIZE="1", ISCA_IPC_TIMEOUT_S=os.environ.get("ISCA_IPC_TIMEOUT_S", "60"), ISCA_COMM_ID_FILE=os.path.join(d, "id"), ISCA_COMM_NONCE=uuid.uuid4().hex,
                            WORLD_SIZE=str(P), ISCA_IPC_DIR=d if os.environ.get("ISCA_BENCH_IPC_TMP") else os.environ.get("ISCA_IPC_DIR", ""))
-                procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--shard-probe", "--workload", workload, "--gpus", str(P),
-                                           "--steps", str(steps), "--warmup", str(warmup)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                env.setdefault("GPU_MAX_HW_QUEUES", "2")       # (a rank has two streams; eight ranks with the runtime's four queues each oversubscribe the device's hardware queues)
+                env.update(extra_env or {})
+                cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--workload", workload, "--gpus", str(P), "--steps", str(steps), "--warmup", str(warmup)]
+                prof = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(rocprof_dir, f"{workload}_P{P}"), "-o", "rank0", "--"] if rocprof_dir else []
+                procs = [subprocess.Popen((prof if r == 0 else []) + cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                                           stderr=subprocess.PIPE, text=True) for r in range(P)]
-                per_rank = []
+                per_rank, per_seg = [], []
                 for pr in procs:
                     try:
                         o, e = pr.communicate(timeout=timeout)
@@ -300,14 +334,22 @@ def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240):
                     m = [ln for ln in o.splitlines() if ln.startswith("SHARD_PROBE ")]
                     if pr.returncode != 0 or not m:
                         raise RuntimeError((e or o)[-200:])
-                    per_rank.append(json.loads(m[-1][len("SHARD_PROBE "):])["kernel_ms"])
+                    rec = json.loads(m[-1][len("SHARD_PROBE "):])
+                    per_rank.append(rec["kernel_ms"]); per_seg.append(rec.get("segment_ms", {}))
             main = [sum(v for k, v in kt.items() if k not in EXCHANGE_TIMERS and k not in SIDE_STREAM_TIMERS) for kt in per_rank]
             side = [sum(v for k, v in kt.items() if k in SIDE_STREAM_TIMERS) for kt in per_rank]
+            segs = [sum(v for k, v in sg.items() if k.startswith("seg_")) for sg in per_seg]
             slow = max(range(P), key=lambda r: main[r])
-            out[f"P={P}"] = {"main_stream_ms": round(main[slow], 5), "side_stream_ms": round(side[slow], 5),
-                             "kernel_ms": {k: round(v, 5) for k, v in per_rank[slow].items() if k not in EXCHANGE_TIMERS}}
+            out[f"P={P}"] = {"main_stream_ms": round(main[slow], 5), "segments_ms": round(max(segs), 5), "side_stream_ms": round(side[slow], 5),
+                             "kernel_ms": {k: round(v, 5) for k, v in per_rank[slow].items() if k not in EXCHANGE_TIMERS},
+                             "segment_ms": {k: round(v, 5) for k, v in per_seg[max(range(P), key=lambda r: segs[r])].items() if k.startswith("seg_")}}
         except Exception as e:                                           # noqa: BLE001
             out[f"P={P}"] = {"error": str(e)[:200]}
+    if keeper is not None:
+        try:
+            keeper.stdin.close(); keeper.wait(timeout=20)
+        except Exception:                                                # noqa: BLE001
+            keeper.kill()
     return out
 
 
@@ -355,9 +397,12 @@ def main():
     ap.add_argument("--workload", default="T85L40", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=24, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--shard-probe", action="store_true", help="internal: one rank of shard_compute()'s P-rank job (RANK / WORLD_SIZE from the environment)")
+    ap.add_argument("--keep-clocks", type=float, default=0.0, help="internal: shard_compute()'s clock keeper, for that many seconds or until stdin closes")
     a = ap.parse_args()
     if a.shard_probe:
         return shard_probe(a)
+    if a.keep_clocks > 0:
+        return keep_clocks_main(a.keep_clocks)
     res, L, dt = WORKLOADS[a.workload]
 
     import torch

@@ -190,6 +190,10 @@ int isca_dyn_cold_start(isca_dyn_t *h);
 /* atmosphere(Time) x nsteps: hs_forcing -> spectral_dynamics -> time-level rotation
  * (atmosphere.F90:276-352).  Asynchronous on the handle's stream unless sync != 0. */
 int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync);
+/* Waits for the handle's stream and raises what the steps since the last synchronisation left behind (temperatures outside valid_range_t: the
+ * reference's FATAL, spectral_dynamics.F90:940).  COLLECTIVE on a handle with a communicator (isca_dyn_comm_init): the verdict is summed over the
+ * ranks so that every rank raises when one band is out of range -- every rank must call it (and pass the same `sync` to isca_dyn_step /
+ * isca_dyn_dynamics) at the same point of the run, like the reference's error_mesg(..., FATAL), which stops all PEs. */
 int isca_dyn_synchronize(isca_dyn_t *h);
 
 /* The physics / dynamics seam of atmosphere.F90:300-329 for a host that keeps a physics package of its own (physics = 2):
@@ -410,6 +414,9 @@ int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, double *pair
 /* per-kernel average milliseconds over the steps run since the last call (HIP events); names are
  * returned as a ';'-separated list in `names` */
 int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int max, char *names, size_t names_len, int *n);
+/* measurement helper: keeps one idle wavefront per XCD resident on `device` for at most `seconds` (0: stop it), so that a job whose
+ * ranks take turns on one GPU (bench.py: shard_compute) is not measured at the clocks of an idle device.  No reference counterpart. */
+int isca_bench_keep_clocks(int device, double seconds);
 
 #ifdef __cplusplus
 }

@@ -47,8 +47,8 @@ struct Timed {
   int id = -1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t st;
-  Timed(isca_dyn *h_, const char *name, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream) {
-    if (!h->timer.enabled) return;
+  Timed(isca_dyn *h_, const char *name, hipStream_t st_ = nullptr, bool segment = false) : h(h_), st(st_ ? st_ : h_->stream) {
+    if (!h->timer.enabled || h->timer.segments != segment) return;
     auto &t = h->timer;
     for (size_t i = 0; i < t.names.size(); ++i)
       if (t.names[i] == name) id = (int)i;
@@ -415,7 +415,9 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (cfg->local_heating_option == 1) {      // hs_forcing_init (:373-384) + local_heating's factors of longitude and latitude (:751-758), srfamp folded into the first
       const double pi = 3.14159265358979323846, twopi = 2. * pi;
       const double xw = cfg->local_heating_xwidth * pi / 180., yw = cfg->local_heating_ywidth * pi / 180.;
-      const double xc = cfg->local_heating_xcenter * pi / 180., yc = cfg->local_heating_ycenter * pi / 180.;
+      double xc = cfg->local_heating_xcenter * pi / 180.;
+      xc = xc - twopi * std::floor(xc / twopi);           // "make sure xcenter falls in the range zero to 2*PI" (hs_forcing.F90:378-380)
+      const double yc = cfg->local_heating_ycenter * pi / 180.;
       const double srfamp = cfg->local_heating_srfamp / 86400.;
       std::vector<double> fx(g.I), fy(T.rad_lat.size());
       for (int i = 0; i < g.I; ++i) {
@@ -1297,7 +1299,7 @@ static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
   const Geom &g = h->g;
   isca::Comm &c = *h->comm;
   upload_wave_matrices(h, sc.delta_t);
-  phase0(h, sc);
+  { Timed seg(h, "seg_grid", nullptr, true); phase0(h, sc); }
   // ISCA_HALO_WITH_ALL_TO_ALL=1: the tracer's halo rows travel in the group of the lat -> m all-to-all (Comm::all_to_all_with_halo: one exchange, one
   // latency hop less on the step's critical path -- three instead of four); the tracer's transport then starts behind that exchange and runs under
   // the spectral phase instead of under the exchange.  Same results; which order is faster is a question for a node with more than one GPU.
@@ -1315,15 +1317,15 @@ static void sharded_step(isca_dyn *h, int store_wg_full = 1) {
     }
     { Timed t(h, "all_to_all_fwd"); c.all_to_all(h->d.Ff_g, h->d.Ff_s, (size_t)g.Ml * g.Jl * h->Cf, h->stream); }
   }
-  phase1(h, sc);
+  { Timed seg(h, "seg_spectral", nullptr, true); phase1(h, sc); }
   { Timed t(h, "all_to_all_inv"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * h->Ci, h->stream); }
-  phase2(h, sc);
+  { Timed seg(h, "seg_fft_inv", nullptr, true); phase2(h, sc); }
   { Timed t(h, "all_reduce"); c.all_reduce_sum(h->d.red, 10, h->stream); }
   if (h->cfg.raw_filter_coeff != 1.0) {    // a third exchange: the Fourier rows of the gradients re-synthesised from the adjusted level
     phase3(h, sc, 1);
     { Timed t(h, "all_to_all_raw"); c.all_to_all(h->d.Fi_s, h->d.Fi_g, (size_t)g.Ml * g.Jl * raw_pitch(h), h->stream); }
     phase3(h, sc, 2);
-  } else phase3(h, sc);
+  } else { Timed seg(h, "seg_fixers", nullptr, true); phase3(h, sc); }
 }
 
 extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
@@ -1338,7 +1340,7 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   for (int i = 0; i < nsteps; ++i) {
     // wg_full (omega) is an output only: the last step of the call stores it, and every step while a diagnostic of omega accumulates
     // (or the moist package runs, whose restart and diagnostics see it too)
-    const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->cfg.physics == 1 || getenv_once("ISCA_ALWAYS_WG_FULL");
+    const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->hist_wg_full || h->cfg.physics == 1 || getenv_once("ISCA_ALWAYS_WG_FULL");
     if (h->g.P > 1) sharded_step(h, store_wg);
     else {
       StepScalars sc = step_scalars(h);
@@ -2370,6 +2372,48 @@ extern "C" int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, d
   API_END
 }
 
+// Measurement helper (bench.py: shard_compute): one resident wavefront per XCD that does nothing but exist, for at most `seconds` (0: stop the one
+// that runs and wait for it).  A P-rank job whose ranks take turns on ONE GPU leaves the device idle four fifths of the time -- between two turns lie
+// a host hand-shake and staged copies -- and its power management then clocks down: kernels of an eighth of the grid measured 1.5-2 x longer than
+// the same kernels in a busy process.  Eight sleeping wavefronts (of 8192 slots) keep the device "busy" without taking anything from the kernels
+// that are measured.
+namespace {
+__global__ void k_keep_clocks(const volatile int *stop, long long ticks) {
+  const long long t0 = wall_clock64();
+  double x = threadIdx.x;
+  while (!*stop && wall_clock64() - t0 < ticks) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x = __builtin_fma(x, 1.0000001, 1e-9);
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (x == 12345.678) *(volatile int *)stop = 2;      // (keeps the arithmetic)
+}
+struct KeepClocks { int *flag = nullptr; hipStream_t st = nullptr; bool running = false; } g_keep;
+}
+extern "C" int isca_bench_keep_clocks(int device, double seconds) {
+  API_BEGIN
+  HIP_CHECK(hipSetDevice(device));
+  if (g_keep.running) {
+    *(volatile int *)g_keep.flag = 1;
+    HIP_CHECK(hipStreamSynchronize(g_keep.st));
+    g_keep.running = false;
+  }
+  if (seconds > 0) {
+    if (!g_keep.flag) {
+      HIP_CHECK(hipHostMalloc((void **)&g_keep.flag, sizeof(int), hipHostMallocMapped));
+      HIP_CHECK(hipStreamCreateWithFlags(&g_keep.st, hipStreamNonBlocking));
+    }
+    *(volatile int *)g_keep.flag = 0;
+    int rate_khz = 100000;                                // wall_clock64 ticks: 100 MHz on this part
+    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device);
+    const long long ticks = (long long)(std::min(seconds, 600.0) * 1e3 * (rate_khz > 0 ? rate_khz : 100000));
+    hipLaunchKernelGGL(k_keep_clocks, dim3(8), dim3(64), 0, g_keep.st, g_keep.flag, ticks);
+    HIP_CHECK(hipGetLastError());
+    g_keep.running = true;
+  }
+  API_END
+}
+
 extern "C" int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int max, char *names, size_t names_len, int *n) {
   API_BEGIN
   timer_collect(h);
@@ -2385,6 +2429,7 @@ extern "C" int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int 
   if (n) *n = cnt;
   t.names.clear(); t.ms.clear(); t.calls.clear();
   t.enabled = enable != 0;
+  t.segments = enable == 2;          // 2: the sharded step's segments between its exchanges ("seg_*") instead of its kernels
   API_END
 }
 #include "shallow.inc"

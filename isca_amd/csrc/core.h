@@ -138,6 +138,7 @@ inline size_t halo_doubles(const Geom &g, int num_tracers) { return (size_t)(3 +
 
 struct KernelTimer {
   bool enabled = false;
+  bool segments = false;        // one event pair per run of kernels between two exchanges (sharded step) instead of one per kernel
   std::vector<std::string> names;
   std::vector<double> ms;
   std::vector<long> calls;
@@ -204,6 +205,7 @@ struct isca_dyn {
   bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
   double *host_red = nullptr;       // pinned: the fixer scalars / temperature extremes read back at a synchronisation point
   isca_history *hist = nullptr;     // history files being written (isca_dyn_diag_open): the step loops call isca_history_after_step
+  bool hist_wg_full = false;        // ... one of them samples omega instantaneously (time_avg = .false.): every step stores wg_full, whichever completes a record
 };
 void isca_history_after_step(isca_dyn *h);      // history_nc.cpp
 void isca_history_destroy(isca_dyn *h);

@@ -287,6 +287,7 @@ void isca_history_after_step(isca_dyn *h) {
 void isca_history_destroy(isca_dyn *h) {
   delete h->hist;
   h->hist = nullptr;
+  h->hist_wg_full = false;
 }
 
 #define HS_BEGIN try {
@@ -319,6 +320,9 @@ extern "C" int isca_dyn_diag_open(isca_dyn_t *h, const char *diag_table, const c
       bool have = false;
       for (const auto &nm : H->names) have = have || nm == fld.info->name;
       if (!have && fld.avg) H->names.push_back(fld.info->name);
+      // an instantaneous sample of omega reads wg_full, which a step only stores on request (isca_dyn_step: store_wg); a record's interval may end on
+      // any step of a multi-step call
+      if (!fld.avg && fld.info->state && std::strcmp(fld.info->state, "wg_full") == 0) h->hist_wg_full = true;
     }
   }
   H->chunk_steps = g;

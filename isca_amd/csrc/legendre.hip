@@ -591,14 +591,23 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     a.frag = d.leg_fwd_frag; a.Fs = Fs; a.S = S; a.m_local = d.m_local; a.C = C; a.full = full;
     a.KS = g.Jh / 4; a.NTP = g.NHP / 16;
     a.CB = ((C + 31) / 32 + 3) / 4;
-    constexpr int FD = 4, NTG = 3;                   // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): DESIGN.md
+    constexpr int FD = 4;                            // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): DESIGN.md
+    // Row tiles per parity and work item.  3 (+3) is what a grid that fills the SIMDs wants: the Fourier rows are read once per row group.  A shard of
+    // the sharded model (Ml = M1 / P wavenumbers) has far fewer items than the device has SIMDs -- 132 wavefronts at T85L40 on 8 ranks -- and each of
+    // them is a serial chain of Jh / 4 k-steps: there one row tile per item gives three times the wavefronts a third of the chain each (the rows a
+    // group re-reads come from L2).  ISCA_LEG_NTG: measurement switch.
+    static const int ntg_env = env_int("ISCA_LEG_NTG", 0);
+    const int items3 = g.Ml * ((C + 31) / 32) * ((a.NTP + 2) / 3);
+    const int NTG = ntg_env ? ntg_env : (items3 >= 512 ? 3 : 1);
     a.RG = (a.NTP + NTG - 1) / NTG;
     const dim3 grid(leg_grid(g.Ml, a.CB * a.RG));
     static const int fd = env_int("ISCA_LEG_FD", 0);       // measurement switch: ring depth 8 / 16 with one wavefront per SIMD
-    if (fd == 8 && a.KS % 8 == 0) hipLaunchKernelGGL((k_leg_fwd<8, NTG, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
-    else if (fd == 16 && a.KS % 16 == 0) hipLaunchKernelGGL((k_leg_fwd<16, NTG, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    if (NTG == 1) hipLaunchKernelGGL((k_leg_fwd<FD, 1, 4>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    else if (NTG == 2) hipLaunchKernelGGL((k_leg_fwd<FD, 2, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    else if (fd == 8 && a.KS % 8 == 0) hipLaunchKernelGGL((k_leg_fwd<8, 3, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    else if (fd == 16 && a.KS % 16 == 0) hipLaunchKernelGGL((k_leg_fwd<16, 3, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     else
-    hipLaunchKernelGGL((k_leg_fwd<FD, NTG, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+    hipLaunchKernelGGL((k_leg_fwd<FD, 3, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     TRACE_DUMP(trace_fwd)
   } else {
     dim3 grid((C + 63) / 64, g.N1, g.Ml);

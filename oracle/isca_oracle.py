@@ -563,6 +563,7 @@ class SpectralCore:
         if c.local_heating_option == "Isidoro":                             # local_heating :233-238, :750-764
             rad = np.pi / 180.0
             xw, yw, xc, yc = c.local_heating_xwidth * rad, c.local_heating_ywidth * rad, c.local_heating_xcenter * rad, c.local_heating_ycenter * rad
+            xc = xc - 2 * np.pi * np.floor(xc / (2 * np.pi))               # hs_forcing_init :378-380
             srfamp = c.local_heating_srfamp / 86400.0
             lon = np.arange(self.I) * 360.0 / self.I * rad
             lon = lon - 2 * np.pi * np.floor(lon / (2 * np.pi))

@@ -1922,6 +1922,36 @@ def test_history_files_written_by_the_library(tmp_path):
     a.close(); b.close()
 
 
+def test_history_instantaneous_omega_inside_a_multi_step_call(tmp_path):
+    """An instantaneous (time_avg = .false.) `omega` samples wg_full, which isca_dyn_step only stores on request (the last step of a call, an omega
+    diagnostic that accumulates, the moist package).  A record whose interval ends in the MIDDLE of a multi-step call must still hold that step's
+    omega (spectral_diagnostics sends wg_full of the step it is called in, spectral_dynamics.F90:1709-1867): an open table with such an entry makes
+    every step store it.  Compared with a handle stepped one step per call (every call's last step stores)."""
+    from scipy.io import netcdf_file
+    L = 6
+    table = ('"FMS Model results"\n0 0 0 0 0 0\n"atmos_1h", 1, "hours", 1, "hours", "time",\n'
+             '"dynamics", "omega", "omega", "atmos_1h", "all", .false., "none", 2,\n')
+    a = make("T21", L); a.cold_start(); a.step(4)
+    b = make("T21", L); b.cold_start(); b.step(4)
+    a.diag_open(table, str(tmp_path / "lib"), start_seconds=4 * 600.0)
+    a.step(15)                                                                  # two records (steps 6 and 12 of the call), neither on its last step
+    a.diag_close()
+    want = []
+    for i in range(12):
+        b.step(1)
+        if i % 6 == 5:
+            want.append(b.get("wg_full"))
+    f = netcdf_file(str(tmp_path / "lib" / "atmos_1h.nc"), "r", mmap=False)
+    try:
+        om = f.variables["omega"][:]
+        assert om.shape[0] == 2
+        for r in range(2):
+            assert np.abs(want[r]).max() > 0 and np.array_equal(om[r], want[r]), r
+    finally:
+        f.close()
+    a.close(); b.close()
+
+
 def test_diagnostics_two_history_files(tmp_path):
     """Two files of one diag_table with different intervals and different field lists: each gets the means of its own intervals (the
     device holds one set of sums per handle; DiagCollector takes them off chunk by chunk and every file keeps its own)."""
