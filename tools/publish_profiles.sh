@@ -3,7 +3,7 @@
 #   usage: bash tools/publish_profiles.sh [round-tag, default r03]
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r03}
+R=${1:-r06}
 T=gpurun_out/prof_final
 for W in T85L40 T170L60 T85L40_moist; do
   S=$T/$W
@@ -17,4 +17,6 @@ for W in T85L40 T170L60 T85L40_moist; do
   if grep -q '^{' $S/bench_stats.log; then grep '^{' $S/bench_stats.log | tail -1 > profiles/${R}_${W}_bench_under_rocprof.json; fi      # the moist run prints no bench line
 done
 grep '^{' $T/bench_T85L40.json.log | tail -1 > profiles/${R}_T85L40_bench.json
-ls -la profiles/
+# the derived table is ALWAYS regenerated from the files just copied (a table older than its sources is not evidence)
+python tools/roofline_table.py $R > profiles/${R}_roofline_table.md
+ls -la profiles/ | grep ${R}_
