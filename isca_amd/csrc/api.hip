@@ -608,6 +608,35 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
       bool sigma = true;
       for (double v : T.pk) if (v != 0.0) sigma = false;
       d.ppm_tab = sigma ? dupload(h, ppm) : nullptr;      // hybrid levels: the tracer kernel forms the weights per column
+      // ---- the column kernel's per-level constants on pure sigma levels (k_column_sig).  With pk = 0 every pressure of a column is b x p_s, so the
+      // logarithms of pressure_variables (press_and_geopot.F90:165-194) differ from ln p_s by constants of the vertical coordinate:
+      //   ln p_half(k+1) - ln p_half(k) = ln(b(k+1)/b(k)) =: a,   ln p_half(k+1) - ln p_full(k) = 1 - b(k) a / (b(k+1) - b(k)) =: d1,   p_full = p_s exp(lcf).
+      // The kernel then needs ONE logarithm and ONE exponential per column instead of one and two per level, and no division per level.  Formed in
+      // extended precision (d1 is a difference of nearly equal numbers) and rounded once.  Not with vert_difference_option = 'mcm' (its own formulas).
+      d.col_sig = nullptr;
+      if (sigma && cfg->vert_difference_option != 1 && !getenv("ISCA_COLUMN_GENERIC")) {
+        const int L = g.L;
+        std::vector<double> cs((size_t)16 * (L + 8), 0.0);       // (+ 8 levels of zeros: the last wavefront's chunk may reach past L)
+        const bool top0 = T.bk[0] == 0.0;
+        const double vcoeff = -h->tab.vkf / (1.0 - cfg->sigma_b), tcoeff = (h->tab.tks - h->tab.tka) / (1.0 - cfg->sigma_b);
+        for (int k = 0; k < L; ++k) {
+          const long double b0 = T.bk[k], b1 = T.bk[k + 1], db = b1 - b0;
+          long double d1, d3, lcf;
+          if (top0 && k == 0) { d1 = 1.0L; d3 = 0.0L; lcf = logl(b1) - 1.0L; }     // ln p_half(top) := 0, ln p_full(top) = ln p_half(2) - 1 (:178-184); d3 only ever meets a zero factor
+          else { const long double a = logl(b1 / b0); d1 = 1.0L - b0 * a / db; d3 = a; lcf = logl(b1) - d1; }
+          const long double d2 = (top0 && k == 0) ? 0.0L : d3 - d1;
+          double *q = &cs[(size_t)16 * k];
+          q[0] = (double)d1; q[1] = (double)d3; q[2] = (double)((b1 * d1 + b0 * d2) / db); q[3] = (double)(1.0L / db);
+          q[4] = (double)expl(lcf); q[5] = (double)expl((long double)KAPPA * lcf); q[6] = (double)lcf;
+          const double sig = q[4];
+          const bool bl = sig <= 1.0 && sig > cfg->sigma_b;                         // hs_forcing's boundary layer (hs_forcing.F90:560-575, 645-655)
+          q[7] = bl ? vcoeff * (sig - cfg->sigma_b) : 0.0;
+          q[8] = bl ? tcoeff * (sig - cfg->sigma_b) : 0.0;
+          q[9] = T.dbk[k]; q[10] = T.bk[k + 1]; q[11] = T.bk[k];
+        }
+        d.col_sig = dupload(h, cs);
+      }
+      { std::vector<double> sl(g.Jl); for (int j = 0; j < g.Jl; ++j) sl[j] = std::sin(T.rad_lat[g.j0 + j]); d.hs_sin_l = dupload(h, sl); }
     }
     // Tracer kernels on the side stream (fork after the column kernel, join before the fixer sums) pay for themselves from about T85 up:
     // at T42L25 / T21L25 the two cross-stream waits cost more than the overlap hides (0.105 -> 0.094 and 0.100 -> 0.083 ms per step

@@ -110,6 +110,8 @@ struct Dev {
   double *fv_c, *fv_cc, *fv_dy, *fv_dyy, *fv_dyp, *fv_dym;   // fv_advection tables (global latitudes)
   double *fv_rcdx, *fv_rdyy, *fv_rcdy, *fv_rdy;              // reciprocals used by the kernels
   double *ppm_tab;           // [6][L] pure-sigma PPM slope / edge weights
+  double *col_sig;           // [L][16] per-level constants of the column kernel on pure sigma levels (k_column_sig; null: hybrid levels, 'mcm')
+  double *hs_sin_l;          // [Jl] sin(lat) as hs_forcing forms it (hs_forcing.F90:519: sin of the latitude in radians), host libm
   double *vors[2], *divs[2], *ts[2], *lnps[2];      // spectral [Ml][N1][L] complex ; lnps [Ml][N1]
   // ---- work
   double *g_dtu, *g_dtv, *g_dtT, *g_E, *g_dtlp;     // forward-batch grid inputs

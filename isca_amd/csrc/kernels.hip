@@ -39,6 +39,9 @@ __device__ __forceinline__ double water_corr(double q, int k, int km, double wfa
 // (byte 0: this step, byte 1: the step before, ...): a pending water factor belongs to the pressures of the step that produced the level.
 __device__ __forceinline__ int kmask_byte(int word, int b) { return (word >> (8 * b)) & 0xff; }
 
+// tables read through the constant address space stay scalar loads also behind stores that might alias (k_tracer_horiz, k_column_sig)
+typedef const double __attribute__((address_space(4))) kdouble;
+
 enum CoefId { C_EIG = 0, C_UVM, C_UVC, C_UVP, C_ALPM, C_ALPP, C_DYM, C_DX, C_DYP, C_MASK, C_DAMP, C_DAMP_VOR, C_DAMP_DIV, C_COUNT };
 
 // =====================================================================================================
@@ -1494,6 +1497,9 @@ struct ColumnArgs {
   int do_conserve_energy;
   const double *lh_lon, *lh_lat;           // local_heating_option = 'Isidoro' (hs_forcing.F90:728-769): srfamp x longitude factor [I], latitude factor [Jl]; null = off
   double lh_decay;                         // local_heating_vert_decay
+  const double *sig;                       // [L][16] per-level constants on pure sigma levels (k_column_sig; api.hip: col_sig); hs_sin: [Jl] sin(lat)
+  const double *hs_sin;
+  double lnP00;                            // log(P00)
 };
 
 __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double ps, double p_full, double up, double vp,
@@ -1526,10 +1532,10 @@ __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double 
 // together (8x the wavefronts and ~50 outstanding loads per lane instead of one level at a time).
 // MCM: vert_difference_option = 'mcm' (press_and_geopot.F90:196-210, spectral_dynamics.F90:1084-1099): p_full = the mean of the two half levels,
 // the pressure-gradient term with grad(p_s)/p_s, the conversion term with (sum above + half the layer's own)/p_full.
-// MAXT: the block's thread count the register allocation is made for -- 512 (8 wavefronts of CH = ceil(L/8) levels: two per SIMD, up to 256 VGPRs),
-// or, for the ISCA_COLUMN_NW=10|14 experiment (more, thinner wavefronts per block: 3 / 4 per SIMD at <= 170 / 128 VGPRs; DESIGN.md 11 "Round 5"), 640 / 896.
-template <int CH, bool EXT, bool VIRT, bool MCM = false, int MAXT = 512, bool EARLY_THIN = true>
-__global__ __launch_bounds__(MAXT) void k_column(Geom g, ColumnArgs a) {
+// (8 wavefronts of CH = ceil(L/8) levels: two per SIMD, up to 256 VGPRs.  More, thinner wavefronts per block -- 3 / 4 per SIMD at <= 170 / 128 VGPRs -- were
+// measured in round 5 and spilled: HISTORY.md.)
+template <int CH, bool EXT, bool VIRT, bool MCM = false>
+__global__ __launch_bounds__(512) void k_column(Geom g, ColumnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int L = g.L, I = g.I;
   const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // w in an SGPR: table lookups by level become scalar loads
@@ -1563,7 +1569,7 @@ __global__ __launch_bounds__(MAXT) void k_column(Geom g, ColumnArgs a) {
   // every global load of the block is issued here, before the barrier of the vertical scans: one memory
   // round trip per block instead of two (the loads below the barrier could not start before it)
   // (chunks of more than 5 levels would not fit the register file that way: they read these six below the barrier)
-  constexpr bool EARLY = CH <= 5 && (MAXT == 512 || EARLY_THIN);      // (the thin-wavefront experiment: with and without the six fields in registers across the barrier)
+  constexpr bool EARLY = CH <= 5;
   double upv[EARLY ? CH : 1], vpv[EARLY ? CH : 1], tpv[EARLY ? CH : 1], vov[EARLY ? CH : 1], dxv[EARLY ? CH : 1], dyv[EARLY ? CH : 1];
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
@@ -1741,6 +1747,195 @@ __global__ __launch_bounds__(MAXT) void k_column(Geom g, ColumnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel for PURE SIGMA levels (pk = 0; the Held-Suarez and Frierson test cases' 'uneven_sigma' / 'even_sigma').  Every pressure of a
+// column is then b x p_s, and what pressure_variables (press_and_geopot.F90:165-194) forms with a logarithm per half level -- ln p_half, the
+// Simmons-Burridge ln p_full, their differences in four_in_one (spectral_dynamics.F90:1064-1083) and compute_geopotential (:350-356) -- differs
+// from ln p_s by constants of the vertical coordinate (ColumnArgs::sig, api.hip "col_sig"): ONE logarithm and ONE exponential per column (for
+// hs_forcing's (p/P00)**kappa) instead of a logarithm, two exponentials and seven divisions per level.  k_column spent 2 550 vector instructions
+// per wavefront on those (SQ_INSTS_VALU, profiles/r05_T85L40_pmc_summary.csv) -- 19 us of issue time at T85L40 which, with one block per CU in
+// lock step around its barrier, did not overlap the block's memory phase: a shard of 64 blocks took the same 21 us as a full round of 256
+// (profiles/r06_T85L40_P8_kernel_stats.csv).  Mathematically the same expressions; the roundings differ (fewer of them), as they already do
+// between this device's log / exp and the host's.
+// sig[k] = {d1 = ln p_half(k+1) - ln p_full(k), d3 = ln p_half(k+1) - ln p_half(k), x1c = (b(k+1) d1 + b(k) d2) / db, 1/db, cf = p_full/p_s, cf**kappa,
+//           ln cf, hs_forcing's Rayleigh factor and boundary-layer part of the Newtonian rate at sigma = cf, db, b(k+1), b(k)}
+// ---------------------------------------------------------------------------------------------------------------------
+// TWO: two blocks per CU (<= 128 registers): the six fields that are only needed below the barrier (previous u, v, T, vorticity, the two T gradients) are
+// then requested below it -- a second memory round trip per block, which the CU's other block covers
+template <int CH, bool EXT, bool VIRT, bool TWO = false>
+__global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = g.L, I = g.I;
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  double *lds_dm = (double *)smem;          // [NW][64] chunk sums of dmean
+  double *lds_a = lds_dm + NW * 64;         // [NW][64] chunk sums of RDGAS*T*dlog3
+  double *lds_e = lds_a + NW * 64;          // [NW] energy partials
+  int *lds_cnt = (int *)(lds_e + NW);       // [NW][64] levels with p_full < water_correction_limit
+  const int col = blockIdx.x * 64 + tid;
+  const int jl = col / I;
+  const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
+  const int k0 = w * CH, nk = min(CH, L - k0);
+  kdouble *sg = (kdouble *)a.sig + 16 * k0;              // constant address space: scalar loads wherever they are needed, also behind the stores
+  const double tc_c = a.pend_c[PEND_TCORR], tc_p = a.pend_p[PEND_TCORR];
+  const double ps = mul_nc(a.ps[c2], a.pend_c[PEND_FACTOR]), psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
+  const int kmw_old = a.kmask_rd[c2];
+  const double dxl = a.dxlp[c2], dyl = a.dylp[c2];
+  const double dx_ps = ps * dxl, dy_ps = ps * dyl;
+  constexpr int ktop = 1;                                   // pk(1) = 0: the hydrostatic sum starts at the second level (press_and_geopot.F90:341-349)
+  const double wts_j = a.wts[jl], cosm = a.cosm[jl], cor = a.coriolis[jl], sin_lat = a.hs_sin[jl];
+  double u[CH], v[CH], t[CH], dm[CH];
+  double tvv[VIRT ? CH : 1];
+#define TV(i) (VIRT ? tvv[VIRT ? (i) : 0] : t[i])
+  constexpr bool EARLY = CH <= 5 && !TWO;
+  double upv[EARLY ? CH : 1], vpv[EARLY ? CH : 1], tpv[EARLY ? CH : 1], vov[EARLY ? CH : 1], dxv[EARLY ? CH : 1], dyv[EARLY ? CH : 1];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int k = k0 + (i < nk ? i : 0);
+    const size_t q = c2 + (size_t)k * lev;
+    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q] + tc_c;
+    if (VIRT) tvv[VIRT ? i : 0] = a.tv[q];
+    if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q] + tc_p; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
+    dm[i] = a.div[q];
+  }
+  double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
+  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q] + tc_c; }
+  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q] + tc_c; }
+  // what needs only p_s, while the fields are on their way
+  const double rps = 1. / ps;
+  double lpn0 = 0.0, pkap = 0.0;
+  if (!EXT) { lpn0 = log(ps) - a.lnP00; pkap = exp(KAPPA * lpn0); }     // ln(p_s/P00), (p_s/P00)**kappa
+  const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
+  const double t_star = a.t_zero - a.delh * sin2 - a.eps * sin_lat, tstr = a.t_strat - a.eps * sin_lat;
+  double csum = 0.0, asum = 0.0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {          // mass divergence of the layer (four_in_one :1064-1067), dp = db p_s
+    const double dbk = sg[16 * i + 9];
+    dm[i] = (i < nk) ? dm[i] * (dbk * ps) + dbk * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
+    csum += dm[i];
+    asum += (i < nk && k0 + i >= ktop) ? RDGAS * TV(i) * sg[16 * i + 1] : 0.0;
+  }
+  lds_dm[w * 64 + tid] = csum;
+  lds_a[w * 64 + tid] = asum;
+  __syncthreads();
+  double base = 0.0, total = 0.0, below = 0.0;
+  for (int ww = 0; ww < NW; ++ww) {
+    const double x = lds_dm[ww * 64 + tid];
+    total += x;
+    if (ww < w) base += x;
+    if (ww > w) below += lds_a[ww * 64 + tid];
+  }
+  double dmean_tot = base;
+  double wg_k = (k0 == 0) ? 0.0 : (-base + total * sg[11]);
+  double e_prev = 0.0;
+  int nbelow = 0;
+  if (a.wg && w == 0) { a.wg[c2] = 0.0; a.psp_copy[c2] = psp; }
+  constexpr double RCP = 1.0 / CP_AIR;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    if (i < nk) {
+      const int k = k0 + i;
+      const size_t q = c2 + (size_t)k * lev;
+      const double d1 = sg[16 * i + 0], d3 = sg[16 * i + 1], x1c = sg[16 * i + 2], rdbk = sg[16 * i + 3], cf = sg[16 * i + 4];
+      const double dbk = sg[16 * i + 9], bkn = sg[16 * i + 10];
+      const double upi = EARLY ? upv[EARLY ? i : 0] : a.up[q], vpi = EARLY ? vpv[EARLY ? i : 0] : a.vp[q], tpi = EARLY ? tpv[EARLY ? i : 0] : a.tp[q] + tc_p;
+      const double voi = EARLY ? vov[EARLY ? i : 0] : a.vor[q], dxti = EARLY ? dxv[EARLY ? i : 0] : a.dxT[q], dyti = EARLY ? dyv[EARLY ? i : 0] : a.dyT[q];
+      const double p_full = cf * ps;
+      double dt_u, dt_v, dt_t;
+      if (EXT) {
+        dt_u = a.phu[q]; dt_v = a.phv[q]; dt_t = a.pht[q];
+      } else {
+        // ---- hs_forcing at the previous level (rayleigh :615-679, dissipative heating :198-200, newtonian :508-611); sigma = cf
+        const double vfactr = sg[16 * i + 7];
+        dt_u = vfactr * upi; dt_v = vfactr * vpi; dt_t = 0.0;
+        if (a.do_conserve_energy) dt_t = -((upi + .5 * dt_u * a.delta_t) * dt_u + (vpi + .5 * dt_v * a.delta_t) * dt_v) * RCP;
+        const double lpn = lpn0 + sg[16 * i + 6];              // log(p_full/P00)
+        const double the = t_star - a.delv * cos2 * lpn;
+        const double teq = fmax(the * (pkap * sg[16 * i + 5]), tstr);   // (p_full/P00)**kappa
+        const double tdamp = a.tka + cos4 * sg[16 * i + 8];
+        dt_t = dt_t + (-tdamp * (tpi - teq));
+      }
+      {  // initialize_corrections (:1318-1321)
+        const double ue = upi + dt_u * a.delta_t, ve = vpi + dt_v * a.delta_t;
+        e_prev += (0.5 * (ue * ue + ve * ve) + CP_AIR * (tpi + dt_t * a.delta_t)) * (dbk * psp);
+      }
+      // ---- four_in_one (:1064-1083): x1 dp_s/dx = x1c dln p_s/dx
+      const double dp_inv = rdbk * rps;
+      const double x2 = x1c * dxl, x3 = x1c * dyl;
+      const double uc = u[i], vc = v[i], tc = t[i], tvc = TV(i);
+      dt_u = dt_u - RDGAS * tvc * x2;
+      dt_v = dt_v - RDGAS * tvc * x3;
+      const double x4 = (dmean_tot * d3 + dm[i] * d1) * dp_inv;
+      const double x5 = x4 - uc * x2 - vc * x3;
+      dt_t = dt_t - KAPPA * tvc * x5;
+      if (a.store_wg_full) a.wg_full[q] = -x5 * p_full;
+      nbelow += (p_full < a.water_limit) ? 1 : 0;
+      dmean_tot = dmean_tot + dm[i];
+      const double wg_n = (k + 1 < L) ? (-dmean_tot + total * bkn) : 0.0;
+      if (a.wg) a.wg[q + lev] = wg_n;
+      // ---- vert_advection SECOND_CENTERED / ADVECTIVE_FORM (vert_advection.F90:185-193, 467-470)
+      const double ukm = (i == 0) ? um : u[i > 0 ? i - 1 : 0], vkm = (i == 0) ? vm : v[i > 0 ? i - 1 : 0], tkm = (i == 0) ? tm : t[i > 0 ? i - 1 : 0];
+      const double ukp = (i == nk - 1) ? un : u[i + 1 < CH ? i + 1 : i], vkp = (i == nk - 1) ? vn : v[i + 1 < CH ? i + 1 : i], tkp = (i == nk - 1) ? tn : t[i + 1 < CH ? i + 1 : i];
+      {
+        const double dw = wg_n - wg_k;
+        const double fu0 = (k == 0) ? wg_k * uc : wg_k * (0.5 * (uc + ukm));
+        const double fv0 = (k == 0) ? wg_k * vc : wg_k * (0.5 * (vc + vkm));
+        const double ft0 = (k == 0) ? wg_k * tc : wg_k * (0.5 * (tc + tkm));
+        const double fu1 = (k + 1 < L) ? wg_n * (0.5 * (ukp + uc)) : wg_n * uc;
+        const double fv1 = (k + 1 < L) ? wg_n * (0.5 * (vkp + vc)) : wg_n * vc;
+        const double ft1 = (k + 1 < L) ? wg_n * (0.5 * (tkp + tc)) : wg_n * tc;
+        if (!(a.vadv_skip & 1)) {
+          dt_u = dt_u + (-(fu1 - fu0 - uc * dw) * dp_inv);
+          dt_v = dt_v + (-(fv1 - fv0 - vc * dw) * dp_inv);
+        }
+        if (!(a.vadv_skip & 2)) dt_t = dt_t + (-(ft1 - ft0 - tc * dw) * dp_inv);
+      }
+      // ---- horizontal T advection (transforms.F90:828), vorticity/Coriolis terms (:895-896)
+      dt_t = dt_t - uc * dxti - vc * dyti;
+      const double av = voi + cor;
+      dt_u = dt_u + av * vc;
+      dt_v = dt_v - av * uc;
+      a.dtu[q] = dt_u * cosm;
+      a.dtv[q] = dt_v * cosm;
+      a.dtT[q] = dt_t;
+      wg_k = wg_n;
+    }
+  }
+  if (w == NW - 1) a.dtlp[c2] = (0.0 - total) * rps;    // (dt_psg - dmean_tot)/psg (:873, :1102)
+  // ---- hydrostatic integral bottom-up within the chunk, Phi + KE (:350-356, :902)
+  {
+    double gh = below + a.surf_geop[c2];
+#pragma unroll
+    for (int i = CH - 1; i >= 0; --i) {
+      if (i < nk) {
+        const size_t q = c2 + (size_t)(k0 + i) * lev;
+        a.E[q] = gh + RDGAS * TV(i) * sg[16 * i + 0] + .5 * (u[i] * u[i] + v[i] * v[i]);
+        if (k0 + i >= ktop) gh = gh + RDGAS * TV(i) * sg[16 * i + 1];
+      }
+    }
+  }
+  // ---- block partial sums: mean_surf_press_previous, mean_energy_previous
+  double s_en = wts_j * e_prev, s_ps = (w == 0) ? wts_j * psp : 0.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s_ps += __shfl_down(s_ps, off, 64);
+    s_en += __shfl_down(s_en, off, 64);
+  }
+  if (tid == 0) lds_e[w] = s_en;
+  lds_cnt[w * 64 + tid] = nbelow;
+  __syncthreads();
+  if (a.kmask && w == 0) {
+    int cnt = 0;
+    for (int ww = 0; ww < NW; ++ww) cnt += lds_cnt[ww * 64 + tid];
+    a.kmask[c2] = (kmw_old << 8) | cnt;
+  }
+  if (threadIdx.x == 0) {
+    double e = 0.0;
+    for (int ww = 0; ww < NW; ++ww) e += lds_e[ww];
+    a.partials[2 * blockIdx.x] = s_ps;
+    a.partials[2 * blockIdx.x + 1] = e;
+  }
+}
+
 #undef TV
 
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
@@ -1776,17 +1971,38 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   a.phu = d.ph_dtu; a.phv = d.ph_dtv; a.pht = d.ph_dtT; a.surf_geop = d.surf_geop;
   a.pend_c = d.pend + 4 * sc.cur; a.pend_p = d.pend + 4 * sc.prev;     // identity rows unless a level's fixers are pending (lazy fixers)
   a.store_wg_full = sc.store_wg_full;
-  int CH = (g.L + 7) / 8;                       // <= 8 wavefronts per block, CH levels each
-  int NW = (g.L + CH - 1) / CH;
-  // experiment (plain Held-Suarez instantiation only): more wavefronts of fewer levels per block -- ISCA_COLUMN_NW=10 (CH = 4 at L = 40) or 14 (CH = 3)
-  static const int nw_env = getenv("ISCA_COLUMN_NW") ? atoi(getenv("ISCA_COLUMN_NW")) : 0;
-  const bool thin = (nw_env == 10 || nw_env == 14) && g.L == 40 && h.cfg.vert_difference_option != 1 && !virtual_t_on(h) && h.cfg.physics == 0;
-  if (thin) { CH = nw_env == 10 ? 4 : 3; NW = (g.L + CH - 1) / CH; }
+  const int CH = (g.L + 7) / 8;                 // <= 8 wavefronts per block, CH levels each
+  const int NW = (g.L + CH - 1) / CH;
   const size_t lds = (size_t)(2 * NW * 64 + NW) * sizeof(double) + (size_t)NW * 64 * sizeof(int);
   const dim3 grid((unsigned)column_partials_count(h)), block(64 * NW);
   a.tv = virtual_t_on(h) ? d.tv : nullptr;
   const bool ext = h.cfg.physics != 0 || hs_forcing_separate(h);      // the physics tendencies come from arrays (a package's, or k_hs_forcing_step's)
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
+  a.sig = d.col_sig; a.hs_sin = d.hs_sin_l; a.lnP00 = std::log(h.cfg.P00);
+  if (a.sig && h.cfg.vert_difference_option != 1) {             // pure sigma levels: the per-level logarithms are constants of the coordinate
+    // two blocks per CU (the six below-the-barrier fields requested there, <= 128 registers): for the plain Held-Suarez instantiations, chunks of <= 5 levels
+    static const int two_env = getenv("ISCA_COLUMN_TWO") ? atoi(getenv("ISCA_COLUMN_TWO")) : 0;
+    if (two_env && !a.tv && !ext && CH <= 5) {
+      switch (CH) {
+        case 1: hipLaunchKernelGGL((k_column_sig<1, false, false, true>), grid, block, lds, s, g, a); break;
+        case 2: hipLaunchKernelGGL((k_column_sig<2, false, false, true>), grid, block, lds, s, g, a); break;
+        case 3: hipLaunchKernelGGL((k_column_sig<3, false, false, true>), grid, block, lds, s, g, a); break;
+        case 4: hipLaunchKernelGGL((k_column_sig<4, false, false, true>), grid, block, lds, s, g, a); break;
+        default: hipLaunchKernelGGL((k_column_sig<5, false, false, true>), grid, block, lds, s, g, a); break;
+      }
+      return;
+    }
+#define LS(N) do { \
+    if (a.tv) { if (ext) hipLaunchKernelGGL((k_column_sig<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column_sig<N, false, true>), grid, block, lds, s, g, a); } \
+    else if (ext) hipLaunchKernelGGL((k_column_sig<N, true, false>), grid, block, lds, s, g, a); \
+    else hipLaunchKernelGGL((k_column_sig<N, false, false>), grid, block, lds, s, g, a); } while (0)
+    switch (CH) {
+      case 1: LS(1); break; case 2: LS(2); break; case 3: LS(3); break; case 4: LS(4); break;
+      case 5: LS(5); break; case 6: LS(6); break; case 7: LS(7); break; default: LS(8); break;
+    }
+#undef LS
+    return;
+  }
 #define LC(N) do { \
     if (h.cfg.vert_difference_option == 1) { \
       if (a.tv) { if (ext) hipLaunchKernelGGL((k_column<N, true, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true, true>), grid, block, lds, s, g, a); } \
@@ -1795,12 +2011,6 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     else if (a.tv) { if (ext) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
     else if (ext) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
     else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
-  if (thin) {
-    static const bool late = getenv("ISCA_COLUMN_LATE") != nullptr;      // the six previous-level / gradient fields loaded below the barrier (fewer registers, a second round trip)
-    if (CH == 4) { if (late) hipLaunchKernelGGL((k_column<4, false, false, false, 640, false>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<4, false, false, false, 640>), grid, block, lds, s, g, a); }
-    else { if (late) hipLaunchKernelGGL((k_column<3, false, false, false, 896, false>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<3, false, false, false, 896>), grid, block, lds, s, g, a); }
-    return;
-  }
   switch (CH) {
     case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
     case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
@@ -2247,7 +2457,6 @@ template <bool P2> __device__ __forceinline__ int wrap_lon(int x, int I) {
 }
 // The kernel stores early (the filtered current level, TracerArgs.filt_horiz) and reads its per-row tables after that: through the constant address
 // space, so that they stay scalar loads (an ordinary load behind a store that may alias goes down the vector path: 133 -> 37 s_load without this).
-typedef const double __attribute__((address_space(4))) kdouble;
 struct TracerTabs {
   kdouble *cc, *dyp, *dym, *rcdx, *rdyy, *rcdy, *rdy;
   __device__ explicit TracerTabs(const TracerArgs &a)

@@ -228,7 +228,7 @@ def prepare_moist_rundir(d, res, nsteps, dt=720, dump_steps=(), phys_steps=(), m
         f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {fmt(dump_steps)}, phys_steps = {fmt(phys_steps)}{harness_extra}\n /\n")
 
 
-def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra=""):
+def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra="", harness_extra=""):
     os.makedirs(os.path.join(d, "INPUT"), exist_ok=True)
     os.makedirs(os.path.join(d, "RESTART"), exist_ok=True)
     open(os.path.join(d, "input.nml"), "w").write(input_nml(res, num_levels, extra, extra_groups, hs_extra))
@@ -236,7 +236,7 @@ def prepare_rundir(d, res, num_levels, mode, nsteps=1, dt=600, dump_steps=(), ex
     open(os.path.join(d, "diag_table"), "w").write("isca_ref_harness\n0 0 0 0 0 0\n")
     ds = ", ".join(str(s) for s in dump_steps) if dump_steps else "-1"
     open(os.path.join(d, "harness.nml"), "w").write(
-        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {ds}\n /\n")
+        f" &harness_nml\n   mode = '{mode}', nsteps = {nsteps}, dt_atmos = {int(dt)}, dump_steps = {ds}{harness_extra}\n /\n")
 
 
 def run_harness(d, exe=EXE, timeout=3600):
@@ -511,12 +511,12 @@ HYBRID_LEVELS_GROUP = """ &vert_coordinate_nml
 """ % (", ".join(str(b) for b in HYBRID_BK), ", ".join(str(p) for p in HYBRID_PK))
 
 
-def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra=""):
+def golden_run(res, L, nsteps, dump_steps, dt=600, keep=None, extra="", extra_groups="", field_table=FIELD_TABLE, hs_extra="", harness_extra=""):
     """`extra`: further spectral_dynamics_nml assignments (they follow the test case's own, so they win); `extra_groups`: whole
     namelist groups appended to input.nml"""
     with tempfile.TemporaryDirectory(prefix="refr_") as d:
         prepare_rundir(d, res, L, "run", nsteps=nsteps, dt=dt, dump_steps=dump_steps, extra=extra, extra_groups=extra_groups,
-                       field_table=field_table, hs_extra=hs_extra)
+                       field_table=field_table, hs_extra=hs_extra, harness_extra=harness_extra)
         stdout = run_harness(d)
         out = read_outputs(d, res, L)
     if keep is not None:
@@ -614,6 +614,12 @@ def main():
             "T21", 25, 144, (2, 144),
             keep=lambda k: k.startswith("tab_") and k != "tab_legendre"
             or re.match(r"st_(ug|vg|tg|psg)_(000002|000144)$", k) is not None or k == "st_tr1_000144"),
+        # the trip test's criterion on configs[0] (exp/test_cases/trip_test/trip_test_functions.py:173-189: atmos_daily with ps, bk, pk, ucomp, vcomp, temp,
+        # vor, div; :286-297 compares every variable of the file): three daily means of the T21L25 Held-Suarez run, formed as spectral_diagnostics +
+        # diag_manager form them (ref_harness.F90: mean_every)
+        "trip_T21L25": lambda: golden_run(
+            "T21", 25, 432, (), harness_extra=", mean_every = 144",
+            keep=lambda k: k in ("tab_pk", "tab_bk") or k.startswith("mean_")),
         # configs[0] for 10 days (1440 steps): the long-run tolerance of SURVEY 8d (1e-7 relative; 1-ulp noise ~2e-10)
         "run_T21L25_10day": lambda: golden_run(
             "T21", 25, 1440, (1440,),

@@ -58,7 +58,12 @@ logical :: dump_tables = .true.
 ! the start value F = s is forgotten as robert**steps (0.04**16 ~ 4e-23) -- and at step dump_full_at writes BOTH time levels (rs_*).
 integer :: track_from = -1, dump_full_at = -1
 real    :: robert_coeff = 0.04      ! spectral_dynamics_nml's value (the module does not export it)
-namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, dump_tables, track_from, dump_full_at, robert_coeff
+! the trip test's criterion (exp/test_cases/trip_test/trip_test_functions.py:173-189, 286-297): time means of ps, ucomp, vcomp, temp, vor, div over every
+! mean_every steps, as spectral_diagnostics (spectral_dynamics.F90:1709-1867, called with the FUTURE level at the end of atmosphere: atmosphere.F90:344)
+! and diag_manager (sum of the samples, divided by their number when the interval ends) form them; netCDF is absent here, so the driver accumulates itself.
+! vor and div on the grid are module-private: they are re-formed from the level's winds through public routines (equal to the module's own to roundoff).
+integer :: mean_every = 0
+namelist /harness_nml/ mode, nsteps, dt_atmos, dump_steps, dump_tables, track_from, dump_full_at, robert_coeff, mean_every
 
 type(time_type) :: Time, Time_step, Time_next
 type(tracer_type), allocatable, dimension(:) :: tracer_attributes
@@ -80,6 +85,10 @@ real, allocatable, dimension(:,:)       :: rad_lon_2d, rad_lat_2d, rad_lonb_2d, 
 complex, allocatable, dimension(:,:,:)  :: sc_vor, sc_div, sc_t, sn_vor, sn_div, sn_t, f_vor, f_div, f_t
 complex, allocatable, dimension(:,:)    :: sc_lp, sn_lp, f_lp
 real, allocatable, dimension(:,:,:,:)   :: f_tr
+real, allocatable, dimension(:,:,:)     :: mn_u, mn_v, mn_t, mn_vor, mn_div, tmp_vor, tmp_div
+real, allocatable, dimension(:,:)       :: mn_ps
+complex, allocatable, dimension(:,:,:)  :: tmp_vs, tmp_ds
+integer :: mean_count = 0
 
 open(newunit=unit, file='harness.nml', status='old', action='read')
 read(unit, nml=harness_nml)
@@ -170,6 +179,7 @@ if(trim(mode) == 'run') then
     if(track_from >= 0 .and. istep >= track_from) call track_filter(istep == track_from)
     if(istep == dump_full_at) call dump_both_levels()
     if(any(dump_steps == istep)) call dump_state(istep)
+    if(mean_every > 0) call accumulate_means(istep)
   enddo
   write(*,'(a,i8,a,f12.6,a,f12.6)') 'REF_TIMING steps=', nsteps, ' seconds=', t_loop, ' ms_per_step=', 1.e3*t_loop/max(nsteps,1)
   write(*,'(a,3es24.16)') 'REF_STATE Tmin,Tmax,maxabsU=', minval(tg(:,:,:,current)), maxval(tg(:,:,:,current)), maxval(abs(ug(:,:,:,current)))
@@ -261,6 +271,30 @@ do ntr = 1, num_tracers
 enddo
 sc_vor = sn_vor; sc_div = sn_div; sc_t = sn_t; sc_lp = sn_lp
 end subroutine track_filter
+
+subroutine accumulate_means(n)
+! after one_step the new level is `current`: the level spectral_diagnostics is handed (atmosphere.F90:344)
+integer, intent(in) :: n
+character(len=8) :: tag
+if(.not.allocated(mn_u)) then
+  allocate(mn_u(is:ie,js:je,num_levels), mn_v(is:ie,js:je,num_levels), mn_t(is:ie,js:je,num_levels), mn_vor(is:ie,js:je,num_levels), &
+           mn_div(is:ie,js:je,num_levels), tmp_vor(is:ie,js:je,num_levels), tmp_div(is:ie,js:je,num_levels), mn_ps(is:ie,js:je))
+  allocate(tmp_vs(ms:me,ns:ne,num_levels), tmp_ds(ms:me,ns:ne,num_levels))
+  mn_u = 0.; mn_v = 0.; mn_t = 0.; mn_vor = 0.; mn_div = 0.; mn_ps = 0.; mean_count = 0
+endif
+call vor_div_from_uv_grid(ug(:,:,:,current), vg(:,:,:,current), tmp_vs, tmp_ds)
+call trans_spherical_to_grid(tmp_vs, tmp_vor)
+call trans_spherical_to_grid(tmp_ds, tmp_div)
+mn_u = mn_u + ug(:,:,:,current); mn_v = mn_v + vg(:,:,:,current); mn_t = mn_t + tg(:,:,:,current)
+mn_vor = mn_vor + tmp_vor; mn_div = mn_div + tmp_div; mn_ps = mn_ps + psg(:,:,current)
+mean_count = mean_count + 1
+if(mod(n, mean_every) /= 0) return
+write(tag,'(i6.6)') n
+call dump3('mean_ucomp_'//trim(tag)//'.bin', mn_u/real(mean_count));  call dump3('mean_vcomp_'//trim(tag)//'.bin', mn_v/real(mean_count))
+call dump3('mean_temp_'//trim(tag)//'.bin', mn_t/real(mean_count));   call dump3('mean_vor_'//trim(tag)//'.bin', mn_vor/real(mean_count))
+call dump3('mean_div_'//trim(tag)//'.bin', mn_div/real(mean_count));  call dump2('mean_ps_'//trim(tag)//'.bin', mn_ps/real(mean_count))
+mn_u = 0.; mn_v = 0.; mn_t = 0.; mn_vor = 0.; mn_div = 0.; mn_ps = 0.; mean_count = 0
+end subroutine accumulate_means
 
 subroutine dump_both_levels()
 ! what a restart of spectral_dynamics_mod + atmosphere_mod holds (spectral_dynamics.F90:1502-1531, atmosphere.F90:362-375)

@@ -1952,6 +1952,50 @@ def test_history_instantaneous_omega_inside_a_multi_step_call(tmp_path):
     a.close(); b.close()
 
 
+TRIP_DIAG_TABLE = """"FMS Model results"
+0 0 0 0 0 0
+"atmos_daily", 1, "days", 1, "days", "time",
+"dynamics", "ps", "ps", "atmos_daily", "all", .true., "none", 2,
+"dynamics", "bk", "bk", "atmos_daily", "all", .false., "none", 2,
+"dynamics", "pk", "pk", "atmos_daily", "all", .false., "none", 2,
+"dynamics", "ucomp", "ucomp", "atmos_daily", "all", .true., "none", 2,
+"dynamics", "vcomp", "vcomp", "atmos_daily", "all", .true., "none", 2,
+"dynamics", "temp", "temp", "atmos_daily", "all", .true., "none", 2,
+"dynamics", "vor", "vor", "atmos_daily", "all", .true., "none", 2,
+"dynamics", "div", "div", "atmos_daily", "all", .true., "none", 2,
+"""
+
+
+def test_trip_test_criterion_against_the_reference(golden_dir, tmp_path):
+    """The reference's regression test (exp/test_cases/trip_test/trip_test_functions.py): run the test case with `define_simple_diag_table` (:173-189 --
+    atmos_daily: ps, bk, pk, ucomp, vcomp, temp, vor, div) and compare every variable of the history file (:286-297; there bit for bit between two
+    commits of one code on one machine).  Here between the reference's CPU run and the GPU library: configs[0] (T21L25 Held-Suarez) for three days, the
+    file written by the library itself from that diag_table (csrc/history_nc.cpp, device-side time means), against tests/golden/trip_T21L25.npz (the
+    reference's daily means, oracle/ref_harness.F90: mean_every).  Tolerances, of each field's maximum: day 1 1e-9 (SURVEY 8d's one-day bound), days 2
+    and 3 1e-8 (the 1-ulp noise floor grows to 2e-10 over ten days); pk and bk bit for bit."""
+    from scipy.io import netcdf_file
+    g = np.load(os.path.join(golden_dir, "trip_T21L25.npz"))
+    a = make("T21", 25); a.cold_start()
+    a.diag_open(TRIP_DIAG_TABLE, str(tmp_path))
+    a.step(200); a.step(232)                                                    # 432 steps = 3 days in two calls that do not end on a day
+    a.diag_close()
+    f = netcdf_file(str(tmp_path / "atmos_daily.nc"), "r", mmap=False)
+    try:
+        assert set(("ps", "bk", "pk", "ucomp", "vcomp", "temp", "vor", "div")) <= set(f.variables)
+        assert np.array_equal(f.variables["pk"][:], g["tab_pk"]) and np.array_equal(f.variables["bk"][:], g["tab_bk"])
+        assert f.variables["temp"].shape[0] == 3
+        worst = {}
+        for day, tol in ((1, 1e-9), (2, 1e-8), (3, 1e-8)):
+            for k in ("ps", "ucomp", "vcomp", "temp", "vor", "div"):
+                e = rel(f.variables[k][day - 1], g[f"mean_{k}_{144 * day:06d}"])
+                worst[(k, day)] = e
+                assert e < tol, (k, day, e)
+        print("trip test, worst relative difference per day:", {d: max(v for (k, dd), v in worst.items() if dd == d) for d in (1, 2, 3)})
+    finally:
+        f.close()
+    a.close()
+
+
 def test_diagnostics_two_history_files(tmp_path):
     """Two files of one diag_table with different intervals and different field lists: each gets the means of its own intervals (the
     device holds one set of sums per handle; DiagCollector takes them off chunk by chunk and every file keeps its own)."""

@@ -164,6 +164,23 @@ def test_trajectory_T21L25_one_day(golden_dir):
     assert abs(tmin - 262.169090) < 1e-6 and abs(tmax - 272.371035) < 1e-6 and abs(umax - 1.148573) < 1e-6
 
 
+def test_trip_test_daily_means(golden_dir):
+    """The reference's own regression criterion (exp/test_cases/trip_test/trip_test_functions.py:173-189, 286-297) applied between the reference and the
+    restatement: daily means of ps, ucomp, vcomp, temp, vor, div of the T21L25 Held-Suarez case (configs[0]) -- day 1 at the one-day tolerance of SURVEY
+    8d (1e-9 of the field's maximum); the static pk, bk bit for bit.  (The GPU test carries all three days.)"""
+    g = np.load(os.path.join(golden_dir, "trip_T21L25.npz"))
+    sc = core("T21", 25); sc.cold_start()
+    assert np.array_equal(sc.pk, g["tab_pk"]) and np.array_equal(sc.bk, g["tab_bk"])
+    acc = {k: 0.0 for k in ("ps", "ucomp", "vcomp", "temp", "vor", "div")}
+    for i in range(144):
+        sc.step()
+        c = sc.current
+        for k, val in (("ps", sc.psg[c]), ("ucomp", sc.ug[c]), ("vcomp", sc.vg[c]), ("temp", sc.tg[c]), ("vor", sc.vorg), ("div", sc.divg)):
+            acc[k] = acc[k] + val
+    for k in acc:
+        assert rel(acc[k] / 144.0, g[f"mean_{k}_000144"]) < 1e-9, k
+
+
 DAMPING_CASES = {       # the option sets of oracle/make_golden.py's run_T21L8_damping_* jobs (spectral_damping.F90:124-156)
     "exponential": dict(damping_option="exponential_cutoff", cutoff_wn=10, damping_order=3, damping_coeff=2.3e-4, damping_coeff_vor=1.2e-4,
                         damping_coeff_div=4.6e-4),
