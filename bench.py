@@ -274,44 +274,21 @@ def shard_probe(a):
     core.close()
 
 
-def keep_clocks_main(seconds):
-    """internal (--keep-clocks S): a process of its own that keeps one idle wavefront per XCD resident for S seconds (isca_bench_keep_clocks), so that a
-    job whose ranks take turns on this GPU is not measured at the clocks of an idle device; ends when its stdin closes"""
-    from isca_amd import dyncore
-    lib = dyncore.load_library()
-    if lib.isca_bench_keep_clocks(0, float(seconds)) != 0:
-        raise SystemExit("keep_clocks: " + lib.isca_last_error().decode())
-    print("KEEP_CLOCKS on", flush=True)
-    sys.stdin.read()
-    lib.isca_bench_keep_clocks(0, 0.0)
-
-
-def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240, keep_clocks=True, extra_env=None, rocprof_dir=None):
+def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240, extra_env=None, rocprof_dir=None):
     """The compute half of the scaling curve, measured on ONE GPU: for P = 2, 4, 8 the per-step device time of a 1/P latitude-band shard of
     `workload` (shard_probe above), exchanges excluded, the slowest rank's --
       `main_stream_ms`   sum of the main stream's kernels, one HIP-event pair per kernel (each pair adds ~4 us to what it brackets);
       `segments_ms`      sum of the four runs of kernels between the step's exchanges, one event pair per run: what the rank's stream is busy
                          per step, launch gaps included -- the number to add the exchanges to;
       `side_stream_ms`   the tracer's transport, which runs under the first all-to-all and the spectral stage.
-    keep_clocks: one idle wavefront per XCD stays resident meanwhile (isca_bench_keep_clocks) -- the ranks take turns with a host hand-shake
-    in between, and an idle device clocks down.  rocprof_dir: rank 0 runs under rocprofv3 --kernel-trace --stats (its kernels' own durations).
+    Every rank runs with GPU_MAX_HW_QUEUES=2: a rank has two streams, and eight processes with the runtime's default of four hardware queues each
+    oversubscribe the device's queues -- their kernels then wait for a queue slot INSIDE the event brackets (round 5's P = 8 figures: fft_inv 30 us
+    instead of 15, legendre_fwd 26 instead of 10).  rocprof_dir: rank 0 runs under rocprofv3 --kernel-trace --stats (its kernels' own durations).
     What this does NOT hold: the exchanges themselves (no xGMI here).  A failure is reported, not raised."""
     import subprocess, tempfile, uuid
     out = {"how": "P processes share this GPU and take turns (ISCA_COMM=ipc, ISCA_IPC_SERIALIZE=1): HIP-event durations of the slowest rank, "
-                  "exchanges excluded; main_stream_ms = per-kernel event pairs summed, segments_ms = one pair per run of kernels between two exchanges"
-                  + ("; one idle wavefront per XCD kept resident so that the device keeps its clocks" if keep_clocks else "") + "; unmeasured on xGMI"}
-    keeper = None
-    if keep_clocks:
-        try:
-            keeper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--keep-clocks", str(min(600, 3 * timeout))], stdin=subprocess.PIPE,
-                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-            for ln in keeper.stdout:
-                if ln.startswith("KEEP_CLOCKS"):
-                    break
-            else:
-                raise RuntimeError("the keeper did not start")
-        except Exception as e:                                           # noqa: BLE001
-            out["keep_clocks_error"] = str(e)[:100]; keeper = None
+                  "exchanges excluded; main_stream_ms = per-kernel event pairs summed, segments_ms = one pair per run of kernels between two exchanges; "
+                  "two hardware queues per process (GPU_MAX_HW_QUEUES=2); unmeasured on xGMI"}
     for P in ranks:
         try:
             with tempfile.TemporaryDirectory(prefix="shard_") as d:
@@ -345,11 +322,6 @@ def shard_compute(workload, ranks=(2, 4, 8), steps=30, warmup=10, timeout=240, k
                              "segment_ms": {k: round(v, 5) for k, v in per_seg[max(range(P), key=lambda r: segs[r])].items() if k.startswith("seg_")}}
         except Exception as e:                                           # noqa: BLE001
             out[f"P={P}"] = {"error": str(e)[:200]}
-    if keeper is not None:
-        try:
-            keeper.stdin.close(); keeper.wait(timeout=20)
-        except Exception:                                                # noqa: BLE001
-            keeper.kill()
     return out
 
 
@@ -397,12 +369,9 @@ def main():
     ap.add_argument("--workload", default="T85L40", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-steps", type=int, default=24, help="bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--shard-probe", action="store_true", help="internal: one rank of shard_compute()'s P-rank job (RANK / WORLD_SIZE from the environment)")
-    ap.add_argument("--keep-clocks", type=float, default=0.0, help="internal: shard_compute()'s clock keeper, for that many seconds or until stdin closes")
     a = ap.parse_args()
     if a.shard_probe:
         return shard_probe(a)
-    if a.keep_clocks > 0:
-        return keep_clocks_main(a.keep_clocks)
     res, L, dt = WORKLOADS[a.workload]
 
     import torch

@@ -414,9 +414,6 @@ int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, double *pair
 /* per-kernel average milliseconds over the steps run since the last call (HIP events); names are
  * returned as a ';'-separated list in `names` */
 int isca_dyn_kernel_times(isca_dyn_t *h, int enable, double *ms, int max, char *names, size_t names_len, int *n);
-/* measurement helper: keeps one idle wavefront per XCD resident on `device` for at most `seconds` (0: stop it), so that a job whose
- * ranks take turns on one GPU (bench.py: shard_compute) is not measured at the clocks of an idle device.  No reference counterpart. */
-int isca_bench_keep_clocks(int device, double seconds);
 
 #ifdef __cplusplus
 }

@@ -547,6 +547,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
     d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
+    d.fix_ticket = dalloc<unsigned>(h, 4);
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
@@ -705,7 +706,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? -1 : 0) + (vadv_ext ? 1 : 0);    // lazy fixers on one rank: k_fixer_sums alone; eager: sums (with the totals) + apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -1187,22 +1188,11 @@ static void phase1(isca_dyn *h, const StepScalars &sc) {          // analysis, s
     { Timed t(h, "legendre_inv"); launch_legendre_inverse(h->g, h->d, h->d.Si, h->d.Fi_s, h->Ci, rect_bounds(h), h->cfg.legendre_impl, h->stream); }
   }
 }
-static bool late_water_fixer(const isca_dyn *h) {
-  static const int env = getenv("ISCA_LATE_WATER_FIXER") ? atoi(getenv("ISCA_LATE_WATER_FIXER")) : 0;      // 1: wherever possible (measurement; see phase2)
-  const bool can = h->lazy_fix && h->g.P == 1 && h->tracer_on && !h->tracer_serial && h->cfg.raw_filter_coeff == 1.0;
-  return can && env > 0;
-}
 static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT + fixer sums
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
-  // ISCA_LATE_WATER_FIXER=1 (measured, not the default): where the tracer's transport on the side stream ends long after the inverse FFT (110 us at
-  // T170L60) the fixers need not wait for it with everything -- the sums of the new u, v, T, ps and the scalars they give (mass factor, temperature
-  // correction: all the next column kernel needs) first, the join after them, then the water fixer's five sums (one wavefront per 64 columns) and the
-  // scalars once more with the water factor.  Bit-identical (test_late_water_fixer_equals_one_pass) and no faster: at T170L60 0.940 against 0.939 ms
-  // -- k_fixer_sums beside k_tracer_vert takes 60 instead of 49 us and k_tracer_vert 347 instead of 305: both stream, and the step is the sum of its bytes.
-  if (late_water_fixer(h)) { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream, 1); return; }
   if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
+  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc, h->stream); }        // (one rank, lazy fixers: its last block also finishes -- scalars, (0,0) patch)
 }
 // raw_filter_coeff /= 1: the reference completes the filter of the NEW level after its grid fields have been synthesised
 // (complete_robert_filter, spectral_dynamics.F90:1031), so u, v, T, ps, vor, div of that level stay those of the unadjusted spectral
@@ -1272,12 +1262,7 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   const bool raw = h->cfg.raw_filter_coeff != 1.0;
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-      { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
-      if (late_water_fixer(h)) {          // (phase2): the join, the water fixer's sums, the scalars again -- now with the water factor, the (0,0) patch not repeated
-        HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-        { Timed t(h, "fixer_sums_water"); launch_fixer_sums(*h, sc.fut, h->stream, 2); }
-        { Timed t(h, "fixer_finish_water"); launch_fixer_finish(*h, sc, h->stream, false); }
-      }
+      if (!fixer_sums_finish(*h)) { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }     // (world_size > 1: behind the all-reduce; one rank: done by k_fixer_sums' last block)
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
     } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
@@ -2398,48 +2383,6 @@ extern "C" int isca_bench_transform_pair(isca_dyn_t *h, int nfields, int reps, d
   *pair_ms = acc[4] / reps;
   for (int i = 0; i < 4; ++i) kernel_ms[i] = acc[i] / reps;
   hipFree(grid);
-  API_END
-}
-
-// Measurement helper (bench.py: shard_compute): one resident wavefront per XCD that does nothing but exist, for at most `seconds` (0: stop the one
-// that runs and wait for it).  A P-rank job whose ranks take turns on ONE GPU leaves the device idle four fifths of the time -- between two turns lie
-// a host hand-shake and staged copies -- and its power management then clocks down: kernels of an eighth of the grid measured 1.5-2 x longer than
-// the same kernels in a busy process.  Eight sleeping wavefronts (of 8192 slots) keep the device "busy" without taking anything from the kernels
-// that are measured.
-namespace {
-__global__ void k_keep_clocks(const volatile int *stop, long long ticks) {
-  const long long t0 = wall_clock64();
-  double x = threadIdx.x;
-  while (!*stop && wall_clock64() - t0 < ticks) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x = __builtin_fma(x, 1.0000001, 1e-9);
-    __builtin_amdgcn_s_sleep(32);
-  }
-  if (x == 12345.678) *(volatile int *)stop = 2;      // (keeps the arithmetic)
-}
-struct KeepClocks { int *flag = nullptr; hipStream_t st = nullptr; bool running = false; } g_keep;
-}
-extern "C" int isca_bench_keep_clocks(int device, double seconds) {
-  API_BEGIN
-  HIP_CHECK(hipSetDevice(device));
-  if (g_keep.running) {
-    *(volatile int *)g_keep.flag = 1;
-    HIP_CHECK(hipStreamSynchronize(g_keep.st));
-    g_keep.running = false;
-  }
-  if (seconds > 0) {
-    if (!g_keep.flag) {
-      HIP_CHECK(hipHostMalloc((void **)&g_keep.flag, sizeof(int), hipHostMallocMapped));
-      HIP_CHECK(hipStreamCreateWithFlags(&g_keep.st, hipStreamNonBlocking));
-    }
-    *(volatile int *)g_keep.flag = 0;
-    int rate_khz = 100000;                                // wall_clock64 ticks: 100 MHz on this part
-    (void)hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device);
-    const long long ticks = (long long)(std::min(seconds, 600.0) * 1e3 * (rate_khz > 0 ? rate_khz : 100000));
-    hipLaunchKernelGGL(k_keep_clocks, dim3(8), dim3(64), 0, g_keep.st, g_keep.flag, ticks);
-    HIP_CHECK(hipGetLastError());
-    g_keep.running = true;
-  }
   API_END
 }
 

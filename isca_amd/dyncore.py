@@ -171,7 +171,6 @@ def load_library():
         "isca_dyn_diag_select": [H, C.c_char_p],
         "isca_dyn_diag_read": [H, C.c_char_p, dp, C.c_size_t, C.POINTER(C.c_long), C.c_int],
         "isca_dyn_kernel_times": [H, C.c_int, dp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)],
-        "isca_bench_keep_clocks": [C.c_int, C.c_double],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
@@ -192,7 +191,7 @@ EXPORTED_SYMBOLS = [
     "isca_vor_div_from_uv_grid", "isca_uv_grid_from_vor_div", "isca_horizontal_advection",
     "isca_trans_spherical_to_fourier", "isca_trans_fourier_to_spherical", "isca_trans_grid_to_fourier",
     "isca_trans_fourier_to_grid", "isca_area_weighted_global_mean", "isca_hs_forcing",
-    "isca_bench_transform_pair", "isca_dyn_kernel_times", "isca_bench_keep_clocks",
+    "isca_bench_transform_pair", "isca_dyn_kernel_times",
     "isca_compute_laplacian", "isca_compute_gradient_cos", "isca_compute_ucos_vcos", "isca_compute_vor_div",
     "isca_triangular_truncation", "isca_divide_by_cos", "isca_mass_weighted_global_integral", "isca_pressure_variables",
     "isca_compute_geopotential", "isca_compute_geopotential_surf", "isca_a_grid_horiz_advection", "isca_vert_advection_ppm", "isca_hs_tracer_source_sink",

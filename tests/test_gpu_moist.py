@@ -146,46 +146,58 @@ def test_moist_trajectory_T21L25(golden_dir):
 
 
 def test_moist_developed_state_steps_vs_reference(golden_dir):
-    """A DEVELOPED state of the reference's moist model handed over -- day 30 of the T42L25 Frierson run, when it rains: deep and shallow
+    """A DEVELOPED state of the reference's MOIST model handed over and stepped (tests/golden/moist_developed_T42L25.npz: day 30 of the T42L25
+    Frierson run of oracle/ref_moist_harness.F90; it rains -- precipitation up to 1.2e-3 kg/m2/s, max |u| 58 m/s, q up to 1.4e-2, deep and shallow
     convection in most tropical columns, condensation with re-evaporation, an evolved mixed layer -- as `developed_T42L25.npz` does for the dry
     core: both time levels of the spectral and grid state, the dynamics' Robert-filtered humidity level and atmosphere_mod's copy, omega, the
     mixed layer's t_surf (module-private in the reference: read by oracle/ref_peek.c), and the gust state of a model that is RUNNING
     (phys_calls > 0: vert_turb_driver's constant_gust, not the first call's 1 m/s).  Then 1 and 10 more steps against the reference's own
-    (idealized_moist_phys.F90:819-1395; the knife-edge branches of qe_moist_convection.F90:1053-1180): 1e-11 and 1e-10 of each field's maximum."""
+    (idealized_moist_phys.F90:819-1395; the knife-edge branches of qe_moist_convection.F90:1053-1180): 1e-11 and 1e-10 of each field's maximum --
+    or, where that is larger, twice the model's own response to a ONE-ULP perturbation of the handed-over temperatures, measured here with a second
+    handle (a convecting state amplifies rounding: after 10 steps the 1-ulp twin differs by ~1e-10 in q; a comparison cannot be tighter than that)."""
     g = np.load(os.path.join(golden_dir, "moist_developed_T42L25.npz"))
     umax, vmax, tmin, tmax, qmax = g["developed_maxu_maxv_Tmin_Tmax_qmax"]
     assert umax > 25.0 and qmax > 0.01, (umax, qmax)              # the fixture IS a developed, moist flow
-    dc = moist_core("T42", float(g["meta_dt_atmos"]))
-    assert np.array_equal(dc.table("bk"), g["tab_bk"])
-    dc.cold_start()
-    dc.set_time_pointers(0, 1, int(g["meta_step0"]))
-    for tl, tag in ((0, "prev"), (1, "cur")):                       # time_level 0 = previous, 1 = current
-        for nm in ("vors", "divs", "ts"):
-            dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
-        dc.set("ln_ps", g[f"rs_lnps_{tag}"], tl)
-        for nm in ("ug", "vg", "tg", "psg"):
-            dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
-    dc.set("tr", g["rs_tr1_prev_filt"], 0); dc.set("tr_atm", g["rs_tr1_prev_atm"], 0)
-    dc.set("tr", g["rs_tr1_cur"], 1); dc.set("tr_atm", g["rs_tr1_cur"], 1)
-    dc.set("wg_full", g["rs_wg_full"])
-    dc.set("t_surf", g["rs_t_surf"])
-    dc.refresh_derived()
-    dc.set_info("phys_calls", int(g["meta_step0"]))
+
+    def handed_over(one_ulp):
+        dc = moist_core("T42", float(g["meta_dt_atmos"]))
+        assert np.array_equal(dc.table("bk"), g["tab_bk"])
+        dc.cold_start()
+        dc.set_time_pointers(0, 1, int(g["meta_step0"]))
+        for tl, tag in ((0, "prev"), (1, "cur")):                       # time_level 0 = previous, 1 = current
+            for nm in ("vors", "divs", "ts"):
+                dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
+            dc.set("ln_ps", g[f"rs_lnps_{tag}"], tl)
+            for nm in ("ug", "vg", "tg", "psg"):
+                a = g[f"rs_{nm}_{tag}"]
+                dc.set(nm, np.nextafter(a, np.inf) if (one_ulp and nm == "tg") else a, tl)
+        dc.set("tr", g["rs_tr1_prev_filt"], 0); dc.set("tr_atm", g["rs_tr1_prev_atm"], 0)
+        dc.set("tr", g["rs_tr1_cur"], 1); dc.set("tr_atm", g["rs_tr1_cur"], 1)
+        dc.set("wg_full", g["rs_wg_full"])
+        dc.set("t_surf", g["rs_t_surf"])
+        dc.refresh_derived()
+        dc.set_info("phys_calls", int(g["meta_step0"]))
+        return dc
+
+    dc, twin = handed_over(False), handed_over(True)
     done = 0
     for n, tol in ((1, 1e-11), (10, 1e-10)):
-        dc.step(n - done); done = n
-        err = {}
+        dc.step(n - done); twin.step(n - done); done = n
+        err, noise = {}, {}
         for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "q")):
             ref = g[f"after{n}_{gk}_s222"]
-            err[k] = float(np.abs(dc.get(k)[::2, ::2, ::2] - ref).max() / np.abs(ref).max())
-            lo, hi = g[f"after{n}_{gk}_minmax"]
             a = dc.get(k)
-            assert abs(a.min() - lo) <= tol * max(abs(lo), abs(hi)) and abs(a.max() - hi) <= tol * max(abs(lo), abs(hi)), (n, k)
-        err["psg"] = rel(dc.get("psg"), g[f"after{n}_psg"])
-        print("developed moist T42L25 state +", n, "steps vs the reference:", err, "rain max", float(dc.get("precip").max()))
-        assert max(err.values()) < tol, (n, err)
+            err[k] = float(np.abs(a[::2, ::2, ::2] - ref).max() / np.abs(ref).max())
+            noise[k] = float(np.abs(twin.get(k) - a).max() / np.abs(ref).max())
+            lo, hi = g[f"after{n}_{gk}_minmax"]
+            bound = max(tol, 2 * noise[k]) * max(abs(lo), abs(hi))
+            assert abs(a.min() - lo) <= bound and abs(a.max() - hi) <= bound, (n, k, noise[k])
+        err["psg"] = rel(dc.get("psg"), g[f"after{n}_psg"]); noise["psg"] = rel(twin.get("psg"), dc.get("psg"))
+        print("developed moist T42L25 state +", n, "steps vs the reference:", err, "| response to 1 ulp in T:", noise, "| rain max", float(dc.get("precip").max()))
+        for k in err:
+            assert err[k] < max(tol, 2 * noise[k]), (n, k, err[k], noise[k])
     assert float(dc.get("precip").max()) > 1e-4                    # (kg/m2/s: it rains)
-    dc.close()
+    dc.close(); twin.close()
 
 
 def test_moist_convection_ahead_equals_in_step(monkeypatch):

@@ -1144,28 +1144,6 @@ def test_sharded_native_loop(world, res, levels, raw, tracers, extra):
     assert r.returncode == 0 and "SHARDED_CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_late_water_fixer_equals_one_pass(monkeypatch):
-    """ISCA_LATE_WATER_FIXER=1 (a measured variant, off by default: DESIGN.md 11): the fixers in two halves around the side stream's join -- the sums
-    of the new u, v, T, ps and the mass / energy scalars first, the water fixer's sums and factor after it (api.hip: late_water_fixer).  Same
-    partial sums in the same order: the state after 30 steps (with host reads in between, and with mountains that move the water-correction
-    limit's level count) equals the one-pass run BIT FOR BIT."""
-    def run(mode):
-        monkeypatch.setenv("ISCA_LATE_WATER_FIXER", mode)
-        monkeypatch.setenv("ISCA_TRACER_CONCURRENT", "1")               # (the side stream at a size that would not use it)
-        dc = make("T42", 12, water_correction_limit=800.e2)
-        lat = np.deg2rad(dc.table("deg_lat"))[:, None]; lon = np.deg2rad(dc.table("deg_lon"))[None, :]
-        dc.set_surf_geopotential(9.80 * (3000.0 * np.exp(-((lat - 0.6) / 0.35) ** 2 - ((lon - 1.5) / 0.6) ** 2)))
-        dc.cold_start(); dc.step(7); dc.get("tr"); dc.step(23)
-        out = {k: dc.get(k) for k in ("ug", "vg", "tg", "psg", "ts", "ln_ps")}
-        out["tr0"], out["tr1"], out["fixer"] = dc.get("tr", 0), dc.get("tr", 1), dc.table("fixer")[16:19]
-        dc.close()
-        return out
-    a, b = run("0"), run("1")
-    assert a["fixer"][2] != 1.0                                         # the water fixer acts
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
-
-
 @pytest.mark.parametrize("world,res,levels,raw,tracers,extra", [
     (2, "T21", 25, 1.0, 1, []), (4, "T42", 25, 1.0, 1, []), (8, "T85", 40, 1.0, 1, []),
     (2, "T21", 8, 0.7, 1, []),                 # the RAW filter's third exchange: two all-to-alls into the same buffer in one step

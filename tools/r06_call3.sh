@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 6, call 3: the GPU suite (folded fixers, sigma column kernel), A/B of ISCA_COLUMN_TWO, the sharded step's compute with rank 0 under rocprofv3
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r06c; mkdir -p $OUT
+timeout 1800 python -m pytest tests -m gpu -q --maxfail=6 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -12 $OUT/pytest.log
+bash tools/ab_env.sh r06c/ab "T85L40" 2 - ISCA_COLUMN_TWO=1 2>&1 | tee $OUT/ab.log
+bash tools/ab_env.sh r06c/ab170 "T170L60" 1 - 2>&1 | tee $OUT/ab170.log
+timeout 900 python tools/shard_ab.py $OUT T85L40 "2 4 8" - -,prof 2>&1 | tee $OUT/shard_T85.log
+timeout 600 python tools/shard_ab.py $OUT T170L60 "4 8" - 2>&1 | tee $OUT/shard_T170.log
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
