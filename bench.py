@@ -419,6 +419,23 @@ def main():
         watchdog = threading.Timer(float(os.environ.get("ISCA_BENCH_WATCHDOG_S", "900")), _stuck)
         watchdog.daemon = True
         watchdog.start()
+    def _failed(exc):
+        """A sharded step that raised (an exchange that never completed, a FATAL on some band, a fault injected by a test): every rank says so in one
+        JSON line -- rank 0 on stdout where the driver reads the bench line, the others on stderr -- and leaves at once (the process group's
+        teardown would wait for the peers that are gone)."""
+        line = json.dumps({"metric": "simulated-years/day at T85L40 Held-Suarez", "value": None, "unit": "sim_years/day", "n_gpus": a.gpus, "steps": a.steps,
+                           "warmup": a.warmup, "rank": rank, "error": str(exc)[:400],
+                           "exchange_driver": (core.lib.isca_dyn_comm_kind(core._h).decode() if getattr(core, "native", False) else "torch.distributed")})
+        print(line, file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+        os._exit(4)
+    if world > 1:
+        _step = core.step
+        def _guarded(n, sync=True):
+            try:
+                return _step(n, sync=sync)
+            except dyncore.IscaError as e:
+                _failed(e)
+        core.step = _guarded
     core.cold_start()
     # Spin-up before the W warm-up steps, untimed and reported as `spinup_steps`: a step is 0.2 ms, so W = 5 steps are 1 ms of GPU work after the
     # model's set-up -- the clocks are still ramping and the first 20 timed steps measure 4-5 % slow (0.202 against 0.193 ms per step in a

@@ -342,8 +342,8 @@ static void sync_and_check_valid_range(isca_dyn *h) {
   }
   HIP_CHECK(hipMemcpyAsync(h->host_red, h->d.red, 22 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(hipMemcpyAsync(h->d.red + 20, h->host_red + 32, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_CHECK(hipStreamSynchronize(h->stream));
-  if (h->comm) h->comm->check();
+  if (h->comm) { h->comm->synchronize(h->stream); h->comm->check(); }      // (RCCL: polls the stream, the communicator's error state and a deadline, comm.h)
+  else HIP_CHECK(hipStreamSynchronize(h->stream));
   const double *red = h->host_red;
   const double tmin = red[20], tmax = red[21];
   const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
@@ -357,7 +357,7 @@ static void sync_and_check_valid_range(isca_dyn *h) {
     HIP_CHECK(hipMemcpyAsync(h->d.red + 24, h->host_red + 40, sizeof(double), hipMemcpyHostToDevice, h->stream));
     h->comm->all_reduce_sum(h->d.red + 24, 1, h->stream);
     HIP_CHECK(hipMemcpyAsync(h->host_red + 41, h->d.red + 24, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->comm->synchronize(h->stream);
     other = !bad && h->host_red[41] > 0.0;
   }
   if (bad) {
@@ -547,7 +547,6 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
     d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
-    d.fix_ticket = dalloc<unsigned>(h, 4);
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
@@ -706,7 +705,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? -1 : 0) + (vadv_ext ? 1 : 0);    // lazy fixers on one rank: k_fixer_sums alone; eager: sums (with the totals) + apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -1192,7 +1191,7 @@ static void phase2(isca_dyn *h, const StepScalars &sc) {          // inverse FFT
   FieldList fl = inverse_list(h, sc.fut);
   { Timed t(h, "fft_inv"); launch_fft_inverse(h->g, h->d, fl, h->d.Fi_g, h->stream); }
   if (h->tracer_on && !h->tracer_serial) HIP_CHECK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc, h->stream); }        // (one rank, lazy fixers: its last block also finishes -- scalars, (0,0) patch)
+  { Timed t(h, "fixer_sums"); launch_fixer_sums(*h, sc.fut, h->stream); }
 }
 // raw_filter_coeff /= 1: the reference completes the filter of the NEW level after its grid fields have been synthesised
 // (complete_robert_filter, spectral_dynamics.F90:1031), so u, v, T, ps, vor, div of that level stay those of the unadjusted spectral
@@ -1262,7 +1261,7 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   const bool raw = h->cfg.raw_filter_coeff != 1.0;
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-      if (!fixer_sums_finish(*h)) { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }     // (world_size > 1: behind the all-reduce; one rank: done by k_fixer_sums' last block)
+      { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
     } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }

@@ -42,10 +42,18 @@ class Comm {
   virtual void attach(double * /*recv_fwd*/, double * /*recv_inv*/, double * /*recv_halo*/, size_t /*halo_half*/) {}
   // at a host synchronisation point: an exchange that gave up on the device (a peer that never arrived) becomes the error here
   virtual void check() {}
+  // the host's wait for the step's stream.  An exchange whose peer never joins would make hipStreamSynchronize wait for ever: an implementation
+  // whose exchanges run on the device without a host hand-shake (RCCL) polls instead -- the stream, the communicator's asynchronous error state,
+  // and a deadline (ISCA_EXCHANGE_TIMEOUT_S, default 120 s) after which it aborts the communicator and throws.  Default: hipStreamSynchronize.
+  virtual void synchronize(hipStream_t s);
+  // ISCA_FAULT_EXCHANGE="<rank>:<n>" (tests): that rank never joins its n-th exchange (counted per communicator, from 0) -- what its peers do about it
+  // is the error path under test.  True when this call is the one to skip.
+  bool fault_here();
 
  protected:
   Comm(int rank, int world) : rank_(rank), world_(world) {}
   int rank_, world_;
+  long exchanges_ = 0;
 };
 
 // comm_peer.hip: ISCA_COMM=peer -- one kernel per exchange that stores into the peers' receive buffers (hipIpc-mapped), flags instead of host hand-shakes

@@ -115,6 +115,7 @@ class IpcComm final : public Comm {
   }
   void all_to_all_with_halo(const double *send, double *recv, size_t count, const double *send_lo, const double *send_hi,
                             double *recv_lo, double *recv_hi, size_t halo_count, hipStream_t s) override {
+    if (fault_here()) never_join("exchange");
     const size_t blk = count * sizeof(double), hb = halo_count * sizeof(double);
     if (blk * world_ > id_.a2a_bytes) throw std::runtime_error("ipc comm: all-to-all larger than the outbox (raise ISCA_IPC_A2A_MB)");
     if (hb > id_.halo_bytes) throw std::runtime_error("ipc comm: halo rows larger than the outbox (raise ISCA_IPC_HALO_MB)");
@@ -136,6 +137,7 @@ class IpcComm final : public Comm {
     wait_turn("exchange: turn");
   }
   void all_reduce_sum(double *buf, size_t count, hipStream_t s) override {
+    if (fault_here()) never_join("all-reduce");
     if (count * sizeof(double) > kReduceBytes) throw std::runtime_error("ipc comm: all-reduce larger than its area");
     hip_ck(hipMemcpyAsync(box_[rank_], buf, count * sizeof(double), hipMemcpyDeviceToHost, s), "copy out (all-reduce)");
     hip_ck(hipStreamSynchronize(s), "synchronize");
@@ -163,6 +165,15 @@ class IpcComm final : public Comm {
   void unmap_all() {
     for (auto &b : box_) if (b) { munmap(b, slot_bytes_); b = nullptr; }
     if (hdr_) { munmap(hdr_, kHeaderBytes); hdr_ = nullptr; }
+  }
+  // ISCA_FAULT_EXCHANGE (comm.h): this rank does not join the exchange -- the equivalent of a rank whose ncclRecv is never posted.  It waits, like a
+  // rank stuck behind a device-side exchange, until a peer gives up (their barrier times out and sets the abort word) or its own limit passes.
+  [[noreturn]] void never_join(const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!hdr_->aborted.load(std::memory_order_acquire) && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2 * timeout_s_)
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    abort();
+    throw std::runtime_error(std::string("ipc comm: fault injected (ISCA_FAULT_EXCHANGE): this rank did not join its ") + what);
   }
   // ISCA_IPC_SERIALIZE: my segment of device work is over (the stream has just been synchronised): the next rank may run its own
   void pass_turn() {

@@ -93,8 +93,7 @@ void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, 
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 bool hs_forcing_separate(const isca_dyn &h);       // an hs_forcing_nml option the fused column kernel does not carry: k_hs_forcing_step in front of it
 void launch_hs_forcing_step(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
-bool fixer_sums_finish(const isca_dyn &h);           // k_fixer_sums' last block does everything (one rank, lazy fixers): no k_fixer_finish launch
-void launch_fixer_sums(const isca_dyn &h, const StepScalars &sc, hipStream_t s);          // R1: partial sums over the local band
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s);  // R2 with lazy fixers: reduce + scalars, left pending on the new level
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s);                    // apply what is pending on both time levels in place

@@ -1980,15 +1980,22 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
   a.sig = d.col_sig; a.hs_sin = d.hs_sin_l; a.lnP00 = std::log(h.cfg.P00);
   if (a.sig && h.cfg.vert_difference_option != 1) {             // pure sigma levels: the per-level logarithms are constants of the coordinate
-    // two blocks per CU (the six below-the-barrier fields requested there, <= 128 registers): for the plain Held-Suarez instantiations, chunks of <= 5 levels
-    static const int two_env = getenv("ISCA_COLUMN_TWO") ? atoi(getenv("ISCA_COLUMN_TWO")) : 0;
-    if (two_env && !a.tv && !ext && CH <= 5) {
+    // Two blocks per CU (k_column_sig<.., TWO>: <= 128 registers, the six below-the-barrier fields requested there) for the plain Held-Suarez
+    // instantiation with chunks of <= 5 levels, when the grid has at least two blocks per CU to interleave: T85L40 on one rank 40.0 -> 37.0 us
+    // (HIP events; step 0.1769 -> 0.1735 ms, two A/B pairs in one gpurun call).  A smaller grid (a shard, T42) is one round of blocks whatever the
+    // occupancy, and there the second memory round trip only adds latency.  ISCA_COLUMN_TWO=0|1 overrides (measurement).
+    static const int two_env = getenv("ISCA_COLUMN_TWO") ? atoi(getenv("ISCA_COLUMN_TWO")) : -1;
+    const bool two = two_env >= 0 ? two_env != 0 : (grid.x >= 512 && CH <= 5);
+    if (two && !a.tv && !ext) {
       switch (CH) {
         case 1: hipLaunchKernelGGL((k_column_sig<1, false, false, true>), grid, block, lds, s, g, a); break;
         case 2: hipLaunchKernelGGL((k_column_sig<2, false, false, true>), grid, block, lds, s, g, a); break;
         case 3: hipLaunchKernelGGL((k_column_sig<3, false, false, true>), grid, block, lds, s, g, a); break;
         case 4: hipLaunchKernelGGL((k_column_sig<4, false, false, true>), grid, block, lds, s, g, a); break;
-        default: hipLaunchKernelGGL((k_column_sig<5, false, false, true>), grid, block, lds, s, g, a); break;
+        case 5: hipLaunchKernelGGL((k_column_sig<5, false, false, true>), grid, block, lds, s, g, a); break;
+        case 6: hipLaunchKernelGGL((k_column_sig<6, false, false, true>), grid, block, lds, s, g, a); break;      // (6..8 levels per wavefront: 11-26 spilled dwords at 128 registers)
+        case 7: hipLaunchKernelGGL((k_column_sig<7, false, false, true>), grid, block, lds, s, g, a); break;
+        default: hipLaunchKernelGGL((k_column_sig<8, false, false, true>), grid, block, lds, s, g, a); break;
       }
       return;
     }
@@ -3256,18 +3263,129 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 // block = 64 columns x NW wavefronts (level chunks), like the column kernel
 constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
 constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
+__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
+                                                    const double *__restrict__ t, const double *__restrict__ psg,
+                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
+                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH,
+                                                    const double *__restrict__ wcol, const double *__restrict__ w0blk, int n_w0) {
+  __shared__ double sred[4][8];
+  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int col = blockIdx.x * 64 + tid;
+  const int jl = col / g.I;
+  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
+  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
+  const double wgt = wts[jl], ps = psg[c2];
+  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
+    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
+  }
+  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
+  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
+    t0 = w0blk ? (col < n_w0 ? w0blk[col] : 0.0) : wgt * wcol[c2];
+    t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
+    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
+  }
+  double sa = 0.0, sb = 0.0;
+  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
+  bool nan = false;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nk) {
+      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
+      sa += e * dpk[k0 + i];
+      sb += e * dbk[k0 + i];
+      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
+      nan = nan || !(tt[i] == tt[i]);
+    }
+  }
+  if (nan) tmx = INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
+    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
+  }
+  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
+  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
+    s2 += __shfl_down(s2, off, 64);
+  }
+  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
+      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
+    }
+  }
+  if (threadIdx.x == 0) {
+    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
+    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
+    double *p = partials + NPART * (size_t)blockIdx.x;
+    p[0] = s0; p[1] = a1; p[2] = a2; p[8] = bmn; p[9] = bmx;
+    p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4;
+  }
+}
+// Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from
+// k_fixer_sums) by ONE block of NT threads, in a fixed order.  Lane layout: value c = t & 15 (0..1 the column kernel's sums, 2..9
+// k_fixer_sums', 10 min, 11 max), group g = t >> 4: a thread folds the sets g, g + NT/16, ... of its value with eight loads in flight,
+// the four groups of a wavefront meet in two shuffles, the wavefronts in LDS.  (The first version had every thread fold all twelve
+// values of its sets and needed 72 cross-lane steps per wavefront: 5-7 us, the larger part of k_fixer_finish.)
+template <int NT>
+__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                             double (*sh)[16], double *tot, double &tmin, double &tmax) {
+  constexpr int NG = NT / 16, NWV = NT / 64;
+  const int t = threadIdx.x, c = t & 15, g = t >> 4, cc = min(c, NRED + 1);
+  const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
+  const int st = cc < 2 ? 2 : NPART;
+  auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
+  double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
+  constexpr int U = 16;                              // loads in flight per thread: one round trip up to 16 NT / 16 = NT sets
+  for (int i0 = g; i0 < nb; i0 += U * NG) {
+    double v[U];
+#pragma unroll
+    for (int r = 0; r < U; ++r) v[r] = p0[(size_t)st * min(i0 + NG * r, nb - 1)];
+#pragma unroll
+    for (int r = 0; r < U; ++r)
+      if (i0 + NG * r < nb) acc = fold(acc, v[r]);
+  }
+  acc = fold(acc, __shfl_xor(acc, 16, 64));
+  acc = fold(acc, __shfl_xor(acc, 32, 64));
+  if ((t & 63) < 16) sh[t >> 6][c] = acc;
+  __syncthreads();
+  if (t < NRED + 2) {                                 // one thread per value folds the wavefronts' results, in wavefront order
+    double x = sh[0][t];
+    for (int w = 1; w < NWV; ++w) x = fold(x, sh[w][t]);
+    sh[0][t] = x;                                     // (thread t is the only reader of column t)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NRED; ++k) tot[k] = sh[0][k];
+  tmin = sh[0][NRED]; tmax = sh[0][NRED + 1];
+}
+// red[0..9] <- totals: for the all-reduce between the phases when world_size > 1, and for k_fixer_apply (the eager path)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                     double *__restrict__ red) {
+  __shared__ double sh[NT / 64][16];
+  double tot[NRED], tmn, tmx;
+  fixer_totals<NT>(pprev, pfut, nb, sh, tot, tmn, tmx);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) red[c] = tot[c];
+    red[20] = fmin(red[20], tmn); red[21] = fmax(red[21], tmx);      // running extremes of this rank's band
+  }
+}
 struct FixerArgs {
-  double *red;                  // [0..9] global sums (all-reduced between the phases when world_size > 1), [16..18] scalars out
+  double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
   const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
-  int nb;
-  // what the LAST block of k_fixer_sums to finish does once every block's partials are in (round 6; it was a kernel of its own: k_fixer_reduce /
-  // k_fixer_finish, 8 us of launch, drain and one block's latency per step):
-  //   1  the totals into red[0..9] -- world_size > 1: the all-reduce follows, then k_fixer_finish; eager fixers: k_fixer_apply follows
-  //   2  everything: totals, compute_corrections' three scalars left pending on the new level, the (0,0) spectral patch (lazy fixers on one rank)
-  int fin;
-  unsigned *ticket;             // blocks that have stored their partials (reset by the last one)
-  double *pend_fut;             // Dev::pend row of the new level
-  int patch;
+  int nb, reduce_here;
+  int patch;               // k_fixer_finish: patch the (0,0) spectral coefficients (not on its second run of a step, after the water sums came in)
   double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
   double *psg, *tg;
   double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
@@ -3329,154 +3447,6 @@ __device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerA
     a.ts_cur[mn * g.L + k].x = p.tc + a.robert * a.raw * dtc;
   }
 }
-// Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from k_fixer_sums) by ONE
-// block, in an order that does not depend on the block's size: 1024 VIRTUAL threads -- value c = v & 15 (0..1 the column kernel's sums, 2..9
-// k_fixer_sums', 10 min, 11 max), group g = v >> 4 -- each fold the sets g, g + 64, ... of their value in ascending order; the 64 groups of a value are
-// then folded in ascending order by one thread.  A real thread takes the virtual threads r, r + blockDim, ...  Same bits from k_fixer_sums' last
-// block (64..512 threads) and from the separate kernels of the eager / sharded paths.  `coherent`: k_fixer_sums' partials were stored by other
-// blocks of the SAME kernel, possibly on another XCD: agent-scope atomic loads (they bypass this XCD's L2).
-__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                             double (*sh)[16], double *tot, double &tmin, double &tmax, bool coherent) {
-  const int NT = blockDim.x, r = threadIdx.x, c = r & 15, cc = min(c, NRED + 1);
-  const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
-  const int st = cc < 2 ? 2 : NPART;
-  const bool atom = coherent && cc >= 2;
-  auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
-  constexpr int U = 8;                               // loads in flight per virtual thread
-  for (int vt = r; vt < 1024; vt += NT) {
-    const int g = vt >> 4;
-    double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
-    for (int i0 = g; i0 < nb; i0 += U * 64) {
-      double x[U];
-#pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const double *pq = p0 + (size_t)st * min(i0 + 64 * q, nb - 1);
-        x[q] = atom ? __hip_atomic_load(pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *pq;
-      }
-#pragma unroll
-      for (int q = 0; q < U; ++q)
-        if (i0 + 64 * q < nb) acc = fold(acc, x[q]);
-    }
-    sh[g][c] = acc;
-  }
-  __syncthreads();
-  if (r < NRED + 2) {                                 // one thread per value folds the 64 groups in ascending order (c = r here)
-    double x = sh[0][r];
-    for (int g = 1; g < 64; ++g) x = fold(x, sh[g][r]);
-    sh[0][r] = x;                                     // (thread r is the only reader of column r)
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NRED; ++k) tot[k] = sh[0][k];
-  tmin = sh[0][NRED]; tmax = sh[0][NRED + 1];
-}
-// The fixer sums over the new level: block partials, then (FixerArgs::fin) the last block to arrive -- an agent-scope ticket -- folds them and finishes.
-// A block publishes its ten partials with agent-scope atomic stores (written through this XCD's L2), waits for their acknowledgement and only then
-// takes its ticket; the last block reads all partials with agent-scope atomic loads.  No fence: a release fence writes the XCD's whole L2 back
-// (measured in round 1: the sums kernel 13 -> 27 us), and nothing but these ten numbers per block has to travel.
-__global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
-                                                    const double *__restrict__ t, const double *__restrict__ psg,
-                                                    const double *__restrict__ dpk, const double *__restrict__ dbk,
-                                                    const double *__restrict__ wts, double *__restrict__ partials, int CH,
-                                                    const double *__restrict__ wcol, const double *__restrict__ w0blk, int n_w0, FixerArgs fa) {
-  __shared__ double sred[4][8];
-  __shared__ double sh[64][16];
-  __shared__ int s_last;
-  const int tid = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
-  const int col = blockIdx.x * 64 + tid;
-  const int jl = col / g.I;
-  const size_t c2 = col, lev = (size_t)g.Jl * g.I;
-  const int k0 = w * CH, nk = min(g.L, k0 + CH) - k0;
-  const double wgt = wts[jl], ps = psg[c2];
-  double uu[8], vv[8], tt[8];                       // CH <= 8: all loads of the thread in flight together
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t q = c2 + (size_t)min(k0 + i, g.L - 1) * lev;
-    uu[i] = u[q]; vv[i] = v[q]; tt[i] = t[q];
-  }
-  double t0 = 0., t1 = 0., t2 = 0., t3 = 0., t4 = 0.;
-  if (wcol && w == 0) {   // water fixer column sums left by the tracer kernel: before, after (dpk part, dbk*ps part), masked
-    // "before": the vertical tracer kernel's column sums, or (w0blk) the horizontal kernel's already weighted block sums, n_w0 of them
-    t0 = w0blk ? (col < n_w0 ? w0blk[col] : 0.0) : wgt * wcol[c2];
-    t1 = wgt * wcol[lev + c2]; t2 = wgt * wcol[2 * lev + c2] * ps;
-    t3 = wgt * wcol[3 * lev + c2]; t4 = wgt * wcol[4 * lev + c2] * ps;
-  }
-  double sa = 0.0, sb = 0.0;
-  double tmn = tt[0], tmx = tt[0];                  // valid_range_t check of the new temperatures (spectral_dynamics.F90:940)
-  bool nan = false;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i < nk) {
-      const double e = 0.5 * (uu[i] * uu[i] + vv[i] * vv[i]) + CP_AIR * tt[i];
-      sa += e * dpk[k0 + i];
-      sb += e * dbk[k0 + i];
-      tmn = fmin(tmn, tt[i]); tmx = fmax(tmx, tt[i]);
-      nan = nan || !(tt[i] == tt[i]);
-    }
-  }
-  if (nan) tmx = INFINITY;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    tmn = fmin(tmn, __shfl_xor(tmn, off, 64));
-    tmx = fmax(tmx, __shfl_xor(tmx, off, 64));
-  }
-  if (tid == 0) { sred[2][w] = tmn; sred[3][w] = tmx; }
-  double s0 = (w == 0) ? wgt * ps : 0.0, s1 = wgt * sa, s2 = wgt * sb * ps;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    s0 += __shfl_down(s0, off, 64);
-    s1 += __shfl_down(s1, off, 64);
-    s2 += __shfl_down(s2, off, 64);
-  }
-  if (tid == 0) { sred[0][w] = s1; sred[1][w] = s2; }
-  __syncthreads();
-  if (w == 0) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      t0 += __shfl_down(t0, off, 64); t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64);
-      t3 += __shfl_down(t3, off, 64); t4 += __shfl_down(t4, off, 64);
-    }
-  }
-  if (threadIdx.x == 0) {
-    double a1 = 0.0, a2 = 0.0, bmn = sred[2][0], bmx = sred[3][0];
-    for (int ww = 0; ww < NW; ++ww) { a1 += sred[0][ww]; a2 += sred[1][ww]; bmn = fmin(bmn, sred[2][ww]); bmx = fmax(bmx, sred[3][ww]); }
-    double *p = partials + NPART * (size_t)blockIdx.x;
-    const double pv[NPART] = {s0, a1, a2, t0, t1, t2, t3, t4, bmn, bmx};
-    if (!fa.fin) {
-#pragma unroll
-      for (int c = 0; c < NPART; ++c) p[c] = pv[c];
-    } else {
-#pragma unroll
-      for (int c = 0; c < NPART; ++c) __hip_atomic_store(p + c, pv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __builtin_amdgcn_s_waitcnt(0);                 // vmcnt(0): the write-through stores are acknowledged ...
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      const unsigned tk = __hip_atomic_fetch_add(fa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the ticket is taken
-      s_last = (tk == gridDim.x - 1) ? 1 : 0;
-    }
-  }
-  if (!fa.fin) return;
-  __syncthreads();
-  if (!s_last) return;
-  // ---- the last block: every block's partials are in memory
-  const bool all = fa.fin == 2;
-  const SpecPatch sp = (all && fa.patch) ? fixer_patch_load(g, fa) : SpecPatch{0., 0., 0., 0.};
-  const double mn_old = fa.red[20], mx_old = fa.red[21];
-  double r_[NRED], fmn, fmx;
-  fixer_totals(fa.pprev, fa.pfut, fa.nb, sh, r_, fmn, fmx, true);
-  double factor = 1.0, tcorr = 0.0, wfac = 1.0;
-  if (all) fixer_scalars(r_, fa, factor, tcorr, wfac);
-  if (threadIdx.x == 0) {
-    for (int c = 0; c < NRED; ++c) fa.red[c] = r_[c];
-    fa.red[20] = fmin(mn_old, fmn); fa.red[21] = fmax(mx_old, fmx);      // running extremes of this rank's band
-    if (all) {
-      fa.red[16] = factor; fa.red[17] = tcorr; fa.red[18] = wfac;
-      fa.pend_fut[PEND_FACTOR] = factor; fa.pend_fut[PEND_TCORR] = tcorr; fa.pend_fut[PEND_WFAC] = wfac;
-    }
-    __hip_atomic_store(fa.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (all && fa.patch) fixer_patch_spectral(g, fa, sp, factor, tcorr);
-}
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
 // Scalars: red[16] mass factor, red[17] temperature correction, red[18] water factor.
@@ -3534,18 +3504,25 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
 }
 // Lazy fixers: the same scalars, but nothing is applied to the grid fields -- they are left PENDING on the new time level
 // (pend[4 * fut + 0..2]) and every later reader of that level applies them (k_column, the tracer kernels; k_fixer_materialize
-// for the host).  On one rank this is the work of k_fixer_sums' last block (FixerArgs::fin = 2); this kernel is what follows the all-reduce of
-// red[0..9] when world_size > 1.  One block; the (0,0) spectral coefficients are patched here as in k_fixer_apply.
-__global__ __launch_bounds__(256) void k_fixer_finish(Geom g, FixerArgs a) {
-  double r_[NRED];
+// for the host).  One block; the (0,0) spectral coefficients are patched here as in k_fixer_apply.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
+  __shared__ double sh[NT / 64][16];
+  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
   const SpecPatch sp = a.patch ? fixer_patch_load(g, a) : SpecPatch{0., 0., 0., 0.};
+  const double mn_old = a.red[20], mx_old = a.red[21];
+  if (a.reduce_here) fixer_totals<NT>(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
+  else {
 #pragma unroll
-  for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
+    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
+  }
   double factor, tcorr, wfac;
   fixer_scalars(r_, a, factor, tcorr, wfac);
   if (threadIdx.x == 0) {
+    for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
     a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
-    a.pend_fut[PEND_FACTOR] = factor; a.pend_fut[PEND_TCORR] = tcorr; a.pend_fut[PEND_WFAC] = wfac;
+    if (a.reduce_here) { a.red[20] = fmin(mn_old, tmn); a.red[21] = fmax(mx_old, tmx); }
+    pend_fut[PEND_FACTOR] = factor; pend_fut[PEND_TCORR] = tcorr; pend_fut[PEND_WFAC] = wfac;
   }
   if (a.patch) fixer_patch_spectral(g, a, sp, factor, tcorr);
 }
@@ -3595,12 +3572,29 @@ __global__ __launch_bounds__(256) void k_fixer_materialize(Geom g, MaterializeAr
   }
 }
 
+void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
+  const Geom &g = h.g;
+  const Dev &d = h.d;
+  const int nb = (int)column_partials_count(h);
+  double *p2 = d.partials + 2 * (size_t)nb;
+  const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
+  const double *wcol = h.tracer_on ? d.wcol : (const double *)nullptr;
+  const double *w0blk = (h.tracer_on && h.tr_filt_horiz) ? d.w0blk : (const double *)nullptr;
+  const int n_w0 = g.L * ((g.Jl + TR_RB - 1) / TR_RB);
+  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol, w0blk, n_w0);
+  // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
+  // on one rank k_fixer_finish folds them itself
+  if (g.P > 1 || !h.lazy_fix) {
+    if (nb > 256) hipLaunchKernelGGL(k_fixer_reduce<1024>, dim3(1), dim3(1024), 0, s, d.partials, p2, nb, d.red);
+    else hipLaunchKernelGGL(k_fixer_reduce<256>, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
+  }
+}
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   const Geom &g = h.g;
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
   a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
-  a.fin = 0; a.ticket = h.d.fix_ticket; a.pend_fut = h.d.pend + 4 * sc.fut;
+  a.reduce_here = (g.P == 1 && h.lazy_fix);      // k_fixer_finish folds the partials itself; otherwise k_fixer_reduce (+ the all-reduce) left red[0..9]
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
   a.psg = h.d.psg[sc.fut]; a.tg = h.d.tg[sc.fut];
@@ -3615,23 +3609,6 @@ static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   a.patch = 1;
   return a;
 }
-// The sums over the local band AND what follows them without an exchange: on one rank with lazy fixers everything (the scalars pending on the new
-// level, the (0,0) patch); otherwise the totals in red[0..9] for the all-reduce between the phases (world_size > 1) or for k_fixer_apply (eager fixers).
-bool fixer_sums_finish(const isca_dyn &h) { return h.g.P == 1 && h.lazy_fix; }
-void launch_fixer_sums(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  const Geom &g = h.g;
-  const Dev &d = h.d;
-  const int fut = sc.fut;
-  const int nb = (int)column_partials_count(h);
-  double *p2 = d.partials + 2 * (size_t)nb;
-  const int CH = (g.L + 7) / 8, NW = (g.L + CH - 1) / CH;
-  const double *wcol = h.tracer_on ? d.wcol : (const double *)nullptr;
-  const double *w0blk = (h.tracer_on && h.tr_filt_horiz) ? d.w0blk : (const double *)nullptr;
-  const int n_w0 = g.L * ((g.Jl + TR_RB - 1) / TR_RB);
-  FixerArgs fa = fixer_args(h, sc);
-  fa.fin = fixer_sums_finish(h) ? 2 : 1;
-  hipLaunchKernelGGL(k_fixer_sums, dim3(nb), dim3(64 * NW), 0, s, g, d.ug[fut], d.vg[fut], d.tg[fut], d.psg[fut], d.dpk, d.dbk, d.wts_lat_l, p2, CH, wcol, w0blk, n_w0, fa);
-}
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const Geom &g = h.g;
   const FixerArgs a = fixer_args(h, sc);
@@ -3639,9 +3616,10 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   const unsigned nblk = (unsigned)std::min<size_t>(1024, (n3 / 2 + 255) / 256);
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
-void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {      // world_size > 1, lazy fixers: behind the all-reduce of red[0..9]
-  const FixerArgs a = fixer_args(h, sc);
-  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(256), 0, s, h.g, a);
+void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
+  FixerArgs a = fixer_args(h, sc);
+  if (a.nb > 256) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+  else hipLaunchKernelGGL(k_fixer_finish<256>, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
 }
 // tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s) {

@@ -1686,6 +1686,28 @@ def test_bench_two_ranks_native_loop_and_variants():
     assert any("ISCA_HALO_WITH_ALL_TO_ALL" in k and "halo" not in x["exchange_ms_rank0"] and "all_to_all_fwd" in x["exchange_ms_rank0"] for k, x in v.items()), v   # the halo rows folded in
 
 
+def test_bench_fault_injection_every_rank_reports_within_a_minute():
+    """A rank that never joins an exchange (ISCA_FAULT_EXCHANGE="1:25": rank 1 skips its 26th exchange -- the ipc driver's equivalent of a rank whose
+    ncclRecv is never posted): the peers' exchange gives up at its deadline (ISCA_IPC_TIMEOUT_S here; ISCA_EXCHANGE_TIMEOUT_S + ncclCommAbort for RCCL,
+    csrc/comm.cpp), the abort word stops the absent rank too, and EVERY rank ends in one JSON error line -- rank 0's on stdout, where the driver reads the
+    bench line -- well inside a minute instead of at the job's own limit."""
+    import json, subprocess, sys, time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29659", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--workload", "T21L25"]
+    env = dict(os.environ, ISCA_BENCH_BACKEND="gloo", ISCA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", ISCA_COMM="ipc",
+               ISCA_BENCH_SPINUP_S="0", ISCA_FAULT_EXCHANGE="1:25", ISCA_IPC_TIMEOUT_S="8")
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=repo)
+    elapsed = time.time() - t0
+    out = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    err = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith('{"metric"')]
+    assert r.returncode != 0 and len(out) == 1 and out[0]["value"] is None and out[0]["rank"] == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "error" in out[0] and ("timed out" in out[0]["error"] or "stopped with an error" in out[0]["error"]), out[0]
+    assert any(e["rank"] == 1 and "fault injected" in e["error"] for e in err), r.stderr[-2500:]
+    assert elapsed < 60.0, elapsed
+
+
 def test_bench_eight_ranks_headline_workload_on_one_gpu():
     """The driver's 8-GPU launch line, run once before the driver runs it: bench.py --gpus 8 on the HEADLINE workload (T85L40: 16 latitude rows and
     11 zonal wavenumbers per rank) with the library issuing the exchanges (ISCA_COMM=ipc: the eight ranks share this box's GPU; RCCL on a node) --
