@@ -31,13 +31,6 @@ void isca_internal_set_error(const std::string &m) { g_last_error = m; }      //
   return 0;
 
 static void fail(const std::string &m) { throw std::runtime_error(m); }
-static bool getenv_once(const char *name) {          // measurement switches: looked up once per name
-  static std::mutex mu; static std::vector<std::pair<std::string, bool>> seen;
-  std::lock_guard<std::mutex> lk(mu);
-  for (auto &e : seen) if (e.first == name) return e.second;
-  seen.emplace_back(name, getenv(name) != nullptr);
-  return seen.back().second;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // kernel timing (HIP events on the handle's stream)
@@ -451,12 +444,15 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
         build_legendre_fragments(g, T, h->h_m_local, ff, fi, sc);
         d.leg_fwd_frag = dupload(h, ff); d.leg_inv_frag = dupload(h, fi); d.leg_scoef = dupload(h, sc);
       }
-      // fused FFT + Legendre analysis of the step (one rank, lon_max = 256, triangular truncation): ISCA_FUSE_FFT_LEG=1
-      if (getenv("ISCA_FUSE_FFT_LEG") && atoi(getenv("ISCA_FUSE_FFT_LEG")) != 0 && fused_forward_ok(g) && cfg->triang_trunc && cfg->fourier_inc == 1) {
+#ifdef ISCA_EXPERIMENTS
+      // fused FFT + Legendre analysis of the step (one rank, lon_max = 256, triangular truncation): ISCA_FUSE_FFT_LEG=1 -- correct, 45 MB less traffic,
+      // 1.7x slower than the two kernels it replaces (round 4, HISTORY.md)
+      if (exp_env("ISCA_FUSE_FFT_LEG") && atoi(exp_env("ISCA_FUSE_FFT_LEG")) != 0 && fused_forward_ok(g) && cfg->triang_trunc && cfg->fourier_inc == 1) {
         std::vector<double> fz; std::vector<int> dz;
         const int nt = build_fused_fwd_tables(g, T, h->h_m_local, fz, dz);
         if (nt) { d.fz_frag = dupload(h, fz); d.fz_desc = dupload(h, dz); d.fz_NT = nt; h->fuse_fwd = true; }
       }
+#endif
     }
     {  // coefficient tables per local m
       const std::vector<double> *src[13] = {&T.eigen, &T.coef_uvm, &T.coef_uvc, &T.coef_uvp, &T.coef_alpm, &T.coef_alpp,
@@ -568,7 +564,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     }
     {  // the tracer's side stream; ISCA_TRACER_PRIO=high|low asks for a queue priority other than the main stream's (measurement switch)
       int lo = 0, hi = 0;
-      const char *pr = getenv("ISCA_TRACER_PRIO");
+      const char *pr = exp_env("ISCA_TRACER_PRIO");
       if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
         HIP_CHECK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
       else HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
@@ -576,7 +572,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // fork / join of the side stream: dependencies between kernels of ONE device -- no system-scope fence when the event is recorded (the default writes the
     // caches back and invalidates them for the host and other devices: measured 7.4 us between k_column and k_fft_fwd3 and 6.5 us in front of k_fixer_sums at
     // T85L40 against 0-1.7 us between the other kernels, tools/kernel_gaps.sh).  ISCA_EVENT_SYSTEM_FENCE=1: the default flags.
-    const unsigned evf = hipEventDisableTiming | (getenv("ISCA_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+    const unsigned evf = hipEventDisableTiming | (exp_env("ISCA_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, evf));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, evf));
     HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, evf));
@@ -641,14 +637,14 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     // Tracer kernels on the side stream (fork after the column kernel, join before the fixer sums) pay for themselves from about T85 up:
     // at T42L25 / T21L25 the two cross-stream waits cost more than the overlap hides (0.105 -> 0.094 and 0.100 -> 0.083 ms per step
     // with the tracer on the main stream), at T85L40 the side stream saves 0.04 ms.  One rank only: a sharded step hides them under its exchange.
-    h->tracer_serial = getenv("ISCA_TRACER_SERIAL") != nullptr ||
+    h->tracer_serial = exp_env("ISCA_TRACER_SERIAL") != nullptr ||
                        (g.P == 1 && (size_t)g.L * g.Jl * g.I < 500000 && getenv("ISCA_TRACER_CONCURRENT") == nullptr);
     // ISCA_TRACER_EARLY=1 (measurement switch): the horizontal tracer kernel starts beside the column kernel instead of after it.  At T170L60
     // the main stream waits ~130 us for the side stream at the join, but starting the tracer earlier only moves the contention: the column
     // kernel beside it takes 365 us instead of 258 and the step 0.979 against 0.974 ms (T85L40: 0.215 against 0.188) -- the step is bound by
     // the sum of the bytes, not by the order of the kernels.  Off by default.
     {
-      const char *e = getenv("ISCA_TRACER_EARLY");
+      const char *e = exp_env("ISCA_TRACER_EARLY");
       h->tracer_early = e && e[0] == '1';
     }
     // ISCA_TRACER_FILTER_IN_VERT=1 (measurement / test switch): the first half of the tracer's Robert filter and the water fixer's "before" sum stay in the
@@ -661,7 +657,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     if (cfg->num_tracers > 0 && !tracer_can)
       fail("spectral_dynamics_init: the grid tracer needs num_levels >= 5 and lat_max / world_size >= 4; "
            "set num_tracers = 0 to run without it");
-    h->tracer_env_off = getenv("ISCA_NO_TRACER") != nullptr;   // measurement switch, reported by isca_dyn_get_info("tracer_env_off")
+    h->tracer_env_off = exp_env("ISCA_NO_TRACER") != nullptr;   // measurement switch, reported by isca_dyn_get_info("tracer_env_off")
     h->tracer_on = tracer_can && (cfg->num_tracers > 0) && !h->tracer_env_off;
     if (cfg->physics == 1) {                  // idealized_moist_phys_init: tables, surface state, tendency arrays
       if (!h->tracer_on) fail("idealized_moist_phys: the specific-humidity grid tracer is not available in this configuration");
@@ -691,10 +687,10 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     h->Ci = col_pitch(7 * g.L + 3);
     // the MFMA synthesis kernel can generate its B operand from the spectral state (no staged work buffer)
     h->fuse_synth = legendre_mfma_ok(g, cfg->legendre_impl) && cfg->triang_trunc && cfg->fourier_inc == 1;      // the fused gather has the triangle's bounds built in
-    if (getenv("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
+    if (exp_env("ISCA_NO_FUSE_SYNTH")) h->fuse_synth = false;
     // x-derivatives in Fourier space: with the fused synthesis, the plain Robert filter (the RAW filter re-synthesises the gradients from the adjusted
     // level in a batch of their own) and the lon_max = 256 / 512 FFT kernels
-    h->dx_fourier = h->fuse_synth && cfg->raw_filter_coeff == 1.0 && g.I >= 256 && (g.I & (g.I - 1)) == 0 && !getenv("ISCA_NO_DX_FOURIER") && !getenv("ISCA_FFT_OLD");
+    h->dx_fourier = h->fuse_synth && cfg->raw_filter_coeff == 1.0 && g.I >= 256 && (g.I & (g.I - 1)) == 0 && !exp_env("ISCA_NO_DX_FOURIER") && !exp_env("ISCA_FFT_OLD");
     if (h->dx_fourier) h->Ci = col_pitch(6 * g.L + 2);
     if (virtual_t_on(*h)) d.tv = dalloc<double>(h, ng3);
     // Lazy fixers (core.h): for the plain configurations -- one grid tracer at most, Robert filter without the RAW term, no virtual
@@ -1123,7 +1119,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   if (h->cfg.physics == 1) {
     // the previous level's pressures are what the step before computed for its current level (grid p_s of a level is final once its
     // fixers are applied; every state write drops the cache): only the current level's are computed then (k_moist_pressures 20 -> 11 us)
-    const bool cached = h->moist_pcache && sc.prev != sc.cur && !getenv_once("ISCA_MOIST_NO_PCACHE");
+    const bool cached = h->moist_pcache && sc.prev != sc.cur && !exp_env("ISCA_MOIST_NO_PCACHE");
     const int slot_prev = cached ? h->moist_pslot : 0, slot_cur = 1 - slot_prev;
     { Timed t(h, "moist_pressures"); launch_moist_pressures(*h, sc, h->stream, slot_prev, slot_cur, cached); }
     // convection + condensation read the previous level only: the kernel of the step before has computed them beside its own chain (cc_valid;
@@ -1164,8 +1160,10 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
       HIP_CHECK(hipEventRecord(h->ev_join, h->stream2));
     }
   }
-  if (h->fuse_fwd) { Timed t(h, "fft_leg_fwd"); launch_fft_legendre_forward(h->g, h->d, h->fl_fwd, h->d.Sf, h->stream); }
-  else { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
+#ifdef ISCA_EXPERIMENTS
+  if (h->fuse_fwd) { Timed t(h, "fft_leg_fwd"); launch_fft_legendre_forward(h->g, h->d, h->fl_fwd, h->d.Sf, h->stream); } else
+#endif
+  { Timed t(h, "fft_fwd"); launch_fft_forward(h->g, h->d, h->fl_fwd, h->d.Ff_g, h->stream); }
 }
 // Sharded runs: the grid tracer's transport, issued when the neighbours' halo rows have arrived (fv_advection's mpp_update_domains) and
 // BEFORE the lat -> m all-to-all, on the side stream: it then runs under that exchange and the spectral pipeline, like on one GPU.
@@ -1353,7 +1351,7 @@ extern "C" int isca_dyn_step(isca_dyn_t *h, int nsteps, int sync) {
   for (int i = 0; i < nsteps; ++i) {
     // wg_full (omega) is an output only: the last step of the call stores it, and every step while a diagnostic of omega accumulates
     // (or the moist package runs, whose restart and diagnostics see it too)
-    const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->hist_wg_full || h->cfg.physics == 1 || getenv_once("ISCA_ALWAYS_WG_FULL");
+    const int store_wg = (i == nsteps - 1) || (h->diag_mask & 0x3C040u) || h->hist_wg_full || h->cfg.physics == 1 || exp_env("ISCA_ALWAYS_WG_FULL");
     if (h->g.P > 1) sharded_step(h, store_wg);
     else {
       StepScalars sc = step_scalars(h);

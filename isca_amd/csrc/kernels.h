@@ -2,6 +2,16 @@
 #pragma once
 #include "core.h"
 
+#include <cstdlib>
+// Switches of measured-and-rejected variants (HISTORY.md has their numbers) exist only in a build with -DISCA_EXPERIMENTS (tools/build_variant.sh);
+// the product looks none of them up and instantiates none of their kernels.  What the product does read from the environment is listed in
+// DESIGN.md 5 "Environment": the communicator's configuration and eight test hooks that force a path a configuration would select by itself.
+#ifdef ISCA_EXPERIMENTS
+inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
 namespace isca {
 
 struct StepScalars {      // per-step scalars passed by value to kernels

@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void k_fft_inv3(Geom g, FieldList fl, const do
   }
 }
 
+#ifdef ISCA_EXPERIMENTS      // (round 4: correct, 45 MB less traffic, 1.7x slower than the two kernels it replaces -- HISTORY.md)
 // =====================================================================================================
 // Fused analysis: longitude FFT + Legendre transform of the step's forward batch in ONE kernel -- the truncated Fourier rows
 // (grid_fourier.F90:129-179 -> spherical_fourier.F90:264-339) never leave the chip.  One rank (no lat <-> m exchange to feed), lon_max = 256.
@@ -705,7 +706,7 @@ bool fused_forward_ok(const Geom &g) { return g.P == 1 && g.I == 256 && g.Jh % F
 void launch_fft_legendre_forward(const Geom &g, const Dev &d, const FieldList &fl, double *S, hipStream_t s) {
   FusedFwdArgs a;
   a.frag = d.fz_frag; a.desc = d.fz_desc; a.S = S; a.C = col_pitch(fl.ncol); a.NCH = g.Jh / FZ_PC; a.MP = g.M1 | 1;
-  static const int dbg = getenv("ISCA_FZ_DBG") ? atoi(getenv("ISCA_FZ_DBG")) : 0;
+  static const int dbg = exp_env("ISCA_FZ_DBG") ? atoi(exp_env("ISCA_FZ_DBG")) : 0;
   a.dbg = dbg;
   const size_t lds = (size_t)(16 * 128 + 2 * 128) * sizeof(double2) + (size_t)2 * FZ_PC * 2 * a.MP * 4 * sizeof(double);
   const dim3 grid((unsigned)((fl.ncol + 1) / 2));
@@ -719,6 +720,7 @@ void launch_fft_legendre_forward(const Geom &g, const Dev &d, const FieldList &f
   else throw std::runtime_error("fused analysis: unsupported tile count");
 #undef LZ
 }
+#endif  // ISCA_EXPERIMENTS
 
 // ---- lon_max = 2^a 3^b 5^c that is not a power of two (the lengths fft99's set99 factors, fft99.F90:83-120; its radix-3 / radix-5 passes
 // :876-1228): the same real <-> half-complex scheme -- one complex Stockham transform of length NC = I/2 and the even/odd split -- with the
@@ -889,15 +891,15 @@ static unsigned fft_grid(int items) {                  // persistent blocks: at 
   const int rounds = (items + cap - 1) / cap;
   return (unsigned)((items + rounds - 1) / rounds);
 }
-static bool fft_old() { static const bool v = getenv("ISCA_FFT_OLD") != nullptr; return v; }   // measurement switch: the generic LDS passes
-static bool fft_twreg() { static const bool v = getenv("ISCA_FFT_TWLDS") == nullptr; return v; }    // pass twiddles in registers (default) or read from LDS
+static bool fft_old() { static const bool v = exp_env("ISCA_FFT_OLD") != nullptr; return v; }   // experiment: the generic LDS passes at lon_max >= 256
+static bool fft_twreg() { static const bool v = exp_env("ISCA_FFT_TWLDS") == nullptr; return v; }    // pass twiddles in registers (default) or, experiment, read from LDS
 static size_t fft3_lds_bytes(int NC) { return (size_t)(fft_rows(NC) * (NC + NC / 8 + 1) + 2 * NC) * sizeof(double2) + (NC + 7 * ISCA_MAX_LEVELS + 3) * sizeof(int); }      // rows, twiddles, slot of m, k_fft_inv3's row table
 static dim3 fft3_grid(int items) {                     // persistent blocks of 256 threads: 2 per CU (~196 VGPRs; measured against 3 and 4 per CU)
-  static const int cap = getenv("ISCA_FFT_CAP") ? atoi(getenv("ISCA_FFT_CAP")) : 512;
+  static const int cap = exp_env("ISCA_FFT_CAP") ? atoi(exp_env("ISCA_FFT_CAP")) : 512;
   const int rounds = (items + cap - 1) / cap;
   // a multiple of 8 blocks: fft_first_item then gives each XCD a contiguous run of items (neighbouring items share 128-byte lines of the Fourier buffer);
   // with any other count it falls back to item = block, i.e. neighbours on different L2s.  (ISCA_FFT_G8=0: the count as it was, for measurements.)
-  static const bool g8 = !(getenv("ISCA_FFT_G8") && atoi(getenv("ISCA_FFT_G8")) == 0);
+  static const bool g8 = !(exp_env("ISCA_FFT_G8") && atoi(exp_env("ISCA_FFT_G8")) == 0);
   const int G = (items + rounds - 1) / rounds;
   return dim3((unsigned)(g8 ? (G + 7) / 8 * 8 : G));
 }
@@ -913,8 +915,18 @@ void launch_fft_forward(const Geom &g, const Dev &d, const FieldList &fl, double
 #define LF(N) hipLaunchKernelGGL(k_fft_fwd<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LF(8); break; case 16: LF(16); break; case 32: LF(32); break; case 64: LF(64); break;
-    case 128: if (fft_old()) LF(128); else if (fft_twreg()) LF3(128, true); else LF3(128, false); break;
-    case 256: if (fft_old()) LF(256); else if (fft_twreg()) LF3(256, true); else LF3(256, false); break;
+    case 128:
+#ifdef ISCA_EXPERIMENTS
+      if (fft_old()) { LF(128); break; }
+      if (!fft_twreg()) { LF3(128, false); break; }
+#endif
+      LF3(128, true); break;
+    case 256:
+#ifdef ISCA_EXPERIMENTS
+      if (fft_old()) { LF(256); break; }
+      if (!fft_twreg()) { LF3(256, false); break; }
+#endif
+      LF3(256, true); break;
     default: launch_fft_mixed(false, g, d, fl, Fg, s);
   }
 #undef LF
@@ -931,8 +943,18 @@ void launch_fft_inverse(const Geom &g, const Dev &d, const FieldList &fl, const 
 #define LI(N) hipLaunchKernelGGL(k_fft_inv<N>, grid, dim3(R * 16), lds, s, g, fl, d.cosm_lat_l, d.slot_of_m, (const double2 *)d.tw, Fg, C, GX)
   switch (NC) {
     case 8: LI(8); break; case 16: LI(16); break; case 32: LI(32); break; case 64: LI(64); break;
-    case 128: if (fft_old()) LI(128); else if (fft_twreg()) LI3(128, true); else LI3(128, false); break;
-    case 256: if (fft_old()) LI(256); else if (fft_twreg()) LI3(256, true); else LI3(256, false); break;
+    case 128:
+#ifdef ISCA_EXPERIMENTS
+      if (fft_old()) { LI(128); break; }
+      if (!fft_twreg()) { LI3(128, false); break; }
+#endif
+      LI3(128, true); break;
+    case 256:
+#ifdef ISCA_EXPERIMENTS
+      if (fft_old()) { LI(256); break; }
+      if (!fft_twreg()) { LI3(256, false); break; }
+#endif
+      LI3(256, true); break;
     default: launch_fft_mixed(true, g, d, fl, const_cast<double *>(Fg), s);
   }
 #undef LI
@@ -1984,7 +2006,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     // instantiation with chunks of <= 5 levels, when the grid has at least two blocks per CU to interleave: T85L40 on one rank 40.0 -> 37.0 us
     // (HIP events; step 0.1769 -> 0.1735 ms, two A/B pairs in one gpurun call).  A smaller grid (a shard, T42) is one round of blocks whatever the
     // occupancy, and there the second memory round trip only adds latency.  ISCA_COLUMN_TWO=0|1 overrides (measurement).
-    static const int two_env = getenv("ISCA_COLUMN_TWO") ? atoi(getenv("ISCA_COLUMN_TWO")) : -1;
+    static const int two_env = exp_env("ISCA_COLUMN_TWO") ? atoi(exp_env("ISCA_COLUMN_TWO")) : -1;
     const bool two = two_env >= 0 ? two_env != 0 : (grid.x >= 512 && CH <= 5);
     if (two && !a.tv && !ext) {
       switch (CH) {
@@ -2018,9 +2040,13 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     else if (a.tv) { if (ext) hipLaunchKernelGGL((k_column<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column<N, false, true>), grid, block, lds, s, g, a); } \
     else if (ext) hipLaunchKernelGGL((k_column<N, true, false>), grid, block, lds, s, g, a); \
     else hipLaunchKernelGGL((k_column<N, false, false>), grid, block, lds, s, g, a); } while (0)
-  switch (CH) {
-    case 1: LC(1); break; case 2: LC(2); break; case 3: LC(3); break; case 4: LC(4); break;
-    case 5: LC(5); break; case 6: LC(6); break; case 7: LC(7); break; default: LC(8); break;
+  // The general kernel (hybrid levels, 'mcm') is instantiated for even chunk sizes only -- it is the fallback since round 6, and its 64 variants were
+  // 1.4 MB of code: an odd ceil(L / 8) takes the next even chunk and fewer wavefronts.
+  {
+    const int CHg = (CH + 1) & ~1, NWg = (g.L + CHg - 1) / CHg;
+    const size_t lds = (size_t)(2 * NWg * 64 + NWg) * sizeof(double) + (size_t)NWg * 64 * sizeof(int);
+    const dim3 block(64 * NWg);
+    switch (CHg) { case 2: LC(2); break; case 4: LC(4); break; case 6: LC(6); break; default: LC(8); break; }
   }
 #undef LC
 }
@@ -3024,7 +3050,7 @@ static void launch_tracer_horiz_kernel(const Geom &g, const TracerArgs &a, size_
   if (g.I & (g.I - 1)) {        // lon_max with factors 3, 5: longitudes wrap with a remainder
     if (g.I > 256) hipLaunchKernelGGL((k_tracer_horiz<4, false>), grid, block, ldsh, s, g, a);
     else hipLaunchKernelGGL((k_tracer_horiz<1, false>), grid, block, ldsh, s, g, a);
-  } else if (g.P == 1 && !getenv("ISCA_TRACER_HORIZ_GENERIC")) {
+  } else if (g.P == 1 && !exp_env("ISCA_TRACER_HORIZ_GENERIC")) {
     if (g.I > 256) hipLaunchKernelGGL((k_tracer_horiz<4, true, true>), grid, block, ldsh, s, g, a);
     else hipLaunchKernelGGL((k_tracer_horiz<1, true, true>), grid, block, ldsh, s, g, a);
   } else if (g.I > 256) hipLaunchKernelGGL(k_tracer_horiz<4>, grid, block, ldsh, s, g, a);

@@ -463,8 +463,8 @@ __global__ void k_leg_inv_simple(Geom g, const int *__restrict__ m_local, const 
   Fs[frow(g, g.J - 1 - jp, ml, C) + c] = e + o;
 }
 
-int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
+int env_int(const char *name, int dflt) {          // experiments build only (kernels.h: exp_env)
+  const char *v = exp_env(name);
   return v ? atoi(v) : dflt;
 }
 
@@ -547,6 +547,7 @@ void build_legendre_fragments(const Geom &g, const Tables &T, const std::vector<
   }
 }
 
+#ifdef ISCA_EXPERIMENTS
 // Tables of the fused analysis (kernels.hip k_fft_leg_fwd): the triangle's tiles of 16 n dealt round-robin to the four MFMA wavefronts of a
 // block, and P(m, n, j') w(j') in the operand order of v_mfma_f64_4x4x4_4b_f64 -- A[b][i][k] in lane 16 k + 4 b + i with b < 2 the tile's even
 // n (n = 16 T + 2 (4 (b & 1) + i)), b >= 2 its odd n, k the latitude pair inside the k-step -- per (wavefront, chunk of 8 pairs, tile), the
@@ -584,6 +585,7 @@ int build_fused_fwd_tables(const Geom &g, const Tables &T, const std::vector<int
     }
   return NT;
 }
+#endif  // ISCA_EXPERIMENTS
 
 void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, double *S, int C, int full, int impl, hipStream_t s) {
   if (legendre_mfma_ok(g, impl) && C % 2 == 0) {
@@ -598,16 +600,17 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     // group re-reads come from L2).  ISCA_LEG_NTG: measurement switch.
     static const int ntg_env = env_int("ISCA_LEG_NTG", 0);
     const int items3 = g.Ml * ((C + 31) / 32) * ((a.NTP + 2) / 3);
-    const int NTG = ntg_env ? ntg_env : (items3 >= 512 ? 3 : 1);
+    const int NTG = (ntg_env == 1 || ntg_env == 2 || ntg_env == 3) ? ntg_env : (items3 >= 512 ? 3 : 1);
     a.RG = (a.NTP + NTG - 1) / NTG;
     const dim3 grid(leg_grid(g.Ml, a.CB * a.RG));
-    static const int fd = env_int("ISCA_LEG_FD", 0);       // measurement switch: ring depth 8 / 16 with one wavefront per SIMD
+    [[maybe_unused]] static const int fd = env_int("ISCA_LEG_FD", 0);       // experiment: ring depth 8 / 16 with one wavefront per SIMD
     if (NTG == 1) hipLaunchKernelGGL((k_leg_fwd<FD, 1, 4>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+#ifdef ISCA_EXPERIMENTS
     else if (NTG == 2) hipLaunchKernelGGL((k_leg_fwd<FD, 2, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     else if (fd == 8 && a.KS % 8 == 0) hipLaunchKernelGGL((k_leg_fwd<8, 3, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     else if (fd == 16 && a.KS % 16 == 0) hipLaunchKernelGGL((k_leg_fwd<16, 3, 1>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
-    else
-    hipLaunchKernelGGL((k_leg_fwd<FD, 3, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
+#endif
+    else hipLaunchKernelGGL((k_leg_fwd<FD, 3, 2>), grid, dim3(256), 0, s, g, a TRACE_LAUNCH(trace_fwd, grid.x));
     TRACE_DUMP(trace_fwd)
   } else {
     dim3 grid((C + 63) / 64, g.N1, g.Ml);
@@ -645,8 +648,10 @@ void launch_legendre_inverse(const Geom &g, const Dev &d, const double *S, doubl
         case 21: LC(2, 1, 2); break;
         case 41: LC(4, 1, 2); break;
         case 42: LC(4, 2, 2); break;
+#ifdef ISCA_EXPERIMENTS
         case 81: LC(8, 1, 2); break;
         case 82: LC(8, 2, 2); break;
+#endif
         default: throw std::runtime_error("legendre_inverse: unsupported cooperative shape");
       }
 #undef LC

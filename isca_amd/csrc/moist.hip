@@ -355,16 +355,16 @@ static MoistArgs moist_args(const isca_dyn &h) {
   a.ml.heat_capacity = mc.depth * (1.035e3 * 3989.24495292815);       // depth*RHO_CP (mixed_layer.F90:514)
   a.ml.evaporation = mc.evaporation != 0; a.ml.ocean_qflux = 0.0;
   a.dt_atmos = h.cfg.dt_atmos;
-  a.full_sweeps = getenv("ISCA_MOIST_FULL_SWEEPS") ? 1 : 0;
+  a.full_sweeps = exp_env("ISCA_MOIST_FULL_SWEEPS") ? 1 : 0;
   return a;
 }
-// LDS per block: one work array is 64 x (L+1) doubles.  ISCA_MOIST_GLOBAL_WORK / ISCA_MOIST_LDS_ARRAYS=2 (tests, measurements): the variants of larger
-// level counts at a small one; ISCA_MOIST_CC_LDS=0|2|3: the convection kernel's alone (its LDS footprint beside the dynamics kernels it runs under).
+// LDS per block: one work array is 64 x (L+1) doubles.  ISCA_MOIST_LDS_ARRAYS=0|2 (test hook): the variants of larger
+// level counts at a small one; (experiments build) ISCA_MOIST_CC_LDS=0|2|3: the convection kernel's alone (its LDS footprint beside the dynamics kernels it runs under).
 static int moist_nlds(int L, const char *own_env) {
   const size_t lds1 = (size_t)64 * (L + 1) * sizeof(double);
-  int nlds = getenv("ISCA_MOIST_GLOBAL_WORK") ? 0 : (3 * lds1 <= 65536 ? 3 : (2 * lds1 <= 65536 ? 2 : 0));      // L <= 41: all three; L <= 63: arrays 0 and 1
-  if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);
-  if (own_env) if (const char *e = getenv(own_env)) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);
+  int nlds = 3 * lds1 <= 65536 ? 3 : (2 * lds1 <= 65536 ? 2 : 0);      // L <= 41: all three; L <= 63: arrays 0 and 1
+  if (const char *e = getenv("ISCA_MOIST_LDS_ARRAYS")) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);       // test hook: 0 (all in global memory) | 2 | 3
+  if (own_env) if (const char *e = exp_env(own_env)) nlds = std::min(nlds, atoi(e) >= 2 ? atoi(e) : 0);
   return nlds;
 }
 static void launch_moist_convcond_kernel(const MoistArgs &a, hipStream_t s) {
@@ -383,11 +383,11 @@ static void launch_moist_convcond_kernel(const MoistArgs &a, hipStream_t s) {
       else hipLaunchKernelGGL((k_moist_convcond<N, 0, false>), grid, block, 0, s, a);                      \
     }                                                                                                    \
   } while (0)
-  if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
+  if (a.L <= 46) LM(48); else LM(64);      // (a 32-level instantiation existed until round 6: 225 KB of code per variant for nothing measurable at T21L25 / T42L25)
 #undef LM
 }
 static void launch_moist_physics_kernel(const MoistArgs &a, hipStream_t s) {
-  const bool two = !getenv("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
+  const bool two = !exp_env("ISCA_MOIST_ONE_WAVE");       // two wavefronts per 64 columns (see the kernel)
   const dim3 grid((a.ncol + 63) / 64), block(two ? 128 : 64);
   const size_t lds1 = (size_t)64 * (a.L + 1) * sizeof(double);
   const int nlds = moist_nlds(a.L, nullptr);
@@ -403,7 +403,7 @@ static void launch_moist_physics_kernel(const MoistArgs &a, hipStream_t s) {
       else hipLaunchKernelGGL((k_moist_physics<N, 0, false>), grid, block, 0, s, a);                      \
     }                                                                                                   \
   } while (0)
-  if (a.L <= 30) LM(32); else if (a.L <= 46) LM(48); else LM(64);
+  if (a.L <= 46) LM(48); else LM(64);      // (a 32-level instantiation existed until round 6: 225 KB of code per variant for nothing measurable at T21L25 / T42L25)
 #undef LM
 }
 

@@ -58,21 +58,21 @@ def test_moist_physics_columns(golden_dir):
 
 def test_moist_work_arrays_in_global_memory(golden_dir):
     """More than 41 levels do not fit the three LDS work arrays: up to 63 the kernel keeps two of them there and the third in a global buffer,
-    beyond that all three.  Same results, bit for bit (forced here at 25 levels through ISCA_MOIST_LDS_ARRAYS / ISCA_MOIST_GLOBAL_WORK)."""
+    beyond that all three.  Same results, bit for bit (forced here at 25 levels through the test hook ISCA_MOIST_LDS_ARRAYS = 0 | 2)."""
     g = np.load(os.path.join(golden_dir, "moist_kernels_T21L25.npz"))
     dc = moist_core()
     args = (float(g["k_in_delta_t"][0]), 1.0, g["lat_of_col"], g["k_in_u_prev"], g["k_in_v_prev"], g["k_in_t_prev"], g["k_in_q_prev"],
             g["k_in_p_half_prev"], g["k_in_p_full_prev"], g["k_in_p_half_cur"], g["k_in_p_full_cur"], g["k_in_z_half_cur"], g["k_in_z_full_cur"],
             g["k_in_t_surf"])
     a = dc.idealized_moist_phys(*args)
-    for var, val in (("ISCA_MOIST_GLOBAL_WORK", "1"), ("ISCA_MOIST_LDS_ARRAYS", "2")):
+    for var, val in (("ISCA_MOIST_LDS_ARRAYS", "0"), ("ISCA_MOIST_LDS_ARRAYS", "2")):
         os.environ[var] = val
         try:
             b = dc.idealized_moist_phys(*args)
         finally:
             del os.environ[var]
         for x, y in zip(a, b):
-            assert np.array_equal(x, y), var
+            assert np.array_equal(x, y), (var, val)
     dc.close()
 
 
