@@ -85,8 +85,8 @@ def cpu_baseline(workload, budget_steps):
             "ms_per_step": 1e3 * sec, "sample": f"{n} steps of {workload} HS, numpy oracle (BLAS threads)"}
 
 
-# timer name -> kernel name (lon_max >= 256; the generic FFT kernels below that are k_fft_fwd / k_fft_inv)
-KERNEL_OF = {"column": "k_column", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop:fused", "fft_fwd": "k_fft_fwd3", "fft_inv": "k_fft_inv3",
+# timer name -> kernel name (lon_max >= 256; the generic FFT kernels below that are k_fft_fwd / k_fft_inv; pure sigma levels: k_column_sig, else k_column)
+KERNEL_OF = {"column": "k_column_sig", "legendre_fwd": "k_leg_fwd", "legendre_inv": "k_leg_inv_coop:fused", "fft_fwd": "k_fft_fwd3", "fft_inv": "k_fft_inv3",
              "moist_physics": "k_moist_physics", "tracer_horiz": "k_tracer_horiz", "tracer_vert": "k_tracer_vert", "spec_update": "k_spec_update",
              "fixer_sums": "k_fixer_sums", "fixer_finish": "k_fixer_finish"}
 
@@ -139,7 +139,7 @@ def kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=None):
 def load_rocprof_us(workload):
     """rocprofv3 --kernel-trace --stats averages (us per launch) of this same command from the newest committed profile; measured earlier, NOT in this run"""
     import csv
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         rel = os.path.join("profiles", f"{tag}_{workload}_kernel_stats.csv")
         if os.path.exists(os.path.join(REPO, rel)):
             with open(os.path.join(REPO, rel)) as f:
@@ -148,19 +148,31 @@ def load_rocprof_us(workload):
 
 
 def dominant_roofline(kt, kern, traffic, traffic_source, workload=None):
-    """The roofline of the LONGEST kernel of the step, whichever stream it runs on (the tracer kernels of the side stream included)."""
-    cand = {k: v for k, v in kt.items() if k in kern}
+    """The roofline of the dominant kernel: the LONGEST kernel on the step's critical path, i.e. on the main stream.  The grid tracer's two kernels run on
+    the side stream UNDER the transform kernels (fork behind the column kernel, join in front of the fixer sums) and get the bandwidth those leave: at
+    T85L40 their 75 us end 40 us before the join, so the step does not wait for them -- their own rooflines are in `kernel_roofline`, and the longer of
+    them is named in `side_stream_longest` when it outlasts the main stream's longest kernel.  (`prefer`: a caller's choice, e.g. the moist kernel.)"""
+    cand = {k: v for k, v in kt.items() if k in kern and k not in SIDE_STREAM_TIMERS}
+    if not cand:
+        cand = {k: v for k, v in kt.items() if k in kern}
     dom = max(cand, key=cand.get) if cand else None
     if dom is None:
         return None
     c = kern[dom]
     name = KERNEL_OF[dom]
+    if name == "k_column_sig" and name not in traffic and "k_column" in traffic:
+        name = "k_column"
     mfma = c["bound"] == "mfma"
     ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)
     tr = traffic.get(name, traffic.get(name.rstrip("3")))                                           # k_fft_*3: lon_max >= 256; generic kernels below
     out = {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": "TFLOP/s" if mfma else "GB/s",
            "frac": ach / peak, "traffic": tr, "traffic_source": traffic_source if tr is not None else None, "avg_launch_ms": c["ms"],
            "clock": "HIP events recorded on the kernel's stream inside this run (isca_dyn_kernel_times): ~4 us per launch above the kernel's own duration"}
+    side = {k: v for k, v in kt.items() if k in kern and k in SIDE_STREAM_TIMERS}
+    if side and max(side.values()) > c["ms"]:
+        sk = max(side, key=side.get)
+        out["side_stream_longest"] = {"kernel": KERNEL_OF[sk], "avg_launch_ms": side[sk], "frac": kern[sk]["frac"], "bound": "hbm",
+                                      "note": "runs beside the main stream's kernels and ends before the join: not on the step's critical path"}
     if workload:      # the same kernel's duration in the committed rocprofv3 trace of this command, and the fraction it gives
         rp, src = load_rocprof_us(workload)
         us = rp.get(name.split(":")[0])
@@ -177,7 +189,9 @@ def step_bytes(kt, traffic, traffic_source, I, J, M1, N, L, nlf_inv=None):
     nlf = 11 * L + 4
     transforms = nlf * (8.0 * I * J + 16.0 * (N + 1) * (N + 4) / 2)
     a = transforms + sum(v for k, v in alg.items() if k in kt and not k.startswith(("fft_", "legendre_")))
-    pm = [traffic.get(KERNEL_OF[k], traffic.get(KERNEL_OF[k].rstrip("3"))) for k in kt if k in KERNEL_OF and k != "moist_physics"]
+    def tr_of(name):      # (k_fft_*3: lon_max >= 256, the generic kernels below; a profile older than round 6 knows the column kernel as k_column)
+        return traffic.get(name, traffic.get(name.rstrip("3"), traffic.get("k_column") if name == "k_column_sig" else None))
+    pm = [tr_of(KERNEL_OF[k]) for k in kt if k in KERNEL_OF and k != "moist_physics"]
     out = {"algorithmic_bytes": a, "fourier_intermediate_bytes": 2.0 * (4 * L + 1 + (nlf_inv or 7 * L + 3)) * 16.0 * M1 * J}
     if pm and all(x is not None for x in pm):
         out.update({"pmc_bytes": sum(pm), "pmc_over_algorithmic": sum(pm) / a, "pmc_source": traffic_source})
@@ -247,7 +261,7 @@ def load_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (2 x FETCH_SIZE per the gfx950 correction,
     calibrated on k_column's known byte count, + WRITE_SIZE; profiles/README.md).  A number measured earlier, NOT in this run: the
     line says which file it came from."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         rel = os.path.join("profiles", f"{tag}_pmc_traffic.json" if workload == "T85L40" else f"{tag}_{workload}_pmc_traffic.json")
         if os.path.exists(os.path.join(REPO, rel)):
             return json.load(open(os.path.join(REPO, rel))).get("bytes_per_launch", {}), rel

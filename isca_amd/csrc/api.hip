@@ -1259,7 +1259,7 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   const bool raw = h->cfg.raw_filter_coeff != 1.0;
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-      { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
+      if (!exp_env("ISCA_X_NO_FINISH")) { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }      // (experiment: what the step would take without this kernel; wrong results)
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
     } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
