@@ -131,7 +131,7 @@ def kernel_rooflines(kt, I, J, M1, N, L, nlf_inv=None):
         # in: u, v, T, q of the previous level, T, q of the current one (the next step's convection), p_full, p_half, the two height increments, the
         # (conv + cond) rates of this step (12); out: the two heights, 4 tendencies, the next step's (conv + cond) rates (8)
         g = 20.0 * field_bytes / (kt["moist_physics"] * 1e-3) / 1e9
-        kern["moist_physics"] = {"bound": "hbm (two dependent chains per 64 columns -- this step's radiation / diffusion and the next step's convection --, one wavefront per SIMD: latency, DESIGN.md 9)",
+        kern["moist_physics"] = {"bound": "hbm (two dependent chains per 64 columns -- this step's radiation / diffusion and the next step's convection --, one wavefront per SIMD: latency, HISTORY.md 9)",
                                  "ms": kt["moist_physics"], "achieved_GBs": g, "frac": g / HBM_PEAK_GBS, "algorithmic_field_passes": 20}
     return kern
 

@@ -2,7 +2,7 @@
 ! device's Frierson column chain.  In the reference atmosphere_init calls idealized_moist_phys_init (atmosphere.F90:246-262), which
 ! reads idealized_moist_phys_nml and initialises two_stream_gray_rad, mixed_layer, qe_moist_convection, lscale_cond, damping_driver,
 ! vert_turb_driver / diffusivity, surface_flux / monin_obukhov -- each reading its own namelist -- and atmosphere(Time) calls
-! idealized_moist_phys every step (:313-319).  Here the chain runs INSIDE the device step (isca_dyn_config%physics = 1, DESIGN.md 9), so
+! idealized_moist_phys every step (:313-319).  Here the chain runs INSIDE the device step (isca_dyn_config%physics = 1, HISTORY.md 9), so
 ! what is left on the host is the namelists: idealized_moist_phys_init reads every group the chain reads, with the reference's variable
 ! names and MODULE defaults, refuses the option values the device package does not implement ("... is not a supported value", the wording
 ! of isca_amd/atmosphere.py:_moist_config), and leaves the values in isca_dropin_mod%dropin_moist for spectral_dynamics_init.

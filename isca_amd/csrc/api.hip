@@ -126,7 +126,15 @@ extern "C" int isca_dyn_config_default(isca_dyn_config *c) {
 static const double PEND_ROWS[12] = {1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0, 0.0};    // Dev::pend with nothing pending
 // Lazy fixers: apply what is pending on the two time levels in place, so that the stored tg, psg, tr, tr_atm are the model's values
 // (host reads and writes of the state, restart files, diagnostics, the transforms of complete_update / refresh_derived).
+// the scalars of the last step's fixers, if their computation was left to the next column kernel (core.h: fin_deferred), now
+static void flush_finish(isca_dyn *h) {
+  if (!h->fin_deferred) return;
+  h->fin_deferred = false;
+  StepScalars sc{}; sc.prev = h->fin_prev; sc.cur = h->fin_cur; sc.fut = h->fin_fut;
+  launch_fixer_finish(*h, sc, h->stream);
+}
 static void materialize(isca_dyn *h) {
+  flush_finish(h);
   const bool any = h->thermo_pending[0] || h->thermo_pending[1] || h->tr_state[0] != isca::TR_MAT || h->tr_state[1] != isca::TR_MAT;
   if (!any) return;
   if (h->in_step) fail("the model state cannot be read or written in the middle of a step driven phase by phase");
@@ -333,11 +341,16 @@ static void sync_and_check_valid_range(isca_dyn *h) {
     HIP_CHECK(hipHostMalloc((void **)&h->host_red, 64 * sizeof(double)));
     h->host_red[32] = INFINITY; h->host_red[33] = -INFINITY;
   }
-  HIP_CHECK(hipMemcpyAsync(h->host_red, h->d.red, 22 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  flush_finish(h);                                     // (the check below looks at the fixers' scalars)
+  HIP_CHECK(hipMemcpyAsync(h->host_red, h->d.red, 26 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(hipMemcpyAsync(h->d.red + 20, h->host_red + 32, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->comm) { h->comm->synchronize(h->stream); h->comm->check(); }      // (RCCL: polls the stream, the communicator's error state and a deadline, comm.h)
   else HIP_CHECK(hipStreamSynchronize(h->stream));
   const double *red = h->host_red;
+  if (red[25] != 0.0) {         // (kernels.hip k_column_sig: a block waited 0.5 ms for block 0's scalars -- the dispatcher did not start block 0 first)
+    HIP_CHECK(hipMemsetAsync(h->d.red + 25, 0, sizeof(double), h->stream));
+    fail("column kernel: the deferred fixer scalars of the step before never arrived (block 0 did not run first); results since the last synchronisation are invalid");
+  }
   const double tmin = red[20], tmax = red[21];
   const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
   const bool bad = stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17]));
@@ -543,6 +556,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
     d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
+    d.fin_flag = dalloc<unsigned>(h, 4); d.fin_val = dalloc<double>(h, 4);
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
@@ -701,7 +715,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? 0 : 1) + (vadv_ext ? 1 : 0);    // eager fixers: sums, totals, apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? (g.P == 1 && column_takes_deferred_finish(*h) ? -1 : 0) : 1) + (vadv_ext ? 1 : 0);    // lazy fixers: sums + finish (the finish in the next column kernel's block 0 on the plain one-rank path); eager: sums, totals, apply
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -873,6 +887,7 @@ static void reset_pending(isca_dyn *h) {       // a state written from scratch h
   h->thermo_pending[0] = h->thermo_pending[1] = false;
   h->tr_state[0] = h->tr_state[1] = isca::TR_MAT;
   h->in_step = false;
+  h->fin_deferred = false;
   moist_invalidate(h);
 }
 static void cold_start_single(isca_dyn *h) {
@@ -989,6 +1004,7 @@ extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_leve
   const Geom &g = h->g;
   const std::string nm(name);
   const size_t ng2 = (size_t)g.Jl * g.I;
+  flush_finish(h);                                  // (the (0,0) coefficients of ts, ln_ps wait for it too, not only the lazy grid fields)
   if (is_lazy_field(nm)) materialize(h);
   if (nm == "p_full" || nm == "p_half" || nm == "z_full" || nm == "z_half") {
     // compute_pressures_and_heights of the requested level (atmosphere.F90:229-241, 331-338)
@@ -1015,6 +1031,7 @@ extern "C" int isca_dyn_get_state(isca_dyn_t *h, const char *name, int time_leve
 extern "C" int isca_dyn_set_state(isca_dyn_t *h, const char *name, int time_level, const double *host, size_t count) {
   API_BEGIN
   if (!h || !name || !host) fail("null argument");
+  flush_finish(h);
   if (is_lazy_field(name)) materialize(h);
   size_t cnt; int kind;
   double *p = state_ptr(h, name, time_level, cnt, kind);
@@ -1115,6 +1132,7 @@ static void timed_tracer(isca_dyn *h, const StepScalars &sc, hipStream_t st, int
   if (part != 0) { Timed t(h, "tracer_vert", st); launch_tracer(*h, sc, st, 1); }
 }
 static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tendencies + longitude FFT
+  if (h->fin_deferred && (!column_takes_deferred_finish(*h) || h->tracer_early)) flush_finish(h);      // (a kernel in front of the column kernel reads the scalars: the moist package, hs_forcing on its own)
   h->in_step = true;
   if (h->cfg.physics == 1) {
     // the previous level's pressures are what the step before computed for its current level (grid p_s of a level is final once its
@@ -1147,6 +1165,7 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
   }
   if (hs_forcing_separate(*h)) { Timed t(h, "hs_forcing"); launch_hs_forcing_step(*h, sc, h->stream); }       // (an hs_forcing_nml option the fused kernel does not carry)
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
+  h->fin_deferred = false;                              // (its block 0 has taken the deferred finish, if there was one)
   if (h->cfg.vert_advect_uv != 0 || h->cfg.vert_advect_t != 0) { Timed t(h, "vert_advection"); launch_vert_advection_schemes(*h, sc, h->stream); }
   if (h->tracer_on) {
     if (h->g.P > 1) {
@@ -1259,7 +1278,11 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   const bool raw = h->cfg.raw_filter_coeff != 1.0;
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-      if (!exp_env("ISCA_X_NO_FINISH")) { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }      // (experiment: what the step would take without this kernel; wrong results)
+      // one rank, the plain column kernel next: its block 0 finishes (ColumnArgs::fin) -- no launch here; otherwise (behind the all-reduce of a sharded
+      // step; diagnostics that read the level right away) the one-block kernel
+      if (h->g.P == 1 && column_takes_deferred_finish(*h) && !h->diag_mask && !exp_env("ISCA_NO_DEFERRED_FINISH")) {
+        h->fin_deferred = true; h->fin_prev = sc.prev; h->fin_cur = sc.cur; h->fin_fut = sc.fut; h->fin_seq = h->fin_seq == 0xffffffffu ? 1u : h->fin_seq + 1u;
+      } else { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }
     } else { Timed t(h, "fixer_apply"); launch_fixer_apply(*h, sc, h->stream); }
@@ -1723,6 +1746,7 @@ extern "C" int isca_dyn_get_table(isca_dyn_t *h, const char *name, double *host,
     v = &tmp;
   } else if (nm == "fixer") {
     tmp.resize(32);
+    flush_finish(h);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipMemcpy(tmp.data(), h->d.red, 32 * sizeof(double), hipMemcpyDeviceToHost));
     v = &tmp;

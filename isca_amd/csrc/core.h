@@ -121,7 +121,8 @@ struct Dev {
   // raw_filter_coeff /= 1 only: prev - 2 cur of the spectral fields and of the grid tracer (leapfrog_2level_A's part_filt_*)
   double *part_vor = nullptr, *part_div = nullptr, *part_t = nullptr, *part_lp = nullptr, *tr_part = nullptr;
   double *partials;                                 // block partial sums
-  double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18]
+  double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18] / [20..21] extremes of T / [25] a column block gave up waiting for the deferred finish
+  unsigned *fin_flag; double *fin_val;              // the deferred finish's sequence word and published scalars
   double *scratch_g[4], *scratch_s[4];              // API transforms
   double *lh_lon = nullptr, *lh_lat_l = nullptr;     // hs_forcing's local_heating_option = 'Isidoro': srfamp x the longitude factor [I], the latitude factor [Jl]
   // ---- moist physics package (physics = 1)
@@ -204,6 +205,12 @@ struct isca_dyn {
   bool lazy_fix = false;
   int tr_state[2] = {0, 0};         // TracerState of the tracer buffers of time level 0 / 1
   bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
+  // The finish of the last step's fixers (the three scalars, the (0,0) patch) is DEFERRED to block 0 of the next column kernel (kernels.hip ColumnArgs::fin)
+  // on the plain one-rank path; anything else that needs the scalars first -- the host reading state, diagnostics, a physics package in front of the
+  // column kernel -- runs k_fixer_finish instead (api.hip: flush_finish).  fin_prev / _cur / _fut: that step's time levels; fin_seq: the word block 0 publishes.
+  bool fin_deferred = false;
+  int fin_prev = 0, fin_cur = 0, fin_fut = 0;
+  unsigned fin_seq = 0;
   bool in_step = false;             // between phase 0 and phase 3 of a step driven phase by phase
   double *host_red = nullptr;       // pinned: the fixer scalars / temperature extremes read back at a synchronisation point
   isca_history *hist = nullptr;     // history files being written (isca_dyn_diag_open): the step loops call isca_history_after_step

@@ -5,7 +5,7 @@
 #include <cstdlib>
 // Switches of measured-and-rejected variants (HISTORY.md has their numbers) exist only in a build with -DISCA_EXPERIMENTS (tools/build_variant.sh);
 // the product looks none of them up and instantiates none of their kernels.  What the product does read from the environment is listed in
-// DESIGN.md 5 "Environment": the communicator's configuration and eight test hooks that force a path a configuration would select by itself.
+// DESIGN.md 7 "Environment": the communicator's configuration and eight test hooks that force a path a configuration would select by itself.
 #ifdef ISCA_EXPERIMENTS
 inline const char *exp_env(const char *name) { return getenv(name); }
 #else
@@ -103,6 +103,7 @@ void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, 
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 bool hs_forcing_separate(const isca_dyn &h);       // an hs_forcing_nml option the fused column kernel does not carry: k_hs_forcing_step in front of it
 void launch_hs_forcing_step(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+bool column_takes_deferred_finish(const isca_dyn &h);    // the step's column kernel is the plain pure-sigma one, whose block 0 can finish the step before's fixers
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s);  // R2 with lazy fixers: reduce + scalars, left pending on the new level

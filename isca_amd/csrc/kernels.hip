@@ -1495,6 +1495,140 @@ void launch_spec_synthesis_inputs(const isca_dyn &h, int tl, hipStream_t s) {
 }
 
 // =====================================================================================================
+// Fixer core (used by the fixer kernels further down AND by the column kernel, whose block 0 finishes the step before's fixers)
+// =====================================================================================================
+// block = 64 columns x NW wavefronts (level chunks), like the column kernel
+constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
+constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
+struct FixerArgs {
+  double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
+  const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
+  int nb, reduce_here;
+  double *pend_fut;             // Dev::pend row of the new level
+  int patch;               // k_fixer_finish: patch the (0,0) spectral coefficients (not on its second run of a step, after the water sums came in)
+  double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
+  double *psg, *tg;
+  double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
+  const int *kmask;
+  int ml0;                 // local slot of m = 0, or -1
+  double sumw_nlon;        // global_sum_of_wts * num_lon
+  double robert;
+  int do_mass, do_energy, do_water;
+  double raw;                 // raw_filter_coeff; tr_part: prev - 2 cur of the tracer (RAW filter), null when raw = 1
+  const double *tr_part;
+};
+// compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums
+__device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs &a, double &factor, double &tcorr, double &wfac) {
+#pragma clang fp contract(off)      // k_fixer_apply and k_fixer_finish must get the same bits from the same sums
+  factor = 1.0; tcorr = 0.0; wfac = 1.0;
+  const double mean_ps_prev = r_[0] / a.sumw_nlon;
+  const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
+  if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
+  if (a.do_energy) {
+    const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
+    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
+  }
+  if (a.do_water && a.tr_fut) {
+    const double nrm = 1.0 / a.sumw_nlon / GRAV;
+    const double water_prev = r_[5] * nrm;
+    const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
+    const double corr = (r_[8] + factor * r_[9]) * nrm;
+    const double notc = water_tmp - corr;
+    if (water_tmp > 0.) {
+      wfac = water_prev / water_tmp;
+      wfac = wfac * (1. + notc / corr) - notc / corr;
+    }
+  }
+}
+// the (0,0) coefficients of ln ps and T follow the grid corrections (:1231, :1241), also on the Robert-filtered `current` level (:1470-1473)
+// (two halves: the coefficients are requested before the scalars are known, so that only their stores follow the reduction)
+struct SpecPatch { double lf, lc, tf, tc; };
+__device__ __forceinline__ SpecPatch fixer_patch_load(const Geom &g, const FixerArgs &a) {
+  SpecPatch p = {0., 0., 0., 0.};
+  if (a.ml0 < 0) return p;
+  const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
+  const int k = min((int)threadIdx.x, g.L - 1);
+  p.lf = a.lnps_fut[mn].x; p.lc = a.lnps_cur[mn].x; p.tf = a.ts_fut[mn * g.L + k].x; p.tc = a.ts_cur[mn * g.L + k].x;
+  return p;
+}
+__device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, const SpecPatch &p, double factor, double tcorr) {
+  if (a.ml0 < 0) return;
+  const size_t mn = (size_t)a.ml0 * g.N1;
+  const double s2 = sqrt(2.);
+  const int k = threadIdx.x;
+  if (k == 0 && a.do_mass) {
+    const double dl = s2 * log(factor);
+    a.lnps_fut[mn].x = p.lf + dl;
+    a.lnps_cur[mn].x = p.lc + a.robert * a.raw * dl;
+  }
+  if (k < g.L && a.do_energy) {
+    const double dtc = s2 * tcorr;
+    a.ts_fut[mn * g.L + k].x = p.tf + dtc;
+    a.ts_cur[mn * g.L + k].x = p.tc + a.robert * a.raw * dtc;
+  }
+}
+// Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from k_fixer_sums) by ONE
+// block, in an order that does not depend on the block's size: 1024 VIRTUAL threads -- value c = v & 15 (0..1 the column kernel's sums, 2..9
+// k_fixer_sums', 10 min, 11 max), group g = v >> 4 -- each fold the sets g, g + 64, ... of their value in ascending order; the 64 groups of a value are
+// then folded in ascending order by one thread.  A real thread takes the virtual threads r, r + blockDim, ...: the same bits from a block of 256, 512
+// or 1024 threads -- k_fixer_reduce, k_fixer_finish, and block 0 of the next step's column kernel (the deferred finish, below).
+__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                             double (*sh)[16], double *tot, double &tmin, double &tmax) {
+  const int NT = blockDim.x, r = threadIdx.x, c = r & 15, cc = min(c, NRED + 1);
+  const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
+  const int st = cc < 2 ? 2 : NPART;
+  auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
+  constexpr int U = 8;                               // loads in flight per virtual thread
+  for (int vt = r; vt < 1024; vt += NT) {
+    const int g = vt >> 4;
+    double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
+    for (int i0 = g; i0 < nb; i0 += U * 64) {
+      double x[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) x[q] = p0[(size_t)st * min(i0 + 64 * q, nb - 1)];
+#pragma unroll
+      for (int q = 0; q < U; ++q)
+        if (i0 + 64 * q < nb) acc = fold(acc, x[q]);
+    }
+    sh[g][c] = acc;
+  }
+  __syncthreads();
+  if (r < NRED + 2) {                                 // one thread per value folds the 64 groups in ascending order (c = r here)
+    double x = sh[0][r];
+    for (int g = 1; g < 64; ++g) x = fold(x, sh[g][r]);
+    sh[0][r] = x;                                     // (thread r is the only reader of column r)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NRED; ++k) tot[k] = sh[0][k];
+  tmin = sh[0][NRED]; tmax = sh[0][NRED + 1];
+}
+// Lazy fixers: compute_corrections' three scalars, left PENDING on the new time level (pend_fut[0..2]) instead of applied to the grid fields -- every
+// later reader of that level applies them (k_column, the tracer kernels; k_fixer_materialize for the host) --, and the (0,0) spectral patch.  One block
+// (>= num_levels threads).  reduce_here: fold the block partials first (one rank); otherwise red[0..9] hold the all-reduced totals.  Returns the
+// scalars to every thread.
+__device__ __forceinline__ void fixer_finish_body(const Geom &g, const FixerArgs &a, double (*sh)[16], double &factor, double &tcorr, double &wfac) {
+  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
+  const SpecPatch sp = a.patch ? fixer_patch_load(g, a) : SpecPatch{0., 0., 0., 0.};
+  const double mn_old = a.red[20], mx_old = a.red[21];
+  if (a.reduce_here) fixer_totals(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
+  else {
+#pragma unroll
+    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
+  }
+  fixer_scalars(r_, a, factor, tcorr, wfac);
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
+    a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
+    if (a.reduce_here) { a.red[20] = fmin(mn_old, tmn); a.red[21] = fmax(mx_old, tmx); }
+    a.pend_fut[PEND_FACTOR] = factor; a.pend_fut[PEND_TCORR] = tcorr; a.pend_fut[PEND_WFAC] = wfac;
+  }
+  if (a.patch) fixer_patch_spectral(g, a, sp, factor, tcorr);
+}
+
+static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc);
+
+// =====================================================================================================
 // Grid-point column kernel: hs_forcing (hs_forcing.F90:148-272) at the PREVIOUS level with CURRENT
 // pressures (atmosphere.F90:304-311), pressure_variables (press_and_geopot.F90:152-221), four_in_one
 // (spectral_dynamics.F90:1038-1112), vert_advection second-centred/advective (vert_advection.F90:185-193,
@@ -1522,6 +1656,13 @@ struct ColumnArgs {
   const double *sig;                       // [L][16] per-level constants on pure sigma levels (k_column_sig; api.hip: col_sig); hs_sin: [Jl] sin(lat)
   const double *hs_sin;
   double lnP00;                            // log(P00)
+  // The deferred finish of the step BEFORE (k_column_sig; api.hip: fin_deferred).  The fixers' three scalars hang on ten global sums, so they used to be a
+  // one-block kernel between k_fixer_sums and this one: 7.6 us + two kernel boundaries on the step's critical path (9-10 us of a 0.166 ms step, measured
+  // by leaving it out).  Now block 0 of this kernel computes them (fixer_finish_body: same code, same bits), publishes factor and temperature correction
+  // with agent-scope stores + a sequence word, and the other blocks -- whose field loads are in flight meanwhile -- wait for that word before their
+  // first arithmetic.  fin_seq = 0: nothing deferred, the scalars are read from pend_c as before.
+  unsigned fin_seq; unsigned *fin_flag; double *fin_val;      // fin_val[0..1]: factor, tcorr as published by block 0; red[25]: set when a block gave up waiting
+  FixerArgs fin;
 };
 
 __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double ps, double p_full, double up, double vp,
@@ -1798,11 +1939,25 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
   const int k0 = w * CH, nk = min(CH, L - k0);
   kdouble *sg = (kdouble *)a.sig + 16 * k0;              // constant address space: scalar loads wherever they are needed, also behind the stores
-  const double tc_c = a.pend_c[PEND_TCORR], tc_p = a.pend_p[PEND_TCORR];
-  const double ps = mul_nc(a.ps[c2], a.pend_c[PEND_FACTOR]), psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
+  __shared__ double fin_sh[64][16];
+  double fac_c = 1.0, tc_c = 0.0;
+  if (a.fin_seq && blockIdx.x == 0) {                     // the deferred finish of the step before: this block computes and publishes
+    double wf;
+    fixer_finish_body(g, a.fin, fin_sh, fac_c, tc_c, wf);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(a.fin_val + 0, fac_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.fin_val + 1, tc_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0): the two values are written through before the word that announces them
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      __hip_atomic_store(a.fin_flag, a.fin_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  const double tc_p = a.pend_p[PEND_TCORR];
+  double ps = a.ps[c2];
+  const double psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
   const int kmw_old = a.kmask_rd[c2];
   const double dxl = a.dxlp[c2], dyl = a.dylp[c2];
-  const double dx_ps = ps * dxl, dy_ps = ps * dyl;
   constexpr int ktop = 1;                                   // pk(1) = 0: the hydrostatic sum starts at the second level (press_and_geopot.F90:341-349)
   const double wts_j = a.wts[jl], cosm = a.cosm[jl], cor = a.coriolis[jl], sin_lat = a.hs_sin[jl];
   double u[CH], v[CH], t[CH], dm[CH];
@@ -1814,14 +1969,37 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   for (int i = 0; i < CH; ++i) {
     const int k = k0 + (i < nk ? i : 0);
     const size_t q = c2 + (size_t)k * lev;
-    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q] + tc_c;
+    u[i] = a.u[q]; v[i] = a.v[q]; t[i] = a.t[q];
     if (VIRT) tvv[VIRT ? i : 0] = a.tv[q];
     if (EARLY) { upv[i] = a.up[q]; vpv[i] = a.vp[q]; tpv[i] = a.tp[q] + tc_p; vov[i] = a.vor[q]; dxv[i] = a.dxT[q]; dyv[i] = a.dyT[q]; }
     dm[i] = a.div[q];
   }
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
-  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q] + tc_c; }
-  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q] + tc_c; }
+  if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
+  if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
+  // the current level's pending scalars: from pend_c, or -- deferred finish -- from block 0 of this launch (the loads above are in flight meanwhile)
+  if (!a.fin_seq) { fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR]; }
+  else if (blockIdx.x != 0) {
+    double f = 1.0, tcv = 0.0;
+    int ok = 1;
+    if (tid == 0) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(a.fin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fin_seq) {
+        if (wall_clock64() - t0 > 50000) { ok = 0; break; }                // 0.5 ms of the 100 MHz counter: block 0 never ran in front of this one
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (ok) {
+        f = __hip_atomic_load(a.fin_val + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tcv = __hip_atomic_load(a.fin_val + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else a.fin.red[25] = 1.0;                                           // raised at the host's next synchronisation (api.hip)
+    }
+    fac_c = __shfl(f, 0, 64); tc_c = __shfl(tcv, 0, 64);
+  }
+  ps = mul_nc(ps, fac_c);
+  const double dx_ps = ps * dxl, dy_ps = ps * dyl;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) t[i] += tc_c;
+  tm += tc_c; tn += tc_c;
   // what needs only p_s, while the fields are on their way
   const double rps = 1. / ps;
   double lpn0 = 0.0, pkap = 0.0;
@@ -1960,6 +2138,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
 
 #undef TV
 
+bool column_takes_deferred_finish(const isca_dyn &h) {
+  return h.d.col_sig && h.cfg.vert_difference_option != 1 && !virtual_t_on(h) && h.cfg.physics == 0 && !hs_forcing_separate(h) && h.lazy_fix;
+}
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }
 
 // virtual_t = T (1 + (rvgas/rdgas - 1) q) (spectral_dynamics.F90:436-438, 858; press_and_geopot.F90:248, 342)
@@ -2001,6 +2182,11 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const bool ext = h.cfg.physics != 0 || hs_forcing_separate(h);      // the physics tendencies come from arrays (a package's, or k_hs_forcing_step's)
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
   a.sig = d.col_sig; a.hs_sin = d.hs_sin_l; a.lnP00 = std::log(h.cfg.P00);
+  a.fin_seq = 0; a.fin_flag = d.fin_flag; a.fin_val = d.fin_val;
+  if (h.fin_deferred) {                         // (api.hip has flushed it unless this launch is the kernel that takes it)
+    StepScalars fs{}; fs.prev = h.fin_prev; fs.cur = h.fin_cur; fs.fut = h.fin_fut;
+    a.fin = fixer_args(h, fs); a.fin_seq = h.fin_seq;
+  } else a.fin = FixerArgs{};
   if (a.sig && h.cfg.vert_difference_option != 1) {             // pure sigma levels: the per-level logarithms are constants of the coordinate
     // Two blocks per CU (k_column_sig<.., TWO>: <= 128 registers, the six below-the-barrier fields requested there) for the plain Held-Suarez
     // instantiation with chunks of <= 5 levels, when the grid has at least two blocks per CU to interleave: T85L40 on one rank 40.0 -> 37.0 us
@@ -3286,9 +3472,7 @@ void launch_tracer_source_sink(const isca_dyn &h, const double *ps, const double
 //   red[2..4]  local sums of the new state:     w*ps(fut), w*sum_k e_k dpk_k, w*sum_k e_k dbk_k ps(fut)
 //   red[16] mass_correction_factor, red[17] temperature_correction, red[18] water_correction_factor
 // =====================================================================================================
-// block = 64 columns x NW wavefronts (level chunks), like the column kernel
-constexpr int NRED = 10;   // 2 sums of the column kernel + 8 of k_fixer_sums
-constexpr int NPART = 10;  // per block of k_fixer_sums: the 8 sums + min and max of the new temperatures
+// block = 64 columns x NW wavefronts (level chunks), like the column kernel (NRED, NPART, FixerArgs, the totals and the scalars: in front of the column kernel)
 __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__restrict__ u, const double *__restrict__ v,
                                                     const double *__restrict__ t, const double *__restrict__ psg,
                                                     const double *__restrict__ dpk, const double *__restrict__ dbk,
@@ -3357,121 +3541,25 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
     p[3] = t0; p[4] = t1; p[5] = t2; p[6] = t3; p[7] = t4;
   }
 }
-// Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from
-// k_fixer_sums) by ONE block of NT threads, in a fixed order.  Lane layout: value c = t & 15 (0..1 the column kernel's sums, 2..9
-// k_fixer_sums', 10 min, 11 max), group g = t >> 4: a thread folds the sets g, g + NT/16, ... of its value with eight loads in flight,
-// the four groups of a wavefront meet in two shuffles, the wavefronts in LDS.  (The first version had every thread fold all twelve
-// values of its sets and needed 72 cross-lane steps per wavefront: 5-7 us, the larger part of k_fixer_finish.)
-template <int NT>
-__device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                             double (*sh)[16], double *tot, double &tmin, double &tmax) {
-  constexpr int NG = NT / 16, NWV = NT / 64;
-  const int t = threadIdx.x, c = t & 15, g = t >> 4, cc = min(c, NRED + 1);
-  const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
-  const int st = cc < 2 ? 2 : NPART;
-  auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
-  double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
-  constexpr int U = 16;                              // loads in flight per thread: one round trip up to 16 NT / 16 = NT sets
-  for (int i0 = g; i0 < nb; i0 += U * NG) {
-    double v[U];
-#pragma unroll
-    for (int r = 0; r < U; ++r) v[r] = p0[(size_t)st * min(i0 + NG * r, nb - 1)];
-#pragma unroll
-    for (int r = 0; r < U; ++r)
-      if (i0 + NG * r < nb) acc = fold(acc, v[r]);
-  }
-  acc = fold(acc, __shfl_xor(acc, 16, 64));
-  acc = fold(acc, __shfl_xor(acc, 32, 64));
-  if ((t & 63) < 16) sh[t >> 6][c] = acc;
-  __syncthreads();
-  if (t < NRED + 2) {                                 // one thread per value folds the wavefronts' results, in wavefront order
-    double x = sh[0][t];
-    for (int w = 1; w < NWV; ++w) x = fold(x, sh[w][t]);
-    sh[0][t] = x;                                     // (thread t is the only reader of column t)
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NRED; ++k) tot[k] = sh[0][k];
-  tmin = sh[0][NRED]; tmax = sh[0][NRED + 1];
-}
 // red[0..9] <- totals: for the all-reduce between the phases when world_size > 1, and for k_fixer_apply (the eager path)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                                     double *__restrict__ red) {
-  __shared__ double sh[NT / 64][16];
+__global__ __launch_bounds__(1024) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                       double *__restrict__ red) {
+  __shared__ double sh[64][16];
   double tot[NRED], tmn, tmx;
-  fixer_totals<NT>(pprev, pfut, nb, sh, tot, tmn, tmx);
+  fixer_totals(pprev, pfut, nb, sh, tot, tmn, tmx);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int c = 0; c < NRED; ++c) red[c] = tot[c];
     red[20] = fmin(red[20], tmn); red[21] = fmax(red[21], tmx);      // running extremes of this rank's band
   }
 }
-struct FixerArgs {
-  double *red;                  // [0..9] global sums (all-reduced by the host when world_size > 1), [16..18] scalars out
-  const double *pprev, *pfut;   // block partials: 2 per block (column kernel), 8 per block (k_fixer_sums)
-  int nb, reduce_here;
-  int patch;               // k_fixer_finish: patch the (0,0) spectral coefficients (not on its second run of a step, after the water sums came in)
-  double2 *lnps_fut, *lnps_cur, *ts_fut, *ts_cur;
-  double *psg, *tg;
-  double *tr_fut, *tr_cur, *tratm_fut;   // grid tracer (null when none)
-  const int *kmask;
-  int ml0;                 // local slot of m = 0, or -1
-  double sumw_nlon;        // global_sum_of_wts * num_lon
-  double robert;
-  int do_mass, do_energy, do_water;
-  double raw;                 // raw_filter_coeff; tr_part: prev - 2 cur of the tracer (RAW filter), null when raw = 1
-  const double *tr_part;
-};
-// compute_corrections (spectral_dynamics.F90:1213-1283, with mj's water-correction limit) from the ten global sums
-__device__ __forceinline__ void fixer_scalars(const double *r_, const FixerArgs &a, double &factor, double &tcorr, double &wfac) {
-#pragma clang fp contract(off)      // k_fixer_apply and k_fixer_finish must get the same bits from the same sums
-  factor = 1.0; tcorr = 0.0; wfac = 1.0;
-  const double mean_ps_prev = r_[0] / a.sumw_nlon;
-  const double mean_en_prev = r_[1] / a.sumw_nlon / GRAV;
-  if (a.do_mass) factor = mean_ps_prev / (r_[2] / a.sumw_nlon);
-  if (a.do_energy) {
-    const double mean_en_tmp = (r_[3] + factor * r_[4]) / a.sumw_nlon / GRAV;
-    tcorr = GRAV * (mean_en_prev - mean_en_tmp) / (CP_AIR * mean_ps_prev);
-  }
-  if (a.do_water && a.tr_fut) {
-    const double nrm = 1.0 / a.sumw_nlon / GRAV;
-    const double water_prev = r_[5] * nrm;
-    const double water_tmp = (r_[6] + factor * r_[7]) * nrm;
-    const double corr = (r_[8] + factor * r_[9]) * nrm;
-    const double notc = water_tmp - corr;
-    if (water_tmp > 0.) {
-      wfac = water_prev / water_tmp;
-      wfac = wfac * (1. + notc / corr) - notc / corr;
-    }
-  }
-}
-// the (0,0) coefficients of ln ps and T follow the grid corrections (:1231, :1241), also on the Robert-filtered `current` level (:1470-1473)
-// (two halves: the coefficients are requested before the scalars are known, so that only their stores follow the reduction)
-struct SpecPatch { double lf, lc, tf, tc; };
-__device__ __forceinline__ SpecPatch fixer_patch_load(const Geom &g, const FixerArgs &a) {
-  SpecPatch p = {0., 0., 0., 0.};
-  if (a.ml0 < 0) return p;
-  const size_t mn = (size_t)a.ml0 * g.N1;     // (m=0, n=0)
-  const int k = min((int)threadIdx.x, g.L - 1);
-  p.lf = a.lnps_fut[mn].x; p.lc = a.lnps_cur[mn].x; p.tf = a.ts_fut[mn * g.L + k].x; p.tc = a.ts_cur[mn * g.L + k].x;
-  return p;
-}
-__device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerArgs &a, const SpecPatch &p, double factor, double tcorr) {
-  if (a.ml0 < 0) return;
-  const size_t mn = (size_t)a.ml0 * g.N1;
-  const double s2 = sqrt(2.);
-  const int k = threadIdx.x;
-  if (k == 0 && a.do_mass) {
-    const double dl = s2 * log(factor);
-    a.lnps_fut[mn].x = p.lf + dl;
-    a.lnps_cur[mn].x = p.lc + a.robert * a.raw * dl;
-  }
-  if (k < g.L && a.do_energy) {
-    const double dtc = s2 * tcorr;
-    a.ts_fut[mn * g.L + k].x = p.tf + dtc;
-    a.ts_cur[mn * g.L + k].x = p.tc + a.robert * a.raw * dtc;
-  }
+// fixer_finish_body as a kernel: behind the all-reduce of a sharded step, and wherever the scalars are needed before the next column kernel runs
+// (the host reads state, diagnostics, a physics package in front of the column kernel).  On the plain one-rank path block 0 of the NEXT step's
+// column kernel does this instead (ColumnArgs::fin).
+__global__ __launch_bounds__(1024) void k_fixer_finish(Geom g, FixerArgs a) {
+  __shared__ double sh[64][16];
+  double factor, tcorr, wfac;
+  fixer_finish_body(g, a, sh, factor, tcorr, wfac);
 }
 // Every block sums the block partials itself (same fixed order everywhere; world_size > 1: reads the all-reduced
 // red[0..9]), derives the fixer scalars and applies them to its slice of psg / tg / tracer; block 0 also patches the (0,0) spectral coefficients, including the Robert-filtered `current` level (:1231,1241,1470-1473).
@@ -3527,30 +3615,6 @@ __global__ __launch_bounds__(256) void k_fixer_apply(Geom g, FixerArgs a) {
     if (threadIdx.x == 0) { a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac; }
     fixer_patch_spectral(g, a, sp, factor, tcorr);
   }
-}
-// Lazy fixers: the same scalars, but nothing is applied to the grid fields -- they are left PENDING on the new time level
-// (pend[4 * fut + 0..2]) and every later reader of that level applies them (k_column, the tracer kernels; k_fixer_materialize
-// for the host).  One block; the (0,0) spectral coefficients are patched here as in k_fixer_apply.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_fixer_finish(Geom g, FixerArgs a, double *__restrict__ pend_fut) {
-  __shared__ double sh[NT / 64][16];
-  double r_[NRED], tmn = INFINITY, tmx = -INFINITY;
-  const SpecPatch sp = a.patch ? fixer_patch_load(g, a) : SpecPatch{0., 0., 0., 0.};
-  const double mn_old = a.red[20], mx_old = a.red[21];
-  if (a.reduce_here) fixer_totals<NT>(a.pprev, a.pfut, a.nb, sh, r_, tmn, tmx);
-  else {
-#pragma unroll
-    for (int c = 0; c < NRED; ++c) r_[c] = a.red[c];
-  }
-  double factor, tcorr, wfac;
-  fixer_scalars(r_, a, factor, tcorr, wfac);
-  if (threadIdx.x == 0) {
-    for (int c = 0; c < NRED; ++c) a.red[c] = r_[c];
-    a.red[16] = factor; a.red[17] = tcorr; a.red[18] = wfac;
-    if (a.reduce_here) { a.red[20] = fmin(mn_old, tmn); a.red[21] = fmax(mx_old, tmx); }
-    pend_fut[PEND_FACTOR] = factor; pend_fut[PEND_TCORR] = tcorr; pend_fut[PEND_WFAC] = wfac;
-  }
-  if (a.patch) fixer_patch_spectral(g, a, sp, factor, tcorr);
 }
 // What is pending on the two time levels, applied in place (before the host reads or writes state, restart files, diagnostics):
 // afterwards tg, psg, tr and tr_atm of both levels hold what the eager k_fixer_apply would have left.
@@ -3611,8 +3675,7 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
   // on one rank k_fixer_finish folds them itself
   if (g.P > 1 || !h.lazy_fix) {
-    if (nb > 256) hipLaunchKernelGGL(k_fixer_reduce<1024>, dim3(1), dim3(1024), 0, s, d.partials, p2, nb, d.red);
-    else hipLaunchKernelGGL(k_fixer_reduce<256>, dim3(1), dim3(256), 0, s, d.partials, p2, nb, d.red);
+    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(nb > 256 ? 1024 : 256), 0, s, d.partials, p2, nb, d.red);
   }
 }
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
@@ -3620,6 +3683,7 @@ static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
   FixerArgs a;
   const int nb = (int)column_partials_count(h);
   a.red = h.d.red; a.pprev = h.d.partials; a.pfut = h.d.partials + 2 * (size_t)nb; a.nb = nb;
+  a.pend_fut = h.d.pend + 4 * sc.fut;
   a.reduce_here = (g.P == 1 && h.lazy_fix);      // k_fixer_finish folds the partials itself; otherwise k_fixer_reduce (+ the all-reduce) left red[0..9]
   a.lnps_fut = (double2 *)h.d.lnps[sc.fut]; a.lnps_cur = (double2 *)h.d.lnps[sc.cur];
   a.ts_fut = (double2 *)h.d.ts[sc.fut]; a.ts_cur = (double2 *)h.d.ts[sc.cur];
@@ -3643,9 +3707,8 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
   hipLaunchKernelGGL(k_fixer_apply, dim3(nblk), dim3(256), 0, s, g, a);
 }
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
-  FixerArgs a = fixer_args(h, sc);
-  if (a.nb > 256) hipLaunchKernelGGL(k_fixer_finish<1024>, dim3(1), dim3(1024), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
-  else hipLaunchKernelGGL(k_fixer_finish<256>, dim3(1), dim3(256), 0, s, h.g, a, h.d.pend + 4 * sc.fut);
+  const FixerArgs a = fixer_args(h, sc);
+  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(a.nb > 256 ? 1024 : 256), 0, s, h.g, a);
 }
 // tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s) {

@@ -593,7 +593,7 @@ void launch_legendre_forward(const Geom &g, const Dev &d, const double *Fs, doub
     a.frag = d.leg_fwd_frag; a.Fs = Fs; a.S = S; a.m_local = d.m_local; a.C = C; a.full = full;
     a.KS = g.Jh / 4; a.NTP = g.NHP / 16;
     a.CB = ((C + 31) / 32 + 3) / 4;
-    constexpr int FD = 4;                            // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): DESIGN.md
+    constexpr int FD = 4;                            // measured against (8, 3), (4 / 8 / 16, 1 or 2), (4, 6): HISTORY.md
     // Row tiles per parity and work item.  3 (+3) is what a grid that fills the SIMDs wants: the Fourier rows are read once per row group.  A shard of
     // the sharded model (Ml = M1 / P wavenumbers) has far fewer items than the device has SIMDs -- 132 wavefronts at T85L40 on 8 ranks -- and each of
     // them is a serial chain of Jh / 4 k-steps: there one row tile per item gives three times the wavefronts a third of the chain each (the rows a

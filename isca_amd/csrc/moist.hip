@@ -56,7 +56,7 @@ struct MoistArgs {
 // time, beside loads it waits for anyway, and its sweeps cover the boundary layer only -- when 3 x 64 x (L+1) doubles fit the 64 KB a block may take
 // without opting in (L <= 41); up to L = 63 the parcel is in LDS and B's arrays are global; beyond that everything is (the parcel thread-private).
 // (Measured and not kept: a 166 K window of the saturation table in LDS instead of B's array -- the ascent's dependent lookups already hit the
-// CU's L1, the kernel went 138 -> 157 us)
+// CU's L1, the kernel went 138 -> 157 us, HISTORY.md 9.)
 // dt_tg = ((conv + cond) + rad) + sponge in the reference's order (:880, :997, :1162, :1237), formed where it is read.
 // Phase timing for kernel experiments (tools/dev/moist_phase_times.py): built with -DMOIST_TIMING=p the kernels stamp wall_clock64 (10 ns
 // ticks) at the marks of phase p (1: convection + condensation, 5: inside the convection scheme, 2: radiation + surface fluxes, 4: height sum + sponge,

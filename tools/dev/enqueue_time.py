@@ -1,4 +1,4 @@
-"""Host time to enqueue steps against the time the GPU needs for them ("Why the step is not a hipGraph")."""
+"""Host time to enqueue steps against the time the GPU needs for them (HISTORY.md 4, "Why the step is not a hipGraph")."""
 import sys, time
 sys.path.insert(0, "/root/repo")
 from isca_amd import dyncore

@@ -1,5 +1,5 @@
 // Probe: does a wave64 VALU instruction on gfx950 cost less when only part of the lanes is enabled (EXEC = low 32 / low 16 lanes)?
-// The moist column kernel is one wavefront per SIMD on a 20 000-instruction stream; if passes over disabled 16-lane groups
+// The moist column kernel is one wavefront per SIMD on a 20 000-instruction stream (HISTORY.md 11); if passes over disabled 16-lane groups
 // were skipped, a wavefront of 32 columns (two per SIMD) would cost half.  Measured: chains of dependent fp64 fma / div / exp / log with
 // 64, 32 and 16 active lanes, one wavefront per SIMD.
 #include <hip/hip_runtime.h>

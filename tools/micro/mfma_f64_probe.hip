@@ -1,4 +1,4 @@
-// Probe for pricing a fused FFT <-> Legendre stage (DESIGN.md 4 "Fused FFT + Legendre: priced"): what the FP64 matrix instructions of
+// Probe for pricing a fused FFT <-> Legendre stage (HISTORY.md 4 "Fused FFT + Legendre: priced"): what the FP64 matrix instructions of
 // gfx950 cost when the output tile is narrow.  A fused block owns a few level-fields (2-8 columns), so the 16-column tile of
 // v_mfma_f64_16x16x4_f64 is mostly empty; v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction) is the alternative.
 //   part 1: lane mapping of the 4x4x4 form, found empirically (one-hot A and B lanes -> which D lanes are non-zero);

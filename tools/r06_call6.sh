@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, call 6: suite with the deferred fixer finish; A/B against the one-block kernel (experiments build)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r06f; mkdir -p $OUT
+timeout 1800 python -m pytest tests -m gpu -q --maxfail=8 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $OUT/pytest.log
+export ISCA_DYN_LIB=$GRAFT_REPO_ROOT/isca_amd/lib/libisca_dyn_exp.so
+bash tools/ab_env.sh r06f/ab "T85L40" 3 - ISCA_NO_DEFERRED_FINISH=1 2>&1 | tee $OUT/ab.log
+bash tools/ab_env.sh r06f/ab170 "T170L60" 2 - ISCA_NO_DEFERRED_FINISH=1 2>&1 | tee $OUT/ab170.log
