@@ -1568,34 +1568,36 @@ __device__ __forceinline__ void fixer_patch_spectral(const Geom &g, const FixerA
   }
 }
 // Totals of the block partials (2 per block from the column kernel, 8 sums + min / max of the new temperatures per block from k_fixer_sums) by ONE
-// block, in an order that does not depend on the block's size: 1024 VIRTUAL threads -- value c = v & 15 (0..1 the column kernel's sums, 2..9
-// k_fixer_sums', 10 min, 11 max), group g = v >> 4 -- each fold the sets g, g + 64, ... of their value in ascending order; the 64 groups of a value are
-// then folded in ascending order by one thread.  A real thread takes the virtual threads r, r + blockDim, ...: the same bits from a block of 256, 512
-// or 1024 threads -- k_fixer_reduce, k_fixer_finish, and block 0 of the next step's column kernel (the deferred finish, below).
+// block, in an order that does not depend on the block's size: 512 VIRTUAL threads -- value c = v & 15 (0..1 the column kernel's sums, 2..9
+// k_fixer_sums', 10 min, 11 max), group g = v >> 4 -- each fold the sets g, g + 32, ... of their value in ascending order; the 32 groups of a value are
+// then folded in ascending order by one thread.  A real thread takes the virtual threads r, r + blockDim, ...: the same bits from a block of 256 or
+// 512 threads -- k_fixer_reduce, k_fixer_finish, and block 0 of the next step's column kernel (the deferred finish, below).  32 loads in flight per
+// virtual thread: one memory round trip up to 1024 sets (T85L40: 512), two at T170L60 (2048) -- this is on the critical path of that block 0.
+constexpr int FT_GROUPS = 32;
 __device__ __forceinline__ void fixer_totals(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
                                              double (*sh)[16], double *tot, double &tmin, double &tmax) {
   const int NT = blockDim.x, r = threadIdx.x, c = r & 15, cc = min(c, NRED + 1);
   const double *p0 = cc < 2 ? pprev + cc : pfut + (cc - 2);
   const int st = cc < 2 ? 2 : NPART;
   auto fold = [&](double a, double b) { return cc < NRED ? a + b : (cc == NRED ? fmin(a, b) : fmax(a, b)); };
-  constexpr int U = 8;                               // loads in flight per virtual thread
-  for (int vt = r; vt < 1024; vt += NT) {
+  constexpr int U = 32;
+  for (int vt = r; vt < 16 * FT_GROUPS; vt += NT) {
     const int g = vt >> 4;
     double acc = cc < NRED ? 0.0 : (cc == NRED ? INFINITY : -INFINITY);
-    for (int i0 = g; i0 < nb; i0 += U * 64) {
+    for (int i0 = g; i0 < nb; i0 += U * FT_GROUPS) {
       double x[U];
 #pragma unroll
-      for (int q = 0; q < U; ++q) x[q] = p0[(size_t)st * min(i0 + 64 * q, nb - 1)];
+      for (int q = 0; q < U; ++q) x[q] = p0[(size_t)st * min(i0 + FT_GROUPS * q, nb - 1)];
 #pragma unroll
       for (int q = 0; q < U; ++q)
-        if (i0 + 64 * q < nb) acc = fold(acc, x[q]);
+        if (i0 + FT_GROUPS * q < nb) acc = fold(acc, x[q]);
     }
     sh[g][c] = acc;
   }
   __syncthreads();
-  if (r < NRED + 2) {                                 // one thread per value folds the 64 groups in ascending order (c = r here)
+  if (r < NRED + 2) {                                 // one thread per value folds the groups in ascending order (c = r here)
     double x = sh[0][r];
-    for (int g = 1; g < 64; ++g) x = fold(x, sh[g][r]);
+    for (int g = 1; g < FT_GROUPS; ++g) x = fold(x, sh[g][r]);
     sh[0][r] = x;                                     // (thread r is the only reader of column r)
   }
   __syncthreads();
@@ -1939,7 +1941,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
   const int k0 = w * CH, nk = min(CH, L - k0);
   kdouble *sg = (kdouble *)a.sig + 16 * k0;              // constant address space: scalar loads wherever they are needed, also behind the stores
-  __shared__ double fin_sh[64][16];
+  __shared__ double fin_sh[FT_GROUPS][16];
   double fac_c = 1.0, tc_c = 0.0;
   if (a.fin_seq && blockIdx.x == 0) {                     // the deferred finish of the step before: this block computes and publishes
     double wf;
@@ -3542,9 +3544,9 @@ __global__ __launch_bounds__(512) void k_fixer_sums(Geom g, const double *__rest
   }
 }
 // red[0..9] <- totals: for the all-reduce between the phases when world_size > 1, and for k_fixer_apply (the eager path)
-__global__ __launch_bounds__(1024) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
-                                                       double *__restrict__ red) {
-  __shared__ double sh[64][16];
+__global__ __launch_bounds__(512) void k_fixer_reduce(const double *__restrict__ pprev, const double *__restrict__ pfut, int nb,
+                                                      double *__restrict__ red) {
+  __shared__ double sh[FT_GROUPS][16];
   double tot[NRED], tmn, tmx;
   fixer_totals(pprev, pfut, nb, sh, tot, tmn, tmx);
   if (threadIdx.x == 0) {
@@ -3556,8 +3558,8 @@ __global__ __launch_bounds__(1024) void k_fixer_reduce(const double *__restrict_
 // fixer_finish_body as a kernel: behind the all-reduce of a sharded step, and wherever the scalars are needed before the next column kernel runs
 // (the host reads state, diagnostics, a physics package in front of the column kernel).  On the plain one-rank path block 0 of the NEXT step's
 // column kernel does this instead (ColumnArgs::fin).
-__global__ __launch_bounds__(1024) void k_fixer_finish(Geom g, FixerArgs a) {
-  __shared__ double sh[64][16];
+__global__ __launch_bounds__(512) void k_fixer_finish(Geom g, FixerArgs a) {
+  __shared__ double sh[FT_GROUPS][16];
   double factor, tcorr, wfac;
   fixer_finish_body(g, a, sh, factor, tcorr, wfac);
 }
@@ -3675,7 +3677,7 @@ void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s) {
   // the totals for the all-reduce of red[0..9] between the phases (world_size > 1) and for k_fixer_apply (eager fixers); with lazy fixers
   // on one rank k_fixer_finish folds them itself
   if (g.P > 1 || !h.lazy_fix) {
-    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(nb > 256 ? 1024 : 256), 0, s, d.partials, p2, nb, d.red);
+    hipLaunchKernelGGL(k_fixer_reduce, dim3(1), dim3(nb > 256 ? 512 : 256), 0, s, d.partials, p2, nb, d.red);
   }
 }
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc) {
@@ -3708,7 +3710,7 @@ void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s)
 }
 void launch_fixer_finish(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const FixerArgs a = fixer_args(h, sc);
-  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(a.nb > 256 ? 1024 : 256), 0, s, h.g, a);
+  hipLaunchKernelGGL(k_fixer_finish, dim3(1), dim3(a.nb > 256 ? 512 : 256), 0, s, h.g, a);
 }
 // tstate / thermo: what is pending on time levels 0 and 1; cur_level: the level whose water mask is byte 0 of the mask word (the newest)
 void launch_fixer_materialize(const isca_dyn &h, hipStream_t s) {
