@@ -556,7 +556,7 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     d.Sf = dalloc<double>(h, nS); d.Si = dalloc<double>(h, nS);
     d.partials = dalloc<double>(h, 12 * (ng2 / 64 + 1));
     d.red = dalloc<double>(h, 32);
-    d.fin_flag = dalloc<unsigned>(h, 4); d.fin_val = dalloc<double>(h, 4);
+    d.fin_args = dalloc<char>(h, deferred_fixer_args_bytes());
     reset_valid_range(h);
     d.wg = dalloc<double>(h, (size_t)(g.L + 1) * ng2); d.trh = dalloc<double>(h, ng3);
     d.tr_atm[0] = dalloc<double>(h, ng3); d.tr_atm[1] = dalloc<double>(h, ng3);
@@ -715,7 +715,8 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
     const bool tr1_std = cfg->num_tracers < 1 || tracer_vert_scheme(*h, 0) == 3;       // (tracer 1 with another advect_vert: the option kernel reads stored levels)
     h->lazy_fix = cfg->raw_filter_coeff == 1.0 && cfg->num_tracers <= 1 && !virtual_t_on(*h) && !vadv_ext && tr1_std && !hs_forcing_separate(*h) &&
                   getenv("ISCA_EAGER_FIXERS") == nullptr;
-    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? (g.P == 1 && column_takes_deferred_finish(*h) ? -1 : 0) : 1) + (vadv_ext ? 1 : 0);    // lazy fixers: sums + finish (the finish in the next column kernel's block 0 on the plain one-rank path); eager: sums, totals, apply
+    h->kernels_per_step = (h->fuse_synth ? 8 : 9) - (h->fuse_fwd ? 1 : 0) + (h->tracer_on ? 2 : 0) + (virtual_t_on(*h) ? 1 : 0) + (h->lazy_fix ? (column_takes_deferred_finish(*h) ? -1 : 0) : 1) + (vadv_ext ? 1 : 0);    // lazy fixers: sums + finish (the finish in the next column kernel's block 0 on the plain one-rank path); eager: sums, totals, apply
+    upload_deferred_fixer_args(*h);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     HIP_CHECK(hipDeviceSynchronize());
     *out = h;
@@ -1278,9 +1279,9 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
   const bool raw = h->cfg.raw_filter_coeff != 1.0;
   if (part != 2) {
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
-      // one rank, the plain column kernel next: its block 0 finishes (ColumnArgs::fin) -- no launch here; otherwise (behind the all-reduce of a sharded
-      // step; diagnostics that read the level right away) the one-block kernel
-      if (h->g.P == 1 && column_takes_deferred_finish(*h) && !h->diag_mask && !exp_env("ISCA_NO_DEFERRED_FINISH")) {
+      // the plain column kernel next: its block 0 finishes (ColumnArgs::fin; sharded: from the all-reduced red[0..9]) -- no launch here; otherwise
+      // (diagnostics that read the level right away, a configuration whose column kernel cannot) the one-block kernel
+      if (column_takes_deferred_finish(*h) && !h->diag_mask && !exp_env("ISCA_NO_DEFERRED_FINISH")) {
         h->fin_deferred = true; h->fin_prev = sc.prev; h->fin_cur = sc.cur; h->fin_fut = sc.fut; h->fin_seq = h->fin_seq == 0xffffffffu ? 1u : h->fin_seq + 1u;
       } else { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
       h->thermo_pending[sc.fut] = true;

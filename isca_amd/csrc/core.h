@@ -122,7 +122,7 @@ struct Dev {
   double *part_vor = nullptr, *part_div = nullptr, *part_t = nullptr, *part_lp = nullptr, *tr_part = nullptr;
   double *partials;                                 // block partial sums
   double *red;                                      // [32] global sums [0..9] / fixer scalars [16..18] / [20..21] extremes of T / [25] a column block gave up waiting for the deferred finish
-  unsigned *fin_flag; double *fin_val;              // the deferred finish's sequence word and published scalars
+  void *fin_args;                                   // the deferred finish's device state (kernels.hip DeferredFin: two argument sets, the sequence word, the published scalars)
   double *scratch_g[4], *scratch_s[4];              // API transforms
   double *lh_lon = nullptr, *lh_lat_l = nullptr;     // hs_forcing's local_heating_option = 'Isidoro': srfamp x the longitude factor [I], the latitude factor [Jl]
   // ---- moist physics package (physics = 1)

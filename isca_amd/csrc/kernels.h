@@ -103,6 +103,8 @@ void launch_spec_tracer_update(const isca_dyn &h, const StepScalars &sc, int e, 
 void launch_tracer_pack_halo(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // rows for the neighbour bands   // grid tracer: van Leer + PPM + filter part A
 bool hs_forcing_separate(const isca_dyn &h);       // an hs_forcing_nml option the fused column kernel does not carry: k_hs_forcing_step in front of it
 void launch_hs_forcing_step(const isca_dyn &h, const StepScalars &sc, hipStream_t s);
+size_t deferred_fixer_args_bytes();
+void upload_deferred_fixer_args(const isca_dyn &h);      // at the end of create: Dev::fin_args
 bool column_takes_deferred_finish(const isca_dyn &h);    // the step's column kernel is the plain pure-sigma one, whose block 0 can finish the step before's fixers
 void launch_fixer_sums(const isca_dyn &h, int fut, hipStream_t s);          // R1: partial sums over the local band
 void launch_fixer_apply(const isca_dyn &h, const StepScalars &sc, hipStream_t s);   // R2: reduce + scalars + apply

@@ -1630,6 +1630,11 @@ __device__ __forceinline__ void fixer_finish_body(const Geom &g, const FixerArgs
 
 static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc);
 
+// The deferred finish's device-resident state (Dev::fin_args): the two argument sets a finish can have (future level 0 or 1; the current level is the
+// other one), the sequence word block 0 publishes and the two scalars it announces.  ONE pointer in ColumnArgs: the column kernel's scalar
+// registers are full (106 with 12-25 spilled), and every spilled scalar takes a vector register from a kernel that lives at the 128 limit.
+struct DeferredFin { FixerArgs fa[2]; unsigned flag; unsigned pad; double val[2]; };
+
 // =====================================================================================================
 // Grid-point column kernel: hs_forcing (hs_forcing.F90:148-272) at the PREVIOUS level with CURRENT
 // pressures (atmosphere.F90:304-311), pressure_variables (press_and_geopot.F90:152-221), four_in_one
@@ -1663,8 +1668,8 @@ struct ColumnArgs {
   // by leaving it out).  Now block 0 of this kernel computes them (fixer_finish_body: same code, same bits), publishes factor and temperature correction
   // with agent-scope stores + a sequence word, and the other blocks -- whose field loads are in flight meanwhile -- wait for that word before their
   // first arithmetic.  fin_seq = 0: nothing deferred, the scalars are read from pend_c as before.
-  unsigned fin_seq; unsigned *fin_flag; double *fin_val;      // fin_val[0..1]: factor, tcorr as published by block 0; red[25]: set when a block gave up waiting
-  FixerArgs fin;
+  unsigned fin_seq; int fin_fut;                              // red[25] is set when a block gave up waiting
+  DeferredFin *fin;
 };
 
 __device__ __forceinline__ void hs_level(const ColumnArgs &a, double dt, double ps, double p_full, double up, double vp,
@@ -1945,14 +1950,14 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   double fac_c = 1.0, tc_c = 0.0;
   if (a.fin_seq && blockIdx.x == 0) {                     // the deferred finish of the step before: this block computes and publishes
     double wf;
-    fixer_finish_body(g, a.fin, fin_sh, fac_c, tc_c, wf);
+    fixer_finish_body(g, a.fin->fa[a.fin_fut], fin_sh, fac_c, tc_c, wf);
     if (threadIdx.x == 0) {
-      __hip_atomic_store(a.fin_val + 0, fac_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.fin_val + 1, tc_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.fin->val[0], fac_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.fin->val[1], tc_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0): the two values are written through before the word that announces them
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __hip_atomic_store(a.fin_flag, a.fin_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.fin->flag, a.fin_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   const double tc_p = a.pend_p[PEND_TCORR];
@@ -1986,14 +1991,14 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     int ok = 1;
     if (tid == 0) {
       const long long t0 = wall_clock64();
-      while (__hip_atomic_load(a.fin_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fin_seq) {
+      while (__hip_atomic_load(&a.fin->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fin_seq) {
         if (wall_clock64() - t0 > 50000) { ok = 0; break; }                // 0.5 ms of the 100 MHz counter: block 0 never ran in front of this one
         __builtin_amdgcn_s_sleep(4);
       }
       if (ok) {
-        f = __hip_atomic_load(a.fin_val + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tcv = __hip_atomic_load(a.fin_val + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else a.fin.red[25] = 1.0;                                           // raised at the host's next synchronisation (api.hip)
+        f = __hip_atomic_load(&a.fin->val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tcv = __hip_atomic_load(&a.fin->val[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else a.fin->fa[0].red[25] = 1.0;                                           // raised at the host's next synchronisation (api.hip)
     }
     fac_c = __shfl(f, 0, 64); tc_c = __shfl(tcv, 0, 64);
   }
@@ -2140,6 +2145,13 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
 
 #undef TV
 
+// the two FixerArgs a deferred finish can have (future level 0 or 1; the current level is the other one), on the device: ColumnArgs::fin
+size_t deferred_fixer_args_bytes() { return sizeof(DeferredFin); }
+void upload_deferred_fixer_args(const isca_dyn &h) {
+  DeferredFin df{};
+  for (int fut = 0; fut < 2; ++fut) { StepScalars sc{}; sc.fut = fut; sc.cur = 1 - fut; sc.prev = fut; df.fa[fut] = fixer_args(h, sc); }
+  (void)hipMemcpy(h.d.fin_args, &df, sizeof(df), hipMemcpyHostToDevice);
+}
 bool column_takes_deferred_finish(const isca_dyn &h) {
   return h.d.col_sig && h.cfg.vert_difference_option != 1 && !virtual_t_on(h) && h.cfg.physics == 0 && !hs_forcing_separate(h) && h.lazy_fix;
 }
@@ -2184,11 +2196,8 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   const bool ext = h.cfg.physics != 0 || hs_forcing_separate(h);      // the physics tendencies come from arrays (a package's, or k_hs_forcing_step's)
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
   a.sig = d.col_sig; a.hs_sin = d.hs_sin_l; a.lnP00 = std::log(h.cfg.P00);
-  a.fin_seq = 0; a.fin_flag = d.fin_flag; a.fin_val = d.fin_val;
-  if (h.fin_deferred) {                         // (api.hip has flushed it unless this launch is the kernel that takes it)
-    StepScalars fs{}; fs.prev = h.fin_prev; fs.cur = h.fin_cur; fs.fut = h.fin_fut;
-    a.fin = fixer_args(h, fs); a.fin_seq = h.fin_seq;
-  } else a.fin = FixerArgs{};
+  a.fin_seq = 0; a.fin_fut = 0; a.fin = (DeferredFin *)d.fin_args;
+  if (h.fin_deferred) { a.fin_fut = h.fin_fut; a.fin_seq = h.fin_seq; }       // (api.hip has flushed it unless this launch is the kernel that takes it)
   if (a.sig && h.cfg.vert_difference_option != 1) {             // pure sigma levels: the per-level logarithms are constants of the coordinate
     // Two blocks per CU (k_column_sig<.., TWO>: <= 128 registers, the six below-the-barrier fields requested there) for the plain Held-Suarez
     // instantiation with chunks of <= 5 levels, when the grid has at least two blocks per CU to interleave: T85L40 on one rank 40.0 -> 37.0 us

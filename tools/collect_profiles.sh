@@ -7,7 +7,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export ISCA_BENCH_NO_EXTRA=1     # only the named workload in the profiled command
 TOP=gpurun_out/prof_final
-rm -rf $TOP; mkdir -p $TOP
+rm -rf $TOP; mkdir -p $TOP $TOP/shard
 WL="T85L40 T170L60"; [ "$ONLY" = moist ] && WL=""        # ONLY=moist: the Frierson configuration's files alone
 for W in $WL; do
   OUT=$TOP/$W; mkdir -p $OUT
@@ -34,6 +34,11 @@ done
 python tools/summarize_profiles.py $OUT
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 [ "$ONLY" = moist ] && exit 0
+# the sharded step's compute: P processes taking turns on this GPU (bench.py: shard_compute), rank 0 of each job under rocprofv3 --kernel-trace --stats
+unset ISCA_BENCH_NO_EXTRA
+timeout 900 python tools/shard_ab.py $TOP/shard T85L40 "2 4 8" -,prof > $TOP/shard/T85L40.log 2>&1
+timeout 600 python tools/shard_ab.py $TOP/shard T170L60 "4 8" -,prof > $TOP/shard/T170L60.log 2>&1
+find $TOP/shard -name "*kernel_trace.csv" -delete; find $TOP/shard -name "*agent_info.csv" -delete
 # the plain bench line of the headline workload (no profiler attached)
 unset ISCA_BENCH_NO_EXTRA
 timeout 600 python bench.py --steps 500 --warmup 50 > $TOP/bench_T85L40.json.log 2>&1
