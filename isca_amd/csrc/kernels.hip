@@ -1984,7 +1984,29 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
   if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
   if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
-  // the current level's pending scalars: from pend_c, or -- deferred finish -- from block 0 of this launch (the loads above are in flight meanwhile)
+  // In front of the barrier: what needs neither the mass factor nor the temperature correction of the current level -- with p_s = f p_s(stored) and
+  // T = T(stored) + c the layer's mass divergence is p_s x dmr, dmr = db (div + u dln p_s/dx + v dln p_s/dy), and the hydrostatic chunk sum is
+  // R (sum T(stored) d3 + c sum d3) --, so that a deferred finish (below) is only waited for behind the barrier, with every load, the chunk sums and
+  // the exchange through LDS done meanwhile.
+  double csum = 0.0, asum = 0.0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {          // mass divergence of the layer over p_s (four_in_one :1064-1067), dp = db p_s
+    const double dbk = sg[16 * i + 9];
+    dm[i] = (i < nk) ? dbk * (dm[i] + (u[i] * dxl + v[i] * dyl)) : 0.0;
+    csum += dm[i];
+    asum += (i < nk && k0 + i >= ktop) ? TV(i) * sg[16 * i + 1] : 0.0;
+  }
+  lds_dm[w * 64 + tid] = csum;
+  lds_a[w * 64 + tid] = asum;
+  __syncthreads();
+  double base = 0.0, total = 0.0, below = 0.0;
+  for (int ww = 0; ww < NW; ++ww) {
+    const double x = lds_dm[ww * 64 + tid];
+    total += x;
+    if (ww < w) base += x;
+    if (ww > w) below += lds_a[ww * 64 + tid];
+  }
+  // the current level's pending scalars: from pend_c, or -- deferred finish -- from block 0 of this launch
   if (!a.fin_seq) { fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR]; }
   else if (blockIdx.x != 0) {
     double f = 1.0, tcv = 0.0;
@@ -2003,34 +2025,17 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     fac_c = __shfl(f, 0, 64); tc_c = __shfl(tcv, 0, 64);
   }
   ps = mul_nc(ps, fac_c);
-  const double dx_ps = ps * dxl, dy_ps = ps * dyl;
 #pragma unroll
-  for (int i = 0; i < CH; ++i) t[i] += tc_c;
+  for (int i = 0; i < CH; ++i) { t[i] += tc_c; dm[i] *= ps; }
   tm += tc_c; tn += tc_c;
-  // what needs only p_s, while the fields are on their way
+  base *= ps; total *= ps;
+  // sd3 = the sum of d3 over the levels below this wavefront's chunk (col_sig entry 12 of the first level behind it)
+  below = RDGAS * (VIRT ? below : below + tc_c * ((k0 + CH < L) ? sg[16 * CH + 12] : 0.0));
   const double rps = 1. / ps;
   double lpn0 = 0.0, pkap = 0.0;
   if (!EXT) { lpn0 = log(ps) - a.lnP00; pkap = exp(KAPPA * lpn0); }     // ln(p_s/P00), (p_s/P00)**kappa
   const double sin2 = sin_lat * sin_lat, cos2 = 1.0 - sin2, cos4 = cos2 * cos2;
   const double t_star = a.t_zero - a.delh * sin2 - a.eps * sin_lat, tstr = a.t_strat - a.eps * sin_lat;
-  double csum = 0.0, asum = 0.0;
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {          // mass divergence of the layer (four_in_one :1064-1067), dp = db p_s
-    const double dbk = sg[16 * i + 9];
-    dm[i] = (i < nk) ? dm[i] * (dbk * ps) + dbk * (u[i] * dx_ps + v[i] * dy_ps) : 0.0;
-    csum += dm[i];
-    asum += (i < nk && k0 + i >= ktop) ? RDGAS * TV(i) * sg[16 * i + 1] : 0.0;
-  }
-  lds_dm[w * 64 + tid] = csum;
-  lds_a[w * 64 + tid] = asum;
-  __syncthreads();
-  double base = 0.0, total = 0.0, below = 0.0;
-  for (int ww = 0; ww < NW; ++ww) {
-    const double x = lds_dm[ww * 64 + tid];
-    total += x;
-    if (ww < w) base += x;
-    if (ww > w) below += lds_a[ww * 64 + tid];
-  }
   double dmean_tot = base;
   double wg_k = (k0 == 0) ? 0.0 : (-base + total * sg[11]);
   double e_prev = 0.0;
