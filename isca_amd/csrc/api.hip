@@ -644,9 +644,6 @@ extern "C" int isca_dyn_create(const isca_dyn_config *cfg, isca_dyn_t **out) {
           q[8] = bl ? tcoeff * (sig - cfg->sigma_b) : 0.0;
           q[9] = T.dbk[k]; q[10] = T.bk[k + 1]; q[11] = T.bk[k];
         }
-        // entry 12: the sum of d3 from this level to the ground, from the second level on (the hydrostatic sum starts there: pk(1) = 0) -- what the
-        // temperature correction of a deferred finish contributes to the chunk sums below a wavefront
-        { long double sfx = 0.0L; for (int k = L - 1; k >= 0; --k) { if (k >= 1) sfx += (long double)cs[(size_t)16 * k + 1]; cs[(size_t)16 * k + 12] = (double)sfx; } }
         d.col_sig = dupload(h, cs);
       }
       { std::vector<double> sl(g.Jl); for (int j = 0; j < g.Jl; ++j) sl[j] = std::sin(T.rad_lat[g.j0 + j]); d.hs_sin_l = dupload(h, sl); }

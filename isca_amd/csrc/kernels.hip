@@ -1984,27 +1984,24 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   double um = 0., vm = 0., tm = 0., un = 0., vn = 0., tn = 0.;
   if (k0 > 0) { const size_t q = c2 + (size_t)(k0 - 1) * lev; um = a.u[q]; vm = a.v[q]; tm = a.t[q]; }
   if (k0 + nk < L) { const size_t q = c2 + (size_t)(k0 + nk) * lev; un = a.u[q]; vn = a.v[q]; tn = a.t[q]; }
-  // In front of the barrier: what needs neither the mass factor nor the temperature correction of the current level -- with p_s = f p_s(stored) and
-  // T = T(stored) + c the layer's mass divergence is p_s x dmr, dmr = db (div + u dln p_s/dx + v dln p_s/dy), and the hydrostatic chunk sum is
-  // R (sum T(stored) d3 + c sum d3) --, so that a deferred finish (below) is only waited for behind the barrier, with every load, the chunk sums and
-  // the exchange through LDS done meanwhile.
-  double csum = 0.0, asum = 0.0;
+  // In front of the barrier: what does not need the current level's pending scalars -- with p_s = f p_s(stored) the layer's mass divergence is p_s x dmr,
+  // dmr = db (div + u dln p_s/dx + v dln p_s/dy) --, so that a deferred finish (below) is only waited for behind the barrier, with every load, the
+  // chunk sums of dmr and their exchange through LDS done meanwhile.  (The hydrostatic chunk sums need the corrected temperature itself -- T(stored) + c
+  // summed as such, or a run restarted from materialised fields would differ in the last bit --: they are exchanged behind the level loop.)
+  double csum = 0.0;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {          // mass divergence of the layer over p_s (four_in_one :1064-1067), dp = db p_s
     const double dbk = sg[16 * i + 9];
     dm[i] = (i < nk) ? dbk * (dm[i] + (u[i] * dxl + v[i] * dyl)) : 0.0;
     csum += dm[i];
-    asum += (i < nk && k0 + i >= ktop) ? TV(i) * sg[16 * i + 1] : 0.0;
   }
   lds_dm[w * 64 + tid] = csum;
-  lds_a[w * 64 + tid] = asum;
   __syncthreads();
-  double base = 0.0, total = 0.0, below = 0.0;
+  double base = 0.0, total = 0.0;
   for (int ww = 0; ww < NW; ++ww) {
     const double x = lds_dm[ww * 64 + tid];
     total += x;
     if (ww < w) base += x;
-    if (ww > w) below += lds_a[ww * 64 + tid];
   }
   // the current level's pending scalars: from pend_c, or -- deferred finish -- from block 0 of this launch
   if (!a.fin_seq) { fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR]; }
@@ -2029,8 +2026,12 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   for (int i = 0; i < CH; ++i) { t[i] += tc_c; dm[i] *= ps; }
   tm += tc_c; tn += tc_c;
   base *= ps; total *= ps;
-  // sd3 = the sum of d3 over the levels below this wavefront's chunk (col_sig entry 12 of the first level behind it)
-  below = RDGAS * (VIRT ? below : below + tc_c * ((k0 + CH < L) ? sg[16 * CH + 12] : 0.0));
+  {   // the hydrostatic chunk sum of my levels (compute_geopotential :350-356), read by the wavefronts above behind the level loop
+    double asum = 0.0;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) asum += (i < nk && k0 + i >= ktop) ? RDGAS * TV(i) * sg[16 * i + 1] : 0.0;
+    lds_a[w * 64 + tid] = asum;
+  }
   const double rps = 1. / ps;
   double lpn0 = 0.0, pkap = 0.0;
   if (!EXT) { lpn0 = log(ps) - a.lnP00; pkap = exp(KAPPA * lpn0); }     // ln(p_s/P00), (p_s/P00)**kappa
@@ -2114,7 +2115,10 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   }
   if (w == NW - 1) a.dtlp[c2] = (0.0 - total) * rps;    // (dt_psg - dmean_tot)/psg (:873, :1102)
   // ---- hydrostatic integral bottom-up within the chunk, Phi + KE (:350-356, :902)
+  __syncthreads();                                        // (lds_a of every wavefront)
   {
+    double below = 0.0;
+    for (int ww = w + 1; ww < NW; ++ww) below += lds_a[ww * 64 + tid];
     double gh = below + a.surf_geop[c2];
 #pragma unroll
     for (int i = CH - 1; i >= 0; --i) {
