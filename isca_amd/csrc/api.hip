@@ -347,13 +347,13 @@ static void sync_and_check_valid_range(isca_dyn *h) {
   if (h->comm) { h->comm->synchronize(h->stream); h->comm->check(); }      // (RCCL: polls the stream, the communicator's error state and a deadline, comm.h)
   else HIP_CHECK(hipStreamSynchronize(h->stream));
   const double *red = h->host_red;
-  if (red[25] != 0.0) {         // (kernels.hip k_column_sig: a block waited 0.5 ms for block 0's scalars -- the dispatcher did not start block 0 first)
-    HIP_CHECK(hipMemsetAsync(h->d.red + 25, 0, sizeof(double), h->stream));
-    fail("column kernel: the deferred fixer scalars of the step before never arrived (block 0 did not run first); results since the last synchronisation are invalid");
-  }
+  // (kernels.hip k_column_sig: a block gave up waiting for block 0's scalars -- the dispatcher did not start block 0 first, or the device was taken away
+  // for seconds.  Part of the verdict below, so that on a sharded run every rank raises at this point.)
+  const bool fin_lost = red[25] != 0.0;
+  if (fin_lost) HIP_CHECK(hipMemsetAsync(h->d.red + 25, 0, sizeof(double), h->stream));
   const double tmin = red[20], tmax = red[21];
   const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
-  const bool bad = stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17]));
+  const bool bad = fin_lost || (stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17])));
   // Sharded with the library's communicator: a rank judges its own band, but error_mesg(..., FATAL) stops EVERY PE (spectral_dynamics.F90:940-972)
   // -- the verdict is summed over the ranks, so that all of them raise at this synchronisation point instead of the others going on into an
   // exchange their peer never joins (every rank reaches this point after the same number of steps: the step loop is collective).
@@ -366,6 +366,7 @@ static void sync_and_check_valid_range(isca_dyn *h) {
     h->comm->synchronize(h->stream);
     other = !bad && h->host_red[41] > 0.0;
   }
+  if (fin_lost) fail("column kernel: the deferred fixer scalars of the step before never arrived (block 0 did not run first); results since the last synchronisation are invalid");
   if (bad) {
     char msg[160];
     snprintf(msg, sizeof(msg), "temperatures out of valid range (min %.3f, max %.3f, valid %.1f..%.1f)", tmin, tmax,
@@ -1165,8 +1166,11 @@ static void phase0(isca_dyn *h, const StepScalars &sc) {          // grid tenden
     timed_tracer(h, sc, h->stream2, 0);
   }
   if (hs_forcing_separate(*h)) { Timed t(h, "hs_forcing"); launch_hs_forcing_step(*h, sc, h->stream); }       // (an hs_forcing_nml option the fused kernel does not carry)
+  // (a deferred finish is taken by this launch's block 0.  fin_seq counts exactly those launches -- never 0, parity alternating also across the wrap --:
+  // its parity picks the slot the pair is published in, and every such launch empties the other slot for the next one)
+  if (h->fin_deferred) h->fin_seq = h->fin_seq >= 0xfffffffeu ? (h->fin_seq & 1u ? 2u : 1u) : h->fin_seq + 1u;
   { Timed t(h, "column"); launch_column(*h, sc, h->stream); }
-  h->fin_deferred = false;                              // (its block 0 has taken the deferred finish, if there was one)
+  h->fin_deferred = false;
   if (h->cfg.vert_advect_uv != 0 || h->cfg.vert_advect_t != 0) { Timed t(h, "vert_advection"); launch_vert_advection_schemes(*h, sc, h->stream); }
   if (h->tracer_on) {
     if (h->g.P > 1) {
@@ -1282,7 +1286,7 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
       // the plain column kernel next: its block 0 finishes (ColumnArgs::fin; sharded: from the all-reduced red[0..9]) -- no launch here; otherwise
       // (diagnostics that read the level right away, a configuration whose column kernel cannot) the one-block kernel
       if (column_takes_deferred_finish(*h) && !h->diag_mask && !exp_env("ISCA_NO_DEFERRED_FINISH")) {
-        h->fin_deferred = true; h->fin_prev = sc.prev; h->fin_cur = sc.cur; h->fin_fut = sc.fut; h->fin_seq = h->fin_seq == 0xffffffffu ? 1u : h->fin_seq + 1u;
+        h->fin_deferred = true; h->fin_prev = sc.prev; h->fin_cur = sc.cur; h->fin_fut = sc.fut;
       } else { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
       h->thermo_pending[sc.fut] = true;
       if (h->tracer_on) { h->tr_state[sc.cur] = isca::TR_FILT; h->tr_state[sc.fut] = isca::TR_NEW; }

@@ -207,7 +207,7 @@ struct isca_dyn {
   bool thermo_pending[2] = {false, false};   // mass factor / temperature correction pending on psg / tg of time level 0 / 1
   // The finish of the last step's fixers (the three scalars, the (0,0) patch) is DEFERRED to block 0 of the next column kernel (kernels.hip ColumnArgs::fin)
   // on the plain one-rank path; anything else that needs the scalars first -- the host reading state, diagnostics, a physics package in front of the
-  // column kernel -- runs k_fixer_finish instead (api.hip: flush_finish).  fin_prev / _cur / _fut: that step's time levels; fin_seq: the word block 0 publishes.
+  // column kernel -- runs k_fixer_finish instead (api.hip: flush_finish).  fin_prev / _cur / _fut: that step's time levels; fin_seq: the number of deferred launches so far (its parity picks the slot block 0 publishes in).
   bool fin_deferred = false;
   int fin_prev = 0, fin_cur = 0, fin_fut = 0;
   unsigned fin_seq = 0;

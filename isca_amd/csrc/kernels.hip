@@ -1633,7 +1633,21 @@ static FixerArgs fixer_args(const isca_dyn &h, const StepScalars &sc);
 // The deferred finish's device-resident state (Dev::fin_args): the two argument sets a finish can have (future level 0 or 1; the current level is the
 // other one), the sequence word block 0 publishes and the two scalars it announces.  ONE pointer in ColumnArgs: the column kernel's scalar
 // registers are full (106 with 12-25 spilled), and every spilled scalar takes a vector register from a kernel that lives at the 128 limit.
-struct DeferredFin { FixerArgs fa[2]; unsigned flag; unsigned pad; double val[2]; };
+struct alignas(64) DeferredFin { FixerArgs fa[2]; alignas(64) double val[2][2]; };
+// val[seq & 1] = {mass factor, temperature correction} of launch `seq`, written by block 0 with ONE 16-byte write-through store; the slot reads {NaN, NaN}
+// until then (block 0 of the launch before reset it), so the pair is its own announcement: no second store, no ordering between two stores -- under
+// the load of 512 blocks' first requests every device-scope round trip costs microseconds, and this one is on the critical path of all of them.
+__device__ __forceinline__ void fin_publish(double *slot, double f, double t) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2 v = {f, t};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slot), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fin_peek(const double *slot, double &f, double &t) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(slot) : "memory");
+  f = v.x; t = v.y;
+}
 
 // =====================================================================================================
 // Grid-point column kernel: hs_forcing (hs_forcing.F90:148-272) at the PREVIOUS level with CURRENT
@@ -1668,7 +1682,8 @@ struct ColumnArgs {
   // by leaving it out).  Now block 0 of this kernel computes them (fixer_finish_body: same code, same bits), publishes factor and temperature correction
   // with agent-scope stores + a sequence word, and the other blocks -- whose field loads are in flight meanwhile -- wait for that word before their
   // first arithmetic.  fin_seq = 0: nothing deferred, the scalars are read from pend_c as before.
-  unsigned fin_seq; int fin_fut;                              // red[25] is set when a block gave up waiting
+  unsigned fin_seq; int fin_fut;                              // fin_seq: 0 = nothing deferred, else 1 + the number of deferred launches before this one (its parity picks the slot);
+                                                              // red[25] is set when a block gave up waiting
   DeferredFin *fin;
 };
 
@@ -1952,12 +1967,8 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     double wf;
     fixer_finish_body(g, a.fin->fa[a.fin_fut], fin_sh, fac_c, tc_c, wf);
     if (threadIdx.x == 0) {
-      __hip_atomic_store(&a.fin->val[0], fac_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&a.fin->val[1], tc_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0): the two values are written through before the word that announces them
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __hip_atomic_store(&a.fin->flag, a.fin_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fin_publish(a.fin->val[a.fin_seq & 1], fac_c, tc_c);
+      fin_publish(a.fin->val[~a.fin_seq & 1], __builtin_nan(""), __builtin_nan(""));      // the next launch's slot: empty until its block 0 fills it
     }
   }
   const double tc_p = a.pend_p[PEND_TCORR];
@@ -2007,17 +2018,16 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   if (!a.fin_seq) { fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR]; }
   else if (blockIdx.x != 0) {
     double f = 1.0, tcv = 0.0;
-    int ok = 1;
     if (tid == 0) {
       const long long t0 = wall_clock64();
-      while (__hip_atomic_load(&a.fin->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.fin_seq) {
-        if (wall_clock64() - t0 > 50000) { ok = 0; break; }                // 0.5 ms of the 100 MHz counter: block 0 never ran in front of this one
-        __builtin_amdgcn_s_sleep(4);
+      const double *slot = a.fin->val[a.fin_seq & 1];
+      for (;;) {
+        fin_peek(slot, f, tcv);
+        if (f == f && tcv == tcv) break;                                      // both halves of the pair have arrived
+        if (wall_clock64() - t0 > 300000000) { f = 1.0; tcv = 0.0; a.fin->fa[0].red[25] = 1.0; break; }      // 3 s of the 100 MHz counter (processes that share the
+                                                                              // device are time-sliced for milliseconds): block 0 never ran in
+        __builtin_amdgcn_s_sleep(4);                                          // front of this one; raised at the host's next synchronisation (api.hip)
       }
-      if (ok) {
-        f = __hip_atomic_load(&a.fin->val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tcv = __hip_atomic_load(&a.fin->val[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else a.fin->fa[0].red[25] = 1.0;                                           // raised at the host's next synchronisation (api.hip)
     }
     fac_c = __shfl(f, 0, 64); tc_c = __shfl(tcv, 0, 64);
   }
@@ -2158,6 +2168,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
 size_t deferred_fixer_args_bytes() { return sizeof(DeferredFin); }
 void upload_deferred_fixer_args(const isca_dyn &h) {
   DeferredFin df{};
+  for (auto &slot : df.val) slot[0] = slot[1] = std::nan("");                 // both slots empty
   for (int fut = 0; fut < 2; ++fut) { StepScalars sc{}; sc.fut = fut; sc.cur = 1 - fut; sc.prev = fut; df.fa[fut] = fixer_args(h, sc); }
   (void)hipMemcpy(h.d.fin_args, &df, sizeof(df), hipMemcpyHostToDevice);
 }
@@ -2206,7 +2217,7 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
   if (a.tv) launch_virtual_t(h, a.t, d.tr[sc.cur], d.tv, s);       // grid_tracers(:,:,:,current,nhum) (spectral_dynamics.F90:858)
   a.sig = d.col_sig; a.hs_sin = d.hs_sin_l; a.lnP00 = std::log(h.cfg.P00);
   a.fin_seq = 0; a.fin_fut = 0; a.fin = (DeferredFin *)d.fin_args;
-  if (h.fin_deferred) { a.fin_fut = h.fin_fut; a.fin_seq = h.fin_seq; }       // (api.hip has flushed it unless this launch is the kernel that takes it)
+  if (h.fin_deferred) { a.fin_fut = h.fin_fut; a.fin_seq = h.fin_seq; }       // (api.hip has flushed it unless this launch is the kernel that takes it; it counts the launches)
   if (a.sig && h.cfg.vert_difference_option != 1) {             // pure sigma levels: the per-level logarithms are constants of the coordinate
     // Two blocks per CU (k_column_sig<.., TWO>: <= 128 registers, the six below-the-barrier fields requested there) for the plain Held-Suarez
     // instantiation with chunks of <= 5 levels, when the grid has at least two blocks per CU to interleave: T85L40 on one rank 40.0 -> 37.0 us
