@@ -160,7 +160,8 @@ def dominant_roofline(kt, kern, traffic, traffic_source, workload=None):
         return None
     c = kern[dom]
     name = KERNEL_OF[dom]
-    if name == "k_column_sig" and name not in traffic and "k_column" in traffic:
+    is_sig = name == "k_column_sig"
+    if is_sig and name not in traffic and "k_column" in traffic:
         name = "k_column"
     mfma = c["bound"] == "mfma"
     ach, peak = (c["achieved_TFs"], FP64_MFMA_PEAK_TF) if mfma else (c["achieved_GBs"], HBM_PEAK_GBS)
@@ -173,6 +174,16 @@ def dominant_roofline(kt, kern, traffic, traffic_source, workload=None):
         sk = max(side, key=side.get)
         out["side_stream_longest"] = {"kernel": KERNEL_OF[sk], "avg_launch_ms": side[sk], "frac": kern[sk]["frac"], "bound": "hbm",
                                       "note": "runs beside the main stream's kernels and ends before the join: not on the step's critical path"}
+    if is_sig:
+        out["note"] = ("the launch includes the deferred finish of the step before: block 0 computes the fixers' three scalars and the other blocks wait for them behind "
+                       "their scan barrier (DESIGN.md 4) -- the one-block kernel this replaced cost the step more than the wait costs this kernel")
+        cf = os.path.join("profiles", f"r06_{workload}_classic_finish_kernel_stats.csv") if workload else None
+        if cf and os.path.exists(os.path.join(REPO, cf)):      # the same kernel with k_fixer_finish as a kernel of its own (experiments build), same collection
+            import csv
+            with open(os.path.join(REPO, cf)) as f:
+                us = {r["kernel"].strip('"'): float(r["avg_us"]) for r in csv.DictReader(f)}.get("k_column_sig")
+            if us:
+                out["without_deferred_finish"] = {"rocprof_avg_launch_ms": us * 1e-3, "frac": (ach * c["ms"] / (us * 1e-3)) / peak, "rocprof_source": cf}
     if workload:      # the same kernel's duration in the committed rocprofv3 trace of this command, and the fraction it gives
         rp, src = load_rocprof_us(workload)
         us = rp.get(name.split(":")[0])

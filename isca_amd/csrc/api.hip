@@ -353,7 +353,8 @@ static void sync_and_check_valid_range(isca_dyn *h) {
   if (fin_lost) HIP_CHECK(hipMemsetAsync(h->d.red + 25, 0, sizeof(double), h->stream));
   const double tmin = red[20], tmax = red[21];
   const bool stepped = !(tmin > tmax);                       // (no step since the last check: nothing to judge)
-  const bool bad = fin_lost || (stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17])));
+  const bool range_bad = stepped && (!(tmin >= h->cfg.valid_range_t[0] && tmax <= h->cfg.valid_range_t[1]) || !std::isfinite(red[16]) || !std::isfinite(red[17]));
+  const bool bad = fin_lost || range_bad;
   // Sharded with the library's communicator: a rank judges its own band, but error_mesg(..., FATAL) stops EVERY PE (spectral_dynamics.F90:940-972)
   // -- the verdict is summed over the ranks, so that all of them raise at this synchronisation point instead of the others going on into an
   // exchange their peer never joins (every rank reaches this point after the same number of steps: the step loop is collective).
@@ -366,13 +367,13 @@ static void sync_and_check_valid_range(isca_dyn *h) {
     h->comm->synchronize(h->stream);
     other = !bad && h->host_red[41] > 0.0;
   }
-  if (fin_lost) fail("column kernel: the deferred fixer scalars of the step before never arrived (block 0 did not run first); results since the last synchronisation are invalid");
-  if (bad) {
+  if (range_bad) {
     char msg[160];
     snprintf(msg, sizeof(msg), "temperatures out of valid range (min %.3f, max %.3f, valid %.1f..%.1f)", tmin, tmax,
              h->cfg.valid_range_t[0], h->cfg.valid_range_t[1]);
     fail(msg);
   }
+  if (fin_lost) fail("column kernel: the deferred fixer scalars of the step before never arrived (block 0 did not run first); results since the last synchronisation are invalid");
   if (other) fail("temperatures out of valid range on another rank's latitude band");
 }
 

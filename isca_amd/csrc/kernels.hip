@@ -1967,7 +1967,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     double wf;
     fixer_finish_body(g, a.fin->fa[a.fin_fut], fin_sh, fac_c, tc_c, wf);
     if (threadIdx.x == 0) {
-      fin_publish(a.fin->val[a.fin_seq & 1], fac_c, tc_c);
+      // (a blown-up run's scalars are NaN, which is what an empty slot reads: published as infinities -- the waiting blocks go on, and the
+      // host's valid-range check sees the NaN in red[16..17])
+      fin_publish(a.fin->val[a.fin_seq & 1], fac_c == fac_c ? fac_c : INFINITY, tc_c == tc_c ? tc_c : INFINITY);
       fin_publish(a.fin->val[~a.fin_seq & 1], __builtin_nan(""), __builtin_nan(""));      // the next launch's slot: empty until its block 0 fills it
     }
   }
