@@ -1286,7 +1286,7 @@ static void phase3(isca_dyn *h, const StepScalars &sc, int part = 0) {          
     if (h->lazy_fix) {       // the scalars only: left pending on the new level (and, for the tracer's filter, on the current one)
       // the plain column kernel next: its block 0 finishes (ColumnArgs::fin; sharded: from the all-reduced red[0..9]) -- no launch here; otherwise
       // (diagnostics that read the level right away, a configuration whose column kernel cannot) the one-block kernel
-      if (column_takes_deferred_finish(*h) && !h->diag_mask && !exp_env("ISCA_NO_DEFERRED_FINISH")) {
+      if (column_takes_deferred_finish(*h) && !h->diag_mask) {
         h->fin_deferred = true; h->fin_prev = sc.prev; h->fin_cur = sc.cur; h->fin_fut = sc.fut;
       } else { Timed t(h, "fixer_finish"); launch_fixer_finish(*h, sc, h->stream); }
       h->thermo_pending[sc.fut] = true;

@@ -1961,8 +1961,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
   const size_t c2 = (size_t)col, lev = (size_t)g.Jl * I;
   const int k0 = w * CH, nk = min(CH, L - k0);
   kdouble *sg = (kdouble *)a.sig + 16 * k0;              // constant address space: scalar loads wherever they are needed, also behind the stores
-  __shared__ double fin_sh[FT_GROUPS][16];
   double fac_c = 1.0, tc_c = 0.0;
+#ifdef ISCA_EXPERIMENTS      // the deferred finish (HISTORY "Round 6": correct, and no faster than the one-block kernel once its cost to this kernel is counted)
+  __shared__ double fin_sh[FT_GROUPS][16];
   if (a.fin_seq && blockIdx.x == 0) {                     // the deferred finish of the step before: this block computes and publishes
     double wf;
     fixer_finish_body(g, a.fin->fa[a.fin_fut], fin_sh, fac_c, tc_c, wf);
@@ -1973,6 +1974,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
       fin_publish(a.fin->val[~a.fin_seq & 1], __builtin_nan(""), __builtin_nan(""));      // the next launch's slot: empty until its block 0 fills it
     }
   }
+#endif
   const double tc_p = a.pend_p[PEND_TCORR];
   double ps = a.ps[c2];
   const double psp = mul_nc(a.psp[c2], a.pend_p[PEND_FACTOR]);
@@ -2017,6 +2019,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     if (ww < w) base += x;
   }
   // the current level's pending scalars: from pend_c, or -- deferred finish -- from block 0 of this launch
+#ifdef ISCA_EXPERIMENTS
   if (!a.fin_seq) { fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR]; }
   else if (blockIdx.x != 0) {
     double f = 1.0, tcv = 0.0;
@@ -2033,6 +2036,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void k_column_sig(Geom g, ColumnA
     }
     fac_c = __shfl(f, 0, 64); tc_c = __shfl(tcv, 0, 64);
   }
+#else
+  fac_c = a.pend_c[PEND_FACTOR]; tc_c = a.pend_c[PEND_TCORR];
+#endif
   ps = mul_nc(ps, fac_c);
 #pragma unroll
   for (int i = 0; i < CH; ++i) { t[i] += tc_c; dm[i] *= ps; }
@@ -2175,6 +2181,10 @@ void upload_deferred_fixer_args(const isca_dyn &h) {
   (void)hipMemcpy(h.d.fin_args, &df, sizeof(df), hipMemcpyHostToDevice);
 }
 bool column_takes_deferred_finish(const isca_dyn &h) {
+  // Experiments build only, and only when asked for (ISCA_DEFERRED_FINISH=1): measured in round 6 -- block 0 of the column kernel computing the fixers'
+  // scalars while the other blocks wait for them is 5 us faster than the same kernel followed by k_fixer_finish, but the waiting code costs the
+  // 128-register variant 4 spilled registers and 4-5 us whether it waits or not; against the kernel WITHOUT that code the step is the same.
+  if (!exp_env("ISCA_DEFERRED_FINISH")) return false;
   return h.d.col_sig && h.cfg.vert_difference_option != 1 && !virtual_t_on(h) && h.cfg.physics == 0 && !hs_forcing_separate(h) && h.lazy_fix;
 }
 size_t column_partials_count(const isca_dyn &h) { return (size_t)h.g.Jl * h.g.I / 64; }

@@ -21,11 +21,10 @@ for W in $WL; do
   python tools/summarize_profiles.py $OUT
   find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete      # the raw traces: gpurun brings back 64 MiB at most
 done
-# the headline once more with the fixers' finish as the one-block kernel it was (experiments build: ISCA_NO_DEFERRED_FINISH=1): what k_column_sig takes
-# when its blocks do not wait for block 0's scalars, and what the step pays for the kernel instead
+# the headline once more with the fixers' finish deferred into block 0 of the next column kernel (experiments build: ISCA_DEFERRED_FINISH=1; HISTORY "Round 6")
 if [ -f isca_amd/lib/libisca_dyn_exp.so ] && [ "$ONLY" != moist ]; then
-  OUT=$TOP/T85L40_classic_finish; mkdir -p $OUT
-  ISCA_DYN_LIB=$GRAFT_REPO_ROOT/isca_amd/lib/libisca_dyn_exp.so ISCA_NO_DEFERRED_FINISH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --workload T85L40 --steps 500 --warmup 50 --cpu-steps 0 > $OUT/bench_stats.log 2>&1
+  OUT=$TOP/T85L40_deferred_finish; mkdir -p $OUT
+  ISCA_DYN_LIB=$GRAFT_REPO_ROOT/isca_amd/lib/libisca_dyn_exp.so ISCA_DEFERRED_FINISH=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --workload T85L40 --steps 500 --warmup 50 --cpu-steps 0 > $OUT/bench_stats.log 2>&1
   python tools/summarize_profiles.py $OUT > /dev/null
   find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 fi

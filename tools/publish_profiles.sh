@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 R=${1:-r06}
 T=gpurun_out/prof_final
-for W in T85L40 T170L60 T85L40_moist T85L40_classic_finish; do
+for W in T85L40 T170L60 T85L40_moist T85L40_deferred_finish; do
   S=$T/$W
   [ -d $S ] || continue
   cp $S/kernel_stats_summary.csv profiles/${R}_${W}_kernel_stats.csv
