@@ -2237,18 +2237,19 @@ void launch_column(const isca_dyn &h, const StepScalars &sc, hipStream_t s) {
     // occupancy, and there the second memory round trip only adds latency.  ISCA_COLUMN_TWO=0|1 overrides (measurement).
     static const int two_env = exp_env("ISCA_COLUMN_TWO") ? atoi(exp_env("ISCA_COLUMN_TWO")) : -1;
     const bool two = two_env >= 0 ? two_env != 0 : (grid.x >= 512 && CH <= 5);
-    if (two && !a.tv && !ext) {
+    if (two && !a.tv) {
+#define LT2(N) do { if (ext) hipLaunchKernelGGL((k_column_sig<N, true, false, true>), grid, block, lds, s, g, a); \
+                    else hipLaunchKernelGGL((k_column_sig<N, false, false, true>), grid, block, lds, s, g, a); } while (0)
       switch (CH) {
-        case 1: hipLaunchKernelGGL((k_column_sig<1, false, false, true>), grid, block, lds, s, g, a); break;
-        case 2: hipLaunchKernelGGL((k_column_sig<2, false, false, true>), grid, block, lds, s, g, a); break;
-        case 3: hipLaunchKernelGGL((k_column_sig<3, false, false, true>), grid, block, lds, s, g, a); break;
-        case 4: hipLaunchKernelGGL((k_column_sig<4, false, false, true>), grid, block, lds, s, g, a); break;
-        case 5: hipLaunchKernelGGL((k_column_sig<5, false, false, true>), grid, block, lds, s, g, a); break;
-        case 6: hipLaunchKernelGGL((k_column_sig<6, false, false, true>), grid, block, lds, s, g, a); break;      // (6..8 levels per wavefront: 11-26 spilled dwords at 128 registers)
-        case 7: hipLaunchKernelGGL((k_column_sig<7, false, false, true>), grid, block, lds, s, g, a); break;
-        default: hipLaunchKernelGGL((k_column_sig<8, false, false, true>), grid, block, lds, s, g, a); break;
+        case 1: LT2(1); break; case 2: LT2(2); break; case 3: LT2(3); break; case 4: LT2(4); break; case 5: LT2(5); break;
+#ifdef ISCA_EXPERIMENTS
+        case 6: LT2(6); break; case 7: LT2(7); break; default: LT2(8); break;      // (6..8 levels per wavefront spill 11-32 registers at 128: T170L60 229-234 against 191 us)
+#else
+        default: break;
+#endif
       }
-      return;
+#undef LT2
+      if (CH <= 5 || two_env >= 0) return;
     }
 #define LS(N) do { \
     if (a.tv) { if (ext) hipLaunchKernelGGL((k_column_sig<N, true, true>), grid, block, lds, s, g, a); else hipLaunchKernelGGL((k_column_sig<N, false, true>), grid, block, lds, s, g, a); } \
