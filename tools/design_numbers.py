@@ -49,7 +49,7 @@ for wl, (I, J, N, L) in (("T85L40", (256, 128, 85, 40)), ("T170L60", (512, 256, 
             tot_c += c
         out.append(f"| `{kname}` | {us:.1f} | {a / 1e6:.1f} | {a / us / 1e6:.2f} | {a / us / 1e6 / 8:.2f} | {c / 1e6:.1f} | {c / a:.2f} | {tf} |" if a and c else
                    f"| `{kname}` | {us:.1f} | — | — | — | {(c or 0) / 1e6:.1f} | — | |")
-    out.append(f"| sum | | {tot_a / 1e6:.0f} | | | {tot_c / 1e6:.0f} | {tot_c / tot_a:.2f} | |\n")
+    out.append(f"| sum of the kernels (the Fourier intermediate counts on both sides of it) | | {tot_a / 1e6:.0f} | | | {tot_c / 1e6:.0f} | {tot_c / tot_a:.2f} | |\n")
 sc = json.load(open(P("shard_compute.json")))
 out.append("**The sharded step's compute on one GPU** (`bench.py: shard_compute_ms`, P processes taking turns, slowest rank, exchanges excluded; "
            f"`profiles/{tag}_shard_compute.json` is the collection under rocprofv3, whose events are a little longer; `profiles/{tag}_<workload>_P<n>_kernel_stats.csv` "
@@ -61,7 +61,7 @@ for wl in ("T85L40", "T170L60"):
     one = b["ms_per_step"] if wl == "T85L40" else next(x["ms_per_step"] for k, x in b["other_workloads"].items() if k.startswith("T170L60"))
     cell = lambda P_: (f"{v[f'P={P_}']['segments_ms']:.3f} (kernels {v[f'P={P_}']['main_stream_ms']:.3f}, side {v[f'P={P_}']['side_stream_ms']:.3f})" if f"P={P_}" in v and "segments_ms" in v[f"P={P_}"] else "—")
     out.append(f"| {wl}: `segments_ms` (per-kernel event sum, side stream), ms | {one:.3f} (whole step) | {cell(2)} | {cell(4)} | {cell(8)} |")
-out.append("")
+out.append("\n(`k_leg_fwd` at T170L60 counts 43 MB for 226 MB of Fourier rows it must read: its rows were written by the kernel before and FETCH_SIZE does not see what the 256 MB memory-side cache serves; the same holds, less visibly, for every consumer that follows its producer.)\n")
 for k, x in b["other_workloads"].items():
     if "ms_per_step" in x and "roofline" in x and x["roofline"]:
         r = x["roofline"]
