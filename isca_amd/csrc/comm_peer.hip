@@ -176,6 +176,11 @@ class PeerComm final : public Comm {
     if (hipExtMallocWithFlags((void **)&flags_, sizeof(PeerFlags), hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
       pk(hipMalloc((void **)&flags_, sizeof(PeerFlags)), "hipMalloc (flags)");
+      // Coarse-grained flags are only known to work between processes that share ONE device (the peers then poll the same L2).  Across GPUs the
+      // system-scope polling is not guaranteed to see remote writes to coarse-grained memory, and every exchange would end in its time-out:
+      // said loudly here instead (RCCL is the default driver; ISCA_COMM=peer is opt-in).
+      fprintf(stderr, "isca peer comm (rank %d): fine-grained device memory for the flag block was refused; falling back to coarse-grained memory, "
+                      "which is only valid for ranks sharing one device -- use RCCL (the default) across GPUs\n", rank);
     }
     pk(hipMemset(flags_, 0, sizeof(PeerFlags)), "hipMemset (flags)");
     pk(hipHostMalloc((void **)&err_, sizeof(int), hipHostMallocMapped), "hipHostMalloc");

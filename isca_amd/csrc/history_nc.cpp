@@ -97,6 +97,7 @@ struct HistFile {
 }  // namespace
 
 struct isca_history {
+  int base_date[6] = {0, 0, 0, 0, 0, 0};     // the table's second line: year month day hour minute second (diag_manager writes it into the time units)
   std::vector<std::unique_ptr<HistFile>> files;
   std::vector<std::string> names;            // union of the files' fields: what the device accumulates
   std::vector<std::vector<double>> chunk;    // the chunk's sums, one per name
@@ -136,7 +137,13 @@ void parse_table(const isca_dyn *h, const std::string &text, const std::string &
   while (std::getline(in, line)) {
     const size_t first = line.find_first_not_of(" \t\r");
     if (first == std::string::npos || line[first] == '#') continue;
-    if (header_lines < 2) { ++header_lines; continue; }               // the title and the base date
+    if (header_lines < 2) {                                           // the title, then the base date ("0 0 0 0 0 0" without a calendar, diagtable.py:13-17)
+      if (header_lines == 1) {
+        std::istringstream bd(line);
+        for (int i = 0; i < 6; ++i) { int v = 0; if (bd >> v) H.base_date[i] = v; }
+      }
+      ++header_lines; continue;
+    }
     const std::vector<std::string> t = split_entry(line);
     if (t.size() < 2) continue;
     if (is_number(t[1])) {                                            // "file_name", output_freq, "output_units", format, "time_units", "long_name"
@@ -184,7 +191,7 @@ void get_table(isca_dyn *h, const char *nm, std::vector<double> &v, size_t n) {
   if (isca_dyn_get_table(h, nm, v.data(), n)) fail(std::string("diag_manager: ") + isca_last_error());
 }
 
-void create_file(isca_dyn *h, HistFile &f) {
+void create_file(isca_dyn *h, const isca_history &H, HistFile &f) {
   const isca::Geom &g = h->g;
   const size_t I = g.I, J = g.Jl, L = g.L;
   Nc3Writer &w = f.w;
@@ -209,7 +216,9 @@ void create_file(isca_dyn *h, HistFile &f) {
   w.var("phalf", {dph}, {{"units", "hPa"}, {"cartesian_axis", "Z"}, {"positive", "down"}}, [p_half](int, double *o) { std::copy(p_half.begin(), p_half.end(), o); });
   w.var("pfull", {dpf}, {{"units", "hPa"}, {"cartesian_axis", "Z"}, {"positive", "down"}}, [p_full](int, double *o) { std::copy(p_full.begin(), p_full.end(), o); });
   HistFile *fp = &f;
-  w.var("time", {dt}, {{"units", f.time_units + " since 0001-01-01 00:00:00"}, {"cartesian_axis", "T"}}, [fp](int, double *o) { o[0] = 0.5 * (fp->t1 + fp->t2) / fp->scale; });
+  char since[64];       // diag_util.F90:1582-1585: a, ' since ', i4.4, '-', i2.2, '-', i2.2, ' ', i2.2, ':', i2.2, ':', i2.2
+  snprintf(since, sizeof since, " since %04d-%02d-%02d %02d:%02d:%02d", H.base_date[0], H.base_date[1], H.base_date[2], H.base_date[3], H.base_date[4], H.base_date[5]);
+  w.var("time", {dt}, {{"units", f.time_units + since}, {"cartesian_axis", "T"}}, [fp](int, double *o) { o[0] = 0.5 * (fp->t1 + fp->t2) / fp->scale; });
   w.var("average_T1", {dt}, {}, [fp](int, double *o) { o[0] = fp->t1 / fp->scale; });
   w.var("average_T2", {dt}, {}, [fp](int, double *o) { o[0] = fp->t2 / fp->scale; });
   w.var("average_DT", {dt}, {}, [fp](int, double *o) { o[0] = (fp->t2 - fp->t1) / fp->scale; });
@@ -330,7 +339,7 @@ extern "C" int isca_dyn_diag_open(isca_dyn_t *h, const char *diag_table, const c
   std::string csv;
   for (const auto &nm : H->names) csv += (csv.empty() ? "" : ",") + nm;
   if (isca_dyn_diag_select(h, csv.c_str())) fail(std::string("diag_manager_init: ") + isca_last_error());
-  for (auto &f : H->files) create_file(h, *f);
+  for (auto &f : H->files) create_file(h, *H, *f);
   h->hist = H.release();
   HS_END
 }

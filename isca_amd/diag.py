@@ -38,13 +38,16 @@ _SECONDS = {"seconds": 1, "minutes": 60, "hours": 3600, "days": 86400}
 class DiagTable:
     """add_file / add_field as in diagtable.py:60-120 (one output file is supported per table entry)."""
 
-    def __init__(self):
+    def __init__(self, base_date=(0, 0, 0, 0, 0, 0)):
+        # the table's base-date line: "0 0 0 0 0 0" without a calendar (the harness's default, diagtable.py:13-17), "0001 1 1 0 0 0" with one;
+        # diag_manager writes it into the time axis' units (diag_util.F90:1582-1585)
+        self.base_date = tuple(int(x) for x in base_date)
         self.files: dict = {}
 
     def add_file(self, name, freq, units="hours", time_units=None):
         if units not in _SECONDS:
             raise IscaError(f"diag_table: unsupported frequency units {units!r}")
-        self.files[name] = {"name": name, "freq": freq, "units": units, "time_units": time_units or units, "fields": []}
+        self.files[name] = {"name": name, "freq": freq, "units": units, "time_units": time_units or units, "fields": [], "base_date": self.base_date}
 
     def add_field(self, module, name, time_avg=False, files=None):
         if name in MOIST_FIELDS:
@@ -63,7 +66,7 @@ class DiagTable:
 
     def copy(self):
         import copy
-        d = DiagTable()
+        d = DiagTable(self.base_date)
         d.files = copy.deepcopy(self.files)
         return d
 
@@ -179,7 +182,7 @@ class History:
         for nm, n, vals in (("phalf", c.L + 1, p_half), ("pfull", c.L, p_full)):
             f.createDimension(nm, n)
             v = f.createVariable(nm, "d", (nm,)); v[:] = vals; v.units = "hPa"; v.cartesian_axis = "Z"; v.positive = "down"
-        tv = f.createVariable("time", "d", ("time",)); tv.units = f"{tu} since 0001-01-01 00:00:00"; tv.cartesian_axis = "T"
+        tv = f.createVariable("time", "d", ("time",)); tv.units = "%s since %04d-%02d-%02d %02d:%02d:%02d" % ((tu,) + tuple(self.spec.get("base_date", (0, 0, 0, 0, 0, 0)))); tv.cartesian_axis = "T"
         t1v = f.createVariable("average_T1", "d", ("time",)); t2v = f.createVariable("average_T2", "d", ("time",))
         dtv = f.createVariable("average_DT", "d", ("time",))
         for nm in self.static:

@@ -793,6 +793,9 @@ def main():
             if k.startswith("st_"):
                 a3 = out.pop(k)
                 out[k + ("_s488" if a3.ndim == 3 else "_s44")] = np.ascontiguousarray(a3[::4, ::8, ::8] if a3.ndim == 3 else a3[::4, ::4])
+                # (round 6) EVERY grid point: the zonal sums of the field and of its square per (level, latitude) -- a localized error off the strided
+                # sample moves them (a relative error > 1e-7 at one point moves the row's sum of squares by > 1e-9)
+                out[k + "_rowsum"] = a3.sum(axis=-1); out[k + "_rowsq"] = (a3 * a3).sum(axis=-1)
         path = os.path.join(GOLD, "run_T85L40.npz")
         np.savez_compressed(path, **out)
         print(f"run_T85L40: {os.path.getsize(path)/1e6:.2f} MB")
@@ -817,6 +820,7 @@ def main():
             if k.startswith("st_"):
                 a3 = out.pop(k)
                 out[k + ("_s6gg" if a3.ndim == 3 else "_s88")] = np.ascontiguousarray(a3[5::6, ::16, ::16] if a3.ndim == 3 else a3[::8, ::8])
+                out[k + "_rowsum"] = a3.sum(axis=-1); out[k + "_rowsq"] = (a3 * a3).sum(axis=-1)       # every grid point (see run_T85L40)
         path = os.path.join(GOLD, "run_T170L60.npz")
         np.savez_compressed(path, **out)
         print(f"run_T170L60: {os.path.getsize(path)/1e6:.2f} MB")

@@ -111,6 +111,19 @@ def test_golden_T42L25_one_day(golden_dir):
     dc.close()
 
 
+def every_point_check(g, mine, key, tol=1e-9):
+    """Round 6: the big fixtures also hold the zonal sums of each field and of its square per (level, latitude), taken over EVERY grid point of the
+    reference's field -- the strided samples alone would let a localized error between sample points pass.  Scale of a row: sqrt(I sum x^2) >= sum |x|.  A relative error > 1e-7 at a single point moves the row's sum of squares by more than tol."""
+    rs, rq = g[key + "_rowsum"], g[key + "_rowsq"]
+    I = mine.shape[-1]
+    # per-point floor of a row's scale: 1 % of the largest row's rms (a tracer row aloft is ~0), and 1 m/s for the winds
+    x0 = max(1e-2 * float(np.sqrt(rq.max() / I)), 1.0 if ("_ug_" in key or "_vg_" in key) else 0.0)
+    e1 = float(np.max(np.abs(mine.sum(axis=-1) - rs) / np.maximum(np.sqrt(I * rq), I * x0)))
+    e2 = float(np.max(np.abs((mine * mine).sum(axis=-1) - rq) / np.maximum(rq, I * x0 * x0)))
+    assert e1 < tol and e2 < tol, (key, e1, e2)
+    return max(e1, e2)
+
+
 def test_golden_T85L40_benchmark_config(golden_dir):
     """The benchmark configuration itself (T85L40, dt = 300 s) against the reference run: 20 steps from the cold start, and one DAY
     (288 steps; SURVEY 8d's 1-day tolerance 1e-9), on the committed [::4, ::8, ::8] sample (ps: [::4, ::4]); winds as a fraction of
@@ -125,6 +138,7 @@ def test_golden_T85L40_benchmark_config(golden_dir):
             ref = g["st_%s_%06d_s488" % (gk, n)]
             err[k] = float(np.abs(dc.get(k)[::4, ::8, ::8] - ref).max() / max(np.abs(ref).max(), 1.0 if k in ("ug", "vg") else 1e-300))
         err["psg"] = rel(dc.get("psg")[::4, ::4], g["st_psg_%06d_s44" % n])
+        err["every point (row sums)"] = max(every_point_check(g, dc.get(k), "st_%s_%06d" % (gk, n)) for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1"), ("psg", "psg")))
         print("T85L40,", n, "steps vs the reference:", err)
         assert max(err.values()) < 1e-9, (n, err)       # measured at 20 steps: u, v 9e-12, T 5e-14, ps 2e-14, tracer 1e-10
     tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]     # of step 288
@@ -892,6 +906,7 @@ def test_golden_T170L60_stress_config(golden_dir):
             ref = g["st_%s_%06d_s6gg" % (gk, n)]
             err[k] = float(np.abs(dc.get(k)[5::6, ::16, ::16] - ref).max() / max(np.abs(ref).max(), 1.0 if k in ("ug", "vg") else 1e-300))
         err["psg"] = rel(dc.get("psg")[::8, ::8], g["st_psg_%06d_s88" % n])
+        err["every point (row sums)"] = max(every_point_check(g, dc.get(k), "st_%s_%06d" % (gk, n)) for k, gk in (("ug", "ug"), ("vg", "vg"), ("tg", "tg"), ("tr", "tr1"), ("psg", "psg")))
         print("T170L60 step", n, "vs the reference:", err)
         assert max(err.values()) < 1e-9, (n, err)
     tmin, tmax, umax = g["final_Tmin_Tmax_maxabsU"]
