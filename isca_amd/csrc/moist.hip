@@ -22,6 +22,7 @@ struct MoistArgs {
   double *precip;                       // convective + large-scale rain rate [ncol] (kg/m2/s)
   double *cc_dT, *cc_dq, *cc_precip;    // this step's (conv + cond) heating and moistening rates [L][ncol] and their rain rate [ncol]: written by k_moist_convcond or, a step ahead, by k_moist_physics
   const double *tn, *qn; double dt_next; double *nx_dT, *nx_dq, *nx_precip; int do_next;   // the NEXT step's convection inside k_moist_physics: its previous level's T, q (pressures: pf_c, ph_c), its delta_t, where its rates go
+  const double *sig;                    // the convection's logarithm tables on pure sigma levels (moist_physics.h: QeParcel::sig), or null
   const double *pk, *bk, *ps_p, *ps_c;  // in the model's step (SIG kernels): the half-level pressures are pk + bk ps, formed where they are needed; ph_p / ph_c unused
   const double *surf_geop;              // non-null: zf_c / zh_c hold the hydrostatic increments of k_moist_pressures and this kernel sums them (moist_heights_scan)
   int ktop;
@@ -74,15 +75,16 @@ struct MoistArgs {
 // increments requested together.  (Was a kernel of its own: 512 wavefronts, five memory round trips, 12 us.)
 __device__ __forceinline__ void moist_heights_scan(double gh, int L, int ktop, double *z_full, double *z_half, size_t s) {
   z_half[(size_t)L * s] = gh / GRAV;
-  for (int k0 = L - 1; k0 >= 0; k0 -= 8) {
-    double zf[8], dz[8];
+  constexpr int HU = 8;
+  for (int k0 = L - 1; k0 >= 0; k0 -= HU) {
+    double zf[HU], dz[HU];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < HU; ++i) {
       const int k = (k0 - i >= 0) ? k0 - i : 0;
       zf[i] = z_full[(size_t)k * s]; dz[i] = z_half[(size_t)k * s];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < HU; ++i) {
       const int k = k0 - i;
       if (k >= 0) {
         z_full[(size_t)k * s] = (gh + zf[i]) / GRAV;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(64) void k_moist_convcond(MoistArgs a) {
   double ptp[NLDS >= 2 ? 1 : LMAX], prp[NLDS >= 2 ? 1 : LMAX];
   moist::QeParcel pc = NLDS >= 2 ? moist::QeParcel{lds_work + lane, lds_work + lane + (size_t)(L + 1) * 64, 64} : moist::QeParcel{ptp, prp, 1};
   if (NLDS == 3) pc.wTv = lds_work + lane + (size_t)2 * (L + 1) * 64;
+  pc.sig = a.sig;
 #if defined(MOIST_TIMING) && MOIST_TIMING == 5      // phase 5: inside the convection scheme (marks in moist_physics.h)
   pc.marks = mt_;
 #endif
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(128) void k_moist_physics(MoistArgs a) {
   if (role == 0 && a.do_next) {
     double ptp[NLDS >= 2 ? 1 : LMAX], prp[NLDS >= 2 ? 1 : LMAX];
     moist::QeParcel pc = NLDS >= 2 ? moist::QeParcel{lds_work + lane, lds_work + lane + (size_t)(L + 1) * 64, 64} : moist::QeParcel{ptp, prp, 1};
+    pc.sig = a.sig;
 #if defined(MOIST_TIMING) && MOIST_TIMING == 5
     pc.marks = mt_;
 #endif
@@ -291,6 +295,7 @@ struct MoistState {
   moist::SatTableHost sat;
   moist::QeTablesHost qe;
   double *d_sat[3] = {nullptr, nullptr, nullptr}, *d_lcl = nullptr;
+  double *d_sig = nullptr;
   moist::SatTable sat_dev;
   moist::QeParams qe_dev;
   moist::RayleighParams ray;
@@ -314,6 +319,28 @@ MoistState *moist_create(const isca_dyn_config &cfg, const Tables &tab) {
   m->sat_dev.tab = m->d_sat[0]; m->sat_dev.dtab = m->d_sat[1]; m->sat_dev.d2tab = m->d_sat[2];
   m->qe_dev = m->qe.params;
   m->qe_dev.lcl_temp_table = m->d_lcl;
+  // QeParcel::sig: with pk = 0 (and not 'mcm') p_half = b p_s and p_full = cf p_s with ln cf(k) = ln b(k+1) - (1 - b(k) a / (b(k+1) - b(k))),
+  // a = ln(b(k+1) / b(k)) (press_and_geopot.F90:165-194; the top layer of a model top at zero pressure: ln cf = ln b(2) - 1, and its ratio of half
+  // levels is infinite as log(p_half(2) / 0) is): what k_moist_pressures computes per column, here once and in extended precision
+  {
+    bool sigma = cfg.vert_difference_option != 1;
+    for (double v : tab.pk) if (v != 0.0) sigma = false;
+    if (sigma && !getenv("ISCA_MOIST_LOG_PER_LEVEL")) {
+      const int L = cfg.num_levels;
+      std::vector<long double> lcf(L);
+      std::vector<double> sg((size_t)3 * L, 0.0);
+      for (int k = 0; k < L; ++k) {
+        const long double b0 = tab.bk[k], b1 = tab.bk[k + 1];
+        if (b0 == 0.0L) { lcf[k] = logl(b1) - 1.0L; sg[L + k] = INFINITY; }
+        else { const long double a = logl(b1 / b0); lcf[k] = logl(b1) - (1.0L - b0 * a / (b1 - b0)); sg[L + k] = (double)a; }
+      }
+      for (int k = 0; k < L; ++k) {
+        if (k + 1 < L) sg[k] = (double)(lcf[k] - lcf[k + 1]);
+        sg[2 * L + k] = (double)(lcf[k] - lcf[L - 1]);
+      }
+      m->d_sig = (double *)dev_upload(sg);
+    }
+  }
   // damping_driver_init (damping_driver.f90:411-420) with the reference pressures of idealized_moist_phys_init (:620-629)
   const int L = cfg.num_levels;
   std::vector<double> lph, lpf;
@@ -335,6 +362,7 @@ void moist_destroy(MoistState *m) {
   if (!m) return;
   for (double *p : m->d_sat) if (p) (void)hipFree(p);
   if (m->d_lcl) (void)hipFree(m->d_lcl);
+  if (m->d_sig) (void)hipFree(m->d_sig);
   delete m;
 }
 
@@ -533,6 +561,7 @@ void launch_moist_convcond(const isca_dyn &h, int level, int pslot, double delta
   a.tp = h.lazy_fix ? d.m_t[pslot] : d.tg[level]; a.qp = h.lazy_fix ? d.m_q[pslot] : d.tr_atm[level];
   a.pf_p = w.pf[pslot]; a.ph_p = w.ph[pslot];
   if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_p = h.lazy_fix ? d.m_ps[pslot] : d.psg[level]; }
+  a.sig = h.moist->d_sig;      // (the model's own pressures: k_moist_pressures)
   a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
   a.delta_t = delta_t;
   launch_moist_convcond_kernel(a, s);
@@ -554,7 +583,7 @@ void launch_moist_physics(const isca_dyn &h, const StepScalars &sc, hipStream_t 
   if (moist_sigma_half(h.g.L)) { a.pk = d.pk; a.bk = d.bk; a.ps_c = h.lazy_fix ? d.m_ps[slot_cur] : d.psg[sc.cur]; }
   a.t_surf = d.t_surf; a.dtu = d.ph_dtu; a.dtv = d.ph_dtv; a.dtT = d.ph_dtT; a.dtq = d.ph_dtq; a.precip = d.precip;
   a.cc_dT = d.cc_dT[ccslot]; a.cc_dq = d.cc_dq[ccslot]; a.cc_precip = d.cc_precip[ccslot];
-  a.do_next = next ? 1 : 0;
+  a.do_next = next ? 1 : 0; a.sig = h.moist->d_sig;
   a.tn = d.tg[sc.cur]; a.qn = d.tr_atm[sc.cur]; a.dt_next = 2 * h.cfg.dt_atmos;
   if (h.lazy_fix) { a.tn = d.m_t[slot_cur]; a.qn = d.m_q[slot_cur]; }
   a.nx_dT = d.cc_dT[1 - ccslot]; a.nx_dq = d.cc_dq[1 - ccslot]; a.nx_precip = d.cc_precip[1 - ccslot];

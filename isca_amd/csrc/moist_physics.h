@@ -6,6 +6,7 @@
 // temperature, grey radiation 'frierson', SIMPLE_BETTS_MILLER convection, diffusivity PBL, mixed-layer surface).
 #pragma once
 #include <cmath>
+#include <type_traits>
 #if defined(__clang__)
 #pragma clang fp contract(off)      // the reference is built without FMA contraction; the convective regime tests are knife-edge
 #endif
@@ -194,7 +195,8 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
     for (int i = 0; i < MP_U; ++i) {
       const double pw = gray_pow(ph[i] / PSTD_MKS, p.wv_exponent);
       tau_n[i] = lw_tau_0 * (p.linear_tau * ph[i] / PSTD_MKS + (1.0 - p.linear_tau) * pw);
-      swd[i] = insolation * exp(-sw_tau_0 * (one_pow ? pw : gray_pow(ph[i] / PSTD_MKS, p.solar_exponent)));
+      // (atm_abs = 0, the grey scheme's default: the shortwave optical depth is zero at every latitude and exp(-0 x) = 1 exactly -- not evaluated)
+      swd[i] = (p.atm_abs == 0.0) ? insolation : insolation * exp(-sw_tau_0 * (one_pow ? pw : gray_pow(ph[i] / PSTD_MKS, p.solar_exponent)));
     }
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {
@@ -291,6 +293,12 @@ struct QeParcel {
   double *wTp, *wrp; int sw;
   double *wTv = nullptr;           // TV_EXT: the environment's virtual temperature in caller storage too (stride sw; the device kernel: a third LDS array
                                    // instead of a thread-private one, which was 424 bytes of scratch per lane)
+  // Pure sigma levels inside the model's step (pk = 0: every pressure of a column is a constant of the vertical coordinate times p_s, as in
+  // k_column_sig): the logarithms of pressure RATIOS between neighbouring levels that the parcel's path takes at every level are constants too,
+  //   sig[k-1] = ln(p_full(k) / p_full(k+1)),  sig[L + k-1] = ln(p_half(k+1) / p_half(k)),  sig[2L + k-1] = ln(p_full(k) / p_full(L))   (k = 1..L),
+  // built once in extended precision (moist.hip: moist_create).  Null: the ratios are divided and their logarithms taken per level and column
+  // (caller pressures, hybrid levels, the host tests).  Two divisions and two logarithms fewer per level of the ascent: a third of its time.
+  const double *sig = nullptr;
 #ifdef MOIST_TIMING
   long long *marks = nullptr;      // timing builds (moist.hip): wall_clock64 stamps at the QE_MARK points of qe_moist_convection
 #define QE_MARK(i) if (MOIST_TIMING == 5 && pc.marks) { const long long t_ = wall_clock64(); for (int i_ = i; i_ < 9; ++i_) pc.marks[i_] = t_; }
@@ -318,6 +326,22 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   auto pf = [&](int k) { return p_full_[(k - 1) * s]; };
   auto ph = [&](int k) { return ph_at(p_half_, s, k - 1); };
   const int ks = L;                                                       // k_surface
+  // walk(k1, k2, body): body(k, p_half(k), p_half(k+1)) for k = k1..k2 while it returns true.  The half-level pressures of 8 levels are requested
+  // together: k1 differs between the columns of a wavefront, so every request is a gather and a memory round trip -- one per chunk here, one per
+  // level (or per four) in the plain loops the adjustment steps were until round 6 (up to 26 us per wavefront in the shallow branch's search).
+  auto walk = [&](int k1, int k2, auto body) {
+    constexpr int W = 8;
+    for (int k0 = k1; k0 <= k2; k0 += W) {
+      double pp[W + 1];
+      MP_UNROLL_ALL
+      for (int i = 0; i <= W; ++i) pp[i] = ph((k0 + i <= ks + 1) ? k0 + i : ks + 1);
+      bool go = true;
+      MP_UNROLL_ALL
+      for (int i = 0; i < W; ++i)
+        if (go && k0 + i <= k2) go = body(k0 + i, pp[i], pp[i + 1]);
+      if (!go) return;
+    }
+  };
   auto set_nocape = [&](double &pLZB, int &kLZB, int &kLFC, double &CIN) {  // set_values_if_nocape (:1014-1030)
     pLZB = pf(1); kLZB = 0; kLFC = 0; CIN = 0.;
     MP_UNROLL
@@ -368,7 +392,21 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       }
       int k = ks;
       CIN = 0.;
-      {
+      if (pc.sig) {      // (the table form: the parcel's dry adiabat from one logarithm per column and one exponential per level)
+        const double *sg = pc.sig;
+        const double lnpfs = log(pf(ks) / QE_PREF);
+        double pfk = pf(ks), tvk = Tv(ks), lrel = sg[2 * L + ks - 1], lh = sg[L + ks - 1];        // next level requested one iteration ahead
+        while (k >= 1 && pfk > pLCL) {
+          const int kn = (k > 1) ? k - 1 : 1;
+          const double pfn = pf(kn), tvn = Tv(kn), lreln = sg[2 * L + kn - 1], lhn = sg[L + kn - 1];
+          const double Tpk = theta0 * exp(KAPPA * (lnpfs + lrel));
+          pc.Tp(k) = Tpk;
+          pc.rp(k) = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
+          CIN = CIN + RDGAS * (tvk - qe_virtual_temp(Tpk, r0)) * lh;
+          k = k - 1;
+          pfk = pfn; tvk = tvn; lrel = lreln; lh = lhn;
+        }
+      } else {
         double pfk = pf(ks), ph1 = ph(ks + 1), phk = ph(ks), tvk = Tv(ks);        // next level requested one iteration ahead
         while (k >= 1 && pfk > pLCL) {
           const int kn = (k > 1) ? k - 1 : 1;
@@ -402,10 +440,11 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
           } else {
             pc.rp(kLCL) = qe_mixing_ratio(lookup_es(st, pc.Tp(kLCL)), pf(kLCL));
             const double tvp = qe_virtual_temp(pc.Tp(kLCL), pc.rp(kLCL));
+            const double lh = pc.sig ? pc.sig[L + kLCL - 1] : log(ph(kLCL + 1) / ph(kLCL));
             if ((tvp < Tv(kLCL)) && nocape) {
-              CIN = CIN + RDGAS * (Tv(kLCL) - tvp) * log(ph(kLCL + 1) / ph(kLCL));
+              CIN = CIN + RDGAS * (Tv(kLCL) - tvp) * lh;
             } else {
-              CAPE = CAPE + RDGAS * (tvp - Tv(kLCL)) * log(ph(kLCL + 1) / ph(kLCL));
+              CAPE = CAPE + RDGAS * (tvp - Tv(kLCL)) * lh;
               if (nocape) { nocape = false; kLFC = kLCL; }
             }
           }
@@ -420,39 +459,54 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
   } else {
     if (kLCL - 1 >= 1) {
       // the parcel's previous level stays in registers; pressures and Tv of the next level are requested one iteration ahead, so their
-      // latency hides behind this level's log / table-lookup chain
-      double Tp1 = pc.Tp(kLCL), rp1 = pc.rp(kLCL);
-      double pf1 = pf(kLCL), pfk = pf(kLCL - 1), ph1 = ph(kLCL), phk = ph(kLCL - 1), tvk = Tv(kLCL - 1);
-      for (int k = kLCL - 1; k >= 1; --k) {
-        const int kn = (k > 1) ? k - 1 : 1;
-        const double pfn = pf(kn), phn = ph(kn), tvn = Tv(kn);
-        double a = KAPPA * Tp1 + (HLV / CP_AIR) * rp1;
-        double b = (HLV * HLV) * rp1 / (CP_AIR * RVGAS * (Tp1 * Tp1));
-        double dtdlnp = a / (1.0 + b);
-        double Tpk = Tp1 + dtdlnp * log(pfk / pf1) / 2;
-        pc.Tp(k) = Tpk;
-        if ((Tpk < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
-        double rpk = qe_mixing_ratio(lookup_es(st, Tpk), (pfk + pf1) / 2);
-        a = KAPPA * Tpk + (HLV / CP_AIR) * rpk;
-        b = (HLV * HLV) * rpk / (CP_AIR * RVGAS * (Tpk * Tpk));
-        dtdlnp = a / (1.0 + b);
-        Tpk = Tp1 + dtdlnp * log(pfk / pf1);
-        pc.Tp(k) = Tpk;
-        if ((Tpk < P.Tmin) && nocape) { pc.rp(k) = rpk; set_nocape(pLZB, kLZB, kLFC, CIN); break; }
-        rpk = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
-        pc.rp(k) = rpk;
-        const double tvp = qe_virtual_temp(Tpk, rpk);
-        if ((tvp < tvk) && nocape) {
-          CIN = CIN + RDGAS * (tvk - tvp) * log(ph1 / phk);
-        } else if ((tvp < tvk) && !nocape) {
-          kLZB = k + 1;
-          break;
-        } else {
-          CAPE = CAPE + RDGAS * (tvp - tvk) * log(ph1 / phk);
-          if (nocape) { nocape = false; kLFC = k; }
+      // latency hides behind this level's table-lookup chain.  TAB: the two logarithms of the level come from pc.sig (requested ahead as well)
+      auto ascent = [&](auto tab) {
+        constexpr bool TAB = decltype(tab)::value;
+        [[maybe_unused]] const double *sg = pc.sig;
+        double Tp1 = pc.Tp(kLCL), rp1 = pc.rp(kLCL);
+        double pf1 = pf(kLCL), pfk = pf(kLCL - 1), tvk = Tv(kLCL - 1);
+        [[maybe_unused]] double ph1 = 0., phk = 0., lf = 0., lh = 0.;
+        if constexpr (TAB) { lf = sg[kLCL - 2]; lh = sg[L + kLCL - 2]; }
+        else { ph1 = ph(kLCL); phk = ph(kLCL - 1); }
+        for (int k = kLCL - 1; k >= 1; --k) {
+          const int kn = (k > 1) ? k - 1 : 1;
+          const double pfn = pf(kn), tvn = Tv(kn);
+          [[maybe_unused]] double phn = 0., lfn = 0., lhn = 0.;
+          if constexpr (TAB) { lfn = sg[kn - 1]; lhn = sg[L + kn - 1]; }
+          else { phn = ph(kn); lf = log(pfk / pf1); }
+          double a = KAPPA * Tp1 + (HLV / CP_AIR) * rp1;
+          double b = (HLV * HLV) * rp1 / (CP_AIR * RVGAS * (Tp1 * Tp1));
+          double dtdlnp = a / (1.0 + b);
+          double Tpk = Tp1 + dtdlnp * lf / 2;
+          pc.Tp(k) = Tpk;
+          if ((Tpk < P.Tmin) && nocape) { set_nocape(pLZB, kLZB, kLFC, CIN); break; }
+          double rpk = qe_mixing_ratio(lookup_es(st, Tpk), (pfk + pf1) / 2);
+          a = KAPPA * Tpk + (HLV / CP_AIR) * rpk;
+          b = (HLV * HLV) * rpk / (CP_AIR * RVGAS * (Tpk * Tpk));
+          dtdlnp = a / (1.0 + b);
+          Tpk = Tp1 + dtdlnp * lf;
+          pc.Tp(k) = Tpk;
+          if ((Tpk < P.Tmin) && nocape) { pc.rp(k) = rpk; set_nocape(pLZB, kLZB, kLFC, CIN); break; }
+          rpk = qe_mixing_ratio(lookup_es(st, Tpk), pfk);
+          pc.rp(k) = rpk;
+          const double tvp = qe_virtual_temp(Tpk, rpk);
+          if ((tvp < tvk) && !nocape) {
+            kLZB = k + 1;
+            break;
+          }
+          if constexpr (!TAB) lh = log(ph1 / phk);
+          if ((tvp < tvk) && nocape) {
+            CIN = CIN + RDGAS * (tvk - tvp) * lh;
+          } else {
+            CAPE = CAPE + RDGAS * (tvp - tvk) * lh;
+            if (nocape) { nocape = false; kLFC = k; }
+          }
+          Tp1 = Tpk; rp1 = rpk; pf1 = pfk; pfk = pfn; tvk = tvn;
+          if constexpr (TAB) { lf = lfn; lh = lhn; }
+          else { ph1 = phk; phk = phn; }
         }
-        Tp1 = Tpk; rp1 = rpk; pf1 = pfk; pfk = pfn; ph1 = phk; phk = phn; tvk = tvn;
-      }
+      };
+      if (pc.sig) ascent(std::true_type{}); else ascent(std::false_type{});
     }
   }
   QE_MARK(3)
@@ -510,8 +564,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         Pq = Pt;
       } else {                                        // do_change_Tref_deepconv (:957-988)
         double deltak = 0.;
-        MP_UNROLL
-        for (int k = kLZB; k <= ks; ++k) deltak = deltak - (dT(k) + (HLV / CP_AIR) * dq(k)) * (ph(k + 1) - ph(k));
+        walk(kLZB, ks, [&](int k, double p0, double p1) { deltak = deltak - (dT(k) + (HLV / CP_AIR) * dq(k)) * (p1 - p0); return true; });
         deltak = deltak / (ph(ks + 1) - ph(kLZB));
         MP_UNROLL
         for (int k = kLZB; k <= ks; ++k) { if (WANT_REF) c.Tref[k] = c.Tref[k] + deltak * P.tau_bm / dt; dT(k) = dT(k) + deltak; }
@@ -520,10 +573,12 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
       // ---- do_shallow_convection (:800-840) with level_of_zero_precip (:844-888)
       int k = kLZB;
       bool found = false;
-      while ((Pq < 0.) && (k <= ks)) {
-        Pq = Pq - dq(k) * (ph(k) - ph(k + 1)) / GRAV;
-        k = k + 1;
-      }
+      walk(kLZB, ks, [&](int kk, double p0, double p1) {       // while ((Pq < 0.) && (k <= ks))
+        if (!(Pq < 0.)) return false;
+        Pq = Pq - dq(kk) * (p0 - p1) / GRAV;
+        k = kk + 1;
+        return true;
+      });
       const int k_top = k - 1;
       if (Pq > 0.) found = true;
       if (k_top > kLZB) to_model(kLZB, k_top - 1);
@@ -532,8 +587,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         dq(k_top) = dq(k_top) * cc;
         dT(k_top) = dT(k_top) * cc;
         double deltak = 0.;
-        MP_UNROLL
-        for (int kk = k_top; kk <= ks; ++kk) deltak = deltak + dT(kk) * (ph(kk) - ph(kk + 1));
+        walk(k_top, ks, [&](int kk, double p0, double p1) { deltak = deltak + dT(kk) * (p0 - p1); return true; });
         deltak = deltak / (ph(ks + 1) - ph(k_top));
         if (k_top != ks)
           for (int kk = k_top; kk <= ks; ++kk) { dT(kk) = dT(kk) + deltak; if (WANT_REF) c.Tref[kk] = c.Tref[kk] + deltak * P.tau_bm / dt; }
@@ -1072,15 +1126,16 @@ MP_HD void vert_diff_up(int L, double delt, const VdiffWork &w, const VdiffSurf 
 template <class DUIN, class DVIN, class DTIN, class DQIN>
 MP_HD void vert_diff_passthrough(int ka, int kb, DUIN du_in, DVIN dv_in, DTIN dt_in, DQIN dq_in, double *dt_u, double *dt_v, double *dt_t, double *dt_q,
                                  int st) {      // levels ka .. kb-1
-  for (int k0 = ka; k0 < kb; k0 += MP_U) {
-    double a[MP_U], b[MP_U], c[MP_U], d[MP_U];
+  constexpr int PU = MP_U;
+  for (int k0 = ka; k0 < kb; k0 += PU) {
+    double a[PU], b[PU], c[PU], d[PU];
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i) {
+    for (int i = 0; i < PU; ++i) {
       const int k = (k0 + i < kb) ? k0 + i : kb - 1;
       a[i] = du_in(k); b[i] = dv_in(k); c[i] = dt_in(k); d[i] = dq_in(k);
     }
     MP_UNROLL_ALL
-    for (int i = 0; i < MP_U; ++i)
+    for (int i = 0; i < PU; ++i)
       if (k0 + i < kb) { const int k = k0 + i; dt_u[k * st] = a[i] + 0.0; dt_v[k * st] = b[i] + 0.0; dt_t[k * st] = c[i] + 0.0; dt_q[k * st] = d[i] + 0.0; }
   }
 }

@@ -145,6 +145,28 @@ def test_moist_trajectory_T21L25(golden_dir):
     dc.close()
 
 
+def developed_core(g, one_ulp=False):
+    """A handle holding the developed moist state of tests/golden/moist_developed_T42L25.npz (one_ulp: every temperature one ulp up)."""
+    dc = moist_core("T42", float(g["meta_dt_atmos"]))
+    assert np.array_equal(dc.table("bk"), g["tab_bk"])
+    dc.cold_start()
+    dc.set_time_pointers(0, 1, int(g["meta_step0"]))
+    for tl, tag in ((0, "prev"), (1, "cur")):                       # time_level 0 = previous, 1 = current
+        for nm in ("vors", "divs", "ts"):
+            dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
+        dc.set("ln_ps", g[f"rs_lnps_{tag}"], tl)
+        for nm in ("ug", "vg", "tg", "psg"):
+            a = g[f"rs_{nm}_{tag}"]
+            dc.set(nm, np.nextafter(a, np.inf) if (one_ulp and nm == "tg") else a, tl)
+    dc.set("tr", g["rs_tr1_prev_filt"], 0); dc.set("tr_atm", g["rs_tr1_prev_atm"], 0)
+    dc.set("tr", g["rs_tr1_cur"], 1); dc.set("tr_atm", g["rs_tr1_cur"], 1)
+    dc.set("wg_full", g["rs_wg_full"])
+    dc.set("t_surf", g["rs_t_surf"])
+    dc.refresh_derived()
+    dc.set_info("phys_calls", int(g["meta_step0"]))
+    return dc
+
+
 def test_moist_developed_state_steps_vs_reference(golden_dir):
     """A DEVELOPED state of the reference's MOIST model handed over and stepped (tests/golden/moist_developed_T42L25.npz: day 30 of the T42L25
     Frierson run of oracle/ref_moist_harness.F90; it rains -- precipitation up to 1.2e-3 kg/m2/s, max |u| 58 m/s, q up to 1.4e-2, deep and shallow
@@ -159,27 +181,7 @@ def test_moist_developed_state_steps_vs_reference(golden_dir):
     umax, vmax, tmin, tmax, qmax = g["developed_maxu_maxv_Tmin_Tmax_qmax"]
     assert umax > 25.0 and qmax > 0.01, (umax, qmax)              # the fixture IS a developed, moist flow
 
-    def handed_over(one_ulp):
-        dc = moist_core("T42", float(g["meta_dt_atmos"]))
-        assert np.array_equal(dc.table("bk"), g["tab_bk"])
-        dc.cold_start()
-        dc.set_time_pointers(0, 1, int(g["meta_step0"]))
-        for tl, tag in ((0, "prev"), (1, "cur")):                       # time_level 0 = previous, 1 = current
-            for nm in ("vors", "divs", "ts"):
-                dc.set(nm, g[f"rs_{nm}_{tag}"], tl)
-            dc.set("ln_ps", g[f"rs_lnps_{tag}"], tl)
-            for nm in ("ug", "vg", "tg", "psg"):
-                a = g[f"rs_{nm}_{tag}"]
-                dc.set(nm, np.nextafter(a, np.inf) if (one_ulp and nm == "tg") else a, tl)
-        dc.set("tr", g["rs_tr1_prev_filt"], 0); dc.set("tr_atm", g["rs_tr1_prev_atm"], 0)
-        dc.set("tr", g["rs_tr1_cur"], 1); dc.set("tr_atm", g["rs_tr1_cur"], 1)
-        dc.set("wg_full", g["rs_wg_full"])
-        dc.set("t_surf", g["rs_t_surf"])
-        dc.refresh_derived()
-        dc.set_info("phys_calls", int(g["meta_step0"]))
-        return dc
-
-    dc, twin = handed_over(False), handed_over(True)
+    dc, twin = developed_core(g, False), developed_core(g, True)
     done = 0
     for n, tol in ((1, 1e-11), (10, 1e-10)):
         dc.step(n - done); twin.step(n - done); done = n
@@ -198,6 +200,35 @@ def test_moist_developed_state_steps_vs_reference(golden_dir):
             assert err[k] < max(tol, 2 * noise[k]), (n, k, err[k], noise[k])
     assert float(dc.get("precip").max()) > 1e-4                    # (kg/m2/s: it rains)
     dc.close(); twin.close()
+
+
+def test_moist_convection_sigma_log_tables(golden_dir, monkeypatch):
+    """On pure sigma levels the convection scheme takes ln(p_full(k) / p_full(k+1)) and ln(p_half(k+1) / p_half(k)) -- constants of the vertical
+    coordinate there -- from a table built once in extended precision (moist_physics.h: QeParcel::sig) instead of dividing and taking two logarithms
+    per level and column (ISCA_MOIST_LOG_PER_LEVEL=1: the per-level form, bit-identical to the host twin's).  The two forms differ in the last bit of
+    a logarithm, which moves a column that sits on one of the scheme's knife-edge branches: on the developed, raining state one step apart by 6e-12
+    of the humidity's maximum (measured; 1e-13 in the other fields, the response to one ulp in T is 4e-14) -- inside the 1e-11 the one-step comparison
+    with the reference allows (test_moist_developed_state_steps_vs_reference runs the table form: 2e-12 in q)."""
+    g = np.load(os.path.join(golden_dir, "moist_developed_T42L25.npz"))
+    tab, twin = developed_core(g, False), developed_core(g, True)
+    monkeypatch.setenv("ISCA_MOIST_LOG_PER_LEVEL", "1")
+    per_level = developed_core(g, False)
+    monkeypatch.delenv("ISCA_MOIST_LOG_PER_LEVEL")
+    for dc in (tab, twin, per_level):
+        dc.step(1)
+    diff, noise = {}, {}
+    for k in ("ug", "vg", "tg", "tr", "psg"):
+        a, b, c = tab.get(k), per_level.get(k), twin.get(k)
+        scale = float(np.abs(a).max())
+        diff[k] = float(np.abs(a - b).max()) / scale
+        noise[k] = float(np.abs(a - c).max()) / scale
+    print("convection's log tables vs per-level logarithms, one step on the developed state:", diff, "| response to 1 ulp in T:", noise)
+    assert float(tab.get("precip").max()) > 1e-4
+    assert any(v > 0 for v in diff.values())                        # (the switch does select another path)
+    for k in diff:
+        assert diff[k] < 1e-11, (k, diff[k], noise[k])
+    for dc in (tab, twin, per_level):
+        dc.close()
 
 
 def test_moist_convection_ahead_equals_in_step(monkeypatch):

@@ -1,4 +1,4 @@
-"""Phase times of k_moist_physics from the MOIST_TIMING builds (tools/build_variant.sh mtP "-DMOIST_TIMING=P" moist, P = 1, 2, 3): lane i of
+"""Phase times of k_moist_physics from the MOIST_TIMING builds (tools/build_moist_timing.sh): lane i of
 every wavefront stores the wall_clock64 ticks (10 ns) between marks i and i+1 of phase P in the precipitation field (moist.hip, MT macros)."""
 import os, sys, subprocess
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
@@ -18,7 +18,8 @@ if len(sys.argv) > 1:
     for i, nm in enumerate(MARKS[ph]):
         print(f"  phase {ph}  {nm:36s} mean {p[:, i].mean():7.1f} us   max {p[:, i].max():7.1f}")
         tot += p[:, i].mean()
-    print(f"  phase {ph}  total {tot:.1f} us")
+    rows = p[:, :len(MARKS[ph])].sum(axis=1)
+    print(f"  phase {ph}  total {tot:.1f} us   slowest wavefront {rows.max():.1f} us (its parts: {' '.join(f'{x:.1f}' for x in p[rows.argmax(), :len(MARKS[ph])])})")
 else:
     only = os.environ.get('MOIST_PHASES')
     for v in (1, 2, 3, 5):
