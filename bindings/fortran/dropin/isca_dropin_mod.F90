@@ -17,6 +17,11 @@ public
 
 type(c_ptr), save :: core = c_null_ptr      ! isca_dyn_t* of this process
 logical, save :: core_ready = .false.
+! spectral_dynamics_nml: graceful_shutdown (spectral_dynamics.F90:976-1005) -- when the step reports temperatures out of the valid range, the
+! reference agrees on that over all PEs, ends the diagnostics (diag_manager_end: partially complete history files are written out) and only then
+! raises the FATAL.  Here the library's verdict is already collective (every rank's step returns the error), so each rank closes its history files
+! (isca_dyn_diag_close: the records accumulated so far) before its FATAL.
+logical, save :: graceful = .false.
 integer, save :: nlon = 0, nlat = 0, nlev = 0, nfour = 0, nsph = 0      ! lon_max, lat_max, num_levels, num_fourier, num_spherical
 integer, save :: ntrace = 0                                                ! prognostic tracers of the field_table
 ! The decomposition (spec_mpp.F90:61-80, atmosphere_domain): this process holds the latitude rows js_loc..je_loc of every longitude -- all of them with
@@ -38,7 +43,12 @@ contains
 subroutine chk(ierr, routine)
   integer(c_int), intent(in) :: ierr
   character(len=*), intent(in) :: routine
-  if(ierr /= 0) call error_mesg(routine, isca_message(), FATAL)
+  character(len=:), allocatable :: msg
+  integer(c_int) :: closed
+  if(ierr == 0) return
+  msg = isca_message()
+  if(graceful .and. core_ready) closed = isca_dyn_diag_close(core)      ! (its own failure would only replace the message that matters)
+  call error_mesg(routine, msg, FATAL)
 end subroutine chk
 
 subroutine need_core(routine)

@@ -301,6 +301,7 @@ cfg%rank = env_rank; cfg%world_size = env_world; cfg%device = env_local
 my_rank = env_rank; num_ranks = env_world
 call chk(isca_dyn_create(cfg, core), 'spectral_dynamics_init')
 core_ready = .true.
+graceful = graceful_shutdown
 call chk(isca_dyn_comm_init_env(core), 'spectral_dynamics_init')
 call chk(isca_dyn_get_info(core, 'lat_local'//c_null_char, info_val), 'spectral_dynamics_init'); je_loc = int(info_val)
 call chk(isca_dyn_get_info(core, 'lat_start'//c_null_char, info_val), 'spectral_dynamics_init'); js_loc = int(info_val) + 1

@@ -117,6 +117,7 @@ class Experiment:
             self.extract_restart_archive(restart_file, indir)
         nsteps = self.steps_per_run()
         dt = self.namelist["main_nml"]["dt_atmos"]
+        collector = None
         try:
             ft = None
             if self.field_table_file is not None:
@@ -135,6 +136,13 @@ class Experiment:
             collector.close()
             atm.atmosphere_end()
         except IscaError as e:
+            # spectral_dynamics_nml: graceful_shutdown (spectral_dynamics.F90:976-1005): the diagnostics are ended -- the history files get the records
+            # accumulated so far -- before the error is raised; they stay in the run directory, like everything else of a failed run
+            if collector is not None and self.namelist.get("spectral_dynamics_nml", {}).get("graceful_shutdown", False):
+                try:
+                    collector.close()
+                except Exception as e2:       # (the failure that matters is e)
+                    self.log.warning("graceful_shutdown: closing the history files failed: %s", e2)
             atm.atmosphere_end()
             self.log.error("Run %d failed: %s", i, e)
             raise FailedRunError(str(e))

@@ -431,6 +431,29 @@ def test_atmosphere_mod_writes_history_files(tmp_path, nranks):
         f.close()
 
 
+def test_atmosphere_mod_graceful_shutdown(tmp_path):
+    """spectral_dynamics_nml: graceful_shutdown = .true. (spectral_dynamics.F90:976-1005: diag_manager_end before the FATAL) through the Fortran host:
+    a run that blows up (dt_atmos far beyond the CFL limit) ends in the reference's FATAL 'temperatures out of valid range' -- not in a fault --, and the
+    run directory's history file is closed and holds the records of the intervals completed before it."""
+    import subprocess
+    from scipy.io import netcdf_file
+    exe = os.path.join(REPO, "oracle", "_ref", "drive_atmos_model_gpu.x")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/drive_atmos_model_gpu.x was not built (python oracle/build_ref.py dropin_atmos)")
+    from oracle import make_golden as mg
+    d = str(tmp_path / "run")
+    mg.prepare_rundir(d, "T21", 8, "run", nsteps=200, dt=21600, extra="graceful_shutdown = .true.")
+    open(os.path.join(d, "diag_table"), "w").write(HS_DIAG_TABLE)
+    open(os.path.join(d, "drive.nml"), "w").write(" &drive_nml\n   nsteps = 200, dt_atmos = 21600\n /\n")
+    r = subprocess.run(f"ulimit -s unlimited; exec {exe}", shell=True, cwd=d, executable="/bin/bash", text=True, capture_output=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "temperatures out of valid range" in out and "FATAL" in out, out[-2000:]
+    f = netcdf_file(os.path.join(d, "atmos_6hourly.nc"), "r", mmap=False)
+    n = f.variables["temp"].shape[0]
+    assert 1 <= n <= 200 and f.variables["time"].shape[0] == n, n      # (the host queues its steps: the range check runs at a synchronisation)
+    f.close()
+
+
 def test_atmosphere_mod_input_topography_from_fortran(tmp_path, golden_dir):
     """topography_option = 'input' from Fortran (get_topography, spectral_init_cond.F90:186-245): spectral_dynamics_init reads zsurf and land_mask of
     INPUT/topography.data.nc with the library's netCDF-classic reader and hands them to isca_dyn_set_topography -- regularised over the ocean with the

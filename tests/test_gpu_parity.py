@@ -1555,6 +1555,33 @@ def test_experiment_restart_chaining(tmp_path):
         c.close()
 
 
+def test_experiment_graceful_shutdown(tmp_path):
+    """spectral_dynamics_nml: graceful_shutdown (spectral_dynamics.F90:976-1005): when the temperatures leave valid_range_t the reference ends the
+    diagnostics -- partially complete history files are written out -- before its FATAL.  A run that blows up (dt_atmos far beyond the CFL limit)
+    through the Experiment host: FailedRunError either way; with the flag the run directory holds the history file with the records of the
+    intervals completed before the failure, without it no file (this host writes a file when its run ends)."""
+    from isca_amd.experiment import Experiment, FailedRunError
+    from isca_amd import configs
+    from scipy.io import netcdf_file
+    for graceful in (True, False):
+        e = Experiment("blows_up_%d" % graceful, str(tmp_path))
+        e.update_namelist(configs.held_suarez())
+        e.update_namelist({"main_nml": {"days": 30, "dt_atmos": 21600}, "spectral_dynamics_nml": {"graceful_shutdown": graceful}})
+        e.set_resolution("T21", 8)
+        e.diag_table.add_file("atmos_6hourly", 6, "hours", time_units="days")
+        for nm in ("ps", "temp"):
+            e.diag_table.add_field("dynamics", nm, time_avg=True)
+        with pytest.raises(FailedRunError, match="valid range"):
+            e.run(1, use_restart=False)
+        path = os.path.join(e.rundir, "atmos_6hourly.nc")
+        assert os.path.exists(path) == graceful
+        if graceful:
+            f = netcdf_file(path, "r", mmap=False)
+            n = f.variables["temp"].shape[0]
+            assert 1 <= n < 120 and np.isfinite(f.variables["temp"][:n - 1]).all(), n      # (the records before the step that failed)
+            f.close()
+
+
 # ------------------------------------------------------------------ every public routine on the path, one by one
 @pytest.mark.parametrize("name,res,L", [("kernels_T10L8", "T10", 8), ("kernels_T21L6", "T21", 6), ("kernels_T31L6", "T31", 6)])
 def test_golden_components(golden_dir, name, res, L):
