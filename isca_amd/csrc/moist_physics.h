@@ -170,7 +170,10 @@ struct GrayRadParams {
 template <class PH>
 MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albedo, const double *t, PH p_half, int s,
                          double *lw_down, double *lw_dtrans, int sw, double *sw_down, int ssw, double &insolation, double &sw_tau_0,
-                         double &net_surf_sw_down, double &surf_lw_down) {
+                         double &net_surf_sw_down, double &surf_lw_down, int slw = -1, bool store_sw = true) {
+  // slw: lw_down's own stride (default: lw_dtrans's); store_sw = false: sw_down is not written -- with atm_abs = 0 it is the insolation at every
+  // half level, which gray_rad_up can be told (sw_uniform), and the caller may then keep lw_down where sw_down would have been (the device kernel: in LDS)
+  const int slwd = slw < 0 ? sw : slw;
   const double sl = sin(lat), sl2 = sl * sl;
   const double p2 = (1. - 3. * sl2) / 4.;
   insolation = 0.25 * p.solar_constant * (1.0 + p.del_sol * p2 + p.del_sw * sl);
@@ -182,7 +185,7 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
   const double pw0 = gray_pow(ph_top / PSTD_MKS, p.wv_exponent);
   double tau_k = lw_tau_0 * (p.linear_tau * ph_top / PSTD_MKS + (1.0 - p.linear_tau) * pw0);
   lw_down[0] = 0.;
-  sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : gray_pow(ph_top / PSTD_MKS, p.solar_exponent)));
+  if (store_sw) sw_down[0] = insolation * exp(-sw_tau_0 * (one_pow ? pw0 : gray_pow(ph_top / PSTD_MKS, p.solar_exponent)));
   double lwd = 0., swd_last = 0.;
   for (int k0 = 0; k0 < L; k0 += MP_U) {
     double ph[MP_U], tk[MP_U], tau_n[MP_U], swd[MP_U];
@@ -203,10 +206,11 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
       if (k0 + i < L) {
         const double dtr = exp(-(tau_n[i] - tau_k));
         lw_dtrans[(k0 + i) * sw] = dtr;
-        sw_down[(k0 + i + 1) * ssw] = swd[i]; swd_last = swd[i];
+        if (store_sw) sw_down[(k0 + i + 1) * ssw] = swd[i];
+        swd_last = swd[i];
         const double b = STEFAN * pow4(tk[i]);
         lwd = lwd * dtr + b * (1. - dtr);
-        lw_down[(k0 + i + 1) * sw] = lwd;
+        lw_down[(k0 + i + 1) * slwd] = lwd;
         tau_k = tau_n[i];
       }
     }
@@ -220,19 +224,21 @@ MP_HD void gray_rad_down(const GrayRadParams &p, int L, double lat, double albed
 template <class PH>
 MP_HD void gray_rad_up(const GrayRadParams &p, int L, double albedo, double t_surf, const double *t, PH p_half, int s,
                        const double *lw_down, const double *lw_dtrans, int sw, const double *sw_down, int ssw, double *tdt, int st,
-                       bool tdt_is_zero = false) {
+                       bool tdt_is_zero = false, int slw = -1, bool sw_uniform = false, double sw_value = 0.0) {
+  // slw, sw_uniform / sw_value: see gray_rad_down (tdt may then BE lw_down: a level's flux is read in the load phase of its chunk, like sw_down's)
+  const int sl = slw < 0 ? sw : slw;
   const double b_surf = STEFAN * pow4(t_surf);
-  const double ph_surf = ph_at(p_half, s, L), sw_surf = sw_down[L * ssw];
+  const double ph_surf = ph_at(p_half, s, L), sw_surf = sw_uniform ? sw_value : sw_down[L * ssw];
   const double sw_up = albedo * sw_surf;
   double lw_up_n = b_surf;                                   // lw_up at half level k+1, integrating upward
-  double flux_n = (lw_up_n - lw_down[L * sw]) + (sw_up - sw_surf);
+  double flux_n = (lw_up_n - lw_down[L * sl]) + (sw_up - sw_surf);
   double ph_n = ph_surf;
   for (int k0 = L - 1; k0 >= 0; k0 -= MP_U) {
     double tk[MP_U], ph[MP_U], td[MP_U], swd[MP_U], dtrs[MP_U], lwd[MP_U];
     MP_UNROLL_ALL
     for (int i = 0; i < MP_U; ++i) {       // everything the chunk reads, the downward pass's arrays included (they may live in global memory)
       const int k = (k0 - i >= 0) ? k0 - i : 0;
-      tk[i] = t[k * s]; ph[i] = ph_at(p_half, s, k); swd[i] = sw_down[k * ssw]; dtrs[i] = lw_dtrans[k * sw]; lwd[i] = lw_down[k * sw];
+      tk[i] = t[k * s]; ph[i] = ph_at(p_half, s, k); swd[i] = sw_uniform ? sw_value : sw_down[k * ssw]; dtrs[i] = lw_dtrans[k * sw]; lwd[i] = lw_down[k * sl];
       td[i] = tdt_is_zero ? 0.0 : tdt[k * st];
     }
     MP_UNROLL_ALL
@@ -282,9 +288,13 @@ MP_HD double qe_get_lcl_temp(const QeParams &p, double value) {
 // Work arrays of one column, 1-based.  The parcel's Tp, rp live in caller storage (QeParcel) and the relaxation deltas dT, dq take that
 // storage over once the reference profiles have consumed the parcel (each level's Tp, rp are read before its dT, dq are written); the
 // reference profiles themselves are only kept when the caller wants them (WANT_REF: the host tests; the device kernel does not).
-template <int LMAX, bool WANT_REF, bool TV_EXT = false>
+// TVM: where the environment's virtual temperature lives -- 0: a thread-private array here; 1: caller storage (QeParcel::wTv); 2: nowhere: the
+// parcel storage holds the environment's T and r of every level until the parcel's own values of that level are written, and each use of T_v(k)
+// stands in front of that write (the LCL level's is carried in a register), so T_v is formed from them where it is read -- the same two operands, the
+// same bits.  (The device kernel: the private array was 424 bytes of scratch per lane, written once and gathered from level by level.)
+template <int LMAX, bool WANT_REF, int TVM = 0>
 struct QeColumn {
-  double Tv[TV_EXT ? 1 : LMAX + 2], Tref[WANT_REF ? LMAX + 2 : 1], qref[WANT_REF ? LMAX + 2 : 1];
+  double Tv[TVM != 0 ? 1 : LMAX + 2], Tref[WANT_REF ? LMAX + 2 : 1], qref[WANT_REF ? LMAX + 2 : 1];
 };
 // The parcel's temperature and mixing ratio, written level by level in the ascent and read back by the reference profiles, live in
 // caller storage: wTp[(k-1)*sw], wrp[(k-1)*sw] for level k = 1..L (LDS on the device; in thread-private arrays every store of the
@@ -310,13 +320,21 @@ struct QeParcel {
 };
 
 // deltaT / deltaq may BE the parcel storage (deltaT == pc.wTp, deltaq == pc.wrp, so == pc.sw): the deltas are then left where they are.
-template <int LMAX, bool WANT_REF = true, class PH = const double *, bool TV_EXT = false>
+template <int LMAX, bool WANT_REF = true, class PH = const double *, int TVM = 0>
 MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, double dt, const double *Tin_, const double *qin_,
                                const double *p_full_, PH p_half_, int s, double *deltaT, double *deltaq, double &rain,
                                double &cape_out, double &cin_out, int &convflag, int &kLZB_out, int &kLCL_out, double *Tref_out,
                                double *qref_out, int so, const QeParcel &pc) {
-  QeColumn<LMAX, WANT_REF, TV_EXT> c;
-  auto Tv = [&](int k) -> double & { if constexpr (TV_EXT) return pc.wTv[(k - 1) * pc.sw]; else return c.Tv[k]; };
+  QeColumn<LMAX, WANT_REF, TVM> c;
+  auto Tv_store = [&](int k, double tt, double r) {
+    if constexpr (TVM == 1) pc.wTv[(k - 1) * pc.sw] = qe_virtual_temp(tt, r);
+    else if constexpr (TVM == 0) c.Tv[k] = qe_virtual_temp(tt, r);
+  };
+  auto Tv = [&](int k) -> double {       // (TVM = 2: only for a level whose parcel values have not been written yet)
+    if constexpr (TVM == 1) return pc.wTv[(k - 1) * pc.sw];
+    else if constexpr (TVM == 0) return c.Tv[k];
+    else return qe_virtual_temp(pc.Tp(k), pc.rp(k));
+  };
   auto dT = [&](int k) -> double & { return pc.wTp[(k - 1) * pc.sw]; };      // valid from the reference-profile pass on
   auto dq = [&](int k) -> double & { return pc.wrp[(k - 1) * pc.sw]; };
   auto set_ref = [&](int k, double tref, double qref) { if (WANT_REF) { c.Tref[k] = tref; c.qref[k] = qref; } };
@@ -359,7 +377,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
     MP_UNROLL_ALL
     for (int i = 0; i < IU; ++i) {
       const int k = k0 + i;
-      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; Tv(k) = qe_virtual_temp(tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
+      if (k <= L) { const double r = qq[i] / (1.0 - qq[i]); pc.Tp(k) = tt[i]; pc.rp(k) = r; Tv_store(k, tt[i], r); }      // (deltaT, deltaq = 0: every exit below sets all levels)
     }
   }
   QE_MARK(1)
@@ -391,6 +409,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
         TLCL = theta0 * pow(pLCL / QE_PREF, KAPPA);
       }
       int k = ks;
+      double tv_lcl;                                    // T_v of the level the loop stops at: the LCL level's, read before the parcel's values of that level are written
       CIN = 0.;
       if (pc.sig) {      // (the table form: the parcel's dry adiabat from one logarithm per column and one exponential per level)
         const double *sg = pc.sig;
@@ -406,6 +425,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
           k = k - 1;
           pfk = pfn; tvk = tvn; lrel = lreln; lh = lhn;
         }
+        tv_lcl = tvk;
       } else {
         double pfk = pf(ks), ph1 = ph(ks + 1), phk = ph(ks), tvk = Tv(ks);        // next level requested one iteration ahead
         while (k >= 1 && pfk > pLCL) {
@@ -418,6 +438,7 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
           k = k - 1;
           pfk = pfn; ph1 = phk; phk = phn; tvk = tvn;
         }
+        tv_lcl = tvk;
       }
       kLCL = k;
       if (kLCL >= 1) {
@@ -441,10 +462,10 @@ MP_HD void qe_moist_convection(const SatTable &st, const QeParams &P, int L, dou
             pc.rp(kLCL) = qe_mixing_ratio(lookup_es(st, pc.Tp(kLCL)), pf(kLCL));
             const double tvp = qe_virtual_temp(pc.Tp(kLCL), pc.rp(kLCL));
             const double lh = pc.sig ? pc.sig[L + kLCL - 1] : log(ph(kLCL + 1) / ph(kLCL));
-            if ((tvp < Tv(kLCL)) && nocape) {
-              CIN = CIN + RDGAS * (Tv(kLCL) - tvp) * lh;
+            if ((tvp < tv_lcl) && nocape) {
+              CIN = CIN + RDGAS * (tv_lcl - tvp) * lh;
             } else {
-              CAPE = CAPE + RDGAS * (tvp - Tv(kLCL)) * lh;
+              CAPE = CAPE + RDGAS * (tvp - tv_lcl) * lh;
               if (nocape) { nocape = false; kLFC = kLCL; }
             }
           }
